@@ -1,0 +1,312 @@
+"""ctypes bindings for the parity oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It loads
+
+* ``oracle/_build/libsperr_oracle.so``  -- this repo's plain-C restatement (``Oracle``), and
+* ``oracle/_ref/libSPERR_ref.so`` + ``libref_probe.so`` -- the real reference compiled from
+  /root/reference by ``oracle/Makefile`` (``Ref``), when those prebuilt files are present.
+
+Nothing here reads /root/reference at run time.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_sz = C.c_size_t
+_vp = C.c_void_p
+
+
+def build_oracle(force=False):
+    """Compile the C restatement (gcc) if the .so is missing or stale."""
+    so = os.path.join(HERE, "_build", "libsperr_oracle.so")
+    src = os.path.join(HERE, "sperr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    return so
+
+
+def build_ref():
+    """(Re)build oracle/_ref from /root/reference when that tree is present; otherwise keep the
+    prebuilt files.  Returns True when libSPERR_ref.so + libref_probe.so exist afterwards."""
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+    return have_ref()
+
+
+def have_ref():
+    return all(os.path.exists(os.path.join(HERE, "_ref", f))
+               for f in ("libSPERR_ref.so", "libref_probe.so"))
+
+
+def _u8(buf):
+    return np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+
+
+class _CApiMixin:
+    """sperr_comp_3d / sperr_decomp_3d shaped entry points (include/SPERR_C_API.h:106-137)."""
+
+    _comp = None
+    _decomp = None
+    _libc = C.CDLL(None)
+
+    def _wire(self):
+        self._comp.restype = C.c_int
+        self._comp.argtypes = [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_double, _sz,
+                               C.POINTER(_vp), C.POINTER(_sz)]
+        self._decomp.restype = C.c_int
+        self._decomp.argtypes = [_vp, _sz, C.c_int, _sz, C.POINTER(_sz), C.POINTER(_sz),
+                                 C.POINTER(_sz), C.POINTER(_vp)]
+        self._libc.free.argtypes = [_vp]
+
+    def comp_3d(self, vol, chunks, mode, quality, nthreads=1):
+        """vol: numpy float32/float64 array shaped (z, y, x). Returns bytes."""
+        vol = np.ascontiguousarray(vol)
+        assert vol.dtype in (np.float32, np.float64) and vol.ndim == 3
+        dz, dy, dx = vol.shape
+        dst, n = _vp(None), _sz(0)
+        rtn = self._comp(vol.ctypes.data, int(vol.dtype == np.float32), dx, dy, dz, chunks[0],
+                         chunks[1], chunks[2], mode, quality, nthreads, C.byref(dst), C.byref(n))
+        if rtn != 0:
+            raise RuntimeError(f"comp_3d returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def decomp_3d(self, stream, output_float=True, nthreads=1):
+        """Returns a numpy array shaped (z, y, x)."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dst = _vp(None)
+        dx, dy, dz = _sz(0), _sz(0), _sz(0)
+        rtn = self._decomp(buf.ctypes.data, buf.size, int(output_float), nthreads, C.byref(dx),
+                           C.byref(dy), C.byref(dz), C.byref(dst))
+        if rtn != 0:
+            raise RuntimeError(f"decomp_3d returned {rtn}")
+        n = dx.value * dy.value * dz.value
+        dt = np.float32 if output_float else np.float64
+        out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        self._libc.free(dst)
+        return out.reshape(dz.value, dy.value, dx.value)
+
+
+class Oracle(_CApiMixin):
+    """The plain-C restatement (oracle/sperr_oracle.c)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        self._comp, self._decomp = L.orc_comp_3d, L.orc_decomp_3d
+        self._wire()
+        L.orc_dwt3d.argtypes = [_vp, _vp]
+        L.orc_idwt3d.argtypes = [_vp, _vp]
+        L.orc_condition.argtypes = [_vp, _sz, _vp]
+        L.orc_condition.restype = C.c_int
+        L.orc_inverse_condition.argtypes = [_vp, _sz, _vp]
+        L.orc_quantize.argtypes = [_vp, _sz, C.c_double, _vp, _vp, C.POINTER(C.c_int)]
+        L.orc_quantize.restype = C.c_int
+        L.orc_inv_quantize.argtypes = [_vp, _vp, _sz, C.c_double, _vp]
+        L.orc_speck3d_encode.argtypes = [_vp, _vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+        L.orc_speck3d_encode.restype = C.c_int
+        L.orc_speck3d_decode.argtypes = [_vp, _sz, _vp, _vp, _vp]
+        L.orc_speck3d_decode.restype = C.c_int
+        L.orc_chunk_compress_rate.argtypes = [_vp, _vp, C.c_double, C.POINTER(_vp), C.POINTER(_sz)]
+        L.orc_chunk_compress_rate.restype = C.c_int
+        L.orc_chunk_decompress.argtypes = [_vp, _sz, _vp, _vp]
+        L.orc_chunk_decompress.restype = C.c_int
+        L.orc_chunk_volume.argtypes = [_vp, _vp, _vp, _sz]
+        L.orc_chunk_volume.restype = _sz
+        L.orc_num_of_xforms.argtypes = [_sz]
+        L.orc_num_of_xforms.restype = _sz
+        L.orc_num_of_partitions.argtypes = [_sz]
+        L.orc_num_of_partitions.restype = _sz
+        L.orc_can_use_dyadic.argtypes = [_vp, C.POINTER(_sz)]
+        L.orc_can_use_dyadic.restype = C.c_int
+        L.orc_approx_detail_len.argtypes = [_sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]
+
+    @staticmethod
+    def _dims(dims):  # dims given as (x, y, z)
+        return (_sz * 3)(*dims)
+
+    def dwt3d(self, vol):
+        """vol: float64 (z,y,x); returns the transformed copy."""
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        self.lib.orc_dwt3d(v.ctypes.data, self._dims((dx, dy, dz)))
+        return v
+
+    def idwt3d(self, vol):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        self.lib.orc_idwt3d(v.ctypes.data, self._dims((dx, dy, dz)))
+        return v
+
+    def condition(self, vol):
+        v = np.array(vol, dtype=np.float64, order="C")
+        hdr = np.zeros(17, dtype=np.uint8)
+        const = self.lib.orc_condition(v.ctypes.data, v.size, hdr.ctypes.data)
+        return v, hdr.tobytes(), bool(const)
+
+    def quantize(self, vals, q):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        coef = np.zeros(v.size, dtype=np.uint64)
+        sign = np.zeros((v.size + 63) // 64, dtype=np.uint64)
+        w = C.c_int(0)
+        rtn = self.lib.orc_quantize(v.ctypes.data, v.size, q, coef.ctypes.data, sign.ctypes.data,
+                                    C.byref(w))
+        if rtn:
+            raise RuntimeError(f"orc_quantize returned {rtn}")
+        return coef.reshape(v.shape), sign, w.value
+
+    def inv_quantize(self, coef, sign, q):
+        c = np.ascontiguousarray(coef, dtype=np.uint64)
+        out = np.zeros(c.shape, dtype=np.float64)
+        self.lib.orc_inv_quantize(c.ctypes.data, sign.ctypes.data, c.size, q, out.ctypes.data)
+        return out
+
+    def speck3d_encode(self, coef, sign, budget_bits=0):
+        """coef: uint64 (z,y,x); sign: uint64 words. Returns the 9-byte-header stream."""
+        c = np.ascontiguousarray(coef, dtype=np.uint64)
+        dz, dy, dx = c.shape
+        out, n = _vp(None), _sz(0)
+        self.lib.orc_speck3d_encode(c.ctypes.data, sign.ctypes.data, self._dims((dx, dy, dz)),
+                                    budget_bits, C.byref(out), C.byref(n))
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def speck3d_decode(self, stream, shape_zyx):
+        dz, dy, dx = shape_zyx
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        coef = np.zeros(shape_zyx, dtype=np.uint64)
+        sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+        self.lib.orc_speck3d_decode(buf.ctypes.data, buf.size, self._dims((dx, dy, dz)),
+                                    coef.ctypes.data, sign.ctypes.data)
+        return coef, sign
+
+    def chunk_compress_rate(self, vol, bpp):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        out, n = _vp(None), _sz(0)
+        rtn = self.lib.orc_chunk_compress_rate(v.ctypes.data, self._dims((dx, dy, dz)), bpp,
+                                               C.byref(out), C.byref(n))
+        if rtn:
+            raise RuntimeError(f"orc_chunk_compress_rate returned {rtn}")
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def chunk_decompress(self, stream, shape_zyx):
+        dz, dy, dx = shape_zyx
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        out = np.zeros(shape_zyx, dtype=np.float64)
+        rtn = self.lib.orc_chunk_decompress(buf.ctypes.data, buf.size, self._dims((dx, dy, dz)),
+                                            out.ctypes.data)
+        if rtn:
+            raise RuntimeError(f"orc_chunk_decompress returned {rtn}")
+        return out
+
+    def chunk_volume(self, vol_xyz, chunk_xyz):
+        n = self.lib.orc_chunk_volume(self._dims(vol_xyz), self._dims(chunk_xyz), None, 0)
+        out = np.zeros((n, 6), dtype=np.uint64)
+        self.lib.orc_chunk_volume(self._dims(vol_xyz), self._dims(chunk_xyz), out.ctypes.data, n)
+        return out
+
+
+class Ref(_CApiMixin):
+    """The real reference (oracle/_ref, built from /root/reference by oracle/Makefile)."""
+
+    def __init__(self):
+        if not have_ref():
+            raise FileNotFoundError("oracle/_ref is not built (run `make -C oracle ref`)")
+        self.lib = C.CDLL(os.path.join(HERE, "_ref", "libSPERR_ref.so"), mode=C.RTLD_GLOBAL)
+        self.probe = C.CDLL(os.path.join(HERE, "_ref", "libref_probe.so"))
+        self._comp, self._decomp = self.lib.sperr_comp_3d, self.lib.sperr_decomp_3d
+        self._wire()
+        P = self.probe
+        P.refp_dwt3d.argtypes = [_vp, _sz, _sz, _sz]
+        P.refp_idwt3d.argtypes = [_vp, _sz, _sz, _sz]
+        P.refp_condition.argtypes = [_vp, _sz, _sz, _sz, _vp]
+        P.refp_condition.restype = C.c_int
+        P.refp_speck3d_encode.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, C.c_int, C.POINTER(_vp),
+                                          C.POINTER(_sz)]
+        P.refp_speck3d_encode.restype = C.c_int
+        P.refp_speck3d_decode.argtypes = [_vp, _sz, _sz, _sz, _sz, _vp, _vp]
+        P.refp_speck3d_decode.restype = C.c_int
+        P.refp_chunk_compress_rate.argtypes = [_vp, _sz, _sz, _sz, C.c_double, C.POINTER(_vp),
+                                               C.POINTER(_sz)]
+        P.refp_chunk_compress_rate.restype = C.c_int
+        P.refp_chunk_decompress.argtypes = [_vp, _sz, _sz, _sz, _sz, _vp]
+        P.refp_chunk_decompress.restype = C.c_int
+        P.refp_chunk_volume.argtypes = [_sz] * 6 + [_vp, _sz]
+        P.refp_chunk_volume.restype = _sz
+
+    def dwt3d(self, vol):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        self.probe.refp_dwt3d(v.ctypes.data, dx, dy, dz)
+        return v
+
+    def idwt3d(self, vol):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        self.probe.refp_idwt3d(v.ctypes.data, dx, dy, dz)
+        return v
+
+    def condition(self, vol):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        hdr = np.zeros(17, dtype=np.uint8)
+        const = self.probe.refp_condition(v.ctypes.data, dx, dy, dz, hdr.ctypes.data)
+        return v, hdr.tobytes(), bool(const)
+
+    def speck3d_encode(self, coef, sign, budget_bits=0, width=8):
+        c = np.ascontiguousarray(coef, dtype=np.uint64)
+        dz, dy, dx = c.shape
+        out, n = _vp(None), _sz(0)
+        rtn = self.probe.refp_speck3d_encode(c.ctypes.data, sign.ctypes.data, dx, dy, dz,
+                                             budget_bits, width, C.byref(out), C.byref(n))
+        if rtn:
+            raise RuntimeError(f"refp_speck3d_encode returned {rtn}")
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def speck3d_decode(self, stream, shape_zyx):
+        dz, dy, dx = shape_zyx
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        coef = np.zeros(shape_zyx, dtype=np.uint64)
+        sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+        self.probe.refp_speck3d_decode(buf.ctypes.data, buf.size, dx, dy, dz, coef.ctypes.data,
+                                       sign.ctypes.data)
+        return coef, sign
+
+    def chunk_compress_rate(self, vol, bpp):
+        v = np.array(vol, dtype=np.float64, order="C")
+        dz, dy, dx = v.shape
+        out, n = _vp(None), _sz(0)
+        rtn = self.probe.refp_chunk_compress_rate(v.ctypes.data, dx, dy, dz, bpp, C.byref(out),
+                                                  C.byref(n))
+        if rtn:
+            raise RuntimeError(f"refp_chunk_compress_rate returned {rtn}")
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def chunk_decompress(self, stream, shape_zyx):
+        dz, dy, dx = shape_zyx
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        out = np.zeros(shape_zyx, dtype=np.float64)
+        rtn = self.probe.refp_chunk_decompress(buf.ctypes.data, buf.size, dx, dy, dz,
+                                               out.ctypes.data)
+        if rtn:
+            raise RuntimeError(f"refp_chunk_decompress returned {rtn}")
+        return out
+
+    def chunk_volume(self, vol_xyz, chunk_xyz):
+        n = self.probe.refp_chunk_volume(*vol_xyz, *chunk_xyz, None, 0)
+        out = np.zeros((n, 6), dtype=np.uint64)
+        self.probe.refp_chunk_volume(*vol_xyz, *chunk_xyz, out.ctypes.data, n)
+        return out

@@ -1,0 +1,1202 @@
+/*
+ * sperr_oracle.c -- plain-C restatement of the NCAR/SPERR 3D chunk pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY (see sperr_oracle.h).  Written from the reference's behaviour; every
+ * function cites the reference file:line it follows.  Compile with -ffp-contract=off: every
+ * fused multiply-add the canonical reference build performs is spelled out as fma() below
+ * (SURVEY.md Appendix B), everything else rounds separately.
+ */
+#include "sperr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* geometry                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/sperr_helper.cpp:36-49 : >=9 samples per level, at most 6 levels */
+size_t orc_num_of_xforms(size_t len)
+{
+  size_t n = 0;
+  while (len >= 9) {
+    n++;
+    len -= len / 2;
+  }
+  return n < 6 ? n : 6;
+}
+
+/* src/sperr_helper.cpp:51-68 */
+int orc_can_use_dyadic(const size_t dims[3], size_t* levels)
+{
+  if (dims[2] < 2 || dims[1] < 2)
+    return 0;
+  size_t xy = orc_num_of_xforms(dims[0] < dims[1] ? dims[0] : dims[1]);
+  size_t z = orc_num_of_xforms(dims[2]);
+  if (xy == z || (xy >= 5 && z >= 5)) {
+    *levels = xy < z ? xy : z;
+    return 1;
+  }
+  return 0;
+}
+
+/* src/sperr_helper.cpp:136-146 */
+void orc_approx_detail_len(size_t orig_len, size_t lev, size_t* approx, size_t* detail)
+{
+  size_t lo = orig_len, hi = 0;
+  for (size_t i = 0; i < lev; i++) {
+    hi = lo / 2;
+    lo -= hi;
+  }
+  *approx = lo;
+  *detail = hi;
+}
+
+/* src/sperr_helper.cpp:125-134 */
+size_t orc_num_of_partitions(size_t len)
+{
+  size_t n = 0;
+  while (len > 1) {
+    n++;
+    len -= len / 2;
+  }
+  return n;
+}
+
+/* src/sperr_helper.cpp:542-592 : x fastest; a remainder longer than half a chunk is its own
+ * segment, a shorter one is merged into the last segment. */
+size_t orc_chunk_volume(const size_t vol[3], const size_t chunk[3], size_t (*out)[6], size_t cap)
+{
+  size_t nseg[3];
+  for (int a = 0; a < 3; a++) {
+    nseg[a] = vol[a] / chunk[a];
+    if (vol[a] % chunk[a] > chunk[a] / 2)
+      nseg[a]++;
+    if (nseg[a] == 0)
+      nseg[a] = 1;
+  }
+  size_t total = nseg[0] * nseg[1] * nseg[2];
+  if (!out)
+    return total;
+  size_t k = 0;
+  for (size_t z = 0; z < nseg[2]; z++)
+    for (size_t y = 0; y < nseg[1]; y++)
+      for (size_t x = 0; x < nseg[0]; x++) {
+        if (k >= cap)
+          return total;
+        size_t idx[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) {
+          size_t beg = idx[a] * chunk[a];
+          size_t end = (idx[a] + 1 == nseg[a]) ? vol[a] : beg + chunk[a];
+          out[k][2 * a] = beg;
+          out[k][2 * a + 1] = end - beg;
+        }
+        k++;
+      }
+  return total;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* conditioner                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/Conditioner.cpp:137-163 */
+static size_t condi_num_strides(size_t len)
+{
+  const size_t dflt = 2048;
+  if (len % dflt == 0)
+    return dflt;
+  for (size_t n = dflt; n <= 32768; n++)
+    if (len % n == 0)
+      return n;
+  size_t n = dflt;
+  while (len % n != 0)
+    n--;
+  return n;
+}
+
+/* src/Conditioner.cpp:119-135 : strictly sequential sums, order is part of the result */
+static double condi_mean(const double* buf, size_t len)
+{
+  const size_t ns = condi_num_strides(len);
+  const size_t ssz = len / ns;
+  double total = 0.0;
+  for (size_t s = 0; s < ns; s++) {
+    double acc = 0.0;
+    const double* p = buf + s * ssz;
+    for (size_t i = 0; i < ssz; i++)
+      acc += p[i];
+    total += acc / (double)ssz;
+  }
+  return total / (double)ns;
+}
+
+/* src/Conditioner.cpp:10-64 ; flag byte per pack_8_booleans (src/sperr_helper.cpp:262-273):
+ * bool[0] -> 0x80 (mean subtracted), bool[7] -> 0x01 (constant field) */
+int orc_condition(double* buf, size_t n, uint8_t header[17])
+{
+  memset(header, 0, 17);
+  int constant = 1;
+  for (size_t i = 1; i < n; i++)
+    if (buf[i] != buf[0]) {
+      constant = 0;
+      break;
+    }
+  if (constant) {
+    header[0] = 0x81;
+    uint64_t nval = n;
+    memcpy(header + 1, &nval, 8);
+    memcpy(header + 9, &buf[0], 8);
+    return 1;
+  }
+  const double mean = condi_mean(buf, n);
+  for (size_t i = 0; i < n; i++)
+    buf[i] -= mean;
+  header[0] = 0x80;
+  memcpy(header + 1, &mean, 8);
+  return 0;
+}
+
+/* src/Conditioner.cpp:66-96 (constant case fills; caller sizes buf from dims) */
+void orc_inverse_condition(double* buf, size_t n, const uint8_t header[17])
+{
+  if (header[0] & 0x01) {
+    double v;
+    memcpy(&v, header + 9, 8);
+    for (size_t i = 0; i < n; i++)
+      buf[i] = v;
+    return;
+  }
+  double mean;
+  memcpy(&mean, header + 1, 8);
+  for (size_t i = 0; i < n; i++)
+    buf[i] += mean;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CDF 9/7                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+  double alpha, beta, gamma, delta, eps, inv_eps;
+} cdf_consts;
+
+/* include/CDF97.h:136-147 */
+static cdf_consts cdf_make_consts(void)
+{
+  const double h[5] = {0.602949018236, 0.266864118443, -0.078223266529, -0.016864118443,
+                       0.026748757411};
+  const double r0 = h[0] - 2.0 * h[4] * h[1] / h[3];
+  const double r1 = h[2] - h[4] - h[4] * h[1] / h[3];
+  const double s0 = h[1] - h[3] - h[3] * r0 / r1;
+  const double t0 = h[0] - 2.0 * (h[2] - h[4]);
+  cdf_consts c;
+  c.alpha = h[4] / h[3];
+  c.beta = h[3] / r1;
+  c.gamma = r1 / s0;
+  c.delta = s0 / t0;
+  c.eps = sqrt(2.0) * t0;
+  c.inv_eps = 1.0 / c.eps;
+  (void)r0;
+  return c;
+}
+
+/* One lifting step on the "odd" half: odd[i] = fma(k, even[i] + even[i+1], odd[i]) with the
+ * right neighbour of the last odd sample mirrored (src/CDF97.cpp:606-608,617-619,652-654,
+ * 663-665).  For even len the last even sample is its own neighbour, for odd len it is the
+ * extra even sample. */
+static void lift_odd(double* even, double* odd, size_t even_len, size_t odd_len, double k)
+{
+  for (size_t i = 0; i + 1 < odd_len; i++)
+    odd[i] = fma(k, even[i] + even[i + 1], odd[i]);
+  odd[odd_len - 1] = fma(k, even[odd_len - 1] + even[even_len - 1], odd[odd_len - 1]);
+}
+
+/* One lifting step on the "even" half (src/CDF97.cpp:611-614,657-660): the first sample sees
+ * odd[0] twice (2k * odd[0], the doubling is exact), the last one odd[even_len-2] and
+ * odd[odd_len-1] (the same sample twice when len is odd). */
+static void lift_even(double* even, const double* odd, size_t even_len, size_t odd_len, double k)
+{
+  even[0] = fma(k + k, odd[0], even[0]);
+  for (size_t i = 1; i + 1 < even_len; i++)
+    even[i] = fma(k, odd[i - 1] + odd[i], even[i]);
+  even[even_len - 1] = fma(k, odd[even_len - 2] + odd[odd_len - 1], even[even_len - 1]);
+}
+
+/* src/CDF97.cpp:598-631 on a line laid out [even | odd] */
+static void cdf_analysis(double* sig, size_t len, const cdf_consts* c)
+{
+  const size_t even_len = len - len / 2, odd_len = len / 2;
+  double* even = sig;
+  double* odd = sig + even_len;
+  lift_odd(even, odd, even_len, odd_len, c->alpha);
+  lift_even(even, odd, even_len, odd_len, c->beta);
+  lift_odd(even, odd, even_len, odd_len, c->gamma);
+  /* even = EPS * (even + DELTA*(..)) : inner fma, outer multiply rounds separately */
+  lift_even(even, odd, even_len, odd_len, c->delta);
+  for (size_t i = 0; i < even_len; i++)
+    even[i] = c->eps * even[i];
+  for (size_t i = 0; i < odd_len; i++)
+    odd[i] = (-c->inv_eps) * odd[i];
+}
+
+/* src/CDF97.cpp:633-666 */
+static void cdf_synthesis(double* sig, size_t len, const cdf_consts* c)
+{
+  const size_t even_len = len - len / 2, odd_len = len / 2;
+  double* even = sig;
+  double* odd = sig + even_len;
+  for (size_t i = 0; i < odd_len; i++)
+    odd[i] = (-c->eps) * odd[i];
+  /* even = even*INV_EPS - DELTA*(..) : the DELTA product rounds first, then one fma */
+  even[0] = fma(even[0], c->inv_eps, -((c->delta + c->delta) * odd[0]));
+  for (size_t i = 1; i + 1 < even_len; i++)
+    even[i] = fma(even[i], c->inv_eps, -(c->delta * (odd[i - 1] + odd[i])));
+  even[even_len - 1] =
+      fma(even[even_len - 1], c->inv_eps, -(c->delta * (odd[even_len - 2] + odd[odd_len - 1])));
+  lift_odd(even, odd, even_len, odd_len, -c->gamma);
+  lift_even(even, odd, even_len, odd_len, -c->beta);
+  lift_odd(even, odd, even_len, odd_len, -c->alpha);
+}
+
+/* Transform every line along `axis` inside the box [0,region) of a dims-shaped volume.
+ * Forward: de-interleave (src/CDF97.cpp:476-519), analyse, store as [approx | detail].
+ * Inverse: synthesise, re-interleave (src/CDF97.cpp:521-564). */
+static void cdf_lift_axis(double* buf, const size_t dims[3], int axis, const size_t region[3],
+                          int forward, const cdf_consts* c, double* tmp)
+{
+  const size_t stride[3] = {1, dims[0], dims[0] * dims[1]};
+  const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+  const size_t len = region[axis], st = stride[axis];
+  const size_t even_len = len - len / 2;
+  for (size_t j = 0; j < region[a2]; j++)
+    for (size_t i = 0; i < region[a1]; i++) {
+      double* line = buf + i * stride[a1] + j * stride[a2];
+      if (forward) {
+        for (size_t k = 0; k < len; k++)
+          tmp[(k & 1) ? even_len + k / 2 : k / 2] = line[k * st];
+        cdf_analysis(tmp, len, c);
+        for (size_t k = 0; k < len; k++)
+          line[k * st] = tmp[k];
+      }
+      else {
+        for (size_t k = 0; k < len; k++)
+          tmp[k] = line[k * st];
+        cdf_synthesis(tmp, len, c);
+        for (size_t k = 0; k < len; k++)
+          line[k * st] = tmp[(k & 1) ? even_len + k / 2 : k / 2];
+      }
+    }
+}
+
+/* src/CDF97.cpp:132-139,170-225,284-292,387-429 */
+void orc_dwt3d(double* buf, const size_t dims[3])
+{
+  const cdf_consts c = cdf_make_consts();
+  size_t maxlen = dims[0] > dims[1] ? dims[0] : dims[1];
+  if (dims[2] > maxlen)
+    maxlen = dims[2];
+  double* tmp = (double*)malloc(maxlen * sizeof(double));
+  size_t levels, d;
+  if (orc_can_use_dyadic(dims, &levels)) {
+    for (size_t lev = 0; lev < levels; lev++) {
+      size_t region[3];
+      for (int a = 0; a < 3; a++)
+        orc_approx_detail_len(dims[a], lev, &region[a], &d);
+      cdf_lift_axis(buf, dims, 0, region, 1, &c, tmp); /* X rows, then Y columns, per plane */
+      cdf_lift_axis(buf, dims, 1, region, 1, &c, tmp);
+      cdf_lift_axis(buf, dims, 2, region, 1, &c, tmp); /* then Z columns */
+    }
+  }
+  else { /* wavelet packet: all Z levels first, then all XY levels on every plane */
+    const size_t nz = orc_num_of_xforms(dims[2]);
+    const size_t nxy = orc_num_of_xforms(dims[0] < dims[1] ? dims[0] : dims[1]);
+    for (size_t lev = 0; lev < nz; lev++) {
+      size_t region[3] = {dims[0], dims[1], 0};
+      orc_approx_detail_len(dims[2], lev, &region[2], &d);
+      cdf_lift_axis(buf, dims, 2, region, 1, &c, tmp);
+    }
+    for (size_t lev = 0; lev < nxy; lev++) {
+      size_t region[3] = {0, 0, dims[2]};
+      orc_approx_detail_len(dims[0], lev, &region[0], &d);
+      orc_approx_detail_len(dims[1], lev, &region[1], &d);
+      cdf_lift_axis(buf, dims, 0, region, 1, &c, tmp);
+      cdf_lift_axis(buf, dims, 1, region, 1, &c, tmp);
+    }
+  }
+  free(tmp);
+}
+
+/* src/CDF97.cpp:141-148,227-302,366-385,431-474 */
+void orc_idwt3d(double* buf, const size_t dims[3])
+{
+  const cdf_consts c = cdf_make_consts();
+  size_t maxlen = dims[0] > dims[1] ? dims[0] : dims[1];
+  if (dims[2] > maxlen)
+    maxlen = dims[2];
+  double* tmp = (double*)malloc(maxlen * sizeof(double));
+  size_t levels, d;
+  if (orc_can_use_dyadic(dims, &levels)) {
+    for (size_t lev = levels; lev > 0; lev--) {
+      size_t region[3];
+      for (int a = 0; a < 3; a++)
+        orc_approx_detail_len(dims[a], lev - 1, &region[a], &d);
+      cdf_lift_axis(buf, dims, 2, region, 0, &c, tmp);
+      cdf_lift_axis(buf, dims, 1, region, 0, &c, tmp);
+      cdf_lift_axis(buf, dims, 0, region, 0, &c, tmp);
+    }
+  }
+  else {
+    const size_t nz = orc_num_of_xforms(dims[2]);
+    const size_t nxy = orc_num_of_xforms(dims[0] < dims[1] ? dims[0] : dims[1]);
+    for (size_t lev = nxy; lev > 0; lev--) {
+      size_t region[3] = {0, 0, dims[2]};
+      orc_approx_detail_len(dims[0], lev - 1, &region[0], &d);
+      orc_approx_detail_len(dims[1], lev - 1, &region[1], &d);
+      cdf_lift_axis(buf, dims, 1, region, 0, &c, tmp);
+      cdf_lift_axis(buf, dims, 0, region, 0, &c, tmp);
+    }
+    for (size_t lev = nz; lev > 0; lev--) {
+      size_t region[3] = {dims[0], dims[1], 0};
+      orc_approx_detail_len(dims[2], lev - 1, &region[2], &d);
+      cdf_lift_axis(buf, dims, 2, region, 0, &c, tmp);
+    }
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* quantiser                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/SPECK_FLT.cpp:311-371 : llrint is round-half-even in the default rounding mode; the sign
+ * bit is (ll >= 0), so zeros carry a set bit. */
+int orc_quantize(const double* vals, size_t n, double q, uint64_t* coeffs, uint64_t* signs,
+                 int* width)
+{
+  double maxabs = 0.0;
+  for (size_t i = 0; i < n; i++) {
+    double a = fabs(vals[i]);
+    if (!(a <= maxabs))
+      maxabs = a; /* NaN would stick; the reference returns FE_Invalid in that case */
+  }
+  if (!(maxabs / q < 9.2e18)) /* llrint would raise FE_INVALID (SPECK_FLT.cpp:323-327) */
+    return 7;                 /* RTNType::FE_Invalid (include/sperr_helper.h:54-64) */
+  const long long maxll = llrint(maxabs / q);
+  *width = maxll <= 0xff ? 1 : maxll <= 0xffff ? 2 : maxll <= 0xffffffffLL ? 4 : 8;
+  const double inv = 1.0 / q;
+  memset(signs, 0, ((n + 63) / 64) * sizeof(uint64_t));
+  for (size_t i = 0; i < n; i++) {
+    const long long ll = llrint(vals[i] * inv);
+    if (ll >= 0)
+      signs[i >> 6] |= (uint64_t)1 << (i & 63);
+    coeffs[i] = (uint64_t)(ll < 0 ? -ll : ll);
+  }
+  return 0;
+}
+
+/* src/SPECK_FLT.cpp:373-399 : (q * c) * (+-1.0), left to right */
+void orc_inv_quantize(const uint64_t* coeffs, const uint64_t* signs, size_t n, double q,
+                      double* vals)
+{
+  for (size_t i = 0; i < n; i++) {
+    const double s = ((signs[i >> 6] >> (i & 63)) & 1) ? 1.0 : -1.0;
+    vals[i] = q * (double)coeffs[i] * s;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* bit containers                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/Bitstream.cpp:74-85,111-173 : LSB-first inside little-endian 64-bit words */
+typedef struct {
+  uint64_t* w;
+  size_t cap_words;
+  size_t pos; /* next bit to write / read */
+} bitfifo;
+
+static void fifo_put(bitfifo* f, int bit)
+{
+  const size_t wi = f->pos >> 6;
+  if (wi >= f->cap_words) {
+    size_t ncap = f->cap_words ? f->cap_words * 2 : 64;
+    f->w = (uint64_t*)realloc(f->w, ncap * sizeof(uint64_t));
+    memset(f->w + f->cap_words, 0, (ncap - f->cap_words) * sizeof(uint64_t));
+    f->cap_words = ncap;
+  }
+  f->w[wi] |= (uint64_t)(bit & 1) << (f->pos & 63);
+  f->pos++;
+}
+
+static int fifo_get(bitfifo* f)
+{
+  const int b = (int)((f->w[f->pos >> 6] >> (f->pos & 63)) & 1);
+  f->pos++;
+  return b;
+}
+
+static int mask_get(const uint64_t* m, size_t i)
+{
+  return (int)((m[i >> 6] >> (i & 63)) & 1);
+}
+static void mask_set(uint64_t* m, size_t i)
+{
+  m[i >> 6] |= (uint64_t)1 << (i & 63);
+}
+static void mask_clr(uint64_t* m, size_t i)
+{
+  m[i >> 6] &= ~((uint64_t)1 << (i & 63));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SPECK3D                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/SPECK3D_INT.h:10-22 */
+typedef struct {
+  uint64_t first; /* position of the set's first sample in the depth-first sample order */
+  uint32_t org[3], len[3];
+} box3;
+
+typedef struct {
+  box3* v;
+  size_t n, cap;
+} boxlist;
+
+static void list_push(boxlist* l, const box3* b)
+{
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 16;
+    l->v = (box3*)realloc(l->v, l->cap * sizeof(box3));
+  }
+  l->v[l->n++] = *b;
+}
+
+static size_t box_count(const box3* b)
+{
+  return (size_t)b->len[0] * b->len[1] * b->len[2];
+}
+
+/* Octree split (src/SPECK3D_INT.cpp:214-326): each axis into (len - len/2, len/2); children in
+ * x-fastest order; depth-first sample offsets accumulate in that order.  Returns the number of
+ * axes that really split (the LIS level increment). */
+static int box_split(const box3* s, box3 kid[8])
+{
+  uint32_t part[3][2], off[3][2];
+  int inc = 0;
+  for (int a = 0; a < 3; a++) {
+    part[a][1] = s->len[a] / 2;
+    part[a][0] = s->len[a] - part[a][1];
+    off[a][0] = s->org[a];
+    off[a][1] = s->org[a] + part[a][0];
+    inc += part[a][1] != 0;
+  }
+  uint64_t first = s->first;
+  for (int k = 0; k < 8; k++) {
+    const int h[3] = {k & 1, (k >> 1) & 1, (k >> 2) & 1};
+    for (int a = 0; a < 3; a++) {
+      kid[k].org[a] = off[a][h[a]];
+      kid[k].len[a] = part[a][h[a]];
+    }
+    kid[k].first = first;
+    first += box_count(&kid[k]);
+  }
+  return inc;
+}
+
+/* Initialisation-only splits (src/SPECK3D_INT.cpp:328-427) */
+static int box_split_xy(const box3* s, box3 kid[4])
+{
+  box3 tmp = *s, all[8];
+  tmp.len[2] = 1; /* split as if one plane thick, then restore the z extent */
+  int inc = box_split(&tmp, all);
+  for (int k = 0; k < 4; k++) {
+    kid[k] = all[k];
+    kid[k].org[2] = s->org[2];
+    kid[k].len[2] = s->len[2];
+  }
+  return inc;
+}
+static int box_split_z(const box3* s, box3 kid[2])
+{
+  kid[0] = *s;
+  kid[1] = *s;
+  kid[1].len[2] = s->len[2] / 2;
+  kid[0].len[2] = s->len[2] - kid[1].len[2];
+  kid[1].org[2] = s->org[2] + kid[0].len[2];
+  return kid[1].len[2] != 0;
+}
+
+typedef struct {
+  size_t dims[3], n;
+  int encoding;
+  uint64_t* coef; /* encoder: working copy, decoder: output */
+  uint64_t* sign; /* encoder: input (const), decoder: output */
+  int8_t* msb;    /* encoder only: msb of every coefficient, depth-first order */
+  uint64_t *lip, *lsp;
+  size_t *fresh, nfresh, capfresh; /* LSP_new */
+  boxlist* lis;
+  size_t nlis;
+  bitfifo bits;
+  uint64_t thr;
+  int plane; /* msb of thr */
+} speck;
+
+static size_t raster_of(const speck* s, const uint32_t p[3])
+{
+  return ((size_t)p[2] * s->dims[1] + p[1]) * s->dims[0] + p[0];
+}
+
+static void fresh_push(speck* s, size_t idx)
+{
+  if (s->nfresh == s->capfresh) {
+    s->capfresh = s->capfresh ? s->capfresh * 2 : 1024;
+    s->fresh = (size_t*)realloc(s->fresh, s->capfresh * sizeof(size_t));
+  }
+  s->fresh[s->nfresh++] = idx;
+}
+
+/* src/SPECK3D_INT_ENC.cpp:8-139 : write msb positions in depth-first order */
+static void deposit_msb(speck* s, const box3* b)
+{
+  const size_t cnt = box_count(b);
+  if (cnt == 0)
+    return;
+  if (cnt == 1) {
+    const uint64_t v = s->coef[raster_of(s, b->org)];
+    s->msb[b->first] = v ? (int8_t)(63 - __builtin_clzll(v)) : -1; /* sperr_helper.cpp:645-658 */
+    return;
+  }
+  box3 kid[8];
+  box_split(b, kid);
+  for (int k = 0; k < 8; k++)
+    deposit_msb(s, &kid[k]);
+}
+
+/* src/SPECK3D_INT.cpp:22-97 (+ ENC.cpp:141-159 for the encoder's depth-first numbering) */
+static void speck_init_lists(speck* s)
+{
+  s->nlis = 1 + orc_num_of_partitions(s->dims[0]) + orc_num_of_partitions(s->dims[1]) +
+            orc_num_of_partitions(s->dims[2]);
+  s->lis = (boxlist*)calloc(s->nlis, sizeof(boxlist));
+  box3 big = {0, {0, 0, 0}, {(uint32_t)s->dims[0], (uint32_t)s->dims[1], (uint32_t)s->dims[2]}};
+  size_t lev = 0, dy;
+  box3 kid[8];
+  if (orc_can_use_dyadic(s->dims, &dy)) {
+    for (size_t i = 0; i < dy; i++) {
+      lev += box_split(&big, kid);
+      for (int k = 1; k < 8; k++)
+        list_push(&s->lis[lev], &kid[k]);
+      big = kid[0];
+    }
+  }
+  else {
+    const size_t nxy = orc_num_of_xforms(s->dims[0] < s->dims[1] ? s->dims[0] : s->dims[1]);
+    const size_t nz = orc_num_of_xforms(s->dims[2]);
+    size_t xf = 0;
+    for (; xf < nxy && xf < nz; xf++) {
+      lev += box_split(&big, kid);
+      for (int k = 1; k < 8; k++)
+        list_push(&s->lis[lev], &kid[k]);
+      big = kid[0];
+    }
+    for (; xf < nxy; xf++) {
+      lev += box_split_xy(&big, kid);
+      for (int k = 1; k < 4; k++)
+        list_push(&s->lis[lev], &kid[k]);
+      big = kid[0];
+    }
+    for (; xf < nz; xf++) {
+      lev += box_split_z(&big, kid);
+      list_push(&s->lis[lev], &kid[1]);
+      big = kid[0];
+    }
+  }
+  /* the remaining low-pass box goes to the FRONT of its list (src/SPECK3D_INT.cpp:93) */
+  boxlist* l = &s->lis[lev];
+  list_push(l, &big);
+  memmove(l->v + 1, l->v, (l->n - 1) * sizeof(box3));
+  l->v[0] = big;
+
+  if (s->encoding) {
+    uint64_t first = 0;
+    for (size_t t = s->nlis; t-- > 0;)
+      for (size_t i = 0; i < s->lis[t].n; i++) {
+        box3* b = &s->lis[t].v[i];
+        b->first = first;
+        deposit_msb(s, b);
+        first += box_count(b);
+      }
+  }
+}
+
+static void speck_test_box(speck* s, size_t lev, size_t idx, int* counter, int coded);
+
+/* pixel with known position (src/SPECK3D_INT_ENC.cpp:182-199, _DEC.cpp:24-37) */
+static void speck_test_pixel(speck* s, size_t ridx, uint64_t first, int* counter, int coded)
+{
+  int sig = 1;
+  if (coded) {
+    if (s->encoding) {
+      sig = s->msb[first] >= s->plane;
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+  }
+  if (sig) {
+    (*counter)++;
+    if (s->encoding)
+      fifo_put(&s->bits, mask_get(s->sign, ridx));
+    else if (fifo_get(&s->bits))
+      mask_set(s->sign, ridx);
+    else
+      mask_clr(s->sign, ridx);
+    fresh_push(s, ridx);
+    mask_clr(s->lip, ridx);
+  }
+}
+
+/* src/SPECK3D_INT.cpp:140-212 : the last non-empty child is not coded when none of its
+ * siblings turned out significant.  (The reference's 2x2x2 fast path is the same rule.) */
+static void speck_split_box(speck* s, size_t lev, size_t idx)
+{
+  const box3 parent = s->lis[lev].v[idx];
+  box3 kid[8];
+  const size_t next = lev + (size_t)box_split(&parent, kid);
+  int nkid = 0;
+  for (int k = 0; k < 8; k++)
+    if (box_count(&kid[k]))
+      kid[nkid++] = kid[k];
+  int found = 0;
+  for (int k = 0; k < nkid; k++) {
+    const int coded = found != 0 || k + 1 != nkid;
+    if (box_count(&kid[k]) == 1) {
+      const size_t ridx = raster_of(s, kid[k].org);
+      mask_set(s->lip, ridx);
+      speck_test_pixel(s, ridx, kid[k].first, &found, coded);
+    }
+    else {
+      list_push(&s->lis[next], &kid[k]);
+      speck_test_box(s, next, s->lis[next].n - 1, &found, coded);
+    }
+  }
+}
+
+/* src/SPECK3D_INT_ENC.cpp:161-180, _DEC.cpp:8-22 */
+static void speck_test_box(speck* s, size_t lev, size_t idx, int* counter, int coded)
+{
+  int sig = 1;
+  if (coded) {
+    if (s->encoding) {
+      const box3* b = &s->lis[lev].v[idx];
+      const int8_t* m = s->msb + b->first;
+      const size_t cnt = box_count(b);
+      sig = 0;
+      for (size_t i = 0; i < cnt; i++)
+        if (m[i] >= s->plane) {
+          sig = 1;
+          break;
+        }
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+  }
+  if (sig) {
+    (*counter)++;
+    speck_split_box(s, lev, idx);
+    s->lis[lev].v[idx].len[0] = 0; /* make_empty */
+  }
+}
+
+/* src/SPECK3D_INT.cpp:99-138 */
+static void speck_sorting_pass(speck* s)
+{
+  for (size_t i = 0; i < s->n; i++) { /* LIP scan in raster order */
+    if ((i & 63) == 0 && s->lip[i >> 6] == 0) {
+      i += 63;
+      continue;
+    }
+    if (!mask_get(s->lip, i))
+      continue;
+    int sig;
+    if (s->encoding) {
+      sig = s->coef[i] >= s->thr;
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+    if (sig) {
+      if (s->encoding)
+        fifo_put(&s->bits, mask_get(s->sign, i));
+      else if (fifo_get(&s->bits))
+        mask_set(s->sign, i);
+      else
+        mask_clr(s->sign, i);
+      fresh_push(s, i);
+      mask_clr(s->lip, i);
+    }
+  }
+  for (size_t lev = s->nlis; lev-- > 0;)
+    for (size_t i = 0; i < s->lis[lev].n; i++) {
+      int dummy = 0;
+      speck_test_box(s, lev, i, &dummy, 1);
+    }
+}
+
+/* src/SPECK3D_INT.cpp:12-20 */
+static void speck_clean_lists(speck* s)
+{
+  for (size_t lev = 0; lev < s->nlis; lev++) {
+    boxlist* l = &s->lis[lev];
+    size_t k = 0;
+    for (size_t i = 0; i < l->n; i++)
+      if (box_count(&l->v[i]))
+        l->v[k++] = l->v[i];
+    l->n = k;
+  }
+}
+
+static void speck_alloc(speck* s, const size_t dims[3], int encoding)
+{
+  memset(s, 0, sizeof(*s));
+  memcpy(s->dims, dims, sizeof(s->dims));
+  s->n = dims[0] * dims[1] * dims[2];
+  s->encoding = encoding;
+  const size_t words = (s->n + 63) / 64;
+  s->lip = (uint64_t*)calloc(words, 8);
+  s->lsp = (uint64_t*)calloc(words, 8);
+}
+
+static void speck_free(speck* s)
+{
+  for (size_t i = 0; i < s->nlis; i++)
+    free(s->lis[i].v);
+  free(s->lis);
+  free(s->lip);
+  free(s->lsp);
+  free(s->fresh);
+  free(s->msb);
+  free(s->bits.w);
+}
+
+/* src/SPECK_INT.cpp:48-58 */
+static size_t round_budget(size_t budget)
+{
+  if (budget == 0)
+    return (size_t)-1;
+  while (budget % 8)
+    budget++;
+  return budget;
+}
+
+/* src/SPECK_INT.cpp:110-163,284-357 */
+int orc_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
+                       size_t budget_bits, uint8_t** stream, size_t* stream_len)
+{
+  speck s;
+  speck_alloc(&s, dims, 1);
+  const size_t budget = round_budget(budget_bits);
+  s.coef = (uint64_t*)malloc(s.n * sizeof(uint64_t));
+  memcpy(s.coef, coeffs, s.n * sizeof(uint64_t));
+  s.sign = (uint64_t*)signs;
+  s.msb = (int8_t*)malloc(s.n);
+  speck_init_lists(&s);
+
+  uint64_t maxc = 0;
+  for (size_t i = 0; i < s.n; i++)
+    if (s.coef[i] > maxc)
+      maxc = s.coef[i];
+  uint8_t nplanes = 0;
+  uint64_t total_bits = 0;
+  if (maxc) {
+    nplanes = 1;
+    s.thr = 1;
+    while (maxc - s.thr >= s.thr) {
+      s.thr *= 2;
+      nplanes++;
+    }
+    for (uint8_t p = 0; p < nplanes; p++) {
+      s.plane = 63 - __builtin_clzll(s.thr);
+      speck_sorting_pass(&s);
+      if (s.bits.pos >= budget)
+        break;
+      /* refinement (src/SPECK_INT.cpp:310-357, ENC.cpp:220-227) */
+      for (size_t i = 0; i < s.n; i++)
+        if (mask_get(s.lsp, i)) {
+          const int b = s.coef[i] >= s.thr;
+          if (b)
+            s.coef[i] -= s.thr;
+          fifo_put(&s.bits, b);
+        }
+      for (size_t k = 0; k < s.nfresh; k++) {
+        s.coef[s.fresh[k]] -= s.thr;
+        mask_set(s.lsp, s.fresh[k]);
+      }
+      s.nfresh = 0;
+      if (s.bits.pos >= budget)
+        break;
+      s.thr /= 2;
+      speck_clean_lists(&s);
+    }
+    total_bits = s.bits.pos;
+  }
+
+  /* header {u8 planes, u64 total_bits} + first min(budget,total) bits (SPECK_INT.cpp:264-308) */
+  const size_t keep = total_bits < budget ? (size_t)total_bits : budget;
+  const size_t nbytes = (keep + 7) / 8;
+  uint8_t* out = (uint8_t*)calloc(9 + nbytes + 8, 1);
+  out[0] = nplanes;
+  memcpy(out + 1, &total_bits, 8);
+  if (nbytes)
+    memcpy(out + 9, s.bits.w, nbytes);
+  if (keep % 8) /* bits past `keep` inside the last byte can only exist when keep==budget, */
+    out[9 + nbytes - 1] &= (uint8_t)((1u << (keep % 8)) - 1); /* which is a multiple of 8   */
+  *stream = out;
+  *stream_len = 9 + nbytes;
+  free(s.coef);
+  speck_free(&s);
+  return 0;
+}
+
+/* src/SPECK_INT.cpp:79-108,165-228,359-469 */
+int orc_speck3d_decode(const uint8_t* stream, size_t len, const size_t dims[3], uint64_t* coeffs,
+                       uint64_t* signs)
+{
+  if (len < 9)
+    return 1;
+  speck s;
+  speck_alloc(&s, dims, 0);
+  const uint8_t nplanes = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  uint64_t avail = (uint64_t)(len - 9) * 8;
+  if (avail > total_bits)
+    avail = total_bits;
+  /* zero-padded bit buffer of total_bits (SPECK_INT.cpp:95-105) */
+  s.bits.cap_words = (size_t)(total_bits / 64 + 2);
+  s.bits.w = (uint64_t*)calloc(s.bits.cap_words, 8);
+  memcpy(s.bits.w, stream + 9, (size_t)((avail + 7) / 8));
+
+  s.coef = coeffs;
+  s.sign = signs;
+  memset(coeffs, 0, s.n * sizeof(uint64_t));
+  memset(signs, 0xff, ((s.n + 63) / 64) * 8);
+  speck_init_lists(&s);
+
+  if (nplanes) {
+    s.thr = (uint64_t)1 << (nplanes - 1);
+    for (uint8_t p = 0; p < nplanes; p++) {
+      speck_sorting_pass(&s);
+      if (s.bits.pos >= avail)
+        break;
+      /* refinement with per-bit exhaustion test (SPECK_INT.cpp:374-451) */
+      const uint64_t half = s.thr / 2;
+      int exhausted = 0;
+      for (size_t i = 0; i < s.n && !exhausted; i++) {
+        if ((i & 63) == 0 && s.lsp[i >> 6] == 0) {
+          i += 63;
+          continue;
+        }
+        if (!mask_get(s.lsp, i))
+          continue;
+        const int b = fifo_get(&s.bits);
+        if (s.thr >= 2)
+          s.coef[i] = b ? s.coef[i] + half : s.coef[i] - half;
+        else if (b)
+          s.coef[i]++;
+        if (s.bits.pos == avail)
+          exhausted = 1;
+      }
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1; /* SPECK_INT.cpp:462-468 */
+      for (size_t k = 0; k < s.nfresh; k++) {
+        s.coef[s.fresh[k]] = init;
+        mask_set(s.lsp, s.fresh[k]);
+      }
+      s.nfresh = 0;
+      if (s.bits.pos >= avail)
+        break;
+      s.thr /= 2;
+      speck_clean_lists(&s);
+    }
+    if (s.nfresh) { /* loop left right after a sorting pass (SPECK_INT.cpp:216-220) */
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1;
+      for (size_t k = 0; k < s.nfresh; k++)
+        s.coef[s.fresh[k]] = init;
+    }
+  }
+  speck_free(&s);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-chunk float pipeline                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/SPECK_FLT.cpp:401-541, CompMode::Rate only */
+int orc_chunk_compress_rate(double* vals, const size_t dims[3], double bpp, uint8_t** stream,
+                            size_t* stream_len)
+{
+  const size_t n = dims[0] * dims[1] * dims[2];
+  uint8_t condi[17];
+  if (orc_condition(vals, n, condi)) {
+    *stream = (uint8_t*)malloc(17);
+    memcpy(*stream, condi, 17);
+    *stream_len = 17;
+    return 0;
+  }
+  orc_dwt3d(vals, dims);
+  double maxabs = 0.0;
+  for (size_t i = 0; i < n; i++)
+    if (fabs(vals[i]) > maxabs)
+      maxabs = fabs(vals[i]);
+
+  uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
+  const size_t budget = (size_t)(bpp * (double)n);
+  uint8_t* speck_stream = NULL;
+  size_t speck_len = 0;
+  int rtn = 0;
+  for (int high_prec = 0; high_prec < 2; high_prec++) {
+    /* SPECK_FLT.cpp:282-301 */
+    const double q = high_prec ? maxabs / 0x1.fffffffffffffp52 : maxabs / 4294967295.0;
+    memcpy(condi + 9, &q, 8);
+    int width;
+    rtn = orc_quantize(vals, n, q, coef, sign, &width);
+    if (rtn)
+      break;
+    free(speck_stream);
+    orc_speck3d_encode(coef, sign, dims, budget, &speck_stream, &speck_len);
+    if (speck_len * 8 >= budget) /* SPECK_FLT.cpp:530-538 : enough bits, no retry */
+      break;
+  }
+  if (!rtn) {
+    *stream = (uint8_t*)malloc(17 + speck_len);
+    memcpy(*stream, condi, 17);
+    memcpy(*stream + 17, speck_stream, speck_len);
+    *stream_len = 17 + speck_len;
+  }
+  free(speck_stream);
+  free(coef);
+  free(sign);
+  return rtn;
+}
+
+/* src/SPECK_FLT.cpp:27-109,543-606 (no outlier stream in rate mode) */
+int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3], double* out)
+{
+  const size_t n = dims[0] * dims[1] * dims[2];
+  if (len < 17)
+    return 1; /* WrongLength */
+  if (stream[0] & 0x01) {
+    if (len != 17)
+      return 1;
+    orc_inverse_condition(out, n, stream);
+    return 0;
+  }
+  double q;
+  memcpy(&q, stream + 9, 8);
+  const uint8_t* sp = stream + 17;
+  size_t remaining = len - 17;
+  if (remaining < 9)
+    return 1;
+  uint64_t total_bits;
+  memcpy(&total_bits, sp + 1, 8);
+  size_t full = 9 + (size_t)((total_bits + 7) / 8);
+  size_t speck_len = full < remaining ? full : remaining;
+  uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
+  orc_speck3d_decode(sp, speck_len, dims, coef, sign);
+  orc_inv_quantize(coef, sign, n, q, out);
+  orc_idwt3d(out, dims);
+  orc_inverse_condition(out, n, stream);
+  free(coef);
+  free(sign);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* container + C API mirrors                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/SPERR_C_API.cpp:156-216, src/SPERR3D_OMP_C.cpp:61-261 */
+int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                size_t nthreads, void** dst, size_t* dst_len)
+{
+  if (*dst != NULL)
+    return 1;
+  if (quality <= 0.0)
+    return 2;
+  if (mode != 1)
+    return mode == 2 || mode == 3 ? -1 : 2; /* the oracle restates the fixed-rate path only */
+  const size_t vol[3] = {dimx, dimy, dimz};
+  size_t want[3] = {chunk_x, chunk_y, chunk_z}, cdim[3];
+  for (int a = 0; a < 3; a++) { /* SPERR3D_OMP_C.cpp:23-30 */
+    cdim[a] = want[a] < 1 ? 1 : want[a];
+    if (cdim[a] > vol[a])
+      cdim[a] = vol[a];
+  }
+  const size_t nchunks = orc_chunk_volume(vol, cdim, NULL, 0);
+  size_t(*chunks)[6] = (size_t(*)[6])malloc(nchunks * sizeof(*chunks));
+  orc_chunk_volume(vol, cdim, chunks, nchunks);
+  uint8_t** streams = (uint8_t**)calloc(nchunks, sizeof(uint8_t*));
+  size_t* lens = (size_t*)calloc(nchunks, sizeof(size_t));
+  int* rtns = (int*)calloc(nchunks, sizeof(int));
+  int nt = (int)nthreads;
+  (void)nt;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(nt > 0 ? nt : 1) if (nt != 1)
+#endif
+  for (long long ci = 0; ci < (long long)nchunks; ci++) {
+    const size_t* c = chunks[ci];
+    const size_t cd[3] = {c[1], c[3], c[5]};
+    const size_t cn = cd[0] * cd[1] * cd[2];
+    double* buf = (double*)malloc(cn * sizeof(double));
+    size_t k = 0; /* gather + widen (SPERR3D_OMP_C.cpp:236-261) */
+    for (size_t z = c[4]; z < c[4] + c[5]; z++)
+      for (size_t y = c[2]; y < c[2] + c[3]; y++) {
+        const size_t row = (z * dimy + y) * dimx + c[0];
+        if (is_float)
+          for (size_t x = 0; x < cd[0]; x++)
+            buf[k++] = (double)((const float*)src)[row + x];
+        else
+          for (size_t x = 0; x < cd[0]; x++)
+            buf[k++] = ((const double*)src)[row + x];
+      }
+    rtns[ci] = orc_chunk_compress_rate(buf, cd, quality, &streams[ci], &lens[ci]);
+    free(buf);
+  }
+  int rtn = 0;
+  for (size_t i = 0; i < nchunks; i++)
+    if (rtns[i])
+      rtn = -1;
+  if (!rtn) { /* header (SPERR3D_OMP_C.cpp:163-234) */
+    const size_t hlen = (nchunks > 1 ? 20 : 14) + 4 * nchunks;
+    size_t total = hlen;
+    for (size_t i = 0; i < nchunks; i++)
+      total += lens[i];
+    uint8_t* out = (uint8_t*)malloc(total);
+    out[0] = 0; /* SPERR_VERSION_MAJOR (CMakeLists.txt:5) */
+    out[1] = (uint8_t)(0x40 | (is_float ? 0x20 : 0) | (nchunks > 1 ? 0x10 : 0));
+    size_t pos = 2;
+    for (int a = 0; a < 3; a++) {
+      uint32_t v = (uint32_t)vol[a];
+      memcpy(out + pos, &v, 4);
+      pos += 4;
+    }
+    if (nchunks > 1)
+      for (int a = 0; a < 3; a++) {
+        uint16_t v = (uint16_t)cdim[a];
+        memcpy(out + pos, &v, 2);
+        pos += 2;
+      }
+    for (size_t i = 0; i < nchunks; i++) {
+      uint32_t v = (uint32_t)lens[i];
+      memcpy(out + pos, &v, 4);
+      pos += 4;
+    }
+    for (size_t i = 0; i < nchunks; i++) {
+      memcpy(out + pos, streams[i], lens[i]);
+      pos += lens[i];
+    }
+    *dst = out;
+    *dst_len = total;
+  }
+  for (size_t i = 0; i < nchunks; i++)
+    free(streams[i]);
+  free(streams);
+  free(lens);
+  free(rtns);
+  free(chunks);
+  return rtn;
+}
+
+/* src/SPERR_C_API.cpp:218-258, src/SPERR3D_OMP_D.cpp:23-184, SPERR3D_Stream_Tools.cpp:46-105 */
+int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
+                  size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
+{
+  if (*dst != NULL)
+    return 1;
+  const uint8_t* p = (const uint8_t*)src;
+  if (src_len < 18 || p[0] != 0 || !(p[1] & 0x40))
+    return -1;
+  const int multi = (p[1] & 0x10) != 0;
+  uint32_t v3[3];
+  memcpy(v3, p + 2, 12);
+  size_t vol[3] = {v3[0], v3[1], v3[2]}, cdim[3] = {v3[0], v3[1], v3[2]};
+  size_t pos = 14;
+  if (multi) {
+    uint16_t c3[3];
+    memcpy(c3, p + 14, 6);
+    for (int a = 0; a < 3; a++)
+      cdim[a] = c3[a];
+    pos = 20;
+  }
+  if (!vol[0] || !vol[1] || !vol[2] || !cdim[0] || !cdim[1] || !cdim[2])
+    return -1;
+  const size_t nchunks = orc_chunk_volume(vol, cdim, NULL, 0);
+  size_t(*chunks)[6] = (size_t(*)[6])malloc(nchunks * sizeof(*chunks));
+  orc_chunk_volume(vol, cdim, chunks, nchunks);
+  size_t* offs = (size_t*)malloc((nchunks + 1) * sizeof(size_t));
+  offs[0] = pos + 4 * nchunks;
+  for (size_t i = 0; i < nchunks; i++) {
+    uint32_t l;
+    memcpy(&l, p + pos + 4 * i, 4);
+    offs[i + 1] = offs[i] + l;
+  }
+  if (offs[nchunks] != src_len) {
+    free(chunks);
+    free(offs);
+    return -1;
+  }
+  const size_t n = vol[0] * vol[1] * vol[2];
+  double* outd = (double*)malloc(n * sizeof(double));
+  int* rtns = (int*)calloc(nchunks, sizeof(int));
+  int nt = (int)nthreads;
+  (void)nt;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(nt > 0 ? nt : 1) if (nt != 1)
+#endif
+  for (long long ci = 0; ci < (long long)nchunks; ci++) {
+    const size_t* c = chunks[ci];
+    const size_t cd[3] = {c[1], c[3], c[5]};
+    const size_t cn = cd[0] * cd[1] * cd[2];
+    double* buf = (double*)malloc(cn * sizeof(double));
+    rtns[ci] = orc_chunk_decompress(p + offs[ci], offs[ci + 1] - offs[ci], cd, buf);
+    size_t k = 0; /* scatter (SPERR3D_OMP_D.cpp:167-184) */
+    for (size_t z = c[4]; z < c[4] + c[5]; z++)
+      for (size_t y = c[2]; y < c[2] + c[3]; y++) {
+        memcpy(outd + (z * vol[1] + y) * vol[0] + c[0], buf + k, cd[0] * sizeof(double));
+        k += cd[0];
+      }
+    free(buf);
+  }
+  int rtn = 0;
+  for (size_t i = 0; i < nchunks; i++)
+    if (rtns[i])
+      rtn = -1;
+  free(rtns);
+  free(chunks);
+  free(offs);
+  if (rtn) {
+    free(outd);
+    return rtn;
+  }
+  *dimx = vol[0];
+  *dimy = vol[1];
+  *dimz = vol[2];
+  if (output_float) {
+    float* f = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++)
+      f[i] = (float)outd[i];
+    free(outd);
+    *dst = f;
+  }
+  else
+    *dst = outd;
+  return 0;
+}
