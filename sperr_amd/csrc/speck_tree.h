@@ -1,0 +1,342 @@
+// speck_tree.h -- geometry of SPECK3D's set-partitioning forest, shared by host and device code.
+//
+// The reference keeps explicit lists of `Set3D` boxes and splits them recursively
+// (/root/reference/src/SPECK3D_INT.cpp:22-97,140-326).  Here the same forest is described
+// implicitly so that any node can be addressed, enumerated and walked in O(1) by a GPU thread:
+//
+//   * a ROOT is one initial LIS entry (a wavelet subband box);
+//   * below a root every split is the reference's XYZ split: each axis of length `len` is cut
+//     into (len - len/2, len/2).  Repeating that rule `e` times cuts an axis of length L into
+//     2^e intervals (some may be empty) where interval i has length
+//         (L >> e) + (bitrev_e(i) < (L mod 2^e))
+//     -- the ceil-first rule hands the remainder out in bit-reversed order;
+//   * a NODE is (root, depth d, ix, iy, iz); on axis a the effective depth is min(d, D_a) with
+//     D_a = ceil(log2 L_a), so saturated axes stop splitting exactly as the reference's
+//     (len, 0) splits do;
+//   * nodes with more than one sample are SETS, nodes with exactly one are PIXELS, empty nodes
+//     do not exist for the coder.
+//
+// All functions here are pure integer arithmetic; the CPU model in tests/model and the HIP
+// kernels in speck_kernels.hip call the very same code.
+#ifndef SPERR_AMD_SPECK_TREE_H
+#define SPERR_AMD_SPECK_TREE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPK_HD __host__ __device__ __forceinline__
+#else
+#define SPK_HD inline
+#endif
+
+namespace spk {
+
+constexpr int kMaxRoots = 96;     // 7 per dyadic level (<=6) + packet extras, generous
+constexpr int kMaxDepth = 17;     // chunk dims are u16 in the container header
+constexpr int kMaxLevels = 64;    // LIS levels: 1 + sum of per-axis partitions (<= 49)
+constexpr int kNodeBlock = 256;   // node ranges of a grid are padded to this many nodes
+
+struct Root {
+  uint16_t org[3];
+  uint16_t len[3];
+  uint8_t D[3];        // per-axis depth at which every interval is <= 1 long
+  uint8_t Dmax;        // number of set depths of this root (pixels live at depth Dmax)
+  uint16_t lev;        // LIS level of the root set itself
+  uint16_t gridFirst;  // index of this root's depth-0 grid in Tree::grids
+  uint32_t tabOff[3];  // offset of the axis' interval-start tables in Tree::tab
+};
+
+struct Grid {          // all nodes of one root at one depth, as a dense 3D array
+  uint32_t nodeOff;    // first flat node id (multiple of kNodeBlock)
+  uint16_t root;
+  uint8_t depth;
+  uint8_t e[3];        // log2 of the grid extent per axis = min(depth, D[a])
+};
+
+// Everything a kernel needs to know about one chunk shape.  Arrays live in device memory (or
+// host memory for the CPU model); the struct itself is passed by value.
+struct Tree {
+  uint32_t dims[3];
+  uint32_t nvals;          // dims[0]*dims[1]*dims[2]
+  uint32_t nroots, ngrids;
+  uint32_t nnodes;         // padded total of flat node ids
+  uint32_t nlevels;        // number of LIS levels
+  uint32_t maxDepth;       // max over roots of Dmax
+  const Root* roots;
+  const Grid* grids;
+  const uint16_t* tab;     // interval start tables
+  const uint16_t* blockGrid;  // grid index of every kNodeBlock-sized block of flat node ids
+};
+
+struct Node {
+  uint16_t grid;           // index into Tree::grids
+  uint16_t i[3];
+};
+
+SPK_HD uint32_t bitrev(uint32_t v, int e)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return e ? (__brev(v) >> (32 - e)) : 0u;
+#else
+  uint32_t r = 0;
+  for (int k = 0; k < e; k++)
+    r |= ((v >> k) & 1u) << (e - 1 - k);
+  return r;
+#endif
+}
+
+// length of interval i of an axis of length L cut e times
+SPK_HD uint32_t axis_len(uint32_t L, int e, uint32_t i)
+{
+  return (L >> e) + (bitrev(i, e) < (L & ((1u << e) - 1u)) ? 1u : 0u);
+}
+
+// start tables: for e = 0..D the 2^e + 1 boundaries, concatenated
+SPK_HD uint32_t tab_index(int e, uint32_t i)
+{
+  return ((1u << e) - 1u) + (uint32_t)e + i;
+}
+
+SPK_HD uint64_t pack_node(const Node& n)
+{
+  return ((uint64_t)n.grid << 48) | ((uint64_t)n.i[2] << 32) | ((uint64_t)n.i[1] << 16) | n.i[0];
+}
+SPK_HD Node unpack_node(uint64_t v)
+{
+  Node n;
+  n.grid = (uint16_t)(v >> 48);
+  n.i[2] = (uint16_t)(v >> 32);
+  n.i[1] = (uint16_t)(v >> 16);
+  n.i[0] = (uint16_t)v;
+  return n;
+}
+
+SPK_HD uint32_t flat_id(const Tree& t, const Node& n)
+{
+  const Grid& g = t.grids[n.grid];
+  return g.nodeOff + ((((uint32_t)n.i[2] << g.e[1]) + n.i[1]) << g.e[0]) + n.i[0];
+}
+
+// inverse of flat_id for ids inside real grid extents; returns false for padding ids
+SPK_HD bool node_from_flat(const Tree& t, uint32_t id, Node& n)
+{
+  const uint32_t gi = t.blockGrid[id / kNodeBlock];
+  const Grid& g = t.grids[gi];
+  const uint32_t local = id - g.nodeOff;
+  if (local >= (1u << (g.e[0] + g.e[1] + g.e[2])))
+    return false;
+  n.grid = (uint16_t)gi;
+  n.i[0] = (uint16_t)(local & ((1u << g.e[0]) - 1u));
+  n.i[1] = (uint16_t)((local >> g.e[0]) & ((1u << g.e[1]) - 1u));
+  n.i[2] = (uint16_t)(local >> (g.e[0] + g.e[1]));
+  return true;
+}
+
+struct NodeGeom {
+  uint32_t len[3];
+  uint32_t count;  // len[0]*len[1]*len[2]
+};
+
+SPK_HD NodeGeom node_geom(const Tree& t, const Node& n)
+{
+  const Grid& g = t.grids[n.grid];
+  const Root& r = t.roots[g.root];
+  NodeGeom q;
+  for (int a = 0; a < 3; a++)
+    q.len[a] = axis_len(r.len[a], g.e[a], n.i[a]);
+  q.count = q.len[0] * q.len[1] * q.len[2];
+  return q;
+}
+
+// raster index (x fastest) of the single sample of a pixel node given as (root, per-axis
+// effective depth, per-axis index)
+SPK_HD uint32_t pixel_raster(const Tree& t, const Root& r, const int e[3], const uint32_t i[3])
+{
+  uint32_t c[3];
+  for (int a = 0; a < 3; a++)
+    c[a] = (uint32_t)r.org[a] + t.tab[r.tabOff[a] + tab_index(e[a], i[a])];
+  return (c[2] * t.dims[1] + c[1]) * t.dims[0] + c[0];
+}
+
+// LIS level of a set's children = level(set) + number of axes of the set that split, where
+// level(set) = root level + the number of splitting ancestors per axis
+// (/root/reference/src/SPECK3D_INT.cpp:226-229).
+SPK_HD uint32_t node_level(const Tree& t, const Node& n)
+{
+  const Grid& g = t.grids[n.grid];
+  const Root& r = t.roots[g.root];
+  uint32_t lev = r.lev;
+  for (int a = 0; a < 3; a++) {
+    const int Da = r.D[a];
+    const int d = g.depth;
+    if (Da == 0)
+      continue;
+    if (d < Da) {
+      lev += (uint32_t)d;  // every ancestor at depth < d <= Da-1 is >= 2 long
+    }
+    else {
+      lev += (uint32_t)(Da - 1);
+      // the ancestor at depth Da-1 splits iff it is 2 long
+      const uint32_t anc = (uint32_t)n.i[a] >> 1;  // effective depth is Da here
+      if (axis_len(r.len[a], Da - 1, anc) >= 2)
+        lev += 1;
+    }
+  }
+  return lev;
+}
+
+// ------------------------------------------------------------------------------------------
+// children of a set node, in the reference's order (x fastest, empty ones dropped)
+// ------------------------------------------------------------------------------------------
+struct Kids {
+  int n;                 // number of non-empty children
+  int childDepth;        // depth of the children
+  bool deepest;          // children live at depth Dmax: they are pixels (or empty)
+  uint16_t childGrid;    // grid of the children when !deepest
+  uint32_t idx[8][3];    // per-axis child index at the child's effective depth
+  uint32_t count[8];     // number of samples of the child
+  int e[3];              // children's effective per-axis depth
+};
+
+SPK_HD void node_kids(const Tree& t, const Node& n, Kids& k)
+{
+  const Grid& g = t.grids[n.grid];
+  const Root& r = t.roots[g.root];
+  k.childDepth = g.depth + 1;
+  k.deepest = (k.childDepth == r.Dmax);
+  k.childGrid = (uint16_t)(n.grid + 1);
+  int nsplit[3];
+  uint32_t base[3];
+  for (int a = 0; a < 3; a++) {
+    const bool splits = g.depth < r.D[a];
+    k.e[a] = splits ? g.e[a] + 1 : g.e[a];
+    nsplit[a] = splits ? 2 : 1;
+    base[a] = splits ? (uint32_t)n.i[a] * 2u : (uint32_t)n.i[a];
+  }
+  k.n = 0;
+  for (int cz = 0; cz < nsplit[2]; cz++)
+    for (int cy = 0; cy < nsplit[1]; cy++)
+      for (int cx = 0; cx < nsplit[0]; cx++) {
+        const uint32_t ci[3] = {base[0] + cx, base[1] + cy, base[2] + cz};
+        uint32_t cnt = 1;
+        for (int a = 0; a < 3; a++)
+          cnt *= axis_len(r.len[a], k.e[a], ci[a]);
+        if (cnt == 0)
+          continue;
+        k.idx[k.n][0] = ci[0];
+        k.idx[k.n][1] = ci[1];
+        k.idx[k.n][2] = ci[2];
+        k.count[k.n] = cnt;
+        k.n++;
+      }
+}
+
+SPK_HD uint32_t kid_flat(const Tree& t, const Kids& k, int j)
+{
+  const Grid& g = t.grids[k.childGrid];
+  return g.nodeOff + (((k.idx[j][2] << g.e[1]) + k.idx[j][1]) << g.e[0]) + k.idx[j][0];
+}
+
+SPK_HD Node kid_node(const Kids& k, int j)
+{
+  Node c;
+  c.grid = k.childGrid;
+  c.i[0] = (uint16_t)k.idx[j][0];
+  c.i[1] = (uint16_t)k.idx[j][1];
+  c.i[2] = (uint16_t)k.idx[j][2];
+  return c;
+}
+
+SPK_HD uint32_t kid_raster(const Tree& t, const Node& parent, const Kids& k, int j)
+{
+  const Root& r = t.roots[t.grids[parent.grid].root];
+  return pixel_raster(t, r, k.e, k.idx[j]);
+}
+
+// parent of a non-root node
+SPK_HD Node node_parent(const Tree& t, const Node& n)
+{
+  const Grid& g = t.grids[n.grid];
+  const Root& r = t.roots[g.root];
+  Node p;
+  p.grid = (uint16_t)(n.grid - 1);
+  for (int a = 0; a < 3; a++)
+    p.i[a] = (g.depth - 1 < r.D[a]) ? (uint16_t)(n.i[a] >> 1) : n.i[a];
+  return p;
+}
+
+SPK_HD bool node_is_root(const Tree& t, const Node& n)
+{
+  return t.grids[n.grid].depth == 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder-side per-node logic.  `M[id]` = msb of the largest coefficient in the node (-1 when
+// all zero), `E[id]` = number of bits the node's split emits (children tests, signs and nested
+// splits) -- both indexed by flat node id; pixel children at the deepest depth read `msb[]`
+// in raster order instead.
+// ------------------------------------------------------------------------------------------
+struct KidInfo {
+  int8_t m[8];         // msb of each child
+  uint32_t e[8];       // split length of each child set (0 for pixels)
+  bool pixel[8];
+};
+
+SPK_HD void kids_info(const Tree& t, const Node& n, const Kids& k, const int8_t* M,
+                      const uint32_t* E, const int8_t* msb, KidInfo& ki)
+{
+  for (int j = 0; j < k.n; j++) {
+    ki.pixel[j] = (k.count[j] == 1);
+    if (k.deepest) {
+      ki.m[j] = msb[kid_raster(t, n, k, j)];
+      ki.e[j] = 0;
+    }
+    else {
+      const uint32_t id = kid_flat(t, k, j);
+      ki.m[j] = M[id];
+      ki.e[j] = ki.pixel[j] ? 0u : E[id];
+    }
+  }
+}
+
+// Number of bits a set emits when it splits at plane `m` (its own msb): one test bit per
+// child except an inferred last child, one sign bit per significant pixel child, plus the
+// nested split of every significant set child
+// (/root/reference/src/SPECK3D_INT.cpp:140-212, SPECK3D_INT_ENC.cpp:161-199).
+SPK_HD uint32_t split_bits(const Kids& k, const KidInfo& ki, int m)
+{
+  uint32_t bits = 0;
+  bool found = false;
+  for (int j = 0; j < k.n; j++) {
+    const bool coded = found || (j + 1 != k.n);
+    bits += coded ? 1u : 0u;
+    const bool sig = coded ? (ki.m[j] == m) : true;
+    if (sig) {
+      found = true;
+      bits += ki.pixel[j] ? 1u : ki.e[j];
+    }
+  }
+  return bits;
+}
+
+// Offset of child `which`'s own code inside its parent's split (bits emitted for the earlier
+// children), and whether `which`'s test bit is coded.
+SPK_HD uint32_t kid_offset(const Kids& k, const KidInfo& ki, int m, int which, bool& coded_out)
+{
+  uint32_t bits = 0;
+  bool found = false;
+  for (int j = 0; j < which; j++) {
+    bits += 1;  // never the last child, so always coded
+    if (ki.m[j] == m) {
+      found = true;
+      bits += ki.pixel[j] ? 1u : ki.e[j];
+    }
+  }
+  coded_out = found || (which + 1 != k.n);
+  return bits;
+}
+
+}  // namespace spk
+
+#endif

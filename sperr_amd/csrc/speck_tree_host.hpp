@@ -1,0 +1,246 @@
+// speck_tree_host.hpp -- host-side construction of the spk::Tree tables for one chunk shape.
+//
+// Follows the reference's list initialisation (/root/reference/src/SPECK3D_INT.cpp:22-97): the
+// volume is split `levels` times (XYZ while both the XY and the Z transform counts last, then
+// XY-only or Z-only); every split hands its non-first children to the LIS as roots and keeps
+// splitting the first child; the box that is left goes to the FRONT of its list.
+#ifndef SPERR_AMD_SPECK_TREE_HOST_HPP
+#define SPERR_AMD_SPECK_TREE_HOST_HPP
+
+#include <algorithm>
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "speck_tree.h"
+
+namespace spk {
+
+// geometry helpers restated from /root/reference/src/sperr_helper.cpp:36-68,125-146
+inline size_t num_of_xforms(size_t len)
+{
+  size_t n = 0;
+  while (len >= 9) {
+    n++;
+    len -= len / 2;
+  }
+  return std::min<size_t>(n, 6);
+}
+inline bool can_use_dyadic(const std::array<size_t, 3>& d, size_t& levels)
+{
+  if (d[2] < 2 || d[1] < 2)
+    return false;
+  const size_t xy = num_of_xforms(std::min(d[0], d[1])), z = num_of_xforms(d[2]);
+  if (xy == z || (xy >= 5 && z >= 5)) {
+    levels = std::min(xy, z);
+    return true;
+  }
+  return false;
+}
+inline size_t num_of_partitions(size_t len)
+{
+  size_t n = 0;
+  while (len > 1) {
+    n++;
+    len -= len / 2;
+  }
+  return n;
+}
+inline std::array<size_t, 2> approx_detail_len(size_t len, size_t lev)
+{
+  size_t lo = len, hi = 0;
+  for (size_t i = 0; i < lev; i++) {
+    hi = lo / 2;
+    lo -= hi;
+  }
+  return {lo, hi};
+}
+
+struct HostTree {
+  std::vector<Root> roots;
+  std::vector<Grid> grids;
+  std::vector<uint16_t> tab;
+  std::vector<uint16_t> blockGrid;
+  std::vector<std::vector<uint64_t>> initLIS;  // per level, packed root nodes in list order
+  std::vector<uint32_t> levelCap;              // per level, number of set nodes (list capacity)
+  std::vector<uint32_t> levelOff;              // exclusive prefix of levelCap (+ total at end)
+  uint32_t dims[3] = {0, 0, 0};
+  uint32_t nnodes = 0, nlevels = 0, maxDepth = 0, nsets = 0;
+
+  Tree view() const
+  {
+    Tree t;
+    for (int a = 0; a < 3; a++)
+      t.dims[a] = dims[a];
+    t.nvals = dims[0] * dims[1] * dims[2];
+    t.nroots = (uint32_t)roots.size();
+    t.ngrids = (uint32_t)grids.size();
+    t.nnodes = nnodes;
+    t.nlevels = nlevels;
+    t.maxDepth = maxDepth;
+    t.roots = roots.data();
+    t.grids = grids.data();
+    t.tab = tab.data();
+    t.blockGrid = blockGrid.data();
+    return t;
+  }
+};
+
+namespace detail {
+struct Box {
+  uint32_t org[3], len[3];
+};
+inline int ceil_log2(uint32_t v)
+{
+  int e = 0;
+  while ((1u << e) < v)
+    e++;
+  return e;
+}
+}  // namespace detail
+
+inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
+{
+  using detail::Box;
+  HostTree h;
+  h.dims[0] = (uint32_t)dx;
+  h.dims[1] = (uint32_t)dy;
+  h.dims[2] = (uint32_t)dz;
+  h.nlevels = (uint32_t)(1 + num_of_partitions(dx) + num_of_partitions(dy) + num_of_partitions(dz));
+
+  // ---- roots, in the order the reference pushes them -----------------------------------
+  struct Pending {
+    Box b;
+    uint32_t lev;
+  };
+  std::vector<std::vector<Box>> lists(h.nlevels);
+  Box big{{0, 0, 0}, {(uint32_t)dx, (uint32_t)dy, (uint32_t)dz}};
+  uint32_t lev = 0;
+  auto split = [&](bool sx, bool sy, bool sz) {
+    // cut `big` on the chosen axes; children in x-fastest order; first child stays `big`
+    uint32_t part[3][2], off[3][2];
+    const bool use[3] = {sx, sy, sz};
+    uint32_t inc = 0;
+    for (int a = 0; a < 3; a++) {
+      if (use[a]) {
+        part[a][1] = big.len[a] / 2;
+        part[a][0] = big.len[a] - part[a][1];
+      }
+      else {
+        part[a][0] = big.len[a];
+        part[a][1] = 0;
+      }
+      off[a][0] = big.org[a];
+      off[a][1] = big.org[a] + part[a][0];
+      inc += (use[a] && part[a][1] != 0) ? 1 : 0;
+    }
+    lev += inc;
+    Box first = big;
+    for (int k = 0; k < 8; k++) {
+      const int hh[3] = {k & 1, (k >> 1) & 1, (k >> 2) & 1};
+      if ((!use[0] && hh[0]) || (!use[1] && hh[1]) || (!use[2] && hh[2]))
+        continue;
+      Box c;
+      for (int a = 0; a < 3; a++) {
+        c.org[a] = off[a][hh[a]];
+        c.len[a] = part[a][hh[a]];
+      }
+      if (k == 0)
+        first = c;
+      else
+        lists[lev].push_back(c);
+    }
+    big = first;
+  };
+  size_t dyadic = 0;
+  if (can_use_dyadic({dx, dy, dz}, dyadic)) {
+    for (size_t i = 0; i < dyadic; i++)
+      split(true, true, true);
+  }
+  else {
+    const size_t nxy = num_of_xforms(std::min(dx, dy)), nz = num_of_xforms(dz);
+    size_t xf = 0;
+    for (; xf < nxy && xf < nz; xf++)
+      split(true, true, true);
+    for (; xf < nxy; xf++)
+      split(true, true, false);
+    for (; xf < nz; xf++)
+      split(false, false, true);
+  }
+  lists[lev].insert(lists[lev].begin(), big);
+
+  // ---- per-root tables -----------------------------------------------------------------
+  h.initLIS.assign(h.nlevels, {});
+  for (uint32_t l = 0; l < h.nlevels; l++)
+    for (const Box& b : lists[l]) {
+      Root r{};
+      uint8_t dmax = 0;
+      for (int a = 0; a < 3; a++) {
+        r.org[a] = (uint16_t)b.org[a];
+        r.len[a] = (uint16_t)b.len[a];
+        r.D[a] = (uint8_t)detail::ceil_log2(b.len[a]);
+        dmax = std::max(dmax, r.D[a]);
+        r.tabOff[a] = (uint32_t)h.tab.size();
+        for (int e = 0; e <= r.D[a]; e++) {
+          uint32_t s = 0;
+          for (uint32_t i = 0; i < (1u << e); i++) {
+            h.tab.push_back((uint16_t)s);
+            s += axis_len(b.len[a], e, i);
+          }
+          h.tab.push_back((uint16_t)s);
+        }
+      }
+      r.Dmax = std::max<uint8_t>(dmax, 1);  // a one-sample root still is a set with one pixel child
+      r.lev = (uint16_t)l;
+      r.gridFirst = (uint16_t)h.grids.size();
+      const uint16_t ri = (uint16_t)h.roots.size();
+      for (int d = 0; d < r.Dmax; d++) {
+        Grid g{};
+        g.root = ri;
+        g.depth = (uint8_t)d;
+        for (int a = 0; a < 3; a++)
+          g.e[a] = (uint8_t)std::min<int>(d, r.D[a]);
+        g.nodeOff = h.nnodes;
+        const uint32_t n = 1u << (g.e[0] + g.e[1] + g.e[2]);
+        const uint32_t padded = (n + kNodeBlock - 1) / kNodeBlock * kNodeBlock;
+        for (uint32_t b2 = 0; b2 < padded / kNodeBlock; b2++)
+          h.blockGrid.push_back((uint16_t)h.grids.size());
+        h.nnodes += padded;
+        h.grids.push_back(g);
+      }
+      h.maxDepth = std::max<uint32_t>(h.maxDepth, r.Dmax);
+      Node rn{r.gridFirst, {0, 0, 0}};
+      h.initLIS[l].push_back(pack_node(rn));
+      h.roots.push_back(r);
+    }
+
+  // ---- list capacities: how many set nodes can ever sit in each LIS level ----------------
+  h.levelCap.assign(h.nlevels, 0);
+  const Tree t = h.view();
+  for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
+    const Grid& g = h.grids[gi];
+    Node n;
+    n.grid = (uint16_t)gi;
+    for (uint32_t z = 0; z < (1u << g.e[2]); z++)
+      for (uint32_t y = 0; y < (1u << g.e[1]); y++)
+        for (uint32_t x = 0; x < (1u << g.e[0]); x++) {
+          n.i[0] = (uint16_t)x;
+          n.i[1] = (uint16_t)y;
+          n.i[2] = (uint16_t)z;
+          const NodeGeom q = node_geom(t, n);
+          if (q.count > 1 || (g.depth == 0 && q.count == 1)) {
+            h.levelCap[node_level(t, n)]++;
+            h.nsets++;
+          }
+        }
+  }
+  h.levelOff.assign(h.nlevels + 1, 0);
+  for (uint32_t l = 0; l < h.nlevels; l++)
+    h.levelOff[l + 1] = h.levelOff[l] + h.levelCap[l];
+  return h;
+}
+
+}  // namespace spk
+
+#endif

@@ -1,0 +1,296 @@
+// speck_model.cpp -- CPU model of the DATA-PARALLEL SPECK3D formulation used by the HIP kernels.
+//
+// TEST INFRASTRUCTURE.  Every "kernel" of sperr_amd/csrc/speck_kernels.hip is modelled here as a
+// plain loop over its thread index, calling the same shared geometry / per-node logic
+// (sperr_amd/csrc/speck_tree.h).  tests/test_speck_model.py checks the model bit for bit against
+// the oracle, which pins the formulation (count -> scan -> emit, no serial traversal) on the CPU
+// before any GPU time is spent.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../sperr_amd/csrc/speck_tree_host.hpp"
+
+using namespace spk;
+
+namespace {
+
+struct BitSink {
+  std::vector<uint64_t> w;
+  uint64_t limit;  // bits at positions >= limit are dropped
+  void put(uint64_t pos, int bit)
+  {
+    if (pos >= limit || !bit)
+      return;
+    w[pos >> 6] |= uint64_t(1) << (pos & 63);
+  }
+};
+
+inline int msb_of(uint64_t v)
+{
+  return v ? 63 - __builtin_clzll(v) : -1;
+}
+
+struct Enc {
+  HostTree ht;
+  Tree t;
+  std::vector<int8_t> M, msb, bplane;
+  std::vector<uint32_t> E;
+  std::vector<uint64_t> opos;
+};
+
+// "kernel" E1: one thread per node of every grid at depth d
+void build_depth(Enc& s, uint32_t depth)
+{
+  const Tree& t = s.t;
+  for (uint32_t gi = 0; gi < t.ngrids; gi++) {
+    const Grid& g = t.grids[gi];
+    if (g.depth != depth)
+      continue;
+    const uint32_t n = 1u << (g.e[0] + g.e[1] + g.e[2]);
+    for (uint32_t local = 0; local < n; local++) {
+      Node nd;
+      const uint32_t id = g.nodeOff + local;
+      if (!node_from_flat(t, id, nd))
+        abort();
+      const NodeGeom q = node_geom(t, nd);
+      if (q.count == 0)
+        continue;
+      const Root& r = t.roots[g.root];
+      const bool isset = q.count > 1 || g.depth == 0;
+      if (!isset) {
+        const int e[3] = {g.e[0], g.e[1], g.e[2]};
+        const uint32_t ii[3] = {nd.i[0], nd.i[1], nd.i[2]};
+        s.M[id] = s.msb[pixel_raster(t, r, e, ii)];
+        continue;
+      }
+      Kids k;
+      node_kids(t, nd, k);
+      KidInfo ki;
+      kids_info(t, nd, k, s.M.data(), s.E.data(), s.msb.data(), ki);
+      int m = -1;
+      for (int j = 0; j < k.n; j++)
+        m = std::max<int>(m, ki.m[j]);
+      s.M[id] = (int8_t)m;
+      s.E[id] = m >= 0 ? split_bits(k, ki, m) : 0;
+      for (int j = 0; j < k.n; j++)
+        if (ki.pixel[j])
+          s.bplane[kid_raster(t, nd, k, j)] = (int8_t)m;
+    }
+  }
+}
+
+struct Born {
+  uint32_t lev;
+  uint64_t pos;
+  uint64_t packed;
+};
+
+// "kernel" K2: one thread per set node; acts only when the node splits at plane p
+void emit_splits(Enc& s, int p, BitSink& out, const std::vector<uint64_t>& sign,
+                 std::vector<Born>& born)
+{
+  const Tree& t = s.t;
+  for (uint32_t id = 0; id < t.nnodes; id++) {
+    Node nd;
+    if (!node_from_flat(t, id, nd))
+      continue;
+    const NodeGeom q = node_geom(t, nd);
+    const bool isset = q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
+    if (!isset || s.M[id] != p)
+      continue;
+    // walk up to the list entry that started this split chain
+    uint64_t off = 0;
+    Node cur = nd;
+    uint32_t curid = id;
+    while (!node_is_root(t, cur)) {
+      const Node par = node_parent(t, cur);
+      const uint32_t pid = flat_id(t, par);
+      if (s.M[pid] != p)
+        break;
+      Kids pk;
+      node_kids(t, par, pk);
+      KidInfo pki;
+      kids_info(t, par, pk, s.M.data(), s.E.data(), s.msb.data(), pki);
+      int which = -1;
+      for (int j = 0; j < pk.n; j++)
+        if (pk.idx[j][0] == cur.i[0] && pk.idx[j][1] == cur.i[1] && pk.idx[j][2] == cur.i[2])
+          which = j;
+      if (which < 0)
+        abort();
+      bool coded;
+      off += kid_offset(pk, pki, p, which, coded);
+      off += coded ? 1 : 0;
+      cur = par;
+      curid = pid;
+    }
+    uint64_t pos = s.opos[curid] + 1 + off;  // first bit of this node's split
+
+    Kids k;
+    node_kids(t, nd, k);
+    KidInfo ki;
+    kids_info(t, nd, k, s.M.data(), s.E.data(), s.msb.data(), ki);
+    const uint32_t kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+    bool found = false;
+    for (int j = 0; j < k.n; j++) {
+      const bool coded = found || (j + 1 != k.n);
+      const bool sig = coded ? (ki.m[j] == p) : true;
+      if (coded)
+        out.put(pos++, sig);
+      if (sig) {
+        found = true;
+        if (ki.pixel[j]) {
+          const uint32_t ridx = kid_raster(t, nd, k, j);
+          out.put(pos++, (int)((sign[ridx >> 6] >> (ridx & 63)) & 1));
+        }
+        else
+          pos += ki.e[j];
+      }
+      else if (!ki.pixel[j])
+        born.push_back({kidlev, pos - 1, pack_node(kid_node(k, j))});
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Same contract as orc_speck3d_encode (oracle/sperr_oracle.h)
+int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
+                         size_t budget_bits, uint8_t** stream, size_t* stream_len)
+{
+  Enc s;
+  s.ht = build_tree(dims[0], dims[1], dims[2]);
+  s.t = s.ht.view();
+  const Tree& t = s.t;
+  const size_t N = t.nvals;
+  uint64_t budget = budget_bits ? budget_bits : ~uint64_t(0);
+  if (budget_bits)
+    while (budget % 8)
+      budget++;
+
+  s.msb.resize(N);
+  for (size_t i = 0; i < N; i++)
+    s.msb[i] = (int8_t)msb_of(coeffs[i]);
+  s.M.assign(t.nnodes, -1);
+  s.E.assign(t.nnodes, 0);
+  s.opos.assign(t.nnodes, 0);
+  s.bplane.assign(N, -1);
+  for (uint32_t d = t.maxDepth; d-- > 0;)
+    build_depth(s, d);
+
+  int nbp = 0;
+  for (uint32_t r = 0; r < t.nroots; r++)
+    nbp = std::max<int>(nbp, s.M[t.grids[t.roots[r].gridFirst].nodeOff] + 1);
+
+  // census (kernel E2): bits per plane of the LIP scans and refinement passes
+  std::vector<uint64_t> lipTot(64, 0), refTot(64, 0);
+  for (size_t i = 0; i < N; i++) {
+    const int m = s.msb[i], b = s.bplane[i];
+    for (int p = 0; p < b && p < nbp; p++)
+      if (p >= m) {
+        lipTot[p] += 1;           // one test bit per LIP scan while insignificant
+        if (p == m)
+          lipTot[p] += 1;         // sign bit on the scan that finds it
+      }
+    for (int p = 0; p < m; p++)
+      refTot[p] += 1;             // one refinement bit on every later plane
+  }
+
+  std::vector<std::vector<uint64_t>> lis(s.ht.initLIS), next(t.nlevels);
+  std::vector<uint64_t> baseLIP(64, 0), baseLIS(64, 0), baseREF(64, 0);
+  std::vector<char> didREF(64, 0);
+  uint64_t pos = 0;
+  int plast = nbp;  // lowest plane whose sorting pass ran
+  BitSink out;
+  out.limit = budget;
+  // upper bound of the stream length is unknown before the plane loop; grow as needed
+  std::vector<Born> born;
+  std::vector<std::pair<int, std::vector<Born>>> unused;
+  // first pass over planes: positions (K1) + set-split emission (K2)
+  // the sink must be large enough: worst case every node coded every plane; size lazily
+  out.w.assign(1, 0);
+  auto ensure = [&](uint64_t bits) {
+    uint64_t lim = std::min<uint64_t>(bits, budget);
+    if ((lim + 127) / 64 > out.w.size())
+      out.w.resize((lim + 127) / 64, 0);
+  };
+  for (int p = nbp - 1; p >= 0; p--) {
+    plast = p;
+    baseLIP[p] = pos;
+    pos += lipTot[p];
+    baseLIS[p] = pos;
+    // kernel K1: positions of the list entries, list compaction
+    for (uint32_t l = t.nlevels; l-- > 0;) {
+      next[l].clear();
+      for (uint64_t packed : lis[l]) {
+        const Node nd = unpack_node(packed);
+        const uint32_t id = flat_id(t, nd);
+        if (s.M[id] == p) {
+          s.opos[id] = pos;
+          pos += 1 + s.E[id];
+        }
+        else {
+          pos += 1;
+          next[l].push_back(packed);
+        }
+      }
+    }
+    ensure(pos);
+    // list entries' own test bits
+    for (uint32_t l = 0; l < t.nlevels; l++)
+      for (uint64_t packed : lis[l]) {
+        const uint32_t id = flat_id(t, unpack_node(packed));
+        if (s.M[id] == p)
+          out.put(s.opos[id], 1);
+      }
+    // kernel K2 + K2b
+    born.clear();
+    emit_splits(s, p, out, std::vector<uint64_t>(signs, signs + (N + 63) / 64), born);
+    std::stable_sort(born.begin(), born.end(), [](const Born& a, const Born& b) {
+      return a.lev != b.lev ? a.lev < b.lev : a.pos < b.pos;
+    });
+    for (const Born& b : born)
+      next[b.lev].push_back(b.packed);
+    lis.swap(next);
+    if (pos >= budget)
+      break;
+    baseREF[p] = pos;
+    pos += refTot[p];
+    didREF[p] = 1;
+    if (pos >= budget)
+      break;
+  }
+  const uint64_t total_bits = nbp ? pos : 0;
+  ensure(total_bits);
+
+  // kernel E5: LIP-scan and refinement bits, raster order
+  for (int p = nbp - 1; p >= plast && nbp; p--) {
+    uint64_t lp = baseLIP[p], rp = baseREF[p];
+    for (size_t i = 0; i < N; i++) {
+      const int m = s.msb[i], b = s.bplane[i];
+      if (b > p && p >= m) {
+        out.put(lp++, m == p);
+        if (m == p)
+          out.put(lp++, (int)((signs[i >> 6] >> (i & 63)) & 1));
+      }
+      if (didREF[p] && m > p)
+        out.put(rp++, (int)((coeffs[i] >> p) & 1));
+    }
+  }
+
+  const uint64_t keep = std::min<uint64_t>(total_bits, budget);
+  const size_t nbytes = (size_t)((keep + 7) / 8);
+  uint8_t* o = (uint8_t*)calloc(9 + nbytes + 8, 1);
+  o[0] = (uint8_t)nbp;
+  memcpy(o + 1, &total_bits, 8);
+  memcpy(o + 9, out.w.data(), nbytes);
+  *stream = o;
+  *stream_len = 9 + nbytes;
+  return 0;
+}
+
+}  // extern "C"
