@@ -293,4 +293,160 @@ int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const si
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Decoder model.  Per plane: (D1) LIP scan parsed with the run-parity rule, (D2) LIS phase as a
+// serial walk (one thread per chunk in the kernel), (D3) refinement as a gather.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct BitSrc {
+  const uint8_t* p;
+  uint64_t avail;  // bits past `avail` read as zero (zero padding of a truncated stream)
+  int get(uint64_t pos) const { return pos < avail ? (p[pos >> 3] >> (pos & 7)) & 1 : 0; }
+};
+
+}  // namespace
+
+// Same contract as orc_speck3d_decode (oracle/sperr_oracle.h)
+int model_speck3d_decode(const uint8_t* stream, size_t len, const size_t dims[3], uint64_t* coef,
+                         uint64_t* sign)
+{
+  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  const Tree t = ht.view();
+  const size_t N = t.nvals;
+  const int nbp = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  uint64_t avail = (uint64_t)(len - 9) * 8;
+  if (avail > total_bits)
+    avail = total_bits;
+  BitSrc in{stream + 9, avail};
+
+  std::vector<int8_t> born(N, -1), sigp(N, -1);
+  memset(coef, 0, N * sizeof(uint64_t));
+  memset(sign, 0xff, ((N + 63) / 64) * 8);
+  auto set_sign = [&](uint32_t i, int b) {
+    if (b)
+      sign[i >> 6] |= uint64_t(1) << (i & 63);
+    else
+      sign[i >> 6] &= ~(uint64_t(1) << (i & 63));
+  };
+  std::vector<std::vector<uint64_t>> lis(ht.initLIS), next(t.nlevels);
+  uint64_t pos = 0;
+  for (int p = nbp - 1; p >= 0; p--) {
+    const uint64_t thr = uint64_t(1) << p;
+    const uint64_t init = thr + thr - thr / 2 - 1;
+    // ---- D1: LIP scan.  candidates in raster order; token k starts where the number of
+    //      consecutive 1 bits right before it is even.
+    std::vector<uint32_t> cand;
+    for (size_t i = 0; i < N; i++)
+      if (born[i] > p && sigp[i] < 0)
+        cand.push_back((uint32_t)i);
+    {
+      size_t j = 0;
+      uint64_t k = 0, ones = 0;
+      for (; j < cand.size(); k++) {
+        const int b = in.get(pos + k);
+        if ((ones & 1) == 0) {  // token start
+          if (b) {
+            sigp[cand[j]] = (int8_t)p;
+            coef[cand[j]] = init;
+            set_sign(cand[j], in.get(pos + k + 1));
+          }
+          j++;
+        }
+        ones = b ? ones + 1 : 0;
+      }
+      // the phase ends where token #cand.size() would start
+      if (ones & 1)
+        k++;  // the last token was "1 s": its sign bit is consumed too
+      pos += k;
+    }
+    // ---- D2: LIS phase, serial
+    for (uint32_t l = 0; l < t.nlevels; l++)
+      next[l].clear();
+    struct Frame {
+      Node nd;
+    };
+    for (uint32_t l = t.nlevels; l-- > 0;) {
+      for (uint64_t packed : lis[l]) {
+        if (!in.get(pos++)) {
+          next[l].push_back(packed);
+          continue;
+        }
+        // significant: split depth-first with an explicit stack of (node, next child)
+        struct Item {
+          Node nd;
+          Kids k;
+          int j;
+          bool found;
+          uint32_t kidlev;
+        };
+        std::vector<Item> st;
+        auto push = [&](const Node& nd) {
+          Item it;
+          it.nd = nd;
+          node_kids(t, nd, it.k);
+          it.j = 0;
+          it.found = false;
+          const NodeGeom q = node_geom(t, nd);
+          it.kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+          st.push_back(it);
+        };
+        push(unpack_node(packed));
+        while (!st.empty()) {
+          Item& it = st.back();
+          if (it.j == it.k.n) {
+            st.pop_back();
+            continue;
+          }
+          const int j = it.j++;
+          const bool coded = it.found || (j + 1 != it.k.n);
+          const bool sig = coded ? in.get(pos++) : true;
+          const bool pixel = it.k.count[j] == 1;
+          if (sig)
+            it.found = true;
+          if (pixel) {
+            const uint32_t ridx = kid_raster(t, it.nd, it.k, j);
+            born[ridx] = (int8_t)p;
+            if (sig) {
+              sigp[ridx] = (int8_t)p;
+              coef[ridx] = init;
+              set_sign(ridx, in.get(pos++));
+            }
+          }
+          else if (sig) {
+            const Node kid = kid_node(it.k, j);
+            push(kid);  // invalidates `it`
+          }
+          else
+            next[it.kidlev].push_back(pack_node(kid_node(it.k, j)));
+        }
+      }
+    }
+    lis.swap(next);
+    if (pos >= avail)
+      break;
+    // ---- D3: refinement, j-th significant pixel (raster order) takes bit pos + j
+    {
+      const uint64_t half = thr / 2;
+      uint64_t j = 0;
+      for (size_t i = 0; i < N && pos + j < avail; i++)
+        if (sigp[i] > p) {
+          const int b = in.get(pos + j);
+          j++;
+          if (thr >= 2)
+            coef[i] = b ? coef[i] + half : coef[i] - half;
+          else if (b)
+            coef[i]++;
+        }
+      pos += j;
+    }
+    if (pos >= avail)
+      break;
+  }
+  return 0;
+}
+
 }  // extern "C"

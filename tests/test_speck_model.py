@@ -71,3 +71,26 @@ def test_model_encoder_sparse_and_zero(oracle, model):
     assert model_encode(model, coef, sign, 0) == oracle.speck3d_encode(coef, sign, 0)
     coef[0, 0, 0] = (1 << 52) + 12345
     assert model_encode(model, coef, sign, 0) == oracle.speck3d_encode(coef, sign, 0)
+
+
+def model_decode(lib, stream, shape):
+    dz, dy, dx = shape
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    coef = np.zeros(shape, dtype=np.uint64)
+    sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+    lib.model_speck3d_decode(buf.ctypes.data, buf.size, (_sz * 3)(dx, dy, dz), coef.ctypes.data,
+                             sign.ctypes.data)
+    return coef, sign
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("budget", [0, 1000, 20000])
+def test_model_decoder_matches_oracle(oracle, model, shape, budget):
+    coef, sign = quantized(oracle, shape, 3000.0)
+    stream = oracle.speck3d_encode(coef, sign, budget)
+    for cut in (len(stream), 9 + (len(stream) - 9) // 2, 9 + (len(stream) - 9) // 7):
+        s = stream[:cut]
+        c0, s0 = oracle.speck3d_decode(s, shape)
+        c1, s1 = model_decode(model, s, shape)
+        assert np.array_equal(c0, c1)
+        assert np.array_equal(s0, s1)
