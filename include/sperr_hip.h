@@ -1,0 +1,105 @@
+/*
+ * sperr_hip.h -- C ABI of libsperr_hip.so, the MI355X (gfx950) SPERR 3D chunk-pipeline engine.
+ *
+ * Two families of entry points:
+ *
+ * 1. Drop-in replacements for the reference's C API (same names, argument meaning, ownership
+ *    and return codes as /root/reference/include/SPERR_C_API.h:106-137,87-92 and
+ *    /root/reference/src/SPERR_C_API.cpp:135-258): host buffers in, malloc'd host buffers out.
+ *    The per-chunk pipeline (conditioner, CDF 9/7 DWT, quantiser, SPECK3D coder, bit packing)
+ *    runs on the GPU; `nthreads` is accepted and ignored (the reference's OpenMP team size,
+ *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate) is implemented; modes 2 and 3 return -1.
+ *
+ * 2. Device-resident entry points (sperrhip_*): the volume and the container stay in HBM, which
+ *    is what bench.py times and what an application that already holds its field on the GPU
+ *    should call.  All pointers marked `d_` are device pointers; `hip_stream` is a hipStream_t
+ *    passed as void* (NULL = the default stream).  Calls are synchronous with respect to the
+ *    host when they return.
+ *
+ * There is no CPU fallback: every entry point returns -1 (and prints the HIP error) when no
+ * gfx950 device or kernel image is available.
+ */
+#ifndef SPERR_HIP_H
+#define SPERR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference-compatible C API (replaces include/SPERR_C_API.h of the reference) ---------- */
+
+/* include/SPERR_C_API.h:106-119 ; returns 0 ok, 1 *dst not NULL, 2 bad parameter, -1 other */
+int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                  size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                  size_t nthreads, void** dst, size_t* dst_len);
+
+/* include/SPERR_C_API.h:129-137 */
+int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
+                    size_t* dimx, size_t* dimy, size_t* dimz, void** dst);
+
+/* include/SPERR_C_API.h:87-92 */
+void sperr_parse_header(const void* src, size_t* dimx, size_t* dimy, size_t* dimz, int* is_float);
+
+/* ---- device-resident API ---------------------------------------------------------------------- */
+
+/* Upper bound of the container size sperrhip_compress_dev can produce (bytes). */
+size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x,
+                                    size_t chunk_y, size_t chunk_z, int mode, double quality);
+
+/* Compress a volume that lives in device memory (x fastest; float if is_float else double) into
+ * a SPERR container written to d_dst (device memory, capacity dst_cap bytes).  *dst_len receives
+ * the container length.  Same modes / return codes as sperr_comp_3d (1 is never returned). */
+int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                          size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                          void* d_dst, size_t dst_cap, size_t* dst_len, void* hip_stream);
+
+/* Decompress a container that lives in device memory into d_dst (device memory holding
+ * dimx*dimy*dimz floats or doubles; query the dims first with sperrhip_parse_header_dev or keep
+ * them from compression).  Returns 0 ok, -1 error. */
+int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float, void* d_dst,
+                            size_t dst_cap_bytes, size_t* dimx, size_t* dimy, size_t* dimz,
+                            void* hip_stream);
+
+/* Reads the container header of a device-resident container. Returns 0 ok. */
+int sperrhip_parse_header_dev(const void* d_src, size_t src_len, size_t* dimx, size_t* dimy,
+                              size_t* dimz, int* is_float, size_t* chunk_x, size_t* chunk_y,
+                              size_t* chunk_z);
+
+/* ---- stage access for parity tests (device pointers; one chunk = the whole array) ------------- */
+
+/* In-place forward / inverse CDF 9/7 3D transform of dimx*dimy*dimz doubles. */
+int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, int inverse,
+                       void* hip_stream);
+
+/* SPECK3D-encode one chunk of already quantised coefficients.  width is 4 or 8 (bytes per
+ * magnitude); d_sign holds (n+63)/64 words, bit i set = non-negative.  budget_bits 0 = unlimited.
+ * The 9-byte-header stream is written to d_dst; *dst_len receives its length. */
+int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d_sign, size_t dimx,
+                                size_t dimy, size_t dimz, size_t budget_bits, void* d_dst,
+                                size_t dst_cap, size_t* dst_len, void* hip_stream);
+
+/* Inverse of the above: d_coef (width 4 if the header says <= 32 planes, else 8) and d_sign are
+ * outputs. *width_out receives the width that was written. */
+int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t dimx, size_t dimy,
+                                size_t dimz, void* d_coef, uint64_t* d_sign, int* width_out,
+                                void* hip_stream);
+
+/* ---- profiling ------------------------------------------------------------------------------ */
+
+/* When enabled, the engine brackets every pipeline stage with HIP events on the launch stream
+ * and accumulates their durations. */
+void sperrhip_profile_enable(int on);
+void sperrhip_profile_reset(void);
+/* Fills up to `cap` entries; returns the number of stages. names[i] points to a static string. */
+int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap);
+
+/* Library/engine identification, e.g. "sperr_hip 0.1 (gfx950)". */
+const char* sperrhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,230 @@
+"""Python binding of libsperr_hip.so (ctypes) -- plumbing for tests and bench.py.
+
+torch is used only for device memory, streams and (in bench.py) torch.distributed; the compute
+path is the C-ABI library declared in include/sperr_hip.h.  There is no CPU fallback: importing
+works anywhere, but every call needs a GPU and raises if the library is missing or a call fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsperr_hip.so")
+_sz, _vp = C.c_size_t, C.c_void_p
+
+# every symbol include/sperr_hip.h declares
+EXPORTS = [
+    "sperr_comp_3d", "sperr_decomp_3d", "sperr_parse_header",
+    "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
+    "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
+    "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
+    "sperrhip_profile_get", "sperrhip_version",
+]
+
+
+class SperrHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise SperrHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.sperr_comp_3d.restype = C.c_int
+    lib.sperr_comp_3d.argtypes = [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_double,
+                                  _sz, C.POINTER(_vp), C.POINTER(_sz)]
+    lib.sperr_decomp_3d.restype = C.c_int
+    lib.sperr_decomp_3d.argtypes = [_vp, _sz, C.c_int, _sz, C.POINTER(_sz), C.POINTER(_sz),
+                                    C.POINTER(_sz), C.POINTER(_vp)]
+    lib.sperr_parse_header.restype = None
+    lib.sperr_parse_header.argtypes = [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz),
+                                       C.POINTER(C.c_int)]
+    lib.sperrhip_max_compressed_size.restype = _sz
+    lib.sperrhip_max_compressed_size.argtypes = [_sz] * 6 + [C.c_int, C.c_double]
+    lib.sperrhip_compress_dev.restype = C.c_int
+    lib.sperrhip_compress_dev.argtypes = [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int,
+                                          C.c_double, _vp, _sz, C.POINTER(_sz), _vp]
+    lib.sperrhip_decompress_dev.restype = C.c_int
+    lib.sperrhip_decompress_dev.argtypes = [_vp, _sz, C.c_int, _vp, _sz, C.POINTER(_sz),
+                                            C.POINTER(_sz), C.POINTER(_sz), _vp]
+    lib.sperrhip_parse_header_dev.restype = C.c_int
+    lib.sperrhip_parse_header_dev.argtypes = [_vp, _sz] + [C.POINTER(_sz)] * 3 + \
+        [C.POINTER(C.c_int)] + [C.POINTER(_sz)] * 3
+    lib.sperrhip_dwt3d_dev.restype = C.c_int
+    lib.sperrhip_dwt3d_dev.argtypes = [_vp, _sz, _sz, _sz, C.c_int, _vp]
+    lib.sperrhip_speck3d_encode_dev.restype = C.c_int
+    lib.sperrhip_speck3d_encode_dev.argtypes = [_vp, C.c_int, _vp, _sz, _sz, _sz, _sz, _vp, _sz,
+                                                C.POINTER(_sz), _vp]
+    lib.sperrhip_speck3d_decode_dev.restype = C.c_int
+    lib.sperrhip_speck3d_decode_dev.argtypes = [_vp, _sz, _sz, _sz, _sz, _vp, _vp,
+                                                C.POINTER(C.c_int), _vp]
+    lib.sperrhip_profile_enable.argtypes = [C.c_int]
+    lib.sperrhip_profile_get.restype = C.c_int
+    lib.sperrhip_profile_get.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int), C.c_int]
+    lib.sperrhip_version.restype = C.c_char_p
+    return lib
+
+
+class SperrHip:
+    """Device-resident SPERR 3D compressor / decompressor (fixed-rate mode)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise SperrHipError("no GPU visible: libsperr_hip has no CPU fallback")
+        self._libc = C.CDLL(None)
+        self._libc.free.argtypes = [_vp]
+
+    def _stream(self):
+        return _vp(self.torch.cuda.current_stream().cuda_stream)
+
+    # ---- device-resident API -------------------------------------------------------------
+    def max_compressed_size(self, shape_zyx, chunks_xyz, bpp):
+        dz, dy, dx = shape_zyx
+        return self.lib.sperrhip_max_compressed_size(dx, dy, dz, *chunks_xyz, 1, bpp)
+
+    def compress(self, vol, chunks_xyz, bpp, out=None, mode=1):
+        """vol: cuda tensor float32/float64 shaped (z, y, x). Returns a cuda uint8 tensor view of
+        the container (a slice of `out` when given)."""
+        torch = self.torch
+        assert vol.is_cuda and vol.is_contiguous() and vol.dim() == 3
+        assert vol.dtype in (torch.float32, torch.float64)
+        dz, dy, dx = vol.shape
+        cap = self.max_compressed_size(vol.shape, chunks_xyz, bpp)
+        if out is None or out.numel() < cap:
+            out = torch.empty(cap, dtype=torch.uint8, device=vol.device)
+        n = _sz(0)
+        rtn = self.lib.sperrhip_compress_dev(vol.data_ptr(), int(vol.dtype == torch.float32), dx,
+                                             dy, dz, *chunks_xyz, mode, float(bpp), out.data_ptr(),
+                                             out.numel(), C.byref(n), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_compress_dev returned {rtn}")
+        return out[:n.value]
+
+    def parse_header(self, container):
+        d = [_sz(0) for _ in range(6)]
+        isf = C.c_int(0)
+        rtn = self.lib.sperrhip_parse_header_dev(container.data_ptr(), container.numel(),
+                                                 C.byref(d[0]), C.byref(d[1]), C.byref(d[2]),
+                                                 C.byref(isf), C.byref(d[3]), C.byref(d[4]),
+                                                 C.byref(d[5]))
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_parse_header_dev returned {rtn}")
+        return (d[2].value, d[1].value, d[0].value), bool(isf.value), \
+               (d[3].value, d[4].value, d[5].value)
+
+    def decompress(self, container, output_float=True, out=None, shape_zyx=None):
+        torch = self.torch
+        assert container.is_cuda and container.dtype == torch.uint8 and container.is_contiguous()
+        if shape_zyx is None:
+            shape_zyx, _, _ = self.parse_header(container)
+        dt = torch.float32 if output_float else torch.float64
+        if out is None:
+            out = torch.empty(shape_zyx, dtype=dt, device=container.device)
+        assert out.dtype == dt and out.is_contiguous()
+        dx, dy, dz = _sz(0), _sz(0), _sz(0)
+        rtn = self.lib.sperrhip_decompress_dev(container.data_ptr(), container.numel(),
+                                               int(output_float), out.data_ptr(),
+                                               out.numel() * out.element_size(), C.byref(dx),
+                                               C.byref(dy), C.byref(dz), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decompress_dev returned {rtn}")
+        return out
+
+    # ---- stage access ----------------------------------------------------------------------
+    def dwt3d(self, vals, inverse=False):
+        """In-place on a contiguous cuda float64 tensor shaped (z, y, x)."""
+        torch = self.torch
+        assert vals.is_cuda and vals.dtype == torch.float64 and vals.is_contiguous()
+        dz, dy, dx = vals.shape
+        rtn = self.lib.sperrhip_dwt3d_dev(vals.data_ptr(), dx, dy, dz, int(inverse), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_dwt3d_dev returned {rtn}")
+        return vals
+
+    def speck3d_encode(self, coef, sign, budget_bits=0):
+        """coef: cuda int32 (uint32 bits) or int64 (uint64 bits) tensor (z, y, x); sign: cuda int64
+        tensor of (n+63)//64 words. Returns the stream as bytes."""
+        torch = self.torch
+        assert coef.is_cuda and coef.is_contiguous() and sign.is_cuda
+        width = coef.element_size()
+        dz, dy, dx = coef.shape
+        n = coef.numel()
+        cap = 9 + (budget_bits + 7) // 8 + 64 if budget_bits else 9 + 70 * n // 8 + 4096
+        out = torch.empty(cap, dtype=torch.uint8, device=coef.device)
+        ln = _sz(0)
+        rtn = self.lib.sperrhip_speck3d_encode_dev(coef.data_ptr(), width, sign.data_ptr(), dx, dy,
+                                                   dz, budget_bits, out.data_ptr(), cap,
+                                                   C.byref(ln), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_speck3d_encode_dev returned {rtn}")
+        return bytes(out[:ln.value].cpu().numpy())
+
+    def speck3d_decode(self, stream, shape_zyx):
+        """Returns (coef uint64 numpy (z,y,x), sign uint64 numpy words)."""
+        torch = self.torch
+        dz, dy, dx = shape_zyx
+        n = dz * dy * dx
+        s = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+        coef = torch.zeros(n, dtype=torch.int64, device="cuda")
+        sign = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        w = C.c_int(0)
+        rtn = self.lib.sperrhip_speck3d_decode_dev(s.data_ptr(), s.numel(), dx, dy, dz,
+                                                   coef.data_ptr(), sign.data_ptr(), C.byref(w),
+                                                   self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_speck3d_decode_dev returned {rtn}")
+        raw = coef.cpu().numpy()
+        if w.value == 4:
+            c = raw.view(np.uint32)[:n].astype(np.uint64)
+        else:
+            c = raw.view(np.uint64)
+        return c.reshape(shape_zyx), sign.cpu().numpy().view(np.uint64)
+
+    # ---- reference-compatible host API (include/sperr_hip.h) ------------------------------
+    def comp_3d(self, vol, chunks_xyz, mode, quality, nthreads=0):
+        vol = np.ascontiguousarray(vol)
+        dz, dy, dx = vol.shape
+        dst, n = _vp(None), _sz(0)
+        rtn = self.lib.sperr_comp_3d(vol.ctypes.data, int(vol.dtype == np.float32), dx, dy, dz,
+                                     *chunks_xyz, mode, quality, nthreads, C.byref(dst),
+                                     C.byref(n))
+        if rtn != 0:
+            raise SperrHipError(f"sperr_comp_3d returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def decomp_3d(self, stream, output_float=True, nthreads=0):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dst = _vp(None)
+        dx, dy, dz = _sz(0), _sz(0), _sz(0)
+        rtn = self.lib.sperr_decomp_3d(buf.ctypes.data, buf.size, int(output_float), nthreads,
+                                       C.byref(dx), C.byref(dy), C.byref(dz), C.byref(dst))
+        if rtn != 0:
+            raise SperrHipError(f"sperr_decomp_3d returned {rtn}")
+        n = dx.value * dy.value * dz.value
+        dt = np.float32 if output_float else np.float64
+        out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        self._libc.free(dst)
+        return out.reshape(dz.value, dy.value, dx.value)
+
+    # ---- profiling ------------------------------------------------------------------------
+    def profile(self, on=True):
+        self.lib.sperrhip_profile_enable(int(on))
+        if on:
+            self.lib.sperrhip_profile_reset()
+
+    def profile_report(self):
+        cap = 128
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int * cap)()
+        n = self.lib.sperrhip_profile_get(names, ms, cnt, cap)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}

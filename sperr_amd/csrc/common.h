@@ -1,0 +1,154 @@
+// common.h -- shared declarations of the HIP engine (device state structs, launch helpers).
+#ifndef SPERR_AMD_COMMON_H
+#define SPERR_AMD_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "speck_tree.h"
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fprintf(stderr, "[sperr_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),    \
+              __FILE__, __LINE__);                                                            \
+      return -1;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+namespace sperrhip {
+
+// per-kernel profiling hooks (engine.hip): no-ops unless sperrhip_profile_enable(1)
+void prof_begin(const char* name, hipStream_t stream);
+void prof_end(hipStream_t stream);
+#define LAUNCH_K(kern, grid, block, smem, stream, ...)                \
+  do {                                                                \
+    ::sperrhip::prof_begin(#kern, stream);                            \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__); \
+    ::sperrhip::prof_end(stream);                                     \
+  } while (0)
+
+constexpr int kMaxPlanes = 64;     // bit planes of a uint64 coefficient
+constexpr int kPixTile = 1024;     // samples per pixel-pass tile (256 threads x 4)
+constexpr int kListTile = 1024;    // list entries per list-pass tile (256 threads x 4)
+constexpr int kThreads = 256;
+
+// ---- geometry of one batch: `nchunks` chunks of identical dims cut from one volume ------------
+struct ChunkGeom {         // one entry per chunk of the batch (device array)
+  uint32_t org[3];         // origin inside the volume
+};
+
+struct VolDesc {
+  uint64_t dims[3];        // volume dims (x fastest)
+};
+
+// ---- per-chunk state, device resident -----------------------------------------------------------
+struct PlaneRec {
+  uint64_t baseLIP, baseLIS, baseREF;
+  uint32_t didSort, didREF;
+};
+
+// results of the float stages + what the container needs to know about the chunk
+struct CoderState {
+  double mean;                   // or the constant value of a constant chunk
+  double q;
+  double maxabs;                 // max |coefficient| after the DWT (bits compared as uint64)
+  uint32_t is_const;             // constant field (src/Conditioner.cpp:28-44)
+  uint32_t not_const_flag;       // scratch for the constant test
+  uint32_t wide;                 // coefficients are uint64 (high-precision retry / >32 planes)
+  uint32_t need_retry;           // fixed-rate stream too short at 32 planes (SPECK_FLT.cpp:530-538)
+  int32_t nbp;                   // SPECK header: number of bit planes
+  uint32_t pad;
+  uint64_t total_bits;           // SPECK header: bits of the complete stream
+  uint64_t stream_len;           // bytes of this chunk's stream (17 or 17 + 9 + payload)
+  uint64_t stream_off;           // byte offset of the chunk stream inside the container
+};
+
+// encoder internals
+struct EncState {
+  uint32_t active;               // this chunk takes part in the current encode pass
+  int32_t nbp;                   // number of bit planes
+  int32_t done;                  // budget reached / all planes coded
+  int32_t plast;                 // lowest plane whose sorting pass ran
+  uint32_t bornCount;            // newborn insignificant sets of the current plane
+  uint32_t cur;                  // which of the two list buffers is current
+  uint64_t pos;                  // running bit position
+  uint64_t total_bits;
+  uint64_t budget;               // rounded up to a multiple of 8, or ~0
+  uint64_t lisBits;              // bits of the current LIS phase
+  PlaneRec rec[kMaxPlanes];
+  uint64_t lipTot[kMaxPlanes], refTot[kMaxPlanes];
+  uint32_t listLen[2][spk::kMaxLevels];
+  uint32_t bornTot[spk::kMaxLevels];
+};
+
+// ---- block-level exclusive scan over kThreads threads ------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane >= d)
+      v += o;
+  }
+  return v;
+}
+
+// returns the exclusive prefix of `v` over the block; *total receives the block sum.
+// `smem` must hold blockDim.x/64 + 1 elements of T.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* smem, T* total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const T inc = wave_inclusive_scan(v);
+  __syncthreads();  // protect smem reuse between consecutive calls
+  if (lane == 63)
+    smem[wave] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+  for (int w = 0; w < nw; w++) {
+    const T s = smem[w];
+    if (w < wave)
+      base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ void atomic_or64(uint64_t* p, uint64_t v)
+{
+  if (v)
+    atomicOr(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+
+// OR `nbits` (<= 64) bits of `val` into a zero-initialised LSB-first bit buffer at `pos`,
+// dropping everything at or past `limit`.
+__device__ __forceinline__ void put_bits(uint64_t* words, uint64_t pos, uint64_t val, int nbits,
+                                         uint64_t limit)
+{
+  if (nbits <= 0 || pos >= limit)
+    return;
+  if (pos + (uint64_t)nbits > limit) {
+    nbits = (int)(limit - pos);
+  }
+  if (nbits < 64)
+    val &= (uint64_t(1) << nbits) - 1;
+  const int sh = (int)(pos & 63);
+  atomic_or64(words + (pos >> 6), val << sh);
+  if (sh && sh + nbits > 64)
+    atomic_or64(words + (pos >> 6) + 1, val >> (64 - sh));
+}
+
+__device__ __forceinline__ int get_bit(const uint64_t* words, uint64_t pos, uint64_t avail)
+{
+  return pos < avail ? (int)((words[pos >> 6] >> (pos & 63)) & 1) : 0;
+}
+
+}  // namespace sperrhip
+
+#endif

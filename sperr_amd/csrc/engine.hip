@@ -1,0 +1,1488 @@
+// engine.hip -- host side of the HIP engine: chunk grid, per-shape plans, batched workspaces,
+// container assembly / parsing, and the C ABI declared in include/sperr_hip.h.
+//
+// Host logic restated from the reference (file:line under /root/reference):
+//   src/sperr_helper.cpp:542-592            chunk_volume (x fastest, short remainders merged)
+//   src/SPERR3D_OMP_C.cpp:23-30,61-141      chunk loop  -> batches of equally shaped chunks
+//   src/SPERR3D_OMP_C.cpp:145-234           container header + concatenated chunk streams
+//   src/SPERR3D_Stream_Tools.cpp:46-105     container header parsing
+//   src/SPERR3D_OMP_D.cpp:23-135            decompress driver
+//   src/SPECK_FLT.cpp:401-541               per-chunk pipeline order and the fixed-rate retry
+//   src/SPERR_C_API.cpp:135-258             C API semantics (ownership, return codes)
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sperr_hip.h"
+#include "speck_dec.h"
+#include "speck_enc.h"
+#include "speck_tree_host.hpp"
+#include "xform.h"
+
+namespace sperrhip {
+
+// ------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct ProfEntry {
+  double ms = 0.0;
+  int launches = 0;
+};
+
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Open {
+    const char* name;
+    hipEvent_t a, b;
+  };
+  std::vector<Open> open;
+  const char* cur = nullptr;
+  hipEvent_t curA = nullptr;
+  std::map<std::string, ProfEntry> acc;
+
+  hipEvent_t get()
+  {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  void collect()
+  {
+    for (auto& o : open) {
+      float ms = 0.f;
+      if (o.a && o.b && hipEventElapsedTime(&ms, o.a, o.b) == hipSuccess) {
+        auto& e = acc[o.name];
+        e.ms += ms;
+        e.launches++;
+      }
+    }
+    open.clear();
+    used = 0;
+  }
+};
+
+Profiler g_prof;
+
+}  // namespace
+
+void prof_begin(const char* name, hipStream_t stream)
+{
+  if (!g_prof.on)
+    return;
+  g_prof.cur = name;
+  g_prof.curA = g_prof.get();
+  if (g_prof.curA)
+    hipEventRecord(g_prof.curA, stream);
+}
+
+void prof_end(hipStream_t stream)
+{
+  if (!g_prof.on || !g_prof.cur)
+    return;
+  hipEvent_t b = g_prof.get();
+  if (b)
+    hipEventRecord(b, stream);
+  g_prof.open.push_back({g_prof.cur, g_prof.curA, b});
+  g_prof.cur = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= n)
+      return 0;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_CHECK(hipMalloc(&p, bytes));
+    n = bytes;
+    return 0;
+  }
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  template <typename T>
+  T* take(size_t count)
+  {
+    const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
+    if (used + bytes > cap)
+      return nullptr;
+    T* r = reinterpret_cast<T*>(base + used);
+    used += bytes;
+    return r;
+  }
+};
+
+size_t round_up(size_t v, size_t m)
+{
+  return (v + m - 1) / m * m;
+}
+
+using Dims = std::array<size_t, 3>;
+
+// src/sperr_helper.cpp:542-592
+std::vector<std::array<size_t, 6>> chunk_volume(const Dims& vol, const Dims& chunk)
+{
+  size_t nseg[3];
+  for (int a = 0; a < 3; a++) {
+    nseg[a] = vol[a] / chunk[a];
+    if (vol[a] % chunk[a] > chunk[a] / 2)
+      nseg[a]++;
+    if (nseg[a] == 0)
+      nseg[a] = 1;
+  }
+  std::vector<std::array<size_t, 6>> out;
+  out.reserve(nseg[0] * nseg[1] * nseg[2]);
+  for (size_t z = 0; z < nseg[2]; z++)
+    for (size_t y = 0; y < nseg[1]; y++)
+      for (size_t x = 0; x < nseg[0]; x++) {
+        const size_t idx[3] = {x, y, z};
+        std::array<size_t, 6> c;
+        for (int a = 0; a < 3; a++) {
+          const size_t beg = idx[a] * chunk[a];
+          const size_t end = (idx[a] + 1 == nseg[a]) ? vol[a] : beg + chunk[a];
+          c[2 * a] = beg;
+          c[2 * a + 1] = end - beg;
+        }
+        out.push_back(c);
+      }
+  return out;
+}
+
+// src/Conditioner.cpp:137-163
+uint32_t condi_num_strides(size_t len)
+{
+  const size_t dflt = 2048;
+  if (len % dflt == 0)
+    return (uint32_t)dflt;
+  for (size_t n = dflt; n <= 32768; n++)
+    if (len % n == 0)
+      return (uint32_t)n;
+  size_t n = dflt;
+  while (len % n != 0)
+    n--;
+  return (uint32_t)n;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-shape plan: tree tables on the device, tile maps, DWT pass list
+// ------------------------------------------------------------------------------------------
+struct LiftPass {
+  int axis;
+  uint32_t region[3];
+};
+
+struct ShapePlan {
+  uint32_t dims[3];
+  uint32_t N = 0;
+  spk::HostTree ht;
+  spk::Tree dtree{};
+  DevBuf tables;
+  const uint64_t* d_initLIS = nullptr;
+  const uint32_t* d_initLen = nullptr;
+  const uint32_t* d_levelOff = nullptr;
+  const uint16_t* d_tileLevel = nullptr;
+  const uint32_t* d_tileStart = nullptr;
+  const uint32_t* d_levelFirstTile = nullptr;
+  const uint32_t* d_levelNumTiles = nullptr;
+  const uint32_t* d_depthBlocks = nullptr;
+  const uint8_t* d_levelSlot = nullptr;
+  const uint8_t* d_slotLevel = nullptr;
+  std::vector<uint32_t> depthBlockOff;
+  uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
+  uint64_t maxPhaseBits = 0;
+  size_t lisEntries = 0;
+  std::vector<LiftPass> fwd;
+};
+
+struct Blob {  // host-side staging of all tables of a plan, uploaded in one copy
+  std::vector<char> bytes;
+  template <typename T>
+  size_t add(const std::vector<T>& v)
+  {
+    const size_t off = round_up(bytes.size(), 256);
+    bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T), 0);
+    if (!v.empty())
+      memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
+int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
+{
+  P.dims[0] = (uint32_t)dx;
+  P.dims[1] = (uint32_t)dy;
+  P.dims[2] = (uint32_t)dz;
+  P.N = (uint32_t)(dx * dy * dz);
+  P.ht = spk::build_tree(dx, dy, dz);
+  const spk::HostTree& h = P.ht;
+  const uint32_t nlev = h.nlevels;
+
+  // LIS storage: level l owns [levelOff[l], levelOff[l+1]); keep room for the roots
+  std::vector<uint32_t> cap(nlev), levelOff(nlev + 1, 0), initLen(nlev);
+  for (uint32_t l = 0; l < nlev; l++) {
+    cap[l] = std::max<uint32_t>(h.levelCap[l], (uint32_t)h.initLIS[l].size());
+    levelOff[l + 1] = levelOff[l] + cap[l];
+    initLen[l] = (uint32_t)h.initLIS[l].size();
+  }
+  P.lisEntries = levelOff[nlev] + 8;
+  std::vector<uint64_t> initLIS(levelOff[nlev] ? levelOff[nlev] : 1, 0);
+  for (uint32_t l = 0; l < nlev; l++)
+    for (size_t k = 0; k < h.initLIS[l].size(); k++)
+      initLIS[levelOff[l] + k] = h.initLIS[l][k];
+
+  // list tiles in traversal order: deepest level first
+  std::vector<uint16_t> tileLevel;
+  std::vector<uint32_t> tileStart, levelFirstTile(nlev, 0), levelNumTiles(nlev, 0);
+  for (uint32_t l = nlev; l-- > 0;) {
+    levelFirstTile[l] = (uint32_t)tileLevel.size();
+    const uint32_t nt = (cap[l] + kListTile - 1) / kListTile;
+    levelNumTiles[l] = nt;
+    for (uint32_t t = 0; t < nt; t++) {
+      tileLevel.push_back((uint16_t)l);
+      tileStart.push_back(t * kListTile);
+    }
+  }
+  P.nListTiles = (uint32_t)tileLevel.size();
+
+  // node blocks grouped by depth
+  std::vector<uint32_t> depthBlocks;
+  P.depthBlockOff.assign(h.maxDepth + 1, 0);
+  for (uint32_t d = 0; d < h.maxDepth; d++) {
+    P.depthBlockOff[d] = (uint32_t)depthBlocks.size();
+    for (uint32_t b = 0; b < h.blockGrid.size(); b++)
+      if (h.grids[h.blockGrid[b]].depth == d)
+        depthBlocks.push_back(b);
+  }
+  P.depthBlockOff[h.maxDepth] = (uint32_t)depthBlocks.size();
+
+  // birth-mask slots: every level that can hold sets
+  std::vector<uint8_t> levelSlot(nlev, 0xff), slotLevel;
+  for (uint32_t l = 0; l < nlev; l++)
+    if (cap[l]) {
+      levelSlot[l] = (uint8_t)slotLevel.size();
+      slotLevel.push_back((uint8_t)l);
+    }
+  P.nSlots = (uint32_t)slotLevel.size();
+  P.maxPhaseBits = (uint64_t)h.nsets + 2ull * P.N + 64;
+  P.nPixTiles = (P.N + kPixTile - 1) / kPixTile;
+  P.nstrides = condi_num_strides(P.N);
+
+  // upload
+  Blob blob;
+  const size_t oRoots = blob.add(h.roots), oGrids = blob.add(h.grids), oTab = blob.add(h.tab),
+               oBG = blob.add(h.blockGrid), oInit = blob.add(initLIS), oInitLen = blob.add(initLen),
+               oLevOff = blob.add(levelOff), oTL = blob.add(tileLevel), oTS = blob.add(tileStart),
+               oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
+               oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel);
+  if (P.tables.ensure(blob.bytes.size()))
+    return -1;
+  HIP_CHECK(hipMemcpy(P.tables.p, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
+  char* base = static_cast<char*>(P.tables.p);
+  P.dtree = h.view();
+  P.dtree.roots = reinterpret_cast<const spk::Root*>(base + oRoots);
+  P.dtree.grids = reinterpret_cast<const spk::Grid*>(base + oGrids);
+  P.dtree.tab = reinterpret_cast<const uint16_t*>(base + oTab);
+  P.dtree.blockGrid = reinterpret_cast<const uint16_t*>(base + oBG);
+  P.d_initLIS = reinterpret_cast<const uint64_t*>(base + oInit);
+  P.d_initLen = reinterpret_cast<const uint32_t*>(base + oInitLen);
+  P.d_levelOff = reinterpret_cast<const uint32_t*>(base + oLevOff);
+  P.d_tileLevel = reinterpret_cast<const uint16_t*>(base + oTL);
+  P.d_tileStart = reinterpret_cast<const uint32_t*>(base + oTS);
+  P.d_levelFirstTile = reinterpret_cast<const uint32_t*>(base + oLFT);
+  P.d_levelNumTiles = reinterpret_cast<const uint32_t*>(base + oLNT);
+  P.d_depthBlocks = reinterpret_cast<const uint32_t*>(base + oDB);
+  P.d_levelSlot = reinterpret_cast<const uint8_t*>(base + oLS);
+  P.d_slotLevel = reinterpret_cast<const uint8_t*>(base + oSL);
+
+  // DWT pass list (src/CDF97.cpp:132-139,170-225,284-292,387-429); the inverse runs it backwards
+  P.fwd.clear();
+  size_t levels = 0;
+  auto approx = [](size_t len, size_t lev) { return (uint32_t)spk::approx_detail_len(len, lev)[0]; };
+  if (spk::can_use_dyadic({dx, dy, dz}, levels)) {
+    for (size_t lev = 0; lev < levels; lev++) {
+      LiftPass ps{0, {approx(dx, lev), approx(dy, lev), approx(dz, lev)}};
+      for (int a = 0; a < 3; a++) {
+        ps.axis = a;
+        P.fwd.push_back(ps);
+      }
+    }
+  }
+  else {
+    const size_t nz = spk::num_of_xforms(dz), nxy = spk::num_of_xforms(std::min(dx, dy));
+    for (size_t lev = 0; lev < nz; lev++)
+      P.fwd.push_back({2, {(uint32_t)dx, (uint32_t)dy, approx(dz, lev)}});
+    for (size_t lev = 0; lev < nxy; lev++) {
+      P.fwd.push_back({0, {approx(dx, lev), approx(dy, lev), (uint32_t)dz}});
+      P.fwd.push_back({1, {approx(dx, lev), approx(dy, lev), (uint32_t)dz}});
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// engine singleton
+// ------------------------------------------------------------------------------------------
+struct Engine {
+  std::mutex mu;
+  bool ready = false;
+  std::map<Dims, std::unique_ptr<ShapePlan>> plans;
+  DevBuf arena, slots, misc;
+  size_t freeMemAtInit = 0;
+
+  int init()
+  {
+    if (ready)
+      return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      fprintf(stderr, "[sperr_hip] no HIP device available; this library has no CPU fallback\n");
+      return -1;
+    }
+    size_t fr = 0, tot = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    freeMemAtInit = fr;
+    ready = true;
+    return 0;
+  }
+
+  ShapePlan* plan(size_t dx, size_t dy, size_t dz)
+  {
+    const Dims key{dx, dy, dz};
+    auto it = plans.find(key);
+    if (it != plans.end())
+      return it->second.get();
+    auto p = std::make_unique<ShapePlan>();
+    if (build_plan(*p, dx, dy, dz))
+      return nullptr;
+    ShapePlan* raw = p.get();
+    plans[key] = std::move(p);
+    return raw;
+  }
+};
+
+Engine g_engine;
+
+// bytes of workspace one chunk of this shape needs
+struct EncSizes {
+  size_t streamWords, maskWords, perChunk;
+};
+
+uint64_t rounded_budget(uint64_t raw)
+{
+  if (raw == 0)
+    return ~0ull;
+  while (raw % 8)
+    raw++;
+  return raw;
+}
+
+uint64_t max_payload_bits(const ShapePlan& P, uint64_t raw_budget)
+{
+  const uint64_t unlimited = 64ull * P.maxPhaseBits;  // every plane, every phase, worst case
+  const uint64_t b = rounded_budget(raw_budget);
+  return std::min(b, unlimited);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels of the container layer
+// ------------------------------------------------------------------------------------------
+
+// chunk stream = conditioner header (17) [+ SPECK header (9) + payload]  (SPECK_FLT.cpp:111-124,
+// Conditioner.cpp:28-63, SPECK_INT.cpp:284-308) written into the chunk's slot
+__global__ void __launch_bounds__(kThreads)
+k_write_slot(const CoderState* cst, const EncState* est, const uint64_t* stream,
+             size_t streamStride, const uint32_t* globalId, uint8_t* slots, const uint64_t* slotOff,
+             uint64_t* lens, uint32_t nvals, int wide_pass)
+{
+  const uint32_t c = blockIdx.y;
+  const CoderState& cs = cst[c];
+  if (cs.is_const ? wide_pass : ((int)cs.wide != wide_pass || (!wide_pass && cs.need_retry)))
+    return;
+  const uint32_t g = globalId[c];
+  uint8_t* out = slots + slotOff[g];
+  const uint64_t len = cs.stream_len;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    lens[g] = len;
+    if (cs.is_const) {
+      out[0] = 0x81;
+      const uint64_t nval = nvals;
+      memcpy(out + 1, &nval, 8);
+      memcpy(out + 9, &cs.mean, 8);
+    }
+    else {
+      out[0] = 0x80;
+      memcpy(out + 1, &cs.mean, 8);
+      memcpy(out + 9, &cs.q, 8);
+      out[17] = (uint8_t)cs.nbp;
+      memcpy(out + 18, &cs.total_bits, 8);
+    }
+  }
+  if (cs.is_const)
+    return;
+  (void)est;
+  const uint64_t payload = len - 26;
+  const uint64_t* w = stream + c * streamStride;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < payload;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    out[26 + i] = (uint8_t)(w[i >> 3] >> (8 * (i & 7)));
+}
+
+// container header (SPERR3D_OMP_C.cpp:163-234) + chunk offsets
+__global__ void k_container_header(uint8_t* dst, const uint64_t* lens, uint64_t* offs,
+                                   uint32_t nchunks, uint32_t vx, uint32_t vy, uint32_t vz,
+                                   uint32_t cx, uint32_t cy, uint32_t cz, int is_float,
+                                   uint64_t* total)
+{
+  if (blockIdx.x || threadIdx.x)
+    return;
+  const bool multi = nchunks > 1;
+  dst[0] = 0;  // SPERR_VERSION_MAJOR (CMakeLists.txt:5)
+  dst[1] = (uint8_t)(0x40 | (is_float ? 0x20 : 0) | (multi ? 0x10 : 0));
+  size_t pos = 2;
+  const uint32_t v3[3] = {vx, vy, vz};
+  memcpy(dst + pos, v3, 12);
+  pos += 12;
+  if (multi) {
+    const uint16_t c3[3] = {(uint16_t)cx, (uint16_t)cy, (uint16_t)cz};
+    memcpy(dst + pos, c3, 6);
+    pos += 6;
+  }
+  uint64_t off = pos + 4ull * nchunks;
+  for (uint32_t i = 0; i < nchunks; i++) {
+    const uint32_t l = (uint32_t)lens[i];
+    memcpy(dst + pos, &l, 4);
+    pos += 4;
+    offs[i] = off;
+    off += lens[i];
+  }
+  *total = off;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_copy_slots(uint8_t* dst, uint64_t dst_cap, const uint8_t* slots, const uint64_t* slotOff,
+             const uint64_t* lens, const uint64_t* offs)
+{
+  const uint32_t g = blockIdx.y;
+  const uint64_t len = lens[g];
+  if (offs[g] + len > dst_cap)
+    return;
+  const uint8_t* in = slots + slotOff[g];
+  uint8_t* out = dst + offs[g];
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
+
+// first 26 bytes of every chunk stream, gathered for the host
+__global__ void k_gather_heads(const uint8_t* container, const uint64_t* offs, const uint64_t* lens,
+                               uint8_t* heads, uint32_t nchunks)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks)
+    return;
+  for (int i = 0; i < 32; i++)
+    heads[c * 32 + i] = (i < 26 && (uint64_t)i < lens[c]) ? container[offs[c] + i] : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// compression
+// ------------------------------------------------------------------------------------------
+struct ChunkRef {
+  uint32_t gid;
+  uint32_t org[3];
+};
+
+struct EncBatchBufs {
+  EncBuffers eb;
+  ChunkGeom* geom;
+  uint32_t* gids;
+  double* vals;
+  size_t valsStride;
+  double* strideMean;
+  size_t strideMeanStride;
+  uint32_t* coef32;
+  int8_t* msb;
+  size_t bytesPerChunk;
+};
+
+// carve the arrays of one batch out of the arena; returns false when it does not fit
+bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, EncBatchBufs& o)
+{
+  const size_t N = P.N, Npad = round_up(N, 256);
+  const size_t nn = P.dtree.nnodes;
+  const uint64_t payloadBits = max_payload_bits(P, raw_budget);
+  const size_t streamWords = (size_t)((payloadBits + 63) / 64) + 4;
+  const uint64_t maskBits = std::min<uint64_t>(P.maxPhaseBits, payloadBits + 64);
+  const size_t maskWords = (size_t)((maskBits + 63) / 64) + 2;
+  EncBuffers& e = o.eb;
+  memset(&e, 0, sizeof(e));
+  e.tree = P.dtree;
+  e.nchunks = B;
+#define TAKE(dst, T, count)            \
+  dst = A.take<T>((size_t)(count));    \
+  if (!dst)                            \
+    return false;
+  TAKE(e.cst, CoderState, B);
+  TAKE(e.st, EncState, B);
+  TAKE(o.geom, ChunkGeom, B);
+  TAKE(o.gids, uint32_t, B);
+  o.valsStride = Npad;
+  TAKE(o.vals, double, Npad * B);
+  o.strideMeanStride = round_up(P.nstrides, 32);
+  TAKE(o.strideMean, double, o.strideMeanStride * B);
+  e.coefStride = Npad;
+  TAKE(o.coef32, uint32_t, Npad * B);
+  e.coef = o.coef32;
+  e.signStride = Npad / 64;
+  uint64_t* sign;
+  TAKE(sign, uint64_t, e.signStride * B);
+  e.sign = sign;
+  e.pixStride = Npad;
+  TAKE(o.msb, int8_t, Npad * B);
+  e.msb = o.msb;
+  TAKE(e.bplane, int8_t, Npad * B);
+  e.nodeStride = nn;
+  TAKE(e.M, int8_t, nn * B);
+  TAKE(e.E, uint32_t, nn * B);
+  TAKE(e.opos, uint64_t, nn * B);
+  e.lisStride = P.lisEntries;
+  TAKE(e.lis[0], uint64_t, P.lisEntries * B);
+  TAKE(e.lis[1], uint64_t, P.lisEntries * B);
+  e.levelOff = P.d_levelOff;
+  e.nListTiles = P.nListTiles;
+  e.tileLevel = P.d_tileLevel;
+  e.tileStart = P.d_tileStart;
+  e.levelFirstTile = P.d_levelFirstTile;
+  e.levelNumTiles = P.d_levelNumTiles;
+  e.tileStride = round_up(P.nListTiles, 32);
+  TAKE(e.tileBits, uint64_t, e.tileStride * B);
+  TAKE(e.tileSurv, uint32_t, e.tileStride * B);
+  TAKE(e.tileBitsOff, uint64_t, e.tileStride * B);
+  TAKE(e.tileSurvOff, uint32_t, e.tileStride * B);
+  e.bornStride = P.ht.nsets + 8;
+  TAKE(e.bornPacked, uint64_t, e.bornStride * B);
+  TAKE(e.bornPosLev, uint64_t, e.bornStride * B);
+  e.levelSlot = P.d_levelSlot;
+  e.slotLevel = P.d_slotLevel;
+  e.nSlots = P.nSlots;
+  e.maskWords = (uint32_t)maskWords;
+  e.maskStride = (size_t)P.nSlots * maskWords;
+  TAKE(e.mask, uint64_t, std::max<size_t>(e.maskStride, 1) * B);
+  TAKE(e.maskPrefix, uint32_t, std::max<size_t>(e.maskStride, 1) * B);
+  e.nPixTiles = P.nPixTiles;
+  e.pixCntStride = (size_t)kMaxPlanes * 2 * P.nPixTiles;
+  TAKE(e.pixCnt, uint32_t, e.pixCntStride * B);
+  TAKE(e.pixOff, uint32_t, e.pixCntStride * B);
+  e.streamStride = streamWords;
+  TAKE(e.stream, uint64_t, streamWords * B);
+#undef TAKE
+  return true;
+}
+
+size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget)
+{
+  Arena probe;
+  probe.base = nullptr;
+  probe.cap = ~size_t(0) / 2;
+  EncBatchBufs tmp;
+  carve_enc(probe, P, 1, raw_budget, tmp);
+  return probe.used;
+}
+
+int reset_enc_pass(hipStream_t st, const EncBatchBufs& bb, uint32_t B)
+{
+  const EncBuffers& e = bb.eb;
+  HIP_CHECK(hipMemsetAsync(e.bplane, 0xff, e.pixStride * B, st));
+  HIP_CHECK(hipMemsetAsync(e.M, 0xff, e.nodeStride * B, st));
+  HIP_CHECK(hipMemsetAsync(e.mask, 0, std::max<size_t>(e.maskStride, 1) * B * sizeof(uint64_t), st));
+  HIP_CHECK(hipMemsetAsync(e.stream, 0, e.streamStride * B * sizeof(uint64_t), st));
+  return 0;
+}
+
+template <typename T>
+int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double bpp,
+                  uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st)
+{
+  Engine& E = g_engine;
+  std::lock_guard<std::mutex> lock(E.mu);
+  if (E.init())
+    return -1;
+  Dims cdim;
+  for (int a = 0; a < 3; a++)  // SPERR3D_OMP_C.cpp:23-30
+    cdim[a] = std::min(std::max<size_t>(1, chunkPref[a]), vol[a]);
+  const auto chunks = chunk_volume(vol, cdim);
+  const uint32_t nchunks = (uint32_t)chunks.size();
+  for (int a = 0; a < 3; a++)
+    if (vol[a] > 0xffffffffull || cdim[a] > 0xffff)
+      return -1;
+
+  // group chunks by shape, keeping chunk order inside a group
+  std::map<Dims, std::vector<ChunkRef>> groups;
+  for (uint32_t i = 0; i < nchunks; i++) {
+    const auto& c = chunks[i];
+    groups[Dims{c[1], c[3], c[5]}].push_back(
+        {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
+  }
+
+  // slots for the finished chunk streams
+  std::vector<uint64_t> slotOff(nchunks + 1, 0);
+  {
+    std::vector<uint64_t> slotLen(nchunks, 0);
+    for (auto& g : groups) {
+      ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+      if (!P)
+        return -1;
+      const uint64_t raw = (uint64_t)(bpp * (double)P->N);
+      const uint64_t len = 26 + (max_payload_bits(*P, raw) + 7) / 8;
+      for (auto& r : g.second)
+        slotLen[r.gid] = round_up(len, 256);
+    }
+    for (uint32_t i = 0; i < nchunks; i++)
+      slotOff[i + 1] = slotOff[i] + slotLen[i];
+  }
+  if (E.slots.ensure(slotOff[nchunks] + 256))
+    return -1;
+  const size_t miscBytes = round_up((size_t)nchunks * 8, 256) * 3 + 256;
+  if (E.misc.ensure(miscBytes))
+    return -1;
+  uint64_t* d_slotOff = reinterpret_cast<uint64_t*>(E.misc.p);
+  uint64_t* d_lens = d_slotOff + round_up(nchunks, 32);
+  uint64_t* d_offs = d_lens + round_up(nchunks, 32);
+  uint64_t* d_total = d_offs + round_up(nchunks, 32);
+  HIP_CHECK(hipMemcpyAsync(d_slotOff, slotOff.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+
+  VolDesc vd{{vol[0], vol[1], vol[2]}};
+  for (auto& g : groups) {
+    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+    const uint64_t raw_budget = (uint64_t)(bpp * (double)P->N);  // SPECK_FLT.cpp:491
+    const size_t per = enc_bytes_per_chunk(*P, raw_budget);
+    size_t fr = 0, tot = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
+    B = std::min<uint32_t>(B, 256);
+    if (E.arena.ensure((size_t)B * per + 4096))
+      return -1;
+    const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
+    for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
+      const uint32_t nb = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
+      Arena A;
+      A.base = static_cast<char*>(E.arena.p);
+      A.cap = E.arena.n;
+      EncBatchBufs bb;
+      if (!carve_enc(A, *P, nb, raw_budget, bb))
+        return -1;
+      EncBuffers& e = bb.eb;
+      std::vector<ChunkGeom> hg(nb);
+      std::vector<uint32_t> hid(nb);
+      for (uint32_t i = 0; i < nb; i++) {
+        const ChunkRef& r = g.second[b0 + i];
+        hid[i] = r.gid;
+        for (int a = 0; a < 3; a++)
+          hg[i].org[a] = r.org[a];
+      }
+      HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(bb.gids, hid.data(), nb * 4, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemsetAsync(e.cst, 0, nb * sizeof(CoderState), st));
+      if (reset_enc_pass(st, bb, nb))
+        return -1;
+
+      // ---- float stages ----
+      if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
+                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst))
+        return -1;
+      for (const LiftPass& ps : P->fwd)
+        if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst))
+          return -1;
+      if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst))
+        return -1;
+      if (launch_quantize(st, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
+                          const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
+        return -1;
+
+      // ---- integer coder, 32-bit coefficients ----
+      EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+      if (launch_speck_encode(st, e, ph, raw_budget, true, false))
+        return -1;
+      const uint32_t wblocks = (uint32_t)std::min<size_t>(4096, (e.streamStride * 8 + kThreads - 1) / kThreads);
+      LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
+               e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
+               d_lens, P->N, 0);
+
+      // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
+      std::vector<CoderState> hc(nb);
+      HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      bool retry = false;
+      for (auto& c : hc)
+        retry |= (c.need_retry != 0);
+      if (retry) {
+        if (launch_make_q_wide(st, nb, e.cst) || reset_enc_pass(st, bb, nb))
+          return -1;
+        // 64-bit magnitudes overwrite the DWT coefficients in place (same element size)
+        if (launch_quantize(st, true, bb.vals, bb.valsStride, nb, P->N, bb.vals, bb.valsStride,
+                            const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
+          return -1;
+        EncBuffers ew = e;
+        ew.coef = bb.vals;
+        ew.coefStride = bb.valsStride;
+        if (launch_speck_encode(st, ew, ph, raw_budget, true, true))
+          return -1;
+        LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
+                 e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
+                 d_lens, P->N, 1);
+      }
+    }
+  }
+
+  // ---- container ----
+  LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_offs, nchunks,
+           (uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2], (uint32_t)cdim[0],
+           (uint32_t)cdim[1], (uint32_t)cdim[2], std::is_same<T, float>::value ? 1 : 0, d_total);
+  LAUNCH_K(k_copy_slots, dim3(1024, nchunks), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap,
+           static_cast<const uint8_t*>(E.slots.p), d_slotOff, d_lens, d_offs);
+  uint64_t total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipGetLastError());
+  g_prof.collect();
+  if (total > dst_cap) {
+    fprintf(stderr, "[sperr_hip] output buffer too small (%zu < %llu)\n", dst_cap,
+            (unsigned long long)total);
+    return -1;
+  }
+  *dst_len = (size_t)total;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// decompression
+// ------------------------------------------------------------------------------------------
+struct ContainerInfo {
+  Dims vol, chunk;
+  bool is_float = false, multi = false;
+  std::vector<uint64_t> off, len;
+};
+
+// SPERR3D_Stream_Tools.cpp:46-105 + the checks of SPERR3D_OMP_D.cpp:23-49
+int parse_container_host(const uint8_t* h, size_t hlen, size_t total_len, ContainerInfo& ci,
+                         size_t* need)
+{
+  if (hlen < 14) {
+    *need = 20;
+    return 1;
+  }
+  if (h[0] != 0 || !(h[1] & 0x40))
+    return -1;  // version mismatch / not 3D
+  ci.is_float = (h[1] & 0x20) != 0;
+  ci.multi = (h[1] & 0x10) != 0;
+  uint32_t v3[3];
+  memcpy(v3, h + 2, 12);
+  ci.vol = {v3[0], v3[1], v3[2]};
+  ci.chunk = ci.vol;
+  size_t pos = 14;
+  if (ci.multi) {
+    if (hlen < 20) {
+      *need = 20;
+      return 1;
+    }
+    uint16_t c3[3];
+    memcpy(c3, h + 14, 6);
+    ci.chunk = {c3[0], c3[1], c3[2]};
+    pos = 20;
+  }
+  for (int a = 0; a < 3; a++)
+    if (ci.vol[a] == 0 || ci.chunk[a] == 0)
+      return -1;
+  const size_t nchunks = chunk_volume(ci.vol, ci.chunk).size();
+  const size_t hdr = pos + 4 * nchunks;
+  if (hlen < hdr) {
+    *need = hdr;
+    return 1;
+  }
+  ci.off.resize(nchunks);
+  ci.len.resize(nchunks);
+  uint64_t off = hdr;
+  for (size_t i = 0; i < nchunks; i++) {
+    uint32_t l;
+    memcpy(&l, h + pos + 4 * i, 4);
+    ci.off[i] = off;
+    ci.len[i] = l;
+    off += l;
+  }
+  if (off != total_len)
+    return -1;  // RTNType::WrongLength
+  return 0;
+}
+
+int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci, hipStream_t st)
+{
+  std::vector<uint8_t> h(std::min<size_t>(src_len, 20));
+  HIP_CHECK(hipMemcpyAsync(h.data(), d_src, h.size(), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  size_t need = 0;
+  int r = parse_container_host(h.data(), h.size(), src_len, ci, &need);
+  if (r == 1) {
+    if (need > src_len)
+      return -1;
+    h.resize(need);
+    HIP_CHECK(hipMemcpyAsync(h.data(), d_src, need, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    r = parse_container_host(h.data(), h.size(), src_len, ci, &need);
+  }
+  return r == 0 ? 0 : -1;
+}
+
+struct DecBatchBufs {
+  DecBuffers db;
+  ChunkGeom* geom;
+  uint64_t *chunkOff, *chunkLen;
+  double* vals;
+  size_t valsStride;
+  uint32_t* coef32;
+};
+
+bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o)
+{
+  const size_t N = P.N, Npad = round_up(N, 256);
+  DecBuffers& d = o.db;
+  memset(&d, 0, sizeof(d));
+  d.tree = P.dtree;
+  d.nchunks = B;
+#define TAKE(dst, T, count)            \
+  dst = A.take<T>((size_t)(count));    \
+  if (!dst)                            \
+    return false;
+  TAKE(d.cst, CoderState, B);
+  TAKE(d.st, DecState, B);
+  TAKE(o.geom, ChunkGeom, B);
+  TAKE(o.chunkOff, uint64_t, B);
+  TAKE(o.chunkLen, uint64_t, B);
+  o.valsStride = Npad;
+  TAKE(o.vals, double, Npad * B);
+  d.coefStride = Npad;
+  TAKE(o.coef32, uint32_t, Npad * B);
+  d.coef = o.coef32;
+  d.signStride = Npad / 64;
+  TAKE(d.sign, uint64_t, d.signStride * B);
+  d.pixStride = Npad;
+  TAKE(d.born, int8_t, Npad * B);
+  TAKE(d.sigp, int8_t, Npad * B);
+  d.lisStride = P.lisEntries;
+  TAKE(d.lis[0], uint64_t, P.lisEntries * B);
+  TAKE(d.lis[1], uint64_t, P.lisEntries * B);
+  d.levelOff = P.d_levelOff;
+  d.nPixTiles = P.nPixTiles;
+  d.tileStride = round_up(P.nPixTiles, 32);
+  TAKE(d.tileLip, uint32_t, d.tileStride * B);
+  TAKE(d.tileRef, uint32_t, d.tileStride * B);
+  TAKE(d.tileLipOff, uint32_t, d.tileStride * B);
+  TAKE(d.tileRefOff, uint32_t, d.tileStride * B);
+  d.candStride = Npad;
+  TAKE(d.cand, uint32_t, Npad * B);
+  d.tokStride = (2 * N + 1 + 63) / 64 + 2;
+  TAKE(d.tokMask, uint64_t, d.tokStride * B);
+  TAKE(d.tokCnt, uint32_t, d.tokStride * B);
+  TAKE(d.tokOff, uint32_t, d.tokStride * B);
+  d.streamStride = (size_t)(maxPayloadBytes / 8) + 4;
+  TAKE(d.stream, uint64_t, d.streamStride * B);
+#undef TAKE
+  return true;
+}
+
+template <typename T>
+int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_cap_vals,
+                    const ContainerInfo& ci, hipStream_t st)
+{
+  Engine& E = g_engine;
+  const auto chunks = chunk_volume(ci.vol, ci.chunk);
+  const uint32_t nchunks = (uint32_t)chunks.size();
+  if (ci.vol[0] * ci.vol[1] * ci.vol[2] > dst_cap_vals)
+    return -1;
+  (void)src_len;
+
+  // chunk heads (flags, number of planes) decide the integer width and the plane count
+  const size_t miscBytes = round_up((size_t)nchunks * 8, 256) * 2 + (size_t)nchunks * 32 + 256;
+  if (E.misc.ensure(miscBytes))
+    return -1;
+  uint64_t* d_off = reinterpret_cast<uint64_t*>(E.misc.p);
+  uint64_t* d_len = d_off + round_up(nchunks, 32);
+  uint8_t* d_heads = reinterpret_cast<uint8_t*>(d_len + round_up(nchunks, 32));
+  HIP_CHECK(hipMemcpyAsync(d_off, ci.off.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(d_len, ci.len.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+  LAUNCH_K(k_gather_heads, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, d_off, d_len,
+           d_heads, nchunks);
+  std::vector<uint8_t> heads((size_t)nchunks * 32);
+  HIP_CHECK(hipMemcpyAsync(heads.data(), d_heads, heads.size(), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+
+  struct Ref {
+    uint32_t gid;
+    uint32_t org[3];
+  };
+  std::map<Dims, std::vector<Ref>> groups;
+  for (uint32_t i = 0; i < nchunks; i++) {
+    const auto& c = chunks[i];
+    groups[Dims{c[1], c[3], c[5]}].push_back({i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
+  }
+
+  VolDesc vd{{ci.vol[0], ci.vol[1], ci.vol[2]}};
+  for (auto& g : groups) {
+    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+    if (!P)
+      return -1;
+    uint64_t maxPayload = 0;
+    for (auto& r : g.second)
+      maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
+    Arena probe;
+    probe.cap = ~size_t(0) / 2;
+    DecBatchBufs tmp;
+    carve_dec(probe, *P, 1, maxPayload, tmp);
+    const size_t per = probe.used;
+    size_t fr = 0, tot = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
+    B = std::min<uint32_t>(B, 256);
+    if (E.arena.ensure((size_t)B * per + 4096))
+      return -1;
+    const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
+    for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
+      const uint32_t nb = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
+      Arena A;
+      A.base = static_cast<char*>(E.arena.p);
+      A.cap = E.arena.n;
+      DecBatchBufs bb;
+      if (!carve_dec(A, *P, nb, maxPayload, bb))
+        return -1;
+      DecBuffers& d = bb.db;
+      std::vector<ChunkGeom> hg(nb);
+      std::vector<uint64_t> ho(nb), hl(nb);
+      int maxNarrow = 0, maxWide = 0;
+      for (uint32_t i = 0; i < nb; i++) {
+        const Ref& r = g.second[b0 + i];
+        for (int a = 0; a < 3; a++)
+          hg[i].org[a] = r.org[a];
+        ho[i] = ci.off[r.gid];
+        hl[i] = ci.len[r.gid];
+        const uint8_t* hd = heads.data() + (size_t)r.gid * 32;
+        if (hl[i] >= 26 && !(hd[0] & 0x01)) {
+          const int nbp = hd[17];
+          if (nbp > 32)
+            maxWide = std::max(maxWide, nbp);
+          else
+            maxNarrow = std::max(maxNarrow, nbp);
+        }
+      }
+      if (maxWide > kMaxPlanes)
+        return -1;
+      HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(bb.chunkOff, ho.data(), nb * 8, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(bb.chunkLen, hl.data(), nb * 8, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), st));
+      HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), st));
+      DecPlanHost ph{P->d_initLIS, P->d_initLen};
+      // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
+      // buffer, which the 32-bit pass then fills for the remaining chunks
+      for (int wide = 1; wide >= 0; wide--) {
+        if (wide && maxWide == 0)
+          continue;
+        HIP_CHECK(hipMemsetAsync(d.born, 0xff, d.pixStride * nb, st));
+        HIP_CHECK(hipMemsetAsync(d.sigp, 0xff, d.pixStride * nb, st));
+        HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, st));
+        HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, st));
+        DecBuffers dw = d;
+        if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
+          dw.coef = bb.vals;
+          dw.coefStride = bb.valsStride;
+          HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, st));
+        }
+        else
+          HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, st));
+        // the header kernel must run even when no plane does (constant / all-zero chunks)
+        if (launch_speck_decode(st, dw, ph, d_src, bb.chunkOff, bb.chunkLen, wide != 0,
+                                wide ? maxWide : maxNarrow))
+          return -1;
+        if (launch_inv_quantize(st, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
+                                P->N, bb.vals, bb.valsStride, d.cst))
+          return -1;
+      }
+      for (size_t k = P->fwd.size(); k-- > 0;) {
+        const LiftPass& ps = P->fwd[k];
+        if (launch_lift(st, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst))
+          return -1;
+      }
+      if (launch_scatter<T>(st, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
+        return -1;
+      // stream errors (wrong lengths) surface here
+      std::vector<DecState> hs(nb);
+      HIP_CHECK(hipMemcpyAsync(hs.data(), d.st, nb * sizeof(DecState), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (auto& s : hs)
+        if (s.error)
+          return -1;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipGetLastError());
+  g_prof.collect();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// stage access (parity tests): helpers
+// ------------------------------------------------------------------------------------------
+template <typename CT>
+__global__ void k_msb_of(const CT* coef, int8_t* msb, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const unsigned long long v = coef[i];
+  msb[i] = v ? (int8_t)(63 - __clzll((long long)v)) : (int8_t)-1;
+}
+
+// {u8 planes, u64 total_bits, payload} (SPECK_INT.cpp:284-308)
+__global__ void __launch_bounds__(kThreads)
+k_speck_stream_out(const CoderState* cst, const uint64_t* stream, uint8_t* dst, uint64_t cap,
+                   uint64_t* len_out)
+{
+  const CoderState& cs = cst[0];
+  const uint64_t len = cs.stream_len - 17;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    *len_out = len;
+  if (len > cap)
+    return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dst[0] = (uint8_t)cs.nbp;
+    memcpy(dst + 1, &cs.total_bits, 8);
+  }
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 9 < len;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    dst[9 + i] = (uint8_t)(stream[i >> 3] >> (8 * (i & 7)));
+}
+
+__global__ void k_fake_condi_header(uint8_t* dst)
+{
+  if (threadIdx.x || blockIdx.x)
+    return;
+  const double zero = 0.0, one = 1.0;
+  dst[0] = 0x80;
+  memcpy(dst + 1, &zero, 8);
+  memcpy(dst + 9, &one, 8);
+}
+
+}  // namespace
+}  // namespace sperrhip
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace sperrhip;
+
+extern "C" {
+
+const char* sperrhip_version(void)
+{
+  return "sperr_hip 0.1 (gfx950; SPERR bitstream major version 0)";
+}
+
+void sperrhip_profile_enable(int on)
+{
+  g_prof.on = on != 0;
+}
+void sperrhip_profile_reset(void)
+{
+  g_prof.acc.clear();
+}
+int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap)
+{
+  int i = 0;
+  for (auto& kv : g_prof.acc) {
+    if (i < cap) {
+      names[i] = kv.first.c_str();
+      millis[i] = kv.second.ms;
+      launches[i] = kv.second.launches;
+    }
+    i++;
+  }
+  return i;
+}
+
+size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x,
+                                    size_t chunk_y, size_t chunk_z, int mode, double quality)
+{
+  (void)mode;
+  const Dims vol{dimx, dimy, dimz};
+  Dims cd{chunk_x, chunk_y, chunk_z};
+  for (int a = 0; a < 3; a++)
+    cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
+  const auto chunks = chunk_volume(vol, cd);
+  size_t total = 20 + 4 * chunks.size();
+  for (auto& c : chunks) {
+    const double n = (double)(c[1] * c[3] * c[5]);
+    const uint64_t raw = (uint64_t)(quality * n);
+    const uint64_t bits = raw ? rounded_budget(raw) : (uint64_t)(64.0 * 3.5 * n);
+    total += 26 + (bits + 7) / 8 + 8;
+  }
+  return total;
+}
+
+int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                          size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                          void* d_dst, size_t dst_cap, size_t* dst_len, void* hip_stream)
+{
+  if (quality <= 0.0)
+    return 2;
+  if (mode == 2 || mode == 3) {
+    fprintf(stderr, "[sperr_hip] mode %d (PSNR / PWE) is not implemented on the GPU path yet\n",
+            mode);
+    return -1;
+  }
+  if (mode != 1)
+    return 2;
+  if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
+    return -1;
+  const Dims vol{dimx, dimy, dimz}, ch{chunk_x, chunk_y, chunk_z};
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (is_float)
+    return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, quality,
+                                static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
+  return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, quality,
+                               static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
+}
+
+int sperrhip_parse_header_dev(const void* d_src, size_t src_len, size_t* dimx, size_t* dimy,
+                              size_t* dimz, int* is_float, size_t* chunk_x, size_t* chunk_y,
+                              size_t* chunk_z)
+{
+  std::lock_guard<std::mutex> lock(g_engine.mu);
+  if (g_engine.init())
+    return -1;
+  ContainerInfo ci;
+  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, nullptr))
+    return -1;
+  *dimx = ci.vol[0];
+  *dimy = ci.vol[1];
+  *dimz = ci.vol[2];
+  *is_float = ci.is_float ? 1 : 0;
+  if (chunk_x)
+    *chunk_x = ci.chunk[0];
+  if (chunk_y)
+    *chunk_y = ci.chunk[1];
+  if (chunk_z)
+    *chunk_z = ci.chunk[2];
+  return 0;
+}
+
+int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float, void* d_dst,
+                            size_t dst_cap_bytes, size_t* dimx, size_t* dimy, size_t* dimz,
+                            void* hip_stream)
+{
+  if (!d_src || !d_dst)
+    return -1;
+  std::lock_guard<std::mutex> lock(g_engine.mu);
+  if (g_engine.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ContainerInfo ci;
+  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
+    return -1;
+  if (dimx)
+    *dimx = ci.vol[0];
+  if (dimy)
+    *dimy = ci.vol[1];
+  if (dimz)
+    *dimz = ci.vol[2];
+  if (output_float)
+    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st);
+  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
+                                 st);
+}
+
+// ---- stage access for parity tests -----------------------------------------------------------
+
+int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, int inverse,
+                       void* hip_stream)
+{
+  Engine& E = g_engine;
+  std::lock_guard<std::mutex> lock(E.mu);
+  if (E.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ShapePlan* P = E.plan(dimx, dimy, dimz);
+  if (!P || E.misc.ensure(4096))
+    return -1;
+  CoderState* cst = static_cast<CoderState*>(E.misc.p);
+  HIP_CHECK(hipMemsetAsync(cst, 0, sizeof(CoderState), st));
+  const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
+  if (!inverse) {
+    for (const LiftPass& ps : P->fwd)
+      if (launch_lift(st, true, d_vals, P->N, 1, cd, ps.axis, ps.region, cst))
+        return -1;
+  }
+  else {
+    for (size_t k = P->fwd.size(); k-- > 0;)
+      if (launch_lift(st, false, d_vals, P->N, 1, cd, P->fwd[k].axis, P->fwd[k].region, cst))
+        return -1;
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  g_prof.collect();
+  return 0;
+}
+
+int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d_sign, size_t dimx,
+                                size_t dimy, size_t dimz, size_t budget_bits, void* d_dst,
+                                size_t dst_cap, size_t* dst_len, void* hip_stream)
+{
+  if (width != 4 && width != 8)
+    return 2;
+  Engine& E = g_engine;
+  std::lock_guard<std::mutex> lock(E.mu);
+  if (E.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ShapePlan* P = E.plan(dimx, dimy, dimz);
+  if (!P)
+    return -1;
+  const uint64_t raw_budget = budget_bits;
+  if (E.arena.ensure(enc_bytes_per_chunk(*P, raw_budget) + 4096) || E.misc.ensure(4096))
+    return -1;
+  Arena A;
+  A.base = static_cast<char*>(E.arena.p);
+  A.cap = E.arena.n;
+  EncBatchBufs bb;
+  if (!carve_enc(A, *P, 1, raw_budget, bb))
+    return -1;
+  EncBuffers e = bb.eb;
+  HIP_CHECK(hipMemsetAsync(e.cst, 0, sizeof(CoderState), st));
+  if (reset_enc_pass(st, bb, 1))
+    return -1;
+  const bool wide = width == 8;
+  const uint32_t n = P->N;
+  HIP_CHECK(hipMemcpyAsync(const_cast<uint64_t*>(e.sign), d_sign, ((n + 63) / 64) * 8,
+                           hipMemcpyDeviceToDevice, st));
+  if (wide) {
+    HIP_CHECK(hipMemcpyAsync(bb.vals, d_coef, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    e.coef = bb.vals;
+    e.coefStride = bb.valsStride;
+    LAUNCH_K(k_msb_of<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, st,
+             reinterpret_cast<const uint64_t*>(bb.vals), bb.msb, n);
+  }
+  else {
+    HIP_CHECK(hipMemcpyAsync(bb.coef32, d_coef, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    LAUNCH_K(k_msb_of<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, st,
+             reinterpret_cast<const uint32_t*>(bb.coef32), bb.msb, n);
+  }
+  EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+  if (launch_speck_encode(st, e, ph, raw_budget, false, wide))
+    return -1;
+  uint64_t* d_len = static_cast<uint64_t*>(E.misc.p);
+  LAUNCH_K(k_speck_stream_out, dim3(1024), dim3(kThreads), 0, st, e.cst, e.stream,
+           static_cast<uint8_t*>(d_dst), (uint64_t)dst_cap, d_len);
+  uint64_t len = 0;
+  HIP_CHECK(hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipGetLastError());
+  g_prof.collect();
+  if (len > dst_cap)
+    return -1;
+  *dst_len = (size_t)len;
+  return 0;
+}
+
+int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t dimx, size_t dimy,
+                                size_t dimz, void* d_coef, uint64_t* d_sign, int* width_out,
+                                void* hip_stream)
+{
+  if (stream_len < 9)
+    return -1;
+  Engine& E = g_engine;
+  std::lock_guard<std::mutex> lock(E.mu);
+  if (E.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ShapePlan* P = E.plan(dimx, dimy, dimz);
+  if (!P)
+    return -1;
+  uint8_t head[9];
+  HIP_CHECK(hipMemcpyAsync(head, d_stream, 9, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  const int nbp = head[0];
+  const bool wide = nbp > 32;
+  if (nbp > kMaxPlanes)
+    return -1;
+  // wrap the bare SPECK stream into a chunk stream with a dummy conditioner header
+  if (E.misc.ensure(round_up(17 + stream_len + 64, 256)))
+    return -1;
+  uint8_t* wrap = static_cast<uint8_t*>(E.misc.p);
+  LAUNCH_K(k_fake_condi_header, dim3(1), dim3(1), 0, st, wrap);
+  HIP_CHECK(hipMemcpyAsync(wrap + 17, d_stream, stream_len, hipMemcpyDeviceToDevice, st));
+  Arena probe;
+  probe.cap = ~size_t(0) / 2;
+  DecBatchBufs tmp;
+  carve_dec(probe, *P, 1, 17 + stream_len, tmp);
+  if (E.arena.ensure(probe.used + 4096))
+    return -1;
+  Arena A;
+  A.base = static_cast<char*>(E.arena.p);
+  A.cap = E.arena.n;
+  DecBatchBufs bb;
+  if (!carve_dec(A, *P, 1, 17 + stream_len, bb))
+    return -1;
+  DecBuffers d = bb.db;
+  const uint64_t off = 0, len = 17 + stream_len;
+  HIP_CHECK(hipMemcpyAsync(bb.chunkOff, &off, 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(bb.chunkLen, &len, 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(d.cst, 0, sizeof(CoderState), st));
+  HIP_CHECK(hipMemsetAsync(d.st, 0, sizeof(DecState), st));
+  HIP_CHECK(hipMemsetAsync(d.born, 0xff, d.pixStride, st));
+  HIP_CHECK(hipMemsetAsync(d.sigp, 0xff, d.pixStride, st));
+  HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
+  const uint32_t n = P->N;
+  if (wide) {
+    d.coef = bb.vals;
+    d.coefStride = bb.valsStride;
+    HIP_CHECK(hipMemsetAsync(bb.vals, 0, (size_t)n * 8, st));
+  }
+  else
+    HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
+  DecPlanHost ph{P->d_initLIS, P->d_initLen};
+  if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
+    return -1;
+  HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(d_sign, d.sign, ((n + 63) / 64) * 8, hipMemcpyDeviceToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipGetLastError());
+  g_prof.collect();
+  *width_out = wide ? 8 : 4;
+  return 0;
+}
+
+// ---- reference-compatible host API (src/SPERR_C_API.cpp:135-258) ---------------------------
+
+void sperr_parse_header(const void* src, size_t* dimx, size_t* dimy, size_t* dimz, int* is_float)
+{
+  const uint8_t* p = static_cast<const uint8_t*>(src);
+  const bool is_3d = (p[1] & 0x40) != 0;
+  *is_float = (p[1] & 0x20) ? 1 : 0;
+  uint32_t d[3] = {1, 1, 1};
+  memcpy(d, p + 2, is_3d ? 12 : 8);
+  *dimx = d[0];
+  *dimy = d[1];
+  *dimz = d[2];
+}
+
+int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                  size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                  size_t nthreads, void** dst, size_t* dst_len)
+{
+  (void)nthreads;
+  if (*dst != nullptr)
+    return 1;
+  if (quality <= 0.0)
+    return 2;
+  if (mode < 1 || mode > 3)
+    return 2;
+  const size_t n = dimx * dimy * dimz;
+  const size_t esz = is_float ? 4 : 8;
+  const size_t cap = sperrhip_max_compressed_size(dimx, dimy, dimz, chunk_x, chunk_y, chunk_z,
+                                                  mode, quality);
+  void *d_in = nullptr, *d_out = nullptr;
+  if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
+    fprintf(stderr, "[sperr_hip] device allocation failed\n");
+    if (d_in)
+      (void)hipFree(d_in);
+    return -1;
+  }
+  int rtn = -1;
+  size_t len = 0;
+  if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
+    rtn = sperrhip_compress_dev(d_in, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode,
+                                quality, d_out, cap, &len, nullptr);
+  if (rtn == 0) {
+    void* buf = malloc(len);
+    if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+      *dst = buf;
+      *dst_len = len;
+    }
+    else {
+      free(buf);
+      rtn = -1;
+    }
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rtn;
+}
+
+int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
+                    size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
+{
+  (void)nthreads;
+  if (*dst != nullptr)
+    return 1;
+  if (src_len < 18)
+    return -1;
+  ContainerInfo ci;
+  size_t need = 0;
+  if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
+    return -1;
+  const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
+  const size_t esz = output_float ? 4 : 8;
+  void *d_in = nullptr, *d_out = nullptr;
+  if (hipMalloc(&d_in, src_len) != hipSuccess || hipMalloc(&d_out, n * esz) != hipSuccess) {
+    fprintf(stderr, "[sperr_hip] device allocation failed\n");
+    if (d_in)
+      (void)hipFree(d_in);
+    return -1;
+  }
+  int rtn = -1;
+  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+    rtn = sperrhip_decompress_dev(d_in, src_len, output_float, d_out, n * esz, dimx, dimy, dimz,
+                                  nullptr);
+  if (rtn == 0) {
+    void* buf = malloc(n * esz);
+    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+      *dst = buf;
+    else {
+      free(buf);
+      rtn = -1;
+    }
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rtn;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// speck_dec.h -- buffers and launcher of the SPECK3D decoder (speck_dec.hip)
+#ifndef SPERR_AMD_SPECK_DEC_H
+#define SPERR_AMD_SPECK_DEC_H
+
+#include "common.h"
+
+namespace sperrhip {
+
+struct DecState {
+  uint32_t active;
+  int32_t done;
+  uint32_t error;
+  int32_t nbp;
+  uint32_t cur;
+  uint32_t nLip, nRef;           // candidates of the current plane's pixel passes
+  uint32_t pad;
+  uint64_t pos;                  // next unread bit
+  uint64_t avail;                // usable bits of the stream
+  uint64_t total_bits;
+  uint64_t payload;              // byte offset of the SPECK payload inside the container
+  uint64_t lipStart, lipBits;    // LIP scan of the current plane
+  uint32_t listLen[2][spk::kMaxLevels];
+};
+
+struct DecBuffers {
+  spk::Tree tree;
+  uint32_t nchunks;
+  CoderState* cst;
+  DecState* st;
+  uint64_t* stream;            // payload as aligned words, zero padded (+2 words of slack)
+  size_t streamStride;
+  int8_t* born;                // plane at which the pixel entered the LIP (-1: not yet)
+  int8_t* sigp;                // plane at which the pixel became significant (-1: not yet)
+  size_t pixStride;
+  void* coef;                  // uint32_t or uint64_t magnitudes being reconstructed
+  size_t coefStride;
+  uint64_t* sign;              // initialised to all ones (SPECK_INT.cpp:174-175)
+  size_t signStride;
+  uint64_t* lis[2];
+  size_t lisStride;
+  const uint32_t* levelOff;
+  uint32_t nPixTiles;
+  uint32_t* tileLip;
+  uint32_t* tileRef;
+  uint32_t* tileLipOff;
+  uint32_t* tileRefOff;
+  size_t tileStride;
+  uint32_t* cand;              // LIP candidates of the current plane, raster order
+  size_t candStride;
+  uint64_t* tokMask;           // token starts of every 64-bit word of the LIP scan
+  uint32_t* tokCnt;
+  uint32_t* tokOff;
+  size_t tokStride;
+};
+
+struct DecPlanHost {
+  const uint64_t* d_initLIS;
+  const uint32_t* d_initLen;
+};
+
+int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,
+                        const uint8_t* container, const uint64_t* d_chunkOff,
+                        const uint64_t* d_chunkLen, bool wide_pass, int maxPlanes);
+
+}  // namespace sperrhip
+#endif

@@ -1,0 +1,80 @@
+// speck_enc.h -- buffers and launcher of the data-parallel SPECK3D encoder (speck_enc.hip)
+#ifndef SPERR_AMD_SPECK_ENC_H
+#define SPERR_AMD_SPECK_ENC_H
+
+#include <vector>
+
+#include "common.h"
+
+namespace sperrhip {
+
+// Device pointers of one batch of `nchunks` equally shaped chunks; chunk c's slice of an array is
+// base + c * stride (strides in elements).
+struct EncBuffers {
+  spk::Tree tree;
+  uint32_t nchunks;
+  CoderState* cst;
+  EncState* st;
+  // quantiser output
+  const void* coef;            // uint32_t or uint64_t magnitudes, raster order
+  size_t coefStride;
+  const uint64_t* sign;        // bit i = (value i >= 0)
+  size_t signStride;
+  const int8_t* msb;           // msb position of every magnitude (-1 for zero)
+  int8_t* bplane;              // plane at which the pixel is first tested (-1: never)
+  size_t pixStride;
+  // significance pyramid
+  int8_t* M;
+  uint32_t* E;
+  uint64_t* opos;
+  size_t nodeStride;
+  // LIS, double buffered; level l occupies [levelOff[l], levelOff[l+1])
+  uint64_t* lis[2];
+  size_t lisStride;
+  const uint32_t* levelOff;
+  // list tiles in traversal order (deepest level first)
+  uint32_t nListTiles;
+  const uint16_t* tileLevel;
+  const uint32_t* tileStart;
+  const uint32_t* levelFirstTile;
+  const uint32_t* levelNumTiles;
+  uint64_t* tileBits;
+  uint32_t* tileSurv;
+  uint64_t* tileBitsOff;
+  uint32_t* tileSurvOff;
+  size_t tileStride;
+  // newborn insignificant sets of one plane
+  uint64_t* bornPacked;
+  uint64_t* bornPosLev;
+  size_t bornStride;
+  // birth masks: one bit per stream position of the LIS phase, per level that can hold sets
+  const uint8_t* levelSlot;    // level -> slot (0xff: none)
+  const uint8_t* slotLevel;    // slot -> level
+  uint32_t nSlots;
+  uint32_t maskWords;
+  uint64_t* mask;
+  uint32_t* maskPrefix;
+  size_t maskStride;           // nSlots * maskWords
+  // pixel-pass census
+  uint32_t nPixTiles;
+  uint32_t* pixCnt;            // [plane*2 + phase][tile]
+  uint32_t* pixOff;
+  size_t pixCntStride;
+  // output bit buffer (zero-initialised)
+  uint64_t* stream;
+  size_t streamStride;
+};
+
+struct EncPlanHost {
+  const uint64_t* d_initLIS;
+  const uint32_t* d_initLen;
+  const uint32_t* d_depthBlocks;
+  std::vector<uint32_t> depthBlockOff;   // [maxDepth + 1]
+  uint32_t nsets;
+};
+
+int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                        uint64_t raw_budget, bool rate_mode, bool wide_pass);
+
+}  // namespace sperrhip
+#endif

@@ -1,0 +1,750 @@
+// speck_enc.hip -- SPECK3D bit-plane set-partitioning ENCODER as data-parallel HIP kernels.
+//
+// The reference encoder (/root/reference/src/SPECK_INT.cpp:110-163,310-357,
+// src/SPECK3D_INT.cpp:99-212, src/SPECK3D_INT_ENC.cpp:141-227) is a serial, data-dependent
+// traversal that appends one bit at a time.  Every bit it emits, and the position it lands on, is
+// a pure function of the msb of each coefficient and of each set's largest coefficient, so the
+// stream is produced here as count -> scan -> scatter (tests/model/speck_model.cpp is the CPU
+// model of exactly these kernels and is pinned bit-for-bit against the oracle):
+//
+//   k_pyramid        bottom-up: M[node] = msb of the set's largest coefficient, E[node] = bits the
+//                    set's split emits, bplane[pixel] = plane at which the pixel enters the LIP
+//   k_census/_scan   per pixel tile and plane: bits of the LIP scan and of the refinement pass
+//   per plane p:
+//     k_list_count / k_list_scan / k_list_apply   positions of the LIS entries (list order is
+//                    part of the format), their '1' test bits, list compaction
+//     k_split_emit   every set with M == p writes its children's test / sign bits at
+//                    (position of the list entry that started its split chain) + (walk-up sum)
+//     k_mask_scan / k_born_place   children that stay insignificant join the lists in the order
+//                    of their stream position (= the reference's append order)
+//   k_emit_pixels    LIP-scan and refinement bits, raster order, LDS-staged
+//
+// Bits past the budget are dropped, but whole passes are still counted so that the header's
+// total_bits equals the reference's (the bit count at the end of the pass that crossed it).
+#include "speck_enc.h"
+
+namespace sperrhip {
+
+using namespace spk;
+
+#define ACTIVE_OR_RETURN(s, p)                                     \
+  if (!(s).active || (s).done || (int)(p) >= (s).nbp)              \
+    return;
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_enc_state_init(EncBuffers b, const uint64_t* initLIS, const uint32_t* initLen,
+                                 uint64_t budget, int wide_pass)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  const CoderState& cs = b.cst[c];
+  s.active = wide_pass ? (cs.need_retry != 0) : (cs.is_const == 0);
+  s.nbp = 0;
+  s.done = 0;
+  s.plast = 0;
+  s.bornCount = 0;
+  s.pos = 0;
+  s.total_bits = 0;
+  s.budget = budget;
+  s.lisBits = 0;
+  s.cur = 0;
+  for (uint32_t l = 0; l < b.tree.nlevels; l++) {
+    s.listLen[0][l] = initLen[l];
+    s.listLen[1][l] = 0;
+    s.bornTot[l] = 0;
+    for (uint32_t k = 0; k < initLen[l]; k++)
+      b.lis[0][c * b.lisStride + b.levelOff[l] + k] = initLIS[b.levelOff[l] + k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pyramid: one thread per node of the grids at one depth (deepest first)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kNodeBlock)
+k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
+{
+  const uint32_t c = blockIdx.y;
+  if (!b.st[c].active)
+    return;
+  const Tree& t = b.tree;
+  const uint32_t id = depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x;
+  Node nd;
+  if (!node_from_flat(t, id, nd))
+    return;
+  const NodeGeom q = node_geom(t, nd);
+  if (q.count == 0)
+    return;
+  int8_t* M = b.M + c * b.nodeStride;
+  uint32_t* E = b.E + c * b.nodeStride;
+  const int8_t* msb = b.msb + c * b.pixStride;
+  int8_t* bplane = b.bplane + c * b.pixStride;
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  const bool isset = q.count > 1 || g.depth == 0;
+  if (!isset) {
+    const int e[3] = {g.e[0], g.e[1], g.e[2]};
+    const uint32_t ii[3] = {nd.i[0], nd.i[1], nd.i[2]};
+    M[id] = msb[pixel_raster(t, r, e, ii)];
+    return;
+  }
+  Kids k;
+  node_kids(t, nd, k);
+  KidInfo ki;
+  kids_info(t, nd, k, M, E, msb, ki);
+  int m = -1;
+  for (int j = 0; j < k.n; j++)
+    m = max(m, (int)ki.m[j]);
+  M[id] = (int8_t)m;
+  E[id] = m >= 0 ? split_bits(k, ki, m) : 0u;
+  for (int j = 0; j < k.n; j++)
+    if (ki.pixel[j])
+      bplane[kid_raster(t, nd, k, j)] = (int8_t)m;
+}
+
+__global__ void k_enc_planes_setup(EncBuffers b)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  if (!s.active)
+    return;
+  const Tree& t = b.tree;
+  int nbp = 0;
+  for (uint32_t r = 0; r < t.nroots; r++)
+    nbp = max(nbp, (int)b.M[c * b.nodeStride + t.grids[t.roots[r].gridFirst].nodeOff] + 1);
+  s.nbp = nbp;
+  s.plast = nbp;
+  if (nbp == 0) {  // all coefficients are zero (SPECK_INT.cpp:130-133)
+    s.done = 1;
+    s.total_bits = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// census of the pixel passes
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_pix4(const int8_t* a, uint32_t i0, uint32_t n, int v[4])
+{
+  if (i0 + 4 <= n) {
+    const char4 q = *reinterpret_cast<const char4*>(a + i0);
+    v[0] = q.x;
+    v[1] = q.y;
+    v[2] = q.z;
+    v[3] = q.w;
+  }
+  else
+    for (int k = 0; k < 4; k++)
+      v[k] = (i0 + k < n) ? a[i0 + k] : -1;
+}
+
+__global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  if (!s.active || s.done)
+    return;
+  __shared__ uint32_t wsum[kThreads / 64][kMaxPlanes];
+  const uint32_t n = b.tree.nvals;
+  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * 4;
+  int m[4], bp[4];
+  load_pix4(b.msb + c * b.pixStride, i0, n, m);
+  load_pix4(b.bplane + c * b.pixStride, i0, n, bp);
+  if (i0 >= n)
+    for (int k = 0; k < 4; k++)
+      bp[k] = -1, m[k] = -1;
+  const int nbp = s.nbp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = 0; p < nbp; p++) {
+    uint32_t lip = 0, ref = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      lip += (bp[k] > p && p >= m[k]) ? (m[k] == p ? 2u : 1u) : 0u;
+      ref += (m[k] > p) ? 1u : 0u;
+    }
+    uint32_t v = lip | (ref << 16);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+      v += __shfl_xor(v, d, 64);
+    if (lane == 0)
+      wsum[wave][p] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nbp) {
+    uint32_t v = 0;
+    for (int w = 0; w < kThreads / 64; w++)
+      v += wsum[w][threadIdx.x];
+    uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
+    cnt[(size_t)(threadIdx.x * 2 + 0) * b.nPixTiles + blockIdx.x] = v & 0xffffu;
+    cnt[(size_t)(threadIdx.x * 2 + 1) * b.nPixTiles + blockIdx.x] = v >> 16;
+  }
+}
+
+// one block per (plane, phase) row and chunk: exclusive scan over the pixel tiles
+__global__ void __launch_bounds__(kThreads) k_census_scan(EncBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  EncState& s = b.st[c];
+  const int p = blockIdx.x >> 1, phase = blockIdx.x & 1;
+  if (!s.active || s.done || p >= s.nbp)
+    return;
+  __shared__ uint64_t sm[kThreads / 64 + 1];
+  const uint32_t* cnt = b.pixCnt + c * b.pixCntStride + (size_t)blockIdx.x * b.nPixTiles;
+  uint32_t* off = b.pixOff + c * b.pixCntStride + (size_t)blockIdx.x * b.nPixTiles;
+  uint64_t carry = 0;
+  for (uint32_t base = 0; base < b.nPixTiles; base += kThreads * 4) {
+    uint32_t v[4];
+    uint64_t tsum = 0;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = base + threadIdx.x * 4 + k;
+      v[k] = i < b.nPixTiles ? cnt[i] : 0;
+      tsum += v[k];
+    }
+    uint64_t total;
+    uint64_t ex = block_exclusive_scan<uint64_t>(tsum, sm, &total) + carry;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = base + threadIdx.x * 4 + k;
+      if (i < b.nPixTiles)
+        off[i] = (uint32_t)ex;
+      ex += v[k];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    if (phase == 0)
+      s.lipTot[p] = carry;
+    else
+      s.refTot[p] = carry;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// plane bookkeeping
+// ------------------------------------------------------------------------------------------
+__global__ void k_plane_begin(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  s.rec[p].baseLIP = s.pos;
+  s.pos += s.lipTot[p];
+  s.rec[p].baseLIS = s.pos;
+  s.rec[p].didSort = 1;
+  s.rec[p].didREF = 0;
+  s.plast = p;
+  s.bornCount = 0;
+  for (uint32_t l = 0; l < b.tree.nlevels; l++)
+    s.bornTot[l] = 0;
+}
+
+__global__ void k_plane_end(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  const uint32_t nx = s.cur ^ 1u;
+  for (uint32_t l = 0; l < b.tree.nlevels; l++)
+    s.listLen[nx][l] += s.bornTot[l];
+  s.cur = nx;
+  s.pos += s.lisBits;
+  if (s.pos >= s.budget) {  // SPECK_INT.cpp:149
+    s.done = 1;
+    s.total_bits = s.pos;
+    return;
+  }
+  s.rec[p].baseREF = s.pos;
+  s.pos += s.refTot[p];
+  s.rec[p].didREF = 1;
+  if (s.pos >= s.budget || p == 0) {  // SPECK_INT.cpp:153,161
+    s.done = 1;
+    s.total_bits = s.pos;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LIS entries: count, scan, apply
+// ------------------------------------------------------------------------------------------
+struct ListItem {
+  uint64_t packed;
+  uint32_t id;
+  uint32_t bits;   // 0 when the slot is past the end of the list
+  bool sig;
+};
+
+__device__ __forceinline__ void load_list4(const EncBuffers& b, uint32_t c, const EncState& s,
+                                           uint32_t tile, int p, ListItem it[4])
+{
+  const uint32_t l = b.tileLevel[tile], start = b.tileStart[tile];
+  const uint32_t n = s.listLen[s.cur][l];
+  const uint64_t* list = b.lis[s.cur] + c * b.lisStride + b.levelOff[l];
+  const int8_t* M = b.M + c * b.nodeStride;
+  const uint32_t* E = b.E + c * b.nodeStride;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t e = start + threadIdx.x * 4 + k;
+    it[k].bits = 0;
+    it[k].sig = false;
+    if (e < n) {
+      it[k].packed = list[e];
+      it[k].id = flat_id(b.tree, unpack_node(it[k].packed));
+      it[k].sig = (M[it[k].id] == p);
+      it[k].bits = 1u + (it[k].sig ? E[it[k].id] : 0u);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_list_count(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  __shared__ uint64_t sm[kThreads / 64 + 1];
+  ListItem it[4];
+  load_list4(b, c, s, blockIdx.x, p, it);
+  uint64_t v = 0;  // low 40 bits: bits, high 24 bits: survivors
+  for (int k = 0; k < 4; k++)
+    if (it[k].bits)
+      v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
+  uint64_t total;
+  block_exclusive_scan<uint64_t>(v, sm, &total);
+  if (threadIdx.x == 0) {
+    b.tileBits[c * b.tileStride + blockIdx.x] = total & ((1ull << 40) - 1);
+    b.tileSurv[c * b.tileStride + blockIdx.x] = (uint32_t)(total >> 40);
+  }
+}
+
+// one block per chunk: scan the tiles in traversal order (deepest level first)
+__global__ void __launch_bounds__(kThreads) k_list_scan(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  __shared__ uint64_t sm[kThreads / 64 + 1];
+  const uint64_t* tb = b.tileBits + c * b.tileStride;
+  const uint32_t* ts = b.tileSurv + c * b.tileStride;
+  uint64_t* tbo = b.tileBitsOff + c * b.tileStride;
+  uint32_t* tso = b.tileSurvOff + c * b.tileStride;   // first pass: global scan
+  uint64_t carryB = 0, carryS = 0;
+  for (uint32_t base = 0; base < b.nListTiles; base += kThreads) {
+    const uint32_t i = base + threadIdx.x;
+    const uint64_t vb = i < b.nListTiles ? tb[i] : 0, vs = i < b.nListTiles ? ts[i] : 0;
+    uint64_t totB, totS;
+    const uint64_t eb = block_exclusive_scan<uint64_t>(vb, sm, &totB) + carryB;
+    const uint64_t es = block_exclusive_scan<uint64_t>(vs, sm, &totS) + carryS;
+    if (i < b.nListTiles) {
+      tbo[i] = eb;
+      tso[i] = (uint32_t)es;
+    }
+    carryB += totB;
+    carryS += totS;
+  }
+  __syncthreads();
+  // survivors restart at every level: new list lengths, then make tso relative to the level
+  const uint32_t nx = s.cur ^ 1u;
+  __shared__ uint32_t levBase[kMaxLevels];
+  for (uint32_t l = threadIdx.x; l < b.tree.nlevels; l += blockDim.x) {
+    const uint32_t nt = b.levelNumTiles[l];
+    levBase[l] = 0;
+    s.listLen[nx][l] = 0;
+    if (nt) {
+      const uint32_t first = b.levelFirstTile[l], last = first + nt;
+      const uint32_t beg = tso[first];
+      const uint32_t end = (last < b.nListTiles) ? tso[last] : (uint32_t)carryS;
+      levBase[l] = beg;
+      s.listLen[nx][l] = end - beg;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < b.nListTiles; i += blockDim.x)
+    tso[i] -= levBase[b.tileLevel[i]];
+  if (threadIdx.x == 0)
+    s.lisBits = carryB;
+}
+
+__global__ void __launch_bounds__(kThreads) k_list_apply(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  const uint32_t tile = blockIdx.x;
+  const uint32_t l = b.tileLevel[tile];
+  if (b.tileStart[tile] >= s.listLen[s.cur][l])
+    return;
+  __shared__ uint64_t sm[kThreads / 64 + 1];
+  ListItem it[4];
+  load_list4(b, c, s, tile, p, it);
+  uint64_t v = 0;
+  for (int k = 0; k < 4; k++)
+    if (it[k].bits)
+      v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
+  uint64_t total;
+  const uint64_t ex = block_exclusive_scan<uint64_t>(v, sm, &total);
+  uint64_t bitpos = s.rec[p].baseLIS + b.tileBitsOff[c * b.tileStride + tile] +
+                    (ex & ((1ull << 40) - 1));
+  uint32_t rank = b.tileSurvOff[c * b.tileStride + tile] + (uint32_t)(ex >> 40);
+  uint64_t* next = b.lis[s.cur ^ 1u] + c * b.lisStride + b.levelOff[l];
+  uint64_t* opos = b.opos + c * b.nodeStride;
+  uint64_t* stream = b.stream + c * b.streamStride;
+  for (int k = 0; k < 4; k++) {
+    if (!it[k].bits)
+      continue;
+    if (it[k].sig) {
+      opos[it[k].id] = bitpos;
+      put_bits(stream, bitpos, 1, 1, s.budget);
+    }
+    else
+      next[rank++] = it[k].packed;
+    bitpos += it[k].bits;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_split_emit: every set whose msb equals the plane splits now
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
+  const int8_t* M = b.M + c * b.nodeStride;
+  if (M[id] != p)
+    return;
+  const Tree& t = b.tree;
+  Node nd;
+  if (!node_from_flat(t, id, nd))
+    return;
+  const NodeGeom q = node_geom(t, nd);
+  const bool isset = q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
+  if (!isset)
+    return;
+  const uint32_t* E = b.E + c * b.nodeStride;
+  const int8_t* msb = b.msb + c * b.pixStride;
+
+  // walk up to the list entry that started this chain of splits
+  uint64_t off = 0;
+  Node cur = nd;
+  uint32_t curid = id;
+  while (!node_is_root(t, cur)) {
+    const Node par = node_parent(t, cur);
+    const uint32_t pid = flat_id(t, par);
+    if (M[pid] != p)
+      break;
+    Kids pk;
+    node_kids(t, par, pk);
+    KidInfo pki;
+    kids_info(t, par, pk, M, E, msb, pki);
+    int which = 0;
+    for (int j = 0; j < pk.n; j++)
+      if (pk.idx[j][0] == cur.i[0] && pk.idx[j][1] == cur.i[1] && pk.idx[j][2] == cur.i[2])
+        which = j;
+    bool coded;
+    off += kid_offset(pk, pki, p, which, coded);
+    off += coded ? 1 : 0;
+    cur = par;
+    curid = pid;
+  }
+  uint64_t pos = b.opos[c * b.nodeStride + curid] + 1 + off;
+
+  Kids k;
+  node_kids(t, nd, k);
+  KidInfo ki;
+  kids_info(t, nd, k, M, E, msb, ki);
+  const uint32_t kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+  const uint64_t* sign = b.sign + c * b.signStride;
+  uint64_t* stream = b.stream + c * b.streamStride;
+  const uint64_t baseLIS = s.rec[p].baseLIS;
+  const uint32_t slot = b.levelSlot[kidlev];
+  bool found = false;
+  uint64_t acc = 0;      // contiguous run of bits being assembled
+  int nacc = 0;
+  uint64_t accpos = pos;
+  for (int j = 0; j < k.n; j++) {
+    const bool coded = found || (j + 1 != k.n);
+    const bool sig = coded ? (ki.m[j] == p) : true;
+    if (coded) {
+      acc |= (uint64_t)sig << nacc;
+      nacc++;
+      pos++;
+    }
+    if (sig) {
+      found = true;
+      if (ki.pixel[j]) {
+        const uint32_t ridx = kid_raster(t, nd, k, j);
+        acc |= ((sign[ridx >> 6] >> (ridx & 63)) & 1ull) << nacc;
+        nacc++;
+        pos++;
+      }
+      else {  // the child writes its own split; flush what we have and skip over it
+        put_bits(stream, accpos, acc, nacc, s.budget);
+        pos += ki.e[j];
+        acc = 0;
+        nacc = 0;
+        accpos = pos;
+      }
+    }
+    else if (!ki.pixel[j]) {  // insignificant set: joins LIS[kidlev] in stream order
+      const uint64_t rel = pos - 1 - baseLIS;
+      if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
+        const uint32_t kslot = atomicAdd(&s.bornCount, 1u);
+        b.bornPacked[c * b.bornStride + kslot] = pack_node(kid_node(k, j));
+        b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
+        atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
+                    1ull << (rel & 63));
+      }
+    }
+  }
+  put_bits(stream, accpos, acc, nacc, s.budget);
+}
+
+// popcount prefix of every birth mask (one block per mask slot and chunk)
+__global__ void __launch_bounds__(kThreads) k_mask_scan(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y, slot = blockIdx.x;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  __shared__ uint32_t sm[kThreads / 64 + 1];
+  const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
+  const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
+  const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
+  uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nwords; base += kThreads * 4) {
+    uint32_t v[4], tsum = 0;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = base + threadIdx.x * 4 + k;
+      v[k] = i < nwords ? (uint32_t)__popcll(mask[i]) : 0u;
+      tsum += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total) + carry;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = base + threadIdx.x * 4 + k;
+      if (i < nwords)
+        pre[i] = ex;
+      ex += v[k];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0)
+    s.bornTot[b.slotLevel[slot]] = carry;
+}
+
+__global__ void __launch_bounds__(kThreads) k_born_place(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= s.bornCount)
+    return;
+  const uint64_t pl = b.bornPosLev[c * b.bornStride + k];
+  const uint32_t lev = (uint32_t)(pl >> 48);
+  const uint64_t rel = pl & ((1ull << 48) - 1);
+  const uint32_t slot = b.levelSlot[lev];
+  const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6);
+  const uint32_t rank = b.maskPrefix[mo] +
+                        (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+  const uint32_t nx = s.cur ^ 1u;
+  b.lis[nx][c * b.lisStride + b.levelOff[lev] + s.listLen[nx][lev] + rank] =
+      b.bornPacked[c * b.bornStride + k];
+}
+
+// clear the part of the birth masks this plane used
+__global__ void __launch_bounds__(kThreads) k_mask_clear(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
+  const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords)
+    return;
+  for (uint32_t slot = 0; slot < b.nSlots; slot++)
+    b.mask[c * b.maskStride + (size_t)slot * b.maskWords + w] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_emit_pixels: LIP-scan bits and refinement bits of every processed plane, raster order.
+// Each tile's bits of one (plane, phase) are contiguous in the stream: stage them in LDS and OR
+// whole words out.
+// ------------------------------------------------------------------------------------------
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  const EncState& s = b.st[c];
+  if (!s.active || s.nbp == 0)
+    return;
+  constexpr int kWords = kPixTile * 2 / 64 + 2;
+  __shared__ unsigned long long lipw[kWords], refw[kWords];
+  __shared__ uint32_t sm[kThreads / 64 + 1];
+  const uint32_t n = b.tree.nvals;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t i0 = tile * kPixTile + threadIdx.x * 4;
+  int m[4], bp[4];
+  load_pix4(b.msb + c * b.pixStride, i0, n, m);
+  load_pix4(b.bplane + c * b.pixStride, i0, n, bp);
+  uint64_t cf[4] = {0, 0, 0, 0};
+  uint32_t sg = 0;
+  const CT* coef = reinterpret_cast<const CT*>(b.coef) + c * b.coefStride;
+  const uint64_t* sign = b.sign + c * b.signStride;
+  for (int k = 0; k < 4; k++)
+    if (i0 + k < n) {
+      cf[k] = coef[i0 + k];
+      sg |= (uint32_t)((sign[(i0 + k) >> 6] >> ((i0 + k) & 63)) & 1ull) << k;
+    }
+    else {
+      m[k] = -1;
+      bp[k] = -1;
+    }
+  const uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
+  const uint32_t* off = b.pixOff + c * b.pixCntStride;
+  uint64_t* stream = b.stream + c * b.streamStride;
+  for (int p = s.nbp - 1; p >= s.plast; p--) {
+    const uint32_t nlip = cnt[(size_t)(p * 2) * b.nPixTiles + tile];
+    const uint32_t nref = s.rec[p].didREF ? cnt[(size_t)(p * 2 + 1) * b.nPixTiles + tile] : 0;
+    if (nlip == 0 && nref == 0)
+      continue;  // uniform across the block
+    const uint64_t lipBase = s.rec[p].baseLIP + off[(size_t)(p * 2) * b.nPixTiles + tile];
+    const uint64_t refBase = s.rec[p].baseREF + off[(size_t)(p * 2 + 1) * b.nPixTiles + tile];
+    for (int w = threadIdx.x; w < kWords; w += blockDim.x) {
+      lipw[w] = 0;
+      refw[w] = 0;
+    }
+    uint32_t lbits = 0, lval = 0, rbits = 0, rval = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (bp[k] > p && p >= m[k]) {
+        if (m[k] == p) {
+          lval |= (1u | (((sg >> k) & 1u) << 1)) << lbits;
+          lbits += 2;
+        }
+        else
+          lbits += 1;
+      }
+      if (m[k] > p) {
+        rval |= (uint32_t)((cf[k] >> p) & 1ull) << rbits;
+        rbits += 1;
+      }
+    }
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<uint32_t>(lbits | (nref ? rbits << 16 : 0u), sm,
+                                                       &total);
+    const uint32_t lsh = (uint32_t)(lipBase & 63), rsh = (uint32_t)(refBase & 63);
+    if (lval) {
+      const uint32_t at = (ex & 0xffffu) + lsh;
+      atomicOr(&lipw[at >> 6], (unsigned long long)lval << (at & 63));
+      if ((at & 63) + lbits > 64)
+        atomicOr(&lipw[(at >> 6) + 1], (unsigned long long)lval >> (64 - (at & 63)));
+    }
+    if (rval && nref) {
+      const uint32_t at = (ex >> 16) + rsh;
+      atomicOr(&refw[at >> 6], (unsigned long long)rval << (at & 63));
+      if ((at & 63) + rbits > 64)
+        atomicOr(&refw[(at >> 6) + 1], (unsigned long long)rval >> (64 - (at & 63)));
+    }
+    __syncthreads();
+    const uint64_t limitWord = (s.budget + 63) / 64;  // words at or past this hold no kept bit
+    for (int w = threadIdx.x; w < kWords; w += blockDim.x) {
+      const uint64_t lw = (lipBase >> 6) + w, rw = (refBase >> 6) + w;
+      uint64_t lv = lipw[w], rv = refw[w];
+      if (lv && lw < limitWord) {
+        if (lw == limitWord - 1 && (s.budget & 63))
+          lv &= (1ull << (s.budget & 63)) - 1;
+        atomic_or64(stream + lw, lv);
+      }
+      if (rv && rw < limitWord) {
+        if (rw == limitWord - 1 && (s.budget & 63))
+          rv &= (1ull << (s.budget & 63)) - 1;
+        atomic_or64(stream + rw, rv);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// stream length and the fixed-rate retry test (SPECK_INT.cpp:264-282, SPECK_FLT.cpp:530-538)
+__global__ void k_enc_finalize(EncBuffers b, uint64_t raw_budget, int rate_mode, int wide_pass)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  CoderState& cs = b.cst[c];
+  if (cs.is_const) {
+    cs.stream_len = 17;
+    cs.need_retry = 0;
+    return;
+  }
+  if (!s.active)
+    return;
+  const uint64_t keep = min(s.total_bits, s.budget);
+  const uint64_t payload = (keep + 7) / 8;
+  cs.stream_len = 17 + 9 + payload;
+  cs.nbp = s.nbp;
+  cs.total_bits = s.total_bits;
+  cs.need_retry = (rate_mode && !wide_pass && (9 + payload) * 8 < raw_budget) ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------
+int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                        uint64_t raw_budget, bool rate_mode, bool wide_pass)
+{
+  uint64_t budget = ~0ull;
+  if (raw_budget != 0) {  // SPECK_INT.cpp:48-58
+    budget = raw_budget;
+    while (budget % 8)
+      budget++;
+  }
+  const uint32_t nc = b.nchunks;
+  const dim3 perChunk((nc + 63) / 64);
+  LAUNCH_K(k_enc_state_init, perChunk, dim3(64), 0, stream, b, plan.d_initLIS,
+                     plan.d_initLen, budget, wide_pass ? 1 : 0);
+  for (int d = (int)b.tree.maxDepth - 1; d >= 0; d--) {
+    const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
+    if (nb)
+      LAUNCH_K(k_pyramid, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
+                         plan.d_depthBlocks + plan.depthBlockOff[d]);
+  }
+  LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
+  LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b);
+  const int maxPlanes = wide_pass ? kMaxPlanes : 32;
+  LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
+  const uint32_t nodeBlocks = b.tree.nnodes / kNodeBlock;
+  const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
+  const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
+  for (int p = maxPlanes - 1; p >= 0; p--) {
+    LAUNCH_K(k_plane_begin, perChunk, dim3(64), 0, stream, b, p);
+    LAUNCH_K(k_list_count, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_list_apply, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_split_emit, dim3(nodeBlocks, nc), dim3(kNodeBlock), 0, stream, b, p);
+    if (b.nSlots) {
+      LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_born_place, dim3(bornBlocks, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_mask_clear, dim3(maskBlocks, nc), dim3(kThreads), 0, stream, b, p);
+    }
+    LAUNCH_K(k_plane_end, perChunk, dim3(64), 0, stream, b, p);
+  }
+  if (wide_pass)
+    LAUNCH_K(k_emit_pixels<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
+                       b);
+  else
+    LAUNCH_K(k_emit_pixels<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
+                       b);
+  LAUNCH_K(k_enc_finalize, perChunk, dim3(64), 0, stream, b, raw_budget,
+                     rate_mode ? 1 : 0, wide_pass ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sperrhip

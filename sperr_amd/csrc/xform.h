@@ -1,0 +1,45 @@
+// xform.h -- launchers of the floating-point stage kernels (xform.hip)
+#ifndef SPERR_AMD_XFORM_H
+#define SPERR_AMD_XFORM_H
+
+#include <string.h>
+
+#include "common.h"
+
+namespace sperrhip {
+
+struct LiftConsts {
+  double alpha, beta, gamma, delta, eps, inv_eps;
+};
+LiftConsts lift_consts();
+
+template <typename T>
+int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
+                     uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
+                     double* strideMean, size_t strideMeanStride, double* vals,
+                     size_t valsStride, CoderState* st);
+
+template <typename T>
+int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
+                   uint32_t nchunks, const uint32_t cdims[3], const double* vals,
+                   size_t valsStride, const CoderState* st);
+
+int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
+                uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
+                const CoderState* st);
+
+int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
+                    uint32_t n, CoderState* st);
+int launch_make_q_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);
+
+int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t valsStride,
+                    uint32_t nchunks, uint32_t n, void* coef, size_t coefStride, uint64_t* sign,
+                    size_t signStride, int8_t* msb, size_t msbStride, const CoderState* st);
+
+int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t coefStride,
+                        const uint64_t* sign, size_t signStride, uint32_t nchunks, uint32_t n,
+                        double* vals, size_t valsStride, const CoderState* st);
+
+}  // namespace sperrhip
+
+#endif

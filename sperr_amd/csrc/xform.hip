@@ -1,0 +1,497 @@
+// xform.hip -- floating-point stages of the chunk pipeline as HIP kernels for gfx950:
+// conditioner (mean / constant test), CDF 9/7 lifting DWT and IDWT, max-reduce, mid-tread
+// quantiser and its inverse, chunk gather/scatter.  Everything is fp64 with the reference's exact
+// operation order; compile with -ffp-contract=off (every fused multiply-add of the canonical
+// reference build is an explicit fma()).
+//
+// Reference behaviour restated (file:line under /root/reference):
+//   src/Conditioner.cpp:10-64,119-163   strided sequential mean, constant test
+//   src/CDF97.cpp:132-148,284-302,345-474,598-666   dyadic / wavelet-packet 3D transform
+//   src/SPECK_FLT.cpp:282-301,311-399   q, quantise, inverse quantise
+//   src/SPERR3D_OMP_C.cpp:236-261, src/SPERR3D_OMP_D.cpp:167-184   gather / scatter
+#include "xform.h"
+
+namespace sperrhip {
+
+// ------------------------------------------------------------------------------------------
+// conditioner
+// ------------------------------------------------------------------------------------------
+
+// One thread per stride: strictly sequential fp64 sum (the order is part of the result), read
+// straight from the volume through the chunk's gather map.  Also tests "all samples equal".
+template <typename T>
+__global__ void k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
+                              uint32_t cx, uint32_t cy, uint32_t cz, uint32_t nstrides,
+                              uint32_t ssz, double* strideMean, size_t strideMeanStride,
+                              CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nstrides)
+    return;
+  const ChunkGeom g = geom[c];
+  const size_t vx = vd.dims[0], vy = vd.dims[1];
+  const T first = vol[((size_t)g.org[2] * vy + g.org[1]) * vx + g.org[0]];
+  const uint32_t e0 = s * ssz;
+  uint32_t x = e0 % cx, y = (e0 / cx) % cy, z = e0 / (cx * cy);
+  double acc = 0.0;
+  bool differs = false;
+  for (uint32_t i = 0; i < ssz; i++) {
+    const T v = vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x];
+    acc += (double)v;
+    differs |= (v != first);
+    if (++x == cx) {
+      x = 0;
+      if (++y == cy) {
+        y = 0;
+        ++z;
+      }
+    }
+  }
+  strideMean[c * strideMeanStride + s] = acc / (double)ssz;
+  if (differs)
+    st[c].not_const_flag = 1;
+}
+
+template <typename T>
+__global__ void k_mean_finalize(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
+                                uint32_t nstrides, const double* strideMean,
+                                size_t strideMeanStride, CoderState* st)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= gridDim.x * blockDim.x)
+    return;
+  const double* sm = strideMean + c * strideMeanStride;
+  double total = 0.0;
+  for (uint32_t s = 0; s < nstrides; s++)
+    total += sm[s];
+  const ChunkGeom g = geom[c];
+  const bool is_const = st[c].not_const_flag == 0;
+  st[c].is_const = is_const ? 1u : 0u;
+  if (is_const)  // the header stores the value itself (Conditioner.cpp:28-44)
+    st[c].mean = (double)vol[((size_t)g.org[2] * vd.dims[1] + g.org[1]) * vd.dims[0] + g.org[0]];
+  else
+    st[c].mean = total / (double)nstrides;
+}
+
+// vals[i] = (double)vol[gather(i)] - mean
+template <typename T>
+__global__ void k_gather_condition(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
+                                   uint32_t cx, uint32_t cy, uint32_t n, double* vals,
+                                   size_t valsStride, const CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  const ChunkGeom g = geom[c];
+  const double mean = st[c].mean;
+  const size_t vx = vd.dims[0], vy = vd.dims[1];
+  double* out = vals + c * valsStride;
+  for (uint32_t i = blockIdx.x * blockDim.x * 4 + threadIdx.x, k = 0; k < 4 && i < n;
+       k++, i += blockDim.x) {
+    const uint32_t x = i % cx, r = i / cx;
+    const uint32_t y = r % cy, z = r / cy;
+    const T v = vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x];
+    out[i] = (double)v - mean;
+  }
+}
+
+// out[scatter(i)] = (T)(vals[i] + mean), or the constant value (Conditioner.cpp:66-96)
+template <typename T>
+__global__ void k_scatter_uncondition(T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
+                                      uint32_t cx, uint32_t cy, uint32_t n, const double* vals,
+                                      size_t valsStride, const CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  const ChunkGeom g = geom[c];
+  const double mean = st[c].mean;
+  const bool is_const = st[c].is_const != 0;
+  const size_t vx = vd.dims[0], vy = vd.dims[1];
+  const double* in = vals + c * valsStride;
+  for (uint32_t i = blockIdx.x * blockDim.x * 4 + threadIdx.x, k = 0; k < 4 && i < n;
+       k++, i += blockDim.x) {
+    const uint32_t x = i % cx, r = i / cx;
+    const uint32_t y = r % cy, z = r / cy;
+    const double v = is_const ? mean : in[i] + mean;
+    vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x] = (T)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CDF 9/7 lifting along one axis, LDS-staged line tiles
+// ------------------------------------------------------------------------------------------
+//
+// A workgroup stages NL adjacent lines of length `len` in LDS as sm[pos * (NL+1) + line] with the
+// samples already de-interleaved ([even | odd], src/CDF97.cpp:476-519), runs the four lifting
+// steps + scaling with a barrier between dependent steps, and writes the lines back.  For the Y
+// and Z axes the NL lines are NL consecutive x positions, so every global access is a coalesced
+// NL*8-byte segment; for the X axis the lines are NL consecutive rows and lanes run along x.
+
+extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+
+template <bool FORWARD>
+__global__ void __launch_bounds__(kThreads)
+k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis, uint32_t rx,
+            uint32_t ry, uint32_t rz, int NL, LiftConsts K, const CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  if (st[c].is_const)
+    return;
+  double* sm = reinterpret_cast<double*>(dyn_smem);
+  double* buf = vals + c * valsStride;
+  const uint32_t region[3] = {rx, ry, rz};
+  const size_t stride[3] = {1, cx, (size_t)cx * cy};
+  const int ua = (axis == 0) ? 1 : 0;            // axis along which the NL lines are adjacent
+  const int wa = (axis == 2) ? 1 : 2;            // remaining axis
+  const uint32_t len = region[axis];
+  const uint32_t ntu = (region[ua] + NL - 1) / NL;
+  const uint32_t tu = blockIdx.x % ntu, tw = blockIdx.x / ntu;
+  const uint32_t u0 = tu * NL;
+  const uint32_t nl = min((uint32_t)NL, region[ua] - u0);  // valid lines in this tile
+  double* tile = buf + (size_t)u0 * stride[ua] + (size_t)tw * stride[wa];
+  const size_t sl = stride[axis], su = stride[ua];
+  const int NLP = NL + 1;
+  const uint32_t even_len = len - len / 2, odd_len = len / 2;
+  const int tid = threadIdx.x;
+
+  // ---- load ----
+  if (axis == 0) {  // lanes along the line
+    for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
+      for (uint32_t p = tid % 64; p < len; p += 64) {
+        const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
+        sm[dst * NLP + l] = tile[l * su + p];
+      }
+  }
+  else {            // lanes across the lines
+    const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
+    if (l < nl)
+      for (uint32_t p = k0; p < len; p += kg) {
+        const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
+        sm[dst * NLP + l] = tile[l * su + p * sl];
+      }
+  }
+  __syncthreads();
+
+  // ---- lift ----
+  {
+    const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
+    double* E = sm + l;
+    double* O = sm + (size_t)even_len * NLP + l;
+#define EV(i) E[(size_t)(i) * NLP]
+#define OD(i) O[(size_t)(i) * NLP]
+    auto odd_step = [&](double k) {
+      if (l < nl)
+        for (uint32_t i = k0; i < odd_len; i += kg) {
+          const uint32_t r = min(i + 1, even_len - 1);
+          OD(i) = fma(k, EV(i) + EV(r), OD(i));
+        }
+      __syncthreads();
+    };
+    auto even_step = [&](double k) {
+      if (l < nl)
+        for (uint32_t i = k0; i < even_len; i += kg) {
+          const uint32_t a = max(i, 1u) - 1, b = min(i, odd_len - 1);
+          EV(i) = fma(k, OD(a) + OD(b), EV(i));
+        }
+      __syncthreads();
+    };
+    if (FORWARD) {  // src/CDF97.cpp:598-631
+      odd_step(K.alpha);
+      even_step(K.beta);
+      odd_step(K.gamma);
+      if (l < nl) {
+        for (uint32_t i = k0; i < even_len; i += kg) {
+          const uint32_t a = max(i, 1u) - 1, b = min(i, odd_len - 1);
+          EV(i) = K.eps * fma(K.delta, OD(a) + OD(b), EV(i));
+        }
+      }
+      __syncthreads();
+      if (l < nl)
+        for (uint32_t i = k0; i < odd_len; i += kg)
+          OD(i) = (-K.inv_eps) * OD(i);
+      __syncthreads();
+    }
+    else {          // src/CDF97.cpp:633-666
+      if (l < nl)
+        for (uint32_t i = k0; i < odd_len; i += kg)
+          OD(i) = (-K.eps) * OD(i);
+      __syncthreads();
+      if (l < nl)
+        for (uint32_t i = k0; i < even_len; i += kg) {
+          const uint32_t a = max(i, 1u) - 1, b = min(i, odd_len - 1);
+          const double t = K.delta * (OD(a) + OD(b));
+          EV(i) = fma(EV(i), K.inv_eps, -t);
+        }
+      __syncthreads();
+      odd_step(-K.gamma);
+      even_step(-K.beta);
+      odd_step(-K.alpha);
+    }
+#undef EV
+#undef OD
+  }
+
+  // ---- store ----
+  if (axis == 0) {
+    for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
+      for (uint32_t p = tid % 64; p < len; p += 64) {
+        const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
+        tile[l * su + p] = sm[src * NLP + l];
+      }
+  }
+  else {
+    const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
+    if (l < nl)
+      for (uint32_t p = k0; p < len; p += kg) {
+        const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
+        tile[l * su + p * sl] = sm[src * NLP + l];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// quantiser
+// ------------------------------------------------------------------------------------------
+
+__global__ void k_maxabs(const double* vals, size_t valsStride, uint32_t n, CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  if (st[c].is_const)
+    return;
+  const double* in = vals + c * valsStride;
+  double m = 0.0;
+  for (uint32_t i = blockIdx.x * blockDim.x * 8 + threadIdx.x, k = 0; k < 8 && i < n;
+       k++, i += blockDim.x)
+    m = fmax(m, fabs(in[i]));
+  for (int d = 32; d > 0; d >>= 1)
+    m = fmax(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.0)  // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(&st[c].maxabs),
+              (unsigned long long)__double_as_longlong(m));
+}
+
+// SPECK_FLT.cpp:282-301 (fixed-rate q) ; `wide` selects the high-precision retry
+__global__ void k_make_q_rate(CoderState* st, uint32_t nchunks, int wide_pass)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks)
+    return;
+  if (wide_pass) {
+    if (!st[c].need_retry)
+      return;
+    st[c].q = st[c].maxabs / 0x1.fffffffffffffp52;
+    st[c].wide = 1;
+  }
+  else {
+    st[c].q = st[c].maxabs / 4294967295.0;
+    st[c].wide = 0;
+  }
+}
+
+// SPECK_FLT.cpp:345-368 : ll = llrint(v * (1/q)) ; sign bit = (ll >= 0) ; magnitude ; plus the
+// msb position that the coder's significance pyramid starts from.  One wave = one sign word.
+template <typename CT>
+__global__ void k_quantize(const double* vals, size_t valsStride, uint32_t n, CT* coef,
+                           size_t coefStride, uint64_t* sign, size_t signStride, int8_t* msb,
+                           size_t msbStride, const CoderState* st, int wide_pass)
+{
+  const uint32_t c = blockIdx.y;
+  const CoderState& s = st[c];
+  if (s.is_const || (wide_pass && !s.need_retry))
+    return;
+  const double inv = 1.0 / s.q;
+  const double* in = vals + c * valsStride;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  long long ll = 0;
+  bool nonneg = false;
+  if (i < n) {
+    ll = __double2ll_rn(in[i] * inv);
+    nonneg = ll >= 0;
+    const unsigned long long mag = (unsigned long long)(ll < 0 ? -ll : ll);
+    coef[c * coefStride + i] = (CT)mag;
+    msb[c * msbStride + i] = mag ? (int8_t)(63 - __clzll((long long)mag)) : (int8_t)-1;
+  }
+  const unsigned long long word = __ballot(nonneg);
+  if ((threadIdx.x & 63) == 0 && i < n)
+    sign[c * signStride + (i >> 6)] = word;
+}
+
+// SPECK_FLT.cpp:373-399 : (q * c) * (+-1.0), left to right
+template <typename CT>
+__global__ void k_inv_quantize(const CT* coef, size_t coefStride, const uint64_t* sign,
+                               size_t signStride, uint32_t n, double* vals, size_t valsStride,
+                               const CoderState* st, int wide_pass)
+{
+  const uint32_t c = blockIdx.y;
+  const CoderState& s = st[c];
+  if (s.is_const || (int)s.wide != wide_pass)
+    return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const double sg = ((sign[c * signStride + (i >> 6)] >> (i & 63)) & 1) ? 1.0 : -1.0;
+  vals[c * valsStride + i] = s.q * (double)coef[c * coefStride + i] * sg;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+
+LiftConsts lift_consts()
+{
+  // include/CDF97.h:136-147 evaluated in IEEE fp64 (bit patterns: SURVEY.md Appendix B)
+  auto bits = [](uint64_t b) {
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+  };
+  LiftConsts k;
+  k.alpha = bits(0xbff960ce676352c0ull);
+  k.beta = bits(0xbfab2035c938c1f9ull);
+  k.gamma = bits(0x3fec40ceba5579b7ull);
+  k.delta = bits(0x3fdc626a9045727dull);
+  k.eps = bits(0x3ff264c795071559ull);
+  k.inv_eps = bits(0x3febd5edf975cca4ull);
+  return k;
+}
+
+static int pick_nl(uint32_t len, size_t* smem)
+{
+  for (int nl = 32; nl >= 1; nl >>= 1) {
+    const size_t bytes = (size_t)len * (nl + 1) * sizeof(double);
+    if (bytes <= 72 * 1024 || nl == 1) {
+      *smem = bytes;
+      return nl;
+    }
+  }
+  return 1;
+}
+
+int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
+                uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
+                const CoderState* st)
+{
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lift_axis<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lift_axis<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const uint32_t len = region[axis];
+  if (len < 2)
+    return 0;
+  size_t smem = 0;
+  const int NL = pick_nl(len, &smem);
+  if (smem > 160 * 1024) {
+    fprintf(stderr, "[sperr_hip] line of %u samples does not fit in LDS\n", len);
+    return -1;
+  }
+  const int ua = (axis == 0) ? 1 : 0, wa = (axis == 2) ? 1 : 2;
+  const uint32_t ntu = (region[ua] + NL - 1) / NL;
+  dim3 grid(ntu * region[wa], nchunks);
+  const LiftConsts K = lift_consts();
+  if (forward)
+    LAUNCH_K(k_lift_axis<true>, grid, dim3(kThreads), smem, stream, vals, valsStride,
+                       cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st);
+  else
+    LAUNCH_K(k_lift_axis<false>, grid, dim3(kThreads), smem, stream, vals, valsStride,
+                       cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
+                     uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
+                     double* strideMean, size_t strideMeanStride, double* vals,
+                     size_t valsStride, CoderState* st)
+{
+  const uint32_t n = cdims[0] * cdims[1] * cdims[2];
+  const uint32_t ssz = n / nstrides;
+  LAUNCH_K(k_stride_sums<T>, dim3((nstrides + 63) / 64, nchunks), dim3(64), 0, stream,
+                     vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz, strideMean,
+                     strideMeanStride, st);
+  LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(1), 0, stream, vol, vd, geom,
+                     nstrides, strideMean, strideMeanStride, st);
+  LAUNCH_K(k_gather_condition<T>, dim3((n + kThreads * 4 - 1) / (kThreads * 4), nchunks),
+                     dim3(kThreads), 0, stream, vol, vd, geom, cdims[0], cdims[1], n, vals,
+                     valsStride, st);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+template int launch_condition<float>(hipStream_t, const float*, VolDesc, const ChunkGeom*,
+                                     uint32_t, const uint32_t[3], uint32_t, double*, size_t,
+                                     double*, size_t, CoderState*);
+template int launch_condition<double>(hipStream_t, const double*, VolDesc, const ChunkGeom*,
+                                      uint32_t, const uint32_t[3], uint32_t, double*, size_t,
+                                      double*, size_t, CoderState*);
+
+template <typename T>
+int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
+                   uint32_t nchunks, const uint32_t cdims[3], const double* vals,
+                   size_t valsStride, const CoderState* st)
+{
+  const uint32_t n = cdims[0] * cdims[1] * cdims[2];
+  LAUNCH_K(k_scatter_uncondition<T>,
+                     dim3((n + kThreads * 4 - 1) / (kThreads * 4), nchunks), dim3(kThreads), 0,
+                     stream, vol, vd, geom, cdims[0], cdims[1], n, vals, valsStride, st);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+template int launch_scatter<float>(hipStream_t, float*, VolDesc, const ChunkGeom*, uint32_t,
+                                   const uint32_t[3], const double*, size_t, const CoderState*);
+template int launch_scatter<double>(hipStream_t, double*, VolDesc, const ChunkGeom*, uint32_t,
+                                    const uint32_t[3], const double*, size_t, const CoderState*);
+
+int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
+                    uint32_t n, CoderState* st)
+{
+  LAUNCH_K(k_maxabs, dim3((n + kThreads * 8 - 1) / (kThreads * 8), nchunks),
+                     dim3(kThreads), 0, stream, vals, valsStride, n, st);
+  LAUNCH_K(k_make_q_rate, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks,
+                     0);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_make_q_wide(hipStream_t stream, uint32_t nchunks, CoderState* st)
+{
+  LAUNCH_K(k_make_q_rate, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks,
+                     1);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t valsStride,
+                    uint32_t nchunks, uint32_t n, void* coef, size_t coefStride, uint64_t* sign,
+                    size_t signStride, int8_t* msb, size_t msbStride, const CoderState* st)
+{
+  dim3 grid((n + kThreads - 1) / kThreads, nchunks);
+  if (wide)
+    LAUNCH_K(k_quantize<uint64_t>, grid, dim3(kThreads), 0, stream, vals, valsStride, n,
+                       (uint64_t*)coef, coefStride, sign, signStride, msb, msbStride, st, 1);
+  else
+    LAUNCH_K(k_quantize<uint32_t>, grid, dim3(kThreads), 0, stream, vals, valsStride, n,
+                       (uint32_t*)coef, coefStride, sign, signStride, msb, msbStride, st, 0);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t coefStride,
+                        const uint64_t* sign, size_t signStride, uint32_t nchunks, uint32_t n,
+                        double* vals, size_t valsStride, const CoderState* st)
+{
+  dim3 grid((n + kThreads - 1) / kThreads, nchunks);
+  if (wide)
+    LAUNCH_K(k_inv_quantize<uint64_t>, grid, dim3(kThreads), 0, stream,
+                       (const uint64_t*)coef, coefStride, sign, signStride, n, vals, valsStride,
+                       st, 1);
+  else
+    LAUNCH_K(k_inv_quantize<uint32_t>, grid, dim3(kThreads), 0, stream,
+                       (const uint32_t*)coef, coefStride, sign, signStride, n, vals, valsStride,
+                       st, 0);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sperrhip

@@ -1,0 +1,283 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libsperr_hip.so, against
+the oracle (oracle/sperr_oracle.c, pinned to the reference) and the committed golden vectors.
+
+Bar: bit-exact containers and SPECK streams (integer / byte work); decoded floats are compared
+bit-for-bit as well -- the stated tolerance is 1 ULP of the output type, and the fp64 pipeline is
+reproduced exactly, so the observed difference is 0."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from fields import ramp_field, smooth_field
+from sperr_amd.synth import turbulence
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from sperr_amd.api import SperrHip
+    return SperrHip()
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def ulp_diff_f32(a, b):
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return int(np.abs(ia - ib).max())
+
+
+DWT_SHAPES = [(17, 17, 17), (32, 32, 32), (23, 45, 70), (41, 64, 64), (9, 40, 48), (64, 64, 64),
+              (128, 128, 128), (20, 300, 9)]
+
+
+@pytest.mark.parametrize("shape", DWT_SHAPES)
+def test_dwt_idwt_bit_exact(eng, oracle, shape):
+    v = turbulence(shape).astype(np.float64)
+    want = oracle.dwt3d(v)
+    d = cuda(v)
+    eng.dwt3d(d)
+    got = d.cpu().numpy()
+    assert np.array_equal(bits(got), bits(want))
+    eng.dwt3d(d, inverse=True)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(oracle.idwt3d(want)))
+
+
+def quantized(oracle, shape, scale):
+    v = oracle.dwt3d(turbulence(shape).astype(np.float64))
+    q = np.abs(v).max() / scale
+    coef, sign, _ = oracle.quantize(v, q)
+    return coef, sign
+
+
+def to_dev_coef(coef, wide):
+    if wide:
+        return cuda(coef.astype(np.uint64).view(np.int64))
+    return cuda(coef.astype(np.uint32).view(np.int32))
+
+
+SPECK_SHAPES = [(8, 8, 8), (16, 16, 16), (17, 17, 17), (13, 21, 30), (32, 32, 32), (9, 40, 48),
+                (41, 64, 64), (3, 5, 7), (1, 16, 16), (2, 2, 2), (48, 48, 48), (64, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", SPECK_SHAPES)
+@pytest.mark.parametrize("budget", [0, 1000, 20000])
+def test_speck_encode_bit_exact(eng, oracle, shape, budget):
+    coef, sign = quantized(oracle, shape, 3000.0)
+    want = oracle.speck3d_encode(coef, sign, budget)
+    got = eng.speck3d_encode(to_dev_coef(coef, False), cuda(sign.view(np.int64)), budget)
+    assert got[:9] == want[:9]
+    assert got == want
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (13, 21, 30), (32, 32, 32)])
+def test_speck_encode_wide_and_32bit_range(eng, oracle, shape):
+    for scale, wide in [(4294967295.0, False), (float(2 ** 53 - 1), True)]:
+        coef, sign = quantized(oracle, shape, scale)
+        for budget in (0, 50000):
+            want = oracle.speck3d_encode(coef, sign, budget)
+            got = eng.speck3d_encode(to_dev_coef(coef, wide), cuda(sign.view(np.int64)), budget)
+            assert got == want
+
+
+def test_speck_encode_zero_and_sparse(eng, oracle):
+    coef = np.zeros((12, 12, 12), dtype=np.uint64)
+    sign = np.full((coef.size + 63) // 64, np.uint64(0xFFFFFFFFFFFFFFFF))
+    for _ in range(3):
+        want = oracle.speck3d_encode(coef, sign, 0)
+        got = eng.speck3d_encode(to_dev_coef(coef, False), cuda(sign.view(np.int64)), 0)
+        assert got == want
+        coef[3, 4, 5] += 77
+        coef[11, 0, 2] += 1
+
+
+@pytest.mark.parametrize("shape", SPECK_SHAPES)
+@pytest.mark.parametrize("budget", [0, 1000, 20000])
+def test_speck_decode_bit_exact(eng, oracle, shape, budget):
+    coef, sign = quantized(oracle, shape, 3000.0)
+    stream = oracle.speck3d_encode(coef, sign, budget)
+    for cut in (len(stream), 9 + (len(stream) - 9) // 2, 9 + (len(stream) - 9) // 7):
+        s = stream[:cut]
+        c0, s0 = oracle.speck3d_decode(s, shape)
+        c1, s1 = eng.speck3d_decode(s, shape)
+        assert np.array_equal(c0, c1)
+        assert np.array_equal(s0, s1)
+
+
+def test_speck_decode_wide(eng, oracle):
+    shape = (16, 20, 24)
+    coef, sign = quantized(oracle, shape, float(2 ** 53 - 1))
+    stream = oracle.speck3d_encode(coef, sign, 0)
+    assert stream[0] > 32
+    c0, s0 = oracle.speck3d_decode(stream, shape)
+    c1, s1 = eng.speck3d_decode(stream, shape)
+    assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+
+
+with open(os.path.join(GOLD, "golden.json")) as f:
+    CASES = json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
+def test_golden_vectors(eng, case):
+    """Containers produced by the REAL reference (tests/golden/make_golden.py)."""
+    name, shape = case["input"], tuple(case["shape_zyx"])
+    path = os.path.join(GOLD, name + ".f32")
+    if os.path.exists(path):
+        arr = np.fromfile(path, dtype=np.float32).reshape(shape)
+    else:
+        arr = smooth_field(shape, dtype=np.dtype(case["dtype"]))
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == case["input_sha256"]
+    with open(os.path.join(GOLD, case["tag"] + ".sperr"), "rb") as f:
+        want = f.read()
+    got = bytes(eng.compress(cuda(arr), case["chunks_xyz"], case["bpp"]).cpu().numpy())
+    assert len(got) == case["stream_len"]
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    dec_f = eng.decompress(dev, True).cpu().numpy()
+    dec_d = eng.decompress(dev, False).cpu().numpy()
+    assert hashlib.sha256(dec_f.tobytes()).hexdigest() == case["decoded_f32_sha256"]
+    assert hashlib.sha256(dec_d.tobytes()).hexdigest() == case["decoded_f64_sha256"]
+
+
+@pytest.mark.parametrize("shape,chunks", [((50, 64, 72), (32, 32, 32)), ((50, 64, 72), (40, 30, 20)),
+                                          ((64, 64, 64), (64, 64, 64)), ((41, 128, 128), (64, 64, 41)),
+                                          ((96, 96, 96), (48, 48, 48))])
+@pytest.mark.parametrize("bpp", [0.5, 2.0, 6.5])
+def test_container_matches_oracle(eng, oracle, shape, chunks, bpp):
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 1, bpp)
+    got = bytes(eng.compress(cuda(v), chunks, bpp).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    f_got, f_want = eng.decompress(dev, True).cpu().numpy(), oracle.decomp_3d(want, True)
+    assert ulp_diff_f32(f_got, f_want) <= 1           # stated tolerance: 1 ULP (fp32)
+    assert np.array_equal(bits(f_got), bits(f_want))  # observed: identical
+    assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, False)))
+
+
+def test_high_precision_retry(eng, oracle):
+    """src/SPECK_FLT.cpp:530-538: 32 planes cannot fill the budget -> 53 planes, 64-bit ints."""
+    r = ramp_field((16, 16, 16))
+    for bpp in (30.0, 60.0):
+        want = oracle.comp_3d(r, (16, 16, 16), 1, bpp)
+        assert want[18 + 17] == 53
+        got = bytes(eng.compress(cuda(r), (16, 16, 16), bpp).cpu().numpy())
+        assert got == want
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()),
+                              bits(oracle.decomp_3d(want, True)))
+    # a volume where only SOME chunks retry
+    v = turbulence((32, 32, 64))
+    v[:, :, 32:] = ramp_field((32, 32, 32))
+    want = oracle.comp_3d(v, (32, 32, 32), 1, 40.0)
+    assert bytes(eng.compress(cuda(v), (32, 32, 32), 40.0).cpu().numpy()) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, False)))
+
+
+def test_constant_and_mixed_chunks(eng, oracle):
+    v = turbulence((32, 32, 64))
+    v[:, :, :32] = 1.25                       # first chunk constant -> 17-byte stream
+    want = oracle.comp_3d(v, (32, 32, 32), 1, 2.0)
+    got = bytes(eng.compress(cuda(v), (32, 32, 32), 2.0).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, True)))
+    c = np.full((16, 20, 32), -3.5, dtype=np.float32)
+    assert bytes(eng.compress(cuda(c), (32, 20, 16), 2.0).cpu().numpy()) == \
+        oracle.comp_3d(c, (32, 20, 16), 1, 2.0)
+
+
+def test_double_input(eng, oracle):
+    v = smooth_field((24, 40, 40), dtype=np.float64)
+    want = oracle.comp_3d(v, (40, 40, 24), 1, 3.0)
+    assert bytes(eng.compress(cuda(v), (40, 40, 24), 3.0).cpu().numpy()) == want
+
+
+def test_reference_c_api_drop_in(eng, oracle):
+    """sperr_comp_3d / sperr_decomp_3d / sperr_parse_header with host buffers and the reference's
+    return codes (include/SPERR_C_API.h:100-105)."""
+    import ctypes as C
+    v = turbulence((40, 48, 56))
+    want = oracle.comp_3d(v, (32, 32, 32), 1, 2.0)
+    got = eng.comp_3d(v, (32, 32, 32), 1, 2.0)
+    assert got == want
+    assert np.array_equal(bits(eng.decomp_3d(want, True)), bits(oracle.decomp_3d(want, True)))
+    assert np.array_equal(bits(eng.decomp_3d(want, False)), bits(oracle.decomp_3d(want, False)))
+    dx, dy, dz, isf = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+    buf = np.frombuffer(want, dtype=np.uint8)
+    eng.lib.sperr_parse_header(buf.ctypes.data, C.byref(dx), C.byref(dy), C.byref(dz), C.byref(isf))
+    assert (dx.value, dy.value, dz.value, isf.value) == (56, 48, 40, 1)
+    # return codes: *dst not NULL -> 1 ; quality <= 0 -> 2 ; unknown mode -> 2
+    dst, n = C.c_void_p(1234), C.c_size_t(0)
+    args = (v.ctypes.data, 1, 56, 48, 40, 32, 32, 32)
+    assert eng.lib.sperr_comp_3d(*args, 1, 2.0, 0, C.byref(dst), C.byref(n)) == 1
+    dst = C.c_void_p(None)
+    assert eng.lib.sperr_comp_3d(*args, 1, -1.0, 0, C.byref(dst), C.byref(n)) == 2
+    assert eng.lib.sperr_comp_3d(*args, 7, 2.0, 0, C.byref(dst), C.byref(n)) == 2
+
+
+def test_truncated_container_is_rejected(eng, oracle):
+    v = turbulence((32, 32, 32))
+    s = oracle.comp_3d(v, (32, 32, 32), 1, 2.0)
+    import ctypes as C
+    buf = np.frombuffer(s[:-5], dtype=np.uint8)
+    dst = C.c_void_p(None)
+    d = [C.c_size_t(0) for _ in range(3)]
+    assert eng.lib.sperr_decomp_3d(buf.ctypes.data, buf.size, 1, 0, C.byref(d[0]), C.byref(d[1]),
+                                   C.byref(d[2]), C.byref(dst)) == -1
+
+
+def test_256_cube_chunk_bpp2(eng, oracle):
+    """The metric's unit of work: one 256^3 fp32 chunk at 2 bpp, byte-identical to the oracle."""
+    v = turbulence((256, 256, 256))
+    want = oracle.comp_3d(v, (256, 256, 256), 1, 2.0)
+    got = bytes(eng.compress(cuda(v), (256, 256, 256), 2.0).cpu().numpy())
+    assert len(got) == 4194348
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, True)))
+
+
+def test_full_size_roundtrip_properties(eng):
+    """512^3 in 256^3 chunks at 2 bpp: size-independent properties -- exact stream length,
+    determinism (checksum of two runs), bounded error, chunk independence (a chunk's stream does
+    not depend on its neighbours)."""
+    import torch
+    from sperr_amd.synth import turbulence_torch
+    vol = turbulence_torch((512, 512, 512), "cuda")
+    s1 = eng.compress(vol, (256, 256, 256), 2.0).clone()
+    s2 = eng.compress(vol, (256, 256, 256), 2.0)
+    assert s1.numel() == 20 + 4 * 8 + 8 * (17 + 9 + 4194304)
+    assert torch.equal(s1, s2)
+    back = eng.decompress(s1, True)
+    err = (back.double() - vol.double()).abs().max().item()
+    rng = (vol.max() - vol.min()).item()
+    assert err < 5e-3 * rng
+    sub = vol[:256, :256, 256:].contiguous()
+    s_sub = eng.compress(sub, (256, 256, 256), 2.0)
+    hdr = 20 + 4 * 8
+    one = 17 + 9 + 4194304
+    assert torch.equal(s_sub[18:], s1[hdr + one: hdr + 2 * one])
