@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on one node: SPERR 3D fixed-rate compress + decompress
+throughput (GB/s of uncompressed fp32 bytes) on 256^3 chunks at BPP = 2.0.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic volume already resident in HBM:
+compress the volume into a SPERR container (device memory) and decompress that container back
+into a device volume.  Every rank owns its own volume of `--size`^3 fp32 samples cut into
+256^3 chunks (independent chunks, no data-path collective: weak scaling).  `value` is the
+whole-job rate: N * volume bytes / max-over-ranks(time per step).
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel's algorithmic bytes / its measured time vs the HBM peak
+  cpu_baseline  the CPU oracle (the real reference build when oracle/_ref is present, else this
+                repo's C restatement) timed on a bounded sample of the same volume on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_VALUE = 4.25    # 4 B fp32 + BPP/8 B stream per value
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="volume edge per GPU")
+    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--bpp", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sperr_amd.api import SperrHip
+    from sperr_amd.synth import turbulence_torch
+
+    eng = SperrHip()   # raises if libsperr_hip.so is missing: there is no fallback path
+    S, C = args.size, args.chunk
+    vol = turbulence_torch((S, S, S), dev, seed=42 + rank)
+    nbytes = vol.numel() * 4
+    chunks = (C, C, C)
+    cap = eng.max_compressed_size(vol.shape, chunks, args.bpp)
+    cbuf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(vol)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(timers=None):
+        if timers is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+        stream = eng.compress(vol, chunks, args.bpp, out=cbuf)
+        if timers is not None:
+            e1.record()
+        eng.decompress(stream, output_float=True, out=out, shape_zyx=vol.shape)
+        if timers is not None:
+            e2.record()
+            timers.append((e0, e1, e2))
+        return stream
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)            # per-kernel HIP events on the launch stream, timed region only
+    timers = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stream = step(timers)
+    barrier()
+    t1 = time.perf_counter()
+    eng.profile(False)
+    prof = eng.profile_report()
+
+    dt = (t1 - t0) / args.steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+    tc = sum(a.elapsed_time(b) for a, b, _ in timers) / len(timers) / 1e3
+    td = sum(b.elapsed_time(c) for _, b, c in timers) / len(timers) / 1e3
+
+    # correctness on the timed data: exact container length, bounded round-trip error
+    nchunks = (S // C) ** 3
+    exp_len = (20 if nchunks > 1 else 14) + 4 * nchunks + nchunks * (17 + 9 + int(args.bpp * C ** 3) // 8)
+    err = float((out.double() - vol.double()).abs().max().item())
+    ok_len = int(stream.numel()) == exp_len
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events recorded by the engine, timed region) ----
+    kern = sorted(prof.items(), key=lambda kv: -kv[1][0])
+    top_name, (top_ms, top_launches) = kern[0]
+    per_step_ms = top_ms / args.steps
+    values = vol.numel()
+    achieved = ALGO_BYTES_PER_VALUE * values / (per_step_ms / 1e3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": top_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "launches_per_step": top_launches // args.steps,
+        "avg_launch_ms": round(top_ms / max(1, top_launches), 4),
+        "kernel_ms_per_step": round(per_step_ms, 3),
+        "top5_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kern[:5]},
+    }
+
+    # ---- CPU baseline on a bounded sample of the same volume, this host -----------------------
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        n = min(args.cpu_sample, S)
+        sample = vol[:n, :n, :n].contiguous().cpu().numpy()
+        cores = os.cpu_count() or 1
+        if pyoracle.have_ref():
+            impl, kind = pyoracle.Ref(), "reference"
+        else:
+            impl, kind = pyoracle.Oracle(), "port"
+        a = time.perf_counter()
+        cs = impl.comp_3d(sample, chunks, 1, args.bpp, nthreads=cores)
+        b = time.perf_counter()
+        impl.decomp_3d(cs, True, nthreads=cores)
+        c = time.perf_counter()
+        # parity of the timed data: the HIP container of the same sample must be byte-identical
+        hs = bytes(eng.compress(torch.from_numpy(sample).to(dev), chunks, args.bpp).cpu().numpy())
+        cpu = {
+            "value": round(sample.nbytes / (c - a) / 1e9, 4), "unit": "GB/s", "cores": cores,
+            "kind": kind,
+            "sample": f"{n}^3 fp32 corner of the bench volume, {C}^3 chunks, bpp {args.bpp}: "
+                      f"compress {b - a:.2f} s + decompress {c - b:.2f} s",
+            "compress_GBps": round(sample.nbytes / (b - a) / 1e9, 4),
+            "decompress_GBps": round(sample.nbytes / (c - b) / 1e9, 4),
+            "hip_stream_identical": hs == cs,
+        }
+
+    line = {
+        "metric": "compress+decompress GB/s/GPU on 256^3 fp32 chunks @ BPP=2.0; bitstream-exact vs ref",
+        "value": round(world * nbytes / dt_max / 1e9, 4),
+        "unit": "GB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt_max * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {S}^3 fp32 turbulence per GPU, {C}^3 chunks, BPP={args.bpp}, "
+                               "step = compress + decompress, volume and container resident in HBM",
+                   "chunks_per_gpu": nchunks, "parallelism": f"chunks farmed over {world} GPU(s), no collective"},
+        "compress_GBps_per_gpu": round(nbytes / tc / 1e9, 4),
+        "decompress_GBps_per_gpu": round(nbytes / td / 1e9, 4),
+        "container_bytes": int(stream.numel()), "container_len_exact": ok_len,
+        "max_abs_err": err,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

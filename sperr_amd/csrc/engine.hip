@@ -607,7 +607,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
 size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget)
 {
   Arena probe;
-  probe.base = nullptr;
+  probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // never dereferenced: size probe only
   probe.cap = ~size_t(0) / 2;
   EncBatchBufs tmp;
   carve_enc(probe, P, 1, raw_budget, tmp);
@@ -960,6 +960,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
     for (auto& r : g.second)
       maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
     Arena probe;
+    probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
     carve_dec(probe, *P, 1, maxPayload, tmp);
@@ -1348,6 +1349,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   LAUNCH_K(k_fake_condi_header, dim3(1), dim3(1), 0, st, wrap);
   HIP_CHECK(hipMemcpyAsync(wrap + 17, d_stream, stream_len, hipMemcpyDeviceToDevice, st));
   Arena probe;
+  probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
   probe.cap = ~size_t(0) / 2;
   DecBatchBufs tmp;
   carve_dec(probe, *P, 1, 17 + stream_len, tmp);

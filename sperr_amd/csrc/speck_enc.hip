@@ -651,7 +651,8 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
         atomicOr(&refw[(at >> 6) + 1], (unsigned long long)rval >> (64 - (at & 63)));
     }
     __syncthreads();
-    const uint64_t limitWord = (s.budget + 63) / 64;  // words at or past this hold no kept bit
+    // words at or past limitWord hold no kept bit (budget may be ~0: no overflow here)
+    const uint64_t limitWord = (s.budget >> 6) + ((s.budget & 63) ? 1 : 0);
     for (int w = threadIdx.x; w < kWords; w += blockDim.x) {
       const uint64_t lw = (lipBase >> 6) + w, rw = (refBase >> 6) + w;
       uint64_t lv = lipw[w], rv = refw[w];
