@@ -1285,10 +1285,14 @@ int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d
   if (!carve_enc(A, *P, 1, raw_budget, bb))
     return -1;
   EncBuffers e = bb.eb;
-  HIP_CHECK(hipMemsetAsync(e.cst, 0, sizeof(CoderState), st));
+  const bool wide = width == 8;
+  CoderState hcs;
+  memset(&hcs, 0, sizeof(hcs));
+  hcs.need_retry = wide ? 1u : 0u;  // the 64-bit pass only encodes chunks flagged for it
+  hcs.wide = wide ? 1u : 0u;
+  HIP_CHECK(hipMemcpyAsync(e.cst, &hcs, sizeof(CoderState), hipMemcpyHostToDevice, st));
   if (reset_enc_pass(st, bb, 1))
     return -1;
-  const bool wide = width == 8;
   const uint32_t n = P->N;
   HIP_CHECK(hipMemcpyAsync(const_cast<uint64_t*>(e.sign), d_sign, ((n + 63) / 64) * 8,
                            hipMemcpyDeviceToDevice, st));

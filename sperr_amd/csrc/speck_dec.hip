@@ -340,14 +340,65 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
-// LIS phase: serial walk, one wavefront (lane 0) per chunk
+// LIS phase: one wavefront per chunk walks the lists.  Control flow is wave-uniform (every lane
+// carries the same walker state; frames live in LDS); the lanes are used for what is parallel
+// inside the walk: copying runs of insignificant entries to the next list (one count-trailing-
+// zeros per run instead of one step per entry), evaluating the up-to-8 children of a splitting
+// set, and writing the pixel results.
 // ------------------------------------------------------------------------------------------
-struct WalkFrame {
-  Node nd;
-  Kids k;
-  int j;
-  bool found;
-  uint32_t kidlev;
+struct WFrame {
+  uint64_t packed;      // the splitting set
+  uint32_t ridx[8];     // raster index of every single-sample child
+  uint32_t base[3];     // child index = base + (ci >> axis & 1)
+  uint16_t childGrid;
+  uint8_t present;      // bit ci: child ci exists
+  uint8_t pixel;        // bit ci: child ci is a single sample
+  uint8_t next;         // next child slot to visit (0..8)
+  uint8_t found;        // some earlier child was significant
+  uint8_t last;         // slot of the last existing child
+  uint8_t kidlev;       // LIS level of the children
+  uint8_t sigmask;      // pixel children found significant
+  uint8_t signmask;     // their sign bits
+};
+
+struct BitReader {      // wave-uniform sequential reader with two words of look-ahead
+  const uint64_t* words;
+  uint64_t nwords;      // words at or past this index read as zero (zero padding)
+  uint64_t pos, cur, n1, n2;
+  __device__ __forceinline__ uint64_t load(uint64_t idx) const
+  {
+    return idx < nwords ? words[idx] : 0ull;
+  }
+  __device__ __forceinline__ void init(const uint64_t* w, uint64_t p, uint64_t avail)
+  {
+    words = w;
+    nwords = (avail + 63) / 64;
+    pos = p;
+    cur = load(p >> 6);
+    n1 = load((p >> 6) + 1);
+    n2 = load((p >> 6) + 2);
+  }
+  __device__ __forceinline__ uint64_t peek64() const
+  {
+    const int sh = (int)(pos & 63);
+    return sh ? (cur >> sh) | (n1 << (64 - sh)) : cur;
+  }
+  __device__ __forceinline__ void skip(uint32_t n)   // n <= 64
+  {
+    const uint64_t np = pos + n;
+    if ((np >> 6) != (pos >> 6)) {
+      cur = n1;
+      n1 = n2;
+      n2 = load((np >> 6) + 2);
+    }
+    pos = np;
+  }
+  __device__ __forceinline__ uint32_t get1()
+  {
+    const uint32_t bit = (uint32_t)((cur >> (pos & 63)) & 1ull);
+    skip(1);
+    return bit;
+  }
 };
 
 template <typename CT>
@@ -356,78 +407,167 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   const uint32_t c = blockIdx.x;
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
-  if (threadIdx.x != 0)
-    return;
+  __shared__ WFrame fr[kMaxDepth + 2];
+  __shared__ uint32_t nextLen[kMaxLevels];
   const Tree& t = b.tree;
+  const int lane = threadIdx.x;
   const uint64_t* words = b.stream + c * b.streamStride;
-  const uint64_t avail = s.avail;
-  uint64_t pos = s.lipStart + s.lipBits;
   int8_t* born = b.born + c * b.pixStride;
   int8_t* sigp = b.sigp + c * b.pixStride;
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
-  uint64_t* sign = b.sign + c * b.signStride;
+  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
   const CT thr = (CT)1 << p;
   const CT init = thr + thr - thr / 2 - 1;
   const uint32_t cur = s.cur, nx = cur ^ 1u;
-  uint32_t nextLen[kMaxLevels];
-  for (uint32_t l = 0; l < t.nlevels; l++)
+  for (uint32_t l = lane; l < t.nlevels; l += 64)
     nextLen[l] = 0;
-  WalkFrame st[kMaxDepth + 1];
+  __syncthreads();
+  BitReader rd;
+  rd.init(words, s.lipStart + s.lipBits, s.avail);
+
   for (uint32_t l = t.nlevels; l-- > 0;) {
     const uint32_t n = s.listLen[cur][l];
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
-    for (uint32_t e = 0; e < n; e++) {
-      const uint64_t packed = list[e];
-      if (!get_bit(words, pos++, avail)) {
-        b.lis[nx][c * b.lisStride + b.levelOff[l] + nextLen[l]++] = packed;
+    uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
+    uint32_t nkeep = 0, e = 0;
+    while (e < n) {
+      const uint64_t w = rd.peek64();
+      uint32_t z = w ? (uint32_t)__ffsll((long long)w) - 1u : 64u;
+      z = min(z, n - e);
+      if (z) {  // a run of insignificant entries: they stay, in order
+        if ((uint32_t)lane < z)
+          keep[nkeep + lane] = list[e + lane];
+        nkeep += z;
+        e += z;
+        rd.skip(z);
         continue;
       }
+      rd.skip(1);  // the entry's '1'
       int sp = 0;
-      auto push = [&](const Node& nd) {
-        WalkFrame& f = st[sp++];
-        f.nd = nd;
-        node_kids(t, nd, f.k);
-        f.j = 0;
-        f.found = false;
-        const NodeGeom q = node_geom(t, nd);
-        f.kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
-      };
-      push(unpack_node(packed));
-      while (sp > 0) {
-        WalkFrame& f = st[sp - 1];
-        if (f.j == f.k.n) {
-          sp--;
-          continue;
+      uint64_t enter = list[e++];
+      bool fresh = true;
+      while (sp >= 0) {
+        WFrame& f = fr[sp];
+        if (fresh) {  // set up the frame of the set `enter`
+          const Node nd = unpack_node(enter);
+          const Grid& g = t.grids[nd.grid];
+          const Root& r = t.roots[g.root];
+          int ee[3];
+          uint32_t base[3], splits = 0, cnt = 1, idx[3];
+          bool valid = lane < 8;
+          for (int a = 0; a < 3; a++) {
+            const bool sa = g.depth < r.D[a];
+            splits |= (sa ? 1u : 0u) << a;
+            ee[a] = sa ? g.e[a] + 1 : g.e[a];
+            base[a] = sa ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
+            const uint32_t bit = ((uint32_t)lane >> a) & 1u;
+            if (bit && !sa)
+              valid = false;
+            idx[a] = base[a] + bit;
+            cnt *= axis_len(r.len[a], ee[a], idx[a]);
+          }
+          if (!valid)
+            cnt = 0;
+          const uint32_t present = (uint32_t)(__ballot(cnt > 0) & 0xffull);
+          const uint32_t pixel = (uint32_t)(__ballot(cnt == 1) & 0xffull);
+          const NodeGeom q = node_geom(t, nd);
+          const uint32_t kidlev =
+              node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+          if (cnt == 1)
+            f.ridx[lane] = pixel_raster(t, r, ee, idx);
+          if (lane == 0) {
+            f.packed = enter;
+            f.base[0] = base[0];
+            f.base[1] = base[1];
+            f.base[2] = base[2];
+            f.childGrid = (uint16_t)(nd.grid + 1);
+            f.present = (uint8_t)present;
+            f.pixel = (uint8_t)pixel;
+            f.next = 0;
+            f.found = 0;
+            f.last = (uint8_t)(31 - __clz((int)present));
+            f.kidlev = (uint8_t)kidlev;
+            f.sigmask = 0;
+            f.signmask = 0;
+          }
+          __syncthreads();
+          fresh = false;
         }
-        const int j = f.j++;
-        const bool coded = f.found || (j + 1 != f.k.n);
-        const bool sig = coded ? (get_bit(words, pos++, avail) != 0) : true;
-        if (sig)
-          f.found = true;
-        if (f.k.count[j] == 1) {
-          const uint32_t ridx = kid_raster(t, f.nd, f.k, j);
-          born[ridx] = (int8_t)p;
-          if (sig) {
-            sigp[ridx] = (int8_t)p;
-            coef[ridx] = init;
-            if (!get_bit(words, pos++, avail))
-              sign[ridx >> 6] &= ~(1ull << (ridx & 63));
+        // visit the children in order until one of them has to be entered
+        uint32_t nextc = f.next, found = f.found, sigmask = f.sigmask, signmask = f.signmask;
+        const uint32_t present = f.present, pixel = f.pixel, last = f.last;
+        bool descend = false;
+        while (nextc < 8) {
+          const uint32_t ci = nextc++;
+          if (!((present >> ci) & 1u))
+            continue;
+          const bool coded = found || ci != last;
+          const uint32_t sig = coded ? rd.get1() : 1u;
+          found |= sig;
+          if ((pixel >> ci) & 1u) {
+            if (sig) {
+              sigmask |= 1u << ci;
+              signmask |= rd.get1() << ci;
+            }
+          }
+          else {
+            Node kid;
+            kid.grid = f.childGrid;
+            kid.i[0] = (uint16_t)(f.base[0] + (ci & 1u));
+            kid.i[1] = (uint16_t)(f.base[1] + ((ci >> 1) & 1u));
+            kid.i[2] = (uint16_t)(f.base[2] + ((ci >> 2) & 1u));
+            if (sig) {
+              enter = pack_node(kid);
+              descend = true;
+              break;
+            }
+            const uint32_t kl = f.kidlev;
+            if (lane == 0) {
+              b.lis[nx][c * b.lisStride + b.levelOff[kl] + nextLen[kl]] = pack_node(kid);
+              nextLen[kl]++;
+            }
           }
         }
-        else if (sig)
-          push(kid_node(f.k, j));
-        else
-          b.lis[nx][c * b.lisStride + b.levelOff[f.kidlev] + nextLen[f.kidlev]++] =
-              pack_node(kid_node(f.k, j));
+        __syncthreads();
+        if (lane == 0) {
+          f.next = (uint8_t)nextc;
+          f.found = (uint8_t)found;
+          f.sigmask = (uint8_t)sigmask;
+          f.signmask = (uint8_t)signmask;
+        }
+        __syncthreads();
+        if (descend) {
+          sp++;
+          fresh = true;
+          continue;
+        }
+        // all children visited: lanes 0..7 write the pixel results, then leave the frame
+        if (lane < 8 && ((present & pixel) >> lane) & 1u) {
+          const uint32_t ridx = f.ridx[lane];
+          born[ridx] = (int8_t)p;
+          if ((sigmask >> lane) & 1u) {
+            sigp[ridx] = (int8_t)p;
+            coef[ridx] = init;
+            if (!((signmask >> lane) & 1u))
+              atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+          }
+        }
+        __syncthreads();
+        sp--;
       }
     }
+    if (lane == 0)
+      nextLen[l] += nkeep;  // nothing was appended to this level yet: survivors come first
+    __syncthreads();
   }
-  for (uint32_t l = 0; l < t.nlevels; l++)
+  for (uint32_t l = lane; l < t.nlevels; l += 64)
     s.listLen[nx][l] = nextLen[l];
-  s.cur = nx;
-  s.pos = pos;
-  if (pos >= avail)  // SPECK_INT.cpp:200-201
-    s.done = 1;
+  if (lane == 0) {
+    s.cur = nx;
+    s.pos = rd.pos;
+    if (rd.pos >= s.avail)  // SPECK_INT.cpp:200-201
+      s.done = 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -449,4 +449,469 @@ int model_speck3d_decode(const uint8_t* stream, size_t len, const size_t dims[3]
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Model of the PARALLEL LIS-phase decoder (kernel k_lis_tables in speck_dec.hip).
+//
+// For a list whose entries all have the same power-of-two shape ("regular" level) the code of an
+// entry is '0' or '1' + the split of a class-(K-1) set; a class-j set has arity[j] children of
+// class j-1 (class 0: children are pixels).  For a window of W stream bits the kernel computes,
+// for EVERY bit position x and every class j, T_j[x] = number of bits the split of a class-j set
+// would take if it started at x (INF when it would leave the window).  That is speculative and
+// embarrassingly parallel.  A cheap serial walk then only hops over entries (1 + T lookups), and
+// every set that splits inside the window is expanded by an independent thread that locates its
+// children with T_{j-1}.  Sets that stay insignificant are collected with their stream position;
+// their order in the next list is the order of those positions.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct LevelClass {
+  bool regular = false;
+  int K = 0;              // number of set classes from this level's shape down to leaf parents
+  int arity[20];          // children per class (index 0 = leaf parent)
+  uint32_t lev[20];       // LIS level of class-j nodes
+};
+
+// shape bookkeeping per level (host side of the plan)
+std::vector<LevelClass> classify_levels(const HostTree& ht)
+{
+  const Tree t = ht.view();
+  std::vector<LevelClass> lc(t.nlevels);
+  std::vector<std::array<uint32_t, 3>> shape(t.nlevels, {0, 0, 0});
+  std::vector<int> state(t.nlevels, 0);  // 0 unseen, 1 uniform so far, 2 mixed
+  for (uint32_t id = 0; id < t.nnodes; id++) {
+    Node nd;
+    if (!node_from_flat(t, id, nd))
+      continue;
+    const NodeGeom q = node_geom(t, nd);
+    if (!(q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1)))
+      continue;
+    const uint32_t l = node_level(t, nd);
+    const std::array<uint32_t, 3> sh = {q.len[0], q.len[1], q.len[2]};
+    if (state[l] == 0) {
+      shape[l] = sh;
+      state[l] = 1;
+    }
+    else if (state[l] == 1 && shape[l] != sh)
+      state[l] = 2;
+  }
+  for (uint32_t l = 0; l < t.nlevels; l++) {
+    if (state[l] != 1)
+      continue;
+    auto sh = shape[l];
+    bool pow2 = true;
+    for (int a = 0; a < 3; a++)
+      pow2 &= (sh[a] & (sh[a] - 1)) == 0;
+    if (!pow2 || sh[0] * sh[1] * sh[2] < 2)
+      continue;
+    // chain of shapes down to the leaf parent
+    std::vector<int> ar;
+    std::vector<uint32_t> lv;
+    uint32_t cl = l;
+    for (;;) {
+      int ns = (sh[0] > 1) + (sh[1] > 1) + (sh[2] > 1);
+      ar.push_back(1 << ns);
+      lv.push_back(cl);
+      cl += ns;
+      for (int a = 0; a < 3; a++)
+        if (sh[a] > 1)
+          sh[a] /= 2;
+      if (sh[0] * sh[1] * sh[2] == 1)
+        break;
+    }
+    LevelClass& c = lc[l];
+    c.regular = true;
+    c.K = (int)ar.size();
+    for (int j = 0; j < c.K; j++) {  // index 0 = leaf parent = last pushed
+      c.arity[j] = ar[c.K - 1 - j];
+      c.lev[j] = lv[c.K - 1 - j];
+    }
+  }
+  return lc;
+}
+
+constexpr uint32_t T_INF = 0xffffffffu;
+
+struct ParCtx {
+  int cls;          // class of the items of this context
+  int remaining;    // items left
+  bool found;       // an earlier sibling was significant
+  bool top;         // base context: list entries, always coded
+  Node parent;      // parent node of the items (unused for top)
+  int nextOrdinal;  // ordinal of the next child
+};
+
+struct WorkItem {
+  Node nd;
+  int cls;
+  uint64_t pos;     // first bit of the node's split
+};
+
+// child `ord` (x-fastest over the axes that split) of a regular node
+Node regular_child(const Tree& t, const Node& nd, int ord)
+{
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  Node c;
+  c.grid = (uint16_t)(nd.grid + 1);
+  int bit = 0;
+  for (int a = 0; a < 3; a++) {
+    if (g.depth < r.D[a]) {
+      c.i[a] = (uint16_t)(nd.i[a] * 2 + ((ord >> bit) & 1));
+      bit++;
+    }
+    else
+      c.i[a] = nd.i[a];
+  }
+  return c;
+}
+
+uint32_t regular_child_raster(const Tree& t, const Node& nd, int ord)
+{
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  int e[3];
+  uint32_t idx[3];
+  int bit = 0;
+  for (int a = 0; a < 3; a++) {
+    if (g.depth < r.D[a]) {
+      e[a] = g.e[a] + 1;
+      idx[a] = nd.i[a] * 2u + ((ord >> bit) & 1);
+      bit++;
+    }
+    else {
+      e[a] = g.e[a];
+      idx[a] = nd.i[a];
+    }
+  }
+  return pixel_raster(t, r, e, idx);
+}
+
+}  // namespace
+
+int g_model_window = 256;  // window size in bits (tests shrink it to stress the boundaries)
+
+// same contract as model_speck3d_decode; regular levels go through the table-driven path
+int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dims[3],
+                             uint64_t* coef, uint64_t* sign, int window)
+{
+  if (window > 0)
+    g_model_window = window;
+  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  const Tree t = ht.view();
+  const std::vector<LevelClass> lc = classify_levels(ht);
+  const size_t N = t.nvals;
+  const int nbp = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  uint64_t avail = (uint64_t)(len - 9) * 8;
+  if (avail > total_bits)
+    avail = total_bits;
+  BitSrc in{stream + 9, avail};
+  std::vector<int8_t> born(N, -1), sigp(N, -1);
+  memset(coef, 0, N * sizeof(uint64_t));
+  memset(sign, 0xff, ((N + 63) / 64) * 8);
+  auto set_sign = [&](uint32_t i, int b) {
+    if (b)
+      sign[i >> 6] |= uint64_t(1) << (i & 63);
+    else
+      sign[i >> 6] &= ~(uint64_t(1) << (i & 63));
+  };
+  std::vector<std::vector<uint64_t>> lis(ht.initLIS), next(t.nlevels);
+  uint64_t pos = 0;
+  for (int p = nbp - 1; p >= 0; p--) {
+    const uint64_t thr = uint64_t(1) << p;
+    const uint64_t init = thr + thr - thr / 2 - 1;
+    // ---- D1 (as in model_speck3d_decode)
+    {
+      std::vector<uint32_t> cand;
+      for (size_t i = 0; i < N; i++)
+        if (born[i] > p && sigp[i] < 0)
+          cand.push_back((uint32_t)i);
+      size_t j = 0;
+      uint64_t k = 0, ones = 0;
+      for (; j < cand.size(); k++) {
+        const int b = in.get(pos + k);
+        if ((ones & 1) == 0) {
+          if (b) {
+            sigp[cand[j]] = (int8_t)p;
+            coef[cand[j]] = init;
+            set_sign(cand[j], in.get(pos + k + 1));
+          }
+          j++;
+        }
+        ones = b ? ones + 1 : 0;
+      }
+      if (ones & 1)
+        k++;
+      pos += k;
+    }
+    // ---- D2, table-driven
+    struct BornRec {
+      uint32_t lev;
+      uint64_t pos;
+      uint64_t packed;
+    };
+    std::vector<BornRec> bornv;
+    for (uint32_t l = 0; l < t.nlevels; l++)
+      next[l].clear();
+    auto pixel_event = [&](uint32_t ridx, bool sig, uint64_t signpos) {
+      born[ridx] = (int8_t)p;
+      if (sig) {
+        sigp[ridx] = (int8_t)p;
+        coef[ridx] = init;
+        set_sign(ridx, in.get(signpos));
+      }
+    };
+    for (uint32_t l = t.nlevels; l-- > 0;) {
+      const size_t n = lis[l].size();
+      if (n == 0)
+        continue;
+      if (!lc[l].regular) {
+        // fallback: serial walk of this level (identical to model_speck3d_decode's D2)
+        for (uint64_t packed : lis[l]) {
+          if (!in.get(pos++)) {
+            next[l].push_back(packed);
+            continue;
+          }
+          struct Item {
+            Node nd;
+            Kids k;
+            int j;
+            bool found;
+            uint32_t kidlev;
+          };
+          std::vector<Item> st;
+          auto push = [&](const Node& nd) {
+            Item it;
+            it.nd = nd;
+            node_kids(t, nd, it.k);
+            it.j = 0;
+            it.found = false;
+            const NodeGeom q = node_geom(t, nd);
+            it.kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+            st.push_back(it);
+          };
+          push(unpack_node(packed));
+          while (!st.empty()) {
+            Item& it = st.back();
+            if (it.j == it.k.n) {
+              st.pop_back();
+              continue;
+            }
+            const int j = it.j++;
+            const bool coded = it.found || (j + 1 != it.k.n);
+            const bool sig = coded ? in.get(pos++) : true;
+            if (sig)
+              it.found = true;
+            if (it.k.count[j] == 1) {
+              const uint32_t ridx = kid_raster(t, it.nd, it.k, j);
+              pixel_event(ridx, sig, pos);
+              if (sig)
+                pos++;
+            }
+            else if (sig)
+              push(kid_node(it.k, j));
+            else
+              bornv.push_back({it.kidlev, pos - 1, pack_node(kid_node(it.k, j))});
+          }
+        }
+        continue;
+      }
+      const LevelClass& C = lc[l];
+      const int K = C.K;
+      const uint64_t W = (uint64_t)g_model_window;
+      // walker state
+      std::vector<ParCtx> ctx;
+      ctx.push_back({K - 1, (int)n, false, true, Node{}, 0});
+      size_t e = 0;  // next list entry
+      while (!ctx.empty()) {
+        // ---- window [a, a+W): tables (parallel in the kernel: one thread per position)
+        const uint64_t a = pos, lim = pos + W;
+        std::vector<std::vector<uint32_t>> T(K, std::vector<uint32_t>(W + 1, T_INF));
+        for (int j = 0; j < K; j++)
+          for (uint64_t x = a; x <= lim; x++) {
+            uint64_t y = x;
+            bool found = false, ok = true;
+            for (int i = 0; i < C.arity[j] && ok; i++) {
+              const bool coded = found || (i + 1 != C.arity[j]);
+              int b = 1;
+              if (coded) {
+                if (y >= lim) {
+                  ok = false;
+                  break;
+                }
+                b = in.get(y++);
+              }
+              if (!b)
+                continue;
+              found = true;
+              if (j == 0) {  // pixel child: sign bit
+                if (y >= lim) {
+                  ok = false;
+                  break;
+                }
+                y++;
+              }
+              else {
+                if (y > lim || T[j - 1][y - a] == T_INF) {
+                  ok = false;
+                  break;
+                }
+                y += T[j - 1][y - a];
+              }
+            }
+            if (ok)
+              T[j][x - a] = (uint32_t)(y - x);
+          }
+        // ---- serial walk over the window
+        std::vector<WorkItem> queue;
+        bool window_full = false;
+        while (!ctx.empty() && !window_full) {
+          ParCtx& c = ctx.back();
+          if (c.remaining == 0) {
+            ctx.pop_back();
+            continue;
+          }
+          const bool coded = c.top || c.found || c.remaining > 1;
+          uint64_t x = pos;
+          int b = 1;
+          if (coded) {
+            if (x >= lim) {
+              window_full = true;
+              break;
+            }
+            b = in.get(x);
+            x++;
+          }
+          // identity of the item
+          Node nd;
+          uint32_t ridx = 0;
+          const bool is_pixel = c.cls < 0;
+          if (c.top)
+            nd = unpack_node(lis[l][e]);
+          else if (is_pixel)
+            ridx = regular_child_raster(t, c.parent, c.nextOrdinal);
+          else
+            nd = regular_child(t, c.parent, c.nextOrdinal);
+          if (is_pixel) {
+            if (b && x >= lim) {  // sign bit not in the window
+              window_full = true;
+              break;
+            }
+            pixel_event(ridx, b != 0, x);
+            if (b) {
+              x++;
+              c.found = true;
+            }
+            c.remaining--;
+            c.nextOrdinal++;
+            pos = x;
+            continue;
+          }
+          if (!b) {
+            if (c.top) {
+              next[l].push_back(lis[l][e]);
+              e++;
+            }
+            else
+              bornv.push_back({C.lev[c.cls], x - 1, pack_node(nd)});
+            c.remaining--;
+            c.nextOrdinal++;
+            pos = x;
+            continue;
+          }
+          // significant set of class c.cls whose split starts at x
+          const uint32_t tl = (x <= lim) ? T[c.cls][x - a] : T_INF;
+          if (tl != T_INF) {
+            queue.push_back({nd, c.cls, x});
+            c.found = true;
+            c.remaining--;
+            c.nextOrdinal++;
+            if (c.top)
+              e++;
+            pos = x + tl;
+            continue;
+          }
+          // does not fit: if nothing was consumed in this window yet we must descend,
+          // otherwise retry it at the start of the next window
+          if (x - (coded ? 1 : 0) != a) {
+            window_full = true;
+            break;
+          }
+          c.found = true;
+          c.remaining--;
+          c.nextOrdinal++;
+          if (c.top)
+            e++;
+          pos = x;
+          const int kidcls = c.cls - 1;  // -1: pixels
+          ParCtx nc{kidcls, C.arity[c.cls], false, false, nd, 0};
+          ctx.push_back(nc);  // invalidates c
+        }
+        // ---- expand everything that was queued (parallel BFS in the kernel)
+        while (!queue.empty()) {
+          std::vector<WorkItem> nq;
+          for (const WorkItem& w : queue) {
+            uint64_t y = w.pos;
+            bool found = false;
+            const int ar = C.arity[w.cls];
+            for (int i = 0; i < ar; i++) {
+              const bool coded = found || (i + 1 != ar);
+              int b = 1;
+              if (coded)
+                b = in.get(y++);
+              if (w.cls == 0) {
+                const uint32_t ridx = regular_child_raster(t, w.nd, i);
+                pixel_event(ridx, b != 0, y);
+                if (b) {
+                  y++;
+                  found = true;
+                }
+              }
+              else {
+                const Node kid = regular_child(t, w.nd, i);
+                if (b) {
+                  found = true;
+                  nq.push_back({kid, w.cls - 1, y});
+                  y += T[w.cls - 1][y - a];
+                }
+                else
+                  bornv.push_back({C.lev[w.cls - 1], y - 1, pack_node(kid)});
+              }
+            }
+          }
+          queue.swap(nq);
+        }
+      }
+    }
+    std::stable_sort(bornv.begin(), bornv.end(), [](const BornRec& x, const BornRec& y) {
+      return x.lev != y.lev ? x.lev < y.lev : x.pos < y.pos;
+    });
+    for (const BornRec& b : bornv)
+      next[b.lev].push_back(b.packed);
+    lis.swap(next);
+    if (pos >= avail)
+      break;
+    // ---- D3
+    {
+      const uint64_t half = thr / 2;
+      uint64_t j = 0;
+      for (size_t i = 0; i < N && pos + j < avail; i++)
+        if (sigp[i] > p) {
+          const int b = in.get(pos + j);
+          j++;
+          if (thr >= 2)
+            coef[i] = b ? coef[i] + half : coef[i] - half;
+          else if (b)
+            coef[i]++;
+        }
+      pos += j;
+    }
+    if (pos >= avail)
+      break;
+  }
+  return 0;
+}
+
 }  // extern "C"

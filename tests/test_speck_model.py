@@ -94,3 +94,32 @@ def test_model_decoder_matches_oracle(oracle, model, shape, budget):
         c1, s1 = model_decode(model, s, shape)
         assert np.array_equal(c0, c1)
         assert np.array_equal(s0, s1)
+
+
+def model_decode_par(lib, stream, shape, window):
+    dz, dy, dx = shape
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    coef = np.zeros(shape, dtype=np.uint64)
+    sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+    lib.model_speck3d_decode_par.argtypes = [_vp, _sz, _vp, _vp, _vp, C.c_int]
+    lib.model_speck3d_decode_par(buf.ctypes.data, buf.size, (_sz * 3)(dx, dy, dz),
+                                 coef.ctypes.data, sign.ctypes.data, window)
+    return coef, sign
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 16, 16), (32, 32, 32), (64, 64, 64),
+                                   (16, 16, 32), (32, 16, 16), (13, 21, 30), (17, 17, 17)])
+@pytest.mark.parametrize("window", [64, 200, 4096])
+def test_model_table_driven_decoder_matches_oracle(oracle, model, shape, window):
+    """The speculative per-position table + hop + parallel-expand formulation of the LIS phase
+    (regular levels), with tiny windows to stress every boundary case."""
+    for scale in (3000.0, 4294967295.0):
+        coef, sign = quantized(oracle, shape, scale)
+        for budget in (0, 30000):
+            stream = oracle.speck3d_encode(coef, sign, budget)
+            for cut in (len(stream), 9 + (len(stream) - 9) // 3):
+                s = stream[:cut]
+                c0, s0 = oracle.speck3d_decode(s, shape)
+                c1, s1 = model_decode_par(model, s, shape, window)
+                assert np.array_equal(c0, c1)
+                assert np.array_equal(s0, s1)
