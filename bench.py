@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--bpp", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline sample")
+    ap.add_argument("--profile-out", default="", help="write the per-kernel event table here")
     args = ap.parse_args()
 
     import torch
@@ -131,6 +132,12 @@ def main():
         "kernel_ms_per_step": round(per_step_ms, 3),
         "top5_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kern[:5]},
     }
+
+    if args.profile_out:
+        with open(args.profile_out, "w") as f:
+            f.write("kernel,total_ms_per_step,launches_per_step,avg_launch_ms\n")
+            for k, (ms, cnt) in kern:
+                f.write(f"{k},{ms / args.steps:.4f},{cnt // args.steps},{ms / max(1, cnt):.5f}\n")
 
     # ---- CPU baseline on a bounded sample of the same volume, this host -----------------------
     cpu = None

@@ -212,6 +212,8 @@ struct ShapePlan {
   const uint32_t* d_depthBlocks = nullptr;
   const uint8_t* d_levelSlot = nullptr;
   const uint8_t* d_slotLevel = nullptr;
+  const spk::LevelClass* d_levelClass = nullptr;
+  int maxK = 0;
   std::vector<uint32_t> depthBlockOff;
   uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
   uint64_t maxPhaseBits = 0;
@@ -298,7 +300,11 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
                oBG = blob.add(h.blockGrid), oInit = blob.add(initLIS), oInitLen = blob.add(initLen),
                oLevOff = blob.add(levelOff), oTL = blob.add(tileLevel), oTS = blob.add(tileStart),
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
-               oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel);
+               oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
+               oLC = blob.add(h.levelClass);
+  P.maxK = 0;
+  for (const auto& lc : h.levelClass)
+    P.maxK = std::max<int>(P.maxK, lc.K);
   if (P.tables.ensure(blob.bytes.size()))
     return -1;
   HIP_CHECK(hipMemcpy(P.tables.p, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
@@ -318,6 +324,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.d_depthBlocks = reinterpret_cast<const uint32_t*>(base + oDB);
   P.d_levelSlot = reinterpret_cast<const uint8_t*>(base + oLS);
   P.d_slotLevel = reinterpret_cast<const uint8_t*>(base + oSL);
+  P.d_levelClass = reinterpret_cast<const spk::LevelClass*>(base + oLC);
 
   // DWT pass list (src/CDF97.cpp:132-139,170-225,284-292,387-429); the inverse runs it backwards
   P.fwd.clear();
@@ -911,6 +918,23 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.tokOff, uint32_t, d.tokStride * B);
   d.streamStride = (size_t)(maxPayloadBytes / 8) + 4;
   TAKE(d.stream, uint64_t, d.streamStride * B);
+  // table-driven LIS phase
+  d.levelClass = P.d_levelClass;
+  d.levelSlot = P.d_levelSlot;
+  d.slotLevel = P.d_slotLevel;
+  d.nSlots = P.nSlots;
+  d.maskWords = (uint32_t)d.streamStride;
+  d.maskStride = (size_t)P.nSlots * d.maskWords;
+  TAKE(d.mask, uint64_t, std::max<size_t>(d.maskStride, 1) * B);
+  TAKE(d.maskPrefix, uint32_t, std::max<size_t>(d.maskStride, 1) * B);
+  d.bornStride = P.ht.nsets + 8;
+  TAKE(d.bornPacked, uint64_t, d.bornStride * B);
+  TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
+  d.queueCap = 8192 + 64;
+  d.queueStride = (size_t)d.queueCap * 4;
+  TAKE(d.queue, uint64_t, d.queueStride * B);
+  d.sigbitsStride = P.lisEntries / 64 + 4;
+  TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
 #undef TAKE
   return true;
 }
@@ -1008,7 +1032,9 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       HIP_CHECK(hipStreamSynchronize(st));
       HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), st));
       HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), st));
-      DecPlanHost ph{P->d_initLIS, P->d_initLen};
+      DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
+                     P->maxK};
+      HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, st));
       // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
       // buffer, which the 32-bit pass then fills for the remaining chunks
       for (int wide = 1; wide >= 0; wide--) {
@@ -1383,7 +1409,9 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   }
   else
     HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
-  DecPlanHost ph{P->d_initLIS, P->d_initLen};
+  DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
+                 P->maxK};
+  HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
   if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
     return -1;
   HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));

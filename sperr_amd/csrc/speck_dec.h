@@ -51,11 +51,30 @@ struct DecBuffers {
   uint32_t* tokCnt;
   uint32_t* tokOff;
   size_t tokStride;
+  // table-driven LIS phase (regular shapes)
+  const spk::LevelClass* levelClass;
+  const uint8_t* levelSlot;    // level -> birth-mask slot (0xff: none)
+  const uint8_t* slotLevel;
+  uint32_t nSlots;
+  uint32_t maskWords;
+  uint64_t* mask;              // [slot][maskWords] one bit per stream position of the phase
+  uint32_t* maskPrefix;
+  size_t maskStride;
+  uint64_t* bornPacked;
+  uint64_t* bornPosLev;
+  size_t bornStride;
+  uint64_t* queue;             // two work queues of queueCap items (2 words each)
+  uint32_t queueCap;
+  size_t queueStride;
+  uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
+  size_t sigbitsStride;
 };
 
 struct DecPlanHost {
   const uint64_t* d_initLIS;
   const uint32_t* d_initLen;
+  bool tables;                 // every LIS level is regular: use k_lis_tables
+  int maxK;                    // longest class chain (sizes the LDS tables)
 };
 
 int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,

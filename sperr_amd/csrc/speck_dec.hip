@@ -571,6 +571,459 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): one
+// 1024-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_par is the
+// CPU model of this kernel.
+//
+// Per window of kTabW stream bits (staged in LDS):
+//   tables   T_j[x] = bits the split of a class-j set takes when it starts at bit x (kTInf when
+//            that would leave the window): speculative, one thread per bit position and class;
+//   hop      one thread walks the entries: '0' -> next bit, '1' -> 1 + T lookup.  It only
+//            descends into an entry (serially) when the entry does not fit in any window;
+//   expand   every set that splits inside the window is one work item; a thread finds its
+//            children with T_{j-1}, writes pixel results, queues significant child sets for the
+//            next round and records insignificant ones with their stream position.
+// After the last level the recorded sets are ranked by position (popcount prefix of per-level
+// position masks) and appended to the next lists; old entries are compacted in order.
+// ------------------------------------------------------------------------------------------
+constexpr int kTabW = 8192;
+constexpr int kTabThreads = 1024;
+constexpr uint32_t kTInf = 0xffffu;
+
+struct TabCtx {
+  uint64_t parent;     // packed parent node of the items (unused for the list context)
+  uint32_t remaining;  // items left in this context
+  int8_t cls;          // class of the items (-1: pixels)
+  uint8_t found;       // an earlier item of this context was significant
+  uint8_t top;         // the list context: every item is coded
+  uint8_t nextOrd;     // ordinal of the next child
+};
+
+__device__ __forceinline__ Node reg_child(const Tree& t, const Node& nd, uint32_t ord, int ee[3],
+                                          uint32_t idx[3])
+{
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  Node c;
+  c.grid = (uint16_t)(nd.grid + 1);
+  int bit = 0;
+  for (int a = 0; a < 3; a++) {
+    if (g.depth < r.D[a]) {
+      ee[a] = g.e[a] + 1;
+      idx[a] = (uint32_t)nd.i[a] * 2u + ((ord >> bit) & 1u);
+      bit++;
+    }
+    else {
+      ee[a] = g.e[a];
+      idx[a] = nd.i[a];
+    }
+    c.i[a] = (uint16_t)idx[a];
+  }
+  return c;
+}
+
+__device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& nd, uint32_t ord)
+{
+  int ee[3];
+  uint32_t idx[3];
+  reg_child(t, nd, ord, ee, idx);
+  return pixel_raster(t, t.roots[t.grids[nd.grid].root], ee, idx);
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  extern __shared__ __attribute__((aligned(16))) char tab_smem[];
+  constexpr int kWords = kTabW / 64 + 4;
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
+  uint16_t* T = reinterpret_cast<uint16_t*>(tab_smem + kWords * 8);  // [K][kTabW + 2]
+  constexpr int kTS = kTabW + 2;
+  __shared__ uint64_t sh_pos;
+  __shared__ int sh_depth;
+  __shared__ TabCtx sh_ctx[kMaxClasses + 2];
+  __shared__ uint32_t sh_e, sh_qn[2], sh_born, sh_flag;
+  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+
+  const Tree& t = b.tree;
+  const int tid = threadIdx.x;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  int8_t* born = b.born + c * b.pixStride;
+  int8_t* sigp = b.sigp + c * b.pixStride;
+  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
+  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
+  const CT thr = (CT)1 << p;
+  const CT init = thr + thr - thr / 2 - 1;
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  uint64_t* qbuf[2] = {b.queue + c * b.queueStride, b.queue + c * b.queueStride + b.queueCap * 2};
+  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
+
+  if (tid == 0) {
+    sh_pos = phase0;
+    sh_born = 0;
+  }
+  __syncthreads();
+
+  uint64_t w0 = 0;  // absolute index of wbits[0]
+  auto bit_at = [&](uint64_t abs) -> uint32_t {
+    return (uint32_t)((wbits[(abs >> 6) - w0] >> (abs & 63)) & 1ull);
+  };
+  auto pixel_event = [&](uint32_t ridx, bool sig, uint64_t signpos) {
+    born[ridx] = (int8_t)p;
+    if (sig) {
+      sigp[ridx] = (int8_t)p;
+      coef[ridx] = init;
+      if (!bit_at(signpos))
+        atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+    }
+  };
+  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
+    const uint64_t rel = abs - phase0;
+    const uint32_t slot = b.levelSlot[lev];
+    if (slot == 0xff || rel >= maskBits)
+      return;  // past the usable stream: decoding stops after this plane anyway
+    const uint32_t k = atomicAdd(&sh_born, 1u);
+    if (k >= b.bornStride)
+      return;
+    bornPacked[k] = packed;
+    bornPosLev[k] = ((uint64_t)lev << 48) | rel;
+    atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
+                1ull << (rel & 63));
+  };
+
+  for (uint32_t l = t.nlevels; l-- > 0;) {
+    const uint32_t n = s.listLen[cur][l];
+    if (n == 0) {
+      if (tid == 0)
+        s.listLen[nx][l] = 0;
+      continue;
+    }
+    const LevelClass C = b.levelClass[l];
+    const int K = C.K;
+    const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
+    // significance bits of the old entries, filled by the hop thread
+    for (uint32_t i = tid; i < (n + 63) / 64; i += kTabThreads)
+      sigbits[i] = 0;
+    if (tid == 0) {
+      sh_depth = 1;
+      sh_ctx[0].parent = 0;
+      sh_ctx[0].remaining = n;
+      sh_ctx[0].cls = (int8_t)(K - 1);
+      sh_ctx[0].found = 0;
+      sh_ctx[0].top = 1;
+      sh_ctx[0].nextOrd = 0;
+      sh_e = 0;
+    }
+    __syncthreads();
+
+    while (sh_depth > 0) {
+      const uint64_t a = sh_pos;
+      __syncthreads();  // everyone has read sh_pos / sh_depth before thread 0 changes them
+      w0 = a >> 6;
+      for (int i = tid; i < kWords; i += kTabThreads) {
+        const uint64_t idx = w0 + i;
+        wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
+      }
+      __syncthreads();
+      // ---- tables: T[j][x - a] for x in [a, a + kTabW]
+      for (int j = 0; j < K; j++) {
+        const int ar = C.arity[j];
+        const uint16_t* Tp = T + (size_t)(j - 1) * kTS;
+        uint16_t* Tj = T + (size_t)j * kTS;
+        for (uint32_t rel = tid; rel <= (uint32_t)kTabW; rel += kTabThreads) {
+          uint32_t y = rel;
+          bool found = false, ok = true;
+          for (int i = 0; i < ar; i++) {
+            const bool coded = found || (i + 1 != ar);
+            uint32_t bit = 1;
+            if (coded) {
+              if (y >= (uint32_t)kTabW) {
+                ok = false;
+                break;
+              }
+              bit = bit_at(a + y);
+              y++;
+            }
+            if (!bit)
+              continue;
+            found = true;
+            if (j == 0) {
+              if (y >= (uint32_t)kTabW) {
+                ok = false;
+                break;
+              }
+              y++;  // sign bit
+            }
+            else {
+              const uint32_t tl = y <= (uint32_t)kTabW ? Tp[y] : kTInf;
+              if (tl == kTInf) {
+                ok = false;
+                break;
+              }
+              y += tl;
+            }
+          }
+          Tj[rel] = ok ? (uint16_t)(y - rel) : (uint16_t)kTInf;
+        }
+        __syncthreads();
+      }
+      // ---- hop: one thread, entries of the window
+      if (tid == 0) {
+        uint64_t pos = a;
+        const uint64_t lim = a + kTabW;
+        int depth = sh_depth;
+        uint32_t e = sh_e, qn = 0;
+        uint64_t sigword = 0;      // bits of entries [e & ~63, e) found significant
+        uint32_t sigbase = e >> 6;
+        sigword = sigbits[sigbase];
+        bool full = false;
+        while (depth > 0 && !full) {
+          TabCtx& cx = sh_ctx[depth - 1];
+          if (cx.remaining == 0) {
+            depth--;
+            continue;
+          }
+          const bool coded = cx.top || cx.found || cx.remaining > 1;
+          uint64_t x = pos;
+          uint32_t bit = 1;
+          if (coded) {
+            if (x >= lim) {
+              full = true;
+              break;
+            }
+            bit = bit_at(x);
+            x++;
+          }
+          if (cx.cls < 0) {  // pixel item of a descended leaf parent
+            if (bit && x >= lim) {
+              full = true;
+              break;
+            }
+            const uint32_t ridx = reg_child_raster(t, unpack_node(cx.parent), cx.nextOrd);
+            pixel_event(ridx, bit != 0, x);
+            if (bit) {
+              x++;
+              cx.found = 1;
+            }
+            cx.remaining--;
+            cx.nextOrd++;
+            pos = x;
+            continue;
+          }
+          if (!bit) {
+            if (cx.top)
+              e++;
+            else {
+              int ee[3];
+              uint32_t idx[3];
+              const Node kid = reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx);
+              record_born(C.lev[cx.cls], x - 1, pack_node(kid));
+            }
+            cx.remaining--;
+            cx.nextOrd++;
+            pos = x;
+            if (cx.top && (e >> 6) != sigbase) {
+              sigbits[sigbase] = sigword;
+              sigbase = e >> 6;
+              sigword = 0;
+            }
+            continue;
+          }
+          // significant set of class cx.cls; its split starts at x
+          const uint32_t tl = (x - a) <= (uint64_t)kTabW ? T[(size_t)cx.cls * kTS + (x - a)] : kTInf;
+          const bool fits = tl != kTInf && qn < b.queueCap;
+          if (!fits && x - (coded ? 1 : 0) != a) {
+            full = true;  // retry at the start of the next window
+            break;
+          }
+          uint64_t ident;
+          if (cx.top) {
+            ident = e;
+            sigword |= 1ull << (e & 63);
+            e++;
+          }
+          else {
+            int ee[3];
+            uint32_t idx[3];
+            ident = pack_node(reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx));
+          }
+          const bool was_top = cx.top != 0;
+          const int cls = cx.cls;
+          cx.found = 1;
+          cx.remaining--;
+          cx.nextOrd++;
+          if (fits) {
+            qbuf[0][qn * 2] = ident;
+            qbuf[0][qn * 2 + 1] = (x << 8) | ((uint64_t)cls << 1) | (was_top ? 1ull : 0ull);
+            qn++;
+            pos = x + tl;
+          }
+          else {  // larger than a window: walk into it
+            pos = x;
+            TabCtx& nc = sh_ctx[depth];
+            nc.parent = was_top ? list[ident] : ident;
+            nc.remaining = C.arity[cls];
+            nc.cls = (int8_t)(cls - 1);
+            nc.found = 0;
+            nc.top = 0;
+            nc.nextOrd = 0;
+            depth++;
+          }
+          if (was_top && (e >> 6) != sigbase) {
+            sigbits[sigbase] = sigword;
+            sigbase = e >> 6;
+            sigword = 0;
+          }
+        }
+        sigbits[sigbase] = sigword;
+        sh_pos = pos;
+        sh_depth = depth;
+        sh_e = e;
+        sh_qn[0] = qn;
+        sh_qn[1] = 0;
+      }
+      __syncthreads();
+      // ---- expand, breadth first
+      for (int round = 0;; round++) {
+        const uint32_t nin = sh_qn[round & 1];
+        if (nin == 0)
+          break;
+        const uint64_t* qin = qbuf[round & 1];
+        uint64_t* qout = qbuf[(round + 1) & 1];
+        for (uint32_t i = tid; i < nin; i += kTabThreads) {
+          const uint64_t ident = qin[i * 2], meta = qin[i * 2 + 1];
+          const int cls = (int)((meta >> 1) & 0x7f);
+          uint64_t y = meta >> 8;
+          const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
+          const int ar = C.arity[cls];
+          bool found = false;
+          for (int k = 0; k < ar; k++) {
+            const bool coded = found || (k + 1 != ar);
+            uint32_t bit = 1;
+            if (coded) {
+              bit = bit_at(y);
+              y++;
+            }
+            if (cls == 0) {
+              const uint32_t ridx = reg_child_raster(t, nd, k);
+              pixel_event(ridx, bit != 0, y);
+              if (bit) {
+                y++;
+                found = true;
+              }
+            }
+            else {
+              int ee[3];
+              uint32_t idx[3];
+              const uint64_t kid = pack_node(reg_child(t, nd, k, ee, idx));
+              if (bit) {
+                found = true;
+                const uint32_t slot = atomicAdd(&sh_qn[(round + 1) & 1], 1u);
+                qout[slot * 2] = kid;   // cannot overflow: see queueCap
+                qout[slot * 2 + 1] = (y << 8) | ((uint64_t)(cls - 1) << 1);
+                y += T[(size_t)(cls - 1) * kTS + (y - a)];
+              }
+              else
+                record_born(C.lev[cls - 1], y - 1, kid);
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0)
+          sh_qn[round & 1] = 0;
+        __syncthreads();
+      }
+    }
+    // ---- old entries that stayed insignificant keep their order
+    {
+      uint32_t* scan = sh_scan;
+      uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
+      uint32_t carry = 0;
+      const uint32_t nw = (n + 63) / 64;
+      for (uint32_t base = 0; base < nw; base += kTabThreads) {
+        const uint32_t wi = base + tid;
+        uint64_t stay = 0;
+        if (wi < nw) {
+          stay = ~sigbits[wi];
+          const uint32_t valid = n - wi * 64;
+          if (valid < 64)
+            stay &= (1ull << valid) - 1;
+        }
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), scan, &total) + carry;
+        while (stay) {
+          const int k = __ffsll((long long)stay) - 1;
+          stay &= stay - 1;
+          keep[ex++] = list[wi * 64 + k];
+        }
+        carry += total;
+      }
+      if (tid == 0)
+        s.listLen[nx][l] = carry;
+      __syncthreads();
+    }
+  }
+
+  // ---- newborn insignificant sets join their lists in stream order
+  __threadfence();
+  __syncthreads();
+  const uint64_t phaseBits = min(sh_pos - phase0, maskBits);
+  const uint32_t pw = (uint32_t)((phaseBits + 63) / 64);
+  for (uint32_t slot = 0; slot < b.nSlots; slot++) {
+    const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
+    uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < pw; base += kTabThreads) {
+      const uint32_t wi = base + tid;
+      const uint64_t m = wi < pw ? __hip_atomic_load(mask + wi, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)
+                                 : 0ull;
+      uint32_t total;
+      const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(m), sh_scan, &total);
+      if (wi < pw)
+        pre[wi] = ex + carry;
+      carry += total;
+    }
+    if (tid == 0)
+      sh_flag = carry;
+    __syncthreads();
+    const uint32_t lev = b.slotLevel[slot];
+    const uint32_t baseLen = s.listLen[nx][lev];
+    const uint32_t nbornTot = min(sh_born, (uint32_t)b.bornStride);
+    for (uint32_t k = tid; k < nbornTot; k += kTabThreads) {
+      const uint64_t pl = bornPosLev[k];
+      if ((uint32_t)(pl >> 48) != lev)
+        continue;
+      const uint64_t rel = pl & ((1ull << 48) - 1);
+      const uint64_t m = __hip_atomic_load(mask + (rel >> 6), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t rank = pre[rel >> 6] + (uint32_t)__popcll(m & ((1ull << (rel & 63)) - 1ull));
+      b.lis[nx][c * b.lisStride + b.levelOff[lev] + baseLen + rank] = bornPacked[k];
+    }
+    __syncthreads();
+    if (tid == 0)
+      s.listLen[nx][lev] = baseLen + sh_flag;
+    __syncthreads();
+  }
+  for (uint32_t slot = 0; slot < b.nSlots; slot++)  // leave the masks clean for the next plane
+    for (uint32_t wi = tid; wi < pw; wi += kTabThreads)
+      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
+  if (tid == 0) {
+    s.cur = nx;
+    s.pos = sh_pos;
+    if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
+      s.done = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // refinement: the j-th pixel that was significant before this plane takes bit pos + j
 // ------------------------------------------------------------------------------------------
 template <typename CT>
@@ -636,6 +1089,17 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   LAUNCH_K(k_dec_load_words, dim3(wordBlocks, nc), dim3(kThreads), 0, stream, b,
                      container);
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
+  const size_t tabSmem = (size_t)(kTabW / 64 + 4) * 8 + (size_t)plan.maxK * (kTabW + 2) * 2;
+  if (plan.tables) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint32_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint64_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+      attr_set = true;
+    }
+  }
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -645,14 +1109,20 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     if (wide_pass) {
       LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
-      LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
+      if (plan.tables)
+        LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+      else
+        LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
       LAUNCH_K(k_ref_apply<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
                          b, p);
     }
     else {
       LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
-      LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
+      if (plan.tables)
+        LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+      else
+        LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
       LAUNCH_K(k_ref_apply<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
                          b, p);
     }

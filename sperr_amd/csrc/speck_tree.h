@@ -74,6 +74,18 @@ struct Node {
   uint16_t i[3];
 };
 
+// A LIS level is "regular" when every set that can sit in it has the same shape and that shape
+// has power-of-two extents.  Then the code of an entry only depends on its class: a class-j set
+// has arity[j] children of class j-1 (class 0: the children are pixels) living on LIS level
+// lev[j-1]; the level's own entries are class K-1.
+constexpr int kMaxClasses = 17;
+struct LevelClass {
+  uint8_t regular;
+  uint8_t K;
+  uint8_t arity[kMaxClasses];
+  uint8_t lev[kMaxClasses];
+};
+
 SPK_HD uint32_t bitrev(uint32_t v, int e)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -65,6 +65,8 @@ struct HostTree {
   std::vector<std::vector<uint64_t>> initLIS;  // per level, packed root nodes in list order
   std::vector<uint32_t> levelCap;              // per level, number of set nodes (list capacity)
   std::vector<uint32_t> levelOff;              // exclusive prefix of levelCap (+ total at end)
+  std::vector<LevelClass> levelClass;          // per level: regular shape chain (or regular = 0)
+  bool allRegular = false;                     // every level that can hold sets is regular
   uint32_t dims[3] = {0, 0, 0};
   uint32_t nnodes = 0, nlevels = 0, maxDepth = 0, nsets = 0;
 
@@ -217,6 +219,8 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
 
   // ---- list capacities: how many set nodes can ever sit in each LIS level ----------------
   h.levelCap.assign(h.nlevels, 0);
+  std::vector<std::array<uint32_t, 3>> levelShape(h.nlevels, {0, 0, 0});
+  std::vector<int> levelState(h.nlevels, 0);  // 0: no sets, 1: one shape so far, 2: mixed
   const Tree t = h.view();
   for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
     const Grid& g = h.grids[gi];
@@ -230,14 +234,59 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
           n.i[2] = (uint16_t)z;
           const NodeGeom q = node_geom(t, n);
           if (q.count > 1 || (g.depth == 0 && q.count == 1)) {
-            h.levelCap[node_level(t, n)]++;
+            const uint32_t l = node_level(t, n);
+            h.levelCap[l]++;
             h.nsets++;
+            const std::array<uint32_t, 3> sh = {q.len[0], q.len[1], q.len[2]};
+            if (levelState[l] == 0) {
+              levelShape[l] = sh;
+              levelState[l] = 1;
+            }
+            else if (levelState[l] == 1 && levelShape[l] != sh)
+              levelState[l] = 2;
           }
         }
   }
   h.levelOff.assign(h.nlevels + 1, 0);
   for (uint32_t l = 0; l < h.nlevels; l++)
     h.levelOff[l + 1] = h.levelOff[l] + h.levelCap[l];
+
+  // ---- shape classes per level (see LevelClass) ------------------------------------------
+  h.levelClass.assign(h.nlevels, LevelClass{});
+  h.allRegular = true;
+  for (uint32_t l = 0; l < h.nlevels; l++) {
+    if (levelState[l] == 0)
+      continue;
+    LevelClass& c = h.levelClass[l];
+    std::array<uint32_t, 3> sh = levelShape[l];
+    bool ok = levelState[l] == 1 && sh[0] * sh[1] * sh[2] >= 2;
+    for (int a = 0; a < 3; a++)
+      ok = ok && (sh[a] & (sh[a] - 1)) == 0;
+    if (!ok) {
+      h.allRegular = false;
+      continue;
+    }
+    int ar[kMaxClasses], lv[kMaxClasses], K = 0;
+    uint32_t cl = l;
+    for (;;) {
+      const int ns = (sh[0] > 1) + (sh[1] > 1) + (sh[2] > 1);
+      ar[K] = 1 << ns;
+      lv[K] = (int)cl;
+      K++;
+      cl += (uint32_t)ns;
+      for (int a = 0; a < 3; a++)
+        if (sh[a] > 1)
+          sh[a] /= 2;
+      if (sh[0] * sh[1] * sh[2] == 1)
+        break;
+    }
+    c.regular = 1;
+    c.K = (uint8_t)K;
+    for (int j = 0; j < K; j++) {  // class 0 = leaf parent = the last shape of the chain
+      c.arity[j] = (uint8_t)ar[K - 1 - j];
+      c.lev[j] = (uint8_t)lv[K - 1 - j];
+    }
+  }
   return h;
 }
 

@@ -465,71 +465,6 @@ int model_speck3d_decode(const uint8_t* stream, size_t len, const size_t dims[3]
 // ------------------------------------------------------------------------------------------
 namespace {
 
-struct LevelClass {
-  bool regular = false;
-  int K = 0;              // number of set classes from this level's shape down to leaf parents
-  int arity[20];          // children per class (index 0 = leaf parent)
-  uint32_t lev[20];       // LIS level of class-j nodes
-};
-
-// shape bookkeeping per level (host side of the plan)
-std::vector<LevelClass> classify_levels(const HostTree& ht)
-{
-  const Tree t = ht.view();
-  std::vector<LevelClass> lc(t.nlevels);
-  std::vector<std::array<uint32_t, 3>> shape(t.nlevels, {0, 0, 0});
-  std::vector<int> state(t.nlevels, 0);  // 0 unseen, 1 uniform so far, 2 mixed
-  for (uint32_t id = 0; id < t.nnodes; id++) {
-    Node nd;
-    if (!node_from_flat(t, id, nd))
-      continue;
-    const NodeGeom q = node_geom(t, nd);
-    if (!(q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1)))
-      continue;
-    const uint32_t l = node_level(t, nd);
-    const std::array<uint32_t, 3> sh = {q.len[0], q.len[1], q.len[2]};
-    if (state[l] == 0) {
-      shape[l] = sh;
-      state[l] = 1;
-    }
-    else if (state[l] == 1 && shape[l] != sh)
-      state[l] = 2;
-  }
-  for (uint32_t l = 0; l < t.nlevels; l++) {
-    if (state[l] != 1)
-      continue;
-    auto sh = shape[l];
-    bool pow2 = true;
-    for (int a = 0; a < 3; a++)
-      pow2 &= (sh[a] & (sh[a] - 1)) == 0;
-    if (!pow2 || sh[0] * sh[1] * sh[2] < 2)
-      continue;
-    // chain of shapes down to the leaf parent
-    std::vector<int> ar;
-    std::vector<uint32_t> lv;
-    uint32_t cl = l;
-    for (;;) {
-      int ns = (sh[0] > 1) + (sh[1] > 1) + (sh[2] > 1);
-      ar.push_back(1 << ns);
-      lv.push_back(cl);
-      cl += ns;
-      for (int a = 0; a < 3; a++)
-        if (sh[a] > 1)
-          sh[a] /= 2;
-      if (sh[0] * sh[1] * sh[2] == 1)
-        break;
-    }
-    LevelClass& c = lc[l];
-    c.regular = true;
-    c.K = (int)ar.size();
-    for (int j = 0; j < c.K; j++) {  // index 0 = leaf parent = last pushed
-      c.arity[j] = ar[c.K - 1 - j];
-      c.lev[j] = lv[c.K - 1 - j];
-    }
-  }
-  return lc;
-}
-
 constexpr uint32_t T_INF = 0xffffffffu;
 
 struct ParCtx {
@@ -599,7 +534,7 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
     g_model_window = window;
   HostTree ht = build_tree(dims[0], dims[1], dims[2]);
   const Tree t = ht.view();
-  const std::vector<LevelClass> lc = classify_levels(ht);
+  const std::vector<LevelClass>& lc = ht.levelClass;
   const size_t N = t.nvals;
   const int nbp = stream[0];
   uint64_t total_bits;
