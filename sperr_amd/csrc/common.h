@@ -82,6 +82,9 @@ struct EncState {
   uint64_t lipTot[kMaxPlanes], refTot[kMaxPlanes];
   uint32_t listLen[2][spk::kMaxLevels];
   uint32_t bornTot[spk::kMaxLevels];
+  uint32_t bucketCnt[kMaxPlanes];   // sets that split at each plane
+  uint32_t bucketOff[kMaxPlanes];
+  uint32_t bucketCur[kMaxPlanes];
 };
 
 // ---- block-level exclusive scan over kThreads threads ------------------------------------------

@@ -577,6 +577,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(e.M, int8_t, nn * B);
   TAKE(e.E, uint32_t, nn * B);
   TAKE(e.opos, uint64_t, nn * B);
+  TAKE(e.bucket, uint32_t, nn * B);
   e.lisStride = P.lisEntries;
   TAKE(e.lis[0], uint64_t, P.lisEntries * B);
   TAKE(e.lis[1], uint64_t, P.lisEntries * B);
@@ -930,7 +931,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.bornStride = P.ht.nsets + 8;
   TAKE(d.bornPacked, uint64_t, d.bornStride * B);
   TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
-  d.queueCap = 8192 + 64;
+  d.tabSmemBytes = 150 * 1024;
+  d.queueCap = 28672 + 64;
   d.queueStride = (size_t)d.queueCap * 4;
   TAKE(d.queue, uint64_t, d.queueStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;

@@ -68,6 +68,7 @@ struct DecBuffers {
   size_t queueStride;
   uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
   size_t sigbitsStride;
+  uint32_t tabSmemBytes;       // dynamic LDS given to k_lis_tables
 };
 
 struct DecPlanHost {

@@ -586,8 +586,20 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 // After the last level the recorded sets are ranked by position (popcount prefix of per-level
 // position masks) and appended to the next lists; old entries are compacted in order.
 // ------------------------------------------------------------------------------------------
-constexpr int kTabW = 8192;
+constexpr int kTabWMax = 28672;   // window bits: < 2^15 (hopExit keeps a flag in bit 15)
 constexpr int kTabThreads = 1024;
+
+// bytes of LDS the tables of a level with chain length K need per window bit: 2K (T) + 3 (hop)
+// + 1/8 (bits).  The window is the largest multiple of 1024 that fits.
+__host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
+{
+  const uint32_t fixed = 4 * 8 + 128 * 3 + (uint32_t)K * 4 + 64;
+  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / (uint64_t)(16 * K + 25));
+  w = w / 1024 * 1024;
+  if (w > (uint32_t)kTabWMax)
+    w = kTabWMax;
+  return w;
+}
 constexpr uint32_t kTInf = 0xffffu;
 
 struct TabCtx {
@@ -637,10 +649,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   extern __shared__ __attribute__((aligned(16))) char tab_smem[];
-  constexpr int kWords = kTabW / 64 + 4;
+  // The window length W depends on the level: short class chains leave room for long windows.
+  // LDS layout: wbits[W/64 + 4] u64 | hopExit[W + 128] u16 | hopCnt[W + 128] u8 | T[K][W + 2] u16
   uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
-  uint16_t* T = reinterpret_cast<uint16_t*>(tab_smem + kWords * 8);  // [K][kTabW + 2]
-  constexpr int kTS = kTabW + 2;
+  uint32_t W = 0;
+  int kWords = 0, kTS = 0;
+  uint16_t* hopExit = nullptr;
+  uint8_t* hopCnt = nullptr;
+  uint16_t* T = nullptr;
+  constexpr int kBlk = kTabWMax / 64 + 2;
+  __shared__ uint16_t blkEntry[kBlk], blkLimit[kBlk];
+  __shared__ uint32_t blkBase[kBlk];
+  __shared__ uint32_t sh_total, sh_stopped;
+  __shared__ uint64_t sh_newpos;
   __shared__ uint64_t sh_pos;
   __shared__ int sh_depth;
   __shared__ TabCtx sh_ctx[kMaxClasses + 2];
@@ -707,6 +728,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     }
     const LevelClass C = b.levelClass[l];
     const int K = C.K;
+    W = tab_window(K, b.tabSmemBytes);
+    kWords = (int)(W / 64 + 4);
+    kTS = (int)W + 2;
+    hopExit = reinterpret_cast<uint16_t*>(tab_smem + (size_t)kWords * 8);
+    hopCnt = reinterpret_cast<uint8_t*>(hopExit + (W + 128));
+    T = reinterpret_cast<uint16_t*>(hopCnt + (W + 128));
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
     // significance bits of the old entries, filled by the hop thread
     for (uint32_t i = tid; i < (n + 63) / 64; i += kTabThreads)
@@ -732,19 +759,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
       }
       __syncthreads();
-      // ---- tables: T[j][x - a] for x in [a, a + kTabW]
+      // ---- tables: T[j][x - a] for x in [a, a + W]
       for (int j = 0; j < K; j++) {
         const int ar = C.arity[j];
         const uint16_t* Tp = T + (size_t)(j - 1) * kTS;
         uint16_t* Tj = T + (size_t)j * kTS;
-        for (uint32_t rel = tid; rel <= (uint32_t)kTabW; rel += kTabThreads) {
+        for (uint32_t rel = tid; rel <= W; rel += kTabThreads) {
           uint32_t y = rel;
           bool found = false, ok = true;
           for (int i = 0; i < ar; i++) {
             const bool coded = found || (i + 1 != ar);
             uint32_t bit = 1;
             if (coded) {
-              if (y >= (uint32_t)kTabW) {
+              if (y >= W) {
                 ok = false;
                 break;
               }
@@ -755,14 +782,14 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
               continue;
             found = true;
             if (j == 0) {
-              if (y >= (uint32_t)kTabW) {
+              if (y >= W) {
                 ok = false;
                 break;
               }
               y++;  // sign bit
             }
             else {
-              const uint32_t tl = y <= (uint32_t)kTabW ? Tp[y] : kTInf;
+              const uint32_t tl = y <= W ? Tp[y] : kTInf;
               if (tl == kTInf) {
                 ok = false;
                 break;
@@ -774,23 +801,21 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         }
         __syncthreads();
       }
-      // ---- hop: one thread, entries of the window
+      // ---- hop, part S: contexts below the list (an entry larger than a window is being
+      //      walked into) are handled serially by one thread
       if (tid == 0) {
         uint64_t pos = a;
-        const uint64_t lim = a + kTabW;
+        const uint64_t lim = a + W;
         int depth = sh_depth;
-        uint32_t e = sh_e, qn = 0;
-        uint64_t sigword = 0;      // bits of entries [e & ~63, e) found significant
-        uint32_t sigbase = e >> 6;
-        sigword = sigbits[sigbase];
+        uint32_t qn = 0;
         bool full = false;
-        while (depth > 0 && !full) {
+        while (depth > 1 && !full) {
           TabCtx& cx = sh_ctx[depth - 1];
           if (cx.remaining == 0) {
             depth--;
             continue;
           }
-          const bool coded = cx.top || cx.found || cx.remaining > 1;
+          const bool coded = cx.found || cx.remaining > 1;
           uint64_t x = pos;
           uint32_t bit = 1;
           if (coded) {
@@ -817,58 +842,35 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             pos = x;
             continue;
           }
+          int ee[3];
+          uint32_t idx[3];
+          const uint64_t kid = pack_node(reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx));
           if (!bit) {
-            if (cx.top)
-              e++;
-            else {
-              int ee[3];
-              uint32_t idx[3];
-              const Node kid = reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx);
-              record_born(C.lev[cx.cls], x - 1, pack_node(kid));
-            }
+            record_born(C.lev[cx.cls], x - 1, kid);
             cx.remaining--;
             cx.nextOrd++;
             pos = x;
-            if (cx.top && (e >> 6) != sigbase) {
-              sigbits[sigbase] = sigword;
-              sigbase = e >> 6;
-              sigword = 0;
-            }
             continue;
           }
-          // significant set of class cx.cls; its split starts at x
-          const uint32_t tl = (x - a) <= (uint64_t)kTabW ? T[(size_t)cx.cls * kTS + (x - a)] : kTInf;
-          const bool fits = tl != kTInf && qn < b.queueCap;
-          if (!fits && x - (coded ? 1 : 0) != a) {
+          const uint32_t tl = (x - a) <= (uint64_t)W ? T[(size_t)cx.cls * kTS + (x - a)] : kTInf;
+          if (tl == kTInf && x - (coded ? 1 : 0) != a) {
             full = true;  // retry at the start of the next window
             break;
           }
-          uint64_t ident;
-          if (cx.top) {
-            ident = e;
-            sigword |= 1ull << (e & 63);
-            e++;
-          }
-          else {
-            int ee[3];
-            uint32_t idx[3];
-            ident = pack_node(reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx));
-          }
-          const bool was_top = cx.top != 0;
           const int cls = cx.cls;
           cx.found = 1;
           cx.remaining--;
           cx.nextOrd++;
-          if (fits) {
-            qbuf[0][qn * 2] = ident;
-            qbuf[0][qn * 2 + 1] = (x << 8) | ((uint64_t)cls << 1) | (was_top ? 1ull : 0ull);
+          if (tl != kTInf) {
+            qbuf[0][qn * 2] = kid;
+            qbuf[0][qn * 2 + 1] = (x << 8) | ((uint64_t)cls << 1);
             qn++;
             pos = x + tl;
           }
           else {  // larger than a window: walk into it
             pos = x;
             TabCtx& nc = sh_ctx[depth];
-            nc.parent = was_top ? list[ident] : ident;
+            nc.parent = kid;
             nc.remaining = C.arity[cls];
             nc.cls = (int8_t)(cls - 1);
             nc.found = 0;
@@ -876,20 +878,150 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             nc.nextOrd = 0;
             depth++;
           }
-          if (was_top && (e >> 6) != sigbase) {
-            sigbits[sigbase] = sigword;
-            sigbase = e >> 6;
-            sigword = 0;
-          }
         }
-        sigbits[sigbase] = sigword;
         sh_pos = pos;
         sh_depth = depth;
-        sh_e = e;
         sh_qn[0] = qn;
         sh_qn[1] = 0;
+        sh_flag = full ? 1u : 0u;
       }
       __syncthreads();
+      // ---- hop, part P: the list itself, in parallel.  64-bit blocks aligned to stream words;
+      //      (P1) per block a backward memo: where the chain leaves the block from each position
+      //      and how many entries it passes; (P2) one thread walks the blocks; (P3) the blocks
+      //      emit their entries.
+      const uint64_t ppos = sh_pos;
+      const uint64_t lim = a + W;
+      const bool doP = sh_depth == 1 && sh_flag == 0 && sh_ctx[0].remaining > 0 && ppos < lim;
+      __syncthreads();
+      if (doP) {
+        const uint32_t remaining = sh_ctx[0].remaining;
+        const uint32_t e0 = sh_e;
+        const uint64_t B0 = ppos >> 6;
+        const uint32_t nblk = (uint32_t)(((lim - 1) >> 6) - B0 + 1);
+        const uint16_t* Ttop = T + (size_t)(K - 1) * kTS;
+        if ((uint32_t)tid < nblk) {  // P1
+          const uint64_t blk0 = (B0 + tid) * 64;
+          const uint64_t wbitsWord = wbits[(B0 + tid) - w0];
+          for (int o = 63; o >= 0; o--) {
+            const uint64_t x = blk0 + o;
+            if (x < ppos || x >= lim)
+              continue;
+            const uint32_t r = (uint32_t)(x - B0 * 64);
+            uint64_t nx;
+            if (!((wbitsWord >> o) & 1ull))
+              nx = x + 1;
+            else {
+              const uint32_t tl = (x + 1 - a) <= (uint64_t)W ? Ttop[x + 1 - a] : kTInf;
+              if (tl == kTInf) {
+                hopExit[r] = (uint16_t)(0x8000u | (uint32_t)(x - a));
+                hopCnt[r] = 0;
+                continue;
+              }
+              nx = x + 1 + tl;
+            }
+            if (nx >= blk0 + 64 || nx >= lim) {
+              hopExit[r] = (uint16_t)(nx - a);
+              hopCnt[r] = 1;
+            }
+            else {
+              const uint32_t rn = (uint32_t)(nx - B0 * 64);
+              hopExit[r] = hopExit[rn];
+              hopCnt[r] = (uint8_t)(hopCnt[rn] + 1);
+            }
+          }
+          blkEntry[tid] = 0xffff;
+        }
+        __syncthreads();
+        if (tid == 0) {  // P2
+          uint64_t x = ppos;
+          uint32_t total = 0;
+          uint32_t stopped = 0;
+          uint64_t newpos = ~0ull;
+          while (true) {
+            if (x >= lim) {
+              newpos = x;
+              break;
+            }
+            const uint32_t bi = (uint32_t)((x >> 6) - B0), r = (uint32_t)(x - B0 * 64);
+            const uint32_t cn = hopCnt[r];
+            const uint32_t ex = hopExit[r];
+            blkEntry[bi] = (uint16_t)(x - a);
+            blkBase[bi] = total;
+            if (total + cn >= remaining) {
+              blkLimit[bi] = (uint16_t)(remaining - total);  // the list ends inside this block
+              total = remaining;
+              break;
+            }
+            blkLimit[bi] = (uint16_t)cn;
+            total += cn;
+            if (ex & 0x8000u) {
+              stopped = 1;
+              newpos = a + (ex & 0x7fffu);
+              break;
+            }
+            x = a + ex;
+          }
+          sh_total = total;
+          sh_stopped = stopped;
+          sh_newpos = newpos;
+        }
+        __syncthreads();
+        if ((uint32_t)tid < nblk && blkEntry[tid] != 0xffff) {  // P3
+          uint64_t y = a + blkEntry[tid];
+          const uint32_t lim_k = blkLimit[tid], base = blkBase[tid];
+          for (uint32_t k = 0; k < lim_k; k++) {
+            const uint32_t ei = e0 + base + k;
+            if (!bit_at(y))
+              y += 1;
+            else {
+              const uint32_t tl = Ttop[y + 1 - a];
+              const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+              qbuf[0][slot * 2] = ei;
+              qbuf[0][slot * 2 + 1] = ((y + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+              atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              y += 1 + tl;
+            }
+          }
+          if (lim_k > 0 && base + lim_k == remaining)
+            sh_newpos = y;  // the list ended in this block (only one block satisfies this)
+        }
+        __syncthreads();
+        if (tid == 0) {  // P4
+          const uint32_t total = sh_total;
+          uint32_t e = e0 + total;
+          uint32_t rem = remaining - total;
+          uint64_t pos = sh_newpos;
+          int depth = 1;
+          if (sh_stopped && pos == a) {
+            // the entry at the very start of the window does not fit: walk into it
+            TabCtx& nc = sh_ctx[1];
+            nc.parent = list[e];
+            nc.remaining = C.arity[K - 1];
+            nc.cls = (int8_t)(K - 2);
+            nc.found = 0;
+            nc.top = 0;
+            nc.nextOrd = 0;
+            atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
+            e++;
+            rem--;
+            pos = pos + 1;  // its '1'
+            depth = 2;
+          }
+          else if (rem == 0)
+            depth = 0;
+          sh_ctx[0].remaining = rem;
+          sh_e = e;
+          sh_pos = pos;
+          sh_depth = depth;
+        }
+        __syncthreads();
+      }
+      else {
+        if (tid == 0 && sh_depth == 1 && sh_ctx[0].remaining == 0)
+          sh_depth = 0;
+        __syncthreads();
+      }
       // ---- expand, breadth first
       for (int round = 0;; round++) {
         const uint32_t nin = sh_qn[round & 1];
@@ -951,7 +1083,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         const uint32_t wi = base + tid;
         uint64_t stay = 0;
         if (wi < nw) {
-          stay = ~sigbits[wi];
+          stay = ~__hip_atomic_load(sigbits + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t valid = n - wi * 64;
           if (valid < 64)
             stay &= (1ull << valid) - 1;
@@ -1089,14 +1221,14 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   LAUNCH_K(k_dec_load_words, dim3(wordBlocks, nc), dim3(kThreads), 0, stream, b,
                      container);
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
-  const size_t tabSmem = (size_t)(kTabW / 64 + 4) * 8 + (size_t)plan.maxK * (kTabW + 2) * 2;
+  const size_t tabSmem = b.tabSmemBytes;
   if (plan.tables) {
     static bool attr_set = false;
     if (!attr_set) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint32_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabSmem));
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint64_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabSmem));
       attr_set = true;
     }
   }

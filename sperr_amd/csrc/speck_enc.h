@@ -27,6 +27,7 @@ struct EncBuffers {
   int8_t* M;
   uint32_t* E;
   uint64_t* opos;
+  uint32_t* bucket;            // flat ids of the splitting sets, grouped by plane
   size_t nodeStride;
   // LIS, double buffered; level l occupies [levelOff[l], levelOff[l+1])
   uint64_t* lis[2];

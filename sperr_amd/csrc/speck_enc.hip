@@ -50,6 +50,8 @@ __global__ void k_enc_state_init(EncBuffers b, const uint64_t* initLIS, const ui
   s.budget = budget;
   s.lisBits = 0;
   s.cur = 0;
+  for (int q = 0; q < kMaxPlanes; q++)
+    s.bucketCnt[q] = 0;
   for (uint32_t l = 0; l < b.tree.nlevels; l++) {
     s.listLen[0][l] = initLen[l];
     s.listLen[1][l] = 0;
@@ -406,23 +408,102 @@ __global__ void __launch_bounds__(kThreads) k_list_apply(EncBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 // k_split_emit: every set whose msb equals the plane splits now
 // ------------------------------------------------------------------------------------------
+// Nodes are bucketed by the plane at which they split (k_bucket_*), so a plane only visits its
+// own splitting sets instead of scanning every node.
+__device__ __forceinline__ bool splitting_set(const Tree& t, uint32_t id, int m)
+{
+  if (m < 0)
+    return false;
+  Node nd;
+  if (!node_from_flat(t, id, nd))
+    return false;
+  const NodeGeom q = node_geom(t, nd);
+  return q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
+}
+
+__global__ void __launch_bounds__(kNodeBlock) k_bucket_hist(EncBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  EncState& s = b.st[c];
+  if (!s.active)
+    return;
+  __shared__ uint32_t h[kMaxPlanes];
+  if (threadIdx.x < kMaxPlanes)
+    h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
+  const int m = b.M[c * b.nodeStride + id];
+  if (splitting_set(b.tree, id, m))
+    atomicAdd(&h[m], 1u);
+  __syncthreads();
+  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
+    atomicAdd(&s.bucketCnt[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void k_bucket_scan(EncBuffers b)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  if (!s.active)
+    return;
+  uint32_t off = 0;
+  for (int p = 0; p < kMaxPlanes; p++) {
+    s.bucketOff[p] = off;
+    s.bucketCur[p] = off;
+    off += s.bucketCnt[p];
+  }
+}
+
+__global__ void __launch_bounds__(kNodeBlock) k_bucket_fill(EncBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  EncState& s = b.st[c];
+  if (!s.active)
+    return;
+  __shared__ uint32_t h[kMaxPlanes], base[kMaxPlanes];
+  if (threadIdx.x < kMaxPlanes)
+    h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
+  const int m = b.M[c * b.nodeStride + id];
+  const bool mine = splitting_set(b.tree, id, m);
+  uint32_t rank = 0;
+  if (mine)
+    rank = atomicAdd(&h[m], 1u);
+  __syncthreads();
+  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
+    base[threadIdx.x] = atomicAdd(&s.bucketCur[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (mine)
+    b.bucket[c * b.nodeStride + base[m] + rank] = id;
+}
+
+constexpr int kSplitBlocks = 512;
+
+__device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
+                                                uint32_t id);
+
 __global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
-  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
+  const uint32_t cnt = s.bucketCnt[p], off = s.bucketOff[p];
+  const uint32_t* bucket = b.bucket + c * b.nodeStride + off;
+  for (uint32_t k = blockIdx.x * kNodeBlock + threadIdx.x; k < cnt; k += gridDim.x * kNodeBlock)
+    split_emit_node(b, c, s, p, bucket[k]);
+}
+
+__device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
+                                                uint32_t id)
+{
   const int8_t* M = b.M + c * b.nodeStride;
-  if (M[id] != p)
-    return;
   const Tree& t = b.tree;
   Node nd;
-  if (!node_from_flat(t, id, nd))
-    return;
+  node_from_flat(t, id, nd);
   const NodeGeom q = node_geom(t, nd);
-  const bool isset = q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
-  if (!isset)
-    return;
   const uint32_t* E = b.E + c * b.nodeStride;
   const int8_t* msb = b.msb + c * b.pixStride;
 
@@ -717,10 +798,15 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
                          plan.d_depthBlocks + plan.depthBlockOff[d]);
   }
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
+  {
+    const uint32_t nodeBlocksAll = b.tree.nnodes / kNodeBlock;
+    LAUNCH_K(k_bucket_hist, dim3(nodeBlocksAll, nc), dim3(kNodeBlock), 0, stream, b);
+    LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);
+    LAUNCH_K(k_bucket_fill, dim3(nodeBlocksAll, nc), dim3(kNodeBlock), 0, stream, b);
+  }
   LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b);
   const int maxPlanes = wide_pass ? kMaxPlanes : 32;
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
-  const uint32_t nodeBlocks = b.tree.nnodes / kNodeBlock;
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
   const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
   for (int p = maxPlanes - 1; p >= 0; p--) {
@@ -728,7 +814,7 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
     LAUNCH_K(k_list_count, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_apply, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_split_emit, dim3(nodeBlocks, nc), dim3(kNodeBlock), 0, stream, b, p);
+    LAUNCH_K(k_split_emit, dim3(kSplitBlocks, nc), dim3(kNodeBlock), 0, stream, b, p);
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
       LAUNCH_K(k_born_place, dim3(bornBlocks, nc), dim3(kThreads), 0, stream, b, p);

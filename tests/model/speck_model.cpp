@@ -699,16 +699,17 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
             if (ok)
               T[j][x - a] = (uint32_t)(y - x);
           }
-        // ---- serial walk over the window
+        // ---- hop, part S: contexts below the list (an entry larger than a window is being
+        //      walked into) are handled by one thread, serially
         std::vector<WorkItem> queue;
         bool window_full = false;
-        while (!ctx.empty() && !window_full) {
+        while (ctx.size() > 1 && !window_full) {
           ParCtx& c = ctx.back();
           if (c.remaining == 0) {
             ctx.pop_back();
             continue;
           }
-          const bool coded = c.top || c.found || c.remaining > 1;
+          const bool coded = c.found || c.remaining > 1;
           uint64_t x = pos;
           int b = 1;
           if (coded) {
@@ -719,22 +720,13 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
             b = in.get(x);
             x++;
           }
-          // identity of the item
-          Node nd;
-          uint32_t ridx = 0;
           const bool is_pixel = c.cls < 0;
-          if (c.top)
-            nd = unpack_node(lis[l][e]);
-          else if (is_pixel)
-            ridx = regular_child_raster(t, c.parent, c.nextOrdinal);
-          else
-            nd = regular_child(t, c.parent, c.nextOrdinal);
           if (is_pixel) {
-            if (b && x >= lim) {  // sign bit not in the window
+            if (b && x >= lim) {
               window_full = true;
               break;
             }
-            pixel_event(ridx, b != 0, x);
+            pixel_event(regular_child_raster(t, c.parent, c.nextOrdinal), b != 0, x);
             if (b) {
               x++;
               c.found = true;
@@ -744,46 +736,161 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
             pos = x;
             continue;
           }
+          const Node nd = regular_child(t, c.parent, c.nextOrdinal);
           if (!b) {
-            if (c.top) {
-              next[l].push_back(lis[l][e]);
-              e++;
-            }
-            else
-              bornv.push_back({C.lev[c.cls], x - 1, pack_node(nd)});
+            bornv.push_back({C.lev[c.cls], x - 1, pack_node(nd)});
             c.remaining--;
             c.nextOrdinal++;
             pos = x;
             continue;
           }
-          // significant set of class c.cls whose split starts at x
           const uint32_t tl = (x <= lim) ? T[c.cls][x - a] : T_INF;
-          if (tl != T_INF) {
-            queue.push_back({nd, c.cls, x});
-            c.found = true;
-            c.remaining--;
-            c.nextOrdinal++;
-            if (c.top)
-              e++;
-            pos = x + tl;
-            continue;
-          }
-          // does not fit: if nothing was consumed in this window yet we must descend,
-          // otherwise retry it at the start of the next window
-          if (x - (coded ? 1 : 0) != a) {
+          if (tl == T_INF && x - (coded ? 1 : 0) != a) {
             window_full = true;
             break;
           }
+          const int cls = c.cls;
           c.found = true;
           c.remaining--;
           c.nextOrdinal++;
-          if (c.top)
-            e++;
-          pos = x;
-          const int kidcls = c.cls - 1;  // -1: pixels
-          ParCtx nc{kidcls, C.arity[c.cls], false, false, nd, 0};
-          ctx.push_back(nc);  // invalidates c
+          if (tl != T_INF) {
+            queue.push_back({nd, cls, x});
+            pos = x + tl;
+          }
+          else {
+            pos = x;
+            ctx.push_back({cls - 1, C.arity[cls], false, false, nd, 0});
+          }
         }
+        // ---- hop, part P: the list itself.  64-bit blocks aligned to absolute word
+        //      boundaries; per block a backward memo gives, for every position, where the chain
+        //      leaves the block and how many entries it passes; one thread then walks the
+        //      blocks; the blocks emit their entries in parallel.
+        if (ctx.size() == 1 && !window_full && ctx[0].remaining > 0 && pos < lim) {
+          ParCtx& c = ctx[0];
+          const uint64_t B0 = pos >> 6, B1 = (lim - 1) >> 6;
+          const size_t nblk = (size_t)(B1 - B0 + 1);
+          std::vector<uint64_t> exitp((size_t)nblk * 64, 0);
+          std::vector<uint32_t> cnt((size_t)nblk * 64, 0);
+          std::vector<char> stop((size_t)nblk * 64, 0);
+          for (size_t bi = 0; bi < nblk; bi++)        // parallel over blocks
+            for (int o = 63; o >= 0; o--) {
+              const uint64_t x = (B0 + bi) * 64 + o;
+              const size_t k = bi * 64 + o;
+              if (x < pos || x >= lim)
+                continue;
+              uint64_t nx;
+              if (!in.get(x))
+                nx = x + 1;
+              else {
+                const uint32_t tl = (x + 1 <= lim) ? T[K - 1][x + 1 - a] : T_INF;
+                if (tl == T_INF) {
+                  stop[k] = 1;
+                  exitp[k] = x;
+                  cnt[k] = 0;
+                  continue;
+                }
+                nx = x + 1 + tl;
+              }
+              if (nx >= (B0 + bi + 1) * 64 || nx >= lim) {
+                exitp[k] = nx;
+                cnt[k] = 1;
+                stop[k] = 0;
+              }
+              else {
+                const size_t kn = (size_t)(nx - B0 * 64);
+                exitp[k] = exitp[kn];
+                cnt[k] = cnt[kn] + 1;
+                stop[k] = stop[kn];
+              }
+            }
+          // one thread: walk the blocks
+          std::vector<uint64_t> entry(nblk, ~0ull);
+          std::vector<uint32_t> base(nblk, 0), limit(nblk, 0);
+          uint64_t x = pos, newpos = pos;
+          uint32_t total = 0;
+          bool stopped = false;
+          const uint32_t remaining = (uint32_t)c.remaining;
+          while (true) {
+            if (x >= lim) {
+              newpos = x;
+              break;
+            }
+            const size_t bi = (size_t)((x >> 6) - B0), k = (size_t)(x - B0 * 64);
+            entry[bi] = x;
+            base[bi] = total;
+            if (total + cnt[k] >= remaining) {
+              limit[bi] = remaining - total;  // the list ends inside this block
+              total = remaining;
+              newpos = ~0ull;                 // set by the block below
+              break;
+            }
+            limit[bi] = cnt[k];
+            total += cnt[k];
+            if (stop[k]) {
+              stopped = true;
+              newpos = exitp[k];
+              break;
+            }
+            x = exitp[k];
+          }
+          // parallel over blocks: emit
+          for (size_t bi = 0; bi < nblk; bi++) {
+            if (entry[bi] == ~0ull)
+              continue;
+            uint64_t y = entry[bi];
+            for (uint32_t k = 0; k < limit[bi]; k++) {
+              const size_t ei = e + base[bi] + k;
+              if (!in.get(y))
+                y += 1;  // stays in the list (collected in order below)
+              else {
+                const uint32_t tl = T[K - 1][y + 1 - a];
+                queue.push_back({unpack_node(lis[l][ei]), K - 1, y + 1});
+                y += 1 + tl;
+              }
+              (void)ei;
+            }
+            if (newpos == ~0ull && base[bi] + limit[bi] == remaining && limit[bi] > 0)
+              newpos = y;
+          }
+          // survivors keep list order: redo the placeholders sequentially (the kernel uses a
+          // significance bitmap + compaction)
+          {
+            // significance per entry in order
+            std::vector<char> sigv(total, 0);
+            for (size_t bi = 0; bi < nblk; bi++) {
+              if (entry[bi] == ~0ull)
+                continue;
+              uint64_t y = entry[bi];
+              for (uint32_t k = 0; k < limit[bi]; k++) {
+                const int bb = in.get(y);
+                sigv[base[bi] + k] = (char)bb;
+                y += bb ? 1 + T[K - 1][y + 1 - a] : 1;
+              }
+            }
+            for (uint32_t k = 0; k < total; k++)
+              if (!sigv[k])
+                next[l].push_back(lis[l][e + k]);
+          }
+          e += total;
+          c.remaining -= (int)total;
+          if (total > 0)
+            c.found = true;
+          if (newpos == ~0ull)
+            abort();
+          const bool progressed = newpos != a;
+          pos = newpos;
+          if (stopped && !progressed) {
+            // the entry at the very start of the window does not fit: walk into it
+            const Node nd = unpack_node(lis[l][e]);
+            e++;
+            c.remaining--;
+            pos = pos + 1;  // its '1'
+            ctx.push_back({K - 2, C.arity[K - 1], false, false, nd, 0});
+          }
+        }
+        if (!ctx.empty() && ctx.size() == 1 && ctx[0].remaining == 0)
+          ctx.pop_back();
         // ---- expand everything that was queued (parallel BFS in the kernel)
         while (!queue.empty()) {
           std::vector<WorkItem> nq;
