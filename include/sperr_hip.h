@@ -96,6 +96,12 @@ void sperrhip_profile_reset(void);
 /* Fills up to `cap` entries; returns the number of stages. names[i] points to a static string. */
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap);
 
+/* Diagnostics of the table-driven LIS decoder: when `on`, thread 0 of every decoding workgroup
+ * accumulates wall-clock ticks (100 MHz-class counter) per phase; out16 (may be NULL) receives the
+ * counters of chunk 0 of the last decoded batch: load, tables, hopS, P1, P2, P3, P4, expand,
+ * compaction, windows, placement. */
+void sperrhip_debug_lis_stamps(int on, unsigned long long* out16);
+
 /* Library/engine identification, e.g. "sperr_hip 0.1 (gfx950)". */
 const char* sperrhip_version(void);
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
-    "sperrhip_profile_get", "sperrhip_version",
+    "sperrhip_profile_get", "sperrhip_version", "sperrhip_debug_lis_stamps",
 ]
 
 

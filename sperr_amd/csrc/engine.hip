@@ -866,6 +866,9 @@ int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci,
   return r == 0 ? 0 : -1;
 }
 
+bool g_lis_stamps_on = false;
+std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
+
 struct DecBatchBufs {
   DecBuffers db;
   ChunkGeom* geom;
@@ -932,6 +935,10 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.bornPacked, uint64_t, d.bornStride * B);
   TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
   d.tabSmemBytes = 150 * 1024;
+  d.lisStamps = nullptr;
+  if (g_lis_stamps_on) {
+    TAKE(d.lisStamps, uint64_t, 16 * B);
+  }
   d.queueCap = 28672 + 64;
   d.queueStride = (size_t)d.queueCap * 4;
   TAKE(d.queue, uint64_t, d.queueStride * B);
@@ -1037,6 +1044,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
                      P->maxK};
       HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, st));
+      if (d.lisStamps)
+        HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 16 * 8 * nb, st));
       // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
       // buffer, which the 32-bit pass then fills for the remaining chunks
       for (int wide = 1; wide >= 0; wide--) {
@@ -1069,6 +1078,10 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       }
       if (launch_scatter<T>(st, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
         return -1;
+      if (d.lisStamps) {
+        g_lis_stamps_host.assign(16, 0);
+        HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), d.lisStamps, 16 * 8, hipMemcpyDeviceToHost, st));
+      }
       // stream errors (wrong lengths) surface here
       std::vector<DecState> hs(nb);
       HIP_CHECK(hipMemcpyAsync(hs.data(), d.st, nb * sizeof(DecState), hipMemcpyDeviceToHost, st));
@@ -1146,6 +1159,13 @@ const char* sperrhip_version(void)
 void sperrhip_profile_enable(int on)
 {
   g_prof.on = on != 0;
+}
+void sperrhip_debug_lis_stamps(int on, unsigned long long* out16)
+{
+  g_lis_stamps_on = on != 0;
+  if (out16)
+    for (size_t i = 0; i < 16; i++)
+      out16[i] = i < g_lis_stamps_host.size() ? g_lis_stamps_host[i] : 0;
 }
 void sperrhip_profile_reset(void)
 {

@@ -69,6 +69,7 @@ struct DecBuffers {
   uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
   size_t sigbitsStride;
   uint32_t tabSmemBytes;       // dynamic LDS given to k_lis_tables
+  uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
 };
 
 struct DecPlanHost {

@@ -586,29 +586,31 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 // After the last level the recorded sets are ranked by position (popcount prefix of per-level
 // position masks) and appended to the next lists; old entries are compacted in order.
 // ------------------------------------------------------------------------------------------
-constexpr int kTabWMax = 28672;   // window bits: < 2^15 (hopExit keeps a flag in bit 15)
+constexpr int kTabWMax = 28672;   // window bits: < 2^15 (table entries keep a flag in bit 15)
 constexpr int kTabThreads = 1024;
+constexpr uint32_t kTInf = 0xffffu;
 
-// bytes of LDS the tables of a level with chain length K need per window bit: 2K (T) + 3 (hop)
-// + 1/8 (bits).  The window is the largest multiple of 1024 that fits.
+// LDS bytes per window bit for a level with chain length K: T_0..T_{K-2} and U_0..U_{K-1} (u16
+// each), the hop word (u32) and the bit itself.  The window is the largest multiple of 1024 that
+// fits.
 __host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
 {
-  const uint32_t fixed = 4 * 8 + 128 * 3 + (uint32_t)K * 4 + 64;
-  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / (uint64_t)(16 * K + 25));
+  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 4) + 1u;   // eighths of a byte
+  const uint32_t fixed = 4 * 8 + 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
+  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
   w = w / 1024 * 1024;
   if (w > (uint32_t)kTabWMax)
     w = kTabWMax;
   return w;
 }
-constexpr uint32_t kTInf = 0xffffu;
 
 struct TabCtx {
-  uint64_t parent;     // packed parent node of the items (unused for the list context)
+  uint64_t parent;     // packed parent node of the items
   uint32_t remaining;  // items left in this context
   int8_t cls;          // class of the items (-1: pixels)
   uint8_t found;       // an earlier item of this context was significant
-  uint8_t top;         // the list context: every item is coded
   uint8_t nextOrd;     // ordinal of the next child
+  uint8_t pad;
 };
 
 __device__ __forceinline__ Node reg_child(const Tree& t, const Node& nd, uint32_t ord, int ee[3],
@@ -634,6 +636,13 @@ __device__ __forceinline__ Node reg_child(const Tree& t, const Node& nd, uint32_
   return c;
 }
 
+__device__ __forceinline__ uint64_t reg_child_packed(const Tree& t, const Node& nd, uint32_t ord)
+{
+  int ee[3];
+  uint32_t idx[3];
+  return pack_node(reg_child(t, nd, ord, ee, idx));
+}
+
 __device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& nd, uint32_t ord)
 {
   int ee[3];
@@ -642,6 +651,11 @@ __device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& 
   return pixel_raster(t, t.roots[t.grids[nd.grid].root], ee, idx);
 }
 
+// Tables of one window (all positions are relative to the window start, 0..W):
+//   T_j[r]  bits the split of a class-j set takes when it starts at r, or kTInf
+//   U_j[r]  the CODED item of class j at r: bit 15 = its test bit, low 15 bits = code length
+//           (1 for an insignificant item, 1 + T_j[r+1] otherwise), or kTInf when it is
+//           significant but leaves the window
 template <typename CT>
 __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 {
@@ -649,23 +663,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   extern __shared__ __attribute__((aligned(16))) char tab_smem[];
-  // The window length W depends on the level: short class chains leave room for long windows.
-  // LDS layout: wbits[W/64 + 4] u64 | hopExit[W + 128] u16 | hopCnt[W + 128] u8 | T[K][W + 2] u16
   uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
-  uint32_t W = 0;
-  int kWords = 0, kTS = 0;
-  uint16_t* hopExit = nullptr;
-  uint8_t* hopCnt = nullptr;
-  uint16_t* T = nullptr;
-  constexpr int kBlk = kTabWMax / 64 + 2;
-  __shared__ uint16_t blkEntry[kBlk], blkLimit[kBlk];
-  __shared__ uint32_t blkBase[kBlk];
-  __shared__ uint32_t sh_total, sh_stopped;
-  __shared__ uint64_t sh_newpos;
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(tab_smem);
+  uint32_t W = 0, TS = 0;
+  uint32_t* hop = nullptr;   // [W + 130]  cnt << 16 | stop << 15 | exit
+  uint16_t* Tt = nullptr;    // [K - 1][TS]
+  uint16_t* Uu = nullptr;    // [K][TS]
+  constexpr int kBlk = kTabWMax / 64 + 4;
+  __shared__ uint32_t blkEB[kBlk];             // entry position | entries before it << 16
+  __shared__ uint32_t sh_total, sh_stopped, sh_newr;
   __shared__ uint64_t sh_pos;
   __shared__ int sh_depth;
   __shared__ TabCtx sh_ctx[kMaxClasses + 2];
-  __shared__ uint32_t sh_e, sh_qn[2], sh_born, sh_flag;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn[2], sh_born, sh_flag;
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
 
   const Tree& t = b.tree;
@@ -691,17 +701,35 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     sh_born = 0;
   }
   __syncthreads();
+  // diagnostic stamps (thread 0 only, when b.lisStamps != nullptr): ticks per phase
+  uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t stamp_t = 0;
+  const bool stamps = b.lisStamps != nullptr && tid == 0;
+#define STAMP(i)                                        \
+  if (stamps) {                                         \
+    const uint64_t now_ = __builtin_readcyclecounter(); \
+    stamp_acc[i] += now_ - stamp_t;                     \
+    stamp_t = now_;                                     \
+  }
+  if (stamps)
+    stamp_t = __builtin_readcyclecounter();
 
-  uint64_t w0 = 0;  // absolute index of wbits[0]
-  auto bit_at = [&](uint64_t abs) -> uint32_t {
-    return (uint32_t)((wbits[(abs >> 6) - w0] >> (abs & 63)) & 1ull);
+  uint32_t wq0 = 0;  // bit offset of window position 0 inside wbits[0]
+  auto bit_at = [&](uint32_t r) -> uint32_t {
+    const uint32_t q = r + wq0;
+    return (w32[q >> 5] >> (q & 31)) & 1u;
   };
-  auto pixel_event = [&](uint32_t ridx, bool sig, uint64_t signpos) {
+  auto bits32 = [&](uint32_t r) -> uint32_t {  // 32 stream bits starting at r
+    const uint32_t q = r + wq0, sh = q & 31;
+    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  };
+  auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
     born[ridx] = (int8_t)p;
     if (sig) {
       sigp[ridx] = (int8_t)p;
       coef[ridx] = init;
-      if (!bit_at(signpos))
+      if (!signbit)
         atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
     }
   };
@@ -729,83 +757,116 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     const LevelClass C = b.levelClass[l];
     const int K = C.K;
     W = tab_window(K, b.tabSmemBytes);
-    kWords = (int)(W / 64 + 4);
-    kTS = (int)W + 2;
-    hopExit = reinterpret_cast<uint16_t*>(tab_smem + (size_t)kWords * 8);
-    hopCnt = reinterpret_cast<uint8_t*>(hopExit + (W + 128));
-    T = reinterpret_cast<uint16_t*>(hopCnt + (W + 128));
+    TS = W + 2;
+    const uint32_t kWords = W / 64 + 4;
+    hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);
+    Tt = reinterpret_cast<uint16_t*>(hop + (W + 130));
+    Uu = Tt + (size_t)(K - 1) * TS;
+    const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
-    // significance bits of the old entries, filled by the hop thread
-    for (uint32_t i = tid; i < (n + 63) / 64; i += kTabThreads)
+    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kTabThreads)
       sigbits[i] = 0;
     if (tid == 0) {
       sh_depth = 1;
-      sh_ctx[0].parent = 0;
-      sh_ctx[0].remaining = n;
-      sh_ctx[0].cls = (int8_t)(K - 1);
-      sh_ctx[0].found = 0;
-      sh_ctx[0].top = 1;
-      sh_ctx[0].nextOrd = 0;
+      sh_rem = n;
       sh_e = 0;
     }
     __syncthreads();
 
+    // split length of a class-j set starting at r (uses the tables of class j-1)
+    auto split_len = [&](int j, uint32_t r) -> uint32_t {
+      const int ar = C.arity[j];
+      if (j == 0) {
+        if (r >= W)
+          return kTInf;
+        const uint32_t v = bits32(r);
+        uint32_t y = 0, found = 0;
+        for (int i = 0; i < ar; i++) {
+          const uint32_t coded = found | (uint32_t)(i + 1 != ar);
+          const uint32_t bit = coded ? (v >> y) & 1u : 1u;
+          y += coded;
+          found |= bit;
+          y += bit;  // sign bit
+        }
+        return r + y <= W ? y : kTInf;
+      }
+      const uint16_t* Up = Uu + (size_t)(j - 1) * TS;
+      uint32_t y = r, found = 0;
+      for (int i = 0; i + 1 < ar; i++) {
+        const uint32_t u = Up[y];
+        if (u == kTInf)
+          return kTInf;
+        found |= u >> 15;
+        y += u & 0x7fffu;
+      }
+      uint32_t last;
+      if (found) {
+        const uint32_t u = Up[y];
+        if (u == kTInf)
+          return kTInf;
+        last = u & 0x7fffu;
+      }
+      else {
+        last = Tt[(size_t)(j - 1) * TS + y];
+        if (last == kTInf)
+          return kTInf;
+      }
+      return y + last - r;
+    };
+
     while (sh_depth > 0) {
       const uint64_t a = sh_pos;
       __syncthreads();  // everyone has read sh_pos / sh_depth before thread 0 changes them
-      w0 = a >> 6;
-      for (int i = tid; i < kWords; i += kTabThreads) {
+      const uint64_t w0 = a >> 6;
+      wq0 = (uint32_t)(a & 63);
+      for (uint32_t i = tid; i < kWords; i += kTabThreads) {
         const uint64_t idx = w0 + i;
         wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
       }
       __syncthreads();
-      // ---- tables: T[j][x - a] for x in [a, a + W]
+      STAMP(0);
+      // ---- tables
       for (int j = 0; j < K; j++) {
-        const int ar = C.arity[j];
-        const uint16_t* Tp = T + (size_t)(j - 1) * kTS;
-        uint16_t* Tj = T + (size_t)j * kTS;
-        for (uint32_t rel = tid; rel <= W; rel += kTabThreads) {
-          uint32_t y = rel;
-          bool found = false, ok = true;
-          for (int i = 0; i < ar; i++) {
-            const bool coded = found || (i + 1 != ar);
-            uint32_t bit = 1;
-            if (coded) {
-              if (y >= W) {
-                ok = false;
-                break;
+        uint16_t* Uj = Uu + (size_t)j * TS;
+        if (j < K - 1) {
+          uint16_t* Tj = Tt + (size_t)j * TS;
+          for (uint32_t r = tid; r <= W; r += kTabThreads)
+            Tj[r] = (uint16_t)split_len(j, r);
+          __syncthreads();
+          for (uint32_t r = tid; r <= W; r += kTabThreads) {
+            uint32_t u = kTInf;
+            if (r < W) {
+              u = 1;
+              if (bit_at(r)) {
+                const uint32_t tl = Tj[r + 1];
+                u = tl == kTInf ? kTInf : (0x8000u | (1u + tl));
               }
-              bit = bit_at(a + y);
-              y++;
             }
-            if (!bit)
-              continue;
-            found = true;
-            if (j == 0) {
-              if (y >= W) {
-                ok = false;
-                break;
-              }
-              y++;  // sign bit
-            }
-            else {
-              const uint32_t tl = y <= W ? Tp[y] : kTInf;
-              if (tl == kTInf) {
-                ok = false;
-                break;
-              }
-              y += tl;
-            }
+            Uj[r] = (uint16_t)u;
           }
-          Tj[rel] = ok ? (uint16_t)(y - rel) : (uint16_t)kTInf;
+        }
+        else {  // the level's own class: only the coded form is ever needed
+          for (uint32_t r = tid; r <= W; r += kTabThreads) {
+            uint32_t u = kTInf;
+            if (r < W) {
+              u = 1;
+              if (bit_at(r)) {
+                const uint32_t tl = split_len(j, r + 1);
+                u = tl == kTInf ? kTInf : (0x8000u | (1u + tl));
+              }
+            }
+            Uj[r] = (uint16_t)u;
+          }
         }
         __syncthreads();
       }
+      STAMP(1);
+      if (stamps)
+        stamp_acc[9] += 1;
       // ---- hop, part S: contexts below the list (an entry larger than a window is being
       //      walked into) are handled serially by one thread
       if (tid == 0) {
-        uint64_t pos = a;
-        const uint64_t lim = a + W;
+        uint32_t r = 0;
         int depth = sh_depth;
         uint32_t qn = 0;
         bool full = false;
@@ -816,212 +877,212 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             continue;
           }
           const bool coded = cx.found || cx.remaining > 1;
-          uint64_t x = pos;
-          uint32_t bit = 1;
-          if (coded) {
-            if (x >= lim) {
-              full = true;
-              break;
-            }
-            bit = bit_at(x);
-            x++;
-          }
           if (cx.cls < 0) {  // pixel item of a descended leaf parent
-            if (bit && x >= lim) {
+            uint32_t bit = 1, y = r;
+            if (coded) {
+              if (y >= W) {
+                full = true;
+                break;
+              }
+              bit = bit_at(y);
+              y++;
+            }
+            if (bit && y >= W) {
               full = true;
               break;
             }
             const uint32_t ridx = reg_child_raster(t, unpack_node(cx.parent), cx.nextOrd);
-            pixel_event(ridx, bit != 0, x);
+            pixel_event(ridx, bit != 0, bit ? bit_at(y) : 1u);
             if (bit) {
-              x++;
+              y++;
               cx.found = 1;
             }
             cx.remaining--;
             cx.nextOrd++;
-            pos = x;
+            r = y;
             continue;
           }
-          int ee[3];
-          uint32_t idx[3];
-          const uint64_t kid = pack_node(reg_child(t, unpack_node(cx.parent), cx.nextOrd, ee, idx));
-          if (!bit) {
-            record_born(C.lev[cx.cls], x - 1, kid);
-            cx.remaining--;
-            cx.nextOrd++;
-            pos = x;
-            continue;
+          const int cls = cx.cls;
+          const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd);
+          uint32_t sig, start, len;   // test bit, first bit of the split, bits of the split
+          if (coded) {
+            const uint32_t u = r < W ? Uu[(size_t)cls * TS + r] : kTInf;
+            if (u == 1) {  // insignificant
+              record_born(C.lev[cls], a + r, kid);
+              cx.remaining--;
+              cx.nextOrd++;
+              r += 1;
+              continue;
+            }
+            if (r >= W) {
+              full = true;
+              break;
+            }
+            sig = 1;
+            start = r + 1;
+            len = u == kTInf ? kTInf : (u & 0x7fffu) - 1u;
           }
-          const uint32_t tl = (x - a) <= (uint64_t)W ? T[(size_t)cx.cls * kTS + (x - a)] : kTInf;
-          if (tl == kTInf && x - (coded ? 1 : 0) != a) {
+          else {
+            sig = 1;
+            start = r;
+            len = Tt[(size_t)cls * TS + r];
+          }
+          (void)sig;
+          if (len == kTInf && r != 0) {
             full = true;  // retry at the start of the next window
             break;
           }
-          const int cls = cx.cls;
           cx.found = 1;
           cx.remaining--;
           cx.nextOrd++;
-          if (tl != kTInf) {
+          if (len != kTInf) {
             qbuf[0][qn * 2] = kid;
-            qbuf[0][qn * 2 + 1] = (x << 8) | ((uint64_t)cls << 1);
+            qbuf[0][qn * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)cls << 1);
             qn++;
-            pos = x + tl;
+            r = start + len;
           }
           else {  // larger than a window: walk into it
-            pos = x;
+            r = start;
             TabCtx& nc = sh_ctx[depth];
             nc.parent = kid;
             nc.remaining = C.arity[cls];
             nc.cls = (int8_t)(cls - 1);
             nc.found = 0;
-            nc.top = 0;
             nc.nextOrd = 0;
             depth++;
           }
         }
-        sh_pos = pos;
+        sh_pos = a + r;
         sh_depth = depth;
         sh_qn[0] = qn;
         sh_qn[1] = 0;
         sh_flag = full ? 1u : 0u;
       }
       __syncthreads();
+      STAMP(2);
       // ---- hop, part P: the list itself, in parallel.  64-bit blocks aligned to stream words;
       //      (P1) per block a backward memo: where the chain leaves the block from each position
       //      and how many entries it passes; (P2) one thread walks the blocks; (P3) the blocks
       //      emit their entries.
-      const uint64_t ppos = sh_pos;
-      const uint64_t lim = a + W;
-      const bool doP = sh_depth == 1 && sh_flag == 0 && sh_ctx[0].remaining > 0 && ppos < lim;
+      const uint32_t pr = (uint32_t)(sh_pos - a);   // first position of the list part
+      const bool doP = sh_depth == 1 && sh_flag == 0 && sh_rem > 0 && pr < W;
       __syncthreads();
       if (doP) {
-        const uint32_t remaining = sh_ctx[0].remaining;
+        const uint32_t remaining = sh_rem;
         const uint32_t e0 = sh_e;
-        const uint64_t B0 = ppos >> 6;
-        const uint32_t nblk = (uint32_t)(((lim - 1) >> 6) - B0 + 1);
-        const uint16_t* Ttop = T + (size_t)(K - 1) * kTS;
+        // hop index h = (r + wq0) - 64 * firstBlock, so blocks are stream words
+        const uint32_t fb = (pr + wq0) >> 6;
+        const uint32_t nblk = ((W - 1 + wq0) >> 6) - fb + 1;
+        const int32_t rbase = (int32_t)(fb * 64) - (int32_t)wq0;   // r = h + rbase
         if ((uint32_t)tid < nblk) {  // P1
-          const uint64_t blk0 = (B0 + tid) * 64;
-          const uint64_t wbitsWord = wbits[(B0 + tid) - w0];
           for (int o = 63; o >= 0; o--) {
-            const uint64_t x = blk0 + o;
-            if (x < ppos || x >= lim)
+            const uint32_t h = (uint32_t)tid * 64 + o;
+            const int32_t rs = (int32_t)h + rbase;
+            if (rs < (int32_t)pr || rs >= (int32_t)W)
               continue;
-            const uint32_t r = (uint32_t)(x - B0 * 64);
-            uint64_t nx;
-            if (!((wbitsWord >> o) & 1ull))
-              nx = x + 1;
-            else {
-              const uint32_t tl = (x + 1 - a) <= (uint64_t)W ? Ttop[x + 1 - a] : kTInf;
-              if (tl == kTInf) {
-                hopExit[r] = (uint16_t)(0x8000u | (uint32_t)(x - a));
-                hopCnt[r] = 0;
-                continue;
-              }
-              nx = x + 1 + tl;
+            const uint32_t r = (uint32_t)rs;
+            const uint32_t u = Utop[r];
+            if (u == kTInf) {
+              hop[h] = 0x8000u | r;
+              continue;
             }
-            if (nx >= blk0 + 64 || nx >= lim) {
-              hopExit[r] = (uint16_t)(nx - a);
-              hopCnt[r] = 1;
-            }
-            else {
-              const uint32_t rn = (uint32_t)(nx - B0 * 64);
-              hopExit[r] = hopExit[rn];
-              hopCnt[r] = (uint8_t)(hopCnt[rn] + 1);
-            }
+            const uint32_t nr = r + (u & 0x7fffu);
+            const uint32_t nh = (uint32_t)((int32_t)nr - rbase);
+            if (nh >= ((uint32_t)tid + 1) * 64 || nr >= W)
+              hop[h] = (1u << 16) | nr;
+            else
+              hop[h] = hop[nh] + (1u << 16);
           }
-          blkEntry[tid] = 0xffff;
+          blkEB[tid] = 0xffffffffu;
         }
         __syncthreads();
+        STAMP(3);
         if (tid == 0) {  // P2
-          uint64_t x = ppos;
-          uint32_t total = 0;
-          uint32_t stopped = 0;
-          uint64_t newpos = ~0ull;
+          uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
           while (true) {
-            if (x >= lim) {
-              newpos = x;
+            if (r >= W) {
+              newr = r;
               break;
             }
-            const uint32_t bi = (uint32_t)((x >> 6) - B0), r = (uint32_t)(x - B0 * 64);
-            const uint32_t cn = hopCnt[r];
-            const uint32_t ex = hopExit[r];
-            blkEntry[bi] = (uint16_t)(x - a);
-            blkBase[bi] = total;
+            const uint32_t h = (uint32_t)((int32_t)r - rbase);
+            const uint32_t v = hop[h];
+            const uint32_t cn = v >> 16;
+            blkEB[h >> 6] = r | (total << 16);
             if (total + cn >= remaining) {
-              blkLimit[bi] = (uint16_t)(remaining - total);  // the list ends inside this block
-              total = remaining;
+              total = remaining;   // the list ends inside this block; P3 reports where
               break;
             }
-            blkLimit[bi] = (uint16_t)cn;
             total += cn;
-            if (ex & 0x8000u) {
+            if (v & 0x8000u) {
               stopped = 1;
-              newpos = a + (ex & 0x7fffu);
+              newr = v & 0x7fffu;
               break;
             }
-            x = a + ex;
+            r = v & 0x7fffu;
           }
           sh_total = total;
           sh_stopped = stopped;
-          sh_newpos = newpos;
+          sh_newr = newr;
         }
         __syncthreads();
-        if ((uint32_t)tid < nblk && blkEntry[tid] != 0xffff) {  // P3
-          uint64_t y = a + blkEntry[tid];
-          const uint32_t lim_k = blkLimit[tid], base = blkBase[tid];
+        STAMP(4);
+        if ((uint32_t)tid < nblk && blkEB[tid] != 0xffffffffu) {  // P3
+          const uint32_t eb = blkEB[tid];
+          uint32_t r = eb & 0xffffu;
+          const uint32_t base = eb >> 16;
+          const uint32_t cn = hop[(uint32_t)((int32_t)r - rbase)] >> 16;
+          const uint32_t lim_k = min(cn, remaining - base);
           for (uint32_t k = 0; k < lim_k; k++) {
-            const uint32_t ei = e0 + base + k;
-            if (!bit_at(y))
-              y += 1;
-            else {
-              const uint32_t tl = Ttop[y + 1 - a];
+            const uint32_t u = Utop[r];
+            if (u & 0x8000u) {
+              const uint32_t ei = e0 + base + k;
               const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
               qbuf[0][slot * 2] = ei;
-              qbuf[0][slot * 2 + 1] = ((y + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+              qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
               atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
-              y += 1 + tl;
             }
+            r += u & 0x7fffu;
           }
           if (lim_k > 0 && base + lim_k == remaining)
-            sh_newpos = y;  // the list ended in this block (only one block satisfies this)
+            sh_newr = r;  // the list ended in this block (only one block satisfies this)
         }
         __syncthreads();
+        STAMP(5);
         if (tid == 0) {  // P4
           const uint32_t total = sh_total;
           uint32_t e = e0 + total;
           uint32_t rem = remaining - total;
-          uint64_t pos = sh_newpos;
+          uint32_t r = sh_newr;
           int depth = 1;
-          if (sh_stopped && pos == a) {
+          if (sh_stopped && r == 0) {
             // the entry at the very start of the window does not fit: walk into it
             TabCtx& nc = sh_ctx[1];
             nc.parent = list[e];
             nc.remaining = C.arity[K - 1];
             nc.cls = (int8_t)(K - 2);
             nc.found = 0;
-            nc.top = 0;
             nc.nextOrd = 0;
             atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
             e++;
             rem--;
-            pos = pos + 1;  // its '1'
+            r = 1;  // its '1'
             depth = 2;
           }
           else if (rem == 0)
             depth = 0;
-          sh_ctx[0].remaining = rem;
+          sh_rem = rem;
           sh_e = e;
-          sh_pos = pos;
+          sh_pos = a + r;
           sh_depth = depth;
         }
         __syncthreads();
       }
       else {
-        if (tid == 0 && sh_depth == 1 && sh_ctx[0].remaining == 0)
+        if (tid == 0 && sh_depth == 1 && sh_rem == 0)
           sh_depth = 0;
         __syncthreads();
       }
+      STAMP(6);
       // ---- expand, breadth first
       for (int round = 0;; round++) {
         const uint32_t nin = sh_qn[round & 1];
@@ -1032,39 +1093,45 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         for (uint32_t i = tid; i < nin; i += kTabThreads) {
           const uint64_t ident = qin[i * 2], meta = qin[i * 2 + 1];
           const int cls = (int)((meta >> 1) & 0x7f);
-          uint64_t y = meta >> 8;
+          uint32_t y = (uint32_t)(meta >> 8);
           const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
           const int ar = C.arity[cls];
-          bool found = false;
+          if (cls == 0) {
+            const uint32_t v = bits32(y);
+            uint32_t yy = 0, found = 0;
+            for (int k = 0; k < ar; k++) {
+              const uint32_t coded = found | (uint32_t)(k + 1 != ar);
+              const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+              yy += coded;
+              const uint32_t sgn = (v >> yy) & 1u;
+              pixel_event(reg_child_raster(t, nd, k), bit != 0, sgn);
+              found |= bit;
+              yy += bit;
+            }
+            continue;
+          }
+          const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
+          uint32_t found = 0;
           for (int k = 0; k < ar; k++) {
+            const uint64_t kid = reg_child_packed(t, nd, k);
             const bool coded = found || (k + 1 != ar);
-            uint32_t bit = 1;
+            uint32_t start = y;
             if (coded) {
-              bit = bit_at(y);
-              y++;
-            }
-            if (cls == 0) {
-              const uint32_t ridx = reg_child_raster(t, nd, k);
-              pixel_event(ridx, bit != 0, y);
-              if (bit) {
-                y++;
-                found = true;
+              const uint32_t u = Up[y];
+              if (!(u & 0x8000u)) {
+                record_born(C.lev[cls - 1], a + y, kid);
+                y += 1;
+                continue;
               }
+              start = y + 1;
+              y += u & 0x7fffu;
             }
-            else {
-              int ee[3];
-              uint32_t idx[3];
-              const uint64_t kid = pack_node(reg_child(t, nd, k, ee, idx));
-              if (bit) {
-                found = true;
-                const uint32_t slot = atomicAdd(&sh_qn[(round + 1) & 1], 1u);
-                qout[slot * 2] = kid;   // cannot overflow: see queueCap
-                qout[slot * 2 + 1] = (y << 8) | ((uint64_t)(cls - 1) << 1);
-                y += T[(size_t)(cls - 1) * kTS + (y - a)];
-              }
-              else
-                record_born(C.lev[cls - 1], y - 1, kid);
-            }
+            else
+              y += Tt[(size_t)(cls - 1) * TS + y];
+            found = 1;
+            const uint32_t slot = atomicAdd(&sh_qn[(round + 1) & 1], 1u);
+            qout[slot * 2] = kid;
+            qout[slot * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)(cls - 1) << 1);
           }
         }
         __syncthreads();
@@ -1072,10 +1139,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           sh_qn[round & 1] = 0;
         __syncthreads();
       }
+      STAMP(7);
     }
     // ---- old entries that stayed insignificant keep their order
     {
-      uint32_t* scan = sh_scan;
       uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
       uint32_t carry = 0;
       const uint32_t nw = (n + 63) / 64;
@@ -1089,7 +1156,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             stay &= (1ull << valid) - 1;
         }
         uint32_t total;
-        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), scan, &total) + carry;
+        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), sh_scan, &total) + carry;
         while (stay) {
           const int k = __ffsll((long long)stay) - 1;
           stay &= stay - 1;
@@ -1101,6 +1168,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         s.listLen[nx][l] = carry;
       __syncthreads();
     }
+    STAMP(8);
   }
 
   // ---- newborn insignificant sets join their lists in stream order
@@ -1147,6 +1215,14 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   for (uint32_t slot = 0; slot < b.nSlots; slot++)  // leave the masks clean for the next plane
     for (uint32_t wi = tid; wi < pw; wi += kTabThreads)
       b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
+  if (stamps) {
+    const uint64_t now_ = __builtin_readcyclecounter();
+    uint64_t* out = b.lisStamps + (size_t)c * 16;
+    for (int i = 0; i < 10; i++)
+      out[i] += stamp_acc[i];
+    out[10] += now_ - stamp_t;  // placement
+  }
+#undef STAMP
   if (tid == 0) {
     s.cur = nx;
     s.pos = sh_pos;
