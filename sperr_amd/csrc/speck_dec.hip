@@ -974,26 +974,46 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         const uint32_t fb = (pr + wq0) >> 6;
         const uint32_t nblk = ((W - 1 + wq0) >> 6) - fb + 1;
         const int32_t rbase = (int32_t)(fb * 64) - (int32_t)wq0;   // r = h + rbase
-        if ((uint32_t)tid < nblk) {  // P1
-          for (int o = 63; o >= 0; o--) {
-            const uint32_t h = (uint32_t)tid * 64 + o;
+        {  // P1: one wavefront per block, lane = position; in-block chains by pointer jumping
+          const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+          for (uint32_t bi = wave; bi < nblk; bi += kTabThreads / 64) {
+            const uint32_t h = bi * 64 + lane;
             const int32_t rs = (int32_t)h + rbase;
-            if (rs < (int32_t)pr || rs >= (int32_t)W)
-              continue;
-            const uint32_t r = (uint32_t)rs;
-            const uint32_t u = Utop[r];
-            if (u == kTInf) {
-              hop[h] = 0x8000u | r;
-              continue;
+            const bool live = rs >= (int32_t)pr && rs < (int32_t)W;
+            // state: nxt = lane of the next entry inside the block, or 64 when the chain has
+            // left the block (then `out` holds cnt << 16 | stop << 15 | exit position)
+            uint32_t nxt = 64, out = 0;
+            if (live) {
+              const uint32_t r = (uint32_t)rs;
+              const uint32_t u = Utop[r];
+              if (u == kTInf)
+                out = 0x8000u | r;
+              else {
+                const uint32_t nr = r + (u & 0x7fffu);
+                const uint32_t nh = (uint32_t)((int32_t)nr - rbase);
+                if (nh >= (bi + 1) * 64 || nr >= W)
+                  out = (1u << 16) | nr;
+                else {
+                  nxt = nh & 63u;
+                  out = 1u << 16;   // one entry so far, exit still unknown
+                }
+              }
             }
-            const uint32_t nr = r + (u & 0x7fffu);
-            const uint32_t nh = (uint32_t)((int32_t)nr - rbase);
-            if (nh >= ((uint32_t)tid + 1) * 64 || nr >= W)
-              hop[h] = (1u << 16) | nr;
-            else
-              hop[h] = hop[nh] + (1u << 16);
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+              const uint32_t src = nxt & 63u;
+              const uint32_t onxt = __shfl(nxt, src, 64);
+              const uint32_t oout = __shfl(out, src, 64);
+              if (nxt < 64) {
+                out = (out & 0xffff0000u) + oout;   // counts add, exit / stop come from ahead
+                nxt = onxt;
+              }
+            }
+            if (live)
+              hop[h] = out;
+            if (lane == 0)
+              blkEB[bi] = 0xffffffffu;
           }
-          blkEB[tid] = 0xffffffffu;
         }
         __syncthreads();
         STAMP(3);
@@ -1096,6 +1116,23 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           uint32_t y = (uint32_t)(meta >> 8);
           const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
           const int ar = C.arity[cls];
+          // geometry of the children, once per item (regular shapes: every axis of the set that
+          // is longer than one sample splits; pixel coordinates are org + index)
+          const Grid g = t.grids[nd.grid];
+          const Root rt = t.roots[g.root];
+          uint32_t cbase[3], cshift[3];  // child index = cbase | ((ord >> cshift) & 1) when it splits
+          uint32_t nb = 0;
+          for (int ax = 0; ax < 3; ax++) {
+            if (g.depth < rt.D[ax]) {
+              cbase[ax] = (uint32_t)nd.i[ax] * 2u;
+              cshift[ax] = nb++;
+            }
+            else {
+              cbase[ax] = nd.i[ax];
+              cshift[ax] = 31;   // (ord >> 31) == 0: no bit of the ordinal
+            }
+          }
+          const uint64_t gridBits = (uint64_t)(nd.grid + 1) << 48;
           if (cls == 0) {
             const uint32_t v = bits32(y);
             uint32_t yy = 0, found = 0;
@@ -1104,7 +1141,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
               const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
               yy += coded;
               const uint32_t sgn = (v >> yy) & 1u;
-              pixel_event(reg_child_raster(t, nd, k), bit != 0, sgn);
+              const uint32_t cx = rt.org[0] + (cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
+              const uint32_t cy = rt.org[1] + (cbase[1] | (((uint32_t)k >> cshift[1]) & 1u));
+              const uint32_t cz = rt.org[2] + (cbase[2] | (((uint32_t)k >> cshift[2]) & 1u));
+              pixel_event((cz * t.dims[1] + cy) * t.dims[0] + cx, bit != 0, sgn);
               found |= bit;
               yy += bit;
             }
@@ -1113,7 +1153,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
           uint32_t found = 0;
           for (int k = 0; k < ar; k++) {
-            const uint64_t kid = reg_child_packed(t, nd, k);
+            const uint64_t kid = gridBits |
+                                 ((uint64_t)(cbase[2] | (((uint32_t)k >> cshift[2]) & 1u)) << 32) |
+                                 ((uint64_t)(cbase[1] | (((uint32_t)k >> cshift[1]) & 1u)) << 16) |
+                                 (uint64_t)(cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
             const bool coded = found || (k + 1 != ar);
             uint32_t start = y;
             if (coded) {
@@ -1126,9 +1169,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
               start = y + 1;
               y += u & 0x7fffu;
             }
-            else
-              y += Tt[(size_t)(cls - 1) * TS + y];
-            found = 1;
+            found = 1;   // (an inferred child is the last one: nothing follows it in this split)
             const uint32_t slot = atomicAdd(&sh_qn[(round + 1) & 1], 1u);
             qout[slot * 2] = kid;
             qout[slot * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)(cls - 1) << 1);
