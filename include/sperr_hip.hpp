@@ -1,0 +1,221 @@
+// sperr_hip.hpp -- header-only C++ mirrors of the reference's driver classes on top of the C ABI
+// of libsperr_hip.so (include/sperr_hip.h).  Same names, methods, argument meaning and return
+// codes as the reference, so code written against
+//
+//     /root/reference/include/SPERR3D_OMP_C.h:14-35   (sperr::SPERR3D_OMP_C)
+//     /root/reference/include/SPERR3D_OMP_D.h:15-32   (sperr::SPERR3D_OMP_D)
+//     /root/reference/include/SPECK_FLT.h:17-65       (sperr::SPECK3D_FLT, the per-chunk pipeline)
+//     /root/reference/include/sperr_helper.h:35,54-64 (dims_type, vec8_type, vecd_type, RTNType)
+//
+// compiles unchanged when it includes this header instead and links -lsperr_hip.  The chunk
+// pipeline itself runs on the GPU; set_num_threads() is accepted and ignored.  Only the
+// fixed-rate mode (set_bitrate) is implemented on the GPU path; set_psnr / set_tolerance make
+// compress() return RTNType::Error.
+#ifndef SPERR_HIP_HPP
+#define SPERR_HIP_HPP
+
+#include <array>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sperr_hip.h"
+
+namespace sperr {
+
+using dims_type = std::array<size_t, 3>;
+using vec8_type = std::vector<uint8_t>;
+using vecd_type = std::vector<double>;
+using vecf_type = std::vector<float>;
+
+enum class RTNType {  // include/sperr_helper.h:54-64
+  Good = 0,
+  WrongLength,
+  IOError,
+  BitBudgetMet,
+  VersionMismatch,
+  SliceVolumeMismatch,
+  CompModeUnknown,
+  FE_Invalid,
+  Error
+};
+
+enum class CompMode : unsigned char { PSNR, PWE, Rate, Unknown };
+
+// ---- src/SPERR3D_OMP_C.cpp:12-161 --------------------------------------------------------------
+class SPERR3D_OMP_C {
+ public:
+  void set_num_threads(size_t) {}
+  void set_dims_and_chunks(dims_type vol_dims, dims_type chunk_dims)
+  {
+    m_dims = vol_dims;
+    for (size_t i = 0; i < 3; i++) {  // clamp to [1, vol] (SPERR3D_OMP_C.cpp:23-30)
+      size_t c = chunk_dims[i] < 1 ? 1 : chunk_dims[i];
+      m_chunk_dims[i] = c > vol_dims[i] ? vol_dims[i] : c;
+    }
+  }
+  void set_psnr(double v) { m_mode = CompMode::PSNR; m_quality = v; }
+  void set_tolerance(double v) { m_mode = CompMode::PWE; m_quality = v; }
+  void set_bitrate(double v) { m_mode = CompMode::Rate; m_quality = v; }
+
+  template <typename T>
+  auto compress(const T* buf, size_t buf_len) -> RTNType
+  {
+    static_assert(std::is_floating_point<T>::value, "!! Only floating point values are supported !!");
+    if (m_mode == CompMode::Unknown)
+      return RTNType::CompModeUnknown;
+    if (buf_len != m_dims[0] * m_dims[1] * m_dims[2])
+      return RTNType::WrongLength;
+    const int mode = m_mode == CompMode::Rate ? 1 : m_mode == CompMode::PSNR ? 2 : 3;
+    void* dst = nullptr;
+    size_t len = 0;
+    const int rtn = sperr_comp_3d(buf, std::is_same<T, float>::value ? 1 : 0, m_dims[0], m_dims[1],
+                                  m_dims[2], m_chunk_dims[0], m_chunk_dims[1], m_chunk_dims[2], mode,
+                                  m_quality, 0, &dst, &len);
+    if (rtn != 0)
+      return RTNType::Error;
+    m_stream.assign(static_cast<uint8_t*>(dst), static_cast<uint8_t*>(dst) + len);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  auto get_encoded_bitstream() const -> vec8_type { return m_stream; }
+
+ private:
+  CompMode m_mode = CompMode::Unknown;
+  double m_quality = 0.0;
+  dims_type m_dims = {0, 0, 0}, m_chunk_dims = {0, 0, 0};
+  vec8_type m_stream;
+};
+
+// ---- src/SPERR3D_OMP_D.cpp:13-165 --------------------------------------------------------------
+class SPERR3D_OMP_D {
+ public:
+  void set_num_threads(size_t) {}
+  auto use_bitstream(const void* p, size_t total_len) -> RTNType
+  {
+    const auto* u8 = static_cast<const uint8_t*>(p);
+    if (total_len < 18)
+      return RTNType::WrongLength;
+    if (u8[0] != 0)
+      return RTNType::VersionMismatch;
+    if (!(u8[1] & 0x40))
+      return RTNType::SliceVolumeMismatch;
+    size_t dx, dy, dz;
+    int is_float;
+    sperr_parse_header(p, &dx, &dy, &dz, &is_float);
+    m_dims = {dx, dy, dz};
+    m_chunk_dims = m_dims;
+    if (u8[1] & 0x10) {
+      uint16_t c3[3];
+      std::memcpy(c3, u8 + 14, 6);
+      m_chunk_dims = {c3[0], c3[1], c3[2]};
+    }
+    m_ptr = u8;
+    m_len = total_len;
+    return RTNType::Good;
+  }
+  // the pointer MUST be the one given to use_bitstream (SPERR3D_OMP_D.cpp:53-56)
+  auto decompress(const void* bitstream, bool multi_res = false) -> RTNType
+  {
+    if (bitstream == nullptr || m_ptr == nullptr || bitstream != m_ptr || multi_res)
+      return RTNType::Error;
+    void* dst = nullptr;
+    size_t dx, dy, dz;
+    if (sperr_decomp_3d(m_ptr, m_len, 0, 0, &dx, &dy, &dz, &dst) != 0)
+      return RTNType::Error;
+    const auto* d = static_cast<const double*>(dst);
+    m_vol.assign(d, d + dx * dy * dz);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  auto view_decoded_data() const -> const vecd_type& { return m_vol; }
+  auto release_decoded_data() -> vecd_type&& { return std::move(m_vol); }
+  auto get_dims() const -> dims_type { return m_dims; }
+  auto get_chunk_dims() const -> dims_type { return m_chunk_dims; }
+
+ private:
+  dims_type m_dims = {0, 0, 0}, m_chunk_dims = {0, 0, 0};
+  const uint8_t* m_ptr = nullptr;
+  size_t m_len = 0;
+  vecd_type m_vol;
+};
+
+// ---- src/SPECK_FLT.cpp:11-606 + src/SPECK3D_FLT.cpp: one chunk ---------------------------------
+// A chunk stream is the single-chunk container minus its 18-byte header
+// (src/SPERR3D_OMP_C.cpp:163-234: 14 bytes + one 4-byte length).
+class SPECK3D_FLT {
+ public:
+  template <typename T>
+  void copy_data(const T* p, size_t len) { m_vals.assign(p, p + len); }
+  void take_data(vecd_type&& buf) { m_vals = std::move(buf); }
+  void set_dims(dims_type d) { m_dims = d; }
+  void set_bitrate(double bpp) { m_mode = CompMode::Rate; m_quality = bpp; }
+  void set_psnr(double v) { m_mode = CompMode::PSNR; m_quality = v; }
+  void set_tolerance(double v) { m_mode = CompMode::PWE; m_quality = v; }
+
+  auto compress() -> RTNType
+  {
+    if (m_vals.empty() || m_vals.size() != m_dims[0] * m_dims[1] * m_dims[2])
+      return RTNType::Error;
+    if (m_mode == CompMode::Unknown)
+      return RTNType::CompModeUnknown;
+    const int mode = m_mode == CompMode::Rate ? 1 : m_mode == CompMode::PSNR ? 2 : 3;
+    void* dst = nullptr;
+    size_t len = 0;
+    if (sperr_comp_3d(m_vals.data(), 0, m_dims[0], m_dims[1], m_dims[2], m_dims[0], m_dims[1],
+                      m_dims[2], mode, m_quality, 0, &dst, &len) != 0)
+      return RTNType::Error;
+    const auto* u8 = static_cast<const uint8_t*>(dst);
+    m_stream.assign(u8 + 18, u8 + len);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  void append_encoded_bitstream(vec8_type& buf) const
+  {
+    buf.insert(buf.end(), m_stream.begin(), m_stream.end());
+  }
+  auto use_bitstream(const void* p, size_t len) -> RTNType
+  {
+    if (len < 17)
+      return RTNType::WrongLength;
+    const auto* u8 = static_cast<const uint8_t*>(p);
+    m_stream.assign(u8, u8 + len);
+    return RTNType::Good;
+  }
+  auto decompress(bool multi_res = false) -> RTNType
+  {
+    if (multi_res || m_stream.empty())
+      return RTNType::Error;
+    // wrap the chunk stream into a single-chunk container (double output)
+    vec8_type c(18 + m_stream.size());
+    c[0] = 0;
+    c[1] = 0x40;
+    const uint32_t v3[3] = {(uint32_t)m_dims[0], (uint32_t)m_dims[1], (uint32_t)m_dims[2]};
+    std::memcpy(c.data() + 2, v3, 12);
+    const uint32_t l = (uint32_t)m_stream.size();
+    std::memcpy(c.data() + 14, &l, 4);
+    std::memcpy(c.data() + 18, m_stream.data(), m_stream.size());
+    void* dst = nullptr;
+    size_t dx, dy, dz;
+    if (sperr_decomp_3d(c.data(), c.size(), 0, 0, &dx, &dy, &dz, &dst) != 0)
+      return RTNType::Error;
+    const auto* d = static_cast<const double*>(dst);
+    m_vals.assign(d, d + dx * dy * dz);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  auto view_decoded_data() const -> const vecd_type& { return m_vals; }
+  auto release_decoded_data() -> vecd_type&& { return std::move(m_vals); }
+
+ private:
+  CompMode m_mode = CompMode::Unknown;
+  double m_quality = 0.0;
+  dims_type m_dims = {0, 0, 0};
+  vecd_type m_vals;
+  vec8_type m_stream;
+};
+
+}  // namespace sperr
+
+#endif
