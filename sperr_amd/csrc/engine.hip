@@ -578,6 +578,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(e.E, uint32_t, nn * B);
   TAKE(e.opos, uint64_t, nn * B);
   TAKE(e.bucket, uint32_t, nn * B);
+  TAKE(e.koff, uint32_t, nn * B);
   e.lisStride = P.lisEntries;
   TAKE(e.lis[0], uint64_t, P.lisEntries * B);
   TAKE(e.lis[1], uint64_t, P.lisEntries * B);
@@ -901,15 +902,16 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.coef = o.coef32;
   d.signStride = Npad / 64;
   TAKE(d.sign, uint64_t, d.signStride * B);
-  d.pixStride = Npad;
-  TAKE(d.born, int8_t, Npad * B);
-  TAKE(d.sigp, int8_t, Npad * B);
+  d.maskPixStride = Npad / 64;
+  TAKE(d.bornM, uint64_t, d.maskPixStride * B);
+  TAKE(d.sigOld, uint64_t, d.maskPixStride * B);
+  TAKE(d.sigNew, uint64_t, d.maskPixStride * B);
   d.lisStride = P.lisEntries;
   TAKE(d.lis[0], uint64_t, P.lisEntries * B);
   TAKE(d.lis[1], uint64_t, P.lisEntries * B);
   d.levelOff = P.d_levelOff;
-  d.nPixTiles = P.nPixTiles;
-  d.tileStride = round_up(P.nPixTiles, 32);
+  d.nPixTiles = (uint32_t)((Npad / 64 + kThreads - 1) / kThreads);   // 256 mask words per tile
+  d.tileStride = round_up(d.nPixTiles, 32);
   TAKE(d.tileLip, uint32_t, d.tileStride * B);
   TAKE(d.tileRef, uint32_t, d.tileStride * B);
   TAKE(d.tileLipOff, uint32_t, d.tileStride * B);
@@ -1051,8 +1053,9 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       for (int wide = 1; wide >= 0; wide--) {
         if (wide && maxWide == 0)
           continue;
-        HIP_CHECK(hipMemsetAsync(d.born, 0xff, d.pixStride * nb, st));
-        HIP_CHECK(hipMemsetAsync(d.sigp, 0xff, d.pixStride * nb, st));
+        HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * nb * 8, st));
+        HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * nb * 8, st));
+        HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, st));
         HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, st));
         HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, st));
         DecBuffers dw = d;
@@ -1419,8 +1422,9 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   HIP_CHECK(hipMemcpyAsync(bb.chunkLen, &len, 8, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(d.cst, 0, sizeof(CoderState), st));
   HIP_CHECK(hipMemsetAsync(d.st, 0, sizeof(DecState), st));
-  HIP_CHECK(hipMemsetAsync(d.born, 0xff, d.pixStride, st));
-  HIP_CHECK(hipMemsetAsync(d.sigp, 0xff, d.pixStride, st));
+  HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
   HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
   HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
   const uint32_t n = P->N;

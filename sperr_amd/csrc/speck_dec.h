@@ -29,9 +29,10 @@ struct DecBuffers {
   DecState* st;
   uint64_t* stream;            // payload as aligned words, zero padded (+2 words of slack)
   size_t streamStride;
-  int8_t* born;                // plane at which the pixel entered the LIP (-1: not yet)
-  int8_t* sigp;                // plane at which the pixel became significant (-1: not yet)
-  size_t pixStride;
+  uint64_t* bornM;             // pixel state bitmasks: tested at least once,
+  uint64_t* sigOld;            //   significant before the current plane,
+  uint64_t* sigNew;            //   found significant during the current plane
+  size_t maskPixStride;
   void* coef;                  // uint32_t or uint64_t magnitudes being reconstructed
   size_t coefStride;
   uint64_t* sign;              // initialised to all ones (SPECK_INT.cpp:174-175)

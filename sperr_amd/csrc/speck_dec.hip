@@ -117,43 +117,44 @@ k_dec_load_words(DecBuffers b, const uint8_t* container)
 }
 
 // ------------------------------------------------------------------------------------------
-// candidates of the two pixel passes
+// candidates of the two pixel passes.  Pixel state is three bitmasks (one bit per sample, the
+// reference's LIP / LSP masks, src/SPECK_INT.cpp:120-125): born = tested at least once, sigOld =
+// significant before this plane, sigNew = found significant during this plane.  A decoder tile is
+// 256 mask words = 16384 samples.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dec_load4(const int8_t* a, uint32_t i0, uint32_t n, int v[4])
-{
-  if (i0 + 4 <= n) {
-    const char4 q = *reinterpret_cast<const char4*>(a + i0);
-    v[0] = q.x;
-    v[1] = q.y;
-    v[2] = q.z;
-    v[3] = q.w;
-  }
-  else
-    for (int k = 0; k < 4; k++)
-      v[k] = (i0 + k < n) ? a[i0 + k] : -1;
-}
+constexpr int kDecTileWords = kThreads;
 
+// merges last plane's new significances, then counts LIP candidates (born & ~sig) and refinement
+// candidates (sig) per tile
 __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   __shared__ uint32_t sm[kThreads / 64 + 1];
-  const uint32_t n = b.tree.nvals;
-  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * 4;
-  int born[4], sg[4];
-  dec_load4(b.born + c * b.pixStride, i0, n, born);
-  dec_load4(b.sigp + c * b.pixStride, i0, n, sg);
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
   uint32_t v = 0;
-  for (int k = 0; k < 4; k++) {
-    v += (born[k] > p && sg[k] < 0) ? 1u : 0u;
-    v += (sg[k] > p) ? (1u << 16) : 0u;
+  if (wi < nw) {
+    uint64_t* so = b.sigOld + c * b.maskPixStride + wi;
+    uint64_t* sn = b.sigNew + c * b.maskPixStride + wi;
+    const uint64_t fresh = *sn;
+    uint64_t sig = *so;
+    if (fresh) {
+      sig |= fresh;
+      *so = sig;
+      *sn = 0;
+    }
+    const uint64_t lip = b.bornM[c * b.maskPixStride + wi] & ~sig;
+    v = (uint32_t)__popcll(lip) | ((uint32_t)__popcll(sig) << 16);
   }
-  uint32_t total;
-  block_exclusive_scan<uint32_t>(v, sm, &total);
+  // 256 words x 64 bits: both counts fit in 15 bits per thread, sums in 32 bits need care:
+  uint32_t total_l, total_r;
+  block_exclusive_scan<uint32_t>(v & 0xffffu, sm, &total_l);
+  block_exclusive_scan<uint32_t>(v >> 16, sm, &total_r);
   if (threadIdx.x == 0) {
-    b.tileLip[c * b.tileStride + blockIdx.x] = total & 0xffffu;
-    b.tileRef[c * b.tileStride + blockIdx.x] = total >> 16;
+    b.tileLip[c * b.tileStride + blockIdx.x] = total_l;
+    b.tileRef[c * b.tileStride + blockIdx.x] = total_r;
   }
 }
 
@@ -194,21 +195,20 @@ __global__ void __launch_bounds__(kThreads) k_dec_candlist(DecBuffers b, int p)
   if (b.tileLip[c * b.tileStride + blockIdx.x] == 0)
     return;
   __shared__ uint32_t sm[kThreads / 64 + 1];
-  const uint32_t n = b.tree.nvals;
-  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * 4;
-  int born[4], sg[4];
-  dec_load4(b.born + c * b.pixStride, i0, n, born);
-  dec_load4(b.sigp + c * b.pixStride, i0, n, sg);
-  uint32_t v = 0;
-  for (int k = 0; k < 4; k++)
-    v += (born[k] > p && sg[k] < 0) ? 1u : 0u;
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
+  uint64_t lip = 0;
+  if (wi < nw)
+    lip = b.bornM[c * b.maskPixStride + wi] & ~b.sigOld[c * b.maskPixStride + wi];
   uint32_t total;
-  uint32_t ex = block_exclusive_scan<uint32_t>(v, sm, &total) +
+  uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(lip), sm, &total) +
                 b.tileLipOff[c * b.tileStride + blockIdx.x];
   uint32_t* cand = b.cand + c * b.candStride;
-  for (int k = 0; k < 4; k++)
-    if (born[k] > p && sg[k] < 0)
-      cand[ex++] = i0 + k;
+  while (lip) {
+    const int k = __ffsll((long long)lip) - 1;
+    lip &= lip - 1;
+    cand[ex++] = wi * 64 + k;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
     return;
   const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
   const uint32_t* cand = b.cand + c * b.candStride;
-  int8_t* sigp = b.sigp + c * b.pixStride;
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
   const CT thr = (CT)1 << p;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
     sig &= sig - 1;
     if ((x >> k) & 1ull) {
       const uint32_t pix = cand[j];
-      sigp[pix] = (int8_t)p;
+      atomicOr(sigNew + (pix >> 6), 1ull << (pix & 63));
       coef[pix] = init;
       const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
       if (!sb)
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   const Tree& t = b.tree;
   const int lane = threadIdx.x;
   const uint64_t* words = b.stream + c * b.streamStride;
-  int8_t* born = b.born + c * b.pixStride;
-  int8_t* sigp = b.sigp + c * b.pixStride;
+  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
   const CT thr = (CT)1 << p;
@@ -544,9 +544,9 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
         // all children visited: lanes 0..7 write the pixel results, then leave the frame
         if (lane < 8 && ((present & pixel) >> lane) & 1u) {
           const uint32_t ridx = f.ridx[lane];
-          born[ridx] = (int8_t)p;
+          atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
           if ((sigmask >> lane) & 1u) {
-            sigp[ridx] = (int8_t)p;
+            atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
             coef[ridx] = init;
             if (!((signmask >> lane) & 1u))
               atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
@@ -682,8 +682,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   const int tid = threadIdx.x;
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
-  int8_t* born = b.born + c * b.pixStride;
-  int8_t* sigp = b.sigp + c * b.pixStride;
+  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
   const CT thr = (CT)1 << p;
@@ -725,9 +725,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
   };
   auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
-    born[ridx] = (int8_t)p;
+    atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
     if (sig) {
-      sigp[ridx] = (int8_t)p;
+      atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
       coef[ridx] = init;
       if (!signbit)
         atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
@@ -1136,6 +1136,18 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           if (cls == 0) {
             const uint32_t v = bits32(y);
             uint32_t yy = 0, found = 0;
+            // x-adjacent children share a mask word: merge their bits into one atomic
+            uint32_t wcur = 0xffffffffu;
+            uint64_t bornBits = 0, sigBits = 0, negBits = 0;
+            auto flush = [&]() {
+              if (wcur == 0xffffffffu)
+                return;
+              atomicOr(bornM + wcur, bornBits);
+              if (sigBits)
+                atomicOr(sigNew + wcur, sigBits);
+              if (negBits)
+                atomicAnd(sign + wcur, ~negBits);
+            };
             for (int k = 0; k < ar; k++) {
               const uint32_t coded = found | (uint32_t)(k + 1 != ar);
               const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
@@ -1144,10 +1156,24 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
               const uint32_t cx = rt.org[0] + (cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
               const uint32_t cy = rt.org[1] + (cbase[1] | (((uint32_t)k >> cshift[1]) & 1u));
               const uint32_t cz = rt.org[2] + (cbase[2] | (((uint32_t)k >> cshift[2]) & 1u));
-              pixel_event((cz * t.dims[1] + cy) * t.dims[0] + cx, bit != 0, sgn);
+              const uint32_t ridx = (cz * t.dims[1] + cy) * t.dims[0] + cx;
+              if ((ridx >> 6) != wcur) {
+                flush();
+                wcur = ridx >> 6;
+                bornBits = sigBits = negBits = 0;
+              }
+              const uint64_t m = 1ull << (ridx & 63);
+              bornBits |= m;
+              if (bit) {
+                sigBits |= m;
+                coef[ridx] = init;
+                if (!sgn)
+                  negBits |= m;
+              }
               found |= bit;
               yy += bit;
             }
+            flush();
             continue;
           }
           const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
@@ -1284,32 +1310,30 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
   if (b.tileRef[c * b.tileStride + blockIdx.x] == 0)
     return;
   __shared__ uint32_t sm[kThreads / 64 + 1];
-  const uint32_t n = b.tree.nvals;
-  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * 4;
-  int sg[4];
-  dec_load4(b.sigp + c * b.pixStride, i0, n, sg);
-  uint32_t v = 0;
-  for (int k = 0; k < 4; k++)
-    v += (sg[k] > p) ? 1u : 0u;
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
+  uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
   uint32_t total;
-  uint64_t j = block_exclusive_scan<uint32_t>(v, sm, &total) +
+  uint64_t j = block_exclusive_scan<uint32_t>((uint32_t)__popcll(sig), sm, &total) +
                (uint64_t)b.tileRefOff[c * b.tileStride + blockIdx.x];
   const uint64_t* words = b.stream + c * b.streamStride;
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   const CT thr = (CT)1 << p, half = thr / 2;
-  for (int k = 0; k < 4; k++)
-    if (sg[k] > p) {
-      const uint64_t at = s.pos + j++;
-      if (at >= s.avail)   // the pass stops the moment the stream is exhausted
-        break;             // (SPECK_INT.cpp:388-389)
-      const int bit = (int)((words[at >> 6] >> (at & 63)) & 1);
-      CT v2 = coef[i0 + k];
-      if (p >= 1)
-        v2 = bit ? v2 + half : v2 - half;
-      else if (bit)
-        v2 += 1;
-      coef[i0 + k] = v2;
-    }
+  while (sig) {
+    const int k = __ffsll((long long)sig) - 1;
+    sig &= sig - 1;
+    const uint64_t at = s.pos + j++;
+    if (at >= s.avail)   // the pass stops the moment the stream is exhausted
+      break;             // (SPECK_INT.cpp:388-389)
+    const int bit = (int)((words[at >> 6] >> (at & 63)) & 1);
+    const uint32_t i = wi * 64 + k;
+    CT v2 = coef[i];
+    if (p >= 1)
+      v2 = bit ? v2 + half : v2 - half;
+    else if (bit)
+      v2 += 1;
+    coef[i] = v2;
+  }
 }
 
 __global__ void k_dec_plane_end(DecBuffers b, int p)

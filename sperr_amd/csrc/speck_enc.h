@@ -28,6 +28,7 @@ struct EncBuffers {
   uint32_t* E;
   uint64_t* opos;
   uint32_t* bucket;            // flat ids of the splitting sets, grouped by plane
+  uint32_t* koff;              // start of a set's own split inside its parent's split
   size_t nodeStride;
   // LIS, double buffered; level l occupies [levelOff[l], levelOff[l+1])
   uint64_t* lis[2];

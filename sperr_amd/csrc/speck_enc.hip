@@ -103,6 +103,19 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
   for (int j = 0; j < k.n; j++)
     if (ki.pixel[j])
       bplane[kid_raster(t, nd, k, j)] = (int8_t)m;
+  // koff[child] = where the child's own split starts inside this node's split (bits of the
+  // earlier children + the child's test bit when it is coded): a split chain's position is then
+  // a sum of one word per ancestor instead of a re-evaluation of every ancestor's children
+  if (m >= 0 && !k.deepest) {
+    uint32_t* koff = b.koff + c * b.nodeStride;
+    for (int j = 0; j < k.n; j++) {
+      if (ki.pixel[j])
+        continue;
+      bool coded;
+      const uint32_t before = kid_offset(k, ki, m, j, coded);
+      koff[kid_flat(t, k, j)] = before + (coded ? 1u : 0u);
+    }
+  }
 }
 
 __global__ void k_enc_planes_setup(EncBuffers b)
@@ -508,6 +521,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   const int8_t* msb = b.msb + c * b.pixStride;
 
   // walk up to the list entry that started this chain of splits
+  const uint32_t* koff = b.koff + c * b.nodeStride;
   uint64_t off = 0;
   Node cur = nd;
   uint32_t curid = id;
@@ -516,17 +530,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     const uint32_t pid = flat_id(t, par);
     if (M[pid] != p)
       break;
-    Kids pk;
-    node_kids(t, par, pk);
-    KidInfo pki;
-    kids_info(t, par, pk, M, E, msb, pki);
-    int which = 0;
-    for (int j = 0; j < pk.n; j++)
-      if (pk.idx[j][0] == cur.i[0] && pk.idx[j][1] == cur.i[1] && pk.idx[j][2] == cur.i[2])
-        which = j;
-    bool coded;
-    off += kid_offset(pk, pki, p, which, coded);
-    off += coded ? 1 : 0;
+    off += koff[curid];
     cur = par;
     curid = pid;
   }
