@@ -354,9 +354,13 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
 // ------------------------------------------------------------------------------------------
 // engine singleton
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kSubStreams = 4;
+
 struct Engine {
   std::mutex mu;
   bool ready = false;
+  hipStream_t sub[kSubStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {nullptr, nullptr, nullptr, nullptr};
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   DevBuf arena, slots, misc;
   size_t freeMemAtInit = 0;
@@ -373,6 +377,11 @@ struct Engine {
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     freeMemAtInit = fr;
+    for (uint32_t q = 0; q < kSubStreams; q++) {
+      HIP_CHECK(hipStreamCreateWithFlags(&sub[q], hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&evJoin[q], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
     ready = true;
     return 0;
   }
@@ -1005,93 +1014,140 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
     const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
     uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
     B = std::min<uint32_t>(B, 256);
-    if (E.arena.ensure((size_t)B * per + 4096))
+    if (E.arena.ensure((size_t)B * per + (1 << 20)))
       return -1;
     const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
     for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
-      const uint32_t nb = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
+      const uint32_t nbAll = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
       Arena A;
       A.base = static_cast<char*>(E.arena.p);
       A.cap = E.arena.n;
-      DecBatchBufs bb;
-      if (!carve_dec(A, *P, nb, maxPayload, bb))
-        return -1;
-      DecBuffers& d = bb.db;
-      std::vector<ChunkGeom> hg(nb);
-      std::vector<uint64_t> ho(nb), hl(nb);
-      int maxNarrow = 0, maxWide = 0;
-      for (uint32_t i = 0; i < nb; i++) {
-        const Ref& r = g.second[b0 + i];
-        for (int a = 0; a < 3; a++)
-          hg[i].org[a] = r.org[a];
-        ho[i] = ci.off[r.gid];
-        hl[i] = ci.len[r.gid];
-        const uint8_t* hd = heads.data() + (size_t)r.gid * 32;
-        if (hl[i] >= 26 && !(hd[0] & 0x01)) {
-          const int nbp = hd[17];
-          if (nbp > 32)
-            maxWide = std::max(maxWide, nbp);
-          else
-            maxNarrow = std::max(maxNarrow, nbp);
-        }
+      // The LIS phase is one latency-bound workgroup per chunk; sub-batches on separate streams
+      // let the bandwidth-bound kernels of one sub-batch run beside the LIS kernels of another.
+      // (measured on MI355X: the streams do not overlap well enough -- 302 ms vs 200 ms for the
+      // 1024^3 volume -- so sub-batching is opt-in: SPERR_HIP_SUBSTREAMS=1)
+      static const bool substreams = getenv("SPERR_HIP_SUBSTREAMS") != nullptr;
+      const uint32_t nsub = (substreams && nbAll >= 16) ? kSubStreams : 1;
+      struct SubHost {
+        std::vector<ChunkGeom> hg;
+        std::vector<uint64_t> ho, hl;
+        std::vector<DecState> hs;
+        DecBatchBufs bb;
+        uint32_t nb = 0;
+      };
+      std::vector<SubHost> subs(nsub);
+      if (nsub > 1) {
+        HIP_CHECK(hipEventRecord(E.evFork, st));
+        for (uint32_t q = 0; q < nsub; q++)
+          HIP_CHECK(hipStreamWaitEvent(E.sub[q], E.evFork, 0));
       }
-      if (maxWide > kMaxPlanes)
-        return -1;
-      HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(bb.chunkOff, ho.data(), nb * 8, hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(bb.chunkLen, hl.data(), nb * 8, hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), st));
-      HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), st));
-      DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
-                     P->maxK};
-      HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, st));
-      if (d.lisStamps)
-        HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 16 * 8 * nb, st));
-      // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
-      // buffer, which the 32-bit pass then fills for the remaining chunks
-      for (int wide = 1; wide >= 0; wide--) {
-        if (wide && maxWide == 0)
+      uint32_t done = 0;
+      for (uint32_t q = 0; q < nsub; q++) {
+        SubHost& S = subs[q];
+        const uint32_t nb = (nbAll - done + (nsub - q) - 1) / (nsub - q);
+        const size_t first = b0 + done;
+        done += nb;
+        S.nb = nb;
+        if (nb == 0)
           continue;
-        HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * nb * 8, st));
-        HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * nb * 8, st));
-        HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, st));
-        HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, st));
-        HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, st));
-        DecBuffers dw = d;
-        if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
-          dw.coef = bb.vals;
-          dw.coefStride = bb.valsStride;
-          HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, st));
+        hipStream_t ss = nsub > 1 ? E.sub[q] : st;
+        DecBatchBufs& bb = S.bb;
+        if (!carve_dec(A, *P, nb, maxPayload, bb))
+          return -1;
+        DecBuffers& d = bb.db;
+        S.hg.resize(nb);
+        S.ho.resize(nb);
+        S.hl.resize(nb);
+        int maxNarrow = 0, maxWide = 0;
+        for (uint32_t i = 0; i < nb; i++) {
+          const Ref& r = g.second[first + i];
+          for (int a = 0; a < 3; a++)
+            S.hg[i].org[a] = r.org[a];
+          S.ho[i] = ci.off[r.gid];
+          S.hl[i] = ci.len[r.gid];
+          const uint8_t* hd = heads.data() + (size_t)r.gid * 32;
+          if (S.hl[i] >= 26 && !(hd[0] & 0x01)) {
+            const int nbp = hd[17];
+            if (nbp > 32)
+              maxWide = std::max(maxWide, nbp);
+            else
+              maxNarrow = std::max(maxNarrow, nbp);
+          }
         }
-        else
-          HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, st));
-        // the header kernel must run even when no plane does (constant / all-zero chunks)
-        if (launch_speck_decode(st, dw, ph, d_src, bb.chunkOff, bb.chunkLen, wide != 0,
-                                wide ? maxWide : maxNarrow))
+        if (maxWide > kMaxPlanes)
           return -1;
-        if (launch_inv_quantize(st, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
-                                P->N, bb.vals, bb.valsStride, d.cst))
+        HIP_CHECK(hipMemcpyAsync(bb.geom, S.hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, ss));
+        HIP_CHECK(hipMemcpyAsync(bb.chunkOff, S.ho.data(), nb * 8, hipMemcpyHostToDevice, ss));
+        HIP_CHECK(hipMemcpyAsync(bb.chunkLen, S.hl.data(), nb * 8, hipMemcpyHostToDevice, ss));
+        HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), ss));
+        HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
+        DecPlanHost ph{P->d_initLIS, P->d_initLen,
+                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->maxK};
+        HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
+        if (d.lisStamps)
+          HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 16 * 8 * nb, ss));
+        // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
+        // buffer, which the 32-bit pass then fills for the remaining chunks
+        for (int wide = 1; wide >= 0; wide--) {
+          if (wide && maxWide == 0)
+            continue;
+          HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * nb * 8, ss));
+          HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * nb * 8, ss));
+          HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, ss));
+          HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, ss));
+          HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, ss));
+          DecBuffers dw = d;
+          if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
+            dw.coef = bb.vals;
+            dw.coefStride = bb.valsStride;
+            HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, ss));
+          }
+          else
+            HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
+          // the header kernel must run even when no plane does (constant / all-zero chunks)
+          if (launch_speck_decode(ss, dw, ph, d_src, bb.chunkOff, bb.chunkLen, wide != 0,
+                                  wide ? maxWide : maxNarrow))
+            return -1;
+          if (launch_inv_quantize(ss, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
+                                  P->N, bb.vals, bb.valsStride, d.cst))
+            return -1;
+        }
+        for (size_t k = P->fwd.size(); k-- > 0;) {
+          const LiftPass& ps = P->fwd[k];
+          if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst))
+            return -1;
+        }
+        if (launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
           return -1;
+        if (nsub > 1) {
+          HIP_CHECK(hipEventRecord(E.evJoin[q], ss));
+          HIP_CHECK(hipStreamWaitEvent(st, E.evJoin[q], 0));
+        }
       }
-      for (size_t k = P->fwd.size(); k-- > 0;) {
-        const LiftPass& ps = P->fwd[k];
-        if (launch_lift(st, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst))
-          return -1;
+      // read-backs only after every sub-batch is enqueued: a device-to-host copy into pageable
+      // memory blocks the host until its stream has drained
+      for (uint32_t q = 0; q < nsub; q++) {
+        SubHost& S = subs[q];
+        if (S.nb == 0)
+          continue;
+        hipStream_t ss = nsub > 1 ? E.sub[q] : st;
+        if (S.bb.db.lisStamps && q == 0) {
+          g_lis_stamps_host.assign(16, 0);
+          HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), S.bb.db.lisStamps, 16 * 8,
+                                   hipMemcpyDeviceToHost, ss));
+        }
+        S.hs.resize(S.nb);   // stream errors (wrong lengths) surface here
+        HIP_CHECK(hipMemcpyAsync(S.hs.data(), S.bb.db.st, S.nb * sizeof(DecState),
+                                 hipMemcpyDeviceToHost, ss));
       }
-      if (launch_scatter<T>(st, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
-        return -1;
-      if (d.lisStamps) {
-        g_lis_stamps_host.assign(16, 0);
-        HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), d.lisStamps, 16 * 8, hipMemcpyDeviceToHost, st));
-      }
-      // stream errors (wrong lengths) surface here
-      std::vector<DecState> hs(nb);
-      HIP_CHECK(hipMemcpyAsync(hs.data(), d.st, nb * sizeof(DecState), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
-      for (auto& s : hs)
-        if (s.error)
-          return -1;
+      if (nsub > 1)
+        for (uint32_t q = 0; q < nsub; q++)
+          HIP_CHECK(hipStreamSynchronize(E.sub[q]));
+      for (auto& S : subs)
+        for (auto& hsx : S.hs)
+          if (hsx.error)
+            return -1;
     }
   }
   HIP_CHECK(hipStreamSynchronize(st));
