@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   __shared__ uint64_t sh_pos;
   __shared__ int sh_depth;
   __shared__ TabCtx sh_ctx[kMaxClasses + 2];
-  __shared__ uint32_t sh_e, sh_rem, sh_qn[2], sh_born, sh_flag;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_flag;
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
 
   const Tree& t = b.tree;
@@ -956,6 +956,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         sh_depth = depth;
         sh_qn[0] = qn;
         sh_qn[1] = 0;
+        sh_qn[2] = 0;
         sh_flag = full ? 1u : 0u;
       }
       __syncthreads();
@@ -1016,6 +1017,28 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           }
         }
         __syncthreads();
+        // widen the memo from 64- to 128- and 256-bit blocks: one more jump per level, through
+        // LDS.  In-place and racy on purpose: whichever version of hop[] a thread reads, old or
+        // already widened, is a correct summary of the chain from that position.
+        for (uint32_t wide = 128; wide <= 256; wide <<= 1) {
+          for (uint32_t h = (uint32_t)tid; h < nblk * 64; h += kTabThreads) {
+            const int32_t rs = (int32_t)h + rbase;
+            if (rs < (int32_t)pr || rs >= (int32_t)W)
+              continue;
+            const uint32_t v = hop[h];
+            if (v & 0x8000u)
+              continue;
+            const uint32_t er = v & 0x7fffu;
+            if (er >= W)
+              continue;
+            const uint32_t eh = (uint32_t)((int32_t)er - rbase);
+            if (eh / wide != h / wide)
+              continue;
+            const uint32_t v2 = hop[eh];
+            hop[h] = (v & 0xffff0000u) + v2;
+          }
+          __syncthreads();
+        }
         STAMP(3);
         if (tid == 0) {  // P2
           uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
@@ -1105,7 +1128,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
       STAMP(6);
       // ---- expand, breadth first
       for (int round = 0;; round++) {
-        const uint32_t nin = sh_qn[round & 1];
+        const uint32_t nin = sh_qn[round % 3];
         if (nin == 0)
           break;
         const uint64_t* qin = qbuf[round & 1];
@@ -1196,14 +1219,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
               y += u & 0x7fffu;
             }
             found = 1;   // (an inferred child is the last one: nothing follows it in this split)
-            const uint32_t slot = atomicAdd(&sh_qn[(round + 1) & 1], 1u);
+            const uint32_t slot = atomicAdd(&sh_qn[(round + 1) % 3], 1u);
             qout[slot * 2] = kid;
             qout[slot * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)(cls - 1) << 1);
           }
         }
-        __syncthreads();
         if (tid == 0)
-          sh_qn[round & 1] = 0;
+          sh_qn[(round + 2) % 3] = 0;   // the counter of the round after next
         __syncthreads();
       }
       STAMP(7);
@@ -1310,23 +1332,33 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
   if (b.tileRef[c * b.tileStride + blockIdx.x] == 0)
     return;
   __shared__ uint32_t sm[kThreads / 64 + 1];
+  __shared__ uint32_t wordBase[kDecTileWords];   // refinement candidates before each word
+  __shared__ uint64_t wordSig[kDecTileWords];
   const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
-  uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
-  uint32_t total;
-  uint64_t j = block_exclusive_scan<uint32_t>((uint32_t)__popcll(sig), sm, &total) +
-               (uint64_t)b.tileRefOff[c * b.tileStride + blockIdx.x];
+  const uint32_t w0 = blockIdx.x * kDecTileWords;
+  {
+    const uint32_t wi = w0 + threadIdx.x;
+    const uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
+    uint32_t total;
+    wordBase[threadIdx.x] = block_exclusive_scan<uint32_t>((uint32_t)__popcll(sig), sm, &total);
+    wordSig[threadIdx.x] = sig;
+  }
+  __syncthreads();
+  const uint64_t base = s.pos + (uint64_t)b.tileRefOff[c * b.tileStride + blockIdx.x];
   const uint64_t* words = b.stream + c * b.streamStride;
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   const CT thr = (CT)1 << p, half = thr / 2;
-  while (sig) {
-    const int k = __ffsll((long long)sig) - 1;
-    sig &= sig - 1;
-    const uint64_t at = s.pos + j++;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous
+  for (uint32_t k = wave; k < (uint32_t)kDecTileWords; k += kThreads / 64) {
+    const uint64_t sig = wordSig[k];
+    if (!((sig >> lane) & 1ull))
+      continue;
+    const uint64_t at = base + wordBase[k] + (uint64_t)__popcll(sig & ((1ull << lane) - 1ull));
     if (at >= s.avail)   // the pass stops the moment the stream is exhausted
-      break;             // (SPECK_INT.cpp:388-389)
+      continue;          // (SPECK_INT.cpp:388-389)
     const int bit = (int)((words[at >> 6] >> (at & 63)) & 1);
-    const uint32_t i = wi * 64 + k;
+    const uint32_t i = (w0 + k) * 64 + lane;
     CT v2 = coef[i];
     if (p >= 1)
       v2 = bit ? v2 + half : v2 - half;
