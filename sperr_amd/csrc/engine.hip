@@ -945,7 +945,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.bornStride = P.ht.nsets + 8;
   TAKE(d.bornPacked, uint64_t, d.bornStride * B);
   TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
-  d.tabSmemBytes = 150 * 1024;
+  d.tabSmemBytes = 144 * 1024;
   d.lisStamps = nullptr;
   if (g_lis_stamps_on) {
     TAKE(d.lisStamps, uint64_t, 16 * B);

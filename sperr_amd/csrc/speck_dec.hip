@@ -677,9 +677,20 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   __shared__ TabCtx sh_ctx[kMaxClasses + 2];
   __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_flag;
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+  // the expansion reads the geometry of every splitting set: keep the root / grid tables in LDS
+  constexpr int kLdsRoots = 48, kLdsGrids = 288;
+  __shared__ Root sh_roots[kLdsRoots];
+  __shared__ Grid sh_grids[kLdsGrids];
 
   const Tree& t = b.tree;
   const int tid = threadIdx.x;
+  const bool ldsGeom = t.nroots <= (uint32_t)kLdsRoots && t.ngrids <= (uint32_t)kLdsGrids;
+  if (ldsGeom) {
+    for (uint32_t i = tid; i < t.nroots; i += kTabThreads)
+      sh_roots[i] = t.roots[i];
+    for (uint32_t i = tid; i < t.ngrids; i += kTabThreads)
+      sh_grids[i] = t.grids[i];
+  }
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
   unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
@@ -1141,8 +1152,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           const int ar = C.arity[cls];
           // geometry of the children, once per item (regular shapes: every axis of the set that
           // is longer than one sample splits; pixel coordinates are org + index)
-          const Grid g = t.grids[nd.grid];
-          const Root rt = t.roots[g.root];
+          const Grid g = ldsGeom ? sh_grids[nd.grid] : t.grids[nd.grid];
+          const Root rt = ldsGeom ? sh_roots[g.root] : t.roots[g.root];
           uint32_t cbase[3], cshift[3];  // child index = cbase | ((ord >> cshift) & 1) when it splits
           uint32_t nb = 0;
           for (int ax = 0; ax < 3; ax++) {

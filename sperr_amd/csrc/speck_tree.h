@@ -166,8 +166,13 @@ SPK_HD NodeGeom node_geom(const Tree& t, const Node& n)
 SPK_HD uint32_t pixel_raster(const Tree& t, const Root& r, const int e[3], const uint32_t i[3])
 {
   uint32_t c[3];
-  for (int a = 0; a < 3; a++)
-    c[a] = (uint32_t)r.org[a] + t.tab[r.tabOff[a] + tab_index(e[a], i[a])];
+  for (int a = 0; a < 3; a++) {
+    const uint32_t L = r.len[a];
+    if ((L & (L - 1u)) == 0)   // power of two: every interval is L >> e long, no table needed
+      c[a] = (uint32_t)r.org[a] + i[a] * (L >> e[a]);
+    else
+      c[a] = (uint32_t)r.org[a] + t.tab[r.tabOff[a] + tab_index(e[a], i[a])];
+  }
   return (c[2] * t.dims[1] + c[1]) * t.dims[0] + c[0];
 }
 
