@@ -124,9 +124,21 @@ def main():
     per_step_ms = top_ms / args.steps
     values = vol.numel()
     achieved = ALGO_BYTES_PER_VALUE * values / (per_step_ms / 1e3) / 1e9
+    # HBM traffic of that kernel per step: PMC counters cannot be collected from inside this
+    # process; profiles/*_pmc_traffic.json holds them for this very workload (separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)
+    traffic = None
+    if S == 1024 and C == 256 and args.bpp == 2.0:
+        import glob
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+            with open(pf) as f:
+                rec = json.load(f)["kernels"].get(top_name)
+            if rec:
+                traffic = rec["hbm_bytes_per_step_corrected"]
     roofline = {
         "bound": "hbm", "kernel": top_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "algorithmic_bytes_per_step": ALGO_BYTES_PER_VALUE * values,
         "launches_per_step": top_launches // args.steps,
         "avg_launch_ms": round(top_ms / max(1, top_launches), 4),
         "kernel_ms_per_step": round(per_step_ms, 3),
