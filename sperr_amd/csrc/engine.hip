@@ -953,6 +953,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.queueCap = 28672 + 64;
   d.queueStride = (size_t)d.queueCap * 4;
   TAKE(d.queue, uint64_t, d.queueStride * B);
+  d.leafCap = P.ht.nsets + 8;
+  d.leafStride = d.leafCap;
+  TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
 #undef TAKE

@@ -13,7 +13,8 @@ struct DecState {
   int32_t nbp;
   uint32_t cur;
   uint32_t nLip, nRef;           // candidates of the current plane's pixel passes
-  uint32_t pad;
+  uint32_t nLeafEv;              // leaf events of the plane just decoded
+  int32_t lastPlane;             // last plane whose sorting pass ran
   uint64_t pos;                  // next unread bit
   uint64_t avail;                // usable bits of the stream
   uint64_t total_bits;
@@ -70,6 +71,9 @@ struct DecBuffers {
   uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
   size_t sigbitsStride;
   uint32_t tabSmemBytes;       // dynamic LDS given to k_lis_tables
+  uint64_t* leafEv;            // leaf-parent splits of one plane: node id | sig mask | neg mask
+  uint32_t leafCap;
+  size_t leafStride;
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
 };
 

@@ -320,17 +320,15 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
   const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
   const uint32_t* cand = b.cand + c * b.candStride;
   unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
-  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
-  const CT thr = (CT)1 << p;
-  const CT init = thr + thr - thr / 2 - 1;   // SPECK_INT.cpp:462-468
+  // the magnitude is not written here: k_ref_apply / k_dec_finish give a newly significant
+  // coefficient its value 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it
   while (sig && j < s.nLip) {
     const int k = __ffsll((long long)sig) - 1;
     sig &= sig - 1;
     if ((x >> k) & 1ull) {
       const uint32_t pix = cand[j];
       atomicOr(sigNew + (pix >> 6), 1ull << (pix & 63));
-      coef[pix] = init;
       const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
       if (!sb)
         atomicAnd(sign + (pix >> 6), ~(1ull << (pix & 63)));
@@ -547,7 +545,6 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
           atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
           if ((sigmask >> lane) & 1u) {
             atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
-            coef[ridx] = init;
             if (!((signmask >> lane) & 1u))
               atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
           }
@@ -565,6 +562,8 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   if (lane == 0) {
     s.cur = nx;
     s.pos = rd.pos;
+    s.nLeafEv = 0;
+    s.lastPlane = p;
     if (rd.pos >= s.avail)  // SPECK_INT.cpp:200-201
       s.done = 1;
   }
@@ -675,7 +674,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   __shared__ uint64_t sh_pos;
   __shared__ int sh_depth;
   __shared__ TabCtx sh_ctx[kMaxClasses + 2];
-  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_flag;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_flag, sh_leaf;
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
   // the expansion reads the geometry of every splitting set: keep the root / grid tables in LDS
   constexpr int kLdsRoots = 48, kLdsGrids = 288;
@@ -707,9 +706,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
 
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
   if (tid == 0) {
     sh_pos = phase0;
     sh_born = 0;
+    sh_leaf = 0;
   }
   __syncthreads();
   // diagnostic stamps (thread 0 only, when b.lisStamps != nullptr): ticks per phase
@@ -739,7 +740,6 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
     if (sig) {
       atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
-      coef[ridx] = init;
       if (!signbit)
         atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
     }
@@ -1168,46 +1168,26 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           }
           const uint64_t gridBits = (uint64_t)(nd.grid + 1) << 48;
           if (cls == 0) {
+            // a leaf parent: its pixel results become ONE event word (node id, significance
+            // and sign masks by child ordinal); k_leaf_apply turns the events of the plane into
+            // mask updates on the whole GPU instead of scattering from this one CU
             const uint32_t v = bits32(y);
-            uint32_t yy = 0, found = 0;
-            // x-adjacent children share a mask word: merge their bits into one atomic
-            uint32_t wcur = 0xffffffffu;
-            uint64_t bornBits = 0, sigBits = 0, negBits = 0;
-            auto flush = [&]() {
-              if (wcur == 0xffffffffu)
-                return;
-              atomicOr(bornM + wcur, bornBits);
-              if (sigBits)
-                atomicOr(sigNew + wcur, sigBits);
-              if (negBits)
-                atomicAnd(sign + wcur, ~negBits);
-            };
+            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
             for (int k = 0; k < ar; k++) {
               const uint32_t coded = found | (uint32_t)(k + 1 != ar);
               const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
               yy += coded;
               const uint32_t sgn = (v >> yy) & 1u;
-              const uint32_t cx = rt.org[0] + (cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
-              const uint32_t cy = rt.org[1] + (cbase[1] | (((uint32_t)k >> cshift[1]) & 1u));
-              const uint32_t cz = rt.org[2] + (cbase[2] | (((uint32_t)k >> cshift[2]) & 1u));
-              const uint32_t ridx = (cz * t.dims[1] + cy) * t.dims[0] + cx;
-              if ((ridx >> 6) != wcur) {
-                flush();
-                wcur = ridx >> 6;
-                bornBits = sigBits = negBits = 0;
-              }
-              const uint64_t m = 1ull << (ridx & 63);
-              bornBits |= m;
-              if (bit) {
-                sigBits |= m;
-                coef[ridx] = init;
-                if (!sgn)
-                  negBits |= m;
-              }
+              sigm |= bit << k;
+              negm |= (bit & (sgn ^ 1u)) << k;
               found |= bit;
               yy += bit;
             }
-            flush();
+            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
+                                 nd.i[0];
+            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
+            if (slot < b.leafCap)
+              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
             continue;
           }
           const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
@@ -1326,8 +1306,78 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   if (tid == 0) {
     s.cur = nx;
     s.pos = sh_pos;
+    s.nLeafEv = min(sh_leaf, b.leafCap);
+    s.lastPlane = p;
     if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
       s.done = 1;
+  }
+}
+
+// Turns the leaf events of one plane into pixel-mask updates: born bits for all children, sigNew
+// and sign bits for the significant ones.  One thread per event, atomics merged per mask word.
+__global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  if (!s.active || (int)p >= s.nbp || s.lastPlane != p)
+    return;   // (runs for the plane just decoded, also when that plane ended the stream)
+  const uint32_t n = s.nLeafEv;
+  const Tree& t = b.tree;
+  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
+  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
+  const uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint64_t ev = leafEv[k];
+    const uint32_t sigm = (uint32_t)(ev >> 32) & 0xffu, negm = (uint32_t)(ev >> 40) & 0xffu;
+    Node nd;
+    node_from_flat(t, (uint32_t)ev, nd);
+    const Grid g = t.grids[nd.grid];
+    const Root rt = t.roots[g.root];
+    uint32_t cbase[3], cshift[3], nb = 0;
+    for (int ax = 0; ax < 3; ax++) {
+      if (g.depth < rt.D[ax]) {
+        cbase[ax] = (uint32_t)nd.i[ax] * 2u;
+        cshift[ax] = nb++;
+      }
+      else {
+        cbase[ax] = nd.i[ax];
+        cshift[ax] = 31;
+      }
+    }
+    const uint32_t ar = 1u << nb;
+    uint32_t wcur = 0xffffffffu;
+    uint64_t bornBits = 0, sigBits = 0, negBits = 0;
+    for (uint32_t q = 0; q <= ar; q++) {
+      uint32_t w = 0xfffffffeu, bitpos = 0;
+      if (q < ar) {
+        const uint32_t cx = rt.org[0] + (cbase[0] | ((q >> cshift[0]) & 1u));
+        const uint32_t cy = rt.org[1] + (cbase[1] | ((q >> cshift[1]) & 1u));
+        const uint32_t cz = rt.org[2] + (cbase[2] | ((q >> cshift[2]) & 1u));
+        const uint32_t ridx = (cz * t.dims[1] + cy) * t.dims[0] + cx;
+        w = ridx >> 6;
+        bitpos = ridx & 63;
+      }
+      if (w != wcur) {  // flush the finished word (q == ar flushes the last one)
+        if (wcur != 0xffffffffu) {
+          atomicOr(bornM + wcur, bornBits);
+          if (sigBits)
+            atomicOr(sigNew + wcur, sigBits);
+          if (negBits)
+            atomicAnd(sign + wcur, ~negBits);
+        }
+        wcur = w;
+        bornBits = sigBits = negBits = 0;
+      }
+      if (q < ar) {
+        const uint64_t m = 1ull << bitpos;
+        bornBits |= m;
+        if ((sigm >> q) & 1u)
+          sigBits |= m;
+        if ((negm >> q) & 1u)
+          negBits |= m;
+      }
+    }
   }
 }
 
@@ -1359,6 +1409,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
   const uint64_t* words = b.stream + c * b.streamStride;
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   const CT thr = (CT)1 << p, half = thr / 2;
+  const CT initPrev = thr * 2 + thr * 2 - thr - 1;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous
   for (uint32_t k = wave; k < (uint32_t)kDecTileWords; k += kThreads / 64) {
@@ -1371,12 +1422,42 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
     const int bit = (int)((words[at >> 6] >> (at & 63)) & 1);
     const uint32_t i = (w0 + k) * 64 + lane;
     CT v2 = coef[i];
+    if (v2 == 0)          // first touch: found significant on the previous plane (threshold 2*thr)
+      v2 = initPrev;      // 1.5 * (2 thr) - 1  (SPECK_INT.cpp:462-468)
     if (p >= 1)
       v2 = bit ? v2 + half : v2 - half;
     else if (bit)
       v2 += 1;
     coef[i] = v2;
   }
+}
+
+// After the last plane: coefficients that became significant but were never refined still hold 0.
+// Those found during the last decoded plane `pl` (sigNew) get 1.5 * 2^pl - 1, those found on the
+// plane before (sigOld, untouched by a complete refinement pass) 1.5 * 2^(pl+1) - 1
+// (SPECK_INT.cpp:216-220,462-468).
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_dec_finish(DecBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  if (!s.active || s.nbp == 0)
+    return;
+  const uint32_t n = b.tree.nvals;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const uint64_t m = 1ull << (i & 63);
+  const bool isNew = (b.sigNew[c * b.maskPixStride + (i >> 6)] & m) != 0;
+  const bool isOld = (b.sigOld[c * b.maskPixStride + (i >> 6)] & m) != 0;
+  if (!isNew && !isOld)
+    return;
+  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
+  if (coef[i] != 0)
+    return;
+  const int pl = s.lastPlane + (isNew ? 0 : 1);
+  const CT thr = (CT)1 << pl;
+  coef[i] = thr + thr - thr / 2 - 1;
 }
 
 __global__ void k_dec_plane_end(DecBuffers b, int p)
@@ -1425,8 +1506,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     if (wide_pass) {
       LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
-      if (plan.tables)
+      if (plan.tables) {
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
+      }
       else
         LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
       LAUNCH_K(k_ref_apply<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
@@ -1435,14 +1518,25 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     else {
       LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
-      if (plan.tables)
+      if (plan.tables) {
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
+      }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
       LAUNCH_K(k_ref_apply<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
                          b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
+  }
+  {
+    const uint32_t n = b.tree.nvals;
+    if (wide_pass)
+      LAUNCH_K(k_dec_finish<uint64_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
+               stream, b);
+    else
+      LAUNCH_K(k_dec_finish<uint32_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
+               stream, b);
   }
   HIP_CHECK(hipGetLastError());
   return 0;
