@@ -731,12 +731,19 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double
         return -1;
 
       // ---- float stages ----
+      // the first lifting pass covers the whole chunk: it reads the volume itself (gather, widen,
+      // subtract the mean); chunks too small to be transformed take the plain gather kernel
+      const bool fuse = !P->fwd.empty();
+      const int io = std::is_same<T, float>::value ? 1 : 2;
       if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
-                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst))
+                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse))
         return -1;
-      for (const LiftPass& ps : P->fwd)
-        if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst))
+      for (size_t k = 0; k < P->fwd.size(); k++) {
+        const LiftPass& ps = P->fwd[k];
+        if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
+                        k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom))
           return -1;
+      }
       if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst))
         return -1;
       if (launch_quantize(st, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
@@ -1115,12 +1122,15 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
                                   P->N, bb.vals, bb.valsStride, d.cst))
             return -1;
         }
+        // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters
         for (size_t k = P->fwd.size(); k-- > 0;) {
           const LiftPass& ps = P->fwd[k];
-          if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst))
+          if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
+                          k == 0 ? (std::is_same<T, float>::value ? 1 : 2) : 0, d_dst, vd, bb.geom))
             return -1;
         }
-        if (launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
+        if (P->fwd.empty() &&
+            launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
           return -1;
         if (nsub > 1) {
           HIP_CHECK(hipEventRecord(E.evJoin[q], ss));

@@ -17,16 +17,19 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st);
+                     size_t valsStride, CoderState* st, bool gather);
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
                    uint32_t nchunks, const uint32_t cdims[3], const double* vals,
                    size_t valsStride, const CoderState* st);
 
+// io: 0 in place; 1 / 2: the pass also reads (forward) or writes (inverse) the float / double
+// volume through the chunk map -- only valid for a pass whose region is the whole chunk
 int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
                 uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
-                const CoderState* st);
+                const CoderState* st, int io = 0, void* volume = nullptr, VolDesc vd = VolDesc{},
+                const ChunkGeom* geom = nullptr);
 
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
                     uint32_t n, CoderState* st);

@@ -9,6 +9,8 @@
 //   src/CDF97.cpp:132-148,284-302,345-474,598-666   dyadic / wavelet-packet 3D transform
 //   src/SPECK_FLT.cpp:282-301,311-399   q, quantise, inverse quantise
 //   src/SPERR3D_OMP_C.cpp:236-261, src/SPERR3D_OMP_D.cpp:167-184   gather / scatter
+#include <type_traits>
+
 #include "xform.h"
 
 namespace sperrhip {
@@ -17,39 +19,58 @@ namespace sperrhip {
 // conditioner
 // ------------------------------------------------------------------------------------------
 
-// One thread per stride: strictly sequential fp64 sum (the order is part of the result), read
-// straight from the volume through the chunk's gather map.  Also tests "all samples equal".
+// Strided mean (src/Conditioner.cpp:119-135): every stride is summed strictly sequentially in fp64
+// (the order is part of the result), so one thread owns one stride -- but reading a stride per
+// thread straight from HBM touches a different cache line per lane.  A workgroup therefore takes
+// kSumStrides strides and stages them segment by segment through LDS: all threads load
+// kSumStrides x kSumSeg samples with coalesced row reads through the chunk's gather map, then
+// kSumStrides threads add their row of the tile in order.  Also tests "all samples equal".
+constexpr int kSumStrides = 64, kSumSeg = 64;
+
 template <typename T>
-__global__ void k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
-                              uint32_t cx, uint32_t cy, uint32_t cz, uint32_t nstrides,
-                              uint32_t ssz, double* strideMean, size_t strideMeanStride,
-                              CoderState* st)
+__global__ void __launch_bounds__(kThreads)
+k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint32_t cx,
+              uint32_t cy, uint32_t cz, uint32_t nstrides, uint32_t ssz, double* strideMean,
+              size_t strideMeanStride, CoderState* st)
 {
+  __shared__ double tile[kSumStrides][kSumSeg + 1];
+  __shared__ uint32_t sh_differs;
   const uint32_t c = blockIdx.y;
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nstrides)
-    return;
+  const uint32_t s0 = blockIdx.x * kSumStrides;
   const ChunkGeom g = geom[c];
   const size_t vx = vd.dims[0], vy = vd.dims[1];
   const T first = vol[((size_t)g.org[2] * vy + g.org[1]) * vx + g.org[0]];
-  const uint32_t e0 = s * ssz;
-  uint32_t x = e0 % cx, y = (e0 / cx) % cy, z = e0 / (cx * cy);
+  if (threadIdx.x == 0)
+    sh_differs = 0;
   double acc = 0.0;
   bool differs = false;
-  for (uint32_t i = 0; i < ssz; i++) {
-    const T v = vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x];
-    acc += (double)v;
-    differs |= (v != first);
-    if (++x == cx) {
-      x = 0;
-      if (++y == cy) {
-        y = 0;
-        ++z;
+  (void)cz;
+  for (uint32_t seg = 0; seg < ssz; seg += kSumSeg) {
+    const uint32_t len = min((uint32_t)kSumSeg, ssz - seg);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kSumStrides * kSumSeg); k += kThreads) {
+      const uint32_t r = k / kSumSeg, j = k % kSumSeg;
+      const uint32_t sidx = s0 + r;
+      if (sidx < nstrides && j < len) {
+        const uint32_t e = sidx * ssz + seg + j;      // sample index inside the chunk
+        const uint32_t x = e % cx, q = e / cx;
+        const uint32_t y = q % cy, z = q / cy;
+        const T v = vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x];
+        differs |= (v != first);
+        tile[r][j] = (double)v;
       }
     }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)kSumStrides && s0 + threadIdx.x < nstrides)
+      for (uint32_t j = 0; j < len; j++)
+        acc += tile[threadIdx.x][j];
   }
-  strideMean[c * strideMeanStride + s] = acc / (double)ssz;
   if (differs)
+    sh_differs = 1;
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)kSumStrides && s0 + threadIdx.x < nstrides)
+    strideMean[c * strideMeanStride + s0 + threadIdx.x] = acc / (double)ssz;
+  if (threadIdx.x == 0 && sh_differs)
     st[c].not_const_flag = 1;
 }
 
@@ -127,13 +148,20 @@ __global__ void k_scatter_uncondition(T* __restrict__ vol, VolDesc vd, const Chu
 
 extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
 
-template <bool FORWARD>
+// IO: 0 = in place on the fp64 chunk buffer; 1 / 2 = the pass also moves the chunk between the
+// float / double VOLUME and the chunk buffer: the first forward pass reads the volume through the
+// gather map and subtracts the mean (src/SPERR3D_OMP_C.cpp:236-261, Conditioner.cpp:48-50), the
+// last inverse pass adds the mean, narrows and scatters (Conditioner.cpp:66-96,
+// SPERR3D_OMP_D.cpp:167-184, SPERR_C_API.cpp:246-250).  Both passes cover the whole chunk.
+template <bool FORWARD, int IO>
 __global__ void __launch_bounds__(kThreads)
 k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis, uint32_t rx,
-            uint32_t ry, uint32_t rz, int NL, LiftConsts K, const CoderState* st)
+            uint32_t ry, uint32_t rz, int NL, LiftConsts K, const CoderState* st, void* volume,
+            VolDesc vd, const ChunkGeom* geom)
 {
   const uint32_t c = blockIdx.y;
-  if (st[c].is_const)
+  const bool is_const = st[c].is_const != 0;
+  if (is_const && !(IO != 0 && !FORWARD))
     return;
   double* sm = reinterpret_cast<double*>(dyn_smem);
   double* buf = vals + c * valsStride;
@@ -152,12 +180,30 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
   const uint32_t even_len = len - len / 2, odd_len = len / 2;
   const int tid = threadIdx.x;
 
+  // volume address of chunk sample (line l, position p) of this tile
+  using VT = typename std::conditional<IO == 1, float, double>::type;
+  VT* vol = reinterpret_cast<VT*>(volume);
+  size_t vbase = 0, vsl = 0, vsu = 0;
+  double mean = 0.0;
+  if (IO != 0) {
+    const ChunkGeom g = geom[c];
+    const size_t vstride[3] = {1, (size_t)vd.dims[0], (size_t)vd.dims[0] * vd.dims[1]};
+    vbase = (size_t)g.org[0] * vstride[0] + (size_t)g.org[1] * vstride[1] +
+            (size_t)g.org[2] * vstride[2] + (size_t)u0 * vstride[ua] + (size_t)tw * vstride[wa];
+    vsl = vstride[axis];
+    vsu = vstride[ua];
+    mean = st[c].mean;
+  }
+
   // ---- load ----
   if (axis == 0) {  // lanes along the line
     for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
       for (uint32_t p = tid % 64; p < len; p += 64) {
         const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
-        sm[dst * NLP + l] = tile[l * su + p];
+        if (IO != 0 && FORWARD)
+          sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
+        else if (!is_const)
+          sm[dst * NLP + l] = tile[l * su + p];
       }
   }
   else {            // lanes across the lines
@@ -165,13 +211,16 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
     if (l < nl)
       for (uint32_t p = k0; p < len; p += kg) {
         const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
-        sm[dst * NLP + l] = tile[l * su + p * sl];
+        if (IO != 0 && FORWARD)
+          sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
+        else if (!is_const)
+          sm[dst * NLP + l] = tile[l * su + p * sl];
       }
   }
   __syncthreads();
 
   // ---- lift ----
-  {
+  if (!is_const) {
     const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
     double* E = sm + l;
     double* O = sm + (size_t)even_len * NLP + l;
@@ -234,7 +283,10 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
     for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
       for (uint32_t p = tid % 64; p < len; p += 64) {
         const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
-        tile[l * su + p] = sm[src * NLP + l];
+        if (IO != 0 && !FORWARD)
+          vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
+        else
+          tile[l * su + p] = sm[src * NLP + l];
       }
   }
   else {
@@ -242,7 +294,10 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
     if (l < nl)
       for (uint32_t p = k0; p < len; p += kg) {
         const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
-        tile[l * su + p * sl] = sm[src * NLP + l];
+        if (IO != 0 && !FORWARD)
+          vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
+        else
+          tile[l * su + p * sl] = sm[src * NLP + l];
       }
   }
 }
@@ -367,19 +422,23 @@ static int pick_nl(uint32_t len, size_t* smem)
 
 int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
                 uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
-                const CoderState* st)
+                const CoderState* st, int io, void* volume, VolDesc vd, const ChunkGeom* geom)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lift_axis<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lift_axis<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_lift_axis<true, 0>),
+                          reinterpret_cast<const void*>(&k_lift_axis<true, 1>),
+                          reinterpret_cast<const void*>(&k_lift_axis<true, 2>),
+                          reinterpret_cast<const void*>(&k_lift_axis<false, 0>),
+                          reinterpret_cast<const void*>(&k_lift_axis<false, 1>),
+                          reinterpret_cast<const void*>(&k_lift_axis<false, 2>)};
+    for (const void* f : fns)
+      HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const uint32_t len = region[axis];
   if (len < 2)
-    return 0;
+    return io ? -1 : 0;
   size_t smem = 0;
   const int NL = pick_nl(len, &smem);
   if (smem > 160 * 1024) {
@@ -390,12 +449,24 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
   const uint32_t ntu = (region[ua] + NL - 1) / NL;
   dim3 grid(ntu * region[wa], nchunks);
   const LiftConsts K = lift_consts();
-  if (forward)
-    LAUNCH_K(k_lift_axis<true>, grid, dim3(kThreads), smem, stream, vals, valsStride,
-                       cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st);
-  else
-    LAUNCH_K(k_lift_axis<false>, grid, dim3(kThreads), smem, stream, vals, valsStride,
-                       cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st);
+#define LIFT_ARGS vals, valsStride, cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st, volume, vd, geom
+  if (forward) {
+    if (io == 1)
+      LAUNCH_K((k_lift_axis<true, 1>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+    else if (io == 2)
+      LAUNCH_K((k_lift_axis<true, 2>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+    else
+      LAUNCH_K((k_lift_axis<true, 0>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+  }
+  else {
+    if (io == 1)
+      LAUNCH_K((k_lift_axis<false, 1>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+    else if (io == 2)
+      LAUNCH_K((k_lift_axis<false, 2>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+    else
+      LAUNCH_K((k_lift_axis<false, 0>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
+  }
+#undef LIFT_ARGS
   HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -404,27 +475,28 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st)
+                     size_t valsStride, CoderState* st, bool gather)
 {
   const uint32_t n = cdims[0] * cdims[1] * cdims[2];
   const uint32_t ssz = n / nstrides;
-  LAUNCH_K(k_stride_sums<T>, dim3((nstrides + 63) / 64, nchunks), dim3(64), 0, stream,
+  LAUNCH_K(k_stride_sums<T>, dim3((nstrides + kSumStrides - 1) / kSumStrides, nchunks),
+           dim3(kThreads), 0, stream,
                      vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz, strideMean,
                      strideMeanStride, st);
   LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(1), 0, stream, vol, vd, geom,
                      nstrides, strideMean, strideMeanStride, st);
-  LAUNCH_K(k_gather_condition<T>, dim3((n + kThreads * 4 - 1) / (kThreads * 4), nchunks),
-                     dim3(kThreads), 0, stream, vol, vd, geom, cdims[0], cdims[1], n, vals,
-                     valsStride, st);
+  if (gather)   // otherwise the first lifting pass reads the volume itself
+    LAUNCH_K(k_gather_condition<T>, dim3((n + kThreads * 4 - 1) / (kThreads * 4), nchunks),
+             dim3(kThreads), 0, stream, vol, vd, geom, cdims[0], cdims[1], n, vals, valsStride, st);
   HIP_CHECK(hipGetLastError());
   return 0;
 }
 template int launch_condition<float>(hipStream_t, const float*, VolDesc, const ChunkGeom*,
                                      uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                     double*, size_t, CoderState*);
+                                     double*, size_t, CoderState*, bool);
 template int launch_condition<double>(hipStream_t, const double*, VolDesc, const ChunkGeom*,
                                       uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                      double*, size_t, CoderState*);
+                                      double*, size_t, CoderState*, bool);
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
