@@ -97,10 +97,11 @@ void sperrhip_profile_reset(void);
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap);
 
 /* Diagnostics of the table-driven LIS decoder: when `on`, thread 0 of every decoding workgroup
- * accumulates wall-clock ticks (100 MHz-class counter) per phase; out16 (may be NULL) receives the
- * counters of chunk 0 of the last decoded batch: load, tables, hopS, P1, P2, P3, P4, expand,
- * compaction, windows, placement. */
-void sperrhip_debug_lis_stamps(int on, unsigned long long* out16);
+ * accumulates shader-clock ticks per phase; out64 (64 entries, may be NULL) receives the counters
+ * of chunk 0 of the last decoded batch: [0..10] load, tables, hopS, P1, P2, P3, P4, expand,
+ * compaction, windows, placement; [16+K] windows, [32+K] table ticks and [48+K] stream bits of
+ * the list levels whose class chain has length K. */
+void sperrhip_debug_lis_stamps(int on, unsigned long long* out64);
 
 /* Library/engine identification, e.g. "sperr_hip 0.1 (gfx950)". */
 const char* sperrhip_version(void);

@@ -955,7 +955,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.tabSmemBytes = 144 * 1024;
   d.lisStamps = nullptr;
   if (g_lis_stamps_on) {
-    TAKE(d.lisStamps, uint64_t, 16 * B);
+    TAKE(d.lisStamps, uint64_t, 64 * B);
   }
   d.queueCap = 28672 + 64;
   d.queueStride = (size_t)d.queueCap * 4;
@@ -1095,7 +1095,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
                        P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->maxK};
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         if (d.lisStamps)
-          HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 16 * 8 * nb, ss));
+          HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 64 * 8 * nb, ss));
         // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
         // buffer, which the 32-bit pass then fills for the remaining chunks
         for (int wide = 1; wide >= 0; wide--) {
@@ -1145,8 +1145,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
           continue;
         hipStream_t ss = nsub > 1 ? E.sub[q] : st;
         if (S.bb.db.lisStamps && q == 0) {
-          g_lis_stamps_host.assign(16, 0);
-          HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), S.bb.db.lisStamps, 16 * 8,
+          g_lis_stamps_host.assign(64, 0);
+          HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), S.bb.db.lisStamps, 64 * 8,
                                    hipMemcpyDeviceToHost, ss));
         }
         S.hs.resize(S.nb);   // stream errors (wrong lengths) surface here
@@ -1232,12 +1232,12 @@ void sperrhip_profile_enable(int on)
 {
   g_prof.on = on != 0;
 }
-void sperrhip_debug_lis_stamps(int on, unsigned long long* out16)
+void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
 {
   g_lis_stamps_on = on != 0;
-  if (out16)
-    for (size_t i = 0; i < 16; i++)
-      out16[i] = i < g_lis_stamps_host.size() ? g_lis_stamps_host[i] : 0;
+  if (out64)
+    for (size_t i = 0; i < 64; i++)
+      out64[i] = i < g_lis_stamps_host.size() ? g_lis_stamps_host[i] : 0;
 }
 void sperrhip_profile_reset(void)
 {

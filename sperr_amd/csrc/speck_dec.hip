@@ -871,6 +871,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         }
         __syncthreads();
       }
+      if (stamps) {  // per chain length K: windows, table ticks
+        uint64_t* out = b.lisStamps + (size_t)c * 64;
+        out[16 + K] += 1;
+        out[32 + K] += __builtin_readcyclecounter() - stamp_t;
+      }
       STAMP(1);
       if (stamps)
         stamp_acc[9] += 1;
@@ -1220,6 +1225,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         __syncthreads();
       }
       STAMP(7);
+      if (stamps)   // stream bits this window consumed
+        b.lisStamps[(size_t)c * 64 + 48 + K] += sh_pos - a;
     }
     // ---- old entries that stayed insignificant keep their order
     {
@@ -1297,7 +1304,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
       b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
   if (stamps) {
     const uint64_t now_ = __builtin_readcyclecounter();
-    uint64_t* out = b.lisStamps + (size_t)c * 16;
+    uint64_t* out = b.lisStamps + (size_t)c * 64;
     for (int i = 0; i < 10; i++)
       out[i] += stamp_acc[i];
     out[10] += now_ - stamp_t;  // placement

@@ -197,14 +197,17 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
 
   // ---- load ----
   if (axis == 0) {  // lanes along the line
-    for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
-      for (uint32_t p = tid % 64; p < len; p += 64) {
-        const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
-        if (IO != 0 && FORWARD)
-          sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
-        else if (!is_const)
-          sm[dst * NLP + l] = tile[l * su + p];
-      }
+    const uint32_t nseg = (len + 63) / 64;   // a wavefront moves 64 consecutive samples of a line
+    for (uint32_t sg = tid / 64; sg < nl * nseg; sg += kThreads / 64) {
+      const uint32_t l = sg / nseg, p = (sg % nseg) * 64 + tid % 64;
+      if (p >= len)
+        continue;
+      const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
+      if (IO != 0 && FORWARD)
+        sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
+      else if (!is_const)
+        sm[dst * NLP + l] = tile[l * su + p];
+    }
   }
   else {            // lanes across the lines
     const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
@@ -280,14 +283,17 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
 
   // ---- store ----
   if (axis == 0) {
-    for (uint32_t l = tid / 64; l < nl; l += kThreads / 64)
-      for (uint32_t p = tid % 64; p < len; p += 64) {
-        const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
-        if (IO != 0 && !FORWARD)
-          vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
-        else
-          tile[l * su + p] = sm[src * NLP + l];
-      }
+    const uint32_t nseg = (len + 63) / 64;
+    for (uint32_t sg = tid / 64; sg < nl * nseg; sg += kThreads / 64) {
+      const uint32_t l = sg / nseg, p = (sg % nseg) * 64 + tid % 64;
+      if (p >= len)
+        continue;
+      const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
+      if (IO != 0 && !FORWARD)
+        vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
+      else
+        tile[l * su + p] = sm[src * NLP + l];
+    }
   }
   else {
     const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
@@ -408,11 +414,16 @@ LiftConsts lift_consts()
   return k;
 }
 
-static int pick_nl(uint32_t len, size_t* smem)
+// Lines per tile.  The kernel is HBM-bound and synchronises between lifting steps, so it wants
+// several workgroups per CU: measured on MI355X (256-sample lines) 8 lines per tile are best along
+// x, where a wavefront reads along the line, and 16 across (128-byte rows); larger tiles halve the
+// throughput.
+static int pick_nl(uint32_t len, int axis, size_t* smem)
 {
+  const size_t cap = (axis == 0 ? 20 : 36) * 1024;
   for (int nl = 32; nl >= 1; nl >>= 1) {
     const size_t bytes = (size_t)len * (nl + 1) * sizeof(double);
-    if (bytes <= 72 * 1024 || nl == 1) {
+    if (bytes <= cap || nl == 1) {
       *smem = bytes;
       return nl;
     }
@@ -440,7 +451,7 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
   if (len < 2)
     return io ? -1 : 0;
   size_t smem = 0;
-  const int NL = pick_nl(len, &smem);
+  const int NL = pick_nl(len, axis, &smem);
   if (smem > 160 * 1024) {
     fprintf(stderr, "[sperr_hip] line of %u samples does not fit in LDS\n", len);
     return -1;
