@@ -62,6 +62,61 @@ __global__ void k_enc_state_init(EncBuffers b, const uint64_t* initLIS, const ui
 }
 
 // ------------------------------------------------------------------------------------------
+// Nodes of spk::kGridOct grids (all of them for power-of-two chunks): the 8 children are loaded
+// with fixed indices, so everything stays in registers.  `base` is the raster index of pixel
+// child 0 (deepest) or the flat id of set child 0; child j is base + (j & 1) + ((j >> 1) & 1) * sy
+// + (j >> 2) * sz.
+// ------------------------------------------------------------------------------------------
+struct OctKids {
+  int m[8];         // msb of each child
+  uint32_t e[8];    // split length of each child set (0 for pixels)
+  uint32_t base, sy, sz;
+  bool deepest;
+};
+
+__device__ __forceinline__ uint32_t oct_kid(const OctKids& k, int j)
+{
+  return k.base + (uint32_t)(j & 1) + (uint32_t)((j >> 1) & 1) * k.sy + (uint32_t)(j >> 2) * k.sz;
+}
+
+__device__ __forceinline__ void oct_load(const Tree& t, const Grid& g, const Root& r, const Node& nd,
+                                         const int8_t* M, const uint32_t* E, const int8_t* msb,
+                                         OctKids& k)
+{
+  k.deepest = g.depth + 1 == r.Dmax;
+  if (k.deepest) {
+    k.sy = t.dims[0];
+    k.sz = t.dims[0] * t.dims[1];
+    k.base = ((uint32_t)r.org[2] + 2u * nd.i[2]) * k.sz + ((uint32_t)r.org[1] + 2u * nd.i[1]) * k.sy +
+             (uint32_t)r.org[0] + 2u * nd.i[0];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const char2 v = *reinterpret_cast<const char2*>(msb + oct_kid(k, 2 * q));
+      k.m[2 * q] = v.x;
+      k.m[2 * q + 1] = v.y;
+      k.e[2 * q] = 0;
+      k.e[2 * q + 1] = 0;
+    }
+  }
+  else {
+    const Grid& cg = t.grids[nd.grid + 1];
+    k.sy = 1u << cg.e[0];
+    k.sz = 1u << (cg.e[0] + cg.e[1]);
+    k.base = cg.nodeOff + 2u * nd.i[2] * k.sz + 2u * nd.i[1] * k.sy + 2u * nd.i[0];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t id = oct_kid(k, 2 * q);
+      const char2 v = *reinterpret_cast<const char2*>(M + id);
+      const uint2 w = *reinterpret_cast<const uint2*>(E + id);
+      k.m[2 * q] = v.x;
+      k.m[2 * q + 1] = v.y;
+      k.e[2 * q] = w.x;
+      k.e[2 * q + 1] = w.y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_pyramid: one thread per node of the grids at one depth (deepest first)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kNodeBlock)
@@ -84,6 +139,41 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
   int8_t* bplane = b.bplane + c * b.pixStride;
   const Grid& g = t.grids[nd.grid];
   const Root& r = t.roots[g.root];
+  if (g.kind & kGridOct) {
+    OctKids k;
+    oct_load(t, g, r, nd, M, b.E + c * b.nodeStride, msb, k);
+    int m = -1;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      m = max(m, k.m[j]);
+    uint32_t bits = 0, ko[8];
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {  // split_bits and kid_offset in one sweep
+      const bool coded = found || j != 7;
+      ko[j] = bits + (coded ? 1u : 0u);
+      bits += coded ? 1u : 0u;
+      if (!coded || k.m[j] == m) {
+        found = true;
+        bits += k.deepest ? 1u : k.e[j];
+      }
+    }
+    M[id] = (int8_t)m;
+    E[id] = m >= 0 ? bits : 0u;
+    if (k.deepest) {
+      const char2 v = {(char)m, (char)m};
+#pragma unroll
+      for (int q2 = 0; q2 < 4; q2++)
+        *reinterpret_cast<char2*>(bplane + oct_kid(k, 2 * q2)) = v;
+    }
+    else if (m >= 0) {
+      uint32_t* koff = b.koff + c * b.nodeStride;
+#pragma unroll
+      for (int q2 = 0; q2 < 4; q2++)
+        *reinterpret_cast<uint2*>(koff + oct_kid(k, 2 * q2)) = make_uint2(ko[2 * q2], ko[2 * q2 + 1]);
+    }
+    return;
+  }
   const bool isset = q.count > 1 || g.depth == 0;
   if (!isset) {
     const int e[3] = {g.e[0], g.e[1], g.e[2]};
@@ -536,19 +626,69 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   }
   uint64_t pos = b.opos[c * b.nodeStride + curid] + 1 + off;
 
+  const uint64_t* sign = b.sign + c * b.signStride;
+  uint64_t* stream = b.stream + c * b.streamStride;
+  const uint64_t baseLIS = s.rec[p].baseLIS;
+  bool found = false;
+  uint64_t acc = 0;      // contiguous run of bits being assembled
+  int nacc = 0;
+  uint64_t accpos = pos;
+  const Grid& g = t.grids[nd.grid];
+  if (g.kind & kGridOct) {  // same loop as below with the 8 children in registers
+    OctKids k;
+    oct_load(t, g, t.roots[g.root], nd, M, E, msb, k);
+    const uint32_t kidlev = node_level(t, nd) + 3;
+    const uint32_t slot = b.levelSlot[kidlev];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const bool coded = found || j != 7;
+      const bool sig = coded ? (k.m[j] == p) : true;
+      if (coded) {
+        acc |= (uint64_t)sig << nacc;
+        nacc++;
+        pos++;
+      }
+      if (sig) {
+        found = true;
+        if (k.deepest) {
+          const uint32_t ridx = oct_kid(k, j);
+          acc |= ((sign[ridx >> 6] >> (ridx & 63)) & 1ull) << nacc;
+          nacc++;
+          pos++;
+        }
+        else {
+          put_bits(stream, accpos, acc, nacc, s.budget);
+          pos += k.e[j];
+          acc = 0;
+          nacc = 0;
+          accpos = pos;
+        }
+      }
+      else if (!k.deepest) {
+        const uint64_t rel = pos - 1 - baseLIS;
+        if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
+          Node kn;
+          kn.grid = (uint16_t)(nd.grid + 1);
+          kn.i[0] = (uint16_t)(2u * nd.i[0] + (uint32_t)(j & 1));
+          kn.i[1] = (uint16_t)(2u * nd.i[1] + (uint32_t)((j >> 1) & 1));
+          kn.i[2] = (uint16_t)(2u * nd.i[2] + (uint32_t)(j >> 2));
+          const uint32_t kslot = atomicAdd(&s.bornCount, 1u);
+          b.bornPacked[c * b.bornStride + kslot] = pack_node(kn);
+          b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
+          atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
+                      1ull << (rel & 63));
+        }
+      }
+    }
+    put_bits(stream, accpos, acc, nacc, s.budget);
+    return;
+  }
   Kids k;
   node_kids(t, nd, k);
   KidInfo ki;
   kids_info(t, nd, k, M, E, msb, ki);
   const uint32_t kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
-  const uint64_t* sign = b.sign + c * b.signStride;
-  uint64_t* stream = b.stream + c * b.streamStride;
-  const uint64_t baseLIS = s.rec[p].baseLIS;
   const uint32_t slot = b.levelSlot[kidlev];
-  bool found = false;
-  uint64_t acc = 0;      // contiguous run of bits being assembled
-  int nacc = 0;
-  uint64_t accpos = pos;
   for (int j = 0; j < k.n; j++) {
     const bool coded = found || (j + 1 != k.n);
     const bool sig = coded ? (ki.m[j] == p) : true;

@@ -47,11 +47,18 @@ struct Root {
   uint32_t tabOff[3];  // offset of the axis' interval-start tables in Tree::tab
 };
 
+// Grid::kind bit: the root has power-of-two extents and all three axes still split at this depth,
+// so every node has exactly 8 non-empty children, child j = (2ix + (j & 1), 2iy + ((j >> 1) & 1),
+// 2iz + (j >> 2)) in the reference's order, and they are all pixels (deepest depth) or all sets.
+// (Also requires an even x origin and an even row length: kernels move pixel pairs.)
+constexpr uint8_t kGridOct = 1;
+
 struct Grid {          // all nodes of one root at one depth, as a dense 3D array
   uint32_t nodeOff;    // first flat node id (multiple of kNodeBlock)
   uint16_t root;
   uint8_t depth;
   uint8_t e[3];        // log2 of the grid extent per axis = min(depth, D[a])
+  uint8_t kind;        // kGridOct or 0
 };
 
 // Everything a kernel needs to know about one chunk shape.  Arrays live in device memory (or

@@ -203,6 +203,10 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
         g.depth = (uint8_t)d;
         for (int a = 0; a < 3; a++)
           g.e[a] = (uint8_t)std::min<int>(d, r.D[a]);
+        bool oct = (b.org[0] % 2 == 0) && (dx % 2 == 0);
+        for (int a = 0; a < 3; a++)
+          oct = oct && d < r.D[a] && b.len[a] == (1u << r.D[a]);
+        g.kind = oct ? kGridOct : 0;
         g.nodeOff = h.nnodes;
         const uint32_t n = 1u << (g.e[0] + g.e[1] + g.e[2]);
         const uint32_t padded = (n + kNodeBlock - 1) / kNodeBlock * kNodeBlock;
