@@ -784,7 +784,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     }
     __syncthreads();
 
-    // split length of a class-j set starting at r (uses the tables of class j-1)
+    // split length of a class-j set starting at r (uses the tables of class j-1).  Octree
+    // classes (8 children) take straight-line code: an item that leaves the window parks the
+    // cursor on index W + 1, whose entries are kTInf in every table, so there is no early exit.
     auto split_len = [&](int j, uint32_t r) -> uint32_t {
       const int ar = C.arity[j];
       if (j == 0) {
@@ -792,16 +794,40 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           return kTInf;
         const uint32_t v = bits32(r);
         uint32_t y = 0, found = 0;
-        for (int i = 0; i < ar; i++) {
-          const uint32_t coded = found | (uint32_t)(i + 1 != ar);
-          const uint32_t bit = coded ? (v >> y) & 1u : 1u;
-          y += coded;
-          found |= bit;
-          y += bit;  // sign bit
+        if (ar == 8) {
+#pragma unroll
+          for (int i = 0; i < 7; i++) {
+            const uint32_t bit = (v >> y) & 1u;
+            found |= bit;
+            y += 1u + bit;
+          }
+          const uint32_t bit = found ? (v >> y) & 1u : 1u;
+          y += found + bit;
+        }
+        else {
+          for (int i = 0; i < ar; i++) {
+            const uint32_t coded = found | (uint32_t)(i + 1 != ar);
+            const uint32_t bit = coded ? (v >> y) & 1u : 1u;
+            y += coded;
+            found |= bit;
+            y += bit;  // sign bit
+          }
         }
         return r + y <= W ? y : kTInf;
       }
       const uint16_t* Up = Uu + (size_t)(j - 1) * TS;
+      const uint16_t* Tp = Tt + (size_t)(j - 1) * TS;
+      if (ar == 8) {
+        uint32_t y = min(r, W + 1), fl = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const uint32_t u = Up[y];
+          fl |= u;
+          y = min(y + (u & 0x7fffu), W + 1);
+        }
+        const uint32_t v = ((fl & 0x8000u) ? Up : Tp)[y];
+        return (y > W || v == kTInf) ? kTInf : y + (v & 0x7fffu) - r;
+      }
       uint32_t y = r, found = 0;
       for (int i = 0; i + 1 < ar; i++) {
         const uint32_t u = Up[y];
@@ -818,7 +844,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         last = u & 0x7fffu;
       }
       else {
-        last = Tt[(size_t)(j - 1) * TS + y];
+        last = Tp[y];
         if (last == kTInf)
           return kTInf;
       }
@@ -836,15 +862,22 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
       }
       __syncthreads();
       STAMP(0);
-      // ---- tables
+      // ---- tables (indices W and W + 1 of every table hold kTInf)
       for (int j = 0; j < K; j++) {
         uint16_t* Uj = Uu + (size_t)j * TS;
         if (j < K - 1) {
           uint16_t* Tj = Tt + (size_t)j * TS;
-          for (uint32_t r = tid; r <= W; r += kTabThreads)
-            Tj[r] = (uint16_t)split_len(j, r);
+          // two independent positions per iteration: their LDS chains overlap
+          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
+            const uint32_t r2 = r + kTabThreads;
+            const uint32_t t1 = split_len(j, r);
+            const uint32_t t2 = r2 <= W + 1 ? split_len(j, r2) : kTInf;
+            Tj[r] = (uint16_t)t1;
+            if (r2 <= W + 1)
+              Tj[r2] = (uint16_t)t2;
+          }
           __syncthreads();
-          for (uint32_t r = tid; r <= W; r += kTabThreads) {
+          for (uint32_t r = tid; r <= W + 1; r += kTabThreads) {
             uint32_t u = kTInf;
             if (r < W) {
               u = 1;
@@ -857,16 +890,18 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           }
         }
         else {  // the level's own class: only the coded form is ever needed
-          for (uint32_t r = tid; r <= W; r += kTabThreads) {
-            uint32_t u = kTInf;
-            if (r < W) {
-              u = 1;
-              if (bit_at(r)) {
-                const uint32_t tl = split_len(j, r + 1);
-                u = tl == kTInf ? kTInf : (0x8000u | (1u + tl));
-              }
-            }
-            Uj[r] = (uint16_t)u;
+          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
+            const uint32_t r2 = r + kTabThreads;
+            const uint32_t t1 = r < W ? split_len(j, r + 1) : kTInf;
+            const uint32_t t2 = r2 < W ? split_len(j, r2 + 1) : kTInf;
+            uint32_t u1 = kTInf, u2 = kTInf;
+            if (r < W)
+              u1 = !bit_at(r) ? 1u : (t1 == kTInf ? kTInf : (0x8000u | (1u + t1)));
+            if (r2 < W)
+              u2 = !bit_at(r2) ? 1u : (t2 == kTInf ? kTInf : (0x8000u | (1u + t2)));
+            Uj[r] = (uint16_t)u1;
+            if (r2 <= W + 1)
+              Uj[r2] = (uint16_t)u2;
           }
         }
         __syncthreads();
