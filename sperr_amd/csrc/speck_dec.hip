@@ -1032,35 +1032,32 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             const uint32_t h = bi * 64 + lane;
             const int32_t rs = (int32_t)h + rbase;
             const bool live = rs >= (int32_t)pr && rs < (int32_t)W;
-            // state: nxt = lane of the next entry inside the block, or 64 when the chain has
-            // left the block (then `out` holds cnt << 16 | stop << 15 | exit position)
-            uint32_t nxt = 64, out = 0;
+            // state: cnt << 16 | stop << 15 | position the chain has reached (window-relative);
+            // inb: that position is an entry of this block, so the chain goes on
+            uint32_t v = 0x8000u;
+            bool inb = false;
+            const uint32_t hEnd = (bi + 1) * 64;
             if (live) {
               const uint32_t r = (uint32_t)rs;
               const uint32_t u = Utop[r];
               if (u == kTInf)
-                out = 0x8000u | r;
+                v = 0x8000u | r;
               else {
                 const uint32_t nr = r + (u & 0x7fffu);
-                const uint32_t nh = (uint32_t)((int32_t)nr - rbase);
-                if (nh >= (bi + 1) * 64 || nr >= W)
-                  out = (1u << 16) | nr;
-                else {
-                  nxt = nh & 63u;
-                  out = 1u << 16;   // one entry so far, exit still unknown
-                }
+                v = (1u << 16) | nr;
+                inb = nr < W && (uint32_t)((int32_t)nr - rbase) < hEnd;
               }
             }
-#pragma unroll
-            for (int it = 0; it < 6; it++) {
-              const uint32_t src = nxt & 63u;
-              const uint32_t onxt = __shfl(nxt, src, 64);
-              const uint32_t oout = __shfl(out, src, 64);
-              if (nxt < 64) {
-                out = (out & 0xffff0000u) + oout;   // counts add, exit / stop come from ahead
-                nxt = onxt;
+            for (int it = 0; it < 6 && __any(inb); it++) {
+              const uint32_t src = (uint32_t)((int32_t)(v & 0x7fffu) - rbase) & 63u;
+              const uint32_t o = __shfl(v, src, 64);
+              if (inb) {
+                v = (v & 0xffff0000u) + o;   // counts add, exit / stop come from ahead
+                const uint32_t np = v & 0x7fffu;
+                inb = !(v & 0x8000u) && np < W && (uint32_t)((int32_t)np - rbase) < hEnd;
               }
             }
+            const uint32_t out = v;
             if (live)
               hop[h] = out;
             if (lane == 0)
@@ -1190,9 +1187,48 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           uint32_t y = (uint32_t)(meta >> 8);
           const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
           const int ar = C.arity[cls];
+          const Grid g = ldsGeom ? sh_grids[nd.grid] : t.grids[nd.grid];
+          if (cls == 0) {
+            // a leaf parent: its pixel results become ONE event word (node id, significance
+            // and sign masks by child ordinal); k_leaf_apply turns the events of the plane into
+            // mask updates on the whole GPU instead of scattering from this one CU
+            const uint32_t v = bits32(y);
+            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
+            if (ar == 8) {
+#pragma unroll
+              for (int k = 0; k < 7; k++) {
+                const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+                sigm |= bit << k;
+                negm |= (bit & (sgn ^ 1u)) << k;
+                found |= bit;
+                yy += 1u + bit;
+              }
+              const uint32_t bit = found ? (v >> yy) & 1u : 1u;
+              const uint32_t sgn = (v >> (yy + found)) & 1u;
+              sigm |= bit << 7;
+              negm |= (bit & (sgn ^ 1u)) << 7;
+            }
+            else {
+              for (int k = 0; k < ar; k++) {
+                const uint32_t coded = found | (uint32_t)(k + 1 != ar);
+                const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+                yy += coded;
+                const uint32_t sgn = (v >> yy) & 1u;
+                sigm |= bit << k;
+                negm |= (bit & (sgn ^ 1u)) << k;
+                found |= bit;
+                yy += bit;
+              }
+            }
+            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
+                                 nd.i[0];
+            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
+            if (slot < b.leafCap)
+              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+            continue;
+          }
           // geometry of the children, once per item (regular shapes: every axis of the set that
           // is longer than one sample splits; pixel coordinates are org + index)
-          const Grid g = ldsGeom ? sh_grids[nd.grid] : t.grids[nd.grid];
           const Root rt = ldsGeom ? sh_roots[g.root] : t.roots[g.root];
           uint32_t cbase[3], cshift[3];  // child index = cbase | ((ord >> cshift) & 1) when it splits
           uint32_t nb = 0;
@@ -1207,29 +1243,6 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             }
           }
           const uint64_t gridBits = (uint64_t)(nd.grid + 1) << 48;
-          if (cls == 0) {
-            // a leaf parent: its pixel results become ONE event word (node id, significance
-            // and sign masks by child ordinal); k_leaf_apply turns the events of the plane into
-            // mask updates on the whole GPU instead of scattering from this one CU
-            const uint32_t v = bits32(y);
-            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
-            for (int k = 0; k < ar; k++) {
-              const uint32_t coded = found | (uint32_t)(k + 1 != ar);
-              const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
-              yy += coded;
-              const uint32_t sgn = (v >> yy) & 1u;
-              sigm |= bit << k;
-              negm |= (bit & (sgn ^ 1u)) << k;
-              found |= bit;
-              yy += bit;
-            }
-            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
-                                 nd.i[0];
-            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
-            if (slot < b.leafCap)
-              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
-            continue;
-          }
           const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
           uint32_t found = 0;
           for (int k = 0; k < ar; k++) {
