@@ -213,6 +213,7 @@ struct ShapePlan {
   const uint8_t* d_levelSlot = nullptr;
   const uint8_t* d_slotLevel = nullptr;
   const spk::LevelClass* d_levelClass = nullptr;
+  const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
   int maxK = 0;
   std::vector<uint32_t> depthBlockOff;
   uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
@@ -294,6 +295,23 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.nPixTiles = (P.N + kPixTile - 1) / kPixTile;
   P.nstrides = condi_num_strides(P.N);
 
+  // raster mask words that lie over one row of 32 leaf sets (spk::kGridLeafWord)
+  std::vector<uint32_t> wordLeaf;
+  for (const spk::Root& r : h.roots) {
+    const spk::Grid& g = h.grids[r.gridFirst + r.Dmax - 1];
+    if (!(g.kind & spk::kGridLeafWord))
+      continue;
+    if (wordLeaf.empty())
+      wordLeaf.assign((P.N + 63) / 64, 0xffffffffu);
+    for (uint32_t z = 0; z < r.len[2]; z++)
+      for (uint32_t y = 0; y < r.len[1]; y++)
+        for (uint32_t x = 0; x < r.len[0]; x += 64) {
+          const size_t idx = ((size_t)(r.org[2] + z) * dy + r.org[1] + y) * dx + r.org[0] + x;
+          const uint32_t fid = g.nodeOff + ((((z / 2) << g.e[1]) + y / 2) << g.e[0]) + x / 2;
+          wordLeaf[idx / 64] = fid | (y & 1u) | ((z & 1u) << 1);
+        }
+  }
+
   // upload
   Blob blob;
   const size_t oRoots = blob.add(h.roots), oGrids = blob.add(h.grids), oTab = blob.add(h.tab),
@@ -301,7 +319,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
                oLevOff = blob.add(levelOff), oTL = blob.add(tileLevel), oTS = blob.add(tileStart),
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
-               oLC = blob.add(h.levelClass);
+               oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
@@ -325,6 +343,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.d_levelSlot = reinterpret_cast<const uint8_t*>(base + oLS);
   P.d_slotLevel = reinterpret_cast<const uint8_t*>(base + oSL);
   P.d_levelClass = reinterpret_cast<const spk::LevelClass*>(base + oLC);
+  P.d_wordLeaf = wordLeaf.empty() ? nullptr : reinterpret_cast<const uint32_t*>(base + oWL);
 
   // DWT pass list (src/CDF97.cpp:132-139,170-225,284-292,387-429); the inverse runs it backwards
   P.fwd.clear();
@@ -965,6 +984,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
+  d.wordLeaf = P.d_wordLeaf;
+  d.leafStateStride = round_up(P.ht.nnodes, 64);
+  TAKE(d.leafState, uint16_t, d.leafStateStride * B);
 #undef TAKE
   return true;
 }
@@ -1105,6 +1127,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
           HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, ss));
+          HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * nb * 2, ss));
           HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, ss));
           DecBuffers dw = d;
           if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
@@ -1495,6 +1518,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * 8, st));
   HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
   HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * 2, st));
   HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
   const uint32_t n = P->N;
   if (wide) {

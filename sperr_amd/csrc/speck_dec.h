@@ -74,6 +74,13 @@ struct DecBuffers {
   uint64_t* leafEv;            // leaf-parent splits of one plane: node id | sig mask | neg mask
   uint32_t leafCap;
   size_t leafStride;
+  // pixel results of the leaf sets of spk::kGridLeafWord grids, by flat node id: low byte =
+  // children found significant when the leaf split (never 0 for a split leaf), high byte = the
+  // negative ones.  wordLeaf[w] = flat id of the first of the 32 leaves under raster mask word w
+  // (a multiple of 32) | (row parity selector / 2), or 0xffffffff; nullptr when no word qualifies.
+  uint16_t* leafState;
+  size_t leafStateStride;
+  const uint32_t* wordLeaf;
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
 };
 

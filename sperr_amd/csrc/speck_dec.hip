@@ -124,8 +124,54 @@ k_dec_load_words(DecBuffers b, const uint8_t* container)
 // ------------------------------------------------------------------------------------------
 constexpr int kDecTileWords = kThreads;
 
-// merges last plane's new significances, then counts LIP candidates (born & ~sig) and refinement
-// candidates (sig) per tile
+// What the leaf states (DecBuffers::leafState) contribute to raster mask word `wi`: every sample
+// of a split leaf has been tested (born), some are significant (sig), some of those negative
+// (neg).  Sample (x, y, z) is child (x & 1) + 2 (y & 1) + 4 (z & 1) of leaf (x/2, y/2, z/2), so
+// the word takes two adjacent bits of each of its 32 leaves.
+__device__ __forceinline__ bool leaf_word(const DecBuffers& b, uint32_t c, uint32_t wi,
+                                          uint64_t& born, uint64_t& sig, uint64_t& neg)
+{
+  born = sig = neg = 0;
+  if (b.wordLeaf == nullptr)
+    return false;
+  const uint32_t wl = b.wordLeaf[wi];
+  if (wl == 0xffffffffu)
+    return false;
+  const uint32_t sel = (wl & 3u) * 2u;
+  const uint4* q = reinterpret_cast<const uint4*>(b.leafState + c * b.leafStateStride + (wl & ~31u));
+  uint32_t v[16];
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint4 t = q[k];
+    v[4 * k] = t.x;
+    v[4 * k + 1] = t.y;
+    v[4 * k + 2] = t.z;
+    v[4 * k + 3] = t.w;
+    any |= t.x | t.y | t.z | t.w;
+  }
+  if (!any)
+    return false;
+  uint32_t bo[2] = {0, 0}, si[2] = {0, 0}, ne[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {   // v[k] holds leaves 2k (low half) and 2k + 1
+    const int h = k >> 3, sh = (k & 7) * 4;
+    const uint32_t a = v[k] & 0xffffu, d = v[k] >> 16;
+    const uint32_t s4 = ((a >> sel) & 3u) | (((d >> sel) & 3u) << 2);
+    const uint32_t n4 = ((a >> (8 + sel)) & 3u) | (((d >> (8 + sel)) & 3u) << 2);
+    const uint32_t b4 = ((a & 0xffu) ? 3u : 0u) | ((d & 0xffu) ? 12u : 0u);
+    si[h] |= s4 << sh;
+    ne[h] |= n4 << sh;
+    bo[h] |= b4 << sh;
+  }
+  born = (uint64_t)bo[0] | ((uint64_t)bo[1] << 32);
+  sig = (uint64_t)si[0] | ((uint64_t)si[1] << 32);
+  neg = (uint64_t)ne[0] | ((uint64_t)ne[1] << 32);
+  return true;
+}
+
+// merges last plane's new significances (sigNew and the leaf states), then counts LIP candidates
+// (born & ~sig) and refinement candidates (sig) per tile
 __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
@@ -140,12 +186,26 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
     uint64_t* sn = b.sigNew + c * b.maskPixStride + wi;
     const uint64_t fresh = *sn;
     uint64_t sig = *so;
-    if (fresh) {
-      sig |= fresh;
-      *so = sig;
-      *sn = 0;
+    uint64_t born = b.bornM[c * b.maskPixStride + wi];
+    uint64_t lb, ls, ln;
+    if (leaf_word(b, c, wi, lb, ls, ln)) {   // idempotent: old leaf results are folded again
+      if (lb & ~born) {
+        born |= lb;
+        b.bornM[c * b.maskPixStride + wi] = born;
+      }
+      if (ln) {
+        const uint64_t sg = b.sign[c * b.signStride + wi];
+        if (sg & ln)
+          b.sign[c * b.signStride + wi] = sg & ~ln;
+      }
     }
-    const uint64_t lip = b.bornM[c * b.maskPixStride + wi] & ~sig;
+    if (fresh | (ls & ~sig)) {
+      sig |= fresh | ls;
+      *so = sig;
+    }
+    if (fresh)
+      *sn = 0;
+    const uint64_t lip = born & ~sig;
     v = (uint32_t)__popcll(lip) | ((uint32_t)__popcll(sig) << 16);
   }
   // 256 words x 64 bits: both counts fit in 15 bits per thread, sums in 32 bits need care:
@@ -1388,6 +1448,10 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
     Node nd;
     node_from_flat(t, (uint32_t)ev, nd);
     const Grid g = t.grids[nd.grid];
+    if (g.kind & kGridLeafWord) {   // folded into the masks by k_dec_count / k_dec_fold
+      b.leafState[c * b.leafStateStride + (uint32_t)ev] = (uint16_t)(sigm | (negm << 8));
+      continue;
+    }
     const Root rt = t.roots[g.root];
     uint32_t cbase[3], cshift[3], nb = 0;
     for (int ax = 0; ax < 3; ax++) {
@@ -1484,6 +1548,31 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
     else if (bit)
       v2 += 1;
     coef[i] = v2;
+  }
+}
+
+// After the last plane: leaf results that no k_dec_count has folded yet are those of the last
+// decoded plane -- they are "new" for k_dec_finish.
+__global__ void __launch_bounds__(kThreads) k_dec_fold(DecBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  if (!s.active || s.nbp == 0)
+    return;
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= nw)
+    return;
+  uint64_t lb, ls, ln;
+  if (!leaf_word(b, c, wi, lb, ls, ln))
+    return;
+  const uint64_t fresh = ls & ~b.sigOld[c * b.maskPixStride + wi];
+  if (fresh)
+    b.sigNew[c * b.maskPixStride + wi] |= fresh;
+  if (ln) {
+    const uint64_t sg = b.sign[c * b.signStride + wi];
+    if (sg & ln)
+      b.sign[c * b.signStride + wi] = sg & ~ln;
   }
 }
 
@@ -1586,6 +1675,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   {
     const uint32_t n = b.tree.nvals;
+    if (plan.tables && b.wordLeaf)
+      LAUNCH_K(k_dec_fold, dim3(((n + 63) / 64 + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
+               stream, b);
     if (wide_pass)
       LAUNCH_K(k_dec_finish<uint64_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
                stream, b);

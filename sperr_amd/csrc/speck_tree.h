@@ -52,6 +52,10 @@ struct Root {
 // 2iz + (j >> 2)) in the reference's order, and they are all pixels (deepest depth) or all sets.
 // (Also requires an even x origin and an even row length: kernels move pixel pairs.)
 constexpr uint8_t kGridOct = 1;
+// Grid::kind bit (deepest oct grids only): a row of the root is whole 64-sample raster mask words,
+// so the decoder keeps the pixel results of these leaf sets per leaf (DecBuffers::leafState) and
+// folds them into the raster masks word by word instead of scattering them with atomics.
+constexpr uint8_t kGridLeafWord = 2;
 
 struct Grid {          // all nodes of one root at one depth, as a dense 3D array
   uint32_t nodeOff;    // first flat node id (multiple of kNodeBlock)

@@ -207,6 +207,9 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
         for (int a = 0; a < 3; a++)
           oct = oct && d < r.D[a] && b.len[a] == (1u << r.D[a]);
         g.kind = oct ? kGridOct : 0;
+        if (oct && d + 1 == r.Dmax && dx % 64 == 0 && b.org[0] % 64 == 0 && b.len[0] >= 64 &&
+            b.org[1] % 2 == 0 && b.org[2] % 2 == 0)
+          g.kind |= kGridLeafWord;
         g.nodeOff = h.nnodes;
         const uint32_t n = 1u << (g.e[0] + g.e[1] + g.e[2]);
         const uint32_t padded = (n + kNodeBlock - 1) / kNodeBlock * kNodeBlock;
