@@ -951,8 +951,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.tileRef, uint32_t, d.tileStride * B);
   TAKE(d.tileLipOff, uint32_t, d.tileStride * B);
   TAKE(d.tileRefOff, uint32_t, d.tileStride * B);
-  d.candStride = Npad;
-  TAKE(d.cand, uint32_t, Npad * B);
+  d.lipResStride = Npad / 64 + 2;
+  TAKE(d.lipSig, uint64_t, d.lipResStride * B);
+  TAKE(d.lipNeg, uint64_t, d.lipResStride * B);
   d.tokStride = (2 * N + 1 + 63) / 64 + 2;
   TAKE(d.tokMask, uint64_t, d.tokStride * B);
   TAKE(d.tokCnt, uint32_t, d.tokStride * B);

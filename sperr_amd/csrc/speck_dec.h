@@ -47,8 +47,9 @@ struct DecBuffers {
   uint32_t* tileLipOff;
   uint32_t* tileRefOff;
   size_t tileStride;
-  uint32_t* cand;              // LIP candidates of the current plane, raster order
-  size_t candStride;
+  uint64_t* lipSig;            // LIP scan results of the current plane by token rank: found
+  uint64_t* lipNeg;            //   significant / and negative
+  size_t lipResStride;
   uint64_t* tokMask;           // token starts of every 64-bit word of the LIP scan
   uint32_t* tokCnt;
   uint32_t* tokOff;

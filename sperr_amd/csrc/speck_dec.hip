@@ -4,12 +4,14 @@
 // src/SPECK3D_INT_DEC.cpp:8-49; tests/model/speck_model.cpp (model_speck3d_decode) is the CPU
 // model of the phases below.  Per bit plane:
 //
-//   LIP scan     (k_dec_count/_scan/_candlist, k_lip_words/_scan/_apply)  data parallel: a token
+//   LIP scan     (k_dec_count/_scan, k_lip_words/_scan/_apply/_deposit)  data parallel: a token
 //                starts at every bit preceded by an EVEN number of consecutive 1 bits (a 1 is
-//                always followed by its sign bit), so token starts, token ranks and the pixel
-//                each token belongs to all come from prefix sums;
-//   LIS phase    (k_lis_walk)  what each bit means depends on every earlier bit of the phase:
-//                one wavefront per chunk walks the lists; chunks run concurrently;
+//                always followed by its sign bit), so token starts and token ranks come from
+//                prefix sums; the results are written by token rank and picked up by the pixels
+//                through the rank of each candidate in raster order;
+//   LIS phase    (k_lis_tables, or k_lis_walk for irregular shapes)  what each bit means depends
+//                on every earlier bit of the phase: one workgroup per chunk; chunks run
+//                concurrently;
 //   refinement   (k_ref_apply)  the j-th significant pixel in raster order takes bit j.
 //
 // Bits past the available length read as zero (the reference zero-pads a truncated stream,
@@ -247,7 +249,9 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_dec_candlist(DecBuffers b, int p)
+// The k-th LIP candidate in raster order owns token k of the scan: take the results k_lip_apply
+// left at bit k of lipSig / lipNeg.  One thread per mask word; it is the only writer of that word.
+__global__ void __launch_bounds__(kThreads) k_lip_deposit(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
@@ -261,14 +265,37 @@ __global__ void __launch_bounds__(kThreads) k_dec_candlist(DecBuffers b, int p)
   if (wi < nw)
     lip = b.bornM[c * b.maskPixStride + wi] & ~b.sigOld[c * b.maskPixStride + wi];
   uint32_t total;
-  uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(lip), sm, &total) +
-                b.tileLipOff[c * b.tileStride + blockIdx.x];
-  uint32_t* cand = b.cand + c * b.candStride;
-  while (lip) {
+  const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(lip), sm, &total) +
+                      b.tileLipOff[c * b.tileStride + blockIdx.x];
+  const uint32_t n = (uint32_t)__popcll(lip);
+  if (n == 0)
+    return;
+  const uint64_t* rs = b.lipSig + c * b.lipResStride;
+  const uint64_t* rn = b.lipNeg + c * b.lipResStride;
+  const uint32_t sh = ex & 63u;
+  uint64_t vs = rs[ex >> 6] >> sh, vn = rn[ex >> 6] >> sh;
+  if (sh && sh + n > 64) {
+    vs |= rs[(ex >> 6) + 1] << (64 - sh);
+    vn |= rn[(ex >> 6) + 1] << (64 - sh);
+  }
+  if (n < 64) {
+    vs &= (1ull << n) - 1;
+    vn &= (1ull << n) - 1;
+  }
+  if (vs == 0)
+    return;
+  uint64_t outS = 0, outN = 0;
+  while (vs) {   // candidate i of the word is the i-th set bit of `lip`
     const int k = __ffsll((long long)lip) - 1;
     lip &= lip - 1;
-    cand[ex++] = wi * 64 + k;
+    outS |= (vs & 1ull) << k;
+    outN |= (vn & 1ull) << k;
+    vs >>= 1;
+    vn >>= 1;
   }
+  b.sigNew[c * b.maskPixStride + wi] |= outS;
+  if (outN)
+    b.sign[c * b.signStride + wi] &= ~outN;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -322,6 +349,10 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
     starts &= (1ull << (nbits & 63)) - 1;
   b.tokMask[c * b.tokStride + w] = starts;
   b.tokCnt[c * b.tokStride + w] = (uint32_t)__popcll(starts);
+  if (w <= (uint64_t)(s.nLip - 1) / 64) {   // results by token rank, filled by k_lip_apply
+    b.lipSig[c * b.lipResStride + w] = 0;
+    b.lipNeg[c * b.lipResStride + w] = 0;
+  }
 }
 
 __global__ void __launch_bounds__(kThreads) k_lip_scan(DecBuffers b, int p)
@@ -378,22 +409,34 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
   if (j >= s.nLip)
     return;
   const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
-  const uint32_t* cand = b.cand + c * b.candStride;
-  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
-  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
-  // the magnitude is not written here: k_ref_apply / k_dec_finish give a newly significant
-  // coefficient its value 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it
-  while (sig && j < s.nLip) {
+  // the tokens that start in this word have consecutive ranks j, j + 1, ...: their results go to
+  // bits j, j + 1, ... of lipSig (found significant) and lipNeg (and negative).  The magnitude is
+  // not written here: k_ref_apply / k_dec_finish give a newly significant coefficient its value
+  // 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it.
+  uint64_t runS = 0, runN = 0;
+  uint32_t i = 0;
+  while (sig && j + i < s.nLip) {
     const int k = __ffsll((long long)sig) - 1;
     sig &= sig - 1;
     if ((x >> k) & 1ull) {
-      const uint32_t pix = cand[j];
-      atomicOr(sigNew + (pix >> 6), 1ull << (pix & 63));
       const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
-      if (!sb)
-        atomicAnd(sign + (pix >> 6), ~(1ull << (pix & 63)));
+      runS |= 1ull << i;
+      runN |= (sb ^ 1ull) << i;
     }
-    j++;
+    i++;
+  }
+  if (runS == 0)
+    return;
+  unsigned long long* rs = reinterpret_cast<unsigned long long*>(b.lipSig + c * b.lipResStride);
+  unsigned long long* rn = reinterpret_cast<unsigned long long*>(b.lipNeg + c * b.lipResStride);
+  const uint32_t sh = j & 63u;
+  atomicOr(rs + (j >> 6), runS << sh);
+  if (sh && (runS >> (64 - sh)))
+    atomicOr(rs + (j >> 6) + 1, runS >> (64 - sh));
+  if (runN) {
+    atomicOr(rn + (j >> 6), runN << sh);
+    if (sh && (runN >> (64 - sh)))
+      atomicOr(rn + (j >> 6) + 1, runN >> (64 - sh));
   }
 }
 
@@ -1644,12 +1687,12 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_dec_candlist, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_words, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     if (wide_pass) {
       LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
+      LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
@@ -1662,6 +1705,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     else {
       LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
                          p);
+      LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
