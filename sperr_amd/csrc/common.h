@@ -31,7 +31,8 @@ void prof_end(hipStream_t stream);
   } while (0)
 
 constexpr int kMaxPlanes = 64;     // bit planes of a uint64 coefficient
-constexpr int kPixTile = 1024;     // samples per pixel-pass tile (256 threads x 4)
+constexpr int kPixPer = 16;        // consecutive samples per thread in the pixel passes
+constexpr int kPixTile = 4096;     // samples per pixel-pass tile (256 threads x kPixPer)
 constexpr int kListTile = 1024;    // list entries per list-pass tile (256 threads x 4)
 constexpr int kThreads = 256;
 

@@ -231,59 +231,70 @@ __global__ void k_enc_planes_setup(EncBuffers b)
 // ------------------------------------------------------------------------------------------
 // census of the pixel passes
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_pix4(const int8_t* a, uint32_t i0, uint32_t n, int v[4])
+// kPixPer consecutive int8 values starting at i0 (a multiple of kPixPer); -1 past the end
+__device__ __forceinline__ void load_pix(const int8_t* a, uint32_t i0, uint32_t n, int v[kPixPer])
 {
-  if (i0 + 4 <= n) {
-    const char4 q = *reinterpret_cast<const char4*>(a + i0);
-    v[0] = q.x;
-    v[1] = q.y;
-    v[2] = q.z;
-    v[3] = q.w;
+  static_assert(kPixPer == 16, "one 16-byte load per thread");
+  if (i0 + kPixPer <= n) {
+    const uint4 q = *reinterpret_cast<const uint4*>(a + i0);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < kPixPer; k++)
+      v[k] = (int)(int8_t)(w[k >> 2] >> ((k & 3) * 8));
   }
   else
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < kPixPer; k++)
       v[k] = (i0 + k < n) ? a[i0 + k] : -1;
 }
 
+// Bits each plane's LIP scan and refinement pass take inside one tile.  A sample with msb m that
+// enters the LIP at plane b (b >= m) costs one LIP bit on planes m <= p < b plus a sign bit on
+// plane m, and one refinement bit on every plane p < m: all of it follows from three histograms.
 __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
 {
   const uint32_t c = blockIdx.y;
   const EncState& s = b.st[c];
   if (!s.active || s.done)
     return;
-  __shared__ uint32_t wsum[kThreads / 64][kMaxPlanes];
+  // bin q + 1 counts value q (-1 .. kMaxPlanes - 1); one set of histograms per wavefront
+  __shared__ uint32_t hist[kThreads / 64][3][kMaxPlanes + 1];
+  for (uint32_t i = threadIdx.x; i < (kThreads / 64) * 3 * (kMaxPlanes + 1); i += kThreads)
+    (&hist[0][0][0])[i] = 0;
+  __syncthreads();
   const uint32_t n = b.tree.nvals;
-  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * 4;
-  int m[4], bp[4];
-  load_pix4(b.msb + c * b.pixStride, i0, n, m);
-  load_pix4(b.bplane + c * b.pixStride, i0, n, bp);
-  if (i0 >= n)
-    for (int k = 0; k < 4; k++)
-      bp[k] = -1, m[k] = -1;
-  const int nbp = s.nbp;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int p = 0; p < nbp; p++) {
-    uint32_t lip = 0, ref = 0;
+  const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * kPixPer;
+  const int wave = threadIdx.x >> 6;
+  if (i0 < n) {
+    int m[kPixPer], bp[kPixPer];
+    load_pix(b.msb + c * b.pixStride, i0, n, m);
+    load_pix(b.bplane + c * b.pixStride, i0, n, bp);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      lip += (bp[k] > p && p >= m[k]) ? (m[k] == p ? 2u : 1u) : 0u;
-      ref += (m[k] > p) ? 1u : 0u;
-    }
-    uint32_t v = lip | (ref << 16);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1)
-      v += __shfl_xor(v, d, 64);
-    if (lane == 0)
-      wsum[wave][p] = v;
+    for (int k = 0; k < kPixPer; k++)
+      if (i0 + k < n) {
+        atomicAdd(&hist[wave][0][m[k] + 1], 1u);
+        atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
+        if (m[k] >= 0 && bp[k] > m[k])
+          atomicAdd(&hist[wave][2][m[k] + 1], 1u);
+      }
   }
   __syncthreads();
-  if ((int)threadIdx.x < nbp) {
-    uint32_t v = 0;
-    for (int w = 0; w < kThreads / 64; w++)
-      v += wsum[w][threadIdx.x];
+  const int p = threadIdx.x;
+  if (p < s.nbp) {
+    uint32_t le_m = 0, le_b = 0, all_m = 0, eq = 0;
+    for (int w = 0; w < kThreads / 64; w++) {
+      for (int q = 0; q <= kMaxPlanes; q++) {
+        const uint32_t hm = hist[w][0][q];
+        all_m += hm;
+        if (q <= p + 1) {
+          le_m += hm;
+          le_b += hist[w][1][q];
+        }
+      }
+      eq += hist[w][2][p + 1];
+    }
     uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
-    cnt[(size_t)(threadIdx.x * 2 + 0) * b.nPixTiles + blockIdx.x] = v & 0xffffu;
-    cnt[(size_t)(threadIdx.x * 2 + 1) * b.nPixTiles + blockIdx.x] = v >> 16;
+    cnt[(size_t)(p * 2 + 0) * b.nPixTiles + blockIdx.x] = le_m - le_b + eq;   // LIP scan bits
+    cnt[(size_t)(p * 2 + 1) * b.nPixTiles + blockIdx.x] = all_m - le_m;       // refinement bits
   }
 }
 
@@ -812,23 +823,19 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
   __shared__ uint32_t sm[kThreads / 64 + 1];
   const uint32_t n = b.tree.nvals;
   const uint32_t tile = blockIdx.x;
-  const uint32_t i0 = tile * kPixTile + threadIdx.x * 4;
-  int m[4], bp[4];
-  load_pix4(b.msb + c * b.pixStride, i0, n, m);
-  load_pix4(b.bplane + c * b.pixStride, i0, n, bp);
-  uint64_t cf[4] = {0, 0, 0, 0};
+  const uint32_t i0 = tile * kPixTile + threadIdx.x * kPixPer;
+  int m[kPixPer], bp[kPixPer];
+  load_pix(b.msb + c * b.pixStride, i0, n, m);
+  load_pix(b.bplane + c * b.pixStride, i0, n, bp);
+  CT cf[kPixPer];
   uint32_t sg = 0;
   const CT* coef = reinterpret_cast<const CT*>(b.coef) + c * b.coefStride;
   const uint64_t* sign = b.sign + c * b.signStride;
-  for (int k = 0; k < 4; k++)
-    if (i0 + k < n) {
-      cf[k] = coef[i0 + k];
-      sg |= (uint32_t)((sign[(i0 + k) >> 6] >> ((i0 + k) & 63)) & 1ull) << k;
-    }
-    else {
-      m[k] = -1;
-      bp[k] = -1;
-    }
+  if (i0 < n)   // kPixPer divides 64: the signs of the thread's samples sit in one word
+    sg = (uint32_t)(sign[i0 >> 6] >> (i0 & 63));
+#pragma unroll
+  for (int k = 0; k < kPixPer; k++)
+    cf[k] = (i0 + k < n) ? coef[i0 + k] : (CT)0;
   const uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
   const uint32_t* off = b.pixOff + c * b.pixCntStride;
   uint64_t* stream = b.stream + c * b.streamStride;
@@ -843,9 +850,9 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
       lipw[w] = 0;
       refw[w] = 0;
     }
-    uint32_t lbits = 0, lval = 0, rbits = 0, rval = 0;
+    uint32_t lbits = 0, lval = 0, rbits = 0, rval = 0;   // at most 2 and 1 bits per sample
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < kPixPer; k++) {
       if (bp[k] > p && p >= m[k]) {
         if (m[k] == p) {
           lval |= (1u | (((sg >> k) & 1u) << 1)) << lbits;
@@ -855,7 +862,7 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
           lbits += 1;
       }
       if (m[k] > p) {
-        rval |= (uint32_t)((cf[k] >> p) & 1ull) << rbits;
+        rval |= (uint32_t)((cf[k] >> p) & 1) << rbits;
         rbits += 1;
       }
     }
