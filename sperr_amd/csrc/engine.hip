@@ -214,6 +214,7 @@ struct ShapePlan {
   const uint8_t* d_slotLevel = nullptr;
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
+  int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
   int maxK = 0;
   std::vector<uint32_t> depthBlockOff;
   uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
@@ -323,6 +324,15 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
+  P.l0Level = -1;   // the first non-empty list the sorting pass visits, when it holds 2x2x2 sets
+  for (uint32_t l = nlev; l-- > 0;) {
+    if (cap[l] == 0)
+      continue;
+    if (h.allRegular && h.levelClass[l].regular && h.levelClass[l].K == 1 &&
+        h.levelClass[l].arity[0] == 8)
+      P.l0Level = (int)l;
+    break;
+  }
   if (P.tables.ensure(blob.bytes.size()))
     return -1;
   HIP_CHECK(hipMemcpy(P.tables.p, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
@@ -985,6 +995,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
+  d.l0FlagStride = (d.streamStride * 64 + N) / 8192 + 4;   // (zero padding may be walked)
+  TAKE(d.l0Flags, unsigned long long, d.l0FlagStride * B);
+  d.l0Level = P.l0Level;
   d.wordLeaf = P.d_wordLeaf;
   d.leafStateStride = round_up(P.ht.nnodes, 64);
   TAKE(d.leafState, uint16_t, d.leafStateStride * B);
@@ -1115,8 +1128,9 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), ss));
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
-                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->maxK};
+                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->maxK};
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
+        HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
         if (d.lisStamps)
           HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 64 * 8 * nb, ss));
         // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
@@ -1530,8 +1544,9 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   else
     HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
   DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
-                 P->maxK};
+                 P->l0Level >= 0, P->maxK};
   HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
   if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
     return -1;
   HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));

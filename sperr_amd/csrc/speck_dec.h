@@ -20,6 +20,12 @@ struct DecState {
   uint64_t total_bits;
   uint64_t payload;              // byte offset of the SPECK payload inside the container
   uint64_t lipStart, lipBits;    // LIP scan of the current plane
+  // GPU-wide pass over the list of the smallest sets (k_lis_l0), which the LIS phase visits first
+  uint32_t l0Ticket;             // next block of the pass to hand out
+  int32_t l0PlaneP1;             // 1 + the plane whose list k_lis_l0 has decoded (0: none)
+  uint32_t l0Sig;                // entries it found significant (= leaf events it wrote)
+  uint32_t l0Pad;
+  uint64_t l0End;                // first bit after the list's code
   uint32_t listLen[2][spk::kMaxLevels];
 };
 
@@ -82,6 +88,10 @@ struct DecBuffers {
   uint16_t* leafState;
   size_t leafStateStride;
   const uint32_t* wordLeaf;
+  // k_lis_l0: one look-back word per block of kL0W stream bits (tagged with the plane)
+  unsigned long long* l0Flags;
+  size_t l0FlagStride;
+  int32_t l0Level;             // LIS level it handles, or -1
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
 };
 
@@ -89,6 +99,7 @@ struct DecPlanHost {
   const uint64_t* d_initLIS;
   const uint32_t* d_initLen;
   bool tables;                 // every LIS level is regular: use k_lis_tables
+  bool l0;                     // the level of the smallest sets is made of 2x2x2 leaf sets: k_lis_l0
   int maxK;                    // longest class chain (sizes the LDS tables)
 };
 

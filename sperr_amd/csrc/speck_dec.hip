@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.nLip = (uint32_t)carry;
     s.nRef = (uint32_t)(carry >> 32);
     s.lipStart = s.pos;
+    s.l0Ticket = 0;
   }
 }
 
@@ -673,6 +674,299 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// LIS phase, list of the smallest sets (2x2x2 leaf sets: class 0).  The sorting pass visits the
+// lists from the smallest sets to the largest (SPECK_INT.cpp:317-327), so this list's code starts
+// where the LIP scan ended and its entry count is known: the whole GPU decodes it before
+// k_lis_tables takes the other lists.  An entry is '0', or '1' followed by the <= 16 bits of its
+// eight pixels; nothing is born.  The stream is cut into blocks of kL0W bits handed out by a
+// ticket counter; each block
+//   * finds, for every bit position, the length of a token that would start there, and by pointer
+//     jumping where a chain of tokens entering at that position leaves the block, how many tokens
+//     it holds and how many of them are significant;
+//   * waits for its predecessor's look-back word (entry offset, entries and significant entries so
+//     far), publishes its own straight from those tables, and only then
+//   * marks the tokens really on the chain and lets every thread handle its share: insignificant
+//     entries are copied to the next list in order, significant ones become leaf events.
+// A block is handed out only after all earlier ones, so a waiting block always waits for a
+// workgroup that is running (or has seen the pass end).
+// ------------------------------------------------------------------------------------------
+constexpr int kL0W = 8192;
+constexpr int kL0Threads = 1024;
+constexpr int kL0Sub = kL0W / 64;
+constexpr uint32_t kL0None = 0xffffffffu;
+constexpr size_t kL0Smem = (size_t)(kL0W / 64 + 4) * 8 + (size_t)kL0W * (1 + 4 + 4);
+
+// chain summary: tokens << 21 | significant tokens << 14 | position reached (block-relative)
+__global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  const uint32_t L = (uint32_t)b.l0Level;
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint32_t n = s.listLen[cur][L];
+  if (n == 0)
+    return;   // (k_lis_tables finds the list empty as well)
+  extern __shared__ __attribute__((aligned(16))) char l0_smem[];
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(l0_smem);
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l0_smem);
+  uint32_t* hop64 = reinterpret_cast<uint32_t*>(l0_smem + (size_t)(kL0W / 64 + 4) * 8);
+  uint32_t* hopW = hop64 + kL0W;     // later: the marks of the tokens on the chain
+  uint8_t* U = reinterpret_cast<uint8_t*>(hopW + kL0W);
+  __shared__ uint32_t memoX[32], memoC[32], memoS[32];
+  __shared__ uint32_t entR[kL0W / 1024], entK[kL0W / 1024], entS[kL0W / 1024];
+  __shared__ uint32_t blkE[kL0Sub], blkK[kL0Sub], blkS[kL0Sub];
+  __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
+
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+  const Tree& t = b.tree;
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[L];
+  uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[L];
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  unsigned long long* flags = b.l0Flags + c * b.l0FlagStride;
+  const unsigned long long tag = (unsigned long long)(p + 1) << 56;
+
+  for (;;) {
+    if (tid == 0) {
+      const bool over = __hip_atomic_load(&s.l0PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                        p + 1;
+      sh_ticket = over ? kL0None : atomicAdd(&s.l0Ticket, 1u);
+    }
+    __syncthreads();
+    const uint32_t i = sh_ticket;
+    if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
+      break;
+    const uint64_t a = phase0 + (uint64_t)i * kL0W;
+    const uint64_t w0 = a >> 6;
+    const uint32_t q0 = (uint32_t)(a & 63);
+    for (uint32_t k = tid; k < (uint32_t)(kL0W / 64 + 4); k += kL0Threads)
+      wbits[k] = w0 + k < nwordsAvail ? words[w0 + k] : 0ull;
+    __syncthreads();
+    auto bit_at = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0;
+      return (w32[q >> 5] >> (q & 31)) & 1u;
+    };
+    auto bits32 = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0, sh = q & 31;
+      const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+      return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    };
+    // ---- token length at every position
+    for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads) {
+      uint32_t len = 1;
+      if (bit_at(r)) {
+        const uint32_t v = bits32(r + 1);
+        uint32_t y = 0, found = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          const uint32_t bit = (v >> y) & 1u;
+          found |= bit;
+          y += 1u + bit;
+        }
+        const uint32_t bit = found ? (v >> y) & 1u : 1u;
+        len = 1u + y + found + bit;
+      }
+      U[r] = (uint8_t)len;
+    }
+    __syncthreads();
+    // ---- chains inside 64-position sub-blocks (lane = position)
+    for (uint32_t sb = wave; sb < (uint32_t)kL0Sub; sb += kL0Threads / 64) {
+      const uint32_t r = sb * 64 + lane, hEnd = (sb + 1) * 64;
+      uint32_t v = (1u << 21) | (bit_at(r) << 14) | (r + U[r]);
+      bool inb = (v & 0x3fffu) < hEnd;
+      for (int it = 0; it < 6 && __any(inb); it++) {
+        const uint32_t o = __shfl(v, (v & 0x3fffu) & 63u, 64);
+        if (inb) {
+          v = (v & ~0x3fffu) + o;
+          inb = (v & 0x3fffu) < hEnd;
+        }
+      }
+      hop64[r] = v;
+      hopW[r] = v;
+    }
+    __syncthreads();
+    // ---- widen a copy to 1024-position blocks (in place: any version read is a valid summary)
+    for (uint32_t wide = 128; wide <= 1024; wide <<= 1) {
+      for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads) {
+        const uint32_t v = hopW[r], e = v & 0x3fffu;
+        if (e < (uint32_t)kL0W && e / wide == r / wide)
+          hopW[r] = (v & ~0x3fffu) + hopW[e];
+      }
+      __syncthreads();
+    }
+    // ---- the whole block, for each of the 17 offsets a chain can enter at
+    if (tid < 17) {
+      uint32_t r = tid, cnt = 0, sg = 0;
+      while (r < (uint32_t)kL0W) {
+        const uint32_t v = hopW[r];
+        cnt += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+      memoX[tid] = r - kL0W;
+      memoC[tid] = cnt;
+      memoS[tid] = sg;
+    }
+    __syncthreads();
+    // ---- look back, publish
+    if (tid == 0) {
+      uint32_t e = 0, rank = 0, sg = 0, stop = 0, last = 0;
+      if (i > 0) {
+        unsigned long long f = 0;
+        uint32_t spins = 0;
+        for (;;) {
+          f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> 56) == (unsigned long long)(p + 1))
+            break;
+          if (__hip_atomic_load(&s.l0PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+            stop = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) {   // cannot happen; never leave a wave spinning for ever
+            s.error = 1;
+            __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stop = 1;
+            break;
+          }
+        }
+        if (!stop) {
+          if ((f >> 55) & 1ull)
+            stop = 1;
+          else {
+            e = (uint32_t)(f >> 50) & 31u;
+            rank = (uint32_t)(f >> 25) & 0x1ffffffu;
+            sg = (uint32_t)f & 0x1ffffffu;
+          }
+        }
+      }
+      if (!stop) {
+        if (rank + memoC[e] >= n) {   // the list ends inside this block
+          last = 1;
+          __hip_atomic_store(flags + i, tag | (1ull << 55), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+          __hip_atomic_store(flags + i,
+                             tag | ((unsigned long long)memoX[e] << 50) |
+                                 ((unsigned long long)(rank + memoC[e]) << 25) |
+                                 (unsigned long long)(sg + memoS[e]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh_e = e;
+      sh_rank = rank;
+      sh_sig = sg;
+      sh_last = last;
+      sh_stop = stop;
+      sh_endpos = 0;
+      sh_endsig = 0;
+    }
+    for (uint32_t k = tid; k < (uint32_t)kL0Sub; k += kL0Threads)
+      blkE[k] = kL0None;
+    if (tid < kL0W / 1024)
+      entR[tid] = kL0None;
+    __syncthreads();
+    if (sh_stop)
+      break;
+    // ---- where the chain enters each 1024-block, then each sub-block
+    if (tid == 0) {
+      uint32_t r = sh_e, rk = 0, sg = 0;
+      while (r < (uint32_t)kL0W) {
+        entR[r >> 10] = r;
+        entK[r >> 10] = rk;
+        entS[r >> 10] = sg;
+        const uint32_t v = hopW[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    if (tid < kL0W / 1024 && entR[tid] != kL0None) {
+      uint32_t r = entR[tid], rk = entK[tid], sg = entS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 1024;
+      while (r < end) {
+        blkE[r >> 6] = r;
+        blkK[r >> 6] = rk;
+        blkS[r >> 6] = sg;
+        const uint32_t v = hop64[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
+    for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads)
+      hopW[r] = 0;
+    __syncthreads();
+    const uint32_t rank0 = sh_rank, sig0 = sh_sig;
+    const uint32_t nloc = n - rank0;   // entries the list still holds at the start of the block
+    if (tid < kL0Sub && blkE[tid] != kL0None) {
+      uint32_t r = blkE[tid], rk = blkK[tid], sg = blkS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 64;
+      bool did = false;
+      while (r < end && rk < nloc) {
+        hopW[r] = (rk + 1u) | (sg << 16);
+        rk++;
+        sg += bit_at(r);
+        r += U[r];
+        did = true;
+      }
+      if (did && rk == nloc) {   // this thread decoded the list's last entry
+        sh_endpos = r;
+        sh_endsig = sg;
+      }
+    }
+    __syncthreads();
+    // ---- every thread handles the tokens that start at its positions
+    for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads) {
+      const uint32_t mk = hopW[r];
+      if (mk == 0)
+        continue;
+      const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
+      const uint64_t ident = list[q];
+      if (!bit_at(r)) {
+        keep[q - sb] = ident;
+        continue;
+      }
+      const uint32_t v = bits32(r + 1);
+      uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+        sigm |= bit << k;
+        negm |= (bit & (sgn ^ 1u)) << k;
+        found |= bit;
+        yy += 1u + bit;
+      }
+      const uint32_t bit = found ? (v >> yy) & 1u : 1u;
+      const uint32_t sgn = (v >> (yy + found)) & 1u;
+      sigm |= bit << 7;
+      negm |= (bit & (sgn ^ 1u)) << 7;
+      const Node nd = unpack_node(ident);
+      const Grid g = t.grids[nd.grid];
+      const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
+      if (sb < b.leafCap)
+        leafEv[sb] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+    }
+    if (sh_last) {
+      if (tid == 0) {
+        s.l0End = a + sh_endpos;
+        s.l0Sig = sig0 + sh_endsig;
+        s.listLen[nx][L] = n - (sig0 + sh_endsig);
+      }
+      break;
+    }
+    __syncthreads();   // LDS is reused by the next block
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): one
 // 1024-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_par is the
 // CPU model of this kernel.
@@ -810,10 +1104,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
 
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  // the list of the smallest sets may already have been decoded by k_lis_l0
+  const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
   if (tid == 0) {
-    sh_pos = phase0;
+    sh_pos = l0done ? s.l0End : phase0;
     sh_born = 0;
-    sh_leaf = 0;
+    sh_leaf = l0done ? s.l0Sig : 0;
   }
   __syncthreads();
   // diagnostic stamps (thread 0 only, when b.lisStamps != nullptr): ticks per phase
@@ -862,6 +1158,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   };
 
   for (uint32_t l = t.nlevels; l-- > 0;) {
+    if (l0done && l == (uint32_t)b.l0Level)
+      continue;
     const uint32_t n = s.listLen[cur][l];
     if (n == 0) {
       if (tid == 0)
@@ -1684,6 +1982,16 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       attr_set = true;
     }
   }
+  // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
+  const uint32_t l0Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 512 / nc));
+  if (plan.tables && plan.l0) {
+    static bool l0_attr = false;
+    if (!l0_attr) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_l0),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL0Smem));
+      l0_attr = true;
+    }
+  }
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -1694,6 +2002,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
                          p);
       LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
+        if (plan.l0)
+          LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
       }
@@ -1707,6 +2017,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
                          p);
       LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
+        if (plan.l0)
+          LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
       }
