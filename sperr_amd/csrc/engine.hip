@@ -215,6 +215,7 @@ struct ShapePlan {
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
   int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
+  int l1Level = -1;                       // LIS level of 4x4x4 sets that k_lis_l1 can decode
   int maxK = 0;
   std::vector<uint32_t> depthBlockOff;
   uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
@@ -333,6 +334,17 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
       P.l0Level = (int)l;
     break;
   }
+  P.l1Level = -1;   // the next non-empty list, when it holds 4x4x4 sets made of those leaf sets
+  if (P.l0Level >= 0)
+    for (uint32_t l = (uint32_t)P.l0Level; l-- > 0;) {
+      if (cap[l] == 0)
+        continue;
+      const spk::LevelClass& lc = h.levelClass[l];
+      if (lc.regular && lc.K == 2 && lc.arity[0] == 8 && lc.arity[1] == 8 &&
+          lc.lev[0] == (uint8_t)P.l0Level)
+        P.l1Level = (int)l;
+      break;
+    }
   if (P.tables.ensure(blob.bytes.size()))
     return -1;
   HIP_CHECK(hipMemcpy(P.tables.p, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
@@ -998,6 +1010,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.l0FlagStride = (d.streamStride * 64 + N) / 8192 + 4;   // (zero padding may be walked)
   TAKE(d.l0Flags, unsigned long long, d.l0FlagStride * B);
   d.l0Level = P.l0Level;
+  TAKE(d.l1Flags, unsigned long long, d.l0FlagStride * B);
+  d.l1Level = P.l1Level;
   d.wordLeaf = P.d_wordLeaf;
   d.leafStateStride = round_up(P.ht.nnodes, 64);
   TAKE(d.leafState, uint16_t, d.leafStateStride * B);
@@ -1128,9 +1142,10 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), ss));
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
-                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->maxK};
+                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->l1Level >= 0, P->maxK};
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
+        HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));
         if (d.lisStamps)
           HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 64 * 8 * nb, ss));
         // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
@@ -1544,9 +1559,10 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   else
     HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
   DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
-                 P->l0Level >= 0, P->maxK};
+                 P->l0Level >= 0, P->l1Level >= 0, P->maxK};
   HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
   HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
   if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
     return -1;
   HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));

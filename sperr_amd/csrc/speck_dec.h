@@ -26,6 +26,12 @@ struct DecState {
   uint32_t l0Sig;                // entries it found significant (= leaf events it wrote)
   uint32_t l0Pad;
   uint64_t l0End;                // first bit after the list's code
+  // same for the next list (4x4x4 sets), k_lis_l1
+  uint32_t l1Ticket;
+  int32_t l1PlaneP1;
+  uint64_t l1End;
+  uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
+  uint32_t leafCount;            //   of the current plane
   uint32_t listLen[2][spk::kMaxLevels];
 };
 
@@ -92,6 +98,8 @@ struct DecBuffers {
   unsigned long long* l0Flags;
   size_t l0FlagStride;
   int32_t l0Level;             // LIS level it handles, or -1
+  unsigned long long* l1Flags; // same for k_lis_l1
+  int32_t l1Level;
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
 };
 
@@ -100,6 +108,7 @@ struct DecPlanHost {
   const uint32_t* d_initLen;
   bool tables;                 // every LIS level is regular: use k_lis_tables
   bool l0;                     // the level of the smallest sets is made of 2x2x2 leaf sets: k_lis_l0
+  bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
 };
 

@@ -247,6 +247,9 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.nRef = (uint32_t)(carry >> 32);
     s.lipStart = s.pos;
     s.l0Ticket = 0;
+    s.l1Ticket = 0;
+    s.bornCount = 0;
+    s.leafCount = 0;
   }
 }
 
@@ -958,6 +961,376 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       if (tid == 0) {
         s.l0End = a + sh_endpos;
         s.l0Sig = sig0 + sh_endsig;
+        s.leafCount = sig0 + sh_endsig;
+        s.listLen[nx][L] = n - (sig0 + sh_endsig);
+      }
+      break;
+    }
+    __syncthreads();   // LDS is reused by the next block
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LIS phase, the next list: 4x4x4 sets (class 1) whose children are the 2x2x2 leaf sets.  Same
+// scheme as k_lis_l0 with one more level inside a token: an entry is '0', or '1' followed by its
+// eight children, each '0' (the child joins the list of the smallest sets: a birth, recorded
+// with its stream position exactly like k_lis_tables does) or '1' + eight pixels (a leaf event).
+// A token takes at most 1 + 7 * 17 + 17 = 137 bits, so the tables of a block cover kL1Ahead
+// positions more than the block itself.  Births and leaf events get their slots per block: each
+// token reserves block-local slots while it is counted, the block reserves its range with one
+// atomic per counter, and a second sweep writes.
+// ------------------------------------------------------------------------------------------
+constexpr int kL1W = 8192;
+constexpr int kL1Ahead = 192;
+constexpr int kL1P = kL1W + kL1Ahead;           // positions with class-0 tables
+constexpr int kL1MaxTok = 137;
+constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)kL1W * (4 + 4 + 1) + (size_t)kL1P * 2;
+
+__global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  const uint32_t L = (uint32_t)b.l1Level, L0 = (uint32_t)b.l0Level;
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint32_t n = s.listLen[cur][L];
+  const bool l0done = s.l0PlaneP1 == p + 1;
+  if (n == 0 || (!l0done && s.listLen[cur][L0] != 0))
+    return;   // (k_lis_tables takes the list)
+  extern __shared__ __attribute__((aligned(16))) char l1_smem[];
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(l1_smem);
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l1_smem);
+  uint32_t* hop64 = reinterpret_cast<uint32_t*>(l1_smem + (size_t)(kL1P / 64 + 4) * 8);
+  uint32_t* hopW = hop64 + kL1W;     // later: the marks of the tokens on the chain
+  uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1W);   // token length at every position
+  uint8_t* U0 = U1 + kL1W;           // coded class-0 item: 1, or 1 + T0 of the next position
+  uint8_t* T0 = U0 + kL1P;           // split of a class-0 set that starts here
+  __shared__ uint32_t memoX[kL1MaxTok + 1], memoC[kL1MaxTok + 1], memoS[kL1MaxTok + 1];
+  __shared__ uint32_t entR[kL1W / 1024], entK[kL1W / 1024], entS[kL1W / 1024];
+  __shared__ uint32_t blkE[kL1W / 64], blkK[kL1W / 64], blkS[kL1W / 64];
+  __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
+  __shared__ uint32_t sh_nb, sh_nl, sh_baseB, sh_baseL;
+
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+  const Tree& t = b.tree;
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t start0 = l0done ? s.l0End : phase0;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[L];
+  uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[L];
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  unsigned long long* flags = b.l1Flags + c * b.l0FlagStride;
+  const unsigned long long tag = (unsigned long long)(p + 1) << 56;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  const uint32_t bornLev = b.levelClass[L].lev[0];
+  const uint32_t bornSlot = b.levelSlot[bornLev];
+  uint64_t* bornMask = b.mask + c * b.maskStride + (size_t)bornSlot * b.maskWords;
+
+  for (;;) {
+    if (tid == 0) {
+      const bool over = __hip_atomic_load(&s.l1PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                        p + 1;
+      sh_ticket = over ? kL0None : atomicAdd(&s.l1Ticket, 1u);
+      sh_nb = 0;
+      sh_nl = 0;
+    }
+    __syncthreads();
+    const uint32_t i = sh_ticket;
+    if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
+      break;
+    const uint64_t a = start0 + (uint64_t)i * kL1W;
+    const uint64_t w0 = a >> 6;
+    const uint32_t q0 = (uint32_t)(a & 63);
+    for (uint32_t k = tid; k < (uint32_t)(kL1P / 64 + 4); k += kL0Threads)
+      wbits[k] = w0 + k < nwordsAvail ? words[w0 + k] : 0ull;
+    __syncthreads();
+    auto bit_at = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0;
+      return (w32[q >> 5] >> (q & 31)) & 1u;
+    };
+    auto bits32 = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0, sh = q & 31;
+      const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+      return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    };
+    // ---- class 0: split length, then the coded item
+    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL0Threads) {
+      const uint32_t v = bits32(r);
+      uint32_t y = 0, found = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t bit = (v >> y) & 1u;
+        found |= bit;
+        y += 1u + bit;
+      }
+      const uint32_t bit = found ? (v >> y) & 1u : 1u;
+      T0[r] = (uint8_t)(y + found + bit);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL0Threads)
+      U0[r] = (uint8_t)((bit_at(r) && r + 1 < (uint32_t)kL1P) ? 1u + T0[r + 1] : 1u);
+    __syncthreads();
+    // ---- class 1: the token at every position of the block
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+      uint32_t len = 1;
+      if (bit_at(r)) {
+        uint32_t y = r + 1, found = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          const uint32_t u = U0[y];
+          found |= u - 1u;
+          y += u;
+        }
+        y += found ? U0[y] : T0[y];
+        len = y - r;
+      }
+      U1[r] = (uint8_t)len;
+    }
+    __syncthreads();
+    // ---- chains inside 64-position sub-blocks (lane = position)
+    for (uint32_t sb = wave; sb < (uint32_t)(kL1W / 64); sb += kL0Threads / 64) {
+      const uint32_t r = sb * 64 + lane, hEnd = (sb + 1) * 64;
+      uint32_t v = (1u << 21) | (bit_at(r) << 14) | (r + U1[r]);
+      bool inb = (v & 0x3fffu) < hEnd;
+      for (int it = 0; it < 6 && __any(inb); it++) {
+        const uint32_t o = __shfl(v, (v & 0x3fffu) & 63u, 64);
+        if (inb) {
+          v = (v & ~0x3fffu) + o;
+          inb = (v & 0x3fffu) < hEnd;
+        }
+      }
+      hop64[r] = v;
+      hopW[r] = v;
+    }
+    __syncthreads();
+    for (uint32_t wide = 128; wide <= 1024; wide <<= 1) {
+      for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+        const uint32_t v = hopW[r], e = v & 0x3fffu;
+        if (e < (uint32_t)kL1W && e / wide == r / wide)
+          hopW[r] = (v & ~0x3fffu) + hopW[e];
+      }
+      __syncthreads();
+    }
+    // ---- the whole block, for each offset a chain can enter at
+    if (tid <= kL1MaxTok) {
+      uint32_t r = tid, cnt = 0, sg = 0;
+      while (r < (uint32_t)kL1W) {
+        const uint32_t v = hopW[r];
+        cnt += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+      memoX[tid] = r - kL1W;
+      memoC[tid] = cnt;
+      memoS[tid] = sg;
+    }
+    __syncthreads();
+    // ---- look back, publish: tag | done << 55 | exit offset << 47 | entries << 23 | significant
+    if (tid == 0) {
+      uint32_t e = 0, rank = 0, sg = 0, stop = 0, last = 0;
+      if (i > 0) {
+        unsigned long long f = 0;
+        uint32_t spins = 0;
+        for (;;) {
+          f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> 56) == (unsigned long long)(p + 1))
+            break;
+          if (__hip_atomic_load(&s.l1PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+            stop = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 24)) {   // cannot happen; never leave a wave spinning for ever
+            s.error = 1;
+            __hip_atomic_store(&s.l1PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stop = 1;
+            break;
+          }
+        }
+        if (!stop) {
+          if ((f >> 55) & 1ull)
+            stop = 1;
+          else {
+            e = (uint32_t)(f >> 47) & 0xffu;
+            rank = (uint32_t)(f >> 23) & 0xffffffu;
+            sg = (uint32_t)f & 0x7fffffu;
+          }
+        }
+      }
+      if (!stop) {
+        if (rank + memoC[e] >= n) {   // the list ends inside this block
+          last = 1;
+          __hip_atomic_store(flags + i, tag | (1ull << 55), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&s.l1PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+          __hip_atomic_store(flags + i,
+                             tag | ((unsigned long long)memoX[e] << 47) |
+                                 ((unsigned long long)(rank + memoC[e]) << 23) |
+                                 (unsigned long long)(sg + memoS[e]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh_e = e;
+      sh_rank = rank;
+      sh_sig = sg;
+      sh_last = last;
+      sh_stop = stop;
+      sh_endpos = 0;
+      sh_endsig = 0;
+    }
+    for (uint32_t k = tid; k < (uint32_t)(kL1W / 64); k += kL0Threads)
+      blkE[k] = kL0None;
+    if (tid < kL1W / 1024)
+      entR[tid] = kL0None;
+    __syncthreads();
+    if (sh_stop)
+      break;
+    // ---- where the chain enters each 1024-block, then each sub-block
+    if (tid == 0) {
+      uint32_t r = sh_e, rk = 0, sg = 0;
+      while (r < (uint32_t)kL1W) {
+        entR[r >> 10] = r;
+        entK[r >> 10] = rk;
+        entS[r >> 10] = sg;
+        const uint32_t v = hopW[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    if (tid < kL1W / 1024 && entR[tid] != kL0None) {
+      uint32_t r = entR[tid], rk = entK[tid], sg = entS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 1024;
+      while (r < end) {
+        blkE[r >> 6] = r;
+        blkK[r >> 6] = rk;
+        blkS[r >> 6] = sg;
+        const uint32_t v = hop64[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads)
+      hopW[r] = 0;
+    __syncthreads();
+    const uint32_t rank0 = sh_rank, sig0 = sh_sig;
+    const uint32_t nloc = n - rank0;
+    if (tid < kL1W / 64 && blkE[tid] != kL0None) {
+      uint32_t r = blkE[tid], rk = blkK[tid], sg = blkS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 64;
+      bool did = false;
+      while (r < end && rk < nloc) {
+        hopW[r] = (rk + 1u) | (sg << 16);
+        rk++;
+        sg += bit_at(r);
+        r += U1[r];
+        did = true;
+      }
+      if (did && rk == nloc) {
+        sh_endpos = r;
+        sh_endsig = sg;
+      }
+    }
+    __syncthreads();
+    // ---- first sweep: insignificant entries stay; significant ones count their births and leaf
+    //      events and take block-local slots (hop64[r] = birth slot | event slot << 16)
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+      const uint32_t mk = hopW[r];
+      if (mk == 0)
+        continue;
+      const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
+      if (!bit_at(r)) {
+        keep[q - sb] = list[q];
+        continue;
+      }
+      uint32_t y = r + 1, found = 0, nb = 0, nl = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool coded = found || k != 7;
+        const uint32_t u = coded ? U0[y] : T0[y];
+        if (coded && u == 1) {
+          const uint64_t rel = a + y - phase0;
+          nb += (bornSlot != 0xff && rel < maskBits) ? 1u : 0u;
+        }
+        else {
+          found = 1;
+          nl++;
+        }
+        y += u;
+      }
+      const uint32_t slotB = nb ? atomicAdd(&sh_nb, nb) : 0u;
+      const uint32_t slotL = atomicAdd(&sh_nl, nl);
+      hop64[r] = slotB | (slotL << 16);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      sh_baseB = sh_nb ? atomicAdd(&s.bornCount, sh_nb) : 0u;
+      sh_baseL = sh_nl ? atomicAdd(&s.leafCount, sh_nl) : 0u;
+    }
+    __syncthreads();
+    // ---- second sweep: write the births and the leaf events
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+      const uint32_t mk = hopW[r];
+      if (mk == 0 || !bit_at(r))
+        continue;
+      const uint32_t q = rank0 + (mk & 0xffffu) - 1u;
+      const Node nd = unpack_node(list[q]);
+      const Grid g1 = t.grids[nd.grid + 1];   // the grid of the children
+      uint32_t slotB = sh_baseB + (hop64[r] & 0xffffu), slotL = sh_baseL + (hop64[r] >> 16);
+      uint32_t y = r + 1, found = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool coded = found || k != 7;
+        const uint32_t u = coded ? U0[y] : T0[y];
+        const uint32_t cx = 2u * nd.i[0] + (uint32_t)(k & 1), cy = 2u * nd.i[1] + (uint32_t)((k >> 1) & 1),
+                       cz = 2u * nd.i[2] + (uint32_t)(k >> 2);
+        if (coded && u == 1) {   // stays insignificant: joins the list of the smallest sets
+          const uint64_t rel = a + y - phase0;
+          if (bornSlot != 0xff && rel < maskBits) {
+            if (slotB < b.bornStride) {
+              bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) |
+                                  ((uint64_t)cy << 16) | (uint64_t)cx;
+              bornPosLev[slotB] = ((uint64_t)bornLev << 48) | rel;
+              atomic_or64(bornMask + (rel >> 6), 1ull << (rel & 63));
+            }
+            slotB++;
+          }
+        }
+        else {                   // splits into its pixels
+          found = 1;
+          const uint32_t v = bits32(coded ? y + 1 : y);
+          uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
+#pragma unroll
+          for (int j = 0; j < 7; j++) {
+            const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+            sigm |= bit << j;
+            negm |= (bit & (sgn ^ 1u)) << j;
+            fnd |= bit;
+            yy += 1u + bit;
+          }
+          const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
+          const uint32_t sgn = (v >> (yy + fnd)) & 1u;
+          sigm |= bit << 7;
+          negm |= (bit & (sgn ^ 1u)) << 7;
+          const uint32_t fid = g1.nodeOff + (((cz << g1.e[1]) + cy) << g1.e[0]) + cx;
+          if (slotL < b.leafCap)
+            leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+          slotL++;
+        }
+        y += u;
+      }
+    }
+    if (sh_last) {
+      if (tid == 0) {
+        s.l1End = a + sh_endpos;
         s.listLen[nx][L] = n - (sig0 + sh_endsig);
       }
       break;
@@ -1106,10 +1479,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
   // the list of the smallest sets may already have been decoded by k_lis_l0
   const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
+  const bool l1done = b.l1Level >= 0 && s.l1PlaneP1 == p + 1;
   if (tid == 0) {
-    sh_pos = l0done ? s.l0End : phase0;
-    sh_born = 0;
-    sh_leaf = l0done ? s.l0Sig : 0;
+    sh_pos = l1done ? s.l1End : l0done ? s.l0End : phase0;
+    sh_born = s.bornCount;
+    sh_leaf = s.leafCount;
   }
   __syncthreads();
   // diagnostic stamps (thread 0 only, when b.lisStamps != nullptr): ticks per phase
@@ -1158,7 +1532,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   };
 
   for (uint32_t l = t.nlevels; l-- > 0;) {
-    if (l0done && l == (uint32_t)b.l0Level)
+    if ((l0done && l == (uint32_t)b.l0Level) || (l1done && l == (uint32_t)b.l1Level))
       continue;
     const uint32_t n = s.listLen[cur][l];
     if (n == 0) {
@@ -1989,9 +2363,12 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     if (!l0_attr) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_l0),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL0Smem));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_l1),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL1Smem));
       l0_attr = true;
     }
   }
+  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 256 / nc));
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -2004,6 +2381,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       if (plan.tables) {
         if (plan.l0)
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
+        if (plan.l1)
+          LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
       }
@@ -2019,6 +2398,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       if (plan.tables) {
         if (plan.l0)
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
+        if (plan.l1)
+          LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
       }
