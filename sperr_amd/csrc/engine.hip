@@ -1007,7 +1007,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
-  d.l0FlagStride = (d.streamStride * 64 + N) / 8192 + 4;   // (zero padding may be walked)
+  d.l0FlagStride = (d.streamStride * 64 + N) / 4096 + 4;   // (zero padding may be walked)
   TAKE(d.l0Flags, unsigned long long, d.l0FlagStride * B);
   d.l0Level = P.l0Level;
   TAKE(d.l1Flags, unsigned long long, d.l0FlagStride * B);
@@ -1143,6 +1143,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->l1Level >= 0, P->maxK};
+        ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));
@@ -1172,7 +1173,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
                                   wide ? maxWide : maxNarrow))
             return -1;
           if (launch_inv_quantize(ss, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
-                                  P->N, bb.vals, bb.valsStride, d.cst))
+                                  P->N, bb.vals, bb.valsStride, d.cst, d.sigNew, d.sigOld,
+                                  d.maskPixStride, d.st))
             return -1;
         }
         // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters

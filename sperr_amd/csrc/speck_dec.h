@@ -110,6 +110,7 @@ struct DecPlanHost {
   bool l0;                     // the level of the smallest sets is made of 2x2x2 leaf sets: k_lis_l0
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
+  bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
 };
 
 int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,

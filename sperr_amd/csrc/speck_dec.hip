@@ -980,7 +980,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
 // token reserves block-local slots while it is counted, the block reserves its range with one
 // atomic per counter, and a second sweep writes.
 // ------------------------------------------------------------------------------------------
-constexpr int kL1W = 8192;
+constexpr int kL1W = 4096;
 constexpr int kL1Ahead = 192;
 constexpr int kL1P = kL1W + kL1Ahead;           // positions with class-0 tables
 constexpr int kL1MaxTok = 137;
@@ -2368,7 +2368,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       l0_attr = true;
     }
   }
-  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 256 / nc));
+  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 768 / nc));
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -2415,12 +2415,14 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     if (plan.tables && b.wordLeaf)
       LAUNCH_K(k_dec_fold, dim3(((n + 63) / 64 + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
                stream, b);
-    if (wide_pass)
-      LAUNCH_K(k_dec_finish<uint64_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
-               stream, b);
-    else
-      LAUNCH_K(k_dec_finish<uint32_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
-               stream, b);
+    if (!plan.skipFinish) {
+      if (wide_pass)
+        LAUNCH_K(k_dec_finish<uint64_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
+                 stream, b);
+      else
+        LAUNCH_K(k_dec_finish<uint32_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
+                 stream, b);
+    }
   }
   HIP_CHECK(hipGetLastError());
   return 0;

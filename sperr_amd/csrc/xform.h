@@ -39,9 +39,14 @@ int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t va
                     uint32_t nchunks, uint32_t n, void* coef, size_t coefStride, uint64_t* sign,
                     size_t signStride, int8_t* msb, size_t msbStride, const CoderState* st);
 
+// sigNew / sigOld / dst: the decoder's significance masks and state, to complete the coefficients
+// that were never refined (then launch_speck_decode is told to skip its own finishing pass)
+struct DecState;
 int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t coefStride,
                         const uint64_t* sign, size_t signStride, uint32_t nchunks, uint32_t n,
-                        double* vals, size_t valsStride, const CoderState* st);
+                        double* vals, size_t valsStride, const CoderState* st,
+                        const uint64_t* sigNew = nullptr, const uint64_t* sigOld = nullptr,
+                        size_t maskStride = 0, const DecState* dst = nullptr);
 
 }  // namespace sperrhip
 

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "xform.h"
+#include "speck_dec.h"
 
 namespace sperrhip {
 
@@ -312,21 +313,39 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
 // quantiser
 // ------------------------------------------------------------------------------------------
 
-__global__ void k_maxabs(const double* vals, size_t valsStride, uint32_t n, CoderState* st)
+constexpr int kMaxPer = 16;   // samples per thread, as 16-byte loads
+__global__ void __launch_bounds__(kThreads)
+k_maxabs(const double* vals, size_t valsStride, uint32_t n, CoderState* st)
 {
   const uint32_t c = blockIdx.y;
   if (st[c].is_const)
     return;
+  __shared__ double wmax[kThreads / 64];
   const double* in = vals + c * valsStride;
+  const uint32_t base = blockIdx.x * (kThreads * kMaxPer);
   double m = 0.0;
-  for (uint32_t i = blockIdx.x * blockDim.x * 8 + threadIdx.x, k = 0; k < 8 && i < n;
-       k++, i += blockDim.x)
-    m = fmax(m, fabs(in[i]));
+#pragma unroll
+  for (int k = 0; k < kMaxPer / 2; k++) {
+    const uint32_t i = base + (k * kThreads + threadIdx.x) * 2;
+    if (i + 1 < n) {
+      const double2 v = *reinterpret_cast<const double2*>(in + i);
+      m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+    }
+    else if (i < n)
+      m = fmax(m, fabs(in[i]));
+  }
   for (int d = 32; d > 0; d >>= 1)
     m = fmax(m, __shfl_xor(m, d, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.0)  // non-negative doubles order like their bit patterns
-    atomicMax(reinterpret_cast<unsigned long long*>(&st[c].maxabs),
-              (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0)
+    wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / 64; w++)
+      m = fmax(m, wmax[w]);
+    if (m > 0.0)  // non-negative doubles order like their bit patterns
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].maxabs),
+                (unsigned long long)__double_as_longlong(m));
+  }
 }
 
 // SPECK_FLT.cpp:282-301 (fixed-rate q) ; `wide` selects the high-precision retry
@@ -375,21 +394,67 @@ __global__ void k_quantize(const double* vals, size_t valsStride, uint32_t n, CT
     sign[c * signStride + (i >> 6)] = word;
 }
 
-// SPECK_FLT.cpp:373-399 : (q * c) * (+-1.0), left to right
+// SPECK_FLT.cpp:373-399 : (q * c) * (+-1.0), left to right.  When the decoder's masks are given,
+// the coefficients that became significant but were never refined are completed here instead of
+// in a pass of their own (k_dec_finish, speck_dec.hip: 1.5 * 2^plane - 1, SPECK_INT.cpp:462-468).
 template <typename CT>
-__global__ void k_inv_quantize(const CT* coef, size_t coefStride, const uint64_t* sign,
-                               size_t signStride, uint32_t n, double* vals, size_t valsStride,
-                               const CoderState* st, int wide_pass)
+__global__ void __launch_bounds__(kThreads)
+k_inv_quantize(const CT* coef, size_t coefStride, const uint64_t* sign, size_t signStride,
+               uint32_t n, double* vals, size_t valsStride, const CoderState* st, int wide_pass,
+               const uint64_t* sigNew, const uint64_t* sigOld, size_t maskStride,
+               const DecState* dst)
 {
   const uint32_t c = blockIdx.y;
   const CoderState& s = st[c];
   if (s.is_const || (int)s.wide != wide_pass)
     return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // four samples of one mask word
+  if (i0 >= n)
     return;
-  const double sg = ((sign[c * signStride + (i >> 6)] >> (i & 63)) & 1) ? 1.0 : -1.0;
-  vals[c * valsStride + i] = s.q * (double)coef[c * coefStride + i] * sg;
+  const CT* in = coef + c * coefStride + i0;
+  double* out = vals + c * valsStride + i0;
+  CT v[4];
+  const uint32_t cnt = min(4u, n - i0);
+  if (cnt == 4) {
+    if (sizeof(CT) == 4) {
+      const uint4 q = *reinterpret_cast<const uint4*>(in);
+      v[0] = (CT)q.x, v[1] = (CT)q.y, v[2] = (CT)q.z, v[3] = (CT)q.w;
+    }
+    else {
+      const ulonglong2 q0 = *reinterpret_cast<const ulonglong2*>(in);
+      const ulonglong2 q1 = *reinterpret_cast<const ulonglong2*>(in + 2);
+      v[0] = (CT)q0.x, v[1] = (CT)q0.y, v[2] = (CT)q1.x, v[3] = (CT)q1.y;
+    }
+  }
+  else
+    for (uint32_t k = 0; k < 4; k++)
+      v[k] = k < cnt ? in[k] : (CT)1;
+  const uint32_t w = i0 >> 6, sh = i0 & 63;
+  if (sigNew != nullptr && (v[0] == 0 || v[1] == 0 || v[2] == 0 || v[3] == 0)) {
+    const uint32_t mn = (uint32_t)(sigNew[c * maskStride + w] >> sh) & 15u;
+    const uint32_t mo = (uint32_t)(sigOld[c * maskStride + w] >> sh) & 15u;
+    if (mn | mo) {
+      const int pl = dst[c].lastPlane;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (v[k] == 0 && ((mn | mo) >> k) & 1u) {
+          const CT thr = (CT)1 << (pl + (((mn >> k) & 1u) ? 0 : 1));
+          v[k] = thr + thr - thr / 2 - 1;
+        }
+    }
+  }
+  const uint32_t sg = (uint32_t)(sign[c * signStride + w] >> sh);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    r[k] = s.q * (double)v[k] * (((sg >> k) & 1u) ? 1.0 : -1.0);
+  if (cnt == 4) {
+    *reinterpret_cast<double2*>(out) = make_double2(r[0], r[1]);
+    *reinterpret_cast<double2*>(out + 2) = make_double2(r[2], r[3]);
+  }
+  else
+    for (uint32_t k = 0; k < cnt; k++)
+      out[k] = r[k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -529,7 +594,7 @@ template int launch_scatter<double>(hipStream_t, double*, VolDesc, const ChunkGe
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
                     uint32_t n, CoderState* st)
 {
-  LAUNCH_K(k_maxabs, dim3((n + kThreads * 8 - 1) / (kThreads * 8), nchunks),
+  LAUNCH_K(k_maxabs, dim3((n + kThreads * kMaxPer - 1) / (kThreads * kMaxPer), nchunks),
                      dim3(kThreads), 0, stream, vals, valsStride, n, st);
   LAUNCH_K(k_make_q_rate, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks,
                      0);
@@ -562,17 +627,19 @@ int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t va
 
 int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t coefStride,
                         const uint64_t* sign, size_t signStride, uint32_t nchunks, uint32_t n,
-                        double* vals, size_t valsStride, const CoderState* st)
+                        double* vals, size_t valsStride, const CoderState* st,
+                        const uint64_t* sigNew, const uint64_t* sigOld, size_t maskStride,
+                        const DecState* dst)
 {
-  dim3 grid((n + kThreads - 1) / kThreads, nchunks);
+  dim3 grid((n + kThreads * 4 - 1) / (kThreads * 4), nchunks);
   if (wide)
     LAUNCH_K(k_inv_quantize<uint64_t>, grid, dim3(kThreads), 0, stream,
                        (const uint64_t*)coef, coefStride, sign, signStride, n, vals, valsStride,
-                       st, 1);
+                       st, 1, sigNew, sigOld, maskStride, dst);
   else
     LAUNCH_K(k_inv_quantize<uint32_t>, grid, dim3(kThreads), 0, stream,
                        (const uint32_t*)coef, coefStride, sign, signStride, n, vals, valsStride,
-                       st, 0);
+                       st, 0, sigNew, sigOld, maskStride, dst);
   HIP_CHECK(hipGetLastError());
   return 0;
 }
