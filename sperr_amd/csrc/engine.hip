@@ -629,6 +629,8 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(e.opos, uint64_t, nn * B);
   TAKE(e.bucket, uint32_t, nn * B);
   TAKE(e.koff, uint32_t, nn * B);
+  TAKE(e.chain, uint64_t, nn * B);
+  TAKE(e.leafDesc, uint16_t, nn * B);
   e.lisStride = P.lisEntries;
   TAKE(e.lis[0], uint64_t, P.lisEntries * B);
   TAKE(e.lis[1], uint64_t, P.lisEntries * B);

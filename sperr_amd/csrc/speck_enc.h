@@ -29,6 +29,12 @@ struct EncBuffers {
   uint64_t* opos;
   uint32_t* bucket;            // flat ids of the splitting sets, grouped by plane
   uint32_t* koff;              // start of a set's own split inside its parent's split
+  // chain[node] (sets above the deepest depth): the set that starts this set's chain of nested
+  // splits (the list entry whose position is known) in the low half, the bits between that
+  // entry's split and this set's own in the high half
+  uint64_t* chain;
+  // leaf sets of oct grids: children with msb == the set's msb | their sign bits << 8
+  uint16_t* leafDesc;
   size_t nodeStride;
   // LIS, double buffered; level l occupies [levelOff[l], levelOff[l+1])
   uint64_t* lis[2];

@@ -161,6 +161,18 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
     M[id] = (int8_t)m;
     E[id] = m >= 0 ? bits : 0u;
     if (k.deepest) {
+      // what k_split_emit needs of the eight pixels: which ones reach the set's msb, and their signs
+      const uint64_t* sign = b.sign + c * b.signStride;
+      uint32_t desc = 0;
+#pragma unroll
+      for (int q2 = 0; q2 < 4; q2++) {
+        const uint32_t ridx = oct_kid(k, 2 * q2);   // even: both pixels sit in one sign word
+        const uint32_t sg = (uint32_t)(sign[ridx >> 6] >> (ridx & 63)) & 3u;
+        desc |= (uint32_t)(k.m[2 * q2] == m) << (2 * q2);
+        desc |= (uint32_t)(k.m[2 * q2 + 1] == m) << (2 * q2 + 1);
+        desc |= sg << (8 + 2 * q2);
+      }
+      b.leafDesc[c * b.nodeStride + id] = (uint16_t)desc;
       const char2 v = {(char)m, (char)m};
 #pragma unroll
       for (int q2 = 0; q2 < 4; q2++)
@@ -206,6 +218,40 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
       koff[kid_flat(t, k, j)] = before + (coded ? 1u : 0u);
     }
   }
+}
+
+// Top-down over the depths (shallowest first): where each set's split sits relative to the list
+// entry that starts its chain of nested splits.  A set whose parent splits on the same plane
+// (M equal) is coded inside the parent's split; otherwise it is a list entry itself.  The sets of
+// a root's deepest depth are not stored: k_split_emit takes the one step from their parent.
+__global__ void __launch_bounds__(kNodeBlock)
+k_chain(EncBuffers b, const uint32_t* depthBlocks)
+{
+  const uint32_t c = blockIdx.y;
+  if (!b.st[c].active)
+    return;
+  const Tree& t = b.tree;
+  const uint32_t id = depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x;
+  Node nd;
+  if (!node_from_flat(t, id, nd))
+    return;
+  const Grid& g = t.grids[nd.grid];
+  if (g.depth + 1 == t.roots[g.root].Dmax && g.depth != 0)
+    return;
+  const int8_t* M = b.M + c * b.nodeStride;
+  uint64_t* chain = b.chain + c * b.nodeStride;
+  const int m = M[id];
+  if (m < 0)
+    return;
+  uint64_t v = id;
+  if (g.depth != 0) {
+    const uint32_t pid = flat_id(t, node_parent(t, nd));
+    if (M[pid] == m) {
+      const uint64_t pc = chain[pid];
+      v = (pc & 0xffffffffull) | ((uint64_t)((uint32_t)(pc >> 32) + b.koff[c * b.nodeStride + id]) << 32);
+    }
+  }
+  chain[id] = v;
 }
 
 __global__ void k_enc_planes_setup(EncBuffers b)
@@ -621,21 +667,28 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   const uint32_t* E = b.E + c * b.nodeStride;
   const int8_t* msb = b.msb + c * b.pixStride;
 
-  // walk up to the list entry that started this chain of splits
+  // the list entry that started this chain of splits, and the bits between its split and ours
+  // (k_chain; one step from the parent for the sets it does not store)
   const uint32_t* koff = b.koff + c * b.nodeStride;
-  uint64_t off = 0;
-  Node cur = nd;
-  uint32_t curid = id;
-  while (!node_is_root(t, cur)) {
-    const Node par = node_parent(t, cur);
-    const uint32_t pid = flat_id(t, par);
-    if (M[pid] != p)
-      break;
-    off += koff[curid];
-    cur = par;
-    curid = pid;
+  const uint64_t* chain = b.chain + c * b.nodeStride;
+  const Grid& g0 = t.grids[nd.grid];
+  uint32_t topid = id, off = 0;
+  if (g0.depth != 0) {
+    if (g0.depth + 1 != t.roots[g0.root].Dmax) {
+      const uint64_t v = chain[id];
+      topid = (uint32_t)v;
+      off = (uint32_t)(v >> 32);
+    }
+    else {
+      const uint32_t pid = flat_id(t, node_parent(t, nd));
+      if (M[pid] == p) {
+        const uint64_t v = chain[pid];
+        topid = (uint32_t)v;
+        off = (uint32_t)(v >> 32) + koff[id];
+      }
+    }
   }
-  uint64_t pos = b.opos[c * b.nodeStride + curid] + 1 + off;
+  uint64_t pos = b.opos[c * b.nodeStride + topid] + 1 + off;
 
   const uint64_t* sign = b.sign + c * b.signStride;
   uint64_t* stream = b.stream + c * b.streamStride;
@@ -646,6 +699,25 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   uint64_t accpos = pos;
   const Grid& g = t.grids[nd.grid];
   if (g.kind & kGridOct) {  // same loop as below with the 8 children in registers
+    if (g.depth + 1 == t.roots[g.root].Dmax) {   // a leaf set: everything is in its descriptor
+      const uint32_t desc = b.leafDesc[c * b.nodeStride + id];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool coded = found || j != 7;
+        const uint32_t sig = coded ? (desc >> j) & 1u : 1u;
+        if (coded) {
+          acc |= (uint64_t)sig << nacc;
+          nacc++;
+        }
+        if (sig) {
+          found = true;
+          acc |= (uint64_t)((desc >> (8 + j)) & 1u) << nacc;
+          nacc++;
+        }
+      }
+      put_bits(stream, accpos, acc, nacc, s.budget);
+      return;
+    }
     OctKids k;
     oct_load(t, g, t.roots[g.root], nd, M, E, msb, k);
     const uint32_t kidlev = node_level(t, nd) + 3;
@@ -947,6 +1019,12 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
     if (nb)
       LAUNCH_K(k_pyramid, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
                          plan.d_depthBlocks + plan.depthBlockOff[d]);
+  }
+  for (int d = 0; d < (int)b.tree.maxDepth; d++) {
+    const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
+    if (nb)
+      LAUNCH_K(k_chain, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
+               plan.d_depthBlocks + plan.depthBlockOff[d]);
   }
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
   {
