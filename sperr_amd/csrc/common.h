@@ -35,6 +35,20 @@ constexpr int kPixPer = 16;        // consecutive samples per thread in the pixe
 constexpr int kPixTile = 4096;     // samples per pixel-pass tile (256 threads x kPixPer)
 constexpr int kListTile = 1024;    // list entries per list-pass tile (256 threads x 4)
 constexpr int kThreads = 256;
+// Per-plane kernels are launched with at most this many workgroups over all chunks and stride
+// over their work: most planes hold little work, and a grid sized for the worst case costs more
+// in empty workgroups than the plane's real work.
+constexpr uint32_t kGridCap = 4096;        // kernels that do little per item
+constexpr uint32_t kGridCapWide = 16384;   // latency-bound kernels that want every wave slot
+inline uint32_t capped_blocks(uint32_t nblocks, uint32_t nchunks, uint32_t total = kGridCap)
+{
+  uint32_t cap = total / (nchunks ? nchunks : 1u);
+  if (cap < 1u)
+    cap = 1u;
+  if (nblocks < 1u)
+    nblocks = 1u;
+  return nblocks < cap ? nblocks : cap;
+}
 
 // ---- geometry of one batch: `nchunks` chunks of identical dims cut from one volume ------------
 struct ChunkGeom {         // one entry per chunk of the batch (device array)

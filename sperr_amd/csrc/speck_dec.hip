@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
   DEC_ACTIVE_OR_RETURN(s, p);
   __shared__ uint32_t sm[kThreads / 64 + 1];
   const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
+  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
+  const uint32_t wi = tile * kDecTileWords + threadIdx.x;
   uint32_t v = 0;
   if (wi < nw) {
     uint64_t* so = b.sigOld + c * b.maskPixStride + wi;
@@ -215,8 +216,9 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
   block_exclusive_scan<uint32_t>(v & 0xffffu, sm, &total_l);
   block_exclusive_scan<uint32_t>(v >> 16, sm, &total_r);
   if (threadIdx.x == 0) {
-    b.tileLip[c * b.tileStride + blockIdx.x] = total_l;
-    b.tileRef[c * b.tileStride + blockIdx.x] = total_r;
+    b.tileLip[c * b.tileStride + tile] = total_l;
+    b.tileRef[c * b.tileStride + tile] = total_r;
+  }
   }
 }
 
@@ -260,46 +262,50 @@ __global__ void __launch_bounds__(kThreads) k_lip_deposit(DecBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
-  if (b.tileLip[c * b.tileStride + blockIdx.x] == 0)
+  if (s.nLip == 0)
     return;
   __shared__ uint32_t sm[kThreads / 64 + 1];
   const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint32_t wi = blockIdx.x * kDecTileWords + threadIdx.x;
-  uint64_t lip = 0;
-  if (wi < nw)
-    lip = b.bornM[c * b.maskPixStride + wi] & ~b.sigOld[c * b.maskPixStride + wi];
-  uint32_t total;
-  const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(lip), sm, &total) +
-                      b.tileLipOff[c * b.tileStride + blockIdx.x];
-  const uint32_t n = (uint32_t)__popcll(lip);
-  if (n == 0)
-    return;
   const uint64_t* rs = b.lipSig + c * b.lipResStride;
   const uint64_t* rn = b.lipNeg + c * b.lipResStride;
-  const uint32_t sh = ex & 63u;
-  uint64_t vs = rs[ex >> 6] >> sh, vn = rn[ex >> 6] >> sh;
-  if (sh && sh + n > 64) {
-    vs |= rs[(ex >> 6) + 1] << (64 - sh);
-    vn |= rn[(ex >> 6) + 1] << (64 - sh);
+  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
+    if (b.tileLip[c * b.tileStride + tile] == 0)
+      continue;
+    const uint32_t wi = tile * kDecTileWords + threadIdx.x;
+    uint64_t lip = 0;
+    if (wi < nw)
+      lip = b.bornM[c * b.maskPixStride + wi] & ~b.sigOld[c * b.maskPixStride + wi];
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(lip), sm, &total) +
+                        b.tileLipOff[c * b.tileStride + tile];
+    const uint32_t n = (uint32_t)__popcll(lip);
+    if (n == 0)
+      continue;
+    const uint32_t sh = ex & 63u;
+    uint64_t vs = rs[ex >> 6] >> sh, vn = rn[ex >> 6] >> sh;
+    if (sh && sh + n > 64) {
+      vs |= rs[(ex >> 6) + 1] << (64 - sh);
+      vn |= rn[(ex >> 6) + 1] << (64 - sh);
+    }
+    if (n < 64) {
+      vs &= (1ull << n) - 1;
+      vn &= (1ull << n) - 1;
+    }
+    if (vs == 0)
+      continue;
+    uint64_t outS = 0, outN = 0;
+    while (vs) {   // candidate i of the word is the i-th set bit of `lip`
+      const int k = __ffsll((long long)lip) - 1;
+      lip &= lip - 1;
+      outS |= (vs & 1ull) << k;
+      outN |= (vn & 1ull) << k;
+      vs >>= 1;
+      vn >>= 1;
+    }
+    b.sigNew[c * b.maskPixStride + wi] |= outS;
+    if (outN)
+      b.sign[c * b.signStride + wi] &= ~outN;
   }
-  if (n < 64) {
-    vs &= (1ull << n) - 1;
-    vn &= (1ull << n) - 1;
-  }
-  if (vs == 0)
-    return;
-  uint64_t outS = 0, outN = 0;
-  while (vs) {   // candidate i of the word is the i-th set bit of `lip`
-    const int k = __ffsll((long long)lip) - 1;
-    lip &= lip - 1;
-    outS |= (vs & 1ull) << k;
-    outN |= (vn & 1ull) << k;
-    vs >>= 1;
-    vn >>= 1;
-  }
-  b.sigNew[c * b.maskPixStride + wi] |= outS;
-  if (outN)
-    b.sign[c * b.signStride + wi] &= ~outN;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,37 +331,39 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
+  if (s.nLip == 0)
+    return;
   const uint64_t nbits = 2ull * s.nLip + 1;
   const uint64_t nwords = (nbits + 63) / 64;
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s.nLip == 0 || w >= nwords)
-    return;
   const uint64_t* words = b.stream + c * b.streamStride;
-  // parity of the run of 1s that ends right before this word
-  uint32_t parity = 0;
-  for (uint64_t back = w; back > 0;) {
-    back--;
-    const uint64_t v = lip_word(words, s, back, nbits);
-    if (v == ~0ull)
-      continue;  // 64 more ones: parity unchanged, keep looking
-    parity = (uint32_t)__clzll((long long)~v) & 1u;  // leading ones of the previous word
-    break;
-  }
-  const uint64_t x = lip_word(words, s, w, nbits);
-  uint64_t starts = 0;
-  uint32_t ones = parity;  // only the parity matters
-  for (int k = 0; k < 64; k++) {
-    if ((ones & 1u) == 0)
-      starts |= 1ull << k;
-    ones = ((x >> k) & 1ull) ? ones + 1 : 0;
-  }
-  if (w == nwords - 1 && (nbits & 63))
-    starts &= (1ull << (nbits & 63)) - 1;
-  b.tokMask[c * b.tokStride + w] = starts;
-  b.tokCnt[c * b.tokStride + w] = (uint32_t)__popcll(starts);
-  if (w <= (uint64_t)(s.nLip - 1) / 64) {   // results by token rank, filled by k_lip_apply
-    b.lipSig[c * b.lipResStride + w] = 0;
-    b.lipNeg[c * b.lipResStride + w] = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    // parity of the run of 1s that ends right before this word
+    uint32_t parity = 0;
+    for (uint64_t back = w; back > 0;) {
+      back--;
+      const uint64_t v = lip_word(words, s, back, nbits);
+      if (v == ~0ull)
+        continue;  // 64 more ones: parity unchanged, keep looking
+      parity = (uint32_t)__clzll((long long)~v) & 1u;  // leading ones of the previous word
+      break;
+    }
+    const uint64_t x = lip_word(words, s, w, nbits);
+    uint64_t starts = 0;
+    uint32_t ones = parity;  // only the parity matters
+    for (int k = 0; k < 64; k++) {
+      if ((ones & 1u) == 0)
+        starts |= 1ull << k;
+      ones = ((x >> k) & 1ull) ? ones + 1 : 0;
+    }
+    if (w == nwords - 1 && (nbits & 63))
+      starts &= (1ull << (nbits & 63)) - 1;
+    b.tokMask[c * b.tokStride + w] = starts;
+    b.tokCnt[c * b.tokStride + w] = (uint32_t)__popcll(starts);
+    if (w <= (uint64_t)(s.nLip - 1) / 64) {   // results by token rank, filled by k_lip_apply
+      b.lipSig[c * b.lipResStride + w] = 0;
+      b.lipNeg[c * b.lipResStride + w] = 0;
+    }
   }
 }
 
@@ -401,46 +409,48 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
+  if (s.nLip == 0)
+    return;
   const uint64_t nbits = 2ull * s.nLip + 1;
-  const uint64_t nwords = (nbits + 63) / 64;
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s.nLip == 0 || w >= nwords)
-    return;
+  const uint64_t nwords = min((nbits + 63) / 64, s.lipBits / 64 + 1);   // the scan's real length
   const uint64_t* words = b.stream + c * b.streamStride;
-  const uint64_t x = lip_word(words, s, w, nbits);
-  uint64_t sig = b.tokMask[c * b.tokStride + w];
-  uint32_t j = b.tokOff[c * b.tokStride + w];
-  if (j >= s.nLip)
-    return;
-  const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
-  // the tokens that start in this word have consecutive ranks j, j + 1, ...: their results go to
-  // bits j, j + 1, ... of lipSig (found significant) and lipNeg (and negative).  The magnitude is
-  // not written here: k_ref_apply / k_dec_finish give a newly significant coefficient its value
-  // 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it.
-  uint64_t runS = 0, runN = 0;
-  uint32_t i = 0;
-  while (sig && j + i < s.nLip) {
-    const int k = __ffsll((long long)sig) - 1;
-    sig &= sig - 1;
-    if ((x >> k) & 1ull) {
-      const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
-      runS |= 1ull << i;
-      runN |= (sb ^ 1ull) << i;
-    }
-    i++;
-  }
-  if (runS == 0)
-    return;
   unsigned long long* rs = reinterpret_cast<unsigned long long*>(b.lipSig + c * b.lipResStride);
   unsigned long long* rn = reinterpret_cast<unsigned long long*>(b.lipNeg + c * b.lipResStride);
-  const uint32_t sh = j & 63u;
-  atomicOr(rs + (j >> 6), runS << sh);
-  if (sh && (runS >> (64 - sh)))
-    atomicOr(rs + (j >> 6) + 1, runS >> (64 - sh));
-  if (runN) {
-    atomicOr(rn + (j >> 6), runN << sh);
-    if (sh && (runN >> (64 - sh)))
-      atomicOr(rn + (j >> 6) + 1, runN >> (64 - sh));
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+       w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t x = lip_word(words, s, w, nbits);
+    uint64_t sig = b.tokMask[c * b.tokStride + w];
+    const uint32_t j = b.tokOff[c * b.tokStride + w];
+    if (j >= s.nLip)
+      continue;
+    const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
+    // the tokens that start in this word have consecutive ranks j, j + 1, ...: their results go
+    // to bits j, j + 1, ... of lipSig (found significant) and lipNeg (and negative).  The
+    // magnitude is not written here: k_ref_apply / the inverse quantiser give a newly significant
+    // coefficient its value 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it.
+    uint64_t runS = 0, runN = 0;
+    uint32_t i = 0;
+    while (sig && j + i < s.nLip) {
+      const int k = __ffsll((long long)sig) - 1;
+      sig &= sig - 1;
+      if ((x >> k) & 1ull) {
+        const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
+        runS |= 1ull << i;
+        runN |= (sb ^ 1ull) << i;
+      }
+      i++;
+    }
+    if (runS == 0)
+      continue;
+    const uint32_t sh = j & 63u;
+    atomicOr(rs + (j >> 6), runS << sh);
+    if (sh && (runS >> (64 - sh)))
+      atomicOr(rs + (j >> 6) + 1, runS >> (64 - sh));
+    if (runN) {
+      atomicOr(rn + (j >> 6), runN << sh);
+      if (sh && (runN >> (64 - sh)))
+        atomicOr(rn + (j >> 6) + 1, runN >> (64 - sh));
+    }
   }
 }
 
@@ -2345,6 +2355,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   LAUNCH_K(k_dec_load_words, dim3(wordBlocks, nc), dim3(kThreads), 0, stream, b,
                      container);
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
+  const uint32_t tokGrid = capped_blocks(tokBlocks, nc), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide);
   const size_t tabSmem = b.tabSmemBytes;
   if (plan.tables) {
     static bool attr_set = false;
@@ -2370,43 +2381,39 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 768 / nc));
   for (int p = maxPlanes - 1; p >= 0; p--) {
-    LAUNCH_K(k_dec_count, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_lip_words, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_lip_words, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     if (wide_pass) {
-      LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
-                         p);
-      LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
         if (plan.l0)
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
-        LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
+        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else
         LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
-                         b, p);
+      LAUNCH_K(k_ref_apply<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     }
     else {
-      LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokBlocks, nc), dim3(kThreads), 0, stream, b,
-                         p);
-      LAUNCH_K(k_lip_deposit, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
       if (plan.tables) {
         if (plan.l0)
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
-        LAUNCH_K(k_leaf_apply, dim3(1024, nc), dim3(kThreads), 0, stream, b, p);
+        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
-                         b, p);
+      LAUNCH_K(k_ref_apply<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
   }

@@ -466,17 +466,26 @@ __global__ void __launch_bounds__(kThreads) k_list_count(EncBuffers b, int p)
   const EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
   __shared__ uint64_t sm[kThreads / 64 + 1];
-  ListItem it[4];
-  load_list4(b, c, s, blockIdx.x, p, it);
-  uint64_t v = 0;  // low 40 bits: bits, high 24 bits: survivors
-  for (int k = 0; k < 4; k++)
-    if (it[k].bits)
-      v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
-  uint64_t total;
-  block_exclusive_scan<uint64_t>(v, sm, &total);
-  if (threadIdx.x == 0) {
-    b.tileBits[c * b.tileStride + blockIdx.x] = total & ((1ull << 40) - 1);
-    b.tileSurv[c * b.tileStride + blockIdx.x] = (uint32_t)(total >> 40);
+  for (uint32_t tile = blockIdx.x; tile < b.nListTiles; tile += gridDim.x) {
+    if (b.tileStart[tile] >= s.listLen[s.cur][b.tileLevel[tile]]) {   // past the end of its list
+      if (threadIdx.x == 0) {
+        b.tileBits[c * b.tileStride + tile] = 0;
+        b.tileSurv[c * b.tileStride + tile] = 0;
+      }
+      continue;
+    }
+    ListItem it[4];
+    load_list4(b, c, s, tile, p, it);
+    uint64_t v = 0;  // low 40 bits: bits, high 24 bits: survivors
+    for (int k = 0; k < 4; k++)
+      if (it[k].bits)
+        v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
+    uint64_t total;
+    block_exclusive_scan<uint64_t>(v, sm, &total);
+    if (threadIdx.x == 0) {
+      b.tileBits[c * b.tileStride + tile] = total & ((1ull << 40) - 1);
+      b.tileSurv[c * b.tileStride + tile] = (uint32_t)(total >> 40);
+    }
   }
 }
 
@@ -533,35 +542,36 @@ __global__ void __launch_bounds__(kThreads) k_list_apply(EncBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
-  const uint32_t tile = blockIdx.x;
-  const uint32_t l = b.tileLevel[tile];
-  if (b.tileStart[tile] >= s.listLen[s.cur][l])
-    return;
   __shared__ uint64_t sm[kThreads / 64 + 1];
-  ListItem it[4];
-  load_list4(b, c, s, tile, p, it);
-  uint64_t v = 0;
-  for (int k = 0; k < 4; k++)
-    if (it[k].bits)
-      v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
-  uint64_t total;
-  const uint64_t ex = block_exclusive_scan<uint64_t>(v, sm, &total);
-  uint64_t bitpos = s.rec[p].baseLIS + b.tileBitsOff[c * b.tileStride + tile] +
-                    (ex & ((1ull << 40) - 1));
-  uint32_t rank = b.tileSurvOff[c * b.tileStride + tile] + (uint32_t)(ex >> 40);
-  uint64_t* next = b.lis[s.cur ^ 1u] + c * b.lisStride + b.levelOff[l];
-  uint64_t* opos = b.opos + c * b.nodeStride;
-  uint64_t* stream = b.stream + c * b.streamStride;
-  for (int k = 0; k < 4; k++) {
-    if (!it[k].bits)
+  for (uint32_t tile = blockIdx.x; tile < b.nListTiles; tile += gridDim.x) {
+    const uint32_t l = b.tileLevel[tile];
+    if (b.tileStart[tile] >= s.listLen[s.cur][l])
       continue;
-    if (it[k].sig) {
-      opos[it[k].id] = bitpos;
-      put_bits(stream, bitpos, 1, 1, s.budget);
+    ListItem it[4];
+    load_list4(b, c, s, tile, p, it);
+    uint64_t v = 0;
+    for (int k = 0; k < 4; k++)
+      if (it[k].bits)
+        v += (uint64_t)it[k].bits + (it[k].sig ? 0ull : (1ull << 40));
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan<uint64_t>(v, sm, &total);
+    uint64_t bitpos = s.rec[p].baseLIS + b.tileBitsOff[c * b.tileStride + tile] +
+                      (ex & ((1ull << 40) - 1));
+    uint32_t rank = b.tileSurvOff[c * b.tileStride + tile] + (uint32_t)(ex >> 40);
+    uint64_t* next = b.lis[s.cur ^ 1u] + c * b.lisStride + b.levelOff[l];
+    uint64_t* opos = b.opos + c * b.nodeStride;
+    uint64_t* stream = b.stream + c * b.streamStride;
+    for (int k = 0; k < 4; k++) {
+      if (!it[k].bits)
+        continue;
+      if (it[k].sig) {
+        opos[it[k].id] = bitpos;
+        put_bits(stream, bitpos, 1, 1, s.budget);
+      }
+      else
+        next[rank++] = it[k].packed;
+      bitpos += it[k].bits;
     }
-    else
-      next[rank++] = it[k].packed;
-    bitpos += it[k].bits;
   }
 }
 
@@ -848,19 +858,19 @@ __global__ void __launch_bounds__(kThreads) k_born_place(EncBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= s.bornCount)
-    return;
-  const uint64_t pl = b.bornPosLev[c * b.bornStride + k];
-  const uint32_t lev = (uint32_t)(pl >> 48);
-  const uint64_t rel = pl & ((1ull << 48) - 1);
-  const uint32_t slot = b.levelSlot[lev];
-  const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6);
-  const uint32_t rank = b.maskPrefix[mo] +
-                        (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
   const uint32_t nx = s.cur ^ 1u;
-  b.lis[nx][c * b.lisStride + b.levelOff[lev] + s.listLen[nx][lev] + rank] =
-      b.bornPacked[c * b.bornStride + k];
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < s.bornCount;
+       k += gridDim.x * blockDim.x) {
+    const uint64_t pl = b.bornPosLev[c * b.bornStride + k];
+    const uint32_t lev = (uint32_t)(pl >> 48);
+    const uint64_t rel = pl & ((1ull << 48) - 1);
+    const uint32_t slot = b.levelSlot[lev];
+    const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6);
+    const uint32_t rank = b.maskPrefix[mo] +
+                          (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    b.lis[nx][c * b.lisStride + b.levelOff[lev] + s.listLen[nx][lev] + rank] =
+        b.bornPacked[c * b.bornStride + k];
+  }
 }
 
 // clear the part of the birth masks this plane used
@@ -871,11 +881,9 @@ __global__ void __launch_bounds__(kThreads) k_mask_clear(EncBuffers b, int p)
   ACTIVE_OR_RETURN(s, p);
   const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
   const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= nwords)
-    return;
-  for (uint32_t slot = 0; slot < b.nSlots; slot++)
-    b.mask[c * b.maskStride + (size_t)slot * b.maskWords + w] = 0;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x)
+    for (uint32_t slot = 0; slot < b.nSlots; slot++)
+      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + w] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1040,14 +1048,14 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
   const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_plane_begin, perChunk, dim3(64), 0, stream, b, p);
-    LAUNCH_K(k_list_count, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_list_apply, dim3(b.nListTiles, nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_split_emit, dim3(kSplitBlocks, nc), dim3(kNodeBlock), 0, stream, b, p);
+    LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_split_emit, dim3(capped_blocks(kSplitBlocks, nc), nc), dim3(kNodeBlock), 0, stream, b, p);
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_born_place, dim3(bornBlocks, nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_mask_clear, dim3(maskBlocks, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_mask_clear, dim3(capped_blocks(maskBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
     }
     LAUNCH_K(k_plane_end, perChunk, dim3(64), 0, stream, b, p);
   }
