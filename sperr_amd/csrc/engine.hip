@@ -1146,6 +1146,10 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->l1Level >= 0, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
+        // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_tables
+        static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
+        if (!gpuWide)
+          ph.l0 = ph.l1 = false;
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));

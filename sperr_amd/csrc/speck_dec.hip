@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
             break;
           }
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) {   // cannot happen; never leave a wave spinning for ever
+          if (++spins > (1u << 19)) {   // cannot happen; never leave a wave spinning for ever
             s.error = 1;
             __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;
@@ -1154,7 +1154,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
             break;
           }
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 24)) {   // cannot happen; never leave a wave spinning for ever
+          if (++spins > (1u << 19)) {   // cannot happen; never leave a wave spinning for ever
             s.error = 1;
             __hip_atomic_store(&s.l1PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;

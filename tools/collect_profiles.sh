@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): kernel-trace statistics and HBM counters of the bench workload.
+#   bash tools/collect_profiles.sh <tag>         -> gpurun_out/prof_<tag>/{trace,fetch,write}/...
+# The counters are collected in their own passes (never together with a trace domain); every
+# profiler run is bounded by `timeout` (a wedged profiler must not eat the GPU budget).
+set -u
+tag=${1:-r1}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+args="bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline"
+timeout 300 python3 bench.py --size 1024 --steps 3 --warmup 1 --profile-out $out/engine_events.csv > $out/bench.json 2> $out/bench.err
+echo "bench rc=$?"
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $args > $out/trace.log 2>&1
+echo "trace rc=$?"
+timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o run -- python3 $args > $out/fetch.log 2>&1
+echo "fetch rc=$?"
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 $args > $out/write.log 2>&1
+echo "write rc=$?"
+tail -1 $out/bench.json | cut -c1-400
