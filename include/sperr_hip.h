@@ -8,7 +8,8 @@
  *    /root/reference/src/SPERR_C_API.cpp:135-258): host buffers in, malloc'd host buffers out.
  *    The per-chunk pipeline (conditioner, CDF 9/7 DWT, quantiser, SPECK3D coder, bit packing)
  *    runs on the GPU; `nthreads` is accepted and ignored (the reference's OpenMP team size,
- *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate) is implemented; modes 2 and 3 return -1.
+ *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate) and mode 2 (fixed PSNR) are implemented;
+ *    mode 3 (point-wise error) returns -1.
  *
  * 2. Device-resident entry points (sperrhip_*): the volume and the container stay in HBM, which
  *    is what bench.py times and what an application that already holds its field on the GPU

@@ -8,9 +8,9 @@
 //     /root/reference/include/sperr_helper.h:35,54-64 (dims_type, vec8_type, vecd_type, RTNType)
 //
 // compiles unchanged when it includes this header instead and links -lsperr_hip.  The chunk
-// pipeline itself runs on the GPU; set_num_threads() is accepted and ignored.  Only the
-// fixed-rate mode (set_bitrate) is implemented on the GPU path; set_psnr / set_tolerance make
-// compress() return RTNType::Error.
+// pipeline itself runs on the GPU; set_num_threads() is accepted and ignored.  The fixed-rate
+// (set_bitrate) and fixed-PSNR (set_psnr) modes are implemented on the GPU path; set_tolerance
+// makes compress() return RTNType::Error.
 #ifndef SPERR_HIP_HPP
 #define SPERR_HIP_HPP
 

@@ -985,7 +985,77 @@ int orc_chunk_compress_rate(double* vals, const size_t dims[3], double bpp, uint
   return rtn;
 }
 
-/* src/SPECK_FLT.cpp:27-109,543-606 (no outlier stream in rate mode) */
+/* src/SPECK_FLT.cpp:237-266 : strides of 4096 values are summed one after the other, each
+ * sequentially; the canonical build contracts `init + diff * diff` into one fma */
+double orc_estimate_mse_midtread(const double* vals, size_t n, double q)
+{
+  const size_t stride = 4096, nstrides = n / stride;
+  const double rcp_q = 1.0 / q;
+  double total = 0.0;
+  for (size_t s = 0; s <= nstrides; s++) {
+    const size_t beg = s * stride, end = s < nstrides ? beg + stride : n;
+    double acc = 0.0;
+    for (size_t i = beg; i < end; i++) {
+      const double diff = fma(-q, rint(vals[i] * rcp_q), vals[i]);
+      acc = fma(diff, diff, acc);
+    }
+    total += acc;
+  }
+  return total / (double)n;
+}
+
+/* src/SPECK_FLT.cpp:268-279 : q for a target PSNR, given the range of the conditioned data */
+double orc_estimate_q_psnr(const double* coeffs, size_t n, double range, double psnr)
+{
+  const double t_mse = (range * range) * pow(10.0, -psnr / 10.0);
+  double q = 2.0 * sqrt(t_mse * 3.0);
+  while (orc_estimate_mse_midtread(coeffs, n, q) > t_mse)
+    q /= exp2(0.25);
+  return q;
+}
+
+/* src/SPECK_FLT.cpp:401-541, CompMode::PSNR: q from the target, every bit plane coded */
+int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uint8_t** stream,
+                            size_t* stream_len)
+{
+  const size_t n = dims[0] * dims[1] * dims[2];
+  uint8_t condi[17];
+  if (orc_condition(vals, n, condi)) {
+    *stream = (uint8_t*)malloc(17);
+    memcpy(*stream, condi, 17);
+    *stream_len = 17;
+    return 0;
+  }
+  double vmin = vals[0], vmax = vals[0]; /* SPECK_FLT.cpp:431-435 */
+  for (size_t i = 1; i < n; i++) {
+    if (vals[i] < vmin)
+      vmin = vals[i];
+    if (vals[i] > vmax)
+      vmax = vals[i];
+  }
+  orc_dwt3d(vals, dims);
+  const double q = orc_estimate_q_psnr(vals, n, vmax - vmin, psnr);
+  memcpy(condi + 9, &q, 8);
+  uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
+  int width;
+  int rtn = orc_quantize(vals, n, q, coef, sign, &width);
+  if (!rtn) {
+    uint8_t* speck_stream = NULL;
+    size_t speck_len = 0;
+    orc_speck3d_encode(coef, sign, dims, 0, &speck_stream, &speck_len);
+    *stream = (uint8_t*)malloc(17 + speck_len);
+    memcpy(*stream, condi, 17);
+    memcpy(*stream + 17, speck_stream, speck_len);
+    *stream_len = 17 + speck_len;
+    free(speck_stream);
+  }
+  free(coef);
+  free(sign);
+  return rtn;
+}
+
+/* src/SPECK_FLT.cpp:27-109,543-606 (no outlier stream in rate and PSNR modes) */
 int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3], double* out)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
@@ -1031,8 +1101,8 @@ int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t 
     return 1;
   if (quality <= 0.0)
     return 2;
-  if (mode != 1)
-    return mode == 2 || mode == 3 ? -1 : 2; /* the oracle restates the fixed-rate path only */
+  if (mode != 1 && mode != 2)
+    return mode == 3 ? -1 : 2; /* the oracle restates the fixed-rate and fixed-PSNR paths */
   const size_t vol[3] = {dimx, dimy, dimz};
   size_t want[3] = {chunk_x, chunk_y, chunk_z}, cdim[3];
   for (int a = 0; a < 3; a++) { /* SPERR3D_OMP_C.cpp:23-30 */
@@ -1067,7 +1137,8 @@ int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t 
           for (size_t x = 0; x < cd[0]; x++)
             buf[k++] = ((const double*)src)[row + x];
       }
-    rtns[ci] = orc_chunk_compress_rate(buf, cd, quality, &streams[ci], &lens[ci]);
+    rtns[ci] = mode == 1 ? orc_chunk_compress_rate(buf, cd, quality, &streams[ci], &lens[ci])
+                         : orc_chunk_compress_psnr(buf, cd, quality, &streams[ci], &lens[ci]);
     free(buf);
   }
   int rtn = 0;

@@ -85,18 +85,19 @@ class SperrHip:
         return _vp(self.torch.cuda.current_stream().cuda_stream)
 
     # ---- device-resident API -------------------------------------------------------------
-    def max_compressed_size(self, shape_zyx, chunks_xyz, bpp):
+    def max_compressed_size(self, shape_zyx, chunks_xyz, quality, mode=1):
         dz, dy, dx = shape_zyx
-        return self.lib.sperrhip_max_compressed_size(dx, dy, dz, *chunks_xyz, 1, bpp)
+        return self.lib.sperrhip_max_compressed_size(dx, dy, dz, *chunks_xyz, mode, quality)
 
     def compress(self, vol, chunks_xyz, bpp, out=None, mode=1):
         """vol: cuda tensor float32/float64 shaped (z, y, x). Returns a cuda uint8 tensor view of
-        the container (a slice of `out` when given)."""
+        the container (a slice of `out` when given).  mode 1: `bpp` is the bit rate; mode 2: it is
+        the target PSNR in dB (the reference's modes, include/SPERR_C_API.h:95-99)."""
         torch = self.torch
         assert vol.is_cuda and vol.is_contiguous() and vol.dim() == 3
         assert vol.dtype in (torch.float32, torch.float64)
         dz, dy, dx = vol.shape
-        cap = self.max_compressed_size(vol.shape, chunks_xyz, bpp)
+        cap = self.max_compressed_size(vol.shape, chunks_xyz, bpp, mode)
         if out is None or out.numel() < cap:
             out = torch.empty(cap, dtype=torch.uint8, device=vol.device)
         n = _sz(0)

@@ -75,7 +75,11 @@ struct CoderState {
   uint32_t wide;                 // coefficients are uint64 (high-precision retry / >32 planes)
   uint32_t need_retry;           // fixed-rate stream too short at 32 planes (SPECK_FLT.cpp:530-538)
   int32_t nbp;                   // SPECK header: number of bit planes
-  uint32_t pad;
+  uint32_t mse_active;           // PSNR mode: this chunk's q is still being searched
+  // PSNR mode (src/SPECK_FLT.cpp:237-279,431-435): range of the input as order-preserving keys
+  // of max(v) and max(-v), and the quantisation error estimate of the current q
+  uint64_t vmaxKey, vnegmaxKey;
+  double mse;
   uint64_t total_bits;           // SPECK header: bits of the complete stream
   uint64_t stream_len;           // bytes of this chunk's stream (17 or 17 + 9 + payload)
   uint64_t stream_off;           // byte offset of the chunk stream inside the container

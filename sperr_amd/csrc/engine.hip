@@ -460,7 +460,9 @@ uint64_t rounded_budget(uint64_t raw)
 
 uint64_t max_payload_bits(const ShapePlan& P, uint64_t raw_budget)
 {
-  const uint64_t unlimited = 64ull * P.maxPhaseBits;  // every plane, every phase, worst case
+  // every plane of a uint64 coded in full: a sample gives at most one bit per plane plus its birth
+  // test and its sign, a set one test per plane
+  const uint64_t unlimited = (uint64_t)P.N * 66ull + (uint64_t)P.ht.nsets * 64ull + 64ull;
   const uint64_t b = rounded_budget(raw_budget);
   return std::min(b, unlimited);
 }
@@ -610,7 +612,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(o.gids, uint32_t, B);
   o.valsStride = Npad;
   TAKE(o.vals, double, Npad * B);
-  o.strideMeanStride = round_up(P.nstrides, 32);
+  o.strideMeanStride = round_up(std::max<size_t>(P.nstrides, P.N / 4096 + 2), 32);   // (also the PSNR-mode mse partials)
   TAKE(o.strideMean, double, o.strideMeanStride * B);
   e.coefStride = Npad;
   TAKE(o.coef32, uint32_t, Npad * B);
@@ -685,10 +687,77 @@ int reset_enc_pass(hipStream_t st, const EncBatchBufs& bb, uint32_t B)
   return 0;
 }
 
+// PSNR mode (src/SPECK_FLT.cpp:268-279,431-435): per chunk q = 2 sqrt(3 t), t = range^2 10^(-psnr/10),
+// divided by 2^(1/4) until the estimated quantisation error is at most t.  The libm calls run on
+// the host (the same libm the reference uses), the error estimate on the device with the
+// reference's summation order; chunks whose largest coefficient needs more than 32 bits are
+// flagged for the 64-bit pass (SPECK_FLT.cpp:324-337).
+int psnr_q_search(hipStream_t st, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb, double psnr)
+{
+  EncBuffers& e = bb.eb;
+  std::vector<CoderState> hc(nb);
+  HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<double> tmse(nb, 0.0);
+  bool any = false;
+  for (uint32_t i = 0; i < nb; i++) {
+    CoderState& c = hc[i];
+    c.mse_active = 0;
+    if (c.is_const)
+      continue;
+    const double vmax = order_key_value(c.vmaxKey), vmin = -order_key_value(c.vnegmaxKey);
+    const double range = (vmax - c.mean) - (vmin - c.mean);   // of the conditioned samples
+    tmse[i] = (range * range) * std::pow(10.0, -psnr / 10.0);
+    c.q = 2.0 * std::sqrt(tmse[i] * 3.0);
+    if (!(c.q > 0.0))
+      return -1;   // (the reference asserts q > 0)
+    c.mse_active = 1;
+    any = true;
+  }
+  const double step = std::exp2(0.25);
+  while (any) {
+    HIP_CHECK(hipMemcpyAsync(e.cst, hc.data(), nb * sizeof(CoderState), hipMemcpyHostToDevice, st));
+    if (launch_mse(st, bb.vals, bb.valsStride, nb, P.N, bb.strideMean, bb.strideMeanStride, e.cst))
+      return -1;
+    std::vector<CoderState> got(nb);
+    HIP_CHECK(hipMemcpyAsync(got.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    any = false;
+    for (uint32_t i = 0; i < nb; i++) {
+      if (!hc[i].mse_active)
+        continue;
+      if (got[i].mse > tmse[i]) {
+        hc[i].q /= step;   // four adjustments halve q
+        any = true;
+      }
+      else
+        hc[i].mse_active = 0;
+    }
+  }
+  for (uint32_t i = 0; i < nb; i++) {
+    CoderState& c = hc[i];
+    c.mse_active = 0;
+    c.wide = 0;
+    c.need_retry = 0;
+    if (c.is_const)
+      continue;
+    const double m = c.maxabs / c.q;
+    if (!(m < 9.3e18))
+      return -1;   // llrint would raise FE_INVALID (SPECK_FLT.cpp:325-327)
+    c.need_retry = std::llrint(m) > (long long)0xffffffffll ? 1u : 0u;
+  }
+  HIP_CHECK(hipMemcpyAsync(e.cst, hc.data(), nb * sizeof(CoderState), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));   // hc goes out of scope
+  return 0;
+}
+
 template <typename T>
-int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double bpp,
+int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mode, double quality,
                   uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st)
 {
+  // mode 1: fixed rate, `quality` bits per value; mode 2: fixed PSNR, every bit plane is coded
+  const bool rate = mode == 1;
+  const double bpp = rate ? quality : 0.0;
   Engine& E = g_engine;
   std::lock_guard<std::mutex> lock(E.mu);
   if (E.init())
@@ -779,7 +848,7 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double
       const bool fuse = !P->fwd.empty();
       const int io = std::is_same<T, float>::value ? 1 : 2;
       if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
-                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse))
+                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, !rate))
         return -1;
       for (size_t k = 0; k < P->fwd.size(); k++) {
         const LiftPass& ps = P->fwd[k];
@@ -789,13 +858,15 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double
       }
       if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst))
         return -1;
+      if (!rate && psnr_q_search(st, *P, bb, nb, quality))
+        return -1;
       if (launch_quantize(st, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
         return -1;
 
       // ---- integer coder, 32-bit coefficients ----
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
-      if (launch_speck_encode(st, e, ph, raw_budget, true, false))
+      if (launch_speck_encode(st, e, ph, raw_budget, rate, false))
         return -1;
       const uint32_t wblocks = (uint32_t)std::min<size_t>(4096, (e.streamStride * 8 + kThreads - 1) / kThreads);
       LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
@@ -810,7 +881,9 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double
       for (auto& c : hc)
         retry |= (c.need_retry != 0);
       if (retry) {
-        if (launch_make_q_wide(st, nb, e.cst) || reset_enc_pass(st, bb, nb))
+        // fixed rate: a finer q for the flagged chunks; PSNR: the same q, coefficients need 64 bits
+        if ((rate ? launch_make_q_wide(st, nb, e.cst) : launch_mark_wide(st, nb, e.cst)) ||
+            reset_enc_pass(st, bb, nb))
           return -1;
         // 64-bit magnitudes overwrite the DWT coefficients in place (same element size)
         if (launch_quantize(st, true, bb.vals, bb.valsStride, nb, P->N, bb.vals, bb.valsStride,
@@ -819,7 +892,7 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, double
         EncBuffers ew = e;
         ew.coef = bb.vals;
         ew.coefStride = bb.valsStride;
-        if (launch_speck_encode(st, ew, ph, raw_budget, true, true))
+        if (launch_speck_encode(st, ew, ph, raw_budget, rate, true))
           return -1;
         LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
@@ -1321,7 +1394,6 @@ int sperrhip_profile_get(const char** names, double* millis, int* launches, int 
 size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x,
                                     size_t chunk_y, size_t chunk_z, int mode, double quality)
 {
-  (void)mode;
   const Dims vol{dimx, dimy, dimz};
   Dims cd{chunk_x, chunk_y, chunk_z};
   for (int a = 0; a < 3; a++)
@@ -1330,8 +1402,10 @@ size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_
   size_t total = 20 + 4 * chunks.size();
   for (auto& c : chunks) {
     const double n = (double)(c[1] * c[3] * c[5]);
-    const uint64_t raw = (uint64_t)(quality * n);
-    const uint64_t bits = raw ? rounded_budget(raw) : (uint64_t)(64.0 * 3.5 * n);
+    const uint64_t raw = mode == 1 ? (uint64_t)(quality * n) : 0;
+    // without a budget every plane is coded: at most 66 bits per sample and 64 tests per set, and
+    // a chunk has fewer sets than samples (the bound of max_payload_bits, engine-side)
+    const uint64_t bits = raw ? rounded_budget(raw) : (uint64_t)(130.0 * n) + 64;
     total += 26 + (bits + 7) / 8 + 8;
   }
   return total;
@@ -1343,21 +1417,20 @@ int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t d
 {
   if (quality <= 0.0)
     return 2;
-  if (mode == 2 || mode == 3) {
-    fprintf(stderr, "[sperr_hip] mode %d (PSNR / PWE) is not implemented on the GPU path yet\n",
-            mode);
+  if (mode == 3) {
+    fprintf(stderr, "[sperr_hip] mode 3 (PWE) is not implemented on the GPU path yet\n");
     return -1;
   }
-  if (mode != 1)
+  if (mode != 1 && mode != 2)
     return 2;
   if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
     return -1;
   const Dims vol{dimx, dimy, dimz}, ch{chunk_x, chunk_y, chunk_z};
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (is_float)
-    return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, quality,
+    return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, mode, quality,
                                 static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
-  return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, quality,
+  return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, mode, quality,
                                static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
 }
 

@@ -40,7 +40,9 @@ __global__ void k_enc_state_init(EncBuffers b, const uint64_t* initLIS, const ui
     return;
   EncState& s = b.st[c];
   const CoderState& cs = b.cst[c];
-  s.active = wide_pass ? (cs.need_retry != 0) : (cs.is_const == 0);
+  // (a chunk already flagged for 64-bit coefficients -- PSNR mode decides that before coding --
+  //  skips the 32-bit pass)
+  s.active = wide_pass ? (cs.need_retry != 0) : (cs.is_const == 0 && cs.need_retry == 0);
   s.nbp = 0;
   s.done = 0;
   s.plast = 0;
@@ -1003,7 +1005,8 @@ __global__ void k_enc_finalize(EncBuffers b, uint64_t raw_budget, int rate_mode,
   cs.stream_len = 17 + 9 + payload;
   cs.nbp = s.nbp;
   cs.total_bits = s.total_bits;
-  cs.need_retry = (rate_mode && !wide_pass && (9 + payload) * 8 < raw_budget) ? 1u : 0u;
+  if (rate_mode)   // (src/SPECK_FLT.cpp:530-538; other modes choose the width before coding)
+    cs.need_retry = (!wide_pass && (9 + payload) * 8 < raw_budget) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st, bool gather);
+                     size_t valsStride, CoderState* st, bool gather, bool want_range = false);
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
@@ -34,6 +34,27 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
                     uint32_t n, CoderState* st);
 int launch_make_q_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);
+int launch_mark_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);
+
+// PSNR mode: st[c].mse = quantisation error estimate of st[c].q for the chunks with mse_active set
+// (partial: n / 4096 + 1 doubles per chunk)
+int launch_mse(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
+               uint32_t n, double* partial, size_t partialStride, CoderState* st);
+
+// doubles as unsigned keys of the same order (the keys of a zeroed state are below every value)
+__host__ __device__ inline unsigned long long order_key(double v)
+{
+  unsigned long long b;
+  memcpy(&b, &v, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double order_key_value(unsigned long long k)
+{
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double v;
+  memcpy(&v, &b, 8);
+  return v;
+}
 
 int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t valsStride,
                     uint32_t nchunks, uint32_t n, void* coef, size_t coefStride, uint64_t* sign,

@@ -28,14 +28,16 @@ namespace sperrhip {
 // kSumStrides threads add their row of the tile in order.  Also tests "all samples equal".
 constexpr int kSumStrides = 64, kSumSeg = 64;
 
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint32_t cx,
               uint32_t cy, uint32_t cz, uint32_t nstrides, uint32_t ssz, double* strideMean,
-              size_t strideMeanStride, CoderState* st)
+              size_t strideMeanStride, CoderState* st, int want_range)
 {
   __shared__ double tile[kSumStrides][kSumSeg + 1];
   __shared__ uint32_t sh_differs;
+  double vmax = -INFINITY, vnegmax = -INFINITY;   // (PSNR mode) range of the chunk's samples
   const uint32_t c = blockIdx.y;
   const uint32_t s0 = blockIdx.x * kSumStrides;
   const ChunkGeom g = geom[c];
@@ -59,6 +61,8 @@ k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint
         const T v = vol[((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0] + x];
         differs |= (v != first);
         tile[r][j] = (double)v;
+        vmax = fmax(vmax, (double)v);
+        vnegmax = fmax(vnegmax, -(double)v);
       }
     }
     __syncthreads();
@@ -73,6 +77,16 @@ k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint
     strideMean[c * strideMeanStride + s0 + threadIdx.x] = acc / (double)ssz;
   if (threadIdx.x == 0 && sh_differs)
     st[c].not_const_flag = 1;
+  if (want_range) {
+    for (int d = 32; d > 0; d >>= 1) {
+      vmax = fmax(vmax, __shfl_xor(vmax, d, 64));
+      vnegmax = fmax(vnegmax, __shfl_xor(vnegmax, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].vmaxKey), order_key(vmax));
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].vnegmaxKey), order_key(vnegmax));
+    }
+  }
 }
 
 template <typename T>
@@ -348,6 +362,63 @@ k_maxabs(const double* vals, size_t valsStride, uint32_t n, CoderState* st)
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// PSNR mode: error of the mid-tread quantiser with step q (src/SPECK_FLT.cpp:237-266).  Strides
+// of 4096 coefficients are summed one after the other, each sequentially, with the fused
+// multiply-adds of the canonical build: diff = fma(-q, rint(v / q'), v), acc = fma(diff, diff, acc)
+// where q' = 1/q is formed first.  Same LDS staging as k_stride_sums.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMseStride = 4096;
+
+__global__ void __launch_bounds__(kThreads)
+k_mse_strides(const double* vals, size_t valsStride, uint32_t n, double* partial,
+              size_t partialStride, const CoderState* st)
+{
+  __shared__ double tile[kSumStrides][kSumSeg + 1];
+  const uint32_t c = blockIdx.y;
+  if (st[c].is_const || !st[c].mse_active)
+    return;
+  const double q = st[c].q, rcp_q = 1.0 / q;
+  const double* in = vals + c * valsStride;
+  const uint32_t npart = n / kMseStride + 1;            // the last one may be short or empty
+  const uint32_t s0 = blockIdx.x * kSumStrides;
+  double acc = 0.0;
+  for (uint32_t seg = 0; seg < kMseStride; seg += kSumSeg) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kSumStrides * kSumSeg); k += kThreads) {
+      const uint32_t r = k / kSumSeg, j = k % kSumSeg;
+      const uint64_t e = (uint64_t)(s0 + r) * kMseStride + seg + j;
+      tile[r][j] = (s0 + r < npart && e < n) ? in[e] : 0.0;   // (a zero adds exactly nothing)
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)kSumStrides && s0 + threadIdx.x < npart) {
+      const uint64_t e0 = (uint64_t)(s0 + threadIdx.x) * kMseStride + seg;
+      const uint32_t len = e0 >= n ? 0u : (uint32_t)min((uint64_t)kSumSeg, n - e0);
+      for (uint32_t j = 0; j < len; j++) {
+        const double v = tile[threadIdx.x][j];
+        const double diff = fma(-q, rint(v * rcp_q), v);
+        acc = fma(diff, diff, acc);
+      }
+    }
+  }
+  if (threadIdx.x < (uint32_t)kSumStrides && s0 + threadIdx.x < npart)
+    partial[c * partialStride + s0 + threadIdx.x] = acc;
+}
+
+__global__ void k_mse_final(uint32_t n, const double* partial, size_t partialStride,
+                            CoderState* st, uint32_t nchunks)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunks || st[c].is_const || !st[c].mse_active)
+    return;
+  const uint32_t npart = n / kMseStride + 1;
+  const double* pp = partial + c * partialStride;
+  double total = 0.0;
+  for (uint32_t s = 0; s < npart; s++)
+    total += pp[s];
+  st[c].mse = total / (double)n;
+}
+
 // SPECK_FLT.cpp:282-301 (fixed-rate q) ; `wide` selects the high-precision retry
 __global__ void k_make_q_rate(CoderState* st, uint32_t nchunks, int wide_pass)
 {
@@ -551,14 +622,14 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st, bool gather)
+                     size_t valsStride, CoderState* st, bool gather, bool want_range)
 {
   const uint32_t n = cdims[0] * cdims[1] * cdims[2];
   const uint32_t ssz = n / nstrides;
   LAUNCH_K(k_stride_sums<T>, dim3((nstrides + kSumStrides - 1) / kSumStrides, nchunks),
            dim3(kThreads), 0, stream,
                      vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz, strideMean,
-                     strideMeanStride, st);
+                     strideMeanStride, st, want_range ? 1 : 0);
   LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(1), 0, stream, vol, vd, geom,
                      nstrides, strideMean, strideMeanStride, st);
   if (gather)   // otherwise the first lifting pass reads the volume itself
@@ -569,10 +640,10 @@ int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGe
 }
 template int launch_condition<float>(hipStream_t, const float*, VolDesc, const ChunkGeom*,
                                      uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                     double*, size_t, CoderState*, bool);
+                                     double*, size_t, CoderState*, bool, bool);
 template int launch_condition<double>(hipStream_t, const double*, VolDesc, const ChunkGeom*,
                                       uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                      double*, size_t, CoderState*, bool);
+                                      double*, size_t, CoderState*, bool, bool);
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
@@ -598,6 +669,33 @@ int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, u
                      dim3(kThreads), 0, stream, vals, valsStride, n, st);
   LAUNCH_K(k_make_q_rate, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks,
                      0);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_mse(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
+               uint32_t n, double* partial, size_t partialStride, CoderState* st)
+{
+  const uint32_t npart = n / kMseStride + 1;
+  LAUNCH_K(k_mse_strides, dim3((npart + kSumStrides - 1) / kSumStrides, nchunks), dim3(kThreads), 0,
+           stream, vals, valsStride, n, partial, partialStride, st);
+  LAUNCH_K(k_mse_final, dim3((nchunks + 63) / 64), dim3(64), 0, stream, n, partial, partialStride,
+           st, nchunks);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// PSNR mode: the chunks flagged for 64-bit coefficients keep their q
+__global__ void k_mark_wide(CoderState* st, uint32_t nchunks)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nchunks && st[c].need_retry)
+    st[c].wide = 1;
+}
+
+int launch_mark_wide(hipStream_t stream, uint32_t nchunks, CoderState* st)
+{
+  LAUNCH_K(k_mark_wide, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks);
   HIP_CHECK(hipGetLastError());
   return 0;
 }

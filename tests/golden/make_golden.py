@@ -7,7 +7,7 @@ Inputs: two small files the reference's own tests use (test_data/wmag17.float, a
 test_data/vorticity.128_128_41, test_data/const32x20x16.float) copied as data fixtures, plus the
 machine-independent integer-arithmetic field from tests/fields.py.  Expected outputs: the exact
 container bytes produced by the reference's sperr_comp_3d and the SHA-256 of the floats/doubles
-its sperr_decomp_3d returns, for several chunkings and bit rates.
+its sperr_decomp_3d returns, for several chunkings and bit rates (mode 1) and target PSNRs (mode 2).
 """
 import hashlib
 import json
@@ -58,22 +58,32 @@ def main():
         ("smooth_f64", (40, 40, 24), [2.0, 40.0]),    # 40 bpp forces the high-precision retry
         ("smooth_flat_z", (64, 64, 9), [2.0]),
     ]
-    for name, chunks, bpps in plan:
+    # mode 2: the quality is a target PSNR in dB (include/SPERR_C_API.h:95-99)
+    plan_psnr = [
+        ("wmag17", (17, 17, 17), [60.0, 110.0]),
+        ("vort_crop", (20, 18, 16), [80.0]),
+        ("const32x20x16", (16, 10, 8), [90.0]),
+        ("smooth_odd", (50, 37, 19), [70.0]),
+        ("smooth_f64", (40, 40, 24), [100.0, 225.0]),   # 225 dB needs 64-bit coefficients
+    ]
+    jobs = [(n, c, 1, q) for n, c, qs in plan for q in qs] + \
+           [(n, c, 2, q) for n, c, qs in plan_psnr for q in qs]
+    for name, chunks, mode, bpp in jobs:
         if name in inputs:
             arr = inputs[name]
         else:
             shape, dt = gen[name]
             arr = smooth_field(shape, dtype=dt)
-        for bpp in bpps:
-            stream = ref.comp_3d(arr, chunks, 1, bpp)
+        if True:
+            stream = ref.comp_3d(arr, chunks, mode, bpp)
             dec_f = ref.decomp_3d(stream, True)
             dec_d = ref.decomp_3d(stream, False)
-            tag = f"{name}_c{chunks[0]}x{chunks[1]}x{chunks[2]}_bpp{bpp}"
+            tag = f"{name}_c{chunks[0]}x{chunks[1]}x{chunks[2]}_{'bpp' if mode == 1 else 'psnr'}{bpp}"
             with open(os.path.join(HERE, tag + ".sperr"), "wb") as f:
                 f.write(stream)
             cases.append({
                 "tag": tag, "input": name, "shape_zyx": list(arr.shape),
-                "dtype": str(arr.dtype), "chunks_xyz": list(chunks), "bpp": bpp,
+                "dtype": str(arr.dtype), "chunks_xyz": list(chunks), "mode": mode, "bpp": bpp,
                 "input_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
                 "stream_len": len(stream),
                 "stream_sha256": hashlib.sha256(stream).hexdigest(),

@@ -147,7 +147,8 @@ def test_golden_vectors(eng, case):
     assert hashlib.sha256(arr.tobytes()).hexdigest() == case["input_sha256"]
     with open(os.path.join(GOLD, case["tag"] + ".sperr"), "rb") as f:
         want = f.read()
-    got = bytes(eng.compress(cuda(arr), case["chunks_xyz"], case["bpp"]).cpu().numpy())
+    got = bytes(eng.compress(cuda(arr), case["chunks_xyz"], case["bpp"],
+                             mode=case.get("mode", 1)).cpu().numpy())
     assert len(got) == case["stream_len"]
     assert got == want
     dev = cuda(np.frombuffer(want, dtype=np.uint8))
@@ -170,6 +171,39 @@ def test_container_matches_oracle(eng, oracle, shape, chunks, bpp):
     f_got, f_want = eng.decompress(dev, True).cpu().numpy(), oracle.decomp_3d(want, True)
     assert ulp_diff_f32(f_got, f_want) <= 1           # stated tolerance: 1 ULP (fp32)
     assert np.array_equal(bits(f_got), bits(f_want))  # observed: identical
+    assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, False)))
+
+
+@pytest.mark.parametrize("shape,chunks", [((50, 64, 72), (32, 32, 32)), ((64, 64, 64), (64, 64, 64)),
+                                          ((41, 128, 128), (64, 64, 41)), ((96, 96, 96), (48, 48, 48))])
+@pytest.mark.parametrize("psnr", [55.0, 90.0, 130.0])
+def test_psnr_mode_matches_oracle(eng, oracle, shape, chunks, psnr):
+    """Mode 2 (src/SPECK_FLT.cpp:237-279): the q search and the full-depth coding give the
+    reference's bytes; the target itself is met."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 2, psnr)
+    got = bytes(eng.compress(cuda(v), chunks, psnr, mode=2).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    f_got, f_want = eng.decompress(dev, False).cpu().numpy(), oracle.decomp_3d(want, False)
+    assert np.array_equal(bits(f_got), bits(f_want))
+    rng = float(v.max()) - float(v.min())
+    mse = float(np.mean((f_got - v.astype(np.float64)) ** 2))
+    assert 10.0 * np.log10(rng * rng / mse) >= psnr - 0.01
+
+
+def test_psnr_mode_wide_coefficients_and_c_api(eng, oracle):
+    """A PSNR so high that the coefficients need more than 32 bits (SPECK_FLT.cpp:324-337), a
+    volume with a constant chunk, double input, and the host C API in mode 2."""
+    v = smooth_field((32, 32, 64), dtype=np.float64)
+    v[:, :, :32] = 0.75
+    want = oracle.comp_3d(v, (32, 32, 32), 2, 230.0)
+    assert want[20 + 8 + 17 + 17] > 32                     # second chunk: more than 32 bit planes
+    got = bytes(eng.compress(cuda(v), (32, 32, 32), 230.0, mode=2).cpu().numpy())
+    assert got == want
+    assert eng.comp_3d(v, (32, 32, 32), 2, 230.0) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
     assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()),
                           bits(oracle.decomp_3d(want, False)))
 

@@ -33,7 +33,7 @@ def test_oracle_matches_golden_stream_and_decode(oracle, case):
     arr = load_input(case)
     with open(os.path.join(GOLD, case["tag"] + ".sperr"), "rb") as f:
         want = f.read()
-    got = oracle.comp_3d(arr, case["chunks_xyz"], 1, case["bpp"])
+    got = oracle.comp_3d(arr, case["chunks_xyz"], case.get("mode", 1), case["bpp"])
     assert len(got) == case["stream_len"]
     assert got == want  # bit-exact container
     dec_f = oracle.decomp_3d(want, True)

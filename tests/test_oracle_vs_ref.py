@@ -79,3 +79,15 @@ def test_double_input_and_f64_field(oracle, ref):
     v = smooth_field((24, 40, 40), dtype=np.float64)
     so, sr = oracle.comp_3d(v, (40, 40, 24), 1, 3.0), ref.comp_3d(v, (40, 40, 24), 1, 3.0)
     assert so == sr and not (sr[1] & 0x20)
+
+
+@pytest.mark.parametrize("chunks", [(32, 32, 32), (48, 40, 24)])
+@pytest.mark.parametrize("psnr", [40.0, 85.0, 140.0, 230.0])
+def test_psnr_mode_bit_exact(oracle, ref, chunks, psnr):
+    """Mode 2 (src/SPECK_FLT.cpp:237-279,431-452): q search, integer width, full-depth coding."""
+    v = turbulence((48, 40, 64))
+    want = ref.comp_3d(v, chunks, 2, psnr)
+    assert oracle.comp_3d(v, chunks, 2, psnr) == want
+    assert np.array_equal(bits(oracle.decomp_3d(want, False)), bits(ref.decomp_3d(want, False)))
+    d = smooth_field((24, 40, 40), dtype=np.float64)
+    assert oracle.comp_3d(d, chunks, 2, psnr) == ref.comp_3d(d, chunks, 2, psnr)
