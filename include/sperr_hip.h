@@ -44,6 +44,10 @@ int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nt
 /* include/SPERR_C_API.h:87-92 */
 void sperr_parse_header(const void* src, size_t* dimx, size_t* dimy, size_t* dimz, int* is_float);
 
+/* include/SPERR_C_API.h:138-156 : keep `pct` percent of every chunk stream (progressive access);
+ * the result decodes with sperr_decomp_3d.  Host only.  Returns 0 ok, 1 *dst not NULL, -1 other. */
+int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, size_t* dst_len);
+
 /* ---- device-resident API ---------------------------------------------------------------------- */
 
 /* Upper bound of the container size sperrhip_compress_dev can produce (bytes). */

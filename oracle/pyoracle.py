@@ -51,6 +51,7 @@ class _CApiMixin:
 
     _comp = None
     _decomp = None
+    _trunc = None
     _libc = C.CDLL(None)
 
     def _wire(self):
@@ -61,6 +62,20 @@ class _CApiMixin:
         self._decomp.argtypes = [_vp, _sz, C.c_int, _sz, C.POINTER(_sz), C.POINTER(_sz),
                                  C.POINTER(_sz), C.POINTER(_vp)]
         self._libc.free.argtypes = [_vp]
+        if self._trunc is not None:
+            self._trunc.restype = C.c_int
+            self._trunc.argtypes = [_vp, _sz, C.c_uint, C.POINTER(_vp), C.POINTER(_sz)]
+
+    def trunc_3d(self, stream, pct):
+        """sperr_trunc_3d (include/SPERR_C_API.h:151-156). Returns bytes."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dst, n = _vp(None), _sz(0)
+        rtn = self._trunc(buf.ctypes.data, buf.size, pct, C.byref(dst), C.byref(n))
+        if rtn != 0:
+            raise RuntimeError(f"trunc_3d returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
 
     def comp_3d(self, vol, chunks, mode, quality, nthreads=1):
         """vol: numpy float32/float64 array shaped (z, y, x). Returns bytes."""
@@ -99,6 +114,7 @@ class Oracle(_CApiMixin):
         self.lib = C.CDLL(build_oracle())
         L = self.lib
         self._comp, self._decomp = L.orc_comp_3d, L.orc_decomp_3d
+        self._trunc = L.orc_trunc_3d
         self._wire()
         L.orc_dwt3d.argtypes = [_vp, _vp]
         L.orc_idwt3d.argtypes = [_vp, _vp]
@@ -224,6 +240,7 @@ class Ref(_CApiMixin):
         self.lib = C.CDLL(os.path.join(HERE, "_ref", "libSPERR_ref.so"), mode=C.RTLD_GLOBAL)
         self.probe = C.CDLL(os.path.join(HERE, "_ref", "libref_probe.so"))
         self._comp, self._decomp = self.lib.sperr_comp_3d, self.lib.sperr_decomp_3d
+        self._trunc = self.lib.sperr_trunc_3d
         self._wire()
         P = self.probe
         P.refp_dwt3d.argtypes = [_vp, _sz, _sz, _sz]

@@ -1271,3 +1271,71 @@ int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthr
     *dst = outd;
   return 0;
 }
+
+/* src/SPERR_C_API.cpp:260-280, src/SPERR3D_Stream_Tools.cpp:134-226, src/sperr_helper.cpp:401-427:
+ * keep `pct` percent of every chunk stream (never less than 64 bytes, never more than it has),
+ * flag the container as a portion, rewrite the chunk lengths */
+int orc_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, size_t* dst_len)
+{
+  if (*dst != NULL)
+    return 1;
+  const uint8_t* h = (const uint8_t*)src;
+  if (src_len < 20)
+    return -1;
+  const int multi = (h[1] & 0x10) != 0;
+  uint32_t v3[3];
+  memcpy(v3, h + 2, 12);
+  size_t vol[3] = {v3[0], v3[1], v3[2]}, cd[3] = {v3[0], v3[1], v3[2]};
+  size_t pos = 14;
+  if (multi) {
+    uint16_t c3[3];
+    memcpy(c3, h + 14, 6);
+    for (int a = 0; a < 3; a++)
+      cd[a] = c3[a];
+    pos = 20;
+  }
+  const size_t nchunks = orc_chunk_volume(vol, cd, NULL, 0);
+  const size_t hlen = pos + 4 * nchunks;
+  if (src_len < hlen)
+    return -1;
+  size_t* off = (size_t*)malloc(nchunks * sizeof(size_t));
+  size_t* len = (size_t*)malloc(nchunks * sizeof(size_t));
+  size_t at = hlen, total = hlen, far = 0;
+  const int whole = pct == 0 || pct >= 100;
+  for (size_t i = 0; i < nchunks; i++) {
+    uint32_t l;
+    memcpy(&l, h + pos + 4 * i, 4);
+    off[i] = at;
+    at += l;
+    len[i] = l;
+    if (!whole && l > 64) {
+      size_t req = (size_t)((double)pct / 100.0 * (double)l);
+      len[i] = req < 64 ? 64 : req;
+    }
+    total += len[i];
+    if (off[i] + len[i] > far)
+      far = off[i] + len[i];
+  }
+  int rtn = -1;
+  if (src_len >= far) {
+    uint8_t* out = (uint8_t*)malloc(total);
+    memcpy(out, h, pos);
+    if (!whole) {
+      out[0] = 0;       /* SPERR_VERSION_MAJOR */
+      out[1] |= 0x80;   /* "a portion of another complete bitstream" */
+    }
+    size_t w = hlen;
+    for (size_t i = 0; i < nchunks; i++) {
+      const uint32_t l = (uint32_t)len[i];
+      memcpy(out + pos + 4 * i, &l, 4);
+      memcpy(out + w, h + off[i], len[i]);
+      w += len[i];
+    }
+    *dst = out;
+    *dst_len = total;
+    rtn = 0;
+  }
+  free(off);
+  free(len);
+  return rtn;
+}

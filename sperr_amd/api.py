@@ -15,7 +15,7 @@ _sz, _vp = C.c_size_t, C.c_void_p
 
 # every symbol include/sperr_hip.h declares
 EXPORTS = [
-    "sperr_comp_3d", "sperr_decomp_3d", "sperr_parse_header",
+    "sperr_comp_3d", "sperr_decomp_3d", "sperr_parse_header", "sperr_trunc_3d",
     "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
@@ -42,6 +42,8 @@ def load_library():
     lib.sperr_parse_header.restype = None
     lib.sperr_parse_header.argtypes = [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz),
                                        C.POINTER(C.c_int)]
+    lib.sperr_trunc_3d.restype = C.c_int
+    lib.sperr_trunc_3d.argtypes = [_vp, _sz, C.c_uint, C.POINTER(_vp), C.POINTER(_sz)]
     lib.sperrhip_max_compressed_size.restype = _sz
     lib.sperrhip_max_compressed_size.argtypes = [_sz] * 6 + [C.c_int, C.c_double]
     lib.sperrhip_compress_dev.restype = C.c_int
@@ -198,6 +200,16 @@ class SperrHip:
                                      C.byref(n))
         if rtn != 0:
             raise SperrHipError(f"sperr_comp_3d returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def trunc_3d(self, stream, pct):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dst, n = _vp(None), _sz(0)
+        rtn = self.lib.sperr_trunc_3d(buf.ctypes.data, buf.size, pct, C.byref(dst), C.byref(n))
+        if rtn != 0:
+            raise SperrHipError(f"sperr_trunc_3d returned {rtn}")
         out = C.string_at(dst.value, n.value)
         self._libc.free(dst)
         return out

@@ -1712,6 +1712,72 @@ int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_
   return rtn;
 }
 
+// include/SPERR_C_API.h:138-156, src/SPERR_C_API.cpp:260-280,
+// src/SPERR3D_Stream_Tools.cpp:134-226: host-side byte surgery, no GPU involved.  Every chunk
+// stream keeps `pct` percent of its bytes (at least 64, at most what it has), the container is
+// flagged as a portion and the chunk lengths are rewritten; the decoder zero-pads what is missing.
+int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, size_t* dst_len)
+{
+  if (*dst != nullptr)
+    return 1;
+  const uint8_t* h = static_cast<const uint8_t*>(src);
+  if (src_len < 20)
+    return -1;
+  const bool multi = (h[1] & 0x10) != 0;
+  uint32_t v3[3];
+  memcpy(v3, h + 2, 12);
+  Dims vol{v3[0], v3[1], v3[2]}, cd = vol;
+  size_t pos = 14;
+  if (multi) {
+    uint16_t c3[3];
+    memcpy(c3, h + 14, 6);
+    cd = {c3[0], c3[1], c3[2]};
+    pos = 20;
+  }
+  for (int a = 0; a < 3; a++)
+    if (vol[a] == 0 || cd[a] == 0)
+      return -1;
+  const size_t nchunks = chunk_volume(vol, cd).size();
+  const size_t hlen = pos + 4 * nchunks;
+  if (src_len < hlen)
+    return -1;
+  constexpr size_t kMinChunkBytes = 64;   // include/SPERR3D_Stream_Tools.h:54
+  const bool whole = pct == 0 || pct >= 100;
+  std::vector<size_t> off(nchunks), len(nchunks);
+  size_t at = hlen, total = hlen, far = 0;
+  for (size_t i = 0; i < nchunks; i++) {
+    uint32_t l;
+    memcpy(&l, h + pos + 4 * i, 4);
+    off[i] = at;
+    at += l;
+    len[i] = l;
+    if (!whole && l > kMinChunkBytes)
+      len[i] = std::max(kMinChunkBytes, (size_t)((double)pct / 100.0 * (double)l));
+    total += len[i];
+    far = std::max(far, off[i] + len[i]);
+  }
+  if (src_len < far)
+    return -1;
+  uint8_t* out = static_cast<uint8_t*>(malloc(total));
+  if (!out)
+    return -1;
+  memcpy(out, h, pos);
+  if (!whole) {
+    out[0] = 0;       // SPERR_VERSION_MAJOR (CMakeLists.txt:5)
+    out[1] |= 0x80;   // portion flag: bool 0 of the packed byte (src/sperr_helper.cpp:262-273)
+  }
+  size_t w = hlen;
+  for (size_t i = 0; i < nchunks; i++) {
+    const uint32_t l = (uint32_t)len[i];
+    memcpy(out + pos + 4 * i, &l, 4);
+    memcpy(out + w, h + off[i], len[i]);
+    w += len[i];
+  }
+  *dst = out;
+  *dst_len = total;
+  return 0;
+}
+
 int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
                     size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
 {

@@ -272,6 +272,21 @@ def test_reference_c_api_drop_in(eng, oracle):
     assert eng.lib.sperr_comp_3d(*args, 7, 2.0, 0, C.byref(dst), C.byref(n)) == 2
 
 
+@pytest.mark.parametrize("pct", [5, 40, 100])
+def test_progressive_truncation(eng, oracle, pct):
+    """sperr_trunc_3d: same bytes as the oracle's restatement of the reference, and the portion
+    decodes on the GPU to the same values (missing bits read as zero)."""
+    v = turbulence((64, 64, 96))
+    full = oracle.comp_3d(v, (32, 32, 32), 1, 4.0)
+    want = oracle.trunc_3d(full, pct)
+    assert eng.trunc_3d(full, pct) == want
+    assert (want[1] & 0x80) == (0x80 if pct < 100 else 0)
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, True)))
+    assert np.array_equal(bits(eng.decomp_3d(want, False)), bits(oracle.decomp_3d(want, False)))
+
+
 def test_truncated_container_is_rejected(eng, oracle):
     v = turbulence((32, 32, 32))
     s = oracle.comp_3d(v, (32, 32, 32), 1, 2.0)

@@ -91,3 +91,16 @@ def test_psnr_mode_bit_exact(oracle, ref, chunks, psnr):
     assert np.array_equal(bits(oracle.decomp_3d(want, False)), bits(ref.decomp_3d(want, False)))
     d = smooth_field((24, 40, 40), dtype=np.float64)
     assert oracle.comp_3d(d, chunks, 2, psnr) == ref.comp_3d(d, chunks, 2, psnr)
+
+
+@pytest.mark.parametrize("chunks", [(64, 40, 48), (32, 32, 32), (20, 18, 16)])
+@pytest.mark.parametrize("pct", [0, 1, 10, 37, 75, 100, 150])
+def test_progressive_truncation_bit_exact(oracle, ref, chunks, pct):
+    """sperr_trunc_3d (src/SPERR3D_Stream_Tools.cpp:134-226): same bytes, and the truncated
+    container decodes to the same values."""
+    v = turbulence((48, 40, 64))
+    v[:16, :18, :20] = 2.5   # a constant chunk for the (20, 18, 16) chunking: 17-byte stream
+    full = ref.comp_3d(v, chunks, 1, 3.0)
+    want = ref.trunc_3d(full, pct)
+    assert oracle.trunc_3d(full, pct) == want
+    assert np.array_equal(bits(oracle.decomp_3d(want, True)), bits(ref.decomp_3d(want, True)))
