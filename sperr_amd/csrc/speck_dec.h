@@ -31,7 +31,9 @@ struct DecState {
   int32_t l1PlaneP1;
   uint64_t l1End;
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
-  uint32_t leafCount;            //   of the current plane
+  uint32_t leafCount;            //   of the current plane (bornCount: all births once k_lis_tables ends)
+  uint64_t lisPhaseBits;         // bits of the plane's LIS phase covered by the birth masks
+  uint32_t slotBorn[spk::kMaxLevels];   // births per mask slot of the plane (k_place_scan)
   uint32_t listLen[2][spk::kMaxLevels];
 };
 

@@ -2091,50 +2091,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     STAMP(8);
   }
 
-  // ---- newborn insignificant sets join their lists in stream order
-  __threadfence();
+  // ---- newborn insignificant sets join their lists in stream order: k_place_scan / _scatter /
+  //      _finish do that on the whole GPU from the position masks and the birth records
   __syncthreads();
   const uint64_t phaseBits = min(sh_pos - phase0, maskBits);
-  const uint32_t pw = (uint32_t)((phaseBits + 63) / 64);
-  for (uint32_t slot = 0; slot < b.nSlots; slot++) {
-    const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
-    uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < pw; base += kTabThreads) {
-      const uint32_t wi = base + tid;
-      const uint64_t m = wi < pw ? __hip_atomic_load(mask + wi, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)
-                                 : 0ull;
-      uint32_t total;
-      const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(m), sh_scan, &total);
-      if (wi < pw)
-        pre[wi] = ex + carry;
-      carry += total;
-    }
-    if (tid == 0)
-      sh_flag = carry;
-    __syncthreads();
-    const uint32_t lev = b.slotLevel[slot];
-    const uint32_t baseLen = s.listLen[nx][lev];
-    const uint32_t nbornTot = min(sh_born, (uint32_t)b.bornStride);
-    for (uint32_t k = tid; k < nbornTot; k += kTabThreads) {
-      const uint64_t pl = bornPosLev[k];
-      if ((uint32_t)(pl >> 48) != lev)
-        continue;
-      const uint64_t rel = pl & ((1ull << 48) - 1);
-      const uint64_t m = __hip_atomic_load(mask + (rel >> 6), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t rank = pre[rel >> 6] + (uint32_t)__popcll(m & ((1ull << (rel & 63)) - 1ull));
-      b.lis[nx][c * b.lisStride + b.levelOff[lev] + baseLen + rank] = bornPacked[k];
-    }
-    __syncthreads();
-    if (tid == 0)
-      s.listLen[nx][lev] = baseLen + sh_flag;
-    __syncthreads();
-  }
-  for (uint32_t slot = 0; slot < b.nSlots; slot++)  // leave the masks clean for the next plane
-    for (uint32_t wi = tid; wi < pw; wi += kTabThreads)
-      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
   if (stamps) {
     const uint64_t now_ = __builtin_readcyclecounter();
     uint64_t* out = b.lisStamps + (size_t)c * 64;
@@ -2147,10 +2107,81 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     s.cur = nx;
     s.pos = sh_pos;
     s.nLeafEv = min(sh_leaf, b.leafCap);
+    s.bornCount = min(sh_born, (uint32_t)b.bornStride);
+    s.lisPhaseBits = phaseBits;
     s.lastPlane = p;
     if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
       s.done = 1;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Placement of the sets born in the plane k_lis_tables (and k_lis_l1) just decoded: a set joins
+// the list of its level behind the entries that survived, in the order of the stream positions at
+// which the sets were born (= the reference's append order).  Every birth set one bit of its
+// level's position mask; the rank of a birth is the number of mask bits before its own.
+// ------------------------------------------------------------------------------------------
+#define PLACE_ACTIVE_OR_RETURN(s, p)                                                   \
+  if (!(s).active || (int)(p) >= (s).nbp || (s).lastPlane != (int)(p) || (s).done)     \
+    return;   /* (after the stream has ended nobody reads the lists again) */
+
+// one workgroup per (mask slot, chunk): popcount prefix of the slot's mask
+__global__ void __launch_bounds__(kTabThreads) k_place_scan(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y, slot = blockIdx.x;
+  DecState& s = b.st[c];
+  PLACE_ACTIVE_OR_RETURN(s, p);
+  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+  const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
+  const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
+  uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < pw; base += kTabThreads) {
+    const uint32_t wi = base + threadIdx.x;
+    const uint64_t m = wi < pw ? mask[wi] : 0ull;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(m), sh_scan, &total);
+    if (wi < pw)
+      pre[wi] = ex + carry;
+    carry += total;
+  }
+  if (threadIdx.x == 0)
+    s.slotBorn[slot] = carry;
+}
+
+__global__ void __launch_bounds__(kThreads) k_place_scatter(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  PLACE_ACTIVE_OR_RETURN(s, p);
+  const uint32_t cur = s.cur;   // (k_lis_tables has already made the next lists current)
+  const uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
+  const uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < s.bornCount;
+       k += gridDim.x * blockDim.x) {
+    const uint64_t pl = bornPosLev[k];
+    const uint32_t lev = (uint32_t)(pl >> 48);
+    const uint64_t rel = pl & ((1ull << 48) - 1);
+    const size_t mo = c * b.maskStride + (size_t)b.levelSlot[lev] * b.maskWords + (rel >> 6);
+    const uint32_t rank = b.maskPrefix[mo] +
+                          (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    b.lis[cur][c * b.lisStride + b.levelOff[lev] + s.listLen[cur][lev] + rank] = bornPacked[k];
+  }
+}
+
+// the lists grow by what was placed; the masks are left clean for the next plane
+__global__ void __launch_bounds__(kThreads) k_place_finish(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  PLACE_ACTIVE_OR_RETURN(s, p);
+  const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
+  for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < pw; wi += gridDim.x * blockDim.x)
+    for (uint32_t slot = 0; slot < b.nSlots; slot++)
+      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (uint32_t slot = 0; slot < b.nSlots; slot++)
+      s.listLen[s.cur][b.slotLevel[slot]] += s.slotBorn[slot];
 }
 
 // Turns the leaf events of one plane into pixel-mask updates: born bits for all children, sigNew
@@ -2380,6 +2411,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     }
   }
   const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 768 / nc));
+  const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -2394,6 +2426,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        if (b.nSlots) {
+          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_finish, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+        }
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else
@@ -2409,6 +2446,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
         LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        if (b.nSlots) {
+          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_finish, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+        }
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else
