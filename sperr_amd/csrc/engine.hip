@@ -1217,7 +1217,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), ss));
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
-                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0, P->l1Level >= 0, P->maxK};
+                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
         // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_tables
         static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
@@ -1640,7 +1640,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   else
     HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
   DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
-                 P->l0Level >= 0, P->l1Level >= 0, P->maxK};
+                 P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
   HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
   HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
   HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));

@@ -703,6 +703,7 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 // A block is handed out only after all earlier ones, so a waiting block always waits for a
 // workgroup that is running (or has seen the pass end).
 // ------------------------------------------------------------------------------------------
+constexpr int kTabLdsGrids = 288;   // grid descriptors the GPU-wide list kernels keep in LDS
 constexpr int kL0W = 8192;
 constexpr int kL0Threads = 1024;
 constexpr int kL0Sub = kL0W / 64;
@@ -730,10 +731,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   __shared__ uint32_t entR[kL0W / 1024], entK[kL0W / 1024], entS[kL0W / 1024];
   __shared__ uint32_t blkE[kL0Sub], blkK[kL0Sub], blkS[kL0Sub];
   __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
+  __shared__ Grid sh_grids[kTabLdsGrids];   // (the launcher checks that the tree's grids fit)
 
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
   const Tree& t = b.tree;
+  for (uint32_t k = tid; k < t.ngrids; k += kL0Threads)
+    sh_grids[k] = t.grids[k];
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
@@ -835,12 +839,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
           f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 56) == (unsigned long long)(p + 1))
             break;
-          if (__hip_atomic_load(&s.l0PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+          // (the end-of-pass marker is looked at now and then: the poll stays one load long)
+          if ((++spins & 15u) == 0 &&
+              __hip_atomic_load(&s.l0PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
             stop = 1;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 19)) {   // cannot happen; never leave a wave spinning for ever
+          if (spins > (1u << 21)) {   // cannot happen; never leave a wave spinning for ever
             s.error = 1;
             __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;
@@ -962,7 +967,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       sigm |= bit << 7;
       negm |= (bit & (sgn ^ 1u)) << 7;
       const Node nd = unpack_node(ident);
-      const Grid g = t.grids[nd.grid];
+      const Grid g = sh_grids[nd.grid];
       const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
       if (sb < b.leafCap)
         leafEv[sb] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
@@ -994,7 +999,8 @@ constexpr int kL1W = 4096;
 constexpr int kL1Ahead = 192;
 constexpr int kL1P = kL1W + kL1Ahead;           // positions with class-0 tables
 constexpr int kL1MaxTok = 137;
-constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)kL1W * (4 + 4 + 1) + (size_t)kL1P * 2;
+constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1W * (4 + 1) +
+                           (size_t)kL1P * 2;
 
 __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
 {
@@ -1011,7 +1017,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
   uint64_t* wbits = reinterpret_cast<uint64_t*>(l1_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l1_smem);
   uint32_t* hop64 = reinterpret_cast<uint32_t*>(l1_smem + (size_t)(kL1P / 64 + 4) * 8);
-  uint32_t* hopW = hop64 + kL1W;     // later: the marks of the tokens on the chain
+  uint32_t* hopW = hop64 + kL1W + 4;     // later: the marks of the tokens on the chain
   uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1W);   // token length at every position
   uint8_t* U0 = U1 + kL1W;           // coded class-0 item: 1, or 1 + T0 of the next position
   uint8_t* T0 = U0 + kL1P;           // split of a class-0 set that starts here
@@ -1020,10 +1026,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
   __shared__ uint32_t blkE[kL1W / 64], blkK[kL1W / 64], blkS[kL1W / 64];
   __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
   __shared__ uint32_t sh_nb, sh_nl, sh_baseB, sh_baseL;
+  __shared__ Grid sh_grids[kTabLdsGrids];   // (the launcher checks that the tree's grids fit)
 
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
   const Tree& t = b.tree;
+  for (uint32_t k = tid; k < t.ngrids; k += kL0Threads)
+    sh_grids[k] = t.grids[k];
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t start0 = l0done ? s.l0End : phase0;
   const uint64_t* words = b.stream + c * b.streamStride;
@@ -1052,6 +1061,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
     const uint32_t i = sh_ticket;
     if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
       break;
+    const bool l1stamps = b.lisStamps != nullptr && tid == 0 && c == 0;
+    uint64_t l1t0 = l1stamps ? __builtin_readcyclecounter() : 0, l1t1 = 0, l1t2 = 0;
     const uint64_t a = start0 + (uint64_t)i * kL1W;
     const uint64_t w0 = a >> 6;
     const uint32_t q0 = (uint32_t)(a & 63);
@@ -1140,6 +1151,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
     }
     __syncthreads();
     // ---- look back, publish: tag | done << 55 | exit offset << 47 | entries << 23 | significant
+    if (l1stamps)
+      l1t1 = __builtin_readcyclecounter();
     if (tid == 0) {
       uint32_t e = 0, rank = 0, sg = 0, stop = 0, last = 0;
       if (i > 0) {
@@ -1149,12 +1162,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
           f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 56) == (unsigned long long)(p + 1))
             break;
-          if (__hip_atomic_load(&s.l1PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+          // (the end-of-pass marker is looked at now and then: the poll stays one load long)
+          if ((++spins & 15u) == 0 &&
+              __hip_atomic_load(&s.l1PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
             stop = 1;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 19)) {   // cannot happen; never leave a wave spinning for ever
+          if (spins > (1u << 21)) {   // cannot happen; never leave a wave spinning for ever
             s.error = 1;
             __hip_atomic_store(&s.l1PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;
@@ -1191,6 +1205,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
       sh_stop = stop;
       sh_endpos = 0;
       sh_endsig = 0;
+      if (l1stamps)
+        l1t2 = __builtin_readcyclecounter();
     }
     for (uint32_t k = tid; k < (uint32_t)(kL1W / 64); k += kL0Threads)
       blkE[k] = kL0None;
@@ -1257,10 +1273,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
       if (mk == 0)
         continue;
       const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
+      const uint64_t ident = list[q];
       if (!bit_at(r)) {
-        keep[q - sb] = list[q];
+        keep[q - sb] = ident;
         continue;
       }
+      hop64[r + 1] = (uint32_t)ident;          // (a significant token is at least 10 bits long:
+      hop64[r + 2] = (uint32_t)(ident >> 32);  //  these words are its own)
       uint32_t y = r + 1, found = 0, nb = 0, nl = 0;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -1281,19 +1300,18 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
       hop64[r] = slotB | (slotL << 16);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0)     // (two threads: the two returning atomics are in flight together)
       sh_baseB = sh_nb ? atomicAdd(&s.bornCount, sh_nb) : 0u;
+    if (tid == 64)
       sh_baseL = sh_nl ? atomicAdd(&s.leafCount, sh_nl) : 0u;
-    }
     __syncthreads();
     // ---- second sweep: write the births and the leaf events
     for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
       const uint32_t mk = hopW[r];
       if (mk == 0 || !bit_at(r))
         continue;
-      const uint32_t q = rank0 + (mk & 0xffffu) - 1u;
-      const Node nd = unpack_node(list[q]);
-      const Grid g1 = t.grids[nd.grid + 1];   // the grid of the children
+      const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
+      const Grid g1 = sh_grids[nd.grid + 1];   // the grid of the children
       uint32_t slotB = sh_baseB + (hop64[r] & 0xffffu), slotL = sh_baseL + (hop64[r] >> 16);
       uint32_t y = r + 1, found = 0;
 #pragma unroll
@@ -1337,6 +1355,13 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
         }
         y += u;
       }
+    }
+    if (l1stamps) {
+      const uint64_t now_ = __builtin_readcyclecounter();
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 56), 1ull);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 57), l1t1 - l1t0);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 58), l1t2 - l1t1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 59), now_ - l1t2);
     }
     if (sh_last) {
       if (tid == 0) {
@@ -2399,7 +2424,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     }
   }
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
-  const uint32_t l0Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 512 / nc));
+  static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
+  const uint32_t l0Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l0Total / nc));
   if (plan.tables && plan.l0) {
     static bool l0_attr = false;
     if (!l0_attr) {
@@ -2410,7 +2436,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       l0_attr = true;
     }
   }
-  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, 768 / nc));
+  // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
+  static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
+  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l1Total / nc));
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);

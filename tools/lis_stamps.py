@@ -27,3 +27,7 @@ for k in range(1, 16):
     w, t, b = out[16 + k], out[32 + k], out[48 + k]
     if w:
         print(k, w, t, t // w, b, b // w)
+
+if out[56]:
+    print("k_lis_l1 chunk 0: blocks", out[56], "ticks/block: tables+memo", out[57] // out[56],
+          "look-back wait", out[58] // out[56], "marks+sweeps", out[59] // out[56])
