@@ -687,6 +687,18 @@ int reset_enc_pass(hipStream_t st, const EncBatchBufs& bb, uint32_t B)
   return 0;
 }
 
+// the transform starts with the full-size x pass followed by the full-size y pass (every dyadic
+// shape; wavelet-packet shapes start along z), and the rows fit the fused kernel's LDS tile
+bool fuse_xy(const ShapePlan& P)
+{
+  if (P.fwd.size() < 2 || P.fwd[0].axis != 0 || P.fwd[1].axis != 1)
+    return false;
+  for (int a = 0; a < 3; a++)
+    if (P.fwd[0].region[a] != P.dims[a] || P.fwd[1].region[a] != P.dims[a])
+      return false;
+  return lift_xy_applicable(P.dims);
+}
+
 // PSNR mode (src/SPECK_FLT.cpp:268-279,431-435): per chunk q = 2 sqrt(3 t), t = range^2 10^(-psnr/10),
 // divided by 2^(1/4) until the estimated quantisation error is at most t.  The libm calls run on
 // the host (the same libm the reference uses), the error estimate on the device with the
@@ -850,7 +862,14 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
       if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
                               bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, !rate))
         return -1;
-      for (size_t k = 0; k < P->fwd.size(); k++) {
+      size_t k0 = 0;
+      if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume
+        if (launch_lift_xy(st, true, bb.vals, bb.valsStride, nb, cd, e.cst, io,
+                           const_cast<T*>(d_src), vd, bb.geom))
+          return -1;
+        k0 = 2;
+      }
+      for (size_t k = k0; k < P->fwd.size(); k++) {
         const LiftPass& ps = P->fwd[k];
         if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
                         k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom))
@@ -1257,12 +1276,16 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
             return -1;
         }
         // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters
-        for (size_t k = P->fwd.size(); k-- > 0;) {
+        const bool fxy = fuse_xy(*P);
+        for (size_t k = P->fwd.size(); k-- > (fxy ? 2u : 0u);) {
           const LiftPass& ps = P->fwd[k];
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
                           k == 0 ? (std::is_same<T, float>::value ? 1 : 2) : 0, d_dst, vd, bb.geom))
             return -1;
         }
+        if (fxy && launch_lift_xy(ss, false, bb.vals, bb.valsStride, nb, cd, d.cst,
+                                  std::is_same<T, float>::value ? 1 : 2, d_dst, vd, bb.geom))
+          return -1;
         if (P->fwd.empty() &&
             launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
           return -1;

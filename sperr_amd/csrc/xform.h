@@ -31,6 +31,13 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
                 const CoderState* st, int io = 0, void* volume = nullptr, VolDesc vd = VolDesc{},
                 const ChunkGeom* geom = nullptr);
 
+// The x and y passes of the finest level fused with the volume access (forward: volume -> vals,
+// inverse: vals -> volume); only for chunks whose first two passes are the full-size x and y ones.
+bool lift_xy_applicable(const uint32_t cdims[3]);
+int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsStride,
+                   uint32_t nchunks, const uint32_t cdims[3], const CoderState* st, int io,
+                   void* volume, VolDesc vd, const ChunkGeom* geom);
+
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
                     uint32_t n, CoderState* st);
 int launch_make_q_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);

@@ -324,6 +324,223 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
 }
 
 // ------------------------------------------------------------------------------------------
+// The two passes of the finest level that touch the volume, fused: forward x-lift then y-lift
+// (volume -> fp64 buffer), inverse y-lift then x-lift (fp64 buffer -> volume).  A workgroup owns
+// R rows of one z-slice and stages them in LDS together with a halo of 4 rows on each side: the
+// four lifting steps reach one row further each, so rows y0-4 .. y0+R+3 determine the R rows
+// exactly (the symmetric boundary rule only ever refers to rows of the slice itself).  Every
+// sample goes through the very same operations as in k_lift_axis; halo rows are recomputed by the
+// neighbouring tiles.  Saves one full read + write of the fp64 buffer per direction.
+//   x direction: threads = (row, slice of the row), lifting steps separated by barriers;
+//   y direction: one thread per column, all steps in sequence, no barrier.
+// ------------------------------------------------------------------------------------------
+constexpr int kXYHalo = 4;
+constexpr int kXYThreads = 1024;
+constexpr int kXYSplit = 4;        // threads per column in the y direction
+
+template <bool FORWARD, int IO>
+__global__ void __launch_bounds__(kXYThreads)
+k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, int R,
+          LiftConsts K, const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom)
+{
+  static_assert(IO == 1 || IO == 2, "float or double volume");
+  using VT = typename std::conditional<IO == 1, float, double>::type;
+  const uint32_t c = blockIdx.y;
+  const bool is_const = st[c].is_const != 0;
+  if (is_const && FORWARD)
+    return;
+  double* sm = reinterpret_cast<double*>(dyn_smem);
+  const uint32_t ntile = (cy + R - 1) / R;
+  const uint32_t z = blockIdx.x / ntile, y0 = (blockIdx.x % ntile) * R;
+  const uint32_t ylo = y0 >= (uint32_t)kXYHalo ? y0 - kXYHalo : 0u;
+  const uint32_t yhi = min(cy, y0 + R + kXYHalo);       // rows [ylo, yhi) are staged
+  const uint32_t yend = min(cy, y0 + R);                // rows [y0, yend) are this tile's output
+  const uint32_t nrow = yhi - ylo;
+  const uint32_t RS = cx + 1;                           // row stride in LDS
+  const uint32_t xe = cx - cx / 2, xo = cx / 2;         // even / odd samples of a row
+  const uint32_t ye = cy - cy / 2, yo = cy / 2;
+  const ChunkGeom g = geom[c];
+  VT* vol = reinterpret_cast<VT*>(volume);
+  const size_t vsy = vd.dims[0], vsz = (size_t)vd.dims[0] * vd.dims[1];
+  const size_t vbase = (size_t)(g.org[2] + z) * vsz + (size_t)g.org[1] * vsy + g.org[0];
+  double* buf = vals + c * valsStride + (size_t)z * cx * cy;
+  const double mean = st[c].mean;
+  const uint32_t tid = threadIdx.x;
+
+  if (is_const) {   // inverse only: the chunk is its constant
+    for (uint32_t k = tid; k < (yend - y0) * cx; k += kXYThreads)
+      vol[vbase + (size_t)(y0 + k / cx) * vsy + k % cx] = (VT)mean;
+    return;
+  }
+
+  // ---- stage the rows.  In LDS everything is interleaved (sample x of row y at [y - ylo][x]).
+  for (uint32_t k = tid; k < nrow * cx; k += kXYThreads) {
+    const uint32_t j = k / cx, x = k % cx, y = ylo + j;
+    double v;
+    if (FORWARD)
+      v = (double)vol[vbase + (size_t)y * vsy + x] - mean;
+    else   // the buffer holds low | high halves along x and along y
+      v = buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + ((x & 1) ? xe + (x >> 1) : (x >> 1))];
+    sm[j * RS + x] = v;
+  }
+  __syncthreads();
+
+  // x direction: lane = row, so LDS accesses of a wavefront differ by the (odd) row stride
+  auto lift_x = [&](uint32_t jlo, uint32_t jhi) {          // staged rows [jlo, jhi)
+    const uint32_t NR = 32;                               // rows handled side by side
+    const uint32_t l = tid % NR, k0 = tid / NR, kg = kXYThreads / NR;
+    for (uint32_t rb = jlo; rb < jhi; rb += NR) {
+      const bool on = rb + l < jhi;
+      double* row = sm + (size_t)(rb + l) * RS;
+#define EV(i) row[2 * (i)]
+#define OD(i) row[2 * (i) + 1]
+      auto odd_step = [&](double k) {
+        if (on)
+          for (uint32_t i = k0; i < xo; i += kg) {
+            const uint32_t r = min(i + 1, xe - 1);
+            OD(i) = fma(k, EV(i) + EV(r), OD(i));
+          }
+        __syncthreads();
+      };
+      auto even_step = [&](double k) {
+        if (on)
+          for (uint32_t i = k0; i < xe; i += kg) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
+            EV(i) = fma(k, OD(a) + OD(b2), EV(i));
+          }
+        __syncthreads();
+      };
+      if (FORWARD) {  // src/CDF97.cpp:598-631
+        odd_step(K.alpha);
+        even_step(K.beta);
+        odd_step(K.gamma);
+        if (on)
+          for (uint32_t i = k0; i < xe; i += kg) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
+            EV(i) = K.eps * fma(K.delta, OD(a) + OD(b2), EV(i));
+          }
+        __syncthreads();
+        if (on)
+          for (uint32_t i = k0; i < xo; i += kg)
+            OD(i) = (-K.inv_eps) * OD(i);
+        __syncthreads();
+      }
+      else {          // src/CDF97.cpp:633-666
+        if (on)
+          for (uint32_t i = k0; i < xo; i += kg)
+            OD(i) = (-K.eps) * OD(i);
+        __syncthreads();
+        if (on)
+          for (uint32_t i = k0; i < xe; i += kg) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
+            const double t = K.delta * (OD(a) + OD(b2));
+            EV(i) = fma(EV(i), K.inv_eps, -t);
+          }
+        __syncthreads();
+        odd_step(-K.gamma);
+        even_step(-K.beta);
+        odd_step(-K.alpha);
+      }
+#undef EV
+#undef OD
+    }
+  };
+
+  // y direction: one thread per column; row y of the slice is even sample y/2 or odd sample y/2.
+  // Neighbours outside the staged rows are clamped into them: what they feed never reaches the
+  // tile's own rows (see above).
+  auto lift_y = [&]() {
+    // columns are handled in groups of kXYThreads / kXYSplit; thread (x, h) takes part h of the samples
+    const uint32_t h = tid % kXYSplit;
+    const uint32_t e_lo = (ylo + 1) / 2, e_hi = (yhi + 1) / 2;   // even samples i: row 2i staged
+    const uint32_t o_lo = ylo / 2, o_hi = yhi / 2;               // odd samples i: row 2i+1 staged
+    const uint32_t ea = e_lo + (e_hi - e_lo) * h / kXYSplit, eb = e_lo + (e_hi - e_lo) * (h + 1) / kXYSplit;
+    const uint32_t oa = o_lo + (o_hi - o_lo) * h / kXYSplit, ob = o_lo + (o_hi - o_lo) * (h + 1) / kXYSplit;
+    for (uint32_t xb = 0; xb < cx; xb += kXYThreads / kXYSplit) {
+      const uint32_t x = xb + tid / kXYSplit;
+      const bool on = x < cx;
+      double* col = sm + x;
+      auto at = [&](uint32_t y) -> double& {   // sample of slice row y (clamped to the staged rows)
+        const uint32_t yy = min(max(y, ylo), yhi - 1);
+        return col[(size_t)(yy - ylo) * RS];
+      };
+      auto EVy = [&](uint32_t i) -> double& { return at(2 * i); };
+      auto ODy = [&](uint32_t i) -> double& { return at(2 * i + 1); };
+      auto odd_step = [&](double k) {
+        if (on)
+          for (uint32_t i = oa; i < ob; i++) {
+            const uint32_t r = min(i + 1, ye - 1);
+            ODy(i) = fma(k, EVy(i) + EVy(r), ODy(i));
+          }
+        __syncthreads();
+      };
+      auto even_step = [&](double k) {
+        if (on)
+          for (uint32_t i = ea; i < eb; i++) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
+            EVy(i) = fma(k, ODy(a) + ODy(b2), EVy(i));
+          }
+        __syncthreads();
+      };
+      if (FORWARD) {
+        odd_step(K.alpha);
+        even_step(K.beta);
+        odd_step(K.gamma);
+        if (on)
+          for (uint32_t i = ea; i < eb; i++) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
+            EVy(i) = K.eps * fma(K.delta, ODy(a) + ODy(b2), EVy(i));
+          }
+        __syncthreads();
+        if (on)
+          for (uint32_t i = oa; i < ob; i++)
+            ODy(i) = (-K.inv_eps) * ODy(i);
+        __syncthreads();
+      }
+      else {
+        if (on)
+          for (uint32_t i = oa; i < ob; i++)
+            ODy(i) = (-K.eps) * ODy(i);
+        __syncthreads();
+        if (on)
+          for (uint32_t i = ea; i < eb; i++) {
+            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
+            const double t = K.delta * (ODy(a) + ODy(b2));
+            EVy(i) = fma(EVy(i), K.inv_eps, -t);
+          }
+        __syncthreads();
+        odd_step(-K.gamma);
+        even_step(-K.beta);
+        odd_step(-K.alpha);
+      }
+    }
+  };
+
+  if (FORWARD) {
+    if (cx >= 2)
+      lift_x(0, nrow);
+    if (cy >= 2)
+      lift_y();
+    // ---- store this tile's rows, low | high halves along both axes
+    for (uint32_t k = tid; k < (yend - y0) * cx; k += kXYThreads) {
+      const uint32_t y = y0 + k / cx, x = k % cx;
+      buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + ((x & 1) ? xe + (x >> 1) : (x >> 1))] =
+          sm[(size_t)(y - ylo) * RS + x];
+    }
+  }
+  else {
+    if (cy >= 2)
+      lift_y();
+    if (cx >= 2)
+      lift_x(y0 - ylo, yend - ylo);   // (only the tile's own rows go on)
+    for (uint32_t k = tid; k < (yend - y0) * cx; k += kXYThreads) {
+      const uint32_t y = y0 + k / cx, x = k % cx;
+      vol[vbase + (size_t)y * vsy + x] = (VT)(sm[(size_t)(y - ylo) * RS + x] + mean);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // quantiser
 // ------------------------------------------------------------------------------------------
 
@@ -614,6 +831,65 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
       LAUNCH_K((k_lift_axis<false, 0>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
   }
 #undef LIFT_ARGS
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// rows per tile of k_lift_xy for rows of cx samples, 0 when the fused kernel does not apply
+static int xy_rows(uint32_t cx, uint32_t cy)
+{
+  if (cx < 2 || cy < 2)
+    return 0;
+  const size_t rowBytes = (size_t)(cx + 1) * sizeof(double);
+  int rows = (int)((68 * 1024) / rowBytes);
+  if (rows > 32)
+    rows = 32;
+  int R = (rows - 2 * kXYHalo) & ~1;
+  if ((uint32_t)R > cy)
+    R = (int)((cy + 1) & ~1u);
+  return R >= 8 ? R : 0;
+}
+
+bool lift_xy_applicable(const uint32_t cdims[3])
+{
+  return xy_rows(cdims[0], cdims[1]) > 0;
+}
+
+int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsStride,
+                   uint32_t nchunks, const uint32_t cdims[3], const CoderState* st, int io,
+                   void* volume, VolDesc vd, const ChunkGeom* geom)
+{
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_lift_xy<true, 1>),
+                          reinterpret_cast<const void*>(&k_lift_xy<true, 2>),
+                          reinterpret_cast<const void*>(&k_lift_xy<false, 1>),
+                          reinterpret_cast<const void*>(&k_lift_xy<false, 2>)};
+    for (const void* f : fns)
+      HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int R = xy_rows(cdims[0], cdims[1]);
+  if (R <= 0 || (io != 1 && io != 2))
+    return -1;
+  const size_t smem = (size_t)(R + 2 * kXYHalo) * (cdims[0] + 1) * sizeof(double);
+  const uint32_t ntile = (cdims[1] + R - 1) / R;
+  const dim3 grid(ntile * cdims[2], nchunks);
+  const LiftConsts K = lift_consts();
+#define XY_ARGS vals, valsStride, cdims[0], cdims[1], cdims[2], R, K, st, volume, vd, geom
+  if (forward) {
+    if (io == 1)
+      LAUNCH_K((k_lift_xy<true, 1>), grid, dim3(kXYThreads), smem, stream, XY_ARGS);
+    else
+      LAUNCH_K((k_lift_xy<true, 2>), grid, dim3(kXYThreads), smem, stream, XY_ARGS);
+  }
+  else {
+    if (io == 1)
+      LAUNCH_K((k_lift_xy<false, 1>), grid, dim3(kXYThreads), smem, stream, XY_ARGS);
+    else
+      LAUNCH_K((k_lift_xy<false, 2>), grid, dim3(kXYThreads), smem, stream, XY_ARGS);
+  }
+#undef XY_ARGS
   HIP_CHECK(hipGetLastError());
   return 0;
 }
