@@ -374,14 +374,19 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
   }
 
   // ---- stage the rows.  In LDS everything is interleaved (sample x of row y at [y - ylo][x]).
-  for (uint32_t k = tid; k < nrow * cx; k += kXYThreads) {
-    const uint32_t j = k / cx, x = k % cx, y = ylo + j;
-    double v;
-    if (FORWARD)
-      v = (double)vol[vbase + (size_t)y * vsy + x] - mean;
-    else   // the buffer holds low | high halves along x and along y
-      v = buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + ((x & 1) ? xe + (x >> 1) : (x >> 1))];
-    sm[j * RS + x] = v;
+  const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYThreads / 64;
+  for (uint32_t j = wave; j < nrow; j += nwaves) {   // one wavefront per row
+    const uint32_t y = ylo + j;
+    if (FORWARD) {
+      const VT* src = vol + vbase + (size_t)y * vsy;
+      for (uint32_t x = lane; x < cx; x += 64)
+        sm[j * RS + x] = (double)src[x] - mean;
+    }
+    else {   // the buffer holds low | high halves along x and along y
+      const double* src = buf + (size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx;
+      for (uint32_t x = lane; x < cx; x += 64)
+        sm[j * RS + x] = src[(x & 1) ? xe + (x >> 1) : (x >> 1)];
+    }
   }
   __syncthreads();
 
@@ -522,10 +527,11 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
     if (cy >= 2)
       lift_y();
     // ---- store this tile's rows, low | high halves along both axes
-    for (uint32_t k = tid; k < (yend - y0) * cx; k += kXYThreads) {
-      const uint32_t y = y0 + k / cx, x = k % cx;
-      buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + ((x & 1) ? xe + (x >> 1) : (x >> 1))] =
-          sm[(size_t)(y - ylo) * RS + x];
+    for (uint32_t y = y0 + wave; y < yend; y += nwaves) {
+      double* dstrow = buf + (size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx;
+      const double* srow = sm + (size_t)(y - ylo) * RS;
+      for (uint32_t x = lane; x < cx; x += 64)
+        dstrow[(x & 1) ? xe + (x >> 1) : (x >> 1)] = srow[x];
     }
   }
   else {
@@ -533,9 +539,11 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
       lift_y();
     if (cx >= 2)
       lift_x(y0 - ylo, yend - ylo);   // (only the tile's own rows go on)
-    for (uint32_t k = tid; k < (yend - y0) * cx; k += kXYThreads) {
-      const uint32_t y = y0 + k / cx, x = k % cx;
-      vol[vbase + (size_t)y * vsy + x] = (VT)(sm[(size_t)(y - ylo) * RS + x] + mean);
+    for (uint32_t y = y0 + wave; y < yend; y += nwaves) {
+      VT* dstrow = vol + vbase + (size_t)y * vsy;
+      const double* srow = sm + (size_t)(y - ylo) * RS;
+      for (uint32_t x = lane; x < cx; x += 64)
+        dstrow[x] = (VT)(srow[x] + mean);
     }
   }
 }
