@@ -97,6 +97,9 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
 /* When enabled, the engine brackets every pipeline stage with HIP events on the launch stream
  * and accumulates their durations. */
 void sperrhip_profile_enable(int on);
+/* Restrict the bracketing to one kernel (a name sperrhip_profile_get reported; NULL or "" = all):
+ * two event records per launch of every kernel cost a few percent of a step. */
+void sperrhip_profile_only(const char* kernel);
 void sperrhip_profile_reset(void);
 /* Fills up to `cap` entries; returns the number of stages. names[i] points to a static string. */
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap);

@@ -19,7 +19,7 @@ EXPORTS = [
     "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
-    "sperrhip_profile_get", "sperrhip_version", "sperrhip_debug_lis_stamps",
+    "sperrhip_profile_get", "sperrhip_profile_only", "sperrhip_version", "sperrhip_debug_lis_stamps",
 ]
 
 
@@ -64,6 +64,7 @@ def load_library():
     lib.sperrhip_speck3d_decode_dev.argtypes = [_vp, _sz, _sz, _sz, _sz, _vp, _vp,
                                                 C.POINTER(C.c_int), _vp]
     lib.sperrhip_profile_enable.argtypes = [C.c_int]
+    lib.sperrhip_profile_only.argtypes = [C.c_char_p]
     lib.sperrhip_profile_get.restype = C.c_int
     lib.sperrhip_profile_get.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                          C.POINTER(C.c_int), C.c_int]
@@ -229,7 +230,9 @@ class SperrHip:
         return out.reshape(dz.value, dy.value, dx.value)
 
     # ---- profiling ------------------------------------------------------------------------
-    def profile(self, on=True):
+    def profile(self, on=True, only=None):
+        """Bracket kernel launches with HIP events; `only`: just that kernel (cheap)."""
+        self.lib.sperrhip_profile_only(only.encode() if only else None)
         self.lib.sperrhip_profile_enable(int(on))
         if on:
             self.lib.sperrhip_profile_reset()

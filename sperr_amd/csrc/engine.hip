@@ -39,6 +39,7 @@ struct ProfEntry {
 
 struct Profiler {
   bool on = false;
+  std::string only;   // when not empty: only launches of this kernel are bracketed
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   struct Open {
@@ -81,7 +82,7 @@ Profiler g_prof;
 
 void prof_begin(const char* name, hipStream_t stream)
 {
-  if (!g_prof.on)
+  if (!g_prof.on || (!g_prof.only.empty() && g_prof.only != name))
     return;
   g_prof.cur = name;
   g_prof.curA = g_prof.get();
@@ -1388,6 +1389,10 @@ const char* sperrhip_version(void)
 void sperrhip_profile_enable(int on)
 {
   g_prof.on = on != 0;
+}
+void sperrhip_profile_only(const char* kernel)
+{
+  g_prof.only = kernel ? kernel : "";
 }
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
 {
