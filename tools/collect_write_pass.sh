@@ -1,0 +1,11 @@
+#!/bin/bash
+# The WRITE_SIZE counter pass on its own box (as the third profiler run of one session it has
+# wedged twice before the first kernel of the workload): bash tools/collect_write_pass.sh <tag>
+set -u
+tag=${1:-r1}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o run -- python3 bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
+echo "write rc=$?"

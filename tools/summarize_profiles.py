@@ -37,9 +37,10 @@ def pmc(which):
 
 fetch, write = pmc("fetch"), pmc("write")
 steps = max(1, fetch["k_enc_finalize"][1])          # one launch per compress
+wsteps = max(1, write["k_enc_finalize"][1])
 rows = {}
 for k in sorted(set(fetch) | set(write)):
-    f_kb, w_kb = fetch[k][0] / steps, write[k][0] / steps
+    f_kb, w_kb = fetch[k][0] / steps, write[k][0] / wsteps
     rows[k] = {
         "launches_per_step": fetch[k][1] / steps,
         "fetch_KB_raw": round(f_kb, 1),
