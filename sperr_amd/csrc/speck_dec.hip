@@ -2284,33 +2284,51 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 // refinement: the j-th pixel that was significant before this plane takes bit pos + j
 // ------------------------------------------------------------------------------------------
+// Four tiles per workgroup (one per group of 256 threads): a grid sized for every tile costs a
+// quarter as many workgroups on the planes where most tiles hold nothing.
+constexpr int kRefGroups = 4;
+
 template <typename CT>
-__global__ void __launch_bounds__(kThreads) k_ref_apply(DecBuffers b, int p)
+__global__ void __launch_bounds__(kThreads * kRefGroups) k_ref_apply(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
-  if (b.tileRef[c * b.tileStride + blockIdx.x] == 0)
-    return;
-  __shared__ uint32_t sm[kThreads / 64 + 1];
-  __shared__ uint32_t wordBase[kDecTileWords];   // refinement candidates before each word
-  __shared__ uint64_t wordSig[kDecTileWords];
+  __shared__ uint32_t sm[kRefGroups][kThreads / 64 + 1];
+  __shared__ uint32_t wordBaseAll[kRefGroups][kDecTileWords];   // refinement candidates before each word
+  __shared__ uint64_t wordSigAll[kRefGroups][kDecTileWords];
+  const uint32_t grp = threadIdx.x / kThreads, gt = threadIdx.x % kThreads;
+  const uint32_t tile = blockIdx.x * kRefGroups + grp;
+  const bool on = tile < b.nPixTiles && b.tileRef[c * b.tileStride + tile] != 0;
+  uint32_t* wordBase = wordBaseAll[grp];
+  uint64_t* wordSig = wordSigAll[grp];
   const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint32_t w0 = blockIdx.x * kDecTileWords;
+  const uint32_t w0 = tile * kDecTileWords;
   {
-    const uint32_t wi = w0 + threadIdx.x;
-    const uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
-    uint32_t total;
-    wordBase[threadIdx.x] = block_exclusive_scan<uint32_t>((uint32_t)__popcll(sig), sm, &total);
-    wordSig[threadIdx.x] = sig;
+    // exclusive scan of the popcounts inside the group's 256 threads (4 wavefronts)
+    const uint32_t wi = w0 + gt;
+    const uint64_t sig = (on && wi < nw) ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
+    const uint32_t cnt = (uint32_t)__popcll(sig);
+    const uint32_t inc = wave_inclusive_scan<uint32_t>(cnt);
+    const uint32_t lane = gt & 63u, wave = gt >> 6;
+    if (lane == 63)
+      sm[grp][wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++)
+      base += sm[grp][w];
+    wordBase[gt] = base + inc - cnt;
+    wordSig[gt] = sig;
   }
   __syncthreads();
-  const uint64_t base = s.pos + (uint64_t)b.tileRefOff[c * b.tileStride + blockIdx.x];
+  if (!on)
+    return;
+  const uint64_t base = s.pos + (uint64_t)b.tileRefOff[c * b.tileStride + tile];
   const uint64_t* words = b.stream + c * b.streamStride;
   CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
   const CT thr = (CT)1 << p, half = thr / 2;
   const CT initPrev = thr * 2 + thr * 2 - thr - 1;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = gt & 63u, wave = gt >> 6;
   // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous
   for (uint32_t k = wave; k < (uint32_t)kDecTileWords; k += kThreads / 64) {
     const uint64_t sig = wordSig[k];
@@ -2463,7 +2481,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       else
         LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_ref_apply<uint64_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
+               dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     else {
       LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -2483,7 +2502,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint32_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
+               dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
   }
