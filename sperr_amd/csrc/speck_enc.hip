@@ -305,8 +305,11 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
   if (!s.active || s.done)
     return;
   // bin q + 1 counts value q (-1 .. kMaxPlanes - 1); one set of histograms per wavefront
-  __shared__ uint32_t hist[kThreads / 64][3][kMaxPlanes + 1];
-  for (uint32_t i = threadIdx.x; i < (kThreads / 64) * 3 * (kMaxPlanes + 1); i += kThreads)
+  // [0]: msb, low half = all samples, high half = those that sit in the LIP before they become
+  // significant (bp > msb >= 0); [1]: birth plane.  (A wavefront's share of a tile is 1024
+  // samples, so 16 bits per half are plenty.)
+  __shared__ uint32_t hist[kThreads / 64][2][kMaxPlanes + 1];
+  for (uint32_t i = threadIdx.x; i < (kThreads / 64) * 2 * (kMaxPlanes + 1); i += kThreads)
     (&hist[0][0][0])[i] = 0;
   __syncthreads();
   const uint32_t n = b.tree.nvals;
@@ -319,10 +322,8 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
 #pragma unroll
     for (int k = 0; k < kPixPer; k++)
       if (i0 + k < n) {
-        atomicAdd(&hist[wave][0][m[k] + 1], 1u);
+        atomicAdd(&hist[wave][0][m[k] + 1], (m[k] >= 0 && bp[k] > m[k]) ? 0x10001u : 1u);
         atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
-        if (m[k] >= 0 && bp[k] > m[k])
-          atomicAdd(&hist[wave][2][m[k] + 1], 1u);
       }
   }
   __syncthreads();
@@ -331,14 +332,14 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
     uint32_t le_m = 0, le_b = 0, all_m = 0, eq = 0;
     for (int w = 0; w < kThreads / 64; w++) {
       for (int q = 0; q <= kMaxPlanes; q++) {
-        const uint32_t hm = hist[w][0][q];
+        const uint32_t hm = hist[w][0][q] & 0xffffu;
         all_m += hm;
         if (q <= p + 1) {
           le_m += hm;
           le_b += hist[w][1][q];
         }
       }
-      eq += hist[w][2][p + 1];
+      eq += hist[w][0][p + 1] >> 16;
     }
     uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
     cnt[(size_t)(p * 2 + 0) * b.nPixTiles + blockIdx.x] = le_m - le_b + eq;   // LIP scan bits
