@@ -860,8 +860,12 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
       // subtract the mean); chunks too small to be transformed take the plain gather kernel
       const bool fuse = !P->fwd.empty();
       const int io = std::is_same<T, float>::value ? 1 : 2;
+      bool orgAligned = true;   // (lets the conditioner stream rows with 16-byte loads)
+      for (uint32_t i = 0; i < nb; i++)
+        orgAligned = orgAligned && hg[i].org[0] % (16 / sizeof(T)) == 0;
       if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
-                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, !rate))
+                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, !rate,
+                              orgAligned))
         return -1;
       size_t k0 = 0;
       if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume

@@ -17,7 +17,8 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st, bool gather, bool want_range = false);
+                     size_t valsStride, CoderState* st, bool gather, bool want_range = false,
+                     bool org_x_aligned = false);   // every chunk's x origin is a multiple of 16 bytes
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,

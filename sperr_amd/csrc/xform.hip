@@ -89,6 +89,62 @@ k_stride_sums(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint
   }
 }
 
+// The same sums when a stride is a whole number of chunk rows (every power-of-two chunk): one
+// thread per stride streams its rows with 16-byte loads, several in flight, and adds them in
+// order.  Eight wavefronts per CU keep enough bytes in flight to follow HBM.
+template <typename T>
+__global__ void __launch_bounds__(64)
+k_stride_sums_rows(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint32_t cx,
+                   uint32_t cy, uint32_t nstrides, uint32_t ssz, double* strideMean,
+                   size_t strideMeanStride, CoderState* st, int want_range)
+{
+  constexpr int V = 16 / sizeof(T);                 // samples per 16-byte load
+  struct alignas(16) Pack { T v[V]; };
+  const uint32_t c = blockIdx.y;
+  const uint32_t sidx = blockIdx.x * 64 + threadIdx.x;
+  const ChunkGeom g = geom[c];
+  const size_t vx = vd.dims[0], vy = vd.dims[1];
+  const T first = vol[((size_t)g.org[2] * vy + g.org[1]) * vx + g.org[0]];
+  double acc = 0.0, vmax = -INFINITY, vnegmax = -INFINITY;
+  bool differs = false;
+  if (sidx < nstrides) {
+    const uint32_t rows = ssz / cx, row0 = sidx * rows;   // chunk rows of this stride
+    for (uint32_t r = 0; r < rows; r++) {
+      const uint32_t y = (row0 + r) % cy, z = (row0 + r) / cy;
+      const T* src = vol + ((size_t)(g.org[2] + z) * vy + (g.org[1] + y)) * vx + g.org[0];
+      for (uint32_t x = 0; x < cx; x += 8 * V) {
+        Pack pk[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          pk[k] = *reinterpret_cast<const Pack*>(src + x + k * V);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int e = 0; e < V; e++) {
+            const T v = pk[k].v[e];
+            differs |= (v != first);
+            acc += (double)v;
+            vmax = fmax(vmax, (double)v);
+            vnegmax = fmax(vnegmax, -(double)v);
+          }
+      }
+    }
+    strideMean[c * strideMeanStride + sidx] = acc / (double)ssz;
+  }
+  if (__any(differs) && threadIdx.x == 0)
+    st[c].not_const_flag = 1;
+  if (want_range) {
+    for (int d = 32; d > 0; d >>= 1) {
+      vmax = fmax(vmax, __shfl_xor(vmax, d, 64));
+      vnegmax = fmax(vnegmax, __shfl_xor(vnegmax, d, 64));
+    }
+    if (threadIdx.x == 0) {
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].vmaxKey), order_key(vmax));
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].vnegmaxKey), order_key(vnegmax));
+    }
+  }
+}
+
 template <typename T>
 __global__ void k_mean_finalize(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
                                 uint32_t nstrides, const double* strideMean,
@@ -906,14 +962,24 @@ template <typename T>
 int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGeom* geom,
                      uint32_t nchunks, const uint32_t cdims[3], uint32_t nstrides,
                      double* strideMean, size_t strideMeanStride, double* vals,
-                     size_t valsStride, CoderState* st, bool gather, bool want_range)
+                     size_t valsStride, CoderState* st, bool gather, bool want_range,
+                     bool org_x_aligned)
 {
   const uint32_t n = cdims[0] * cdims[1] * cdims[2];
   const uint32_t ssz = n / nstrides;
-  LAUNCH_K(k_stride_sums<T>, dim3((nstrides + kSumStrides - 1) / kSumStrides, nchunks),
-           dim3(kThreads), 0, stream,
-                     vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz, strideMean,
-                     strideMeanStride, st, want_range ? 1 : 0);
+  // rows of whole 128-byte pieces, 16-byte aligned in the volume, a stride = whole rows
+  const uint32_t perLoad = 8 * (16 / (uint32_t)sizeof(T));
+  const bool rowsPath = cdims[0] % perLoad == 0 && ssz % cdims[0] == 0 &&
+                        vd.dims[0] % (16 / sizeof(T)) == 0 &&
+                        reinterpret_cast<uintptr_t>(vol) % 16 == 0 && org_x_aligned;
+  if (rowsPath)
+    LAUNCH_K(k_stride_sums_rows<T>, dim3((nstrides + 63) / 64, nchunks), dim3(64), 0, stream, vol,
+             vd, geom, cdims[0], cdims[1], nstrides, ssz, strideMean, strideMeanStride, st,
+             want_range ? 1 : 0);
+  else
+    LAUNCH_K(k_stride_sums<T>, dim3((nstrides + kSumStrides - 1) / kSumStrides, nchunks),
+             dim3(kThreads), 0, stream, vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz,
+             strideMean, strideMeanStride, st, want_range ? 1 : 0);
   LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(1), 0, stream, vol, vd, geom,
                      nstrides, strideMean, strideMeanStride, st);
   if (gather)   // otherwise the first lifting pass reads the volume itself
@@ -924,10 +990,10 @@ int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGe
 }
 template int launch_condition<float>(hipStream_t, const float*, VolDesc, const ChunkGeom*,
                                      uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                     double*, size_t, CoderState*, bool, bool);
+                                     double*, size_t, CoderState*, bool, bool, bool);
 template int launch_condition<double>(hipStream_t, const double*, VolDesc, const ChunkGeom*,
                                       uint32_t, const uint32_t[3], uint32_t, double*, size_t,
-                                      double*, size_t, CoderState*, bool, bool);
+                                      double*, size_t, CoderState*, bool, bool, bool);
 
 template <typename T>
 int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom,
