@@ -1002,7 +1002,10 @@ constexpr int kL1MaxTok = 137;
 constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1W * (4 + 1) +
                            (size_t)kL1P * 2;
 
-__global__ void __launch_bounds__(kL0Threads) k_lis_l1(DecBuffers b, int p)
+// (eight waves per SIMD = two of these workgroups per CU: the phases are barrier- and latency-
+//  bound, a second resident workgroup fills the gaps)
+__global__ void __launch_bounds__(kL0Threads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_lis_l1(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   DecState& s = b.st[c];
