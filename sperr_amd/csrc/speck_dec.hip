@@ -1580,6 +1580,16 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     }
     const LevelClass C = b.levelClass[l];
     const int K = C.K;
+    // children of a class-j set and the LIS level of class j, one byte per class, in registers:
+    // indexing the struct would be a scratch (vector-memory) load, and those queue behind every
+    // global store a thread has in flight
+    uint64_t arityP = 0, levP = 0;
+    for (int j = 0; j < K && j < 8; j++) {
+      arityP |= (uint64_t)C.arity[j] << (8 * j);
+      levP |= (uint64_t)C.lev[j] << (8 * j);
+    }
+    auto arity_of = [&](int j) -> int { return (int)((arityP >> (8 * j)) & 0xffull); };
+    auto lev_of = [&](int j) -> uint32_t { return (uint32_t)((levP >> (8 * j)) & 0xffull); };
     W = tab_window(K, b.tabSmemBytes);
     TS = W + 2;
     const uint32_t kWords = W / 64 + 4;
@@ -1601,7 +1611,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     // classes (8 children) take straight-line code: an item that leaves the window parks the
     // cursor on index W + 1, whose entries are kTInf in every table, so there is no early exit.
     auto split_len = [&](int j, uint32_t r) -> uint32_t {
-      const int ar = C.arity[j];
+      const int ar = arity_of(j);
       if (j == 0) {
         if (r >= W)
           return kTInf;
@@ -1772,7 +1782,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           if (coded) {
             const uint32_t u = r < W ? Uu[(size_t)cls * TS + r] : kTInf;
             if (u == 1) {  // insignificant
-              record_born(C.lev[cls], a + r, kid);
+              record_born(lev_of(cls), a + r, kid);
               cx.remaining--;
               cx.nextOrd++;
               r += 1;
@@ -1809,7 +1819,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             r = start;
             TabCtx& nc = sh_ctx[depth];
             nc.parent = kid;
-            nc.remaining = C.arity[cls];
+            nc.remaining = arity_of(cls);
             nc.cls = (int8_t)(cls - 1);
             nc.found = 0;
             nc.nextOrd = 0;
@@ -1962,7 +1972,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             // the entry at the very start of the window does not fit: walk into it
             TabCtx& nc = sh_ctx[1];
             nc.parent = list[e];
-            nc.remaining = C.arity[K - 1];
+            nc.remaining = arity_of(K - 1);
             nc.cls = (int8_t)(K - 2);
             nc.found = 0;
             nc.nextOrd = 0;
@@ -1999,7 +2009,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
           const int cls = (int)((meta >> 1) & 0x7f);
           uint32_t y = (uint32_t)(meta >> 8);
           const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
-          const int ar = C.arity[cls];
+          const int ar = arity_of(cls);
           const Grid g = ldsGeom ? sh_grids[nd.grid] : t.grids[nd.grid];
           if (cls == 0) {
             // a leaf parent: its pixel results become ONE event word (node id, significance
@@ -2068,7 +2078,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
             if (coded) {
               const uint32_t u = Up[y];
               if (!(u & 0x8000u)) {
-                record_born(C.lev[cls - 1], a + y, kid);
+                record_born(lev_of(cls - 1), a + y, kid);
                 y += 1;
                 continue;
               }
