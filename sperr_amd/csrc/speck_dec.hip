@@ -1690,26 +1690,29 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
         uint16_t* Uj = Uu + (size_t)j * TS;
         if (j < K - 1) {
           uint16_t* Tj = Tt + (size_t)j * TS;
-          // two independent positions per iteration: their LDS chains overlap
+          // two independent positions per iteration: their LDS chains overlap.  The thread that has
+          // T_j[r] also writes the coded form of the item one position earlier, U_j[r - 1] (its
+          // test bit, then a class-j split from r), so a class costs one pass and one barrier.
+          auto coded = [&](uint32_t q, uint32_t tl) -> uint16_t {   // U_j[q] given T_j[q + 1]
+            if (q >= W)
+              return (uint16_t)kTInf;
+            if (!bit_at(q))
+              return (uint16_t)1;
+            return (uint16_t)(tl == kTInf ? kTInf : (0x8000u | (1u + tl)));
+          };
           for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
             const uint32_t r2 = r + kTabThreads;
             const uint32_t t1 = split_len(j, r);
             const uint32_t t2 = r2 <= W + 1 ? split_len(j, r2) : kTInf;
             Tj[r] = (uint16_t)t1;
-            if (r2 <= W + 1)
+            if (r >= 1)
+              Uj[r - 1] = coded(r - 1, t1);
+            if (r2 <= W + 1) {
               Tj[r2] = (uint16_t)t2;
-          }
-          __syncthreads();
-          for (uint32_t r = tid; r <= W + 1; r += kTabThreads) {
-            uint32_t u = kTInf;
-            if (r < W) {
-              u = 1;
-              if (bit_at(r)) {
-                const uint32_t tl = Tj[r + 1];
-                u = tl == kTInf ? kTInf : (0x8000u | (1u + tl));
-              }
+              Uj[r2 - 1] = coded(r2 - 1, t2);
             }
-            Uj[r] = (uint16_t)u;
+            if (r == W + 1 || r2 == W + 1)
+              Uj[W + 1] = (uint16_t)kTInf;
           }
         }
         else {  // the level's own class: only the coded form is ever needed
