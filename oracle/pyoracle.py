@@ -42,6 +42,19 @@ def have_ref():
                for f in ("libSPERR_ref.so", "libref_probe.so"))
 
 
+def pack_mask(bools):
+    """bool[n] -> uint64 words, bit i of the mask = bools[i] (the reference's Bitmask layout)."""
+    b = np.asarray(bools, dtype=bool).ravel()
+    pad = (-b.size) % 64
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=bool)])
+    return np.packbits(b, bitorder="little").view(np.uint64).copy()
+
+
+def unpack_mask(words, n):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
 def _u8(buf):
     return np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
 
@@ -128,6 +141,10 @@ class Oracle(_CApiMixin):
         L.orc_speck3d_encode.restype = C.c_int
         L.orc_speck3d_decode.argtypes = [_vp, _sz, _vp, _vp, _vp]
         L.orc_speck3d_decode.restype = C.c_int
+        L.orc_speck1d_encode.argtypes = [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+        L.orc_speck1d_encode.restype = C.c_int
+        L.orc_speck1d_decode.argtypes = [_vp, _sz, _sz, _vp, _vp]
+        L.orc_speck1d_decode.restype = C.c_int
         L.orc_chunk_compress_rate.argtypes = [_vp, _vp, C.c_double, C.POINTER(_vp), C.POINTER(_sz)]
         L.orc_chunk_compress_rate.restype = C.c_int
         L.orc_chunk_decompress.argtypes = [_vp, _sz, _vp, _vp]
@@ -202,6 +219,27 @@ class Oracle(_CApiMixin):
                                     coef.ctypes.data, sign.ctypes.data)
         return coef, sign
 
+    def speck1d_encode(self, coef, sign_bools):
+        """coef: uint64[n]; sign_bools: bool[n] (True = non-negative). Returns the stream."""
+        c = np.ascontiguousarray(coef, dtype=np.uint64)
+        sign = pack_mask(sign_bools)
+        out, n = _vp(None), _sz(0)
+        self.lib.orc_speck1d_encode(c.ctypes.data, sign.ctypes.data, C.c_size_t(c.size),
+                                    C.byref(out), C.byref(n))
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def speck1d_decode(self, stream, n):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        coef = np.zeros(n, dtype=np.uint64)
+        sign = np.zeros((n + 63) // 64, dtype=np.uint64)
+        rtn = self.lib.orc_speck1d_decode(buf.ctypes.data, C.c_size_t(buf.size), C.c_size_t(n),
+                                          coef.ctypes.data, sign.ctypes.data)
+        if rtn:
+            raise RuntimeError(f"orc_speck1d_decode returned {rtn}")
+        return coef, unpack_mask(sign, n)
+
     def chunk_compress_rate(self, vol, bpp):
         v = np.array(vol, dtype=np.float64, order="C")
         dz, dy, dx = v.shape
@@ -252,6 +290,10 @@ class Ref(_CApiMixin):
         P.refp_speck3d_encode.restype = C.c_int
         P.refp_speck3d_decode.argtypes = [_vp, _sz, _sz, _sz, _sz, _vp, _vp]
         P.refp_speck3d_decode.restype = C.c_int
+        P.refp_speck1d_encode.argtypes = [_vp, _vp, _sz, C.c_int, C.POINTER(_vp), C.POINTER(_sz)]
+        P.refp_speck1d_encode.restype = C.c_int
+        P.refp_speck1d_decode.argtypes = [_vp, _sz, _sz, _vp, _vp]
+        P.refp_speck1d_decode.restype = C.c_int
         P.refp_chunk_compress_rate.argtypes = [_vp, _sz, _sz, _sz, C.c_double, C.POINTER(_vp),
                                                C.POINTER(_sz)]
         P.refp_chunk_compress_rate.restype = C.c_int
@@ -299,6 +341,26 @@ class Ref(_CApiMixin):
         self.probe.refp_speck3d_decode(buf.ctypes.data, buf.size, dx, dy, dz, coef.ctypes.data,
                                        sign.ctypes.data)
         return coef, sign
+
+    def speck1d_encode(self, coef, sign_bools, width=8):
+        c = np.ascontiguousarray(coef, dtype=np.uint64)
+        sign = pack_mask(sign_bools)
+        out, n = _vp(None), _sz(0)
+        rtn = self.probe.refp_speck1d_encode(c.ctypes.data, sign.ctypes.data, c.size, width,
+                                             C.byref(out), C.byref(n))
+        if rtn:
+            raise RuntimeError(f"refp_speck1d_encode returned {rtn}")
+        s = C.string_at(out.value, n.value)
+        self._libc.free(out)
+        return s
+
+    def speck1d_decode(self, stream, n):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        coef = np.zeros(n, dtype=np.uint64)
+        sign = np.zeros((n + 63) // 64, dtype=np.uint64)
+        self.probe.refp_speck1d_decode(buf.ctypes.data, buf.size, n, coef.ctypes.data,
+                                       sign.ctypes.data)
+        return coef, unpack_mask(sign, n)
 
     def chunk_compress_rate(self, vol, bpp):
         v = np.array(vol, dtype=np.float64, order="C")

@@ -10,6 +10,8 @@
 
 #include "CDF97.h"
 #include "Conditioner.h"
+#include "SPECK1D_INT_DEC.h"
+#include "SPECK1D_INT_ENC.h"
 #include "SPECK3D_FLT.h"
 #include "SPECK3D_INT_DEC.h"
 #include "SPECK3D_INT_ENC.h"
@@ -17,7 +19,7 @@
 
 namespace {
 
-template <typename T>
+template <typename T, typename ENC = sperr::SPECK3D_INT_ENC<T>>
 int encode_as(const uint64_t* coeffs, const uint64_t* signs, sperr::dims_type dims, size_t budget,
               std::vector<uint8_t>& out)
 {
@@ -27,7 +29,7 @@ int encode_as(const uint64_t* coeffs, const uint64_t* signs, sperr::dims_type di
     c[i] = static_cast<T>(coeffs[i]);
   sperr::Bitmask mask(n);
   mask.use_bitstream(signs);
-  sperr::SPECK3D_INT_ENC<T> enc;
+  ENC enc;
   enc.set_dims(dims);
   enc.set_budget(budget);
   if (enc.use_coeffs(std::move(c), std::move(mask)) != sperr::RTNType::Good)
@@ -37,12 +39,12 @@ int encode_as(const uint64_t* coeffs, const uint64_t* signs, sperr::dims_type di
   return 0;
 }
 
-template <typename T>
+template <typename T, typename DEC = sperr::SPECK3D_INT_DEC<T>>
 int decode_as(const uint8_t* stream, size_t len, sperr::dims_type dims, uint64_t* coeffs,
               uint64_t* signs)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
-  sperr::SPECK3D_INT_DEC<T> dec;
+  DEC dec;
   dec.set_dims(dims);
   dec.use_bitstream(stream, len);
   dec.decode();
@@ -121,6 +123,41 @@ int refp_speck3d_decode(const uint8_t* stream, size_t len, size_t dx, size_t dy,
   if (planes <= 32)
     return decode_as<uint32_t>(stream, len, dims, coeffs, signs);
   return decode_as<uint64_t>(stream, len, dims, coeffs, signs);
+}
+
+// the coder of the outlier list (SPECK1D_INT_ENC / _DEC over a length-n array, no bit budget)
+int refp_speck1d_encode(const uint64_t* coeffs, const uint64_t* signs, size_t n, int width,
+                        uint8_t** out, size_t* out_len)
+{
+  std::vector<uint8_t> s;
+  const sperr::dims_type dims = {n, 1, 1};
+  int rtn = 1;
+  switch (width) {
+    case 1: rtn = encode_as<uint8_t, sperr::SPECK1D_INT_ENC<uint8_t>>(coeffs, signs, dims, 0, s); break;
+    case 2: rtn = encode_as<uint16_t, sperr::SPECK1D_INT_ENC<uint16_t>>(coeffs, signs, dims, 0, s); break;
+    case 4: rtn = encode_as<uint32_t, sperr::SPECK1D_INT_ENC<uint32_t>>(coeffs, signs, dims, 0, s); break;
+    case 8: rtn = encode_as<uint64_t, sperr::SPECK1D_INT_ENC<uint64_t>>(coeffs, signs, dims, 0, s); break;
+  }
+  if (rtn)
+    return rtn;
+  *out = static_cast<uint8_t*>(std::malloc(s.size()));
+  std::memcpy(*out, s.data(), s.size());
+  *out_len = s.size();
+  return 0;
+}
+
+int refp_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* coeffs,
+                        uint64_t* signs)
+{
+  const sperr::dims_type dims = {n, 1, 1};
+  const auto planes = sperr::speck_int_get_num_bitplanes(stream);
+  if (planes <= 8)
+    return decode_as<uint8_t, sperr::SPECK1D_INT_DEC<uint8_t>>(stream, len, dims, coeffs, signs);
+  if (planes <= 16)
+    return decode_as<uint16_t, sperr::SPECK1D_INT_DEC<uint16_t>>(stream, len, dims, coeffs, signs);
+  if (planes <= 32)
+    return decode_as<uint32_t, sperr::SPECK1D_INT_DEC<uint32_t>>(stream, len, dims, coeffs, signs);
+  return decode_as<uint64_t, sperr::SPECK1D_INT_DEC<uint64_t>>(stream, len, dims, coeffs, signs);
 }
 
 // one chunk through the reference's SPECK3D_FLT in fixed-rate mode; *out is malloc'd

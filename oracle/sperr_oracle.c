@@ -933,6 +933,387 @@ int orc_speck3d_decode(const uint8_t* stream, size_t len, const size_t dims[3], 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* SPECK1D (the coder of the outlier list)                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/SPECK1D_INT.h:10-42 : a run of the array; its LIS level is the number of splits */
+typedef struct {
+  uint64_t start, len;
+} run1;
+
+typedef struct {
+  run1* v;
+  size_t n, cap;
+} runlist;
+
+typedef struct {
+  size_t n;
+  int encoding;
+  uint64_t* coef; /* encoder: working copy, decoder: output */
+  uint64_t* sign;
+  uint32_t* nzpre; /* encoder only: non-zero values before each 64-value block (skips empty runs) */
+  uint64_t *lip, *lsp;
+  size_t *fresh, nfresh, capfresh;
+  runlist* lis;
+  size_t nlis;
+  bitfifo bits;
+  uint64_t thr;
+} speck1;
+
+static void run_push(runlist* l, run1 r)
+{
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 16;
+    l->v = (run1*)realloc(l->v, l->cap * sizeof(run1));
+  }
+  l->v[l->n++] = r;
+}
+
+static void fresh1_push(speck1* s, size_t idx)
+{
+  if (s->nfresh == s->capfresh) {
+    s->capfresh = s->capfresh ? s->capfresh * 2 : 1024;
+    s->fresh = (size_t*)realloc(s->fresh, s->capfresh * sizeof(size_t));
+  }
+  s->fresh[s->nfresh++] = idx;
+}
+
+/* src/SPECK1D_INT_ENC.cpp:165-178 (any value of the run at or above the threshold) */
+static int run_significant(const speck1* s, run1 r)
+{
+  const uint64_t end = r.start + r.len;
+  /* whole 64-blocks without a non-zero value cannot hold a significant one */
+  uint64_t i = r.start;
+  while (i < end) {
+    if ((i & 63) == 0 && i + 64 <= end && s->nzpre[(i >> 6) + 1] == s->nzpre[i >> 6]) {
+      i += 64;
+      continue;
+    }
+    if (s->coef[i] >= s->thr)
+      return 1;
+    i++;
+  }
+  return 0;
+}
+
+static void speck1_test_run(speck1* s, size_t lev, size_t idx, int* counter, int coded);
+
+/* src/SPECK1D_INT_ENC.cpp:97-118, _DEC.cpp:72-87 */
+static void speck1_test_pixel(speck1* s, size_t idx, int* counter, int coded)
+{
+  int sig = 1;
+  if (s->encoding) {
+    if (coded) { /* (an uncoded pixel is significant by inference) */
+      sig = s->coef[idx] >= s->thr;
+      fifo_put(&s->bits, sig);
+    }
+  }
+  else if (coded)
+    sig = fifo_get(&s->bits);
+  if (sig) {
+    (*counter)++;
+    if (s->encoding) {
+      fifo_put(&s->bits, mask_get(s->sign, idx));
+      s->coef[idx] -= s->thr;
+    }
+    else if (fifo_get(&s->bits))
+      mask_set(s->sign, idx);
+    else
+      mask_clr(s->sign, idx);
+    fresh1_push(s, idx);
+    mask_clr(s->lip, idx);
+  }
+}
+
+/* src/SPECK1D_INT.cpp:36-56 + _ENC.cpp:120-163, _DEC.cpp:89-124 : halves (len - len/2, len/2),
+ * one level deeper; the second half is not coded when the first turned out insignificant */
+static void speck1_split_run(speck1* s, size_t lev, size_t idx)
+{
+  const run1 parent = s->lis[lev].v[idx];
+  run1 kid[2];
+  kid[0].start = parent.start;
+  kid[0].len = parent.len - parent.len / 2;
+  kid[1].start = parent.start + kid[0].len;
+  kid[1].len = parent.len / 2;
+  int found = 0;
+  for (int k = 0; k < 2; k++) {
+    const int coded = k == 0 || found != 0;
+    if (kid[k].len == 1) {
+      mask_set(s->lip, kid[k].start);
+      speck1_test_pixel(s, kid[k].start, &found, coded);
+    }
+    else {
+      run_push(&s->lis[lev + 1], kid[k]);
+      speck1_test_run(s, lev + 1, s->lis[lev + 1].n - 1, &found, coded);
+    }
+  }
+}
+
+/* src/SPECK1D_INT_ENC.cpp:58-95, _DEC.cpp:56-70 */
+static void speck1_test_run(speck1* s, size_t lev, size_t idx, int* counter, int coded)
+{
+  int sig = 1;
+  if (s->encoding) {
+    sig = coded ? run_significant(s, s->lis[lev].v[idx]) : 1;
+    if (coded)
+      fifo_put(&s->bits, sig);
+  }
+  else if (coded)
+    sig = fifo_get(&s->bits);
+  if (sig) {
+    (*counter)++;
+    speck1_split_run(s, lev, idx);
+    s->lis[lev].v[idx].len = 0;
+  }
+}
+
+/* src/SPECK1D_INT_ENC.cpp:12-56, _DEC.cpp:12-54 */
+static void speck1_sorting_pass(speck1* s)
+{
+  for (size_t i = 0; i < s->n; i++) {
+    if ((i & 63) == 0 && s->lip[i >> 6] == 0) {
+      i += 63;
+      continue;
+    }
+    if (!mask_get(s->lip, i))
+      continue;
+    int dummy = 0;
+    speck1_test_pixel(s, i, &dummy, 1);
+  }
+  for (size_t lev = s->nlis; lev-- > 0;)
+    for (size_t i = 0; i < s->lis[lev].n; i++) {
+      int dummy = 0;
+      speck1_test_run(s, lev, i, &dummy, 1);
+    }
+}
+
+static void speck1_alloc(speck1* s, size_t n, int encoding)
+{
+  memset(s, 0, sizeof(*s));
+  s->n = n;
+  s->encoding = encoding;
+  const size_t words = (n + 63) / 64;
+  s->lip = (uint64_t*)calloc(words, 8);
+  s->lsp = (uint64_t*)calloc(words, 8);
+  /* src/SPECK1D_INT.cpp:19-34 : the two halves of the array, on the list of level 1 */
+  s->nlis = orc_num_of_partitions(n) + 1;
+  s->lis = (runlist*)calloc(s->nlis + 1, sizeof(runlist));
+  run1 whole = {0, n}, kid[2];
+  kid[0].start = 0;
+  kid[0].len = whole.len - whole.len / 2;
+  kid[1].start = kid[0].len;
+  kid[1].len = whole.len / 2;
+  run_push(&s->lis[1], kid[0]);
+  run_push(&s->lis[1], kid[1]);
+}
+
+static void speck1_free(speck1* s)
+{
+  for (size_t i = 0; i <= s->nlis; i++)
+    free(s->lis[i].v);
+  free(s->lis);
+  free(s->lip);
+  free(s->lsp);
+  free(s->fresh);
+  free(s->nzpre);
+  free(s->bits.w);
+}
+
+static void speck1_clean_lists(speck1* s)
+{
+  for (size_t lev = 0; lev < s->nlis; lev++) {
+    runlist* l = &s->lis[lev];
+    size_t k = 0;
+    for (size_t i = 0; i < l->n; i++)
+      if (l->v[i].len)
+        l->v[k++] = l->v[i];
+    l->n = k;
+  }
+}
+
+/* src/SPECK_INT.cpp:110-163 with the 1D passes; no bit budget (the outlier coder never sets one) */
+int orc_speck1d_encode(const uint64_t* coeffs, const uint64_t* signs, size_t n, uint8_t** stream,
+                       size_t* stream_len)
+{
+  speck1 s;
+  speck1_alloc(&s, n, 1);
+  s.coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  memcpy(s.coef, coeffs, n * sizeof(uint64_t));
+  s.sign = (uint64_t*)signs;
+  s.nzpre = (uint32_t*)calloc(n / 64 + 2, sizeof(uint32_t));
+  uint64_t maxc = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (s.coef[i] > maxc)
+      maxc = s.coef[i];
+    if (s.coef[i])
+      s.nzpre[(i >> 6) + 1]++;
+  }
+  for (size_t b = 0; b < n / 64 + 1; b++)
+    s.nzpre[b + 1] += s.nzpre[b];
+  uint8_t nplanes = 0;
+  uint64_t total_bits = 0;
+  if (maxc) {
+    nplanes = 1;
+    s.thr = 1;
+    while (maxc - s.thr >= s.thr) {
+      s.thr *= 2;
+      nplanes++;
+    }
+    for (uint8_t p = 0; p < nplanes; p++) {
+      speck1_sorting_pass(&s);
+      for (size_t i = 0; i < n; i++) { /* src/SPECK_INT.cpp:310-357 */
+        if ((i & 63) == 0 && s.lsp[i >> 6] == 0) {
+          i += 63;
+          continue;
+        }
+        if (!mask_get(s.lsp, i))
+          continue;
+        const int b = s.coef[i] >= s.thr;
+        if (b)
+          s.coef[i] -= s.thr;
+        fifo_put(&s.bits, b);
+      }
+      for (size_t k = 0; k < s.nfresh; k++)
+        mask_set(s.lsp, s.fresh[k]);
+      s.nfresh = 0;
+      s.thr /= 2;
+      speck1_clean_lists(&s);
+    }
+    total_bits = s.bits.pos;
+  }
+  const size_t nbytes = (size_t)((total_bits + 7) / 8);
+  uint8_t* out = (uint8_t*)calloc(9 + nbytes + 8, 1);
+  out[0] = nplanes;
+  memcpy(out + 1, &total_bits, 8);
+  if (nbytes)
+    memcpy(out + 9, s.bits.w, nbytes);
+  *stream = out;
+  *stream_len = 9 + nbytes;
+  free(s.coef);
+  speck1_free(&s);
+  return 0;
+}
+
+/* src/SPECK_INT.cpp:165-228 with the 1D passes; the stream is complete (a partial outlier stream
+ * is discarded by the caller, src/SPECK_FLT.cpp:88-103) */
+int orc_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* coeffs,
+                       uint64_t* signs)
+{
+  if (len < 9)
+    return 1;
+  speck1 s;
+  speck1_alloc(&s, n, 0);
+  const uint8_t nplanes = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  if ((uint64_t)(len - 9) * 8 < total_bits) {
+    speck1_free(&s);
+    return 1;
+  }
+  s.bits.cap_words = (size_t)(total_bits / 64 + 2);
+  s.bits.w = (uint64_t*)calloc(s.bits.cap_words, 8);
+  memcpy(s.bits.w, stream + 9, (size_t)((total_bits + 7) / 8));
+  s.coef = coeffs;
+  s.sign = signs;
+  memset(coeffs, 0, n * sizeof(uint64_t));
+  memset(signs, 0xff, ((n + 63) / 64) * 8);
+  if (nplanes) {
+    s.thr = (uint64_t)1 << (nplanes - 1);
+    for (uint8_t p = 0; p < nplanes; p++) {
+      speck1_sorting_pass(&s);
+      if (s.bits.pos >= total_bits)
+        break;
+      const uint64_t half = s.thr / 2;
+      int exhausted = 0;
+      for (size_t i = 0; i < n && !exhausted; i++) {
+        if ((i & 63) == 0 && s.lsp[i >> 6] == 0) {
+          i += 63;
+          continue;
+        }
+        if (!mask_get(s.lsp, i))
+          continue;
+        const int b = fifo_get(&s.bits);
+        if (s.thr >= 2)
+          s.coef[i] = b ? s.coef[i] + half : s.coef[i] - half;
+        else if (b)
+          s.coef[i]++;
+        if (s.bits.pos == total_bits)
+          exhausted = 1;
+      }
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1;
+      for (size_t k = 0; k < s.nfresh; k++) {
+        s.coef[s.fresh[k]] = init;
+        mask_set(s.lsp, s.fresh[k]);
+      }
+      s.nfresh = 0;
+      if (s.bits.pos >= total_bits)
+        break;
+      s.thr /= 2;
+      speck1_clean_lists(&s);
+    }
+    if (s.nfresh) {
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1;
+      for (size_t k = 0; k < s.nfresh; k++)
+        s.coef[s.fresh[k]] = init;
+    }
+  }
+  speck1_free(&s);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* outlier coder                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/Outlier_Coder.cpp:71-129,179-197 : errors in units of the tolerance, rounded to nearest;
+ * pos[] ascending.  Returns 1 on a bad list (an error within the tolerance). */
+int orc_outlier_encode(const uint64_t* pos, const double* err, size_t count, size_t n, double tol,
+                       uint8_t** stream, size_t* stream_len)
+{
+  if (n == 0 || tol <= 0.0 || count == 0)
+    return 1;
+  for (size_t k = 0; k < count; k++)
+    if (pos[k] >= n || fabs(err[k]) <= tol)
+      return 1;
+  uint64_t* coef = (uint64_t*)calloc(n, sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * 8);
+  memset(sign, 0xff, ((n + 63) / 64) * 8);
+  const double inv = 1.0 / tol;
+  for (size_t k = 0; k < count; k++) {
+    const long long ll = llrint(err[k] * inv);
+    if (ll >= 0)
+      mask_set(sign, pos[k]);
+    else
+      mask_clr(sign, pos[k]);
+    coef[pos[k]] = (uint64_t)(ll < 0 ? -ll : ll);
+  }
+  const int rtn = orc_speck1d_encode(coef, sign, n, stream, stream_len);
+  free(coef);
+  free(sign);
+  return rtn;
+}
+
+/* src/Outlier_Coder.cpp:131-152,199-233 : correctors 1.1 tol for magnitude 1, (m - 0.25) tol
+ * otherwise, added to vals[] */
+int orc_outlier_decode_apply(const uint8_t* stream, size_t len, size_t n, double tol, double* vals)
+{
+  uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * 8);
+  const int rtn = orc_speck1d_decode(stream, len, n, coef, sign);
+  if (!rtn)
+    for (size_t i = 0; i < n; i++) {
+      if (coef[i] == 0)
+        continue;
+      double e = coef[i] == 1 ? 1.1 : (double)coef[i] - 0.25;
+      e *= tol * (mask_get(sign, i) ? 1.0 : -1.0);
+      vals[i] += e;
+    }
+  free(coef);
+  free(sign);
+  return rtn;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* per-chunk float pipeline                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -1055,7 +1436,74 @@ int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uin
   return rtn;
 }
 
-/* src/SPECK_FLT.cpp:27-109,543-606 (no outlier stream in rate and PSNR modes) */
+/* src/SPECK_FLT.cpp:401-541, CompMode::PWE: q = 1.5 tol (:280-281), every bit plane coded, then
+ * the values the decoder would see are rebuilt and every error above the tolerance goes to the
+ * outlier coder (:461-486) */
+int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8_t** stream,
+                           size_t* stream_len)
+{
+  const size_t n = dims[0] * dims[1] * dims[2];
+  uint8_t condi[17];
+  if (orc_condition(vals, n, condi)) {
+    *stream = (uint8_t*)malloc(17);
+    memcpy(*stream, condi, 17);
+    *stream_len = 17;
+    return 0;
+  }
+  double* orig = (double*)malloc(n * sizeof(double));
+  memcpy(orig, vals, n * sizeof(double));
+  orc_dwt3d(vals, dims);
+  const double q = 1.5 * tol;
+  memcpy(condi + 9, &q, 8);
+  uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
+  uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
+  int width;
+  int rtn = orc_quantize(vals, n, q, coef, sign, &width);
+  uint8_t* out_stream = NULL;
+  size_t out_len = 0;
+  if (!rtn) {
+    orc_inv_quantize(coef, sign, n, q, vals);
+    orc_idwt3d(vals, dims);
+    size_t count = 0;
+    for (size_t i = 0; i < n; i++)
+      if (fabs(orig[i] - vals[i]) > tol)
+        count++;
+    if (count) {
+      uint64_t* pos = (uint64_t*)malloc(count * sizeof(uint64_t));
+      double* err = (double*)malloc(count * sizeof(double));
+      size_t k = 0;
+      for (size_t i = 0; i < n; i++) {
+        const double diff = orig[i] - vals[i];
+        if (fabs(diff) > tol) {
+          pos[k] = i;
+          err[k++] = diff;
+        }
+      }
+      rtn = orc_outlier_encode(pos, err, count, n, tol, &out_stream, &out_len);
+      free(pos);
+      free(err);
+    }
+  }
+  if (!rtn) {
+    uint8_t* speck_stream = NULL;
+    size_t speck_len = 0;
+    orc_speck3d_encode(coef, sign, dims, 0, &speck_stream, &speck_len);
+    *stream = (uint8_t*)malloc(17 + speck_len + out_len);
+    memcpy(*stream, condi, 17);
+    memcpy(*stream + 17, speck_stream, speck_len);
+    if (out_len)
+      memcpy(*stream + 17 + speck_len, out_stream, out_len);
+    *stream_len = 17 + speck_len + out_len;
+    free(speck_stream);
+  }
+  free(out_stream);
+  free(orig);
+  free(coef);
+  free(sign);
+  return rtn;
+}
+
+/* src/SPECK_FLT.cpp:27-109,543-606 */
 int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3], double* out)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
@@ -1082,10 +1530,23 @@ int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3]
   orc_speck3d_decode(sp, speck_len, dims, coef, sign);
   orc_inv_quantize(coef, sign, n, q, out);
   orc_idwt3d(out, dims);
+  /* an outlier stream follows only when all of it is there (SPECK_FLT.cpp:88-103); its tolerance
+   * is q / 1.5 (:578) */
+  int rtn = 0;
+  if (17 + speck_len < len) {
+    const uint8_t* op = sp + speck_len;
+    const size_t rem = len - 17 - speck_len;
+    if (rem >= 9) {
+      uint64_t obits;
+      memcpy(&obits, op + 1, 8);
+      if (rem == 9 + (size_t)((obits + 7) / 8))
+        rtn = orc_outlier_decode_apply(op, rem, n, q / 1.5, out);
+    }
+  }
   orc_inverse_condition(out, n, stream);
   free(coef);
   free(sign);
-  return 0;
+  return rtn;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1101,8 +1562,8 @@ int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t 
     return 1;
   if (quality <= 0.0)
     return 2;
-  if (mode != 1 && mode != 2)
-    return mode == 3 ? -1 : 2; /* the oracle restates the fixed-rate and fixed-PSNR paths */
+  if (mode < 1 || mode > 3)
+    return 2;
   const size_t vol[3] = {dimx, dimy, dimz};
   size_t want[3] = {chunk_x, chunk_y, chunk_z}, cdim[3];
   for (int a = 0; a < 3; a++) { /* SPERR3D_OMP_C.cpp:23-30 */
@@ -1137,8 +1598,9 @@ int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t 
           for (size_t x = 0; x < cd[0]; x++)
             buf[k++] = ((const double*)src)[row + x];
       }
-    rtns[ci] = mode == 1 ? orc_chunk_compress_rate(buf, cd, quality, &streams[ci], &lens[ci])
-                         : orc_chunk_compress_psnr(buf, cd, quality, &streams[ci], &lens[ci]);
+    rtns[ci] = mode == 1   ? orc_chunk_compress_rate(buf, cd, quality, &streams[ci], &lens[ci])
+               : mode == 2 ? orc_chunk_compress_psnr(buf, cd, quality, &streams[ci], &lens[ci])
+                           : orc_chunk_compress_pwe(buf, cd, quality, &streams[ci], &lens[ci]);
     free(buf);
   }
   int rtn = 0;

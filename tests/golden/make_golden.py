@@ -7,7 +7,8 @@ Inputs: two small files the reference's own tests use (test_data/wmag17.float, a
 test_data/vorticity.128_128_41, test_data/const32x20x16.float) copied as data fixtures, plus the
 machine-independent integer-arithmetic field from tests/fields.py.  Expected outputs: the exact
 container bytes produced by the reference's sperr_comp_3d and the SHA-256 of the floats/doubles
-its sperr_decomp_3d returns, for several chunkings and bit rates (mode 1) and target PSNRs (mode 2).
+its sperr_decomp_3d returns, for several chunkings and bit rates (mode 1), target PSNRs (mode 2) and point-wise error
+tolerances (mode 3).
 """
 import hashlib
 import json
@@ -66,8 +67,18 @@ def main():
         ("smooth_odd", (50, 37, 19), [70.0]),
         ("smooth_f64", (40, 40, 24), [100.0, 225.0]),   # 225 dB needs 64-bit coefficients
     ]
+    # mode 3: the quality is the largest point-wise error allowed; the chunk streams carry an
+    # outlier stream when the quantiser alone does not meet it (src/SPECK_FLT.cpp:461-486)
+    plan_pwe = [
+        ("wmag17", (17, 17, 17), [1.0, 0.001]),
+        ("vort_crop", (20, 18, 16), [1e-3, 1e-5, 1e-7]),   # 1e-3: every coefficient quantises to 0
+        ("const32x20x16", (16, 10, 8), [0.1]),
+        ("smooth_odd", (50, 37, 19), [0.01]),
+        ("smooth_f64", (40, 40, 24), [1e-9, 1e-13]),      # 64-bit coefficients, 5 outlier planes
+    ]
     jobs = [(n, c, 1, q) for n, c, qs in plan for q in qs] + \
-           [(n, c, 2, q) for n, c, qs in plan_psnr for q in qs]
+           [(n, c, 2, q) for n, c, qs in plan_psnr for q in qs] + \
+           [(n, c, 3, q) for n, c, qs in plan_pwe for q in qs]
     for name, chunks, mode, bpp in jobs:
         if name in inputs:
             arr = inputs[name]
@@ -78,7 +89,7 @@ def main():
             stream = ref.comp_3d(arr, chunks, mode, bpp)
             dec_f = ref.decomp_3d(stream, True)
             dec_d = ref.decomp_3d(stream, False)
-            tag = f"{name}_c{chunks[0]}x{chunks[1]}x{chunks[2]}_{'bpp' if mode == 1 else 'psnr'}{bpp}"
+            tag = f"{name}_c{chunks[0]}x{chunks[1]}x{chunks[2]}_{('bpp', 'psnr', 'pwe')[mode - 1]}{bpp}"
             with open(os.path.join(HERE, tag + ".sperr"), "wb") as f:
                 f.write(stream)
             cases.append({

@@ -93,6 +93,40 @@ def test_psnr_mode_bit_exact(oracle, ref, chunks, psnr):
     assert oracle.comp_3d(d, chunks, 2, psnr) == ref.comp_3d(d, chunks, 2, psnr)
 
 
+@pytest.mark.parametrize("chunks", [(32, 32, 32), (48, 40, 24), (64, 40, 48)])
+@pytest.mark.parametrize("tol", [0.3, 1e-2, 1e-4, 1e-9])
+def test_pwe_mode_bit_exact(oracle, ref, chunks, tol):
+    """Mode 3 (src/SPECK_FLT.cpp:280-281,461-486,573-584): q = 1.5 tol, full-depth coding, and the
+    outlier list through Outlier_Coder / SPECK1D_INT; decoded values honour the tolerance."""
+    v = turbulence((48, 40, 64))
+    want = ref.comp_3d(v, chunks, 3, tol)
+    assert oracle.comp_3d(v, chunks, 3, tol) == want
+    dec = oracle.decomp_3d(want, False)
+    assert np.array_equal(bits(dec), bits(ref.decomp_3d(want, False)))
+    assert np.abs(dec - v.astype(np.float64)).max() <= tol
+    d = smooth_field((24, 40, 40), dtype=np.float64) * 1e-3
+    want = ref.comp_3d(d, chunks, 3, tol)
+    assert oracle.comp_3d(d, chunks, 3, tol) == want
+    assert np.array_equal(bits(oracle.decomp_3d(want, False)), bits(ref.decomp_3d(want, False)))
+
+
+def test_speck1d_bit_exact(oracle, ref):
+    """SPECK1D_INT_ENC / _DEC (src/SPECK1D_INT*.cpp) on sparse arrays: same stream, and it
+    round-trips exactly through both decoders."""
+    rng = np.random.default_rng(5)
+    for n, k, top in [(3, 2, 3), (5, 5, 9), (100, 7, 200), (4097, 300, 5), (65536, 1000, 70000)]:
+        coef = np.zeros(n, dtype=np.uint64)
+        pos = rng.choice(n, size=min(k, n), replace=False)
+        coef[pos] = rng.integers(1, top + 1, size=pos.size, dtype=np.uint64)
+        sign = rng.integers(0, 2, size=n).astype(bool)
+        stream = oracle.speck1d_encode(coef, sign)
+        assert stream == ref.speck1d_encode(coef, sign)
+        for dec in (oracle, ref):
+            c2, s2 = dec.speck1d_decode(stream, n)
+            assert np.array_equal(c2, coef)
+            assert np.array_equal(s2[coef > 0], sign[coef > 0])
+
+
 @pytest.mark.parametrize("chunks", [(64, 40, 48), (32, 32, 32), (20, 18, 16)])
 @pytest.mark.parametrize("pct", [0, 1, 10, 37, 75, 100, 150])
 def test_progressive_truncation_bit_exact(oracle, ref, chunks, pct):
