@@ -23,6 +23,7 @@
 #include "speck_dec.h"
 #include "speck_enc.h"
 #include "speck_tree_host.hpp"
+#include "outlier.h"
 #include "xform.h"
 
 namespace sperrhip {
@@ -405,6 +406,7 @@ struct Engine {
   hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {nullptr, nullptr, nullptr, nullptr};
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   DevBuf arena, slots, misc;
+  DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   size_t freeMemAtInit = 0;
 
   int init()
@@ -513,10 +515,11 @@ k_write_slot(const CoderState* cst, const EncState* est, const uint64_t* stream,
 }
 
 // container header (SPERR3D_OMP_C.cpp:163-234) + chunk offsets
-__global__ void k_container_header(uint8_t* dst, const uint64_t* lens, uint64_t* offs,
-                                   uint32_t nchunks, uint32_t vx, uint32_t vy, uint32_t vz,
-                                   uint32_t cx, uint32_t cy, uint32_t cz, int is_float,
-                                   uint64_t* total)
+// (lens2: bytes of the outlier stream that follows each chunk's SPECK stream, PWE mode)
+__global__ void k_container_header(uint8_t* dst, const uint64_t* lens, const uint64_t* lens2,
+                                   uint64_t* offs, uint32_t nchunks, uint32_t vx, uint32_t vy,
+                                   uint32_t vz, uint32_t cx, uint32_t cy, uint32_t cz,
+                                   int is_float, uint64_t* total)
 {
   if (blockIdx.x || threadIdx.x)
     return;
@@ -534,11 +537,12 @@ __global__ void k_container_header(uint8_t* dst, const uint64_t* lens, uint64_t*
   }
   uint64_t off = pos + 4ull * nchunks;
   for (uint32_t i = 0; i < nchunks; i++) {
-    const uint32_t l = (uint32_t)lens[i];
+    const uint64_t both = lens[i] + lens2[i];
+    const uint32_t l = (uint32_t)both;
     memcpy(dst + pos, &l, 4);
     pos += 4;
     offs[i] = off;
-    off += lens[i];
+    off += both;
   }
   *total = off;
 }
@@ -553,6 +557,23 @@ k_copy_slots(uint8_t* dst, uint64_t dst_cap, const uint8_t* slots, const uint64_
     return;
   const uint8_t* in = slots + slotOff[g];
   uint8_t* out = dst + offs[g];
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
+
+// outlier streams of one batch (local index b): they follow the chunk's SPECK stream
+__global__ void __launch_bounds__(kThreads)
+k_copy_slots2(uint8_t* dst, uint64_t dst_cap, const uint8_t* slots2, const uint64_t* slotOff2,
+              const uint32_t* gids, const uint64_t* lens, const uint64_t* lens2,
+              const uint64_t* offs)
+{
+  const uint32_t b = blockIdx.y, g = gids[b];
+  const uint64_t len = lens2[g], at = offs[g] + lens[g];
+  if (len == 0 || at + len > dst_cap)
+    return;
+  const uint8_t* in = slots2 + slotOff2[b];
+  uint8_t* out = dst + at;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (uint64_t)gridDim.x * blockDim.x)
     out[i] = in[i];
@@ -764,11 +785,215 @@ int psnr_q_search(hipStream_t st, const ShapePlan& P, EncBatchBufs& bb, uint32_t
   return 0;
 }
 
+// PWE mode (src/SPECK_FLT.cpp:280-281): q = 1.5 tol for every chunk; chunks whose largest
+// coefficient needs more than 32 bits are flagged for the 64-bit pass (SPECK_FLT.cpp:324-337)
+int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol)
+{
+  EncBuffers& e = bb.eb;
+  std::vector<CoderState> hc(nb);
+  HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (uint32_t i = 0; i < nb; i++) {
+    CoderState& c = hc[i];
+    c.wide = 0;
+    c.need_retry = 0;
+    if (c.is_const)
+      continue;
+    c.q = 1.5 * tol;
+    const double m = c.maxabs / c.q;
+    if (!(m < 9.3e18))
+      return -1;   // llrint would raise FE_INVALID (SPECK_FLT.cpp:325-327)
+    c.need_retry = std::llrint(m) > (long long)0xffffffffll ? 1u : 0u;
+  }
+  HIP_CHECK(hipMemcpyAsync(e.cst, hc.data(), nb * sizeof(CoderState), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// outlier streams of one batch, kept on the device until the container is assembled
+struct PweKeep {
+  void* mem = nullptr;
+  uint32_t nb = 0;
+  uint32_t* gids = nullptr;
+  uint64_t* slotOff = nullptr;
+  uint8_t* slots = nullptr;
+};
+struct PweKeepList {
+  std::vector<PweKeep> v;
+  ~PweKeepList()
+  {
+    for (auto& k : v)
+      if (k.mem)
+        (void)hipFree(k.mem);
+  }
+};
+
+// list storage of the 1D coder: level l holds at most 2^l runs, and never more than `most`
+void speck1d_level_offsets(OutlierBufs& ob, uint32_t N, uint64_t most)
+{
+  ob.nlists = (uint32_t)spk::num_of_partitions(N) + 1;
+  uint64_t off = 0;
+  for (uint32_t l = 0; l <= (uint32_t)kO1MaxLevels; l++) {
+    ob.levelOff[l] = (uint32_t)std::min<uint64_t>(off, 0xffffffffull);
+    if (l < ob.nlists)
+      off += l < 40 ? std::min<uint64_t>(1ull << l, most) : most;
+  }
+  ob.runStride = round_up((size_t)off + 64, 64);
+}
+
+// PWE mode, after the integer coder (src/SPECK_FLT.cpp:461-486): rebuild the values the decoder
+// will see (inverse quantiser + inverse transform, in the chunk buffer), compare them with the
+// conditioned input, and code every error above the tolerance with the 1D coder.
+template <typename T>
+int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                      const T* d_src, VolDesc vd, const uint32_t cd[3], double tol,
+                      uint64_t* d_lens2, PweKeepList& keep)
+{
+  EncBuffers& e = bb.eb;
+  if (launch_inv_quantize(st, false, bb.coef32, e.coefStride, e.sign, e.signStride, nb, P.N, bb.vals,
+                          bb.valsStride, e.cst) ||
+      launch_inv_quantize(st, true, bb.vals, bb.valsStride, e.sign, e.signStride, nb, P.N, bb.vals,
+                          bb.valsStride, e.cst))
+    return -1;
+  for (size_t k = P.fwd.size(); k-- > 0;) {
+    const LiftPass& ps = P.fwd[k];
+    if (launch_lift(st, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst, 0, nullptr,
+                    vd, bb.geom))
+      return -1;
+  }
+  OutlierBufs ob;
+  memset(&ob, 0, sizeof(ob));
+  ob.nchunks = nb;
+  ob.N = P.N;
+  ob.nw = (P.N + 63) / 64;
+  ob.wordStride = round_up((size_t)ob.nw + 2, 32);
+  {
+    const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) + (size_t)nb * ob.wordStride * (8 + 4 + 8) + 1024;
+    if (E.outlFixed.ensure(bytes))
+      return -1;
+    Arena A;
+    A.base = static_cast<char*>(E.outlFixed.p);
+    A.cap = E.outlFixed.n;
+    ob.oc = A.take<OutlierChunk>(nb);
+    ob.outMask = A.take<uint64_t>(nb * ob.wordStride);
+    ob.lip = A.take<uint64_t>(nb * ob.wordStride);
+    ob.outPre = A.take<uint32_t>(nb * ob.wordStride);
+    if (!ob.oc || !ob.outMask || !ob.lip || !ob.outPre)
+      return -1;
+  }
+  HIP_CHECK(hipMemsetAsync(ob.oc, 0, nb * sizeof(OutlierChunk), st));
+  ob.kStride = 1;
+  if (launch_outlier_scan<T>(st, 0, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
+    return -1;
+  std::vector<OutlierChunk> hoc(nb);
+  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  bool any = false;
+  for (auto& o : hoc) {
+    if (!o.flagged)
+      continue;
+    any = true;
+    // the integer type the reference keeps the magnitudes in comes from the largest ERROR, not
+    // from the largest magnitude (Outlier_Coder.cpp:82-100); magnitudes wrap to that width
+    double maxerr;
+    memcpy(&maxerr, &o.maxErrKey, 8);
+    if (!(maxerr < 9.2e18))
+      return -1;
+    const long long mi = std::llrint(maxerr);
+    o.widthMask = mi <= 0xffll ? 0xffull : mi <= 0xffffll ? 0xffffull : mi <= 0xffffffffll ? 0xffffffffull : ~0ull;
+  }
+  if (!any)
+    return 0;   // (d_lens2 stays zero for these chunks)
+  HIP_CHECK(hipMemcpyAsync(ob.oc, hoc.data(), nb * sizeof(OutlierChunk), hipMemcpyHostToDevice, st));
+  if (launch_outlier_scan<T>(st, 1, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
+    return -1;
+  ob.kStride = P.N;   // (only the overflow check of the prefix kernel reads it here)
+  if (launch_outlier_prefix(st, ob))
+    return -1;
+  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  uint32_t kmax = 0;
+  for (auto& o : hoc)
+    kmax = std::max(kmax, o.count);
+  ob.kStride = round_up(std::max<size_t>(kmax, 1), 64);
+  ob.tblLevels = 1;
+  while ((2u << (ob.tblLevels - 1)) <= kmax)
+    ob.tblLevels++;
+  speck1d_level_offsets(ob, P.N, 2ull * kmax + 2);
+  const size_t varFixed = (size_t)nb * (ob.kStride * (4 + 8 + 1 + ob.tblLevels) + ob.runStride * (8 + 8 + 1)) + 4096;
+  if (E.outlVar.ensure(varFixed))
+    return -1;
+  {
+    Arena A;
+    A.base = static_cast<char*>(E.outlVar.p);
+    A.cap = E.outlVar.n;
+    ob.mag = A.take<uint64_t>(nb * ob.kStride);
+    ob.runs = A.take<uint64_t>(nb * ob.runStride);
+    ob.rng = A.take<uint64_t>(nb * ob.runStride);
+    ob.pos = A.take<uint32_t>(nb * ob.kStride);
+    ob.sgn = A.take<uint8_t>(nb * ob.kStride);
+    ob.tbl = A.take<int8_t>(nb * ob.kStride * ob.tblLevels);
+    ob.sval = A.take<int8_t>(nb * ob.runStride);
+    if (!ob.mag || !ob.runs || !ob.rng || !ob.pos || !ob.sgn || !ob.tbl || !ob.sval)
+      return -1;
+  }
+  if (launch_outlier_scan<T>(st, 2, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
+    return -1;
+  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  int maxPlanes = 1;
+  for (auto& o : hoc)
+    if (o.maxMag)
+      maxPlanes = std::max(maxPlanes, 64 - __builtin_clzll(o.maxMag));
+  // bits of one chunk's stream: every outlier has at most nlists sets above it, each with a
+  // sibling, and every one of those (and the value itself) gives at most one bit per plane, plus
+  // the value's sign; and never more than every node of the whole tree doing so
+  const uint64_t perOutlier = (uint64_t)(2 * ob.nlists + 2) * maxPlanes + 1;
+  const uint64_t sparse = (uint64_t)kmax * perOutlier + 2ull * maxPlanes;
+  const uint64_t dense = (uint64_t)P.N * (4ull * maxPlanes + 1);
+  const uint64_t maxBits = std::min(sparse, dense) + 64;
+  ob.streamStride = round_up((size_t)(maxBits / 64) + 4, 32);
+  if (E.outlStream.ensure((size_t)nb * ob.streamStride * 8 + 256))
+    return -1;
+  ob.stream = static_cast<uint64_t*>(E.outlStream.p);
+  HIP_CHECK(hipMemsetAsync(ob.stream, 0, (size_t)nb * ob.streamStride * 8, st));
+  HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 8, st));
+  if (launch_outlier_rmq(st, ob, kmax) || launch_speck1d_encode(st, ob))
+    return -1;
+  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<uint64_t> off2(nb + 1, 0);
+  for (uint32_t i = 0; i < nb; i++) {
+    if (hoc[i].error) {
+      fprintf(stderr, "[sperr_hip] outlier coder failed (chunk %u, code %u)\n", i, hoc[i].error);
+      return -1;
+    }
+    const uint64_t len = hoc[i].flagged ? 9 + (hoc[i].total_bits + 7) / 8 : 0;
+    off2[i + 1] = off2[i] + round_up(len, 16);
+  }
+  PweKeep K;
+  K.nb = nb;
+  const size_t headBytes = round_up((size_t)nb * 8, 256) + round_up((size_t)nb * 4, 256);
+  HIP_CHECK(hipMalloc(&K.mem, headBytes + off2[nb] + 256));
+  keep.v.push_back(K);
+  PweKeep& kk = keep.v.back();
+  kk.slotOff = reinterpret_cast<uint64_t*>(kk.mem);
+  kk.gids = reinterpret_cast<uint32_t*>(static_cast<char*>(kk.mem) + round_up((size_t)nb * 8, 256));
+  kk.slots = reinterpret_cast<uint8_t*>(static_cast<char*>(kk.mem) + headBytes);
+  HIP_CHECK(hipMemcpyAsync(kk.slotOff, off2.data(), nb * 8, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(kk.gids, bb.gids, nb * 4, hipMemcpyDeviceToDevice, st));
+  if (launch_outlier_stream_out(st, ob, kk.gids, kk.slots, kk.slotOff, d_lens2))
+    return -1;
+  HIP_CHECK(hipStreamSynchronize(st));   // off2 goes out of scope
+  return 0;
+}
+
 template <typename T>
 int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mode, double quality,
                   uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st)
 {
-  // mode 1: fixed rate, `quality` bits per value; mode 2: fixed PSNR, every bit plane is coded
+  // mode 1: fixed rate, `quality` bits per value; mode 2: fixed PSNR and mode 3: fixed point-wise
+  // error, every bit plane is coded
   const bool rate = mode == 1;
   const double bpp = rate ? quality : 0.0;
   Engine& E = g_engine;
@@ -810,13 +1035,16 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
   }
   if (E.slots.ensure(slotOff[nchunks] + 256))
     return -1;
-  const size_t miscBytes = round_up((size_t)nchunks * 8, 256) * 3 + 256;
+  const size_t miscBytes = round_up((size_t)nchunks * 8, 256) * 4 + 256;
   if (E.misc.ensure(miscBytes))
     return -1;
   uint64_t* d_slotOff = reinterpret_cast<uint64_t*>(E.misc.p);
   uint64_t* d_lens = d_slotOff + round_up(nchunks, 32);
   uint64_t* d_offs = d_lens + round_up(nchunks, 32);
-  uint64_t* d_total = d_offs + round_up(nchunks, 32);
+  uint64_t* d_lens2 = d_offs + round_up(nchunks, 32);   // outlier streams (PWE mode)
+  uint64_t* d_total = d_lens2 + round_up(nchunks, 32);
+  HIP_CHECK(hipMemsetAsync(d_lens2, 0, (size_t)nchunks * 8, st));
+  PweKeepList pweKeep;
   HIP_CHECK(hipMemcpyAsync(d_slotOff, slotOff.data(), nchunks * 8, hipMemcpyHostToDevice, st));
 
   VolDesc vd{{vol[0], vol[1], vol[2]}};
@@ -864,7 +1092,7 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
       for (uint32_t i = 0; i < nb; i++)
         orgAligned = orgAligned && hg[i].org[0] % (16 / sizeof(T)) == 0;
       if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
-                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, !rate,
+                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, mode == 2,
                               orgAligned))
         return -1;
       size_t k0 = 0;
@@ -882,7 +1110,9 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
       }
       if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst))
         return -1;
-      if (!rate && psnr_q_search(st, *P, bb, nb, quality))
+      if (mode == 2 && psnr_q_search(st, *P, bb, nb, quality))
+        return -1;
+      if (mode == 3 && pwe_q_setup(st, bb, nb, quality))
         return -1;
       if (launch_quantize(st, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
@@ -922,15 +1152,21 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
                  d_lens, P->N, 1);
       }
+      if (mode == 3 &&
+          pwe_outlier_stage<T>(st, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep))
+        return -1;
     }
   }
 
   // ---- container ----
-  LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_offs, nchunks,
+  LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs, nchunks,
            (uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2], (uint32_t)cdim[0],
            (uint32_t)cdim[1], (uint32_t)cdim[2], std::is_same<T, float>::value ? 1 : 0, d_total);
   LAUNCH_K(k_copy_slots, dim3(1024, nchunks), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap,
            static_cast<const uint8_t*>(E.slots.p), d_slotOff, d_lens, d_offs);
+  for (auto& k : pweKeep.v)
+    LAUNCH_K(k_copy_slots2, dim3(256, k.nb), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap, k.slots,
+             k.slotOff, k.gids, d_lens, d_lens2, d_offs);
   uint64_t total = 0;
   HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
@@ -1144,6 +1380,56 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
   HIP_CHECK(hipMemcpyAsync(heads.data(), d_heads, heads.size(), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
 
+  // PWE streams: a chunk's SPECK stream may be followed by an outlier stream, which counts only
+  // when all of it is there (src/SPECK_FLT.cpp:88-103)
+  struct OutHead {
+    bool has = false;
+    uint64_t off = 0, total_bits = 0;
+    int nbp = 0;
+  };
+  std::vector<OutHead> outHead(nchunks);
+  bool anyOutlier = false;
+  {
+    std::vector<uint64_t> tailOff(nchunks, 0), tailLen(nchunks, 0);
+    bool anyTail = false;
+    for (uint32_t i = 0; i < nchunks; i++) {
+      const uint8_t* hd = heads.data() + (size_t)i * 32;
+      if (ci.len[i] < 26 || (hd[0] & 0x01))
+        continue;
+      uint64_t tb;
+      memcpy(&tb, hd + 18, 8);
+      const uint64_t speckLen = std::min<uint64_t>(9 + (tb + 7) / 8, ci.len[i] - 17);
+      if (17 + speckLen + 9 <= ci.len[i]) {
+        tailOff[i] = ci.off[i] + 17 + speckLen;
+        tailLen[i] = ci.len[i] - 17 - speckLen;
+        anyTail = true;
+      }
+    }
+    if (anyTail) {
+      HIP_CHECK(hipMemcpyAsync(d_off, tailOff.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(d_len, tailLen.data(), nchunks * 8, hipMemcpyHostToDevice, st));
+      LAUNCH_K(k_gather_heads, dim3((nchunks + 63) / 64), dim3(64), 0, st, d_src, d_off, d_len,
+               d_heads, nchunks);
+      std::vector<uint8_t> tails((size_t)nchunks * 32);
+      HIP_CHECK(hipMemcpyAsync(tails.data(), d_heads, tails.size(), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (uint32_t i = 0; i < nchunks; i++) {
+        if (tailLen[i] < 9)
+          continue;
+        const uint8_t* t = tails.data() + (size_t)i * 32;
+        uint64_t ob;
+        memcpy(&ob, t + 1, 8);
+        if (tailLen[i] != 9 + (ob + 7) / 8)
+          continue;
+        outHead[i].has = true;
+        outHead[i].off = tailOff[i];
+        outHead[i].total_bits = ob;
+        outHead[i].nbp = t[0];
+        anyOutlier = true;
+      }
+    }
+  }
+
   struct Ref {
     uint32_t gid;
     uint32_t org[3];
@@ -1186,7 +1472,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       // (measured on MI355X: the streams do not overlap well enough -- 302 ms vs 200 ms for the
       // 1024^3 volume -- so sub-batching is opt-in: SPERR_HIP_SUBSTREAMS=1)
       static const bool substreams = getenv("SPERR_HIP_SUBSTREAMS") != nullptr;
-      const uint32_t nsub = (substreams && nbAll >= 16) ? kSubStreams : 1;
+      const uint32_t nsub = (substreams && nbAll >= 16 && !anyOutlier) ? kSubStreams : 1;
       struct SubHost {
         std::vector<ChunkGeom> hg;
         std::vector<uint64_t> ho, hl;
@@ -1280,18 +1566,83 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
                                   d.maskPixStride, d.st))
             return -1;
         }
-        // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters
-        const bool fxy = fuse_xy(*P);
+        // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters --
+        // unless outlier correctors have to be added to the transformed values first
+        // (src/SPECK_FLT.cpp:573-590), in which case every pass stays in the chunk buffer
+        bool batchOutliers = false;
+        for (uint32_t i = 0; i < nb; i++)
+          batchOutliers |= outHead[g.second[first + i].gid].has;
+        const bool fxy = fuse_xy(*P) && !batchOutliers;
         for (size_t k = P->fwd.size(); k-- > (fxy ? 2u : 0u);) {
           const LiftPass& ps = P->fwd[k];
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
-                          k == 0 ? (std::is_same<T, float>::value ? 1 : 2) : 0, d_dst, vd, bb.geom))
+                          (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
+                          d_dst, vd, bb.geom))
             return -1;
         }
         if (fxy && launch_lift_xy(ss, false, bb.vals, bb.valsStride, nb, cd, d.cst,
                                   std::is_same<T, float>::value ? 1 : 2, d_dst, vd, bb.geom))
           return -1;
-        if (P->fwd.empty() &&
+        if (batchOutliers) {
+          std::vector<OutlierChunk> hoc(nb);
+          memset(hoc.data(), 0, nb * sizeof(OutlierChunk));
+          uint64_t maxBits = 0;
+          int maxNbp = 1;
+          for (uint32_t i = 0; i < nb; i++) {
+            const OutHead& oh = outHead[g.second[first + i].gid];
+            if (!oh.has)
+              continue;
+            hoc[i].has = 1;
+            hoc[i].streamOff = oh.off;
+            hoc[i].total_bits = oh.total_bits;
+            hoc[i].nbp = oh.nbp;
+            if (oh.nbp > kMaxPlanes)
+              return -1;
+            maxBits = std::max(maxBits, oh.total_bits);
+            maxNbp = std::max(maxNbp, oh.nbp);
+          }
+          OutlierBufs ob;
+          memset(&ob, 0, sizeof(ob));
+          ob.nchunks = nb;
+          ob.N = P->N;
+          ob.nw = (P->N + 63) / 64;
+          ob.wordStride = round_up((size_t)ob.nw + 2, 32);
+          // every value found costs at least its sign bit, every run kept on a list its test bit
+          ob.kStride = round_up((size_t)std::min<uint64_t>(P->N, maxBits) + 1, 64);
+          speck1d_level_offsets(ob, P->N, std::min<uint64_t>(maxBits + 2, 2ull * P->N));
+          ob.streamStride = (size_t)(maxBits / 64) + 4;
+          ob.planeStride = (size_t)maxNbp * ob.wordStride;
+          const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) +
+                               (size_t)nb * (ob.wordStride * 16 + ob.kStride * 5 + ob.runStride * 8 +
+                                             ob.streamStride * 8 + ob.planeStride * 8) + 8192;
+          if (E.outlVar.ensure(bytes))
+            return -1;
+          Arena OA;
+          OA.base = static_cast<char*>(E.outlVar.p);
+          OA.cap = E.outlVar.n;
+          ob.oc = OA.take<OutlierChunk>(nb);
+          ob.lip = OA.take<uint64_t>(nb * ob.wordStride);
+          ob.lsp = OA.take<uint64_t>(nb * ob.wordStride);
+          ob.runs = OA.take<uint64_t>(nb * ob.runStride);
+          ob.stream = OA.take<uint64_t>(nb * ob.streamStride);
+          ob.planeBits = OA.take<uint64_t>(nb * ob.planeStride);
+          ob.pos = OA.take<uint32_t>(nb * ob.kStride);
+          ob.sgn = OA.take<uint8_t>(nb * ob.kStride);
+          if (!ob.oc || !ob.lip || !ob.lsp || !ob.runs || !ob.stream || !ob.planeBits || !ob.pos || !ob.sgn)
+            return -1;
+          HIP_CHECK(hipMemcpyAsync(ob.oc, hoc.data(), nb * sizeof(OutlierChunk), hipMemcpyHostToDevice, ss));
+          HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 16, ss));   // lip + lsp
+          if (launch_speck1d_decode(ss, ob, d_src, d.cst, bb.vals, bb.valsStride))
+            return -1;
+          HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, ss));
+          HIP_CHECK(hipStreamSynchronize(ss));
+          for (auto& o : hoc)
+            if (o.error) {
+              fprintf(stderr, "[sperr_hip] outlier decoder failed (code %u)\n", o.error);
+              return -1;
+            }
+        }
+        if ((P->fwd.empty() || batchOutliers) &&
             launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
           return -1;
         if (nsub > 1) {
@@ -1439,6 +1790,8 @@ size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_
     // a chunk has fewer sets than samples (the bound of max_payload_bits, engine-side)
     const uint64_t bits = raw ? rounded_budget(raw) : (uint64_t)(130.0 * n) + 64;
     total += 26 + (bits + 7) / 8 + 8;
+    if (mode == 3)   // the outlier stream: the same bound for the 1D coder over n values
+      total += 9 + ((uint64_t)(130.0 * n) + 64 + 7) / 8;
   }
   return total;
 }
@@ -1449,11 +1802,7 @@ int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t d
 {
   if (quality <= 0.0)
     return 2;
-  if (mode == 3) {
-    fprintf(stderr, "[sperr_hip] mode 3 (PWE) is not implemented on the GPU path yet\n");
-    return -1;
-  }
-  if (mode != 1 && mode != 2)
+  if (mode < 1 || mode > 3)
     return 2;
   if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
     return -1;

@@ -208,6 +208,53 @@ def test_psnr_mode_wide_coefficients_and_c_api(eng, oracle):
                           bits(oracle.decomp_3d(want, False)))
 
 
+@pytest.mark.parametrize("shape,chunks", [((50, 64, 72), (32, 32, 32)), ((64, 64, 64), (64, 64, 64)),
+                                          ((41, 128, 128), (64, 64, 41)), ((96, 96, 96), (48, 48, 48))])
+@pytest.mark.parametrize("tol", [0.2, 1e-2, 1e-4])
+def test_pwe_mode_matches_oracle(eng, oracle, shape, chunks, tol):
+    """Mode 3 (src/SPECK_FLT.cpp:280-281,461-486,573-584): q = 1.5 tol, full-depth coding, the
+    outlier list through the 1D coder (src/Outlier_Coder.cpp, src/SPECK1D_INT*.cpp): the
+    reference's bytes, its decoded values, and the tolerance itself is met."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 3, tol)
+    got = bytes(eng.compress(cuda(v), chunks, tol, mode=3).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    f_got, f_want = eng.decompress(dev, False).cpu().numpy(), oracle.decomp_3d(want, False)
+    assert np.array_equal(bits(f_got), bits(f_want))
+    assert np.abs(f_got - v.astype(np.float64)).max() <= tol
+
+
+def test_pwe_mode_wide_coefficients_constant_chunk_and_c_api(eng, oracle):
+    """A tolerance so small that the coefficients need more than 32 bits, a volume with a constant
+    chunk, double input, and the host C API in mode 3."""
+    v = smooth_field((32, 32, 64), dtype=np.float64)
+    v[:, :, :32] = 0.75
+    for tol in (1e-9, 1e-2):
+        want = oracle.comp_3d(v, (32, 32, 32), 3, tol)
+        got = bytes(eng.compress(cuda(v), (32, 32, 32), tol, mode=3).cpu().numpy())
+        assert got == want
+        assert eng.comp_3d(v, (32, 32, 32), 3, tol) == want
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        f = eng.decompress(dev, False).cpu().numpy()
+        assert np.array_equal(bits(f), bits(oracle.decomp_3d(want, False)))
+        assert np.abs(f - v).max() <= tol
+
+
+def test_pwe_mode_many_outliers(eng, oracle):
+    """Noise on top of a smooth field: a few per cent of the values become outliers, on several
+    bit planes of the 1D coder."""
+    rng = np.random.default_rng(11)
+    v = (turbulence((64, 64, 64)) + 0.3 * rng.standard_normal((64, 64, 64))).astype(np.float32)
+    for tol in (0.05, 0.5):
+        want = oracle.comp_3d(v, (64, 64, 64), 3, tol)
+        got = bytes(eng.compress(cuda(v), (64, 64, 64), tol, mode=3).cpu().numpy())
+        assert got == want
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()),
+                              bits(oracle.decomp_3d(want, True)))
+
+
 def test_high_precision_retry(eng, oracle):
     """src/SPECK_FLT.cpp:530-538: 32 planes cannot fill the budget -> 53 planes, 64-bit ints."""
     r = ramp_field((16, 16, 16))
