@@ -8,8 +8,9 @@
  *    /root/reference/src/SPERR_C_API.cpp:135-258): host buffers in, malloc'd host buffers out.
  *    The per-chunk pipeline (conditioner, CDF 9/7 DWT, quantiser, SPECK3D coder, bit packing)
  *    runs on the GPU; `nthreads` is accepted and ignored (the reference's OpenMP team size,
- *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate) and mode 2 (fixed PSNR) are implemented;
- *    mode 3 (point-wise error) returns -1.
+ *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate, `quality` = bits per value), mode 2
+ *    (fixed PSNR, dB) and mode 3 (fixed point-wise error, the tolerance; the outlier list goes
+ *    through the reference's Outlier_Coder / SPECK1D_INT stream format) are implemented.
  *
  * 2. Device-resident entry points (sperrhip_*): the volume and the container stay in HBM, which
  *    is what bench.py times and what an application that already holds its field on the GPU

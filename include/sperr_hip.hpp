@@ -9,8 +9,8 @@
 //
 // compiles unchanged when it includes this header instead and links -lsperr_hip.  The chunk
 // pipeline itself runs on the GPU; set_num_threads() is accepted and ignored.  The fixed-rate
-// (set_bitrate) and fixed-PSNR (set_psnr) modes are implemented on the GPU path; set_tolerance
-// makes compress() return RTNType::Error.
+// (set_bitrate), fixed-PSNR (set_psnr) and fixed point-wise error (set_tolerance) modes all run
+// on the GPU path.
 #ifndef SPERR_HIP_HPP
 #define SPERR_HIP_HPP
 

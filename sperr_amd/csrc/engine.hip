@@ -868,7 +868,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   ob.nw = (P.N + 63) / 64;
   ob.wordStride = round_up((size_t)ob.nw + 2, 32);
   {
-    const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) + (size_t)nb * ob.wordStride * (8 + 4 + 8) + 1024;
+    const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) + (size_t)nb * ob.wordStride * (5 * 8 + 2 * 4) + 4096;
     if (E.outlFixed.ensure(bytes))
       return -1;
     Arena A;
@@ -877,8 +877,12 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     ob.oc = A.take<OutlierChunk>(nb);
     ob.outMask = A.take<uint64_t>(nb * ob.wordStride);
     ob.lip = A.take<uint64_t>(nb * ob.wordStride);
+    ob.signMask = A.take<uint64_t>(nb * ob.wordStride);
+    ob.maskGE = A.take<uint64_t>(nb * ob.wordStride);
+    ob.maskEQ = A.take<uint64_t>(nb * ob.wordStride);
     ob.outPre = A.take<uint32_t>(nb * ob.wordStride);
-    if (!ob.oc || !ob.outMask || !ob.lip || !ob.outPre)
+    ob.cpos = A.take<uint32_t>(nb * ob.wordStride);
+    if (!ob.oc || !ob.outMask || !ob.lip || !ob.signMask || !ob.maskGE || !ob.maskEQ || !ob.outPre || !ob.cpos)
       return -1;
   }
   HIP_CHECK(hipMemsetAsync(ob.oc, 0, nb * sizeof(OutlierChunk), st));
@@ -916,11 +920,8 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   for (auto& o : hoc)
     kmax = std::max(kmax, o.count);
   ob.kStride = round_up(std::max<size_t>(kmax, 1), 64);
-  ob.tblLevels = 1;
-  while ((2u << (ob.tblLevels - 1)) <= kmax)
-    ob.tblLevels++;
   speck1d_level_offsets(ob, P.N, 2ull * kmax + 2);
-  const size_t varFixed = (size_t)nb * (ob.kStride * (4 + 8 + 1 + ob.tblLevels) + ob.runStride * (8 + 8 + 1)) + 4096;
+  const size_t varFixed = (size_t)nb * (ob.kStride * (4 + 8 + 1 + 1 + 4 + 1) + ob.runStride * 8) + 8192;
   if (E.outlVar.ensure(varFixed))
     return -1;
   {
@@ -929,12 +930,12 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     A.cap = E.outlVar.n;
     ob.mag = A.take<uint64_t>(nb * ob.kStride);
     ob.runs = A.take<uint64_t>(nb * ob.runStride);
-    ob.rng = A.take<uint64_t>(nb * ob.runStride);
     ob.pos = A.take<uint32_t>(nb * ob.kStride);
+    ob.posGE = A.take<uint32_t>(nb * ob.kStride);
     ob.sgn = A.take<uint8_t>(nb * ob.kStride);
-    ob.tbl = A.take<int8_t>(nb * ob.kStride * ob.tblLevels);
-    ob.sval = A.take<int8_t>(nb * ob.runStride);
-    if (!ob.mag || !ob.runs || !ob.rng || !ob.pos || !ob.sgn || !ob.tbl || !ob.sval)
+    ob.msb = A.take<uint8_t>(nb * ob.kStride);
+    ob.sgnGE = A.take<uint8_t>(nb * ob.kStride);
+    if (!ob.mag || !ob.runs || !ob.pos || !ob.posGE || !ob.sgn || !ob.msb || !ob.sgnGE)
       return -1;
   }
   if (launch_outlier_scan<T>(st, 2, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
@@ -958,7 +959,8 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   ob.stream = static_cast<uint64_t*>(E.outlStream.p);
   HIP_CHECK(hipMemsetAsync(ob.stream, 0, (size_t)nb * ob.streamStride * 8, st));
   HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 8, st));
-  if (launch_outlier_rmq(st, ob, kmax) || launch_speck1d_encode(st, ob))
+  HIP_CHECK(hipMemsetAsync(ob.maskGE, 0, (size_t)nb * ob.wordStride * 8, st));
+  if (launch_speck1d_encode(st, ob))
     return -1;
   HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));

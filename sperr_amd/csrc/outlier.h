@@ -35,20 +35,23 @@ struct OutlierBufs {
   size_t wordStride;             // >= nw + 2
   uint64_t* outMask;             // encoder: positions of the outliers
   uint32_t* outPre;              //          outliers before each mask word ([nw] = their number)
+  uint64_t* signMask;            //          positions of the non-negative ones
+  uint64_t* maskGE;              //          outliers at or above the current threshold, by position
+  uint64_t* maskEQ;              //          ... whose msb is the current plane
+  uint32_t* cpos;                //          set bits of maskGE before each word ([nw] = all)
   uint64_t* lip;                 // LIP bitmask (SPECK_INT.cpp:120-125)
   uint64_t* lsp;                 // decoder: LSP bitmask
   size_t kStride;                // outliers (encoder) / significant values (decoder) per chunk
   uint32_t* pos;                 // encoder: position of every outlier, ascending; decoder: of every value found
   uint64_t* mag;                 // encoder: quantised magnitudes
   uint8_t* sgn;                  // encoder: 1 = non-negative; decoder: plane | sign << 7
-  int8_t* tbl;                   // encoder: range-maximum table of the msb, [level][kStride] per chunk
-  uint32_t tblLevels;
+  uint8_t* msb;                  // encoder: msb of every magnitude
+  uint32_t* posGE;               // encoder, per plane: positions / signs of the outliers at or
+  uint8_t* sgnGE;                //   above the threshold, in order
   uint32_t nlists;               // LIS levels (src/SPECK1D_INT.cpp:19-34)
   uint32_t levelOff[kO1MaxLevels + 1];   // first entry of each level inside a chunk's list storage
   size_t runStride;
   uint64_t* runs;                // start | length << 32
-  uint64_t* rng;                 // encoder: first outlier | one past the last << 32
-  int8_t* sval;                  // encoder: msb of the largest magnitude inside (-1: none)
   size_t streamStride;           // 64-bit words
   uint64_t* stream;
   uint64_t* planeBits;           // decoder: refinement bits of every plane, [plane][wordStride]
@@ -63,7 +66,6 @@ int launch_outlier_scan(hipStream_t st, int pass, const T* vol, VolDesc vd, cons
                         const uint32_t cdims[3], const double* vals, size_t valsStride,
                         const CoderState* cst, double tol, const OutlierBufs& b);
 int launch_outlier_prefix(hipStream_t st, const OutlierBufs& b);
-int launch_outlier_rmq(hipStream_t st, const OutlierBufs& b, uint32_t maxCount);
 int launch_speck1d_encode(hipStream_t st, const OutlierBufs& b);
 // chunk slot = {u8 planes, u64 total_bits, payload}; lens2[gid] = its length (0: no outliers)
 int launch_outlier_stream_out(hipStream_t st, const OutlierBufs& b, const uint32_t* gids,

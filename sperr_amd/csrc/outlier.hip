@@ -80,9 +80,11 @@ k_outlier_scan(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uin
       const bool f2 = flag && m != 0;
       const unsigned long long word = __ballot(f2);
       if (PASS == 1) {
+        const unsigned long long sgw = __ballot(f2 && ll >= 0);
         if (lane == 0) {
           b.outMask[c * b.wordStride + w] = word;
           b.outPre[c * b.wordStride + w] = (uint32_t)__popcll(word);
+          b.signMask[c * b.wordStride + w] = sgw;
         }
       }
       else if (f2) {
@@ -91,7 +93,7 @@ k_outlier_scan(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uin
           b.pos[c * b.kStride + k] = i;
           b.mag[c * b.kStride + k] = m;
           b.sgn[c * b.kStride + k] = ll >= 0 ? 1 : 0;
-          b.tbl[c * b.kStride * b.tblLevels + k] = (int8_t)(63 - __clzll((long long)m));
+          b.msb[c * b.kStride + k] = (uint8_t)(63 - __clzll((long long)m));
         }
         best = m > best ? m : best;
       }
@@ -134,27 +136,30 @@ __global__ void __launch_bounds__(1024) k_outlier_prefix(OutlierBufs b)
   }
 }
 
-// tbl[j][i] = max msb over outliers [i, i + 2^j)
-__global__ void __launch_bounds__(kThreads) k_outlier_rmq(OutlierBufs b, uint32_t j)
-{
-  const uint32_t c = blockIdx.y;
-  const uint32_t K = b.oc[c].count;
-  const uint32_t span = 1u << j;
-  if (K < span)
-    return;
-  int8_t* t = b.tbl + c * b.kStride * b.tblLevels;
-  const int8_t* prev = t + (size_t)(j - 1) * b.kStride;
-  int8_t* cur = t + (size_t)j * b.kStride;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i + span <= K;
-       i += gridDim.x * blockDim.x) {
-    const int8_t a = prev[i], d = prev[i + span / 2];
-    cur[i] = a > d ? a : d;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // SPECK1D, one wavefront per chunk
 // ------------------------------------------------------------------------------------------
+// The set recursion is strictly sequential, so it is written for the scalar unit: every value that
+// steers it is wave-uniform (readfirstlane / readlane results), and the small indexed arrays it
+// needs -- the recursion stack and the list lengths -- live in vector registers addressed by LANE
+// (v_readlane / v_writelane with a uniform index), not in LDS or scratch.
+__device__ __forceinline__ uint32_t rfl(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t rfl64(uint64_t v)
+{
+  return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l)
+{
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ void wrlane(uint32_t& v, uint32_t l, uint32_t val)
+{
+  v = threadIdx.x == l ? val : v;   // (val and l are wave-uniform)
+}
+
 template <bool ENC>
 __global__ void __launch_bounds__(64)
 k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
@@ -176,32 +181,35 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     return;
   const uint32_t lane = threadIdx.x;
   const uint32_t N = b.N, nw = b.nw;
-  const uint32_t K = ENC ? oc.count : 0u;
-  const int nbp = ENC ? 64 - __clzll((long long)oc.maxMag) : oc.nbp;
+  const uint32_t K = ENC ? rfl(oc.count) : 0u;
+  const int nbp = (int)rfl((uint32_t)(ENC ? 64 - __clzll((long long)oc.maxMag) : oc.nbp));
 
   uint64_t* lip = b.lip + c * b.wordStride;
   uint64_t* runs = b.runs + c * b.runStride;
-  uint64_t* rng = ENC ? b.rng + c * b.runStride : nullptr;
-  int8_t* sval = ENC ? b.sval + c * b.runStride : nullptr;
   unsigned long long* words = reinterpret_cast<unsigned long long*>(b.stream + c * b.streamStride);
-  const uint64_t* outMask = ENC ? b.outMask + c * b.wordStride : nullptr;
-  const uint32_t* outPre = ENC ? b.outPre + c * b.wordStride : nullptr;
+  // encoder: the outliers (ascending position) and, per plane, those at or above the threshold
   const uint32_t* opos = b.pos + c * b.kStride;
-  (void)opos;
   const uint64_t* omag = ENC ? b.mag + c * b.kStride : nullptr;
   const uint8_t* osgn = b.sgn + c * b.kStride;
-  const int8_t* tbl = ENC ? b.tbl + c * b.kStride * b.tblLevels : nullptr;
+  const uint8_t* omsb = ENC ? b.msb + c * b.kStride : nullptr;
+  uint32_t* posGE = ENC ? b.posGE + c * b.kStride : nullptr;
+  uint8_t* sgnGE = ENC ? b.sgnGE + c * b.kStride : nullptr;
+  unsigned long long* maskGE = ENC ? reinterpret_cast<unsigned long long*>(b.maskGE + c * b.wordStride) : nullptr;
+  unsigned long long* maskEQ = ENC ? reinterpret_cast<unsigned long long*>(b.maskEQ + c * b.wordStride) : nullptr;
+  uint32_t* cpos = ENC ? b.cpos + c * b.wordStride : nullptr;
+  const uint64_t* signMask = ENC ? b.signMask + c * b.wordStride : nullptr;
+  // decoder
   uint64_t* lsp = ENC ? nullptr : b.lsp + c * b.wordStride;
   uint64_t* planeBits = ENC ? nullptr : b.planeBits + c * b.planeStride;
-  uint32_t* fpos = b.pos + c * b.kStride;      // decoder: values found
+  uint32_t* fpos = b.pos + c * b.kStride;      // values found
   uint8_t* fmeta = b.sgn + c * b.kStride;
 
-  __shared__ uint32_t sh_n[kO1MaxLevels + 1];
-  __shared__ uint32_t st_start[kO1MaxLevels + 2], st_len[kO1MaxLevels + 2];
-  __shared__ uint32_t st_lo[kO1MaxLevels + 2], st_mid[kO1MaxLevels + 2], st_hi[kO1MaxLevels + 2];
-  __shared__ uint32_t st_state[kO1MaxLevels + 2];   // next child | found << 8 | level << 16
-  for (uint32_t i = lane; i <= (uint32_t)kO1MaxLevels; i += 64)
-    sh_n[i] = 0;
+  // lane-indexed registers: list length / first slot / end slot of level `lane`; recursion stack
+  uint32_t vCnt = 0;
+  const uint32_t vOff = b.levelOff[min(lane, (uint32_t)kO1MaxLevels)];
+  const uint32_t vEnd = b.levelOff[min(lane + 1u, (uint32_t)kO1MaxLevels)];
+  uint32_t vS = 0, vL = 0, vA = 0, vM = 0, vB = 0, vT = 0;   // start, len, counts at start / mid / end, state
+  uint32_t err = 0;
 
   // ---- bit writer (encoder): bits leave in order through `acc`; whole-word results of the
   //      lane-parallel passes are OR-ed straight into the zeroed stream
@@ -227,8 +235,8 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
   auto window = [&]() -> uint64_t {
     const uint64_t wi = rpos >> 6;
     if (wi != cw) {
-      w0 = (wi == cw + 1) ? w1 : words[wi];
-      w1 = words[wi + 1];
+      w0 = (wi == cw + 1) ? w1 : rfl64(words[wi]);
+      w1 = rfl64(words[wi + 1]);
       cw = wi;
     }
     const uint32_t sh = (uint32_t)(rpos & 63);
@@ -240,20 +248,30 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     return bit;
   };
 
-  // ---- encoder geometry: outliers before position x; msb of the largest magnitude in [lo, hi)
-  auto rank_of = [&](uint32_t x) -> uint32_t {
-    if (x >= N)
-      return K;
+  // ---- encoder: number of outliers at or above the threshold before position x.  Inside a run
+  //      with at most 64 of them their positions sit in a register (lane i = i-th of the run), so
+  //      the whole recursion below such a run needs no memory access
+  uint32_t vWinPos = 0, vWinSgn = 0, winBase = 0, winCnt = 0;
+  auto rank_mem = [&](uint32_t x) -> uint32_t {
     const uint32_t w = x >> 6;
-    return outPre[w] + (uint32_t)__popcll(outMask[w] & low_mask(x & 63u));
+    const uint32_t pre = cpos[w];
+    const uint64_t m = maskGE[w];
+    return rfl(pre + (uint32_t)__popcll(m & low_mask(x & 63u)));
   };
-  auto range_msb = [&](uint32_t lo, uint32_t hi) -> int {
-    if (hi <= lo)
-      return -1;
-    const uint32_t j = 31u - (uint32_t)__clz((int)(hi - lo));
-    const int8_t* t = tbl + (size_t)j * b.kStride;
-    const int a = t[lo], d = t[hi - (1u << j)];
-    return a > d ? a : d;
+  auto win_covers = [&](uint32_t a, uint32_t e) -> bool { return a >= winBase && e <= winBase + winCnt; };
+  auto win_load = [&](uint32_t a, uint32_t e) {   // e - a <= 64
+    winBase = a;
+    winCnt = e - a;
+    const bool in = lane < winCnt;
+    vWinPos = in ? posGE[a + lane] : 0xffffffffu;
+    vWinSgn = in ? (uint32_t)sgnGE[a + lane] : 0u;
+  };
+  auto rank_in = [&](uint32_t x, uint32_t a, uint32_t e) -> uint32_t {   // a, e: counts at the run's ends
+    if (e == a)
+      return a;
+    if (win_covers(a, e))
+      return winBase + (uint32_t)__popcll(__ballot(lane < winCnt && vWinPos < x));
+    return rank_mem(x);
   };
 
   uint32_t nfound = 0, lspDone = 0;   // decoder: values found so far / of them, already in the LSP mask
@@ -261,32 +279,62 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     if (lane == 0)
       atomicOr(reinterpret_cast<unsigned long long*>(lip) + (x >> 6), 1ull << (x & 63u));
   };
-  auto list_push = [&](uint32_t lev, uint32_t start, uint32_t len, uint32_t lo, uint32_t hi, int s) {
-    const uint32_t idx = sh_n[lev];
-    const uint32_t slot = b.levelOff[lev] + idx;
-    if (slot < b.levelOff[lev + 1]) {
-      if (lane == 0) {
+  auto list_push = [&](uint32_t lev, uint32_t start, uint32_t len) {
+    const uint32_t idx = rdlane(vCnt, lev);
+    const uint32_t slot = rdlane(vOff, lev) + idx;
+    if (slot < rdlane(vEnd, lev)) {
+      if (lane == 0)
         runs[slot] = (uint64_t)start | ((uint64_t)len << 32);
-        if (ENC) {
-          rng[slot] = (uint64_t)lo | ((uint64_t)hi << 32);
-          sval[slot] = (int8_t)s;
-        }
-      }
-      sh_n[lev] = idx + 1;
+      wrlane(vCnt, lev, idx + 1);
     }
     else
-      oc.error = 2;   // list storage exhausted (cannot happen with the host's bounds)
+      err = 2;   // list storage exhausted (cannot happen with the host's bounds)
   };
 
   // src/SPECK1D_INT.cpp:19-34 : the two halves of the array start on the list of level 1
-  {
-    const uint32_t l0 = N - N / 2;
-    const uint32_t m = ENC ? rank_of(l0) : 0u;
-    list_push(1, 0, l0, 0, m, ENC ? range_msb(0, m) : 0);
-    list_push(1, l0, N / 2, m, K, ENC ? range_msb(m, K) : 0);
-  }
+  list_push(1, 0, N - N / 2);
+  list_push(1, N - N / 2, N / 2);
 
   for (int p = nbp - 1; p >= 0; p--) {
+    if (ENC) {
+      // ---- this plane's threshold structures: EQ = outliers whose msb is p, GE = at or above
+      for (uint32_t w = lane; w < nw; w += 64)
+        maskEQ[w] = 0ull;
+      __threadfence_block();
+      for (uint32_t kb = 0; kb < K; kb += 64) {
+        const uint32_t k = kb + lane;
+        if (k < K && (int)omsb[k] == p) {
+          const uint32_t x = opos[k];
+          atomicOr(maskEQ + (x >> 6), 1ull << (x & 63u));
+          atomicOr(maskGE + (x >> 6), 1ull << (x & 63u));
+        }
+      }
+      __threadfence_block();
+      uint32_t run = 0;
+      for (uint32_t wb = 0; wb < nw; wb += 64) {
+        const uint32_t w = wb + lane;
+        const uint32_t cntw = w < nw ? (uint32_t)__popcll(maskGE[w]) : 0u;
+        const uint32_t inc = wave_inclusive_scan<uint32_t>(cntw);
+        if (w < nw)
+          cpos[w] = run + inc - cntw;
+        run += rdlane(inc, 63);
+      }
+      if (lane == 0)
+        cpos[nw] = run;
+      run = 0;
+      for (uint32_t kb = 0; kb < K; kb += 64) {
+        const uint32_t k = kb + lane;
+        const bool in = k < K && (int)omsb[k] >= p;
+        const uint64_t bm = __ballot(in);
+        if (in) {
+          const uint32_t j = run + (uint32_t)__popcll(bm & low_mask(lane));
+          posGE[j] = opos[k];
+          sgnGE[j] = osgn[k];
+        }
+        run += (uint32_t)__popcll(bm);
+      }
+      winCnt = 0;
+    }
     __threadfence_block();
     // ================= LIP pass (src/SPECK1D_INT_ENC.cpp:15-45, _DEC.cpp:15-45) =================
     for (uint32_t wb = 0; wb < nw; wb += 64) {
@@ -297,43 +345,36 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
         continue;
       if (ENC) {
         // every lane codes the pixels of its own word: test bit, then the sign of a significant one
-        uint64_t plo = 0, phi = 0, keep = lw;
+        uint64_t plo = 0, phi = 0;
         uint32_t len = 0;
         if (lw) {
-          const uint64_t om = outMask[w];
-          const uint32_t pre = outPre[w];
+          const uint64_t sig = lw & maskEQ[w];
+          const uint64_t sgn = signMask[w];
           uint64_t m = lw;
           while (m) {
             const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
             m &= m - 1;
-            uint32_t sig = 0, sg = 0;
-            if ((om >> j) & 1ull) {
-              const uint32_t k = pre + (uint32_t)__popcll(om & low_mask(j));
-              sig = tbl[k] == p;
-              sg = osgn[k];
-            }
-            if (sig) {
+            if ((sig >> j) & 1ull) {
               if (len < 64)
                 plo |= 1ull << len;
               else
                 phi |= 1ull << (len - 64);
               len++;
-              if (sg) {
+              if ((sgn >> j) & 1ull) {
                 if (len < 64)
                   plo |= 1ull << len;
                 else
                   phi |= 1ull << (len - 64);
               }
-              keep &= ~(1ull << j);
             }
             len++;
           }
-          if (keep != lw)
-            lip[w] = keep;
+          if (sig)
+            lip[w] = lw & ~sig;
         }
         flush_acc();
         const uint32_t inc = wave_inclusive_scan<uint32_t>(len);
-        const uint32_t total = __shfl(inc, 63, 64);
+        const uint32_t total = rdlane(inc, 63);
         if (plo | phi) {
           const uint64_t at = wpos + (inc - len);
           const uint32_t sh = (uint32_t)(at & 63);
@@ -355,7 +396,7 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
         while (nz) {
           const uint32_t l = (uint32_t)__ffsll((long long)nz) - 1u;
           nz &= nz - 1;
-          const uint64_t wv = __shfl(lw, (int)l, 64);
+          const uint64_t wv = (uint64_t)rdlane((uint32_t)lw, l) | ((uint64_t)rdlane((uint32_t)(lw >> 32), l) << 32);
           uint64_t keep = wv, m = wv;
           while (m) {
             const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
@@ -378,19 +419,23 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
 
     // ================= LIS pass, smallest sets first (ENC.cpp:47-56, DEC.cpp:47-54) =============
     for (uint32_t lev = b.nlists; lev-- > 0;) {
-      const uint32_t n = sh_n[lev];
+      const uint32_t n = rdlane(vCnt, lev);
       if (n == 0)
         continue;
       __threadfence_block();
-      const uint32_t base = b.levelOff[lev];
+      const uint32_t base = rdlane(vOff, lev);
       uint32_t wr = 0;
       for (uint32_t rd = 0; rd < n; rd += 64) {
         const uint32_t blockN = min(64u, n - rd);
         const bool valid = lane < blockN;
         const uint64_t myRun = valid ? runs[base + rd + lane] : 0ull;
-        const uint64_t myRng = (ENC && valid) ? rng[base + rd + lane] : 0ull;
-        const int myS = (ENC && valid) ? (int)sval[base + rd + lane] : -1;
-        const uint64_t sigmask = ENC ? __ballot(valid && myS == p) : 0ull;
+        uint32_t myA = 0, myB = 0;
+        if (ENC && valid) {   // every lane tests its own entry: outliers at or above the threshold inside
+          const uint32_t s0 = (uint32_t)myRun, e0 = s0 + (uint32_t)(myRun >> 32);
+          myA = cpos[s0 >> 6] + (uint32_t)__popcll(maskGE[s0 >> 6] & low_mask(s0 & 63u));
+          myB = e0 >= N ? cpos[nw] : cpos[e0 >> 6] + (uint32_t)__popcll(maskGE[e0 >> 6] & low_mask(e0 & 63u));
+        }
+        const uint64_t sigmask = ENC ? __ballot(valid && myB > myA) : 0ull;
         uint32_t i = 0;
         while (i < blockN) {
           // entries that stay insignificant, up to the next significant one
@@ -405,13 +450,8 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
             z = min(z, blockN - i);
           }
           if (z) {
-            if (lane >= i && lane < i + z && wr + (lane - i) != rd + lane) {
+            if (lane >= i && lane < i + z && wr + (lane - i) != rd + lane)
               runs[base + wr + (lane - i)] = myRun;
-              if (ENC) {
-                rng[base + wr + (lane - i)] = myRng;
-                sval[base + wr + (lane - i)] = (int8_t)myS;
-              }
-            }
             wr += z;
             if (ENC)
               skip_zeros(z);
@@ -428,43 +468,54 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
             put(1);
           else
             rpos++;
-          const uint64_t er = __shfl(myRun, (int)i, 64);
-          const uint64_t eg = __shfl(myRng, (int)i, 64);
-          i++;
           uint32_t sp = 1;
-          st_start[0] = (uint32_t)er;
-          st_len[0] = (uint32_t)(er >> 32);
-          st_lo[0] = (uint32_t)eg;
-          st_hi[0] = (uint32_t)(eg >> 32);
-          st_state[0] = lev << 16;
+          wrlane(vS, 0, rdlane((uint32_t)myRun, i));
+          wrlane(vL, 0, rdlane((uint32_t)(myRun >> 32), i));
+          wrlane(vT, 0, lev << 16);
+          if (ENC) {
+            const uint32_t a0 = rdlane(myA, i), e0 = rdlane(myB, i);
+            wrlane(vA, 0, a0);
+            wrlane(vB, 0, e0);
+            if (e0 - a0 <= 64 && !win_covers(a0, e0))
+              win_load(a0, e0);
+          }
+          i++;
           while (sp > 0) {
             const uint32_t f = sp - 1;
-            const uint32_t state = st_state[f];
+            const uint32_t state = rdlane(vT, f);
             const uint32_t k = state & 0xffu, found = (state >> 8) & 0xffu, flev = state >> 16;
             if (k == 2) {
               sp--;
               continue;
             }
-            const uint32_t ps = st_start[f], pl = st_len[f];
+            const uint32_t ps = rdlane(vS, f), pl = rdlane(vL, f);
             const uint32_t l0 = pl - pl / 2;
-            if (ENC && k == 0)
-              st_mid[f] = rank_of(ps + l0);
+            uint32_t clo = 0, chi = 0;
+            if (ENC) {
+              const uint32_t fa = rdlane(vA, f), fb = rdlane(vB, f);
+              uint32_t fm;
+              if (k == 0) {
+                fm = rank_in(ps + l0, fa, fb);
+                wrlane(vM, f, fm);
+              }
+              else
+                fm = rdlane(vM, f);
+              clo = k == 0 ? fa : fm;
+              chi = k == 0 ? fm : fb;
+            }
             const uint32_t cs = k == 0 ? ps : ps + l0;
             const uint32_t cl = k == 0 ? l0 : pl / 2;
-            const uint32_t clo = ENC ? (k == 0 ? st_lo[f] : st_mid[f]) : 0u;
-            const uint32_t chi = ENC ? (k == 0 ? st_mid[f] : st_hi[f]) : 0u;
             const bool coded = k == 0 || found != 0;
             uint32_t sig = 1;
             uint32_t nstate = (k + 1) | (found << 8) | (flev << 16);
             if (cl == 1) {   // a pixel (m_process_P)
               if (ENC) {
-                const int s = chi > clo ? (int)tbl[clo] : -1;
                 if (coded) {
-                  sig = s == p;
+                  sig = chi > clo;
                   put(sig);
                 }
-                if (sig)
-                  put(osgn[clo]);
+                if (sig)   // (its run has one outlier, so the register window holds it)
+                  put(win_covers(clo, chi) ? rdlane(vWinSgn, clo - winBase) : rfl((uint32_t)sgnGE[clo]));
               }
               else {
                 if (coded)
@@ -482,14 +533,12 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
                 nstate |= 1u << 8;
               else
                 lip_set(cs);
-              st_state[f] = nstate;
+              wrlane(vT, f, nstate);
             }
             else {           // a set (m_process_S)
-              int s = 0;
               if (ENC) {
-                s = range_msb(clo, chi);
                 if (coded) {
-                  sig = s == p;
+                  sig = chi > clo;
                   put(sig);
                 }
               }
@@ -497,23 +546,27 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
                 sig = get();
               if (sig) {
                 nstate |= 1u << 8;
-                st_state[f] = nstate;
-                st_start[sp] = cs;
-                st_len[sp] = cl;
-                st_lo[sp] = clo;
-                st_hi[sp] = chi;
-                st_state[sp] = (flev + 1) << 16;
+                wrlane(vT, f, nstate);
+                wrlane(vS, sp, cs);
+                wrlane(vL, sp, cl);
+                wrlane(vT, sp, (flev + 1) << 16);
+                if (ENC) {
+                  wrlane(vA, sp, clo);
+                  wrlane(vB, sp, chi);
+                  if (chi - clo <= 64 && !win_covers(clo, chi))
+                    win_load(clo, chi);
+                }
                 sp++;
               }
               else {
-                st_state[f] = nstate;
-                list_push(flev + 1, cs, cl, clo, chi, s);
+                wrlane(vT, f, nstate);
+                list_push(flev + 1, cs, cl);
               }
             }
           }
         }
       }
-      sh_n[lev] = wr;
+      wrlane(vCnt, lev, wr);
     }
 
     // ================= refinement pass (SPECK_INT.cpp:310-357 / 359-469) ========================
@@ -521,7 +574,7 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
       flush_acc();
       for (uint32_t kb = 0; kb < K; kb += 64) {
         const uint32_t k = kb + lane;
-        const bool in = k < K && (int)tbl[k] > p;
+        const bool in = k < K && (int)omsb[k] > p;
         const uint32_t bit = in ? (uint32_t)((omag[k] >> p) & 1ull) : 0u;
         const uint64_t lm = __ballot(in);
         if (bit) {
@@ -555,7 +608,7 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
           }
           pb[w] = res;
         }
-        rpos += __shfl(inc, 63, 64);
+        rpos += rdlane(inc, 63);
       }
       // the values found in this plane join the LSP (SPECK_INT.cpp:462-468)
       __threadfence_block();
@@ -573,12 +626,14 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     if (lane == 0) {
       oc.nbp = nbp;
       oc.total_bits = wpos;
+      if (err)
+        oc.error = err;
     }
   }
   else {
-    if (nfound > b.kStride) {
+    if (nfound > b.kStride || err) {
       if (lane == 0)
-        oc.error = 3;
+        oc.error = err ? err : 3;
       return;
     }
     if (lane == 0)
@@ -684,16 +739,6 @@ template int launch_outlier_scan<double>(hipStream_t, int, const double*, VolDes
 int launch_outlier_prefix(hipStream_t st, const OutlierBufs& b)
 {
   LAUNCH_K(k_outlier_prefix, dim3(b.nchunks), dim3(1024), 0, st, b);
-  HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-int launch_outlier_rmq(hipStream_t st, const OutlierBufs& b, uint32_t maxCount)
-{
-  for (uint32_t j = 1; j < b.tblLevels && (1u << j) <= maxCount; j++) {
-    const uint32_t blocks = capped_blocks((maxCount + kThreads - 1) / kThreads, b.nchunks);
-    LAUNCH_K(k_outlier_rmq, dim3(blocks, b.nchunks), dim3(kThreads), 0, st, b, j);
-  }
   HIP_CHECK(hipGetLastError());
   return 0;
 }
