@@ -357,6 +357,42 @@ def test_256_cube_chunk_bpp2(eng, oracle):
                           bits(oracle.decomp_3d(want, True)))
 
 
+def test_config2_fp64_128cube_chunks_pwe(eng, oracle):
+    """BASELINE.json configs[1]: a 128x128x256 fp64 field in 128^3 chunks at PWE = 1e-6 (the named
+    file is not in the reference tree; SURVEY.md 8(d) substitutes the synthetic field, kept in
+    fp64).  Same container as the oracle, same decoded doubles, tolerance met."""
+    v = turbulence((256, 128, 128), dtype=np.float64)
+    want = oracle.comp_3d(v, (128, 128, 128), 3, 1e-6, nthreads=2)
+    got = bytes(eng.compress(cuda(v), (128, 128, 128), 1e-6, mode=3).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    f = eng.decompress(dev, False).cpu().numpy()
+    assert np.array_equal(bits(f), bits(oracle.decomp_3d(want, False)))
+    assert np.abs(f - v).max() <= 1e-6
+
+
+def test_pwe_full_size_properties(eng):
+    """512^3 fp32 in 256^3 chunks, point-wise error mode: the tolerance holds for every value,
+    two runs give the same bytes, and a chunk's stream does not depend on its neighbours."""
+    import struct
+    import torch
+    from sperr_amd.synth import turbulence_torch
+    vol = turbulence_torch((512, 512, 512), "cuda")
+    tol = 2e-3
+    s1 = eng.compress(vol, (256, 256, 256), tol, mode=3).clone()
+    s2 = eng.compress(vol, (256, 256, 256), tol, mode=3)
+    assert torch.equal(s1, s2)
+    back = eng.decompress(s1, True)
+    # (the float cast of the output may add half an ulp of the value to the fp64 error)
+    assert (back.double() - vol.double()).abs().max().item() <= tol * (1 + 1e-3)
+    lens = struct.unpack_from("<8I", bytes(s1[20:52].cpu().numpy()))
+    sub = vol[:256, :256, 256:].contiguous()
+    s_sub = eng.compress(sub, (256, 256, 256), tol, mode=3)
+    hdr = 20 + 4 * 8
+    assert s_sub.numel() == 18 + lens[1]
+    assert torch.equal(s_sub[18:], s1[hdr + lens[0]: hdr + lens[0] + lens[1]])
+
+
 def test_full_size_roundtrip_properties(eng):
     """512^3 in 256^3 chunks at 2 bpp: size-independent properties -- exact stream length,
     determinism (checksum of two runs), bounded error, chunk independence (a chunk's stream does
