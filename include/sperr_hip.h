@@ -102,8 +102,15 @@ void sperrhip_profile_enable(int on);
  * two event records per launch of every kernel cost a few percent of a step. */
 void sperrhip_profile_only(const char* kernel);
 void sperrhip_profile_reset(void);
-/* Fills up to `cap` entries; returns the number of stages. names[i] points to a static string. */
+/* Fills up to `cap` entries; returns the number of stages. names[i] points to a static string.
+ * millis: time during which the kernel was running (decoding enqueues sub-batches on several
+ * streams, whose launches of one kernel overlap; for everything else this is the sum of the
+ * launch durations). */
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap);
+/* Same, plus the plain sum of the launch durations (sum / launches = what a kernel trace
+ * reports as the average duration); sum_millis may be NULL. */
+int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_millis,
+                          int* launches, int cap);
 
 /* Diagnostics of the table-driven LIS decoder: when `on`, thread 0 of every decoding workgroup
  * accumulates shader-clock ticks per phase; out64 (64 entries, may be NULL) receives the counters

@@ -19,7 +19,7 @@ EXPORTS = [
     "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
-    "sperrhip_profile_get", "sperrhip_profile_only", "sperrhip_version", "sperrhip_debug_lis_stamps",
+    "sperrhip_profile_get", "sperrhip_profile_get2", "sperrhip_profile_only", "sperrhip_version", "sperrhip_debug_lis_stamps",
 ]
 
 
@@ -65,6 +65,9 @@ def load_library():
                                                 C.POINTER(C.c_int), _vp]
     lib.sperrhip_profile_enable.argtypes = [C.c_int]
     lib.sperrhip_profile_only.argtypes = [C.c_char_p]
+    lib.sperrhip_profile_get2.restype = C.c_int
+    lib.sperrhip_profile_get2.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
     lib.sperrhip_profile_get.restype = C.c_int
     lib.sperrhip_profile_get.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                          C.POINTER(C.c_int), C.c_int]
@@ -237,10 +240,15 @@ class SperrHip:
         if on:
             self.lib.sperrhip_profile_reset()
 
-    def profile_report(self):
+    def profile_report(self, with_sum=False):
+        """{kernel: (ms during which it was running, launches)}; with_sum: (busy ms, launches, sum
+        of the launch durations) -- launches of sub-batches on different streams overlap."""
         cap = 128
         names = (C.c_char_p * cap)()
         ms = (C.c_double * cap)()
+        sm = (C.c_double * cap)()
         cnt = (C.c_int * cap)()
-        n = self.lib.sperrhip_profile_get(names, ms, cnt, cap)
+        n = self.lib.sperrhip_profile_get2(names, ms, sm, cnt, cap)
+        if with_sum:
+            return {names[i].decode(): (ms[i], cnt[i], sm[i]) for i in range(min(n, cap))}
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}

@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -34,25 +35,27 @@ namespace sperrhip {
 namespace {
 
 struct ProfEntry {
-  double ms = 0.0;
+  double ms = 0.0;     // sum of the launch durations
+  double busy = 0.0;   // time during which at least one launch of the kernel was running (launches
+                       // of sub-batches on different streams overlap)
   int launches = 0;
 };
 
 struct Profiler {
   bool on = false;
   std::string only;   // when not empty: only launches of this kernel are bracketed
+  std::mutex mu;      // sub-batches are enqueued from several host threads
   std::vector<hipEvent_t> pool;
   size_t used = 0;
+  hipEvent_t ref = nullptr;   // origin of the time axis of one collect() period
   struct Open {
     const char* name;
     hipEvent_t a, b;
   };
   std::vector<Open> open;
-  const char* cur = nullptr;
-  hipEvent_t curA = nullptr;
   std::map<std::string, ProfEntry> acc;
 
-  hipEvent_t get()
+  hipEvent_t get()   // (mu held)
   {
     if (used == pool.size()) {
       hipEvent_t e;
@@ -64,20 +67,45 @@ struct Profiler {
   }
   void collect()
   {
+    std::lock_guard<std::mutex> lock(mu);
+    std::map<std::string, std::vector<std::pair<float, float>>> spans;
     for (auto& o : open) {
-      float ms = 0.f;
+      float ms = 0.f, t0 = 0.f;
       if (o.a && o.b && hipEventElapsedTime(&ms, o.a, o.b) == hipSuccess) {
         auto& e = acc[o.name];
         e.ms += ms;
         e.launches++;
+        if (ref && hipEventElapsedTime(&t0, ref, o.a) == hipSuccess)
+          spans[o.name].push_back({t0, t0 + ms});
+        else
+          e.busy += ms;
       }
+    }
+    for (auto& kv : spans) {
+      auto& v = kv.second;
+      std::sort(v.begin(), v.end());
+      double busy = 0.0;
+      float lo = v[0].first, hi = v[0].second;
+      for (size_t i = 1; i < v.size(); i++) {
+        if (v[i].first > hi) {
+          busy += hi - lo;
+          lo = v[i].first;
+          hi = v[i].second;
+        }
+        else
+          hi = std::max(hi, v[i].second);
+      }
+      acc[kv.first].busy += busy + (hi - lo);
     }
     open.clear();
     used = 0;
+    ref = nullptr;
   }
 };
 
 Profiler g_prof;
+thread_local const char* t_prof_cur = nullptr;
+thread_local hipEvent_t t_prof_a = nullptr;
 
 }  // namespace
 
@@ -85,21 +113,28 @@ void prof_begin(const char* name, hipStream_t stream)
 {
   if (!g_prof.on || (!g_prof.only.empty() && g_prof.only != name))
     return;
-  g_prof.cur = name;
-  g_prof.curA = g_prof.get();
-  if (g_prof.curA)
-    hipEventRecord(g_prof.curA, stream);
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (!g_prof.ref) {
+    g_prof.ref = g_prof.get();
+    if (g_prof.ref)
+      hipEventRecord(g_prof.ref, stream);
+  }
+  t_prof_cur = name;
+  t_prof_a = g_prof.get();
+  if (t_prof_a)
+    hipEventRecord(t_prof_a, stream);
 }
 
 void prof_end(hipStream_t stream)
 {
-  if (!g_prof.on || !g_prof.cur)
+  if (!g_prof.on || !t_prof_cur)
     return;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   hipEvent_t b = g_prof.get();
   if (b)
     hipEventRecord(b, stream);
-  g_prof.open.push_back({g_prof.cur, g_prof.curA, b});
-  g_prof.cur = nullptr;
+  g_prof.open.push_back({t_prof_cur, t_prof_a, b});
+  t_prof_cur = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1469,18 +1504,25 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       Arena A;
       A.base = static_cast<char*>(E.arena.p);
       A.cap = E.arena.n;
-      // The LIS phase is one latency-bound workgroup per chunk; sub-batches on separate streams
-      // let the bandwidth-bound kernels of one sub-batch run beside the LIS kernels of another.
-      // (measured on MI355X: the streams do not overlap well enough -- 302 ms vs 200 ms for the
-      // 1024^3 volume -- so sub-batching is opt-in: SPERR_HIP_SUBSTREAMS=1)
-      static const bool substreams = getenv("SPERR_HIP_SUBSTREAMS") != nullptr;
-      const uint32_t nsub = (substreams && nbAll >= 16 && !anyOutlier) ? kSubStreams : 1;
+      // The LIS phase of a plane keeps one latency-bound workgroup per chunk busy; sub-batches on
+      // separate streams let the bandwidth-bound kernels of one sub-batch run beside the LIS
+      // kernels of another.  Measured on MI355X, 64 chunks of 256^3: 1 stream 130 ms per
+      // compress + decompress step, 2 streams 124 ms, 3 streams 122 ms, 4 streams 154 ms (the
+      // GPU-wide list kernels of four sub-batches get in each other's way).
+      // SPERR_HIP_SUBSTREAMS=n overrides the choice (1 = a single stream).
+      static const int subEnv = getenv("SPERR_HIP_SUBSTREAMS") ? atoi(getenv("SPERR_HIP_SUBSTREAMS")) : 0;
+      uint32_t nsub = nbAll >= 48 ? 3u : nbAll >= 32 ? 2u : 1u;
+      if (subEnv > 0)
+        nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
+      if (anyOutlier || nbAll < 2 * nsub)
+        nsub = 1;
       struct SubHost {
         std::vector<ChunkGeom> hg;
         std::vector<uint64_t> ho, hl;
         std::vector<DecState> hs;
         DecBatchBufs bb;
         uint32_t nb = 0;
+        size_t first = 0;
       };
       std::vector<SubHost> subs(nsub);
       if (nsub > 1) {
@@ -1491,16 +1533,27 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       uint32_t done = 0;
       for (uint32_t q = 0; q < nsub; q++) {
         SubHost& S = subs[q];
-        const uint32_t nb = (nbAll - done + (nsub - q) - 1) / (nsub - q);
-        const size_t first = b0 + done;
-        done += nb;
-        S.nb = nb;
+        S.nb = (nbAll - done + (nsub - q) - 1) / (nsub - q);
+        S.first = b0 + done;
+        done += S.nb;
+        if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb))
+          return -1;
+      }
+      int devId = 0;
+      HIP_CHECK(hipGetDevice(&devId));
+      // everything one sub-batch enqueues on its stream.  With several sub-batches each is
+      // enqueued by its own host thread: one thread would start the last sub-batch only after
+      // launching all kernels of the others (about 1300 launches each)
+      auto enqueue = [&](uint32_t q) -> int {
+        SubHost& S = subs[q];
+        const uint32_t nb = S.nb;
+        const size_t first = S.first;
         if (nb == 0)
-          continue;
+          return 0;
+        if (nsub > 1)
+          HIP_CHECK(hipSetDevice(devId));
         hipStream_t ss = nsub > 1 ? E.sub[q] : st;
         DecBatchBufs& bb = S.bb;
-        if (!carve_dec(A, *P, nb, maxPayload, bb))
-          return -1;
         DecBuffers& d = bb.db;
         S.hg.resize(nb);
         S.ho.resize(nb);
@@ -1647,9 +1700,33 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         if ((P->fwd.empty() || batchOutliers) &&
             launch_scatter<T>(ss, d_dst, vd, bb.geom, nb, cd, bb.vals, bb.valsStride, d.cst))
           return -1;
-        if (nsub > 1) {
+        if (nsub > 1)
           HIP_CHECK(hipEventRecord(E.evJoin[q], ss));
-          HIP_CHECK(hipStreamWaitEvent(st, E.evJoin[q], 0));
+        return 0;
+      };
+      if (nsub == 1) {
+        if (enqueue(0))
+          return -1;
+      }
+      else {
+        // (SPERR_HIP_ENQUEUE_THREADS=1: one host thread per sub-batch; measured no gain on MI355X)
+        static const bool threads = getenv("SPERR_HIP_ENQUEUE_THREADS") != nullptr;
+        std::vector<int> rc(nsub, 0);
+        if (threads) {
+          std::vector<std::thread> workers;
+          for (uint32_t q = 0; q < nsub; q++)
+            workers.emplace_back([&, q]() { rc[q] = enqueue(q); });
+          for (auto& w : workers)
+            w.join();
+        }
+        else
+          for (uint32_t q = 0; q < nsub; q++)
+            rc[q] = enqueue(q);
+        for (uint32_t q = 0; q < nsub; q++) {
+          if (rc[q])
+            return -1;
+          if (subs[q].nb)
+            HIP_CHECK(hipStreamWaitEvent(st, E.evJoin[q], 0));
         }
       }
       // read-backs only after every sub-batch is enqueued: a device-to-host copy into pageable
@@ -1764,11 +1841,18 @@ void sperrhip_profile_reset(void)
 }
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap)
 {
+  return sperrhip_profile_get2(names, millis, nullptr, launches, cap);
+}
+int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_millis, int* launches,
+                          int cap)
+{
   int i = 0;
   for (auto& kv : g_prof.acc) {
     if (i < cap) {
       names[i] = kv.first.c_str();
-      millis[i] = kv.second.ms;
+      busy_millis[i] = kv.second.busy;
+      if (sum_millis)
+        sum_millis[i] = kv.second.ms;
       launches[i] = kv.second.launches;
     }
     i++;

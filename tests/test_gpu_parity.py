@@ -393,6 +393,17 @@ def test_pwe_full_size_properties(eng):
     assert torch.equal(s_sub[18:], s1[hdr + lens[0]: hdr + lens[0] + lens[1]])
 
 
+def test_many_chunks_decode_in_sub_batches(eng, oracle):
+    """48 chunks of one shape: the decoder splits the batch into sub-batches on separate streams
+    (engine.hip, decompress_impl); same values as the oracle."""
+    v = turbulence((192, 256, 256))
+    want = oracle.comp_3d(v, (64, 64, 64), 1, 2.0, nthreads=8)
+    got = eng.compress(cuda(v), (64, 64, 64), 2.0)
+    assert bytes(got.cpu().numpy()) == want
+    assert np.array_equal(bits(eng.decompress(got, True).cpu().numpy()),
+                          bits(oracle.decomp_3d(want, True)))
+
+
 def test_full_size_roundtrip_properties(eng):
     """512^3 in 256^3 chunks at 2 bpp: size-independent properties -- exact stream length,
     determinism (checksum of two runs), bounded error, chunk independence (a chunk's stream does
