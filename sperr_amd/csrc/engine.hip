@@ -1738,7 +1738,11 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         hipStream_t ss = nsub > 1 ? E.sub[q] : st;
         if (S.bb.db.lisStamps && q == 0) {
           g_lis_stamps_host.assign(64, 0);
-          HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), S.bb.db.lisStamps, 64 * 8,
+          // (SPERR_HIP_STAMP_CHUNK=i: the counters of the batch's i-th chunk instead of the first)
+          const uint32_t sc = getenv("SPERR_HIP_STAMP_CHUNK")
+                                  ? std::min<uint32_t>(S.nb - 1, (uint32_t)atoi(getenv("SPERR_HIP_STAMP_CHUNK")))
+                                  : 0u;
+          HIP_CHECK(hipMemcpyAsync(g_lis_stamps_host.data(), S.bb.db.lisStamps + (size_t)sc * 64, 64 * 8,
                                    hipMemcpyDeviceToHost, ss));
         }
         S.hs.resize(S.nb);   // stream errors (wrong lengths) surface here
