@@ -1,0 +1,69 @@
+"""Randomised parity sweep (-m gpu): random small volumes, chunkings, modes and qualities; the
+HIP container must equal the oracle's byte for byte and decode to the same values."""
+import numpy as np
+import pytest
+
+from fields import smooth_field
+from sperr_amd.synth import turbulence
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from sperr_amd.api import SperrHip
+    return SperrHip()
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    shape = tuple(int(v) for v in rng.integers(9, 56, size=3))            # (z, y, x)
+    chunks = tuple(int(min(s, v)) for s, v in zip(shape[::-1], rng.integers(8, 60, size=3)))
+    dtype = np.float32 if rng.random() < 0.7 else np.float64
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        v = turbulence(shape, seed=int(seed) + 1, dtype=dtype)
+    elif kind == 1:
+        v = smooth_field(shape, seed=int(seed) + 3, dtype=dtype)
+    else:   # noisy: many outliers in PWE mode, several bit planes of them
+        v = (turbulence(shape, seed=int(seed) + 5, dtype=np.float64) +
+             0.2 * rng.standard_normal(shape) * (rng.random(shape) < 0.2)).astype(dtype)
+    if rng.random() < 0.2:   # a constant block (constant chunk when the chunking lines up)
+        v[: shape[0] // 2, : shape[1] // 2, : shape[2] // 2] = 1.5
+    mode = int(rng.integers(1, 4))
+    span = float(v.max() - v.min()) or 1.0
+    if mode == 1:
+        quality = float(rng.choice([0.3, 1.0, 2.5, 7.0, 19.0]))
+    elif mode == 2:
+        quality = float(rng.choice([30.0, 62.5, 101.0, 150.0]))
+    else:
+        quality = span * float(rng.choice([0.2, 3e-2, 1e-3, 1e-5]))
+    return v, chunks, mode, quality
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_case(eng, seed):
+    from oracle.pyoracle import Oracle
+    oracle = Oracle()
+    v, chunks, mode, quality = make_case(1000 + seed)
+    want = oracle.comp_3d(v, chunks, mode, quality)
+    got = bytes(eng.compress(cuda(v), chunks, quality, mode=mode).cpu().numpy())
+    assert got == want, (v.shape, chunks, mode, quality, str(v.dtype))
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    for as_float in (True, False):
+        assert np.array_equal(bits(eng.decompress(dev, as_float).cpu().numpy()),
+                              bits(oracle.decomp_3d(want, as_float))), (v.shape, chunks, mode, quality)
+    if mode == 3:
+        assert np.abs(oracle.decomp_3d(want, False) - v.astype(np.float64)).max() <= quality
