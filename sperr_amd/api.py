@@ -98,7 +98,8 @@ class SperrHip:
     def compress(self, vol, chunks_xyz, bpp, out=None, mode=1):
         """vol: cuda tensor float32/float64 shaped (z, y, x). Returns a cuda uint8 tensor view of
         the container (a slice of `out` when given).  mode 1: `bpp` is the bit rate; mode 2: it is
-        the target PSNR in dB (the reference's modes, include/SPERR_C_API.h:95-99)."""
+        the target PSNR in dB; mode 3: the point-wise error tolerance (the reference's modes,
+        include/SPERR_C_API.h:95-99)."""
         torch = self.torch
         assert vol.is_cuda and vol.is_contiguous() and vol.dim() == 3
         assert vol.dtype in (torch.float32, torch.float64)

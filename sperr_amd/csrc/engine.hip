@@ -11,6 +11,7 @@
 //   src/SPERR_C_API.cpp:135-258             C API semantics (ownership, return codes)
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -432,13 +433,13 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
 // ------------------------------------------------------------------------------------------
 // engine singleton
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSubStreams = 4;
+constexpr uint32_t kSubStreams = 8;
 
 struct Engine {
   std::mutex mu;
   bool ready = false;
-  hipStream_t sub[kSubStreams] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t sub[kSubStreams] = {};
+  hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {};
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
@@ -820,6 +821,22 @@ int psnr_q_search(hipStream_t st, const ShapePlan& P, EncBatchBufs& bb, uint32_t
   return 0;
 }
 
+// diagnostics: SPERR_HIP_TIMING=1 prints host-side wall-clock marks of the PWE stages
+struct HostMarks {
+  bool on = getenv("SPERR_HIP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what, hipStream_t st)
+  {
+    if (!on)
+      return;
+    (void)hipStreamSynchronize(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sperr_hip] %-28s %8.2f ms\n", what,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // PWE mode (src/SPECK_FLT.cpp:280-281): q = 1.5 tol for every chunk; chunks whose largest
 // coefficient needs more than 32 bits are flagged for the 64-bit pass (SPECK_FLT.cpp:324-337)
 int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol)
@@ -885,6 +902,8 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
                       uint64_t* d_lens2, PweKeepList& keep)
 {
   EncBuffers& e = bb.eb;
+  HostMarks hm;
+  hm.mark("(3D coder done)", st);
   if (launch_inv_quantize(st, false, bb.coef32, e.coefStride, e.sign, e.signStride, nb, P.N, bb.vals,
                           bb.valsStride, e.cst) ||
       launch_inv_quantize(st, true, bb.vals, bb.valsStride, e.sign, e.signStride, nb, P.N, bb.vals,
@@ -896,6 +915,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
                     vd, bb.geom))
       return -1;
   }
+  hm.mark("inverse path", st);
   OutlierBufs ob;
   memset(&ob, 0, sizeof(ob));
   ob.nchunks = nb;
@@ -927,6 +947,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   std::vector<OutlierChunk> hoc(nb);
   HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  hm.mark("outlier pass 0", st);
   bool any = false;
   for (auto& o : hoc) {
     if (!o.flagged)
@@ -951,6 +972,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     return -1;
   HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  hm.mark("outlier pass 1 + prefix", st);
   uint32_t kmax = 0;
   for (auto& o : hoc)
     kmax = std::max(kmax, o.count);
@@ -977,6 +999,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     return -1;
   HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  hm.mark("alloc + outlier pass 2", st);
   int maxPlanes = 1;
   for (auto& o : hoc)
     if (o.maxMag)
@@ -999,6 +1022,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     return -1;
   HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
+  hm.mark("1D coder", st);
   std::vector<uint64_t> off2(nb + 1, 0);
   for (uint32_t i = 0; i < nb; i++) {
     if (hoc[i].error) {
@@ -1022,6 +1046,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   if (launch_outlier_stream_out(st, ob, kk.gids, kk.slots, kk.slotOff, d_lens2))
     return -1;
   HIP_CHECK(hipStreamSynchronize(st));   // off2 goes out of scope
+  hm.mark("stream out", st);
   return 0;
 }
 
