@@ -93,6 +93,24 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
                                 size_t dimz, void* d_coef, uint64_t* d_sign, int* width_out,
                                 void* hip_stream);
 
+/* ---- multi-resolution decoding ---------------------------------------------------------------
+ * sperr::SPERR3D_OMP_D::decompress(p, multi_res = true) + release_hierarchy()
+ * (/root/reference/include/SPERR3D_OMP_D.h:22-29, src/SPERR3D_OMP_D.cpp:50-150,
+ * src/CDF97.cpp:150-168, src/SPECK_FLT.cpp:592-603): besides the volume, the volume at every
+ * coarsened resolution of the chunks (src/sperr_helper.cpp:70-123), coarsest first, as doubles.
+ * Exists only when the chunks are dyadic and tile the volume; otherwise there are 0 levels. */
+/* number of levels and their dims (level_dims: 3 entries per level, x y z; room for 16 levels) */
+int sperrhip_multires_levels(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x, size_t chunk_y,
+                             size_t chunk_z, size_t* nlev, size_t* level_dims);
+/* d_levels: host array of `nlev` device pointers, level h sized by sperrhip_multires_levels */
+int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int output_float,
+                                     void* d_dst, size_t dst_cap_bytes, size_t nlev,
+                                     double* const* d_levels, void* hip_stream);
+/* host buffers: *dst must be NULL; *dst and levels[0 .. *nlev) are malloc'd (free() them) */
+int sperrhip_decomp_3d_multires(const void* src, size_t src_len, int output_float, size_t* dimx,
+                                size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
+                                size_t* level_dims, double** levels);
+
 /* ---- profiling ------------------------------------------------------------------------------ */
 
 /* When enabled, the engine brackets every pipeline stage with HIP events on the launch stream

@@ -118,11 +118,23 @@ class SPERR3D_OMP_D {
   // the pointer MUST be the one given to use_bitstream (SPERR3D_OMP_D.cpp:53-56)
   auto decompress(const void* bitstream, bool multi_res = false) -> RTNType
   {
-    if (bitstream == nullptr || m_ptr == nullptr || bitstream != m_ptr || multi_res)
+    if (bitstream == nullptr || m_ptr == nullptr || bitstream != m_ptr)
       return RTNType::Error;
     void* dst = nullptr;
     size_t dx, dy, dz;
-    if (sperr_decomp_3d(m_ptr, m_len, 0, 0, &dx, &dy, &dz, &dst) != 0)
+    m_hierarchy.clear();
+    if (multi_res) {   // SPERR3D_OMP_D.cpp:68-84,121-130: the volume at every coarsened resolution
+      size_t nlev = 0, ldims[48];
+      double* levels[16] = {};
+      if (sperrhip_decomp_3d_multires(m_ptr, m_len, 0, &dx, &dy, &dz, &dst, &nlev, ldims, levels) != 0)
+        return RTNType::Error;
+      for (size_t h = 0; h < nlev; h++) {
+        const size_t n = ldims[3 * h] * ldims[3 * h + 1] * ldims[3 * h + 2];
+        m_hierarchy.emplace_back(levels[h], levels[h] + n);
+        std::free(levels[h]);
+      }
+    }
+    else if (sperr_decomp_3d(m_ptr, m_len, 0, 0, &dx, &dy, &dz, &dst) != 0)
       return RTNType::Error;
     const auto* d = static_cast<const double*>(dst);
     m_vol.assign(d, d + dx * dy * dz);
@@ -131,6 +143,8 @@ class SPERR3D_OMP_D {
   }
   auto view_decoded_data() const -> const vecd_type& { return m_vol; }
   auto release_decoded_data() -> vecd_type&& { return std::move(m_vol); }
+  auto view_hierarchy() const -> const std::vector<vecd_type>& { return m_hierarchy; }
+  auto release_hierarchy() -> std::vector<vecd_type>&& { return std::move(m_hierarchy); }
   auto get_dims() const -> dims_type { return m_dims; }
   auto get_chunk_dims() const -> dims_type { return m_chunk_dims; }
 
@@ -139,6 +153,7 @@ class SPERR3D_OMP_D {
   const uint8_t* m_ptr = nullptr;
   size_t m_len = 0;
   vecd_type m_vol;
+  std::vector<vecd_type> m_hierarchy;   // multi-resolution decoding, coarsest first
 };
 
 // ---- src/SPECK_FLT.cpp:11-606 + src/SPECK3D_FLT.cpp: one chunk ---------------------------------

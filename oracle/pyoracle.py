@@ -141,6 +141,9 @@ class Oracle(_CApiMixin):
         L.orc_speck3d_encode.restype = C.c_int
         L.orc_speck3d_decode.argtypes = [_vp, _sz, _vp, _vp, _vp]
         L.orc_speck3d_decode.restype = C.c_int
+        L.orc_decomp_3d_multi_res.restype = C.c_int
+        L.orc_decomp_3d_multi_res.argtypes = [_vp, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz),
+                                              C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _vp, _vp]
         L.orc_speck1d_encode.argtypes = [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
         L.orc_speck1d_encode.restype = C.c_int
         L.orc_speck1d_decode.argtypes = [_vp, _sz, _sz, _vp, _vp]
@@ -218,6 +221,29 @@ class Oracle(_CApiMixin):
         self.lib.orc_speck3d_decode(buf.ctypes.data, buf.size, self._dims((dx, dy, dz)),
                                     coef.ctypes.data, sign.ctypes.data)
         return coef, sign
+
+    def decomp_3d_multi_res(self, stream, nthreads=1):
+        """-> (volume float64 (z, y, x), [level volumes float64, coarsest first])."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        d = [_sz(0) for _ in range(3)]
+        dst, nlev = _vp(None), _sz(0)
+        ldims = ((_sz * 3) * 16)()
+        levels = (_vp * 16)()
+        rtn = self.lib.orc_decomp_3d_multi_res(buf.ctypes.data, _sz(buf.size), _sz(nthreads),
+                                               C.byref(d[0]), C.byref(d[1]), C.byref(d[2]),
+                                               C.byref(dst), C.byref(nlev), ldims, levels)
+        if rtn:
+            raise RuntimeError(f"orc_decomp_3d_multi_res returned {rtn}")
+        shape = (d[2].value, d[1].value, d[0].value)
+        vol = np.frombuffer(C.string_at(dst.value, int(np.prod(shape)) * 8), dtype=np.float64).reshape(shape).copy()
+        self._libc.free(dst)
+        out = []
+        for h in range(nlev.value):
+            sh = (ldims[h][2], ldims[h][1], ldims[h][0])
+            out.append(np.frombuffer(C.string_at(levels[h], int(np.prod(sh)) * 8),
+                                     dtype=np.float64).reshape(sh).copy())
+            self._libc.free(_vp(levels[h]))
+        return vol, out
 
     def speck1d_encode(self, coef, sign_bools):
         """coef: uint64[n]; sign_bools: bool[n] (True = non-negative). Returns the stream."""
@@ -341,6 +367,29 @@ class Ref(_CApiMixin):
         self.probe.refp_speck3d_decode(buf.ctypes.data, buf.size, dx, dy, dz, coef.ctypes.data,
                                        sign.ctypes.data)
         return coef, sign
+
+    def decomp_3d_multi_res(self, stream, nthreads=1):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dims = (_sz * 3)()
+        vol = _vp(None)
+        ldims = ((_sz * 3) * 16)()
+        levels = (_vp * 16)()
+        self.probe.refp_decomp_multi_res.restype = C.c_int
+        self.probe.refp_decomp_multi_res.argtypes = [_vp, _sz, _sz, _vp, C.POINTER(_vp), _vp, _vp, _sz]
+        n = self.probe.refp_decomp_multi_res(buf.ctypes.data, _sz(buf.size), _sz(nthreads), dims,
+                                             C.byref(vol), ldims, levels, _sz(16))
+        if n < 0:
+            raise RuntimeError("refp_decomp_multi_res failed")
+        shape = (dims[2], dims[1], dims[0])
+        v = np.frombuffer(C.string_at(vol.value, int(np.prod(shape)) * 8), dtype=np.float64).reshape(shape).copy()
+        self._libc.free(vol)
+        out = []
+        for h in range(n):
+            sh = (ldims[h][2], ldims[h][1], ldims[h][0])
+            out.append(np.frombuffer(C.string_at(levels[h], int(np.prod(sh)) * 8),
+                                     dtype=np.float64).reshape(sh).copy())
+            self._libc.free(_vp(levels[h]))
+        return v, out
 
     def speck1d_encode(self, coef, sign_bools, width=8):
         c = np.ascontiguousarray(coef, dtype=np.uint64)

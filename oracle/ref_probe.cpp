@@ -13,6 +13,7 @@
 #include "SPECK1D_INT_DEC.h"
 #include "SPECK1D_INT_ENC.h"
 #include "SPECK3D_FLT.h"
+#include "SPERR3D_OMP_D.h"
 #include "SPECK3D_INT_DEC.h"
 #include "SPECK3D_INT_ENC.h"
 #include "sperr_helper.h"
@@ -200,6 +201,38 @@ size_t refp_chunk_volume(size_t vx, size_t vy, size_t vz, size_t cx, size_t cy, 
     for (size_t k = 0; k < 6; k++)
       out6[i * 6 + k] = chunks[i][k];
   return chunks.size();
+}
+
+
+// SPERR3D_OMP_D::decompress(p, multi_res = true): the volume (malloc'd doubles) and every level of
+// the hierarchy (malloc'd doubles, coarsest first); returns the number of levels or -1
+int refp_decomp_multi_res(const uint8_t* stream, size_t len, size_t nthreads, size_t dims[3],
+                          double** vol, size_t (*ldims)[3], double** levels, size_t cap)
+{
+  sperr::SPERR3D_OMP_D dec;
+  dec.set_num_threads(nthreads);
+  if (dec.use_bitstream(stream, len) != sperr::RTNType::Good)
+    return -1;
+  if (dec.decompress(stream, true) != sperr::RTNType::Good)
+    return -1;
+  const auto d = dec.get_dims();
+  const auto cd = dec.get_chunk_dims();
+  for (int a = 0; a < 3; a++)
+    dims[a] = d[a];
+  const auto& v = dec.view_decoded_data();
+  *vol = static_cast<double*>(std::malloc(v.size() * sizeof(double)));
+  std::memcpy(*vol, v.data(), v.size() * sizeof(double));
+  const auto res = sperr::coarsened_resolutions(d, cd);
+  const auto& h = dec.view_hierarchy();
+  if (h.size() != res.size() || h.size() > cap)
+    return -1;
+  for (size_t i = 0; i < h.size(); i++) {
+    for (int a = 0; a < 3; a++)
+      ldims[i][a] = res[i][a];
+    levels[i] = static_cast<double*>(std::malloc(h[i].size() * sizeof(double)));
+    std::memcpy(levels[i], h[i].data(), h[i].size() * sizeof(double));
+  }
+  return static_cast<int>(h.size());
 }
 
 }  // extern "C"

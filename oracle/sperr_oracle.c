@@ -328,8 +328,39 @@ void orc_dwt3d(double* buf, const size_t dims[3])
   free(tmp);
 }
 
+/* src/sperr_helper.cpp:70-97 : the coarsened resolutions of a dyadic chunk, coarsest first */
+size_t orc_coarsened_resolutions(const size_t dims[3], size_t (*res)[3], size_t cap)
+{
+  size_t levels;
+  if (!orc_can_use_dyadic(dims, &levels))
+    return 0;
+  for (size_t lev = levels; lev > 0; lev--) {
+    const size_t h = levels - lev;
+    if (res && h < cap)
+      for (int a = 0; a < 3; a++) {
+        size_t d;
+        orc_approx_detail_len(dims[a], lev, &res[h][a], &d);
+      }
+  }
+  return levels;
+}
+
+static void idwt3d_impl(double* buf, const size_t dims[3], double** hier);
+
 /* src/CDF97.cpp:141-148,227-302,366-385,431-474 */
 void orc_idwt3d(double* buf, const size_t dims[3])
+{
+  idwt3d_impl(buf, dims, NULL);
+}
+
+/* src/CDF97.cpp:150-168 : before every level of the inverse transform the approximation corner
+ * (the volume at that coarser resolution, unscaled) is copied out, coarsest first */
+void orc_idwt3d_multi_res(double* buf, const size_t dims[3], double** hier)
+{
+  idwt3d_impl(buf, dims, hier);
+}
+
+static void idwt3d_impl(double* buf, const size_t dims[3], double** hier)
 {
   const cdf_consts c = cdf_make_consts();
   size_t maxlen = dims[0] > dims[1] ? dims[0] : dims[1];
@@ -340,6 +371,17 @@ void orc_idwt3d(double* buf, const size_t dims[3])
   if (orc_can_use_dyadic(dims, &levels)) {
     for (size_t lev = levels; lev > 0; lev--) {
       size_t region[3];
+      if (hier) { /* m_sub_volume, src/CDF97.cpp:581-593 */
+        size_t sub[3];
+        for (int a = 0; a < 3; a++)
+          orc_approx_detail_len(dims[a], lev, &sub[a], &d);
+        double* dst = hier[levels - lev];
+        for (size_t z = 0; z < sub[2]; z++)
+          for (size_t y = 0; y < sub[1]; y++) {
+            memcpy(dst, buf + (z * dims[1] + y) * dims[0], sub[0] * sizeof(double));
+            dst += sub[0];
+          }
+      }
       for (int a = 0; a < 3; a++)
         orc_approx_detail_len(dims[a], lev - 1, &region[a], &d);
       cdf_lift_axis(buf, dims, 2, region, 0, &c, tmp);
@@ -1503,16 +1545,38 @@ int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8
   return rtn;
 }
 
+static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t dims[3],
+                                 double* out, double** hier);
+
 /* src/SPECK_FLT.cpp:27-109,543-606 */
 int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3], double* out)
 {
+  return chunk_decompress_impl(stream, len, dims, out, NULL);
+}
+
+/* src/SPECK_FLT.cpp:543-620 with multi_res: hier[h] receives the chunk at its h-th coarsened
+ * resolution (orc_coarsened_resolutions), mean added back (:592-603).  A constant chunk fills
+ * them with its value (the reference leaves its hierarchy untouched in that case). */
+int orc_chunk_decompress_multi_res(const uint8_t* stream, size_t len, const size_t dims[3],
+                                   double* out, double** hier)
+{
+  return chunk_decompress_impl(stream, len, dims, out, hier);
+}
+
+static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t dims[3],
+                                 double* out, double** hier)
+{
   const size_t n = dims[0] * dims[1] * dims[2];
+  size_t res[16][3];
+  const size_t nres = hier ? orc_coarsened_resolutions(dims, res, 16) : 0;
   if (len < 17)
     return 1; /* WrongLength */
   if (stream[0] & 0x01) {
     if (len != 17)
       return 1;
     orc_inverse_condition(out, n, stream);
+    for (size_t h = 0; h < nres; h++)
+      orc_inverse_condition(hier[h], res[h][0] * res[h][1] * res[h][2], stream);
     return 0;
   }
   double q;
@@ -1529,7 +1593,13 @@ int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3]
   uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
   orc_speck3d_decode(sp, speck_len, dims, coef, sign);
   orc_inv_quantize(coef, sign, n, q, out);
-  orc_idwt3d(out, dims);
+  if (nres) {
+    orc_idwt3d_multi_res(out, dims, hier);
+    for (size_t h = 0; h < nres; h++)
+      orc_inverse_condition(hier[h], res[h][0] * res[h][1] * res[h][2], stream);
+  }
+  else
+    orc_idwt3d(out, dims);
   /* an outlier stream follows only when all of it is there (SPECK_FLT.cpp:88-103); its tolerance
    * is q / 1.5 (:578) */
   int rtn = 0;
@@ -1649,8 +1719,31 @@ int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t 
 }
 
 /* src/SPERR_C_API.cpp:218-258, src/SPERR3D_OMP_D.cpp:23-184, SPERR3D_Stream_Tools.cpp:46-105 */
+static int decomp_3d_impl(const void* src, size_t src_len, int output_float, size_t nthreads,
+                          size_t* dimx, size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
+                          size_t (*ldims)[3], double** levels);
+
 int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
                   size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
+{
+  return decomp_3d_impl(src, src_len, output_float, nthreads, dimx, dimy, dimz, dst, NULL, NULL,
+                        NULL);
+}
+
+/* SPERR3D_OMP_D::decompress(p, multi_res = true), src/SPERR3D_OMP_D.cpp:50-150: besides the
+ * volume (doubles), the volume at every coarsened resolution (src/sperr_helper.cpp:70-123),
+ * coarsest first: *nlev levels (0 when the chunks are not dyadic or do not tile the volume),
+ * ldims[h] their dims, levels[h] malloc'd doubles. */
+int orc_decomp_3d_multi_res(const void* src, size_t src_len, size_t nthreads, size_t* dimx,
+                            size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
+                            size_t (*ldims)[3], double** levels)
+{
+  return decomp_3d_impl(src, src_len, 0, nthreads, dimx, dimy, dimz, dst, nlev, ldims, levels);
+}
+
+static int decomp_3d_impl(const void* src, size_t src_len, int output_float, size_t nthreads,
+                          size_t* dimx, size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
+                          size_t (*ldims)[3], double** levels)
 {
   if (*dst != NULL)
     return 1;
@@ -1689,6 +1782,22 @@ int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthr
   const size_t n = vol[0] * vol[1] * vol[2];
   double* outd = (double*)malloc(n * sizeof(double));
   int* rtns = (int*)calloc(nchunks, sizeof(int));
+  /* multi-resolution: chunk resolutions scaled by the chunk grid (sperr_helper.cpp:99-123) */
+  size_t cres[16][3], nres = 0, grid[3] = {1, 1, 1};
+  if (nlev) {
+    *nlev = 0;
+    if (vol[0] % cdim[0] == 0 && vol[1] % cdim[1] == 0 && vol[2] % cdim[2] == 0) {
+      nres = orc_coarsened_resolutions(cdim, cres, 16);
+      for (int a = 0; a < 3; a++)
+        grid[a] = vol[a] / cdim[a];
+      for (size_t h = 0; h < nres; h++) {
+        for (int a = 0; a < 3; a++)
+          ldims[h][a] = cres[h][a] * grid[a];
+        levels[h] = (double*)malloc(ldims[h][0] * ldims[h][1] * ldims[h][2] * sizeof(double));
+      }
+      *nlev = nres;
+    }
+  }
   int nt = (int)nthreads;
   (void)nt;
 #ifdef _OPENMP
@@ -1699,7 +1808,27 @@ int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthr
     const size_t cd[3] = {c[1], c[3], c[5]};
     const size_t cn = cd[0] * cd[1] * cd[2];
     double* buf = (double*)malloc(cn * sizeof(double));
-    rtns[ci] = orc_chunk_decompress(p + offs[ci], offs[ci + 1] - offs[ci], cd, buf);
+    if (nres) {
+      double* hb[16];
+      for (size_t h = 0; h < nres; h++)
+        hb[h] = (double*)malloc(cres[h][0] * cres[h][1] * cres[h][2] * sizeof(double));
+      rtns[ci] = orc_chunk_decompress_multi_res(p + offs[ci], offs[ci + 1] - offs[ci], cd, buf, hb);
+      const size_t gi[3] = {c[0] / cdim[0], c[2] / cdim[1], c[4] / cdim[2]};
+      for (size_t h = 0; h < nres; h++) { /* SPERR3D_OMP_D.cpp:121-130 */
+        const size_t* r = cres[h];
+        size_t kk = 0;
+        for (size_t z = 0; z < r[2]; z++)
+          for (size_t y = 0; y < r[1]; y++) {
+            memcpy(levels[h] + ((gi[2] * r[2] + z) * ldims[h][1] + gi[1] * r[1] + y) * ldims[h][0] +
+                       gi[0] * r[0],
+                   hb[h] + kk, r[0] * sizeof(double));
+            kk += r[0];
+          }
+        free(hb[h]);
+      }
+    }
+    else
+      rtns[ci] = orc_chunk_decompress(p + offs[ci], offs[ci + 1] - offs[ci], cd, buf);
     size_t k = 0; /* scatter (SPERR3D_OMP_D.cpp:167-184) */
     for (size_t z = c[4]; z < c[4] + c[5]; z++)
       for (size_t y = c[2]; y < c[2] + c[3]; y++) {
@@ -1717,6 +1846,10 @@ int orc_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthr
   free(offs);
   if (rtn) {
     free(outd);
+    for (size_t h = 0; h < nres; h++)
+      free(levels[h]);
+    if (nlev)
+      *nlev = 0;
     return rtn;
   }
   *dimx = vol[0];

@@ -19,7 +19,8 @@ EXPORTS = [
     "sperrhip_max_compressed_size", "sperrhip_compress_dev", "sperrhip_decompress_dev",
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
-    "sperrhip_profile_get", "sperrhip_profile_get2", "sperrhip_profile_only", "sperrhip_version", "sperrhip_debug_lis_stamps",
+    "sperrhip_profile_get", "sperrhip_profile_get2", "sperrhip_profile_only",
+    "sperrhip_multires_levels", "sperrhip_decompress_multires_dev", "sperrhip_decomp_3d_multires", "sperrhip_version", "sperrhip_debug_lis_stamps",
 ]
 
 
@@ -232,6 +233,36 @@ class SperrHip:
         out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
         self._libc.free(dst)
         return out.reshape(dz.value, dy.value, dx.value)
+
+    # ---- multi-resolution decoding ----------------------------------------------------------
+    def multires_levels(self, shape_zyx, chunks_xyz):
+        """[(z, y, x) of every coarsened level], coarsest first (empty: no hierarchy exists)."""
+        dz, dy, dx = shape_zyx
+        nlev = _sz(0)
+        dims = (_sz * 48)()
+        self.lib.sperrhip_multires_levels.argtypes = [_sz] * 6 + [C.POINTER(_sz), C.POINTER(_sz)]
+        if self.lib.sperrhip_multires_levels(dx, dy, dz, *chunks_xyz, C.byref(nlev), dims) != 0:
+            raise SperrHipError("sperrhip_multires_levels failed")
+        return [(dims[3 * h + 2], dims[3 * h + 1], dims[3 * h]) for h in range(nlev.value)]
+
+    def decompress_multires(self, stream, output_float=True):
+        """-> (volume, [float64 level volumes, coarsest first]); SPERR3D_OMP_D::decompress(p, true)."""
+        torch = self.torch
+        shape, _, chunks = self.parse_header(stream)   # (z, y, x), is_float, (x, y, z)
+        lv = self.multires_levels(shape, chunks)
+        out = torch.empty(shape, dtype=torch.float32 if output_float else torch.float64,
+                          device=stream.device)
+        levels = [torch.empty(s, dtype=torch.float64, device=stream.device) for s in lv]
+        ptrs = (C.c_void_p * max(1, len(lv)))(*[t.data_ptr() for t in levels])
+        self.lib.sperrhip_decompress_multires_dev.argtypes = [C.c_void_p, _sz, C.c_int, C.c_void_p,
+                                                              _sz, _sz, C.c_void_p, C.c_void_p]
+        rtn = self.lib.sperrhip_decompress_multires_dev(stream.data_ptr(), stream.numel(),
+                                                        int(output_float), out.data_ptr(),
+                                                        out.numel() * out.element_size(), len(lv),
+                                                        ptrs, self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decompress_multires_dev returned {rtn}")
+        return out, levels
 
     # ---- profiling ------------------------------------------------------------------------
     def profile(self, on=True, only=None):

@@ -1416,9 +1416,59 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   return true;
 }
 
+// multi-resolution decoding (SPERR3D_OMP_D::decompress(p, true), src/SPERR3D_OMP_D.cpp:50-150):
+// the volume at every coarsened resolution of the chunks (src/sperr_helper.cpp:70-123), coarsest
+// first.  Only for dyadic chunks that tile the volume.
+struct MultiRes {
+  size_t nlev = 0;
+  std::array<uint32_t, 3> cres[16];   // chunk resolution of level h
+  std::array<uint32_t, 3> grid;       // chunks per axis
+  double* d_level[16];
+};
+
+int multires_levels(const Dims& vol, const Dims& cdim, MultiRes& m)
+{
+  m.nlev = 0;
+  size_t levels = 0;
+  for (int a = 0; a < 3; a++)
+    if (cdim[a] == 0 || vol[a] % cdim[a] != 0)
+      return 0;
+  if (!spk::can_use_dyadic({cdim[0], cdim[1], cdim[2]}, levels) || levels > 16)
+    return 0;
+  for (int a = 0; a < 3; a++)
+    m.grid[a] = (uint32_t)(vol[a] / cdim[a]);
+  for (size_t lev = levels; lev > 0; lev--)
+    for (int a = 0; a < 3; a++)
+      m.cres[levels - lev][a] = (uint32_t)spk::approx_detail_len(cdim[a], lev)[0];
+  m.nlev = levels;
+  return 0;
+}
+
+// the approximation corner of every chunk (src/CDF97.cpp:150-168,581-593), mean added back
+// (src/SPECK_FLT.cpp:592-603), placed at the chunk's position in the level's volume
+__global__ void __launch_bounds__(kThreads)
+k_sub_volume(const double* vals, size_t valsStride, const CoderState* cst, const ChunkGeom* geom,
+             uint32_t cx, uint32_t cy, uint32_t cdx, uint32_t cdy, uint32_t cdz, uint32_t sx,
+             uint32_t sy, uint32_t sz, uint32_t gx, uint32_t gy, double* level)
+{
+  const uint32_t c = blockIdx.y;
+  const CoderState& cs = cst[c];
+  const ChunkGeom g = geom[c];
+  const uint32_t gi[3] = {g.org[0] / cdx, g.org[1] / cdy, g.org[2] / cdz};
+  const size_t ldx = (size_t)sx * gx, ldy = (size_t)sy * gy;
+  const double* in = vals + c * valsStride;
+  const uint32_t n = sx * sy * sz;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t x = i % sx, r = i / sx;
+    const uint32_t y = r % sy, z = r / sy;
+    const double v = cs.is_const ? cs.mean : in[((size_t)z * cy + y) * cx + x] + cs.mean;
+    level[(((size_t)gi[2] * sz + z) * ldy + (size_t)gi[1] * sy + y) * ldx + (size_t)gi[0] * sx + x] = v;
+  }
+}
+
 template <typename T>
 int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_cap_vals,
-                    const ContainerInfo& ci, hipStream_t st)
+                    const ContainerInfo& ci, hipStream_t st, const MultiRes* mr = nullptr)
 {
   Engine& E = g_engine;
   const auto chunks = chunk_volume(ci.vol, ci.chunk);
@@ -1655,6 +1705,14 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         const bool fxy = fuse_xy(*P) && !batchOutliers;
         for (size_t k = P->fwd.size(); k-- > (fxy ? 2u : 0u);) {
           const LiftPass& ps = P->fwd[k];
+          if (mr && mr->nlev && k % 3 == 2) {   // a level of the inverse transform starts
+            const size_t h = mr->nlev - (k / 3 + 1);
+            const auto& r = mr->cres[h];
+            const uint32_t blocks = capped_blocks((r[0] * r[1] * r[2] + kThreads - 1) / kThreads, nb);
+            LAUNCH_K(k_sub_volume, dim3(blocks, nb), dim3(kThreads), 0, ss, bb.vals, bb.valsStride,
+                     d.cst, bb.geom, cd[0], cd[1], cd[0], cd[1], cd[2], r[0], r[1], r[2],
+                     mr->grid[0], mr->grid[1], mr->d_level[h]);
+          }
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
                           (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
                           d_dst, vd, bb.geom))
@@ -1978,6 +2036,56 @@ int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float,
   return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
                                  static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
                                  st);
+}
+
+int sperrhip_multires_levels(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x, size_t chunk_y,
+                             size_t chunk_z, size_t* nlev, size_t* level_dims)
+{
+  const Dims vol{dimx, dimy, dimz};
+  Dims cd{chunk_x, chunk_y, chunk_z};
+  if (!nlev || dimx == 0 || dimy == 0 || dimz == 0)
+    return -1;
+  for (int a = 0; a < 3; a++)
+    cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
+  MultiRes m;
+  multires_levels(vol, cd, m);
+  *nlev = m.nlev;
+  if (level_dims)
+    for (size_t h = 0; h < m.nlev; h++)
+      for (int a = 0; a < 3; a++)
+        level_dims[3 * h + a] = (size_t)m.cres[h][a] * m.grid[a];
+  return 0;
+}
+
+int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int output_float,
+                                     void* d_dst, size_t dst_cap_bytes, size_t nlev,
+                                     double* const* d_levels, void* hip_stream)
+{
+  if (!d_src || !d_dst || (nlev && !d_levels))
+    return -1;
+  std::lock_guard<std::mutex> lock(g_engine.mu);
+  if (g_engine.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ContainerInfo ci;
+  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
+    return -1;
+  MultiRes m;
+  multires_levels(ci.vol, ci.chunk, m);
+  if (m.nlev != nlev)
+    return -1;   // (sperrhip_multires_levels tells how many there are)
+  for (size_t h = 0; h < nlev; h++) {
+    if (!d_levels[h])
+      return -1;
+    m.d_level[h] = d_levels[h];
+  }
+  if (output_float)
+    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
+                                  &m);
+  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
+                                 st, &m);
 }
 
 // ---- stage access for parity tests -----------------------------------------------------------
@@ -2310,6 +2418,79 @@ int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nt
   }
   (void)hipFree(d_in);
   (void)hipFree(d_out);
+  return rtn;
+}
+
+// host buffers in, malloc'd host buffers out: the volume and the levels of the hierarchy
+// (SPERR3D_OMP_D::decompress(p, true) + release_decoded_data / release_hierarchy)
+int sperrhip_decomp_3d_multires(const void* src, size_t src_len, int output_float, size_t* dimx,
+                                size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
+                                size_t* level_dims, double** levels)
+{
+  if (!dst || *dst != nullptr)
+    return 1;
+  if (src_len < 18 || !nlev || !level_dims || !levels)
+    return -1;
+  ContainerInfo ci;
+  size_t need = 0;
+  if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
+    return -1;
+  if (sperrhip_multires_levels(ci.vol[0], ci.vol[1], ci.vol[2], ci.chunk[0], ci.chunk[1], ci.chunk[2],
+                               nlev, level_dims))
+    return -1;
+  const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
+  const size_t esz = output_float ? 4 : 8;
+  std::vector<void*> dev;
+  auto release = [&]() {
+    for (void* p : dev)
+      (void)hipFree(p);
+  };
+  auto dalloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess)
+      return nullptr;
+    dev.push_back(p);
+    return p;
+  };
+  void* d_in = dalloc(src_len);
+  void* d_out = dalloc(n * esz);
+  std::vector<double*> d_lv(*nlev, nullptr);
+  std::vector<size_t> lvn(*nlev, 0);
+  bool ok = d_in && d_out;
+  for (size_t h = 0; ok && h < *nlev; h++) {
+    lvn[h] = level_dims[3 * h] * level_dims[3 * h + 1] * level_dims[3 * h + 2];
+    d_lv[h] = static_cast<double*>(dalloc(lvn[h] * 8));
+    ok = d_lv[h] != nullptr;
+  }
+  if (!ok) {
+    fprintf(stderr, "[sperr_hip] device allocation failed\n");
+    release();
+    return -1;
+  }
+  int rtn = -1;
+  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+    rtn = sperrhip_decompress_multires_dev(d_in, src_len, output_float, d_out, n * esz, *nlev,
+                                           d_lv.data(), nullptr);
+  if (rtn == 0) {
+    void* buf = malloc(n * esz);
+    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+      *dst = buf;
+    else {
+      free(buf);
+      rtn = -1;
+    }
+    for (size_t h = 0; rtn == 0 && h < *nlev; h++) {
+      levels[h] = static_cast<double*>(malloc(lvn[h] * 8));
+      if (!levels[h] || hipMemcpy(levels[h], d_lv[h], lvn[h] * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rtn = -1;
+    }
+    if (rtn == 0) {
+      *dimx = ci.vol[0];
+      *dimy = ci.vol[1];
+      *dimz = ci.vol[2];
+    }
+  }
+  release();
   return rtn;
 }
 

@@ -393,6 +393,39 @@ def test_pwe_full_size_properties(eng):
     assert torch.equal(s_sub[18:], s1[hdr + lens[0]: hdr + lens[0] + lens[1]])
 
 
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), (32, 32, 32)), ((48, 64, 32), (32, 32, 24)),
+                                          ((64, 64, 64), (64, 64, 64)), ((40, 40, 40), (40, 40, 40)),
+                                          ((128, 128, 128), (128, 128, 128))])
+def test_multi_resolution_decode(eng, oracle, shape, chunks):
+    """SPERR3D_OMP_D::decompress(p, multi_res = true) (src/SPERR3D_OMP_D.cpp:50-150,
+    src/CDF97.cpp:150-168): the volume and every coarsened level, bit for bit."""
+    v = turbulence(shape)
+    v[: shape[0] // 2, : chunks[1], : chunks[0]] = 0.25   # a constant chunk when the grid is 2x2x2
+    stream = oracle.comp_3d(v, chunks, 1, 3.0)
+    want_vol, want_levels = oracle.decomp_3d_multi_res(stream)
+    assert eng.multires_levels(shape, chunks) == [lv.shape for lv in want_levels]
+    dev = cuda(np.frombuffer(stream, dtype=np.uint8))
+    vol, levels = eng.decompress_multires(dev, output_float=False)
+    assert np.array_equal(bits(vol.cpu().numpy()), bits(want_vol))
+    assert len(levels) == len(want_levels) > 0
+    for got, want in zip(levels, want_levels):
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want))
+
+
+def test_multi_resolution_absent_for_other_shapes(eng, oracle):
+    """Chunks that are not dyadic (wavelet-packet transform), or do not tile the volume, have no
+    hierarchy (src/sperr_helper.cpp:70-123); the volume still decodes."""
+    for shape, chunks in [((9, 64, 64), (64, 64, 9)), ((50, 64, 72), (32, 32, 32))]:
+        v = turbulence(shape)
+        stream = oracle.comp_3d(v, chunks, 1, 2.0)
+        assert oracle.decomp_3d_multi_res(stream)[1] == []
+        assert eng.multires_levels(shape, chunks) == []
+        dev = cuda(np.frombuffer(stream, dtype=np.uint8))
+        vol, levels = eng.decompress_multires(dev, output_float=True)
+        assert levels == []
+        assert np.array_equal(bits(vol.cpu().numpy()), bits(oracle.decomp_3d(stream, True)))
+
+
 def test_many_chunks_decode_in_sub_batches(eng, oracle):
     """48 chunks of one shape: the decoder splits the batch into sub-batches on separate streams
     (engine.hip, decompress_impl); same values as the oracle."""

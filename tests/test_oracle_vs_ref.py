@@ -110,6 +110,21 @@ def test_pwe_mode_bit_exact(oracle, ref, chunks, tol):
     assert np.array_equal(bits(oracle.decomp_3d(want, False)), bits(ref.decomp_3d(want, False)))
 
 
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), (32, 32, 32)), ((48, 64, 32), (32, 32, 24)),
+                                          ((40, 40, 40), (40, 40, 40)), ((41, 64, 64), (64, 64, 41))])
+def test_multi_resolution_decode_bit_exact(oracle, ref, shape, chunks):
+    """SPERR3D_OMP_D::decompress(p, true): volume and hierarchy (src/SPERR3D_OMP_D.cpp:50-150,
+    src/CDF97.cpp:150-168, src/SPECK_FLT.cpp:592-603) against the reference's own classes."""
+    v = turbulence(shape)
+    stream = ref.comp_3d(v, chunks, 1, 3.0)
+    vol_o, lv_o = oracle.decomp_3d_multi_res(stream)
+    vol_r, lv_r = ref.decomp_3d_multi_res(stream)
+    assert np.array_equal(bits(vol_o), bits(vol_r))
+    assert [a.shape for a in lv_o] == [a.shape for a in lv_r]
+    for a, b in zip(lv_o, lv_r):
+        assert np.array_equal(bits(a), bits(b))
+
+
 def test_speck1d_bit_exact(oracle, ref):
     """SPECK1D_INT_ENC / _DEC (src/SPECK1D_INT*.cpp) on sparse arrays: same stream, and it
     round-trips exactly through both decoders."""
