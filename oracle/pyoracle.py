@@ -65,6 +65,8 @@ class _CApiMixin:
     _comp = None
     _decomp = None
     _trunc = None
+    _comp2 = None
+    _decomp2 = None
     _libc = C.CDLL(None)
 
     def _wire(self):
@@ -78,6 +80,12 @@ class _CApiMixin:
         if self._trunc is not None:
             self._trunc.restype = C.c_int
             self._trunc.argtypes = [_vp, _sz, C.c_uint, C.POINTER(_vp), C.POINTER(_sz)]
+        if self._comp2 is not None:
+            self._comp2.restype = C.c_int
+            self._comp2.argtypes = [_vp, C.c_int, _sz, _sz, C.c_int, C.c_double, C.c_int,
+                                    C.POINTER(_vp), C.POINTER(_sz)]
+            self._decomp2.restype = C.c_int
+            self._decomp2.argtypes = [_vp, _sz, C.c_int, _sz, _sz, C.POINTER(_vp)]
 
     def trunc_3d(self, stream, pct):
         """sperr_trunc_3d (include/SPERR_C_API.h:151-156). Returns bytes."""
@@ -87,6 +95,32 @@ class _CApiMixin:
         if rtn != 0:
             raise RuntimeError(f"trunc_3d returned {rtn}")
         out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def comp_2d(self, img, mode, quality, header=False):
+        """img: numpy float32/float64 (y, x). Returns bytes (sperr_comp_2d)."""
+        img = np.ascontiguousarray(img)
+        assert img.dtype in (np.float32, np.float64) and img.ndim == 2
+        dy, dx = img.shape
+        dst, n = _vp(None), _sz(0)
+        rtn = self._comp2(img.ctypes.data, int(img.dtype == np.float32), dx, dy, mode, quality,
+                          int(header), C.byref(dst), C.byref(n))
+        if rtn != 0:
+            raise RuntimeError(f"comp_2d returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def decomp_2d(self, stream, shape_yx, as_float):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dy, dx = shape_yx
+        dst = _vp(None)
+        rtn = self._decomp2(buf.ctypes.data, buf.size, int(as_float), dx, dy, C.byref(dst))
+        if rtn != 0:
+            raise RuntimeError(f"decomp_2d returned {rtn}")
+        dt = np.float32 if as_float else np.float64
+        out = np.frombuffer(C.string_at(dst.value, dx * dy * np.dtype(dt).itemsize), dtype=dt).reshape(dy, dx).copy()
         self._libc.free(dst)
         return out
 
@@ -128,6 +162,7 @@ class Oracle(_CApiMixin):
         L = self.lib
         self._comp, self._decomp = L.orc_comp_3d, L.orc_decomp_3d
         self._trunc = L.orc_trunc_3d
+        self._comp2, self._decomp2 = L.orc_comp_2d, L.orc_decomp_2d
         self._wire()
         L.orc_dwt3d.argtypes = [_vp, _vp]
         L.orc_idwt3d.argtypes = [_vp, _vp]
@@ -305,6 +340,7 @@ class Ref(_CApiMixin):
         self.probe = C.CDLL(os.path.join(HERE, "_ref", "libref_probe.so"))
         self._comp, self._decomp = self.lib.sperr_comp_3d, self.lib.sperr_decomp_3d
         self._trunc = self.lib.sperr_trunc_3d
+        self._comp2, self._decomp2 = self.lib.sperr_comp_2d, self.lib.sperr_decomp_2d
         self._wire()
         P = self.probe
         P.refp_dwt3d.argtypes = [_vp, _sz, _sz, _sz]

@@ -1304,6 +1304,392 @@ int orc_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* co
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* SPECK2D (slices)                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/SPECK2D_INT.h:12-31 */
+typedef struct {
+  uint32_t sx, sy, lx, ly;
+  uint16_t lev;
+} rect2;
+
+typedef struct {
+  rect2* v;
+  size_t n, cap;
+} rectlist;
+
+typedef struct {
+  size_t dx, dy, n;
+  int encoding;
+  uint64_t* coef;
+  uint64_t* sign;
+  int8_t* msb; /* encoder: msb of every coefficient, raster order (SPECK2D_INT_ENC.cpp:101-107) */
+  uint64_t *lip, *lsp;
+  size_t *fresh, nfresh, capfresh;
+  rectlist* lis;
+  size_t nlis;
+  rect2 I; /* the type-I set: everything outside the box [0,sx) x [0,sy); lev == 0: empty */
+  bitfifo bits;
+  uint64_t thr;
+  int plane;
+} speck2;
+
+static void rect_push(rectlist* l, rect2 r)
+{
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 16;
+    l->v = (rect2*)realloc(l->v, l->cap * sizeof(rect2));
+  }
+  l->v[l->n++] = r;
+}
+
+static void fresh2_push(speck2* s, size_t idx)
+{
+  if (s->nfresh == s->capfresh) {
+    s->capfresh = s->capfresh ? s->capfresh * 2 : 1024;
+    s->fresh = (size_t*)realloc(s->fresh, s->capfresh * sizeof(size_t));
+  }
+  s->fresh[s->nfresh++] = idx;
+}
+
+static int rect_any_significant(const speck2* s, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1)
+{
+  for (uint32_t y = y0; y < y1; y++) {
+    const int8_t* row = s->msb + (size_t)y * s->dx;
+    for (uint32_t x = x0; x < x1; x++)
+      if (row[x] >= s->plane)
+        return 1;
+  }
+  return 0;
+}
+
+static void speck2_test_set(speck2* s, size_t lev, size_t idx, int* counter, int coded);
+
+/* src/SPECK2D_INT_ENC.cpp:29-46, _DEC.cpp:24-39 */
+static void speck2_test_pixel(speck2* s, size_t idx, int* counter, int coded)
+{
+  int sig = 1;
+  if (coded) {
+    if (s->encoding) {
+      sig = s->msb[idx] >= s->plane;
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+  }
+  if (sig) {
+    (*counter)++;
+    if (s->encoding)
+      fifo_put(&s->bits, mask_get(s->sign, idx));
+    else if (fifo_get(&s->bits))
+      mask_set(s->sign, idx);
+    else
+      mask_clr(s->sign, idx);
+    fresh2_push(s, idx);
+    mask_clr(s->lip, idx);
+  }
+}
+
+/* src/SPECK2D_INT.cpp:58-82,104-147 : quadrants in the order bottom-right, bottom-left,
+ * top-right, top-left; the last non-empty one is not coded when none before it was significant */
+static void speck2_split_set(speck2* s, size_t lev, size_t idx)
+{
+  const rect2 p = s->lis[lev].v[idx];
+  const uint32_t dlx = p.lx / 2, dly = p.ly / 2, alx = p.lx - dlx, aly = p.ly - dly;
+  rect2 kid[4] = {{p.sx + alx, p.sy + aly, dlx, dly, (uint16_t)(p.lev + 1)},
+                  {p.sx, p.sy + aly, alx, dly, (uint16_t)(p.lev + 1)},
+                  {p.sx + alx, p.sy, dlx, aly, (uint16_t)(p.lev + 1)},
+                  {p.sx, p.sy, alx, aly, (uint16_t)(p.lev + 1)}};
+  int nkid = 0;
+  for (int k = 0; k < 4; k++)
+    if (kid[k].lx && kid[k].ly)
+      kid[nkid++] = kid[k];
+  int found = 0;
+  for (int k = 0; k < nkid; k++) {
+    const int coded = found != 0 || k + 1 != nkid;
+    if (kid[k].lx == 1 && kid[k].ly == 1) {
+      const size_t pix = (size_t)kid[k].sy * s->dx + kid[k].sx;
+      mask_set(s->lip, pix);
+      speck2_test_pixel(s, pix, &found, coded);
+    }
+    else {
+      rect_push(&s->lis[kid[k].lev], kid[k]);
+      speck2_test_set(s, kid[k].lev, s->lis[kid[k].lev].n - 1, &found, coded);
+    }
+  }
+}
+
+/* src/SPECK2D_INT_ENC.cpp:7-27, _DEC.cpp:6-22 */
+static void speck2_test_set(speck2* s, size_t lev, size_t idx, int* counter, int coded)
+{
+  int sig = 1;
+  if (coded) {
+    if (s->encoding) {
+      const rect2* r = &s->lis[lev].v[idx];
+      sig = rect_any_significant(s, r->sx, r->sx + r->lx, r->sy, r->sy + r->ly);
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+  }
+  if (sig) {
+    (*counter)++;
+    speck2_split_set(s, lev, idx);
+    s->lis[lev].v[idx].lx = 0; /* make_empty */
+  }
+}
+
+static void speck2_test_I(speck2* s, int coded);
+
+/* src/SPECK2D_INT.cpp:84-98,149-186 : the three subbands of the level join the lists (always
+ * coded), I shrinks; the new I is significant by inference when none of them was */
+static void speck2_code_I(speck2* s)
+{
+  size_t ax, dxl, ay, dyl;
+  orc_approx_detail_len(s->dx, s->I.lev, &ax, &dxl);
+  orc_approx_detail_len(s->dy, s->I.lev, &ay, &dyl);
+  const rect2 kid[3] = {{(uint32_t)ax, (uint32_t)ay, (uint32_t)dxl, (uint32_t)dyl, s->I.lev},
+                        {(uint32_t)ax, 0, (uint32_t)dxl, (uint32_t)ay, s->I.lev},
+                        {0, (uint32_t)ay, (uint32_t)ax, (uint32_t)dyl, s->I.lev}};
+  s->I.sx += (uint32_t)dxl;
+  s->I.sy += (uint32_t)dyl;
+  s->I.lev--;
+  int found = 0;
+  for (int k = 0; k < 3; k++)
+    if (kid[k].lx && kid[k].ly) {
+      rect_push(&s->lis[kid[k].lev], kid[k]);
+      speck2_test_set(s, kid[k].lev, s->lis[kid[k].lev].n - 1, &found, 1);
+    }
+  speck2_test_I(s, found != 0);
+}
+
+/* src/SPECK2D_INT_ENC.cpp:48-62,78-99, _DEC.cpp:41-51 */
+static void speck2_test_I(speck2* s, int coded)
+{
+  if (s->I.lev == 0)
+    return;
+  int sig = 1;
+  if (coded) {
+    if (s->encoding) {
+      sig = rect_any_significant(s, 0, (uint32_t)s->dx, s->I.sy, (uint32_t)s->dy) ||
+            rect_any_significant(s, s->I.sx, (uint32_t)s->dx, 0, s->I.sy);
+      fifo_put(&s->bits, sig);
+    }
+    else
+      sig = fifo_get(&s->bits);
+  }
+  if (sig)
+    speck2_code_I(s);
+}
+
+/* src/SPECK2D_INT.cpp:10-56 */
+static void speck2_sorting_pass(speck2* s)
+{
+  for (size_t i = 0; i < s->n; i++) {
+    if ((i & 63) == 0 && s->lip[i >> 6] == 0) {
+      i += 63;
+      continue;
+    }
+    if (!mask_get(s->lip, i))
+      continue;
+    int dummy = 0;
+    speck2_test_pixel(s, i, &dummy, 1);
+  }
+  for (size_t lev = s->nlis; lev-- > 0;)
+    for (size_t i = 0; i < s->lis[lev].n; i++) {
+      int dummy = 0;
+      speck2_test_set(s, lev, i, &dummy, 1);
+    }
+  speck2_test_I(s, 1);
+}
+
+/* src/SPECK2D_INT.cpp:188-218 */
+static void speck2_alloc(speck2* s, size_t dx, size_t dy, int encoding)
+{
+  memset(s, 0, sizeof(*s));
+  s->dx = dx;
+  s->dy = dy;
+  s->n = dx * dy;
+  s->encoding = encoding;
+  const size_t words = (s->n + 63) / 64;
+  s->lip = (uint64_t*)calloc(words, 8);
+  s->lsp = (uint64_t*)calloc(words, 8);
+  s->nlis = orc_num_of_partitions(dx > dy ? dx : dy) + 1;
+  s->lis = (rectlist*)calloc(s->nlis + 1, sizeof(rectlist));
+  const size_t nx = orc_num_of_xforms(dx < dy ? dx : dy);
+  size_t ax, ay, d;
+  orc_approx_detail_len(dx, nx, &ax, &d);
+  orc_approx_detail_len(dy, nx, &ay, &d);
+  const rect2 root = {0, 0, (uint32_t)ax, (uint32_t)ay, (uint16_t)nx};
+  rect_push(&s->lis[nx], root);
+  s->I.sx = (uint32_t)ax;
+  s->I.sy = (uint32_t)ay;
+  s->I.lx = (uint32_t)dx;
+  s->I.ly = (uint32_t)dy;
+  s->I.lev = (uint16_t)nx;
+}
+
+static void speck2_free(speck2* s)
+{
+  for (size_t i = 0; i <= s->nlis; i++)
+    free(s->lis[i].v);
+  free(s->lis);
+  free(s->lip);
+  free(s->lsp);
+  free(s->fresh);
+  free(s->msb);
+  free(s->bits.w);
+}
+
+static void speck2_clean_lists(speck2* s)
+{
+  for (size_t lev = 0; lev < s->nlis; lev++) {
+    rectlist* l = &s->lis[lev];
+    size_t k = 0;
+    for (size_t i = 0; i < l->n; i++)
+      if (l->v[i].lx && l->v[i].ly)
+        l->v[k++] = l->v[i];
+    l->n = k;
+  }
+}
+
+/* src/SPECK_INT.cpp:110-163,284-357 with the 2D passes */
+int orc_speck2d_encode(const uint64_t* coeffs, const uint64_t* signs, size_t dx, size_t dy,
+                       size_t budget_bits, uint8_t** stream, size_t* stream_len)
+{
+  speck2 s;
+  speck2_alloc(&s, dx, dy, 1);
+  const size_t budget = round_budget(budget_bits);
+  s.coef = (uint64_t*)malloc(s.n * sizeof(uint64_t));
+  memcpy(s.coef, coeffs, s.n * sizeof(uint64_t));
+  s.sign = (uint64_t*)signs;
+  s.msb = (int8_t*)malloc(s.n);
+  uint64_t maxc = 0;
+  for (size_t i = 0; i < s.n; i++) {
+    if (s.coef[i] > maxc)
+      maxc = s.coef[i];
+    s.msb[i] = s.coef[i] ? (int8_t)(63 - __builtin_clzll(s.coef[i])) : -1;
+  }
+  uint8_t nplanes = 0;
+  uint64_t total_bits = 0;
+  if (maxc) {
+    nplanes = 1;
+    s.thr = 1;
+    while (maxc - s.thr >= s.thr) {
+      s.thr *= 2;
+      nplanes++;
+    }
+    for (uint8_t p = 0; p < nplanes; p++) {
+      s.plane = 63 - __builtin_clzll(s.thr);
+      speck2_sorting_pass(&s);
+      if (s.bits.pos >= budget)
+        break;
+      for (size_t i = 0; i < s.n; i++) {
+        if ((i & 63) == 0 && s.lsp[i >> 6] == 0) {
+          i += 63;
+          continue;
+        }
+        if (!mask_get(s.lsp, i))
+          continue;
+        const int b = s.coef[i] >= s.thr;
+        if (b)
+          s.coef[i] -= s.thr;
+        fifo_put(&s.bits, b);
+      }
+      for (size_t k = 0; k < s.nfresh; k++) {
+        s.coef[s.fresh[k]] -= s.thr;
+        mask_set(s.lsp, s.fresh[k]);
+      }
+      s.nfresh = 0;
+      if (s.bits.pos >= budget)
+        break;
+      s.thr /= 2;
+      speck2_clean_lists(&s);
+    }
+    total_bits = s.bits.pos;
+  }
+  const size_t keep = total_bits < budget ? (size_t)total_bits : budget;
+  const size_t nbytes = (keep + 7) / 8;
+  uint8_t* out = (uint8_t*)calloc(9 + nbytes + 8, 1);
+  out[0] = nplanes;
+  memcpy(out + 1, &total_bits, 8);
+  if (nbytes)
+    memcpy(out + 9, s.bits.w, nbytes);
+  if (keep % 8)
+    out[9 + nbytes - 1] &= (uint8_t)((1u << (keep % 8)) - 1);
+  *stream = out;
+  *stream_len = 9 + nbytes;
+  free(s.coef);
+  speck2_free(&s);
+  return 0;
+}
+
+/* src/SPECK_INT.cpp:79-108,165-228,359-469 with the 2D passes */
+int orc_speck2d_decode(const uint8_t* stream, size_t len, size_t dx, size_t dy, uint64_t* coeffs,
+                       uint64_t* signs)
+{
+  if (len < 9)
+    return 1;
+  speck2 s;
+  speck2_alloc(&s, dx, dy, 0);
+  const uint8_t nplanes = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  uint64_t avail = (uint64_t)(len - 9) * 8;
+  if (avail > total_bits)
+    avail = total_bits;
+  s.bits.cap_words = (size_t)(total_bits / 64 + 2);
+  s.bits.w = (uint64_t*)calloc(s.bits.cap_words, 8);
+  memcpy(s.bits.w, stream + 9, (size_t)((avail + 7) / 8));
+  s.coef = coeffs;
+  s.sign = signs;
+  memset(coeffs, 0, s.n * sizeof(uint64_t));
+  memset(signs, 0xff, ((s.n + 63) / 64) * 8);
+  if (nplanes) {
+    s.thr = (uint64_t)1 << (nplanes - 1);
+    for (uint8_t p = 0; p < nplanes; p++) {
+      speck2_sorting_pass(&s);
+      if (s.bits.pos >= avail)
+        break;
+      const uint64_t half = s.thr / 2;
+      int exhausted = 0;
+      for (size_t i = 0; i < s.n && !exhausted; i++) {
+        if ((i & 63) == 0 && s.lsp[i >> 6] == 0) {
+          i += 63;
+          continue;
+        }
+        if (!mask_get(s.lsp, i))
+          continue;
+        const int b = fifo_get(&s.bits);
+        if (s.thr >= 2)
+          s.coef[i] = b ? s.coef[i] + half : s.coef[i] - half;
+        else if (b)
+          s.coef[i]++;
+        if (s.bits.pos == avail)
+          exhausted = 1;
+      }
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1;
+      for (size_t k = 0; k < s.nfresh; k++) {
+        s.coef[s.fresh[k]] = init;
+        mask_set(s.lsp, s.fresh[k]);
+      }
+      s.nfresh = 0;
+      if (s.bits.pos >= avail)
+        break;
+      s.thr /= 2;
+      speck2_clean_lists(&s);
+    }
+    if (s.nfresh) {
+      const uint64_t init = s.thr + s.thr - s.thr / 2 - 1;
+      for (size_t k = 0; k < s.nfresh; k++)
+        s.coef[s.fresh[k]] = init;
+    }
+  }
+  speck2_free(&s);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* outlier coder                                                                              */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -1358,9 +1744,25 @@ int orc_outlier_decode_apply(const uint8_t* stream, size_t len, size_t n, double
 /* ------------------------------------------------------------------------------------------ */
 /* per-chunk float pipeline                                                                   */
 /* ------------------------------------------------------------------------------------------ */
+/* SPECK2D_FLT and SPECK3D_FLT differ only in the transform and the integer coder
+ * (src/SPECK2D_FLT.cpp:48-58, src/SPECK3D_FLT.cpp); a slice is a chunk with dims[2] == 1, whose
+ * 3D transform plan already is dwt2d (src/CDF97.cpp:102-112,327-385) */
+static int int_encode(int two_d, const uint64_t* coef, const uint64_t* sign, const size_t dims[3],
+                      size_t budget, uint8_t** stream, size_t* len)
+{
+  return two_d ? orc_speck2d_encode(coef, sign, dims[0], dims[1], budget, stream, len)
+               : orc_speck3d_encode(coef, sign, dims, budget, stream, len);
+}
+static int int_decode(int two_d, const uint8_t* stream, size_t len, const size_t dims[3],
+                      uint64_t* coef, uint64_t* sign)
+{
+  return two_d ? orc_speck2d_decode(stream, len, dims[0], dims[1], coef, sign)
+               : orc_speck3d_decode(stream, len, dims, coef, sign);
+}
+
 
 /* src/SPECK_FLT.cpp:401-541, CompMode::Rate only */
-int orc_chunk_compress_rate(double* vals, const size_t dims[3], double bpp, uint8_t** stream,
+static int chunk_compress_rate_impl(int two_d, double* vals, const size_t dims[3], double bpp, uint8_t** stream,
                             size_t* stream_len)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
@@ -1392,7 +1794,7 @@ int orc_chunk_compress_rate(double* vals, const size_t dims[3], double bpp, uint
     if (rtn)
       break;
     free(speck_stream);
-    orc_speck3d_encode(coef, sign, dims, budget, &speck_stream, &speck_len);
+    int_encode(two_d, coef, sign, dims, budget, &speck_stream, &speck_len);
     if (speck_len * 8 >= budget) /* SPECK_FLT.cpp:530-538 : enough bits, no retry */
       break;
   }
@@ -1438,7 +1840,7 @@ double orc_estimate_q_psnr(const double* coeffs, size_t n, double range, double 
 }
 
 /* src/SPECK_FLT.cpp:401-541, CompMode::PSNR: q from the target, every bit plane coded */
-int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uint8_t** stream,
+static int chunk_compress_psnr_impl(int two_d, double* vals, const size_t dims[3], double psnr, uint8_t** stream,
                             size_t* stream_len)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
@@ -1466,7 +1868,7 @@ int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uin
   if (!rtn) {
     uint8_t* speck_stream = NULL;
     size_t speck_len = 0;
-    orc_speck3d_encode(coef, sign, dims, 0, &speck_stream, &speck_len);
+    int_encode(two_d, coef, sign, dims, 0, &speck_stream, &speck_len);
     *stream = (uint8_t*)malloc(17 + speck_len);
     memcpy(*stream, condi, 17);
     memcpy(*stream + 17, speck_stream, speck_len);
@@ -1481,7 +1883,7 @@ int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uin
 /* src/SPECK_FLT.cpp:401-541, CompMode::PWE: q = 1.5 tol (:280-281), every bit plane coded, then
  * the values the decoder would see are rebuilt and every error above the tolerance goes to the
  * outlier coder (:461-486) */
-int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8_t** stream,
+static int chunk_compress_pwe_impl(int two_d, double* vals, const size_t dims[3], double tol, uint8_t** stream,
                            size_t* stream_len)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
@@ -1529,7 +1931,7 @@ int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8
   if (!rtn) {
     uint8_t* speck_stream = NULL;
     size_t speck_len = 0;
-    orc_speck3d_encode(coef, sign, dims, 0, &speck_stream, &speck_len);
+    int_encode(two_d, coef, sign, dims, 0, &speck_stream, &speck_len);
     *stream = (uint8_t*)malloc(17 + speck_len + out_len);
     memcpy(*stream, condi, 17);
     memcpy(*stream + 17, speck_stream, speck_len);
@@ -1545,13 +1947,29 @@ int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8
   return rtn;
 }
 
-static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t dims[3],
-                                 double* out, double** hier);
+int orc_chunk_compress_rate(double* vals, const size_t dims[3], double bpp, uint8_t** stream,
+                            size_t* stream_len)
+{
+  return chunk_compress_rate_impl(0, vals, dims, bpp, stream, stream_len);
+}
+int orc_chunk_compress_psnr(double* vals, const size_t dims[3], double psnr, uint8_t** stream,
+                            size_t* stream_len)
+{
+  return chunk_compress_psnr_impl(0, vals, dims, psnr, stream, stream_len);
+}
+int orc_chunk_compress_pwe(double* vals, const size_t dims[3], double tol, uint8_t** stream,
+                           size_t* stream_len)
+{
+  return chunk_compress_pwe_impl(0, vals, dims, tol, stream, stream_len);
+}
+
+static int chunk_decompress_impl(int two_d, const uint8_t* stream, size_t len,
+                                 const size_t dims[3], double* out, double** hier);
 
 /* src/SPECK_FLT.cpp:27-109,543-606 */
 int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3], double* out)
 {
-  return chunk_decompress_impl(stream, len, dims, out, NULL);
+  return chunk_decompress_impl(0, stream, len, dims, out, NULL);
 }
 
 /* src/SPECK_FLT.cpp:543-620 with multi_res: hier[h] receives the chunk at its h-th coarsened
@@ -1560,11 +1978,11 @@ int orc_chunk_decompress(const uint8_t* stream, size_t len, const size_t dims[3]
 int orc_chunk_decompress_multi_res(const uint8_t* stream, size_t len, const size_t dims[3],
                                    double* out, double** hier)
 {
-  return chunk_decompress_impl(stream, len, dims, out, hier);
+  return chunk_decompress_impl(0, stream, len, dims, out, hier);
 }
 
-static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t dims[3],
-                                 double* out, double** hier)
+static int chunk_decompress_impl(int two_d, const uint8_t* stream, size_t len,
+                                 const size_t dims[3], double* out, double** hier)
 {
   const size_t n = dims[0] * dims[1] * dims[2];
   size_t res[16][3];
@@ -1591,7 +2009,7 @@ static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t
   size_t speck_len = full < remaining ? full : remaining;
   uint64_t* coef = (uint64_t*)malloc(n * sizeof(uint64_t));
   uint64_t* sign = (uint64_t*)malloc(((n + 63) / 64) * sizeof(uint64_t));
-  orc_speck3d_decode(sp, speck_len, dims, coef, sign);
+  int_decode(two_d, sp, speck_len, dims, coef, sign);
   orc_inv_quantize(coef, sign, n, q, out);
   if (nres) {
     orc_idwt3d_multi_res(out, dims, hier);
@@ -1622,6 +2040,70 @@ static int chunk_decompress_impl(const uint8_t* stream, size_t len, const size_t
 /* ------------------------------------------------------------------------------------------ */
 /* container + C API mirrors                                                                  */
 /* ------------------------------------------------------------------------------------------ */
+
+/* src/SPERR_C_API.cpp:7-97 : one slice through SPECK2D_FLT; the optional 10-byte header is
+ * {version, flags (0x20: float input), u32 dimx, u32 dimy} */
+int orc_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int mode, double quality,
+                int out_inc_header, void** dst, size_t* dst_len)
+{
+  if (*dst != NULL)
+    return 1;
+  if (quality <= 0.0)
+    return 2;
+  if (mode < 1 || mode > 3)
+    return 2;
+  const size_t n = dimx * dimy, dims[3] = {dimx, dimy, 1};
+  double* buf = (double*)malloc(n * sizeof(double));
+  for (size_t i = 0; i < n; i++)
+    buf[i] = is_float ? (double)((const float*)src)[i] : ((const double*)src)[i];
+  uint8_t* stream = NULL;
+  size_t len = 0;
+  const int rtn = mode == 1   ? chunk_compress_rate_impl(1, buf, dims, quality, &stream, &len)
+                  : mode == 2 ? chunk_compress_psnr_impl(1, buf, dims, quality, &stream, &len)
+                              : chunk_compress_pwe_impl(1, buf, dims, quality, &stream, &len);
+  free(buf);
+  if (rtn) {
+    free(stream);
+    return -1;
+  }
+  const size_t hlen = out_inc_header ? 10 : 0;
+  uint8_t* out = (uint8_t*)malloc(hlen + len);
+  if (out_inc_header) {
+    out[0] = 0; /* SPERR_VERSION_MAJOR */
+    out[1] = (uint8_t)(is_float ? 0x20 : 0);
+    const uint32_t d2[2] = {(uint32_t)dimx, (uint32_t)dimy};
+    memcpy(out + 2, d2, 8);
+  }
+  memcpy(out + hlen, stream, len);
+  free(stream);
+  *dst = out;
+  *dst_len = hlen + len;
+  return 0;
+}
+
+/* src/SPERR_C_API.cpp:99-134 : `src` is the stream without the optional header */
+int orc_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx, size_t dimy,
+                  void** dst)
+{
+  if (*dst != NULL)
+    return 1;
+  const size_t n = dimx * dimy, dims[3] = {dimx, dimy, 1};
+  double* outd = (double*)malloc(n * sizeof(double));
+  if (chunk_decompress_impl(1, (const uint8_t*)src, src_len, dims, outd, NULL)) {
+    free(outd);
+    return -1;
+  }
+  if (output_float) {
+    float* f = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++)
+      f[i] = (float)outd[i];
+    free(outd);
+    *dst = f;
+  }
+  else
+    *dst = outd;
+  return 0;
+}
 
 /* src/SPERR_C_API.cpp:156-216, src/SPERR3D_OMP_C.cpp:61-261 */
 int orc_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,

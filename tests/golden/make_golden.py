@@ -102,10 +102,37 @@ def main():
                 "decoded_f64_sha256": hashlib.sha256(dec_d.tobytes()).hexdigest(),
             })
             print(tag, len(stream))
+    # 2D slices through sperr_comp_2d / sperr_decomp_2d (SPECK2D_FLT): a crop of the reference's
+    # test_data/999x999.float (BASELINE configs[3]: PSNR = 90 dB) and a generated field
+    img = np.fromfile(f"{TD}/999x999.float", dtype=np.float32).reshape(999, 999)
+    crop = np.ascontiguousarray(img[200:296, 300:421])   # y96 x121
+    crop.tofile(os.path.join(HERE, "img999_crop.f32"))
+    slices = {"img999_crop": crop, "smooth2d_f64": smooth_field((1, 50, 72), dtype=np.float64)[0]}
+    cases2d = []
+    for name, mode, q, hdr in [("img999_crop", 2, 90.0, True), ("img999_crop", 1, 2.0, False),
+                               ("img999_crop", 3, 0.05, True), ("smooth2d_f64", 1, 6.0, False),
+                               ("smooth2d_f64", 2, 120.0, True), ("smooth2d_f64", 3, 1e-6, False)]:
+        arr = slices[name]
+        stream = ref.comp_2d(arr, mode, q, hdr)
+        body = stream[10:] if hdr else stream
+        dec_f = ref.decomp_2d(body, arr.shape, True)
+        dec_d = ref.decomp_2d(body, arr.shape, False)
+        tag = f"{name}_2d_{('bpp', 'psnr', 'pwe')[mode - 1]}{q}{'_hdr' if hdr else ''}"
+        with open(os.path.join(HERE, tag + ".sperr"), "wb") as f:
+            f.write(stream)
+        cases2d.append({
+            "tag": tag, "input": name, "shape_yx": list(arr.shape), "dtype": str(arr.dtype),
+            "mode": mode, "quality": q, "header": hdr,
+            "input_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
+            "stream_len": len(stream), "stream_sha256": hashlib.sha256(stream).hexdigest(),
+            "decoded_f32_sha256": hashlib.sha256(dec_f.tobytes()).hexdigest(),
+            "decoded_f64_sha256": hashlib.sha256(dec_d.tobytes()).hexdigest(),
+        })
+        print(tag, len(stream))
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "reference": "NCAR/SPERR v0.8.5, g++ -O3 -mavx2 -mfma (oracle/Makefile)",
-                   "cases": cases}, f, indent=1)
+                   "cases": cases, "cases_2d": cases2d}, f, indent=1)
 
 
 if __name__ == "__main__":

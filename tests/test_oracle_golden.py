@@ -14,7 +14,8 @@ from fields import smooth_field
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 with open(os.path.join(GOLD, "golden.json")) as f:
-    CASES = json.load(f)["cases"]
+    _G = json.load(f)
+    CASES, CASES_2D = _G["cases"], _G["cases_2d"]
 
 
 def load_input(case):
@@ -38,6 +39,33 @@ def test_oracle_matches_golden_stream_and_decode(oracle, case):
     assert got == want  # bit-exact container
     dec_f = oracle.decomp_3d(want, True)
     dec_d = oracle.decomp_3d(want, False)
+    assert hashlib.sha256(dec_f.tobytes()).hexdigest() == case["decoded_f32_sha256"]
+    assert hashlib.sha256(dec_d.tobytes()).hexdigest() == case["decoded_f64_sha256"]
+
+
+def load_slice(case):
+    name, shape = case["input"], tuple(case["shape_yx"])
+    path = os.path.join(GOLD, name + ".f32")
+    if os.path.exists(path):
+        arr = np.fromfile(path, dtype=np.float32).reshape(shape)
+    else:
+        arr = smooth_field((1,) + shape, dtype=np.dtype(case["dtype"]))[0]
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == case["input_sha256"]
+    return arr
+
+
+@pytest.mark.parametrize("case", CASES_2D, ids=[c["tag"] for c in CASES_2D])
+def test_oracle_matches_golden_2d(oracle, case):
+    """sperr_comp_2d / sperr_decomp_2d (src/SPERR_C_API.cpp:7-134) through SPECK2D_INT."""
+    arr = load_slice(case)
+    with open(os.path.join(GOLD, case["tag"] + ".sperr"), "rb") as f:
+        want = f.read()
+    got = oracle.comp_2d(arr, case["mode"], case["quality"], case["header"])
+    assert len(got) == case["stream_len"]
+    assert got == want
+    body = want[10:] if case["header"] else want
+    dec_f = oracle.decomp_2d(body, arr.shape, True)
+    dec_d = oracle.decomp_2d(body, arr.shape, False)
     assert hashlib.sha256(dec_f.tobytes()).hexdigest() == case["decoded_f32_sha256"]
     assert hashlib.sha256(dec_d.tobytes()).hexdigest() == case["decoded_f64_sha256"]
 

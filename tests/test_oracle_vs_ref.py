@@ -125,6 +125,22 @@ def test_multi_resolution_decode_bit_exact(oracle, ref, shape, chunks):
         assert np.array_equal(bits(a), bits(b))
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (37, 50), (96, 121), (9, 200), (150, 11)])
+@pytest.mark.parametrize("mode,quality", [(1, 0.7), (1, 5.0), (2, 75.0), (2, 160.0), (3, 1e-2), (3, 1e-6)])
+def test_2d_slices_bit_exact(oracle, ref, shape, mode, quality):
+    """sperr_comp_2d / sperr_decomp_2d (src/SPERR_C_API.cpp:7-134): dwt2d, SPECK2D_INT with its
+    type-I set (src/SPECK2D_INT*.cpp), all three modes, with and without the 10-byte header."""
+    for dtype in (np.float32, np.float64):
+        img = turbulence((1,) + shape, dtype=dtype)[0]
+        for hdr in (False, True):
+            want = ref.comp_2d(img, mode, quality, hdr)
+            assert oracle.comp_2d(img, mode, quality, hdr) == want
+        body = want[10:]
+        for as_float in (True, False):
+            assert np.array_equal(bits(oracle.decomp_2d(body, shape, as_float)),
+                                  bits(ref.decomp_2d(body, shape, as_float)))
+
+
 def test_speck1d_bit_exact(oracle, ref):
     """SPECK1D_INT_ENC / _DEC (src/SPECK1D_INT*.cpp) on sparse arrays: same stream, and it
     round-trips exactly through both decoders."""
