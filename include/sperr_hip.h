@@ -93,6 +93,23 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
                                 size_t dimz, void* d_coef, uint64_t* d_sign, int* width_out,
                                 void* hip_stream);
 
+/* ---- 2D slices -------------------------------------------------------------------------------
+ * Drop-in replacements for /root/reference/include/SPERR_C_API.h:53-81
+ * (src/SPERR_C_API.cpp:7-134): one slice through SPECK2D_FLT (dwt2d, SPECK2D_INT), the three
+ * modes of sperr_comp_3d; out_inc_header != 0 prepends the 10-byte header {version, flags,
+ * u32 dimx, u32 dimy}; sperr_decomp_2d takes the stream WITHOUT that header. */
+int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int mode, double quality,
+                  int out_inc_header, void** dst, size_t* dst_len);
+int sperr_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx, size_t dimy,
+                    void** dst);
+/* the same on device-resident buffers */
+size_t sperrhip_max_compressed_size_2d(size_t dimx, size_t dimy, int mode, double quality);
+int sperrhip_compress_2d_dev(const void* d_src, int is_float, size_t dimx, size_t dimy, int mode,
+                             double quality, int out_inc_header, void* d_dst, size_t dst_cap,
+                             size_t* dst_len, void* hip_stream);
+int sperrhip_decompress_2d_dev(const void* d_src, size_t src_len, int output_float, size_t dimx,
+                               size_t dimy, void* d_dst, size_t dst_cap_bytes, void* hip_stream);
+
 /* ---- multi-resolution decoding ---------------------------------------------------------------
  * sperr::SPERR3D_OMP_D::decompress(p, multi_res = true) + release_hierarchy()
  * (/root/reference/include/SPERR3D_OMP_D.h:22-29, src/SPERR3D_OMP_D.cpp:50-150,

@@ -20,7 +20,9 @@ EXPORTS = [
     "sperrhip_parse_header_dev", "sperrhip_dwt3d_dev", "sperrhip_speck3d_encode_dev",
     "sperrhip_speck3d_decode_dev", "sperrhip_profile_enable", "sperrhip_profile_reset",
     "sperrhip_profile_get", "sperrhip_profile_get2", "sperrhip_profile_only",
-    "sperrhip_multires_levels", "sperrhip_decompress_multires_dev", "sperrhip_decomp_3d_multires", "sperrhip_version", "sperrhip_debug_lis_stamps",
+    "sperrhip_multires_levels", "sperrhip_decompress_multires_dev", "sperrhip_decomp_3d_multires",
+    "sperr_comp_2d", "sperr_decomp_2d", "sperrhip_max_compressed_size_2d", "sperrhip_compress_2d_dev",
+    "sperrhip_decompress_2d_dev", "sperrhip_version", "sperrhip_debug_lis_stamps",
 ]
 
 
@@ -233,6 +235,42 @@ class SperrHip:
         out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
         self._libc.free(dst)
         return out.reshape(dz.value, dy.value, dx.value)
+
+    # ---- 2D slices --------------------------------------------------------------------------
+    def compress_2d(self, img, quality, mode=1, header=False):
+        """img: cuda tensor float32/float64 (y, x). Returns a cuda uint8 tensor (sperr_comp_2d)."""
+        torch = self.torch
+        assert img.is_cuda and img.is_contiguous() and img.dim() == 2
+        dy, dx = img.shape
+        self.lib.sperrhip_max_compressed_size_2d.restype = _sz
+        self.lib.sperrhip_max_compressed_size_2d.argtypes = [_sz, _sz, C.c_int, C.c_double]
+        cap = self.lib.sperrhip_max_compressed_size_2d(dx, dy, mode, float(quality))
+        out = torch.empty(cap, dtype=torch.uint8, device=img.device)
+        n = _sz(0)
+        self.lib.sperrhip_compress_2d_dev.argtypes = [C.c_void_p, C.c_int, _sz, _sz, C.c_int, C.c_double,
+                                                      C.c_int, C.c_void_p, _sz, C.POINTER(_sz), C.c_void_p]
+        rtn = self.lib.sperrhip_compress_2d_dev(img.data_ptr(), int(img.dtype == torch.float32), dx, dy,
+                                                mode, float(quality), int(header), out.data_ptr(),
+                                                out.numel(), C.byref(n), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_compress_2d_dev returned {rtn}")
+        return out[:n.value]
+
+    def decompress_2d(self, stream, shape_yx, output_float=True):
+        """stream: cuda uint8 tensor WITHOUT the optional 10-byte header (sperr_decomp_2d)."""
+        torch = self.torch
+        dy, dx = shape_yx
+        stream = stream.contiguous()
+        out = torch.empty((dy, dx), dtype=torch.float32 if output_float else torch.float64,
+                          device=stream.device)
+        self.lib.sperrhip_decompress_2d_dev.argtypes = [C.c_void_p, _sz, C.c_int, _sz, _sz, C.c_void_p,
+                                                        _sz, C.c_void_p]
+        rtn = self.lib.sperrhip_decompress_2d_dev(stream.data_ptr(), stream.numel(), int(output_float),
+                                                  dx, dy, out.data_ptr(),
+                                                  out.numel() * out.element_size(), self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decompress_2d_dev returned {rtn}")
+        return out
 
     # ---- multi-resolution decoding ----------------------------------------------------------
     def multires_levels(self, shape_zyx, chunks_xyz):

@@ -26,6 +26,7 @@
 #include "speck_enc.h"
 #include "speck_tree_host.hpp"
 #include "outlier.h"
+#include "speck2d.h"
 #include "xform.h"
 
 namespace sperrhip {
@@ -443,6 +444,7 @@ struct Engine {
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
+  DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
   size_t freeMemAtInit = 0;
 
   int init()
@@ -1050,10 +1052,62 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   return 0;
 }
 
+// ---- 2D slices (sperr_comp_2d / sperr_decomp_2d, src/SPERR_C_API.cpp:7-134): a slice is a
+// one-chunk batch of dims (x, y, 1) -- its transform plan already is dwt2d -- coded by the 2D
+// coder of speck2d.hip instead of the 3D one
+int carve_slice2d(Engine& E, const ShapePlan& P, Speck2dBufs& sb)
+{
+  memset(&sb, 0, sizeof(sb));
+  sb.dx = P.dims[0];
+  sb.dy = P.dims[1];
+  sb.N = P.N;
+  sb.nw = (P.N + 63) / 64;
+  sb.nxforms = (uint32_t)spk::num_of_xforms(std::min(P.dims[0], P.dims[1]));
+  sb.nlists = (uint32_t)spk::num_of_partitions(std::max(P.dims[0], P.dims[1])) + 1;
+  if (sb.dx > 0xffffu || sb.dy > 0xffffu || sb.nlists > (uint32_t)kS2MaxLevels)
+    return -1;
+  const size_t entries = speck2d_list_entries(sb);
+  const size_t words = round_up((size_t)sb.nw + 2, 32);
+  const size_t bytes = round_up(entries * 8, 256) + round_up(entries, 256) + 2 * words * 8 +
+                       round_up((size_t)P.N * 4, 256) + 1024 + 4096;
+  if (E.slice2d.ensure(bytes))
+    return -1;
+  Arena A;
+  A.base = static_cast<char*>(E.slice2d.p);
+  A.cap = E.slice2d.n;
+  sb.runs = A.take<uint64_t>(entries);
+  sb.sval = A.take<int8_t>(entries);
+  sb.lip = A.take<uint64_t>(words);
+  sb.lsp = A.take<uint64_t>(words);
+  sb.fresh = A.take<uint32_t>(P.N);
+  sb.prep = A.take<int32_t>(256);
+  return (sb.runs && sb.sval && sb.lip && sb.lsp && sb.fresh && sb.prep) ? 0 : -1;
+}
+
+// optional 10-byte header {version, flags, u32 dimx, u32 dimy} (SPERR_C_API.cpp:45-83), then the
+// chunk stream and its outlier stream
+__global__ void k_slice_header(uint8_t* dst, const uint64_t* lens, const uint64_t* lens2,
+                               uint64_t* offs, uint32_t vx, uint32_t vy, int is_float,
+                               int with_header, uint64_t* total)
+{
+  if (blockIdx.x || threadIdx.x)
+    return;
+  uint64_t pos = 0;
+  if (with_header) {
+    dst[0] = 0;
+    dst[1] = (uint8_t)(is_float ? 0x20 : 0);
+    const uint32_t d2[2] = {vx, vy};
+    memcpy(dst + 2, d2, 8);
+    pos = 10;
+  }
+  offs[0] = pos;
+  *total = pos + lens[0] + lens2[0];
+}
+
 template <typename T>
 int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mode, double quality,
-                  uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st)
-{
+                  uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st, int slice = 0)
+{   // slice: 0 = a 3D container; 1 / 2 = one 2D slice without / with the 10-byte header
   // mode 1: fixed rate, `quality` bits per value; mode 2: fixed PSNR and mode 3: fixed point-wise
   // error, every bit plane is coded
   const bool rate = mode == 1;
@@ -1182,7 +1236,20 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
 
       // ---- integer coder, 32-bit coefficients ----
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
-      if (launch_speck_encode(st, e, ph, raw_budget, rate, false))
+      Speck2dBufs sb;
+      if (slice) {
+        if (carve_slice2d(E, *P, sb))
+          return -1;
+        sb.coef = bb.coef32;
+        sb.sign = const_cast<uint64_t*>(e.sign);
+        sb.msb = bb.msb;
+        sb.stream = e.stream;
+        sb.streamWords = e.streamStride;
+        sb.cst = e.cst;
+        if (launch_speck2d_encode(st, sb, raw_budget, rate, false))
+          return -1;
+      }
+      else if (launch_speck_encode(st, e, ph, raw_budget, rate, false))
         return -1;
       const uint32_t wblocks = (uint32_t)std::min<size_t>(4096, (e.streamStride * 8 + kThreads - 1) / kThreads);
       LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
@@ -1208,7 +1275,12 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
         EncBuffers ew = e;
         ew.coef = bb.vals;
         ew.coefStride = bb.valsStride;
-        if (launch_speck_encode(st, ew, ph, raw_budget, rate, true))
+        if (slice) {
+          sb.coef = bb.vals;
+          if (launch_speck2d_encode(st, sb, raw_budget, rate, true))
+            return -1;
+        }
+        else if (launch_speck_encode(st, ew, ph, raw_budget, rate, true))
           return -1;
         LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
@@ -1221,9 +1293,14 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
   }
 
   // ---- container ----
-  LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs, nchunks,
-           (uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2], (uint32_t)cdim[0],
-           (uint32_t)cdim[1], (uint32_t)cdim[2], std::is_same<T, float>::value ? 1 : 0, d_total);
+  if (slice)
+    LAUNCH_K(k_slice_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs,
+             (uint32_t)vol[0], (uint32_t)vol[1], std::is_same<T, float>::value ? 1 : 0,
+             slice == 2 ? 1 : 0, d_total);
+  else
+    LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs, nchunks,
+             (uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2], (uint32_t)cdim[0],
+             (uint32_t)cdim[1], (uint32_t)cdim[2], std::is_same<T, float>::value ? 1 : 0, d_total);
   LAUNCH_K(k_copy_slots, dim3(1024, nchunks), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap,
            static_cast<const uint8_t*>(E.slots.p), d_slotOff, d_lens, d_offs);
   for (auto& k : pweKeep.v)
@@ -1468,8 +1545,9 @@ k_sub_volume(const double* vals, size_t valsStride, const CoderState* cst, const
 
 template <typename T>
 int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_cap_vals,
-                    const ContainerInfo& ci, hipStream_t st, const MultiRes* mr = nullptr)
-{
+                    const ContainerInfo& ci, hipStream_t st, const MultiRes* mr = nullptr,
+                    bool slice = false)
+{   // slice: `ci` describes one chunk of dims (x, y, 1) whose stream starts at d_src (2D coder)
   Engine& E = g_engine;
   const auto chunks = chunk_volume(ci.vol, ci.chunk);
   const uint32_t nchunks = (uint32_t)chunks.size();
@@ -1687,6 +1765,25 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
           }
           else
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
+          if (slice) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
+            DecPlanHost ph2 = ph;
+            ph2.tables = ph2.l0 = ph2.l1 = false;
+            Speck2dBufs sb;
+            if (launch_speck_decode(ss, dw, ph2, d_src, bb.chunkOff, bb.chunkLen, wide != 0, 0) ||
+                carve_slice2d(E, *P, sb))
+              return -1;
+            sb.coef = dw.coef;
+            sb.sign = d.sign;
+            sb.stream = d.stream;
+            sb.streamWords = d.streamStride;
+            sb.cst = d.cst;
+            sb.dst = d.st;
+            if (launch_speck2d_decode(ss, sb, wide != 0) ||
+                launch_inv_quantize(ss, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
+                                    P->N, bb.vals, bb.valsStride, d.cst))
+              return -1;
+            continue;
+          }
           // the header kernel must run even when no plane does (constant / all-zero chunks)
           if (launch_speck_decode(ss, dw, ph, d_src, bb.chunkOff, bb.chunkLen, wide != 0,
                                   wide ? maxWide : maxNarrow))
@@ -2088,6 +2185,57 @@ int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int outp
                                  st, &m);
 }
 
+// ---- 2D slices (include/SPERR_C_API.h:53-81, src/SPERR_C_API.cpp:7-134) ------------------------
+size_t sperrhip_max_compressed_size_2d(size_t dimx, size_t dimy, int mode, double quality)
+{
+  return 10 + sperrhip_max_compressed_size(dimx, dimy, 1, dimx, dimy, 1, mode, quality);
+}
+
+int sperrhip_compress_2d_dev(const void* d_src, int is_float, size_t dimx, size_t dimy, int mode,
+                             double quality, int out_inc_header, void* d_dst, size_t dst_cap,
+                             size_t* dst_len, void* hip_stream)
+{
+  if (quality <= 0.0)
+    return 2;
+  if (mode < 1 || mode > 3)
+    return 2;
+  if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0)
+    return -1;
+  const Dims vol{dimx, dimy, 1};
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int slice = out_inc_header ? 2 : 1;
+  if (is_float)
+    return compress_impl<float>(static_cast<const float*>(d_src), vol, vol, mode, quality,
+                                static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
+  return compress_impl<double>(static_cast<const double*>(d_src), vol, vol, mode, quality,
+                               static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
+}
+
+// d_src: the stream WITHOUT the optional 10-byte header, as sperr_decomp_2d takes it
+int sperrhip_decompress_2d_dev(const void* d_src, size_t src_len, int output_float, size_t dimx,
+                               size_t dimy, void* d_dst, size_t dst_cap_bytes, void* hip_stream)
+{
+  if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17)
+    return -1;
+  std::lock_guard<std::mutex> lock(g_engine.mu);
+  if (g_engine.init())
+    return -1;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ContainerInfo ci;
+  ci.vol = {dimx, dimy, 1};
+  ci.chunk = ci.vol;
+  ci.is_float = output_float != 0;
+  ci.off = {0};
+  ci.len = {src_len};
+  if (output_float)
+    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
+                                  nullptr, true);
+  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st,
+                                 nullptr, true);
+}
+
 // ---- stage access for parity tests -----------------------------------------------------------
 
 int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, int inverse,
@@ -2407,6 +2555,77 @@ int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nt
   if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
     rtn = sperrhip_decompress_dev(d_in, src_len, output_float, d_out, n * esz, dimx, dimy, dimz,
                                   nullptr);
+  if (rtn == 0) {
+    void* buf = malloc(n * esz);
+    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+      *dst = buf;
+    else {
+      free(buf);
+      rtn = -1;
+    }
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rtn;
+}
+
+// include/SPERR_C_API.h:53-62, src/SPERR_C_API.cpp:7-97
+int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int mode, double quality,
+                  int out_inc_header, void** dst, size_t* dst_len)
+{
+  if (*dst != nullptr)
+    return 1;
+  if (quality <= 0.0)
+    return 2;
+  if (mode < 1 || mode > 3)
+    return 2;
+  const size_t n = dimx * dimy, esz = is_float ? 4 : 8;
+  const size_t cap = sperrhip_max_compressed_size_2d(dimx, dimy, mode, quality);
+  void *d_in = nullptr, *d_out = nullptr;
+  if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
+    fprintf(stderr, "[sperr_hip] device allocation failed\n");
+    if (d_in)
+      (void)hipFree(d_in);
+    return -1;
+  }
+  int rtn = -1;
+  size_t len = 0;
+  if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
+    rtn = sperrhip_compress_2d_dev(d_in, is_float, dimx, dimy, mode, quality, out_inc_header, d_out,
+                                   cap, &len, nullptr);
+  if (rtn == 0) {
+    void* buf = malloc(len);
+    if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+      *dst = buf;
+      *dst_len = len;
+    }
+    else {
+      free(buf);
+      rtn = -1;
+    }
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rtn;
+}
+
+// include/SPERR_C_API.h:75-81, src/SPERR_C_API.cpp:99-134
+int sperr_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx, size_t dimy,
+                    void** dst)
+{
+  if (*dst != nullptr)
+    return 1;
+  const size_t n = dimx * dimy, esz = output_float ? 4 : 8;
+  void *d_in = nullptr, *d_out = nullptr;
+  if (src_len < 17 || hipMalloc(&d_in, src_len) != hipSuccess ||
+      hipMalloc(&d_out, n * esz) != hipSuccess) {
+    if (d_in)
+      (void)hipFree(d_in);
+    return -1;
+  }
+  int rtn = -1;
+  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+    rtn = sperrhip_decompress_2d_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, nullptr);
   if (rtn == 0) {
     void* buf = malloc(n * esz);
     if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)

@@ -132,7 +132,8 @@ def test_speck_decode_wide(eng, oracle):
 
 
 with open(os.path.join(GOLD, "golden.json")) as f:
-    CASES = json.load(f)["cases"]
+    _G = json.load(f)
+    CASES, CASES_2D = _G["cases"], _G["cases_2d"]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
@@ -424,6 +425,73 @@ def test_multi_resolution_absent_for_other_shapes(eng, oracle):
         vol, levels = eng.decompress_multires(dev, output_float=True)
         assert levels == []
         assert np.array_equal(bits(vol.cpu().numpy()), bits(oracle.decomp_3d(stream, True)))
+
+
+@pytest.mark.parametrize("case", CASES_2D, ids=[c["tag"] for c in CASES_2D])
+def test_golden_vectors_2d(eng, case):
+    """sperr_comp_2d / sperr_decomp_2d against streams written by the reference itself."""
+    shape = tuple(case["shape_yx"])
+    path = os.path.join(GOLD, case["input"] + ".f32")
+    if os.path.exists(path):
+        arr = np.fromfile(path, dtype=np.float32).reshape(shape)
+    else:
+        arr = smooth_field((1,) + shape, dtype=np.dtype(case["dtype"]))[0]
+    with open(os.path.join(GOLD, case["tag"] + ".sperr"), "rb") as f:
+        want = f.read()
+    got = bytes(eng.compress_2d(cuda(arr), case["quality"], mode=case["mode"],
+                                header=case["header"]).cpu().numpy())
+    assert got == want
+    body = cuda(np.frombuffer(want[10:] if case["header"] else want, dtype=np.uint8))
+    dec_f = eng.decompress_2d(body, shape, True).cpu().numpy()
+    dec_d = eng.decompress_2d(body, shape, False).cpu().numpy()
+    assert hashlib.sha256(dec_f.tobytes()).hexdigest() == case["decoded_f32_sha256"]
+    assert hashlib.sha256(dec_d.tobytes()).hexdigest() == case["decoded_f64_sha256"]
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 50), (96, 121), (9, 200), (150, 11), (256, 256)])
+@pytest.mark.parametrize("mode,quality", [(1, 0.7), (1, 5.0), (2, 75.0), (2, 160.0), (3, 1e-2), (3, 1e-6)])
+def test_2d_slices_match_oracle(eng, oracle, shape, mode, quality):
+    """dwt2d + SPECK2D_INT with its type-I set, all three modes (src/SPECK2D_INT*.cpp,
+    src/SPERR_C_API.cpp:7-134), float and double input, with and without the header."""
+    for dtype in (np.float32, np.float64):
+        img = turbulence((1,) + shape, dtype=dtype)[0]
+        for hdr in (False, True):
+            want = oracle.comp_2d(img, mode, quality, hdr)
+            got = bytes(eng.compress_2d(cuda(img), quality, mode=mode, header=hdr).cpu().numpy())
+            assert got == want
+        body = cuda(np.frombuffer(want[10:], dtype=np.uint8))
+        for as_float in (True, False):
+            assert np.array_equal(bits(eng.decompress_2d(body, shape, as_float).cpu().numpy()),
+                                  bits(oracle.decomp_2d(want[10:], shape, as_float)))
+
+
+def test_2d_host_c_api_and_truncated_stream(eng, oracle):
+    """The host entry points (malloc'd results, return codes) and a stream cut short: the decoder
+    pads with zeros like the reference (src/SPECK_INT.cpp:95-105)."""
+    import ctypes as C
+    img = turbulence((1, 80, 120))[0]
+    want = oracle.comp_2d(img, 1, 3.0, False)
+    lib = eng.lib
+    dst, n = C.c_void_p(None), C.c_size_t(0)
+    lib.sperr_comp_2d.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_double,
+                                  C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    assert lib.sperr_comp_2d(img.ctypes.data, 1, 120, 80, 1, 3.0, 0, C.byref(dst), C.byref(n)) == 0
+    assert C.string_at(dst.value, n.value) == want
+    assert lib.sperr_comp_2d(img.ctypes.data, 1, 120, 80, 1, 3.0, 0, C.byref(dst), C.byref(n)) == 1
+    C.CDLL(None).free(dst)
+    dst = C.c_void_p(None)
+    assert lib.sperr_comp_2d(img.ctypes.data, 1, 120, 80, 7, 3.0, 0, C.byref(dst), C.byref(n)) == 2
+    assert lib.sperr_comp_2d(img.ctypes.data, 1, 120, 80, 1, -1.0, 0, C.byref(dst), C.byref(n)) == 2
+    for cut in (len(want), len(want) - 700, 60):
+        part = want[:cut]
+        buf = np.frombuffer(part, dtype=np.uint8)
+        out = C.c_void_p(None)
+        lib.sperr_decomp_2d.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t,
+                                        C.POINTER(C.c_void_p)]
+        assert lib.sperr_decomp_2d(buf.ctypes.data, buf.size, 0, 120, 80, C.byref(out)) == 0
+        got = np.frombuffer(C.string_at(out.value, 80 * 120 * 8), dtype=np.float64).reshape(80, 120)
+        C.CDLL(None).free(out)
+        assert np.array_equal(bits(got.copy()), bits(oracle.decomp_2d(part, (80, 120), False)))
 
 
 def test_many_chunks_decode_in_sub_batches(eng, oracle):
