@@ -67,3 +67,30 @@ def test_random_case(eng, seed):
                               bits(oracle.decomp_3d(want, as_float))), (v.shape, chunks, mode, quality)
     if mode == 3:
         assert np.abs(oracle.decomp_3d(want, False) - v.astype(np.float64)).max() <= quality
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_slice(eng, seed):
+    """The 2D entry points on random slices: sperr_comp_2d / sperr_decomp_2d, the three modes."""
+    from oracle.pyoracle import Oracle
+    oracle = Oracle()
+    rng = np.random.default_rng(5000 + seed)
+    shape = (int(rng.integers(9, 140)), int(rng.integers(9, 140)))
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    img = turbulence((1,) + shape, seed=seed + 11, dtype=dtype)[0]
+    if rng.random() < 0.3:
+        img = (img + 0.1 * rng.standard_normal(shape)).astype(dtype)
+    mode = int(rng.integers(1, 4))
+    span = float(img.max() - img.min()) or 1.0
+    quality = (float(rng.choice([0.4, 1.5, 4.0, 11.0])), float(rng.choice([35.0, 70.0, 120.0, 200.0])),
+               span * float(rng.choice([0.1, 1e-2, 1e-4, 1e-7])))[mode - 1]
+    hdr = bool(rng.integers(0, 2))
+    want = oracle.comp_2d(img, mode, quality, hdr)
+    got = bytes(eng.compress_2d(cuda(img), quality, mode=mode, header=hdr).cpu().numpy())
+    assert got == want, (shape, mode, quality, str(dtype))
+    body = want[10:] if hdr else want
+    cut = len(body) if rng.random() < 0.5 else max(27, int(len(body) * rng.random()))
+    dev = cuda(np.frombuffer(body[:cut], dtype=np.uint8))
+    for as_float in (True, False):
+        assert np.array_equal(bits(eng.decompress_2d(dev, shape, as_float).cpu().numpy()),
+                              bits(oracle.decomp_2d(body[:cut], shape, as_float))), (shape, mode, quality, cut)
