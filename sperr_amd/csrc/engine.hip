@@ -925,21 +925,20 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   ob.nw = (P.N + 63) / 64;
   ob.wordStride = round_up((size_t)ob.nw + 2, 32);
   {
-    const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) + (size_t)nb * ob.wordStride * (5 * 8 + 2 * 4) + 4096;
+    const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) + (size_t)nb * ob.wordStride * (4 * 8 + 2 * 4) + 4096;
     if (E.outlFixed.ensure(bytes))
       return -1;
     Arena A;
     A.base = static_cast<char*>(E.outlFixed.p);
     A.cap = E.outlFixed.n;
     ob.oc = A.take<OutlierChunk>(nb);
-    ob.outMask = A.take<uint64_t>(nb * ob.wordStride);
     ob.lip = A.take<uint64_t>(nb * ob.wordStride);
     ob.signMask = A.take<uint64_t>(nb * ob.wordStride);
     ob.maskGE = A.take<uint64_t>(nb * ob.wordStride);
     ob.maskEQ = A.take<uint64_t>(nb * ob.wordStride);
     ob.outPre = A.take<uint32_t>(nb * ob.wordStride);
     ob.cpos = A.take<uint32_t>(nb * ob.wordStride);
-    if (!ob.oc || !ob.outMask || !ob.lip || !ob.signMask || !ob.maskGE || !ob.maskEQ || !ob.outPre || !ob.cpos)
+    if (!ob.oc || !ob.lip || !ob.signMask || !ob.maskGE || !ob.maskEQ || !ob.outPre || !ob.cpos)
       return -1;
   }
   HIP_CHECK(hipMemsetAsync(ob.oc, 0, nb * sizeof(OutlierChunk), st));

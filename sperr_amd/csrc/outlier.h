@@ -33,8 +33,7 @@ struct OutlierBufs {
   uint32_t nchunks, N, nw;       // nw = mask words per chunk
   OutlierChunk* oc;
   size_t wordStride;             // >= nw + 2
-  uint64_t* outMask;             // encoder: positions of the outliers
-  uint32_t* outPre;              //          outliers before each mask word ([nw] = their number)
+  uint32_t* outPre;              // encoder: outliers before each 64-value word ([nw] = their number)
   uint64_t* signMask;            //          positions of the non-negative ones
   uint64_t* maskGE;              //          outliers at or above the current threshold, by position
   uint64_t* maskEQ;              //          ... whose msb is the current plane
@@ -59,7 +58,7 @@ struct OutlierBufs {
 };
 
 // encoder, three passes over the reconstructed chunk (vals) and the input volume:
-//   pass 0: flagged, maxErrKey;  pass 1: outMask + per-word counts (into outPre);  pass 2 (after
+//   pass 0: flagged, maxErrKey;  pass 1: signMask + per-word counts (into outPre);  pass 2 (after
 //   launch_outlier_prefix): pos / mag / sgn / msb, maxMag
 template <typename T>
 int launch_outlier_scan(hipStream_t st, int pass, const T* vol, VolDesc vd, const ChunkGeom* geom,

@@ -5,10 +5,10 @@
 // that is zero everywhere else.
 //
 // The array is sparse, so the coder never touches N values:
-//   * encoder: the outliers are kept as sorted (position, magnitude, sign) triples; a run of the
-//     array [start, start + len) maps to a range of outlier indices through a position bitmask with
-//     a popcount prefix, and the msb of its largest magnitude is one lookup in a range-maximum
-//     table.  A run is tested against the current threshold by comparing that msb with the plane.
+//   * encoder: the outliers are kept as sorted (position, magnitude, sign, msb) records; per bit
+//     plane a position bitmask of the outliers at or above the threshold, with a popcount prefix,
+//     turns "is the run [start, start + len) significant" into a difference of two counts, and
+//     once a run holds at most 64 of them their positions sit in a register.
 //   * decoder: refinement bits are stored as one dense bit plane per threshold (deposited under the
 //     LSP bitmask); magnitudes are assembled at the end for the values that were found.
 // One wavefront codes one chunk.  The bit stream of a set-partitioning coder is inherently ordered
@@ -82,7 +82,6 @@ k_outlier_scan(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uin
       if (PASS == 1) {
         const unsigned long long sgw = __ballot(f2 && ll >= 0);
         if (lane == 0) {
-          b.outMask[c * b.wordStride + w] = word;
           b.outPre[c * b.wordStride + w] = (uint32_t)__popcll(word);
           b.signMask[c * b.wordStride + w] = sgw;
         }
