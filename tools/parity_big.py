@@ -1,0 +1,32 @@
+"""One-off byte-parity checks at sizes the test suite leaves out (the oracle needs minutes):
+a 256^3 chunk in point-wise error mode, a 999 x 999 slice."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+from oracle.pyoracle import Oracle
+from sperr_amd.api import SperrHip
+from sperr_amd.synth import turbulence
+
+eng, o = SperrHip(), Oracle()
+v = turbulence((256, 256, 256))
+for tol in (1e-2, 1e-4):
+    t = time.time()
+    want = o.comp_3d(v, (256, 256, 256), 3, tol, nthreads=8)
+    got = bytes(eng.compress(torch.from_numpy(v).cuda(), (256, 256, 256), tol, mode=3).cpu().numpy())
+    dev = torch.from_numpy(np.frombuffer(want, dtype=np.uint8).copy()).cuda()
+    same = np.array_equal(eng.decompress(dev, True).cpu().numpy().view(np.uint32), o.decomp_3d(want, True).view(np.uint32))
+    print("256^3 PWE tol", tol, "bytes", len(want), "container identical:", got == want, "decode identical:", same,
+          "(%.0f s)" % (time.time() - t))
+img = turbulence((1, 999, 999))[0]
+for mode, q in ((2, 90.0), (3, 1e-3)):
+    want = o.comp_2d(img, mode, q, True)
+    got = bytes(eng.compress_2d(torch.from_numpy(img).cuda(), q, mode=mode, header=True).cpu().numpy())
+    dev = torch.from_numpy(np.frombuffer(want[10:], dtype=np.uint8).copy()).cuda()
+    same = np.array_equal(eng.decompress_2d(dev, (999, 999), False).cpu().numpy().view(np.uint64),
+                          o.decomp_2d(want[10:], (999, 999), False).view(np.uint64))
+    print("999x999 mode", mode, "bytes", len(want), "stream identical:", got == want, "decode identical:", same)
