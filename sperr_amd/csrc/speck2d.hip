@@ -207,46 +207,78 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
   };
 
   // encoder: largest msb inside each quadrant of a set (BR, BL, TR, TL as bytes 0..3), and the
-  // signs of quadrants that are single pixels
+  // signs of quadrants that are single pixels.  A set of at most 64 samples is loaded once --
+  // lane e holds sample (cbx + e % cblx, cby + e / cblx) -- and everything below it is answered
+  // from those registers; larger sets are scanned in memory.
   uint32_t scanKS = 0, scanKG = 0;
+  uint32_t cbx = 0, cby = 0, cblx = 0, cbly = 0;   // cached block (cblx == 0: none)
+  int vCM = -1;
+  uint32_t vCX = 0, vCY = 0, vCS = 0;
   auto scan_children = [&](uint32_t px, uint32_t py, uint32_t plx, uint32_t ply) {
     const uint32_t alx = plx - plx / 2, aly = ply - ply / 2;
     const uint32_t area = plx * ply;
     int m0 = -1, m1 = -1, m2 = -1, m3 = -1;
-    uint32_t sg = 0;
-    for (uint32_t i = 0; i < area; i += 64) {
-      const uint32_t e = i + lane;
-      if (e < area) {
-        const uint32_t x = e % plx, y = e / plx;
-        const uint32_t idx = (py + y) * dx + px + x;
-        const int m = msb[idx];
-        const uint32_t q = (x >= alx ? 1u : 0u) | (y >= aly ? 2u : 0u);   // TL 0, TR 1, BL 2, BR 3
-        if (q == 3)
-          m0 = max(m0, m);
-        else if (q == 2)
-          m1 = max(m1, m);
-        else if (q == 1)
-          m2 = max(m2, m);
+    if (area <= 64) {
+      const bool inside = cblx != 0 && px >= cbx && py >= cby && px + plx <= cbx + cblx && py + ply <= cby + cbly;
+      if (!inside) {
+        cbx = px;
+        cby = py;
+        cblx = plx;
+        cbly = ply;
+        vCM = -1;
+        vCS = 0;
+        vCX = px + lane % plx;
+        vCY = py + lane / plx;
+        if (lane < area) {
+          const uint32_t idx = vCY * dx + vCX;
+          vCM = msb[idx];
+          vCS = (uint32_t)((sign[idx >> 6] >> (idx & 63u)) & 1ull);
+        }
         else
-          m3 = max(m3, m);
-        if (area <= 64)
-          sg = (uint32_t)((sign[idx >> 6] >> (idx & 63u)) & 1ull);
+          vCX = 0xffffffffu;   // (never inside any set)
       }
+      const bool in = vCX >= px && vCX < px + plx && vCY >= py && vCY < py + ply;
+      const bool right = vCX >= px + alx, low = vCY >= py + aly;
+      m0 = wave_max(in && right && low ? vCM : -1);
+      m1 = wave_max(in && !right && low ? vCM : -1);
+      m2 = wave_max(in && right && !low ? vCM : -1);
+      m3 = wave_max(in && !right && !low ? vCM : -1);
+      // a quadrant of one pixel: BR at (alx, aly), BL at (0, aly), TR at (alx, 0), TL at (0, 0)
+      const uint64_t sb = __ballot(vCS != 0);
+      auto sign_at = [&](uint32_t x, uint32_t y) -> uint32_t {
+        if (x >= px + plx || y >= py + ply)
+          return 0u;
+        const uint32_t e = (y - cby) * cblx + (x - cbx);
+        return (uint32_t)((sb >> e) & 1ull);
+      };
+      scanKG = sign_at(px + alx, py + aly) | (sign_at(px, py + aly) << 1) | (sign_at(px + alx, py) << 2) |
+               (sign_at(px, py) << 3);
     }
-    m0 = wave_max(m0);
-    m1 = wave_max(m1);
-    m2 = wave_max(m2);
-    m3 = wave_max(m3);
+    else {
+      for (uint32_t i = 0; i < area; i += 64) {
+        const uint32_t e = i + lane;
+        if (e < area) {
+          const uint32_t x = e % plx, y = e / plx;
+          const int m = msb[(py + y) * dx + px + x];
+          const uint32_t q = (x >= alx ? 1u : 0u) | (y >= aly ? 2u : 0u);   // TL 0, TR 1, BL 2, BR 3
+          if (q == 3)
+            m0 = max(m0, m);
+          else if (q == 2)
+            m1 = max(m1, m);
+          else if (q == 1)
+            m2 = max(m2, m);
+          else
+            m3 = max(m3, m);
+        }
+      }
+      m0 = wave_max(m0);
+      m1 = wave_max(m1);
+      m2 = wave_max(m2);
+      m3 = wave_max(m3);
+      scanKG = 0;
+    }
     scanKS = rfl((uint32_t)(m0 & 0xff) | ((uint32_t)(m1 & 0xff) << 8) | ((uint32_t)(m2 & 0xff) << 16) |
                  ((uint32_t)(m3 & 0xff) << 24));
-    scanKG = 0;
-    if (area <= 64) {
-      // a quadrant of one pixel: BR at (alx, aly), BL at (0, aly), TR at (alx, 0), TL at (0, 0)
-      const uint64_t sb = __ballot(sg != 0);
-      const uint32_t eBR = aly * plx + alx, eBL = aly * plx, eTR = alx, eTL = 0;
-      scanKG = (uint32_t)((eBR < area ? (sb >> eBR) & 1ull : 0ull) | ((eBL < area ? (sb >> eBL) & 1ull : 0ull) << 1) |
-                          ((eTR < area ? (sb >> eTR) & 1ull : 0ull) << 2) | (((sb >> eTL) & 1ull) << 3));
-    }
   };
 
   // the recursion below one significant set (m_code_S, src/SPECK2D_INT.cpp:58-82): p = plane
