@@ -1675,6 +1675,37 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
     };
 
     while (sh_depth > 0) {
+      if (sh_depth == 1) {
+        // A window always starts at a significant entry: the insignificant entries in front of it
+        // (one '0' each) are counted off the stream without building tables.  In the sparse
+        // planes whole lists go this way.
+        __syncthreads();
+        if (tid == 0) {
+          uint64_t pos = sh_pos;
+          uint32_t rem = sh_rem, e = sh_e;
+          while (rem) {
+            const uint64_t wi = pos >> 6;
+            const uint32_t sh = (uint32_t)(pos & 63);
+            const uint64_t lo = wi < nwordsAvail ? words[wi] : 0ull;
+            const uint64_t hi = wi + 1 < nwordsAvail ? words[wi + 1] : 0ull;
+            const uint64_t bits = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+            const uint32_t z = min(bits ? (uint32_t)__ffsll((long long)bits) - 1u : 64u, rem);
+            pos += z;
+            e += z;
+            rem -= z;
+            if (z < 64)
+              break;   // (a '1' follows, or the list has ended)
+          }
+          sh_pos = pos;
+          sh_e = e;
+          sh_rem = rem;
+          if (rem == 0)
+            sh_depth = 0;
+        }
+        __syncthreads();
+        if (sh_depth == 0)
+          break;
+      }
       const uint64_t a = sh_pos;
       __syncthreads();  // everyone has read sh_pos / sh_depth before thread 0 changes them
       const uint64_t w0 = a >> 6;
