@@ -247,30 +247,15 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     return bit;
   };
 
-  // ---- encoder: number of outliers at or above the threshold before position x.  Inside a run
-  //      with at most 64 of them their positions sit in a register (lane i = i-th of the run), so
-  //      the whole recursion below such a run needs no memory access
-  uint32_t vWinPos = 0, vWinSgn = 0, winBase = 0, winCnt = 0;
+  // ---- encoder: number of outliers at or above the threshold before position x
   auto rank_mem = [&](uint32_t x) -> uint32_t {
     const uint32_t w = x >> 6;
     const uint32_t pre = cpos[w];
     const uint64_t m = maskGE[w];
     return rfl(pre + (uint32_t)__popcll(m & low_mask(x & 63u)));
   };
-  auto win_covers = [&](uint32_t a, uint32_t e) -> bool { return a >= winBase && e <= winBase + winCnt; };
-  auto win_load = [&](uint32_t a, uint32_t e) {   // e - a <= 64
-    winBase = a;
-    winCnt = e - a;
-    const bool in = lane < winCnt;
-    vWinPos = in ? posGE[a + lane] : 0xffffffffu;
-    vWinSgn = in ? (uint32_t)sgnGE[a + lane] : 0u;
-  };
   auto rank_in = [&](uint32_t x, uint32_t a, uint32_t e) -> uint32_t {   // a, e: counts at the run's ends
-    if (e == a)
-      return a;
-    if (win_covers(a, e))
-      return winBase + (uint32_t)__popcll(__ballot(lane < winCnt && vWinPos < x));
-    return rank_mem(x);
+    return e == a ? a : rank_mem(x);
   };
 
   uint32_t nfound = 0, lspDone = 0;   // decoder: values found so far / of them, already in the LSP mask
@@ -288,6 +273,169 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     }
     else
       err = 2;   // list storage exhausted (cannot happen with the host's bounds)
+  };
+
+  // ---- encoder: the whole expansion of a significant run that holds at most 64 outliers, by the
+  //      wave at once.  Lane i is the run's i-th outlier (all of them have their msb on this
+  //      plane).  Depth by depth the lanes follow their outlier down the halving tree; the lanes of
+  //      one node are contiguous, its first lane leads it.  Then, bottom-up, the bits every node's
+  //      expansion takes (E); top-down, where each expansion starts; the leaders set their node's
+  //      test bits and sign bits in an LDS bit buffer and hand the runs / pixels born
+  //      insignificant to the lists / the LIP in lane order, which is stream order.
+  constexpr int kWT = kO1MaxLevels + 2;
+  constexpr int kWTWords = 128;
+  __shared__ uint32_t wtL[ENC ? kWT : 1][64], wtS[ENC ? kWT : 1][64], wtO[ENC ? kWT : 1][64];
+  __shared__ uint16_t wtE[ENC ? kWT : 1][64];
+  __shared__ unsigned long long wtSide[ENC ? kWT : 1], wtLead[ENC ? kWT : 1];
+  __shared__ unsigned long long wtBits[ENC ? kWTWords : 1];
+  auto wave_tree = [&](uint32_t ns, uint32_t nl, uint32_t nlev, uint32_t a, uint32_t e) -> bool {
+    const uint32_t cnt = e - a;
+    const bool mine = lane < cnt;
+    const uint32_t pos = mine ? posGE[a + lane] : 0xffffffffu;
+    const uint32_t sgn = mine ? (uint32_t)sgnGE[a + lane] : 0u;
+    const uint64_t validMask = low_mask(cnt);
+    const uint64_t sgnMask = __ballot(sgn != 0);
+    // ---- structure, top-down
+    uint32_t S = ns, L = nl;
+    uint64_t lead = 1ull;
+    uint32_t D = 0;
+    for (;; D++) {
+      if (D >= (uint32_t)kWT)
+        return false;
+      wtS[D][lane] = S;
+      wtL[D][lane] = L;
+      const uint64_t alive = __ballot(mine && L > 1);
+      const uint32_t h0 = L - L / 2;
+      const bool side = mine && L > 1 && pos >= S + h0;
+      const uint64_t sideMask = __ballot(side);
+      if (lane == 0) {
+        wtLead[D] = lead;
+        wtSide[D] = sideMask;
+      }
+      if (alive == 0)
+        break;
+      lead |= sideMask & ~(sideMask << 1) & ~lead;
+      if (L > 1) {
+        if (side) {
+          S += h0;
+          L = L / 2;
+        }
+        else
+          L = h0;
+      }
+    }
+    __syncthreads();
+    // group of the node this lane leads at depth d
+    auto group = [&](uint32_t d, uint32_t& nLeft, uint32_t& nRight) -> bool {
+      const uint64_t lm = wtLead[d];
+      if (!mine || !((lm >> lane) & 1ull) || wtL[d][lane] <= 1)
+        return false;
+      const uint64_t above = lm & validMask & ~low_mask(lane + 1);
+      const uint32_t ge = above ? (uint32_t)__ffsll((long long)above) - 1u : cnt;
+      const uint64_t gm = low_mask(ge) & ~low_mask(lane);
+      nRight = (uint32_t)__popcll(wtSide[d] & gm);
+      nLeft = ge - lane - nRight;
+      return true;
+    };
+    // ---- expansion sizes, bottom-up
+    for (uint32_t d = D; d-- > 0;) {
+      uint32_t nLeft = 0, nRight = 0;
+      if (group(d, nLeft, nRight)) {
+        const uint32_t Ln = wtL[d][lane], h0 = Ln - Ln / 2, r0 = Ln / 2;
+        const uint32_t size0 = nLeft ? (h0 == 1 ? 1u : (uint32_t)wtE[d + 1][lane]) : 0u;
+        const uint32_t size1 = nRight ? (r0 == 1 ? 1u : (uint32_t)wtE[d + 1][lane + nLeft]) : 0u;
+        wtE[d][lane] = (uint16_t)(1u + size0 + (nLeft ? 1u : 0u) + size1);
+      }
+      __syncthreads();
+    }
+    const uint32_t total = wtE[0][0];
+    if (total + 64 > (uint32_t)kWTWords * 64)
+      return false;
+    for (uint32_t w = lane; w < (total + 63) / 64 + 1; w += 64)
+      wtBits[w] = 0ull;
+    if (lane == 0)
+      wtO[0][0] = 0;
+    __syncthreads();
+    auto setbit = [&](uint32_t x) { atomicOr(&wtBits[x >> 6], 1ull << (x & 63u)); };
+    // ---- offsets, bits and births, top-down
+    for (uint32_t d = 0; d < D; d++) {
+      uint32_t nLeft = 0, nRight = 0;
+      const bool leads = group(d, nLeft, nRight);
+      bool bornSet = false, bornPix = false;
+      uint32_t bs = 0, bl = 0;
+      if (leads) {
+        const uint32_t Ln = wtL[d][lane], Sn = wtS[d][lane], h0 = Ln - Ln / 2, r0 = Ln / 2;
+        const uint32_t O = wtO[d][lane];
+        uint32_t size0 = 0;
+        if (nLeft) {
+          setbit(O);
+          if (h0 == 1) {
+            size0 = 1;
+            if (sgn)
+              setbit(O + 1);
+          }
+          else {
+            size0 = wtE[d + 1][lane];
+            wtO[d + 1][lane] = O + 1;
+          }
+        }
+        else {   // the left half is born insignificant; the right one is significant by inference
+          bs = Sn;
+          bl = h0;
+          bornSet = h0 > 1;
+          bornPix = h0 == 1;
+        }
+        const uint32_t posB = O + 1 + size0;
+        const uint32_t c1 = posB + (nLeft ? 1u : 0u);
+        if (nRight) {
+          if (nLeft)
+            setbit(posB);
+          if (r0 == 1) {
+            if ((sgnMask >> (lane + nLeft)) & 1ull)
+              setbit(c1);
+          }
+          else
+            wtO[d + 1][lane + nLeft] = c1;
+        }
+        else {   // (coded, since the left half was significant) born insignificant
+          bs = Sn + h0;
+          bl = r0;
+          bornSet = r0 > 1;
+          bornPix = r0 == 1;
+        }
+      }
+      if (bornPix)
+        atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
+      const uint64_t bm = __ballot(bornSet);
+      if (bm) {
+        const uint32_t lvl = nlev + d + 1;
+        const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
+        const uint32_t nbn = (uint32_t)__popcll(bm);
+        if (lvl >= b.nlists || first + nbn > rdlane(vEnd, lvl))
+          err = 2;
+        else {
+          if (bornSet)
+            runs[first + (uint32_t)__popcll(bm & low_mask(lane))] = (uint64_t)bs | ((uint64_t)bl << 32);
+          wrlane(vCnt, lvl, have + nbn);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- the bit buffer goes into the stream
+    flush_acc();
+    for (uint32_t w = lane; w < (total + 63) / 64; w += 64) {
+      const uint64_t v = wtBits[w];
+      if (v) {
+        const uint64_t at = wpos + (uint64_t)w * 64;
+        const uint32_t sh = (uint32_t)(at & 63);
+        atomicOr(words + (at >> 6), (unsigned long long)(v << sh));
+        if (sh && (v >> (64 - sh)))
+          atomicOr(words + (at >> 6) + 1, (unsigned long long)(v >> (64 - sh)));
+      }
+    }
+    wpos += total;
+    __syncthreads();
+    return true;
   };
 
   // src/SPECK1D_INT.cpp:19-34 : the two halves of the array start on the list of level 1
@@ -332,7 +480,6 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
         }
         run += (uint32_t)__popcll(bm);
       }
-      winCnt = 0;
     }
     __threadfence_block();
     // ================= LIP pass (src/SPECK1D_INT_ENC.cpp:15-45, _DEC.cpp:15-45) =================
@@ -475,8 +622,9 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
             const uint32_t a0 = rdlane(myA, i), e0 = rdlane(myB, i);
             wrlane(vA, 0, a0);
             wrlane(vB, 0, e0);
-            if (e0 - a0 <= 64 && !win_covers(a0, e0))
-              win_load(a0, e0);
+            if (e0 - a0 <= 64 &&
+                wave_tree(rdlane((uint32_t)myRun, i), rdlane((uint32_t)(myRun >> 32), i), lev, a0, e0))
+              sp = 0;   // (the whole expansion is done)
           }
           i++;
           while (sp > 0) {
@@ -513,8 +661,8 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
                   sig = chi > clo;
                   put(sig);
                 }
-                if (sig)   // (its run has one outlier, so the register window holds it)
-                  put(win_covers(clo, chi) ? rdlane(vWinSgn, clo - winBase) : rfl((uint32_t)sgnGE[clo]));
+                if (sig)
+                  put(rfl((uint32_t)sgnGE[clo]));
               }
               else {
                 if (coded)
@@ -546,14 +694,14 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
               if (sig) {
                 nstate |= 1u << 8;
                 wrlane(vT, f, nstate);
+                if (ENC && chi - clo <= 64 && wave_tree(cs, cl, flev + 1, clo, chi))
+                  continue;   // (at most 64 outliers below: expanded by the wave at once)
                 wrlane(vS, sp, cs);
                 wrlane(vL, sp, cl);
                 wrlane(vT, sp, (flev + 1) << 16);
                 if (ENC) {
                   wrlane(vA, sp, clo);
                   wrlane(vB, sp, chi);
-                  if (chi - clo <= 64 && !win_covers(clo, chi))
-                    win_load(clo, chi);
                 }
                 sp++;
               }
