@@ -241,8 +241,17 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     const uint32_t sh = (uint32_t)(rpos & 63);
     return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
   };
+  // (bbuf: the next bn bits from rpos on; whoever moves rpos otherwise resets bn)
+  uint64_t bbuf = 0;
+  uint32_t bn = 0;
   auto get = [&]() -> uint32_t {
-    const uint32_t bit = (uint32_t)(window() & 1ull);
+    if (bn == 0) {
+      bbuf = window();
+      bn = 64;
+    }
+    const uint32_t bit = (uint32_t)(bbuf & 1ull);
+    bbuf >>= 1;
+    bn--;
     rpos++;
     return bit;
   };
@@ -438,11 +447,87 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     return true;
   };
 
+  // ---- decoder: the recursion below one significant run (m_code_S), written as a descent with a
+  //      stack of the right halves that still wait for their test bit: a '1' goes down the left
+  //      half and parks the right one, a '0' hands the left half to its list (or the LIP) and goes
+  //      down the right half, which is then significant without a test bit
+  auto found_pixel = [&](uint32_t idx, int p) {
+    const uint32_t sg = get();
+    if (nfound < b.kStride && lane == 0) {
+      fpos[nfound] = idx;
+      fmeta[nfound] = (uint8_t)((uint32_t)p | (sg << 7));
+    }
+    nfound++;
+  };
+  int curPlane = 0;
+  auto expand_dec = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {
+    uint32_t sp = 0;
+    while (true) {
+      const uint32_t h0 = nl - nl / 2, r0 = nl / 2;
+      bool atPixel = false;
+      if (get()) {
+        wrlane(vS, sp, ns + h0);
+        wrlane(vL, sp, r0);
+        wrlane(vT, sp, nlev + 1);
+        sp++;
+        if (h0 == 1) {
+          found_pixel(ns, curPlane);
+          atPixel = true;
+        }
+        else {
+          nl = h0;
+          nlev++;
+        }
+      }
+      else {
+        if (h0 == 1)
+          lip_set(ns);
+        else
+          list_push(nlev + 1, ns, h0);
+        if (r0 == 1) {
+          found_pixel(ns + h0, curPlane);
+          atPixel = true;
+        }
+        else {
+          ns += h0;
+          nl = r0;
+          nlev++;
+        }
+      }
+      if (!atPixel)
+        continue;
+      // back up: the parked right halves, innermost first
+      bool down = false;
+      while (sp > 0) {
+        sp--;
+        const uint32_t rs = rdlane(vS, sp), rl = rdlane(vL, sp), rlev = rdlane(vT, sp);
+        if (get()) {
+          if (rl == 1) {
+            found_pixel(rs, curPlane);
+            continue;
+          }
+          ns = rs;
+          nl = rl;
+          nlev = rlev;
+          down = true;
+          break;
+        }
+        if (rl == 1)
+          lip_set(rs);
+        else
+          list_push(rlev, rs, rl);
+      }
+      if (!down)
+        break;
+    }
+  };
+
   // src/SPECK1D_INT.cpp:19-34 : the two halves of the array start on the list of level 1
   list_push(1, 0, N - N / 2);
   list_push(1, N - N / 2, N / 2);
 
   for (int p = nbp - 1; p >= 0; p--) {
+    curPlane = p;
     if (ENC) {
       // ---- this plane's threshold structures: EQ = outliers whose msb is p, GE = at or above
       for (uint32_t w = lane; w < nw; w += 64)
@@ -603,6 +688,7 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
               skip_zeros(z);
             else
               rpos += z;
+              bn = 0;
             i += z;
           }
           if (i >= blockN)
@@ -612,8 +698,13 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
           // entry i is significant: its '1', then the recursion (m_code_S)
           if (ENC)
             put(1);
-          else
+          else {
             rpos++;
+            bn = 0;
+            expand_dec(rdlane((uint32_t)myRun, i), rdlane((uint32_t)(myRun >> 32), i), lev);
+            i++;
+            continue;
+          }
           uint32_t sp = 1;
           wrlane(vS, 0, rdlane((uint32_t)myRun, i));
           wrlane(vL, 0, rdlane((uint32_t)(myRun >> 32), i));
@@ -756,6 +847,7 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
           pb[w] = res;
         }
         rpos += rdlane(inc, 63);
+        bn = 0;
       }
       // the values found in this plane join the LSP (SPECK_INT.cpp:462-468)
       __threadfence_block();
