@@ -272,16 +272,17 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     if (lane == 0)
       atomicOr(reinterpret_cast<unsigned long long*>(lip) + (x >> 6), 1ull << (x & 63u));
   };
+  // (the bookkeeping of level `lev` sits in lane `lev`: that lane does the append itself)
+  uint32_t vErr = 0;
   auto list_push = [&](uint32_t lev, uint32_t start, uint32_t len) {
-    const uint32_t idx = rdlane(vCnt, lev);
-    const uint32_t slot = rdlane(vOff, lev) + idx;
-    if (slot < rdlane(vEnd, lev)) {
-      if (lane == 0)
-        runs[slot] = (uint64_t)start | ((uint64_t)len << 32);
-      wrlane(vCnt, lev, idx + 1);
+    if (lane == lev) {
+      if (vOff + vCnt < vEnd) {
+        runs[vOff + vCnt] = (uint64_t)start | ((uint64_t)len << 32);
+        vCnt++;
+      }
+      else
+        vErr = 2;   // list storage exhausted (cannot happen with the host's bounds)
     }
-    else
-      err = 2;   // list storage exhausted (cannot happen with the host's bounds)
   };
 
   // ---- encoder: the whole expansion of a significant run that holds at most 64 outliers, by the
@@ -860,6 +861,8 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     }
   }
 
+  if (__any(vErr != 0))
+    err = 2;
   if (ENC) {
     flush_acc();
     if (lane == 0) {
