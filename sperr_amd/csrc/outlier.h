@@ -47,6 +47,7 @@ struct OutlierBufs {
   uint8_t* msb;                  // encoder: msb of every magnitude
   uint32_t* posGE;               // encoder, per plane: positions / signs of the outliers at or
   uint8_t* sgnGE;                //   above the threshold, in order
+  uint32_t singleMax;            // decoder: runs up to this length are tried as single-outlier paths
   uint32_t nlists;               // LIS levels (src/SPECK1D_INT.cpp:19-34)
   uint32_t levelOff[kO1MaxLevels + 1];   // first entry of each level inside a chunk's list storage
   size_t runStride;

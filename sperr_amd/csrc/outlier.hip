@@ -461,12 +461,78 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     nfound++;
   };
   int curPlane = 0;
+  // Most significant runs hold a single outlier.  Their code is a plain path: one bit per level
+  // ('1' = it lies in the left half, whose right sibling then gets a closing '0' on the way back;
+  // '0' = in the right half, the left sibling is born at once), the sign, then the closing zeros.
+  // single_path() reads that shape off the next 64 stream bits: if the closing bits are all zero
+  // the parse is what the general walk would have done, and the siblings -- exactly one per level,
+  // so their mutual order does not matter -- are appended by the lanes that keep their levels'
+  // lists, all at once.  Anything else is left to the general walk.
+  uint32_t vSibS = 0, vSibL = 0;
+  const uint32_t kSingleMax = b.singleMax;
+  auto single_path = [&](uint32_t ns, uint32_t nl, uint32_t nlev) -> bool {
+    const uint64_t peek = window();
+    uint32_t t = 0, lefts = 0, s0 = ns, l0 = nl, lv = nlev, pixel = 0;
+    for (;;) {
+      if (t >= 40 || lv + 1 >= 64)
+        return false;
+      const uint32_t bit = (uint32_t)(peek >> t) & 1u;
+      t++;
+      const uint32_t h0 = l0 - l0 / 2, r0 = l0 / 2;
+      lv++;
+      if (bit) {
+        wrlane(vSibS, lv, s0 + h0);
+        wrlane(vSibL, lv, r0);
+        lefts++;
+        if (h0 == 1) {
+          pixel = s0;
+          break;
+        }
+        l0 = h0;
+      }
+      else {
+        wrlane(vSibS, lv, s0);
+        wrlane(vSibL, lv, h0);
+        if (r0 == 1) {
+          pixel = s0 + h0;
+          break;
+        }
+        s0 += h0;
+        l0 = r0;
+      }
+    }
+    const uint32_t sg = (uint32_t)(peek >> t) & 1u;
+    t++;
+    if (t + lefts > 64 || ((peek >> t) & low_mask(lefts)) != 0)
+      return false;
+    // commit
+    rpos += t + lefts;
+    bn = 0;
+    if (nfound < b.kStride && lane == 0) {
+      fpos[nfound] = pixel;
+      fmeta[nfound] = (uint8_t)((uint32_t)curPlane | (sg << 7));
+    }
+    nfound++;
+    if (lane > nlev && lane <= lv) {   // the sibling born on level `lane`
+      if (vSibL == 1)
+        atomicOr(reinterpret_cast<unsigned long long*>(lip) + (vSibS >> 6), 1ull << (vSibS & 63u));
+      else if (vOff + vCnt < vEnd) {
+        runs[vOff + vCnt] = (uint64_t)vSibS | ((uint64_t)vSibL << 32);
+        vCnt++;
+      }
+      else
+        vErr = 2;
+    }
+    return true;
+  };
   auto expand_dec = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {
     uint32_t sp = 0;
     while (true) {
       const uint32_t h0 = nl - nl / 2, r0 = nl / 2;
       bool atPixel = false;
-      if (get()) {
+      if (nl <= kSingleMax && single_path(ns, nl, nlev))   // (longer runs rarely hold just one outlier)
+        atPixel = true;
+      else if (get()) {
         wrlane(vS, sp, ns + h0);
         wrlane(vL, sp, r0);
         wrlane(vT, sp, nlev + 1);
@@ -1004,9 +1070,12 @@ int launch_outlier_stream_out(hipStream_t st, const OutlierBufs& b, const uint32
   return 0;
 }
 
-int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b, const uint8_t* container,
+int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b_, const uint8_t* container,
                           const CoderState* cst, double* vals, size_t valsStride)
 {
+  OutlierBufs b = b_;
+  static const uint32_t singleMax = getenv("SPERR_HIP_SINGLE_MAX") ? (uint32_t)atoi(getenv("SPERR_HIP_SINGLE_MAX")) : 64u;
+  b.singleMax = singleMax;
   const uint32_t blocks =
       capped_blocks((uint32_t)((b.streamStride + kThreads - 1) / kThreads), b.nchunks);
   LAUNCH_K(k_outlier_stream_in, dim3(blocks, b.nchunks), dim3(kThreads), 0, st, b, container);
