@@ -16,6 +16,7 @@ struct Speck2dBufs {
   uint32_t dx, dy, N, nw;        // dims < 65536 each; nw = mask words
   uint32_t nxforms;              // transform levels = level of the root set (SPECK2D_INT.cpp:200-207)
   uint32_t nlists;
+  uint32_t wbMin;                // encoder: sets of at least this many (and at most 64) samples are expanded by the wave at once
   uint32_t levelOff[kS2MaxLevels + 1];   // list storage: first entry of every level
   uint64_t* runs;                // sx | sy << 16 | lx << 32 | ly << 48
   int8_t* sval;                  // encoder: msb of the largest coefficient inside

@@ -281,6 +281,190 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
                  ((uint32_t)(m3 & 0xff) << 24));
   };
 
+  // ---- encoder: the whole expansion of a significant set of at most 64 samples, by the wave at
+  //      once (cf. wave_tree in outlier.hip).  Lane e is sample (px + e % plx, py + e / plx).
+  //      Depth by depth every lane moves into the quadrant that holds its sample; the lane of a
+  //      node's top-left sample leads the node.  The nodes' largest msb come from LDS atomics, the
+  //      bits every significant node's expansion takes (E) bottom-up, the places of the expansions
+  //      top-down; the leaders set their children's test and sign bits in an LDS bit buffer, hand
+  //      single pixels born insignificant to the LIP, and sets born insignificant to the lists in
+  //      the order of their test bits, which is stream order.
+  constexpr int kWB = 8;   // depths of a 64-sample set: at most 7
+  __shared__ uint32_t wbRect[ENC ? kWB : 1][64], wbE[ENC ? kWB : 1][64], wbO[ENC ? kWB : 1][64];
+  __shared__ uint32_t wbBorn[ENC ? kWB : 1][64];
+  __shared__ int wbMax[ENC ? kWB : 1][64];
+  __shared__ unsigned long long wbBits[ENC ? 64 : 1], wbRank[ENC ? 64 : 1];
+  auto wave_block = [&](uint32_t px, uint32_t py, uint32_t plx, uint32_t ply, uint32_t plev, int p) -> bool {
+    const uint32_t area = plx * ply;
+    const bool mine = lane < area;
+    const uint32_t ex = mine ? lane % plx : 0u, ey = mine ? lane / plx : 0u;
+    int m = -1;
+    uint32_t sg = 0;
+    if (mine) {
+      const uint32_t idx = (py + ey) * dx + px + ex;
+      m = msb[idx];
+      sg = (uint32_t)((sign[idx >> 6] >> (idx & 63u)) & 1ull);
+    }
+    const uint64_t sgnMask = __ballot(sg != 0);
+    // ---- structure: my node at every depth (relative rectangle x | y << 8 | lx << 16 | ly << 24)
+    uint32_t rx = 0, ry = 0, rlx = plx, rly = ply, D = 0;
+    for (;; D++) {
+      if (D >= (uint32_t)kWB)
+        return false;
+      wbRect[D][lane] = rx | (ry << 8) | (rlx << 16) | (rly << 24);
+      wbMax[D][lane] = -1;
+      wbO[D][lane] = 0;
+      wbBorn[D][lane] = 0;
+      wbE[D][lane] = 0;
+      if (__ballot(mine && rlx * rly > 1) == 0)
+        break;
+      if (rlx * rly > 1) {
+        const uint32_t dlx = rlx / 2, dly = rly / 2, alx = rlx - dlx, aly = rly - dly;
+        const bool right = ex >= rx + alx, low = ey >= ry + aly;
+        rx += right ? alx : 0u;
+        rlx = right ? dlx : alx;
+        ry += low ? aly : 0u;
+        rly = low ? dly : aly;
+      }
+    }
+    __syncthreads();
+    for (uint32_t d = 0; d <= D; d++)
+      if (mine) {
+        const uint32_t r = wbRect[d][lane];
+        atomicMax(&wbMax[d][((r >> 8) & 0xffu) * plx + (r & 0xffu)], m);
+      }
+    __syncthreads();
+    // children of the node (rx, ry, rlx, rly) in the coder's order BR, BL, TR, TL
+    auto child = [&](uint32_t r, int k, uint32_t& cx, uint32_t& cy, uint32_t& clx, uint32_t& cly) {
+      const uint32_t x0 = r & 0xffu, y0 = (r >> 8) & 0xffu, lx = (r >> 16) & 0xffu, ly = r >> 24;
+      const uint32_t dlx = lx / 2, dly = ly / 2, alx = lx - dlx, aly = ly - dly;
+      cx = (k == 0 || k == 2) ? x0 + alx : x0;
+      cy = (k <= 1) ? y0 + aly : y0;
+      clx = (k == 0 || k == 2) ? dlx : alx;
+      cly = (k <= 1) ? dly : aly;
+    };
+    auto leads = [&](uint32_t d, uint32_t& r) -> bool {   // a significant set led by this lane
+      if (!mine)
+        return false;
+      r = wbRect[d][lane];
+      const uint32_t lx = (r >> 16) & 0xffu, ly = r >> 24;
+      return (r & 0xffu) == ex && ((r >> 8) & 0xffu) == ey && lx * ly > 1 && wbMax[d][lane] == p;
+    };
+    // ---- expansion sizes, bottom-up
+    for (uint32_t d = D; d-- > 0;) {
+      uint32_t r;
+      if (leads(d, r)) {
+        uint32_t E = 0, found = 0;
+        for (int k = 0; k < 4; k++) {
+          uint32_t cx, cy, clx, cly;
+          child(r, k, cx, cy, clx, cly);
+          if (clx == 0 || cly == 0)
+            continue;
+          const uint32_t q = cy * plx + cx;
+          const bool sig = wbMax[d + 1][q] == p;
+          E += (found || k != 3) ? 1u : 0u;
+          if (sig) {
+            E += (clx * cly == 1) ? 1u : wbE[d + 1][q];
+            found = 1;
+          }
+        }
+        wbE[d][lane] = E;
+      }
+      __syncthreads();
+    }
+    const uint32_t total = wbE[0][0];
+    if (total + 64 > 64u * 64u)
+      return false;
+    for (uint32_t w = lane; w < (total + 63) / 64 + 1; w += 64)
+      wbBits[w] = 0ull;
+    if (lane == 0)
+      wbO[0][0] = 1;   // (offset + 1; 0 = the node is not reached)
+    __syncthreads();
+    auto setbit = [&](uint32_t x) { atomicOr(&wbBits[x >> 6], 1ull << (x & 63u)); };
+    // ---- places, bits and births, top-down
+    for (uint32_t d = 0; d < D; d++) {
+      uint32_t r;
+      if (leads(d, r) && wbO[d][lane] != 0) {
+        uint32_t o = wbO[d][lane] - 1, found = 0;
+        for (int k = 0; k < 4; k++) {
+          uint32_t cx, cy, clx, cly;
+          child(r, k, cx, cy, clx, cly);
+          if (clx == 0 || cly == 0)
+            continue;
+          const uint32_t q = cy * plx + cx;
+          const bool sig = wbMax[d + 1][q] == p, pixel = clx * cly == 1;
+          const bool coded = found || k != 3;
+          if (coded) {
+            if (sig)
+              setbit(o);
+            else if (!pixel)
+              wbBorn[d + 1][q] = o + 1;   // (ranked by the place of its test bit)
+            o++;
+          }
+          if (sig) {
+            found = 1;
+            if (pixel) {
+              if ((sgnMask >> q) & 1ull)
+                setbit(o);
+              o++;
+            }
+            else {
+              wbO[d + 1][q] = o + 1;
+              o += wbE[d + 1][q];
+            }
+          }
+          else if (pixel) {
+            const uint32_t idx = (py + cy) * dx + px + cx;
+            atomicOr(lip + (idx >> 6), 1ull << (idx & 63u));
+          }
+        }
+      }
+      for (uint32_t w = lane; w < (total + 63) / 64 + 1; w += 64)
+        wbRank[w] = 0ull;
+      __syncthreads();
+      const uint32_t bo = mine ? wbBorn[d + 1][lane] : 0u;
+      if (bo)
+        atomicOr(&wbRank[(bo - 1) >> 6], 1ull << ((bo - 1) & 63u));
+      __syncthreads();
+      const uint64_t bm = __ballot(bo != 0);
+      if (bm) {
+        const uint32_t lvl = plev + d + 1;
+        const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
+        const uint32_t nbn = (uint32_t)__popcll(bm);
+        if (lvl >= b.nlists || first + nbn > rdlane(vEnd, lvl))
+          err = 2;
+        else {
+          if (bo) {
+            uint32_t rank = (uint32_t)__popcll(wbRank[(bo - 1) >> 6] & low_mask((bo - 1) & 63u));
+            for (uint32_t w = 0; w < ((bo - 1) >> 6); w++)
+              rank += (uint32_t)__popcll(wbRank[w]);
+            const uint32_t cr = wbRect[d + 1][lane];
+            const uint32_t ax = px + (cr & 0xffu), ay = py + ((cr >> 8) & 0xffu);
+            runs[first + rank] = (uint64_t)(ax | (ay << 16)) | ((uint64_t)(((cr >> 16) & 0xffu) | ((cr >> 24) << 16)) << 32);
+            sval[first + rank] = (int8_t)wbMax[d + 1][lane];
+          }
+          wrlane(vCnt, lvl, have + nbn);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- the bit buffer goes into the stream
+    flush_acc();
+    for (uint32_t w = lane; w < (total + 63) / 64; w += 64) {
+      const uint64_t v = wbBits[w];
+      if (v) {
+        const uint64_t at = wpos + (uint64_t)w * 64;
+        const uint32_t sh = (uint32_t)(at & 63);
+        atomicOr(words + (at >> 6), (unsigned long long)(v << sh));
+        if (sh && (v >> (64 - sh)))
+          atomicOr(words + (at >> 6) + 1, (unsigned long long)(v >> (64 - sh)));
+      }
+    }
+    wpos += total;
+    __syncthreads();
+    return true;
+  };
+
   // the recursion below one significant set (m_code_S, src/SPECK2D_INT.cpp:58-82): p = plane
   auto expand = [&](uint32_t rlo, uint32_t rhi, uint32_t lev, int p) {
     uint32_t sp = 1;
@@ -288,6 +472,9 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
     wrlane(vRhi, 0, rhi);
     wrlane(vT, 0, lev << 16);
     if (ENC) {
+      if ((rhi & 0xffffu) * (rhi >> 16) <= 64 && (rhi & 0xffffu) * (rhi >> 16) >= b.wbMin &&
+          wave_block(rlo & 0xffffu, rlo >> 16, rhi & 0xffffu, rhi >> 16, lev, p))
+        return;
       scan_children(rlo & 0xffffu, rlo >> 16, rhi & 0xffffu, rhi >> 16);
       wrlane(vKS, 0, scanKS);
       wrlane(vKG, 0, scanKG);
@@ -349,6 +536,8 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
         if (sig) {
           nstate |= 1u << 8;
           wrlane(vT, f, nstate);
+          if (ENC && clx * cly <= 64 && clx * cly >= b.wbMin && wave_block(cx, cy, clx, cly, flev + 1, p))
+            continue;   // (at most 64 samples: expanded by the wave at once)
           wrlane(vRlo, sp, crlo);
           wrlane(vRhi, sp, crhi);
           wrlane(vT, sp, (flev + 1) << 16);
@@ -619,14 +808,12 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
           }
           if ((size_t)w * 64 + 64 > N)
             in &= low_mask(N - w * 64);
-          if (in) {
+          if (in) {   // the word's 64 coefficients in one sweep (the buffer is padded past N)
             const CT* cp = coef + (size_t)w * 64;
-            uint64_t m = in;
-            while (m) {
-              const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
-              m &= m - 1;
+#pragma unroll
+            for (int j = 0; j < 64; j++)
               bits |= (uint64_t)((cp[j] >> p) & (CT)1) << j;
-            }
+            bits &= in;
           }
         }
         // compress the bits of the word under its mask
@@ -674,20 +861,28 @@ k_speck2d(Speck2dBufs b, uint64_t budget, uint64_t raw_budget, int rate_mode, in
             const uint32_t sh = (uint32_t)(at & 63);
             const uint64_t a = word_at(at >> 6), d = word_at((at >> 6) + 1);
             uint64_t bits = sh ? (a >> sh) | (d << (64 - sh)) : a;
+            // the word's 64 coefficients in one sweep: sample j takes bit rank(j) of `bits`, as
+            // long as the stream has not run out (the buffer is padded past N)
             CT* cp = coef + (size_t)w * 64;
-            uint64_t m = sw;
-            uint64_t t = first;
-            while (m && t < left) {
-              const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
-              m &= m - 1;
-              const bool one = bits & 1ull;
-              bits >>= 1;
-              t++;
-              if (p >= 1)
-                cp[j] = one ? cp[j] + half : cp[j] - half;
-              else if (one)
-                cp[j] = cp[j] + 1;
+            CT cv[64];
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+              cv[j] = cp[j];
+            const uint64_t room = left - first;   // >= 1
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+              const uint32_t rk = (uint32_t)__popcll(sw & low_mask((uint32_t)j));
+              if (((sw >> j) & 1ull) && rk < room) {
+                const bool one = (bits >> rk) & 1ull;
+                if (p >= 1)
+                  cv[j] = one ? cv[j] + half : cv[j] - half;
+                else if (one)
+                  cv[j] = cv[j] + 1;
+              }
             }
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+              cp[j] = cv[j];
           }
         }
         const uint32_t total = rdlane(inc, 63);
@@ -743,9 +938,12 @@ size_t speck2d_list_entries(Speck2dBufs& b)
   return (size_t)off + 64;
 }
 
-int launch_speck2d_encode(hipStream_t st, const Speck2dBufs& b, uint64_t raw_budget, bool rate_mode,
+int launch_speck2d_encode(hipStream_t st, const Speck2dBufs& b_, uint64_t raw_budget, bool rate_mode,
                           bool wide_pass)
 {
+  Speck2dBufs b = b_;
+  static const uint32_t wbMin = getenv("SPERR_HIP_WB_MIN") ? (uint32_t)atoi(getenv("SPERR_HIP_WB_MIN")) : 4u;
+  b.wbMin = wbMin;
   uint64_t budget = ~0ull;
   if (raw_budget != 0) {  // SPECK_INT.cpp:48-58
     budget = raw_budget;
