@@ -184,9 +184,8 @@ size_t round_up(size_t v, size_t m)
 using Dims = std::array<size_t, 3>;
 
 // src/sperr_helper.cpp:542-592
-std::vector<std::array<size_t, 6>> chunk_volume(const Dims& vol, const Dims& chunk)
+static void chunk_segments(const Dims& vol, const Dims& chunk, size_t nseg[3])
 {
-  size_t nseg[3];
   for (int a = 0; a < 3; a++) {
     nseg[a] = vol[a] / chunk[a];
     if (vol[a] % chunk[a] > chunk[a] / 2)
@@ -194,6 +193,25 @@ std::vector<std::array<size_t, 6>> chunk_volume(const Dims& vol, const Dims& chu
     if (nseg[a] == 0)
       nseg[a] = 1;
   }
+}
+
+// how many chunks chunk_volume would list, SIZE_MAX if that does not fit (dimensions read from a
+// container header are checked against the container's length with this before anything is sized)
+size_t chunk_count(const Dims& vol, const Dims& chunk)
+{
+  size_t nseg[3];
+  chunk_segments(vol, chunk, nseg);
+  unsigned __int128 n = (unsigned __int128)nseg[0] * nseg[1];
+  if (n > SIZE_MAX)
+    return SIZE_MAX;
+  n *= nseg[2];
+  return n > SIZE_MAX ? SIZE_MAX : (size_t)n;
+}
+
+std::vector<std::array<size_t, 6>> chunk_volume(const Dims& vol, const Dims& chunk)
+{
+  size_t nseg[3];
+  chunk_segments(vol, chunk, nseg);
   std::vector<std::array<size_t, 6>> out;
   out.reserve(nseg[0] * nseg[1] * nseg[2]);
   for (size_t z = 0; z < nseg[2]; z++)
@@ -278,6 +296,13 @@ struct Blob {  // host-side staging of all tables of a plan, uploaded in one cop
 
 int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
 {
+  // set coordinates are packed 16 bits per axis (speck_tree.h pack_node), sample indices are 32 bits
+  const unsigned __int128 samples = (unsigned __int128)dx * dy * dz;
+  if (dx == 0 || dy == 0 || dz == 0 || dx > 0xffff || dy > 0xffff || dz > 0xffff || samples > (1ull << 31)) {
+    fprintf(stderr, "[sperr_hip] chunk of %zu x %zu x %zu not supported (at most 65535 per axis, 2^31 samples)\n",
+            dx, dy, dz);
+    return -1;
+  }
   P.dims[0] = (uint32_t)dx;
   P.dims[1] = (uint32_t)dy;
   P.dims[2] = (uint32_t)dz;
@@ -1358,7 +1383,11 @@ int parse_container_host(const uint8_t* h, size_t hlen, size_t total_len, Contai
   for (int a = 0; a < 3; a++)
     if (ci.vol[a] == 0 || ci.chunk[a] == 0)
       return -1;
-  const size_t nchunks = chunk_volume(ci.vol, ci.chunk).size();
+  // every chunk has a 4-byte length in the header: a damaged header must not make us list more
+  // chunks than the container could hold
+  const size_t nchunks = chunk_count(ci.vol, ci.chunk);
+  if (nchunks > (total_len - pos) / 4)
+    return -1;
   const size_t hdr = pos + 4 * nchunks;
   if (hlen < hdr) {
     *need = hdr;
@@ -1996,6 +2025,26 @@ __global__ void k_fake_condi_header(uint8_t* dst)
 // ==========================================================================================
 using namespace sperrhip;
 
+// nothing thrown by the host side (std::bad_alloc of a vector, std::system_error of a thread)
+// may cross the C boundary
+template <typename F>
+static int guarded(const char* what, F&& body) noexcept
+{
+  try {
+    return body();
+  }
+  catch (const std::bad_alloc&) {
+    fprintf(stderr, "[sperr_hip] %s: out of host memory\n", what);
+  }
+  catch (const std::exception& e) {
+    fprintf(stderr, "[sperr_hip] %s: %s\n", what, e.what());
+  }
+  catch (...) {
+    fprintf(stderr, "[sperr_hip] %s: unknown exception\n", what);
+  }
+  return -1;
+}
+
 extern "C" {
 
 const char* sperrhip_version(void)
@@ -2024,23 +2073,27 @@ void sperrhip_profile_reset(void)
 }
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap)
 {
-  return sperrhip_profile_get2(names, millis, nullptr, launches, cap);
+  return guarded("sperrhip_profile_get", [&]() -> int {
+    return sperrhip_profile_get2(names, millis, nullptr, launches, cap);
+  });
 }
 int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_millis, int* launches,
                           int cap)
 {
-  int i = 0;
-  for (auto& kv : g_prof.acc) {
-    if (i < cap) {
-      names[i] = kv.first.c_str();
-      busy_millis[i] = kv.second.busy;
-      if (sum_millis)
-        sum_millis[i] = kv.second.ms;
-      launches[i] = kv.second.launches;
+  return guarded("sperrhip_profile_get2", [&]() -> int {
+    int i = 0;
+    for (auto& kv : g_prof.acc) {
+      if (i < cap) {
+        names[i] = kv.first.c_str();
+        busy_millis[i] = kv.second.busy;
+        if (sum_millis)
+          sum_millis[i] = kv.second.ms;
+        launches[i] = kv.second.launches;
+      }
+      i++;
     }
-    i++;
-  }
-  return i;
+    return i;
+  });
 }
 
 size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x,
@@ -2069,119 +2122,129 @@ int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t d
                           size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
                           void* d_dst, size_t dst_cap, size_t* dst_len, void* hip_stream)
 {
-  if (quality <= 0.0)
-    return 2;
-  if (mode < 1 || mode > 3)
-    return 2;
-  if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
-    return -1;
-  const Dims vol{dimx, dimy, dimz}, ch{chunk_x, chunk_y, chunk_z};
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (is_float)
-    return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, mode, quality,
-                                static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
-  return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, mode, quality,
-                               static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
+  return guarded("sperrhip_compress_dev", [&]() -> int {
+    if (quality <= 0.0)
+      return 2;
+    if (mode < 1 || mode > 3)
+      return 2;
+    if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
+      return -1;
+    const Dims vol{dimx, dimy, dimz}, ch{chunk_x, chunk_y, chunk_z};
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (is_float)
+      return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, mode, quality,
+                                  static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
+    return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, mode, quality,
+                                 static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
+  });
 }
 
 int sperrhip_parse_header_dev(const void* d_src, size_t src_len, size_t* dimx, size_t* dimy,
                               size_t* dimz, int* is_float, size_t* chunk_x, size_t* chunk_y,
                               size_t* chunk_z)
 {
-  std::lock_guard<std::mutex> lock(g_engine.mu);
-  if (g_engine.init())
-    return -1;
-  ContainerInfo ci;
-  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, nullptr))
-    return -1;
-  *dimx = ci.vol[0];
-  *dimy = ci.vol[1];
-  *dimz = ci.vol[2];
-  *is_float = ci.is_float ? 1 : 0;
-  if (chunk_x)
-    *chunk_x = ci.chunk[0];
-  if (chunk_y)
-    *chunk_y = ci.chunk[1];
-  if (chunk_z)
-    *chunk_z = ci.chunk[2];
-  return 0;
+  return guarded("sperrhip_parse_header_dev", [&]() -> int {
+    std::lock_guard<std::mutex> lock(g_engine.mu);
+    if (g_engine.init())
+      return -1;
+    ContainerInfo ci;
+    if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, nullptr))
+      return -1;
+    *dimx = ci.vol[0];
+    *dimy = ci.vol[1];
+    *dimz = ci.vol[2];
+    *is_float = ci.is_float ? 1 : 0;
+    if (chunk_x)
+      *chunk_x = ci.chunk[0];
+    if (chunk_y)
+      *chunk_y = ci.chunk[1];
+    if (chunk_z)
+      *chunk_z = ci.chunk[2];
+    return 0;
+  });
 }
 
 int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float, void* d_dst,
                             size_t dst_cap_bytes, size_t* dimx, size_t* dimy, size_t* dimz,
                             void* hip_stream)
 {
-  if (!d_src || !d_dst)
-    return -1;
-  std::lock_guard<std::mutex> lock(g_engine.mu);
-  if (g_engine.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ContainerInfo ci;
-  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
-    return -1;
-  if (dimx)
-    *dimx = ci.vol[0];
-  if (dimy)
-    *dimy = ci.vol[1];
-  if (dimz)
-    *dimz = ci.vol[2];
-  if (output_float)
-    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
-                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st);
-  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
-                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
-                                 st);
+  return guarded("sperrhip_decompress_dev", [&]() -> int {
+    if (!d_src || !d_dst)
+      return -1;
+    std::lock_guard<std::mutex> lock(g_engine.mu);
+    if (g_engine.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ContainerInfo ci;
+    if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
+      return -1;
+    if (dimx)
+      *dimx = ci.vol[0];
+    if (dimy)
+      *dimy = ci.vol[1];
+    if (dimz)
+      *dimz = ci.vol[2];
+    if (output_float)
+      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                    static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st);
+    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                   static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
+                                   st);
+  });
 }
 
 int sperrhip_multires_levels(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x, size_t chunk_y,
                              size_t chunk_z, size_t* nlev, size_t* level_dims)
 {
-  const Dims vol{dimx, dimy, dimz};
-  Dims cd{chunk_x, chunk_y, chunk_z};
-  if (!nlev || dimx == 0 || dimy == 0 || dimz == 0)
-    return -1;
-  for (int a = 0; a < 3; a++)
-    cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
-  MultiRes m;
-  multires_levels(vol, cd, m);
-  *nlev = m.nlev;
-  if (level_dims)
-    for (size_t h = 0; h < m.nlev; h++)
-      for (int a = 0; a < 3; a++)
-        level_dims[3 * h + a] = (size_t)m.cres[h][a] * m.grid[a];
-  return 0;
+  return guarded("sperrhip_multires_levels", [&]() -> int {
+    const Dims vol{dimx, dimy, dimz};
+    Dims cd{chunk_x, chunk_y, chunk_z};
+    if (!nlev || dimx == 0 || dimy == 0 || dimz == 0)
+      return -1;
+    for (int a = 0; a < 3; a++)
+      cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
+    MultiRes m;
+    multires_levels(vol, cd, m);
+    *nlev = m.nlev;
+    if (level_dims)
+      for (size_t h = 0; h < m.nlev; h++)
+        for (int a = 0; a < 3; a++)
+          level_dims[3 * h + a] = (size_t)m.cres[h][a] * m.grid[a];
+    return 0;
+  });
 }
 
 int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int output_float,
                                      void* d_dst, size_t dst_cap_bytes, size_t nlev,
                                      double* const* d_levels, void* hip_stream)
 {
-  if (!d_src || !d_dst || (nlev && !d_levels))
-    return -1;
-  std::lock_guard<std::mutex> lock(g_engine.mu);
-  if (g_engine.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ContainerInfo ci;
-  if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
-    return -1;
-  MultiRes m;
-  multires_levels(ci.vol, ci.chunk, m);
-  if (m.nlev != nlev)
-    return -1;   // (sperrhip_multires_levels tells how many there are)
-  for (size_t h = 0; h < nlev; h++) {
-    if (!d_levels[h])
+  return guarded("sperrhip_decompress_multires_dev", [&]() -> int {
+    if (!d_src || !d_dst || (nlev && !d_levels))
       return -1;
-    m.d_level[h] = d_levels[h];
-  }
-  if (output_float)
-    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
-                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
-                                  &m);
-  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
-                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
-                                 st, &m);
+    std::lock_guard<std::mutex> lock(g_engine.mu);
+    if (g_engine.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ContainerInfo ci;
+    if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
+      return -1;
+    MultiRes m;
+    multires_levels(ci.vol, ci.chunk, m);
+    if (m.nlev != nlev)
+      return -1;   // (sperrhip_multires_levels tells how many there are)
+    for (size_t h = 0; h < nlev; h++) {
+      if (!d_levels[h])
+        return -1;
+      m.d_level[h] = d_levels[h];
+    }
+    if (output_float)
+      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                    static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
+                                    &m);
+    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                   static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
+                                   st, &m);
+  });
 }
 
 // ---- 2D slices (include/SPERR_C_API.h:53-81, src/SPERR_C_API.cpp:7-134) ------------------------
@@ -2194,45 +2257,49 @@ int sperrhip_compress_2d_dev(const void* d_src, int is_float, size_t dimx, size_
                              double quality, int out_inc_header, void* d_dst, size_t dst_cap,
                              size_t* dst_len, void* hip_stream)
 {
-  if (quality <= 0.0)
-    return 2;
-  if (mode < 1 || mode > 3)
-    return 2;
-  if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0)
-    return -1;
-  const Dims vol{dimx, dimy, 1};
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const int slice = out_inc_header ? 2 : 1;
-  if (is_float)
-    return compress_impl<float>(static_cast<const float*>(d_src), vol, vol, mode, quality,
-                                static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
-  return compress_impl<double>(static_cast<const double*>(d_src), vol, vol, mode, quality,
-                               static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
+  return guarded("sperrhip_compress_2d_dev", [&]() -> int {
+    if (quality <= 0.0)
+      return 2;
+    if (mode < 1 || mode > 3)
+      return 2;
+    if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0)
+      return -1;
+    const Dims vol{dimx, dimy, 1};
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int slice = out_inc_header ? 2 : 1;
+    if (is_float)
+      return compress_impl<float>(static_cast<const float*>(d_src), vol, vol, mode, quality,
+                                  static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
+    return compress_impl<double>(static_cast<const double*>(d_src), vol, vol, mode, quality,
+                                 static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
+  });
 }
 
 // d_src: the stream WITHOUT the optional 10-byte header, as sperr_decomp_2d takes it
 int sperrhip_decompress_2d_dev(const void* d_src, size_t src_len, int output_float, size_t dimx,
                                size_t dimy, void* d_dst, size_t dst_cap_bytes, void* hip_stream)
 {
-  if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17)
-    return -1;
-  std::lock_guard<std::mutex> lock(g_engine.mu);
-  if (g_engine.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ContainerInfo ci;
-  ci.vol = {dimx, dimy, 1};
-  ci.chunk = ci.vol;
-  ci.is_float = output_float != 0;
-  ci.off = {0};
-  ci.len = {src_len};
-  if (output_float)
-    return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
-                                  static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
-                                  nullptr, true);
-  return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
-                                 static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st,
-                                 nullptr, true);
+  return guarded("sperrhip_decompress_2d_dev", [&]() -> int {
+    if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17)
+      return -1;
+    std::lock_guard<std::mutex> lock(g_engine.mu);
+    if (g_engine.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ContainerInfo ci;
+    ci.vol = {dimx, dimy, 1};
+    ci.chunk = ci.vol;
+    ci.is_float = output_float != 0;
+    ci.off = {0};
+    ci.len = {src_len};
+    if (output_float)
+      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                    static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
+                                    nullptr, true);
+    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                   static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st,
+                                   nullptr, true);
+  });
 }
 
 // ---- stage access for parity tests -----------------------------------------------------------
@@ -2240,170 +2307,176 @@ int sperrhip_decompress_2d_dev(const void* d_src, size_t src_len, int output_flo
 int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, int inverse,
                        void* hip_stream)
 {
-  Engine& E = g_engine;
-  std::lock_guard<std::mutex> lock(E.mu);
-  if (E.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ShapePlan* P = E.plan(dimx, dimy, dimz);
-  if (!P || E.misc.ensure(4096))
-    return -1;
-  CoderState* cst = static_cast<CoderState*>(E.misc.p);
-  HIP_CHECK(hipMemsetAsync(cst, 0, sizeof(CoderState), st));
-  const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
-  if (!inverse) {
-    for (const LiftPass& ps : P->fwd)
-      if (launch_lift(st, true, d_vals, P->N, 1, cd, ps.axis, ps.region, cst))
-        return -1;
-  }
-  else {
-    for (size_t k = P->fwd.size(); k-- > 0;)
-      if (launch_lift(st, false, d_vals, P->N, 1, cd, P->fwd[k].axis, P->fwd[k].region, cst))
-        return -1;
-  }
-  HIP_CHECK(hipStreamSynchronize(st));
-  g_prof.collect();
-  return 0;
+  return guarded("sperrhip_dwt3d_dev", [&]() -> int {
+    Engine& E = g_engine;
+    std::lock_guard<std::mutex> lock(E.mu);
+    if (E.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ShapePlan* P = E.plan(dimx, dimy, dimz);
+    if (!P || E.misc.ensure(4096))
+      return -1;
+    CoderState* cst = static_cast<CoderState*>(E.misc.p);
+    HIP_CHECK(hipMemsetAsync(cst, 0, sizeof(CoderState), st));
+    const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
+    if (!inverse) {
+      for (const LiftPass& ps : P->fwd)
+        if (launch_lift(st, true, d_vals, P->N, 1, cd, ps.axis, ps.region, cst))
+          return -1;
+    }
+    else {
+      for (size_t k = P->fwd.size(); k-- > 0;)
+        if (launch_lift(st, false, d_vals, P->N, 1, cd, P->fwd[k].axis, P->fwd[k].region, cst))
+          return -1;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    g_prof.collect();
+    return 0;
+  });
 }
 
 int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d_sign, size_t dimx,
                                 size_t dimy, size_t dimz, size_t budget_bits, void* d_dst,
                                 size_t dst_cap, size_t* dst_len, void* hip_stream)
 {
-  if (width != 4 && width != 8)
-    return 2;
-  Engine& E = g_engine;
-  std::lock_guard<std::mutex> lock(E.mu);
-  if (E.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ShapePlan* P = E.plan(dimx, dimy, dimz);
-  if (!P)
-    return -1;
-  const uint64_t raw_budget = budget_bits;
-  if (E.arena.ensure(enc_bytes_per_chunk(*P, raw_budget) + 4096) || E.misc.ensure(4096))
-    return -1;
-  Arena A;
-  A.base = static_cast<char*>(E.arena.p);
-  A.cap = E.arena.n;
-  EncBatchBufs bb;
-  if (!carve_enc(A, *P, 1, raw_budget, bb))
-    return -1;
-  EncBuffers e = bb.eb;
-  const bool wide = width == 8;
-  CoderState hcs;
-  memset(&hcs, 0, sizeof(hcs));
-  hcs.need_retry = wide ? 1u : 0u;  // the 64-bit pass only encodes chunks flagged for it
-  hcs.wide = wide ? 1u : 0u;
-  HIP_CHECK(hipMemcpyAsync(e.cst, &hcs, sizeof(CoderState), hipMemcpyHostToDevice, st));
-  if (reset_enc_pass(st, bb, 1))
-    return -1;
-  const uint32_t n = P->N;
-  HIP_CHECK(hipMemcpyAsync(const_cast<uint64_t*>(e.sign), d_sign, ((n + 63) / 64) * 8,
-                           hipMemcpyDeviceToDevice, st));
-  if (wide) {
-    HIP_CHECK(hipMemcpyAsync(bb.vals, d_coef, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-    e.coef = bb.vals;
-    e.coefStride = bb.valsStride;
-    LAUNCH_K(k_msb_of<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, st,
-             reinterpret_cast<const uint64_t*>(bb.vals), bb.msb, n);
-  }
-  else {
-    HIP_CHECK(hipMemcpyAsync(bb.coef32, d_coef, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-    LAUNCH_K(k_msb_of<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, st,
-             reinterpret_cast<const uint32_t*>(bb.coef32), bb.msb, n);
-  }
-  EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
-  if (launch_speck_encode(st, e, ph, raw_budget, false, wide))
-    return -1;
-  uint64_t* d_len = static_cast<uint64_t*>(E.misc.p);
-  LAUNCH_K(k_speck_stream_out, dim3(1024), dim3(kThreads), 0, st, e.cst, e.stream,
-           static_cast<uint8_t*>(d_dst), (uint64_t)dst_cap, d_len);
-  uint64_t len = 0;
-  HIP_CHECK(hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  HIP_CHECK(hipGetLastError());
-  g_prof.collect();
-  if (len > dst_cap)
-    return -1;
-  *dst_len = (size_t)len;
-  return 0;
+  return guarded("sperrhip_speck3d_encode_dev", [&]() -> int {
+    if (width != 4 && width != 8)
+      return 2;
+    Engine& E = g_engine;
+    std::lock_guard<std::mutex> lock(E.mu);
+    if (E.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ShapePlan* P = E.plan(dimx, dimy, dimz);
+    if (!P)
+      return -1;
+    const uint64_t raw_budget = budget_bits;
+    if (E.arena.ensure(enc_bytes_per_chunk(*P, raw_budget) + 4096) || E.misc.ensure(4096))
+      return -1;
+    Arena A;
+    A.base = static_cast<char*>(E.arena.p);
+    A.cap = E.arena.n;
+    EncBatchBufs bb;
+    if (!carve_enc(A, *P, 1, raw_budget, bb))
+      return -1;
+    EncBuffers e = bb.eb;
+    const bool wide = width == 8;
+    CoderState hcs;
+    memset(&hcs, 0, sizeof(hcs));
+    hcs.need_retry = wide ? 1u : 0u;  // the 64-bit pass only encodes chunks flagged for it
+    hcs.wide = wide ? 1u : 0u;
+    HIP_CHECK(hipMemcpyAsync(e.cst, &hcs, sizeof(CoderState), hipMemcpyHostToDevice, st));
+    if (reset_enc_pass(st, bb, 1))
+      return -1;
+    const uint32_t n = P->N;
+    HIP_CHECK(hipMemcpyAsync(const_cast<uint64_t*>(e.sign), d_sign, ((n + 63) / 64) * 8,
+                             hipMemcpyDeviceToDevice, st));
+    if (wide) {
+      HIP_CHECK(hipMemcpyAsync(bb.vals, d_coef, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+      e.coef = bb.vals;
+      e.coefStride = bb.valsStride;
+      LAUNCH_K(k_msb_of<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, st,
+               reinterpret_cast<const uint64_t*>(bb.vals), bb.msb, n);
+    }
+    else {
+      HIP_CHECK(hipMemcpyAsync(bb.coef32, d_coef, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+      LAUNCH_K(k_msb_of<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, st,
+               reinterpret_cast<const uint32_t*>(bb.coef32), bb.msb, n);
+    }
+    EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+    if (launch_speck_encode(st, e, ph, raw_budget, false, wide))
+      return -1;
+    uint64_t* d_len = static_cast<uint64_t*>(E.misc.p);
+    LAUNCH_K(k_speck_stream_out, dim3(1024), dim3(kThreads), 0, st, e.cst, e.stream,
+             static_cast<uint8_t*>(d_dst), (uint64_t)dst_cap, d_len);
+    uint64_t len = 0;
+    HIP_CHECK(hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    g_prof.collect();
+    if (len > dst_cap)
+      return -1;
+    *dst_len = (size_t)len;
+    return 0;
+  });
 }
 
 int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t dimx, size_t dimy,
                                 size_t dimz, void* d_coef, uint64_t* d_sign, int* width_out,
                                 void* hip_stream)
 {
-  if (stream_len < 9)
-    return -1;
-  Engine& E = g_engine;
-  std::lock_guard<std::mutex> lock(E.mu);
-  if (E.init())
-    return -1;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  ShapePlan* P = E.plan(dimx, dimy, dimz);
-  if (!P)
-    return -1;
-  uint8_t head[9];
-  HIP_CHECK(hipMemcpyAsync(head, d_stream, 9, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  const int nbp = head[0];
-  const bool wide = nbp > 32;
-  if (nbp > kMaxPlanes)
-    return -1;
-  // wrap the bare SPECK stream into a chunk stream with a dummy conditioner header
-  if (E.misc.ensure(round_up(17 + stream_len + 64, 256)))
-    return -1;
-  uint8_t* wrap = static_cast<uint8_t*>(E.misc.p);
-  LAUNCH_K(k_fake_condi_header, dim3(1), dim3(1), 0, st, wrap);
-  HIP_CHECK(hipMemcpyAsync(wrap + 17, d_stream, stream_len, hipMemcpyDeviceToDevice, st));
-  Arena probe;
-  probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
-  probe.cap = ~size_t(0) / 2;
-  DecBatchBufs tmp;
-  carve_dec(probe, *P, 1, 17 + stream_len, tmp);
-  if (E.arena.ensure(probe.used + 4096))
-    return -1;
-  Arena A;
-  A.base = static_cast<char*>(E.arena.p);
-  A.cap = E.arena.n;
-  DecBatchBufs bb;
-  if (!carve_dec(A, *P, 1, 17 + stream_len, bb))
-    return -1;
-  DecBuffers d = bb.db;
-  const uint64_t off = 0, len = 17 + stream_len;
-  HIP_CHECK(hipMemcpyAsync(bb.chunkOff, &off, 8, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(bb.chunkLen, &len, 8, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemsetAsync(d.cst, 0, sizeof(CoderState), st));
-  HIP_CHECK(hipMemsetAsync(d.st, 0, sizeof(DecState), st));
-  HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * 2, st));
-  HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
-  const uint32_t n = P->N;
-  if (wide) {
-    d.coef = bb.vals;
-    d.coefStride = bb.valsStride;
-    HIP_CHECK(hipMemsetAsync(bb.vals, 0, (size_t)n * 8, st));
-  }
-  else
-    HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
-  DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
-                 P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
-  HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
-  HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
-  if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
-    return -1;
-  HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(d_sign, d.sign, ((n + 63) / 64) * 8, hipMemcpyDeviceToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  HIP_CHECK(hipGetLastError());
-  g_prof.collect();
-  *width_out = wide ? 8 : 4;
-  return 0;
+  return guarded("sperrhip_speck3d_decode_dev", [&]() -> int {
+    if (stream_len < 9)
+      return -1;
+    Engine& E = g_engine;
+    std::lock_guard<std::mutex> lock(E.mu);
+    if (E.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ShapePlan* P = E.plan(dimx, dimy, dimz);
+    if (!P)
+      return -1;
+    uint8_t head[9];
+    HIP_CHECK(hipMemcpyAsync(head, d_stream, 9, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int nbp = head[0];
+    const bool wide = nbp > 32;
+    if (nbp > kMaxPlanes)
+      return -1;
+    // wrap the bare SPECK stream into a chunk stream with a dummy conditioner header
+    if (E.misc.ensure(round_up(17 + stream_len + 64, 256)))
+      return -1;
+    uint8_t* wrap = static_cast<uint8_t*>(E.misc.p);
+    LAUNCH_K(k_fake_condi_header, dim3(1), dim3(1), 0, st, wrap);
+    HIP_CHECK(hipMemcpyAsync(wrap + 17, d_stream, stream_len, hipMemcpyDeviceToDevice, st));
+    Arena probe;
+    probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
+    probe.cap = ~size_t(0) / 2;
+    DecBatchBufs tmp;
+    carve_dec(probe, *P, 1, 17 + stream_len, tmp);
+    if (E.arena.ensure(probe.used + 4096))
+      return -1;
+    Arena A;
+    A.base = static_cast<char*>(E.arena.p);
+    A.cap = E.arena.n;
+    DecBatchBufs bb;
+    if (!carve_dec(A, *P, 1, 17 + stream_len, bb))
+      return -1;
+    DecBuffers d = bb.db;
+    const uint64_t off = 0, len = 17 + stream_len;
+    HIP_CHECK(hipMemcpyAsync(bb.chunkOff, &off, 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(bb.chunkLen, &len, 8, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(d.cst, 0, sizeof(CoderState), st));
+    HIP_CHECK(hipMemsetAsync(d.st, 0, sizeof(DecState), st));
+    HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * 2, st));
+    HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
+    const uint32_t n = P->N;
+    if (wide) {
+      d.coef = bb.vals;
+      d.coefStride = bb.valsStride;
+      HIP_CHECK(hipMemsetAsync(bb.vals, 0, (size_t)n * 8, st));
+    }
+    else
+      HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
+    DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
+                   P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
+    HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
+    if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
+      return -1;
+    HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_sign, d.sign, ((n + 63) / 64) * 8, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipGetLastError());
+    g_prof.collect();
+    *width_out = wide ? 8 : 4;
+    return 0;
+  });
 }
 
 // ---- reference-compatible host API (src/SPERR_C_API.cpp:135-258) ---------------------------
@@ -2424,43 +2497,45 @@ int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_
                   size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
                   size_t nthreads, void** dst, size_t* dst_len)
 {
-  (void)nthreads;
-  if (*dst != nullptr)
-    return 1;
-  if (quality <= 0.0)
-    return 2;
-  if (mode < 1 || mode > 3)
-    return 2;
-  const size_t n = dimx * dimy * dimz;
-  const size_t esz = is_float ? 4 : 8;
-  const size_t cap = sperrhip_max_compressed_size(dimx, dimy, dimz, chunk_x, chunk_y, chunk_z,
-                                                  mode, quality);
-  void *d_in = nullptr, *d_out = nullptr;
-  if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
-    fprintf(stderr, "[sperr_hip] device allocation failed\n");
-    if (d_in)
-      (void)hipFree(d_in);
-    return -1;
-  }
-  int rtn = -1;
-  size_t len = 0;
-  if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
-    rtn = sperrhip_compress_dev(d_in, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode,
-                                quality, d_out, cap, &len, nullptr);
-  if (rtn == 0) {
-    void* buf = malloc(len);
-    if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
-      *dst = buf;
-      *dst_len = len;
+  return guarded("sperr_comp_3d", [&]() -> int {
+    (void)nthreads;
+    if (*dst != nullptr)
+      return 1;
+    if (quality <= 0.0)
+      return 2;
+    if (mode < 1 || mode > 3)
+      return 2;
+    const size_t n = dimx * dimy * dimz;
+    const size_t esz = is_float ? 4 : 8;
+    const size_t cap = sperrhip_max_compressed_size(dimx, dimy, dimz, chunk_x, chunk_y, chunk_z,
+                                                    mode, quality);
+    void *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
+      fprintf(stderr, "[sperr_hip] device allocation failed\n");
+      if (d_in)
+        (void)hipFree(d_in);
+      return -1;
     }
-    else {
-      free(buf);
-      rtn = -1;
+    int rtn = -1;
+    size_t len = 0;
+    if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_compress_dev(d_in, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode,
+                                  quality, d_out, cap, &len, nullptr);
+    if (rtn == 0) {
+      void* buf = malloc(len);
+      if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+        *dst = buf;
+        *dst_len = len;
+      }
+      else {
+        free(buf);
+        rtn = -1;
+      }
     }
-  }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  return rtn;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rtn;
+  });
 }
 
 // include/SPERR_C_API.h:138-156, src/SPERR_C_API.cpp:260-280,
@@ -2469,174 +2544,182 @@ int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_
 // flagged as a portion and the chunk lengths are rewritten; the decoder zero-pads what is missing.
 int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, size_t* dst_len)
 {
-  if (*dst != nullptr)
-    return 1;
-  const uint8_t* h = static_cast<const uint8_t*>(src);
-  if (src_len < 20)
-    return -1;
-  const bool multi = (h[1] & 0x10) != 0;
-  uint32_t v3[3];
-  memcpy(v3, h + 2, 12);
-  Dims vol{v3[0], v3[1], v3[2]}, cd = vol;
-  size_t pos = 14;
-  if (multi) {
-    uint16_t c3[3];
-    memcpy(c3, h + 14, 6);
-    cd = {c3[0], c3[1], c3[2]};
-    pos = 20;
-  }
-  for (int a = 0; a < 3; a++)
-    if (vol[a] == 0 || cd[a] == 0)
+  return guarded("sperr_trunc_3d", [&]() -> int {
+    if (*dst != nullptr)
+      return 1;
+    const uint8_t* h = static_cast<const uint8_t*>(src);
+    if (src_len < 20)
       return -1;
-  const size_t nchunks = chunk_volume(vol, cd).size();
-  const size_t hlen = pos + 4 * nchunks;
-  if (src_len < hlen)
-    return -1;
-  constexpr size_t kMinChunkBytes = 64;   // include/SPERR3D_Stream_Tools.h:54
-  const bool whole = pct == 0 || pct >= 100;
-  std::vector<size_t> off(nchunks), len(nchunks);
-  size_t at = hlen, total = hlen, far = 0;
-  for (size_t i = 0; i < nchunks; i++) {
-    uint32_t l;
-    memcpy(&l, h + pos + 4 * i, 4);
-    off[i] = at;
-    at += l;
-    len[i] = l;
-    if (!whole && l > kMinChunkBytes)
-      len[i] = std::max(kMinChunkBytes, (size_t)((double)pct / 100.0 * (double)l));
-    total += len[i];
-    far = std::max(far, off[i] + len[i]);
-  }
-  if (src_len < far)
-    return -1;
-  uint8_t* out = static_cast<uint8_t*>(malloc(total));
-  if (!out)
-    return -1;
-  memcpy(out, h, pos);
-  if (!whole) {
-    out[0] = 0;       // SPERR_VERSION_MAJOR (CMakeLists.txt:5)
-    out[1] |= 0x80;   // portion flag: bool 0 of the packed byte (src/sperr_helper.cpp:262-273)
-  }
-  size_t w = hlen;
-  for (size_t i = 0; i < nchunks; i++) {
-    const uint32_t l = (uint32_t)len[i];
-    memcpy(out + pos + 4 * i, &l, 4);
-    memcpy(out + w, h + off[i], len[i]);
-    w += len[i];
-  }
-  *dst = out;
-  *dst_len = total;
-  return 0;
+    const bool multi = (h[1] & 0x10) != 0;
+    uint32_t v3[3];
+    memcpy(v3, h + 2, 12);
+    Dims vol{v3[0], v3[1], v3[2]}, cd = vol;
+    size_t pos = 14;
+    if (multi) {
+      uint16_t c3[3];
+      memcpy(c3, h + 14, 6);
+      cd = {c3[0], c3[1], c3[2]};
+      pos = 20;
+    }
+    for (int a = 0; a < 3; a++)
+      if (vol[a] == 0 || cd[a] == 0)
+        return -1;
+    const size_t nchunks = chunk_count(vol, cd);
+    if (src_len < pos || nchunks > (src_len - pos) / 4)
+      return -1;
+    const size_t hlen = pos + 4 * nchunks;
+    constexpr size_t kMinChunkBytes = 64;   // include/SPERR3D_Stream_Tools.h:54
+    const bool whole = pct == 0 || pct >= 100;
+    std::vector<size_t> off(nchunks), len(nchunks);
+    size_t at = hlen, total = hlen, far = 0;
+    for (size_t i = 0; i < nchunks; i++) {
+      uint32_t l;
+      memcpy(&l, h + pos + 4 * i, 4);
+      off[i] = at;
+      at += l;
+      len[i] = l;
+      if (!whole && l > kMinChunkBytes)
+        len[i] = std::max(kMinChunkBytes, (size_t)((double)pct / 100.0 * (double)l));
+      total += len[i];
+      far = std::max(far, off[i] + len[i]);
+    }
+    if (src_len < far)
+      return -1;
+    uint8_t* out = static_cast<uint8_t*>(malloc(total));
+    if (!out)
+      return -1;
+    memcpy(out, h, pos);
+    if (!whole) {
+      out[0] = 0;       // SPERR_VERSION_MAJOR (CMakeLists.txt:5)
+      out[1] |= 0x80;   // portion flag: bool 0 of the packed byte (src/sperr_helper.cpp:262-273)
+    }
+    size_t w = hlen;
+    for (size_t i = 0; i < nchunks; i++) {
+      const uint32_t l = (uint32_t)len[i];
+      memcpy(out + pos + 4 * i, &l, 4);
+      memcpy(out + w, h + off[i], len[i]);
+      w += len[i];
+    }
+    *dst = out;
+    *dst_len = total;
+    return 0;
+  });
 }
 
 int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
                     size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
 {
-  (void)nthreads;
-  if (*dst != nullptr)
-    return 1;
-  if (src_len < 18)
-    return -1;
-  ContainerInfo ci;
-  size_t need = 0;
-  if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
-    return -1;
-  const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
-  const size_t esz = output_float ? 4 : 8;
-  void *d_in = nullptr, *d_out = nullptr;
-  if (hipMalloc(&d_in, src_len) != hipSuccess || hipMalloc(&d_out, n * esz) != hipSuccess) {
-    fprintf(stderr, "[sperr_hip] device allocation failed\n");
-    if (d_in)
-      (void)hipFree(d_in);
-    return -1;
-  }
-  int rtn = -1;
-  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
-    rtn = sperrhip_decompress_dev(d_in, src_len, output_float, d_out, n * esz, dimx, dimy, dimz,
-                                  nullptr);
-  if (rtn == 0) {
-    void* buf = malloc(n * esz);
-    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
-      *dst = buf;
-    else {
-      free(buf);
-      rtn = -1;
+  return guarded("sperr_decomp_3d", [&]() -> int {
+    (void)nthreads;
+    if (*dst != nullptr)
+      return 1;
+    if (src_len < 18)
+      return -1;
+    ContainerInfo ci;
+    size_t need = 0;
+    if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
+      return -1;
+    const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
+    const size_t esz = output_float ? 4 : 8;
+    void *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, src_len) != hipSuccess || hipMalloc(&d_out, n * esz) != hipSuccess) {
+      fprintf(stderr, "[sperr_hip] device allocation failed\n");
+      if (d_in)
+        (void)hipFree(d_in);
+      return -1;
     }
-  }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  return rtn;
+    int rtn = -1;
+    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_decompress_dev(d_in, src_len, output_float, d_out, n * esz, dimx, dimy, dimz,
+                                    nullptr);
+    if (rtn == 0) {
+      void* buf = malloc(n * esz);
+      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+        *dst = buf;
+      else {
+        free(buf);
+        rtn = -1;
+      }
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rtn;
+  });
 }
 
 // include/SPERR_C_API.h:53-62, src/SPERR_C_API.cpp:7-97
 int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int mode, double quality,
                   int out_inc_header, void** dst, size_t* dst_len)
 {
-  if (*dst != nullptr)
-    return 1;
-  if (quality <= 0.0)
-    return 2;
-  if (mode < 1 || mode > 3)
-    return 2;
-  const size_t n = dimx * dimy, esz = is_float ? 4 : 8;
-  const size_t cap = sperrhip_max_compressed_size_2d(dimx, dimy, mode, quality);
-  void *d_in = nullptr, *d_out = nullptr;
-  if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
-    fprintf(stderr, "[sperr_hip] device allocation failed\n");
-    if (d_in)
-      (void)hipFree(d_in);
-    return -1;
-  }
-  int rtn = -1;
-  size_t len = 0;
-  if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
-    rtn = sperrhip_compress_2d_dev(d_in, is_float, dimx, dimy, mode, quality, out_inc_header, d_out,
-                                   cap, &len, nullptr);
-  if (rtn == 0) {
-    void* buf = malloc(len);
-    if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
-      *dst = buf;
-      *dst_len = len;
+  return guarded("sperr_comp_2d", [&]() -> int {
+    if (*dst != nullptr)
+      return 1;
+    if (quality <= 0.0)
+      return 2;
+    if (mode < 1 || mode > 3)
+      return 2;
+    const size_t n = dimx * dimy, esz = is_float ? 4 : 8;
+    const size_t cap = sperrhip_max_compressed_size_2d(dimx, dimy, mode, quality);
+    void *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
+      fprintf(stderr, "[sperr_hip] device allocation failed\n");
+      if (d_in)
+        (void)hipFree(d_in);
+      return -1;
     }
-    else {
-      free(buf);
-      rtn = -1;
+    int rtn = -1;
+    size_t len = 0;
+    if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_compress_2d_dev(d_in, is_float, dimx, dimy, mode, quality, out_inc_header, d_out,
+                                     cap, &len, nullptr);
+    if (rtn == 0) {
+      void* buf = malloc(len);
+      if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+        *dst = buf;
+        *dst_len = len;
+      }
+      else {
+        free(buf);
+        rtn = -1;
+      }
     }
-  }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  return rtn;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rtn;
+  });
 }
 
 // include/SPERR_C_API.h:75-81, src/SPERR_C_API.cpp:99-134
 int sperr_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx, size_t dimy,
                     void** dst)
 {
-  if (*dst != nullptr)
-    return 1;
-  const size_t n = dimx * dimy, esz = output_float ? 4 : 8;
-  void *d_in = nullptr, *d_out = nullptr;
-  if (src_len < 17 || hipMalloc(&d_in, src_len) != hipSuccess ||
-      hipMalloc(&d_out, n * esz) != hipSuccess) {
-    if (d_in)
-      (void)hipFree(d_in);
-    return -1;
-  }
-  int rtn = -1;
-  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
-    rtn = sperrhip_decompress_2d_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, nullptr);
-  if (rtn == 0) {
-    void* buf = malloc(n * esz);
-    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
-      *dst = buf;
-    else {
-      free(buf);
-      rtn = -1;
+  return guarded("sperr_decomp_2d", [&]() -> int {
+    if (*dst != nullptr)
+      return 1;
+    const size_t n = dimx * dimy, esz = output_float ? 4 : 8;
+    void *d_in = nullptr, *d_out = nullptr;
+    if (src_len < 17 || hipMalloc(&d_in, src_len) != hipSuccess ||
+        hipMalloc(&d_out, n * esz) != hipSuccess) {
+      if (d_in)
+        (void)hipFree(d_in);
+      return -1;
     }
-  }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  return rtn;
+    int rtn = -1;
+    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_decompress_2d_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, nullptr);
+    if (rtn == 0) {
+      void* buf = malloc(n * esz);
+      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+        *dst = buf;
+      else {
+        free(buf);
+        rtn = -1;
+      }
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rtn;
+  });
 }
 
 // host buffers in, malloc'd host buffers out: the volume and the levels of the hierarchy
@@ -2645,71 +2728,73 @@ int sperrhip_decomp_3d_multires(const void* src, size_t src_len, int output_floa
                                 size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
                                 size_t* level_dims, double** levels)
 {
-  if (!dst || *dst != nullptr)
-    return 1;
-  if (src_len < 18 || !nlev || !level_dims || !levels)
-    return -1;
-  ContainerInfo ci;
-  size_t need = 0;
-  if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
-    return -1;
-  if (sperrhip_multires_levels(ci.vol[0], ci.vol[1], ci.vol[2], ci.chunk[0], ci.chunk[1], ci.chunk[2],
-                               nlev, level_dims))
-    return -1;
-  const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
-  const size_t esz = output_float ? 4 : 8;
-  std::vector<void*> dev;
-  auto release = [&]() {
-    for (void* p : dev)
-      (void)hipFree(p);
-  };
-  auto dalloc = [&](size_t bytes) -> void* {
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess)
-      return nullptr;
-    dev.push_back(p);
-    return p;
-  };
-  void* d_in = dalloc(src_len);
-  void* d_out = dalloc(n * esz);
-  std::vector<double*> d_lv(*nlev, nullptr);
-  std::vector<size_t> lvn(*nlev, 0);
-  bool ok = d_in && d_out;
-  for (size_t h = 0; ok && h < *nlev; h++) {
-    lvn[h] = level_dims[3 * h] * level_dims[3 * h + 1] * level_dims[3 * h + 2];
-    d_lv[h] = static_cast<double*>(dalloc(lvn[h] * 8));
-    ok = d_lv[h] != nullptr;
-  }
-  if (!ok) {
-    fprintf(stderr, "[sperr_hip] device allocation failed\n");
-    release();
-    return -1;
-  }
-  int rtn = -1;
-  if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
-    rtn = sperrhip_decompress_multires_dev(d_in, src_len, output_float, d_out, n * esz, *nlev,
-                                           d_lv.data(), nullptr);
-  if (rtn == 0) {
-    void* buf = malloc(n * esz);
-    if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
-      *dst = buf;
-    else {
-      free(buf);
-      rtn = -1;
+  return guarded("sperrhip_decomp_3d_multires", [&]() -> int {
+    if (!dst || *dst != nullptr)
+      return 1;
+    if (src_len < 18 || !nlev || !level_dims || !levels)
+      return -1;
+    ContainerInfo ci;
+    size_t need = 0;
+    if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
+      return -1;
+    if (sperrhip_multires_levels(ci.vol[0], ci.vol[1], ci.vol[2], ci.chunk[0], ci.chunk[1], ci.chunk[2],
+                                 nlev, level_dims))
+      return -1;
+    const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
+    const size_t esz = output_float ? 4 : 8;
+    std::vector<void*> dev;
+    auto release = [&]() {
+      for (void* p : dev)
+        (void)hipFree(p);
+    };
+    auto dalloc = [&](size_t bytes) -> void* {
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess)
+        return nullptr;
+      dev.push_back(p);
+      return p;
+    };
+    void* d_in = dalloc(src_len);
+    void* d_out = dalloc(n * esz);
+    std::vector<double*> d_lv(*nlev, nullptr);
+    std::vector<size_t> lvn(*nlev, 0);
+    bool ok = d_in && d_out;
+    for (size_t h = 0; ok && h < *nlev; h++) {
+      lvn[h] = level_dims[3 * h] * level_dims[3 * h + 1] * level_dims[3 * h + 2];
+      d_lv[h] = static_cast<double*>(dalloc(lvn[h] * 8));
+      ok = d_lv[h] != nullptr;
     }
-    for (size_t h = 0; rtn == 0 && h < *nlev; h++) {
-      levels[h] = static_cast<double*>(malloc(lvn[h] * 8));
-      if (!levels[h] || hipMemcpy(levels[h], d_lv[h], lvn[h] * 8, hipMemcpyDeviceToHost) != hipSuccess)
-        rtn = -1;
+    if (!ok) {
+      fprintf(stderr, "[sperr_hip] device allocation failed\n");
+      release();
+      return -1;
     }
+    int rtn = -1;
+    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_decompress_multires_dev(d_in, src_len, output_float, d_out, n * esz, *nlev,
+                                             d_lv.data(), nullptr);
     if (rtn == 0) {
-      *dimx = ci.vol[0];
-      *dimy = ci.vol[1];
-      *dimz = ci.vol[2];
+      void* buf = malloc(n * esz);
+      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+        *dst = buf;
+      else {
+        free(buf);
+        rtn = -1;
+      }
+      for (size_t h = 0; rtn == 0 && h < *nlev; h++) {
+        levels[h] = static_cast<double*>(malloc(lvn[h] * 8));
+        if (!levels[h] || hipMemcpy(levels[h], d_lv[h], lvn[h] * 8, hipMemcpyDeviceToHost) != hipSuccess)
+          rtn = -1;
+      }
+      if (rtn == 0) {
+        *dimx = ci.vol[0];
+        *dimy = ci.vol[1];
+        *dimz = ci.vol[2];
+      }
     }
-  }
-  release();
-  return rtn;
+    release();
+    return rtn;
+  });
 }
 
 }  // extern "C"

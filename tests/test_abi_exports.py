@@ -42,3 +42,17 @@ def test_no_gpu_means_loud_failure():
     rtn = lib.sperr_comp_3d(v.ctypes.data, 1, 8, 8, 8, 8, 8, 8, 1, 2.0, 0, ctypes.byref(dst),
                             ctypes.byref(n))
     assert rtn == -1 and not dst.value
+
+
+def test_truncation_refuses_headers_naming_more_chunks_than_bytes():
+    """sperr_trunc_3d is host only: a header whose dimensions imply billions of chunks has to be
+    refused (return code), not run into an allocation failure inside the library."""
+    import numpy as np
+    from sperr_amd import api
+    lib = api.load_library()
+    for vol, chunk in (((0x7fffffff,) * 3, (1, 1, 1)), ((0xffffffff,) * 3, (2, 3, 1))):
+        head = bytes([0, 0x40 | 0x20 | 0x10]) + np.array(vol, dtype=np.uint32).tobytes() + \
+            np.array(chunk, dtype=np.uint16).tobytes() + bytes(200)
+        dst, n = ctypes.c_void_p(None), ctypes.c_size_t(0)
+        rtn = lib.sperr_trunc_3d(head, ctypes.c_size_t(len(head)), 50, ctypes.byref(dst), ctypes.byref(n))
+        assert rtn != 0 and not dst.value

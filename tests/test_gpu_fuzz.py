@@ -1,9 +1,12 @@
 """Randomised parity sweep (-m gpu): random small volumes, chunkings, modes and qualities; the
 HIP container must equal the oracle's byte for byte and decode to the same values."""
+import os
+
 import numpy as np
 import pytest
 
 from fields import smooth_field
+from sperr_amd.api import SperrHipError
 from sperr_amd.synth import turbulence
 
 pytestmark = pytest.mark.gpu
@@ -94,3 +97,37 @@ def test_random_slice(eng, seed):
     for as_float in (True, False):
         assert np.array_equal(bits(eng.decompress_2d(dev, shape, as_float).cpu().numpy()),
                               bits(oracle.decomp_2d(body[:cut], shape, as_float))), (shape, mode, quality, cut)
+
+
+def test_damaged_containers_are_rejected_or_decoded(eng):
+    """Bytes flipped anywhere, inside the container / chunk / outlier headers, or the container cut
+    short: the decoder returns an error or some values, and the undamaged container still decodes to
+    exactly what it did before (tools/fuzz_corrupt.py runs more of these)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "fuzz_corrupt.py")
+    spec = importlib.util.spec_from_file_location("fuzz_corrupt", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, trials, rejected, decoded, same in mod.run(trials=48, seed=7, eng=eng):
+        assert same, name
+        assert rejected + decoded == trials
+
+
+def test_header_with_absurd_dimensions_is_rejected(eng):
+    """A header naming more chunks than the container has bytes must be refused before anything is
+    sized from it (no allocation failure escapes the C boundary)."""
+    v = turbulence((24, 24, 24), seed=3)
+    good = eng.compress(cuda(v), (12, 12, 12), 2.0).cpu().numpy()
+    for vol, chunk in (((0x7fffffff,) * 3, (1, 1, 1)), ((0xffffffff,) * 3, (2, 3, 1)),
+                       ((1 << 22,) * 3, (0xffff,) * 3)):
+        bad = good.copy()
+        bad[2:14] = np.frombuffer(np.array(vol, dtype=np.uint32).tobytes(), dtype=np.uint8)
+        bad[14:20] = np.frombuffer(np.array(chunk, dtype=np.uint16).tobytes(), dtype=np.uint8)
+        with pytest.raises(SperrHipError):
+            eng.parse_header(cuda(bad))
+        with pytest.raises(SperrHipError):
+            eng.decompress(cuda(bad), True, shape_zyx=(24, 24, 24))
+        with pytest.raises(SperrHipError):
+            eng.decomp_3d(bytes(bad))
+        with pytest.raises(SperrHipError):
+            eng.trunc_3d(bytes(bad), 50)
