@@ -1,7 +1,8 @@
 // sperr2d -- compress / decompress a 2D slice on the GPU.  Same command line, files and messages
 // as the reference's utilities/sperr2d.cpp (options :95-200, checks :202-233, work :236-418): the
-// bitstream file starts with the 10-byte header {version, flags, u32 dimx, u32 dimy}.
-// Not available: --decomp_lowres_f / --decomp_lowres_d (the 2D resolution hierarchy).
+// bitstream file starts with the 10-byte header {version, flags, u32 dimx, u32 dimy};
+// --decomp_lowres_f / --decomp_lowres_d write one file per coarsened resolution, "name.XxY"
+// (utilities/sperr2d.cpp:13-24).
 #include "cli_common.hpp"
 #include "sperr_hip.h"
 
@@ -11,6 +12,35 @@ struct Freed {
   ~Freed() { free(p); }
 };
 constexpr size_t kHeaderLen = 10;
+
+// decodes the header-less `stream`, writes what was asked for; `out` keeps the slice (doubles)
+int decode_and_write(const uint8_t* stream, size_t len, size_t dx, size_t dy, const std::string& f64,
+                     const std::string& f32, const std::string& low64, const std::string& low32, Freed& out)
+{
+  const bool multi_res = !low64.empty() || !low32.empty();
+  size_t nlev = 0, level_dims[2 * 16] = {};
+  double* levels[16] = {};
+  const int rtn = multi_res ? sperrhip_decomp_2d_multires(stream, len, 0, dx, dy, &out.p, &nlev, level_dims, levels)
+                            : sperr_decomp_2d(stream, len, 0, dx, dy, &out.p);
+  if (rtn != 0) {
+    printf("Decompression failed!\n");
+    return 1;
+  }
+  int bad = 0;
+  for (const std::string* name : {&low64, &low32})
+    for (size_t l = 0; l < nlev && !bad && !name->empty(); l++) {
+      const std::string file = *name + "." + std::to_string(level_dims[2 * l]) + "x" + std::to_string(level_dims[2 * l + 1]);
+      const bool as64 = name == &low64;
+      if (!cli::write_volume(levels[l], level_dims[2 * l] * level_dims[2 * l + 1], as64 ? file : "", as64 ? "" : file,
+                             "hierarchy"))
+        bad = 1;
+    }
+  for (size_t l = 0; l < nlev; l++)
+    free(levels[l]);
+  if (bad)
+    return 1;
+  return cli::write_volume(static_cast<const double*>(out.p), dx * dy, f64, f32, "data") ? 0 : 1;
+}
 }  // namespace
 
 int main(int argc, char** argv)
@@ -32,8 +62,8 @@ int main(int argc, char** argv)
   app.text("--bitstream", bitstream, "Output compressed bitstream.", go).needs = {"-c"};
   app.text("--decomp_f", decomp_f32, "Output decompressed slice in f32 precision.", go);
   app.text("--decomp_d", decomp_f64, "Output decompressed slice in f64 precision.", go);
-  app.text("--decomp_lowres_f", low_f32, "(not available in this build)", go);
-  app.text("--decomp_lowres_d", low_f64, "(not available in this build)", go);
+  app.text("--decomp_lowres_f", low_f32, "Output lower resolutions of the decompressed slice in f32 precision.", go);
+  app.text("--decomp_lowres_d", low_f64, "Output lower resolutions of the decompressed slice in f64 precision.", go);
   app.flag("--print_stats", print_stats, "Show statistics measuring the compression quality.", go).needs = {"-c"};
   app.real("--pwe", pwe, "Maximum point-wise error (PWE) tolerance.", gc);
   app.real("--psnr", psnr, "Target PSNR to achieve.", gc).excludes = {"--pwe"};
@@ -68,11 +98,8 @@ int main(int argc, char** argv)
     printf("Compression quality (--psnr, --pwe) must be positive!\n");
     return 1;
   }
-  if (!low_f32.empty() || !low_f64.empty()) {
-    printf("The 2D resolution hierarchy (--decomp_lowres_f, --decomp_lowres_d) is not available in this build.\n");
-    return 1;
-  }
-  if (dflag && decomp_f32.empty() && decomp_f64.empty()) {
+  const bool multi_res = !low_f32.empty() || !low_f64.empty();
+  if (dflag && decomp_f32.empty() && decomp_f64.empty() && !multi_res) {
     printf("SPERR needs an output destination when decoding!\n");
     return 1;
   }
@@ -103,16 +130,12 @@ int main(int argc, char** argv)
       printf("Writing compressed bitstream failed: %s\n", bitstream.c_str());
       return 1;
     }
-    if (print_stats || !decomp_f64.empty() || !decomp_f32.empty()) {
+    if (print_stats || !decomp_f64.empty() || !decomp_f32.empty() || multi_res) {
       Freed vol;
-      if (sperr_decomp_2d(static_cast<const uint8_t*>(enc.p) + kHeaderLen, enc_len - kHeaderLen, 0, dims[0], dims[1],
-                          &vol.p) != 0) {
-        printf("Decompression failed!\n");
+      if (decode_and_write(static_cast<const uint8_t*>(enc.p) + kHeaderLen, enc_len - kHeaderLen, dims[0], dims[1],
+                           decomp_f64, decomp_f32, low_f64, low_f32, vol))
         return 1;
-      }
       const double* recon = static_cast<const double*>(vol.p);
-      if (!cli::write_volume(recon, total, decomp_f64, decomp_f32, "data"))
-        return 1;
       if (print_stats) {
         const double rate = (double)enc_len * 8.0 / (double)total;
         const cli::Stats s = ftype == 32 ? cli::quality(reinterpret_cast<const float*>(input.data()), recon, total)
@@ -139,11 +162,8 @@ int main(int argc, char** argv)
     uint32_t d2[2];
     memcpy(d2, input.data() + 2, 8);
     Freed vol;
-    if (sperr_decomp_2d(input.data() + kHeaderLen, input.size() - kHeaderLen, 0, d2[0], d2[1], &vol.p) != 0) {
-      printf("Decompression failed!\n");
-      return 1;
-    }
-    if (!cli::write_volume(static_cast<const double*>(vol.p), (size_t)d2[0] * d2[1], decomp_f64, decomp_f32, "data"))
+    if (decode_and_write(input.data() + kHeaderLen, input.size() - kHeaderLen, d2[0], d2[1], decomp_f64, decomp_f32,
+                         low_f64, low_f32, vol))
       return 1;
   }
   return 0;

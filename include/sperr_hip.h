@@ -128,6 +128,22 @@ int sperrhip_decomp_3d_multires(const void* src, size_t src_len, int output_floa
                                 size_t* dimy, size_t* dimz, void** dst, size_t* nlev,
                                 size_t* level_dims, double** levels);
 
+/* The same for a slice: SPECK2D_FLT::decompress(multi_res = true) + release_hierarchy()
+ * (/root/reference/src/SPECK2D_FLT.cpp:52-58, src/CDF97.cpp:114-130,566-579,
+ * src/SPECK_FLT.cpp:592-603; what utilities/sperr2d.cpp --decomp_lowres_f/_d writes): the slice at
+ * every coarsened resolution (src/sperr_helper.cpp:86-95), coarsest first, as doubles.  Every
+ * slice shape has them (none if the shorter side is below 8).  level_dims: 2 entries per level
+ * (x y), room for 16 levels.  `src` is the stream WITHOUT the 10-byte header, as for
+ * sperr_decomp_2d. */
+int sperrhip_multires_levels_2d(size_t dimx, size_t dimy, size_t* nlev, size_t* level_dims);
+int sperrhip_decompress_2d_multires_dev(const void* d_src, size_t src_len, int output_float,
+                                        size_t dimx, size_t dimy, void* d_dst, size_t dst_cap_bytes,
+                                        size_t nlev, double* const* d_levels, void* hip_stream);
+/* host buffers: *dst must be NULL; *dst and levels[0 .. *nlev) are malloc'd (free() them) */
+int sperrhip_decomp_2d_multires(const void* src, size_t src_len, int output_float, size_t dimx,
+                                size_t dimy, void** dst, size_t* nlev, size_t* level_dims,
+                                double** levels);
+
 /* ---- profiling ------------------------------------------------------------------------------ */
 
 /* When enabled, the engine brackets every pipeline stage with HIP events on the launch stream

@@ -67,6 +67,7 @@ class _CApiMixin:
     _trunc = None
     _comp2 = None
     _decomp2 = None
+    _decomp2mr = None
     _libc = C.CDLL(None)
 
     def _wire(self):
@@ -124,6 +125,27 @@ class _CApiMixin:
         self._libc.free(dst)
         return out
 
+    def decomp_2d_multi_res(self, stream, shape_yx):
+        """-> (slice float64 (y, x), [level slices float64, coarsest first])."""
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dy, dx = shape_yx
+        dst, nlev = _vp(None), _sz(0)
+        ldims = (_sz * 32)()
+        levels = (_vp * 16)()
+        self._decomp2mr.restype = C.c_int
+        self._decomp2mr.argtypes = [_vp, _sz, _sz, _sz, C.POINTER(_vp), C.POINTER(_sz), _vp, _vp]
+        rtn = self._decomp2mr(buf.ctypes.data, buf.size, dx, dy, C.byref(dst), C.byref(nlev), ldims, levels)
+        if rtn != 0:
+            raise RuntimeError(f"decomp_2d_multi_res returned {rtn}")
+        img = np.frombuffer(C.string_at(dst.value, dx * dy * 8), dtype=np.float64).reshape(dy, dx).copy()
+        self._libc.free(dst)
+        out = []
+        for h in range(nlev.value):
+            lx, ly = ldims[2 * h], ldims[2 * h + 1]
+            out.append(np.frombuffer(C.string_at(levels[h], lx * ly * 8), dtype=np.float64).reshape(ly, lx).copy())
+            self._libc.free(_vp(levels[h]))
+        return img, out
+
     def comp_3d(self, vol, chunks, mode, quality, nthreads=1):
         """vol: numpy float32/float64 array shaped (z, y, x). Returns bytes."""
         vol = np.ascontiguousarray(vol)
@@ -163,6 +185,7 @@ class Oracle(_CApiMixin):
         self._comp, self._decomp = L.orc_comp_3d, L.orc_decomp_3d
         self._trunc = L.orc_trunc_3d
         self._comp2, self._decomp2 = L.orc_comp_2d, L.orc_decomp_2d
+        self._decomp2mr = L.orc_decomp_2d_multi_res
         self._wire()
         L.orc_dwt3d.argtypes = [_vp, _vp]
         L.orc_idwt3d.argtypes = [_vp, _vp]
@@ -341,6 +364,7 @@ class Ref(_CApiMixin):
         self._comp, self._decomp = self.lib.sperr_comp_3d, self.lib.sperr_decomp_3d
         self._trunc = self.lib.sperr_trunc_3d
         self._comp2, self._decomp2 = self.lib.sperr_comp_2d, self.lib.sperr_decomp_2d
+        self._decomp2mr = self.probe.refp_decomp_2d_multi_res
         self._wire()
         P = self.probe
         P.refp_dwt3d.argtypes = [_vp, _sz, _sz, _sz]

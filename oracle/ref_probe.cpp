@@ -12,6 +12,7 @@
 #include "Conditioner.h"
 #include "SPECK1D_INT_DEC.h"
 #include "SPECK1D_INT_ENC.h"
+#include "SPECK2D_FLT.h"
 #include "SPECK3D_FLT.h"
 #include "SPERR3D_OMP_D.h"
 #include "SPECK3D_INT_DEC.h"
@@ -233,6 +234,35 @@ int refp_decomp_multi_res(const uint8_t* stream, size_t len, size_t nthreads, si
     std::memcpy(levels[i], h[i].data(), h[i].size() * sizeof(double));
   }
   return static_cast<int>(h.size());
+}
+
+// SPECK2D_FLT::decompress(multi_res = true) (what utilities/sperr2d.cpp:352-366 does): the slice
+// and every level of its hierarchy, coarsest first; level_dims holds x y per level
+int refp_decomp_2d_multi_res(const void* src, size_t len, size_t dimx, size_t dimy, void** dst,
+                             size_t* nlev, size_t* level_dims, double** levels)
+{
+  sperr::SPECK2D_FLT dec;
+  const sperr::dims_type dims{dimx, dimy, 1};
+  dec.set_dims(dims);
+  if (dec.use_bitstream(src, len) != sperr::RTNType::Good)
+    return -1;
+  if (dec.decompress(true) != sperr::RTNType::Good)
+    return -1;
+  const auto h = dec.release_hierarchy();
+  const auto v = dec.release_decoded_data();
+  const auto res = sperr::coarsened_resolutions(dims);
+  if (h.size() != res.size() || h.size() > 16)
+    return -1;
+  for (size_t i = 0; i < h.size(); i++) {
+    level_dims[2 * i] = res[i][0];
+    level_dims[2 * i + 1] = res[i][1];
+    levels[i] = static_cast<double*>(std::malloc(h[i].size() * sizeof(double)));
+    std::memcpy(levels[i], h[i].data(), h[i].size() * sizeof(double));
+  }
+  *nlev = h.size();
+  *dst = std::malloc(v.size() * sizeof(double));
+  std::memcpy(*dst, v.data(), v.size() * sizeof(double));
+  return 0;
 }
 
 }  // extern "C"

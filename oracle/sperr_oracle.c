@@ -345,6 +345,23 @@ size_t orc_coarsened_resolutions(const size_t dims[3], size_t (*res)[3], size_t 
   return levels;
 }
 
+/* src/sperr_helper.cpp:86-95 : the coarsened resolutions of a slice (dims[2] == 1), coarsest
+ * first: one per level of dwt2d */
+size_t orc_coarsened_resolutions_2d(const size_t dims[3], size_t (*res)[3], size_t cap)
+{
+  const size_t levels = orc_num_of_xforms(dims[0] < dims[1] ? dims[0] : dims[1]);
+  for (size_t lev = levels; lev > 0; lev--) {
+    const size_t h = levels - lev;
+    if (res && h < cap) {
+      size_t d;
+      orc_approx_detail_len(dims[0], lev, &res[h][0], &d);
+      orc_approx_detail_len(dims[1], lev, &res[h][1], &d);
+      res[h][2] = 1;
+    }
+  }
+  return levels;
+}
+
 static void idwt3d_impl(double* buf, const size_t dims[3], double** hier);
 
 /* src/CDF97.cpp:141-148,227-302,366-385,431-474 */
@@ -394,6 +411,14 @@ static void idwt3d_impl(double* buf, const size_t dims[3], double** hier)
     const size_t nxy = orc_num_of_xforms(dims[0] < dims[1] ? dims[0] : dims[1]);
     for (size_t lev = nxy; lev > 0; lev--) {
       size_t region[3] = {0, 0, dims[2]};
+      if (hier && dims[2] == 1) { /* idwt2d_multi_res + m_sub_slice, src/CDF97.cpp:114-130,569-579 */
+        size_t sx, sy;
+        orc_approx_detail_len(dims[0], lev, &sx, &d);
+        orc_approx_detail_len(dims[1], lev, &sy, &d);
+        double* dst = hier[nxy - lev];
+        for (size_t y = 0; y < sy; y++)
+          memcpy(dst + y * sx, buf + y * dims[0], sx * sizeof(double));
+      }
       orc_approx_detail_len(dims[0], lev - 1, &region[0], &d);
       orc_approx_detail_len(dims[1], lev - 1, &region[1], &d);
       cdf_lift_axis(buf, dims, 1, region, 0, &c, tmp);
@@ -1986,7 +2011,8 @@ static int chunk_decompress_impl(int two_d, const uint8_t* stream, size_t len,
 {
   const size_t n = dims[0] * dims[1] * dims[2];
   size_t res[16][3];
-  const size_t nres = hier ? orc_coarsened_resolutions(dims, res, 16) : 0;
+  const size_t nres = !hier ? 0 : two_d ? orc_coarsened_resolutions_2d(dims, res, 16)
+                                         : orc_coarsened_resolutions(dims, res, 16);
   if (len < 17)
     return 1; /* WrongLength */
   if (stream[0] & 0x01) {
@@ -2102,6 +2128,37 @@ int orc_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx
   }
   else
     *dst = outd;
+  return 0;
+}
+
+/* SPECK2D_FLT::decompress(multi_res = true), src/SPECK_FLT.cpp:543-606 with
+ * src/SPECK2D_FLT.cpp:52-58: besides the slice (doubles), the slice at every coarsened resolution,
+ * coarsest first, mean added back.  level_dims: x y per level; levels[h] is malloc'd. */
+int orc_decomp_2d_multi_res(const void* src, size_t src_len, size_t dimx, size_t dimy, void** dst,
+                            size_t* nlev, size_t* level_dims, double** levels)
+{
+  if (*dst != NULL)
+    return 1;
+  const size_t n = dimx * dimy, dims[3] = {dimx, dimy, 1};
+  size_t res[16][3];
+  const size_t nres = orc_coarsened_resolutions_2d(dims, res, 16);
+  if (nres > 16)
+    return -1;
+  for (size_t h = 0; h < nres; h++) {
+    level_dims[2 * h] = res[h][0];
+    level_dims[2 * h + 1] = res[h][1];
+    levels[h] = (double*)malloc(res[h][0] * res[h][1] * sizeof(double));
+  }
+  double* outd = (double*)malloc(n * sizeof(double));
+  double* none = NULL;
+  if (chunk_decompress_impl(1, (const uint8_t*)src, src_len, dims, outd, nres ? levels : &none)) {
+    free(outd);
+    for (size_t h = 0; h < nres; h++)
+      free(levels[h]);
+    return -1;
+  }
+  *nlev = nres;
+  *dst = outd;
   return 0;
 }
 

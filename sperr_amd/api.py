@@ -23,6 +23,7 @@ EXPORTS = [
     "sperrhip_multires_levels", "sperrhip_decompress_multires_dev", "sperrhip_decomp_3d_multires",
     "sperr_comp_2d", "sperr_decomp_2d", "sperrhip_max_compressed_size_2d", "sperrhip_compress_2d_dev",
     "sperrhip_decompress_2d_dev", "sperrhip_version", "sperrhip_debug_lis_stamps",
+    "sperrhip_multires_levels_2d", "sperrhip_decompress_2d_multires_dev", "sperrhip_decomp_2d_multires",
 ]
 
 
@@ -300,6 +301,36 @@ class SperrHip:
                                                         ptrs, self._stream())
         if rtn != 0:
             raise SperrHipError(f"sperrhip_decompress_multires_dev returned {rtn}")
+        return out, levels
+
+    def multires_levels_2d(self, shape_yx):
+        """[(y, x) of every coarsened level of a slice], coarsest first."""
+        dy, dx = shape_yx
+        nlev = _sz(0)
+        dims = (_sz * 32)()
+        self.lib.sperrhip_multires_levels_2d.argtypes = [_sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]
+        if self.lib.sperrhip_multires_levels_2d(dx, dy, C.byref(nlev), dims) != 0:
+            raise SperrHipError("sperrhip_multires_levels_2d failed")
+        return [(dims[2 * h + 1], dims[2 * h]) for h in range(nlev.value)]
+
+    def decompress_2d_multires(self, stream, shape_yx, output_float=True):
+        """-> (slice, [float64 level slices, coarsest first]); SPECK2D_FLT::decompress(true)."""
+        torch = self.torch
+        dy, dx = shape_yx
+        stream = stream.contiguous()
+        lv = self.multires_levels_2d(shape_yx)
+        out = torch.empty((dy, dx), dtype=torch.float32 if output_float else torch.float64,
+                          device=stream.device)
+        levels = [torch.empty(s, dtype=torch.float64, device=stream.device) for s in lv]
+        ptrs = (C.c_void_p * max(1, len(lv)))(*[t.data_ptr() for t in levels])
+        self.lib.sperrhip_decompress_2d_multires_dev.argtypes = [C.c_void_p, _sz, C.c_int, _sz, _sz, C.c_void_p,
+                                                                 _sz, _sz, C.c_void_p, C.c_void_p]
+        rtn = self.lib.sperrhip_decompress_2d_multires_dev(stream.data_ptr(), stream.numel(), int(output_float),
+                                                           dx, dy, out.data_ptr(),
+                                                           out.numel() * out.element_size(), len(lv), ptrs,
+                                                           self._stream())
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decompress_2d_multires_dev returned {rtn}")
         return out, levels
 
     # ---- profiling ------------------------------------------------------------------------

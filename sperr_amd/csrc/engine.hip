@@ -1549,6 +1549,17 @@ int multires_levels(const Dims& vol, const Dims& cdim, MultiRes& m)
   return 0;
 }
 
+// a slice: one level per level of dwt2d (src/sperr_helper.cpp:86-95, src/CDF97.cpp:114-130)
+void multires_levels_2d(size_t dx, size_t dy, MultiRes& m)
+{
+  const size_t levels = std::min<size_t>(spk::num_of_xforms(std::min(dx, dy)), 16);
+  m.grid = {1, 1, 1};
+  for (size_t lev = levels; lev > 0; lev--)
+    m.cres[levels - lev] = {(uint32_t)spk::approx_detail_len(dx, lev)[0],
+                            (uint32_t)spk::approx_detail_len(dy, lev)[0], 1u};
+  m.nlev = levels;
+}
+
 // the approximation corner of every chunk (src/CDF97.cpp:150-168,581-593), mean added back
 // (src/SPECK_FLT.cpp:592-603), placed at the chunk's position in the level's volume
 __global__ void __launch_bounds__(kThreads)
@@ -1828,21 +1839,28 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         for (uint32_t i = 0; i < nb; i++)
           batchOutliers |= outHead[g.second[first + i].gid].has;
         const bool fxy = fuse_xy(*P) && !batchOutliers;
+        // a level of the inverse transform is 3 passes (z y x) of a dyadic chunk, 2 (y x) of a slice
+        const size_t perLevel = slice ? 2 : 3;
+        auto sub_volume = [&](size_t k) -> int {   // before pass k, the first of its level
+          const size_t h = mr->nlev - (k / perLevel + 1);
+          const auto& r = mr->cres[h];
+          const uint32_t blocks = capped_blocks((r[0] * r[1] * r[2] + kThreads - 1) / kThreads, nb);
+          LAUNCH_K(k_sub_volume, dim3(blocks, nb), dim3(kThreads), 0, ss, bb.vals, bb.valsStride,
+                   d.cst, bb.geom, cd[0], cd[1], cd[0], cd[1], cd[2], r[0], r[1], r[2],
+                   mr->grid[0], mr->grid[1], mr->d_level[h]);
+          return 0;
+        };
         for (size_t k = P->fwd.size(); k-- > (fxy ? 2u : 0u);) {
           const LiftPass& ps = P->fwd[k];
-          if (mr && mr->nlev && k % 3 == 2) {   // a level of the inverse transform starts
-            const size_t h = mr->nlev - (k / 3 + 1);
-            const auto& r = mr->cres[h];
-            const uint32_t blocks = capped_blocks((r[0] * r[1] * r[2] + kThreads - 1) / kThreads, nb);
-            LAUNCH_K(k_sub_volume, dim3(blocks, nb), dim3(kThreads), 0, ss, bb.vals, bb.valsStride,
-                     d.cst, bb.geom, cd[0], cd[1], cd[0], cd[1], cd[2], r[0], r[1], r[2],
-                     mr->grid[0], mr->grid[1], mr->d_level[h]);
-          }
+          if (mr && mr->nlev && k % perLevel == perLevel - 1 && sub_volume(k))
+            return -1;
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
                           (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
                           d_dst, vd, bb.geom))
             return -1;
         }
+        if (fxy && mr && mr->nlev && slice && sub_volume(1))   // the finest level of a slice is the fused pair
+          return -1;
         if (fxy && launch_lift_xy(ss, false, bb.vals, bb.valsStride, nb, cd, d.cst,
                                   std::is_same<T, float>::value ? 1 : 2, d_dst, vd, bb.geom))
           return -1;
@@ -2690,6 +2708,118 @@ int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int m
 }
 
 // include/SPERR_C_API.h:75-81, src/SPERR_C_API.cpp:99-134
+int sperrhip_multires_levels_2d(size_t dimx, size_t dimy, size_t* nlev, size_t* level_dims)
+{
+  return guarded("sperrhip_multires_levels_2d", [&]() -> int {
+    if (!nlev || !level_dims || dimx == 0 || dimy == 0 || dimx > 0xffff || dimy > 0xffff)
+      return -1;
+    MultiRes m;
+    multires_levels_2d(dimx, dimy, m);
+    *nlev = m.nlev;
+    for (size_t h = 0; h < m.nlev; h++) {
+      level_dims[2 * h] = m.cres[h][0];
+      level_dims[2 * h + 1] = m.cres[h][1];
+    }
+    return 0;
+  });
+}
+
+int sperrhip_decompress_2d_multires_dev(const void* d_src, size_t src_len, int output_float, size_t dimx,
+                                        size_t dimy, void* d_dst, size_t dst_cap_bytes, size_t nlev,
+                                        double* const* d_levels, void* hip_stream)
+{
+  return guarded("sperrhip_decompress_2d_multires_dev", [&]() -> int {
+    if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17 || (nlev && !d_levels))
+      return -1;
+    std::lock_guard<std::mutex> lock(g_engine.mu);
+    if (g_engine.init())
+      return -1;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    MultiRes m;
+    multires_levels_2d(dimx, dimy, m);
+    if (m.nlev != nlev)
+      return -1;   // (sperrhip_multires_levels_2d tells how many there are)
+    for (size_t h = 0; h < nlev; h++) {
+      if (!d_levels[h])
+        return -1;
+      m.d_level[h] = d_levels[h];
+    }
+    ContainerInfo ci;
+    ci.vol = {dimx, dimy, 1};
+    ci.chunk = ci.vol;
+    ci.is_float = output_float != 0;
+    ci.off = {0};
+    ci.len = {src_len};
+    if (output_float)
+      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+                                    static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st, &m,
+                                    true);
+    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+                                   static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st, &m,
+                                   true);
+  });
+}
+
+int sperrhip_decomp_2d_multires(const void* src, size_t src_len, int output_float, size_t dimx,
+                                size_t dimy, void** dst, size_t* nlev, size_t* level_dims, double** levels)
+{
+  return guarded("sperrhip_decomp_2d_multires", [&]() -> int {
+    if (!dst || *dst != nullptr)
+      return 1;
+    if (src_len < 17 || !nlev || !level_dims || !levels ||
+        sperrhip_multires_levels_2d(dimx, dimy, nlev, level_dims))
+      return -1;
+    const size_t n = dimx * dimy, esz = output_float ? 4 : 8;
+    std::vector<void*> dev;
+    auto release = [&]() {
+      for (void* p : dev)
+        (void)hipFree(p);
+    };
+    auto dalloc = [&](size_t bytes) -> void* {
+      void* p = nullptr;
+      if (hipMalloc(&p, bytes) != hipSuccess)
+        return nullptr;
+      dev.push_back(p);
+      return p;
+    };
+    void* d_in = dalloc(src_len);
+    void* d_out = dalloc(n * esz);
+    std::vector<double*> d_lv(*nlev, nullptr);
+    std::vector<size_t> lvn(*nlev, 0);
+    bool ok = d_in && d_out;
+    for (size_t h = 0; ok && h < *nlev; h++) {
+      lvn[h] = level_dims[2 * h] * level_dims[2 * h + 1];
+      d_lv[h] = static_cast<double*>(dalloc(lvn[h] * 8));
+      ok = d_lv[h] != nullptr;
+    }
+    if (!ok) {
+      fprintf(stderr, "[sperr_hip] device allocation failed\n");
+      release();
+      return -1;
+    }
+    int rtn = -1;
+    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+      rtn = sperrhip_decompress_2d_multires_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, *nlev,
+                                                d_lv.data(), nullptr);
+    if (rtn == 0) {
+      void* buf = malloc(n * esz);
+      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+        *dst = buf;
+      else {
+        free(buf);
+        rtn = -1;
+      }
+      for (size_t h = 0; rtn == 0 && h < *nlev; h++) {
+        levels[h] = static_cast<double*>(malloc(lvn[h] * 8));
+        if (!levels[h] || hipMemcpy(levels[h], d_lv[h], lvn[h] * 8, hipMemcpyDeviceToHost) != hipSuccess)
+          rtn = -1;
+      }
+    }
+    release();
+    return rtn;
+  });
+}
+
 int sperr_decomp_2d(const void* src, size_t src_len, int output_float, size_t dimx, size_t dimy,
                     void** dst)
 {

@@ -164,6 +164,13 @@ def test_sperr2d_files_match_the_oracle(tools, oracle, tmp_path, ftype, mode, fl
     dec = oracle.decomp_2d(want[10:], img.shape, False)
     assert (tmp_path / "c.f64").read_bytes() == dec.tobytes()
     assert f"Bitrate = {len(want) * 8 / img.size:.2f}" in out
-    rc, out, err = run(tools, "sperr2d", bs, "-d", "--decomp_f", tmp_path / "d.f32")
+    rc, out, err = run(tools, "sperr2d", bs, "-d", "--decomp_f", tmp_path / "d.f32", "--decomp_lowres_d",
+                       tmp_path / "low", "--decomp_lowres_f", tmp_path / "lowf")
     assert rc == 0, out + err
     assert (tmp_path / "d.f32").read_bytes() == dec.astype(np.float32).tobytes()
+    _, levels = oracle.decomp_2d_multi_res(want[10:], img.shape)
+    assert len(levels) == 3
+    for lv in levels:
+        y, x = lv.shape
+        assert (tmp_path / f"low.{x}x{y}").read_bytes() == lv.tobytes()
+        assert (tmp_path / f"lowf.{x}x{y}").read_bytes() == lv.astype(np.float32).tobytes()

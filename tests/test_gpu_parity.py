@@ -494,6 +494,55 @@ def test_2d_host_c_api_and_truncated_stream(eng, oracle):
         assert np.array_equal(bits(got.copy()), bits(oracle.decomp_2d(part, (80, 120), False)))
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (37, 50), (9, 200), (150, 11), (7, 7), (200, 333), (1024, 256)])
+@pytest.mark.parametrize("mode,quality", [(1, 3.0), (2, 90.0), (3, 1e-3)])
+def test_2d_multi_resolution_decode(eng, oracle, shape, mode, quality):
+    """SPECK2D_FLT::decompress(multi_res = true): the slice at every coarsened resolution, coarsest
+    first, full and truncated streams, float and double slices; the level shapes; a constant slice."""
+    img = turbulence((1,) + shape, dtype=np.float64 if mode == 3 else np.float32)[0]
+    stream = oracle.comp_2d(img, mode, quality, False)
+    for cut in (len(stream), max(27, len(stream) * 2 // 5)):
+        want, want_lv = oracle.decomp_2d_multi_res(stream[:cut], shape)
+        dev = cuda(np.frombuffer(stream[:cut], dtype=np.uint8))
+        assert eng.multires_levels_2d(shape) == [x.shape for x in want_lv]
+        for as_float in (True, False):
+            got, got_lv = eng.decompress_2d_multires(dev, shape, as_float)
+            ref_vol = want.astype(np.float32) if as_float else want
+            assert np.array_equal(bits(got.cpu().numpy()), bits(ref_vol))
+            assert len(got_lv) == len(want_lv)
+            for a, b in zip(got_lv, want_lv):
+                assert np.array_equal(bits(a.cpu().numpy()), bits(b))
+    flat = np.full(shape, 2.5, dtype=np.float32)
+    s = oracle.comp_2d(flat, 1, 2.0, False)
+    got, got_lv = eng.decompress_2d_multires(cuda(np.frombuffer(s, dtype=np.uint8)), shape, False)
+    assert np.all(got.cpu().numpy() == 2.5) and all(np.all(a.cpu().numpy() == 2.5) for a in got_lv)
+
+
+def test_2d_multi_resolution_host_api(eng, oracle):
+    import ctypes as C
+    shape = (90, 141)
+    img = turbulence((1,) + shape)[0]
+    stream = oracle.comp_2d(img, 1, 4.0, False)
+    want, want_lv = oracle.decomp_2d_multi_res(stream, shape)
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    dst, nlev = C.c_void_p(None), C.c_size_t(0)
+    ldims, levels = (C.c_size_t * 32)(), (C.c_void_p * 16)()
+    f = eng.lib.sperrhip_decomp_2d_multires
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p),
+                  C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
+    assert f(buf.ctypes.data, buf.size, 0, shape[1], shape[0], C.byref(dst), C.byref(nlev), ldims, levels) == 0
+    assert nlev.value == len(want_lv)
+    got = np.frombuffer(C.string_at(dst.value, want.size * 8), dtype=np.float64).reshape(shape)
+    assert np.array_equal(bits(got.copy()), bits(want))
+    for h, lv in enumerate(want_lv):
+        assert (ldims[2 * h + 1], ldims[2 * h]) == lv.shape
+        a = np.frombuffer(C.string_at(levels[h], lv.size * 8), dtype=np.float64).reshape(lv.shape)
+        assert np.array_equal(bits(a.copy()), bits(lv))
+        C.CDLL(None).free(C.c_void_p(levels[h]))
+    assert f(buf.ctypes.data, buf.size, 0, shape[1], shape[0], C.byref(dst), C.byref(nlev), ldims, levels) == 1
+    C.CDLL(None).free(dst)
+
+
 def test_many_chunks_decode_in_sub_batches(eng, oracle):
     """48 chunks of one shape: the decoder splits the batch into sub-batches on separate streams
     (engine.hip, decompress_impl); same values as the oracle."""

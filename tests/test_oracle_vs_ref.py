@@ -141,6 +141,24 @@ def test_2d_slices_bit_exact(oracle, ref, shape, mode, quality):
                                   bits(ref.decomp_2d(body, shape, as_float)))
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (37, 50), (96, 121), (9, 200), (150, 11), (7, 7), (100, 128)])
+@pytest.mark.parametrize("mode,quality", [(1, 3.0), (2, 90.0), (3, 1e-3)])
+def test_2d_multi_resolution_bit_exact(oracle, ref, shape, mode, quality):
+    """SPECK2D_FLT::decompress(multi_res = true) (src/SPECK2D_FLT.cpp:52-58, src/CDF97.cpp:114-130,
+    src/SPECK_FLT.cpp:592-603): the slice and the slice at every coarsened resolution, full and
+    truncated streams."""
+    img = turbulence((1,) + shape, dtype=np.float64 if mode == 3 else np.float32)[0]
+    stream = ref.comp_2d(img, mode, quality, False)
+    for cut in (len(stream), max(27, len(stream) * 2 // 5)):
+        a, la = oracle.decomp_2d_multi_res(stream[:cut], shape)
+        b, lb = ref.decomp_2d_multi_res(stream[:cut], shape)
+        assert np.array_equal(bits(a), bits(b))
+        assert np.array_equal(bits(a), bits(ref.decomp_2d(stream[:cut], shape, False)))
+        assert [x.shape for x in la] == [x.shape for x in lb]
+        for x, y in zip(la, lb):
+            assert np.array_equal(bits(x), bits(y))
+
+
 def test_speck1d_bit_exact(oracle, ref):
     """SPECK1D_INT_ENC / _DEC (src/SPECK1D_INT*.cpp) on sparse arrays: same stream, and it
     round-trips exactly through both decoders."""
