@@ -4,7 +4,9 @@
 //
 //     /root/reference/include/SPERR3D_OMP_C.h:14-35   (sperr::SPERR3D_OMP_C)
 //     /root/reference/include/SPERR3D_OMP_D.h:15-32   (sperr::SPERR3D_OMP_D)
-//     /root/reference/include/SPECK_FLT.h:17-65       (sperr::SPECK3D_FLT, the per-chunk pipeline)
+//     /root/reference/include/SPECK_FLT.h:17-65       (sperr::SPECK3D_FLT, the per-chunk pipeline;
+//                                                      sperr::SPECK2D_FLT, one slice)
+//     /root/reference/include/SPERR3D_Stream_Tools.h:11-66 (SPERR3D_Header, SPERR3D_Stream_Tools)
 //     /root/reference/include/sperr_helper.h:35,54-64 (dims_type, vec8_type, vecd_type, RTNType)
 //
 // compiles unchanged when it includes this header instead and links -lsperr_hip.  The chunk
@@ -17,7 +19,9 @@
 #include <array>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "sperr_hip.h"
@@ -200,7 +204,7 @@ class SPECK3D_FLT {
   }
   auto decompress(bool multi_res = false) -> RTNType
   {
-    if (multi_res || m_stream.empty())
+    if (m_stream.empty())
       return RTNType::Error;
     // wrap the chunk stream into a single-chunk container (double output)
     vec8_type c(18 + m_stream.size());
@@ -213,13 +217,26 @@ class SPECK3D_FLT {
     std::memcpy(c.data() + 18, m_stream.data(), m_stream.size());
     void* dst = nullptr;
     size_t dx, dy, dz;
-    if (sperr_decomp_3d(c.data(), c.size(), 0, 0, &dx, &dy, &dz, &dst) != 0)
+    m_hierarchy.clear();
+    if (multi_res) {   // a chunk that is not dyadic has no hierarchy (src/CDF97.cpp:150-168)
+      size_t nlev = 0, ld[48];
+      double* lv[16] = {};
+      if (sperrhip_decomp_3d_multires(c.data(), c.size(), 0, &dx, &dy, &dz, &dst, &nlev, ld, lv) != 0)
+        return RTNType::Error;
+      for (size_t h = 0; h < nlev; h++) {
+        m_hierarchy.emplace_back(lv[h], lv[h] + ld[3 * h] * ld[3 * h + 1] * ld[3 * h + 2]);
+        std::free(lv[h]);
+      }
+    }
+    else if (sperr_decomp_3d(c.data(), c.size(), 0, 0, &dx, &dy, &dz, &dst) != 0)
       return RTNType::Error;
     const auto* d = static_cast<const double*>(dst);
     m_vals.assign(d, d + dx * dy * dz);
     std::free(dst);
     return RTNType::Good;
   }
+  auto view_hierarchy() const -> const std::vector<vecd_type>& { return m_hierarchy; }
+  auto release_hierarchy() -> std::vector<vecd_type>&& { return std::move(m_hierarchy); }
   auto view_decoded_data() const -> const vecd_type& { return m_vals; }
   auto release_decoded_data() -> vecd_type&& { return std::move(m_vals); }
 
@@ -229,6 +246,184 @@ class SPECK3D_FLT {
   dims_type m_dims = {0, 0, 0};
   vecd_type m_vals;
   vec8_type m_stream;
+  std::vector<vecd_type> m_hierarchy;
+};
+
+// ---- src/SPECK_FLT.cpp + src/SPECK2D_FLT.cpp: one slice, dims = {x, y, 1} ------------------------
+// The stream is the one sperr_comp_2d produces without its 10-byte header (src/SPERR_C_API.cpp:7-83).
+class SPECK2D_FLT {
+ public:
+  template <typename T>
+  void copy_data(const T* p, size_t len) { m_vals.assign(p, p + len); }
+  void take_data(vecd_type&& buf) { m_vals = std::move(buf); }
+  void set_dims(dims_type d) { m_dims = d; }
+  void set_bitrate(double bpp) { m_mode = CompMode::Rate; m_quality = bpp; }
+  void set_psnr(double v) { m_mode = CompMode::PSNR; m_quality = v; }
+  void set_tolerance(double v) { m_mode = CompMode::PWE; m_quality = v; }
+
+  auto compress() -> RTNType
+  {
+    if (m_dims[2] != 1 || m_vals.empty() || m_vals.size() != m_dims[0] * m_dims[1])
+      return RTNType::Error;
+    if (m_mode == CompMode::Unknown)
+      return RTNType::CompModeUnknown;
+    const int mode = m_mode == CompMode::Rate ? 1 : m_mode == CompMode::PSNR ? 2 : 3;
+    void* dst = nullptr;
+    size_t len = 0;
+    if (sperr_comp_2d(m_vals.data(), 0, m_dims[0], m_dims[1], mode, m_quality, 0, &dst, &len) != 0)
+      return RTNType::Error;
+    const auto* u8 = static_cast<const uint8_t*>(dst);
+    m_stream.assign(u8, u8 + len);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  void append_encoded_bitstream(vec8_type& buf) const
+  {
+    buf.insert(buf.end(), m_stream.begin(), m_stream.end());
+  }
+  auto use_bitstream(const void* p, size_t len) -> RTNType
+  {
+    if (len < 17)
+      return RTNType::WrongLength;
+    const auto* u8 = static_cast<const uint8_t*>(p);
+    m_stream.assign(u8, u8 + len);
+    return RTNType::Good;
+  }
+  auto decompress(bool multi_res = false) -> RTNType
+  {
+    if (m_stream.empty() || m_dims[2] != 1)
+      return RTNType::Error;
+    void* dst = nullptr;
+    m_hierarchy.clear();
+    if (multi_res) {
+      size_t nlev = 0, ld[32];
+      double* lv[16] = {};
+      if (sperrhip_decomp_2d_multires(m_stream.data(), m_stream.size(), 0, m_dims[0], m_dims[1], &dst, &nlev,
+                                      ld, lv) != 0)
+        return RTNType::Error;
+      for (size_t h = 0; h < nlev; h++) {
+        m_hierarchy.emplace_back(lv[h], lv[h] + ld[2 * h] * ld[2 * h + 1]);
+        std::free(lv[h]);
+      }
+    }
+    else if (sperr_decomp_2d(m_stream.data(), m_stream.size(), 0, m_dims[0], m_dims[1], &dst) != 0)
+      return RTNType::Error;
+    const auto* d = static_cast<const double*>(dst);
+    m_vals.assign(d, d + m_dims[0] * m_dims[1]);
+    std::free(dst);
+    return RTNType::Good;
+  }
+  auto view_decoded_data() const -> const vecd_type& { return m_vals; }
+  auto release_decoded_data() -> vecd_type&& { return std::move(m_vals); }
+  auto view_hierarchy() const -> const std::vector<vecd_type>& { return m_hierarchy; }
+  auto release_hierarchy() -> std::vector<vecd_type>&& { return std::move(m_hierarchy); }
+
+ private:
+  CompMode m_mode = CompMode::Unknown;
+  double m_quality = 0.0;
+  dims_type m_dims = {0, 0, 0};
+  vecd_type m_vals;
+  vec8_type m_stream;
+  std::vector<vecd_type> m_hierarchy;
+};
+
+// ---- include/SPERR3D_Stream_Tools.h:11-66, src/SPERR3D_Stream_Tools.cpp ---------------------------
+struct SPERR3D_Header {
+  uint8_t major_version = 0;
+  bool is_portion = false;
+  bool is_3D = false;
+  bool is_float = false;
+  bool multi_chunk = false;
+  dims_type vol_dims = {0, 0, 0};
+  dims_type chunk_dims = {0, 0, 0};
+  size_t header_len = 0;
+  size_t stream_len = 0;
+  std::vector<size_t> chunk_offsets;   // (offset, length) of every chunk
+};
+
+class SPERR3D_Stream_Tools {
+ public:
+  auto get_header_len(std::array<uint8_t, 20> magic) const -> size_t
+  {
+    const bool multi = (magic[1] & 0x10) != 0;
+    dims_type v, c;
+    m_dims_of(magic.data(), multi, v, c);
+    return (multi ? 20 : 14) + 4 * m_num_chunks(v, c);
+  }
+  auto get_stream_header(const void* p) const -> SPERR3D_Header
+  {
+    SPERR3D_Header h;
+    const auto* u8 = static_cast<const uint8_t*>(p);
+    h.major_version = u8[0];
+    h.is_portion = (u8[1] & 0x80) != 0;   // pack_8_booleans: bool i at bit 7 - i
+    h.is_3D = (u8[1] & 0x40) != 0;
+    h.is_float = (u8[1] & 0x20) != 0;
+    h.multi_chunk = (u8[1] & 0x10) != 0;
+    m_dims_of(u8, h.multi_chunk, h.vol_dims, h.chunk_dims);
+    const size_t n = m_num_chunks(h.vol_dims, h.chunk_dims), at = h.multi_chunk ? 20 : 14;
+    h.header_len = at + 4 * n;
+    h.chunk_offsets.resize(2 * n);
+    size_t off = h.header_len;
+    for (size_t i = 0; i < n; i++) {
+      uint32_t l;
+      std::memcpy(&l, u8 + at + 4 * i, 4);
+      h.chunk_offsets[2 * i] = off;
+      h.chunk_offsets[2 * i + 1] = l;
+      off += l;
+    }
+    h.stream_len = off;
+    return h;
+  }
+  // keep `pct` percent of every chunk (at least 64 bytes of each); an empty vector on failure
+  auto progressive_truncate(const void* stream, size_t stream_len, unsigned pct) const -> vec8_type
+  {
+    vec8_type out;
+    void* dst = nullptr;
+    size_t len = 0;
+    if (sperr_trunc_3d(stream, stream_len, pct, &dst, &len) == 0) {
+      const auto* u8 = static_cast<const uint8_t*>(dst);
+      out.assign(u8, u8 + len);
+      std::free(dst);
+    }
+    return out;
+  }
+  auto progressive_read(const std::string& filename, unsigned pct) const -> vec8_type
+  {
+    vec8_type whole;
+    if (std::FILE* f = std::fopen(filename.c_str(), "rb")) {
+      uint8_t buf[1 << 16];
+      for (size_t got; (got = std::fread(buf, 1, sizeof(buf), f)) > 0;)
+        whole.insert(whole.end(), buf, buf + got);
+      std::fclose(f);
+    }
+    return whole.size() < 18 ? vec8_type() : progressive_truncate(whole.data(), whole.size(), pct);
+  }
+
+ private:
+  static void m_dims_of(const uint8_t* u8, bool multi, dims_type& v, dims_type& c)
+  {
+    uint32_t v3[3];
+    std::memcpy(v3, u8 + 2, 12);
+    v = {v3[0], v3[1], v3[2]};
+    c = v;
+    if (multi) {
+      uint16_t c3[3];
+      std::memcpy(c3, u8 + 14, 6);
+      c = {c3[0], c3[1], c3[2]};
+    }
+  }
+  // src/sperr_helper.cpp:542-592: a remainder longer than half a chunk becomes a chunk of its own
+  static auto m_num_chunks(const dims_type& v, const dims_type& c) -> size_t
+  {
+    size_t n = 1;
+    for (int a = 0; a < 3; a++) {
+      size_t seg = c[a] ? v[a] / c[a] : 0;
+      if (c[a] && v[a] % c[a] > c[a] / 2)
+        seg++;
+      n *= seg ? seg : 1;
+    }
+    return n;
+  }
 };
 
 }  // namespace sperr

@@ -22,11 +22,17 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_cpp_mirror_header_compiles():
-    """include/sperr_hip.hpp (SPERR3D_OMP_C / _D / SPECK3D_FLT mirrors) is valid C++17."""
+    """include/sperr_hip.hpp (SPERR3D_OMP_C / _D, SPECK3D_FLT, SPECK2D_FLT, SPERR3D_Stream_Tools
+    mirrors) is valid C++17; tests/cpp/mirror_check.cpp, which drives all of them, compiles."""
     src = '#include "sperr_hip.hpp"\nint main(){ sperr::SPERR3D_OMP_C c; c.set_bitrate(2.0); ' \
-          'sperr::SPERR3D_OMP_D d; sperr::SPECK3D_FLT f; f.set_dims({8,8,8}); return 0; }\n'
+          'sperr::SPERR3D_OMP_D d; sperr::SPECK3D_FLT f; f.set_dims({8,8,8}); ' \
+          'sperr::SPECK2D_FLT g; g.set_dims({8,8,1}); sperr::SPERR3D_Stream_Tools t; ' \
+          'sperr::SPERR3D_Header h; (void)t; (void)h; return 0; }\n'
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                     "-x", "c++", "-"], input=src.encode(), check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I",
+                    os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_check.cpp")],
+                   check=True)
 
 
 def test_no_gpu_means_loud_failure():

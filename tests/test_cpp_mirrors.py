@@ -1,0 +1,64 @@
+"""include/sperr_hip.hpp: the C++ mirrors of the reference's classes (SPERR3D_OMP_C / _D,
+SPECK3D_FLT, SPECK2D_FLT, SPERR3D_Stream_Tools), driven by tests/cpp/mirror_check.cpp on the GPU;
+everything they produce has to be what the oracle produces."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from sperr_amd.synth import turbulence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint64)
+
+
+def test_mirror_classes_match_the_oracle(oracle, tmp_path):
+    from sperr_amd import api
+    exe = tmp_path / "mirror_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "mirror_check.cpp"), "-o", str(exe),
+                           "-L" + os.path.dirname(api.LIB_PATH), "-lsperr_hip", "-L/opt/rocm/lib",
+                           "-Wl,-rpath," + os.path.dirname(api.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"])
+    dims, chunks = (64, 64, 32), (32, 32, 32)    # x y z
+    v = turbulence(dims[::-1])
+    v.tofile(tmp_path / "vol.f32")
+    p = subprocess.run([str(exe), str(tmp_path / "vol.f32"), *map(str, dims), *map(str, chunks), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+    def data(name, dtype=np.float64):
+        return np.fromfile(tmp_path / name, dtype=dtype)
+
+    rate = oracle.comp_3d(v, chunks, 1, 2.5)
+    assert (tmp_path / "omp_c_mode1").read_bytes() == rate
+    assert (tmp_path / "omp_c_mode2").read_bytes() == oracle.comp_3d(v, chunks, 2, 80.0)
+    assert (tmp_path / "omp_c_mode3").read_bytes() == oracle.comp_3d(v, chunks, 3, 1e-2)
+    vol, levels = oracle.decomp_3d_multi_res(rate)
+    assert np.array_equal(bits(data("omp_d_vol")), bits(vol.ravel()))
+    assert len(levels) == 2
+    for l, lv in enumerate(levels):
+        assert np.array_equal(bits(data(f"omp_d_level{l}")), bits(lv.ravel()))
+    assert (tmp_path / "trunc30").read_bytes() == oracle.trunc_3d(rate, 30)
+
+    # SPECK3D_FLT: a chunk stream is the single-chunk container minus its 18-byte header
+    corner = np.ascontiguousarray(v[:32, :32, :32]).astype(np.float64)
+    single = oracle.comp_3d(corner, (32, 32, 32), 3, 1e-3)
+    assert (tmp_path / "speck3d_flt_stream").read_bytes() == single[18:]
+    cvol, clevels = oracle.decomp_3d_multi_res(single)
+    assert np.array_equal(bits(data("speck3d_flt_vol")), bits(cvol.ravel()))
+    for l, lv in enumerate(clevels):
+        assert np.array_equal(bits(data(f"speck3d_flt_level{l}")), bits(lv.ravel()))
+
+    img = np.ascontiguousarray(v[0])
+    s2 = oracle.comp_2d(img, 2, 90.0, False)
+    assert (tmp_path / "speck2d_flt_stream").read_bytes() == s2
+    slice_, slevels = oracle.decomp_2d_multi_res(s2, img.shape)
+    assert np.array_equal(bits(data("speck2d_flt_slice")), bits(slice_.ravel()))
+    assert len(slevels) == 3
+    for l, lv in enumerate(slevels):
+        assert np.array_equal(bits(data(f"speck2d_flt_level{l}")), bits(lv.ravel()))
