@@ -387,12 +387,70 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
 // exactly (the symmetric boundary rule only ever refers to rows of the slice itself).  Every
 // sample goes through the very same operations as in k_lift_axis; halo rows are recomputed by the
 // neighbouring tiles.  Saves one full read + write of the fp64 buffer per direction.
-//   x direction: threads = (row, slice of the row), lifting steps separated by barriers;
-//   y direction: one thread per column, all steps in sequence, no barrier.
+// The lifting itself runs in registers (lift16): the first version kept every intermediate in LDS
+// and was bound by LDS bandwidth (about 40 eight-byte LDS accesses per sample against 12 bytes of
+// HBM traffic); now a sample costs about 6.
 // ------------------------------------------------------------------------------------------
 constexpr int kXYHalo = 4;
-constexpr int kXYThreads = 1024;
-constexpr int kXYSplit = 4;        // threads per column in the y direction
+constexpr int kXYThreads = 512;    // two workgroups per CU (LDS) = 4 waves per SIMD: 128 VGPRs each
+constexpr int kStage = 16;         // global loads a lane has in flight while staging
+constexpr int kSeg = 8;            // samples a thread produces per pass (plus 4 + 4 halo = 16 registers)
+
+// position q of the whole-sample symmetric extension of a signal of n >= 2 samples
+__device__ __forceinline__ uint32_t reflect_index(int q, int n)
+{
+  const int period = 2 * (n - 1);
+  q = q < 0 ? -q : q;
+  if (q >= period)
+    q %= period;
+  return (uint32_t)(q < n ? q : period - q);
+}
+
+// The lifting steps of QccWAVCDF97AnalysisSymmetric / SynthesisSymmetric (src/CDF97.cpp:598-666) on
+// 16 consecutive samples r[0..16) of the symmetrically extended signal, r[0] at an even position:
+// r[4..12) come out exactly as the whole-signal loops compute them -- a step reaches one sample to
+// each side, the extension is symmetric about the first and the last sample and a + b == b + a, so
+// the mirrored copies stay equal to the samples the reference's clamped indices refer to.
+template <bool FORWARD>
+__device__ __forceinline__ void lift16(double (&r)[16], const LiftConsts& K)
+{
+  if (FORWARD) {
+#pragma unroll
+    for (int k = 1; k <= 13; k += 2)
+      r[k] = fma(K.alpha, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 2; k <= 12; k += 2)
+      r[k] = fma(K.beta, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 3; k <= 11; k += 2)
+      r[k] = fma(K.gamma, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 4; k <= 10; k += 2)
+      r[k] = K.eps * fma(K.delta, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 5; k <= 11; k += 2)
+      r[k] = (-K.inv_eps) * r[k];
+  }
+  else {
+#pragma unroll
+    for (int k = 1; k <= 15; k += 2)
+      r[k] = (-K.eps) * r[k];
+#pragma unroll
+    for (int k = 2; k <= 14; k += 2) {
+      const double t = K.delta * (r[k - 1] + r[k + 1]);
+      r[k] = fma(r[k], K.inv_eps, -t);
+    }
+#pragma unroll
+    for (int k = 3; k <= 13; k += 2)
+      r[k] = fma(-K.gamma, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 4; k <= 12; k += 2)
+      r[k] = fma(-K.beta, r[k - 1] + r[k + 1], r[k]);
+#pragma unroll
+    for (int k = 5; k <= 11; k += 2)
+      r[k] = fma(-K.alpha, r[k - 1] + r[k + 1], r[k]);
+  }
+}
 
 template <bool FORWARD, int IO>
 __global__ void __launch_bounds__(kXYThreads)
@@ -413,8 +471,7 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
   const uint32_t yend = min(cy, y0 + R);                // rows [y0, yend) are this tile's output
   const uint32_t nrow = yhi - ylo;
   const uint32_t RS = cx + 1;                           // row stride in LDS
-  const uint32_t xe = cx - cx / 2, xo = cx / 2;         // even / odd samples of a row
-  const uint32_t ye = cy - cy / 2, yo = cy / 2;
+  const uint32_t xe = cx - cx / 2, ye = cy - cy / 2;    // even samples of a row / of a column
   const ChunkGeom g = geom[c];
   VT* vol = reinterpret_cast<VT*>(volume);
   const size_t vsy = vd.dims[0], vsz = (size_t)vd.dims[0] * vd.dims[1];
@@ -430,171 +487,150 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
   }
 
   // ---- stage the rows.  In LDS everything is interleaved (sample x of row y at [y - ylo][x]).
+  // One wavefront per row, 64 samples per load; a lane issues kStage loads before it touches the
+  // first value, so a workgroup keeps its whole tile in flight (one load at a time per wavefront
+  // left the kernel waiting on HBM latency).
   const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYThreads / 64;
-  for (uint32_t j = wave; j < nrow; j += nwaves) {   // one wavefront per row
-    const uint32_t y = ylo + j;
-    if (FORWARD) {
-      const VT* src = vol + vbase + (size_t)y * vsy;
-      for (uint32_t x = lane; x < cx; x += 64)
-        sm[j * RS + x] = (double)src[x] - mean;
-    }
-    else {   // the buffer holds low | high halves along x and along y
-      const double* src = buf + (size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx;
-      for (uint32_t x = lane; x < cx; x += 64)
-        sm[j * RS + x] = src[(x & 1) ? xe + (x >> 1) : (x >> 1)];
+  {
+    using ST = typename std::conditional<FORWARD, VT, double>::type;
+    const uint32_t nxb = (cx + 63) / 64;
+    const uint32_t rowsW = nrow > wave ? (nrow - wave + nwaves - 1) / nwaves : 0;
+    const uint32_t items = rowsW * nxb;        // (row, 64-sample block) pairs of this wavefront
+    uint32_t ri = 0, bi = 0;                   // pair m = (row wave + nwaves * ri, block bi)
+    for (uint32_t m0 = 0; m0 < items; m0 += kStage) {
+      ST v[kStage];
+      uint32_t ri2 = ri, bi2 = bi;
+#pragma unroll
+      for (int u = 0; u < kStage; u++) {
+        const uint32_t j = wave + nwaves * ri2, x = lane + 64 * bi2;
+        v[u] = 0;
+        if (m0 + u < items && x < cx) {
+          const uint32_t y = ylo + j;
+          if (FORWARD)
+            v[u] = (ST)vol[vbase + (size_t)y * vsy + x];
+          else   // the buffer holds low | high halves along x and along y
+            v[u] = (ST)buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + ((x & 1) ? xe + (x >> 1) : (x >> 1))];
+        }
+        if (++bi2 == nxb) {
+          bi2 = 0;
+          ri2++;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kStage; u++) {
+        const uint32_t j = wave + nwaves * ri, x = lane + 64 * bi;
+        if (m0 + u < items && x < cx)
+          sm[j * RS + x] = FORWARD ? (double)v[u] - mean : (double)v[u];
+        if (++bi == nxb) {
+          bi = 0;
+          ri++;
+        }
+      }
     }
   }
   __syncthreads();
 
-  // x direction: lane = row, so LDS accesses of a wavefront differ by the (odd) row stride
-  auto lift_x = [&](uint32_t jlo, uint32_t jhi) {          // staged rows [jlo, jhi)
-    const uint32_t NR = 32;                               // rows handled side by side
-    const uint32_t l = tid % NR, k0 = tid / NR, kg = kXYThreads / NR;
-    for (uint32_t rb = jlo; rb < jhi; rb += NR) {
-      const bool on = rb + l < jhi;
+  // ---- the passes.  A thread takes 8 consecutive samples of a row (or of a column) together
+  // with a halo of 4 on each side into registers (lift16) and writes only its 8 results back.
+  // Rows are independent in the x pass and columns in the y pass, so one round handles whole rows
+  // (columns): all loads of a round precede its stores.
+  const uint32_t nseg = (cx + kSeg - 1) / kSeg;
+  auto lift_x = [&](uint32_t jlo, uint32_t jhi) {          // staged rows [jlo, jhi), in place
+    // lanes of a wavefront take different rows: addresses differ by the (odd) row stride
+    const uint32_t rpr = min(32u, (uint32_t)kXYThreads / nseg);
+    const uint32_t l = tid % rpr, sg = tid / rpr;
+    for (uint32_t rb = jlo; rb < jhi; rb += rpr) {
+      const bool on = sg < nseg && rb + l < jhi;
       double* row = sm + (size_t)(rb + l) * RS;
-#define EV(i) row[2 * (i)]
-#define OD(i) row[2 * (i) + 1]
-      auto odd_step = [&](double k) {
-        if (on)
-          for (uint32_t i = k0; i < xo; i += kg) {
-            const uint32_t r = min(i + 1, xe - 1);
-            OD(i) = fma(k, EV(i) + EV(r), OD(i));
-          }
-        __syncthreads();
-      };
-      auto even_step = [&](double k) {
-        if (on)
-          for (uint32_t i = k0; i < xe; i += kg) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
-            EV(i) = fma(k, OD(a) + OD(b2), EV(i));
-          }
-        __syncthreads();
-      };
-      if (FORWARD) {  // src/CDF97.cpp:598-631
-        odd_step(K.alpha);
-        even_step(K.beta);
-        odd_step(K.gamma);
-        if (on)
-          for (uint32_t i = k0; i < xe; i += kg) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
-            EV(i) = K.eps * fma(K.delta, OD(a) + OD(b2), EV(i));
-          }
-        __syncthreads();
-        if (on)
-          for (uint32_t i = k0; i < xo; i += kg)
-            OD(i) = (-K.inv_eps) * OD(i);
-        __syncthreads();
+      const int s = (int)(sg * kSeg);
+      double r[16];
+      if (on) {
+        if (s >= 4 && s + 12 <= (int)cx) {
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            r[k] = row[s - 4 + k];
+        }
+        else {
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            r[k] = row[reflect_index(s - 4 + k, (int)cx)];
+        }
+        lift16<FORWARD>(r, K);
       }
-      else {          // src/CDF97.cpp:633-666
-        if (on)
-          for (uint32_t i = k0; i < xo; i += kg)
-            OD(i) = (-K.eps) * OD(i);
-        __syncthreads();
-        if (on)
-          for (uint32_t i = k0; i < xe; i += kg) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, xo - 1);
-            const double t = K.delta * (OD(a) + OD(b2));
-            EV(i) = fma(EV(i), K.inv_eps, -t);
-          }
-        __syncthreads();
-        odd_step(-K.gamma);
-        even_step(-K.beta);
-        odd_step(-K.alpha);
+      __syncthreads();
+      if (on) {
+#pragma unroll
+        for (int k = 0; k < kSeg; k++)
+          if ((uint32_t)(s + k) < cx)
+            row[s + k] = r[4 + k];
       }
-#undef EV
-#undef OD
+      __syncthreads();
     }
   };
 
-  // y direction: one thread per column; row y of the slice is even sample y/2 or odd sample y/2.
-  // Neighbours outside the staged rows are clamped into them: what they feed never reaches the
-  // tile's own rows (see above).
-  auto lift_y = [&]() {
-    // columns are handled in groups of kXYThreads / kXYSplit; thread (x, h) takes part h of the samples
-    const uint32_t h = tid % kXYSplit;
-    const uint32_t e_lo = (ylo + 1) / 2, e_hi = (yhi + 1) / 2;   // even samples i: row 2i staged
-    const uint32_t o_lo = ylo / 2, o_hi = yhi / 2;               // odd samples i: row 2i+1 staged
-    const uint32_t ea = e_lo + (e_hi - e_lo) * h / kXYSplit, eb = e_lo + (e_hi - e_lo) * (h + 1) / kXYSplit;
-    const uint32_t oa = o_lo + (o_hi - o_lo) * h / kXYSplit, ob = o_lo + (o_hi - o_lo) * (h + 1) / kXYSplit;
-    for (uint32_t xb = 0; xb < cx; xb += kXYThreads / kXYSplit) {
-      const uint32_t x = xb + tid / kXYSplit;
-      const bool on = x < cx;
-      double* col = sm + x;
-      auto at = [&](uint32_t y) -> double& {   // sample of slice row y (clamped to the staged rows)
-        const uint32_t yy = min(max(y, ylo), yhi - 1);
-        return col[(size_t)(yy - ylo) * RS];
-      };
-      auto EVy = [&](uint32_t i) -> double& { return at(2 * i); };
-      auto ODy = [&](uint32_t i) -> double& { return at(2 * i + 1); };
-      auto odd_step = [&](double k) {
-        if (on)
-          for (uint32_t i = oa; i < ob; i++) {
-            const uint32_t r = min(i + 1, ye - 1);
-            ODy(i) = fma(k, EVy(i) + EVy(r), ODy(i));
-          }
-        __syncthreads();
-      };
-      auto even_step = [&](double k) {
-        if (on)
-          for (uint32_t i = ea; i < eb; i++) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
-            EVy(i) = fma(k, ODy(a) + ODy(b2), EVy(i));
-          }
-        __syncthreads();
-      };
-      if (FORWARD) {
-        odd_step(K.alpha);
-        even_step(K.beta);
-        odd_step(K.gamma);
-        if (on)
-          for (uint32_t i = ea; i < eb; i++) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
-            EVy(i) = K.eps * fma(K.delta, ODy(a) + ODy(b2), EVy(i));
-          }
-        __syncthreads();
-        if (on)
-          for (uint32_t i = oa; i < ob; i++)
-            ODy(i) = (-K.inv_eps) * ODy(i);
-        __syncthreads();
-      }
-      else {
-        if (on)
-          for (uint32_t i = oa; i < ob; i++)
-            ODy(i) = (-K.eps) * ODy(i);
-        __syncthreads();
-        if (on)
-          for (uint32_t i = ea; i < eb; i++) {
-            const uint32_t a = max(i, 1u) - 1, b2 = min(i, yo - 1);
-            const double t = K.delta * (ODy(a) + ODy(b2));
-            EVy(i) = fma(EVy(i), K.inv_eps, -t);
-          }
-        __syncthreads();
-        odd_step(-K.gamma);
-        even_step(-K.beta);
-        odd_step(-K.alpha);
+  // y direction: thread = (column, 8 rows of the tile); lanes take consecutive columns
+  const uint32_t nq = (yend - y0 + kSeg - 1) / kSeg;
+  const uint32_t cpr = (uint32_t)kXYThreads / nq;          // columns per round
+  auto load_column = [&](uint32_t x, uint32_t q, double (&r)[16]) {
+    const int s = (int)(y0 + q * kSeg);
+    const double* col = sm + x;
+    if (s - 4 >= (int)ylo && s + 12 <= (int)yhi) {   // all 16 rows are staged rows of the slice
+      const double* top = col + (size_t)(s - 4 - (int)ylo) * RS;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        r[k] = top[(size_t)k * RS];
+    }
+    else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        // rows outside the slice mirror into it; what lies outside the staged rows is clamped
+        // into them: it cannot reach the tile's own rows (see above)
+        const uint32_t yy = min(max(reflect_index(s - 4 + k, (int)cy), ylo), yhi - 1);
+        r[k] = col[(size_t)(yy - ylo) * RS];
       }
     }
   };
 
   if (FORWARD) {
-    if (cx >= 2)
-      lift_x(0, nrow);
-    if (cy >= 2)
-      lift_y();
-    // ---- store this tile's rows, low | high halves along both axes
-    for (uint32_t y = y0 + wave; y < yend; y += nwaves) {
-      double* dstrow = buf + (size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx;
-      const double* srow = sm + (size_t)(y - ylo) * RS;
-      for (uint32_t x = lane; x < cx; x += 64)
-        dstrow[(x & 1) ? xe + (x >> 1) : (x >> 1)] = srow[x];
+    lift_x(0, nrow);
+    // y pass straight from LDS into the buffer: low | high halves along both axes
+    for (uint32_t xb = 0; xb < cx; xb += cpr) {
+      const uint32_t x = xb + tid % cpr, q = tid / cpr;
+      if (x < cx && q < nq) {
+        double r[16];
+        load_column(x, q, r);
+        lift16<true>(r, K);
+        const uint32_t dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+#pragma unroll
+        for (int k = 0; k < kSeg; k++) {
+          const uint32_t y = y0 + q * kSeg + k;
+          if (y < yend)
+            buf[(size_t)((y & 1) ? ye + (y >> 1) : (y >> 1)) * cx + dcol] = r[4 + k];
+        }
+      }
     }
   }
   else {
-    if (cy >= 2)
-      lift_y();
-    if (cx >= 2)
-      lift_x(y0 - ylo, yend - ylo);   // (only the tile's own rows go on)
+    for (uint32_t xb = 0; xb < cx; xb += cpr) {
+      const uint32_t x = xb + tid % cpr, q = tid / cpr;
+      const bool on = x < cx && q < nq;
+      double r[16];
+      if (on) {
+        load_column(x, q, r);
+        lift16<false>(r, K);
+      }
+      __syncthreads();
+      if (on) {
+#pragma unroll
+        for (int k = 0; k < kSeg; k++) {
+          const uint32_t y = y0 + q * kSeg + k;
+          if (y < yend)
+            sm[(size_t)(y - ylo) * RS + x] = r[4 + k];
+        }
+      }
+    }
+    __syncthreads();
+    lift_x(y0 - ylo, yend - ylo);   // (only the tile's own rows go on)
     for (uint32_t y = y0 + wave; y < yend; y += nwaves) {
       VT* dstrow = vol + vbase + (size_t)y * vsy;
       const double* srow = sm + (size_t)(y - ylo) * RS;
