@@ -224,6 +224,8 @@ extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
 // gather map and subtracts the mean (src/SPERR3D_OMP_C.cpp:236-261, Conditioner.cpp:48-50), the
 // last inverse pass adds the mean, narrows and scatters (Conditioner.cpp:66-96,
 // SPERR3D_OMP_D.cpp:167-184, SPERR_C_API.cpp:246-250).  Both passes cover the whole chunk.
+constexpr int kLoadBatch = 8;
+
 template <bool FORWARD, int IO>
 __global__ void __launch_bounds__(kThreads)
 k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis, uint32_t rx,
@@ -266,30 +268,50 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
     mean = st[c].mean;
   }
 
-  // ---- load ----
-  if (axis == 0) {  // lanes along the line
-    const uint32_t nseg = (len + 63) / 64;   // a wavefront moves 64 consecutive samples of a line
-    for (uint32_t sg = tid / 64; sg < nl * nseg; sg += kThreads / 64) {
-      const uint32_t l = sg / nseg, p = (sg % nseg) * 64 + tid % 64;
-      if (p >= len)
-        continue;
-      const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
-      if (IO != 0 && FORWARD)
-        sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
-      else if (!is_const)
-        sm[dst * NLP + l] = tile[l * su + p];
-    }
-  }
-  else {            // lanes across the lines
-    const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
-    if (l < nl)
-      for (uint32_t p = k0; p < len; p += kg) {
-        const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
-        if (IO != 0 && FORWARD)
-          sm[dst * NLP + l] = (double)vol[vbase + l * vsu + p * vsl] - mean;
-        else if (!is_const)
-          sm[dst * NLP + l] = tile[l * su + p * sl];
+  // ---- load: a thread issues kLoadBatch loads before it uses the first value (one at a time
+  // leaves the pass waiting on HBM latency) ----
+  using LT = typename std::conditional<(IO != 0 && FORWARD), VT, double>::type;
+  auto fetch = [&](uint32_t l, uint32_t p) -> LT {
+    if (IO != 0 && FORWARD)
+      return (LT)vol[vbase + l * vsu + p * vsl];
+    return (LT)tile[l * su + p * sl];
+  };
+  auto deposit = [&](uint32_t l, uint32_t p, LT v) {
+    const uint32_t dst = FORWARD ? ((p & 1) ? even_len + (p >> 1) : (p >> 1)) : p;
+    sm[dst * NLP + l] = (IO != 0 && FORWARD) ? (double)v - mean : (double)v;
+  };
+  if (!(is_const && !(IO != 0 && FORWARD))) {
+    if (axis == 0) {  // lanes along the line: a wavefront moves 64 consecutive samples of a line
+      const uint32_t nseg = (len + 63) / 64, nsg = nl * nseg, step = kThreads / 64;
+      for (uint32_t sg0 = tid / 64; sg0 < nsg; sg0 += step * kLoadBatch) {
+        LT v[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+          const uint32_t sg = sg0 + u * step, l = sg / nseg, p = (sg % nseg) * 64 + tid % 64;
+          v[u] = (sg < nsg && p < len) ? fetch(l, p) : (LT)0;
+        }
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+          const uint32_t sg = sg0 + u * step, l = sg / nseg, p = (sg % nseg) * 64 + tid % 64;
+          if (sg < nsg && p < len)
+            deposit(l, p, v[u]);
+        }
       }
+    }
+    else {            // lanes across the lines
+      const uint32_t l = tid % NL, k0 = tid / NL, kg = kThreads / NL;
+      if (l < nl)
+        for (uint32_t p0 = k0; p0 < len; p0 += kg * kLoadBatch) {
+          LT v[kLoadBatch];
+#pragma unroll
+          for (int u = 0; u < kLoadBatch; u++)
+            v[u] = p0 + u * kg < len ? fetch(l, p0 + u * kg) : (LT)0;
+#pragma unroll
+          for (int u = 0; u < kLoadBatch; u++)
+            if (p0 + u * kg < len)
+              deposit(l, p0 + u * kg, v[u]);
+        }
+    }
   }
   __syncthreads();
 
@@ -941,9 +963,11 @@ static int xy_rows(uint32_t cx, uint32_t cy)
   if (cx < 2 || cy < 2)
     return 0;
   const size_t rowBytes = (size_t)(cx + 1) * sizeof(double);
-  int rows = (int)((68 * 1024) / rowBytes);
-  if (rows > 32)
-    rows = 32;
+  static const int ldsKB = getenv("SPERR_HIP_XY_LDS_KB") ? atoi(getenv("SPERR_HIP_XY_LDS_KB")) : 68;
+  static const int maxRows = getenv("SPERR_HIP_XY_ROWS") ? atoi(getenv("SPERR_HIP_XY_ROWS")) : 32;
+  int rows = (int)(((size_t)ldsKB * 1024) / rowBytes);
+  if (rows > maxRows)
+    rows = maxRows;
   int R = (rows - 2 * kXYHalo) & ~1;
   if ((uint32_t)R > cy)
     R = (int)((cy + 1) & ~1u);
