@@ -543,6 +543,23 @@ def test_2d_multi_resolution_host_api(eng, oracle):
     C.CDLL(None).free(dst)
 
 
+@pytest.mark.parametrize("shape,chunks,dtype", [((10, 37, 300), (300, 37, 10), np.float32),
+                                                ((9, 520, 543), (543, 520, 9), np.float32),
+                                                ((12, 100, 511), (511, 100, 12), np.float64),
+                                                ((16, 33, 400), (200, 33, 8), np.float32),
+                                                ((24, 258, 258), (258, 258, 24), np.float32)])
+def test_long_rows_and_odd_tiles(eng, oracle, shape, chunks, dtype):
+    """Rows longer than 256 samples: the fused x/y lifting kernel (k_lift_xy) takes the rows of a
+    tile in several rounds and its last tile is ragged; mirrored halos at every border."""
+    v = turbulence(shape, dtype=dtype)
+    want = oracle.comp_3d(v, chunks, 1, 4.0)
+    assert bytes(eng.compress(cuda(v), chunks, 4.0).cpu().numpy()) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    for as_float in (True, False):
+        assert np.array_equal(bits(eng.decompress(dev, as_float).cpu().numpy()),
+                              bits(oracle.decomp_3d(want, as_float)))
+
+
 def test_many_chunks_decode_in_sub_batches(eng, oracle):
     """48 chunks of one shape: the decoder splits the batch into sub-batches on separate streams
     (engine.hip, decompress_impl); same values as the oracle."""
