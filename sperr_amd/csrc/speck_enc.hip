@@ -315,6 +315,9 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
   const uint32_t n = b.tree.nvals;
   const uint32_t i0 = blockIdx.x * kPixTile + threadIdx.x * kPixPer;
   const int wave = threadIdx.x >> 6;
+  // most samples are zero (msb -1) and were never born (-1): those two bins are summed over the
+  // wavefront and added once, instead of up to 64 lanes queueing on the same LDS word 16 times
+  uint32_t zeroM = 0, zeroB = 0;
   if (i0 < n) {
     int m[kPixPer], bp[kPixPer];
     load_pix(b.msb + c * b.pixStride, i0, n, m);
@@ -322,25 +325,48 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
 #pragma unroll
     for (int k = 0; k < kPixPer; k++)
       if (i0 + k < n) {
-        atomicAdd(&hist[wave][0][m[k] + 1], (m[k] >= 0 && bp[k] > m[k]) ? 0x10001u : 1u);
-        atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
+        if (m[k] < 0)
+          zeroM++;
+        else
+          atomicAdd(&hist[wave][0][m[k] + 1], bp[k] > m[k] ? 0x10001u : 1u);
+        if (bp[k] < 0)
+          zeroB++;
+        else
+          atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
       }
+  }
+  uint32_t z = zeroM | (zeroB << 16);       // both at most 1024 per wavefront
+  for (int d = 32; d > 0; d >>= 1)
+    z += __shfl_xor(z, d, 64);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&hist[wave][0][0], z & 0xffffu);
+    atomicAdd(&hist[wave][1][0], z >> 16);
+  }
+  __syncthreads();
+  // the tile's histograms (sum over the wavefronts), then their running sums over the bins
+  __shared__ uint32_t tot[2][kMaxPlanes + 1];
+  __shared__ uint64_t pre[kMaxPlanes + 1];      // low half: msb bins 0..q (all samples), high: birth bins
+  for (uint32_t i = threadIdx.x; i < 2 * (kMaxPlanes + 1); i += kThreads) {
+    const uint32_t h = i / (kMaxPlanes + 1), q = i % (kMaxPlanes + 1);
+    uint32_t v = 0;
+    for (int w = 0; w < kThreads / 64; w++)
+      v += hist[w][h][q];                       // (both 16-bit halves of [0] stay below 2^13)
+    tot[h][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    static_assert(kMaxPlanes == 64, "one wavefront scans the bins");
+    const uint64_t v = (uint64_t)(tot[0][threadIdx.x] & 0xffffu) | ((uint64_t)tot[1][threadIdx.x] << 32);
+    const uint64_t inc = wave_inclusive_scan<uint64_t>(v);
+    pre[threadIdx.x] = inc;
+    if (threadIdx.x == 63)
+      pre[64] = inc + ((uint64_t)(tot[0][64] & 0xffffu) | ((uint64_t)tot[1][64] << 32));
   }
   __syncthreads();
   const int p = threadIdx.x;
   if (p < s.nbp) {
-    uint32_t le_m = 0, le_b = 0, all_m = 0, eq = 0;
-    for (int w = 0; w < kThreads / 64; w++) {
-      for (int q = 0; q <= kMaxPlanes; q++) {
-        const uint32_t hm = hist[w][0][q] & 0xffffu;
-        all_m += hm;
-        if (q <= p + 1) {
-          le_m += hm;
-          le_b += hist[w][1][q];
-        }
-      }
-      eq += hist[w][0][p + 1] >> 16;
-    }
+    const uint32_t le_m = (uint32_t)pre[p + 1], le_b = (uint32_t)(pre[p + 1] >> 32);
+    const uint32_t all_m = (uint32_t)pre[kMaxPlanes], eq = tot[0][p + 1] >> 16;
     uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
     cnt[(size_t)(p * 2 + 0) * b.nPixTiles + blockIdx.x] = le_m - le_b + eq;   // LIP scan bits
     cnt[(size_t)(p * 2 + 1) * b.nPixTiles + blockIdx.x] = all_m - le_m;       // refinement bits
