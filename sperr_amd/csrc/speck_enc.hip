@@ -945,21 +945,39 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
 #pragma unroll
   for (int k = 0; k < kPixPer; k++)
     cf[k] = (i0 + k < n) ? coef[i0 + k] : (CT)0;
+  int bpmax = -1;   // no sample of the thread is in the LIP or significant at planes >= bpmax
+#pragma unroll
+  for (int k = 0; k < kPixPer; k++)
+    bpmax = max(bpmax, bp[k]);
   const uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
   const uint32_t* off = b.pixOff + c * b.pixCntStride;
   uint64_t* stream = b.stream + c * b.streamStride;
-  for (int p = s.nbp - 1; p >= s.plast; p--) {
-    const uint32_t nlip = cnt[(size_t)(p * 2) * b.nPixTiles + tile];
-    const uint32_t nref = s.rec[p].didREF ? cnt[(size_t)(p * 2 + 1) * b.nPixTiles + tile] : 0;
+  // the tile's counts and stream positions of every plane, fetched at once: read plane by plane
+  // they put a dependent global load in front of every iteration of the loop below
+  __shared__ uint32_t tcnt[2 * kMaxPlanes];
+  __shared__ uint64_t tbase[2 * kMaxPlanes];
+  const int nbp = s.nbp, plast = s.plast;
+  for (int t = threadIdx.x; t < 2 * nbp; t += blockDim.x) {
+    const int pp = t >> 1;
+    const bool ref = (t & 1) != 0;
+    tcnt[t] = (ref && !s.rec[pp].didREF) ? 0u : cnt[(size_t)t * b.nPixTiles + tile];
+    tbase[t] = (ref ? s.rec[pp].baseREF : s.rec[pp].baseLIP) + off[(size_t)t * b.nPixTiles + tile];
+  }
+  const uint64_t budget = s.budget;
+  __syncthreads();
+  for (int p = nbp - 1; p >= plast; p--) {
+    const uint32_t nlip = tcnt[p * 2];
+    const uint32_t nref = tcnt[p * 2 + 1];
     if (nlip == 0 && nref == 0)
       continue;  // uniform across the block
-    const uint64_t lipBase = s.rec[p].baseLIP + off[(size_t)(p * 2) * b.nPixTiles + tile];
-    const uint64_t refBase = s.rec[p].baseREF + off[(size_t)(p * 2 + 1) * b.nPixTiles + tile];
+    const uint64_t lipBase = tbase[p * 2];
+    const uint64_t refBase = tbase[p * 2 + 1];
     for (int w = threadIdx.x; w < kWords; w += blockDim.x) {
       lipw[w] = 0;
       refw[w] = 0;
     }
     uint32_t lbits = 0, lval = 0, rbits = 0, rval = 0;   // at most 2 and 1 bits per sample
+    if (p < bpmax)   // (a sample takes part from its birth plane on: most threads hold none yet)
 #pragma unroll
     for (int k = 0; k < kPixPer; k++) {
       if (bp[k] > p && p >= m[k]) {
@@ -993,18 +1011,18 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
     }
     __syncthreads();
     // words at or past limitWord hold no kept bit (budget may be ~0: no overflow here)
-    const uint64_t limitWord = (s.budget >> 6) + ((s.budget & 63) ? 1 : 0);
+    const uint64_t limitWord = (budget >> 6) + ((budget & 63) ? 1 : 0);
     for (int w = threadIdx.x; w < kWords; w += blockDim.x) {
       const uint64_t lw = (lipBase >> 6) + w, rw = (refBase >> 6) + w;
       uint64_t lv = lipw[w], rv = refw[w];
       if (lv && lw < limitWord) {
-        if (lw == limitWord - 1 && (s.budget & 63))
-          lv &= (1ull << (s.budget & 63)) - 1;
+        if (lw == limitWord - 1 && (budget & 63))
+          lv &= (1ull << (budget & 63)) - 1;
         atomic_or64(stream + lw, lv);
       }
       if (rv && rw < limitWord) {
-        if (rw == limitWord - 1 && (s.budget & 63))
-          rv &= (1ull << (s.budget & 63)) - 1;
+        if (rw == limitWord - 1 && (budget & 63))
+          rv &= (1ull << (budget & 63)) - 1;
         atomic_or64(stream + rw, rv);
       }
     }
