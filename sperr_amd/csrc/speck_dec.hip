@@ -383,21 +383,36 @@ __global__ void __launch_bounds__(kThreads) k_lip_scan(DecBuffers b, int p)
   uint32_t* cnt = b.tokCnt + c * b.tokStride;
   uint32_t* off = b.tokOff + c * b.tokStride;
   const uint64_t* mask = b.tokMask + c * b.tokStride;
+  // one workgroup per chunk walks the words: kLipPer consecutive words per thread and round, so a
+  // round is one batch of loads and one block scan for 2048 words (a word per thread and round
+  // made the late planes, with their 10^5 words, a chain of dependent round trips)
+  constexpr int kLipPer = 8;
+  const uint32_t nLip = s.nLip;
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < nwords; base += kThreads) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nwords ? cnt[i] : 0;
+  for (uint32_t base = 0; base < nwords; base += kThreads * kLipPer) {
+    const uint32_t i0 = base + threadIdx.x * kLipPer;
+    uint32_t v[kLipPer], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < kLipPer; k++) {
+      v[k] = i0 + k < nwords ? cnt[i0 + k] : 0;
+      tsum += v[k];
+    }
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<uint32_t>(v, sm, &total) + carry;
-    if (i < nwords) {
-      off[i] = ex;
-      // token #nLip (0-based) starts in this word?  Then the phase is that many bits long.
-      if (ex <= s.nLip && s.nLip < ex + v) {
-        uint64_t m = mask[i];
-        for (uint32_t r = s.nLip - ex; r > 0; r--)
-          m &= m - 1;
-        s.lipBits = (uint64_t)i * 64 + (uint64_t)__ffsll((long long)m) - 1;
+    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total) + carry;
+#pragma unroll
+    for (int k = 0; k < kLipPer; k++) {
+      const uint32_t i = i0 + k;
+      if (i < nwords) {
+        off[i] = ex;
+        // token #nLip (0-based) starts in this word?  Then the phase is that many bits long.
+        if (ex <= nLip && nLip < ex + v[k]) {
+          uint64_t m = mask[i];
+          for (uint32_t r = nLip - ex; r > 0; r--)
+            m &= m - 1;
+          s.lipBits = (uint64_t)i * 64 + (uint64_t)__ffsll((long long)m) - 1;
+        }
       }
+      ex += v[k];
     }
     carry += total;
   }
@@ -2207,14 +2222,24 @@ __global__ void __launch_bounds__(kTabThreads) k_place_scan(DecBuffers b, int p)
   const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
   const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
   uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
+  constexpr int kPer = 4;   // consecutive words per thread and round: one batch of loads per scan
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < pw; base += kTabThreads) {
-    const uint32_t wi = base + threadIdx.x;
-    const uint64_t m = wi < pw ? mask[wi] : 0ull;
+  for (uint32_t base = 0; base < pw; base += kTabThreads * kPer) {
+    const uint32_t w0 = base + threadIdx.x * kPer;
+    uint32_t v[kPer], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      v[k] = w0 + k < pw ? (uint32_t)__popcll(mask[w0 + k]) : 0u;
+      tsum += v[k];
+    }
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(m), sh_scan, &total);
-    if (wi < pw)
-      pre[wi] = ex + carry;
+    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sh_scan, &total) + carry;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      if (w0 + k < pw)
+        pre[w0 + k] = ex;
+      ex += v[k];
+    }
     carry += total;
   }
   if (threadIdx.x == 0)
