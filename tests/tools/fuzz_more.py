@@ -1,8 +1,8 @@
-"""Wider run of the randomised parity sweep of tests/test_gpu_fuzz.py: python tools/fuzz_more.py 40 600"""
+"""Wider run of the randomised parity sweep of tests/test_gpu_fuzz.py: python tests/tools/fuzz_more.py 40 600"""
 import os
 import sys
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
