@@ -171,7 +171,9 @@ class _CApiMixin:
             raise RuntimeError(f"decomp_3d returned {rtn}")
         n = dx.value * dy.value * dz.value
         dt = np.float32 if output_float else np.float64
-        out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        # (ctypes.string_at takes the size as a C int: volumes of 2 GiB and more go through a view)
+        view = np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_float if output_float else C.c_double)), shape=(n,))
+        out = view.astype(dt, copy=True)
         self._libc.free(dst)
         return out.reshape(dz.value, dy.value, dx.value)
 
