@@ -1670,32 +1670,114 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
   }
 
   VolDesc vd{{ci.vol[0], ci.vol[1], ci.vol[2]}};
-  for (auto& g : groups) {
-    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
-    if (!P)
-      return -1;
-    uint64_t maxPayload = 0;
-    for (auto& r : g.second)
-      maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
+  struct SubHost {
+    std::vector<ChunkGeom> hg;
+    std::vector<uint64_t> ho, hl;
+    std::vector<DecState> hs;
+    DecBatchBufs bb;
+    uint32_t nb = 0;
+    size_t first = 0;
+  };
+  // Small groups (the border shapes of a volume that the chunk size does not divide; their chunks
+  // decode through the serial walk, one wavefront each) are not waited for one by one: each gets
+  // its own piece of the arena and one of the sub-streams, and all of them are drained together.
+  // SPERR_HIP_DEFER_GROUPS=0 decodes group after group.
+  static const bool deferEnv = !(getenv("SPERR_HIP_DEFER_GROUPS") && atoi(getenv("SPERR_HIP_DEFER_GROUPS")) == 0);
+  const bool deferOK = deferEnv && !anyOutlier && !mr && !slice && groups.size() > 1;
+  // (groups of 32 and more chunks of a shape the table kernels take keep the sub-batch scheme)
+  auto deferrable = [](const ShapePlan& P, size_t nchunksOfShape) {
+    const bool tables = P.ht.allRegular && P.maxK >= 1 && P.maxK <= 8;
+    return nchunksOfShape < 32 || !tables;
+  };
+  std::vector<std::unique_ptr<SubHost>> pending;
+  size_t deferOff = 0;
+  uint32_t deferNext = 0;
+  bool deferForked = false;
+  auto drain = [&]() -> int {
+    int rc = 0;
+    for (uint32_t q = 0; q < kSubStreams; q++)
+      HIP_CHECK(hipStreamSynchronize(E.sub[q]));
+    for (auto& S : pending) {                  // stream errors (wrong lengths) surface here
+      S->hs.resize(S->nb);
+      HIP_CHECK(hipMemcpy(S->hs.data(), S->bb.db.st, S->nb * sizeof(DecState), hipMemcpyDeviceToHost));
+      for (auto& hsx : S->hs)
+        if (hsx.error)
+          rc = -1;
+    }
+    pending.clear();
+    deferOff = 0;
+    return rc;
+  };
+  auto bytes_per_chunk = [&](const ShapePlan& P, uint64_t maxPayload) -> size_t {
     Arena probe;
     probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
-    carve_dec(probe, *P, 1, maxPayload, tmp);
-    const size_t per = probe.used;
+    carve_dec(probe, P, 1, maxPayload, tmp);
+    return probe.used;
+  };
+  bool deferSized = false;
+  for (int pass = 0; pass < 2; pass++)
+  for (auto& g : groups) {
+    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+    if (!P)
+      return -1;
+    const bool deferG = deferOK && deferrable(*P, g.second.size());
+    if (deferG != (pass == 1))
+      continue;
+    if (deferG && !deferSized) {   // room for all the small groups at once, if the memory is there
+      deferSized = true;
+      size_t sum = 0;
+      for (auto& h : groups) {
+        ShapePlan* Q = E.plan(h.first[0], h.first[1], h.first[2]);
+        if (!Q)
+          return -1;
+        if (!deferrable(*Q, h.second.size()))
+          continue;
+        uint64_t mp = 0;
+        for (auto& r : h.second)
+          mp = std::max<uint64_t>(mp, ci.len[r.gid]);
+        sum += round_up(h.second.size() * bytes_per_chunk(*Q, mp) + (1 << 20), 4096);
+      }
+      size_t fr = 0, tot = 0;
+      HIP_CHECK(hipMemGetInfo(&fr, &tot));
+      const size_t room = (size_t)((fr + E.arena.n) * 0.80);
+      if (E.arena.ensure(std::min(sum, room)))
+        return -1;
+    }
+    uint64_t maxPayload = 0;
+    for (auto& r : g.second)
+      maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
+    const size_t per = bytes_per_chunk(*P, maxPayload);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
     uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
     B = std::min<uint32_t>(B, 256);
-    if (E.arena.ensure((size_t)B * per + (1 << 20)))
+    const size_t needBytes = (size_t)B * per + (1 << 20);
+    if (deferG && deferOff + needBytes > E.arena.n && drain())   // no room beside the groups in flight
+      return -1;
+    if (E.arena.ensure(needBytes))   // (grows only when nothing is in flight: deferOff == 0 here)
       return -1;
     const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
     for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
       const uint32_t nbAll = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
+      if (deferG && deferOff + needBytes > E.arena.n && drain())
+        return -1;
       Arena A;
-      A.base = static_cast<char*>(E.arena.p);
-      A.cap = E.arena.n;
+      A.base = static_cast<char*>(E.arena.p) + (deferG ? deferOff : 0);
+      A.cap = E.arena.n - (deferG ? deferOff : 0);
+      hipStream_t deferStream = nullptr;
+      if (deferG) {
+        if (!deferForked) {   // the sub-streams start behind what the caller's stream holds
+          HIP_CHECK(hipEventRecord(E.evFork, st));
+          for (uint32_t q = 0; q < kSubStreams; q++)
+            HIP_CHECK(hipStreamWaitEvent(E.sub[q], E.evFork, 0));
+          deferForked = true;
+        }
+        deferStream = E.sub[deferNext++ % kSubStreams];
+        deferOff += round_up(needBytes, 4096);
+      }
       // The LIS phase of a plane keeps one latency-bound workgroup per chunk busy; sub-batches on
       // separate streams let the bandwidth-bound kernels of one sub-batch run beside the LIS
       // kernels of another.  Measured on MI355X, 64 chunks of 256^3: 1 stream 130 ms per
@@ -1706,16 +1788,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       uint32_t nsub = nbAll >= 48 ? 3u : nbAll >= 32 ? 2u : 1u;
       if (subEnv > 0)
         nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
-      if (anyOutlier || nbAll < 2 * nsub)
+      if (anyOutlier || nbAll < 2 * nsub || deferG)
         nsub = 1;
-      struct SubHost {
-        std::vector<ChunkGeom> hg;
-        std::vector<uint64_t> ho, hl;
-        std::vector<DecState> hs;
-        DecBatchBufs bb;
-        uint32_t nb = 0;
-        size_t first = 0;
-      };
       std::vector<SubHost> subs(nsub);
       if (nsub > 1) {
         HIP_CHECK(hipEventRecord(E.evFork, st));
@@ -1744,7 +1818,7 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
           return 0;
         if (nsub > 1)
           HIP_CHECK(hipSetDevice(devId));
-        hipStream_t ss = nsub > 1 ? E.sub[q] : st;
+        hipStream_t ss = deferStream ? deferStream : (nsub > 1 ? E.sub[q] : st);
         DecBatchBufs& bb = S.bb;
         DecBuffers& d = bb.db;
         S.hg.resize(nb);
@@ -1933,6 +2007,10 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
       if (nsub == 1) {
         if (enqueue(0))
           return -1;
+        if (deferG) {   // waited for in drain()
+          pending.push_back(std::make_unique<SubHost>(std::move(subs[0])));
+          continue;
+        }
       }
       else {
         // (SPERR_HIP_ENQUEUE_THREADS=1: one host thread per sub-batch; measured no gain on MI355X)
@@ -1985,6 +2063,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
             return -1;
     }
   }
+  if (drain())
+    return -1;
   HIP_CHECK(hipStreamSynchronize(st));
   HIP_CHECK(hipGetLastError());
   g_prof.collect();
