@@ -1444,6 +1444,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   DecBuffers& d = o.db;
   memset(&d, 0, sizeof(d));
   d.tree = P.dtree;
+  d.treeTabLen = (uint32_t)P.ht.tab.size();
   d.nchunks = B;
 #define TAKE(dst, T, count)            \
   dst = A.take<T>((size_t)(count));    \

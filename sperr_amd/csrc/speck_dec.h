@@ -86,6 +86,7 @@ struct DecBuffers {
   uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
   size_t sigbitsStride;
   uint32_t tabSmemBytes;       // dynamic LDS given to k_lis_tables
+  uint32_t treeTabLen;         // entries of tree.tab (k_lis_walk stages the tree's tables in LDS)
   uint64_t* leafEv;            // leaf-parent splits of one plane: node id | sig mask | neg mask
   uint32_t leafCap;
   size_t leafStride;
