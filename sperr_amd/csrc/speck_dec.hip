@@ -633,6 +633,40 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
             cnt = 0;
           const uint32_t present = (uint32_t)(__ballot(cnt > 0) & 0xffull);
           const uint32_t pixel = (uint32_t)(__ballot(cnt == 1) & 0xffull);
+          if ((present & ~pixel) == 0u) {
+            // Every child is a single sample (most significant sets are such leaf parents): at most
+            // 16 bits, read off the stream at once; nothing can be entered, so no frame is set up.
+            const uint64_t w = rd.peek64();
+            const uint32_t last = 31u - (uint32_t)__clz((int)present);
+            uint32_t y = 0, found = 0, sigmask = 0, signmask = 0;
+#pragma unroll
+            for (uint32_t ci = 0; ci < 8; ci++) {
+              if (!((present >> ci) & 1u))
+                continue;
+              const uint32_t coded = found | (uint32_t)(ci != last);
+              const uint32_t sig = coded ? (uint32_t)((w >> y) & 1ull) : 1u;
+              y += coded;
+              found |= sig;
+              if (sig) {
+                sigmask |= 1u << ci;
+                signmask |= (uint32_t)((w >> y) & 1ull) << ci;
+                y++;
+              }
+            }
+            rd.skip(y);
+            if (cnt == 1) {   // lanes 0..7 with a sample: (cnt == 1 implies lane < 8)
+              const uint32_t ridx = pixel_raster(t, r, ee, idx);
+              atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
+              if ((sigmask >> lane) & 1u) {
+                atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
+                if (!((signmask >> lane) & 1u))
+                  atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+              }
+            }
+            sp--;
+            fresh = false;
+            continue;
+          }
           const NodeGeom q = node_geom(t, nd);
           const uint32_t kidlev =
               node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
