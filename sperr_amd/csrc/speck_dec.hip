@@ -579,6 +579,61 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   BitReader rd;
   rd.init(words, s.lipStart + s.lipBits, s.avail);
 
+  // A significant set whose children are all single samples (most significant sets are such leaf
+  // parents): at most 16 bits, read off the stream at once, decoded in straight-line code.  Nothing
+  // can be entered, so no frame is set up and no barrier is needed; the set's parent goes on with
+  // its next child.  Returns false (and reads nothing) for any other set.
+  auto try_leaf = [&](const Node& nd) -> bool {
+    const Grid& g = t.grids[nd.grid];
+    const Root& r = t.roots[g.root];
+    int ee[3];
+    uint32_t cnt = 1, idx[3];
+    bool valid = lane < 8;
+    for (int a = 0; a < 3; a++) {
+      const bool sa = g.depth < r.D[a];
+      ee[a] = sa ? g.e[a] + 1 : g.e[a];
+      const uint32_t bit = ((uint32_t)lane >> a) & 1u;
+      if (bit && !sa)
+        valid = false;
+      idx[a] = (sa ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a]) + bit;
+      cnt *= axis_len(r.len[a], ee[a], idx[a]);
+    }
+    if (!valid)
+      cnt = 0;
+    const uint32_t present = (uint32_t)(__ballot(cnt > 0) & 0xffull);
+    const uint32_t pixel = (uint32_t)(__ballot(cnt == 1) & 0xffull);
+    if ((present & ~pixel) != 0u)
+      return false;
+    const uint64_t w = rd.peek64();
+    const uint32_t last = 31u - (uint32_t)__clz((int)present);
+    uint32_t y = 0, found = 0, sigmask = 0, signmask = 0;
+#pragma unroll
+    for (uint32_t ci = 0; ci < 8; ci++) {
+      if (!((present >> ci) & 1u))
+        continue;
+      const uint32_t coded = found | (uint32_t)(ci != last);
+      const uint32_t sig = coded ? (uint32_t)((w >> y) & 1ull) : 1u;
+      y += coded;
+      found |= sig;
+      if (sig) {
+        sigmask |= 1u << ci;
+        signmask |= (uint32_t)((w >> y) & 1ull) << ci;
+        y++;
+      }
+    }
+    rd.skip(y);
+    if (cnt == 1) {   // lanes 0..7 that have a sample
+      const uint32_t ridx = pixel_raster(t, r, ee, idx);
+      atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
+      if ((sigmask >> lane) & 1u) {
+        atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
+        if (!((signmask >> lane) & 1u))
+          atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+      }
+    }
+    return true;
+  };
+
   for (uint32_t l = t.nlevels; l-- > 0;) {
     const uint32_t n = s.listLen[cur][l];
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
@@ -608,6 +663,8 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
       }
       uint64_t enter = __shfl(win, (int)(e - winBase), 64);
       e++;
+      if (try_leaf(unpack_node(enter)))
+        continue;
       bool fresh = true;
       while (sp >= 0) {
         WFrame& f = fr[sp];
@@ -633,40 +690,6 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
             cnt = 0;
           const uint32_t present = (uint32_t)(__ballot(cnt > 0) & 0xffull);
           const uint32_t pixel = (uint32_t)(__ballot(cnt == 1) & 0xffull);
-          if ((present & ~pixel) == 0u) {
-            // Every child is a single sample (most significant sets are such leaf parents): at most
-            // 16 bits, read off the stream at once; nothing can be entered, so no frame is set up.
-            const uint64_t w = rd.peek64();
-            const uint32_t last = 31u - (uint32_t)__clz((int)present);
-            uint32_t y = 0, found = 0, sigmask = 0, signmask = 0;
-#pragma unroll
-            for (uint32_t ci = 0; ci < 8; ci++) {
-              if (!((present >> ci) & 1u))
-                continue;
-              const uint32_t coded = found | (uint32_t)(ci != last);
-              const uint32_t sig = coded ? (uint32_t)((w >> y) & 1ull) : 1u;
-              y += coded;
-              found |= sig;
-              if (sig) {
-                sigmask |= 1u << ci;
-                signmask |= (uint32_t)((w >> y) & 1ull) << ci;
-                y++;
-              }
-            }
-            rd.skip(y);
-            if (cnt == 1) {   // lanes 0..7 with a sample: (cnt == 1 implies lane < 8)
-              const uint32_t ridx = pixel_raster(t, r, ee, idx);
-              atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
-              if ((sigmask >> lane) & 1u) {
-                atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
-                if (!((signmask >> lane) & 1u))
-                  atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
-              }
-            }
-            sp--;
-            fresh = false;
-            continue;
-          }
           const NodeGeom q = node_geom(t, nd);
           const uint32_t kidlev =
               node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
@@ -714,6 +737,8 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
             kid.i[1] = (uint16_t)(f.base[1] + ((ci >> 1) & 1u));
             kid.i[2] = (uint16_t)(f.base[2] + ((ci >> 2) & 1u));
             if (sig) {
+              if (try_leaf(kid))
+                continue;   // (handled in place: the frame stays in registers)
               enter = pack_node(kid);
               descend = true;
               break;
