@@ -583,9 +583,19 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   // parents): at most 16 bits, read off the stream at once, decoded in straight-line code.  Nothing
   // can be entered, so no frame is set up and no barrier is needed; the set's parent goes on with
   // its next child.  Returns false (and reads nothing) for any other set.
+  // (the grid and root of the last set stay in registers: consecutive sets mostly share them)
+  uint32_t lastGrid = 0xffffffffu;
+  Grid gc = {};
+  Root rc = {};
+  const bool tabStaged = t.tab == sh_tab;
   auto try_leaf = [&](const Node& nd) -> bool {
-    const Grid& g = t.grids[nd.grid];
-    const Root& r = t.roots[g.root];
+    if (nd.grid != lastGrid) {
+      lastGrid = nd.grid;
+      gc = t.grids[nd.grid];
+      rc = t.roots[gc.root];
+    }
+    const Grid& g = gc;
+    const Root& r = rc;
     int ee[3];
     uint32_t cnt = 1, idx[3];
     bool valid = lane < 8;
@@ -623,7 +633,20 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
     }
     rd.skip(y);
     if (cnt == 1) {   // lanes 0..7 that have a sample
-      const uint32_t ridx = pixel_raster(t, r, ee, idx);
+      uint32_t ridx;
+      if (tabStaged) {   // pixel_raster with the interval starts read from LDS as LDS
+        uint32_t cc[3];
+        for (int a = 0; a < 3; a++) {
+          const uint32_t L = r.len[a];
+          if ((L & (L - 1u)) == 0)
+            cc[a] = (uint32_t)r.org[a] + idx[a] * (L >> ee[a]);
+          else
+            cc[a] = (uint32_t)r.org[a] + sh_tab[r.tabOff[a] + tab_index(ee[a], idx[a])];
+        }
+        ridx = (cc[2] * t.dims[1] + cc[1]) * t.dims[0] + cc[0];
+      }
+      else
+        ridx = pixel_raster(t, r, ee, idx);
       atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
       if ((sigmask >> lane) & 1u) {
         atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
