@@ -491,22 +491,34 @@ struct WFrame {
   uint8_t signmask;     // their sign bits
 };
 
-struct BitReader {      // wave-uniform sequential reader with two words of look-ahead
+struct BitReader {      // wave-uniform sequential reader over a 64-word window held in a register
   const uint64_t* words;
   uint64_t nwords;      // words at or past this index read as zero (zero padding)
-  uint64_t pos, cur, n1, n2;
-  __device__ __forceinline__ uint64_t load(uint64_t idx) const
+  uint64_t pos, cur, n1;
+  // Lane i keeps stream word wbase + i.  A word is picked out of the window when the reader gets
+  // to it; memory is touched once per 4096 bits.  (With a load per word the compiler wants the
+  // loaded word in scalar registers at once and waits for it there -- and with it for every
+  // atomic the walk has in flight, several times per 64 stream bits.)
+  uint64_t win, wbase;
+  __device__ __forceinline__ uint64_t word(uint64_t idx)
   {
-    return idx < nwords ? words[idx] : 0ull;
+    if (idx - wbase >= 64ull) {
+      wbase = idx;
+      const uint64_t k = idx + (threadIdx.x & 63u);
+      win = k < nwords ? words[k] : 0ull;
+    }
+    return __shfl(win, (int)(idx - wbase), 64);
   }
   __device__ __forceinline__ void init(const uint64_t* w, uint64_t p, uint64_t avail)
   {
     words = w;
     nwords = (avail + 63) / 64;
     pos = p;
-    cur = load(p >> 6);
-    n1 = load((p >> 6) + 1);
-    n2 = load((p >> 6) + 2);
+    wbase = p >> 6;
+    const uint64_t k = wbase + (threadIdx.x & 63u);
+    win = k < nwords ? words[k] : 0ull;
+    cur = word(p >> 6);
+    n1 = word((p >> 6) + 1);
   }
   __device__ __forceinline__ uint64_t peek64() const
   {
@@ -518,8 +530,7 @@ struct BitReader {      // wave-uniform sequential reader with two words of look
     const uint64_t np = pos + n;
     if ((np >> 6) != (pos >> 6)) {
       cur = n1;
-      n1 = n2;
-      n2 = load((np >> 6) + 2);
+      n1 = word((np >> 6) + 1);
     }
     pos = np;
   }
