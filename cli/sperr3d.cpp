@@ -63,6 +63,10 @@ int decode_and_write(const std::vector<uint8_t>& stream, bool multi_res, const s
 
 int main(int argc, char** argv)
 {
+  // volumes that the chunk size does not divide decode several shape groups side by side, one
+  // stream each: let the runtime map them to more than its default 4 hardware queues (has to be
+  // set before the first HIP call; an existing setting wins)
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   std::string input_file, bitstream, decomp_f32, decomp_f64, low_f32, low_f64;
   bool cflag = false, dflag = false, print_stats = false;
   size_t omp = 0, ftype = 0, dims[3] = {0, 0, 0}, chunks[3] = {256, 256, 256};

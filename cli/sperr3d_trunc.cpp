@@ -13,6 +13,10 @@ struct Freed {
 
 int main(int argc, char** argv)
 {
+  // volumes that the chunk size does not divide decode several shape groups side by side, one
+  // stream each: let the runtime map them to more than its default 4 hardware queues (has to be
+  // set before the first HIP call; an existing setting wins)
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   std::string input_file, out_file, orig32, orig64;
   size_t pct = 0, omp = 0;
   cli::Parser app("Truncate a SPERR3D bitstream to a percentage of its length (MI355X)\n");
