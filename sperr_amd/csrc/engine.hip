@@ -1497,7 +1497,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.bornStride = P.ht.nsets + 8;
   TAKE(d.bornPacked, uint64_t, d.bornStride * B);
   TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
-  d.tabSmemBytes = 144 * 1024;
+  d.tabSmemBytes = 152 * 1024;   // (k_lis_tables has 7 KB of static LDS: 160 KB in all)
   d.lisStamps = nullptr;
   if (g_lis_stamps_on) {
     TAKE(d.lisStamps, uint64_t, 64 * B);
