@@ -627,20 +627,18 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
       return false;
     const uint64_t w = rd.peek64();
     const uint32_t last = 31u - (uint32_t)__clz((int)present);
+    // (branch-free: a lone wavefront pays some twenty cycles for every taken branch)
     uint32_t y = 0, found = 0, sigmask = 0, signmask = 0;
 #pragma unroll
     for (uint32_t ci = 0; ci < 8; ci++) {
-      if (!((present >> ci) & 1u))
-        continue;
-      const uint32_t coded = found | (uint32_t)(ci != last);
-      const uint32_t sig = coded ? (uint32_t)((w >> y) & 1ull) : 1u;
+      const uint32_t pres = (present >> ci) & 1u;
+      const uint32_t coded = pres & (found | (uint32_t)(ci != last));
+      const uint32_t sig = pres & (((uint32_t)(w >> y) & coded) | (coded ^ 1u));   // not coded: implied 1
       y += coded;
       found |= sig;
-      if (sig) {
-        sigmask |= 1u << ci;
-        signmask |= (uint32_t)((w >> y) & 1ull) << ci;
-        y++;
-      }
+      sigmask |= sig << ci;
+      signmask |= ((uint32_t)(w >> y) & sig) << ci;   // the sign follows a significant sample
+      y += sig;
     }
     rd.skip(y);
     if (cnt == 1) {   // lanes 0..7 that have a sample
