@@ -594,33 +594,48 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
   // parents): at most 16 bits, read off the stream at once, decoded in straight-line code.  Nothing
   // can be entered, so no frame is set up and no barrier is needed; the set's parent goes on with
   // its next child.  Returns false (and reads nothing) for any other set.
-  // (the grid and root of the last set stay in registers: consecutive sets mostly share them)
+  // (what a set's grid and root contribute stays in registers: consecutive sets mostly share them)
   uint32_t lastGrid = 0xffffffffu;
-  Grid gc = {};
   Root rc = {};
+  int gee[3] = {0, 0, 0};             // log2 extent of the children's grid per axis
+  uint32_t gsa[3] = {0, 0, 0};        // 1: the axis still splits at this depth
+  uint32_t gstep[3] = {0, 0, 0};      // power-of-two axis: length of a child interval
+  uint32_t gtab[3] = {0, 0, 0};       // other axes: index of interval 0 in the staged table
+  uint32_t gpow2 = 0;                 // bit a: axis a has a power-of-two length
   const bool tabStaged = t.tab == sh_tab;
   auto try_leaf = [&](const Node& nd) -> bool {
     if (nd.grid != lastGrid) {
       lastGrid = nd.grid;
-      gc = t.grids[nd.grid];
+      const Grid gc = t.grids[nd.grid];
       rc = t.roots[gc.root];
+      gpow2 = 0;
+      for (int a = 0; a < 3; a++) {
+        gsa[a] = gc.depth < rc.D[a] ? 1u : 0u;
+        gee[a] = (int)gc.e[a] + (int)gsa[a];
+        const uint32_t L = rc.len[a];
+        if ((L & (L - 1u)) == 0) {
+          gpow2 |= 1u << a;
+          gstep[a] = L >> gee[a];
+          gtab[a] = 0;
+        }
+        else {
+          gstep[a] = 0;
+          gtab[a] = rc.tabOff[a] + tab_index(gee[a], 0);
+        }
+      }
     }
-    const Grid& g = gc;
     const Root& r = rc;
-    int ee[3];
+    const int* ee = gee;
     uint32_t cnt = 1, idx[3];
-    bool valid = lane < 8;
+    uint32_t ok = (uint32_t)lane < 8u ? 1u : 0u;
+#pragma unroll
     for (int a = 0; a < 3; a++) {
-      const bool sa = g.depth < r.D[a];
-      ee[a] = sa ? g.e[a] + 1 : g.e[a];
       const uint32_t bit = ((uint32_t)lane >> a) & 1u;
-      if (bit && !sa)
-        valid = false;
-      idx[a] = (sa ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a]) + bit;
+      ok &= (bit & (gsa[a] ^ 1u)) ^ 1u;                 // the upper half only where the axis splits
+      idx[a] = ((uint32_t)nd.i[a] << gsa[a]) + bit;
       cnt *= axis_len(r.len[a], ee[a], idx[a]);
     }
-    if (!valid)
-      cnt = 0;
+    cnt *= ok;
     const uint32_t present = (uint32_t)(__ballot(cnt > 0) & 0xffull);
     const uint32_t pixel = (uint32_t)(__ballot(cnt == 1) & 0xffull);
     if ((present & ~pixel) != 0u)
@@ -643,14 +658,12 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
     rd.skip(y);
     if (cnt == 1) {   // lanes 0..7 that have a sample
       uint32_t ridx;
-      if (tabStaged) {   // pixel_raster with the interval starts read from LDS as LDS
+      if (tabStaged) {   // pixel_raster with the interval starts read from LDS as LDS, no branch per axis
         uint32_t cc[3];
+#pragma unroll
         for (int a = 0; a < 3; a++) {
-          const uint32_t L = r.len[a];
-          if ((L & (L - 1u)) == 0)
-            cc[a] = (uint32_t)r.org[a] + idx[a] * (L >> ee[a]);
-          else
-            cc[a] = (uint32_t)r.org[a] + sh_tab[r.tabOff[a] + tab_index(ee[a], idx[a])];
+          const uint32_t tv = sh_tab[min(gtab[a] + idx[a], (uint32_t)kWalkTab - 1u)];
+          cc[a] = (uint32_t)r.org[a] + (((gpow2 >> a) & 1u) ? idx[a] * gstep[a] : tv);
         }
         ridx = (cc[2] * t.dims[1] + cc[1]) * t.dims[0] + cc[0];
       }
