@@ -14,7 +14,14 @@ whole-job rate: N * volume bytes / max-over-ranks(time per step).
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel's algorithmic bytes / its measured time vs the HBM peak
   cpu_baseline  the CPU oracle (the real reference build when oracle/_ref is present, else this
-                repo's C restatement) timed on a bounded sample of the same volume on this host
+                repo's C restatement) timed on the same volume on this host (all threads: the
+                reference's OpenMP loop runs one chunk per thread, so at most 64 threads work) and
+                on one 256^3 chunk with one thread
+  host_path     ONE volume in (pinned) host memory through the library's chunk farm
+                (sperrhip_comp_3d_farm / sperrhip_decomp_3d_into: what sperr_comp_3d runs on) over
+                the N devices of this launch, transfers included: the H2D/D2H-inclusive rate of
+                SURVEY 8(d) at N = 1, and the strong-scaling figure (a fixed 64-chunk volume dealt
+                to N GPUs) at N > 1.  Driven by rank 0; never used as `value`.
 """
 import argparse
 import json
@@ -30,6 +37,79 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 ALGO_BYTES_PER_VALUE = 4.25    # 4 B fp32 + BPP/8 B stream per value
 
 
+def run_host_path(eng, vol, chunks, bpp, devices, reps, dev_stream, dev_out):
+    """One volume in pinned host memory through the chunk farm on `devices`; transfers included."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    lib = eng.lib
+    dz, dy, dx = vol.shape
+    nbytes = vol.numel() * 4
+    hvol = torch.empty(vol.shape, dtype=torch.float32).pin_memory()
+    hvol.copy_(vol)
+    hout = torch.empty(vol.shape, dtype=torch.float32).pin_memory()
+    arr = (C.c_int * len(devices))(*devices)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def comp(ptr):
+        dst, n = C.c_void_p(None), C.c_size_t(0)
+        t0 = time.perf_counter()
+        rc = lib.sperrhip_comp_3d_farm(ptr, 1, dx, dy, dz, *chunks, 1, float(bpp), 0, arr, len(devices),
+                                       C.byref(dst), C.byref(n))
+        t1 = time.perf_counter()
+        assert rc == 0, f"sperrhip_comp_3d_farm returned {rc}"
+        return dst, n.value, t1 - t0
+
+    def decomp(dst, n, out_ptr):
+        x, y, z = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        t0 = time.perf_counter()
+        rc = lib.sperrhip_decomp_3d_into(dst, n, 1, 0, arr, len(devices), out_ptr, nbytes, C.byref(x),
+                                         C.byref(y), C.byref(z))
+        t1 = time.perf_counter()
+        assert rc == 0, f"sperrhip_decomp_3d_into returned {rc}"
+        return t1 - t0
+
+    tc, td = [], []
+    same = None
+    for it in range(reps + 1):          # the first pass allocates the staging buffers: untimed
+        dst, n, a = comp(hvol.data_ptr())
+        b = decomp(dst, n, hout.data_ptr())
+        if it == 0:
+            got = np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_uint8)), shape=(n,))
+            same = bool(n == dev_stream.numel() and
+                        torch.equal(torch.from_numpy(got.copy()), dev_stream.cpu()))
+        else:
+            tc.append(a)
+            td.append(b)
+        libc.free(dst)
+    # the same from pageable memory (numpy): rows are staged by helper threads
+    pvol = hvol.numpy().copy()
+    dst, n, _ = comp(pvol.ctypes.data)
+    libc.free(dst)
+    dst, n, pc = comp(pvol.ctypes.data)
+    pout = np.empty_like(pvol)
+    decomp(dst, n, pout.ctypes.data)
+    pd = decomp(dst, n, pout.ctypes.data)
+    libc.free(dst)
+    c, d = min(tc), min(td)
+    return {
+        "what": f"one {dx}x{dy}x{dz} fp32 volume in pinned host memory, chunks {chunks}, BPP {bpp}, farmed over "
+                f"{len(devices)} device(s) by the library (sperrhip_comp_3d_farm / sperrhip_decomp_3d_into); "
+                "H2D of the volume and D2H of the container (and back) inside the timing; best of "
+                f"{reps} after one untimed pass",
+        "scaling": "strong", "n_gpus": len(devices),
+        "compress_GBps": round(nbytes / c / 1e9, 3), "decompress_GBps": round(nbytes / d / 1e9, 3),
+        "round_trip_GBps": round(nbytes / (c + d) / 1e9, 3),
+        "compress_ms": round(c * 1e3, 2), "decompress_ms": round(d * 1e3, 2),
+        "pageable_compress_GBps": round(nbytes / pc / 1e9, 3),
+        "pageable_decompress_GBps": round(nbytes / pd / 1e9, 3),
+        "container_identical_to_device_path": same,
+        "decoded_identical_to_device_path": bool(torch.equal(hout, dev_out.cpu()) and
+                                                 torch.equal(hout, torch.from_numpy(pout))),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,8 +119,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--bpp", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="edge of the CPU baseline sample")
     ap.add_argument("--profile-out", default="", help="write the per-kernel event table here")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-resident farm run")
+    ap.add_argument("--host-reps", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -49,9 +131,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    host_pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")
+        # a host-side group: ranks that wait for rank 0's farm run must not spin on their GPUs
+        host_pg = dist.new_group(backend="gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -122,6 +207,14 @@ def main():
     err = float((out.double() - vol.double()).abs().max().item())
     ok_len = int(stream.numel()) == exp_len
 
+    # ---- one host-resident volume through the library's farm over all N devices (rank 0) ------
+    host_path = None
+    if not args.no_host_path:
+        if rank == 0:
+            host_path = run_host_path(eng, vol, chunks, args.bpp, list(range(world)), args.host_reps, stream, out)
+        if world > 1:
+            dist.barrier(group=host_pg)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -165,13 +258,18 @@ def main():
             for k, (ms, cnt, sm) in kern:
                 f.write(f"{k},{ms:.4f},{cnt},{sm / max(1, cnt):.5f}\n")
 
-    # ---- CPU baseline on a bounded sample of the same volume, this host -----------------------
+    # ---- CPU baseline: the same workload on this host's cores --------------------------------
+    # The reference's chunk loop is `omp parallel for` over chunks (SPERR3D_OMP_C.cpp:94), so a
+    # volume of 64 chunks keeps at most 64 threads busy: the sample is the bench volume itself
+    # (or its --cpu-sample^3 corner) and `effective_threads` says how many threads had a chunk.
+    # A one-thread figure on one chunk goes with it.
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         n = min(args.cpu_sample, S)
         sample = vol[:n, :n, :n].contiguous().cpu().numpy()
         cores = os.cpu_count() or 1
+        nch = max(1, (n // C)) ** 3
         if pyoracle.have_ref():
             impl, kind = pyoracle.Ref(), "reference"
         else:
@@ -182,14 +280,27 @@ def main():
         impl.decomp_3d(cs, True, nthreads=cores)
         c = time.perf_counter()
         # parity of the timed data: the HIP container of the same sample must be byte-identical
-        hs = bytes(eng.compress(torch.from_numpy(sample).to(dev), chunks, args.bpp).cpu().numpy())
+        if n == S:
+            hs = bytes(stream.cpu().numpy())
+        else:
+            hs = bytes(eng.compress(torch.from_numpy(sample).to(dev), chunks, args.bpp).cpu().numpy())
+        one = sample[:C, :C, :C].copy() if n >= C else sample
+        a1 = time.perf_counter()
+        c1 = impl.comp_3d(one, chunks, 1, args.bpp, nthreads=1)
+        b1 = time.perf_counter()
+        impl.decomp_3d(c1, True, nthreads=1)
+        d1 = time.perf_counter()
         cpu = {
             "value": round(sample.nbytes / (c - a) / 1e9, 4), "unit": "GB/s", "cores": cores,
+            "effective_threads": min(cores, nch),
             "kind": kind,
-            "sample": f"{n}^3 fp32 corner of the bench volume, {C}^3 chunks, bpp {args.bpp}: "
-                      f"compress {b - a:.2f} s + decompress {c - b:.2f} s",
+            "sample": f"{n}^3 fp32 of the bench volume ({nch} chunks of {C}^3), bpp {args.bpp}, all {cores} "
+                      f"threads offered: compress {b - a:.2f} s + decompress {c - b:.2f} s",
             "compress_GBps": round(sample.nbytes / (b - a) / 1e9, 4),
             "decompress_GBps": round(sample.nbytes / (c - b) / 1e9, 4),
+            "one_thread": {"sample": f"one {C}^3 chunk", "compress_GBps": round(one.nbytes / (b1 - a1) / 1e9, 4),
+                           "decompress_GBps": round(one.nbytes / (d1 - b1) / 1e9, 4),
+                           "value": round(one.nbytes / (d1 - a1) / 1e9, 4)},
             "hip_stream_identical": hs == cs,
         }
 
@@ -210,6 +321,7 @@ def main():
         "max_abs_err": err,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "host_path": host_path,
     }
     print(json.dumps(line))
     if world > 1:

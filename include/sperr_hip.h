@@ -7,8 +7,8 @@
  *    and return codes as /root/reference/include/SPERR_C_API.h:106-137,87-92 and
  *    /root/reference/src/SPERR_C_API.cpp:135-258): host buffers in, malloc'd host buffers out.
  *    The per-chunk pipeline (conditioner, CDF 9/7 DWT, quantiser, SPECK3D coder, bit packing)
- *    runs on the GPU; `nthreads` is accepted and ignored (the reference's OpenMP team size,
- *    src/SPERR3D_OMP_C.cpp:12-20).  mode 1 (fixed rate, `quality` = bits per value), mode 2
+ *    runs on the GPU(s); `nthreads` (the reference's OpenMP team size, src/SPERR3D_OMP_C.cpp:12-20)
+ *    is the number of host threads that stage rows for the transfers.  mode 1 (fixed rate, `quality` = bits per value), mode 2
  *    (fixed PSNR, dB) and mode 3 (fixed point-wise error, the tolerance; the outlier list goes
  *    through the reference's Outlier_Coder / SPECK1D_INT stream format) are implemented.
  *
@@ -48,6 +48,41 @@ void sperr_parse_header(const void* src, size_t* dimx, size_t* dimy, size_t* dim
 /* include/SPERR_C_API.h:138-156 : keep `pct` percent of every chunk stream (progressive access);
  * the result decodes with sperr_decomp_3d.  Host only.  Returns 0 ok, 1 *dst not NULL, -1 other. */
 int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, size_t* dst_len);
+
+/* ---- chunk farm: the same on an explicit list of devices -----------------------------------
+ * sperr_comp_3d / sperr_decomp_3d above run on the chunk farm of sperr_amd/csrc/farm.hip: the
+ * volume is cut into work items (runs of equally shaped chunks in chunk_volume order,
+ * /root/reference/src/sperr_helper.cpp:542-592), a shared queue hands them to a few worker threads
+ * per device, and every worker streams its items through pinned staging buffers (gather -> H2D ->
+ * the device pipeline -> D2H), so the volume is never resident on a device as a whole and may be
+ * larger than HBM.  This replaces the OpenMP chunk loops of
+ * /root/reference/src/SPERR3D_OMP_C.cpp:94-130 and src/SPERR3D_OMP_D.cpp:101-127.
+ * They use the devices SPERR_HIP_DEVICES names ("all", the default, or "0,2,3"); the entry points
+ * below take the list as an argument (devices == NULL or ndevices == 0: the same default).  An
+ * ordinal may repeat.  `nthreads`: host threads that move rows between the caller's buffers and the
+ * staging buffers (0 = a default of 4 per worker).  A caller's volume that is pinned host memory
+ * (hipHostMalloc / hipHostRegister) is read and written by DMA without staging.
+ * Return codes as sperr_comp_3d / sperr_decomp_3d. */
+int sperrhip_comp_3d_farm(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                          size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                          size_t nthreads, const int* devices, size_t ndevices, void** dst,
+                          size_t* dst_len);
+int sperrhip_decomp_3d_farm(const void* src, size_t src_len, int output_float, size_t nthreads,
+                            const int* devices, size_t ndevices, size_t* dimx, size_t* dimy,
+                            size_t* dimz, void** dst);
+/* the volume into a buffer of the caller (dst_bytes of room; it may be pinned memory) */
+int sperrhip_decomp_3d_into(const void* src, size_t src_len, int output_float, size_t nthreads,
+                            const int* devices, size_t ndevices, void* dst, size_t dst_bytes,
+                            size_t* dimx, size_t* dimy, size_t* dimz);
+/* Host-only check of the farm's queue (no device is touched): how the chunks of a volume are cut
+ * into items and which of ndevices * workers_per_device idle workers takes which.  lockstep != 0:
+ * the workers take their items in rounds (all equally fast), which makes the outcome
+ * deterministic.  per_worker_chunks[ndevices * workers_per_device], item_of_chunk[nchunks],
+ * worker_of_chunk[nchunks] (each may be NULL); worker w belongs to device w mod ndevices. */
+int sperrhip_farm_selftest(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x, size_t chunk_y,
+                           size_t chunk_z, size_t bytes_per_value, size_t ndevices,
+                           size_t workers_per_device, int lockstep, uint32_t* per_worker_chunks,
+                           uint32_t* item_of_chunk, uint32_t* worker_of_chunk, size_t* nitems);
 
 /* ---- device-resident API ---------------------------------------------------------------------- */
 

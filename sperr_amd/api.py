@@ -24,6 +24,8 @@ EXPORTS = [
     "sperr_comp_2d", "sperr_decomp_2d", "sperrhip_max_compressed_size_2d", "sperrhip_compress_2d_dev",
     "sperrhip_decompress_2d_dev", "sperrhip_version", "sperrhip_debug_lis_stamps",
     "sperrhip_multires_levels_2d", "sperrhip_decompress_2d_multires_dev", "sperrhip_decomp_2d_multires",
+    "sperrhip_comp_3d_farm", "sperrhip_decomp_3d_farm", "sperrhip_decomp_3d_into",
+    "sperrhip_farm_selftest",
 ]
 
 
@@ -76,6 +78,15 @@ def load_library():
     lib.sperrhip_profile_get.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                          C.POINTER(C.c_int), C.c_int]
     lib.sperrhip_version.restype = C.c_char_p
+    lib.sperrhip_comp_3d_farm.restype = C.c_int
+    lib.sperrhip_comp_3d_farm.argtypes = [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_double,
+                                          _sz, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+    lib.sperrhip_decomp_3d_farm.restype = C.c_int
+    lib.sperrhip_decomp_3d_farm.argtypes = [_vp, _sz, C.c_int, _sz, _vp, _sz, C.POINTER(_sz),
+                                            C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_vp)]
+    lib.sperrhip_decomp_3d_into.restype = C.c_int
+    lib.sperrhip_decomp_3d_into.argtypes = [_vp, _sz, C.c_int, _sz, _vp, _sz, _vp, _sz, C.POINTER(_sz),
+                                            C.POINTER(_sz), C.POINTER(_sz)]
     return lib
 
 
@@ -236,6 +247,68 @@ class SperrHip:
         out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
         self._libc.free(dst)
         return out.reshape(dz.value, dy.value, dx.value)
+
+    # ---- chunk farm on an explicit device list (include/sperr_hip.h) -------------------------
+    @staticmethod
+    def _devs(devices):
+        if not devices:
+            return None, 0
+        arr = (C.c_int * len(devices))(*devices)
+        return arr, len(devices)
+
+    def comp_3d_farm(self, vol, chunks_xyz, mode, quality, devices=None, nthreads=0):
+        """vol: numpy (z, y, x) or a pinned torch CPU tensor; -> container bytes."""
+        ptr, shape, is_float = self._host_array(vol)
+        dz, dy, dx = shape
+        dst, n = _vp(None), _sz(0)
+        arr, nd = self._devs(devices)
+        rtn = self.lib.sperrhip_comp_3d_farm(ptr, is_float, dx, dy, dz, *chunks_xyz, mode, quality,
+                                             nthreads, arr, nd, C.byref(dst), C.byref(n))
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_comp_3d_farm returned {rtn}")
+        out = C.string_at(dst.value, n.value)
+        self._libc.free(dst)
+        return out
+
+    def _host_array(self, vol):
+        if isinstance(vol, np.ndarray):
+            vol = np.ascontiguousarray(vol)
+            self._keep = vol
+            return vol.ctypes.data, vol.shape, int(vol.dtype == np.float32)
+        assert not vol.is_cuda and vol.is_contiguous()
+        return vol.data_ptr(), tuple(vol.shape), int(vol.dtype == self.torch.float32)
+
+    def decomp_3d_farm(self, stream, output_float=True, devices=None, nthreads=0):
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        dst = _vp(None)
+        dx, dy, dz = _sz(0), _sz(0), _sz(0)
+        arr, nd = self._devs(devices)
+        rtn = self.lib.sperrhip_decomp_3d_farm(buf.ctypes.data, buf.size, int(output_float), nthreads,
+                                               arr, nd, C.byref(dx), C.byref(dy), C.byref(dz),
+                                               C.byref(dst))
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decomp_3d_farm returned {rtn}")
+        n = dx.value * dy.value * dz.value
+        dt = np.float32 if output_float else np.float64
+        out = np.frombuffer(C.string_at(dst.value, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        self._libc.free(dst)
+        return out.reshape(dz.value, dy.value, dx.value)
+
+    def decomp_3d_into(self, stream, out, devices=None, nthreads=0):
+        """out: numpy array or (pinned) torch CPU tensor shaped (z, y, x), float32 or float64."""
+        buf = np.frombuffer(stream, dtype=np.uint8) if isinstance(stream, (bytes, bytearray)) else stream
+        sptr = buf.ctypes.data if isinstance(buf, np.ndarray) else buf.data_ptr()
+        slen = buf.size if isinstance(buf, np.ndarray) else buf.numel()
+        ptr, shape, is_float = self._host_array(out)
+        nbytes = int(np.prod(shape)) * (4 if is_float else 8)
+        dx, dy, dz = _sz(0), _sz(0), _sz(0)
+        arr, nd = self._devs(devices)
+        rtn = self.lib.sperrhip_decomp_3d_into(sptr, slen, is_float, nthreads, arr, nd, ptr, nbytes,
+                                               C.byref(dx), C.byref(dy), C.byref(dz))
+        if rtn != 0:
+            raise SperrHipError(f"sperrhip_decomp_3d_into returned {rtn}")
+        assert (dz.value, dy.value, dx.value) == tuple(shape)
+        return out
 
     # ---- 2D slices --------------------------------------------------------------------------
     def compress_2d(self, img, quality, mode=1, header=False):

@@ -23,6 +23,8 @@ namespace sperrhip {
 // per-kernel profiling hooks (engine.hip): no-ops unless sperrhip_profile_enable(1)
 void prof_begin(const char* name, hipStream_t stream);
 void prof_end(hipStream_t stream);
+// allow `bytes` of dynamic LDS for a kernel on the current device (engine.hip; once per device)
+int set_max_dyn_lds(const void* fn, int bytes);
 #define LAUNCH_K(kern, grid, block, smem, stream, ...)                \
   do {                                                                \
     ::sperrhip::prof_begin(#kern, stream);                            \

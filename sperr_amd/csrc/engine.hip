@@ -16,12 +16,14 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
 
 #include "../../include/sperr_hip.h"
+#include "engine_internal.h"
 #include "speck_dec.h"
 #include "speck_enc.h"
 #include "speck_tree_host.hpp"
@@ -105,7 +107,11 @@ struct Profiler {
   }
 };
 
-Profiler g_prof;
+// global switches (sperrhip_profile_enable / _only); the accumulators live in the engines
+bool g_prof_on = false;
+std::string g_prof_only;
+std::mutex g_prof_cfg_mu;
+thread_local Profiler* t_prof = nullptr;       // the profiler of the engine this thread drives
 thread_local const char* t_prof_cur = nullptr;
 thread_local hipEvent_t t_prof_a = nullptr;
 
@@ -113,29 +119,31 @@ thread_local hipEvent_t t_prof_a = nullptr;
 
 void prof_begin(const char* name, hipStream_t stream)
 {
-  if (!g_prof.on || (!g_prof.only.empty() && g_prof.only != name))
+  Profiler* P = t_prof;
+  if (!P || !P->on || (!P->only.empty() && P->only != name))
     return;
-  std::lock_guard<std::mutex> lock(g_prof.mu);
-  if (!g_prof.ref) {
-    g_prof.ref = g_prof.get();
-    if (g_prof.ref)
-      hipEventRecord(g_prof.ref, stream);
+  std::lock_guard<std::mutex> lock(P->mu);
+  if (!P->ref) {
+    P->ref = P->get();
+    if (P->ref)
+      hipEventRecord(P->ref, stream);
   }
   t_prof_cur = name;
-  t_prof_a = g_prof.get();
+  t_prof_a = P->get();
   if (t_prof_a)
     hipEventRecord(t_prof_a, stream);
 }
 
 void prof_end(hipStream_t stream)
 {
-  if (!g_prof.on || !t_prof_cur)
+  Profiler* P = t_prof;
+  if (!P || !P->on || !t_prof_cur)
     return;
-  std::lock_guard<std::mutex> lock(g_prof.mu);
-  hipEvent_t b = g_prof.get();
+  std::lock_guard<std::mutex> lock(P->mu);
+  hipEvent_t b = P->get();
   if (b)
     hipEventRecord(b, stream);
-  g_prof.open.push_back({t_prof_cur, t_prof_a, b});
+  P->open.push_back({t_prof_cur, t_prof_a, b});
   t_prof_cur = nullptr;
 }
 
@@ -457,16 +465,25 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
 }
 
 // ------------------------------------------------------------------------------------------
-// engine singleton
+// engines: one per (device, concurrent caller)
 // ------------------------------------------------------------------------------------------
+// The reference's classes are re-entrant (one compressor object per OpenMP thread,
+// src/SPERR3D_OMP_C.cpp:61-92).  Here an engine owns everything a call needs on ONE device (streams,
+// per-shape plans, workspaces); a call leases an idle engine of the device that is current on the
+// calling thread and a new one is made when all of them are busy (up to
+// SPERR_HIP_ENGINES_PER_DEVICE, default 4; then callers wait).  The chunk farm (farm.hip) runs
+// several workers per device this way.
 constexpr uint32_t kSubStreams = 8;
 
 struct Engine {
-  std::mutex mu;
+  int dev = -1;
+  bool busy = false;
   bool ready = false;
+  Profiler prof;
   hipStream_t sub[kSubStreams] = {};
   hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {};
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
+  std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
@@ -476,11 +493,6 @@ struct Engine {
   {
     if (ready)
       return 0;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-      fprintf(stderr, "[sperr_hip] no HIP device available; this library has no CPU fallback\n");
-      return -1;
-    }
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     freeMemAtInit = fr;
@@ -493,22 +505,125 @@ struct Engine {
     return 0;
   }
 
+  // the device tables of at most kMaxPlans chunk shapes are kept (a ragged volume has 8 shapes)
+  static constexpr size_t kMaxPlans = 64;
   ShapePlan* plan(size_t dx, size_t dy, size_t dz)
   {
     const Dims key{dx, dy, dz};
     auto it = plans.find(key);
-    if (it != plans.end())
+    if (it != plans.end()) {
+      auto pos = std::find(planOrder.begin(), planOrder.end(), key);
+      if (pos != planOrder.end())
+        planOrder.erase(pos);
+      planOrder.push_back(key);
       return it->second.get();
+    }
     auto p = std::make_unique<ShapePlan>();
     if (build_plan(*p, dx, dy, dz))
       return nullptr;
     ShapePlan* raw = p.get();
     plans[key] = std::move(p);
+    planOrder.push_back(key);
     return raw;
+  }
+  // called between calls only (no kernel of this engine is in flight)
+  void trim_plans()
+  {
+    while (planOrder.size() > kMaxPlans) {
+      auto it = plans.find(planOrder.front());
+      if (it != plans.end()) {
+        if (it->second->tables.p)
+          (void)hipFree(it->second->tables.p);
+        plans.erase(it);
+      }
+      planOrder.erase(planOrder.begin());
+    }
   }
 };
 
-Engine g_engine;
+struct EnginePool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::unique_ptr<Engine>> all;
+
+  // an idle engine of the device current on this thread; nullptr: no device / initialisation failed
+  Engine* acquire()
+  {
+    int ndev = 0, dev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      fprintf(stderr, "[sperr_hip] no HIP device available; this library has no CPU fallback\n");
+      return nullptr;
+    }
+    if (hipGetDevice(&dev) != hipSuccess)
+      return nullptr;
+    static const size_t perDev = getenv("SPERR_HIP_ENGINES_PER_DEVICE")
+                                     ? (size_t)std::max(1, atoi(getenv("SPERR_HIP_ENGINES_PER_DEVICE")))
+                                     : 4;
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+      size_t have = 0;
+      for (auto& e : all)
+        if (e->dev == dev) {
+          have++;
+          if (!e->busy) {
+            e->busy = true;
+            return e.get();
+          }
+        }
+      if (have < perDev) {
+        auto e = std::make_unique<Engine>();
+        e->dev = dev;
+        e->busy = true;
+        Engine* raw = e.get();
+        all.push_back(std::move(e));
+        lock.unlock();
+        if (raw->init()) {
+          lock.lock();
+          raw->busy = false;
+          raw->dev = -1;   // never handed out again
+          cv.notify_all();
+          return nullptr;
+        }
+        return raw;
+      }
+      cv.wait(lock);
+    }
+  }
+  void release(Engine* e)
+  {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      e->busy = false;
+    }
+    cv.notify_all();
+  }
+};
+
+EnginePool g_pool;
+
+// a call's hold on an engine; also makes the engine's profiler the calling thread's
+struct Lease {
+  Engine* e;
+  Lease() : e(g_pool.acquire())
+  {
+    if (e) {
+      std::lock_guard<std::mutex> lock(g_prof_cfg_mu);
+      e->prof.on = g_prof_on;
+      e->prof.only = g_prof_only;
+      t_prof = &e->prof;
+    }
+  }
+  ~Lease()
+  {
+    if (e) {
+      t_prof = nullptr;
+      e->trim_plans();
+      g_pool.release(e);
+    }
+  }
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+};
 
 // bytes of workspace one chunk of this shape needs
 struct EncSizes {
@@ -612,17 +727,18 @@ __global__ void k_container_header(uint8_t* dst, const uint64_t* lens, const uin
 
 __global__ void __launch_bounds__(kThreads)
 k_copy_slots(uint8_t* dst, uint64_t dst_cap, const uint8_t* slots, const uint64_t* slotOff,
-             const uint64_t* lens, const uint64_t* offs)
+             const uint64_t* lens, const uint64_t* offs, uint32_t nchunks)
 {
-  const uint32_t g = blockIdx.y;
-  const uint64_t len = lens[g];
-  if (offs[g] + len > dst_cap)
-    return;
-  const uint8_t* in = slots + slotOff[g];
-  uint8_t* out = dst + offs[g];
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    out[i] = in[i];
+  for (uint32_t g = blockIdx.y; g < nchunks; g += gridDim.y) {   // (grid.y is limited to 65535)
+    const uint64_t len = lens[g];
+    if (offs[g] + len > dst_cap)
+      continue;
+    const uint8_t* in = slots + slotOff[g];
+    uint8_t* out = dst + offs[g];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (uint64_t)gridDim.x * blockDim.x)
+      out[i] = in[i];
+  }
 }
 
 // outlier streams of one batch (local index b): they follow the chunk's SPECK stream
@@ -1128,18 +1244,34 @@ __global__ void k_slice_header(uint8_t* dst, const uint64_t* lens, const uint64_
   *total = pos + lens[0] + lens2[0];
 }
 
+// Work queued by a call that fails must not outlive the call: the caller's buffers and the engine's
+// arena are reused as soon as it returns.  Every exit that is not marked ok waits for the caller's
+// stream and the engine's sub-streams first.
+struct DrainOnError {
+  Engine& E;
+  hipStream_t st;
+  bool ok = false;
+  ~DrainOnError()
+  {
+    if (ok)
+      return;
+    (void)hipStreamSynchronize(st);
+    for (uint32_t q = 0; q < kSubStreams; q++)
+      if (E.sub[q])
+        (void)hipStreamSynchronize(E.sub[q]);
+    (void)hipGetLastError();
+  }
+};
+
 template <typename T>
-int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mode, double quality,
+int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkPref, int mode, double quality,
                   uint8_t* d_dst, size_t dst_cap, size_t* dst_len, hipStream_t st, int slice = 0)
 {   // slice: 0 = a 3D container; 1 / 2 = one 2D slice without / with the 10-byte header
   // mode 1: fixed rate, `quality` bits per value; mode 2: fixed PSNR and mode 3: fixed point-wise
   // error, every bit plane is coded
   const bool rate = mode == 1;
   const double bpp = rate ? quality : 0.0;
-  Engine& E = g_engine;
-  std::lock_guard<std::mutex> lock(E.mu);
-  if (E.init())
-    return -1;
+  DrainOnError drainGuard{E, st};
   Dims cdim;
   for (int a = 0; a < 3; a++)  // SPERR3D_OMP_C.cpp:23-30
     cdim[a] = std::min(std::max<size_t>(1, chunkPref[a]), vol[a]);
@@ -1317,6 +1449,11 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
   }
 
   // ---- container ----
+  // (the header kernels write before any length is known to them: check its room here)
+  if (dst_cap < (slice ? (slice == 2 ? 10u : 0u) : (nchunks > 1 ? 20u : 14u) + 4ull * nchunks)) {
+    fprintf(stderr, "[sperr_hip] output buffer too small for the container header (%zu bytes)\n", dst_cap);
+    return -1;
+  }
   if (slice)
     LAUNCH_K(k_slice_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs,
              (uint32_t)vol[0], (uint32_t)vol[1], std::is_same<T, float>::value ? 1 : 0,
@@ -1325,8 +1462,12 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
     LAUNCH_K(k_container_header, dim3(1), dim3(1), 0, st, d_dst, d_lens, d_lens2, d_offs, nchunks,
              (uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2], (uint32_t)cdim[0],
              (uint32_t)cdim[1], (uint32_t)cdim[2], std::is_same<T, float>::value ? 1 : 0, d_total);
-  LAUNCH_K(k_copy_slots, dim3(1024, nchunks), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap,
-           static_cast<const uint8_t*>(E.slots.p), d_slotOff, d_lens, d_offs);
+  {
+    const uint32_t gy = std::min<uint32_t>(nchunks, 32768u);
+    const uint32_t gx = nchunks >= 4096 ? 4u : nchunks >= 256 ? 64u : 1024u;
+    LAUNCH_K(k_copy_slots, dim3(gx, gy), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap,
+             static_cast<const uint8_t*>(E.slots.p), d_slotOff, d_lens, d_offs, nchunks);
+  }
   for (auto& k : pweKeep.v)
     LAUNCH_K(k_copy_slots2, dim3(256, k.nb), dim3(kThreads), 0, st, d_dst, (uint64_t)dst_cap, k.slots,
              k.slotOff, k.gids, d_lens, d_lens2, d_offs);
@@ -1334,13 +1475,14 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
   HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   HIP_CHECK(hipGetLastError());
-  g_prof.collect();
+  E.prof.collect();
   if (total > dst_cap) {
     fprintf(stderr, "[sperr_hip] output buffer too small (%zu < %llu)\n", dst_cap,
             (unsigned long long)total);
     return -1;
   }
   *dst_len = (size_t)total;
+  drainGuard.ok = true;
   return 0;
 }
 
@@ -1349,6 +1491,7 @@ int compress_impl(const T* d_src, const Dims& vol, const Dims& chunkPref, int mo
 // ------------------------------------------------------------------------------------------
 struct ContainerInfo {
   Dims vol, chunk;
+  size_t nvals = 0;   // vol[0] * vol[1] * vol[2], checked not to wrap
   bool is_float = false, multi = false;
   std::vector<uint64_t> off, len;
 };
@@ -1383,6 +1526,12 @@ int parse_container_host(const uint8_t* h, size_t hlen, size_t total_len, Contai
   for (int a = 0; a < 3; a++)
     if (ci.vol[a] == 0 || ci.chunk[a] == 0)
       return -1;
+  {   // three 32-bit dims can wrap a size_t; everything downstream sizes buffers from this product
+    const unsigned __int128 nv = (unsigned __int128)ci.vol[0] * ci.vol[1] * ci.vol[2];
+    if (nv > (unsigned __int128)(SIZE_MAX / 8))
+      return -1;
+    ci.nvals = (size_t)nv;
+  }
   // every chunk has a 4-byte length in the header: a damaged header must not make us list more
   // chunks than the container could hold
   const size_t nchunks = chunk_count(ci.vol, ci.chunk);
@@ -1584,14 +1733,14 @@ k_sub_volume(const double* vals, size_t valsStride, const CoderState* cst, const
 }
 
 template <typename T>
-int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_cap_vals,
+int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_cap_vals,
                     const ContainerInfo& ci, hipStream_t st, const MultiRes* mr = nullptr,
                     bool slice = false)
 {   // slice: `ci` describes one chunk of dims (x, y, 1) whose stream starts at d_src (2D coder)
-  Engine& E = g_engine;
+  DrainOnError drainGuard{E, st};
   const auto chunks = chunk_volume(ci.vol, ci.chunk);
   const uint32_t nchunks = (uint32_t)chunks.size();
-  if (ci.vol[0] * ci.vol[1] * ci.vol[2] > dst_cap_vals)
+  if (ci.nvals == 0 || ci.nvals > dst_cap_vals)
     return -1;
   (void)src_len;
 
@@ -1817,8 +1966,10 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
         const size_t first = S.first;
         if (nb == 0)
           return 0;
-        if (nsub > 1)
+        if (nsub > 1) {
           HIP_CHECK(hipSetDevice(devId));
+          t_prof = &E.prof;   // (this may be a thread of its own)
+        }
         hipStream_t ss = deferStream ? deferStream : (nsub > 1 ? E.sub[q] : st);
         DecBatchBufs& bb = S.bb;
         DecBuffers& d = bb.db;
@@ -2068,7 +2219,8 @@ int decompress_impl(const uint8_t* d_src, size_t src_len, T* d_dst, size_t dst_c
     return -1;
   HIP_CHECK(hipStreamSynchronize(st));
   HIP_CHECK(hipGetLastError());
-  g_prof.collect();
+  E.prof.collect();
+  drainGuard.ok = true;
   return 0;
 }
 
@@ -2117,6 +2269,61 @@ __global__ void k_fake_condi_header(uint8_t* dst)
 }
 
 }  // namespace
+
+// dynamic LDS above 64 KB has to be allowed per kernel and per device
+std::vector<std::array<size_t, 6>> host_chunk_volume(const Dims3& vol, const Dims3& chunk)
+{
+  return chunk_volume(vol, chunk);
+}
+
+int host_parse_container(const uint8_t* p, size_t len, HostContainer& out)
+{
+  if (len < 18)
+    return -1;
+  ContainerInfo ci;
+  size_t need = 0;
+  if (parse_container_host(p, len, len, ci, &need) != 0)
+    return -1;
+  out.vol = ci.vol;
+  out.chunk = ci.chunk;
+  out.nvals = ci.nvals;
+  out.is_float = ci.is_float;
+  out.multi = ci.multi;
+  out.portion = (p[1] & 0x80) != 0;
+  out.off = std::move(ci.off);
+  out.len = std::move(ci.len);
+  return 0;
+}
+
+size_t host_chunk_stream_bound(size_t nvals, int mode, double quality)
+{
+  const double n = (double)nvals;
+  const uint64_t raw = mode == 1 ? (uint64_t)(quality * n) : 0;
+  // without a budget every plane is coded: at most 66 bits per sample and 64 tests per set, and
+  // a chunk has fewer sets than samples (the bound of max_payload_bits, engine-side)
+  const uint64_t unlimited = (uint64_t)(130.0 * n) + 64;
+  const uint64_t bits = raw ? std::min(rounded_budget(raw), unlimited) : unlimited;
+  size_t total = 26 + (size_t)((bits + 7) / 8) + 8;
+  if (mode == 3)   // the outlier stream: the same bound for the 1D coder over n values
+    total += 9 + (size_t)((unlimited + 7) / 8);
+  return total;
+}
+
+int set_max_dyn_lds(const void* fn, int bytes)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({dev, fn});
+  if (it != done.end() && it->second >= bytes)
+    return 0;
+  HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[{dev, fn}] = bytes;
+  return 0;
+}
+
 }  // namespace sperrhip
 
 // ==========================================================================================
@@ -2153,11 +2360,13 @@ const char* sperrhip_version(void)
 
 void sperrhip_profile_enable(int on)
 {
-  g_prof.on = on != 0;
+  std::lock_guard<std::mutex> lock(g_prof_cfg_mu);
+  g_prof_on = on != 0;
 }
 void sperrhip_profile_only(const char* kernel)
 {
-  g_prof.only = kernel ? kernel : "";
+  std::lock_guard<std::mutex> lock(g_prof_cfg_mu);
+  g_prof_only = kernel ? kernel : "";
 }
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
 {
@@ -2168,7 +2377,11 @@ void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
 }
 void sperrhip_profile_reset(void)
 {
-  g_prof.acc.clear();
+  std::lock_guard<std::mutex> lock(g_pool.mu);
+  for (auto& e : g_pool.all) {
+    std::lock_guard<std::mutex> l2(e->prof.mu);
+    e->prof.acc.clear();
+  }
 }
 int sperrhip_profile_get(const char** names, double* millis, int* launches, int cap)
 {
@@ -2180,8 +2393,25 @@ int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_m
                           int cap)
 {
   return guarded("sperrhip_profile_get2", [&]() -> int {
+    // the engines' tables merged; the names stay valid until the next call
+    static std::mutex mu;
+    static std::map<std::string, ProfEntry> merged;
+    std::lock_guard<std::mutex> lock(mu);
+    merged.clear();
+    {
+      std::lock_guard<std::mutex> lp(g_pool.mu);
+      for (auto& e : g_pool.all) {
+        std::lock_guard<std::mutex> l2(e->prof.mu);
+        for (auto& kv : e->prof.acc) {
+          ProfEntry& m = merged[kv.first];
+          m.ms += kv.second.ms;
+          m.busy += kv.second.busy;
+          m.launches += kv.second.launches;
+        }
+      }
+    }
     int i = 0;
-    for (auto& kv : g_prof.acc) {
+    for (auto& kv : merged) {
       if (i < cap) {
         names[i] = kv.first.c_str();
         busy_millis[i] = kv.second.busy;
@@ -2204,16 +2434,8 @@ size_t sperrhip_max_compressed_size(size_t dimx, size_t dimy, size_t dimz, size_
     cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
   const auto chunks = chunk_volume(vol, cd);
   size_t total = 20 + 4 * chunks.size();
-  for (auto& c : chunks) {
-    const double n = (double)(c[1] * c[3] * c[5]);
-    const uint64_t raw = mode == 1 ? (uint64_t)(quality * n) : 0;
-    // without a budget every plane is coded: at most 66 bits per sample and 64 tests per set, and
-    // a chunk has fewer sets than samples (the bound of max_payload_bits, engine-side)
-    const uint64_t bits = raw ? rounded_budget(raw) : (uint64_t)(130.0 * n) + 64;
-    total += 26 + (bits + 7) / 8 + 8;
-    if (mode == 3)   // the outlier stream: the same bound for the 1D coder over n values
-      total += 9 + ((uint64_t)(130.0 * n) + 64 + 7) / 8;
-  }
+  for (auto& c : chunks)
+    total += host_chunk_stream_bound(c[1] * c[3] * c[5], mode, quality);
   return total;
 }
 
@@ -2228,12 +2450,16 @@ int sperrhip_compress_dev(const void* d_src, int is_float, size_t dimx, size_t d
       return 2;
     if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
       return -1;
+    Lease L;
+    if (!L.e)
+      return -1;
+    Engine& E = *L.e;
     const Dims vol{dimx, dimy, dimz}, ch{chunk_x, chunk_y, chunk_z};
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (is_float)
-      return compress_impl<float>(static_cast<const float*>(d_src), vol, ch, mode, quality,
+      return compress_impl<float>(E, static_cast<const float*>(d_src), vol, ch, mode, quality,
                                   static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
-    return compress_impl<double>(static_cast<const double*>(d_src), vol, ch, mode, quality,
+    return compress_impl<double>(E, static_cast<const double*>(d_src), vol, ch, mode, quality,
                                  static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st);
   });
 }
@@ -2243,9 +2469,10 @@ int sperrhip_parse_header_dev(const void* d_src, size_t src_len, size_t* dimx, s
                               size_t* chunk_z)
 {
   return guarded("sperrhip_parse_header_dev", [&]() -> int {
-    std::lock_guard<std::mutex> lock(g_engine.mu);
-    if (g_engine.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     ContainerInfo ci;
     if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, nullptr))
       return -1;
@@ -2270,9 +2497,10 @@ int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float,
   return guarded("sperrhip_decompress_dev", [&]() -> int {
     if (!d_src || !d_dst)
       return -1;
-    std::lock_guard<std::mutex> lock(g_engine.mu);
-    if (g_engine.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ContainerInfo ci;
     if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
@@ -2284,9 +2512,9 @@ int sperrhip_decompress_dev(const void* d_src, size_t src_len, int output_float,
     if (dimz)
       *dimz = ci.vol[2];
     if (output_float)
-      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+      return decompress_impl<float>(E, static_cast<const uint8_t*>(d_src), src_len,
                                     static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st);
-    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+    return decompress_impl<double>(E, static_cast<const uint8_t*>(d_src), src_len,
                                    static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
                                    st);
   });
@@ -2320,9 +2548,10 @@ int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int outp
   return guarded("sperrhip_decompress_multires_dev", [&]() -> int {
     if (!d_src || !d_dst || (nlev && !d_levels))
       return -1;
-    std::lock_guard<std::mutex> lock(g_engine.mu);
-    if (g_engine.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ContainerInfo ci;
     if (read_container_info(static_cast<const uint8_t*>(d_src), src_len, ci, st))
@@ -2337,10 +2566,10 @@ int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int outp
       m.d_level[h] = d_levels[h];
     }
     if (output_float)
-      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+      return decompress_impl<float>(E, static_cast<const uint8_t*>(d_src), src_len,
                                     static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
                                     &m);
-    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+    return decompress_impl<double>(E, static_cast<const uint8_t*>(d_src), src_len,
                                    static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci,
                                    st, &m);
   });
@@ -2363,13 +2592,17 @@ int sperrhip_compress_2d_dev(const void* d_src, int is_float, size_t dimx, size_
       return 2;
     if (!d_src || !d_dst || !dst_len || dimx == 0 || dimy == 0)
       return -1;
+    Lease L;
+    if (!L.e)
+      return -1;
+    Engine& E = *L.e;
     const Dims vol{dimx, dimy, 1};
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int slice = out_inc_header ? 2 : 1;
     if (is_float)
-      return compress_impl<float>(static_cast<const float*>(d_src), vol, vol, mode, quality,
+      return compress_impl<float>(E, static_cast<const float*>(d_src), vol, vol, mode, quality,
                                   static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
-    return compress_impl<double>(static_cast<const double*>(d_src), vol, vol, mode, quality,
+    return compress_impl<double>(E, static_cast<const double*>(d_src), vol, vol, mode, quality,
                                  static_cast<uint8_t*>(d_dst), dst_cap, dst_len, st, slice);
   });
 }
@@ -2381,21 +2614,23 @@ int sperrhip_decompress_2d_dev(const void* d_src, size_t src_len, int output_flo
   return guarded("sperrhip_decompress_2d_dev", [&]() -> int {
     if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17)
       return -1;
-    std::lock_guard<std::mutex> lock(g_engine.mu);
-    if (g_engine.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ContainerInfo ci;
     ci.vol = {dimx, dimy, 1};
+    ci.nvals = dimx * dimy;
     ci.chunk = ci.vol;
     ci.is_float = output_float != 0;
     ci.off = {0};
     ci.len = {src_len};
     if (output_float)
-      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+      return decompress_impl<float>(E, static_cast<const uint8_t*>(d_src), src_len,
                                     static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st,
                                     nullptr, true);
-    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+    return decompress_impl<double>(E, static_cast<const uint8_t*>(d_src), src_len,
                                    static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st,
                                    nullptr, true);
   });
@@ -2407,10 +2642,10 @@ int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, in
                        void* hip_stream)
 {
   return guarded("sperrhip_dwt3d_dev", [&]() -> int {
-    Engine& E = g_engine;
-    std::lock_guard<std::mutex> lock(E.mu);
-    if (E.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ShapePlan* P = E.plan(dimx, dimy, dimz);
     if (!P || E.misc.ensure(4096))
@@ -2429,7 +2664,7 @@ int sperrhip_dwt3d_dev(double* d_vals, size_t dimx, size_t dimy, size_t dimz, in
           return -1;
     }
     HIP_CHECK(hipStreamSynchronize(st));
-    g_prof.collect();
+    E.prof.collect();
     return 0;
   });
 }
@@ -2441,10 +2676,10 @@ int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d
   return guarded("sperrhip_speck3d_encode_dev", [&]() -> int {
     if (width != 4 && width != 8)
       return 2;
-    Engine& E = g_engine;
-    std::lock_guard<std::mutex> lock(E.mu);
-    if (E.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ShapePlan* P = E.plan(dimx, dimy, dimz);
     if (!P)
@@ -2492,7 +2727,7 @@ int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d
     HIP_CHECK(hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
-    g_prof.collect();
+    E.prof.collect();
     if (len > dst_cap)
       return -1;
     *dst_len = (size_t)len;
@@ -2507,10 +2742,10 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
   return guarded("sperrhip_speck3d_decode_dev", [&]() -> int {
     if (stream_len < 9)
       return -1;
-    Engine& E = g_engine;
-    std::lock_guard<std::mutex> lock(E.mu);
-    if (E.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ShapePlan* P = E.plan(dimx, dimy, dimz);
     if (!P)
@@ -2572,7 +2807,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     HIP_CHECK(hipMemcpyAsync(d_sign, d.sign, ((n + 63) / 64) * 8, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipGetLastError());
-    g_prof.collect();
+    E.prof.collect();
     *width_out = wide ? 8 : 4;
     return 0;
   });
@@ -2590,51 +2825,6 @@ void sperr_parse_header(const void* src, size_t* dimx, size_t* dimy, size_t* dim
   *dimx = d[0];
   *dimy = d[1];
   *dimz = d[2];
-}
-
-int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
-                  size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
-                  size_t nthreads, void** dst, size_t* dst_len)
-{
-  return guarded("sperr_comp_3d", [&]() -> int {
-    (void)nthreads;
-    if (*dst != nullptr)
-      return 1;
-    if (quality <= 0.0)
-      return 2;
-    if (mode < 1 || mode > 3)
-      return 2;
-    const size_t n = dimx * dimy * dimz;
-    const size_t esz = is_float ? 4 : 8;
-    const size_t cap = sperrhip_max_compressed_size(dimx, dimy, dimz, chunk_x, chunk_y, chunk_z,
-                                                    mode, quality);
-    void *d_in = nullptr, *d_out = nullptr;
-    if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
-      fprintf(stderr, "[sperr_hip] device allocation failed\n");
-      if (d_in)
-        (void)hipFree(d_in);
-      return -1;
-    }
-    int rtn = -1;
-    size_t len = 0;
-    if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
-      rtn = sperrhip_compress_dev(d_in, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode,
-                                  quality, d_out, cap, &len, nullptr);
-    if (rtn == 0) {
-      void* buf = malloc(len);
-      if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
-        *dst = buf;
-        *dst_len = len;
-      }
-      else {
-        free(buf);
-        rtn = -1;
-      }
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rtn;
-  });
 }
 
 // include/SPERR_C_API.h:138-156, src/SPERR_C_API.cpp:260-280,
@@ -2705,47 +2895,6 @@ int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, si
   });
 }
 
-int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
-                    size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
-{
-  return guarded("sperr_decomp_3d", [&]() -> int {
-    (void)nthreads;
-    if (*dst != nullptr)
-      return 1;
-    if (src_len < 18)
-      return -1;
-    ContainerInfo ci;
-    size_t need = 0;
-    if (parse_container_host(static_cast<const uint8_t*>(src), src_len, src_len, ci, &need) != 0)
-      return -1;
-    const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
-    const size_t esz = output_float ? 4 : 8;
-    void *d_in = nullptr, *d_out = nullptr;
-    if (hipMalloc(&d_in, src_len) != hipSuccess || hipMalloc(&d_out, n * esz) != hipSuccess) {
-      fprintf(stderr, "[sperr_hip] device allocation failed\n");
-      if (d_in)
-        (void)hipFree(d_in);
-      return -1;
-    }
-    int rtn = -1;
-    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
-      rtn = sperrhip_decompress_dev(d_in, src_len, output_float, d_out, n * esz, dimx, dimy, dimz,
-                                    nullptr);
-    if (rtn == 0) {
-      void* buf = malloc(n * esz);
-      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
-        *dst = buf;
-      else {
-        free(buf);
-        rtn = -1;
-      }
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rtn;
-  });
-}
-
 // include/SPERR_C_API.h:53-62, src/SPERR_C_API.cpp:7-97
 int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int mode, double quality,
                   int out_inc_header, void** dst, size_t* dst_len)
@@ -2812,9 +2961,10 @@ int sperrhip_decompress_2d_multires_dev(const void* d_src, size_t src_len, int o
   return guarded("sperrhip_decompress_2d_multires_dev", [&]() -> int {
     if (!d_src || !d_dst || dimx == 0 || dimy == 0 || src_len < 17 || (nlev && !d_levels))
       return -1;
-    std::lock_guard<std::mutex> lock(g_engine.mu);
-    if (g_engine.init())
+    Lease L;
+    if (!L.e)
       return -1;
+    Engine& E = *L.e;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     MultiRes m;
     multires_levels_2d(dimx, dimy, m);
@@ -2827,15 +2977,16 @@ int sperrhip_decompress_2d_multires_dev(const void* d_src, size_t src_len, int o
     }
     ContainerInfo ci;
     ci.vol = {dimx, dimy, 1};
+    ci.nvals = dimx * dimy;
     ci.chunk = ci.vol;
     ci.is_float = output_float != 0;
     ci.off = {0};
     ci.len = {src_len};
     if (output_float)
-      return decompress_impl<float>(static_cast<const uint8_t*>(d_src), src_len,
+      return decompress_impl<float>(E, static_cast<const uint8_t*>(d_src), src_len,
                                     static_cast<float*>(d_dst), dst_cap_bytes / sizeof(float), ci, st, &m,
                                     true);
-    return decompress_impl<double>(static_cast<const uint8_t*>(d_src), src_len,
+    return decompress_impl<double>(E, static_cast<const uint8_t*>(d_src), src_len,
                                    static_cast<double*>(d_dst), dst_cap_bytes / sizeof(double), ci, st, &m,
                                    true);
   });
@@ -2951,7 +3102,7 @@ int sperrhip_decomp_3d_multires(const void* src, size_t src_len, int output_floa
     if (sperrhip_multires_levels(ci.vol[0], ci.vol[1], ci.vol[2], ci.chunk[0], ci.chunk[1], ci.chunk[2],
                                  nlev, level_dims))
       return -1;
-    const size_t n = ci.vol[0] * ci.vol[1] * ci.vol[2];
+    const size_t n = ci.nvals;
     const size_t esz = output_float ? 4 : 8;
     std::vector<void*> dev;
     auto release = [&]() {

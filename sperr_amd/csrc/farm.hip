@@ -1,0 +1,893 @@
+// farm.hip -- the chunk farm: host volumes of any size through the per-chunk pipeline, on every
+// device of the node, with the transfers of one batch of chunks hidden behind the kernels of others.
+//
+// What it replaces in the reference (file:line under /root/reference):
+//   src/SPERR3D_OMP_C.cpp:61-141    the OpenMP chunk loop of compress(): gather a chunk (:236-261),
+//                                   run the per-chunk pipeline, keep its stream
+//   src/SPERR3D_OMP_C.cpp:145-234   header + concatenated chunk streams
+//   src/SPERR3D_OMP_D.cpp:50-150    the OpenMP chunk loop of decompress(): per-chunk pipeline,
+//                                   scatter into the volume (:167-184)
+//   src/SPERR_C_API.cpp:135-258     sperr_comp_3d / sperr_decomp_3d (ownership, return codes)
+//
+// Design.  Chunks share nothing, so the volume is cut into WORK ITEMS: runs of equally shaped chunks
+// in chunk_volume order (src/sperr_helper.cpp:542-592), a few hundred MB each.  A shared atomic
+// counter hands the items to WORKERS, a few host threads per device (a device list with one entry
+// per device; an entry may repeat).  A worker owns a HIP stream, pinned staging buffers and device
+// buffers, and handles one item at a time:
+//     compress:    gather the item's chunk rows into pinned memory (helper threads; or DMA them
+//                  straight out of the caller's buffer when that is pinned) -> H2D -> the
+//                  device-resident compressor on a volume made of the item's chunks stacked along z
+//                  (sperrhip_compress_dev, which leases its own engine) -> D2H of the small
+//                  container -> chunk streams to their place in the output
+//     decompress:  the item's chunk streams as a small container -> H2D -> sperrhip_decompress_dev
+//                  -> D2H -> rows scattered into the caller's volume
+// Each step of a worker is synchronous; overlap of copies and kernels comes from the other workers
+// of the device, balance between devices from the queue.  No collective, no peer traffic.  The
+// volume is never resident on a device as a whole, so its size is bounded by host memory only
+// (BASELINE.json config 5).
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/sperr_hip.h"
+#include "common.h"
+#include "engine_internal.h"
+
+namespace sperrhip {
+namespace {
+
+size_t env_size(const char* name, size_t dflt)
+{
+  const char* v = getenv(name);
+  if (!v || !*v)
+    return dflt;
+  const long long x = atoll(v);
+  return x > 0 ? (size_t)x : dflt;
+}
+
+// ------------------------------------------------------------------------------------------
+// work items and the queue
+// ------------------------------------------------------------------------------------------
+struct Item {
+  Dims3 shape;                               // dims of every chunk of the item
+  std::vector<uint32_t> gid;                 // index in chunk_volume order
+  std::vector<std::array<size_t, 3>> org;    // origin inside the volume
+};
+
+struct FarmShape {
+  size_t workersPerDevice, helpers, itemBytesMax, itemChunksForced;
+};
+
+FarmShape farm_shape(size_t nthreads, size_t ndev)
+{
+  FarmShape f;
+  f.workersPerDevice = env_size("SPERR_HIP_FARM_WORKERS", 3);
+  f.itemBytesMax = env_size("SPERR_HIP_FARM_ITEM_MB", 768) << 20;
+  f.itemChunksForced = env_size("SPERR_HIP_FARM_ITEM", 0);
+  // `nthreads` (the reference's OpenMP team size, src/SPERR3D_OMP_C.cpp:12-20) is taken as the
+  // number of host threads that move rows between the caller's buffers and the staging buffers
+  size_t helpers = 4;
+  if (nthreads > 0)
+    helpers = std::max<size_t>(1, nthreads / std::max<size_t>(1, ndev * f.workersPerDevice));
+  f.helpers = env_size("SPERR_HIP_FARM_HELPERS", helpers);
+  return f;
+}
+
+// Equally shaped chunks, in chunk_volume order, `perItem` at a time.  An item is sized so that
+// every worker sees a few of them (balance) but none is tiny (the per-plane kernels of the coder
+// have a fixed cost per launch) or larger than the staging buffers should be.
+std::vector<Item> make_items(const std::vector<std::array<size_t, 6>>& chunks, size_t bytesPerValue,
+                             size_t nworkers, const FarmShape& fs)
+{
+  std::map<Dims3, std::vector<uint32_t>> groups;
+  for (uint32_t i = 0; i < chunks.size(); i++)
+    groups[Dims3{chunks[i][1], chunks[i][3], chunks[i][5]}].push_back(i);
+  // the largest shapes first: they take longest
+  std::vector<const std::pair<const Dims3, std::vector<uint32_t>>*> order;
+  for (auto& g : groups)
+    order.push_back(&g);
+  std::stable_sort(order.begin(), order.end(), [](auto* a, auto* b) {
+    return a->first[0] * a->first[1] * a->first[2] > b->first[0] * b->first[1] * b->first[2];
+  });
+  std::vector<Item> items;
+  for (auto* g : order) {
+    const Dims3& sh = g->first;
+    const size_t chunkBytes = sh[0] * sh[1] * sh[2] * bytesPerValue;
+    const size_t n = g->second.size();
+    const size_t kMax = std::max<size_t>(1, fs.itemBytesMax / std::max<size_t>(1, chunkBytes));
+    const size_t kMin = std::max<size_t>(1, (size_t(32) << 20) / std::max<size_t>(1, chunkBytes));
+    size_t k = (n + 2 * nworkers - 1) / (2 * nworkers);
+    k = std::min(std::max(k, kMin), kMax);
+    k = std::min<size_t>(k, 256);   // (a batch of the engine holds at most 256 chunks)
+    if (fs.itemChunksForced)
+      k = std::min<size_t>(fs.itemChunksForced, 256);
+    for (size_t b0 = 0; b0 < n; b0 += k) {
+      Item it;
+      it.shape = sh;
+      for (size_t i = b0; i < std::min(n, b0 + k); i++) {
+        const uint32_t gid = g->second[i];
+        it.gid.push_back(gid);
+        it.org.push_back({chunks[gid][0], chunks[gid][2], chunks[gid][4]});
+      }
+      items.push_back(std::move(it));
+    }
+  }
+  return items;
+}
+
+// SPERR_HIP_DEVICES: "all" (default) or a comma separated list of device ordinals; an ordinal may
+// repeat (more workers on that device).  `explicitList` overrides it.
+int device_list(const int* explicitList, size_t nExplicit, std::vector<int>& devs)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    fprintf(stderr, "[sperr_hip] no HIP device available; this library has no CPU fallback\n");
+    return -1;
+  }
+  devs.clear();
+  if (explicitList && nExplicit) {
+    for (size_t i = 0; i < nExplicit; i++)
+      devs.push_back(explicitList[i]);
+  }
+  else {
+    const char* v = getenv("SPERR_HIP_DEVICES");
+    if (v && *v && strcmp(v, "all") != 0) {
+      std::string s(v);
+      size_t pos = 0;
+      while (pos < s.size()) {
+        size_t e = s.find(',', pos);
+        if (e == std::string::npos)
+          e = s.size();
+        if (e > pos)
+          devs.push_back(atoi(s.substr(pos, e - pos).c_str()));
+        pos = e + 1;
+      }
+    }
+    if (devs.empty())
+      for (int d = 0; d < ndev; d++)
+        devs.push_back(d);
+  }
+  for (int d : devs)
+    if (d < 0 || d >= ndev) {
+      fprintf(stderr, "[sperr_hip] device %d is not one of the %d visible devices\n", d, ndev);
+      return -1;
+    }
+  return 0;
+}
+
+// run fn(t) for t in [0, nthreads) on that many threads (the caller is one of them)
+template <typename F>
+void parallel_do(size_t nthreads, F&& fn)
+{
+  if (nthreads <= 1) {
+    fn(size_t(0));
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nthreads - 1);
+  for (size_t t = 1; t < nthreads; t++)
+    th.emplace_back([&fn, t]() { fn(t); });
+  fn(size_t(0));
+  for (auto& t : th)
+    t.join();
+}
+
+bool host_ptr_is_pinned(const void* p)
+{
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof(a));
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();   // plain malloc'd memory is reported as an invalid value
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// ------------------------------------------------------------------------------------------
+// worker contexts: stream + staging buffers, kept between calls (pinning memory is slow)
+// ------------------------------------------------------------------------------------------
+struct WorkerCtx {
+  int dev = -1;
+  bool busy = false;
+  hipStream_t st = nullptr;
+  void *pinIn = nullptr, *pinOut = nullptr, *dIn = nullptr, *dOut = nullptr;
+  size_t pinInCap = 0, pinOutCap = 0, dInCap = 0, dOutCap = 0;
+
+  static int grow_pinned(void*& p, size_t& cap, size_t bytes)
+  {
+    if (bytes <= cap)
+      return 0;
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocPortable));
+    cap = want;
+    return 0;
+  }
+  static int grow_dev(void*& p, size_t& cap, size_t bytes)
+  {
+    if (bytes <= cap)
+      return 0;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + 4096;
+    HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  int need_pin_in(size_t b) { return grow_pinned(pinIn, pinInCap, b); }
+  int need_pin_out(size_t b) { return grow_pinned(pinOut, pinOutCap, b); }
+  int need_dev_in(size_t b) { return grow_dev(dIn, dInCap, b); }
+  int need_dev_out(size_t b) { return grow_dev(dOut, dOutCap, b); }
+};
+
+std::mutex g_ctx_mu;
+std::vector<std::unique_ptr<WorkerCtx>> g_ctx;
+
+// (the calling thread has made `dev` current)
+WorkerCtx* ctx_acquire(int dev)
+{
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (auto& c : g_ctx)
+      if (c->dev == dev && !c->busy) {
+        c->busy = true;
+        return c.get();
+      }
+  }
+  auto c = std::make_unique<WorkerCtx>();
+  c->dev = dev;
+  c->busy = true;
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+    fprintf(stderr, "[sperr_hip] cannot create a stream on device %d\n", dev);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  g_ctx.push_back(std::move(c));
+  return g_ctx.back().get();
+}
+
+void ctx_release(WorkerCtx* c)
+{
+  // staging memory above SPERR_HIP_FARM_KEEP_MB (default 4096) per worker is given back
+  static const size_t keep = env_size("SPERR_HIP_FARM_KEEP_MB", 4096) << 20;
+  if (c->pinInCap + c->pinOutCap > keep) {
+    if (c->pinIn)
+      (void)hipHostFree(c->pinIn);
+    if (c->pinOut)
+      (void)hipHostFree(c->pinOut);
+    c->pinIn = c->pinOut = nullptr;
+    c->pinInCap = c->pinOutCap = 0;
+  }
+  if (c->dInCap + c->dOutCap > 2 * keep) {
+    if (c->dIn)
+      (void)hipFree(c->dIn);
+    if (c->dOut)
+      (void)hipFree(c->dOut);
+    c->dIn = c->dOut = nullptr;
+    c->dInCap = c->dOutCap = 0;
+  }
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  c->busy = false;
+}
+
+// ------------------------------------------------------------------------------------------
+// rows between a volume in host memory and a buffer of stacked chunks
+// ------------------------------------------------------------------------------------------
+// toStack: volume -> stack (compress); else stack -> volume (decompress).  Planes [p0, p1) of the
+// item's nb * cz chunk planes.
+void move_planes(bool toStack, uint8_t* volume, const Dims3& vol, uint8_t* stack, const Item& it,
+                 size_t esz, size_t p0, size_t p1)
+{
+  const size_t cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
+  const size_t rowBytes = cx * esz;
+  for (size_t p = p0; p < p1; p++) {
+    const size_t c = p / cz, z = p % cz;
+    const auto& o = it.org[c];
+    uint8_t* v = volume + (((o[2] + z) * vol[1] + o[1]) * vol[0] + o[0]) * esz;
+    uint8_t* s = stack + p * cy * rowBytes;
+    const size_t vpitch = vol[0] * esz;
+    if (cx == vol[0]) {   // rows are adjacent in the volume as well
+      if (toStack)
+        memcpy(s, v, cy * rowBytes);
+      else
+        memcpy(v, s, cy * rowBytes);
+      continue;
+    }
+    for (size_t y = 0; y < cy; y++) {
+      if (toStack)
+        memcpy(s + y * rowBytes, v + y * vpitch, rowBytes);
+      else
+        memcpy(v + y * vpitch, s + y * rowBytes, rowBytes);
+    }
+  }
+}
+
+void move_item(bool toStack, uint8_t* volume, const Dims3& vol, uint8_t* stack, const Item& it,
+               size_t esz, size_t helpers)
+{
+  const size_t planes = it.gid.size() * it.shape[2];
+  const size_t nt = std::max<size_t>(1, std::min(helpers, planes));
+  parallel_do(nt, [&](size_t t) {
+    move_planes(toStack, volume, vol, stack, it, esz, planes * t / nt, planes * (t + 1) / nt);
+  });
+}
+
+// the same by DMA, when the caller's volume is pinned memory: one 3D copy per chunk
+int dma_item(bool toStack, uint8_t* volume, const Dims3& vol, uint8_t* d_stack, const Item& it,
+             size_t esz, hipStream_t st)
+{
+  const size_t cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
+  for (size_t c = 0; c < it.gid.size(); c++) {
+    hipMemcpy3DParms p;
+    memset(&p, 0, sizeof(p));
+    const hipPitchedPtr vptr = make_hipPitchedPtr(volume, vol[0] * esz, vol[0] * esz, vol[1]);
+    const hipPitchedPtr sptr = make_hipPitchedPtr(d_stack + c * cx * cy * cz * esz, cx * esz, cx * esz, cy);
+    const hipPos vpos = make_hipPos(it.org[c][0] * esz, it.org[c][1], it.org[c][2]);
+    const hipPos spos = make_hipPos(0, 0, 0);
+    if (toStack) {
+      p.srcPtr = vptr;
+      p.srcPos = vpos;
+      p.dstPtr = sptr;
+      p.dstPos = spos;
+      p.kind = hipMemcpyHostToDevice;
+    }
+    else {
+      p.srcPtr = sptr;
+      p.srcPos = spos;
+      p.dstPtr = vptr;
+      p.dstPos = vpos;
+      p.kind = hipMemcpyDeviceToHost;
+    }
+    p.extent = make_hipExtent(cx * esz, cy, cz);
+    HIP_CHECK(hipMemcpy3DAsync(&p, st));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// jobs
+// ------------------------------------------------------------------------------------------
+struct Job {
+  // common
+  Dims3 vol, cdim;
+  std::vector<Item> items;
+  std::vector<int> workerDev;
+  FarmShape fs;
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  bool direct = false;   // the caller's volume is pinned: DMA instead of staging
+  // compress
+  const uint8_t* src = nullptr;
+  int is_float = 1, mode = 1;
+  double quality = 0.0;
+  size_t esz = 4;
+  uint8_t* outBuf = nullptr;                 // rate mode: chunk streams land at their upper-bound offsets
+  std::vector<uint64_t> slotOff;             // (rate mode)
+  std::vector<std::unique_ptr<uint8_t[]>> chunkBytes;   // (other modes)
+  std::vector<uint64_t> chunkLen;
+  // decompress
+  const uint8_t* container = nullptr;
+  const HostContainer* hc = nullptr;
+  int output_float = 1;
+  uint8_t* dstVol = nullptr;
+};
+
+int comp_item(Job& J, WorkerCtx& C, const Item& it)
+{
+  const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
+  const size_t inBytes = nb * cx * cy * cz * J.esz;
+  if (C.need_dev_in(inBytes))
+    return -1;
+  if (J.direct) {
+    if (dma_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.dIn), it, J.esz, C.st))
+      return -1;
+  }
+  else {
+    if (C.need_pin_in(inBytes))
+      return -1;
+    move_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.pinIn), it, J.esz,
+              J.fs.helpers);
+    HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, inBytes, hipMemcpyHostToDevice, C.st));
+  }
+  // the item's chunks stacked along z are a volume of their own, cut into exactly these chunks
+  const size_t cap = sperrhip_max_compressed_size(cx, cy, cz * nb, cx, cy, cz, J.mode, J.quality);
+  if (C.need_dev_out(cap))
+    return -1;
+  size_t len = 0;
+  const int rc = sperrhip_compress_dev(C.dIn, J.is_float, cx, cy, cz * nb, cx, cy, cz, J.mode,
+                                       J.quality, C.dOut, cap, &len, C.st);
+  if (rc)
+    return rc;
+  const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
+  if (len < hdr || C.need_pin_out(len))
+    return -1;
+  HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, len, hipMemcpyDeviceToHost, C.st));
+  HIP_CHECK(hipStreamSynchronize(C.st));
+  const uint8_t* h = static_cast<const uint8_t*>(C.pinOut);
+  size_t at = hdr;
+  for (size_t i = 0; i < nb; i++) {
+    uint32_t l;
+    memcpy(&l, h + (hdr - 4 * nb) + 4 * i, 4);
+    if (at + l > len)
+      return -1;
+    const uint32_t gid = it.gid[i];
+    J.chunkLen[gid] = l;
+    if (J.outBuf) {
+      if (l > J.slotOff[gid + 1] - J.slotOff[gid])
+        return -1;
+      memcpy(J.outBuf + J.slotOff[gid], h + at, l);
+    }
+    else {
+      J.chunkBytes[gid].reset(new uint8_t[std::max<size_t>(l, 1)]);
+      memcpy(J.chunkBytes[gid].get(), h + at, l);
+    }
+    at += l;
+  }
+  return 0;
+}
+
+int decomp_item(Job& J, WorkerCtx& C, const Item& it)
+{
+  const HostContainer& hc = *J.hc;
+  const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
+  const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
+  size_t total = hdr;
+  for (uint32_t g : it.gid)
+    total += hc.len[g];
+  if (C.need_pin_in(total) || C.need_dev_in(total))
+    return -1;
+  uint8_t* h = static_cast<uint8_t*>(C.pinIn);
+  h[0] = 0;   // SPERR_VERSION_MAJOR
+  h[1] = (uint8_t)(0x40 | (hc.is_float ? 0x20 : 0) | (nb > 1 ? 0x10 : 0) | (hc.portion ? 0x80 : 0));
+  const uint32_t v3[3] = {(uint32_t)cx, (uint32_t)cy, (uint32_t)(cz * nb)};
+  memcpy(h + 2, v3, 12);
+  if (nb > 1) {
+    const uint16_t c3[3] = {(uint16_t)cx, (uint16_t)cy, (uint16_t)cz};
+    memcpy(h + 14, c3, 6);
+  }
+  size_t at = hdr;
+  for (size_t i = 0; i < nb; i++) {
+    const uint32_t g = it.gid[i];
+    const uint32_t l = (uint32_t)hc.len[g];
+    memcpy(h + (hdr - 4 * nb) + 4 * i, &l, 4);
+    memcpy(h + at, J.container + hc.off[g], l);
+    at += l;
+  }
+  HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, total, hipMemcpyHostToDevice, C.st));
+  const size_t osz = J.output_float ? 4 : 8;
+  const size_t outBytes = nb * cx * cy * cz * osz;
+  if (C.need_dev_out(outBytes))
+    return -1;
+  size_t x = 0, y = 0, z = 0;
+  const int rc = sperrhip_decompress_dev(C.dIn, total, J.output_float, C.dOut, outBytes, &x, &y, &z, C.st);
+  if (rc)
+    return rc;
+  if (J.direct) {
+    if (dma_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.dOut), it, osz, C.st))
+      return -1;
+    HIP_CHECK(hipStreamSynchronize(C.st));
+  }
+  else {
+    if (C.need_pin_out(outBytes))
+      return -1;
+    HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, outBytes, hipMemcpyDeviceToHost, C.st));
+    HIP_CHECK(hipStreamSynchronize(C.st));
+    move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.pinOut), it, osz, J.fs.helpers);
+  }
+  return 0;
+}
+
+template <typename F>
+int run_workers(Job& J, F&& doItem)
+{
+  const size_t nw = J.workerDev.size();
+  std::vector<std::thread> th;
+  auto body = [&](size_t w) {
+    const int dev = J.workerDev[w];
+    if (hipSetDevice(dev) != hipSuccess) {
+      J.failed = -1;
+      return;
+    }
+    WorkerCtx* C = ctx_acquire(dev);
+    if (!C) {
+      J.failed = -1;
+      return;
+    }
+    try {
+      while (!J.failed.load()) {
+        const size_t i = J.next.fetch_add(1);
+        if (i >= J.items.size())
+          break;
+        const int rc = doItem(J, *C, J.items[i]);
+        if (rc) {
+          J.failed = rc;
+          break;
+        }
+      }
+    }
+    catch (...) {
+      J.failed = -1;
+    }
+    (void)hipStreamSynchronize(C->st);
+    ctx_release(C);
+  };
+  // the calling thread keeps its current device: all workers are threads of their own
+  for (size_t w = 0; w < nw; w++)
+    th.emplace_back(body, w);
+  for (auto& t : th)
+    t.join();
+  return J.failed.load();
+}
+
+void assign_workers(Job& J, const std::vector<int>& devs)
+{
+  // worker w drives device devs[w mod ndev]; no more workers than items
+  const size_t most = devs.size() * J.fs.workersPerDevice;
+  const size_t nw = std::max<size_t>(1, std::min(most, J.items.size()));
+  J.workerDev.clear();
+  for (size_t w = 0; w < nw; w++)
+    J.workerDev.push_back(devs[w % devs.size()]);
+}
+
+uint64_t rounded_up8(uint64_t bits)
+{
+  return (bits + 7) / 8 * 8;
+}
+
+int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& chunkPref, int mode,
+                  double quality, size_t nthreads, const int* devList, size_t nDev, void** dst,
+                  size_t* dst_len)
+{
+  Job J;
+  J.vol = vol;
+  for (int a = 0; a < 3; a++) {   // SPERR3D_OMP_C.cpp:23-30
+    J.cdim[a] = std::min(std::max<size_t>(1, chunkPref[a]), vol[a]);
+    if (vol[a] > 0xffffffffull || J.cdim[a] > 0xffff)
+      return -1;   // the header holds 32-bit volume and 16-bit chunk dims (SPERR3D_OMP_C.cpp:210-221)
+  }
+  std::vector<int> devs;
+  if (device_list(devList, nDev, devs))
+    return -1;
+  const auto chunks = host_chunk_volume(vol, J.cdim);
+  const size_t nchunks = chunks.size();
+  if (nchunks > 0xffffffffull)
+    return -1;
+  J.fs = farm_shape(nthreads, devs.size());
+  J.esz = is_float ? 4 : 8;
+  J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs);
+  assign_workers(J, devs);
+  J.src = static_cast<const uint8_t*>(src);
+  J.is_float = is_float;
+  J.mode = mode;
+  J.quality = quality;
+  static const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
+  J.direct = allowDirect && host_ptr_is_pinned(src);
+  J.chunkLen.assign(nchunks, 0);
+  const size_t hdr = (nchunks > 1 ? 20 : 14) + 4 * nchunks;
+
+  // Fixed rate: a chunk stream is 17 + 9 + budget / 8 bytes unless the chunk is constant or runs
+  // out of bits first, so the streams can land where they belong in the final buffer
+  // (src/SPECK_INT.cpp:54-56: the budget is rounded up to whole bytes).
+  bool inPlace = mode == 1;
+  if (inPlace) {
+    J.slotOff.assign(nchunks + 1, hdr);
+    for (size_t i = 0; i < nchunks; i++) {
+      const size_t n = chunks[i][1] * chunks[i][3] * chunks[i][5];
+      const double raw = quality * (double)n;
+      if (!(raw < 1.8e19)) {
+        inPlace = false;
+        break;
+      }
+      const uint64_t bits = rounded_up8((uint64_t)raw);
+      const size_t len = std::min<size_t>(26 + (size_t)(bits / 8), host_chunk_stream_bound(n, mode, quality));
+      J.slotOff[i + 1] = J.slotOff[i] + len;
+    }
+    if (inPlace) {
+      J.outBuf = static_cast<uint8_t*>(malloc(J.slotOff[nchunks]));
+      if (!J.outBuf)
+        return -1;
+    }
+  }
+  if (!inPlace) {
+    J.slotOff.clear();
+    J.chunkBytes.resize(nchunks);
+  }
+
+  const int rc = run_workers(J, comp_item);
+  if (rc) {
+    free(J.outBuf);
+    return rc;
+  }
+
+  // header (src/SPERR3D_OMP_C.cpp:163-234) + the chunk streams back to back
+  size_t total = hdr;
+  for (size_t i = 0; i < nchunks; i++) {
+    if (J.chunkLen[i] > 0xffffffffull) {
+      free(J.outBuf);
+      return -1;
+    }
+    total += J.chunkLen[i];
+  }
+  uint8_t* out = J.outBuf;
+  if (inPlace) {
+    size_t at = hdr;
+    for (size_t i = 0; i < nchunks; i++) {   // (moves nothing when every stream fills its slot)
+      if (at != J.slotOff[i])
+        memmove(out + at, out + J.slotOff[i], J.chunkLen[i]);
+      at += J.chunkLen[i];
+    }
+    if (total < J.slotOff[nchunks]) {
+      uint8_t* shrunk = static_cast<uint8_t*>(realloc(out, total));
+      if (shrunk)
+        out = shrunk;
+    }
+  }
+  else {
+    out = static_cast<uint8_t*>(malloc(total));
+    if (!out)
+      return -1;
+    std::vector<size_t> at(nchunks + 1, hdr);
+    for (size_t i = 0; i < nchunks; i++)
+      at[i + 1] = at[i] + J.chunkLen[i];
+    const size_t nt = std::max<size_t>(1, std::min<size_t>(J.fs.helpers * J.workerDev.size(), nchunks));
+    parallel_do(nt, [&](size_t t) {
+      for (size_t i = nchunks * t / nt; i < nchunks * (t + 1) / nt; i++)
+        memcpy(out + at[i], J.chunkBytes[i].get(), J.chunkLen[i]);
+    });
+  }
+  out[0] = 0;   // SPERR_VERSION_MAJOR (CMakeLists.txt:5)
+  out[1] = (uint8_t)(0x40 | (is_float ? 0x20 : 0) | (nchunks > 1 ? 0x10 : 0));
+  const uint32_t v3[3] = {(uint32_t)vol[0], (uint32_t)vol[1], (uint32_t)vol[2]};
+  memcpy(out + 2, v3, 12);
+  size_t pos = 14;
+  if (nchunks > 1) {
+    const uint16_t c3[3] = {(uint16_t)J.cdim[0], (uint16_t)J.cdim[1], (uint16_t)J.cdim[2]};
+    memcpy(out + 14, c3, 6);
+    pos = 20;
+  }
+  for (size_t i = 0; i < nchunks; i++) {
+    const uint32_t l = (uint32_t)J.chunkLen[i];
+    memcpy(out + pos + 4 * i, &l, 4);
+  }
+  *dst = out;
+  *dst_len = total;
+  return 0;
+}
+
+int farm_decompress(const void* src, size_t src_len, int output_float, size_t nthreads,
+                    const int* devList, size_t nDev, const HostContainer& hc, void* dstVol)
+{
+  Job J;
+  J.vol = hc.vol;
+  J.cdim = hc.chunk;
+  std::vector<int> devs;
+  if (device_list(devList, nDev, devs))
+    return -1;
+  const auto chunks = host_chunk_volume(hc.vol, hc.chunk);
+  if (chunks.size() != hc.len.size())
+    return -1;
+  J.fs = farm_shape(nthreads, devs.size());
+  // (items sized by the bytes that come out; fewer, larger items than the encoder wants: the
+  // decoder's list kernels keep one workgroup per chunk busy)
+  J.fs.itemBytesMax = env_size("SPERR_HIP_FARM_DEC_ITEM_MB", 1536) << 20;
+  J.fs.workersPerDevice = env_size("SPERR_HIP_FARM_DEC_WORKERS", J.fs.workersPerDevice);
+  J.items = make_items(chunks, output_float ? 4 : 8, devs.size() * J.fs.workersPerDevice, J.fs);
+  assign_workers(J, devs);
+  J.container = static_cast<const uint8_t*>(src);
+  J.hc = &hc;
+  J.output_float = output_float;
+  J.dstVol = static_cast<uint8_t*>(dstVol);
+  static const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
+  J.direct = allowDirect && host_ptr_is_pinned(dstVol);
+  (void)src_len;
+  return run_workers(J, decomp_item);
+}
+
+template <typename F>
+int guarded_farm(const char* what, F&& body) noexcept
+{
+  try {
+    return body();
+  }
+  catch (const std::bad_alloc&) {
+    fprintf(stderr, "[sperr_hip] %s: out of host memory\n", what);
+  }
+  catch (const std::exception& e) {
+    fprintf(stderr, "[sperr_hip] %s: %s\n", what, e.what());
+  }
+  catch (...) {
+    fprintf(stderr, "[sperr_hip] %s: unknown exception\n", what);
+  }
+  return -1;
+}
+
+}  // namespace
+}  // namespace sperrhip
+
+using namespace sperrhip;
+
+extern "C" {
+
+int sperrhip_comp_3d_farm(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                          size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                          size_t nthreads, const int* devices, size_t ndevices, void** dst,
+                          size_t* dst_len)
+{
+  return guarded_farm("sperrhip_comp_3d_farm", [&]() -> int {
+    if (!dst || *dst != nullptr)
+      return 1;
+    if (quality <= 0.0)
+      return 2;
+    if (mode < 1 || mode > 3)
+      return 2;
+    if (!src || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
+      return -1;
+    return farm_compress(src, is_float, Dims3{dimx, dimy, dimz}, Dims3{chunk_x, chunk_y, chunk_z},
+                         mode, quality, nthreads, devices, ndevices, dst, dst_len);
+  });
+}
+
+int sperrhip_decomp_3d_into(const void* src, size_t src_len, int output_float, size_t nthreads,
+                            const int* devices, size_t ndevices, void* dst, size_t dst_bytes,
+                            size_t* dimx, size_t* dimy, size_t* dimz)
+{
+  return guarded_farm("sperrhip_decomp_3d_into", [&]() -> int {
+    if (!src || !dst)
+      return -1;
+    HostContainer hc;
+    if (host_parse_container(static_cast<const uint8_t*>(src), src_len, hc))
+      return -1;
+    if (hc.nvals > dst_bytes / (output_float ? 4 : 8))
+      return -1;
+    const int rc = farm_decompress(src, src_len, output_float, nthreads, devices, ndevices, hc, dst);
+    if (rc == 0) {
+      if (dimx)
+        *dimx = hc.vol[0];
+      if (dimy)
+        *dimy = hc.vol[1];
+      if (dimz)
+        *dimz = hc.vol[2];
+    }
+    return rc;
+  });
+}
+
+int sperrhip_decomp_3d_farm(const void* src, size_t src_len, int output_float, size_t nthreads,
+                            const int* devices, size_t ndevices, size_t* dimx, size_t* dimy,
+                            size_t* dimz, void** dst)
+{
+  return guarded_farm("sperrhip_decomp_3d_farm", [&]() -> int {
+    if (!dst || *dst != nullptr)
+      return 1;
+    if (!src)
+      return -1;
+    HostContainer hc;
+    if (host_parse_container(static_cast<const uint8_t*>(src), src_len, hc))
+      return -1;
+    const size_t bytes = hc.nvals * (output_float ? 4 : 8);
+    void* buf = malloc(std::max<size_t>(bytes, 1));
+    if (!buf)
+      return -1;
+    const int rc = farm_decompress(src, src_len, output_float, nthreads, devices, ndevices, hc, buf);
+    if (rc) {
+      free(buf);
+      return rc;
+    }
+    *dst = buf;
+    *dimx = hc.vol[0];
+    *dimy = hc.vol[1];
+    *dimz = hc.vol[2];
+    return 0;
+  });
+}
+
+// ---- reference-compatible host API (src/SPERR_C_API.cpp:135-258) ---------------------------
+
+int sperr_comp_3d(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
+                  size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,
+                  size_t nthreads, void** dst, size_t* dst_len)
+{
+  return sperrhip_comp_3d_farm(src, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode,
+                               quality, nthreads, nullptr, 0, dst, dst_len);
+}
+
+int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nthreads,
+                    size_t* dimx, size_t* dimy, size_t* dimz, void** dst)
+{
+  return sperrhip_decomp_3d_farm(src, src_len, output_float, nthreads, nullptr, 0, dimx, dimy, dimz,
+                                 dst);
+}
+
+// The queue without any device: how the chunks of a volume are cut into items and which worker
+// takes which, with `nworkers` host threads that do nothing else.  lockstep != 0: the workers take
+// their items in rounds (every worker equally fast), which makes the outcome deterministic.
+// per_worker_chunks[nworkers], item_of_chunk[nchunks] (either may be NULL), *nitems.
+int sperrhip_farm_selftest(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x, size_t chunk_y,
+                           size_t chunk_z, size_t bytes_per_value, size_t ndevices,
+                           size_t workers_per_device, int lockstep, uint32_t* per_worker_chunks,
+                           uint32_t* item_of_chunk, uint32_t* worker_of_chunk, size_t* nitems)
+{
+  return guarded_farm("sperrhip_farm_selftest", [&]() -> int {
+    if (dimx == 0 || dimy == 0 || dimz == 0 || ndevices == 0 || workers_per_device == 0)
+      return -1;
+    const Dims3 vol{dimx, dimy, dimz};
+    Dims3 cd{chunk_x, chunk_y, chunk_z};
+    for (int a = 0; a < 3; a++)
+      cd[a] = std::min(std::max<size_t>(1, cd[a]), vol[a]);
+    const auto chunks = host_chunk_volume(vol, cd);
+    FarmShape fs = farm_shape(0, ndevices);
+    fs.workersPerDevice = workers_per_device;
+    const auto items = make_items(chunks, bytes_per_value, ndevices * workers_per_device, fs);
+    const size_t nw = std::max<size_t>(1, std::min(ndevices * workers_per_device, items.size()));
+    if (nitems)
+      *nitems = items.size();
+    if (item_of_chunk)
+      for (size_t i = 0; i < items.size(); i++)
+        for (uint32_t g : items[i].gid)
+          item_of_chunk[g] = (uint32_t)i;
+    std::vector<uint32_t> count(ndevices * workers_per_device, 0);
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t waiting = 0, alive = nw, round = 0;
+    auto body = [&](size_t w) {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= items.size())
+          break;
+        count[w] += (uint32_t)items[i].gid.size();
+        if (worker_of_chunk)
+          for (uint32_t g : items[i].gid)
+            worker_of_chunk[g] = (uint32_t)w;
+        if (lockstep) {   // wait until every live worker has taken its item of this round
+          std::unique_lock<std::mutex> lock(mu);
+          const size_t my = round;
+          if (++waiting == alive) {
+            waiting = 0;
+            round++;
+            cv.notify_all();
+          }
+          else
+            cv.wait(lock, [&]() { return round != my; });
+        }
+      }
+      if (lockstep) {
+        std::lock_guard<std::mutex> lock(mu);
+        alive--;
+        if (alive && waiting == alive) {
+          waiting = 0;
+          round++;
+          cv.notify_all();
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t w = 0; w < nw; w++)
+      th.emplace_back(body, w);
+    for (auto& t : th)
+      t.join();
+    if (per_worker_chunks)
+      for (size_t w = 0; w < ndevices * workers_per_device; w++)
+        per_worker_chunks[w] = count[w];
+    return 0;
+  });
+}
+
+}  // extern "C"

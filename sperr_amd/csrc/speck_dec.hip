@@ -2641,27 +2641,17 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   const uint32_t tokGrid = capped_blocks(tokBlocks, nc), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide);
   const size_t tabSmem = b.tabSmemBytes;
   if (plan.tables) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint32_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabSmem));
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_tables<uint64_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tabSmem));
-      attr_set = true;
-    }
+    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_tables<uint32_t>), (int)tabSmem) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_tables<uint64_t>), (int)tabSmem))
+      return -1;
   }
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
   const uint32_t l0Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l0Total / nc));
   if (plan.tables && plan.l0) {
-    static bool l0_attr = false;
-    if (!l0_attr) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_l0),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL0Smem));
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_l1),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL1Smem));
-      l0_attr = true;
-    }
+    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l0), (int)kL0Smem) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l1), (int)kL1Smem))
+      return -1;
   }
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
   static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;

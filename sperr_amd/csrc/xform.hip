@@ -910,8 +910,7 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
                 uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
                 const CoderState* st, int io, void* volume, VolDesc vd, const ChunkGeom* geom)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     const void* fns[6] = {reinterpret_cast<const void*>(&k_lift_axis<true, 0>),
                           reinterpret_cast<const void*>(&k_lift_axis<true, 1>),
                           reinterpret_cast<const void*>(&k_lift_axis<true, 2>),
@@ -919,8 +918,8 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
                           reinterpret_cast<const void*>(&k_lift_axis<false, 1>),
                           reinterpret_cast<const void*>(&k_lift_axis<false, 2>)};
     for (const void* f : fns)
-      HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+      if (set_max_dyn_lds(f, 160 * 1024))
+        return -1;
   }
   const uint32_t len = region[axis];
   if (len < 2)
@@ -983,15 +982,14 @@ int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsSt
                    uint32_t nchunks, const uint32_t cdims[3], const CoderState* st, int io,
                    void* volume, VolDesc vd, const ChunkGeom* geom)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     const void* fns[4] = {reinterpret_cast<const void*>(&k_lift_xy<true, 1>),
                           reinterpret_cast<const void*>(&k_lift_xy<true, 2>),
                           reinterpret_cast<const void*>(&k_lift_xy<false, 1>),
                           reinterpret_cast<const void*>(&k_lift_xy<false, 2>)};
     for (const void* f : fns)
-      HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+      if (set_max_dyn_lds(f, 160 * 1024))
+        return -1;
   }
   const int R = xy_rows(cdims[0], cdims[1]);
   if (R <= 0 || (io != 1 && io != 2))

@@ -1,11 +1,14 @@
-"""Chunk farming over the GPUs of one node (one process per GPU, torch.distributed).
+"""Chunk farming with one PROCESS per GPU (torch.distributed), for hosts that are organised that way.
 
-Chunks are independent end to end (separate mean, q, DWT, SPECK stream --
-/root/reference/src/SPERR3D_OMP_C.cpp:94-130), so the data path needs NO collective: every rank
-compresses whole z-slabs of chunks of the volume on its own GPU, and only the finished byte
-streams travel (a host-side gather of variable-length blobs) to be stitched into one container
-in chunk_volume order (x fastest, then y, then z -- /root/reference/src/sperr_helper.cpp:579-589;
-container layout /root/reference/src/SPERR3D_OMP_C.cpp:163-234).
+The product farm lives in the library (sperr_amd/csrc/farm.hip: one process, worker threads per
+device, a shared queue of work items; it is what sperr_comp_3d / sperr_decomp_3d run on).  This
+module is the same dealing for ranks that each own one GPU: chunks are independent end to end
+(separate mean, q, DWT, SPECK stream -- /root/reference/src/SPERR3D_OMP_C.cpp:94-130), so the data
+path needs NO collective.  Every rank takes a balanced run of CHUNKS in chunk_volume order (x
+fastest, then y, then z -- /root/reference/src/sperr_helper.cpp:579-589), stacks equally shaped
+ones along z into a small volume, compresses that with its device compressor, and only the finished
+byte streams travel (a host-side gather of variable-length blobs) to be stitched into one container
+(layout: /root/reference/src/SPERR3D_OMP_C.cpp:163-234).  Decompression mirrors it.
 """
 import struct
 
@@ -23,22 +26,18 @@ def chunk_segments(vol_len, chunk_len):
     return [(tics[i], tics[i + 1] - tics[i]) for i in range(n)]
 
 
-def shard_z_slabs(vol_zyx, chunks_xyz, world):
-    """Deal the z-segments of the chunk grid to `world` ranks in contiguous runs.  Returns a list
-    of (z0, z1) voxel ranges, one per rank (z0 == z1 for a rank without work)."""
-    segs = chunk_segments(vol_zyx[0], min(max(chunks_xyz[2], 1), vol_zyx[0]))
-    n = len(segs)
-    out, start = [], 0
-    for r in range(world):
-        cnt = n // world + (1 if r < n % world else 0)
-        if cnt == 0:
-            out.append((vol_zyx[0], vol_zyx[0]))
-            continue
-        z0 = segs[start][0]
-        z1 = segs[start + cnt - 1][0] + segs[start + cnt - 1][1]
-        out.append((z0, z1))
-        start += cnt
-    return out
+def chunk_grid(vol_zyx, chunks_xyz):
+    """[(x0, lx, y0, ly, z0, lz)] in chunk_volume order (x fastest)."""
+    vz, vy, vx = vol_zyx
+    cd = [min(max(c, 1), v) for c, v in zip(chunks_xyz, (vx, vy, vz))]
+    sx, sy, sz = chunk_segments(vx, cd[0]), chunk_segments(vy, cd[1]), chunk_segments(vz, cd[2])
+    return [(x0, lx, y0, ly, z0, lz) for z0, lz in sz for y0, ly in sy for x0, lx in sx]
+
+
+def deal_chunks(nchunks, world):
+    """Balanced contiguous runs of chunk indices, one list per rank (every rank gets work as long
+    as there are at least `world` chunks: 64 chunks over 8 ranks = 8 each)."""
+    return [list(range(nchunks * r // world, nchunks * (r + 1) // world)) for r in range(world)]
 
 
 def split_container(stream):
@@ -63,45 +62,87 @@ def split_container(stream):
     return flags, (vx, vy, vz), cd, parts
 
 
-def merge_containers(slab_streams, vol_zyx, chunks_xyz, is_float):
-    """Stitch the per-slab containers (in rank order) into the container of the whole volume."""
-    cd = tuple(min(max(c, 1), v) for c, v in zip(chunks_xyz, vol_zyx[::-1]))
-    parts = []
-    for s in slab_streams:
-        if s:
-            parts.extend(split_container(s)[3])
+def build_container(parts, vol_xyz, chunk_xyz, is_float, portion=False):
+    """Header (src/SPERR3D_OMP_C.cpp:163-234) + the chunk streams back to back."""
     multi = len(parts) > 1
-    head = bytearray([0, 0x40 | (0x20 if is_float else 0) | (0x10 if multi else 0)])
-    head += struct.pack("<3I", vol_zyx[2], vol_zyx[1], vol_zyx[0])
+    head = bytearray([0, 0x40 | (0x20 if is_float else 0) | (0x10 if multi else 0) | (0x80 if portion else 0)])
+    head += struct.pack("<3I", *vol_xyz)
     if multi:
-        head += struct.pack("<3H", *cd)
+        head += struct.pack("<3H", *chunk_xyz)
     head += struct.pack(f"<{len(parts)}I", *[len(p) for p in parts])
     return bytes(head) + b"".join(parts)
 
 
-def farm_compress(vol, chunks_xyz, bpp, compress_fn, group=None):
-    """Every rank holds (at least) its own z-slab of `vol` (numpy, shaped z,y,x) and compresses it
-    with `compress_fn(subvol, chunks_xyz, bpp) -> bytes`; rank 0 returns the merged container,
-    the other ranks return None.  No collective on the data path; one gather of byte blobs."""
+def _groups(ids, grid):
+    """the rank's chunks grouped by shape, order kept"""
+    g = {}
+    for i in ids:
+        x0, lx, y0, ly, z0, lz = grid[i]
+        g.setdefault((lx, ly, lz), []).append(i)
+    return g
+
+
+def _gather(obj, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    slabs = shard_z_slabs(vol.shape, chunks_xyz, world)
-    z0, z1 = slabs[rank]
-    mine = b""
-    if z1 > z0:
-        # the slab is cut with the volume's own chunk dims so that its chunk grid is the
-        # corresponding part of the volume's grid
-        cd = tuple(min(max(c, 1), v) for c, v in zip(chunks_xyz, vol.shape[::-1]))
-        mine = compress_fn(np.ascontiguousarray(vol[z0:z1]), cd, bpp)
     if world == 1:
-        blobs = [mine]
-    else:
-        blobs = [None] * world if rank == 0 else None
-        dist.gather_object(mine, blobs, dst=0, group=group)
+        return [obj]
+    blobs = [None] * world if rank == 0 else None
+    dist.gather_object(obj, blobs, dst=0, group=group)
+    return blobs
+
+
+def farm_compress(vol, chunks_xyz, quality, compress_fn, mode=1, group=None):
+    """Every rank holds `vol` (numpy, shaped z,y,x) or at least its own chunks of it and compresses
+    them with `compress_fn(subvol, chunks_xyz, mode, quality) -> bytes`; rank 0 returns the container
+    of the whole volume, the other ranks None.  No collective on the data path; one gather of blobs."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grid = chunk_grid(vol.shape, chunks_xyz)
+    mine = {}
+    for (lx, ly, lz), ids in _groups(deal_chunks(len(grid), world)[rank], grid).items():
+        # equally shaped chunks stacked along z are a volume that is cut into exactly these chunks
+        stack = np.concatenate([vol[grid[i][4]:grid[i][4] + lz, grid[i][2]:grid[i][2] + ly,
+                                    grid[i][0]:grid[i][0] + lx] for i in ids], axis=0)
+        parts = split_container(compress_fn(np.ascontiguousarray(stack), (lx, ly, lz), mode, quality))[3]
+        assert len(parts) == len(ids)
+        mine.update(zip(ids, parts))
+    blobs = _gather(mine, group)
     if rank != 0:
         return None
-    return merge_containers(blobs, vol.shape, chunks_xyz, vol.dtype == np.float32)
+    parts = {}
+    for b in blobs:
+        parts.update(b)
+    vz, vy, vx = vol.shape
+    cd = tuple(min(max(c, 1), v) for c, v in zip(chunks_xyz, (vx, vy, vz)))
+    return build_container([parts[i] for i in range(len(grid))], (vx, vy, vz), cd, vol.dtype == np.float32)
+
+
+def farm_decompress(stream, decompress_fn, output_float=True, group=None):
+    """`decompress_fn(container_bytes, output_float) -> numpy (z,y,x)`; rank 0 returns the volume."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    flags, (vx, vy, vz), cd, parts = split_container(stream)
+    grid = chunk_grid((vz, vy, vx), cd)
+    mine = {}
+    for (lx, ly, lz), ids in _groups(deal_chunks(len(grid), world)[rank], grid).items():
+        mini = build_container([parts[i] for i in ids], (lx, ly, lz * len(ids)), (lx, ly, lz),
+                               bool(flags & 0x20), bool(flags & 0x80))
+        out = decompress_fn(mini, output_float)
+        for k, i in enumerate(ids):
+            mine[i] = np.ascontiguousarray(out[k * lz:(k + 1) * lz])
+    blobs = _gather(mine, group)
+    if rank != 0:
+        return None
+    vol = np.empty((vz, vy, vx), dtype=np.float32 if output_float else np.float64)
+    for b in blobs:
+        for i, a in b.items():
+            x0, lx, y0, ly, z0, lz = grid[i]
+            vol[z0:z0 + lz, y0:y0 + ly, x0:x0 + lx] = a
+    return vol
 
 
 def reduce_max_seconds(seconds, device=None, group=None):
