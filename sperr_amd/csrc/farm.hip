@@ -577,7 +577,7 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
   J.is_float = is_float;
   J.mode = mode;
   J.quality = quality;
-  static const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
+  const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
   J.direct = allowDirect && host_ptr_is_pinned(src);
   J.chunkLen.assign(nchunks, 0);
   const size_t hdr = (nchunks > 1 ? 20 : 14) + 4 * nchunks;
@@ -694,7 +694,7 @@ int farm_decompress(const void* src, size_t src_len, int output_float, size_t nt
   J.hc = &hc;
   J.output_float = output_float;
   J.dstVol = static_cast<uint8_t*>(dstVol);
-  static const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
+  const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
   J.direct = allowDirect && host_ptr_is_pinned(dstVol);
   (void)src_len;
   return run_workers(J, decomp_item);
