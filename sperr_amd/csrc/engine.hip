@@ -1575,7 +1575,15 @@ int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci,
   return r == 0 ? 0 : -1;
 }
 
+// the lists of the larger sets GPU-wide (k_lis_hi) or one workgroup per chunk (k_lis_tables:
+// SPERR_HIP_LIS_HI=0, trees whose geometry tables do not fit the kernel's LDS, diagnostics stamps)
 bool g_lis_stamps_on = false;
+bool use_lis_hi(const ShapePlan& P, bool tables)
+{
+  static const bool hiEnv = !(getenv("SPERR_HIP_LIS_HI") && atoi(getenv("SPERR_HIP_LIS_HI")) == 0);
+  return hiEnv && !g_lis_stamps_on && tables && P.ht.grids.size() <= 288 && P.ht.roots.size() <= 48 &&
+         P.maxK >= 1 && P.maxK <= 8;
+}
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
 
 struct DecBatchBufs {
@@ -1652,8 +1660,15 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
     TAKE(d.lisStamps, uint64_t, 64 * B);
   }
   d.queueCap = 28672 + 64;
-  d.queueStride = (size_t)d.queueCap * 4;
+  // k_lis_hi: a pair of queues per workgroup, up to hiGroupsMax workgroups per chunk
+  d.hiGroupsMax = 8;
+  d.hiK = (uint32_t)std::max(2, P.maxK);
+  d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
+  d.hiW = tab_window((int)d.hiK, d.hiSmemBytes);
+  d.queueStride = (size_t)d.queueCap * 4 * d.hiGroupsMax;
   TAKE(d.queue, uint64_t, d.queueStride * B);
+  d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(1024u, d.hiW) + 4) * 4;
+  TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
   d.leafCap = P.ht.nsets + 8;
   d.leafStride = d.leafCap;
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
@@ -2002,6 +2017,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
+        // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
+        ph.hi = use_lis_hi(*P, ph.tables);
         // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_tables
         static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
         if (!gpuWide)
@@ -2009,6 +2026,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));
+        HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * nb * 8, ss));
+        HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * nb * 8, ss));
         if (d.lisStamps)
           HIP_CHECK(hipMemsetAsync(d.lisStamps, 0, 64 * 8 * nb, ss));
         // 64-bit chunks first: their magnitudes are decoded into (and converted inside) the fp64
@@ -2798,9 +2817,12 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
       HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
     DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
+    ph.hi = use_lis_hi(*P, ph.tables);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * 8, st));
     if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))
       return -1;
     HIP_CHECK(hipMemcpyAsync(d_coef, d.coef, (size_t)n * (wide ? 8 : 4), hipMemcpyDeviceToDevice, st));

@@ -30,6 +30,12 @@ struct DecState {
   uint32_t l1Ticket;
   int32_t l1PlaneP1;
   uint64_t l1End;
+  // GPU-wide pass over the lists of the larger sets (k_lis_hi)
+  uint32_t hiTicket;             // next region of the pass to hand out
+  int32_t hiPlaneP1;             // 1 + the plane whose pass has ended (0: none)
+  int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
+  uint32_t hiPad;
+  uint64_t hiEnd;                // first bit after the phase
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
   uint32_t leafCount;            //   of the current plane (bornCount: all births once k_lis_tables ends)
   uint64_t lisPhaseBits;         // bits of the plane's LIS phase covered by the birth masks
@@ -104,6 +110,13 @@ struct DecBuffers {
   unsigned long long* l1Flags; // same for k_lis_l1
   int32_t l1Level;
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
+  // k_lis_hi: four look-back words per region of hiW stream bits (tagged with the plane)
+  unsigned long long* hiFlags;
+  size_t hiFlagStride;         // words per chunk
+  uint32_t hiW;                // region bits (tab_window of the shape's longest class chain)
+  uint32_t hiK;                // classes the LDS tables have room for
+  uint32_t hiSmemBytes;        // dynamic LDS given to k_lis_hi
+  uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for
 };
 
 struct DecPlanHost {
@@ -113,8 +126,24 @@ struct DecPlanHost {
   bool l0;                     // the level of the smallest sets is made of 2x2x2 leaf sets: k_lis_l0
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
+  bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
 };
+
+constexpr int kTabWMax = 28672;   // window bits: < 2^15 (table entries keep a flag in bit 15)
+// LDS bytes per window bit for a level with chain length K: T_0..T_{K-2} and U_0..U_{K-1} (u16
+// each), the hop word (u32) and the bit itself.  The window is the largest multiple of 1024 that
+// fits.
+__host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
+{
+  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 4) + 1u;   // eighths of a byte
+  const uint32_t fixed = 4 * 8 + 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
+  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
+  w = w / 1024 * 1024;
+  if (w > (uint32_t)kTabWMax)
+    w = kTabWMax;
+  return w;
+}
 
 int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,
                         const uint8_t* container, const uint64_t* d_chunkOff,

@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.lipStart = s.pos;
     s.l0Ticket = 0;
     s.l1Ticket = 0;
+    s.hiTicket = 0;
     s.bornCount = 0;
     s.leafCount = 0;
   }
@@ -1545,23 +1546,8 @@ k_lis_l1(DecBuffers b, int p)
 // After the last level the recorded sets are ranked by position (popcount prefix of per-level
 // position masks) and appended to the next lists; old entries are compacted in order.
 // ------------------------------------------------------------------------------------------
-constexpr int kTabWMax = 28672;   // window bits: < 2^15 (table entries keep a flag in bit 15)
 constexpr int kTabThreads = 1024;
 constexpr uint32_t kTInf = 0xffffu;
-
-// LDS bytes per window bit for a level with chain length K: T_0..T_{K-2} and U_0..U_{K-1} (u16
-// each), the hop word (u32) and the bit itself.  The window is the largest multiple of 1024 that
-// fits.
-__host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
-{
-  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 4) + 1u;   // eighths of a byte
-  const uint32_t fixed = 4 * 8 + 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
-  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
-  w = w / 1024 * 1024;
-  if (w > (uint32_t)kTabWMax)
-    w = kTabWMax;
-  return w;
-}
 
 struct TabCtx {
   uint64_t parent;     // packed parent node of the items
@@ -2340,6 +2326,956 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// LIS phase, lists of the 8x8x8 and larger sets, GPU-WIDE: k_lis_tables' method (speculative
+// tables per window, pointer jumping over the list entries, breadth-first expansion of the sets
+// that split inside the window) with the windows at FIXED places, so that several workgroups per
+// chunk work on one chunk's phase at a time and only a short hop stays on the serial chain.
+//
+//   * the phase's stream, from where k_lis_l1 ended, is cut into regions of W bits; region i is
+//     handed out by a ticket counter (a region is handed out only after all earlier ones, so a
+//     waiting workgroup always waits for a running one);
+//   * OFF the chain a workgroup loads its region and builds the tables T_j / U_j of every class
+//     the level needs (the level is taken from a hint the chain leaves behind; a wrong guess
+//     costs a rebuild on the chain) and the pointer-jump table of the list's own class;
+//   * ON the chain it takes its predecessor's state -- stream position, list level, entry index,
+//     entries left, and the stack of sets being walked into (child ordinal + "found" bit per
+//     frame, the list entry at the bottom) packed into four tagged words read and written with
+//     relaxed agent-scope atomics, no fence -- resolves the hop through its region with the
+//     tables (serial contexts, then the list entries by pointer jumping), and publishes the
+//     state at its end;
+//   * OFF the chain again it expands the sets that split inside the region.
+// Births and leaf events take their slots from the chunk's global counters, one atomic per
+// wavefront and round.  Old entries are compacted afterwards by k_lis_compact; k_lis_hi_end sets
+// the chunk's state for the placement kernels.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kHiTagShift = 57;
+constexpr unsigned long long kHiPayloadMask = (1ull << kHiTagShift) - 1ull;
+constexpr int kHiFrames = 8;
+
+template <typename CT>
+__global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  extern __shared__ __attribute__((aligned(16))) char tab_smem[];
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(tab_smem);
+  const uint32_t W = b.hiW, TS = W + 2;
+  const int Kcap = (int)b.hiK;                     // classes the LDS tables have room for
+  const uint32_t kWords = W / 64 + 4;
+  uint32_t* hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);   // [W + 130]
+  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop + (W + 130));                  // [Kcap - 1][TS]
+  uint16_t* Uu = Tt + (size_t)(Kcap - 1) * TS;                                  // [Kcap][TS]
+  constexpr int kBlk = kTabWMax / 64 + 4;
+  __shared__ uint32_t blkEB[kBlk];
+  __shared__ uint32_t sh_total, sh_stopped, sh_newr;
+  __shared__ TabCtx sh_ctx[kHiFrames + 2];
+  __shared__ uint32_t sh_qn[3];
+  __shared__ uint32_t sh_len[kMaxLevels];
+  __shared__ LevelClass sh_lc[kMaxLevels];
+  constexpr int kLdsRoots = 48, kLdsGrids = 288;
+  __shared__ Root sh_roots[kLdsRoots];
+  __shared__ Grid sh_grids[kLdsGrids];
+  // chain state (thread 0 owns it; the others read it between barriers)
+  __shared__ uint64_t sh_pos, sh_base;
+  __shared__ uint32_t sh_level, sh_depth, sh_e, sh_rem, sh_stop, sh_action, sh_ticket, sh_any;
+  __shared__ unsigned long long sh_in[4];
+  __shared__ int sh_tabLevel, sh_tabK, sh_hopTop, sh_tabFrom;   // what the tables in LDS were built for
+  __shared__ uint32_t sh_over, sh_nhb;
+  constexpr int kHiHopBorn = 96;   // births the serial hop found: their slots are taken off the chain
+  __shared__ uint64_t sh_hbKid[kHiHopBorn], sh_hbMeta[kHiHopBorn];
+
+  const Tree& t = b.tree;
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u;
+  for (uint32_t i = tid; i < t.nroots && i < (uint32_t)kLdsRoots; i += kTabThreads)
+    sh_roots[i] = t.roots[i];
+  for (uint32_t i = tid; i < t.ngrids && i < (uint32_t)kLdsGrids; i += kTabThreads)
+    sh_grids[i] = t.grids[i];
+  const uint32_t cur = s.cur;
+  for (uint32_t l = tid; l < t.nlevels; l += kTabThreads) {
+    sh_len[l] = s.listLen[cur][l];
+    sh_lc[l] = b.levelClass[l];
+  }
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  uint64_t* qbase = b.queue + c * b.queueStride + (size_t)blockIdx.x * b.queueCap * 4;
+  uint64_t* qbuf[2] = {qbase, qbase + b.queueCap * 2};
+  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  const uint64_t* lisCur = b.lis[cur] + c * b.lisStride;
+  unsigned long long* flags = b.hiFlags + c * b.hiFlagStride;
+  const unsigned long long tag = (unsigned long long)(p + 1) << kHiTagShift;
+  const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
+  const bool l1done = b.l1Level >= 0 && s.l1PlaneP1 == p + 1;
+  const uint64_t S0 = l1done ? s.l1End : l0done ? s.l0End : phase0;
+  __syncthreads();
+
+  // the next list after level `l` (exclusive) that holds entries and is this kernel's to decode
+  auto next_level = [&](int l) -> int {
+    for (l = l - 1; l >= 0; l--) {
+      if ((l0done && l == b.l0Level) || (l1done && l == b.l1Level))
+        continue;
+      if (sh_len[l] != 0)
+        return l;
+    }
+    return -1;
+  };
+
+  uint32_t wq0 = 0;
+  auto bit_at = [&](uint32_t r) -> uint32_t {
+    const uint32_t q = r + wq0;
+    return (w32[q >> 5] >> (q & 31)) & 1u;
+  };
+  auto bits32 = [&](uint32_t r) -> uint32_t {
+    const uint32_t q = r + wq0, sh = q & 31;
+    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  };
+  uint64_t a = 0;   // absolute bit of window position 0
+
+  // ---- tables of classes [j0, j1) of level `lv`'s chain (see k_lis_tables)
+  auto split_len = [&](const LevelClass& C, int j, uint32_t r) -> uint32_t {
+    const int ar = C.arity[j];
+    if (j == 0) {
+      if (r >= W)
+        return kTInf;
+      const uint32_t v = bits32(r);
+      uint32_t y = 0, found = 0;
+      if (ar == 8) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const uint32_t bit = (v >> y) & 1u;
+          found |= bit;
+          y += 1u + bit;
+        }
+        const uint32_t bit = found ? (v >> y) & 1u : 1u;
+        y += found + bit;
+      }
+      else {
+        for (int i = 0; i < ar; i++) {
+          const uint32_t coded = found | (uint32_t)(i + 1 != ar);
+          const uint32_t bit = coded ? (v >> y) & 1u : 1u;
+          y += coded;
+          found |= bit;
+          y += bit;
+        }
+      }
+      return r + y <= W ? y : kTInf;
+    }
+    const uint16_t* Up = Uu + (size_t)(j - 1) * TS;
+    const uint16_t* Tp = Tt + (size_t)(j - 1) * TS;
+    if (ar == 8) {
+      uint32_t y = min(r, W + 1), fl = 0;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const uint32_t u = Up[y];
+        fl |= u;
+        y = min(y + (u & 0x7fffu), W + 1);
+      }
+      const uint32_t v = ((fl & 0x8000u) ? Up : Tp)[y];
+      return (y > W || v == kTInf) ? kTInf : y + (v & 0x7fffu) - r;
+    }
+    uint32_t y = r, found = 0;
+    for (int i = 0; i + 1 < ar; i++) {
+      const uint32_t u = y <= W + 1 ? Up[y] : kTInf;
+      if (u == kTInf)
+        return kTInf;
+      found |= u >> 15;
+      y += u & 0x7fffu;
+    }
+    if (y > W + 1)
+      return kTInf;
+    uint32_t last;
+    if (found) {
+      const uint32_t u = Up[y];
+      if (u == kTInf)
+        return kTInf;
+      last = u & 0x7fffu;
+    }
+    else {
+      last = Tp[y];
+      if (last == kTInf)
+        return kTInf;
+    }
+    return y + last - r;
+  };
+  // all threads; T_j for j < j1 - 1 ... every class in [j0, j1) gets both T_j and U_j (the top
+  // class of a level only needs U, but a later level of the same chain may sit on top of it)
+  auto build_tables = [&](int lv, int j0, int j1) {
+    const LevelClass& C = sh_lc[lv];
+    for (int j = j0; j < j1; j++) {
+      uint16_t* Uj = Uu + (size_t)j * TS;
+      uint16_t* Tj = j < Kcap - 1 ? Tt + (size_t)j * TS : nullptr;
+      auto coded = [&](uint32_t q, uint32_t tl) -> uint16_t {   // U_j[q] given T_j[q + 1]
+        if (q >= W)
+          return (uint16_t)kTInf;
+        if (!bit_at(q))
+          return (uint16_t)1;
+        return (uint16_t)(tl == kTInf ? kTInf : (0x8000u | (1u + tl)));
+      };
+      for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
+        const uint32_t r2 = r + kTabThreads;
+        const uint32_t t1 = split_len(C, j, r);
+        const uint32_t t2 = r2 <= W + 1 ? split_len(C, j, r2) : kTInf;
+        if (Tj)
+          Tj[r] = (uint16_t)t1;
+        if (r >= 1)
+          Uj[r - 1] = coded(r - 1, t1);
+        if (r2 <= W + 1) {
+          if (Tj)
+            Tj[r2] = (uint16_t)t2;
+          Uj[r2 - 1] = coded(r2 - 1, t2);
+        }
+        if (r == W + 1 || r2 == W + 1)
+          Uj[W + 1] = (uint16_t)kTInf;
+      }
+      __syncthreads();
+    }
+  };
+  // all threads; pointer-jump table over the coded items of class `top`, from every position:
+  // hop[h] for h = r + wq0 (64-bit blocks are stream words): cnt << 16 | stop << 15 | exit
+  auto build_hop = [&](int top) {
+    const uint16_t* Utop = Uu + (size_t)top * TS;
+    const uint32_t nblk = ((W - 1 + wq0) >> 6) + 1;
+    const int32_t rbase = -(int32_t)wq0;
+    const uint32_t wave = (uint32_t)tid >> 6;
+    for (uint32_t bi = wave; bi < nblk; bi += kTabThreads / 64) {
+      const uint32_t h = bi * 64 + lane;
+      const int32_t rs = (int32_t)h + rbase;
+      const bool live = rs >= 0 && rs < (int32_t)W;
+      uint32_t v = 0x8000u;
+      bool inb = false;
+      const uint32_t hEnd = (bi + 1) * 64;
+      if (live) {
+        const uint32_t r = (uint32_t)rs;
+        const uint32_t u = Utop[r];
+        if (u == kTInf)
+          v = 0x8000u | r;
+        else {
+          const uint32_t nr = r + (u & 0x7fffu);
+          v = (1u << 16) | nr;
+          inb = nr < W && (uint32_t)((int32_t)nr - rbase) < hEnd;
+        }
+      }
+      for (int it = 0; it < 6 && __any(inb); it++) {
+        const uint32_t src = (uint32_t)((int32_t)(v & 0x7fffu) - rbase) & 63u;
+        const uint32_t o = __shfl(v, src, 64);
+        if (inb) {
+          v = (v & 0xffff0000u) + o;
+          const uint32_t np = v & 0x7fffu;
+          inb = !(v & 0x8000u) && np < W && (uint32_t)((int32_t)np - rbase) < hEnd;
+        }
+      }
+      if (live)
+        hop[h] = v;
+    }
+    __syncthreads();
+    for (uint32_t wide = 128; wide <= 256; wide <<= 1) {
+      for (uint32_t h = (uint32_t)tid; h < nblk * 64; h += kTabThreads) {
+        const int32_t rs = (int32_t)h + rbase;
+        if (rs < 0 || rs >= (int32_t)W)
+          continue;
+        const uint32_t v = hop[h];
+        if (v & 0x8000u)
+          continue;
+        const uint32_t er = v & 0x7fffu;
+        if (er >= W)
+          continue;
+        const uint32_t eh = (uint32_t)((int32_t)er - rbase);
+        if (eh / wide != h / wide)
+          continue;
+        hop[h] = (v & 0xffff0000u) + hop[eh];
+      }
+      __syncthreads();
+    }
+  };
+  // thread 0: do the tables in LDS (built for sh_tabLevel, classes [0, sh_tabK)) serve level lv?
+  auto tables_serve = [&](int lv) -> bool {
+    if (sh_tabLevel < 0)
+      return false;
+    const LevelClass& A = sh_lc[sh_tabLevel];
+    const LevelClass& B = sh_lc[lv];
+    if ((int)B.K > sh_tabK)
+      return false;
+    for (int j = 0; j < (int)B.K; j++)
+      if (A.arity[j] != B.arity[j] || A.lev[j] != B.lev[j])
+        return false;
+    return true;
+  };
+
+  // births and leaf events: slots from the chunk's counters, one atomic per wavefront
+  auto wave_slots = [&](uint32_t* counter, uint32_t n) -> uint32_t {
+    const uint32_t inc = wave_inclusive_scan<uint32_t>(n);
+    const uint32_t tot = __shfl(inc, 63, 64);
+    uint32_t base = 0;
+    if (tot) {
+      if (lane == 63)
+        base = atomicAdd(counter, tot);
+      base = __shfl(base, 63, 64);
+    }
+    return base + inc - n;
+  };
+  auto write_born = [&](uint32_t slot, uint32_t lev, uint64_t abs, uint64_t packed) {
+    const uint64_t rel = abs - phase0;
+    if (slot >= b.bornStride)
+      return;
+    bornPacked[slot] = packed;
+    bornPosLev[slot] = ((uint64_t)lev << 48) | rel;
+    atomic_or64(b.mask + c * b.maskStride + (size_t)b.levelSlot[lev] * b.maskWords + (rel >> 6),
+                1ull << (rel & 63));
+  };
+  auto born_counts = [&](uint32_t lev, uint64_t abs) -> bool {   // is this birth recorded at all
+    return b.levelSlot[lev] != 0xff && abs - phase0 < maskBits;
+  };
+
+  // all threads: expand what the queue holds, breadth first (tables of level sh_tabLevel's chain)
+  auto expand_all = [&]() {
+    const LevelClass& C = sh_lc[sh_tabLevel];
+    for (int round = 0;; round++) {
+      const uint32_t nin = sh_qn[round % 3];
+      if (nin == 0)
+        break;
+      const uint64_t* qin = qbuf[round & 1];
+      uint64_t* qout = qbuf[(round + 1) & 1];
+      for (uint32_t i0 = 0; i0 < nin; i0 += kTabThreads) {
+        const uint32_t i = i0 + tid;
+        const bool have = i < nin;
+        uint64_t ident = 0, meta = 0;
+        if (have) {
+          ident = qin[i * 2];
+          meta = qin[i * 2 + 1];
+        }
+        const int cls = (int)((meta >> 1) & 0x7f);
+        const uint32_t y0 = (uint32_t)(meta >> 8);
+        const Node nd = unpack_node(have ? ((meta & 1ull) ? lisCur[ident] : ident) : 0ull);
+        const int ar = have ? C.arity[cls] : 0;
+        const Grid g = sh_grids[nd.grid];
+        // ---- leaf parents: one event word each
+        const bool isLeaf = have && cls == 0;
+        uint32_t sigm = 0, negm = 0;
+        if (isLeaf) {
+          const uint32_t v = bits32(y0);
+          uint32_t yy = 0, found = 0;
+          if (ar == 8) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+              const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+              sigm |= bit << k;
+              negm |= (bit & (sgn ^ 1u)) << k;
+              found |= bit;
+              yy += 1u + bit;
+            }
+            const uint32_t bit = found ? (v >> yy) & 1u : 1u;
+            const uint32_t sgn = (v >> (yy + found)) & 1u;
+            sigm |= bit << 7;
+            negm |= (bit & (sgn ^ 1u)) << 7;
+          }
+          else {
+            for (int k = 0; k < ar; k++) {
+              const uint32_t coded = found | (uint32_t)(k + 1 != ar);
+              const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+              yy += coded;
+              const uint32_t sgn = (v >> yy) & 1u;
+              sigm |= bit << k;
+              negm |= (bit & (sgn ^ 1u)) << k;
+              found |= bit;
+              yy += bit;
+            }
+          }
+        }
+        // ---- other sets: children from the tables; count the births first
+        const bool isSet = have && cls > 0;
+        const uint16_t* Up = Uu + (size_t)(isSet ? cls - 1 : 0) * TS;
+        const uint32_t kidLev = isSet ? C.lev[cls - 1] : 0u;
+        uint32_t nborn = 0;
+        if (isSet) {
+          uint32_t y = y0, found = 0;
+          for (int k = 0; k < ar; k++) {
+            const bool coded = found || (k + 1 != ar);
+            if (coded) {
+              const uint32_t u = Up[y];
+              if (!(u & 0x8000u)) {
+                nborn += born_counts(kidLev, a + y) ? 1u : 0u;
+                y += 1;
+                continue;
+              }
+              y += u & 0x7fffu;
+            }
+            found = 1;
+          }
+        }
+        uint32_t slotL = wave_slots(&s.leafCount, isLeaf ? 1u : 0u);
+        uint32_t slotB = wave_slots(&s.bornCount, nborn);
+        if (isLeaf) {
+          const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
+          if (slotL < b.leafCap)
+            leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+        }
+        if (isSet) {
+          const Root rt = sh_roots[g.root];
+          uint32_t cbase[3], cshift[3];
+          uint32_t nb = 0;
+          for (int ax = 0; ax < 3; ax++) {
+            if (g.depth < rt.D[ax]) {
+              cbase[ax] = (uint32_t)nd.i[ax] * 2u;
+              cshift[ax] = nb++;
+            }
+            else {
+              cbase[ax] = nd.i[ax];
+              cshift[ax] = 31;
+            }
+          }
+          const uint64_t gridBits = (uint64_t)(nd.grid + 1) << 48;
+          uint32_t y = y0, found = 0;
+          for (int k = 0; k < ar; k++) {
+            const uint64_t kid = gridBits |
+                                 ((uint64_t)(cbase[2] | (((uint32_t)k >> cshift[2]) & 1u)) << 32) |
+                                 ((uint64_t)(cbase[1] | (((uint32_t)k >> cshift[1]) & 1u)) << 16) |
+                                 (uint64_t)(cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
+            const bool coded = found || (k + 1 != ar);
+            uint32_t start = y;
+            if (coded) {
+              const uint32_t u = Up[y];
+              if (!(u & 0x8000u)) {
+                if (born_counts(kidLev, a + y))
+                  write_born(slotB++, kidLev, a + y, kid);
+                y += 1;
+                continue;
+              }
+              start = y + 1;
+              y += u & 0x7fffu;
+            }
+            found = 1;
+            const uint32_t slot = atomicAdd(&sh_qn[(round + 1) % 3], 1u);
+            if (slot < b.queueCap) {
+              qout[slot * 2] = kid;
+              qout[slot * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)(cls - 1) << 1);
+            }
+          }
+        }
+      }
+      if (tid == 0)
+        sh_qn[(round + 2) % 3] = 0;
+      __syncthreads();
+    }
+    if (tid == 0)
+      sh_qn[0] = sh_qn[1] = sh_qn[2] = 0;
+    __syncthreads();
+  };
+
+  // actions thread 0 can ask the workgroup for
+  constexpr uint32_t kActDone = 0, kActTables = 1, kActHop = 2, kActList = 3, kActFlushTables = 4;
+
+  for (;;) {
+    // ---- ticket
+    if (tid == 0) {
+      const bool over = __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1;
+      sh_ticket = over ? kL0None : atomicAdd(&s.hiTicket, 1u);
+      sh_any = 0;
+      sh_over = 0;
+      sh_nhb = 0;
+      sh_qn[0] = sh_qn[1] = sh_qn[2] = 0;
+    }
+    __syncthreads();
+    const uint32_t i = sh_ticket;
+    if (i == kL0None || ((size_t)i + 1) * 4 > b.hiFlagStride)
+      break;
+    a = S0 + (uint64_t)i * W;
+    wq0 = (uint32_t)(a & 63);
+    {
+      const uint64_t w0 = a >> 6;
+      uint64_t any = 0;
+      for (uint32_t k = tid; k < kWords; k += kTabThreads) {
+        const uint64_t idx = w0 + k;
+        const uint64_t v = idx < nwordsAvail ? words[idx] : 0ull;
+        wbits[k] = v;
+        any |= v;
+      }
+      if (any)
+        sh_any = 1;   // (benign race: everybody writes 1)
+    }
+    if (tid == 0) {
+      int hint = __hip_atomic_load(&s.hiHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((hint >> 8) != p + 1)
+        hint = -1;
+      else
+        hint &= 0xff;
+      if (hint < 0 || hint >= (int)t.nlevels || sh_len[hint] == 0)
+        hint = next_level((int)t.nlevels);
+      sh_tabLevel = hint;
+    }
+    __syncthreads();
+    // ---- speculative tables for the hinted level (nothing to build over a region of zeros:
+    //      there every item is one insignificant bit, which the chain handles without tables)
+    const bool zeroRegion = sh_any == 0;
+    if (!zeroRegion && sh_tabLevel >= 0) {
+      const int lv = sh_tabLevel;
+      const int K = sh_lc[lv].K;
+      build_tables(lv, 0, K);
+      build_hop(K - 1);
+      if (tid == 0) {
+        sh_tabK = K;
+        sh_hopTop = K - 1;
+      }
+    }
+    else if (tid == 0) {
+      sh_tabLevel = -1;
+      sh_tabK = 0;
+      sh_hopTop = -1;
+    }
+    __syncthreads();
+
+    // ---- look back (threads 0..3 take one word each)
+    if (tid < 4) {
+      unsigned long long f = 0;
+      if (i > 0) {
+        uint32_t spins = 0;
+        for (;;) {
+          f = __hip_atomic_load(flags + (size_t)(i - 1) * 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> kHiTagShift) == (unsigned long long)(p + 1))
+            break;
+          if ((++spins & 15u) == 0 &&
+              __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+            f = tag | (1ull << 56);   // the phase is over
+            break;
+          }
+          if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
+            s.error = 1;
+            __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f = tag | (1ull << 56);
+            break;
+          }
+        }
+      }
+      sh_in[tid] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t stop = 0;
+      if (i == 0) {
+        const int lv = next_level((int)t.nlevels);
+        sh_level = lv < 0 ? 0u : (uint32_t)lv;
+        sh_depth = 1;
+        sh_e = 0;
+        sh_rem = lv < 0 ? 0u : sh_len[lv];
+        sh_pos = S0;
+        sh_base = 0;
+        if (lv < 0) {   // nothing for this kernel to decode: the phase ends where it starts
+          stop = 2;
+        }
+      }
+      else {
+        const unsigned long long f0 = sh_in[0], f1 = sh_in[1], f2 = sh_in[2], f3 = sh_in[3];
+        if (((f0 >> 56) & 1ull) || ((f1 >> 56) & 1ull) || ((f2 >> 56) & 1ull) || ((f3 >> 56) & 1ull))
+          stop = 1;
+        else {
+          sh_depth = (uint32_t)(f0 >> 52) & 15u;
+          sh_level = (uint32_t)(f0 >> 46) & 63u;
+          sh_pos = S0 + (f0 & ((1ull << 46) - 1ull));
+          sh_e = (uint32_t)(f1 >> 28) & 0xfffffffu;
+          sh_rem = (uint32_t)f1 & 0xfffffffu;
+          sh_base = f3 & kHiPayloadMask;
+          // rebuild the stack of sets being walked into: frame d holds the children of the set that
+          // frame d - 1 entered (frame 1: of the list entry)
+          const LevelClass& C = sh_lc[sh_level];
+          uint64_t parent = sh_base;
+          for (uint32_t d = 1; d < sh_depth; d++) {
+            const uint32_t fr = (uint32_t)(f2 >> (5 * (d - 1))) & 31u;
+            TabCtx& cx = sh_ctx[d];
+            const int pcls = (int)C.K - (int)d;   // class of the parent set
+            cx.parent = parent;
+            cx.cls = (int8_t)(pcls - 1);
+            cx.nextOrd = (uint8_t)(fr & 15u);
+            cx.found = (uint8_t)(fr >> 4);
+            cx.remaining = (uint32_t)C.arity[pcls] - (fr & 15u);
+            if (d + 1 < sh_depth)
+              parent = reg_child_packed(t, unpack_node(parent), (fr & 15u) - 1u);
+          }
+        }
+      }
+      sh_stop = stop;
+    }
+    __syncthreads();
+    if (sh_stop == 1)
+      break;
+
+    // ---- the hop through this region: thread 0 decides what the workgroup does next
+    while (sh_stop == 0) {
+      if (tid == 0) {
+        uint32_t act = kActDone;
+        for (;;) {
+          const uint64_t pos = sh_pos;
+          if (pos >= a + W)
+            break;
+          if (sh_depth == 1 && sh_rem == 0) {   // this list is through: the next one
+            const int lv = next_level((int)sh_level);
+            if (lv < 0) {
+              sh_over = 1;
+              break;
+            }
+            sh_level = (uint32_t)lv;
+            sh_e = 0;
+            sh_rem = sh_len[lv];
+          }
+          if (zeroRegion && sh_depth == 1) {
+            // one '0' per entry, nothing splits: count them off
+            const uint32_t z = min((uint32_t)(a + W - pos), sh_rem);
+            sh_e += z;
+            sh_rem -= z;
+            sh_pos = pos + z;
+            continue;
+          }
+          const int lv = (int)sh_level;
+          if (!tables_serve(lv)) {
+            // chains that agree from the leaf class upwards share tables: classes are only added
+            bool extend = sh_tabLevel >= 0;
+            if (extend) {
+              const LevelClass& A = sh_lc[sh_tabLevel];
+              const LevelClass& B = sh_lc[lv];
+              for (int j = 0; j < sh_tabK && j < (int)B.K; j++)
+                extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+            }
+            sh_tabFrom = extend ? sh_tabK : 0;
+            act = (!extend && sh_tabLevel >= 0 && sh_qn[0] != 0) ? kActFlushTables : kActTables;
+          }
+          else
+            act = sh_depth > 1 ? kActHop : kActList;
+          break;
+        }
+        sh_action = act;
+      }
+      __syncthreads();
+      uint32_t act = sh_action;
+      if (act == kActDone)
+        break;
+      if (act == kActFlushTables) {   // sets of the previous chain are queued: expand them with its
+        expand_all();                 // tables before those are replaced
+        act = kActTables;
+      }
+      if (act == kActTables) {
+        const int lv = (int)sh_level;
+        const int K = sh_lc[lv].K;
+        const int j0 = sh_tabFrom;
+        __syncthreads();
+        build_tables(lv, j0, K);
+        if (tid == 0) {
+          sh_tabLevel = lv;
+          sh_tabK = K;
+          sh_hopTop = -1;
+        }
+        __syncthreads();
+        continue;
+      }
+      const LevelClass& C = sh_lc[sh_level];
+      const int K = C.K;
+      if (act == kActHop) {
+        // serial part: the sets being walked into (k_lis_tables, "hop, part S"); an item that
+        // leaves the region is entered, so the chain always reaches the region's end
+        if (tid == 0) {
+          uint32_t r = (uint32_t)(sh_pos - a);
+          int depth = (int)sh_depth;
+          uint32_t qn = sh_qn[0];
+          uint32_t nhb = sh_nhb;
+          while (depth > 1 && r < W) {
+            TabCtx& cx = sh_ctx[depth - 1];
+            if (cx.remaining == 0) {
+              depth--;
+              continue;
+            }
+            const bool coded = cx.found || cx.remaining > 1;
+            const int cls = cx.cls;
+            const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd);
+            uint32_t start, len;
+            if (coded) {
+              const uint32_t u = Uu[(size_t)cls * TS + r];
+              if (u == 1) {  // insignificant: born (its slot is taken after the state is published)
+                const uint32_t lev = C.lev[cls];
+                if (born_counts(lev, a + r)) {
+                  if (nhb < (uint32_t)kHiHopBorn) {
+                    sh_hbKid[nhb] = kid;
+                    sh_hbMeta[nhb] = ((uint64_t)lev << 48) | (a + r);
+                    nhb++;
+                  }
+                  else
+                    write_born(atomicAdd(&s.bornCount, 1u), lev, a + r, kid);
+                }
+                cx.remaining--;
+                cx.nextOrd++;
+                r += 1;
+                continue;
+              }
+              start = r + 1;
+              len = u == kTInf ? kTInf : (u & 0x7fffu) - 1u;
+            }
+            else {
+              start = r;
+              len = Tt[(size_t)cls * TS + r];
+            }
+            cx.found = 1;
+            cx.remaining--;
+            cx.nextOrd++;
+            if (len != kTInf) {
+              if (qn < b.queueCap) {
+                qbuf[0][qn * 2] = kid;
+                qbuf[0][qn * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)cls << 1);
+                qn++;
+              }
+              r = start + len;
+            }
+            else {  // leaves the region: walk into it (a leaf parent always fits: the tables of
+              r = start;  // class 0 look at the bits loaded past the region's end)
+              TabCtx& nc = sh_ctx[depth];
+              nc.parent = kid;
+              nc.remaining = C.arity[cls];
+              nc.cls = (int8_t)(cls - 1);
+              nc.found = 0;
+              nc.nextOrd = 0;
+              depth++;
+            }
+          }
+          sh_pos = a + r;
+          sh_depth = (uint32_t)depth;
+          sh_qn[0] = qn;
+          sh_nhb = nhb;
+        }
+        __syncthreads();
+        continue;
+      }
+      // ---- act == kActList: the list entries from sh_pos on, by pointer jumping
+      if (sh_hopTop != K - 1) {
+        build_hop(K - 1);
+        if (tid == 0)
+          sh_hopTop = K - 1;
+        __syncthreads();
+      }
+      const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
+      const uint32_t pr = (uint32_t)(sh_pos - a);
+      const uint32_t remaining = sh_rem, e0 = sh_e;
+      const uint32_t lOff = b.levelOff[sh_level];
+      const uint32_t nblk = ((W - 1 + wq0) >> 6) + 1;
+      const int32_t rbase = -(int32_t)wq0;
+      for (uint32_t k = tid; k < nblk; k += kTabThreads)
+        blkEB[k] = 0xffffffffu;
+      __syncthreads();
+      if (tid == 0) {  // P2: walk the blocks
+        uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
+        while (true) {
+          if (r >= W) {
+            newr = r;
+            break;
+          }
+          const uint32_t h = (uint32_t)((int32_t)r - rbase);
+          const uint32_t v = hop[h];
+          const uint32_t cn = v >> 16;
+          blkEB[h >> 6] = r | (total << 16);
+          if (total + cn >= remaining) {
+            total = remaining;
+            break;
+          }
+          total += cn;
+          if (v & 0x8000u) {
+            stopped = 1;
+            newr = v & 0x7fffu;
+            break;
+          }
+          r = v & 0x7fffu;
+        }
+        sh_total = total;
+        sh_stopped = stopped;
+        sh_newr = newr;
+      }
+      __syncthreads();
+      if ((uint32_t)tid < nblk && blkEB[tid] != 0xffffffffu) {  // P3: the blocks emit their entries
+        const uint32_t eb = blkEB[tid];
+        uint32_t r = eb & 0xffffu;
+        const uint32_t base = eb >> 16;
+        const uint32_t cn = hop[(uint32_t)((int32_t)r - rbase)] >> 16;
+        const uint32_t lim_k = min(cn, remaining - base);
+        for (uint32_t k = 0; k < lim_k; k++) {
+          const uint32_t u = Utop[r];
+          if (u & 0x8000u) {
+            const uint32_t ei = lOff + e0 + base + k;   // index into the chunk's list storage
+            const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+            if (slot < b.queueCap) {
+              qbuf[0][slot * 2] = ei;
+              qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+            }
+            atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+          }
+          r += u & 0x7fffu;
+        }
+        if (lim_k > 0 && base + lim_k == remaining)
+          sh_newr = r;  // the list ended in this block (only one block satisfies this)
+      }
+      __syncthreads();
+      if (tid == 0) {  // P4
+        const uint32_t total = sh_total;
+        uint32_t e = e0 + total;
+        uint32_t rem = remaining - total;
+        uint32_t r = sh_newr;
+        uint32_t depth = 1;
+        if (sh_stopped && rem > 0) {
+          // the entry at r leaves the region: walk into it
+          const uint32_t ei = lOff + e;
+          const uint64_t ent = lisCur[ei];
+          TabCtx& nc = sh_ctx[1];
+          nc.parent = ent;
+          nc.remaining = C.arity[K - 1];
+          nc.cls = (int8_t)(K - 2);
+          nc.found = 0;
+          nc.nextOrd = 0;
+          sh_base = ent;
+          atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+          e++;
+          rem--;
+          r += 1;  // its '1'
+          depth = 2;
+        }
+        sh_rem = rem;
+        sh_e = e;
+        sh_pos = a + r;
+        sh_depth = depth;
+      }
+      __syncthreads();
+    }
+
+    // ---- publish the state at the end of the region (or the end of the phase)
+    if (tid == 0) {
+      const bool over = sh_stop == 2 || sh_over != 0;
+      if (over) {
+        s.hiEnd = sh_pos;
+        __hip_atomic_store(flags + (size_t)i * 4 + 0, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 1, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      else {
+        unsigned long long fr = 0;
+        for (uint32_t d = 1; d < sh_depth; d++)
+          fr |= (unsigned long long)((sh_ctx[d].nextOrd & 15u) | ((sh_ctx[d].found ? 1u : 0u) << 4)) << (5 * (d - 1));
+        const unsigned long long f0 = tag | ((unsigned long long)sh_depth << 52) |
+                                      ((unsigned long long)sh_level << 46) | (unsigned long long)(sh_pos - S0);
+        const unsigned long long f1 = tag | ((unsigned long long)sh_e << 28) | (unsigned long long)sh_rem;
+        __hip_atomic_store(flags + (size_t)i * 4 + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (sh_base & kHiPayloadMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&s.hiHint, ((p + 1) << 8) | (int)sh_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh_stop = over ? 1u : 0u;
+    }
+    __syncthreads();
+    // ---- off the chain: the births the serial hop found, then the sets that split in this region
+    if (sh_nhb) {
+      const uint32_t nhb = sh_nhb;
+      if (tid == 0)
+        sh_total = atomicAdd(&s.bornCount, nhb);
+      __syncthreads();
+      if ((uint32_t)tid < nhb) {
+        const uint64_t m = sh_hbMeta[tid];
+        write_born(sh_total + (uint32_t)tid, (uint32_t)(m >> 48), m & ((1ull << 48) - 1ull), sh_hbKid[tid]);
+      }
+      __syncthreads();
+    }
+    if (sh_tabLevel >= 0)
+      expand_all();
+    if (sh_stop)
+      break;
+    __syncthreads();   // LDS is reused by the next region
+  }
+}
+
+// Old entries of the lists k_lis_hi decoded that stayed insignificant keep their order
+// (SPECK3D_INT.cpp:12-20): one workgroup per (level, chunk) compacts by the significance bits.
+__global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y, l = blockIdx.x;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  if ((b.l0Level >= 0 && s.l0PlaneP1 == p + 1 && (int)l == b.l0Level) ||
+      (b.l1Level >= 0 && s.l1PlaneP1 == p + 1 && (int)l == b.l1Level))
+    return;   // (those kernels kept their own survivors)
+  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint32_t n = s.listLen[cur][l];
+  const uint32_t lOff = b.levelOff[l];
+  const uint64_t* list = b.lis[cur] + c * b.lisStride;
+  uint64_t* keep = b.lis[nx] + c * b.lisStride + lOff;
+  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
+  const int tid = threadIdx.x;
+  uint32_t carry = 0;
+  // the level's bits start at bit lOff of the chunk's bit array
+  for (uint32_t base = 0; base < n; base += kTabThreads * 32) {
+    const uint32_t i0 = base + (uint32_t)tid * 32;
+    uint32_t stay = 0;
+    if (i0 < n) {
+      const uint32_t gi = lOff + i0;
+      const uint64_t lo = sigbits[gi >> 6], hi = sigbits[(gi >> 6) + 1];
+      const uint32_t sh = gi & 63u;
+      const uint32_t sig = (uint32_t)(sh ? (lo >> sh) | (hi << (64 - sh)) : lo);
+      stay = ~sig;
+      const uint32_t valid = n - i0;
+      if (valid < 32)
+        stay &= (1u << valid) - 1u;
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popc(stay), sh_scan, &total) + carry;
+    while (stay) {
+      const int k = __ffs((int)stay) - 1;
+      stay &= stay - 1;
+      keep[ex++] = list[lOff + i0 + k];
+    }
+    carry += total;
+  }
+  __syncthreads();
+  // leave the bits clean for the next plane (neighbouring levels share words: atomic)
+  for (uint32_t i0 = (uint32_t)tid * 64; i0 < n + 64; i0 += kTabThreads * 64) {
+    const uint32_t g0 = lOff + i0, g1 = min(lOff + n, g0 + 64);
+    if (g0 >= lOff + n)
+      break;
+    // bits [g0, g1) span at most two words
+    for (uint32_t g = g0; g < g1;) {
+      const uint32_t w = g >> 6, upto = min(g1, (w + 1) * 64);
+      const uint64_t m = ((upto - w * 64 == 64) ? ~0ull : ((1ull << (upto - w * 64)) - 1ull)) &
+                         ~((1ull << (g & 63)) - 1ull);
+      atomicAnd(reinterpret_cast<unsigned long long*>(sigbits + w), ~m);
+      g = upto;
+    }
+  }
+  if (tid == 0)
+    s.listLen[nx][l] = carry;
+}
+
+// the chunk's state after the phase (what k_lis_tables' last lines do)
+__global__ void k_lis_hi_end(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  const uint64_t end = s.hiEnd;
+  s.cur ^= 1u;
+  s.pos = end;
+  s.nLeafEv = min(s.leafCount, b.leafCap);
+  s.bornCount = min(s.bornCount, (uint32_t)b.bornStride);
+  s.lisPhaseBits = min(end - phase0, maskBits);
+  s.lastPlane = p;
+  if (end >= s.avail)  // SPECK_INT.cpp:200-201
+    s.done = 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Placement of the sets born in the plane k_lis_tables (and k_lis_l1) just decoded: a set joins
 // the list of its level behind the entries that survived, in the order of the stream positions at
 // which the sets were born (= the reference's append order).  Every birth set one bit of its
@@ -2657,6 +3593,15 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
   const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l1Total / nc));
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
+  // workgroups per chunk of the k_lis_hi pass: one per CU over all chunks, at most what the
+  // queues were sized for (SPERR_HIP_HI_WGS: the total)
+  static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 256u;
+  const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
+  if (plan.tables && plan.hi) {
+    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint32_t>), (int)b.hiSmemBytes) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint64_t>), (int)b.hiSmemBytes))
+      return -1;
+  }
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -2670,7 +3615,13 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
-        LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        if (plan.hi) {
+          LAUNCH_K(k_lis_hi<uint64_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
+          LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_lis_hi_end, perChunk, dim3(64), 0, stream, b, p);
+        }
+        else
+          LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -2691,7 +3642,13 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
           LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
         if (plan.l1)
           LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
-        LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        if (plan.hi) {
+          LAUNCH_K(k_lis_hi<uint32_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
+          LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_lis_hi_end, perChunk, dim3(64), 0, stream, b, p);
+        }
+        else
+          LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
