@@ -1581,7 +1581,7 @@ bool g_lis_stamps_on = false;
 bool use_lis_hi(const ShapePlan& P, bool tables)
 {
   static const bool hiEnv = !(getenv("SPERR_HIP_LIS_HI") && atoi(getenv("SPERR_HIP_LIS_HI")) == 0);
-  return hiEnv && !g_lis_stamps_on && tables && P.ht.grids.size() <= 288 && P.ht.roots.size() <= 48 &&
+  return hiEnv && tables && P.ht.grids.size() <= 288 && P.ht.roots.size() <= 48 &&
          P.maxK >= 1 && P.maxK <= 8;
 }
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
@@ -1652,8 +1652,11 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.mask, uint64_t, std::max<size_t>(d.maskStride, 1) * B);
   TAKE(d.maskPrefix, uint32_t, std::max<size_t>(d.maskStride, 1) * B);
   d.bornStride = P.ht.nsets + 8;
-  TAKE(d.bornPacked, uint64_t, d.bornStride * B);
-  TAKE(d.bornPosLev, uint64_t, d.bornStride * B);
+  d.hiGroupsMax = 8;
+  d.bornSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
+  d.bornPitch = d.bornStride + (size_t)d.bornSeg * d.hiGroupsMax;
+  TAKE(d.bornPacked, uint64_t, d.bornPitch * B);
+  TAKE(d.bornPosLev, uint64_t, d.bornPitch * B);
   d.tabSmemBytes = 152 * 1024;   // (k_lis_tables has 7 KB of static LDS: 160 KB in all)
   d.lisStamps = nullptr;
   if (g_lis_stamps_on) {
@@ -1661,16 +1664,23 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   }
   d.queueCap = 28672 + 64;
   // k_lis_hi: a pair of queues per workgroup, up to hiGroupsMax workgroups per chunk
-  d.hiGroupsMax = 8;
   d.hiK = (uint32_t)std::max(2, P.maxK);
+  {
+    static const uint32_t ahead = getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_AHEAD")) : 512u;
+    d.hiAhead = ahead;
+    static const uint32_t extra = getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_EXTRA")) : 1u;
+    d.hiExtra = extra;
+  }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
-  d.hiW = tab_window((int)d.hiK, d.hiSmemBytes);
+  d.hiW = hi_window((int)d.hiK, d.hiSmemBytes);
   d.queueStride = (size_t)d.queueCap * 4 * d.hiGroupsMax;
   TAKE(d.queue, uint64_t, d.queueStride * B);
-  d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(1024u, d.hiW) + 4) * 4;
+  d.hiAhead = std::min(d.hiAhead / 64 * 64, d.hiW / 2);
+  d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 4) * 4;
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
   d.leafCap = P.ht.nsets + 8;
-  d.leafStride = d.leafCap;
+  d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
+  d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);

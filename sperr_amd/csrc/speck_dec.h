@@ -36,6 +36,8 @@ struct DecState {
   int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
   uint32_t hiPad;
   uint64_t hiEnd;                // first bit after the phase
+  uint32_t hiBornCnt[8];         // births / leaf events in the workgroups' own segments
+  uint32_t hiLeafCnt[8];
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
   uint32_t leafCount;            //   of the current plane (bornCount: all births once k_lis_tables ends)
   uint64_t lisPhaseBits;         // bits of the plane's LIS phase covered by the birth masks
@@ -85,7 +87,10 @@ struct DecBuffers {
   size_t maskStride;
   uint64_t* bornPacked;
   uint64_t* bornPosLev;
-  size_t bornStride;
+  size_t bornStride;           // slots of the shared part (claimed with atomics on DecState::bornCount)
+  size_t bornPitch;            // slots per chunk: the shared part + hiGroupsMax segments of bornSeg
+  uint32_t bornSeg;            // k_lis_hi: every workgroup of a chunk fills a segment of its own
+  uint32_t leafSeg;            //   (same for the leaf events, behind leafCap shared slots)
   uint64_t* queue;             // two work queues of queueCap items (2 words each)
   uint32_t queueCap;
   size_t queueStride;
@@ -116,7 +121,10 @@ struct DecBuffers {
   uint32_t hiW;                // region bits (tab_window of the shape's longest class chain)
   uint32_t hiK;                // classes the LDS tables have room for
   uint32_t hiSmemBytes;        // dynamic LDS given to k_lis_hi
-  uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for
+  uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for (<= 8)
+  uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
+  uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
+                               //   the region and end within them are not walked into
 };
 
 struct DecPlanHost {
@@ -138,6 +146,18 @@ __host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
 {
   const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 4) + 1u;   // eighths of a byte
   const uint32_t fixed = 4 * 8 + 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
+  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
+  w = w / 1024 * 1024;
+  if (w > (uint32_t)kTabWMax)
+    w = kTabWMax;
+  return w;
+}
+
+// the same for k_lis_hi, which keeps two pointer-jump tables (the list's class and the next one)
+__host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
+{
+  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 8) + 1u;   // eighths of a byte
+  const uint32_t fixed = 4 * 8 + 2 * 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
   w = w / 1024 * 1024;
   if (w > (uint32_t)kTabWMax)

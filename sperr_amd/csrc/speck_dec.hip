@@ -253,6 +253,8 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.hiTicket = 0;
     s.bornCount = 0;
     s.leafCount = 0;
+    for (int g = 0; g < 8; g++)
+      s.hiBornCnt[g] = s.hiLeafCnt[g] = 0;
   }
 }
 
@@ -1196,8 +1198,8 @@ k_lis_l1(DecBuffers b, int p)
   const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[L];
   uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[L];
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
-  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
-  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
   unsigned long long* flags = b.l1Flags + c * b.l0FlagStride;
   const unsigned long long tag = (unsigned long long)(p + 1) << 56;
   const uint64_t maskBits = (uint64_t)b.maskWords * 64;
@@ -1648,8 +1650,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t maskBits = (uint64_t)b.maskWords * 64;
   uint64_t* qbuf[2] = {b.queue + c * b.queueStride, b.queue + c * b.queueStride + b.queueCap * 2};
-  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
-  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
 
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
@@ -2352,6 +2354,15 @@ constexpr uint32_t kHiTagShift = 57;
 constexpr unsigned long long kHiPayloadMask = (1ull << kHiTagShift) - 1ull;
 constexpr int kHiFrames = 8;
 
+// Lanes of ONE wavefront that talk through LDS: the hardware keeps a wavefront's LDS traffic in
+// order, but the compiler reasons per thread (it may forward a lane's own earlier store to its
+// later load and never look at memory), so every hand-over between lanes needs a fence.
+#define HI_WAVE_SYNC()                                        \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+
 template <typename CT>
 __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
 {
@@ -2361,11 +2372,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   extern __shared__ __attribute__((aligned(16))) char tab_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(tab_smem);
-  const uint32_t W = b.hiW, TS = W + 2;
+  const uint32_t W = b.hiW, TS = W + 2;   // positions the tables cover
+  const uint32_t SR = W - b.hiAhead;      // bits of a region (the tables look hiAhead bits further)
   const int Kcap = (int)b.hiK;                     // classes the LDS tables have room for
   const uint32_t kWords = W / 64 + 4;
   uint32_t* hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);   // [W + 130]
-  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop + (W + 130));                  // [Kcap - 1][TS]
+  uint32_t* hop2 = hop + (W + 130);                                             // [W + 130]
+  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop2 + (W + 130));                 // [Kcap - 1][TS]
   uint16_t* Uu = Tt + (size_t)(Kcap - 1) * TS;                                  // [Kcap][TS]
   constexpr int kBlk = kTabWMax / 64 + 4;
   __shared__ uint32_t blkEB[kBlk];
@@ -2374,6 +2387,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   __shared__ uint32_t sh_qn[3];
   __shared__ uint32_t sh_len[kMaxLevels];
   __shared__ LevelClass sh_lc[kMaxLevels];
+  __shared__ uint8_t sh_lslot[kMaxLevels];
+  __shared__ uint64_t sh_serve;   // bit l: the tables in LDS serve level l's lists
+  __shared__ uint32_t sh_segBorn, sh_segLeaf, sh_segBornEnd;   // filled slots of this workgroup's segments
   constexpr int kLdsRoots = 48, kLdsGrids = 288;
   __shared__ Root sh_roots[kLdsRoots];
   __shared__ Grid sh_grids[kLdsGrids];
@@ -2381,22 +2397,33 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   __shared__ uint64_t sh_pos, sh_base;
   __shared__ uint32_t sh_level, sh_depth, sh_e, sh_rem, sh_stop, sh_action, sh_ticket, sh_any;
   __shared__ unsigned long long sh_in[4];
-  __shared__ int sh_tabLevel, sh_tabK, sh_hopTop, sh_tabFrom;   // what the tables in LDS were built for
-  __shared__ uint32_t sh_over, sh_nhb;
+  __shared__ int sh_tabLevel, sh_tabK, sh_hopTop[2], sh_tabFrom, sh_hintK;   // what the tables in LDS were built for
+  __shared__ uint32_t sh_over, sh_nhb, sh_haveState, sh_act2;
+  __shared__ uint64_t sh_t2, sh_t3, sh_tacc[8];
+#define HI_T(k)                                               \
+  if (b.lisStamps && lane == 0) {                             \
+    const uint64_t now_ = __builtin_readcyclecounter();       \
+    sh_tacc[k] += now_ - tmark;                               \
+    tmark = now_;                                             \
+  }
   constexpr int kHiHopBorn = 96;   // births the serial hop found: their slots are taken off the chain
   __shared__ uint64_t sh_hbKid[kHiHopBorn], sh_hbMeta[kHiHopBorn];
 
-  const Tree& t = b.tree;
+  // (the tree's geometry tables are read from LDS: the serial hop derives child sets from them)
+  Tree t = b.tree;
+  t.roots = sh_roots;
+  t.grids = sh_grids;
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u;
   for (uint32_t i = tid; i < t.nroots && i < (uint32_t)kLdsRoots; i += kTabThreads)
-    sh_roots[i] = t.roots[i];
+    sh_roots[i] = b.tree.roots[i];
   for (uint32_t i = tid; i < t.ngrids && i < (uint32_t)kLdsGrids; i += kTabThreads)
-    sh_grids[i] = t.grids[i];
+    sh_grids[i] = b.tree.grids[i];
   const uint32_t cur = s.cur;
   for (uint32_t l = tid; l < t.nlevels; l += kTabThreads) {
     sh_len[l] = s.listLen[cur][l];
     sh_lc[l] = b.levelClass[l];
+    sh_lslot[l] = b.levelSlot[l];
   }
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
@@ -2404,8 +2431,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   const uint64_t maskBits = (uint64_t)b.maskWords * 64;
   uint64_t* qbase = b.queue + c * b.queueStride + (size_t)blockIdx.x * b.queueCap * 4;
   uint64_t* qbuf[2] = {qbase, qbase + b.queueCap * 2};
-  uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
-  uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
   const uint64_t* lisCur = b.lis[cur] + c * b.lisStride;
@@ -2414,6 +2441,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
   const bool l1done = b.l1Level >= 0 && s.l1PlaneP1 == p + 1;
   const uint64_t S0 = l1done ? s.l1End : l0done ? s.l0End : phase0;
+  if (tid == 0) {
+    sh_segBorn = sh_segLeaf = 0;
+    sh_segBornEnd = 0xffffffffu;
+  }
   __syncthreads();
 
   // the next list after level `l` (exclusive) that holds entries and is this kernel's to decode
@@ -2443,7 +2474,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   auto split_len = [&](const LevelClass& C, int j, uint32_t r) -> uint32_t {
     const int ar = C.arity[j];
     if (j == 0) {
-      if (r >= W)
+      // a leaf parent's split is at most 16 bits and the bits past the region's end are loaded:
+      // it is known wherever it starts (r <= W), so the chain never has to walk into one
+      if (r > W)
         return kTInf;
       const uint32_t v = bits32(r);
       uint32_t y = 0, found = 0;
@@ -2466,7 +2499,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           y += bit;
         }
       }
-      return r + y <= W ? y : kTInf;
+      return y;
     }
     const uint16_t* Up = Uu + (size_t)(j - 1) * TS;
     const uint16_t* Tp = Tt + (size_t)(j - 1) * TS;
@@ -2519,36 +2552,41 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           return (uint16_t)1;
         return (uint16_t)(tl == kTInf ? kTInf : (0x8000u | (1u + tl)));
       };
-      for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
-        const uint32_t r2 = r + kTabThreads;
-        const uint32_t t1 = split_len(C, j, r);
-        const uint32_t t2 = r2 <= W + 1 ? split_len(C, j, r2) : kTInf;
-        if (Tj)
-          Tj[r] = (uint16_t)t1;
-        if (r >= 1)
-          Uj[r - 1] = coded(r - 1, t1);
-        if (r2 <= W + 1) {
-          if (Tj)
-            Tj[r2] = (uint16_t)t2;
-          Uj[r2 - 1] = coded(r2 - 1, t2);
+      // four independent positions per thread and pass: their LDS chains overlap
+      for (uint32_t r0 = tid; r0 <= W + 1; r0 += 4 * kTabThreads) {
+        uint32_t tl[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t r = r0 + (uint32_t)q * kTabThreads;
+          tl[q] = r <= W + 1 ? split_len(C, j, r) : kTInf;
         }
-        if (r == W + 1 || r2 == W + 1)
-          Uj[W + 1] = (uint16_t)kTInf;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t r = r0 + (uint32_t)q * kTabThreads;
+          if (r > W + 1)
+            continue;
+          if (Tj)
+            Tj[r] = (uint16_t)tl[q];
+          if (r >= 1)
+            Uj[r - 1] = coded(r - 1, tl[q]);
+          if (r == W + 1)
+            Uj[W + 1] = (uint16_t)kTInf;
+        }
       }
       __syncthreads();
     }
   };
   // all threads; pointer-jump table over the coded items of class `top`, from every position:
   // hop[h] for h = r + wq0 (64-bit blocks are stream words): cnt << 16 | stop << 15 | exit
-  auto build_hop = [&](int top) {
+  auto build_hop = [&](uint32_t* hop, int top) {
     const uint16_t* Utop = Uu + (size_t)top * TS;
-    const uint32_t nblk = ((W - 1 + wq0) >> 6) + 1;
+    const uint32_t nblk = ((SR - 1 + wq0) >> 6) + 1;
     const int32_t rbase = -(int32_t)wq0;
     const uint32_t wave = (uint32_t)tid >> 6;
     for (uint32_t bi = wave; bi < nblk; bi += kTabThreads / 64) {
       const uint32_t h = bi * 64 + lane;
       const int32_t rs = (int32_t)h + rbase;
-      const bool live = rs >= 0 && rs < (int32_t)W;
+      const bool live = rs >= 0 && rs < (int32_t)SR;
       uint32_t v = 0x8000u;
       bool inb = false;
       const uint32_t hEnd = (bi + 1) * 64;
@@ -2560,7 +2598,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         else {
           const uint32_t nr = r + (u & 0x7fffu);
           v = (1u << 16) | nr;
-          inb = nr < W && (uint32_t)((int32_t)nr - rbase) < hEnd;
+          inb = nr < SR && (uint32_t)((int32_t)nr - rbase) < hEnd;
         }
       }
       for (int it = 0; it < 6 && __any(inb); it++) {
@@ -2569,7 +2607,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         if (inb) {
           v = (v & 0xffff0000u) + o;
           const uint32_t np = v & 0x7fffu;
-          inb = !(v & 0x8000u) && np < W && (uint32_t)((int32_t)np - rbase) < hEnd;
+          inb = !(v & 0x8000u) && np < SR && (uint32_t)((int32_t)np - rbase) < hEnd;
         }
       }
       if (live)
@@ -2579,13 +2617,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     for (uint32_t wide = 128; wide <= 256; wide <<= 1) {
       for (uint32_t h = (uint32_t)tid; h < nblk * 64; h += kTabThreads) {
         const int32_t rs = (int32_t)h + rbase;
-        if (rs < 0 || rs >= (int32_t)W)
+        if (rs < 0 || rs >= (int32_t)SR)
           continue;
         const uint32_t v = hop[h];
         if (v & 0x8000u)
           continue;
         const uint32_t er = v & 0x7fffu;
-        if (er >= W)
+        if (er >= SR)
           continue;
         const uint32_t eh = (uint32_t)((int32_t)er - rbase);
         if (eh / wide != h / wide)
@@ -2609,29 +2647,38 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     return true;
   };
 
-  // births and leaf events: slots from the chunk's counters, one atomic per wavefront
-  auto wave_slots = [&](uint32_t* counter, uint32_t n) -> uint32_t {
-    const uint32_t inc = wave_inclusive_scan<uint32_t>(n);
-    const uint32_t tot = __shfl(inc, 63, 64);
-    uint32_t base = 0;
-    if (tot) {
-      if (lane == 63)
-        base = atomicAdd(counter, tot);
-      base = __shfl(base, 63, 64);
-    }
-    return base + inc - n;
+  // births and leaf events of the expansion go to a segment of the chunk's arrays that is this
+  // workgroup's alone (an LDS counter; the shared part, with its global counter, takes what does
+  // not fit)
+  const uint32_t segB0 = (uint32_t)b.bornStride + blockIdx.x * b.bornSeg;
+  const uint32_t segL0 = b.leafCap + blockIdx.x * b.leafSeg;
+  auto born_slots = [&](uint32_t n) -> uint32_t {
+    if (n == 0)
+      return 0;
+    const uint32_t k = atomicAdd(&sh_segBorn, n);
+    if (k + n <= b.bornSeg)
+      return segB0 + k;
+    atomicMin(&sh_segBornEnd, k);        // the segment is full from here on
+    return atomicAdd(&s.bornCount, n);   // (slots at or past bornStride are dropped by write_born)
+  };
+  auto leaf_slot = [&]() -> uint32_t {
+    const uint32_t k = atomicAdd(&sh_segLeaf, 1u);
+    if (k < b.leafSeg)
+      return segL0 + k;
+    const uint32_t g = atomicAdd(&s.leafCount, 1u);
+    return g < b.leafCap ? g : 0xffffffffu;
   };
   auto write_born = [&](uint32_t slot, uint32_t lev, uint64_t abs, uint64_t packed) {
     const uint64_t rel = abs - phase0;
-    if (slot >= b.bornStride)
-      return;
+    if (!(slot < b.bornStride || (slot >= segB0 && slot < segB0 + b.bornSeg)))
+      return;   // (only a damaged stream asks for more slots than there are sets)
     bornPacked[slot] = packed;
     bornPosLev[slot] = ((uint64_t)lev << 48) | rel;
-    atomic_or64(b.mask + c * b.maskStride + (size_t)b.levelSlot[lev] * b.maskWords + (rel >> 6),
+    atomic_or64(b.mask + c * b.maskStride + (size_t)sh_lslot[lev] * b.maskWords + (rel >> 6),
                 1ull << (rel & 63));
   };
   auto born_counts = [&](uint32_t lev, uint64_t abs) -> bool {   // is this birth recorded at all
-    return b.levelSlot[lev] != 0xff && abs - phase0 < maskBits;
+    return sh_lslot[lev] != 0xff && abs - phase0 < maskBits;
   };
 
   // all threads: expand what the queue holds, breadth first (tables of level sh_tabLevel's chain)
@@ -2689,32 +2736,14 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             }
           }
         }
-        // ---- other sets: children from the tables; count the births first
+        // ---- other sets: children from the tables
         const bool isSet = have && cls > 0;
         const uint16_t* Up = Uu + (size_t)(isSet ? cls - 1 : 0) * TS;
         const uint32_t kidLev = isSet ? C.lev[cls - 1] : 0u;
-        uint32_t nborn = 0;
-        if (isSet) {
-          uint32_t y = y0, found = 0;
-          for (int k = 0; k < ar; k++) {
-            const bool coded = found || (k + 1 != ar);
-            if (coded) {
-              const uint32_t u = Up[y];
-              if (!(u & 0x8000u)) {
-                nborn += born_counts(kidLev, a + y) ? 1u : 0u;
-                y += 1;
-                continue;
-              }
-              y += u & 0x7fffu;
-            }
-            found = 1;
-          }
-        }
-        uint32_t slotL = wave_slots(&s.leafCount, isLeaf ? 1u : 0u);
-        uint32_t slotB = wave_slots(&s.bornCount, nborn);
         if (isLeaf) {
           const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
-          if (slotL < b.leafCap)
+          const uint32_t slotL = leaf_slot();
+          if (slotL != 0xffffffffu)
             leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
         }
         if (isSet) {
@@ -2744,7 +2773,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               const uint32_t u = Up[y];
               if (!(u & 0x8000u)) {
                 if (born_counts(kidLev, a + y))
-                  write_born(slotB++, kidLev, a + y, kid);
+                  write_born(born_slots(1u), kidLev, a + y, kid);
                 y += 1;
                 continue;
               }
@@ -2769,8 +2798,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     __syncthreads();
   };
 
-  // actions thread 0 can ask the workgroup for
-  constexpr uint32_t kActDone = 0, kActTables = 1, kActHop = 2, kActList = 3, kActFlushTables = 4;
+  // classes built speculatively beyond the hinted list's own (SPERR_HIP_HI_EXTRA; the chain builds
+  // what is missing when it gets further than that inside one region)
+  const int kSpecExtra = (int)b.hiExtra;
+  // what the chain (wavefront 0) can ask the whole workgroup for
+  constexpr uint32_t kActDone = 0, kActTables = 1, kActHopTab = 2, kActFlushTables = 4;
+  const uint32_t wave = (uint32_t)tid >> 6;
 
   for (;;) {
     // ---- ticket
@@ -2780,13 +2813,20 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       sh_any = 0;
       sh_over = 0;
       sh_nhb = 0;
+      sh_haveState = 0;
+      sh_stop = 0;
+      for (int k = 0; k < 8; k++)
+        sh_tacc[k] = 0;
       sh_qn[0] = sh_qn[1] = sh_qn[2] = 0;
     }
     __syncthreads();
     const uint32_t i = sh_ticket;
     if (i == kL0None || ((size_t)i + 1) * 4 > b.hiFlagStride)
       break;
-    a = S0 + (uint64_t)i * W;
+    // diagnostics (thread 0, when b.lisStamps != nullptr): ticks per part of a region
+    const bool stamps = b.lisStamps != nullptr && tid == 0;
+    uint64_t st0 = stamps ? __builtin_readcyclecounter() : 0, st1 = 0;
+    a = S0 + (uint64_t)i * SR;
     wq0 = (uint32_t)(a & 63);
     {
       const uint64_t w0 = a >> 6;
@@ -2801,6 +2841,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         sh_any = 1;   // (benign race: everybody writes 1)
     }
     if (tid == 0) {
+      // the level the chain was last seen in: its list's class and the next one get pointer-jump
+      // tables; the class tables are built for the longest chain that continues this one upwards
+      // (every level of a power-of-two cube), so that list changes inside the region find theirs
       int hint = __hip_atomic_load(&s.hiHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((hint >> 8) != p + 1)
         hint = -1;
@@ -2808,147 +2851,466 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         hint &= 0xff;
       if (hint < 0 || hint >= (int)t.nlevels || sh_len[hint] == 0)
         hint = next_level((int)t.nlevels);
-      sh_tabLevel = hint;
+      int best = hint;
+      if (hint >= 0) {
+        const LevelClass& A = sh_lc[hint];
+        for (int lv = hint - 1; lv >= 0; lv--) {
+          if (sh_len[lv] == 0 || !sh_lc[lv].regular)
+            continue;
+          const LevelClass& B = sh_lc[lv];
+          if (B.K <= sh_lc[best].K || (int)B.K > Kcap || (int)B.K > (int)A.K + kSpecExtra)
+            continue;
+          bool same = true;
+          for (int j = 0; j < (int)A.K; j++)
+            same = same && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+          const LevelClass& Cb = sh_lc[best];
+          for (int j = 0; j < (int)Cb.K; j++)
+            same = same && Cb.arity[j] == B.arity[j] && Cb.lev[j] == B.lev[j];
+          if (same)
+            best = lv;
+        }
+      }
+      sh_tabLevel = best;
+      sh_hintK = hint >= 0 ? (int)sh_lc[hint].K : 0;
     }
     __syncthreads();
-    // ---- speculative tables for the hinted level (nothing to build over a region of zeros:
-    //      there every item is one insignificant bit, which the chain handles without tables)
+    // ---- speculative tables (nothing to build over a region of zeros: there every item is one
+    //      insignificant bit, which the chain handles without tables)
     const bool zeroRegion = sh_any == 0;
     if (!zeroRegion && sh_tabLevel >= 0) {
       const int lv = sh_tabLevel;
-      const int K = sh_lc[lv].K;
+      const int K = sh_lc[lv].K, Kh = sh_hintK;
       build_tables(lv, 0, K);
-      build_hop(K - 1);
+      build_hop(hop, Kh - 1);
+      if (Kh < K)
+        build_hop(hop2, Kh);
       if (tid == 0) {
         sh_tabK = K;
-        sh_hopTop = K - 1;
+        sh_hopTop[0] = Kh - 1;
+        sh_hopTop[1] = Kh < K ? Kh : -1;
+        uint64_t m = 0;
+        for (uint32_t l = 0; l < t.nlevels; l++)
+          if (sh_len[l] && tables_serve((int)l))
+            m |= 1ull << l;
+        sh_serve = m;
       }
     }
     else if (tid == 0) {
       sh_tabLevel = -1;
       sh_tabK = 0;
-      sh_hopTop = -1;
+      sh_hopTop[0] = sh_hopTop[1] = -1;
+      sh_serve = 0;
     }
+    if (stamps)
+      st1 = __builtin_readcyclecounter();
     __syncthreads();
 
-    // ---- look back (threads 0..3 take one word each)
-    if (tid < 4) {
-      unsigned long long f = 0;
-      if (i > 0) {
-        uint32_t spins = 0;
+    // ---- the chain: wavefront 0 alone (no workgroup barrier on the serial path); it comes back
+    //      when it is through the region or needs all hands (tables it does not have)
+    for (;;) {
+      if (wave == 0) {
+        if (!sh_haveState) {
+          // look back (lanes 0..3 take one word each)
+          if (lane < 4) {
+            unsigned long long f = 0;
+            if (i > 0) {
+              uint32_t spins = 0;
+              for (;;) {
+                f = __hip_atomic_load(flags + (size_t)(i - 1) * 4 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((f >> kHiTagShift) == (unsigned long long)(p + 1))
+                  break;
+                if ((++spins & 15u) == 0 &&
+                    __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+                  f = tag | (1ull << 56);   // the phase is over
+                  break;
+                }
+                if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
+                  s.error = 1;
+                  __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  f = tag | (1ull << 56);
+                  break;
+                }
+              }
+            }
+            sh_in[lane] = f;
+          }
+          HI_WAVE_SYNC();
+          if (lane == 0) {
+            if (b.lisStamps)
+              sh_t2 = __builtin_readcyclecounter();
+            uint32_t stop = 0;
+            if (i == 0) {
+              const int lv = next_level((int)t.nlevels);
+              sh_level = lv < 0 ? 0u : (uint32_t)lv;
+              sh_depth = 1;
+              sh_e = 0;
+              sh_rem = lv < 0 ? 0u : sh_len[lv];
+              sh_pos = S0;
+              sh_base = 0;
+              if (lv < 0)
+                stop = 2;   // nothing for this kernel to decode: the phase ends where it starts
+            }
+            else {
+              const unsigned long long f0 = sh_in[0], f1 = sh_in[1], f2 = sh_in[2], f3 = sh_in[3];
+              if (((f0 | f1 | f2 | f3) >> 56) & 1ull)
+                stop = 1;
+              else {
+                sh_depth = (uint32_t)(f0 >> 52) & 15u;
+                sh_level = (uint32_t)(f0 >> 46) & 63u;
+                sh_pos = S0 + (f0 & ((1ull << 46) - 1ull));
+                sh_e = (uint32_t)(f1 >> 28) & 0xfffffffu;
+                sh_rem = (uint32_t)f1 & 0xfffffffu;
+                sh_base = f3 & kHiPayloadMask;
+                // (a state that does not add up cannot be followed: give up loudly)
+                if (sh_level >= t.nlevels || sh_depth == 0 || sh_depth > (uint32_t)kHiFrames ||
+                    sh_e + sh_rem != sh_len[sh_level] || sh_pos < a ||
+                    sh_depth > (uint32_t)sh_lc[sh_level].K) {
+                  s.error = 1;
+                  __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  stop = 1;
+                  sh_depth = 1;
+                  sh_level = 0;
+                }
+                // rebuild the stack of sets being walked into: frame d holds the children of the set
+                // that frame d - 1 entered (frame 1: of the list entry)
+                const LevelClass& C = sh_lc[sh_level];
+                uint64_t parent = sh_base;
+                for (uint32_t d = 1; d < sh_depth; d++) {
+                  const uint32_t fr = (uint32_t)(f2 >> (5 * (d - 1))) & 31u;
+                  TabCtx& cx = sh_ctx[d];
+                  const int pcls = (int)C.K - (int)d;   // class of the parent set
+                  cx.parent = parent;
+                  cx.cls = (int8_t)(pcls - 1);
+                  cx.nextOrd = (uint8_t)(fr & 15u);
+                  cx.found = (uint8_t)(fr >> 4);
+                  cx.remaining = (uint32_t)C.arity[pcls] - (fr & 15u);
+                  if (d + 1 < sh_depth)
+                    parent = reg_child_packed(t, unpack_node(parent), (fr & 15u) - 1u);
+                }
+              }
+            }
+            sh_stop = stop;
+            sh_haveState = 1;
+          }
+          HI_WAVE_SYNC();
+        }
+        // (LDS traffic of one wavefront is in order: what lane 0 wrote above is what the lanes read)
+        uint64_t tmark = b.lisStamps ? __builtin_readcyclecounter() : 0;
         for (;;) {
-          f = __hip_atomic_load(flags + (size_t)(i - 1) * 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((f >> kHiTagShift) == (unsigned long long)(p + 1))
-            break;
-          if ((++spins & 15u) == 0 &&
-              __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
-            f = tag | (1ull << 56);   // the phase is over
-            break;
-          }
-          if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
-            s.error = 1;
-            __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f = tag | (1ull << 56);
-            break;
-          }
-        }
-      }
-      sh_in[tid] = f;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t stop = 0;
-      if (i == 0) {
-        const int lv = next_level((int)t.nlevels);
-        sh_level = lv < 0 ? 0u : (uint32_t)lv;
-        sh_depth = 1;
-        sh_e = 0;
-        sh_rem = lv < 0 ? 0u : sh_len[lv];
-        sh_pos = S0;
-        sh_base = 0;
-        if (lv < 0) {   // nothing for this kernel to decode: the phase ends where it starts
-          stop = 2;
-        }
-      }
-      else {
-        const unsigned long long f0 = sh_in[0], f1 = sh_in[1], f2 = sh_in[2], f3 = sh_in[3];
-        if (((f0 >> 56) & 1ull) || ((f1 >> 56) & 1ull) || ((f2 >> 56) & 1ull) || ((f3 >> 56) & 1ull))
-          stop = 1;
-        else {
-          sh_depth = (uint32_t)(f0 >> 52) & 15u;
-          sh_level = (uint32_t)(f0 >> 46) & 63u;
-          sh_pos = S0 + (f0 & ((1ull << 46) - 1ull));
-          sh_e = (uint32_t)(f1 >> 28) & 0xfffffffu;
-          sh_rem = (uint32_t)f1 & 0xfffffffu;
-          sh_base = f3 & kHiPayloadMask;
-          // rebuild the stack of sets being walked into: frame d holds the children of the set that
-          // frame d - 1 entered (frame 1: of the list entry)
-          const LevelClass& C = sh_lc[sh_level];
-          uint64_t parent = sh_base;
-          for (uint32_t d = 1; d < sh_depth; d++) {
-            const uint32_t fr = (uint32_t)(f2 >> (5 * (d - 1))) & 31u;
-            TabCtx& cx = sh_ctx[d];
-            const int pcls = (int)C.K - (int)d;   // class of the parent set
-            cx.parent = parent;
-            cx.cls = (int8_t)(pcls - 1);
-            cx.nextOrd = (uint8_t)(fr & 15u);
-            cx.found = (uint8_t)(fr >> 4);
-            cx.remaining = (uint32_t)C.arity[pcls] - (fr & 15u);
-            if (d + 1 < sh_depth)
-              parent = reg_child_packed(t, unpack_node(parent), (fr & 15u) - 1u);
-          }
-        }
-      }
-      sh_stop = stop;
-    }
-    __syncthreads();
-    if (sh_stop == 1)
-      break;
-
-    // ---- the hop through this region: thread 0 decides what the workgroup does next
-    while (sh_stop == 0) {
-      if (tid == 0) {
-        uint32_t act = kActDone;
-        for (;;) {
-          const uint64_t pos = sh_pos;
-          if (pos >= a + W)
-            break;
-          if (sh_depth == 1 && sh_rem == 0) {   // this list is through: the next one
-            const int lv = next_level((int)sh_level);
-            if (lv < 0) {
-              sh_over = 1;
+          if (lane == 0) {
+            uint32_t act = kActDone;
+            for (; sh_stop == 0;) {
+              const uint64_t pos = sh_pos;
+              if (pos >= a + SR)
+                break;
+              if (sh_depth == 1 && sh_rem == 0) {   // this list is through: the next one
+                const int lv = next_level((int)sh_level);
+                if (lv < 0) {
+                  sh_over = 1;
+                  break;
+                }
+                sh_level = (uint32_t)lv;
+                sh_e = 0;
+                sh_rem = sh_len[lv];
+              }
+              if (zeroRegion && sh_depth == 1) {
+                // one '0' per entry, nothing splits: count them off
+                const uint32_t z = min((uint32_t)(a + SR - pos), sh_rem);
+                sh_e += z;
+                sh_rem -= z;
+                sh_pos = pos + z;
+                continue;
+              }
+              const int lv = (int)sh_level;
+              const int K = sh_lc[lv].K;
+              if (!((sh_serve >> lv) & 1ull)) {
+                // chains that agree from the leaf class upwards share tables: classes are only added
+                bool extend = sh_tabLevel >= 0;
+                if (extend) {
+                  const LevelClass& A = sh_lc[sh_tabLevel];
+                  const LevelClass& B = sh_lc[lv];
+                  for (int j = 0; j < sh_tabK && j < (int)B.K; j++)
+                    extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+                }
+                sh_tabFrom = extend ? sh_tabK : 0;
+                act = (!extend && sh_tabLevel >= 0 && sh_qn[0] != 0) ? kActFlushTables : kActTables;
+              }
+              else if (sh_depth > 1)
+                act = 8;    // serial hop
+              else if (sh_hopTop[0] == K - 1 || sh_hopTop[1] == K - 1)
+                act = 9;    // list entries
+              else
+                act = kActHopTab;
               break;
             }
-            sh_level = (uint32_t)lv;
-            sh_e = 0;
-            sh_rem = sh_len[lv];
+            sh_act2 = act;
           }
-          if (zeroRegion && sh_depth == 1) {
-            // one '0' per entry, nothing splits: count them off
-            const uint32_t z = min((uint32_t)(a + W - pos), sh_rem);
-            sh_e += z;
-            sh_rem -= z;
-            sh_pos = pos + z;
+          HI_WAVE_SYNC();
+          HI_T(0);
+          const uint32_t act = sh_act2;
+          if (act < 8) {   // through the region, or all hands needed
+            if (lane == 0) {
+              if (act == kActDone && sh_stop != 1) {
+                // ---- publish the state at the end of the region (or the end of the phase)
+                const bool over = sh_stop == 2 || sh_over != 0;
+                if (over) {
+                  s.hiEnd = sh_pos;
+                  for (int k = 0; k < 4; k++)
+                    __hip_atomic_store(flags + (size_t)i * 4 + k, tag | (1ull << 56), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                else {
+                  unsigned long long fr = 0;
+                  for (uint32_t d = 1; d < sh_depth; d++)
+                    fr |= (unsigned long long)((sh_ctx[d].nextOrd & 15u) | ((sh_ctx[d].found ? 1u : 0u) << 4))
+                          << (5 * (d - 1));
+                  const unsigned long long f0 = tag | ((unsigned long long)sh_depth << 52) |
+                                                ((unsigned long long)sh_level << 46) |
+                                                (unsigned long long)(sh_pos - S0);
+                  const unsigned long long f1 = tag | ((unsigned long long)sh_e << 28) | (unsigned long long)sh_rem;
+                  __hip_atomic_store(flags + (size_t)i * 4 + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(flags + (size_t)i * 4 + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (sh_base & kHiPayloadMask), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&s.hiHint, ((p + 1) << 8) | (int)sh_level, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (over)
+                  sh_stop = 3;   // published the end of the phase
+                if (b.lisStamps)
+                  sh_t3 = __builtin_readcyclecounter();
+              }
+              sh_action = act;
+            }
+            HI_T(1);
+            break;
+          }
+          const LevelClass& C = sh_lc[sh_level];
+          const int K = C.K;
+          if (act == 8) {
+            // The sets being walked into (k_lis_tables, "hop, part S"); an item that leaves the
+            // tables is entered, so the chain always reaches the region's end.  The whole wavefront
+            // runs this with uniform values: the children of a frame are stepped over with one table
+            // look-up each, then lane k does what child k needs (its node, its birth record or
+            // queue entry), all children at once.
+            uint32_t r = (uint32_t)(sh_pos - a);
+            int depth = (int)sh_depth;
+            while (depth > 1 && r < SR) {
+              const TabCtx cx = sh_ctx[depth - 1];
+              if (cx.remaining == 0) {
+                depth--;
+                continue;
+              }
+              const int cls = cx.cls;
+              const uint32_t n = cx.remaining;
+              uint32_t y = r, found = cx.found, done = 0;
+              uint32_t myKind = 0, myPos = 0;   // 1: born at myPos, 2: splits from myPos on (queued), 3: entered
+              bool enter = false;
+              for (uint32_t k = 0; k < n && y < SR; k++) {
+                const bool coded = found || (n - k) > 1;
+                uint32_t kind, at;
+                if (coded) {
+                  const uint32_t u = Uu[(size_t)cls * TS + y];
+                  if (u == 1) {
+                    kind = 1;
+                    at = y;
+                    y += 1;
+                  }
+                  else {
+                    found = 1;
+                    at = y + 1;
+                    if (u == kTInf) {
+                      kind = 3;
+                      y = at;
+                    }
+                    else {
+                      kind = 2;
+                      y += u & 0x7fffu;
+                    }
+                  }
+                }
+                else {
+                  found = 1;
+                  at = y;
+                  const uint32_t len = Tt[(size_t)cls * TS + y];
+                  if (len == kTInf)
+                    kind = 3;
+                  else {
+                    kind = 2;
+                    y += len;
+                  }
+                }
+                if (lane == k) {
+                  myKind = kind;
+                  myPos = at;
+                }
+                done = k + 1;
+                if (kind == 3) {
+                  enter = true;
+                  break;
+                }
+              }
+              if (enter && (cls <= 0 || depth >= kHiFrames)) {   // cannot happen
+                if (lane == 0)
+                  s.error = 1;
+                r = SR;
+                break;
+              }
+              if (myKind) {
+                const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd + lane);
+                if (myKind == 1) {
+                  const uint32_t lev = C.lev[cls];
+                  if (born_counts(lev, a + myPos)) {
+                    const uint32_t slot = atomicAdd(&sh_nhb, 1u);
+                    if (slot < (uint32_t)kHiHopBorn) {
+                      sh_hbKid[slot] = kid;
+                      sh_hbMeta[slot] = ((uint64_t)lev << 48) | (a + myPos);
+                    }
+                    else
+                      write_born(atomicAdd(&s.bornCount, 1u), lev, a + myPos, kid);
+                  }
+                }
+                else if (myKind == 2) {
+                  const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+                  if (slot < b.queueCap) {
+                    qbuf[0][slot * 2] = kid;
+                    qbuf[0][slot * 2 + 1] = ((uint64_t)myPos << 8) | ((uint64_t)cls << 1);
+                  }
+                }
+                else {
+                  TabCtx& nc = sh_ctx[depth];
+                  nc.parent = kid;
+                  nc.remaining = C.arity[cls];
+                  nc.cls = (int8_t)(cls - 1);
+                  nc.found = 0;
+                  nc.nextOrd = 0;
+                }
+              }
+              if (lane == 0) {
+                TabCtx& w = sh_ctx[depth - 1];
+                w.remaining = n - done;
+                w.nextOrd = (uint8_t)(cx.nextOrd + done);
+                w.found = (uint8_t)found;
+              }
+              HI_WAVE_SYNC();
+              r = y;
+              if (enter)
+                depth++;
+            }
+            if (lane == 0) {
+              sh_pos = a + r;
+              sh_depth = (uint32_t)depth;
+              if (sh_nhb > (uint32_t)kHiHopBorn)
+                sh_nhb = kHiHopBorn;
+            }
+            HI_WAVE_SYNC();
+            HI_T(2);
             continue;
           }
-          const int lv = (int)sh_level;
-          if (!tables_serve(lv)) {
-            // chains that agree from the leaf class upwards share tables: classes are only added
-            bool extend = sh_tabLevel >= 0;
-            if (extend) {
-              const LevelClass& A = sh_lc[sh_tabLevel];
-              const LevelClass& B = sh_lc[lv];
-              for (int j = 0; j < sh_tabK && j < (int)B.K; j++)
-                extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+          // ---- act == 9: the list entries from sh_pos on, by pointer jumping
+          const uint32_t* hp = sh_hopTop[0] == K - 1 ? hop : hop2;
+          const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
+          const uint32_t pr = (uint32_t)(sh_pos - a);
+          const uint32_t remaining = sh_rem, e0 = sh_e;
+          const uint32_t lOff = b.levelOff[sh_level];
+          const uint32_t nblk = ((SR - 1 + wq0) >> 6) + 1;
+          const int32_t rbase = -(int32_t)wq0;
+          for (uint32_t k = lane; k < nblk; k += 64)
+            blkEB[k] = 0xffffffffu;
+          HI_WAVE_SYNC();
+          if (lane == 0) {  // P2: walk the blocks
+            uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
+            while (true) {
+              if (r >= SR) {
+                newr = r;
+                break;
+              }
+              const uint32_t h = (uint32_t)((int32_t)r - rbase);
+              const uint32_t v = hp[h];
+              const uint32_t cn = v >> 16;
+              blkEB[h >> 6] = r | (total << 16);
+              if (total + cn >= remaining) {
+                total = remaining;
+                break;
+              }
+              total += cn;
+              if (v & 0x8000u) {
+                stopped = 1;
+                newr = v & 0x7fffu;
+                break;
+              }
+              r = v & 0x7fffu;
             }
-            sh_tabFrom = extend ? sh_tabK : 0;
-            act = (!extend && sh_tabLevel >= 0 && sh_qn[0] != 0) ? kActFlushTables : kActTables;
+            sh_total = total;
+            sh_stopped = stopped;
+            sh_newr = newr;
           }
-          else
-            act = sh_depth > 1 ? kActHop : kActList;
-          break;
+          HI_WAVE_SYNC();
+          HI_T(3);
+          for (uint32_t kb = lane; kb < nblk; kb += 64) {  // P3: the blocks emit their entries
+            const uint32_t eb = blkEB[kb];
+            if (eb == 0xffffffffu)
+              continue;
+            uint32_t r = eb & 0xffffu;
+            const uint32_t base = eb >> 16;
+            const uint32_t cn = hp[(uint32_t)((int32_t)r - rbase)] >> 16;
+            const uint32_t lim_k = min(cn, remaining - base);
+            for (uint32_t k = 0; k < lim_k; k++) {
+              const uint32_t u = Utop[r];
+              if (u & 0x8000u) {
+                const uint32_t ei = lOff + e0 + base + k;   // index into the chunk's list storage
+                const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+                if (slot < b.queueCap) {
+                  qbuf[0][slot * 2] = ei;
+                  qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+                }
+                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              }
+              r += u & 0x7fffu;
+            }
+            if (lim_k > 0 && base + lim_k == remaining)
+              sh_newr = r;  // the list ended in this block (only one block satisfies this)
+          }
+          HI_WAVE_SYNC();
+          HI_T(4);
+          if (lane == 0) {  // P4
+            const uint32_t total = sh_total;
+            uint32_t e = e0 + total;
+            uint32_t rem = remaining - total;
+            uint32_t r = sh_newr;
+            uint32_t depth = 1;
+            if (r == 0xffffffffu || e + rem != sh_len[sh_level]) {   // cannot happen
+              s.error = 1;
+              r = SR;
+              rem = sh_len[sh_level] - min(e, sh_len[sh_level]);
+            }
+            else if (sh_stopped && rem > 0) {
+              // the entry at r leaves the region: walk into it
+              const uint32_t ei = lOff + e;
+              const uint64_t ent = lisCur[ei];
+              TabCtx& nc = sh_ctx[1];
+              nc.parent = ent;
+              nc.remaining = C.arity[K - 1];
+              nc.cls = (int8_t)(K - 2);
+              nc.found = 0;
+              nc.nextOrd = 0;
+              sh_base = ent;
+              atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              e++;
+              rem--;
+              r += 1;  // its '1'
+              depth = 2;
+            }
+            sh_rem = rem;
+            sh_e = e;
+            sh_pos = a + r;
+            sh_depth = depth;
+          }
+          HI_WAVE_SYNC();
+          HI_T(5);
         }
-        sh_action = act;
       }
       __syncthreads();
       uint32_t act = sh_action;
@@ -2962,217 +3324,31 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         const int lv = (int)sh_level;
         const int K = sh_lc[lv].K;
         const int j0 = sh_tabFrom;
-        __syncthreads();
         build_tables(lv, j0, K);
         if (tid == 0) {
           sh_tabLevel = lv;
           sh_tabK = K;
-          sh_hopTop = -1;
+          sh_hopTop[0] = sh_hopTop[1] = -1;
+          uint64_t m = 0;
+          for (uint32_t l = 0; l < t.nlevels; l++)
+            if (sh_len[l] && tables_serve((int)l))
+              m |= 1ull << l;
+          sh_serve = m;
         }
-        __syncthreads();
-        continue;
       }
-      const LevelClass& C = sh_lc[sh_level];
-      const int K = C.K;
-      if (act == kActHop) {
-        // serial part: the sets being walked into (k_lis_tables, "hop, part S"); an item that
-        // leaves the region is entered, so the chain always reaches the region's end
-        if (tid == 0) {
-          uint32_t r = (uint32_t)(sh_pos - a);
-          int depth = (int)sh_depth;
-          uint32_t qn = sh_qn[0];
-          uint32_t nhb = sh_nhb;
-          while (depth > 1 && r < W) {
-            TabCtx& cx = sh_ctx[depth - 1];
-            if (cx.remaining == 0) {
-              depth--;
-              continue;
-            }
-            const bool coded = cx.found || cx.remaining > 1;
-            const int cls = cx.cls;
-            const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd);
-            uint32_t start, len;
-            if (coded) {
-              const uint32_t u = Uu[(size_t)cls * TS + r];
-              if (u == 1) {  // insignificant: born (its slot is taken after the state is published)
-                const uint32_t lev = C.lev[cls];
-                if (born_counts(lev, a + r)) {
-                  if (nhb < (uint32_t)kHiHopBorn) {
-                    sh_hbKid[nhb] = kid;
-                    sh_hbMeta[nhb] = ((uint64_t)lev << 48) | (a + r);
-                    nhb++;
-                  }
-                  else
-                    write_born(atomicAdd(&s.bornCount, 1u), lev, a + r, kid);
-                }
-                cx.remaining--;
-                cx.nextOrd++;
-                r += 1;
-                continue;
-              }
-              start = r + 1;
-              len = u == kTInf ? kTInf : (u & 0x7fffu) - 1u;
-            }
-            else {
-              start = r;
-              len = Tt[(size_t)cls * TS + r];
-            }
-            cx.found = 1;
-            cx.remaining--;
-            cx.nextOrd++;
-            if (len != kTInf) {
-              if (qn < b.queueCap) {
-                qbuf[0][qn * 2] = kid;
-                qbuf[0][qn * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)cls << 1);
-                qn++;
-              }
-              r = start + len;
-            }
-            else {  // leaves the region: walk into it (a leaf parent always fits: the tables of
-              r = start;  // class 0 look at the bits loaded past the region's end)
-              TabCtx& nc = sh_ctx[depth];
-              nc.parent = kid;
-              nc.remaining = C.arity[cls];
-              nc.cls = (int8_t)(cls - 1);
-              nc.found = 0;
-              nc.nextOrd = 0;
-              depth++;
-            }
-          }
-          sh_pos = a + r;
-          sh_depth = (uint32_t)depth;
-          sh_qn[0] = qn;
-          sh_nhb = nhb;
-        }
-        __syncthreads();
-        continue;
-      }
-      // ---- act == kActList: the list entries from sh_pos on, by pointer jumping
-      if (sh_hopTop != K - 1) {
-        build_hop(K - 1);
+      else {   // kActHopTab
+        const int K = sh_lc[sh_level].K;
+        build_hop(hop, K - 1);
         if (tid == 0)
-          sh_hopTop = K - 1;
-        __syncthreads();
+          sh_hopTop[0] = K - 1;
       }
-      const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
-      const uint32_t pr = (uint32_t)(sh_pos - a);
-      const uint32_t remaining = sh_rem, e0 = sh_e;
-      const uint32_t lOff = b.levelOff[sh_level];
-      const uint32_t nblk = ((W - 1 + wq0) >> 6) + 1;
-      const int32_t rbase = -(int32_t)wq0;
-      for (uint32_t k = tid; k < nblk; k += kTabThreads)
-        blkEB[k] = 0xffffffffu;
-      __syncthreads();
-      if (tid == 0) {  // P2: walk the blocks
-        uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
-        while (true) {
-          if (r >= W) {
-            newr = r;
-            break;
-          }
-          const uint32_t h = (uint32_t)((int32_t)r - rbase);
-          const uint32_t v = hop[h];
-          const uint32_t cn = v >> 16;
-          blkEB[h >> 6] = r | (total << 16);
-          if (total + cn >= remaining) {
-            total = remaining;
-            break;
-          }
-          total += cn;
-          if (v & 0x8000u) {
-            stopped = 1;
-            newr = v & 0x7fffu;
-            break;
-          }
-          r = v & 0x7fffu;
-        }
-        sh_total = total;
-        sh_stopped = stopped;
-        sh_newr = newr;
-      }
-      __syncthreads();
-      if ((uint32_t)tid < nblk && blkEB[tid] != 0xffffffffu) {  // P3: the blocks emit their entries
-        const uint32_t eb = blkEB[tid];
-        uint32_t r = eb & 0xffffu;
-        const uint32_t base = eb >> 16;
-        const uint32_t cn = hop[(uint32_t)((int32_t)r - rbase)] >> 16;
-        const uint32_t lim_k = min(cn, remaining - base);
-        for (uint32_t k = 0; k < lim_k; k++) {
-          const uint32_t u = Utop[r];
-          if (u & 0x8000u) {
-            const uint32_t ei = lOff + e0 + base + k;   // index into the chunk's list storage
-            const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
-            if (slot < b.queueCap) {
-              qbuf[0][slot * 2] = ei;
-              qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
-            }
-            atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
-          }
-          r += u & 0x7fffu;
-        }
-        if (lim_k > 0 && base + lim_k == remaining)
-          sh_newr = r;  // the list ended in this block (only one block satisfies this)
-      }
-      __syncthreads();
-      if (tid == 0) {  // P4
-        const uint32_t total = sh_total;
-        uint32_t e = e0 + total;
-        uint32_t rem = remaining - total;
-        uint32_t r = sh_newr;
-        uint32_t depth = 1;
-        if (sh_stopped && rem > 0) {
-          // the entry at r leaves the region: walk into it
-          const uint32_t ei = lOff + e;
-          const uint64_t ent = lisCur[ei];
-          TabCtx& nc = sh_ctx[1];
-          nc.parent = ent;
-          nc.remaining = C.arity[K - 1];
-          nc.cls = (int8_t)(K - 2);
-          nc.found = 0;
-          nc.nextOrd = 0;
-          sh_base = ent;
-          atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
-          e++;
-          rem--;
-          r += 1;  // its '1'
-          depth = 2;
-        }
-        sh_rem = rem;
-        sh_e = e;
-        sh_pos = a + r;
-        sh_depth = depth;
-      }
+      if (tid == 0 && b.lisStamps)
+        atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + (size_t)c * 64) + (act == kActTables ? 5 : 6), 1ull);
       __syncthreads();
     }
-
-    // ---- publish the state at the end of the region (or the end of the phase)
-    if (tid == 0) {
-      const bool over = sh_stop == 2 || sh_over != 0;
-      if (over) {
-        s.hiEnd = sh_pos;
-        __hip_atomic_store(flags + (size_t)i * 4 + 0, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 1, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (1ull << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      else {
-        unsigned long long fr = 0;
-        for (uint32_t d = 1; d < sh_depth; d++)
-          fr |= (unsigned long long)((sh_ctx[d].nextOrd & 15u) | ((sh_ctx[d].found ? 1u : 0u) << 4)) << (5 * (d - 1));
-        const unsigned long long f0 = tag | ((unsigned long long)sh_depth << 52) |
-                                      ((unsigned long long)sh_level << 46) | (unsigned long long)(sh_pos - S0);
-        const unsigned long long f1 = tag | ((unsigned long long)sh_e << 28) | (unsigned long long)sh_rem;
-        __hip_atomic_store(flags + (size_t)i * 4 + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (sh_base & kHiPayloadMask), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&s.hiHint, ((p + 1) << 8) | (int)sh_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      sh_stop = over ? 1u : 0u;
-    }
-    __syncthreads();
+    const bool last = sh_stop == 1 || sh_stop == 3;
+    if (sh_stop == 1)
+      break;
     // ---- off the chain: the births the serial hop found, then the sets that split in this region
     if (sh_nhb) {
       const uint32_t nhb = sh_nhb;
@@ -3187,9 +3363,26 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     }
     if (sh_tabLevel >= 0)
       expand_all();
-    if (sh_stop)
+    if (stamps) {
+      unsigned long long* out = reinterpret_cast<unsigned long long*>(b.lisStamps + (size_t)c * 64);
+      const uint64_t st4 = __builtin_readcyclecounter();
+      atomicAdd(out + 0, 1ull);
+      atomicAdd(out + 1, st1 - st0);          // load + speculative tables
+      atomicAdd(out + 2, sh_t2 - st1);        // look-back wait
+      atomicAdd(out + 3, sh_t3 - sh_t2);      // on the chain
+      atomicAdd(out + 4, st4 - sh_t3);        // expansion
+      atomicAdd(out + 9, zeroRegion ? 1ull : 0ull);
+      for (int k = 0; k < 6; k++)
+        atomicAdd(out + 10 + k, (unsigned long long)sh_tacc[k]);
+    }
+    if (last)
       break;
     __syncthreads();   // LDS is reused by the next region
+  }
+  __syncthreads();
+  if (tid == 0 && blockIdx.x < 8) {
+    s.hiBornCnt[blockIdx.x] = min(min(sh_segBorn, sh_segBornEnd), b.bornSeg);
+    s.hiLeafCnt[blockIdx.x] = min(sh_segLeaf, b.leafSeg);
   }
 }
 
@@ -3325,10 +3518,22 @@ __global__ void __launch_bounds__(kThreads) k_place_scatter(DecBuffers b, int p)
   const DecState& s = b.st[c];
   PLACE_ACTIVE_OR_RETURN(s, p);
   const uint32_t cur = s.cur;   // (k_lis_tables has already made the next lists current)
-  const uint64_t* bornPacked = b.bornPacked + c * b.bornStride;
-  const uint64_t* bornPosLev = b.bornPosLev + c * b.bornStride;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < s.bornCount;
-       k += gridDim.x * blockDim.x) {
+  const uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  const uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
+  // the shared part, then the segments the workgroups of k_lis_hi filled
+  uint32_t segEnd[9];
+  segEnd[0] = s.bornCount;
+  for (int g = 0; g < 8; g++)
+    segEnd[g + 1] = segEnd[g] + (g < (int)b.hiGroupsMax ? s.hiBornCnt[g] : 0u);
+  for (uint32_t kk = blockIdx.x * blockDim.x + threadIdx.x; kk < segEnd[8];
+       kk += gridDim.x * blockDim.x) {
+    uint32_t k = kk;
+    if (kk >= segEnd[0]) {
+      int g = 0;
+      while (kk >= segEnd[g + 1])
+        g++;
+      k = (uint32_t)b.bornStride + (uint32_t)g * b.bornSeg + (kk - segEnd[g]);
+    }
     const uint64_t pl = bornPosLev[k];
     const uint32_t lev = (uint32_t)(pl >> 48);
     const uint64_t rel = pl & ((1ull << 48) - 1);
@@ -3362,13 +3567,24 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
   const DecState& s = b.st[c];
   if (!s.active || (int)p >= s.nbp || s.lastPlane != p)
     return;   // (runs for the plane just decoded, also when that plane ended the stream)
-  const uint32_t n = s.nLeafEv;
+  uint32_t segEnd[9];
+  segEnd[0] = s.nLeafEv;
+  for (int g = 0; g < 8; g++)
+    segEnd[g + 1] = segEnd[g] + (g < (int)b.hiGroupsMax ? s.hiLeafCnt[g] : 0u);
+  const uint32_t n = segEnd[8];
   const Tree& t = b.tree;
   unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
   unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
   unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
   const uint64_t* leafEv = b.leafEv + c * b.leafStride;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+  for (uint32_t kk = blockIdx.x * blockDim.x + threadIdx.x; kk < n; kk += gridDim.x * blockDim.x) {
+    uint32_t k = kk;
+    if (kk >= segEnd[0]) {
+      int g = 0;
+      while (kk >= segEnd[g + 1])
+        g++;
+      k = b.leafCap + (uint32_t)g * b.leafSeg + (kk - segEnd[g]);
+    }
     const uint64_t ev = leafEv[k];
     const uint32_t sigm = (uint32_t)(ev >> 32) & 0xffu, negm = (uint32_t)(ev >> 40) & 0xffu;
     Node nd;
