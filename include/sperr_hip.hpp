@@ -47,6 +47,22 @@ enum class RTNType {  // include/sperr_helper.h:54-64
 
 enum class CompMode : unsigned char { PSNR, PWE, Rate, Unknown };
 
+namespace detail {
+// Width in bytes of the integer coefficients of a chunk stream (SPECK_FLT::integer_len,
+// /root/reference/src/SPECK_FLT.cpp:193-213).  The reference picks it from the largest quantised
+// coefficient when it encodes (:324-337: <= 255, <= 65535, <= 2^32 - 1) and from the number of
+// bit planes in the SPECK header when it decodes (:64-72: <= 8, <= 16, <= 32) -- one and the same
+// rule, so the stream's header byte answers for both.  A stream without coefficients (constant
+// field) leaves the default, uint64 (include/SPECK_FLT.h:68).
+inline size_t integer_len_of(const vec8_type& stream)
+{
+  if (stream.size() < 18 || (stream[0] & 0x01))
+    return sizeof(uint64_t);
+  const unsigned nbp = stream[17];
+  return nbp <= 8 ? 1 : nbp <= 16 ? 2 : nbp <= 32 ? 4 : 8;
+}
+}  // namespace detail
+
 // ---- src/SPERR3D_OMP_C.cpp:12-161 --------------------------------------------------------------
 class SPERR3D_OMP_C {
  public:
@@ -172,6 +188,7 @@ class SPECK3D_FLT {
   void set_bitrate(double bpp) { m_mode = CompMode::Rate; m_quality = bpp; }
   void set_psnr(double v) { m_mode = CompMode::PSNR; m_quality = v; }
   void set_tolerance(double v) { m_mode = CompMode::PWE; m_quality = v; }
+  auto integer_len() const -> size_t { return detail::integer_len_of(m_stream); }
 
   auto compress() -> RTNType
   {
@@ -260,6 +277,7 @@ class SPECK2D_FLT {
   void set_bitrate(double bpp) { m_mode = CompMode::Rate; m_quality = bpp; }
   void set_psnr(double v) { m_mode = CompMode::PSNR; m_quality = v; }
   void set_tolerance(double v) { m_mode = CompMode::PWE; m_quality = v; }
+  auto integer_len() const -> size_t { return detail::integer_len_of(m_stream); }
 
   auto compress() -> RTNType
   {

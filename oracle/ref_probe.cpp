@@ -265,4 +265,27 @@ int refp_decomp_2d_multi_res(const void* src, size_t len, size_t dimx, size_t di
   return 0;
 }
 
+// SPECK3D_FLT::integer_len() of the reference's own encoder and decoder for one chunk in PSNR mode
+// (what test_scripts/speck3d_flt_unit_test.cpp:63-147 asserts): widths[0] = encoder, [1] = decoder.
+int refp_integer_len_psnr(const double* vals, size_t dx, size_t dy, size_t dz, double psnr,
+                          size_t widths[2])
+{
+  sperr::SPECK3D_FLT enc;
+  enc.set_dims({dx, dy, dz});
+  enc.set_psnr(psnr);
+  enc.copy_data(vals, dx * dy * dz);
+  if (enc.compress() != sperr::RTNType::Good)
+    return 1;
+  std::vector<uint8_t> stream;
+  enc.append_encoded_bitstream(stream);
+  sperr::SPECK3D_FLT dec;
+  dec.set_dims({dx, dy, dz});
+  if (dec.use_bitstream(stream.data(), stream.size()) != sperr::RTNType::Good ||
+      dec.decompress() != sperr::RTNType::Good)
+    return 1;
+  widths[0] = enc.integer_len();
+  widths[1] = dec.integer_len();
+  return 0;
+}
+
 }  // extern "C"

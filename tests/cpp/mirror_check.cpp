@@ -131,6 +131,38 @@ int main(int argc, char** argv)
     for (size_t l = 0; l < h.size(); l++)
       CHECK(dump(out + "speck2d_flt_level" + std::to_string(l), h[l].data(), h[l].size() * 8));
   }
+  // integer_len() of both chunk classes (test_scripts/speck3d_flt_unit_test.cpp:63-147): the PSNR
+  // targets walk through the four widths; tests/test_cpp_mirrors.py compares with the oracle's streams
+  {
+    std::string widths;
+    const sperr::dims_type cd = chunks;
+    std::vector<double> corner(cd[0] * cd[1] * cd[2]);
+    for (size_t z = 0; z < cd[2]; z++)
+      for (size_t y = 0; y < cd[1]; y++)
+        for (size_t x = 0; x < cd[0]; x++)
+          corner[(z * cd[1] + y) * cd[0] + x] = vol[(z * dims[1] + y) * dims[0] + x];
+    for (double psnr : {20.0, 60.0, 120.0, 250.0}) {
+      sperr::SPECK3D_FLT enc, dec;
+      enc.set_dims(cd);
+      enc.set_psnr(psnr);
+      enc.copy_data(corner.data(), corner.size());
+      CHECK(enc.compress() == sperr::RTNType::Good);
+      sperr::vec8_type stream;
+      enc.append_encoded_bitstream(stream);
+      dec.set_dims(cd);
+      CHECK(dec.use_bitstream(stream.data(), stream.size()) == sperr::RTNType::Good);
+      CHECK(dec.decompress() == sperr::RTNType::Good);
+      CHECK(enc.integer_len() == dec.integer_len());
+      widths += std::to_string(enc.integer_len()) + " ";
+      sperr::SPECK2D_FLT e2;
+      e2.set_dims({dims[0], dims[1], 1});
+      e2.set_psnr(psnr);
+      e2.copy_data(vol.data(), dims[0] * dims[1]);
+      CHECK(e2.compress() == sperr::RTNType::Good);
+      widths += std::to_string(e2.integer_len()) + " ";
+    }
+    CHECK(dump(out + "integer_len", widths.data(), widths.size()));
+  }
   std::printf("mirrors ok\n");
   return 0;
 }

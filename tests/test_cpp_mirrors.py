@@ -62,3 +62,17 @@ def test_mirror_classes_match_the_oracle(oracle, tmp_path):
     assert len(slevels) == 3
     for l, lv in enumerate(slevels):
         assert np.array_equal(bits(data(f"speck2d_flt_level{l}")), bits(lv.ravel()))
+
+    # integer_len(): the oracle's streams carry the number of bit planes (byte 17 of a chunk stream),
+    # from which the reference picks uint8 / 16 / 32 / 64 (src/SPECK_FLT.cpp:64-72,324-337)
+    def width(chunk_stream):
+        nbp = chunk_stream[17]
+        return 1 if nbp <= 8 else 2 if nbp <= 16 else 4 if nbp <= 32 else 8
+
+    want = []
+    for psnr in (20.0, 60.0, 120.0, 250.0):
+        want.append(width(oracle.comp_3d(corner, (32, 32, 32), 2, psnr)[18:]))
+        want.append(width(oracle.comp_2d(img, 2, psnr, False)))
+    got = [int(x) for x in (tmp_path / "integer_len").read_text().split()]
+    assert got == want
+    assert set(want) >= {1, 2, 4, 8}, want   # the targets do walk through all four widths

@@ -187,3 +187,22 @@ def test_progressive_truncation_bit_exact(oracle, ref, chunks, pct):
     want = ref.trunc_3d(full, pct)
     assert oracle.trunc_3d(full, pct) == want
     assert np.array_equal(bits(oracle.decomp_3d(want, True)), bits(ref.decomp_3d(want, True)))
+
+
+def test_integer_len_rule_matches_the_reference(oracle, ref):
+    """SPECK_FLT::integer_len() (src/SPECK_FLT.cpp:193-213) of the reference's encoder and decoder
+    against the rule include/sperr_hip.hpp derives from the oracle's stream: byte 17 of a chunk
+    stream, the number of bit planes, <= 8 / 16 / 32 / more -> 1 / 2 / 4 / 8 bytes."""
+    import ctypes as C
+    corner = turbulence((32, 32, 32)).astype(np.float64)
+    seen = set()
+    for psnr in (20.0, 60.0, 120.0, 250.0):
+        w = (C.c_size_t * 2)()
+        ref.probe.refp_integer_len_psnr.restype = C.c_int
+        ref.probe.refp_integer_len_psnr.argtypes = [C.c_void_p] + [C.c_size_t] * 3 + [C.c_double, C.c_void_p]
+        assert ref.probe.refp_integer_len_psnr(corner.ctypes.data, 32, 32, 32, psnr, w) == 0
+        nbp = oracle.comp_3d(corner, (32, 32, 32), 2, psnr)[18 + 17]
+        rule = 1 if nbp <= 8 else 2 if nbp <= 16 else 4 if nbp <= 32 else 8
+        assert w[0] == w[1] == rule
+        seen.add(rule)
+    assert seen == {1, 2, 4, 8}
