@@ -1845,12 +1845,12 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       }
       // The LIS phase of a plane keeps one latency-bound workgroup per chunk busy; sub-batches on
       // separate streams let the bandwidth-bound kernels of one sub-batch run beside the LIS
-      // kernels of another.  Measured on MI355X, 64 chunks of 256^3: 1 stream 130 ms per
-      // compress + decompress step, 2 streams 124 ms, 3 streams 122 ms, 4 streams 154 ms (the
-      // GPU-wide list kernels of four sub-batches get in each other's way).
+      // kernels of another.  Measured on MI355X, 64 chunks of 256^3, decompression only: 1 stream
+      // 60.4 ms, 2 streams 58.0 ms, 3 streams 57.9 ms (round 1, with one workgroup per chunk in the
+      // LIS phase of the larger sets: 1 stream 74 ms, 3 streams 65 ms).
       // SPERR_HIP_SUBSTREAMS=n overrides the choice (1 = a single stream).
       static const int subEnv = getenv("SPERR_HIP_SUBSTREAMS") ? atoi(getenv("SPERR_HIP_SUBSTREAMS")) : 0;
-      uint32_t nsub = nbAll >= 48 ? 3u : nbAll >= 32 ? 2u : 1u;
+      uint32_t nsub = nbAll >= 32 ? 2u : 1u;
       if (subEnv > 0)
         nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
       if (anyOutlier || nbAll < 2 * nsub || deferG)

@@ -34,7 +34,7 @@ struct DecState {
   uint32_t hiTicket;             // next region of the pass to hand out
   int32_t hiPlaneP1;             // 1 + the plane whose pass has ended (0: none)
   int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
-  uint32_t hiPad;
+  uint32_t hiCompactDone;        // workgroups of k_lis_compact that have finished (the last one ends the phase)
   uint64_t hiEnd;                // first bit after the phase
   uint32_t hiBornCnt[8];         // births / leaf events in the workgroups' own segments
   uint32_t hiLeafCnt[8];

@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.l0Ticket = 0;
     s.l1Ticket = 0;
     s.hiTicket = 0;
+    s.hiCompactDone = 0;
     s.bornCount = 0;
     s.leafCount = 0;
     for (int g = 0; g < 8; g++)
@@ -3393,12 +3394,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
   const uint32_t c = blockIdx.y, l = blockIdx.x;
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
-  if ((b.l0Level >= 0 && s.l0PlaneP1 == p + 1 && (int)l == b.l0Level) ||
-      (b.l1Level >= 0 && s.l1PlaneP1 == p + 1 && (int)l == b.l1Level))
-    return;   // (those kernels kept their own survivors)
+  // (the GPU-wide kernels of the two smallest set sizes kept their own survivors)
+  const bool skip = (b.l0Level >= 0 && s.l0PlaneP1 == p + 1 && (int)l == b.l0Level) ||
+                    (b.l1Level >= 0 && s.l1PlaneP1 == p + 1 && (int)l == b.l1Level);
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
   const uint32_t cur = s.cur, nx = cur ^ 1u;
-  const uint32_t n = s.listLen[cur][l];
+  const uint32_t n = skip ? 0u : s.listLen[cur][l];
   const uint32_t lOff = b.levelOff[l];
   const uint64_t* list = b.lis[cur] + c * b.lisStride;
   uint64_t* keep = b.lis[nx] + c * b.lisStride + lOff;
@@ -3443,29 +3444,26 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
       g = upto;
     }
   }
-  if (tid == 0)
-    s.listLen[nx][l] = carry;
-}
-
-// the chunk's state after the phase (what k_lis_tables' last lines do)
-__global__ void k_lis_hi_end(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= b.nchunks)
-    return;
-  DecState& s = b.st[c];
-  DEC_ACTIVE_OR_RETURN(s, p);
-  const uint64_t phase0 = s.lipStart + s.lipBits;
-  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
-  const uint64_t end = s.hiEnd;
-  s.cur ^= 1u;
-  s.pos = end;
-  s.nLeafEv = min(s.leafCount, b.leafCap);
-  s.bornCount = min(s.bornCount, (uint32_t)b.bornStride);
-  s.lisPhaseBits = min(end - phase0, maskBits);
-  s.lastPlane = p;
-  if (end >= s.avail)  // SPECK_INT.cpp:200-201
-    s.done = 1;
+  if (tid == 0) {
+    if (!skip)
+      s.listLen[nx][l] = carry;
+    // the workgroup that finishes last sets the chunk's state after the phase (what k_lis_tables'
+    // last lines do): nobody reads the current lists any more
+    __threadfence();
+    if (atomicAdd(&s.hiCompactDone, 1u) == gridDim.x - 1) {
+      const uint64_t phase0 = s.lipStart + s.lipBits;
+      const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+      const uint64_t end = s.hiEnd;
+      s.cur = nx;
+      s.pos = end;
+      s.nLeafEv = min(s.leafCount, b.leafCap);
+      s.bornCount = min(s.bornCount, (uint32_t)b.bornStride);
+      s.lisPhaseBits = min(end - phase0, maskBits);
+      s.lastPlane = p;
+      if (end >= s.avail)  // SPECK_INT.cpp:200-201
+        s.done = 1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3544,29 +3542,25 @@ __global__ void __launch_bounds__(kThreads) k_place_scatter(DecBuffers b, int p)
   }
 }
 
-// the lists grow by what was placed; the masks are left clean for the next plane
-__global__ void __launch_bounds__(kThreads) k_place_finish(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.y;
-  DecState& s = b.st[c];
-  PLACE_ACTIVE_OR_RETURN(s, p);
-  const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
-  for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < pw; wi += gridDim.x * blockDim.x)
-    for (uint32_t slot = 0; slot < b.nSlots; slot++)
-      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (uint32_t slot = 0; slot < b.nSlots; slot++)
-      s.listLen[s.cur][b.slotLevel[slot]] += s.slotBorn[slot];
-}
-
 // Turns the leaf events of one plane into pixel-mask updates: born bits for all children, sigNew
 // and sign bits for the significant ones.  One thread per event, atomics merged per mask word.
 __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
-  const DecState& s = b.st[c];
+  DecState& s = b.st[c];
   if (!s.active || (int)p >= s.nbp || s.lastPlane != p)
     return;   // (runs for the plane just decoded, also when that plane ended the stream)
+  // the end of the placement (after k_place_scatter): the lists grow by what was placed, the birth
+  // masks are left clean for the next plane (after the stream has ended nobody reads the lists)
+  if (!s.done && b.nSlots) {
+    const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
+    for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < pw; wi += gridDim.x * blockDim.x)
+      for (uint32_t slot = 0; slot < b.nSlots; slot++)
+        b.mask[c * b.maskStride + (size_t)slot * b.maskWords + wi] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (uint32_t slot = 0; slot < b.nSlots; slot++)
+        s.listLen[s.cur][b.slotLevel[slot]] += s.slotBorn[slot];
+  }
   uint32_t segEnd[9];
   segEnd[0] = s.nLeafEv;
   for (int g = 0; g < 8; g++)
@@ -3834,14 +3828,12 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         if (plan.hi) {
           LAUNCH_K(k_lis_hi<uint64_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
           LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_lis_hi_end, perChunk, dim3(64), 0, stream, b, p);
         }
         else
           LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_finish, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
         }
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
@@ -3861,14 +3853,12 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         if (plan.hi) {
           LAUNCH_K(k_lis_hi<uint32_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
           LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_lis_hi_end, perChunk, dim3(64), 0, stream, b, p);
         }
         else
           LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_finish, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
         }
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
