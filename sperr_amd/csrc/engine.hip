@@ -858,6 +858,48 @@ bool fuse_xy(const ShapePlan& P)
   return lift_xy_applicable(P.dims);
 }
 
+// LiftFuse of pass k (xform.h): the samples of its region that no LATER pass of the forward order
+// touches.  The later passes' regions are boxes at the origin; when one of them contains all the
+// others (dyadic plans: the next pass; wavelet-packet plans: the full-size x pass for every z pass)
+// the samples are those outside it.  Returns 0 when there are none, 1 when there are (inner = that
+// box), -1 when the later regions are not nested (no plan of build_plan is like that).
+int pass_fuse(const ShapePlan& P, size_t k, uint32_t inner[3])
+{
+  const LiftPass& ps = P.fwd[k];
+  inner[0] = inner[1] = inner[2] = 0;
+  for (size_t j = k + 1; j < P.fwd.size(); j++)
+    for (int a = 0; a < 3; a++)
+      inner[a] = std::max(inner[a], P.fwd[j].region[a]);
+  bool nested = k + 1 >= P.fwd.size();
+  for (size_t j = k + 1; j < P.fwd.size(); j++)
+    nested = nested || (P.fwd[j].region[0] == inner[0] && P.fwd[j].region[1] == inner[1] &&
+                        P.fwd[j].region[2] == inner[2]);
+  if (!nested)
+    return -1;
+  bool covers = true;
+  for (int a = 0; a < 3; a++)
+    covers = covers && inner[a] >= ps.region[a];
+  return covers ? 0 : 1;
+}
+
+// Can the lifting passes collect the largest coefficient / dequantise on the way?  Not when the
+// fused x-y kernel of the finest level would have to (slices: their next pass is a coarser level).
+bool plan_fusable(const ShapePlan& P)
+{
+  if (P.fwd.empty())
+    return false;
+  static const bool on = !(getenv("SPERR_HIP_LIFT_FUSE") && atoi(getenv("SPERR_HIP_LIFT_FUSE")) == 0);
+  if (!on)
+    return false;
+  uint32_t inner[3];
+  for (size_t k = 0; k < P.fwd.size(); k++)
+    if (pass_fuse(P, k, inner) < 0)
+      return false;
+  if (fuse_xy(P) && (pass_fuse(P, 0, inner) != 0 || pass_fuse(P, 1, inner) != 0))
+    return false;
+  return true;
+}
+
 // PSNR mode (src/SPECK_FLT.cpp:268-279,431-435): per chunk q = 2 sqrt(3 t), t = range^2 10^(-psnr/10),
 // divided by 2^(1/4) until the estimated quantisation error is at most t.  The libm calls run on
 // the host (the same libm the reference uses), the error estimate on the device with the
@@ -1332,13 +1374,19 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
           return -1;
         k0 = 2;
       }
+      // the passes after which samples have their final value also collect the largest magnitude
+      // (src/SPECK_FLT.cpp:282-301): no pass over the coefficients of its own
+      const bool fuseMax = plan_fusable(*P);
       for (size_t k = k0; k < P->fwd.size(); k++) {
         const LiftPass& ps = P->fwd[k];
+        LiftFuse lf;
+        if (fuseMax && pass_fuse(*P, k, lf.inner) > 0)
+          lf.mode = 1;
         if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
-                        k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom))
+                        k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom, &lf))
           return -1;
       }
-      if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst))
+      if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst, fuseMax))
         return -1;
       if (mode == 2 && psnr_q_search(st, *P, bb, nb, quality))
         return -1;
@@ -1919,6 +1967,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
+        // the inverse passes dequantise on the way (not for the resolution hierarchy, whose coarsest
+        // level is read before any pass has run)
+        const bool fuseDq = plan_fusable(*P) && !mr && !slice;
         // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_tables
         static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
         if (!gpuWide)
@@ -1972,7 +2023,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           if (launch_speck_decode(ss, dw, ph, d_src, bb.chunkOff, bb.chunkLen, wide != 0,
                                   wide ? maxWide : maxNarrow))
             return -1;
-          if (launch_inv_quantize(ss, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
+          // (32-bit coefficients are dequantised by the inverse passes as they load them, LiftFuse)
+          if ((wide || !fuseDq) &&
+              launch_inv_quantize(ss, wide != 0, dw.coef, dw.coefStride, d.sign, d.signStride, nb,
                                   P->N, bb.vals, bb.valsStride, d.cst, d.sigNew, d.sigOld,
                                   d.maskPixStride, d.st))
             return -1;
@@ -1999,9 +2052,21 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           const LiftPass& ps = P->fwd[k];
           if (mr && mr->nlev && k % perLevel == perLevel - 1 && sub_volume(k))
             return -1;
+          LiftFuse lf;
+          if (fuseDq && pass_fuse(*P, k, lf.inner) > 0) {
+            lf.mode = 2;
+            lf.coef = bb.coef32;
+            lf.coefStride = d.coefStride;
+            lf.sign = d.sign;
+            lf.signStride = d.signStride;
+            lf.sigNew = d.sigNew;
+            lf.sigOld = d.sigOld;
+            lf.maskStride = d.maskPixStride;
+            lf.dst = d.st;
+          }
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
                           (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
-                          d_dst, vd, bb.geom))
+                          d_dst, vd, bb.geom, &lf))
             return -1;
         }
         if (fxy && mr && mr->nlev && slice && sub_volume(1))   // the finest level of a slice is the fused pair

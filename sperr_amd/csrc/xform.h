@@ -25,12 +25,35 @@ int launch_scatter(hipStream_t stream, T* vol, VolDesc vd, const ChunkGeom* geom
                    uint32_t nchunks, const uint32_t cdims[3], const double* vals,
                    size_t valsStride, const CoderState* st);
 
+// What a lifting pass can do on the way for the samples of its region that no LATER pass (in
+// forward order) touches, i.e. those outside `inner`, the region of the next pass:
+//   forward (mode 1)  they have their final value: the largest magnitude goes to
+//                     CoderState::maxabs (src/SPECK_FLT.cpp:282-301), no pass of its own;
+//   inverse (mode 2)  they come straight from the decoder: the pass dequantises them from the
+//                     integer coefficients while it loads (src/SPECK_FLT.cpp:373-399, with the
+//                     decoder's masks completing the ones never refined), so no fp64 copy of the
+//                     whole chunk is written and read again.  Chunks with 64-bit coefficients keep
+//                     theirs in the fp64 buffer (converted in place beforehand) and are read as ever.
+struct DecState;
+struct LiftFuse {
+  int mode = 0;
+  uint32_t inner[3] = {0, 0, 0};
+  const uint32_t* coef = nullptr;
+  size_t coefStride = 0;
+  const uint64_t* sign = nullptr;
+  size_t signStride = 0;
+  const uint64_t* sigNew = nullptr;
+  const uint64_t* sigOld = nullptr;
+  size_t maskStride = 0;
+  const DecState* dst = nullptr;
+};
+
 // io: 0 in place; 1 / 2: the pass also reads (forward) or writes (inverse) the float / double
 // volume through the chunk map -- only valid for a pass whose region is the whole chunk
 int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
                 uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
-                const CoderState* st, int io = 0, void* volume = nullptr, VolDesc vd = VolDesc{},
-                const ChunkGeom* geom = nullptr);
+                CoderState* st, int io = 0, void* volume = nullptr, VolDesc vd = VolDesc{},
+                const ChunkGeom* geom = nullptr, const LiftFuse* fuse = nullptr);
 
 // The x and y passes of the finest level fused with the volume access (forward: volume -> vals,
 // inverse: vals -> volume); only for chunks whose first two passes are the full-size x and y ones.
@@ -39,8 +62,9 @@ int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsSt
                    uint32_t nchunks, const uint32_t cdims[3], const CoderState* st, int io,
                    void* volume, VolDesc vd, const ChunkGeom* geom);
 
+// have_max: CoderState::maxabs is already there (the lifting passes collected it)
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
-                    uint32_t n, CoderState* st);
+                    uint32_t n, CoderState* st, bool have_max = false);
 int launch_make_q_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);
 int launch_mark_wide(hipStream_t stream, uint32_t nchunks, CoderState* st);
 
@@ -70,7 +94,6 @@ int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t va
 
 // sigNew / sigOld / dst: the decoder's significance masks and state, to complete the coefficients
 // that were never refined (then launch_speck_decode is told to skip its own finishing pass)
-struct DecState;
 int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t coefStride,
                         const uint64_t* sign, size_t signStride, uint32_t nchunks, uint32_t n,
                         double* vals, size_t valsStride, const CoderState* st,

@@ -229,8 +229,8 @@ constexpr int kLoadBatch = 8;
 template <bool FORWARD, int IO>
 __global__ void __launch_bounds__(kThreads)
 k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis, uint32_t rx,
-            uint32_t ry, uint32_t rz, int NL, LiftConsts K, const CoderState* st, void* volume,
-            VolDesc vd, const ChunkGeom* geom)
+            uint32_t ry, uint32_t rz, int NL, LiftConsts K, CoderState* st, void* volume,
+            VolDesc vd, const ChunkGeom* geom, LiftFuse F)
 {
   const uint32_t c = blockIdx.y;
   const bool is_const = st[c].is_const != 0;
@@ -271,9 +271,40 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
   // ---- load: a thread issues kLoadBatch loads before it uses the first value (one at a time
   // leaves the pass waiting on HBM latency) ----
   using LT = typename std::conditional<(IO != 0 && FORWARD), VT, double>::type;
+  // (l, p) of this tile as chunk coordinates, and whether a later pass of the forward order
+  // touches the sample (LiftFuse)
+  auto outside_inner = [&](uint32_t l, uint32_t p, size_t& idx) -> bool {
+    uint32_t xyz[3];
+    xyz[axis] = p;
+    xyz[ua] = u0 + l;
+    xyz[wa] = tw;
+    idx = ((size_t)xyz[2] * cy + xyz[1]) * cx + xyz[0];
+    return !(xyz[0] < F.inner[0] && xyz[1] < F.inner[1] && xyz[2] < F.inner[2]);
+  };
+  const bool dequant = !FORWARD && F.mode == 2 && !st[c].wide;
+  const double fq = dequant ? st[c].q : 0.0;
+  // value of a coefficient that became significant on the last decoded plane / the one before and
+  // was never refined (k_inv_quantize)
+  const uint32_t lastPl = (dequant && F.dst) ? (uint32_t)F.dst[c].lastPlane : 0u;
+  const uint32_t initNew = (1u << lastPl) + (1u << lastPl) - (1u << lastPl) / 2 - 1;
+  const uint32_t initOld = lastPl < 31 ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
   auto fetch = [&](uint32_t l, uint32_t p) -> LT {
     if (IO != 0 && FORWARD)
       return (LT)vol[vbase + l * vsu + p * vsl];
+    if (!FORWARD && dequant) {
+      size_t idx;
+      if (outside_inner(l, p, idx)) {   // k_inv_quantize for this one sample; the loads are independent
+        const uint32_t w = (uint32_t)(idx >> 6), sh = (uint32_t)(idx & 63);
+        uint32_t v = F.coef[c * F.coefStride + idx];
+        const uint64_t sgw = F.sign[c * F.signStride + w];
+        const uint64_t mnw = F.sigNew ? F.sigNew[c * F.maskStride + w] : 0ull;
+        const uint64_t mow = F.sigNew ? F.sigOld[c * F.maskStride + w] : 0ull;
+        const uint32_t mn = (uint32_t)(mnw >> sh) & 1u, mo = (uint32_t)(mow >> sh) & 1u;
+        const uint32_t fill = mn ? initNew : (mo ? initOld : 0u);
+        v = v ? v : fill;
+        return (LT)(fq * (double)v * (((sgw >> sh) & 1ull) ? 1.0 : -1.0));
+      }
+    }
     return (LT)tile[l * su + p * sl];
   };
   auto deposit = [&](uint32_t l, uint32_t p, LT v) {
@@ -375,6 +406,8 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
   }
 
   // ---- store ----
+  const bool wantMax = FORWARD && F.mode == 1 && !is_const;
+  double vmax = 0.0;
   if (axis == 0) {
     const uint32_t nseg = (len + 63) / 64;
     for (uint32_t sg = tid / 64; sg < nl * nseg; sg += kThreads / 64) {
@@ -384,8 +417,13 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
       const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
       if (IO != 0 && !FORWARD)
         vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
-      else
-        tile[l * su + p] = sm[src * NLP + l];
+      else {
+        const double v = sm[src * NLP + l];
+        tile[l * su + p] = v;
+        size_t idx;
+        if (wantMax && outside_inner(l, p, idx))
+          vmax = fmax(vmax, fabs(v));
+      }
     }
   }
   else {
@@ -395,9 +433,21 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
         const uint32_t src = FORWARD ? p : ((p & 1) ? even_len + (p >> 1) : (p >> 1));
         if (IO != 0 && !FORWARD)
           vol[vbase + l * vsu + p * vsl] = (VT)(is_const ? mean : sm[src * NLP + l] + mean);
-        else
-          tile[l * su + p * sl] = sm[src * NLP + l];
+        else {
+          const double v = sm[src * NLP + l];
+          tile[l * su + p * sl] = v;
+          size_t idx;
+          if (wantMax && outside_inner(l, p, idx))
+            vmax = fmax(vmax, fabs(v));
+        }
       }
+  }
+  if (FORWARD && F.mode == 1) {   // (uniform: every wavefront reduces, one atomic each)
+    for (int d = 32; d > 0; d >>= 1)
+      vmax = fmax(vmax, __shfl_xor(vmax, d, 64));
+    if ((tid & 63) == 0 && vmax > 0.0)  // non-negative doubles order like their bit patterns
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].maxabs),
+                (unsigned long long)__double_as_longlong(vmax));
   }
 }
 
@@ -908,8 +958,10 @@ static int pick_nl(uint32_t len, int axis, size_t* smem)
 
 int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStride,
                 uint32_t nchunks, const uint32_t cdims[3], int axis, const uint32_t region[3],
-                const CoderState* st, int io, void* volume, VolDesc vd, const ChunkGeom* geom)
+                CoderState* st, int io, void* volume, VolDesc vd, const ChunkGeom* geom,
+                const LiftFuse* fuse)
 {
+  const LiftFuse F = fuse ? *fuse : LiftFuse{};
   {
     const void* fns[6] = {reinterpret_cast<const void*>(&k_lift_axis<true, 0>),
                           reinterpret_cast<const void*>(&k_lift_axis<true, 1>),
@@ -934,7 +986,7 @@ int launch_lift(hipStream_t stream, bool forward, double* vals, size_t valsStrid
   const uint32_t ntu = (region[ua] + NL - 1) / NL;
   dim3 grid(ntu * region[wa], nchunks);
   const LiftConsts K = lift_consts();
-#define LIFT_ARGS vals, valsStride, cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st, volume, vd, geom
+#define LIFT_ARGS vals, valsStride, cdims[0], cdims[1], axis, region[0], region[1], region[2], NL, K, st, volume, vd, geom, F
   if (forward) {
     if (io == 1)
       LAUNCH_K((k_lift_axis<true, 1>), grid, dim3(kThreads), smem, stream, LIFT_ARGS);
@@ -1071,10 +1123,11 @@ template int launch_scatter<double>(hipStream_t, double*, VolDesc, const ChunkGe
                                     const uint32_t[3], const double*, size_t, const CoderState*);
 
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
-                    uint32_t n, CoderState* st)
+                    uint32_t n, CoderState* st, bool have_max)
 {
-  LAUNCH_K(k_maxabs, dim3((n + kThreads * kMaxPer - 1) / (kThreads * kMaxPer), nchunks),
-                     dim3(kThreads), 0, stream, vals, valsStride, n, st);
+  if (!have_max)
+    LAUNCH_K(k_maxabs, dim3((n + kThreads * kMaxPer - 1) / (kThreads * kMaxPer), nchunks),
+                       dim3(kThreads), 0, stream, vals, valsStride, n, st);
   LAUNCH_K(k_make_q_rate, dim3((nchunks + 63) / 64), dim3(64), 0, stream, st, nchunks,
                      0);
   HIP_CHECK(hipGetLastError());
