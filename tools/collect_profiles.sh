@@ -10,7 +10,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 args="bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline --no-host-path"
-timeout 400 python3 bench.py --size 1024 --steps 3 --warmup 1 --no-cpu-baseline --profile-out $out/engine_events.csv > $out/bench.json 2> $out/bench.err
+timeout 600 python3 bench.py --size 1024 --steps 5 --warmup 1 --profile-out $out/engine_events.csv > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $args > $out/trace.log 2>&1
 echo "trace rc=$?"
