@@ -646,3 +646,15 @@ def test_output_buffer_smaller_than_the_header_is_refused(eng):
         assert rtn == -1
     torch.cuda.synchronize()
     assert int(small[32:].sum().item()) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3), (1, 1, 2), (1, 2, 1), (1, 1, 1), (2, 2, 2), (1, 1, 5), (3, 1, 1)])
+def test_tiny_chunks_pwe(eng, oracle, shape):
+    """Chunks of a few samples in point-wise error mode: the reference accepts them (no transform,
+    q = 1.5 tol, never an outlier); containers and decoded doubles as the oracle's."""
+    v = (np.arange(int(np.prod(shape)), dtype=np.float64).reshape(shape) * 0.37 + 0.1) ** 2
+    for tol in (1e-1, 1e-3, 1e-9):
+        want = oracle.comp_3d(v, shape[::-1], 3, tol)
+        assert bytes(eng.compress(cuda(v), shape[::-1], tol, mode=3).cpu().numpy()) == want
+        back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), False).cpu().numpy()
+        assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, False)))
