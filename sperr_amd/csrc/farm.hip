@@ -240,6 +240,26 @@ struct WorkerCtx {
 std::mutex g_ctx_mu;
 std::vector<std::unique_ptr<WorkerCtx>> g_ctx;
 
+// One large copy per device and direction at a time: PCIe is shared, and three workers that copy
+// their items at once all finish late and then all compute at once; one after the other, the
+// second item's copy runs behind the first item's kernels and the link never idles (measured on
+// MI355X, 1024^3 fp32: compress 106 -> 97 ms; decompress, which is bound by its kernels, stays at
+// 110 ms; H2D and D2H are separate
+// tokens because the link is full duplex: 57 GB/s each way, 97 GB/s together).
+struct CopyTokens {
+  std::mutex h2d, d2h;
+};
+CopyTokens& copy_tokens(int dev)
+{
+  static std::mutex mu;
+  static std::map<int, std::unique_ptr<CopyTokens>> all;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& p = all[dev];
+  if (!p)
+    p = std::make_unique<CopyTokens>();
+  return *p;
+}
+
 // (the calling thread has made `dev` current)
 WorkerCtx* ctx_acquire(int dev)
 {
@@ -396,15 +416,19 @@ int comp_item(Job& J, WorkerCtx& C, const Item& it)
   if (C.need_dev_in(inBytes))
     return -1;
   if (J.direct) {
+    std::lock_guard<std::mutex> token(copy_tokens(C.dev).h2d);
     if (dma_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.dIn), it, J.esz, C.st))
       return -1;
+    HIP_CHECK(hipStreamSynchronize(C.st));
   }
   else {
     if (C.need_pin_in(inBytes))
       return -1;
     move_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.pinIn), it, J.esz,
               J.fs.helpers);
+    std::lock_guard<std::mutex> token(copy_tokens(C.dev).h2d);
     HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, inBytes, hipMemcpyHostToDevice, C.st));
+    HIP_CHECK(hipStreamSynchronize(C.st));
   }
   // the item's chunks stacked along z are a volume of their own, cut into exactly these chunks
   const size_t cap = sperrhip_max_compressed_size(cx, cy, cz * nb, cx, cy, cz, J.mode, J.quality);
@@ -480,6 +504,7 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
   if (rc)
     return rc;
   if (J.direct) {
+    std::lock_guard<std::mutex> token(copy_tokens(C.dev).d2h);
     if (dma_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.dOut), it, osz, C.st))
       return -1;
     HIP_CHECK(hipStreamSynchronize(C.st));
@@ -487,8 +512,11 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
   else {
     if (C.need_pin_out(outBytes))
       return -1;
-    HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, outBytes, hipMemcpyDeviceToHost, C.st));
-    HIP_CHECK(hipStreamSynchronize(C.st));
+    {
+      std::lock_guard<std::mutex> token(copy_tokens(C.dev).d2h);
+      HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, outBytes, hipMemcpyDeviceToHost, C.st));
+      HIP_CHECK(hipStreamSynchronize(C.st));
+    }
     move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.pinOut), it, osz, J.fs.helpers);
   }
   return 0;
