@@ -1516,11 +1516,20 @@ int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci,
 // the lists of the larger sets GPU-wide (k_lis_hi) or one workgroup per chunk (k_lis_tables:
 // SPERR_HIP_LIS_HI=0, trees whose geometry tables do not fit the kernel's LDS, diagnostics stamps)
 bool g_lis_stamps_on = false;
+constexpr int kHiMaxK = 9;   // longest class chain k_lis_hi takes (chunk dims up to 1024)
 bool use_lis_hi(const ShapePlan& P, bool tables)
 {
   static const bool hiEnv = !(getenv("SPERR_HIP_LIS_HI") && atoi(getenv("SPERR_HIP_LIS_HI")) == 0);
   return hiEnv && tables && P.ht.grids.size() <= 288 && P.ht.roots.size() <= 48 &&
-         P.maxK >= 1 && P.maxK <= 8;
+         P.maxK >= 1 && P.maxK <= kHiMaxK;
+}
+// every LIS level is regular and the table kernels can take the shape: k_lis_tables up to chains of
+// 8 classes, k_lis_hi one more
+bool use_tables(const ShapePlan& P)
+{
+  if (!P.ht.allRegular || P.maxK < 1)
+    return false;
+  return P.maxK <= 8 || use_lis_hi(P, true);
 }
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
 
@@ -1799,7 +1808,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   const bool deferOK = deferEnv && !anyOutlier && !mr && !slice && groups.size() > 1;
   // (groups of 32 and more chunks of a shape the table kernels take keep the sub-batch scheme)
   auto deferrable = [](const ShapePlan& P, size_t nchunksOfShape) {
-    const bool tables = P.ht.allRegular && P.maxK >= 1 && P.maxK <= 8;
+    const bool tables = use_tables(P);
     return nchunksOfShape < 32 || !tables;
   };
   std::vector<std::unique_ptr<SubHost>> pending;
@@ -1963,7 +1972,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         HIP_CHECK(hipMemsetAsync(d.cst, 0, nb * sizeof(CoderState), ss));
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
-                       P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8, P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
+                       use_tables(*P), P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
@@ -2780,7 +2789,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     }
     else
       HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
-    DecPlanHost ph{P->d_initLIS, P->d_initLen, P->ht.allRegular && P->maxK >= 1 && P->maxK <= 8,
+    DecPlanHost ph{P->d_initLIS, P->d_initLen, use_tables(*P),
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));

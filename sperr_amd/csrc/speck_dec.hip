@@ -2353,7 +2353,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHiTagShift = 57;
 constexpr unsigned long long kHiPayloadMask = (1ull << kHiTagShift) - 1ull;
-constexpr int kHiFrames = 8;
+constexpr int kHiFrames = 10;   // list level + the sets being walked into (chains of up to 9 classes)
 
 // Lanes of ONE wavefront that talk through LDS: the hardware keeps a wavefront's LDS traffic in
 // order, but the compiler reasons per thread (it may forward a lane's own earlier store to its
@@ -3829,8 +3829,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
           LAUNCH_K(k_lis_hi<uint64_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
           LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
         }
-        else
+        else if (plan.maxK <= 8)
           LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        else
+          return -1;
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -3854,8 +3856,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
           LAUNCH_K(k_lis_hi<uint32_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
           LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
         }
-        else
+        else if (plan.maxK <= 8)
           LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
+        else
+          return -1;
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);

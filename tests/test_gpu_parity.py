@@ -658,3 +658,22 @@ def test_tiny_chunks_pwe(eng, oracle, shape):
         assert bytes(eng.compress(cuda(v), shape[::-1], tol, mode=3).cpu().numpy()) == want
         back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), False).cpu().numpy()
         assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, False)))
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 1024), (1, 1024, 1024), (32, 32, 1024)])
+def test_long_class_chains(eng, oracle, shape):
+    """Chunks with an axis of 1024 samples: list levels whose class chain is 9 long (sets of 512 down
+    to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes and k_lis_tables does not.
+    Streams, truncated streams and whole containers against the oracle."""
+    coef, sign = quantized(oracle, shape, 200000.0)
+    stream = oracle.speck3d_encode(coef, sign, 0)
+    assert eng.speck3d_encode(to_dev_coef(coef, False), cuda(sign.view(np.int64)), 0) == stream
+    for cut in (len(stream), 9 + (len(stream) - 9) // 3):
+        c0, s0 = oracle.speck3d_decode(stream[:cut], shape)
+        c1, s1 = eng.speck3d_decode(stream[:cut], shape)
+        assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, shape[::-1], 1, 3.0)
+    assert bytes(eng.compress(cuda(v), shape[::-1], 3.0).cpu().numpy()) == want
+    back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), True).cpu().numpy()
+    assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, True)))
