@@ -945,7 +945,10 @@ LiftConsts lift_consts()
 // throughput.
 static int pick_nl(uint32_t len, int axis, size_t* smem)
 {
-  const size_t cap = (axis == 0 ? 20 : 36) * 1024;
+  // (measured again with the dequantising inverse passes, SPERR_HIP_LIFT_LDS_KB: 20 / 36 / 72 KB
+  //  along y and z give 9.1 / 8.3 / 11.5 ms for the 13 inverse passes of the bench volume)
+  static const int capYZ = getenv("SPERR_HIP_LIFT_LDS_KB") ? atoi(getenv("SPERR_HIP_LIFT_LDS_KB")) : 36;
+  const size_t cap = (size_t)(axis == 0 ? 20 : capYZ) * 1024;
   for (int nl = 32; nl >= 1; nl >>= 1) {
     const size_t bytes = (size_t)len * (nl + 1) * sizeof(double);
     if (bytes <= cap || nl == 1) {
