@@ -445,6 +445,7 @@ struct Engine {
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
+  std::vector<std::unique_ptr<DevBuf>> pweBufs;   // outlier streams of the batches of one call
   size_t freeMemAtInit = 0;
 
   int init()
@@ -1013,14 +1014,10 @@ struct PweKeep {
   uint64_t* slotOff = nullptr;
   uint8_t* slots = nullptr;
 };
+// (the memory belongs to the engine, Engine::pweBufs, and is reused by later calls: a hipFree per
+//  batch waits for every stream of the device, which stalls the other workers of the chunk farm)
 struct PweKeepList {
   std::vector<PweKeep> v;
-  ~PweKeepList()
-  {
-    for (auto& k : v)
-      if (k.mem)
-        (void)hipFree(k.mem);
-  }
 };
 
 // list storage of the 1D coder: level l holds at most 2^l runs, and never more than `most`
@@ -1177,7 +1174,12 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   PweKeep K;
   K.nb = nb;
   const size_t headBytes = round_up((size_t)nb * 8, 256) + round_up((size_t)nb * 4, 256);
-  HIP_CHECK(hipMalloc(&K.mem, headBytes + off2[nb] + 256));
+  if (keep.v.size() >= E.pweBufs.size())
+    E.pweBufs.push_back(std::make_unique<DevBuf>());
+  DevBuf& kb = *E.pweBufs[keep.v.size()];
+  if (kb.ensure(headBytes + off2[nb] + 256))
+    return -1;
+  K.mem = kb.p;
   keep.v.push_back(K);
   PweKeep& kk = keep.v.back();
   kk.slotOff = reinterpret_cast<uint64_t*>(kk.mem);

@@ -430,15 +430,24 @@ int comp_item(Job& J, WorkerCtx& C, const Item& it)
     HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, inBytes, hipMemcpyHostToDevice, C.st));
     HIP_CHECK(hipStreamSynchronize(C.st));
   }
-  // the item's chunks stacked along z are a volume of their own, cut into exactly these chunks
-  const size_t cap = sperrhip_max_compressed_size(cx, cy, cz * nb, cx, cy, cz, J.mode, J.quality);
-  if (C.need_dev_out(cap))
-    return -1;
+  // the item's chunks stacked along z are a volume of their own, cut into exactly these chunks.
+  // Without a bit budget the bound on the container is 33 bytes per value; real containers are a
+  // fraction of the input, so the first attempt gets three times the input and only a container
+  // that does not fit (never seen) is produced again into the full bound.
+  const size_t bound = sperrhip_max_compressed_size(cx, cy, cz * nb, cx, cy, cz, J.mode, J.quality);
+  size_t cap = std::min(bound, 3 * inBytes + (size_t(1) << 20));
   size_t len = 0;
-  const int rc = sperrhip_compress_dev(C.dIn, J.is_float, cx, cy, cz * nb, cx, cy, cz, J.mode,
-                                       J.quality, C.dOut, cap, &len, C.st);
-  if (rc)
-    return rc;
+  for (;;) {
+    if (C.need_dev_out(cap))
+      return -1;
+    const int rc = sperrhip_compress_dev(C.dIn, J.is_float, cx, cy, cz * nb, cx, cy, cz, J.mode,
+                                         J.quality, C.dOut, cap, &len, C.st);
+    if (rc == 0)
+      break;
+    if (rc != -1 || cap >= bound)
+      return rc;
+    cap = bound;
+  }
   const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
   if (len < hdr || C.need_pin_out(len))
     return -1;
