@@ -211,7 +211,12 @@ def main():
     host_path = None
     if not args.no_host_path:
         if rank == 0:
-            host_path = run_host_path(eng, vol, chunks, args.bpp, list(range(world)), args.host_reps, stream, out)
+            # (a launcher may show every rank only its own GPU: then the farm has that one)
+            ndev = max(1, min(world, torch.cuda.device_count()))
+            try:
+                host_path = run_host_path(eng, vol, chunks, args.bpp, list(range(ndev)), args.host_reps, stream, out)
+            except Exception as ex:   # never lose the line of the weak-scaling run over this
+                host_path = {"error": f"{type(ex).__name__}: {ex}", "n_gpus": ndev}
         if world > 1:
             dist.barrier(group=host_pg)
 
