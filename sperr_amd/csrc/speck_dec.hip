@@ -3684,24 +3684,44 @@ __global__ void __launch_bounds__(kThreads * kRefGroups) k_ref_apply(DecBuffers 
   const CT thr = (CT)1 << p, half = thr / 2;
   const CT initPrev = thr * 2 + thr * 2 - thr - 1;
   const uint32_t lane = gt & 63u, wave = gt >> 6;
-  // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous
-  for (uint32_t k = wave; k < (uint32_t)kDecTileWords; k += kThreads / 64) {
-    const uint64_t sig = wordSig[k];
-    if (!((sig >> lane) & 1ull))
-      continue;
-    const uint64_t at = base + wordBase[k] + (uint64_t)__popcll(sig & ((1ull << lane) - 1ull));
-    if (at >= s.avail)   // the pass stops the moment the stream is exhausted
-      continue;          // (SPECK_INT.cpp:388-389)
-    const int bit = (int)((words[at >> 6] >> (at & 63)) & 1);
-    const uint32_t i = (w0 + k) * 64 + lane;
-    CT v2 = coef[i];
-    if (v2 == 0)          // first touch: found significant on the previous plane (threshold 2*thr)
-      v2 = initPrev;      // 1.5 * (2 thr) - 1  (SPECK_INT.cpp:462-468)
-    if (p >= 1)
-      v2 = bit ? v2 + half : v2 - half;
-    else if (bit)
-      v2 += 1;
-    coef[i] = v2;
+  // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous.  Four words
+  // per round: their stream and coefficient loads are issued together (one word at a time left the
+  // pass waiting for a load most of the time)
+  constexpr int kRefBatch = 4;
+  for (uint32_t k0 = wave; k0 < (uint32_t)kDecTileWords; k0 += (kThreads / 64) * kRefBatch) {
+    bool act[kRefBatch];
+    uint64_t at[kRefBatch];
+    uint32_t idx[kRefBatch];
+    uint64_t sw[kRefBatch];
+    CT cv[kRefBatch];
+#pragma unroll
+    for (int u = 0; u < kRefBatch; u++) {
+      const uint32_t k = k0 + (uint32_t)u * (kThreads / 64);
+      const uint64_t sig = k < (uint32_t)kDecTileWords ? wordSig[k] : 0ull;
+      act[u] = ((sig >> lane) & 1ull) != 0;
+      at[u] = act[u] ? base + wordBase[k] + (uint64_t)__popcll(sig & ((1ull << lane) - 1ull)) : 0ull;
+      act[u] = act[u] && at[u] < s.avail;   // the pass stops the moment the stream is exhausted
+      idx[u] = (w0 + k) * 64 + lane;        // (SPECK_INT.cpp:388-389)
+    }
+#pragma unroll
+    for (int u = 0; u < kRefBatch; u++) {
+      sw[u] = act[u] ? words[at[u] >> 6] : 0ull;
+      cv[u] = act[u] ? coef[idx[u]] : (CT)0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRefBatch; u++) {
+      if (!act[u])
+        continue;
+      const int bit = (int)((sw[u] >> (at[u] & 63)) & 1);
+      CT v2 = cv[u];
+      if (v2 == 0)          // first touch: found significant on the previous plane (threshold 2*thr)
+        v2 = initPrev;      // 1.5 * (2 thr) - 1  (SPECK_INT.cpp:462-468)
+      if (p >= 1)
+        v2 = bit ? v2 + half : v2 - half;
+      else if (bit)
+        v2 += 1;
+      coef[idx[u]] = v2;
+    }
   }
 }
 
