@@ -1,7 +1,7 @@
 // sperr3d -- compress / decompress a 3D volume on the GPU.  Same command line, files, messages
 // and output naming as the reference's utilities/sperr3d.cpp (options :100-204, checks :206-262,
-// work :267-418); the work itself is libsperr_hip.so (include/sperr_hip.h).  --omp is accepted and
-// ignored: there is no thread team, chunks are batched on the device.
+// work :267-418); the work itself is libsperr_hip.so (include/sperr_hip.h).  --omp is the number of
+// host threads that stage rows for the transfers: the chunk loop runs on the library's GPU farm.
 #include "cli_common.hpp"
 #include "sperr_hip.h"
 
@@ -78,7 +78,7 @@ int main(int argc, char** argv)
              *gc = "Compression settings";
   app.flag("-c", cflag, "Perform a compression task.", gx);
   app.flag("-d", dflag, "Perform a decompression task.", gx).excludes = {"-c"};
-  app.count("--omp", omp, "Accepted for compatibility; the GPU engine has no thread team.", gx);
+  app.count("--omp", omp, "Number of host threads that stage rows for the GPU(s). Default (or 0): 4 per worker.\nThe GPUs are chosen by SPERR_HIP_DEVICES (default: all).", gx);
   app.count("--ftype", ftype, "Specify the input float type in bits. Must be 32 or 64.", gi);
   app.counts("--dims", dims, 3, "Dimensions of the input volume. E.g., `--dims 128 128 128`\n"
              "(The fastest-varying dimension appears first.)", gi);

@@ -35,3 +35,6 @@ for name, fn in (("compress", lambda: eng.compress(vol, (256, 256, 256), 2.0, ou
     ksum = sum(v[2] for v in rep.values())
     nl = sum(v[1] for v in rep.values())
     print(f"{name:10s} {n}^3: wall {min(ts) * 1e3:6.2f} ms   kernels {ksum:6.2f} ms in {nl} launches")
+    if len(sys.argv) > 2:
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1][2])[:14]:
+            print(f"   {k:28s} {v[2]:7.3f} ms  {v[1]:4d} launches")
