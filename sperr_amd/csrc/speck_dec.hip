@@ -3823,9 +3823,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
   const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l1Total / nc));
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
-  // workgroups per chunk of the k_lis_hi pass: one per CU over all chunks, at most what the
-  // queues were sized for (SPERR_HIP_HI_WGS: the total)
-  static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 256u;
+  // workgroups per chunk of the k_lis_hi pass, at most what the queues were sized for
+  // (SPERR_HIP_HI_WGS: the total over the batch's chunks; measured on MI355X with two sub-batches
+  // of 32 chunks side by side: 96 / 128 / 160 / 192 / 224 / 256 / 384 workgroups per sub-batch give
+  // 70.8 / 75.3 / 76.3 / 76.0 / 75.0 / 74.5 / 74.3 GB/s of decompression)
+  static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 192u;
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
   if (plan.tables && plan.hi) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint32_t>), (int)b.hiSmemBytes) ||
