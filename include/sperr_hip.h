@@ -61,7 +61,9 @@ int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, si
  * below take the list as an argument (devices == NULL or ndevices == 0: the same default).  An
  * ordinal may repeat.  `nthreads`: host threads that move rows between the caller's buffers and the
  * staging buffers (0 = a default of 4 per worker).  A caller's volume that is pinned host memory
- * (hipHostMalloc / hipHostRegister) is read and written by DMA without staging.
+ * (hipHostMalloc / hipHostRegister) is read and written by DMA without staging; a volume that is
+ * DEVICE memory (compress: src, decompress: the dst of sperrhip_decomp_3d_into) is handled by the
+ * device-resident path on the device it lives on, and only the container crosses the bus.
  * Return codes as sperr_comp_3d / sperr_decomp_3d. */
 int sperrhip_comp_3d_farm(const void* src, int is_float, size_t dimx, size_t dimy, size_t dimz,
                           size_t chunk_x, size_t chunk_y, size_t chunk_z, int mode, double quality,

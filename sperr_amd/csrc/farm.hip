@@ -184,16 +184,42 @@ void parallel_do(size_t nthreads, F&& fn)
     t.join();
 }
 
-bool host_ptr_is_pinned(const void* p)
+// 0: pageable host memory, 1: pinned host memory, 2: device memory (then *dev is its device)
+int classify_ptr(const void* p, int* dev)
 {
   hipPointerAttribute_t a;
   memset(&a, 0, sizeof(a));
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();   // plain malloc'd memory is reported as an invalid value
-    return false;
+    return 0;
   }
-  return a.type == hipMemoryTypeHost;
+  if (a.type == hipMemoryTypeDevice) {
+    if (dev)
+      *dev = a.device;
+    return 2;
+  }
+  return a.type == hipMemoryTypeHost ? 1 : 0;
 }
+bool host_ptr_is_pinned(const void* p)
+{
+  return classify_ptr(p, nullptr) == 1;
+}
+
+// keeps the calling thread's device across a detour to another one
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev)
+  {
+    if (hipGetDevice(&prev) != hipSuccess)
+      prev = -1;
+    (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard()
+  {
+    if (prev >= 0)
+      (void)hipSetDevice(prev);
+  }
+};
 
 // ------------------------------------------------------------------------------------------
 // worker contexts: stream + staging buffers, kept between calls (pinning memory is slow)
@@ -776,6 +802,34 @@ int sperrhip_comp_3d_farm(const void* src, int is_float, size_t dimx, size_t dim
       return 2;
     if (!src || !dst_len || dimx == 0 || dimy == 0 || dimz == 0)
       return -1;
+    int dev = 0;
+    if (classify_ptr(src, &dev) == 2) {
+      // the volume already lives on a device: no farm, the device-resident compressor there, and
+      // only the container travels
+      DeviceGuard guard(dev);
+      const size_t cap = sperrhip_max_compressed_size(dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode, quality);
+      void* d_out = nullptr;
+      if (hipMalloc(&d_out, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+      }
+      size_t len = 0;
+      int rc = sperrhip_compress_dev(src, is_float, dimx, dimy, dimz, chunk_x, chunk_y, chunk_z, mode, quality,
+                                     d_out, cap, &len, nullptr);
+      if (rc == 0) {
+        void* buf = malloc(std::max<size_t>(len, 1));
+        if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+          *dst = buf;
+          *dst_len = len;
+        }
+        else {
+          free(buf);
+          rc = -1;
+        }
+      }
+      (void)hipFree(d_out);
+      return rc;
+    }
     return farm_compress(src, is_float, Dims3{dimx, dimy, dimz}, Dims3{chunk_x, chunk_y, chunk_z},
                          mode, quality, nthreads, devices, ndevices, dst, dst_len);
   });
@@ -793,6 +847,21 @@ int sperrhip_decomp_3d_into(const void* src, size_t src_len, int output_float, s
       return -1;
     if (hc.nvals > dst_bytes / (output_float ? 4 : 8))
       return -1;
+    int dev = 0;
+    if (classify_ptr(dst, &dev) == 2) {
+      // the volume is wanted on a device: the container goes there, the device-resident decoder runs
+      DeviceGuard guard(dev);
+      void* d_in = nullptr;
+      if (hipMalloc(&d_in, std::max<size_t>(src_len, 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+      }
+      int r2 = -1;
+      if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
+        r2 = sperrhip_decompress_dev(d_in, src_len, output_float, dst, dst_bytes, dimx, dimy, dimz, nullptr);
+      (void)hipFree(d_in);
+      return r2;
+    }
     const int rc = farm_decompress(src, src_len, output_float, nthreads, devices, ndevices, hc, dst);
     if (rc == 0) {
       if (dimx)

@@ -117,3 +117,27 @@ def test_farm_rejects_bad_arguments(eng):
     assert not dst.value
     with pytest.raises(Exception):
         eng.decomp_3d_farm(b"\x00" * 64, True)
+
+
+def test_device_pointers_through_the_host_entry_points(eng, oracle):
+    """A volume that already lives on a device (or is wanted there) is not an error for
+    sperrhip_comp_3d_farm / sperrhip_decomp_3d_into: the device-resident path runs where the data is."""
+    import ctypes as C
+    import torch
+    vol = turbulence((48, 64, 80))
+    want = oracle.comp_3d(vol, (32, 32, 32), 1, 2.0)
+    dv = torch.from_numpy(vol).cuda()
+    dst, n = C.c_void_p(None), C.c_size_t(0)
+    rc = eng.lib.sperrhip_comp_3d_farm(dv.data_ptr(), 1, 80, 64, 48, 32, 32, 32, 1, 2.0, 0, None, 0,
+                                       C.byref(dst), C.byref(n))
+    assert rc == 0
+    got = C.string_at(dst.value, n.value)
+    eng._libc.free(dst)
+    assert got == want
+    out = torch.empty((48, 64, 80), dtype=torch.float32, device="cuda")
+    buf = np.frombuffer(want, dtype=np.uint8)
+    d = [C.c_size_t(0) for _ in range(3)]
+    rc = eng.lib.sperrhip_decomp_3d_into(buf.ctypes.data, buf.size, 1, 0, None, 0, out.data_ptr(), out.numel() * 4,
+                                         C.byref(d[0]), C.byref(d[1]), C.byref(d[2]))
+    assert rc == 0 and (d[0].value, d[1].value, d[2].value) == (80, 64, 48)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.decomp_3d(want, True).view(np.uint32))
