@@ -60,7 +60,7 @@ int sperr_trunc_3d(const void* src, size_t src_len, unsigned pct, void** dst, si
  * They use the devices SPERR_HIP_DEVICES names ("all", the default, or "0,2,3"); the entry points
  * below take the list as an argument (devices == NULL or ndevices == 0: the same default).  An
  * ordinal may repeat.  `nthreads`: host threads that move rows between the caller's buffers and the
- * staging buffers (0 = a default of 4 per worker).  A caller's volume that is pinned host memory
+ * staging buffers (0 = a default of 4 to 12 per worker, by the host's thread count).  A caller's volume that is pinned host memory
  * (hipHostMalloc / hipHostRegister) is read and written by DMA without staging; a volume that is
  * DEVICE memory (compress: src, decompress: the dst of sperrhip_decomp_3d_into) is handled by the
  * device-resident path on the device it lives on, and only the container crosses the bus.
