@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(kNodeBlock) k_bucket_fill(EncBuffers b)
 constexpr int kSplitBlocks = 512;
 
 __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
-                                                uint32_t id);
+                                                uint32_t id, bool have);
 
 __global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
 {
@@ -691,12 +691,17 @@ __global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
   ACTIVE_OR_RETURN(s, p);
   const uint32_t cnt = s.bucketCnt[p], off = s.bucketOff[p];
   const uint32_t* bucket = b.bucket + c * b.nodeStride + off;
-  for (uint32_t k = blockIdx.x * kNodeBlock + threadIdx.x; k < cnt; k += gridDim.x * kNodeBlock)
-    split_emit_node(b, c, s, p, bucket[k]);
+  // (every lane of a wavefront takes part in every round: the birth slots of a wavefront's sets
+  //  are claimed with one atomic)
+  for (uint32_t k0 = blockIdx.x * kNodeBlock; k0 < cnt; k0 += gridDim.x * kNodeBlock) {
+    const uint32_t k = k0 + threadIdx.x;
+    const bool have = k < cnt;
+    split_emit_node(b, c, s, p, have ? bucket[k] : 0u, have);
+  }
 }
 
 __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
-                                                uint32_t id)
+                                                uint32_t id, bool have)
 {
   const int8_t* M = b.M + c * b.nodeStride;
   const Tree& t = b.tree;
@@ -737,8 +742,71 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   int nacc = 0;
   uint64_t accpos = pos;
   const Grid& g = t.grids[nd.grid];
-  if (g.kind & kGridOct) {  // same loop as below with the 8 children in registers
-    if (g.depth + 1 == t.roots[g.root].Dmax) {   // a leaf set: everything is in its descriptor
+  // ---- births first: how many children of this set stay insignificant sets (they get consecutive
+  //      slots of the chunk's birth records; one atomic per wavefront claims them)
+  const bool isOct = (g.kind & kGridOct) != 0;
+  const bool isLeafSet = isOct && g.depth + 1 == t.roots[g.root].Dmax;
+  OctKids k;
+  Kids kg;
+  KidInfo ki;
+  uint32_t kidlev = 0, slot = 0xff, nborn = 0;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  if (have && isOct && !isLeafSet) {
+    oct_load(t, g, t.roots[g.root], nd, M, E, msb, k);
+    kidlev = node_level(t, nd) + 3;
+    slot = b.levelSlot[kidlev];
+    if (!k.deepest && slot != 0xff) {
+      uint64_t q2 = pos;
+      bool fnd = false;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool coded = fnd || j != 7;
+        const bool sig = coded ? (k.m[j] == p) : true;
+        q2 += coded ? 1u : 0u;
+        if (sig) {
+          fnd = true;
+          q2 += k.e[j];
+        }
+        else if (q2 - 1 - baseLIS < maskBits)
+          nborn++;
+      }
+    }
+  }
+  else if (have && !isOct) {
+    node_kids(t, nd, kg);
+    kids_info(t, nd, kg, M, E, msb, ki);
+    kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+    slot = b.levelSlot[kidlev];
+    uint64_t q2 = pos;
+    bool fnd = false;
+    for (int j = 0; j < kg.n; j++) {
+      const bool coded = fnd || (j + 1 != kg.n);
+      const bool sig = coded ? (ki.m[j] == p) : true;
+      q2 += coded ? 1u : 0u;
+      if (sig) {
+        fnd = true;
+        q2 += ki.pixel[j] ? 1u : ki.e[j];
+      }
+      else if (!ki.pixel[j] && slot != 0xff && q2 - 1 - baseLIS < maskBits)
+        nborn++;
+    }
+  }
+  uint32_t kslot;
+  {
+    const uint32_t inc = wave_inclusive_scan<uint32_t>(nborn);
+    const uint32_t tot = __shfl(inc, 63, 64);
+    uint32_t base = 0;
+    if (tot) {
+      if ((threadIdx.x & 63) == 63)
+        base = atomicAdd(&s.bornCount, tot);
+      base = __shfl(base, 63, 64);
+    }
+    kslot = base + inc - nborn;
+  }
+  if (!have)
+    return;
+  if (isOct) {  // same loop as below with the 8 children in registers
+    if (isLeafSet) {   // a leaf set: everything is in its descriptor
       const uint32_t desc = b.leafDesc[c * b.nodeStride + id];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -757,10 +825,6 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
       put_bits(stream, accpos, acc, nacc, s.budget);
       return;
     }
-    OctKids k;
-    oct_load(t, g, t.roots[g.root], nd, M, E, msb, k);
-    const uint32_t kidlev = node_level(t, nd) + 3;
-    const uint32_t slot = b.levelSlot[kidlev];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const bool coded = found || j != 7;
@@ -794,9 +858,9 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
           kn.i[0] = (uint16_t)(2u * nd.i[0] + (uint32_t)(j & 1));
           kn.i[1] = (uint16_t)(2u * nd.i[1] + (uint32_t)((j >> 1) & 1));
           kn.i[2] = (uint16_t)(2u * nd.i[2] + (uint32_t)(j >> 2));
-          const uint32_t kslot = atomicAdd(&s.bornCount, 1u);
           b.bornPacked[c * b.bornStride + kslot] = pack_node(kn);
           b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
+          kslot++;
           atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
                       1ull << (rel & 63));
         }
@@ -805,14 +869,8 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     put_bits(stream, accpos, acc, nacc, s.budget);
     return;
   }
-  Kids k;
-  node_kids(t, nd, k);
-  KidInfo ki;
-  kids_info(t, nd, k, M, E, msb, ki);
-  const uint32_t kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
-  const uint32_t slot = b.levelSlot[kidlev];
-  for (int j = 0; j < k.n; j++) {
-    const bool coded = found || (j + 1 != k.n);
+  for (int j = 0; j < kg.n; j++) {
+    const bool coded = found || (j + 1 != kg.n);
     const bool sig = coded ? (ki.m[j] == p) : true;
     if (coded) {
       acc |= (uint64_t)sig << nacc;
@@ -822,7 +880,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     if (sig) {
       found = true;
       if (ki.pixel[j]) {
-        const uint32_t ridx = kid_raster(t, nd, k, j);
+        const uint32_t ridx = kid_raster(t, nd, kg, j);
         acc |= ((sign[ridx >> 6] >> (ridx & 63)) & 1ull) << nacc;
         nacc++;
         pos++;
@@ -838,9 +896,9 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     else if (!ki.pixel[j]) {  // insignificant set: joins LIS[kidlev] in stream order
       const uint64_t rel = pos - 1 - baseLIS;
       if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
-        const uint32_t kslot = atomicAdd(&s.bornCount, 1u);
-        b.bornPacked[c * b.bornStride + kslot] = pack_node(kid_node(k, j));
+        b.bornPacked[c * b.bornStride + kslot] = pack_node(kid_node(kg, j));
         b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
+        kslot++;
         atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
                     1ull << (rel & 63));
       }
