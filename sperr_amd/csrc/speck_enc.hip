@@ -707,7 +707,6 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   const Tree& t = b.tree;
   Node nd;
   node_from_flat(t, id, nd);
-  const NodeGeom q = node_geom(t, nd);
   const uint32_t* E = b.E + c * b.nodeStride;
   const int8_t* msb = b.msb + c * b.pixStride;
 
@@ -775,6 +774,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   else if (have && !isOct) {
     node_kids(t, nd, kg);
     kids_info(t, nd, kg, M, E, msb, ki);
+    const NodeGeom q = node_geom(t, nd);
     kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
     slot = b.levelSlot[kidlev];
     uint64_t q2 = pos;
