@@ -351,7 +351,8 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
                oLevOff = blob.add(levelOff), oTL = blob.add(tileLevel), oTS = blob.add(tileStart),
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
-               oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf);
+               oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf), oCls = blob.add(h.cls),
+               oGC = blob.add(h.gridCls);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
@@ -384,6 +385,8 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.dtree.grids = reinterpret_cast<const spk::Grid*>(base + oGrids);
   P.dtree.tab = reinterpret_cast<const uint16_t*>(base + oTab);
   P.dtree.blockGrid = reinterpret_cast<const uint16_t*>(base + oBG);
+  P.dtree.cls = reinterpret_cast<const spk::ShapeCls*>(base + oCls);
+  P.dtree.gridCls = reinterpret_cast<const uint8_t*>(base + oGC);
   P.d_initLIS = reinterpret_cast<const uint64_t*>(base + oInit);
   P.d_initLen = reinterpret_cast<const uint32_t*>(base + oInitLen);
   P.d_levelOff = reinterpret_cast<const uint32_t*>(base + oLevOff);
@@ -1533,6 +1536,17 @@ bool use_tables(const ShapePlan& P)
     return false;
   return P.maxK <= 8 || use_lis_hi(P, true);
 }
+// lists that mix set shapes (any chunk extent that is not a power of two): k_lis_mixed, tables keyed
+// by shape class and one walking thread per chunk (SPERR_HIP_LIS_MIXED=0: k_lis_walk, the serial walk)
+constexpr uint32_t kMixSmemBytes = 144 * 1024;   // (k_lis_mixed has 15 KB of static LDS)
+bool use_mixed(const ShapePlan& P)
+{
+  static const bool mixEnv = !(getenv("SPERR_HIP_LIS_MIXED") && atoi(getenv("SPERR_HIP_LIS_MIXED")) == 0);
+  if (!mixEnv || use_tables(P) || P.ht.cls.empty())
+    return false;
+  const uint32_t w = mix_window(P.ht.nslots, kMixSmemBytes);
+  return w >= 512 && w >= P.ht.slotMaxT + 2;
+}
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
 
 struct DecBatchBufs {
@@ -1627,6 +1641,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.hiAhead = std::min(d.hiAhead / 64 * 64, d.hiW / 2);
   d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 4) * 4;
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
+  d.mixSmemBytes = kMixSmemBytes;
+  d.mixW = mix_window(P.ht.nslots, kMixSmemBytes);
   d.leafCap = P.ht.nsets + 8;
   d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;
@@ -1978,6 +1994,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
+        ph.mixed = use_mixed(*P);
         // the inverse passes dequantise on the way (not for the resolution hierarchy, whose coarsest
         // level is read before any pass has run)
         const bool fuseDq = plan_fusable(*P) && !mr && !slice;
@@ -2013,7 +2030,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
           if (slice) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
             DecPlanHost ph2 = ph;
-            ph2.tables = ph2.l0 = ph2.l1 = false;
+            ph2.tables = ph2.l0 = ph2.l1 = ph2.mixed = false;
             Speck2dBufs sb;
             if (launch_speck_decode(ss, dw, ph2, d_src, bb.chunkOff, bb.chunkLen, wide != 0, 0) ||
                 carve_slice2d(E, *P, sb))
@@ -2794,6 +2811,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     DecPlanHost ph{P->d_initLIS, P->d_initLen, use_tables(*P),
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);
+    ph.mixed = use_mixed(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));

@@ -125,6 +125,9 @@ struct DecBuffers {
   uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
   uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
                                //   the region and end within them are not walked into
+  // k_lis_mixed (chunks whose lists mix set shapes): window bits and dynamic LDS
+  uint32_t mixW;
+  uint32_t mixSmemBytes;
 };
 
 struct DecPlanHost {
@@ -135,6 +138,7 @@ struct DecPlanHost {
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
+  bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
 };
 
@@ -162,6 +166,22 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   w = w / 1024 * 1024;
   if (w > (uint32_t)kTabWMax)
     w = kTabWMax;
+  return w;
+}
+
+// k_lis_mixed: LDS bytes per window bit are one u16 table entry per class with a table, the class
+// byte of a list entry the window may reach and the bit itself.  The window is the largest
+// multiple of 256 that fits (tables keep two sentinel entries, the bit window four slack words).
+__host__ __device__ inline uint32_t mix_window(uint32_t nslots, uint32_t smemBytes)
+{
+  const uint32_t perBit8 = 8u * (2u * nslots + 1u) + 1u;   // eighths of a byte
+  const uint32_t fixed = 4 * 8 + 4u * nslots + 64;
+  if (smemBytes <= fixed)
+    return 0;
+  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
+  w = w / 256 * 256;
+  if (w > 16384u)
+    w = 16384u;
   return w;
 }
 

@@ -2329,6 +2329,556 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// LIS phase for chunks whose lists MIX set shapes (any extent that is not a power of two): one
+// 1024-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_mixed is the
+// CPU model of this kernel.
+//
+// The code of a set depends on its extents only, so every set has a SHAPE CLASS (spk::ShapeCls,
+// built on the host): a leaf parent of 2, 4 or 8 samples, a set made of such leaf parents and
+// single samples, and so on.  A list entry's class is read off the entry (spk::node_cls: which
+// of its three intervals are the long ones); what pointer jumping needs -- one code structure
+// for all entries of a list -- is gone, so the list is walked by ONE thread, but the walk only
+// hops:
+//   tables   per window of W stream bits, for every class that has a table slot (h <= 1 by
+//            default) and EVERY bit position: the bits a split of that class takes when it starts
+//            there (kTInf when that leaves the window); speculative, all threads;
+//   walk     one thread: runs of '0' entries are counted off the stream (in front of a window by
+//            the whole workgroup), a significant entry of a class with a table costs one look-up,
+//            any other set is walked into child by child (its children's tables do the rest);
+//   expand   every set that was hopped over is a work item: a thread finds its children with the
+//            tables, leaf parents become leaf events (k_leaf_apply), insignificant child sets are
+//            recorded with their stream position (k_place_scan / _scatter rank them), significant
+//            ones are queued for the next round.
+// ------------------------------------------------------------------------------------------
+constexpr int kMixLdsRoots = 48, kMixLdsGrids = 352;
+
+struct MixCtx {
+  uint64_t parent;     // packed node of the set being walked into
+  KidBox kb;
+  uint8_t pc;          // its class
+  uint8_t next;        // ordinal of the next child
+  uint8_t found;       // an earlier child was significant
+  uint8_t pad;
+};
+
+template <typename CT>
+__global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  extern __shared__ __attribute__((aligned(16))) char mix_smem[];
+  __shared__ ShapeCls sh_cls[kMaxCls];
+  __shared__ uint64_t sh_kslot[kMaxCls];            // byte k: table slot of child k (0xfe: a single sample)
+  __shared__ Root sh_roots[kMixLdsRoots];
+  __shared__ Grid sh_grids[kMixLdsGrids];
+  __shared__ uint8_t sh_gridCls[kMixLdsGrids * 8];
+  __shared__ MixCtx sh_ctx[kMaxDepth + 2];
+  __shared__ uint8_t sh_slotCls[64];
+  __shared__ uint64_t sh_pos;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_leaf, sh_zfound;
+  __shared__ int sh_depth;
+  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+
+  const int tid = threadIdx.x;
+  Tree t = b.tree;
+  const uint32_t nslots = t.nslots;
+  if (t.nroots <= (uint32_t)kMixLdsRoots && t.ngrids <= (uint32_t)kMixLdsGrids) {
+    for (uint32_t i = tid; i < t.nroots; i += kTabThreads)
+      sh_roots[i] = b.tree.roots[i];
+    for (uint32_t i = tid; i < t.ngrids; i += kTabThreads)
+      sh_grids[i] = b.tree.grids[i];
+    for (uint32_t i = tid; i < t.ngrids * 8; i += kTabThreads)
+      sh_gridCls[i] = b.tree.gridCls[i];
+    t.roots = sh_roots;
+    t.grids = sh_grids;
+    t.gridCls = sh_gridCls;
+  }
+  for (uint32_t i = tid; i < t.ncls; i += kTabThreads) {
+    const ShapeCls cc = b.tree.cls[i];
+    sh_cls[i] = cc;
+    uint64_t ks = 0;
+    for (int k = 0; k < 8; k++) {
+      const uint32_t kc = k < cc.nk ? cc.kid[k] : kClsPixel;
+      ks |= (uint64_t)(kc == kClsPixel ? 0xfeu : b.tree.cls[kc].slot) << (8 * k);
+    }
+    sh_kslot[i] = ks;
+    if (cc.slot != 0xff)
+      sh_slotCls[cc.slot] = (uint8_t)i;
+  }
+  t.cls = sh_cls;
+
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
+  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  uint64_t* qbuf[2] = {b.queue + c * b.queueStride, b.queue + c * b.queueStride + b.queueCap * 2};
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
+  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+
+  const uint32_t W = b.mixW, TS = W + 2;
+  const uint32_t kWords = W / 64 + 4;
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(mix_smem);
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(mix_smem);
+  uint16_t* Tt = reinterpret_cast<uint16_t*>(mix_smem + (size_t)kWords * 8);   // [nslots][TS]
+  uint8_t* ecls = reinterpret_cast<uint8_t*>(Tt + (size_t)nslots * TS);        // [W]
+
+  if (tid == 0) {
+    sh_pos = phase0;
+    sh_born = s.bornCount;
+    sh_leaf = s.leafCount;
+  }
+  __syncthreads();
+  uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t stamp_t = 0;
+  const bool stamps = b.lisStamps != nullptr && tid == 0;
+#define STAMP(i)                                        \
+  if (stamps) {                                         \
+    const uint64_t now_ = __builtin_readcyclecounter(); \
+    stamp_acc[i] += now_ - stamp_t;                     \
+    stamp_t = now_;                                     \
+  }
+  if (stamps)
+    stamp_t = __builtin_readcyclecounter();
+
+  uint32_t wq0 = 0;  // bit offset of window position 0 inside wbits[0]
+  auto bit_at = [&](uint32_t r) -> uint32_t {
+    const uint32_t q = r + wq0;
+    return (w32[q >> 5] >> (q & 31)) & 1u;
+  };
+  auto bits32 = [&](uint32_t r) -> uint32_t {  // 32 stream bits starting at r
+    const uint32_t q = r + wq0, sh = q & 31;
+    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  };
+  auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
+    atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
+    if (sig) {
+      atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
+      if (!signbit)
+        atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+    }
+  };
+  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
+    const uint64_t rel = abs - phase0;
+    const uint32_t slot = b.levelSlot[lev];
+    if (slot == 0xff || rel >= maskBits)
+      return;  // past the usable stream: decoding stops after this plane anyway
+    const uint32_t k = atomicAdd(&sh_born, 1u);
+    if (k >= b.bornStride)
+      return;
+    bornPacked[k] = packed;
+    bornPosLev[k] = ((uint64_t)lev << 48) | rel;
+    atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
+                1ull << (rel & 63));
+  };
+  // bits of a split of class `ci` that starts at r (kTInf: it leaves the window); the tables of
+  // the children's classes are complete.  Indices W and W + 1 of every table hold kTInf.
+  auto split_len = [&](uint32_t ci, uint32_t r) -> uint32_t {
+    const uint32_t nk = sh_cls[ci].nk;
+    if (sh_cls[ci].h == 0) {
+      if (r >= W)
+        return kTInf;
+      const uint32_t v = bits32(r);
+      uint32_t y = 0, found = 0;
+      if (nk == 8) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const uint32_t bit = (v >> y) & 1u;
+          found |= bit;
+          y += 1u + bit;
+        }
+        const uint32_t bit = found ? (v >> y) & 1u : 1u;
+        y += found + bit;
+      }
+      else {
+        for (uint32_t i = 0; i < nk; i++) {
+          const uint32_t coded = found | (uint32_t)(i + 1 != nk);
+          const uint32_t bit = coded ? (v >> y) & 1u : 1u;
+          y += coded;
+          found |= bit;
+          y += bit;  // sign bit
+        }
+      }
+      return r + y <= W ? y : kTInf;
+    }
+    const uint64_t ks = sh_kslot[ci];
+    uint32_t y = min(r, W + 1), found = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+      const uint32_t bit = coded ? bit_at(y) : 1u;
+      y += coded;
+      const uint32_t sl = (uint32_t)(ks >> (8 * k)) & 0xffu;
+      if (sl == 0xfeu)
+        y += bit;   // the sign of a significant sample
+      else if (bit) {
+        const uint32_t tl = Tt[(size_t)sl * TS + min(y, W + 1)];
+        if (tl == kTInf)
+          return kTInf;
+        y += tl;
+      }
+      found |= bit;
+    }
+    return y <= W ? y - r : kTInf;
+  };
+
+  for (uint32_t l = t.nlevels; l-- > 0;) {
+    const uint32_t n = s.listLen[cur][l];
+    if (n == 0) {
+      if (tid == 0)
+        s.listLen[nx][l] = 0;
+      continue;
+    }
+    const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
+    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kTabThreads)
+      sigbits[i] = 0;
+    if (tid == 0) {
+      sh_depth = 1;
+      sh_rem = n;
+      sh_e = 0;
+    }
+    __syncthreads();
+
+    while (true) {
+      // ---- in front of a window: the insignificant entries up to the next '1' of the list are
+      //      counted off the stream by the whole workgroup, 64 Kbit per round (no tables: in the
+      //      sparse planes whole lists go this way)
+      while (sh_depth == 1) {
+        __syncthreads();
+        if (tid == 0)
+          sh_zfound = 0xffffffffu;
+        __syncthreads();
+        const uint64_t pos = sh_pos;
+        const uint32_t rem = sh_rem;
+        const uint32_t off = (uint32_t)(pos & 63);
+        const uint64_t wi = (pos >> 6) + (uint32_t)tid;
+        uint64_t w = wi < nwordsAvail ? words[wi] : 0ull;
+        if (tid == 0)
+          w &= ~0ull << off;
+        if (w)
+          atomicMin(&sh_zfound, (uint32_t)tid * 64u + (uint32_t)__ffsll((long long)w) - 1u);
+        __syncthreads();
+        const uint32_t f = sh_zfound;
+        const uint32_t zeros = (f == 0xffffffffu ? (uint32_t)kTabThreads * 64u : f) - off;
+        const uint32_t z = min(zeros, rem);
+        __syncthreads();
+        if (tid == 0) {
+          sh_pos = pos + z;
+          sh_e += z;
+          sh_rem = rem - z;
+          if (rem == z)
+            sh_depth = 0;
+        }
+        __syncthreads();
+        if (f != 0xffffffffu || rem == z)
+          break;
+      }
+      __syncthreads();
+      if (sh_depth == 0)
+        break;
+      const uint64_t a = sh_pos;
+      const uint32_t e0 = sh_e;
+      const uint32_t ecnt = min(sh_rem, W);
+      __syncthreads();  // everyone has read the walker's state before thread 0 changes it
+      const uint64_t w0 = a >> 6;
+      wq0 = (uint32_t)(a & 63);
+      for (uint32_t i = tid; i < kWords; i += kTabThreads) {
+        const uint64_t idx = w0 + i;
+        wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
+      }
+      // classes of the list entries this window can reach
+      for (uint32_t i = tid; i < ecnt; i += kTabThreads)
+        ecls[i] = (uint8_t)node_cls(t, unpack_node(list[e0 + i]));
+      __syncthreads();
+      STAMP(0);
+      // ---- tables, lowest classes first (slots are sorted by h)
+      {
+        uint32_t hprev = 0;
+        for (uint32_t sl = 0; sl < nslots; sl++) {
+          const uint32_t ci = sh_slotCls[sl];
+          const uint32_t hh = sh_cls[ci].h;
+          if (hh != hprev) {
+            __syncthreads();
+            hprev = hh;
+          }
+          uint16_t* Ts = Tt + (size_t)sl * TS;
+          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
+            const uint32_t r2 = r + kTabThreads;
+            const uint32_t t1 = split_len(ci, r);
+            const uint32_t t2 = r2 <= W + 1 ? split_len(ci, r2) : kTInf;
+            Ts[r] = (uint16_t)t1;
+            if (r2 <= W + 1)
+              Ts[r2] = (uint16_t)t2;
+          }
+        }
+      }
+      __syncthreads();
+      STAMP(1);
+      // ---- the walk: one thread
+      if (tid == 0) {
+        uint32_t r = 0, e = sh_e, rem = sh_rem, qn = 0;
+        int depth = sh_depth;
+        while (true) {
+          if (depth > 1) {
+            MixCtx& cx = sh_ctx[depth - 1];
+            const uint32_t pc = cx.pc;
+            const uint32_t nk = sh_cls[pc].nk;
+            const uint32_t k = cx.next;
+            if (k == nk) {
+              depth--;
+              continue;
+            }
+            const uint32_t kc = sh_cls[pc].kid[k];
+            const bool coded = cx.found || (k + 1 != nk);
+            uint32_t x = r, bit = 1;
+            if (coded) {
+              if (x >= W)
+                break;
+              bit = bit_at(x);
+              x++;
+            }
+            if (kc == kClsPixel) {
+              if (bit && x >= W)
+                break;
+              const uint32_t ridx = kid_pixel_raster(t, unpack_node(cx.parent), cx.kb, k);
+              pixel_event(ridx, bit != 0, bit ? bit_at(x) : 1u);
+              if (bit) {
+                x++;
+                cx.found = 1;
+              }
+              cx.next = (uint8_t)(k + 1);
+              r = x;
+              continue;
+            }
+            const uint64_t kid = kid_packed(cx.kb, k);
+            if (!bit) {
+              record_born(cx.kb.kidlev, a + x - 1, kid);
+              cx.next = (uint8_t)(k + 1);
+              r = x;
+              continue;
+            }
+            const uint32_t sl = sh_cls[kc].slot;
+            if (sl != 0xff) {
+              const uint32_t tl = Tt[(size_t)sl * TS + min(x, W + 1)];
+              if (tl == kTInf)
+                break;   // the next window starts at this child's first bit
+              qbuf[0][qn * 2] = kid;
+              qbuf[0][qn * 2 + 1] = ((uint64_t)x << 16) | ((uint64_t)kc << 8);
+              qn++;
+              cx.found = 1;
+              cx.next = (uint8_t)(k + 1);
+              r = x + tl;
+            }
+            else {
+              cx.found = 1;
+              cx.next = (uint8_t)(k + 1);
+              r = x;
+              MixCtx& nc = sh_ctx[depth];
+              nc.parent = kid;
+              kid_box(t, unpack_node(kid), nc.kb);
+              nc.pc = (uint8_t)kc;
+              nc.next = 0;
+              nc.found = 0;
+              depth++;
+            }
+            continue;
+          }
+          // the list itself
+          if (rem == 0) {
+            depth = 0;
+            break;
+          }
+          if (r >= W)
+            break;
+          {
+            const uint64_t bits = (uint64_t)bits32(r) | ((uint64_t)bits32(r + 32) << 32);
+            const uint32_t z = min(min(bits ? (uint32_t)__ffsll((long long)bits) - 1u : 64u, rem), W - r);
+            if (z) {
+              r += z;
+              e += z;
+              rem -= z;
+              continue;
+            }
+          }
+          // entry e is significant
+          const uint32_t ci = ecls[e - e0];
+          const uint32_t sl = sh_cls[ci].slot;
+          const uint32_t x = r + 1;
+          if (sl != 0xff) {
+            const uint32_t tl = Tt[(size_t)sl * TS + min(x, W + 1)];
+            if (tl == kTInf)
+              break;   // the next window starts at this entry
+            qbuf[0][qn * 2] = e;
+            qbuf[0][qn * 2 + 1] = ((uint64_t)x << 16) | ((uint64_t)ci << 8) | 1ull;
+            qn++;
+            r = x + tl;
+          }
+          else {
+            const uint64_t packed = list[e];
+            atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
+            MixCtx& nc = sh_ctx[1];
+            nc.parent = packed;
+            kid_box(t, unpack_node(packed), nc.kb);
+            nc.pc = (uint8_t)ci;
+            nc.next = 0;
+            nc.found = 0;
+            depth = 2;
+            r = x;
+          }
+          e++;
+          rem--;
+        }
+        // (a window that changes nothing would be walked for ever: cannot happen while the window is
+        // longer than every split that has a table, which the host checks -- kept as a guard)
+        const bool stuck = r == 0 && e == sh_e && depth == sh_depth && qn == 0;
+        sh_pos = a + r;
+        sh_e = e;
+        sh_rem = rem;
+        sh_depth = stuck ? -1 : depth;
+        sh_qn[0] = qn;
+        sh_qn[1] = 0;
+        sh_qn[2] = 0;
+      }
+      __syncthreads();
+      if (sh_depth < 0) {
+        if (tid == 0) {
+          s.error = 1;
+          s.done = 1;
+        }
+        return;
+      }
+      STAMP(2);
+      if (stamps)
+        stamp_acc[9] += 1;
+      // ---- expand, breadth first
+      for (int round = 0;; round++) {
+        const uint32_t nin = sh_qn[round % 3];
+        if (nin == 0)
+          break;
+        const uint64_t* qin = qbuf[round & 1];
+        uint64_t* qout = qbuf[(round + 1) & 1];
+        for (uint32_t i = tid; i < nin; i += kTabThreads) {
+          const uint64_t ident = qin[i * 2], meta = qin[i * 2 + 1];
+          const uint32_t ci = (uint32_t)(meta >> 8) & 0xffu;
+          uint32_t y = (uint32_t)(meta >> 16);
+          uint64_t packed = ident;
+          if (meta & 1ull) {
+            packed = list[ident];
+            atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
+          }
+          const Node nd = unpack_node(packed);
+          const uint32_t nk = sh_cls[ci].nk;
+          if (sh_cls[ci].h == 0) {
+            // a leaf parent: its pixel results become ONE event word (node id, significance and
+            // sign masks by child ordinal) that k_leaf_apply turns into mask updates GPU-wide
+            const uint32_t v = bits32(y);
+            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
+            for (uint32_t k = 0; k < nk; k++) {
+              const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+              const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+              yy += coded;
+              const uint32_t sgn = (v >> yy) & 1u;
+              sigm |= bit << k;
+              negm |= (bit & (sgn ^ 1u)) << k;
+              found |= bit;
+              yy += bit;
+            }
+            const Grid& g = t.grids[nd.grid];
+            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
+                                 nd.i[0];
+            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
+            if (slot < b.leafCap)
+              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+            continue;
+          }
+          KidBox kb;
+          kid_box(t, nd, kb);
+          const uint64_t ks = sh_kslot[ci];
+          uint32_t found = 0;
+          for (uint32_t k = 0; k < nk; k++) {
+            const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+            const uint32_t bit = coded ? bit_at(y) : 1u;
+            y += coded;
+            const uint32_t sl = (uint32_t)(ks >> (8 * k)) & 0xffu;
+            if (sl == 0xfeu) {
+              pixel_event(kid_pixel_raster(t, nd, kb, k), bit != 0, bit ? bit_at(y) : 1u);
+              y += bit;
+            }
+            else if (bit) {
+              const uint32_t slot = atomicAdd(&sh_qn[(round + 1) % 3], 1u);
+              qout[slot * 2] = kid_packed(kb, k);
+              qout[slot * 2 + 1] = ((uint64_t)y << 16) | ((uint64_t)sh_cls[ci].kid[k] << 8);
+              y += Tt[(size_t)sl * TS + y];
+            }
+            else
+              record_born(kb.kidlev, a + y - 1, kid_packed(kb, k));
+            found |= bit;
+          }
+        }
+        if (tid == 0)
+          sh_qn[(round + 2) % 3] = 0;   // the counter of the round after next
+        __syncthreads();
+      }
+      STAMP(3);
+    }
+    // ---- old entries that stayed insignificant keep their order
+    {
+      __syncthreads();
+      uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
+      uint32_t carry = 0;
+      const uint32_t nw = (n + 63) / 64;
+      for (uint32_t base = 0; base < nw; base += kTabThreads) {
+        const uint32_t wi = base + tid;
+        uint64_t stay = 0;
+        if (wi < nw) {
+          stay = ~__hip_atomic_load(sigbits + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t valid = n - wi * 64;
+          if (valid < 64)
+            stay &= (1ull << valid) - 1;
+        }
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), sh_scan, &total) + carry;
+        while (stay) {
+          const int k = __ffsll((long long)stay) - 1;
+          stay &= stay - 1;
+          keep[ex++] = list[wi * 64 + k];
+        }
+        carry += total;
+      }
+      if (tid == 0)
+        s.listLen[nx][l] = carry;
+      __syncthreads();
+    }
+    STAMP(4);
+  }
+
+  __syncthreads();
+  const uint64_t phaseBits = min(sh_pos - phase0, maskBits);
+  if (stamps) {
+    uint64_t* out = b.lisStamps + (size_t)c * 64;
+    for (int i = 0; i < 10; i++)
+      out[i] += stamp_acc[i];
+  }
+#undef STAMP
+  if (tid == 0) {
+    s.cur = nx;
+    s.pos = sh_pos;
+    s.nLeafEv = min(sh_leaf, b.leafCap);
+    s.bornCount = min(sh_born, (uint32_t)b.bornStride);
+    s.lisPhaseBits = phaseBits;
+    s.lastPlane = p;
+    if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
+      s.done = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LIS phase, lists of the 8x8x8 and larger sets, GPU-WIDE: k_lis_tables' method (speculative
 // tables per window, pointer jumping over the list entries, breadth-first expansion of the sets
 // that split inside the window) with the windows at FIXED places, so that several workgroups per
@@ -3588,6 +4138,20 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
       b.leafState[c * b.leafStateStride + (uint32_t)ev] = (uint16_t)(sigm | (negm << 8));
       continue;
     }
+    if (!(g.kind & kGridOct)) {   // any shape (events of k_lis_mixed): the existing children by ordinal
+      KidBox kb;
+      kid_box(t, nd, kb);
+      for (uint32_t q = 0; q < kb.nk; q++) {
+        const uint32_t ridx = kid_pixel_raster(t, nd, kb, q);
+        const unsigned long long m = 1ull << (ridx & 63);
+        atomicOr(bornM + (ridx >> 6), m);
+        if ((sigm >> q) & 1u)
+          atomicOr(sigNew + (ridx >> 6), m);
+        if ((negm >> q) & 1u)
+          atomicAnd(sign + (ridx >> 6), ~m);
+      }
+      continue;
+    }
     const Root rt = t.roots[g.root];
     uint32_t cbase[3], cshift[3], nb = 0;
     for (int ax = 0; ax < 3; ax++) {
@@ -3829,6 +4393,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   // 70.8 / 75.3 / 76.3 / 76.0 / 75.0 / 74.5 / 74.3 GB/s of decompression)
   static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 192u;
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
+  if (plan.mixed) {
+    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<uint32_t>), (int)b.mixSmemBytes) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<uint64_t>), (int)b.mixSmemBytes))
+      return -1;
+  }
   if (plan.tables && plan.hi) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint32_t>), (int)b.hiSmemBytes) ||
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint64_t>), (int)b.hiSmemBytes))
@@ -3855,6 +4424,14 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
           LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
         else
           return -1;
+        if (b.nSlots) {
+          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+        }
+        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
+      }
+      else if (plan.mixed) {
+        LAUNCH_K(k_lis_mixed<uint64_t>, dim3(nc), dim3(kTabThreads), b.mixSmemBytes, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -3888,6 +4465,14 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         }
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
+      else if (plan.mixed) {
+        LAUNCH_K(k_lis_mixed<uint32_t>, dim3(nc), dim3(kTabThreads), b.mixSmemBytes, stream, b, p);
+        if (b.nSlots) {
+          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
+          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+        }
+        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
+      }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
       LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
@@ -3897,7 +4482,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   {
     const uint32_t n = b.tree.nvals;
-    if (plan.tables && b.wordLeaf)
+    if ((plan.tables || plan.mixed) && b.wordLeaf)
       LAUNCH_K(k_dec_fold, dim3(((n + 63) / 64 + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
                stream, b);
     if (!plan.skipFinish) {

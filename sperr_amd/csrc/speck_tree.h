@@ -65,6 +65,22 @@ struct Grid {          // all nodes of one root at one depth, as a dense 3D arra
   uint8_t kind;        // kGridOct or 0
 };
 
+// The CODE of a set (the bits its split takes, /root/reference/src/SPECK3D_INT.cpp:140-212) depends
+// on the set's extents only: every axis longer than one sample is cut into (len - len/2, len/2),
+// the children come x fastest, and so on down to single samples.  Sets with the same structure
+// share a SHAPE CLASS; the decoder of chunks whose lists mix shapes (k_lis_mixed) keys its
+// speculative tables by class instead of by list level.  Classes are numbered children first.
+constexpr uint8_t kClsPixel = 0xff;   // "class" of a single sample
+constexpr int kMaxCls = 254;
+struct ShapeCls {
+  uint8_t nk;              // children, 1..8 (empty halves do not exist)
+  uint8_t h;               // 0: every child is a single sample; else 1 + the largest h of a child
+  uint8_t slot;            // table slot of the class, 0xff: no table (such sets are walked into)
+  uint8_t nsplit;          // axes longer than one sample: the children's list level is the set's + nsplit
+  uint8_t kid[8];          // class of child k in the reference's order
+  uint32_t maxT;           // upper bound of the bits of a split
+};
+
 // Everything a kernel needs to know about one chunk shape.  Arrays live in device memory (or
 // host memory for the CPU model); the struct itself is passed by value.
 struct Tree {
@@ -78,6 +94,10 @@ struct Tree {
   const Grid* grids;
   const uint16_t* tab;     // interval start tables
   const uint16_t* blockGrid;  // grid index of every kNodeBlock-sized block of flat node ids
+  // shape classes (ncls == 0: more than kMaxCls, not available)
+  uint32_t ncls, nslots;
+  const ShapeCls* cls;
+  const uint8_t* gridCls;  // [grid][8]: class of a node by which of its three intervals are the long ones
 };
 
 struct Node {
@@ -297,6 +317,72 @@ SPK_HD Node node_parent(const Tree& t, const Node& n)
 SPK_HD bool node_is_root(const Tree& t, const Node& n)
 {
   return t.grids[n.grid].depth == 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Shape classes: class of a node, and its children by ordinal in O(1)
+// ------------------------------------------------------------------------------------------
+SPK_HD uint32_t node_cls(const Tree& t, const Node& n)
+{
+  const Grid& g = t.grids[n.grid];
+  const Root& r = t.roots[g.root];
+  uint32_t k = 0;
+  for (int a = 0; a < 3; a++) {
+    const int e = g.e[a];
+    const uint32_t rem = (uint32_t)r.len[a] & ((1u << e) - 1u);
+    k |= (bitrev(n.i[a], e) < rem ? 1u : 0u) << a;
+  }
+  return t.gridCls[(uint32_t)n.grid * 8u + k];
+}
+
+// The non-empty children of a set are a box of n[0] x n[1] x n[2] (each 1 or 2) child intervals:
+// child k (x fastest) has index base[a] + its selector on every axis.
+struct KidBox {
+  uint32_t base[3];
+  uint32_t n[3];
+  int e[3];              // the children's effective depth per axis
+  uint32_t nk;           // n[0] * n[1] * n[2]
+  uint32_t kidlev;       // LIS level of the children that are sets
+  uint16_t grid;         // their grid (meaningless when they are single samples of the deepest depth)
+};
+
+SPK_HD void kid_box(const Tree& t, const Node& nd, KidBox& k)
+{
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  k.grid = (uint16_t)(nd.grid + 1);
+  k.kidlev = node_level(t, nd);
+  for (int a = 0; a < 3; a++) {
+    const bool splits = g.depth < r.D[a];
+    k.e[a] = splits ? g.e[a] + 1 : g.e[a];
+    k.base[a] = splits ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
+    k.n[a] = (splits && axis_len(r.len[a], k.e[a], k.base[a] + 1u) > 0) ? 2u : 1u;
+    k.kidlev += k.n[a] - 1u;   // (an interval longer than one sample has two non-empty halves)
+  }
+  k.nk = k.n[0] * k.n[1] * k.n[2];
+}
+
+SPK_HD void kid_index(const KidBox& k, uint32_t ord, uint32_t idx[3])
+{
+  idx[0] = k.base[0] + (k.n[0] == 2 ? (ord & 1u) : 0u);
+  const uint32_t o1 = k.n[0] == 2 ? ord >> 1 : ord;
+  idx[1] = k.base[1] + (k.n[1] == 2 ? (o1 & 1u) : 0u);
+  const uint32_t o2 = k.n[1] == 2 ? o1 >> 1 : o1;
+  idx[2] = k.base[2] + o2;
+}
+
+SPK_HD uint64_t kid_packed(const KidBox& k, uint32_t ord)
+{
+  uint32_t idx[3];
+  kid_index(k, ord, idx);
+  return ((uint64_t)k.grid << 48) | ((uint64_t)idx[2] << 32) | ((uint64_t)idx[1] << 16) | idx[0];
+}
+
+SPK_HD uint32_t kid_pixel_raster(const Tree& t, const Node& parent, const KidBox& k, uint32_t ord)
+{
+  uint32_t idx[3];
+  kid_index(k, ord, idx);
+  return pixel_raster(t, t.roots[t.grids[parent.grid].root], k.e, idx);
 }
 
 // ------------------------------------------------------------------------------------------

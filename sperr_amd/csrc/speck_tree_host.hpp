@@ -11,6 +11,7 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <vector>
 
 #include "speck_tree.h"
@@ -67,6 +68,10 @@ struct HostTree {
   std::vector<uint32_t> levelOff;              // exclusive prefix of levelCap (+ total at end)
   std::vector<LevelClass> levelClass;          // per level: regular shape chain (or regular = 0)
   bool allRegular = false;                     // every level that can hold sets is regular
+  std::vector<ShapeCls> cls;                   // shape classes, children first (empty: too many)
+  std::vector<uint8_t> gridCls;                // [grid][8]
+  uint32_t nslots = 0;                         // classes that have a table slot
+  uint32_t slotMaxT = 0;                       // longest split of a class with a table
   uint32_t dims[3] = {0, 0, 0};
   uint32_t nnodes = 0, nlevels = 0, maxDepth = 0, nsets = 0;
 
@@ -85,6 +90,10 @@ struct HostTree {
     t.grids = grids.data();
     t.tab = tab.data();
     t.blockGrid = blockGrid.data();
+    t.ncls = (uint32_t)cls.size();
+    t.nslots = nslots;
+    t.cls = cls.data();
+    t.gridCls = gridCls.data();
     return t;
   }
 };
@@ -101,6 +110,127 @@ inline int ceil_log2(uint32_t v)
   return e;
 }
 }  // namespace detail
+
+constexpr int kClsTableH = 1;            // default: tables for leaf parents and their parents
+constexpr uint32_t kClsTableSlots = 24;
+
+// Shape classes of every set of the forest (speck_tree.h, ShapeCls).  Classes whose sets are at
+// most `hmax` splits above single samples get a table slot, as many as `maxSlots` allows.
+inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots)
+{
+  h.cls.clear();
+  h.gridCls.assign(h.grids.size() * 8, kClsPixel);
+  h.nslots = 0;
+  h.slotMaxT = 0;
+  std::map<std::array<uint32_t, 3>, int> byDims;
+  std::map<std::array<uint8_t, 9>, int> byStruct;
+  bool overflow = false;
+  auto intern = [&](const ShapeCls& c) -> int {
+    std::array<uint8_t, 9> key{};
+    key[0] = c.nk;
+    for (int k = 0; k < 8; k++)
+      key[1 + k] = k < c.nk ? c.kid[k] : 0;
+    auto it = byStruct.find(key);
+    if (it != byStruct.end())
+      return it->second;
+    if ((int)h.cls.size() >= kMaxCls) {
+      overflow = true;
+      return 0;
+    }
+    h.cls.push_back(c);
+    byStruct[key] = (int)h.cls.size() - 1;
+    return (int)h.cls.size() - 1;
+  };
+  // class of a set of `d` samples per axis (more than one sample in all)
+  auto of_dims = [&](auto&& self, const std::array<uint32_t, 3>& d) -> int {
+    auto it = byDims.find(d);
+    if (it != byDims.end())
+      return it->second;
+    uint32_t part[3][2], n[3];
+    for (int a = 0; a < 3; a++) {
+      part[a][1] = d[a] > 1 ? d[a] / 2 : 0;
+      part[a][0] = d[a] - part[a][1];
+      n[a] = d[a] > 1 ? 2 : 1;
+    }
+    ShapeCls c{};
+    c.slot = 0xff;
+    c.nsplit = (uint8_t)((n[0] - 1) + (n[1] - 1) + (n[2] - 1));
+    uint64_t maxT = 0;
+    int hh = 0;
+    for (uint32_t cz = 0; cz < n[2]; cz++)
+      for (uint32_t cy = 0; cy < n[1]; cy++)
+        for (uint32_t cx = 0; cx < n[0]; cx++) {
+          const std::array<uint32_t, 3> kd = {part[0][cx], part[1][cy], part[2][cz]};
+          if (kd[0] * kd[1] * kd[2] == 1) {
+            c.kid[c.nk++] = kClsPixel;
+            maxT += 2;
+          }
+          else {
+            const int kc = self(self, kd);
+            c.kid[c.nk++] = (uint8_t)kc;
+            if (!overflow) {
+              maxT += 1 + (uint64_t)h.cls[kc].maxT;
+              hh = std::max(hh, 1 + (int)h.cls[kc].h);
+            }
+          }
+        }
+    c.h = (uint8_t)std::min(hh, 255);
+    c.maxT = (uint32_t)std::min<uint64_t>(maxT, 0xffffffffu);
+    const int id = intern(c);
+    byDims[d] = id;
+    return id;
+  };
+  const Tree t = h.view();
+  for (uint32_t gi = 0; gi < h.grids.size() && !overflow; gi++) {
+    const Grid& g = h.grids[gi];
+    const Root& r = h.roots[g.root];
+    for (uint32_t k = 0; k < 8 && !overflow; k++) {
+      std::array<uint32_t, 3> d;
+      bool exists = true;
+      for (int a = 0; a < 3; a++) {
+        const uint32_t rem = (uint32_t)r.len[a] & ((1u << g.e[a]) - 1u);
+        const uint32_t longer = (k >> a) & 1u;
+        if (longer && rem == 0)
+          exists = false;
+        d[a] = ((uint32_t)r.len[a] >> g.e[a]) + longer;
+      }
+      const uint32_t cnt = d[0] * d[1] * d[2];
+      if (!exists || cnt == 0)
+        continue;
+      if (cnt == 1) {
+        if (g.depth == 0) {   // a one-sample root still is a set, with one pixel child
+          ShapeCls c{};
+          c.nk = 1;
+          c.slot = 0xff;
+          c.kid[0] = kClsPixel;
+          c.maxT = 2;
+          h.gridCls[gi * 8 + k] = (uint8_t)intern(c);
+        }
+        continue;
+      }
+      h.gridCls[gi * 8 + k] = (uint8_t)of_dims(of_dims, d);
+    }
+  }
+  (void)t;
+  if (overflow) {
+    h.cls.clear();
+    return;
+  }
+  // table slots: lowest classes first (a class with a table needs tables of all its children)
+  for (int hh = 0; hh <= hmax; hh++)
+    for (size_t i = 0; i < h.cls.size(); i++) {
+      ShapeCls& c = h.cls[i];
+      if (c.h != hh || c.maxT > 0x7000u || h.nslots >= maxSlots)
+        continue;
+      bool ok = true;
+      for (int k = 0; k < c.nk; k++)
+        ok = ok && (c.kid[k] == kClsPixel || h.cls[c.kid[k]].slot != 0xff);
+      if (!ok)
+        continue;
+      c.slot = (uint8_t)h.nslots++;
+      h.slotMaxT = std::max(h.slotMaxT, c.maxT);
+    }
+}
 
 inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
 {
@@ -294,6 +424,7 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
       c.lev[j] = (uint8_t)lv[K - 1 - j];
     }
   }
+  build_classes(h, kClsTableH, kClsTableSlots);
   return h;
 }
 

@@ -956,4 +956,317 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Model of the LIS-phase decoder for chunks whose lists mix set shapes (kernel k_lis_mixed in
+// speck_dec.hip).  The code of a set depends on its extents only (spk::ShapeCls): per window of W
+// stream bits the kernel builds, for every class that has a table slot and EVERY bit position, the
+// length of a split of that class starting there (speculative, parallel); ONE thread then walks
+// the list -- runs of '0' entries counted off the stream, a significant entry of a class with a
+// table hopped over with one look-up (its class read from the entry), any other set walked into
+// child by child with the tables of its children -- and every set that was hopped over is expanded
+// by an independent thread.  Births are ranked by stream position as in the regular model.
+// ------------------------------------------------------------------------------------------
+int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t dims[3],
+                               uint64_t* coef, uint64_t* sign, int window, int hmax)
+{
+  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  build_classes(ht, hmax, 24);
+  if (ht.cls.empty())
+    return -2;
+  const Tree t = ht.view();
+  const std::vector<ShapeCls>& cls = ht.cls;
+  uint64_t W = window > 0 ? (uint64_t)window : 256;
+  if (W < (uint64_t)ht.slotMaxT + 2)
+    W = (uint64_t)ht.slotMaxT + 2;
+  const size_t N = t.nvals;
+  const int nbp = stream[0];
+  uint64_t total_bits;
+  memcpy(&total_bits, stream + 1, 8);
+  uint64_t avail = (uint64_t)(len - 9) * 8;
+  if (avail > total_bits)
+    avail = total_bits;
+  BitSrc in{stream + 9, avail};
+  std::vector<int8_t> born(N, -1), sigp(N, -1);
+  memset(coef, 0, N * sizeof(uint64_t));
+  memset(sign, 0xff, ((N + 63) / 64) * 8);
+  auto set_sign = [&](uint32_t i, int b) {
+    if (b)
+      sign[i >> 6] |= uint64_t(1) << (i & 63);
+    else
+      sign[i >> 6] &= ~(uint64_t(1) << (i & 63));
+  };
+  std::vector<std::vector<uint64_t>> lis(ht.initLIS), next(t.nlevels);
+  uint64_t pos = 0;
+  for (int p = nbp - 1; p >= 0; p--) {
+    const uint64_t thr = uint64_t(1) << p;
+    const uint64_t init = thr + thr - thr / 2 - 1;
+    {  // ---- D1 (as in model_speck3d_decode)
+      std::vector<uint32_t> cand;
+      for (size_t i = 0; i < N; i++)
+        if (born[i] > p && sigp[i] < 0)
+          cand.push_back((uint32_t)i);
+      size_t j = 0;
+      uint64_t k = 0, ones = 0;
+      for (; j < cand.size(); k++) {
+        const int b = in.get(pos + k);
+        if ((ones & 1) == 0) {
+          if (b) {
+            sigp[cand[j]] = (int8_t)p;
+            coef[cand[j]] = init;
+            set_sign(cand[j], in.get(pos + k + 1));
+          }
+          j++;
+        }
+        ones = b ? ones + 1 : 0;
+      }
+      if (ones & 1)
+        k++;
+      pos += k;
+    }
+    // ---- D2
+    struct BornRec {
+      uint32_t lev;
+      uint64_t pos;
+      uint64_t packed;
+    };
+    std::vector<BornRec> bornv;
+    for (uint32_t l = 0; l < t.nlevels; l++)
+      next[l].clear();
+    auto pixel_event = [&](uint32_t ridx, bool sig, uint64_t signpos) {
+      born[ridx] = (int8_t)p;
+      if (sig) {
+        sigp[ridx] = (int8_t)p;
+        coef[ridx] = init;
+        set_sign(ridx, in.get(signpos));
+      }
+    };
+    struct Ctx {
+      Node parent;
+      uint32_t pc;
+      KidBox kb;
+      uint32_t next;
+      bool found;
+    };
+    struct Item {
+      Node nd;
+      uint32_t c;
+      uint64_t y;   // first bit of the split, window-relative
+    };
+    for (uint32_t l = t.nlevels; l-- > 0;) {
+      const size_t n = lis[l].size();
+      if (n == 0)
+        continue;
+      std::vector<char> sigv(n, 0);
+      std::vector<Ctx> ctx;
+      size_t e = 0, rem = n;
+      bool listDone = false;
+      auto push_ctx = [&](const Node& nd, uint32_t c) {
+        Ctx cx;
+        cx.parent = nd;
+        cx.pc = c;
+        kid_box(t, nd, cx.kb);
+        cx.next = 0;
+        cx.found = false;
+        if (cx.kb.nk != cls[c].nk)
+          abort();
+        ctx.push_back(cx);
+      };
+      while (!listDone) {
+        const uint64_t a = pos;
+        // ---- tables of the window (parallel in the kernel: one thread per position and slot)
+        std::vector<std::vector<uint32_t>> T(ht.nslots, std::vector<uint32_t>(W + 2, T_INF));
+        for (uint32_t s = 0; s < ht.nslots; s++) {
+          uint32_t ci = 0;
+          while (cls[ci].slot != s)
+            ci++;
+          const ShapeCls& C = cls[ci];
+          for (uint64_t x = 0; x <= W; x++) {
+            uint64_t y = x;
+            bool found = false, ok = true;
+            for (uint32_t k = 0; k < C.nk && ok; k++) {
+              const bool coded = found || (k + 1 != C.nk);
+              int b = 1;
+              if (coded)
+                b = in.get(a + y++);
+              if (!b)
+                continue;
+              found = true;
+              if (C.kid[k] == kClsPixel)
+                y++;
+              else {
+                const uint32_t tl = y <= W ? T[cls[C.kid[k]].slot][y] : T_INF;
+                if (tl == T_INF)
+                  ok = false;
+                else
+                  y += tl;
+              }
+            }
+            if (ok && y <= W)
+              T[s][x] = (uint32_t)(y - x);
+          }
+        }
+        // ---- one thread: the walk
+        std::vector<Item> queue;
+        uint64_t r = 0;
+        while (true) {
+          if (!ctx.empty()) {
+            Ctx& cx = ctx.back();
+            const ShapeCls& C = cls[cx.pc];
+            if (cx.next == C.nk) {
+              ctx.pop_back();
+              continue;
+            }
+            const uint32_t k = cx.next, kc = C.kid[k];
+            const bool coded = cx.found || (k + 1 != C.nk);
+            uint64_t x = r;
+            int b = 1;
+            if (coded) {
+              if (x >= W)
+                break;
+              b = in.get(a + x);
+              x++;
+            }
+            if (kc == kClsPixel) {
+              if (b && x >= W)
+                break;
+              pixel_event(kid_pixel_raster(t, cx.parent, cx.kb, k), b != 0, a + x);
+              if (b) {
+                x++;
+                cx.found = true;
+              }
+              cx.next++;
+              r = x;
+              continue;
+            }
+            if (!b) {
+              bornv.push_back({cx.kb.kidlev, a + x - 1, kid_packed(cx.kb, k)});
+              cx.next++;
+              r = x;
+              continue;
+            }
+            const Node kid = unpack_node(kid_packed(cx.kb, k));
+            if (cls[kc].slot != 0xff) {
+              const uint32_t tl = x <= W ? T[cls[kc].slot][x] : T_INF;
+              if (tl == T_INF) {
+                if (r == 0)
+                  abort();   // (the window is longer than any split that has a table)
+                break;
+              }
+              queue.push_back({kid, kc, x});
+              cx.found = true;
+              cx.next++;
+              r = x + tl;
+            }
+            else {
+              cx.found = true;
+              cx.next++;
+              r = x;
+              push_ctx(kid, kc);
+            }
+            continue;
+          }
+          // the list itself
+          if (rem == 0) {
+            listDone = true;
+            break;
+          }
+          if (r >= W)
+            break;
+          if (!in.get(a + r)) {
+            r++;
+            e++;
+            rem--;
+            continue;
+          }
+          const Node nd = unpack_node(lis[l][e]);
+          const uint32_t c = node_cls(t, nd);
+          if (c == kClsPixel)
+            abort();
+          const uint64_t x = r + 1;
+          if (cls[c].slot != 0xff) {
+            const uint32_t tl = x <= W ? T[cls[c].slot][x] : T_INF;
+            if (tl == T_INF) {
+              if (r == 0)
+                abort();
+              break;
+            }
+            queue.push_back({nd, c, x});
+            r = x + tl;
+          }
+          else {
+            r = x;
+            push_ctx(nd, c);
+          }
+          sigv[e] = 1;
+          e++;
+          rem--;
+        }
+        pos = a + r;
+        // ---- expansion of what was hopped over (parallel, breadth first in the kernel)
+        while (!queue.empty()) {
+          std::vector<Item> nq;
+          for (const Item& w : queue) {
+            const ShapeCls& C = cls[w.c];
+            KidBox kb;
+            kid_box(t, w.nd, kb);
+            if (kb.nk != C.nk)
+              abort();
+            uint64_t y = w.y;
+            bool found = false;
+            for (uint32_t k = 0; k < C.nk; k++) {
+              const bool coded = found || (k + 1 != C.nk);
+              int b = 1;
+              if (coded)
+                b = in.get(a + y++);
+              if (C.kid[k] == kClsPixel) {
+                pixel_event(kid_pixel_raster(t, w.nd, kb, k), b != 0, a + y);
+                if (b) {
+                  y++;
+                  found = true;
+                }
+              }
+              else if (b) {
+                found = true;
+                nq.push_back({unpack_node(kid_packed(kb, k)), C.kid[k], y});
+                y += T[cls[C.kid[k]].slot][y];
+              }
+              else
+                bornv.push_back({kb.kidlev, a + y - 1, kid_packed(kb, k)});
+            }
+          }
+          queue.swap(nq);
+        }
+      }
+      for (size_t k = 0; k < n; k++)
+        if (!sigv[k])
+          next[l].push_back(lis[l][k]);
+    }
+    std::stable_sort(bornv.begin(), bornv.end(), [](const BornRec& x, const BornRec& y) {
+      return x.lev != y.lev ? x.lev < y.lev : x.pos < y.pos;
+    });
+    for (const BornRec& b : bornv)
+      next[b.lev].push_back(b.packed);
+    lis.swap(next);
+    if (pos >= avail)
+      break;
+    {  // ---- D3
+      const uint64_t half = thr / 2;
+      uint64_t j = 0;
+      for (size_t i = 0; i < N && pos + j < avail; i++)
+        if (sigp[i] > p) {
+          const int b = in.get(pos + j);
+          j++;
+          if (thr >= 2)
+            coef[i] = b ? coef[i] + half : coef[i] - half;
+          else if (b)
+            coef[i]++;
+        }
+      pos += j;
+    }
+    if (pos >= avail)
+      break;
+  }
+  return 0;
+}
+
 }  // extern "C"

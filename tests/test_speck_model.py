@@ -123,3 +123,39 @@ def test_model_table_driven_decoder_matches_oracle(oracle, model, shape, window)
                 c1, s1 = model_decode_par(model, s, shape, window)
                 assert np.array_equal(c0, c1)
                 assert np.array_equal(s0, s1)
+
+
+def model_decode_mixed(lib, stream, shape, window, hmax):
+    dz, dy, dx = shape
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    coef = np.zeros(shape, dtype=np.uint64)
+    sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+    lib.model_speck3d_decode_mixed.argtypes = [_vp, _sz, _vp, _vp, _vp, C.c_int, C.c_int]
+    lib.model_speck3d_decode_mixed.restype = C.c_int
+    rc = lib.model_speck3d_decode_mixed(buf.ctypes.data, buf.size, (_sz * 3)(dx, dy, dz),
+                                        coef.ctypes.data, sign.ctypes.data, window, hmax)
+    assert rc == 0
+    return coef, sign
+
+
+MIXED_SHAPES = [(17, 17, 17), (13, 21, 30), (3, 5, 7), (1, 16, 16), (2, 2, 2), (48, 48, 48), (1, 1, 1),
+                (9, 40, 48), (41, 64, 64), (25, 25, 25), (31, 33, 30), (20, 18, 16), (12, 12, 12),
+                (1, 1, 9), (5, 1, 1), (16, 16, 16), (50, 35, 17)]
+
+
+@pytest.mark.parametrize("shape", MIXED_SHAPES)
+@pytest.mark.parametrize("window,hmax", [(64, 0), (150, 1), (4096, 1), (1200, 2), (300, -1)])
+def test_model_mixed_shape_decoder_matches_oracle(oracle, model, shape, window, hmax):
+    """Shape-class tables + one serial walk + parallel expansion (k_lis_mixed's formulation) on
+    chunks whose lists mix set shapes: odd lengths, wavelet-packet shapes, tiny chunks; small
+    windows stress the window boundaries, hmax = -1 walks into every set (no tables at all)."""
+    for scale in (3000.0, 4294967295.0):
+        coef, sign = quantized(oracle, shape, scale)
+        for budget in (0, 30000):
+            stream = oracle.speck3d_encode(coef, sign, budget)
+            for cut in (len(stream), 9 + (len(stream) - 9) // 3):
+                s = stream[:cut]
+                c0, s0 = oracle.speck3d_decode(s, shape)
+                c1, s1 = model_decode_mixed(model, s, shape, window, hmax)
+                assert np.array_equal(c0, c1)
+                assert np.array_equal(s0, s1)
