@@ -1544,7 +1544,7 @@ bool use_mixed(const ShapePlan& P)
   static const bool mixEnv = !(getenv("SPERR_HIP_LIS_MIXED") && atoi(getenv("SPERR_HIP_LIS_MIXED")) == 0);
   if (!mixEnv || use_tables(P) || P.ht.cls.empty())
     return false;
-  const uint32_t w = mix_window(P.ht.nslots, kMixSmemBytes);
+  const uint32_t w = mix_window(kMixSmemBytes);
   return w >= 512 && w >= P.ht.slotMaxT + 2;
 }
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
@@ -1642,7 +1642,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 4) * 4;
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
   d.mixSmemBytes = kMixSmemBytes;
-  d.mixW = mix_window(P.ht.nslots, kMixSmemBytes);
+  d.mixW = mix_window(kMixSmemBytes);
   d.leafCap = P.ht.nsets + 8;
   d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;

@@ -169,13 +169,15 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   return w;
 }
 
-// k_lis_mixed: LDS bytes per window bit are one u16 table entry per class with a table, the class
-// byte of a list entry the window may reach and the bit itself.  The window is the largest
-// multiple of 256 that fits (tables keep two sentinel entries, the bit window four slack words).
-__host__ __device__ inline uint32_t mix_window(uint32_t nslots, uint32_t smemBytes)
+// k_lis_mixed: LDS bytes per window bit are a row of eight coded lengths and one of four split
+// lengths (u16 each), the class word of a list entry the window may reach and the bit itself; the
+// item queue and the slack of the arrays are fixed.  The window is the largest multiple of 256
+// that fits.
+constexpr int kMixQueue = 1536;     // sets the walk of one window can hand to the expansion
+__host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
 {
-  const uint32_t perBit8 = 8u * (2u * nslots + 1u) + 1u;   // eighths of a byte
-  const uint32_t fixed = 4 * 8 + 4u * nslots + 64;
+  const uint32_t perBit8 = 8u * (16u + 8u + 2u) + 1u;   // eighths of a byte
+  const uint32_t fixed = 6 * 8 + 2 * 24 + (uint32_t)kMixQueue * 12u + 64;
   if (smemBytes <= fixed)
     return 0;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);

@@ -2330,27 +2330,32 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 
 // ------------------------------------------------------------------------------------------
 // LIS phase for chunks whose lists MIX set shapes (any extent that is not a power of two): one
-// 1024-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_mixed is the
+// 512-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_mixed is the
 // CPU model of this kernel.
 //
 // The code of a set depends on its extents only, so every set has a SHAPE CLASS (spk::ShapeCls,
 // built on the host): a leaf parent of 2, 4 or 8 samples, a set made of such leaf parents and
-// single samples, and so on.  A list entry's class is read off the entry (spk::node_cls: which
-// of its three intervals are the long ones); what pointer jumping needs -- one code structure
-// for all entries of a list -- is gone, so the list is walked by ONE thread, but the walk only
-// hops:
-//   tables   per window of W stream bits, for every class that has a table slot (h <= 1 by
-//            default) and EVERY bit position: the bits a split of that class takes when it starts
-//            there (kTInf when that leaves the window); speculative, all threads;
+// single samples (h = 1), and so on.  A list entry's class is read off the entry (spk::node_cls:
+// which of its three intervals are the long ones).  What pointer jumping needs -- one code
+// structure for all entries of a list -- is gone, so the list is walked by ONE thread, but the
+// walk only hops:
+//   rows     per window of W stream bits and for EVERY bit position q a row of eight 16-bit
+//            entries U[q][col]: the length of the CODED item of column col that starts at q (its
+//            test bit, and its split when that bit is set: bit 15), kUInf when it leaves the
+//            window.  Column 0 is a single sample, 1..3 the leaf parents of 2 / 4 / 8 samples,
+//            4..7 the most frequent h = 1 classes of the chunk shape (host: build_classes).  A
+//            second row T[q][0..3] is the split alone (an implied last child has no test bit).
+//            Speculative, all threads;
 //   walk     one thread: runs of '0' entries are counted off the stream (in front of a window by
-//            the whole workgroup), a significant entry of a class with a table costs one look-up,
-//            any other set is walked into child by child (its children's tables do the rest);
+//            the whole workgroup), a significant entry whose class has a column costs one look-up,
+//            any other set is walked into child by child (its children's columns do the rest);
 //   expand   every set that was hopped over is a work item: a thread finds its children with the
-//            tables, leaf parents become leaf events (k_leaf_apply), insignificant child sets are
-//            recorded with their stream position (k_place_scan / _scatter rank them), significant
-//            ones are queued for the next round.
+//            rows; leaf parents become leaf events (k_leaf_apply), insignificant child sets are
+//            recorded with their stream position (k_place_scan / _scatter rank them).
 // ------------------------------------------------------------------------------------------
+constexpr int kMixThreads = 512;
 constexpr int kMixLdsRoots = 48, kMixLdsGrids = 352;
+constexpr uint32_t kUInf = 0xffffu;
 
 struct MixCtx {
   uint64_t parent;     // packed node of the set being walked into
@@ -2362,49 +2367,54 @@ struct MixCtx {
 };
 
 template <typename CT>
-__global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
+__global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.x;
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   extern __shared__ __attribute__((aligned(16))) char mix_smem[];
   __shared__ ShapeCls sh_cls[kMaxCls];
-  __shared__ uint64_t sh_kslot[kMaxCls];            // byte k: table slot of child k (0xfe: a single sample)
+  __shared__ uint64_t sh_kcol[kMaxCls];             // byte k: column of child k (0: a single sample, 0xff: none)
   __shared__ Root sh_roots[kMixLdsRoots];
   __shared__ Grid sh_grids[kMixLdsGrids];
   __shared__ uint8_t sh_gridCls[kMixLdsGrids * 8];
   __shared__ MixCtx sh_ctx[kMaxDepth + 2];
-  __shared__ uint8_t sh_slotCls[64];
+  __shared__ uint8_t sh_colCls[8];                  // class of columns 4..7 (0xff: unused)
+  __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
   __shared__ uint64_t sh_pos;
-  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_leaf, sh_zfound;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn, sh_born, sh_leaf, sh_zfound;
   __shared__ int sh_depth;
-  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
+  __shared__ uint32_t sh_scan[kMixThreads / 64 + 1];
 
   const int tid = threadIdx.x;
   Tree t = b.tree;
-  const uint32_t nslots = t.nslots;
+  if (tid < 8)
+    sh_colCls[tid] = 0xff;
+  if (tid < kMaxLevels)
+    sh_levelSlot[tid] = (uint32_t)tid < t.nlevels ? b.levelSlot[tid] : (uint8_t)0xff;
+  __syncthreads();
   if (t.nroots <= (uint32_t)kMixLdsRoots && t.ngrids <= (uint32_t)kMixLdsGrids) {
-    for (uint32_t i = tid; i < t.nroots; i += kTabThreads)
+    for (uint32_t i = tid; i < t.nroots; i += kMixThreads)
       sh_roots[i] = b.tree.roots[i];
-    for (uint32_t i = tid; i < t.ngrids; i += kTabThreads)
+    for (uint32_t i = tid; i < t.ngrids; i += kMixThreads)
       sh_grids[i] = b.tree.grids[i];
-    for (uint32_t i = tid; i < t.ngrids * 8; i += kTabThreads)
+    for (uint32_t i = tid; i < t.ngrids * 8; i += kMixThreads)
       sh_gridCls[i] = b.tree.gridCls[i];
     t.roots = sh_roots;
     t.grids = sh_grids;
     t.gridCls = sh_gridCls;
   }
-  for (uint32_t i = tid; i < t.ncls; i += kTabThreads) {
+  for (uint32_t i = tid; i < t.ncls; i += kMixThreads) {
     const ShapeCls cc = b.tree.cls[i];
     sh_cls[i] = cc;
-    uint64_t ks = 0;
+    uint64_t kc = 0;
     for (int k = 0; k < 8; k++) {
-      const uint32_t kc = k < cc.nk ? cc.kid[k] : kClsPixel;
-      ks |= (uint64_t)(kc == kClsPixel ? 0xfeu : b.tree.cls[kc].slot) << (8 * k);
+      const uint32_t kid = k < cc.nk ? cc.kid[k] : kClsPixel;
+      kc |= (uint64_t)(kid == kClsPixel ? 0u : b.tree.cls[kid].slot) << (8 * k);
     }
-    sh_kslot[i] = ks;
-    if (cc.slot != 0xff)
-      sh_slotCls[cc.slot] = (uint8_t)i;
+    sh_kcol[i] = kc;
+    if (cc.slot >= 4 && cc.slot < 8)
+      sh_colCls[cc.slot] = (uint8_t)i;
   }
   t.cls = sh_cls;
 
@@ -2416,18 +2426,20 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
   const uint32_t cur = s.cur, nx = cur ^ 1u;
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t maskBits = (uint64_t)b.maskWords * 64;
-  uint64_t* qbuf[2] = {b.queue + c * b.queueStride, b.queue + c * b.queueStride + b.queueCap * 2};
   uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
   uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
 
-  const uint32_t W = b.mixW, TS = W + 2;
-  const uint32_t kWords = W / 64 + 4;
+  const uint32_t W = b.mixW;
+  const uint32_t kWords = (W / 64 + 4 + 1) & ~1u;
   uint64_t* wbits = reinterpret_cast<uint64_t*>(mix_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(mix_smem);
-  uint16_t* Tt = reinterpret_cast<uint16_t*>(mix_smem + (size_t)kWords * 8);   // [nslots][TS]
-  uint8_t* ecls = reinterpret_cast<uint8_t*>(Tt + (size_t)nslots * TS);        // [W]
+  uint16_t* Urow = reinterpret_cast<uint16_t*>(mix_smem + (size_t)kWords * 8);   // [W + 2][8]
+  uint16_t* Trow = Urow + (size_t)(W + 2) * 8;                                    // [W + 2][4]
+  uint16_t* ecls = Trow + (size_t)(W + 2) * 4;                                    // [W]: class | column << 8
+  uint64_t* qid = reinterpret_cast<uint64_t*>(ecls + W);                          // [kMixQueue]
+  uint32_t* qmeta = reinterpret_cast<uint32_t*>(qid + kMixQueue);                 // [kMixQueue]
 
   if (tid == 0) {
     sh_pos = phase0;
@@ -2446,6 +2458,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
   }
   if (stamps)
     stamp_t = __builtin_readcyclecounter();
+  uint64_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0;
 
   uint32_t wq0 = 0;  // bit offset of window position 0 inside wbits[0]
   auto bit_at = [&](uint32_t r) -> uint32_t {
@@ -2465,67 +2478,42 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
         atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
     }
   };
-  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
-    const uint64_t rel = abs - phase0;
-    const uint32_t slot = b.levelSlot[lev];
-    if (slot == 0xff || rel >= maskBits)
-      return;  // past the usable stream: decoding stops after this plane anyway
-    const uint32_t k = atomicAdd(&sh_born, 1u);
+  // a set born insignificant at stream position `abs`; k = its record (the walk counts its own
+  // records in a register, the expansion's threads claim theirs from sh_born)
+  auto write_born = [&](uint32_t k, uint32_t lev, uint64_t rel, uint64_t packed) {
     if (k >= b.bornStride)
       return;
     bornPacked[k] = packed;
     bornPosLev[k] = ((uint64_t)lev << 48) | rel;
-    atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
+    atomic_or64(b.mask + c * b.maskStride + (size_t)sh_levelSlot[lev] * b.maskWords + (rel >> 6),
                 1ull << (rel & 63));
   };
-  // bits of a split of class `ci` that starts at r (kTInf: it leaves the window); the tables of
-  // the children's classes are complete.  Indices W and W + 1 of every table hold kTInf.
-  auto split_len = [&](uint32_t ci, uint32_t r) -> uint32_t {
-    const uint32_t nk = sh_cls[ci].nk;
-    if (sh_cls[ci].h == 0) {
-      if (r >= W)
-        return kTInf;
-      const uint32_t v = bits32(r);
-      uint32_t y = 0, found = 0;
-      if (nk == 8) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-          const uint32_t bit = (v >> y) & 1u;
-          found |= bit;
-          y += 1u + bit;
-        }
-        const uint32_t bit = found ? (v >> y) & 1u : 1u;
-        y += found + bit;
-      }
-      else {
-        for (uint32_t i = 0; i < nk; i++) {
-          const uint32_t coded = found | (uint32_t)(i + 1 != nk);
-          const uint32_t bit = coded ? (v >> y) & 1u : 1u;
-          y += coded;
-          found |= bit;
-          y += bit;  // sign bit
-        }
-      }
-      return r + y <= W ? y : kTInf;
-    }
-    const uint64_t ks = sh_kslot[ci];
-    uint32_t y = min(r, W + 1), found = 0;
+  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
+    const uint64_t rel = abs - phase0;
+    if (sh_levelSlot[lev] == 0xff || rel >= maskBits)
+      return;  // past the usable stream: decoding stops after this plane anyway
+    write_born(atomicAdd(&sh_born, 1u), lev, rel, packed);
+  };
+  // a significant leaf parent of nk samples whose split starts at y: ONE event word (node id,
+  // significance and sign masks by child ordinal) that k_leaf_apply turns into mask updates
+  auto leaf_event = [&](const Node& nd, uint32_t y, uint32_t nk) {
+    const uint32_t v = bits32(y);
+    uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
     for (uint32_t k = 0; k < nk; k++) {
       const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-      const uint32_t bit = coded ? bit_at(y) : 1u;
-      y += coded;
-      const uint32_t sl = (uint32_t)(ks >> (8 * k)) & 0xffu;
-      if (sl == 0xfeu)
-        y += bit;   // the sign of a significant sample
-      else if (bit) {
-        const uint32_t tl = Tt[(size_t)sl * TS + min(y, W + 1)];
-        if (tl == kTInf)
-          return kTInf;
-        y += tl;
-      }
+      const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+      yy += coded;
+      const uint32_t sgn = (v >> yy) & 1u;
+      sigm |= bit << k;
+      negm |= (bit & (sgn ^ 1u)) << k;
       found |= bit;
+      yy += bit;
     }
-    return y <= W ? y - r : kTInf;
+    const Grid& g = t.grids[nd.grid];
+    const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
+    const uint32_t slot = atomicAdd(&sh_leaf, 1u);
+    if (slot < b.leafCap)
+      leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
   };
 
   for (uint32_t l = t.nlevels; l-- > 0;) {
@@ -2536,7 +2524,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
       continue;
     }
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
-    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kTabThreads)
+    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kMixThreads)
       sigbits[i] = 0;
     if (tid == 0) {
       sh_depth = 1;
@@ -2547,7 +2535,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
 
     while (true) {
       // ---- in front of a window: the insignificant entries up to the next '1' of the list are
-      //      counted off the stream by the whole workgroup, 64 Kbit per round (no tables: in the
+      //      counted off the stream by the whole workgroup, 32 Kbit per round (no tables: in the
       //      sparse planes whole lists go this way)
       while (sh_depth == 1) {
         __syncthreads();
@@ -2565,7 +2553,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
           atomicMin(&sh_zfound, (uint32_t)tid * 64u + (uint32_t)__ffsll((long long)w) - 1u);
         __syncthreads();
         const uint32_t f = sh_zfound;
-        const uint32_t zeros = (f == 0xffffffffu ? (uint32_t)kTabThreads * 64u : f) - off;
+        const uint32_t zeros = (f == 0xffffffffu ? (uint32_t)kMixThreads * 64u : f) - off;
         const uint32_t z = min(zeros, rem);
         __syncthreads();
         if (tid == 0) {
@@ -2576,10 +2564,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
             sh_depth = 0;
         }
         __syncthreads();
+        cnt_skips++;
         if (f != 0xffffffffu || rem == z)
           break;
       }
       __syncthreads();
+      STAMP(5);
       if (sh_depth == 0)
         break;
       const uint64_t a = sh_pos;
@@ -2588,162 +2578,249 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
       __syncthreads();  // everyone has read the walker's state before thread 0 changes it
       const uint64_t w0 = a >> 6;
       wq0 = (uint32_t)(a & 63);
-      for (uint32_t i = tid; i < kWords; i += kTabThreads) {
+      for (uint32_t i = tid; i < kWords; i += kMixThreads) {
         const uint64_t idx = w0 + i;
         wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
       }
-      // classes of the list entries this window can reach
-      for (uint32_t i = tid; i < ecnt; i += kTabThreads)
-        ecls[i] = (uint8_t)node_cls(t, unpack_node(list[e0 + i]));
+      // classes (and columns) of the list entries this window can reach
+      for (uint32_t i = tid; i < ecnt; i += kMixThreads) {
+        const uint32_t ci = node_cls(t, unpack_node(list[e0 + i]));
+        ecls[i] = (uint16_t)(ci | ((uint32_t)sh_cls[ci].slot << 8));
+      }
       __syncthreads();
       STAMP(0);
-      // ---- tables, lowest classes first (slots are sorted by h)
-      {
-        uint32_t hprev = 0;
-        for (uint32_t sl = 0; sl < nslots; sl++) {
-          const uint32_t ci = sh_slotCls[sl];
-          const uint32_t hh = sh_cls[ci].h;
-          if (hh != hprev) {
-            __syncthreads();
-            hprev = hh;
+      // ---- rows, columns 0..3: the thread of position x has the splits that start at x and, with
+      //      the bit in front of them, the coded items that start at x - 1
+      for (uint32_t x = tid; x <= W + 1; x += kMixThreads) {
+        const uint32_t v = bits32(x);
+        // children 0..6 coded one after the other; the last child of 2 / 4 / 8 is coded only when
+        // an earlier one was significant
+        uint32_t y = 0, found = 0, t2 = 0, t4 = 0, t8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (k == 1 || k == 3 || k == 7) {
+            const uint32_t bit = found ? (v >> y) & 1u : 1u;
+            const uint32_t tl = y + found + bit;
+            if (k == 1)
+              t2 = tl;
+            else if (k == 3)
+              t4 = tl;
+            else
+              t8 = tl;
           }
-          uint16_t* Ts = Tt + (size_t)sl * TS;
-          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
-            const uint32_t r2 = r + kTabThreads;
-            const uint32_t t1 = split_len(ci, r);
-            const uint32_t t2 = r2 <= W + 1 ? split_len(ci, r2) : kTInf;
-            Ts[r] = (uint16_t)t1;
-            if (r2 <= W + 1)
-              Ts[r2] = (uint16_t)t2;
+          if (k < 7) {
+            const uint32_t bit = (v >> y) & 1u;
+            found |= bit;
+            y += 1u + bit;
           }
+        }
+        const uint32_t T0 = x + 1 <= W ? 1u : kUInf;
+        const uint32_t T1 = x + t2 <= W ? t2 : kUInf;
+        const uint32_t T2 = x + t4 <= W ? t4 : kUInf;
+        const uint32_t T3 = x + t8 <= W ? t8 : kUInf;
+        *reinterpret_cast<uint2*>(Trow + (size_t)x * 4) = make_uint2(T0 | (T1 << 16), T2 | (T3 << 16));
+        if (x >= 1) {
+          const uint32_t q = x - 1;
+          uint32_t u0 = kUInf, u1 = kUInf, u2 = kUInf, u3 = kUInf;
+          if (q < W) {
+            if (!bit_at(q))
+              u0 = u1 = u2 = u3 = 1u;
+            else {
+              u0 = T0 == kUInf ? kUInf : 0x8002u;
+              u1 = T1 == kUInf ? kUInf : 0x8001u + T1;
+              u2 = T2 == kUInf ? kUInf : 0x8001u + T2;
+              u3 = T3 == kUInf ? kUInf : 0x8001u + T3;
+            }
+          }
+          *reinterpret_cast<uint2*>(Urow + (size_t)q * 8) = make_uint2(u0 | (u1 << 16), u2 | (u3 << 16));
+          if (q == W)
+            *reinterpret_cast<uint2*>(Urow + (size_t)(W + 1) * 8) = make_uint2(0xffffffffu, 0xffffffffu);
+        }
+      }
+      __syncthreads();
+      // ---- columns 4..7: a chain of look-ups through the children's columns, only where the item's
+      //      test bit is set
+      for (uint32_t col = 4; col < 8; col++) {
+        const uint32_t ci = sh_colCls[col];
+        if (ci == 0xff)
+          continue;
+        const uint32_t nk = sh_cls[ci].nk;
+        const uint64_t kc = sh_kcol[ci];
+        for (uint32_t q = tid; q <= W + 1; q += kMixThreads) {
+          uint32_t u = kUInf;
+          if (q < W) {
+            if (!bit_at(q))
+              u = 1u;
+            else {
+              uint32_t y = q + 1, fl = 0;
+              for (uint32_t k = 0; k + 1 < nk; k++) {
+                const uint32_t uu = Urow[(size_t)y * 8 + ((uint32_t)(kc >> (8 * k)) & 0xffu)];
+                fl |= uu;
+                y = min(y + (uu & 0x7fffu), W + 1);
+              }
+              const uint32_t lc = (uint32_t)(kc >> (8 * (nk - 1))) & 0xffu;
+              const uint32_t uu = (fl & 0x8000u) ? Urow[(size_t)y * 8 + lc] : Trow[(size_t)y * 4 + lc];
+              y = min(y + (uu & 0x7fffu), W + 1);
+              if (y <= W)
+                u = 0x8000u | (y - q);
+            }
+          }
+          Urow[(size_t)q * 8 + col] = (uint16_t)u;
         }
       }
       __syncthreads();
       STAMP(1);
       // ---- the walk: one thread
       if (tid == 0) {
-        uint32_t r = 0, e = sh_e, rem = sh_rem, qn = 0;
+        uint32_t r = 0, e = sh_e, rem = sh_rem, qn = 0, nborn = sh_born;
         int depth = sh_depth;
+#ifdef MIX_WALK_SPLIT
+        uint64_t walk_t = __builtin_readcyclecounter();
+        int lastKind = 8;
+#endif
         while (true) {
-          if (depth > 1) {
-            MixCtx& cx = sh_ctx[depth - 1];
-            const uint32_t pc = cx.pc;
-            const uint32_t nk = sh_cls[pc].nk;
-            const uint32_t k = cx.next;
-            if (k == nk) {
-              depth--;
-              continue;
-            }
-            const uint32_t kc = sh_cls[pc].kid[k];
-            const bool coded = cx.found || (k + 1 != nk);
-            uint32_t x = r, bit = 1;
-            if (coded) {
-              if (x >= W)
-                break;
-              bit = bit_at(x);
-              x++;
-            }
-            if (kc == kClsPixel) {
-              if (bit && x >= W)
-                break;
-              const uint32_t ridx = kid_pixel_raster(t, unpack_node(cx.parent), cx.kb, k);
-              pixel_event(ridx, bit != 0, bit ? bit_at(x) : 1u);
-              if (bit) {
-                x++;
-                cx.found = 1;
-              }
-              cx.next = (uint8_t)(k + 1);
-              r = x;
-              continue;
-            }
-            const uint64_t kid = kid_packed(cx.kb, k);
-            if (!bit) {
-              record_born(cx.kb.kidlev, a + x - 1, kid);
-              cx.next = (uint8_t)(k + 1);
-              r = x;
-              continue;
-            }
-            const uint32_t sl = sh_cls[kc].slot;
-            if (sl != 0xff) {
-              const uint32_t tl = Tt[(size_t)sl * TS + min(x, W + 1)];
-              if (tl == kTInf)
-                break;   // the next window starts at this child's first bit
-              qbuf[0][qn * 2] = kid;
-              qbuf[0][qn * 2 + 1] = ((uint64_t)x << 16) | ((uint64_t)kc << 8);
-              qn++;
-              cx.found = 1;
-              cx.next = (uint8_t)(k + 1);
-              r = x + tl;
-            }
-            else {
-              cx.found = 1;
-              cx.next = (uint8_t)(k + 1);
-              r = x;
-              MixCtx& nc = sh_ctx[depth];
-              nc.parent = kid;
-              kid_box(t, unpack_node(kid), nc.kb);
-              nc.pc = (uint8_t)kc;
-              nc.next = 0;
-              nc.found = 0;
-              depth++;
-            }
-            continue;
-          }
-          // the list itself
-          if (rem == 0) {
-            depth = 0;
+          if (r >= W || qn >= (uint32_t)kMixQueue)
             break;
-          }
-          if (r >= W)
-            break;
+#ifdef MIX_WALK_SPLIT
           {
+            const uint64_t now_ = __builtin_readcyclecounter();
+            if (stamps)
+              stamp_acc[lastKind] += now_ - walk_t;
+            walk_t = now_;
+            lastKind = depth == 1 ? 6 : 7;
+          }
+#endif
+          if (depth == 1) {   // the list itself
+            if (rem == 0) {
+              depth = 0;
+              break;
+            }
             const uint64_t bits = (uint64_t)bits32(r) | ((uint64_t)bits32(r + 32) << 32);
             const uint32_t z = min(min(bits ? (uint32_t)__ffsll((long long)bits) - 1u : 64u, rem), W - r);
             if (z) {
+              cnt_zruns++;
               r += z;
               e += z;
               rem -= z;
               continue;
             }
+            cnt_hops++;
+            const uint32_t ec = ecls[e - e0];
+            const uint32_t col = ec >> 8, ci = ec & 0xffu;
+            if (col != 0xffu) {
+              const uint32_t u = Urow[(size_t)r * 8 + col];
+              if (u == kUInf)
+                break;   // the next window starts at this entry
+              qid[qn] = e;
+              qmeta[qn] = (r + 1) | (ci << 16) | (1u << 24);
+              qn++;
+              r += u & 0x7fffu;
+            }
+            else {
+              cnt_push++;
+              const uint64_t packed = list[e];
+              atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
+              MixCtx& nc = sh_ctx[1];
+              nc.parent = packed;
+              kid_box(t, unpack_node(packed), nc.kb);
+              nc.pc = (uint8_t)ci;
+              nc.next = 0;
+              nc.found = 0;
+              depth = 2;
+              r += 1;
+            }
+            e++;
+            rem--;
+            continue;
           }
-          // entry e is significant
-          const uint32_t ci = ecls[e - e0];
-          const uint32_t sl = sh_cls[ci].slot;
-          const uint32_t x = r + 1;
-          if (sl != 0xff) {
-            const uint32_t tl = Tt[(size_t)sl * TS + min(x, W + 1)];
-            if (tl == kTInf)
-              break;   // the next window starts at this entry
-            qbuf[0][qn * 2] = e;
-            qbuf[0][qn * 2 + 1] = ((uint64_t)x << 16) | ((uint64_t)ci << 8) | 1ull;
+          // a set that is being walked into: its next child
+          MixCtx& cx = sh_ctx[depth - 1];
+          const uint32_t pc = cx.pc;
+          const uint32_t nk = sh_cls[pc].nk;
+          const uint32_t k = cx.next;
+          if (k == nk) {
+            depth--;
+            continue;
+          }
+          cnt_steps++;
+          const uint32_t kc = sh_cls[pc].kid[k];
+          const uint32_t col = (uint32_t)(sh_kcol[pc] >> (8 * k)) & 0xffu;
+          const bool coded = cx.found || (k + 1 != nk);
+          if (kc == kClsPixel) {
+            uint32_t sig = 1, sgn, len = 1;
+            if (coded) {
+              const uint32_t u = Urow[(size_t)r * 8];
+              if (u == kUInf)
+                break;
+              sig = u >> 15;
+              len = u & 0x7fffu;
+              sgn = sig ? bit_at(r + 1) : 1u;
+            }
+            else
+              sgn = bit_at(r);
+            pixel_event(kid_pixel_raster(t, unpack_node(cx.parent), cx.kb, k), sig != 0, sgn);
+            if (sig)
+              cx.found = 1;
+            cx.next = (uint8_t)(k + 1);
+            r += len;
+            continue;
+          }
+          const uint64_t kid = kid_packed(cx.kb, k);
+          uint32_t start = r;   // first bit of the child's split
+          if (coded) {
+            if (!bit_at(r)) {
+              const uint64_t rel = a + r - phase0;
+              if (sh_levelSlot[cx.kb.kidlev] != 0xff && rel < maskBits)
+                write_born(nborn++, cx.kb.kidlev, rel, kid);
+              cx.next = (uint8_t)(k + 1);
+              r += 1;
+              continue;
+            }
+            start = r + 1;
+          }
+          uint32_t len = kUInf;   // bits from r to the end of the child's split, when a row has them
+          if (col != 0xffu && coded) {
+            const uint32_t u = Urow[(size_t)r * 8 + col];
+            if (u == kUInf)
+              break;   // the next window starts at this child's first bit
+            len = u & 0x7fffu;
+          }
+          else if (col != 0xffu && col < 4u) {
+            const uint32_t tl = Trow[(size_t)r * 4 + col];
+            if (tl == kUInf)
+              break;
+            len = tl;
+          }
+          cx.found = 1;
+          cx.next = (uint8_t)(k + 1);
+          if (len != kUInf) {
+            qid[qn] = kid;
+            qmeta[qn] = start | (kc << 16);
             qn++;
-            r = x + tl;
+            r += len;
           }
           else {
-            const uint64_t packed = list[e];
-            atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
-            MixCtx& nc = sh_ctx[1];
-            nc.parent = packed;
-            kid_box(t, unpack_node(packed), nc.kb);
-            nc.pc = (uint8_t)ci;
+            cnt_push++;
+            MixCtx& nc = sh_ctx[depth];
+            nc.parent = kid;
+            kid_box(t, unpack_node(kid), nc.kb);
+            nc.pc = (uint8_t)kc;
             nc.next = 0;
             nc.found = 0;
-            depth = 2;
-            r = x;
+            depth++;
+            r = start;
           }
-          e++;
-          rem--;
         }
         // (a window that changes nothing would be walked for ever: cannot happen while the window is
-        // longer than every split that has a table, which the host checks -- kept as a guard)
+        // longer than every split that has a column, which the host checks -- kept as a guard)
+        cnt_bits += r;
         const bool stuck = r == 0 && e == sh_e && depth == sh_depth && qn == 0;
         sh_pos = a + r;
         sh_e = e;
         sh_rem = rem;
         sh_depth = stuck ? -1 : depth;
-        sh_qn[0] = qn;
-        sh_qn[1] = 0;
-        sh_qn[2] = 0;
+        sh_qn = qn;
+        sh_born = nborn;
       }
       __syncthreads();
       if (sh_depth < 0) {
@@ -2756,75 +2833,65 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
       STAMP(2);
       if (stamps)
         stamp_acc[9] += 1;
-      // ---- expand, breadth first
-      for (int round = 0;; round++) {
-        const uint32_t nin = sh_qn[round % 3];
-        if (nin == 0)
-          break;
-        const uint64_t* qin = qbuf[round & 1];
-        uint64_t* qout = qbuf[(round + 1) & 1];
-        for (uint32_t i = tid; i < nin; i += kTabThreads) {
-          const uint64_t ident = qin[i * 2], meta = qin[i * 2 + 1];
-          const uint32_t ci = (uint32_t)(meta >> 8) & 0xffu;
-          uint32_t y = (uint32_t)(meta >> 16);
+      // ---- expand what was hopped over
+      {
+        const uint32_t nin = sh_qn;
+        cnt_items += nin;
+        for (uint32_t i = tid; i < nin; i += kMixThreads) {
+          const uint64_t ident = qid[i];
+          const uint32_t meta = qmeta[i];
+          const uint32_t ci = (meta >> 16) & 0xffu;
+          uint32_t y = meta & 0xffffu;
           uint64_t packed = ident;
-          if (meta & 1ull) {
+          if (meta >> 24) {
             packed = list[ident];
             atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
           }
           const Node nd = unpack_node(packed);
           const uint32_t nk = sh_cls[ci].nk;
           if (sh_cls[ci].h == 0) {
-            // a leaf parent: its pixel results become ONE event word (node id, significance and
-            // sign masks by child ordinal) that k_leaf_apply turns into mask updates GPU-wide
-            const uint32_t v = bits32(y);
-            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
-            for (uint32_t k = 0; k < nk; k++) {
-              const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-              const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
-              yy += coded;
-              const uint32_t sgn = (v >> yy) & 1u;
-              sigm |= bit << k;
-              negm |= (bit & (sgn ^ 1u)) << k;
-              found |= bit;
-              yy += bit;
-            }
-            const Grid& g = t.grids[nd.grid];
-            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
-                                 nd.i[0];
-            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
-            if (slot < b.leafCap)
-              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+            leaf_event(nd, y, nk);
             continue;
           }
           KidBox kb;
           kid_box(t, nd, kb);
-          const uint64_t ks = sh_kslot[ci];
+          const uint64_t kc = sh_kcol[ci];
           uint32_t found = 0;
           for (uint32_t k = 0; k < nk; k++) {
             const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-            const uint32_t bit = coded ? bit_at(y) : 1u;
-            y += coded;
-            const uint32_t sl = (uint32_t)(ks >> (8 * k)) & 0xffu;
-            if (sl == 0xfeu) {
-              pixel_event(kid_pixel_raster(t, nd, kb, k), bit != 0, bit ? bit_at(y) : 1u);
-              y += bit;
+            const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
+            if (col == 0) {   // a single sample
+              uint32_t sig = 1, sgn, len = 1;
+              if (coded) {
+                const uint32_t u = Urow[(size_t)y * 8];
+                sig = u >> 15;
+                len = u & 0x7fffu;
+                sgn = sig ? bit_at(y + 1) : 1u;
+              }
+              else
+                sgn = bit_at(y);
+              pixel_event(kid_pixel_raster(t, nd, kb, k), sig != 0, sgn);
+              found |= sig;
+              y += len;
+              continue;
             }
-            else if (bit) {
-              const uint32_t slot = atomicAdd(&sh_qn[(round + 1) % 3], 1u);
-              qout[slot * 2] = kid_packed(kb, k);
-              qout[slot * 2 + 1] = ((uint64_t)y << 16) | ((uint64_t)sh_cls[ci].kid[k] << 8);
-              y += Tt[(size_t)sl * TS + y];
+            uint32_t start = y;
+            if (coded) {
+              const uint32_t u = Urow[(size_t)y * 8 + col];
+              if (!(u & 0x8000u)) {
+                record_born(kb.kidlev, a + y, kid_packed(kb, k));
+                y += 1;
+                continue;
+              }
+              start = y + 1;
+              y += u & 0x7fffu;
             }
-            else
-              record_born(kb.kidlev, a + y - 1, kid_packed(kb, k));
-            found |= bit;
+            found = 1;   // (an implied child is the last one: nothing follows it in this split)
+            leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
           }
         }
-        if (tid == 0)
-          sh_qn[(round + 2) % 3] = 0;   // the counter of the round after next
-        __syncthreads();
       }
+      __syncthreads();
       STAMP(3);
     }
     // ---- old entries that stayed insignificant keep their order
@@ -2833,7 +2900,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
       uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
       uint32_t carry = 0;
       const uint32_t nw = (n + 63) / 64;
-      for (uint32_t base = 0; base < nw; base += kTabThreads) {
+      for (uint32_t base = 0; base < nw; base += kMixThreads) {
         const uint32_t wi = base + tid;
         uint64_t stay = 0;
         if (wi < nw) {
@@ -2864,6 +2931,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_mixed(DecBuffers b, int p)
     uint64_t* out = b.lisStamps + (size_t)c * 64;
     for (int i = 0; i < 10; i++)
       out[i] += stamp_acc[i];
+    out[16] += cnt_hops;
+    out[17] += cnt_steps;
+    out[18] += cnt_push;
+    out[19] += cnt_zruns;
+    out[20] += cnt_bits;
+    out[21] += cnt_skips;
+    out[22] += cnt_items;
   }
 #undef STAMP
   if (tid == 0) {
@@ -4431,7 +4505,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else if (plan.mixed) {
-        LAUNCH_K(k_lis_mixed<uint64_t>, dim3(nc), dim3(kTabThreads), b.mixSmemBytes, stream, b, p);
+        LAUNCH_K(k_lis_mixed<uint64_t>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -4466,7 +4540,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else if (plan.mixed) {
-        LAUNCH_K(k_lis_mixed<uint32_t>, dim3(nc), dim3(kTabThreads), b.mixSmemBytes, stream, b, p);
+        LAUNCH_K(k_lis_mixed<uint32_t>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);

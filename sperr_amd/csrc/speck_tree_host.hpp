@@ -70,6 +70,7 @@ struct HostTree {
   bool allRegular = false;                     // every level that can hold sets is regular
   std::vector<ShapeCls> cls;                   // shape classes, children first (empty: too many)
   std::vector<uint8_t> gridCls;                // [grid][8]
+  std::vector<uint64_t> clsCount;              // sets of the forest per class
   uint32_t nslots = 0;                         // classes that have a table slot
   uint32_t slotMaxT = 0;                       // longest split of a class with a table
   uint32_t dims[3] = {0, 0, 0};
@@ -112,11 +113,11 @@ inline int ceil_log2(uint32_t v)
 }  // namespace detail
 
 constexpr int kClsTableH = 1;            // default: tables for leaf parents and their parents
-constexpr uint32_t kClsTableSlots = 24;
+constexpr uint32_t kClsTableSlots = 4;
 
-// Shape classes of every set of the forest (speck_tree.h, ShapeCls).  Classes whose sets are at
-// most `hmax` splits above single samples get a table slot, as many as `maxSlots` allows.
-inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots)
+// Shape classes of every set of the forest (speck_tree.h, ShapeCls).  hmax >= 0: the leaf parents
+// get table slots, hmax >= 1: up to `maxSlots` (at most 4) of the classes made of leaf parents too.
+inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minShare = 0.02)
 {
   h.cls.clear();
   h.gridCls.assign(h.grids.size() * 8, kClsPixel);
@@ -216,20 +217,57 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots)
     h.cls.clear();
     return;
   }
-  // table slots: lowest classes first (a class with a table needs tables of all its children)
-  for (int hh = 0; hh <= hmax; hh++)
-    for (size_t i = 0; i < h.cls.size(); i++) {
-      ShapeCls& c = h.cls[i];
-      if (c.h != hh || c.maxT > 0x7000u || h.nslots >= maxSlots)
+  // how many sets of the forest have each class
+  h.clsCount.assign(h.cls.size(), 0);
+  for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
+    const Grid& g = h.grids[gi];
+    const Root& r = h.roots[g.root];
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint8_t ci = h.gridCls[gi * 8 + k];
+      if (ci == kClsPixel)
         continue;
-      bool ok = true;
+      uint64_t cnt = 1;
+      for (int a = 0; a < 3; a++) {
+        const uint32_t rem = (uint32_t)r.len[a] & ((1u << g.e[a]) - 1u);
+        cnt *= ((k >> a) & 1u) ? rem : (1u << g.e[a]) - rem;
+      }
+      h.clsCount[ci] += cnt;
+    }
+  }
+  // Table slots = columns of the decoder's per-position rows (k_lis_mixed): 0 is the single
+  // sample, 1..3 the leaf parents of 2, 4 and 8 samples, 4..7 the most frequent classes made of
+  // those (h = 1: each must hold at least `minShare` of all such sets to be worth a column).
+  if (hmax >= 0)
+    for (ShapeCls& c : h.cls)
+      if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8)) {
+        c.slot = (uint8_t)(c.nk == 2 ? 1 : c.nk == 4 ? 2 : 3);
+        h.nslots++;
+        h.slotMaxT = std::max(h.slotMaxT, c.maxT);
+      }
+  if (hmax >= 1) {
+    uint64_t all = 0;
+    std::vector<size_t> order;
+    for (size_t i = 0; i < h.cls.size(); i++)
+      if (h.cls[i].h == 1) {
+        all += h.clsCount[i];
+        order.push_back(i);
+      }
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+      return h.clsCount[x] != h.clsCount[y] ? h.clsCount[x] > h.clsCount[y] : x < y;
+    });
+    uint32_t next = 4;
+    for (size_t i : order) {
+      ShapeCls& c = h.cls[i];
+      bool ok = next < 4 + std::min<uint32_t>(maxSlots, 4) && (double)h.clsCount[i] >= minShare * (double)all;
       for (int k = 0; k < c.nk; k++)
         ok = ok && (c.kid[k] == kClsPixel || h.cls[c.kid[k]].slot != 0xff);
       if (!ok)
         continue;
-      c.slot = (uint8_t)h.nslots++;
+      c.slot = (uint8_t)next++;
+      h.nslots++;
       h.slotMaxT = std::max(h.slotMaxT, c.maxT);
     }
+  }
 }
 
 inline HostTree build_tree(size_t dx, size_t dy, size_t dz)

@@ -970,7 +970,7 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
                                uint64_t* coef, uint64_t* sign, int window, int hmax)
 {
   HostTree ht = build_tree(dims[0], dims[1], dims[2]);
-  build_classes(ht, hmax, 24);
+  build_classes(ht, hmax, 4, hmax >= 2 ? 0.0 : 0.02);
   if (ht.cls.empty())
     return -2;
   const Tree t = ht.view();
@@ -1074,11 +1074,11 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
       while (!listDone) {
         const uint64_t a = pos;
         // ---- tables of the window (parallel in the kernel: one thread per position and slot)
-        std::vector<std::vector<uint32_t>> T(ht.nslots, std::vector<uint32_t>(W + 2, T_INF));
-        for (uint32_t s = 0; s < ht.nslots; s++) {
-          uint32_t ci = 0;
-          while (cls[ci].slot != s)
-            ci++;
+        std::vector<std::vector<uint32_t>> T(8, std::vector<uint32_t>(W + 2, T_INF));
+        for (uint32_t ci = 0; ci < cls.size(); ci++) {   // (classes are numbered children first)
+          if (cls[ci].slot == 0xff)
+            continue;
+          const uint32_t s = cls[ci].slot;
           const ShapeCls& C = cls[ci];
           for (uint64_t x = 0; x <= W; x++) {
             uint64_t y = x;

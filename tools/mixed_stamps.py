@@ -1,0 +1,36 @@
+"""Per-phase tick counters of k_lis_mixed (chunk 0 of a volume of one chunk):
+python tools/mixed_stamps.py [edge]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+from sperr_amd.api import SperrHip
+from sperr_amd.synth import turbulence_torch
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 250
+eng = SperrHip()
+vol = turbulence_torch((n, n, n), "cuda")
+s = eng.compress(vol, (n, n, n), 2.0).clone()
+eng.lib.sperrhip_debug_lis_stamps.argtypes = [C.c_int, C.c_void_p]
+eng.lib.sperrhip_debug_lis_stamps(1, None)
+eng.decompress(s, True)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 64)()
+eng.lib.sperrhip_debug_lis_stamps(0, out)
+names = {0: "load+classes", 1: "tables", 2: "walk", 3: "expand", 4: "compact", 5: "zero skip"}
+tot = sum(out[i] for i in names)
+for i, nm in names.items():
+    print("%-14s %12d ticks  %5.1f%%" % (nm, out[i], 100 * out[i] / max(tot, 1)))
+w = max(out[9], 1)
+print("windows %d: ticks/window tables %d walk %d expand %d load %d; stream bits/window %d" %
+      (out[9], out[1] // w, out[2] // w, out[3] // w, out[0] // w, out[20] // w))
+print("walk: %d significant list entries, %d child steps in %d entered sets, %d zero runs; %d skip rounds; %d expanded items"
+      % (out[16], out[17], out[18], out[19], out[21], out[22]))
+if out[6] + out[7]:
+    print("walk split: list part %d ticks (%.0f per hop or zero run), entered sets %d ticks (%.0f per child step)"
+          % (out[6], out[6] / max(out[16] + out[19], 1), out[7], out[7] / max(out[17], 1)))
+if out[16] + out[17]:
+    print("walk ticks per hop/step: %.0f" % (out[2] / (out[16] + out[17] + out[19])))
