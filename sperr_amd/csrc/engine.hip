@@ -237,6 +237,7 @@ struct ShapePlan {
   const uint8_t* d_slotLevel = nullptr;
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
+  const uint8_t* d_levelGroup = nullptr;  // k_lis_mixed: column group of every list level
   int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
   int l1Level = -1;                       // LIS level of 4x4x4 sets that k_lis_l1 can decode
   int maxK = 0;
@@ -352,7 +353,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
                oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf), oCls = blob.add(h.cls),
-               oGC = blob.add(h.gridCls);
+               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
@@ -387,6 +388,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.dtree.blockGrid = reinterpret_cast<const uint16_t*>(base + oBG);
   P.dtree.cls = reinterpret_cast<const spk::ShapeCls*>(base + oCls);
   P.dtree.gridCls = reinterpret_cast<const uint8_t*>(base + oGC);
+  P.d_levelGroup = reinterpret_cast<const uint8_t*>(base + oLG);
   P.d_initLIS = reinterpret_cast<const uint64_t*>(base + oInit);
   P.d_initLen = reinterpret_cast<const uint32_t*>(base + oInitLen);
   P.d_levelOff = reinterpret_cast<const uint32_t*>(base + oLevOff);
@@ -1542,7 +1544,7 @@ constexpr uint32_t kMixSmemBytes = 144 * 1024;   // (k_lis_mixed has 15 KB of st
 bool use_mixed(const ShapePlan& P)
 {
   static const bool mixEnv = !(getenv("SPERR_HIP_LIS_MIXED") && atoi(getenv("SPERR_HIP_LIS_MIXED")) == 0);
-  if (!mixEnv || use_tables(P) || P.ht.cls.empty())
+  if (!mixEnv || use_tables(P) || P.ht.cls.empty() || P.ht.roots.size() > 48 || P.ht.grids.size() > 352)
     return false;
   const uint32_t w = mix_window(kMixSmemBytes);
   return w >= 512 && w >= P.ht.slotMaxT + 2;
@@ -1643,6 +1645,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
   d.mixSmemBytes = kMixSmemBytes;
   d.mixW = mix_window(kMixSmemBytes);
+  d.mixLevelGroup = P.d_levelGroup;
   d.leafCap = P.ht.nsets + 8;
   d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;

@@ -128,6 +128,7 @@ struct DecBuffers {
   // k_lis_mixed (chunks whose lists mix set shapes): window bits and dynamic LDS
   uint32_t mixW;
   uint32_t mixSmemBytes;
+  const uint8_t* mixLevelGroup;   // per list level: the column group (0..2) most of its entries belong to
 };
 
 struct DecPlanHost {
@@ -169,21 +170,21 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   return w;
 }
 
-// k_lis_mixed: LDS bytes per window bit are a row of eight coded lengths and one of four split
-// lengths (u16 each), the class word of a list entry the window may reach and the bit itself; the
-// item queue and the slack of the arrays are fixed.  The window is the largest multiple of 256
-// that fits.
+// k_lis_mixed: LDS bytes per window bit are a row of twelve split lengths (u16 each), the class
+// word of a list entry the window may reach, a slot of the list of candidate positions and the
+// bit itself; the item queue and the slack of the arrays are fixed.  The window is the largest
+// multiple of 256 that fits (at most 7936: the walk keeps its stream words in two registers).
 constexpr int kMixQueue = 1536;     // sets the walk of one window can hand to the expansion
 __host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
 {
-  const uint32_t perBit8 = 8u * (16u + 8u + 2u) + 1u;   // eighths of a byte
-  const uint32_t fixed = 6 * 8 + 2 * 24 + (uint32_t)kMixQueue * 12u + 64;
+  const uint32_t perBit8 = 8u * (24u + 2u + 2u) + 1u;   // eighths of a byte
+  const uint32_t fixed = 6 * 8 + 3 * 24 + (uint32_t)kMixQueue * 12u + 64;
   if (smemBytes <= fixed)
     return 0;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
   w = w / 256 * 256;
-  if (w > 16384u)
-    w = 16384u;
+  if (w > 7936u)
+    w = 7936u;
   return w;
 }
 

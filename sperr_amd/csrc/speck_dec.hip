@@ -2334,28 +2334,31 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
 // CPU model of this kernel.
 //
 // The code of a set depends on its extents only, so every set has a SHAPE CLASS (spk::ShapeCls,
-// built on the host): a leaf parent of 2, 4 or 8 samples, a set made of such leaf parents and
-// single samples (h = 1), and so on.  A list entry's class is read off the entry (spk::node_cls:
-// which of its three intervals are the long ones).  What pointer jumping needs -- one code
-// structure for all entries of a list -- is gone, so the list is walked by ONE thread, but the
-// walk only hops:
-//   rows     per window of W stream bits and for EVERY bit position q a row of eight 16-bit
-//            entries U[q][col]: the length of the CODED item of column col that starts at q (its
-//            test bit, and its split when that bit is set: bit 15), kUInf when it leaves the
-//            window.  Column 0 is a single sample, 1..3 the leaf parents of 2 / 4 / 8 samples,
-//            4..7 the most frequent h = 1 classes of the chunk shape (host: build_classes).  A
-//            second row T[q][0..3] is the split alone (an implied last child has no test bit).
-//            Speculative, all threads;
-//   walk     one thread: runs of '0' entries are counted off the stream (in front of a window by
-//            the whole workgroup), a significant entry whose class has a column costs one look-up,
-//            any other set is walked into child by child (its children's columns do the rest);
+// built on the host): a leaf parent of 2, 4 or 8 samples (h = 0), a set made of such leaf parents
+// and single samples (h = 1), and so on.  A list entry's class is read off the entry (which of
+// its three intervals are the long ones).  What pointer jumping needs -- one code structure for
+// all entries of a list -- is gone, so the list is walked serially, but the walk only hops:
+//   rows     per window of W stream bits and for every bit position x a row of twelve 16-bit
+//            entries T[x][col]: the bits the split of a set of column col takes when it starts at
+//            x (kTInf: it leaves the window, kTNone: not computed).  Column 0 is a single sample,
+//            1..3 the leaf parents of 2 / 4 / 8 samples (from the next 16 bits, every x), 4..7 and
+//            8..11 the most frequent h = 1 and h = 2 classes of the chunk shape (host:
+//            build_classes): a chain of look-ups through the children's columns, only where a
+//            coded item can start (the bit in front of x is set).  Speculative, all threads;
+//   walk     the first wavefront, control flow wave-uniform: runs of '0' entries are counted off
+//            the stream (in front of a window by the whole workgroup), a significant entry whose
+//            class has a column costs a few register look-ups (lane = position: the stream word
+//            and the row entries of the list's column group; lane = entry: its class), any other
+//            set is walked into: one look-up per child, the children's records written by one
+//            lane each;
 //   expand   every set that was hopped over is a work item: a thread finds its children with the
 //            rows; leaf parents become leaf events (k_leaf_apply), insignificant child sets are
 //            recorded with their stream position (k_place_scan / _scatter rank them).
 // ------------------------------------------------------------------------------------------
 constexpr int kMixThreads = 512;
-constexpr int kMixLdsRoots = 48, kMixLdsGrids = 352;
-constexpr uint32_t kUInf = 0xffffu;
+constexpr int kMixCols = 12;
+constexpr int kMixLdsRoots = 48, kMixLdsGrids = 352;   // (host: use_mixed checks that the tree fits)
+constexpr uint32_t kTNone = 0xfffeu;                   // (kTInf = 0xffff)
 
 struct MixCtx {
   uint64_t parent;     // packed node of the set being walked into
@@ -2379,32 +2382,28 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   __shared__ Grid sh_grids[kMixLdsGrids];
   __shared__ uint8_t sh_gridCls[kMixLdsGrids * 8];
   __shared__ MixCtx sh_ctx[kMaxDepth + 2];
-  __shared__ uint8_t sh_colCls[8];                  // class of columns 4..7 (0xff: unused)
+  __shared__ uint8_t sh_colCls[kMixCols];           // class of every column (0xff: unused)
   __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
   __shared__ uint64_t sh_pos;
-  __shared__ uint32_t sh_e, sh_rem, sh_qn, sh_born, sh_leaf, sh_zfound;
+  __shared__ uint32_t sh_e, sh_rem, sh_qn, sh_qn2, sh_born, sh_leaf, sh_zfound, sh_ncand;
   __shared__ int sh_depth;
   __shared__ uint32_t sh_scan[kMixThreads / 64 + 1];
 
   const int tid = threadIdx.x;
-  Tree t = b.tree;
-  if (tid < 8)
+  const uint32_t lane = (uint32_t)tid & 63u;
+  const uint32_t nlevels = b.tree.nlevels;
+  if (tid < kMixCols)
     sh_colCls[tid] = 0xff;
   if (tid < kMaxLevels)
-    sh_levelSlot[tid] = (uint32_t)tid < t.nlevels ? b.levelSlot[tid] : (uint8_t)0xff;
+    sh_levelSlot[tid] = (uint32_t)tid < nlevels ? b.levelSlot[tid] : (uint8_t)0xff;
   __syncthreads();
-  if (t.nroots <= (uint32_t)kMixLdsRoots && t.ngrids <= (uint32_t)kMixLdsGrids) {
-    for (uint32_t i = tid; i < t.nroots; i += kMixThreads)
-      sh_roots[i] = b.tree.roots[i];
-    for (uint32_t i = tid; i < t.ngrids; i += kMixThreads)
-      sh_grids[i] = b.tree.grids[i];
-    for (uint32_t i = tid; i < t.ngrids * 8; i += kMixThreads)
-      sh_gridCls[i] = b.tree.gridCls[i];
-    t.roots = sh_roots;
-    t.grids = sh_grids;
-    t.gridCls = sh_gridCls;
-  }
-  for (uint32_t i = tid; i < t.ncls; i += kMixThreads) {
+  for (uint32_t i = tid; i < b.tree.nroots; i += kMixThreads)
+    sh_roots[i] = b.tree.roots[i];
+  for (uint32_t i = tid; i < b.tree.ngrids; i += kMixThreads)
+    sh_grids[i] = b.tree.grids[i];
+  for (uint32_t i = tid; i < b.tree.ngrids * 8; i += kMixThreads)
+    sh_gridCls[i] = b.tree.gridCls[i];
+  for (uint32_t i = tid; i < b.tree.ncls; i += kMixThreads) {
     const ShapeCls cc = b.tree.cls[i];
     sh_cls[i] = cc;
     uint64_t kc = 0;
@@ -2413,10 +2412,9 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       kc |= (uint64_t)(kid == kClsPixel ? 0u : b.tree.cls[kid].slot) << (8 * k);
     }
     sh_kcol[i] = kc;
-    if (cc.slot >= 4 && cc.slot < 8)
+    if (cc.slot < kMixCols)
       sh_colCls[cc.slot] = (uint8_t)i;
   }
-  t.cls = sh_cls;
 
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
@@ -2432,14 +2430,14 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
 
   const uint32_t W = b.mixW;
-  const uint32_t kWords = (W / 64 + 4 + 1) & ~1u;
+  const uint32_t kWords = (W / 64 + 4 + 1) & ~1u;   // (at most 128: the walk keeps them in two registers per lane)
   uint64_t* wbits = reinterpret_cast<uint64_t*>(mix_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(mix_smem);
-  uint16_t* Urow = reinterpret_cast<uint16_t*>(mix_smem + (size_t)kWords * 8);   // [W + 2][8]
-  uint16_t* Trow = Urow + (size_t)(W + 2) * 8;                                    // [W + 2][4]
-  uint16_t* ecls = Trow + (size_t)(W + 2) * 4;                                    // [W]: class | column << 8
-  uint64_t* qid = reinterpret_cast<uint64_t*>(ecls + W);                          // [kMixQueue]
-  uint32_t* qmeta = reinterpret_cast<uint32_t*>(qid + kMixQueue);                 // [kMixQueue]
+  uint16_t* Tr = reinterpret_cast<uint16_t*>(mix_smem + (size_t)kWords * 8);      // [W + 3][12]
+  uint16_t* ecls = Tr + (size_t)(W + 3) * kMixCols;                               // [W]: class | column in the level's group << 8
+  uint16_t* cand = ecls + W;                                                      // [W]: positions where a coded item's split can start
+  uint64_t* qid = reinterpret_cast<uint64_t*>(mix_smem + (((size_t)kWords * 8 + ((size_t)(W + 3) * kMixCols + 2 * (size_t)W) * 2 + 7) & ~(size_t)7));
+  uint32_t* qmeta = reinterpret_cast<uint32_t*>(qid + kMixQueue);                 // first bit | class << 16 | list entry << 24
 
   if (tid == 0) {
     sh_pos = phase0;
@@ -2458,7 +2456,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   }
   if (stamps)
     stamp_t = __builtin_readcyclecounter();
-  uint64_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0;
+  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0;
 
   uint32_t wq0 = 0;  // bit offset of window position 0 inside wbits[0]
   auto bit_at = [&](uint32_t r) -> uint32_t {
@@ -2478,8 +2476,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
         atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
     }
   };
-  // a set born insignificant at stream position `abs`; k = its record (the walk counts its own
-  // records in a register, the expansion's threads claim theirs from sh_born)
+  // a set born insignificant at stream position phase0 + rel; k = its record (the walk counts its
+  // own records in a register, the expansion's threads claim theirs from sh_born)
   auto write_born = [&](uint32_t k, uint32_t lev, uint64_t rel, uint64_t packed) {
     if (k >= b.bornStride)
       return;
@@ -2493,6 +2491,46 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     if (sh_levelSlot[lev] == 0xff || rel >= maskBits)
       return;  // past the usable stream: decoding stops after this plane anyway
     write_born(atomicAdd(&sh_born, 1u), lev, rel, packed);
+  };
+  // geometry with the tree's tables in LDS (spk::kid_box / node_cls with these arrays)
+  auto kid_box_l = [&](const Node& nd, KidBox& k) {
+    const Grid g = sh_grids[nd.grid];
+    const Root r = sh_roots[g.root];
+    k.grid = (uint16_t)(nd.grid + 1);
+    uint32_t lev = r.lev;
+    const int d = g.depth;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int Da = r.D[a];
+      if (Da != 0) {   // spk::node_level
+        if (d < Da)
+          lev += (uint32_t)d;
+        else {
+          lev += (uint32_t)(Da - 1);
+          if (axis_len(r.len[a], Da - 1, (uint32_t)nd.i[a] >> 1) >= 2)
+            lev += 1;
+        }
+      }
+      const bool splits = d < Da;
+      k.e[a] = splits ? g.e[a] + 1 : g.e[a];
+      k.base[a] = splits ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
+      k.n[a] = (splits && axis_len(r.len[a], k.e[a], k.base[a] + 1u) > 0) ? 2u : 1u;
+      lev += k.n[a] - 1u;
+    }
+    k.kidlev = lev;
+    k.nk = k.n[0] * k.n[1] * k.n[2];
+  };
+  auto node_cls_l = [&](const Node& nd) -> uint32_t {
+    const Grid g = sh_grids[nd.grid];
+    const Root& r = sh_roots[g.root];
+    uint32_t k = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int e = g.e[a];
+      const uint32_t rem = (uint32_t)r.len[a] & ((1u << e) - 1u);
+      k |= (bitrev(nd.i[a], e) < rem ? 1u : 0u) << a;
+    }
+    return sh_gridCls[(uint32_t)nd.grid * 8u + k];
   };
   // a significant leaf parent of nk samples whose split starts at y: ONE event word (node id,
   // significance and sign masks by child ordinal) that k_leaf_apply turns into mask updates
@@ -2509,14 +2547,36 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       found |= bit;
       yy += bit;
     }
-    const Grid& g = t.grids[nd.grid];
+    const Grid& g = sh_grids[nd.grid];
     const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
     const uint32_t slot = atomicAdd(&sh_leaf, 1u);
     if (slot < b.leafCap)
       leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
   };
+  // bits of the split of a class (nk children, their columns in kc) that starts at x: one look-up
+  // per child through the children's columns
+  auto chain = [&](uint32_t nk, uint64_t kc, uint32_t x) -> uint32_t {
+    uint32_t y = x, found = 0, bad = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+      const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
+      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+      const uint32_t yy = min(y, W + 1);
+      const uint32_t bit = coded ? bit_at(yy) : 1u;
+      const uint32_t s0 = yy + coded;   // where the child's split (or a sample's sign) starts
+      uint32_t tl = Tr[(size_t)s0 * kMixCols + col];
+      if (tl >= kTNone) {
+        bad |= bit ? (tl == kTInf ? 1u : 2u) : 0u;
+        tl = 0;
+      }
+      y = bit ? s0 + tl : yy + 1;
+      found |= bit;
+    }
+    if ((bad & 1u) || y > W)
+      return kTInf;
+    return (bad & 2u) ? kTNone : y - x;
+  };
 
-  for (uint32_t l = t.nlevels; l-- > 0;) {
+  for (uint32_t l = nlevels; l-- > 0;) {
     const uint32_t n = s.listLen[cur][l];
     if (n == 0) {
       if (tid == 0)
@@ -2524,6 +2584,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       continue;
     }
     const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
+    const uint32_t grp = b.mixLevelGroup[l] & 3u;    // column group of (most of) this list's entries
+    const uint32_t topGrp = b.mixLevelGroup[l] >> 4;  // highest column group its windows can need
     for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kMixThreads)
       sigbits[i] = 0;
     if (tid == 0) {
@@ -2575,128 +2637,224 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       const uint64_t a = sh_pos;
       const uint32_t e0 = sh_e;
       const uint32_t ecnt = min(sh_rem, W);
-      __syncthreads();  // everyone has read the walker's state before thread 0 changes it
+      __syncthreads();  // everyone has read the walker's state before it changes
       const uint64_t w0 = a >> 6;
       wq0 = (uint32_t)(a & 63);
       for (uint32_t i = tid; i < kWords; i += kMixThreads) {
         const uint64_t idx = w0 + i;
         wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
       }
-      // classes (and columns) of the list entries this window can reach
+      // classes of the list entries this window can reach, with their column inside the list's group
       for (uint32_t i = tid; i < ecnt; i += kMixThreads) {
-        const uint32_t ci = node_cls(t, unpack_node(list[e0 + i]));
-        ecls[i] = (uint16_t)(ci | ((uint32_t)sh_cls[ci].slot << 8));
+        const uint32_t ci = node_cls_l(unpack_node(list[e0 + i]));
+        const uint32_t col = sh_cls[ci].slot;
+        ecls[i] = (uint16_t)(ci | ((col < (uint32_t)kMixCols && (col >> 2) == grp ? (col & 3u) : 0xffu) << 8));
       }
+      if (tid == 0)
+        sh_ncand = 0;
       __syncthreads();
       STAMP(0);
-      // ---- rows, columns 0..3: the thread of position x has the splits that start at x and, with
-      //      the bit in front of them, the coded items that start at x - 1
-      for (uint32_t x = tid; x <= W + 1; x += kMixThreads) {
-        const uint32_t v = bits32(x);
-        // children 0..6 coded one after the other; the last child of 2 / 4 / 8 is coded only when
-        // an earlier one was significant
-        uint32_t y = 0, found = 0, t2 = 0, t4 = 0, t8 = 0;
+      // ---- rows, columns 0..3 at every position (the next 16 bits give the three leaf parents'
+      //      splits), the other columns marked "not computed"; positions where a coded item's
+      //      split can start are collected
+      for (uint32_t x = tid; x <= W + 2; x += kMixThreads) {
+        uint32_t T0 = kTInf, T1 = kTInf, T2 = kTInf, T3 = kTInf, rest = 0xffffffffu;
+        bool isCand = false;
+        if (x < W) {
+          const uint32_t v = bits32(x);
+          // children 0..6 coded one after the other; the last child of 2 / 4 / 8 is coded only when
+          // an earlier one was significant
+          uint32_t y = 0, found = 0, t2 = 0, t4 = 0, t8 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (k == 1 || k == 3 || k == 7) {
-            const uint32_t bit = found ? (v >> y) & 1u : 1u;
-            const uint32_t tl = y + found + bit;
-            if (k == 1)
-              t2 = tl;
-            else if (k == 3)
-              t4 = tl;
-            else
-              t8 = tl;
-          }
-          if (k < 7) {
-            const uint32_t bit = (v >> y) & 1u;
-            found |= bit;
-            y += 1u + bit;
-          }
-        }
-        const uint32_t T0 = x + 1 <= W ? 1u : kUInf;
-        const uint32_t T1 = x + t2 <= W ? t2 : kUInf;
-        const uint32_t T2 = x + t4 <= W ? t4 : kUInf;
-        const uint32_t T3 = x + t8 <= W ? t8 : kUInf;
-        *reinterpret_cast<uint2*>(Trow + (size_t)x * 4) = make_uint2(T0 | (T1 << 16), T2 | (T3 << 16));
-        if (x >= 1) {
-          const uint32_t q = x - 1;
-          uint32_t u0 = kUInf, u1 = kUInf, u2 = kUInf, u3 = kUInf;
-          if (q < W) {
-            if (!bit_at(q))
-              u0 = u1 = u2 = u3 = 1u;
-            else {
-              u0 = T0 == kUInf ? kUInf : 0x8002u;
-              u1 = T1 == kUInf ? kUInf : 0x8001u + T1;
-              u2 = T2 == kUInf ? kUInf : 0x8001u + T2;
-              u3 = T3 == kUInf ? kUInf : 0x8001u + T3;
+          for (int k = 0; k < 8; k++) {
+            if (k == 1 || k == 3 || k == 7) {
+              const uint32_t bit = found ? (v >> y) & 1u : 1u;
+              const uint32_t tl = y + found + bit;
+              if (k == 1)
+                t2 = tl;
+              else if (k == 3)
+                t4 = tl;
+              else
+                t8 = tl;
+            }
+            if (k < 7) {
+              const uint32_t bit = (v >> y) & 1u;
+              found |= bit;
+              y += 1u + bit;
             }
           }
-          *reinterpret_cast<uint2*>(Urow + (size_t)q * 8) = make_uint2(u0 | (u1 << 16), u2 | (u3 << 16));
-          if (q == W)
-            *reinterpret_cast<uint2*>(Urow + (size_t)(W + 1) * 8) = make_uint2(0xffffffffu, 0xffffffffu);
+          T0 = 1u;
+          T1 = x + t2 <= W ? t2 : kTInf;
+          T2 = x + t4 <= W ? t4 : kTInf;
+          T3 = x + t8 <= W ? t8 : kTInf;
+          rest = kTNone | (kTNone << 16);
+          isCand = x >= 1 && bit_at(x - 1) != 0;
+        }
+        uint2* row = reinterpret_cast<uint2*>(Tr + (size_t)x * kMixCols);
+        row[0] = make_uint2(T0 | (T1 << 16), T2 | (T3 << 16));
+        row[1] = make_uint2(rest, rest);
+        row[2] = make_uint2(rest, rest);
+        const uint64_t cm = __ballot(isCand);
+        if (cm) {
+          uint32_t base = 0;
+          const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(true)) - 1u;
+          if (lane == leader)
+            base = atomicAdd(&sh_ncand, (uint32_t)__popcll(cm));
+          base = __shfl(base, (int)leader, 64);
+          if (isCand)
+            cand[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)x;
         }
       }
       __syncthreads();
-      // ---- columns 4..7: a chain of look-ups through the children's columns, only where the item's
-      //      test bit is set
-      for (uint32_t col = 4; col < 8; col++) {
-        const uint32_t ci = sh_colCls[col];
-        if (ci == 0xff)
-          continue;
-        const uint32_t nk = sh_cls[ci].nk;
-        const uint64_t kc = sh_kcol[ci];
-        for (uint32_t q = tid; q <= W + 1; q += kMixThreads) {
-          uint32_t u = kUInf;
-          if (q < W) {
-            if (!bit_at(q))
-              u = 1u;
-            else {
-              uint32_t y = q + 1, fl = 0;
-              for (uint32_t k = 0; k + 1 < nk; k++) {
-                const uint32_t uu = Urow[(size_t)y * 8 + ((uint32_t)(kc >> (8 * k)) & 0xffu)];
-                fl |= uu;
-                y = min(y + (uu & 0x7fffu), W + 1);
-              }
-              const uint32_t lc = (uint32_t)(kc >> (8 * (nk - 1))) & 0xffu;
-              const uint32_t uu = (fl & 0x8000u) ? Urow[(size_t)y * 8 + lc] : Trow[(size_t)y * 4 + lc];
-              y = min(y + (uu & 0x7fffu), W + 1);
-              if (y <= W)
-                u = 0x8000u | (y - q);
+      // ---- columns 4..7, then 8..11: a chain of look-ups through the children's columns at the
+      //      collected positions (two per thread and round: their LDS round trips overlap)
+      {
+        const uint32_t ncand = sh_ncand;
+        for (uint32_t g4 = 4; g4 <= 4u * topGrp; g4 += 4) {
+          bool any = false;
+          for (uint32_t col = g4; col < g4 + 4; col++) {
+            const uint32_t ci = sh_colCls[col];
+            if (ci == 0xff)
+              continue;
+            any = true;
+            const uint32_t nk = sh_cls[ci].nk;
+            const uint64_t kc = sh_kcol[ci];
+            for (uint32_t i = tid; i < ncand; i += 2 * kMixThreads) {
+              const uint32_t i2 = i + kMixThreads;
+              const uint32_t x1 = cand[i], x2 = i2 < ncand ? cand[i2] : 0u;
+              const uint32_t t1 = chain(nk, kc, x1);
+              const uint32_t t2 = i2 < ncand ? chain(nk, kc, x2) : 0u;
+              Tr[(size_t)x1 * kMixCols + col] = (uint16_t)t1;
+              if (i2 < ncand)
+                Tr[(size_t)x2 * kMixCols + col] = (uint16_t)t2;
             }
           }
-          Urow[(size_t)q * 8 + col] = (uint16_t)u;
+          if (any)
+            __syncthreads();
         }
       }
       __syncthreads();
       STAMP(1);
-      // ---- the walk: one thread
-      if (tid == 0) {
-        uint32_t r = 0, e = sh_e, rem = sh_rem, qn = 0, nborn = sh_born;
-        int depth = sh_depth;
-#ifdef MIX_WALK_SPLIT
-        uint64_t walk_t = __builtin_readcyclecounter();
-        int lastKind = 8;
-#endif
-        while (true) {
-          if (r >= W || qn >= (uint32_t)kMixQueue)
-            break;
-#ifdef MIX_WALK_SPLIT
-          {
-            const uint64_t now_ = __builtin_readcyclecounter();
-            if (stamps)
-              stamp_acc[lastKind] += now_ - walk_t;
-            walk_t = now_;
-            lastKind = depth == 1 ? 6 : 7;
+      // ---- the walk: the first wavefront, every lane carrying the same walker state
+      if (tid < 64) {
+        // (the walker's state is wave-uniform: kept in scalar registers)
+        uint32_t r = 0, e = __builtin_amdgcn_readfirstlane(sh_e), rem = __builtin_amdgcn_readfirstlane(sh_rem);
+        uint32_t qn = 0, qcost = 0, nborn = __builtin_amdgcn_readfirstlane(sh_born), ns = 0;
+        int depth = __builtin_amdgcn_readfirstlane(sh_depth);
+        const uint32_t itemCost = grp == 2u ? 9u : 1u;   // (an h = 2 item queues up to 8 more)
+        const uint32_t e_in = e;
+        const int depth_in = depth;
+        uint32_t stE = 0, stM = 0;   // staged items of the list hops: lane = item
+        // lane = stream word of the window
+        const uint64_t sw0 = wbits[lane];
+        const uint64_t sw1 = lane + 64u < kWords ? wbits[lane + 64u] : 0ull;
+        uint32_t curK = 0xffffffffu;   // stream word the registers below belong to
+        uint64_t m = 0;                // that word (uniform)
+        uint64_t lrow = 0;             // lane = bit of it: the group's four row entries one position on
+        uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
+        uint64_t lrowNext = 0;         // the same for word nextK
+        uint32_t nextK = 0xfffffffeu;
+        auto load_lrow = [&](uint32_t kk) -> uint64_t {
+          const int32_t row = (int32_t)(kk * 64u + lane) - (int32_t)wq0 + 1;
+          return (row >= 0 && row <= (int32_t)W + 2)
+                     ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMixCols + grp * 4u)
+                     : ~0ull;
+        };
+        uint32_t eb = e + 64u;         // lane = list entry eb + lane: its ecls word (nothing loaded yet)
+        uint32_t ecv = 0;
+        auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
+          return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);
+        };
+        auto rl64 = [&](uint64_t v, uint32_t idx) -> uint64_t {
+          return (uint64_t)rl32((uint32_t)v, idx) | ((uint64_t)rl32((uint32_t)(v >> 32), idx) << 32);
+        };
+        auto flush = [&]() {
+          if (lane < ns) {
+            qid[qn + lane] = stE;
+            qmeta[qn + lane] = stM;
           }
-#endif
+          qn += ns;
+          ns = 0;
+        };
+        while (true) {
+          if (r >= W || qcost + 80u >= (uint32_t)kMixQueue)
+            break;
           if (depth == 1) {   // the list itself
             if (rem == 0) {
               depth = 0;
               break;
             }
-            const uint64_t bits = (uint64_t)bits32(r) | ((uint64_t)bits32(r + 32) << 32);
-            const uint32_t z = min(min(bits ? (uint32_t)__ffsll((long long)bits) - 1u : 64u, rem), W - r);
+            const uint32_t q = r + wq0, k = q >> 6, o = q & 63u;
+            if (k != curK) {
+              curK = k;
+              m = k < 64u ? rl64(sw0, k) : rl64(sw1, k - 64u);
+              lrowK = 0xffffffffu;
+            }
+            if ((m >> o) == 0ull && rem >= 64u - o && k * 64u + 64u <= W + wq0) {
+              // the rest of the word holds no '1': insignificant entries, nothing to look up
+              cnt_zruns++;
+              r += 64u - o;
+              e += 64u - o;
+              rem -= 64u - o;
+              continue;
+            }
+            if (lrowK != k) {   // (the next word's entries are fetched while this word is walked)
+              lrow = nextK == k ? lrowNext : load_lrow(k);
+              lrowK = k;
+              nextK = k + 1u;
+              lrowNext = load_lrow(nextK);
+            }
+            // A stream word that lies inside the window, with at least 64 entries left and room
+            // for 64 items: its entries in a tight loop -- no end-of-list, end-of-window or queue
+            // checks per entry; anything unusual (a set to walk into, a split that leaves the
+            // window) is left to the general code below.
+            if (rem >= 64u && k * 64u + 64u <= W + wq0 && qcost + 64u * itemCost + 80u < (uint32_t)kMixQueue) {
+              const uint32_t eEnd = e + rem;
+              // (at most 64 entries start inside the word, at most 32 of them significant: one load
+              // of entry classes and the staging registers cover it)
+              if (e - eb > o) {   // (the entries of this word: fewer than 64 - o from e on)
+                eb = e;
+                ecv = e - e0 + lane < ecnt ? ecls[e - e0 + lane] : 0xffffu;
+              }
+              if (ns > 32u)
+                flush();
+              const uint32_t ns0 = ns;
+              const uint32_t pbase = k * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
+              uint32_t oo = o;   // bit of the word the walk is at: below 64 at the top of the loop
+              while (true) {
+                const uint64_t mm = m >> oo;
+                const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
+                oo += z;
+                e += z;
+                const uint32_t ec = rl32(ecv, (e - eb) & 63u);
+                const uint32_t loc = ec >> 8;
+                const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
+                if (oo >= 64u || loc == 0xffu || tl >= kTNone)
+                  break;   // the word is done, or something the general code has to look at
+                {   // lane ns of the staging registers takes the item (the values stay scalar)
+                  const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
+                  const uint32_t itemE = __builtin_amdgcn_readfirstlane(e), itemL = __builtin_amdgcn_readfirstlane(ns);
+                  asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                               : "+v"(stE), "+v"(stM)
+                               : "s"(itemE), "s"(itemL), "s"(itemM)
+                               : "m0");
+                }
+                ns++;
+                oo += 1u + tl;
+                e++;
+                if (oo >= 64u)
+                  break;
+              }
+              cnt_hops += ns - ns0;
+              qcost += (ns - ns0) * itemCost;
+              r = k * 64u + oo - wq0;
+              rem = eEnd - e;
+              if (oo >= 64u)
+                continue;   // on to the next word
+            }
+            const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
+            const uint64_t tt = m >> o2;
+            const uint32_t z = min(min(tt ? (uint32_t)__ffsll((long long)tt) - 1u : 64u - o2, rem), W - r);
             if (z) {
               cnt_zruns++;
               r += z;
@@ -2705,27 +2863,43 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
               continue;
             }
             cnt_hops++;
-            const uint32_t ec = ecls[e - e0];
-            const uint32_t col = ec >> 8, ci = ec & 0xffu;
-            if (col != 0xffu) {
-              const uint32_t u = Urow[(size_t)r * 8 + col];
-              if (u == kUInf)
-                break;   // the next window starts at this entry
-              qid[qn] = e;
-              qmeta[qn] = (r + 1) | (ci << 16) | (1u << 24);
-              qn++;
-              r += u & 0x7fffu;
+            if (e - eb >= 64u) {
+              eb = e;
+              ecv = e - e0 + lane < ecnt ? ecls[e - e0 + lane] : 0xffffu;
             }
-            else {
+            const uint32_t ec = rl32(ecv, e - eb);
+            const uint32_t loc = ec >> 8, ci = ec & 0xffu;
+            uint32_t tl = kTNone;
+            if (loc != 0xffu)
+              tl = (uint32_t)(rl64(lrow, o2) >> (16u * loc)) & 0xffffu;
+            if (tl == kTInf)
+              break;   // the next window starts at this entry
+            if (tl != kTNone) {
+              if (lane == ns) {
+                stE = e;
+                stM = (r + 1u) | (ci << 16) | (1u << 24);
+              }
+              ns++;
+              qcost += itemCost;
+              if (ns == 64u)
+                flush();
+              r += 1u + tl;
+            }
+            else {   // walk into it
               cnt_push++;
               const uint64_t packed = list[e];
-              atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
-              MixCtx& nc = sh_ctx[1];
-              nc.parent = packed;
-              kid_box(t, unpack_node(packed), nc.kb);
-              nc.pc = (uint8_t)ci;
-              nc.next = 0;
-              nc.found = 0;
+              if (lane == 0)
+                atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
+              KidBox kb;
+              kid_box_l(unpack_node(packed), kb);
+              if (lane == 0) {
+                MixCtx& nc = sh_ctx[1];
+                nc.parent = packed;
+                nc.kb = kb;
+                nc.pc = (uint8_t)ci;
+                nc.next = 0;
+                nc.found = 0;
+              }
               depth = 2;
               r += 1;
             }
@@ -2733,94 +2907,139 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             rem--;
             continue;
           }
-          // a set that is being walked into: its next child
+          // ---- a set that is being walked into: its children from `next` on, one look-up each;
+          //      lane k remembers what became of child k and writes its record afterwards
           MixCtx& cx = sh_ctx[depth - 1];
           const uint32_t pc = cx.pc;
           const uint32_t nk = sh_cls[pc].nk;
-          const uint32_t k = cx.next;
-          if (k == nk) {
-            depth--;
-            continue;
-          }
-          cnt_steps++;
-          const uint32_t kc = sh_cls[pc].kid[k];
-          const uint32_t col = (uint32_t)(sh_kcol[pc] >> (8 * k)) & 0xffu;
-          const bool coded = cx.found || (k + 1 != nk);
-          if (kc == kClsPixel) {
-            uint32_t sig = 1, sgn, len = 1;
-            if (coded) {
-              const uint32_t u = Urow[(size_t)r * 8];
-              if (u == kUInf)
-                break;
-              sig = u >> 15;
-              len = u & 0x7fffu;
-              sgn = sig ? bit_at(r + 1) : 1u;
+          const uint64_t kcol = sh_kcol[pc];
+          const uint64_t parent = cx.parent;
+          const KidBox kb = cx.kb;
+          const uint32_t k0 = cx.next;
+          uint32_t found = cx.found, k = k0;
+          uint32_t myAct = 0, myY = 0;   // 1: born insignificant (test bit at myY), 2: hopped over (split starts at myY)
+          bool pushed = false, halted = false;
+          while (k < nk) {
+            if (r >= W) {
+              halted = true;
+              break;
             }
-            else
-              sgn = bit_at(r);
-            pixel_event(kid_pixel_raster(t, unpack_node(cx.parent), cx.kb, k), sig != 0, sgn);
-            if (sig)
-              cx.found = 1;
-            cx.next = (uint8_t)(k + 1);
-            r += len;
-            continue;
-          }
-          const uint64_t kid = kid_packed(cx.kb, k);
-          uint32_t start = r;   // first bit of the child's split
-          if (coded) {
-            if (!bit_at(r)) {
-              const uint64_t rel = a + r - phase0;
-              if (sh_levelSlot[cx.kb.kidlev] != 0xff && rel < maskBits)
-                write_born(nborn++, cx.kb.kidlev, rel, kid);
-              cx.next = (uint8_t)(k + 1);
-              r += 1;
+            cnt_steps++;
+            const uint32_t col = (uint32_t)(kcol >> (8 * k)) & 0xffu;
+            const bool coded = found || (k + 1 != nk);
+            if (col == 0) {   // a single sample
+              uint32_t sig = 1, sgn, len = 1;
+              if (coded) {
+                sig = bit_at(r);
+                if (sig && r + 1 >= W) {
+                  halted = true;
+                  break;
+                }
+                sgn = sig ? bit_at(r + 1) : 1u;
+                len = 1u + sig;
+              }
+              else
+                sgn = bit_at(r);
+              if (lane == 0)
+                pixel_event(kid_pixel_raster(b.tree, unpack_node(parent), kb, k), sig != 0, sgn);
+              found |= sig;
+              r += len;
+              k++;
               continue;
             }
-            start = r + 1;
-          }
-          uint32_t len = kUInf;   // bits from r to the end of the child's split, when a row has them
-          if (col != 0xffu && coded) {
-            const uint32_t u = Urow[(size_t)r * 8 + col];
-            if (u == kUInf)
-              break;   // the next window starts at this child's first bit
-            len = u & 0x7fffu;
-          }
-          else if (col != 0xffu && col < 4u) {
-            const uint32_t tl = Trow[(size_t)r * 4 + col];
-            if (tl == kUInf)
+            uint32_t start = r, bit = 1;
+            if (coded) {
+              bit = bit_at(r);
+              start = r + 1;
+            }
+            if (!bit) {
+              if (lane == k) {
+                myAct = 1;
+                myY = r;
+              }
+              r += 1;
+              k++;
+              continue;
+            }
+            const uint32_t tl = col != 0xffu ? (uint32_t)Tr[(size_t)start * kMixCols + col] : kTNone;
+            if (tl == kTInf) {
+              halted = true;   // the next window starts at this child's first bit
               break;
-            len = tl;
-          }
-          cx.found = 1;
-          cx.next = (uint8_t)(k + 1);
-          if (len != kUInf) {
-            qid[qn] = kid;
-            qmeta[qn] = start | (kc << 16);
-            qn++;
-            r += len;
-          }
-          else {
-            cnt_push++;
-            MixCtx& nc = sh_ctx[depth];
-            nc.parent = kid;
-            kid_box(t, unpack_node(kid), nc.kb);
-            nc.pc = (uint8_t)kc;
-            nc.next = 0;
-            nc.found = 0;
-            depth++;
+            }
+            found = 1;
+            if (tl != kTNone) {
+              if (lane == k) {
+                myAct = 2;
+                myY = start;
+              }
+              qcost += (col >> 2) == 2u ? 9u : 1u;
+              r = start + tl;
+              k++;
+              continue;
+            }
+            k++;   // walk into this child
+            pushed = true;
             r = start;
+            break;
           }
+          // the records of the children handled in this round
+          {
+            const uint64_t rel = a + myY - phase0;
+            const bool bornOk = myAct == 1 && sh_levelSlot[kb.kidlev] != 0xff && rel < maskBits;
+            const uint64_t bm = __ballot(bornOk);
+            if (bornOk)
+              write_born(nborn + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), kb.kidlev, rel,
+                         kid_packed(kb, lane));
+            nborn += (uint32_t)__popcll(bm);
+            const uint64_t im = __ballot(myAct == 2);
+            if (im) {
+              flush();
+              if (myAct == 2) {
+                const uint32_t idx = qn + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
+                qid[idx] = kid_packed(kb, lane);
+                qmeta[idx] = myY | ((uint32_t)sh_cls[pc].kid[lane] << 16);
+              }
+              qn += (uint32_t)__popcll(im);
+            }
+          }
+          if (lane == 0) {
+            cx.next = (uint8_t)k;
+            cx.found = (uint8_t)found;
+          }
+          if (pushed) {
+            cnt_push++;
+            const uint64_t kid = kid_packed(kb, k - 1);
+            KidBox nkb;
+            kid_box_l(unpack_node(kid), nkb);
+            if (lane == 0) {
+              MixCtx& nc = sh_ctx[depth];
+              nc.parent = kid;
+              nc.kb = nkb;
+              nc.pc = sh_cls[pc].kid[k - 1];
+              nc.next = 0;
+              nc.found = 0;
+            }
+            depth++;
+          }
+          else if (halted)
+            break;
+          else
+            depth--;
         }
+        flush();
         // (a window that changes nothing would be walked for ever: cannot happen while the window is
         // longer than every split that has a column, which the host checks -- kept as a guard)
         cnt_bits += r;
-        const bool stuck = r == 0 && e == sh_e && depth == sh_depth && qn == 0;
-        sh_pos = a + r;
-        sh_e = e;
-        sh_rem = rem;
-        sh_depth = stuck ? -1 : depth;
-        sh_qn = qn;
-        sh_born = nborn;
+        const bool stuck = r == 0 && e == e_in && depth == depth_in && qn == 0;
+        if (lane == 0) {
+          sh_pos = a + r;
+          sh_e = e;
+          sh_rem = rem;
+          sh_depth = stuck ? -1 : depth;
+          sh_qn = qn;
+          sh_qn2 = qn;
+          sh_born = nborn;
+        }
       }
       __syncthreads();
       if (sh_depth < 0) {
@@ -2833,65 +3052,66 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       STAMP(2);
       if (stamps)
         stamp_acc[9] += 1;
-      // ---- expand what was hopped over
+      // ---- expand what was hopped over: the walk's items, then the h = 1 children of its h = 2 items
       {
-        const uint32_t nin = sh_qn;
-        cnt_items += nin;
-        for (uint32_t i = tid; i < nin; i += kMixThreads) {
-          const uint64_t ident = qid[i];
-          const uint32_t meta = qmeta[i];
-          const uint32_t ci = (meta >> 16) & 0xffu;
-          uint32_t y = meta & 0xffffu;
-          uint64_t packed = ident;
-          if (meta >> 24) {
-            packed = list[ident];
-            atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
-          }
-          const Node nd = unpack_node(packed);
-          const uint32_t nk = sh_cls[ci].nk;
-          if (sh_cls[ci].h == 0) {
-            leaf_event(nd, y, nk);
-            continue;
-          }
-          KidBox kb;
-          kid_box(t, nd, kb);
-          const uint64_t kc = sh_kcol[ci];
-          uint32_t found = 0;
-          for (uint32_t k = 0; k < nk; k++) {
-            const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-            const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
-            if (col == 0) {   // a single sample
-              uint32_t sig = 1, sgn, len = 1;
-              if (coded) {
-                const uint32_t u = Urow[(size_t)y * 8];
-                sig = u >> 15;
-                len = u & 0x7fffu;
-                sgn = sig ? bit_at(y + 1) : 1u;
-              }
-              else
-                sgn = bit_at(y);
-              pixel_event(kid_pixel_raster(t, nd, kb, k), sig != 0, sgn);
-              found |= sig;
-              y += len;
+        const uint32_t n1 = sh_qn;
+        cnt_items += n1;
+        for (int round = 0; round < 2; round++) {
+          const uint32_t i0 = round == 0 ? 0u : n1;
+          const uint32_t i1 = round == 0 ? n1 : min(sh_qn2, (uint32_t)kMixQueue);
+          for (uint32_t i = i0 + tid; i < i1; i += kMixThreads) {
+            const uint64_t ident = qid[i];
+            const uint32_t meta = qmeta[i];
+            const uint32_t ci = (meta >> 16) & 0xffu;
+            uint32_t y = meta & 0xffffu;
+            uint64_t packed = ident;
+            if (meta >> 24) {
+              packed = list[ident];
+              atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
+            }
+            const Node nd = unpack_node(packed);
+            const uint32_t nk = sh_cls[ci].nk;
+            if (sh_cls[ci].h == 0) {
+              leaf_event(nd, y, nk);
               continue;
             }
-            uint32_t start = y;
-            if (coded) {
-              const uint32_t u = Urow[(size_t)y * 8 + col];
-              if (!(u & 0x8000u)) {
+            KidBox kb;
+            kid_box_l(nd, kb);
+            const uint64_t kc = sh_kcol[ci];
+            uint32_t found = 0;
+            for (uint32_t k = 0; k < nk; k++) {
+              const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+              const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
+              const uint32_t bit = coded ? bit_at(y) : 1u;
+              const uint32_t start = y + coded;
+              if (col == 0) {   // a single sample: its sign follows
+                pixel_event(kid_pixel_raster(b.tree, nd, kb, k), bit != 0, bit ? bit_at(start) : 1u);
+                found |= bit;
+                y = start + bit;
+                continue;
+              }
+              if (!bit) {
                 record_born(kb.kidlev, a + y, kid_packed(kb, k));
                 y += 1;
                 continue;
               }
-              start = y + 1;
-              y += u & 0x7fffu;
+              found = 1;
+              // (an implied child is the last one: nothing follows it, its length is not needed)
+              y = start + (coded ? (uint32_t)Tr[(size_t)start * kMixCols + col] : 0u);
+              if (col < 4u)
+                leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
+              else {
+                const uint32_t slot = atomicAdd(&sh_qn2, 1u);
+                if (slot < (uint32_t)kMixQueue) {
+                  qid[slot] = kid_packed(kb, k);
+                  qmeta[slot] = start | ((uint32_t)sh_cls[ci].kid[k] << 16);
+                }
+              }
             }
-            found = 1;   // (an implied child is the last one: nothing follows it in this split)
-            leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
           }
+          __syncthreads();
         }
       }
-      __syncthreads();
       STAMP(3);
     }
     // ---- old entries that stayed insignificant keep their order

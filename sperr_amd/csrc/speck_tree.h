@@ -75,7 +75,7 @@ constexpr int kMaxCls = 254;
 struct ShapeCls {
   uint8_t nk;              // children, 1..8 (empty halves do not exist)
   uint8_t h;               // 0: every child is a single sample; else 1 + the largest h of a child
-  uint8_t slot;            // table column of the class (1..7), 0xff: no table (such sets are walked into)
+  uint8_t slot;            // table column of the class (1..11), 0xff: no table (such sets are walked into)
   uint8_t nsplit;          // axes longer than one sample: the children's list level is the set's + nsplit
   uint8_t kid[8];          // class of child k in the reference's order
   uint32_t maxT;           // upper bound of the bits of a split

@@ -71,6 +71,7 @@ struct HostTree {
   std::vector<ShapeCls> cls;                   // shape classes, children first (empty: too many)
   std::vector<uint8_t> gridCls;                // [grid][8]
   std::vector<uint64_t> clsCount;              // sets of the forest per class
+  std::vector<uint8_t> levelGroup;             // per list level: column group of most of its entries
   uint32_t nslots = 0;                         // classes that have a table slot
   uint32_t slotMaxT = 0;                       // longest split of a class with a table
   uint32_t dims[3] = {0, 0, 0};
@@ -112,11 +113,11 @@ inline int ceil_log2(uint32_t v)
 }
 }  // namespace detail
 
-constexpr int kClsTableH = 1;            // default: tables for leaf parents and their parents
+constexpr int kClsTableH = 2;            // default: tables up to two steps above the leaf parents
 constexpr uint32_t kClsTableSlots = 4;
 
 // Shape classes of every set of the forest (speck_tree.h, ShapeCls).  hmax >= 0: the leaf parents
-// get table slots, hmax >= 1: up to `maxSlots` (at most 4) of the classes made of leaf parents too.
+// get table slots, hmax >= 1 / 2: up to `maxSlots` (at most 4) of the classes one / two steps up.
 inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minShare = 0.02)
 {
   h.cls.clear();
@@ -236,7 +237,8 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
   }
   // Table slots = columns of the decoder's per-position rows (k_lis_mixed): 0 is the single
   // sample, 1..3 the leaf parents of 2, 4 and 8 samples, 4..7 the most frequent classes made of
-  // those (h = 1: each must hold at least `minShare` of all such sets to be worth a column).
+  // those (h = 1), 8..11 the most frequent classes one step up (h = 2); a class must hold at least
+  // `minShare` of the sets of its h to be worth a column, and needs columns for all its children.
   if (hmax >= 0)
     for (ShapeCls& c : h.cls)
       if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8)) {
@@ -244,21 +246,22 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
         h.nslots++;
         h.slotMaxT = std::max(h.slotMaxT, c.maxT);
       }
-  if (hmax >= 1) {
+  for (int hh = 1; hh <= std::min(hmax, 2); hh++) {
     uint64_t all = 0;
     std::vector<size_t> order;
     for (size_t i = 0; i < h.cls.size(); i++)
-      if (h.cls[i].h == 1) {
+      if (h.cls[i].h == hh) {
         all += h.clsCount[i];
         order.push_back(i);
       }
     std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
       return h.clsCount[x] != h.clsCount[y] ? h.clsCount[x] > h.clsCount[y] : x < y;
     });
-    uint32_t next = 4;
+    uint32_t next = 4u * (uint32_t)hh;
     for (size_t i : order) {
       ShapeCls& c = h.cls[i];
-      bool ok = next < 4 + std::min<uint32_t>(maxSlots, 4) && (double)h.clsCount[i] >= minShare * (double)all;
+      bool ok = next < 4u * (uint32_t)hh + std::min<uint32_t>(maxSlots, 4) && c.maxT < 0x7000u &&
+                (double)h.clsCount[i] >= minShare * (double)all;
       for (int k = 0; k < c.nk; k++)
         ok = ok && (c.kid[k] == kClsPixel || h.cls[c.kid[k]].slot != 0xff);
       if (!ok)
@@ -267,6 +270,38 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
       h.nslots++;
       h.slotMaxT = std::max(h.slotMaxT, c.maxT);
     }
+  }
+  // the column group (slot / 4) most entries of each list level belong to: the walk keeps that
+  // group's lengths in registers, entries of other groups are walked into
+  h.levelGroup.assign(h.nlevels, 0);
+  if (!h.allRegular) {
+    std::vector<std::array<uint64_t, 3>> cnt(h.nlevels, {0, 0, 0});
+    std::vector<uint32_t> top(h.nlevels, 0);
+    const Tree tv = h.view();
+    for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
+      const Grid& g = h.grids[gi];
+      Node n;
+      n.grid = (uint16_t)gi;
+      for (uint32_t z = 0; z < (1u << g.e[2]); z++)
+        for (uint32_t y = 0; y < (1u << g.e[1]); y++)
+          for (uint32_t x = 0; x < (1u << g.e[0]); x++) {
+            n.i[0] = (uint16_t)x;
+            n.i[1] = (uint16_t)y;
+            n.i[2] = (uint16_t)z;
+            const uint32_t ci = node_cls(tv, n);
+            if (ci == kClsPixel)
+              continue;
+            const uint32_t l = node_level(tv, n);
+            top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, 2));
+            if (h.cls[ci].slot != 0xff)
+              cnt[l][h.cls[ci].slot >> 2]++;
+          }
+    }
+    // (bits 4..5: the highest column group a window of this level's list can need: sets of h = 0
+    // are never walked into and have no set children, and so on)
+    for (uint32_t l = 0; l < h.nlevels; l++)
+      h.levelGroup[l] = (uint8_t)((cnt[l][2] > cnt[l][1] && cnt[l][2] > cnt[l][0] ? 2 : cnt[l][1] > cnt[l][0] ? 1 : 0) |
+                                  (top[l] << 4));
   }
 }
 

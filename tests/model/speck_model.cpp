@@ -1074,7 +1074,7 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
       while (!listDone) {
         const uint64_t a = pos;
         // ---- tables of the window (parallel in the kernel: one thread per position and slot)
-        std::vector<std::vector<uint32_t>> T(8, std::vector<uint32_t>(W + 2, T_INF));
+        std::vector<std::vector<uint32_t>> T(12, std::vector<uint32_t>(W + 2, T_INF));
         for (uint32_t ci = 0; ci < cls.size(); ci++) {   // (classes are numbered children first)
           if (cls[ci].slot == 0xff)
             continue;

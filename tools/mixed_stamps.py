@@ -29,8 +29,5 @@ print("windows %d: ticks/window tables %d walk %d expand %d load %d; stream bits
       (out[9], out[1] // w, out[2] // w, out[3] // w, out[0] // w, out[20] // w))
 print("walk: %d significant list entries, %d child steps in %d entered sets, %d zero runs; %d skip rounds; %d expanded items"
       % (out[16], out[17], out[18], out[19], out[21], out[22]))
-if out[6] + out[7]:
-    print("walk split: list part %d ticks (%.0f per hop or zero run), entered sets %d ticks (%.0f per child step)"
-          % (out[6], out[6] / max(out[16] + out[19], 1), out[7], out[7] / max(out[17], 1)))
 if out[16] + out[17]:
     print("walk ticks per hop/step: %.0f" % (out[2] / (out[16] + out[17] + out[19])))
