@@ -9,7 +9,7 @@
 //                always followed by its sign bit), so token starts and token ranks come from
 //                prefix sums; the results are written by token rank and picked up by the pixels
 //                through the rank of each candidate in raster order;
-//   LIS phase    (k_lis_tables, or k_lis_walk for irregular shapes)  what each bit means depends
+//   LIS phase    (k_lis_l0/_l1/_hi or k_lis_tables; k_lis_mixed for lists that mix set shapes)  what each bit means depends
 //                on every earlier bit of the phase: one workgroup per chunk; chunks run
 //                concurrently;
 //   refinement   (k_ref_apply)  the j-th significant pixel in raster order takes bit j.

@@ -1269,4 +1269,65 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
   return 0;
 }
 
+// every set node against its shape class (tests/test_speck_model.py::test_shape_classes_are_consistent)
+int model_check_classes(const size_t dims[3])
+{
+  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  if (ht.cls.empty())
+    return -2;
+  const Tree t = ht.view();
+  for (uint32_t gi = 0; gi < ht.grids.size(); gi++) {
+    const Grid& g = ht.grids[gi];
+    Node n;
+    n.grid = (uint16_t)gi;
+    for (uint32_t z = 0; z < (1u << g.e[2]); z++)
+      for (uint32_t y = 0; y < (1u << g.e[1]); y++)
+        for (uint32_t x = 0; x < (1u << g.e[0]); x++) {
+          n.i[0] = (uint16_t)x;
+          n.i[1] = (uint16_t)y;
+          n.i[2] = (uint16_t)z;
+          const NodeGeom q = node_geom(t, n);
+          const bool isSet = q.count > 1 || (g.depth == 0 && q.count == 1);
+          if (!isSet)
+            continue;
+          const uint32_t ci = node_cls(t, n);
+          if (ci == kClsPixel || ci >= ht.cls.size())
+            return 1;
+          const ShapeCls& c = ht.cls[ci];
+          Kids k;
+          node_kids(t, n, k);
+          KidBox kb;
+          kid_box(t, n, kb);
+          if ((int)c.nk != k.n || kb.nk != c.nk)
+            return 2;
+          for (int j = 0; j < k.n; j++) {
+            uint32_t idx[3];
+            kid_index(kb, (uint32_t)j, idx);
+            if (idx[0] != k.idx[j][0] || idx[1] != k.idx[j][1] || idx[2] != k.idx[j][2])
+              return 3;
+            if (k.count[j] == 1) {
+              if (c.kid[j] != kClsPixel)
+                return 4;
+              if (kid_pixel_raster(t, n, kb, (uint32_t)j) != kid_raster(t, n, k, j))
+                return 5;
+            }
+            else {
+              const Node kid = kid_node(k, j);
+              if (node_cls(t, kid) != c.kid[j] || pack_node(kid) != kid_packed(kb, (uint32_t)j))
+                return 6;
+              if (node_level(t, kid) != kb.kidlev)
+                return 7;
+              if (c.slot != 0xff && ht.cls[c.kid[j]].slot == 0xff)
+                return 8;
+            }
+          }
+          if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8) && c.slot != (c.nk == 2 ? 1 : c.nk == 4 ? 2 : 3))
+            return 9;
+          if (c.slot != 0xff && (c.slot >> 2) != c.h)
+            return 10;
+        }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -660,10 +660,11 @@ def test_tiny_chunks_pwe(eng, oracle, shape):
         assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, False)))
 
 
-@pytest.mark.parametrize("shape", [(16, 16, 1024), (1, 1024, 1024), (32, 32, 1024)])
+@pytest.mark.parametrize("shape", [(16, 16, 1024), (1, 1024, 1024), (32, 32, 1024), (8, 8, 4096)])
 def test_long_class_chains(eng, oracle, shape):
     """Chunks with an axis of 1024 samples: list levels whose class chain is 9 long (sets of 512 down
-    to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes and k_lis_tables does not.
+    to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes and k_lis_tables does not; an
+    axis of 4096 (chains of 11) goes to k_lis_mixed, whose tables are keyed by shape class.
     Streams, truncated streams and whole containers against the oracle."""
     coef, sign = quantized(oracle, shape, 200000.0)
     stream = oracle.speck3d_encode(coef, sign, 0)
@@ -677,3 +678,37 @@ def test_long_class_chains(eng, oracle, shape):
     assert bytes(eng.compress(cuda(v), shape[::-1], 3.0).cpu().numpy()) == want
     back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), True).cpu().numpy()
     assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, True)))
+
+
+@pytest.mark.parametrize("shape,chunks,bpp", [((129, 129, 129), (129, 129, 129), 2.0),
+                                              ((33, 70, 100), (30, 40, 8), 3.0),
+                                              ((96, 96, 192), (96, 96, 96), 1.0),
+                                              ((80, 80, 80), (80, 80, 80), 4.0),
+                                              ((100, 100, 100), (100, 100, 100), 0.5),
+                                              ((17, 300, 21), (17, 300, 21), 2.0)])
+def test_mixed_shape_chunks(eng, oracle, shape, chunks, bpp):
+    """Chunks whose lists mix set shapes (k_lis_mixed: shape-class tables and one walking wavefront,
+    /root/reference/src/SPECK3D_INT.cpp:214-326 is the split rule behind the classes): odd lengths,
+    lengths of the form 3 * 2^k, levels that hold leaf parents and larger sets side by side,
+    wavelet-packet shapes; containers and decoded values identical to the oracle, also for a
+    stream cut short."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 1, bpp)
+    got = bytes(eng.compress(cuda(v), chunks, bpp).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
+    part = oracle.trunc_3d(want, 37)
+    assert np.array_equal(bits(eng.decompress(cuda(np.frombuffer(part, dtype=np.uint8)), True).cpu().numpy()),
+                          bits(oracle.decomp_3d(part, True)))
+
+
+def test_250_cube_chunk(eng, oracle):
+    """One 250^3 chunk at 2 bpp (decoded through a serial walk in 1.4 s): container and
+    decoded floats identical to the oracle's."""
+    v = turbulence((250, 250, 250))
+    want = oracle.comp_3d(v, (250, 250, 250), 1, 2.0)
+    got = bytes(eng.compress(cuda(v), (250, 250, 250), 2.0).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))

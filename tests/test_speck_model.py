@@ -159,3 +159,16 @@ def test_model_mixed_shape_decoder_matches_oracle(oracle, model, shape, window, 
                 c1, s1 = model_decode_mixed(model, s, shape, window, hmax)
                 assert np.array_equal(c0, c1)
                 assert np.array_equal(s0, s1)
+
+
+def test_shape_classes_are_consistent(model):
+    """Host-side shape classes (sperr_amd/csrc/speck_tree_host.hpp build_classes): for every set of the
+    forest the class read off the node (spk::node_cls) has as many children as the node, the children's
+    classes are those of the child nodes, leaf parents sit in columns 1..3 by their size and every class
+    with a column has columns for all its children."""
+    lib = model
+    lib.model_check_classes.argtypes = [_vp]
+    lib.model_check_classes.restype = C.c_int
+    for dims in [(250, 250, 250), (129, 129, 129), (100, 70, 33), (96, 96, 96), (17, 300, 21), (1, 1, 9),
+                 (80, 80, 80), (64, 64, 320), (30, 40, 8), (2, 3, 5)]:
+        assert lib.model_check_classes((_sz * 3)(*dims)) == 0, dims
