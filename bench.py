@@ -22,12 +22,19 @@ Besides the contract fields the JSON line carries
                 the N devices of this launch, transfers included: the H2D/D2H-inclusive rate of
                 SURVEY 8(d) at N = 1, and the strong-scaling figure (a fixed 64-chunk volume dealt
                 to N GPUs) at N > 1.  Driven by rank 0; never used as `value`.
+  ragged_volume a 1000^3 volume in the same 256^3 chunks: the chunk size does not divide it, so most
+                chunks have extents that are not powers of two (decoded by k_lis_mixed).  Rank 0;
+                never used as `value`.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# the decoder runs the shape groups of a volume side by side on up to 8 streams: ask the runtime for
+# as many hardware queues (its default is 4; must be set before the first HIP call of the process)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -123,6 +130,8 @@ def main():
     ap.add_argument("--profile-out", default="", help="write the per-kernel event table here")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-resident farm run")
     ap.add_argument("--host-reps", type=int, default=3)
+    ap.add_argument("--no-ragged", action="store_true", help="skip the volume the chunk size does not divide")
+    ap.add_argument("--ragged-size", type=int, default=1000)
     args = ap.parse_args()
 
     import torch
@@ -224,6 +233,42 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+
+    # ---- a volume the chunk size does not divide (rank 0; reported beside the metric, never as it):
+    #      chunk_volume (src/sperr_helper.cpp:542-592) leaves border chunks whose extents are not
+    #      powers of two; their lists mix set shapes and decode through k_lis_mixed
+    ragged = None
+    if not args.no_ragged and args.ragged_size > C:
+        try:
+            R = args.ragged_size
+            del out
+            rv = turbulence_torch((R, R, R), dev, seed=7)
+            rs = eng.compress(rv, chunks, args.bpp).clone()
+            ro = eng.decompress(rs, output_float=True)
+            torch.cuda.synchronize()
+            best_c, best_d = 1e9, 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                eng.compress(rv, chunks, args.bpp)
+                torch.cuda.synchronize()
+                b = time.perf_counter()
+                ro = eng.decompress(rs, output_float=True)
+                torch.cuda.synchronize()
+                c = time.perf_counter()
+                best_c, best_d = min(best_c, b - a), min(best_d, c - b)
+            per = [R // C + (1 if R % C > C // 2 else 0)] * 3
+            ragged = {
+                "what": f"{R}^3 fp32 in {C}^3 chunks at BPP {args.bpp}: {per[0] ** 3} chunks, all but {(R // C) ** 3} of them "
+                        "with extents that are not powers of two; volume and container resident in HBM; best of 2",
+                "compress_GBps": round(rv.numel() * 4 / best_c / 1e9, 3),
+                "decompress_GBps": round(rv.numel() * 4 / best_d / 1e9, 3),
+                "compress_ms": round(best_c * 1e3, 2), "decompress_ms": round(best_d * 1e3, 2),
+                "max_abs_err": float((ro.double() - rv.double()).abs().max().item()),
+            }
+            del rv, rs, ro
+        except Exception as ex:
+            ragged = {"error": f"{type(ex).__name__}: {ex}"}
 
     # ---- roofline of the dominant kernel (HIP events recorded by the engine, timed region) ----
     kern = sorted(prof_all.items(), key=lambda kv: -kv[1][0])   # (one untimed step, all kernels)
@@ -327,6 +372,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "host_path": host_path,
+        "ragged_volume": ragged,
     }
     print(json.dumps(line))
     if world > 1:

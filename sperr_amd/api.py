@@ -9,6 +9,10 @@ import os
 
 import numpy as np
 
+# the decoder runs the shape groups of a volume side by side on up to 8 streams: ask the ROCm runtime
+# for as many hardware queues (default 4; only read at the process's first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsperr_hip.so")
 _sz, _vp = C.c_size_t, C.c_void_p

@@ -32,6 +32,14 @@
 #include "speck2d.h"
 #include "xform.h"
 
+// The decoder runs the shape groups of a volume side by side on up to eight streams; the ROCm
+// runtime maps streams onto four hardware queues unless told otherwise, and reads the variable at
+// the process's first HIP call: a host that loads this library before that gets eight.
+__attribute__((constructor)) static void sperrhip_ask_for_hw_queues()
+{
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 namespace sperrhip {
 
 // ------------------------------------------------------------------------------------------
@@ -275,6 +283,11 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.dims[2] = (uint32_t)dz;
   P.N = (uint32_t)(dx * dy * dz);
   P.ht = spk::build_tree(dx, dy, dz);
+  {   // SPERR_HIP_MIX_H: classes up to this many steps above the leaf parents get table columns (k_lis_mixed)
+    static const int mixH = getenv("SPERR_HIP_MIX_H") ? atoi(getenv("SPERR_HIP_MIX_H")) : spk::kClsTableH;
+    if (mixH != spk::kClsTableH && !P.ht.cls.empty())
+      spk::build_classes(P.ht, mixH, spk::kClsTableSlots);
+  }
   const spk::HostTree& h = P.ht;
   const uint32_t nlev = h.nlevels;
 

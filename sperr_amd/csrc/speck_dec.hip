@@ -2760,7 +2760,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
                      ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMixCols + grp * 4u)
                      : ~0ull;
         };
-        uint32_t eb = e + 64u;         // lane = list entry eb + lane: its ecls word (nothing loaded yet)
+        uint32_t eb = 0x80000000u;     // lane = list entry eb + lane: its ecls word (nothing loaded yet: no
+                                       //   entry index is within 64 of this value)
         uint32_t ecv = 0;
         auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
           return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);

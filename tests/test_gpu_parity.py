@@ -712,3 +712,18 @@ def test_250_cube_chunk(eng, oracle):
     assert got == want
     dev = cuda(np.frombuffer(want, dtype=np.uint8))
     assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
+
+
+def test_block_of_a_1000_cube_volume(eng, oracle):
+    """A chunk of 232 x 256 x 256 cut from a 1000^3 field (what `chunk_volume` leaves at the border of
+    such a volume in 256^3 chunks).  Regression: in one of its planes a list of sets that are walked
+    into holds a run of more than 64 insignificant entries right after a window restart; the
+    walker's class window (k_lis_mixed) was taken for loaded there and one entry decoded as a leaf
+    parent -- every later bit of the chunk was read out of place."""
+    from sperr_amd.synth import turbulence_torch
+    v = turbulence_torch((1000, 1000, 1000), "cuda", seed=7)[256:512, 256:512, 768:1000].contiguous()
+    hv = v.cpu().numpy()
+    want = oracle.comp_3d(hv, (232, 256, 256), 1, 2.0)
+    assert bytes(eng.compress(v, (232, 256, 256), 2.0).cpu().numpy()) == want
+    back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), True).cpu().numpy()
+    assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, True)))
