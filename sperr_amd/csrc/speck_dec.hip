@@ -2791,67 +2791,85 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
               m = k < 64u ? rl64(sw0, k) : rl64(sw1, k - 64u);
               lrowK = 0xffffffffu;
             }
-            if ((m >> o) == 0ull && rem >= 64u - o && k * 64u + 64u <= W + wq0) {
-              // the rest of the word holds no '1': insignificant entries, nothing to look up
-              cnt_zruns++;
-              r += 64u - o;
-              e += 64u - o;
-              rem -= 64u - o;
-              continue;
-            }
-            if (lrowK != k) {   // (the next word's entries are fetched while this word is walked)
-              lrow = nextK == k ? lrowNext : load_lrow(k);
-              lrowK = k;
-              nextK = k + 1u;
-              lrowNext = load_lrow(nextK);
-            }
-            // A stream word that lies inside the window, with at least 64 entries left and room
-            // for 64 items: its entries in a tight loop -- no end-of-list, end-of-window or queue
-            // checks per entry; anything unusual (a set to walk into, a split that leaves the
-            // window) is left to the general code below.
+            // Stream words that lie inside the window, with at least 64 entries left and room for
+            // 64 more items: their entries in a tight loop, word after word -- no end-of-list,
+            // end-of-window or queue checks per entry; anything unusual (a set to walk into, a split
+            // that leaves the window) is left to the general code below.
             if (rem >= 64u && k * 64u + 64u <= W + wq0 && qcost + 64u * itemCost + 80u < (uint32_t)kMixQueue) {
               const uint32_t eEnd = e + rem;
-              // (at most 64 entries start inside the word, at most 32 of them significant: one load
-              // of entry classes and the staging registers cover it)
-              if (e - eb > o) {   // (the entries of this word: fewer than 64 - o from e on)
-                eb = e;
-                ecv = e - e0 + lane < ecnt ? ecls[e - e0 + lane] : 0xffffu;
-              }
-              if (ns > 32u)
-                flush();
-              const uint32_t ns0 = ns;
-              const uint32_t pbase = k * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
-              uint32_t oo = o;   // bit of the word the walk is at: below 64 at the top of the loop
+              uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
+              bool unusual = false;
               while (true) {
-                const uint64_t mm = m >> oo;
-                const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
-                oo += z;
-                e += z;
-                const uint32_t ec = rl32(ecv, (e - eb) & 63u);
-                const uint32_t loc = ec >> 8;
-                const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
-                if (oo >= 64u || loc == 0xffu || tl >= kTNone)
-                  break;   // the word is done, or something the general code has to look at
-                {   // lane ns of the staging registers takes the item (the values stay scalar)
-                  const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
-                  const uint32_t itemE = __builtin_amdgcn_readfirstlane(e), itemL = __builtin_amdgcn_readfirstlane(ns);
-                  asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                               : "+v"(stE), "+v"(stM)
-                               : "s"(itemE), "s"(itemL), "s"(itemM)
-                               : "m0");
+                if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
+                  if (kk != curK) {
+                    curK = kk;
+                    m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
+                  }
+                  lrow = nextK == kk ? lrowNext : load_lrow(kk);
+                  lrowK = kk;
+                  nextK = kk + 1u;
+                  lrowNext = load_lrow(nextK);
                 }
-                ns++;
-                oo += 1u + tl;
-                e++;
-                if (oo >= 64u)
+                // (at most 64 entries start inside a word, at most 32 of them significant: one load
+                // of entry classes and the staging registers cover it)
+                if (e - eb > oo) {   // (the entries of this word: fewer than 64 - oo from e on)
+                  eb = e;
+                  ecv = e - e0 + lane < ecnt ? ecls[e - e0 + lane] : 0xffffu;
+                }
+                if (ns > 32u)
+                  flush();
+                const uint32_t ns0 = ns;
+                const uint32_t pbase = kk * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
+                while (true) {   // oo < 64 here
+                  const uint64_t mm = m >> oo;
+                  const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
+                  oo += z;
+                  e += z;
+                  const uint32_t ec = rl32(ecv, (e - eb) & 63u);
+                  const uint32_t loc = ec >> 8;
+                  const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
+                  if (oo >= 64u)
+                    break;   // the word is done
+                  if (loc == 0xffu || tl >= kTNone) {
+                    unusual = true;   // something the general code has to look at
+                    break;
+                  }
+                  {   // lane ns of the staging registers takes the item (the values stay scalar)
+                    const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
+                    const uint32_t itemE = __builtin_amdgcn_readfirstlane(e), itemL = __builtin_amdgcn_readfirstlane(ns);
+                    asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                                 : "+v"(stE), "+v"(stM)
+                                 : "s"(itemE), "s"(itemL), "s"(itemM)
+                                 : "m0");
+                  }
+                  ns++;
+                  oo += 1u + tl;
+                  e++;
+                  if (oo >= 64u)
+                    break;
+                }
+                cnt_hops += ns - ns0;
+                qcost += (ns - ns0) * itemCost;
+                if (unusual)
+                  break;
+                // on to the word the walk is in now (a long split may have skipped some)
+                kk += oo >> 6;
+                oo &= 63u;
+                if (!(eEnd - e >= 64u && kk * 64u + 64u <= W + wq0 && qcost + 64u * itemCost + 80u < (uint32_t)kMixQueue))
                   break;
               }
-              cnt_hops += ns - ns0;
-              qcost += (ns - ns0) * itemCost;
-              r = k * 64u + oo - wq0;
+              r = kk * 64u + oo - wq0;
               rem = eEnd - e;
-              if (oo >= 64u)
-                continue;   // on to the next word
+              if (!unusual)
+                continue;
+              if (kk != curK) {   // (cannot happen: an unusual entry lies in the word just walked)
+                curK = kk;
+                m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
+              }
+            }
+            if (lrowK != curK) {
+              lrow = load_lrow(curK);
+              lrowK = curK;
             }
             const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
             const uint64_t tt = m >> o2;
