@@ -2706,6 +2706,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
         }
       }
       __syncthreads();
+      STAMP(6);
       // ---- columns 4..7, then 8..11: a chain of look-ups through the children's columns at the
       //      collected positions (two per thread and round: their LDS round trips overlap)
       {
@@ -2719,14 +2720,49 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             any = true;
             const uint32_t nk = sh_cls[ci].nk;
             const uint64_t kc = sh_kcol[ci];
-            for (uint32_t i = tid; i < ncand; i += 2 * kMixThreads) {
-              const uint32_t i2 = i + kMixThreads;
-              const uint32_t x1 = cand[i], x2 = i2 < ncand ? cand[i2] : 0u;
-              const uint32_t t1 = chain(nk, kc, x1);
-              const uint32_t t2 = i2 < ncand ? chain(nk, kc, x2) : 0u;
-              Tr[(size_t)x1 * kMixCols + col] = (uint16_t)t1;
-              if (i2 < ncand)
-                Tr[(size_t)x2 * kMixCols + col] = (uint16_t)t2;
+            for (uint32_t i = tid; i < ncand; i += 4 * kMixThreads) {
+              // four positions per thread and round, their chains in lockstep: the LDS round trips overlap
+              uint32_t x[4], y[4], found[4], bad[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const uint32_t iu = i + (uint32_t)u * kMixThreads;
+                x[u] = iu < ncand ? (uint32_t)cand[iu] : W + 1u;
+                y[u] = x[u];
+                found[u] = 0;
+                bad[u] = 0;
+              }
+              for (uint32_t k = 0; k < nk; k++) {
+                const uint32_t ccol = (uint32_t)(kc >> (8 * k)) & 0xffu;
+                const uint32_t last = k + 1 == nk ? 1u : 0u;
+                uint32_t bitv[4], s0[4], tl[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  const uint32_t coded = found[u] | (last ^ 1u);
+                  const uint32_t yy = min(y[u], W + 1);
+                  bitv[u] = coded ? bit_at(yy) : 1u;
+                  s0[u] = yy + coded;
+                  tl[u] = Tr[(size_t)s0[u] * kMixCols + ccol];
+                  y[u] = yy;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  uint32_t t = tl[u];
+                  if (t >= kTNone) {
+                    bad[u] |= bitv[u] ? (t == kTInf ? 1u : 2u) : 0u;
+                    t = 0;
+                  }
+                  y[u] = bitv[u] ? s0[u] + t : y[u] + 1;
+                  found[u] |= bitv[u];
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const uint32_t iu = i + (uint32_t)u * kMixThreads;
+                if (iu < ncand) {
+                  const uint32_t t = ((bad[u] & 1u) || y[u] > W) ? kTInf : (bad[u] & 2u) ? kTNone : y[u] - x[u];
+                  Tr[(size_t)x[u] * kMixCols + col] = (uint16_t)t;
+                }
+              }
             }
           }
           if (any)

@@ -20,13 +20,13 @@ eng.decompress(s, True)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 eng.lib.sperrhip_debug_lis_stamps(0, out)
-names = {0: "load+classes", 1: "tables", 2: "walk", 3: "expand", 4: "compact", 5: "zero skip"}
+names = {0: "load+classes", 6: "rows 0..3", 1: "rows 4..11", 2: "walk", 3: "expand", 4: "compact", 5: "zero skip"}
 tot = sum(out[i] for i in names)
 for i, nm in names.items():
     print("%-14s %12d ticks  %5.1f%%" % (nm, out[i], 100 * out[i] / max(tot, 1)))
 w = max(out[9], 1)
-print("windows %d: ticks/window tables %d walk %d expand %d load %d; stream bits/window %d" %
-      (out[9], out[1] // w, out[2] // w, out[3] // w, out[0] // w, out[20] // w))
+print("windows %d: ticks/window rows %d + %d walk %d expand %d load %d; stream bits/window %d" %
+      (out[9], out[6] // w, out[1] // w, out[2] // w, out[3] // w, out[0] // w, out[20] // w))
 print("walk: %d significant list entries, %d child steps in %d entered sets, %d zero runs; %d skip rounds; %d expanded items"
       % (out[16], out[17], out[18], out[19], out[21], out[22]))
 if out[16] + out[17]:
