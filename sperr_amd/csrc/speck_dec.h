@@ -170,21 +170,22 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   return w;
 }
 
-// k_lis_mixed: LDS bytes per window bit are a row of twelve split lengths (u16 each), the class
-// word of a list entry the window may reach, a slot of the list of candidate positions and the
-// bit itself; the item queue and the slack of the arrays are fixed.  The window is the largest
-// multiple of 256 that fits (at most 7936: the walk keeps its stream words in two registers).
-constexpr int kMixQueue = 1536;     // sets the walk of one window can hand to the expansion
+// k_lis_mixed keeps two windows in LDS (one being walked, one being expanded / built): per window
+// bit two rows of twelve split lengths (u16 each), a slot of the list of candidate positions and the
+// bit itself twice; the two item queues, the ring of entry classes and the slack of the arrays are
+// fixed.  The window is the largest multiple of 256 that fits.
+constexpr int kMixQueue = 768;      // sets the walk of one window can hand to the expansion
+constexpr int kMixRing = 8192;      // list entries whose class words are kept (at least two windows' worth)
 __host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
 {
-  const uint32_t perBit8 = 8u * (24u + 2u + 2u) + 1u;   // eighths of a byte
-  const uint32_t fixed = 6 * 8 + 3 * 24 + (uint32_t)kMixQueue * 12u + 64;
+  const uint32_t perBit8 = 8u * (2u * 24u + 2u) + 2u;   // eighths of a byte
+  const uint32_t fixed = 2 * 6 * 8 + 2 * 3 * 24 + 2u * (uint32_t)kMixQueue * 12u + (uint32_t)kMixRing * 2u + 64;
   if (smemBytes <= fixed)
     return 0;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
   w = w / 256 * 256;
-  if (w > 7936u)
-    w = 7936u;
+  if (w > (uint32_t)kMixRing / 4u)
+    w = (uint32_t)kMixRing / 4u;
   return w;
 }
 

@@ -20,14 +20,18 @@ eng.decompress(s, True)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 eng.lib.sperrhip_debug_lis_stamps(0, out)
-names = {0: "load+classes", 6: "rows 0..3", 1: "rows 4..11", 2: "walk", 3: "expand", 4: "compact", 5: "zero skip"}
+names = {0: "restart: classes", 1: "restart: rows", 7: "walk", 2: "walker waits for helpers", 3: "expand (level end)", 4: "compact", 5: "zero skip"}
 tot = sum(out[i] for i in names)
 for i, nm in names.items():
     print("%-14s %12d ticks  %5.1f%%" % (nm, out[i], 100 * out[i] / max(tot, 1)))
 w = max(out[9], 1)
-print("windows %d: ticks/window rows %d + %d walk %d expand %d load %d; stream bits/window %d" %
-      (out[9], out[6] // w, out[1] // w, out[2] // w, out[3] // w, out[0] // w, out[20] // w))
+print("windows %d (%d pipeline restarts): ticks/window walk %d, waiting for the helpers %d; stream bits/window %d" %
+      (out[9], out[8], out[7] // w, out[2] // w, out[20] // w))
+if out[28]:
+    print("helpers (%d wavefronts per plane sum): ticks/window expand %d, entry classes %d, rows %d; whole phase %d" %
+          (out[28], out[25] // w, out[26] // w, out[27] // w, out[29] // w))
+print("helper wavefronts, ticks of work per window:", [out[32 + i] // w for i in range(8)])
 print("walk: %d significant list entries, %d child steps in %d entered sets, %d zero runs; %d skip rounds; %d expanded items"
       % (out[16], out[17], out[18], out[19], out[21], out[22]))
 if out[16] + out[17]:
-    print("walk ticks per hop/step: %.0f" % (out[2] / (out[16] + out[17] + out[19])))
+    print("walk ticks per hop/step: %.0f" % (out[7] / (out[16] + out[17] + out[19])))
