@@ -285,8 +285,9 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.ht = spk::build_tree(dx, dy, dz);
   {   // SPERR_HIP_MIX_H: classes up to this many steps above the leaf parents get table columns (k_lis_mixed)
     static const int mixH = getenv("SPERR_HIP_MIX_H") ? atoi(getenv("SPERR_HIP_MIX_H")) : spk::kClsTableH;
-    if (mixH != spk::kClsTableH && !P.ht.cls.empty())
-      spk::build_classes(P.ht, mixH, spk::kClsTableSlots);
+    static const double mixShare = getenv("SPERR_HIP_MIX_SHARE") ? atof(getenv("SPERR_HIP_MIX_SHARE")) / 100.0 : spk::kClsMinShare;
+    if ((mixH != spk::kClsTableH || mixShare != spk::kClsMinShare) && !P.ht.cls.empty())
+      spk::build_classes(P.ht, mixH, spk::kClsTableSlots, mixShare);
   }
   const spk::HostTree& h = P.ht;
   const uint32_t nlev = h.nlevels;

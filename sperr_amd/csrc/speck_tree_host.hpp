@@ -113,12 +113,13 @@ inline int ceil_log2(uint32_t v)
 }
 }  // namespace detail
 
-constexpr int kClsTableH = 2;            // default: tables up to two steps above the leaf parents
+constexpr int kClsTableH = 2;            // default: columns up to two steps above the leaf parents (measured: 1 is 5 % faster on a 250^3 chunk, 25 % slower on the 128^3-sized border chunks of a ragged volume)
 constexpr uint32_t kClsTableSlots = 4;
+constexpr double kClsMinShare = 0.02;       // a class needs this share of the sets of its h to get a column
 
 // Shape classes of every set of the forest (speck_tree.h, ShapeCls).  hmax >= 0: the leaf parents
 // get table slots, hmax >= 1 / 2: up to `maxSlots` (at most 4) of the classes one / two steps up.
-inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minShare = 0.02)
+inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minShare = kClsMinShare)
 {
   h.cls.clear();
   h.gridCls.assign(h.grids.size() * 8, kClsPixel);
