@@ -1341,8 +1341,50 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   HIP_CHECK(hipMemcpyAsync(d_slotOff, slotOff.data(), nchunks * 8, hipMemcpyHostToDevice, st));
 
   VolDesc vd{{vol[0], vol[1], vol[2]}};
-  for (auto& g : groups) {
-    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+  // Shape groups side by side (fixed-rate mode, a volume the chunk size does not divide): every
+  // group gets a piece of the arena and a sub-stream of its own, the check for the rare 64-bit
+  // retry (one read-back per group) waits until all groups are enqueued.  SPERR_HIP_ENC_GROUPS=0:
+  // group after group.
+  struct LateGroup {
+    ShapePlan* P;
+    EncBatchBufs bb;
+    uint32_t nb, wblocks;
+    uint64_t raw_budget;
+    hipStream_t ss;
+    std::vector<CoderState> hc;
+    std::vector<ChunkGeom> hg;
+    std::vector<uint32_t> hid;
+  };
+  std::vector<std::unique_ptr<LateGroup>> late;
+  static const bool encGroupsEnv = !(getenv("SPERR_HIP_ENC_GROUPS") && atoi(getenv("SPERR_HIP_ENC_GROUPS")) == 0);
+  bool sideBySide = encGroupsEnv && mode == 1 && !slice && groups.size() > 1;
+  std::vector<size_t> groupOff;
+  if (sideBySide) {
+    size_t fr = 0, tot = 0, need = 0;
+    HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    for (auto& g : groups) {
+      ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+      groupOff.push_back(need);
+      need += round_up(g.second.size() * enc_bytes_per_chunk(*P, (uint64_t)(bpp * (double)P->N)) + 4096, 4096);
+      sideBySide = sideBySide && g.second.size() <= 256;
+    }
+    sideBySide = sideBySide && need <= budgetBytes;
+    if (sideBySide) {
+      if (E.arena.ensure(need))
+        return -1;
+      HIP_CHECK(hipEventRecord(E.evFork, st));
+      for (uint32_t q = 0; q < kSubStreams; q++)
+        HIP_CHECK(hipStreamWaitEvent(E.sub[q], E.evFork, 0));
+    }
+  }
+  late.resize(groups.size());
+  std::vector<ShapePlan*> groupPlan;   // (looked up here: the plan cache is not for several threads)
+  for (auto& g : groups)
+    groupPlan.push_back(E.plan(g.first[0], g.first[1], g.first[2]));
+  auto do_group = [&](uint32_t gi, std::pair<const Dims, std::vector<ChunkRef>>& g) -> int {
+    hipStream_t ss = sideBySide ? E.sub[gi % kSubStreams] : st;
+    ShapePlan* P = groupPlan[gi];
     const uint64_t raw_budget = (uint64_t)(bpp * (double)P->N);  // SPECK_FLT.cpp:491
     const size_t per = enc_bytes_per_chunk(*P, raw_budget);
     size_t fr = 0, tot = 0;
@@ -1350,14 +1392,16 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
     uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
     B = std::min<uint32_t>(B, 256);
-    if (E.arena.ensure((size_t)B * per + 4096))
+    if (sideBySide)
+      B = (uint32_t)g.second.size();
+    else if (E.arena.ensure((size_t)B * per + 4096))
       return -1;
     const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
     for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
       const uint32_t nb = (uint32_t)std::min<size_t>(B, g.second.size() - b0);
       Arena A;
-      A.base = static_cast<char*>(E.arena.p);
-      A.cap = E.arena.n;
+      A.base = static_cast<char*>(E.arena.p) + (sideBySide ? groupOff[gi] : 0);
+      A.cap = E.arena.n - (sideBySide ? groupOff[gi] : 0);
       EncBatchBufs bb;
       if (!carve_enc(A, *P, nb, raw_budget, bb))
         return -1;
@@ -1370,10 +1414,10 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         for (int a = 0; a < 3; a++)
           hg[i].org[a] = r.org[a];
       }
-      HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(bb.gids, hid.data(), nb * 4, hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemsetAsync(e.cst, 0, nb * sizeof(CoderState), st));
-      if (reset_enc_pass(st, bb, nb))
+      HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, ss));
+      HIP_CHECK(hipMemcpyAsync(bb.gids, hid.data(), nb * 4, hipMemcpyHostToDevice, ss));
+      HIP_CHECK(hipMemsetAsync(e.cst, 0, nb * sizeof(CoderState), ss));
+      if (reset_enc_pass(ss, bb, nb))
         return -1;
 
       // ---- float stages ----
@@ -1384,13 +1428,13 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       bool orgAligned = true;   // (lets the conditioner stream rows with 16-byte loads)
       for (uint32_t i = 0; i < nb; i++)
         orgAligned = orgAligned && hg[i].org[0] % (16 / sizeof(T)) == 0;
-      if (launch_condition<T>(st, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
+      if (launch_condition<T>(ss, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
                               bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, mode == 2,
                               orgAligned))
         return -1;
       size_t k0 = 0;
       if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume
-        if (launch_lift_xy(st, true, bb.vals, bb.valsStride, nb, cd, e.cst, io,
+        if (launch_lift_xy(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io,
                            const_cast<T*>(d_src), vd, bb.geom))
           return -1;
         k0 = 2;
@@ -1403,17 +1447,17 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         LiftFuse lf;
         if (fuseMax && pass_fuse(*P, k, lf.inner) > 0)
           lf.mode = 1;
-        if (launch_lift(st, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
+        if (launch_lift(ss, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
                         k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom, &lf))
           return -1;
       }
-      if (launch_maxabs_q(st, bb.vals, bb.valsStride, nb, P->N, e.cst, fuseMax))
+      if (launch_maxabs_q(ss, bb.vals, bb.valsStride, nb, P->N, e.cst, fuseMax))
         return -1;
-      if (mode == 2 && psnr_q_search(st, *P, bb, nb, quality))
+      if (mode == 2 && psnr_q_search(ss, *P, bb, nb, quality))
         return -1;
-      if (mode == 3 && pwe_q_setup(st, bb, nb, quality))
+      if (mode == 3 && pwe_q_setup(ss, bb, nb, quality))
         return -1;
-      if (launch_quantize(st, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
+      if (launch_quantize(ss, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
         return -1;
 
@@ -1429,30 +1473,36 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         sb.stream = e.stream;
         sb.streamWords = e.streamStride;
         sb.cst = e.cst;
-        if (launch_speck2d_encode(st, sb, raw_budget, rate, false))
+        if (launch_speck2d_encode(ss, sb, raw_budget, rate, false))
           return -1;
       }
-      else if (launch_speck_encode(st, e, ph, raw_budget, rate, false))
+      else if (launch_speck_encode(ss, e, ph, raw_budget, rate, false))
         return -1;
       const uint32_t wblocks = (uint32_t)std::min<size_t>(4096, (e.streamStride * 8 + kThreads - 1) / kThreads);
-      LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
+      LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, ss, e.cst, e.st,
                e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
                d_lens, P->N, 0);
 
       // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
+      if (sideBySide) {   // (the read-back is looked at once every group is enqueued)
+        std::unique_ptr<LateGroup> L(new LateGroup{P, bb, nb, wblocks, raw_budget, ss, std::vector<CoderState>(nb),
+                                                   std::move(hg), std::move(hid)});
+        late[gi] = std::move(L);        // (a read-back into pageable memory would block the host until
+        continue;                       //  this group's stream has drained: it is done further down)
+      }
       std::vector<CoderState> hc(nb);
-      HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, ss));
+      HIP_CHECK(hipStreamSynchronize(ss));
       bool retry = false;
       for (auto& c : hc)
         retry |= (c.need_retry != 0);
       if (retry) {
         // fixed rate: a finer q for the flagged chunks; PSNR: the same q, coefficients need 64 bits
-        if ((rate ? launch_make_q_wide(st, nb, e.cst) : launch_mark_wide(st, nb, e.cst)) ||
-            reset_enc_pass(st, bb, nb))
+        if ((rate ? launch_make_q_wide(ss, nb, e.cst) : launch_mark_wide(ss, nb, e.cst)) ||
+            reset_enc_pass(ss, bb, nb))
           return -1;
         // 64-bit magnitudes overwrite the DWT coefficients in place (same element size)
-        if (launch_quantize(st, true, bb.vals, bb.valsStride, nb, P->N, bb.vals, bb.valsStride,
+        if (launch_quantize(ss, true, bb.vals, bb.valsStride, nb, P->N, bb.vals, bb.valsStride,
                             const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
           return -1;
         EncBuffers ew = e;
@@ -1460,20 +1510,84 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         ew.coefStride = bb.valsStride;
         if (slice) {
           sb.coef = bb.vals;
-          if (launch_speck2d_encode(st, sb, raw_budget, rate, true))
+          if (launch_speck2d_encode(ss, sb, raw_budget, rate, true))
             return -1;
         }
-        else if (launch_speck_encode(st, ew, ph, raw_budget, rate, true))
+        else if (launch_speck_encode(ss, ew, ph, raw_budget, rate, true))
           return -1;
-        LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, st, e.cst, e.st,
+        LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, ss, e.cst, e.st,
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
                  d_lens, P->N, 1);
       }
       if (mode == 3 &&
-          pwe_outlier_stage<T>(st, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep))
+          pwe_outlier_stage<T>(ss, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep))
         return -1;
     }
+  
+    return 0;
+  };
+  {
+    // SPERR_HIP_ENC_THREADS=1: side by side, every group is enqueued by a host thread of its own
+    // (measured on MI355X, 1000^3 in 256^3 chunks, eight groups of about 1100 launches: 64.6 ms
+    // with one thread, 66 ms with eight -- the groups' chains of small launches bound the call,
+    // not the enqueueing host thread; off by default)
+    static const bool encThreadsEnv = getenv("SPERR_HIP_ENC_THREADS") && atoi(getenv("SPERR_HIP_ENC_THREADS")) != 0;
+    const bool threaded = sideBySide && encThreadsEnv && !(t_prof && t_prof->on);
+    std::vector<int> rcs(groups.size(), 0);
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::vector<std::thread> workers;
+    uint32_t groupIdx = 0;
+    for (auto& g : groups) {
+      const uint32_t gi = groupIdx++;
+      if (threaded)
+        workers.emplace_back([&, gi, dev]() {
+          rcs[gi] = hipSetDevice(dev) == hipSuccess ? do_group(gi, g) : -1;
+        });
+      else
+        rcs[gi] = do_group(gi, g);
+      if (!threaded && rcs[gi])
+        return -1;
+    }
+    for (auto& w : workers)
+      w.join();
+    for (int r : rcs)
+      if (r)
+        return -1;
   }
+  for (auto& L : late) {   // the groups that ran side by side: the 64-bit retry, where a chunk asked for it
+    if (!L)
+      continue;
+    HIP_CHECK(hipMemcpyAsync(L->hc.data(), L->bb.eb.cst, L->nb * sizeof(CoderState), hipMemcpyDeviceToHost, L->ss));
+    HIP_CHECK(hipStreamSynchronize(L->ss));
+    bool retry = false;
+    for (auto& cs : L->hc)
+      retry |= (cs.need_retry != 0);
+    if (!retry)
+      continue;
+    EncBatchBufs& bb = L->bb;
+    EncBuffers& e = bb.eb;
+    ShapePlan* P = L->P;
+    EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+    if (launch_make_q_wide(L->ss, L->nb, e.cst) || reset_enc_pass(L->ss, bb, L->nb))
+      return -1;
+    if (launch_quantize(L->ss, true, bb.vals, bb.valsStride, L->nb, P->N, bb.vals, bb.valsStride,
+                        const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
+      return -1;
+    EncBuffers ew = e;
+    ew.coef = bb.vals;
+    ew.coefStride = bb.valsStride;
+    if (launch_speck_encode(L->ss, ew, ph, L->raw_budget, true, true))
+      return -1;
+    LAUNCH_K(k_write_slot, dim3(std::max(1u, L->wblocks), L->nb), dim3(kThreads), 0, L->ss, e.cst, e.st,
+             e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff, d_lens,
+             P->N, 1);
+  }
+  if (sideBySide)
+    for (uint32_t q = 0; q < kSubStreams; q++) {
+      HIP_CHECK(hipEventRecord(E.evJoin[q], E.sub[q]));
+      HIP_CHECK(hipStreamWaitEvent(st, E.evJoin[q], 0));
+    }
 
   // ---- container ----
   // (the header kernels write before any length is known to them: check its room here)
