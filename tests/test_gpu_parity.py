@@ -727,3 +727,27 @@ def test_block_of_a_1000_cube_volume(eng, oracle):
     assert bytes(eng.compress(v, (232, 256, 256), 2.0).cpu().numpy()) == want
     back = eng.decompress(cuda(np.frombuffer(want, dtype=np.uint8)), True).cpu().numpy()
     assert np.array_equal(bits(back), bits(oracle.decomp_3d(want, True)))
+
+
+def test_serial_walk_fallback_in_a_fresh_process(oracle):
+    """`SPERR_HIP_LIS_MIXED=0` (read once per process) sends chunks whose lists mix set shapes through the
+    serial walk `k_lis_walk`, which also is what trees the class machinery does not take fall back to:
+    the same bits as the oracle's."""
+    import subprocess
+    import sys
+    import tempfile
+    shape = (21, 34, 27)
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, shape[::-1], 1, 3.0)
+    ref = oracle.decomp_3d(want, True)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "c.npy"), np.frombuffer(want, dtype=np.uint8))
+        np.save(os.path.join(td, "r.npy"), ref)
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from sperr_amd.api import SperrHip; "
+                "e = SperrHip(); c = torch.from_numpy(np.load(%r)).cuda(); r = np.load(%r); "
+                "d = e.decompress(c, True).cpu().numpy(); "
+                "sys.exit(0 if np.array_equal(d.view(np.uint32), r.view(np.uint32)) else 3)"
+                % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(td, "c.npy"),
+                   os.path.join(td, "r.npy")))
+        env = dict(os.environ, SPERR_HIP_LIS_MIXED="0")
+        assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
