@@ -3756,6 +3756,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     }
   };
   // thread 0: do the tables in LDS (built for sh_tabLevel, classes [0, sh_tabK)) serve level lv?
+  // (one lane per level: tables built for level tl with tk classes)
+  auto serve_mask = [&](int tl, int tk) -> uint64_t {
+    const uint32_t l = (uint32_t)tid & 63u;
+    bool ok = l < t.nlevels && sh_len[l] != 0 && tl >= 0;
+    if (ok) {
+      const LevelClass& A = sh_lc[tl];
+      const LevelClass& B = sh_lc[l];
+      ok = (int)B.K <= tk;
+      for (int j = 0; ok && j < (int)B.K; j++)
+        ok = A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+    }
+    return __ballot(ok);
+  };
   auto tables_serve = [&](int lv) -> bool {
     if (sh_tabLevel < 0)
       return false;
@@ -3962,40 +3975,57 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       if (any)
         sh_any = 1;   // (benign race: everybody writes 1)
     }
-    if (tid == 0) {
+    if (tid < 64) {
       // the level the chain was last seen in: its list's class and the next one get pointer-jump
       // tables; the class tables are built for the longest chain that continues this one upwards
-      // (every level of a power-of-two cube), so that list changes inside the region find theirs
-      int hint = __hip_atomic_load(&s.hiHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (every level of a power-of-two cube), so that list changes inside the region find theirs.
+      // The first wavefront, one lane per level (a loop over the levels on one lane is a
+      // dependent LDS load per step).
+      int hint = 0;
+      if (lane == 0)
+        hint = __hip_atomic_load(&s.hiHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hint = __shfl(hint, 0, 64);
       if ((hint >> 8) != p + 1)
         hint = -1;
       else
         hint &= 0xff;
       if (hint < 0 || hint >= (int)t.nlevels || sh_len[hint] == 0)
         hint = next_level((int)t.nlevels);
+      const int lv_ = (int)lane;
+      const bool inr = lv_ < (int)t.nlevels;
+      const int Kl = inr ? (int)sh_lc[lv_].K : 0;
+      const bool usable = inr && sh_len[lv_] != 0 && sh_lc[lv_].regular && Kl <= Kcap;
       int best = hint;
       if (hint >= 0) {
-        const LevelClass& A = sh_lc[hint];
-        for (int lv = hint - 1; lv >= 0; lv--) {
-          if (sh_len[lv] == 0 || !sh_lc[lv].regular)
+        const int AK = (int)sh_lc[hint].K;
+        int bestK = AK;
+        uint64_t cm = __ballot(usable && lv_ < hint && Kl > AK && Kl <= AK + kSpecExtra);
+        while (cm) {   // from the level below the hint downwards, as long as the chains get longer
+          const int lv = 63 - __builtin_clzll(cm);
+          cm &= ~(1ull << lv);
+          const int Kv = __shfl(Kl, lv, 64);
+          if (Kv <= bestK)
             continue;
-          const LevelClass& B = sh_lc[lv];
-          if (B.K <= sh_lc[best].K || (int)B.K > Kcap || (int)B.K > (int)A.K + kSpecExtra)
-            continue;
-          bool same = true;
-          for (int j = 0; j < (int)A.K; j++)
-            same = same && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
-          const LevelClass& Cb = sh_lc[best];
-          for (int j = 0; j < (int)Cb.K; j++)
-            same = same && Cb.arity[j] == B.arity[j] && Cb.lev[j] == B.lev[j];
-          if (same)
+          // (lane j: class j of level lv against the hint's and the best level's)
+          const int j = (int)lane;
+          bool diff = false;
+          if (j < AK)
+            diff = sh_lc[hint].arity[j] != sh_lc[lv].arity[j] || sh_lc[hint].lev[j] != sh_lc[lv].lev[j];
+          if (j < bestK)
+            diff = diff || sh_lc[best].arity[j] != sh_lc[lv].arity[j] || sh_lc[best].lev[j] != sh_lc[lv].lev[j];
+          if (__ballot(diff) == 0ull) {
             best = lv;
+            bestK = Kv;
+          }
         }
       }
-      sh_tabLevel = best;
-      sh_hintK = hint >= 0 ? (int)sh_lc[hint].K : 0;
+      if (lane == 0) {
+        sh_tabLevel = best;
+        sh_hintK = hint >= 0 ? (int)sh_lc[hint].K : 0;
+      }
     }
     __syncthreads();
+    uint64_t dbg0 = stamps ? __builtin_readcyclecounter() : 0, dbg1 = 0, dbg2 = 0;
     // ---- speculative tables (nothing to build over a region of zeros: there every item is one
     //      insignificant bit, which the chain handles without tables)
     const bool zeroRegion = sh_any == 0;
@@ -4003,18 +4033,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       const int lv = sh_tabLevel;
       const int K = sh_lc[lv].K, Kh = sh_hintK;
       build_tables(lv, 0, K);
+      if (stamps) dbg1 = __builtin_readcyclecounter();
       build_hop(hop, Kh - 1);
       if (Kh < K)
         build_hop(hop2, Kh);
-      if (tid == 0) {
-        sh_tabK = K;
-        sh_hopTop[0] = Kh - 1;
-        sh_hopTop[1] = Kh < K ? Kh : -1;
-        uint64_t m = 0;
-        for (uint32_t l = 0; l < t.nlevels; l++)
-          if (sh_len[l] && tables_serve((int)l))
-            m |= 1ull << l;
-        sh_serve = m;
+      if (stamps) dbg2 = __builtin_readcyclecounter();
+      if (tid < 64) {   // which lists the tables serve: one lane per level
+        const uint64_t m = serve_mask(lv, K);
+        if (tid == 0) {
+          sh_tabK = K;
+          sh_hopTop[0] = Kh - 1;
+          sh_hopTop[1] = Kh < K ? Kh : -1;
+          sh_serve = m;
+        }
       }
     }
     else if (tid == 0) {
@@ -4025,6 +4056,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     }
     if (stamps)
       st1 = __builtin_readcyclecounter();
+    if (stamps && dbg2) {
+      unsigned long long* o_ = reinterpret_cast<unsigned long long*>(b.lisStamps + (size_t)c * 64);
+      atomicAdd(o_ + 40, (unsigned long long)(dbg0 - st0));    // load + decide
+      atomicAdd(o_ + 41, (unsigned long long)(dbg1 - dbg0));   // class tables
+      atomicAdd(o_ + 42, (unsigned long long)(dbg2 - dbg1));   // hop tables
+      atomicAdd(o_ + 43, (unsigned long long)(st1 - dbg2));    // serve mask
+    }
     __syncthreads();
 
     // ---- the chain: wavefront 0 alone (no workgroup barrier on the serial path); it comes back
@@ -4447,15 +4485,14 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         const int K = sh_lc[lv].K;
         const int j0 = sh_tabFrom;
         build_tables(lv, j0, K);
-        if (tid == 0) {
-          sh_tabLevel = lv;
-          sh_tabK = K;
-          sh_hopTop[0] = sh_hopTop[1] = -1;
-          uint64_t m = 0;
-          for (uint32_t l = 0; l < t.nlevels; l++)
-            if (sh_len[l] && tables_serve((int)l))
-              m |= 1ull << l;
-          sh_serve = m;
+        if (tid < 64) {
+          const uint64_t m = serve_mask(lv, K);
+          if (tid == 0) {
+            sh_tabLevel = lv;
+            sh_tabK = K;
+            sh_hopTop[0] = sh_hopTop[1] = -1;
+            sh_serve = m;
+          }
         }
       }
       else {   // kActHopTab
