@@ -3823,6 +3823,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       const uint32_t nin = sh_qn[round % 3];
       if (nin == 0)
         break;
+      if (tid == 0 && b.lisStamps) {
+        unsigned long long* o_ = reinterpret_cast<unsigned long long*>(b.lisStamps + (size_t)c * 64);
+        atomicAdd(o_ + 44, 1ull);
+        atomicAdd(o_ + 45, (unsigned long long)nin);
+      }
       const uint64_t* qin = qbuf[round & 1];
       uint64_t* qout = qbuf[(round + 1) & 1];
       for (uint32_t i0 = 0; i0 < nin; i0 += kTabThreads) {

@@ -32,3 +32,4 @@ for i, name in enumerate(["decide", "publish", "hop", "P2", "P3", "P4"]):
     print(f"  chain/{name:8s} per region {out[10 + i] // nb:8d}")
 print("on-chain table builds", out[5], "hop rebuilds", out[6], "serial hops", out[7], "list passes", out[8])
 print("table phase per region: load+decide %d, class tables %d, hop tables %d, serve mask %d" % tuple(out[40 + i] // nb for i in range(4)))
+print("expansion per region: %.1f rounds, %d items" % (out[44] / nb, out[45] // nb))
