@@ -1759,7 +1759,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   // k_lis_hi: a pair of queues per workgroup, up to hiGroupsMax workgroups per chunk
   d.hiK = (uint32_t)std::max(2, P.maxK);
   {
-    static const uint32_t ahead = getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_AHEAD")) : 512u;
+    static const uint32_t ahead = getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_AHEAD")) : 384u;
     d.hiAhead = ahead;
     static const uint32_t extra = getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_EXTRA")) : 1u;
     d.hiExtra = extra;
