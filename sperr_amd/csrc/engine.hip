@@ -242,6 +242,7 @@ struct ShapePlan {
   const uint32_t* d_levelNumTiles = nullptr;
   const uint32_t* d_depthBlocks = nullptr;
   const uint8_t* d_levelSlot = nullptr;
+  const uint64_t* d_iRoots = nullptr;   // (2D forest)
   const uint8_t* d_slotLevel = nullptr;
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
@@ -269,7 +270,8 @@ struct Blob {  // host-side staging of all tables of a plan, uploaded in one cop
   }
 };
 
-int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
+// twoD: the plan of a slice's DECODER, with the forest of the 2D coder (spk::kTree2D)
+int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
 {
   // set coordinates are packed 16 bits per axis (speck_tree.h pack_node), sample indices are 32 bits
   const unsigned __int128 samples = (unsigned __int128)dx * dy * dz;
@@ -282,7 +284,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.dims[1] = (uint32_t)dy;
   P.dims[2] = (uint32_t)dz;
   P.N = (uint32_t)(dx * dy * dz);
-  P.ht = spk::build_tree(dx, dy, dz);
+  P.ht = spk::build_tree(dx, dy, dz, twoD);
   {   // SPERR_HIP_MIX_H: classes up to this many steps above the leaf parents get table columns (k_lis_mixed)
     static const int mixH = getenv("SPERR_HIP_MIX_H") ? atoi(getenv("SPERR_HIP_MIX_H")) : spk::kClsTableH;
     static const double mixShare = getenv("SPERR_HIP_MIX_SHARE") ? atof(getenv("SPERR_HIP_MIX_SHARE")) / 100.0 : spk::kClsMinShare;
@@ -367,7 +369,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
                oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf), oCls = blob.add(h.cls),
-               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup);
+               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup), oIR = blob.add(h.iRoots);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
@@ -403,6 +405,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz)
   P.dtree.cls = reinterpret_cast<const spk::ShapeCls*>(base + oCls);
   P.dtree.gridCls = reinterpret_cast<const uint8_t*>(base + oGC);
   P.d_levelGroup = reinterpret_cast<const uint8_t*>(base + oLG);
+  P.d_iRoots = h.iRoots.empty() ? nullptr : reinterpret_cast<const uint64_t*>(base + oIR);
   P.d_initLIS = reinterpret_cast<const uint64_t*>(base + oInit);
   P.d_initLen = reinterpret_cast<const uint32_t*>(base + oInitLen);
   P.d_levelOff = reinterpret_cast<const uint32_t*>(base + oLevOff);
@@ -485,6 +488,7 @@ struct Engine {
 
   // the device tables of at most kMaxPlans chunk shapes are kept (a ragged volume has 8 shapes)
   static constexpr size_t kMaxPlans = 64;
+  // (dz = 0: the decoder's plan of a dx x dy slice, with the 2D coder's forest)
   ShapePlan* plan(size_t dx, size_t dy, size_t dz)
   {
     const Dims key{dx, dy, dz};
@@ -497,7 +501,7 @@ struct Engine {
       return it->second.get();
     }
     auto p = std::make_unique<ShapePlan>();
-    if (build_plan(*p, dx, dy, dz))
+    if (dz == 0 ? build_plan(*p, dx, dy, 1, true) : build_plan(*p, dx, dy, dz))
       return nullptr;
     ShapePlan* raw = p.get();
     plans[key] = std::move(p);
@@ -1774,6 +1778,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.mixSmemBytes = kMixSmemBytes;
   d.mixW = mix_window(kMixSmemBytes);
   d.mixLevelGroup = P.d_levelGroup;
+  d.iRoots = P.d_iRoots;
+  d.iLevels = P.ht.iLevels;
   d.leafCap = P.ht.nsets + 8;
   d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;
@@ -1988,9 +1994,19 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     return probe.used;
   };
   bool deferSized = false;
+  // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mixed and its
+  // type-I phase); SPERR_HIP_SLICE_MIXED=0: by k_speck2d_decode, one workgroup walking the quadtree
+  static const bool sliceMixed = !(getenv("SPERR_HIP_SLICE_MIXED") && atoi(getenv("SPERR_HIP_SLICE_MIXED")) == 0);
   for (int pass = 0; pass < 2; pass++)
   for (auto& g : groups) {
-    ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+    ShapePlan* P = nullptr;
+    if (slice && sliceMixed) {
+      P = E.plan(g.first[0], g.first[1], 0);
+      if (P && !use_mixed(*P))
+        P = nullptr;
+    }
+    if (!P)
+      P = E.plan(g.first[0], g.first[1], g.first[2]);
     if (!P)
       return -1;
     const bool deferG = deferOK && deferrable(*P, g.second.size());
@@ -2159,7 +2175,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           }
           else
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
-          if (slice) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
+          if (slice && !(P->ht.flags & spk::kTree2D)) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
             DecPlanHost ph2 = ph;
             ph2.tables = ph2.l0 = ph2.l1 = ph2.mixed = false;
             Speck2dBufs sb;

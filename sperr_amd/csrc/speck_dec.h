@@ -41,6 +41,7 @@ struct DecState {
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
   uint32_t leafCount;            //   of the current plane (bornCount: all births once k_lis_tables ends)
   uint64_t lisPhaseBits;         // bits of the plane's LIS phase covered by the birth masks
+  uint32_t iPart, iPad;          // 2D coder: part_level of what is left of the type-I set (0: nothing)
   uint32_t slotBorn[spk::kMaxLevels];   // births per mask slot of the plane (k_place_scan)
   uint32_t listLen[2][spk::kMaxLevels];
 };
@@ -128,6 +129,8 @@ struct DecBuffers {
   // k_lis_mixed (chunks whose lists mix set shapes): window bits and dynamic LDS
   uint32_t mixW;
   uint32_t mixSmemBytes;
+  const uint64_t* iRoots;         // 2D coder (spk::kTree2D): packed roots of the subbands the type-I set releases,
+  uint32_t iLevels;               //   three per level from the coarsest on (~0: empty); iLevels: transform levels
   const uint8_t* mixLevelGroup;   // per list level: the column group (0..2) most of its entries belong to
 };
 

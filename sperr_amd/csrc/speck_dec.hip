@@ -90,6 +90,7 @@ __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint6
   cs.nbp = nbp;
   cs.total_bits = total_bits;
   s.active = (nbp > 0 && (int)cs.wide == wide_pass) ? 1u : 0u;
+  s.iPart = b.iLevels;
   for (uint32_t l = 0; l < b.tree.nlevels; l++) {
     s.listLen[0][l] = initLen[l];
     s.listLen[1][l] = 0;
@@ -2389,6 +2390,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     __shared__ int sh_depth;
   __shared__ uint32_t sh_scan[kMixThreads / 64 + 1];
   __shared__ uint32_t sh_simd[kMixThreads / 64];
+  __shared__ uint64_t sh_one;                       // 2D coder: the subband being tested, as a list of one entry
 
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u;
@@ -2522,12 +2524,13 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     const Grid g = sh_grids[nd.grid];
     const Root r = sh_roots[g.root];
     k.grid = (uint16_t)(nd.grid + 1);
+    k.rev = (uint16_t)(b.tree.flags & kTree2D);
     uint32_t lev = r.lev;
     const int d = g.depth;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const int Da = r.D[a];
-      if (Da != 0) {   // spk::node_level
+      if (Da != 0 && !k.rev) {   // spk::node_level
         if (d < Da)
           lev += (uint32_t)d;
         else {
@@ -2540,9 +2543,10 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       k.e[a] = splits ? g.e[a] + 1 : g.e[a];
       k.base[a] = splits ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
       k.n[a] = (splits && axis_len(r.len[a], k.e[a], k.base[a] + 1u) > 0) ? 2u : 1u;
-      lev += k.n[a] - 1u;
+      if (!k.rev)
+        lev += k.n[a] - 1u;
     }
-    k.kidlev = lev;
+    k.kidlev = k.rev ? r.lev + (uint32_t)d + 1u : lev;   // (2D coder: one level per partition step)
     k.nk = k.n[0] * k.n[1] * k.n[2];
   };
   auto node_cls_l = [&](const Node& nd) -> uint32_t {
@@ -3222,14 +3226,73 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     }
   };
 
-  for (uint32_t l = nlevels; l-- > 0;) {
-    n = s.listLen[cur][l];
-    if (n == 0) {
-      if (tid == 0)
-        s.listLen[nx][l] = 0;
-      continue;
+  // The lists, deepest level first.  2D coder (spk::kTree2D): then the type-I set, tested at the end
+  // of every sorting pass (SPECK2D_INT.cpp:44-98): when it is significant, the three subbands of its
+  // level are tested -- each goes through the machinery below as a list of one entry, and joins the
+  // list of its level as a birth when it is insignificant -- and the rest of it is tested next (a
+  // test that is implied when none of the three was significant).
+  const bool twoD = (b.tree.flags & kTree2D) != 0;
+  uint32_t lv = nlevels;
+  bool inI = false, iNeed = true;
+  int iJ = -1;                     // next of the three subbands (-1: the type-I set's own test)
+  uint32_t iPart = s.iPart, iCounter = 0;
+  uint64_t iRoot = 0, iPos0 = 0;
+  for (;;) {
+    uint32_t l;
+    if (!inI) {
+      if (lv == 0) {
+        if (!twoD)
+          break;
+        inI = true;
+        continue;
+      }
+      l = --lv;
+      n = s.listLen[cur][l];
+      if (n == 0) {
+        if (tid == 0)
+          s.listLen[nx][l] = 0;
+        continue;
+      }
+      list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
     }
-    list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
+    else {
+      if (iJ < 0) {
+        if (iPart == 0)
+          break;
+        if (iNeed) {
+          __syncthreads();
+          const uint64_t pos = sh_pos;
+          const uint32_t bit = (pos >> 6) < nwordsAvail ? (uint32_t)(words[pos >> 6] >> (pos & 63)) & 1u : 0u;
+          __syncthreads();
+          if (tid == 0)
+            sh_pos = pos + 1;
+          __syncthreads();
+          if (!bit)
+            break;
+        }
+        iJ = 0;
+        iCounter = 0;
+        continue;
+      }
+      if (iJ == 3) {
+        iPart--;
+        iNeed = iCounter != 0;
+        iJ = -1;
+        continue;
+      }
+      iRoot = b.iRoots[(size_t)(b.iLevels - iPart) * 3 + (uint32_t)iJ];
+      iJ++;
+      if (iRoot == ~0ull)   // (an empty subband)
+        continue;
+      __syncthreads();
+      if (tid == 0)
+        sh_one = iRoot;
+      iPos0 = sh_pos;
+      l = iPart;
+      n = 1;
+      list = &sh_one;
+      __syncthreads();
+    }
     grp = b.mixLevelGroup[l] & 3u;      // column group of (most of) this list's entries
     topGrp = b.mixLevelGroup[l] >> 4;   // highest column group its windows can need
     // the walk of a window stops at S: items of the columns in use that start before S end inside
@@ -3381,6 +3444,15 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       expand((uint32_t)pend, (uint32_t)tid, kMixThreads, false);
     __syncthreads();
     STAMP(3);
+    if (inI) {   // a subband the type-I set released
+      const bool sig = (__hip_atomic_load(sigbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull) != 0;
+      if (sig)
+        iCounter++;
+      else if (tid == 0)
+        record_born(iPart, iPos0, iRoot);
+      __syncthreads();
+      continue;
+    }
     // ---- old entries that stayed insignificant keep their order
     {
       __syncthreads();
@@ -3440,6 +3512,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   if (tid == 0) {
     s.cur = nx;
     s.pos = sh_pos;
+    s.iPart = iPart;
     s.nLeafEv = min(sh_leaf, b.leafCap);
     s.bornCount = min(sh_born, (uint32_t)b.bornStride);
     s.lisPhaseBits = phaseBits;

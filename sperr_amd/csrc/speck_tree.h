@@ -56,6 +56,7 @@ constexpr uint8_t kGridOct = 1;
 // so the decoder keeps the pixel results of these leaf sets per leaf (DecBuffers::leafState) and
 // folds them into the raster masks word by word instead of scattering them with atomics.
 constexpr uint8_t kGridLeafWord = 2;
+constexpr uint32_t kTree2D = 1;
 
 struct Grid {          // all nodes of one root at one depth, as a dense 3D array
   uint32_t nodeOff;    // first flat node id (multiple of kNodeBlock)
@@ -94,6 +95,9 @@ struct Tree {
   const Grid* grids;
   const uint16_t* tab;     // interval start tables
   const uint16_t* blockGrid;  // grid index of every kNodeBlock-sized block of flat node ids
+  // kTree2D: the forest of the 2D coder (SPECK2D_INT.cpp): the children of a set come in the reverse
+  // order (bottom right first), a child's list level is its parent's + 1 whatever splits
+  uint32_t flags;
   // shape classes (ncls == 0: more than kMaxCls, not available)
   uint32_t ncls, nslots;
   const ShapeCls* cls;
@@ -214,6 +218,8 @@ SPK_HD uint32_t node_level(const Tree& t, const Node& n)
 {
   const Grid& g = t.grids[n.grid];
   const Root& r = t.roots[g.root];
+  if (t.flags & kTree2D)   // one level per partition step (/root/reference/src/SPECK2D_INT.cpp:121-147)
+    return (uint32_t)r.lev + g.depth;
   uint32_t lev = r.lev;
   for (int a = 0; a < 3; a++) {
     const int Da = r.D[a];
@@ -344,6 +350,7 @@ struct KidBox {
   uint32_t nk;           // n[0] * n[1] * n[2]
   uint32_t kidlev;       // LIS level of the children that are sets
   uint16_t grid;         // their grid (meaningless when they are single samples of the deepest depth)
+  uint16_t rev;          // 2D coder: child ordinals count from the far corner
 };
 
 SPK_HD void kid_box(const Tree& t, const Node& nd, KidBox& k)
@@ -352,18 +359,24 @@ SPK_HD void kid_box(const Tree& t, const Node& nd, KidBox& k)
   const Root& r = t.roots[g.root];
   k.grid = (uint16_t)(nd.grid + 1);
   k.kidlev = node_level(t, nd);
+  k.rev = (uint16_t)(t.flags & kTree2D);
   for (int a = 0; a < 3; a++) {
     const bool splits = g.depth < r.D[a];
     k.e[a] = splits ? g.e[a] + 1 : g.e[a];
     k.base[a] = splits ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
     k.n[a] = (splits && axis_len(r.len[a], k.e[a], k.base[a] + 1u) > 0) ? 2u : 1u;
-    k.kidlev += k.n[a] - 1u;   // (an interval longer than one sample has two non-empty halves)
+    if (!k.rev)
+      k.kidlev += k.n[a] - 1u;   // (an interval longer than one sample has two non-empty halves)
   }
+  if (k.rev)
+    k.kidlev += 1u;
   k.nk = k.n[0] * k.n[1] * k.n[2];
 }
 
 SPK_HD void kid_index(const KidBox& k, uint32_t ord, uint32_t idx[3])
 {
+  if (k.rev)
+    ord = k.nk - 1u - ord;
   idx[0] = k.base[0] + (k.n[0] == 2 ? (ord & 1u) : 0u);
   const uint32_t o1 = k.n[0] == 2 ? ord >> 1 : ord;
   idx[1] = k.base[1] + (k.n[1] == 2 ? (o1 & 1u) : 0u);

@@ -76,6 +76,12 @@ struct HostTree {
   uint32_t slotMaxT = 0;                       // longest split of a class with a table
   uint32_t dims[3] = {0, 0, 0};
   uint32_t nnodes = 0, nlevels = 0, maxDepth = 0, nsets = 0;
+  uint32_t flags = 0;                          // spk::kTree2D
+  // 2D coder: the subbands the type-I set releases, three per transform level from the coarsest on
+  // (bottom right, top right, bottom left: SPECK2D_INT.cpp:149-186), as packed root nodes (kNoRoot: empty)
+  static constexpr uint64_t kNoRoot = ~0ull;
+  std::vector<uint64_t> iRoots;
+  uint32_t iLevels = 0;                        // transform levels = part_level of the first type-I set
 
   Tree view() const
   {
@@ -92,6 +98,7 @@ struct HostTree {
     t.grids = grids.data();
     t.tab = tab.data();
     t.blockGrid = blockGrid.data();
+    t.flags = flags;
     t.ncls = (uint32_t)cls.size();
     t.nslots = nslots;
     t.cls = cls.data();
@@ -160,9 +167,11 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
     c.nsplit = (uint8_t)((n[0] - 1) + (n[1] - 1) + (n[2] - 1));
     uint64_t maxT = 0;
     int hh = 0;
-    for (uint32_t cz = 0; cz < n[2]; cz++)
-      for (uint32_t cy = 0; cy < n[1]; cy++)
-        for (uint32_t cx = 0; cx < n[0]; cx++) {
+    const uint32_t nkAll = n[0] * n[1] * n[2];
+    for (uint32_t ord = 0; ord < nkAll; ord++) {
+          // (x fastest; the 2D coder takes its children from the far corner backwards)
+          const uint32_t o = (h.flags & kTree2D) ? nkAll - 1u - ord : ord;
+          const uint32_t cx = o % n[0], cy = (o / n[0]) % n[1], cz = o / (n[0] * n[1]);
           const std::array<uint32_t, 3> kd = {part[0][cx], part[1][cy], part[2][cz]};
           if (kd[0] * kd[1] * kd[2] == 1) {
             c.kid[c.nk++] = kClsPixel;
@@ -306,7 +315,11 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
   }
 }
 
-inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
+// twoD: the forest of the 2D coder for a slice of dx x dy samples (dz = 1): the root set S is the
+// coarsest approximation, at list level = the number of transform levels; the three detail subbands
+// of every level are roots too (released by the type-I set, SPECK2D_INT.cpp:149-218: they are NOT
+// in the initial lists), at list level = their transform level.
+inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false)
 {
   using detail::Box;
   HostTree h;
@@ -314,6 +327,10 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
   h.dims[1] = (uint32_t)dy;
   h.dims[2] = (uint32_t)dz;
   h.nlevels = (uint32_t)(1 + num_of_partitions(dx) + num_of_partitions(dy) + num_of_partitions(dz));
+  if (twoD) {
+    h.flags = kTree2D;
+    h.nlevels = (uint32_t)(1 + num_of_partitions(std::max(dx, dy)));
+  }
 
   // ---- roots, in the order the reference pushes them -----------------------------------
   struct Pending {
@@ -360,7 +377,29 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
     big = first;
   };
   size_t dyadic = 0;
-  if (can_use_dyadic({dx, dy, dz}, dyadic)) {
+  std::vector<std::pair<uint32_t, uint32_t>> iOrder;   // (level, index in lists[level]) of the released subbands
+  if (twoD) {
+    const size_t xf = num_of_xforms(std::min(dx, dy));
+    h.iLevels = (uint32_t)xf;
+    const auto ax = approx_detail_len(dx, xf), ay = approx_detail_len(dy, xf);
+    lists[xf].push_back(Box{{0, 0, 0}, {(uint32_t)ax[0], (uint32_t)ay[0], 1}});   // S
+    for (size_t k = xf; k >= 1; k--) {   // the type-I set at part_level k releases BR, TR, BL of level k
+      const auto lx = approx_detail_len(dx, k), ly = approx_detail_len(dy, k);
+      const Box sub[3] = {{{(uint32_t)lx[0], (uint32_t)ly[0], 0}, {(uint32_t)lx[1], (uint32_t)ly[1], 1}},
+                          {{(uint32_t)lx[0], 0, 0}, {(uint32_t)lx[1], (uint32_t)ly[0], 1}},
+                          {{0, (uint32_t)ly[0], 0}, {(uint32_t)lx[0], (uint32_t)ly[1], 1}}};
+      for (const Box& bx : sub) {
+        if (bx.len[0] == 0 || bx.len[1] == 0) {
+          iOrder.push_back({0xffffffffu, 0});
+          continue;
+        }
+        iOrder.push_back({(uint32_t)k, (uint32_t)lists[k].size()});
+        lists[k].push_back(bx);
+      }
+    }
+    lev = (uint32_t)xf;
+  }
+  else if (can_use_dyadic({dx, dy, dz}, dyadic)) {
     for (size_t i = 0; i < dyadic; i++)
       split(true, true, true);
   }
@@ -374,10 +413,12 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
     for (; xf < nz; xf++)
       split(false, false, true);
   }
-  lists[lev].insert(lists[lev].begin(), big);
+  if (!twoD)
+    lists[lev].insert(lists[lev].begin(), big);
 
   // ---- per-root tables -----------------------------------------------------------------
   h.initLIS.assign(h.nlevels, {});
+  std::vector<std::vector<uint64_t>> rootNode(h.nlevels);
   for (uint32_t l = 0; l < h.nlevels; l++)
     for (const Box& b : lists[l]) {
       Root r{};
@@ -424,9 +465,13 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
       }
       h.maxDepth = std::max<uint32_t>(h.maxDepth, r.Dmax);
       Node rn{r.gridFirst, {0, 0, 0}};
-      h.initLIS[l].push_back(pack_node(rn));
+      if (!twoD || (l == h.iLevels && h.initLIS[l].empty()))   // (2D: only S is listed from the start)
+        h.initLIS[l].push_back(pack_node(rn));
+      rootNode[l].push_back(pack_node(rn));
       h.roots.push_back(r);
     }
+  for (const auto& io : iOrder)
+    h.iRoots.push_back(io.first == 0xffffffffu ? HostTree::kNoRoot : rootNode[io.first][io.second]);
 
   // ---- list capacities: how many set nodes can ever sit in each LIS level ----------------
   h.levelCap.assign(h.nlevels, 0);
@@ -498,6 +543,8 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz)
       c.lev[j] = (uint8_t)lv[K - 1 - j];
     }
   }
+  if (twoD)   // (the chains of LevelClass follow the 3D level rule: the 2D forest goes by shape classes only)
+    h.allRegular = false;
   build_classes(h, kClsTableH, kClsTableSlots);
   return h;
 }

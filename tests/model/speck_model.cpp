@@ -966,10 +966,10 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
 // child by child with the tables of its children -- and every set that was hopped over is expanded
 // by an independent thread.  Births are ranked by stream position as in the regular model.
 // ------------------------------------------------------------------------------------------
-int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t dims[3],
-                               uint64_t* coef, uint64_t* sign, int window, int hmax)
+static int model_decode_mixed_impl(const uint8_t* stream, size_t len, const size_t dims[3],
+                                   uint64_t* coef, uint64_t* sign, int window, int hmax, bool twoD)
 {
-  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  HostTree ht = build_tree(dims[0], dims[1], dims[2], twoD);
   build_classes(ht, hmax, 4, hmax >= 2 ? 0.0 : 0.02);
   if (ht.cls.empty())
     return -2;
@@ -997,6 +997,7 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
   };
   std::vector<std::vector<uint64_t>> lis(ht.initLIS), next(t.nlevels);
   uint64_t pos = 0;
+  uint32_t iPart = ht.iLevels;   // 2D: part_level of the type-I set that is left (0: none)
   for (int p = nbp - 1; p >= 0; p--) {
     const uint64_t thr = uint64_t(1) << p;
     const uint64_t init = thr + thr - thr / 2 - 1;
@@ -1052,11 +1053,10 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
       uint32_t c;
       uint64_t y;   // first bit of the split, window-relative
     };
-    for (uint32_t l = t.nlevels; l-- > 0;) {
-      const size_t n = lis[l].size();
-      if (n == 0)
-        continue;
-      std::vector<char> sigv(n, 0);
+    // one list (a level's, or a single subband the type-I set releases): sigv[k] = entry k was significant
+    auto run_list = [&](const std::vector<uint64_t>& curList, std::vector<char>& sigv) {
+      const size_t n = curList.size();
+      sigv.assign(n, 0);
       std::vector<Ctx> ctx;
       size_t e = 0, rem = n;
       bool listDone = false;
@@ -1178,7 +1178,7 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
             rem--;
             continue;
           }
-          const Node nd = unpack_node(lis[l][e]);
+          const Node nd = unpack_node(curList[e]);
           const uint32_t c = node_cls(t, nd);
           if (c == kClsPixel)
             abort();
@@ -1237,9 +1237,41 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
           queue.swap(nq);
         }
       }
-      for (size_t k = 0; k < n; k++)
+    };
+    for (uint32_t l = t.nlevels; l-- > 0;) {
+      if (lis[l].empty())
+        continue;
+      std::vector<char> sigv;
+      run_list(lis[l], sigv);
+      for (size_t k = 0; k < lis[l].size(); k++)
         if (!sigv[k])
           next[l].push_back(lis[l][k]);
+    }
+    // 2D: the type-I set, tested at the end of every sorting pass (SPECK2D_INT.cpp:44-98): when it
+    // is significant the three subbands of its level are tested (always with a bit) and join the
+    // lists or split at once, then the rest of it is tested (implied when none of the three was)
+    if (twoD) {
+      bool need = true;
+      while (iPart > 0) {
+        if (need && !in.get(pos++))
+          break;
+        int counter = 0;
+        for (int j = 0; j < 3; j++) {
+          const uint64_t root = ht.iRoots[(size_t)(ht.iLevels - iPart) * 3 + j];
+          if (root == HostTree::kNoRoot)
+            continue;
+          const uint64_t at = pos;   // its test bit
+          std::vector<uint64_t> one(1, root);
+          std::vector<char> sv;
+          run_list(one, sv);
+          if (sv[0])
+            counter++;
+          else
+            bornv.push_back({iPart, at, root});
+        }
+        iPart--;
+        need = counter != 0;
+      }
     }
     std::stable_sort(bornv.begin(), bornv.end(), [](const BornRec& x, const BornRec& y) {
       return x.lev != y.lev ? x.lev < y.lev : x.pos < y.pos;
@@ -1267,6 +1299,19 @@ int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
       break;
   }
   return 0;
+}
+
+int model_speck3d_decode_mixed(const uint8_t* stream, size_t len, const size_t dims[3],
+                               uint64_t* coef, uint64_t* sign, int window, int hmax)
+{
+  return model_decode_mixed_impl(stream, len, dims, coef, sign, window, hmax, false);
+}
+
+// the 2D coder's streams (SPECK2D_INT) with the same machinery: dims[2] = 1
+int model_speck2d_decode_mixed(const uint8_t* stream, size_t len, const size_t dims[3],
+                               uint64_t* coef, uint64_t* sign, int window, int hmax)
+{
+  return model_decode_mixed_impl(stream, len, dims, coef, sign, window, hmax, true);
 }
 
 // every set node against its shape class (tests/test_speck_model.py::test_shape_classes_are_consistent)

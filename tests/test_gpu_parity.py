@@ -751,3 +751,41 @@ def test_serial_walk_fallback_in_a_fresh_process(oracle):
                    os.path.join(td, "r.npy")))
         env = dict(os.environ, SPERR_HIP_LIS_MIXED="0")
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (5, 300), (2, 9), (1, 40), (33, 17), (500, 301), (1024, 1024)])
+def test_2d_slice_decoder_on_the_shared_forest(eng, oracle, shape):
+    """Slices are decoded by the 3D decoder's kernels on the 2D coder's forest (quadtrees whose
+    children come from the bottom right backwards, the subbands released by the type-I set at the end of
+    a sorting pass: src/SPECK2D_INT.cpp:44-186): slices without a transform level (no type-I set), with
+    empty subbands, one row only, more than 32 bit planes, and streams cut short."""
+    img = turbulence((1,) + shape, dtype=np.float64)[0]
+    for mode, quality in [(1, 3.0), (2, 120.0), (3, 1e-11)]:
+        want = oracle.comp_2d(img, mode, quality, False)
+        for cut in (len(want), 26 + (len(want) - 26) // 3):
+            s = want[:cut]
+            got = eng.decompress_2d(cuda(np.frombuffer(s, dtype=np.uint8)), shape, False).cpu().numpy()
+            assert np.array_equal(bits(got), bits(oracle.decomp_2d(s, shape, False))), (shape, mode, cut)
+
+
+def test_2d_quadtree_walk_decoder_in_a_fresh_process(oracle):
+    """`SPERR_HIP_SLICE_MIXED=0` (read once per process) decodes slices with k_speck2d_decode, the
+    quadtree walk that also takes the slices the shared forest does not: the same bits."""
+    import subprocess
+    import sys
+    import tempfile
+    shape = (121, 96)
+    img = turbulence((1,) + shape)[0]
+    want = oracle.comp_2d(img, 2, 90.0, False)
+    ref = oracle.decomp_2d(want, shape, True)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "c.npy"), np.frombuffer(want, dtype=np.uint8))
+        np.save(os.path.join(td, "r.npy"), ref)
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from sperr_amd.api import SperrHip; "
+                "e = SperrHip(); c = torch.from_numpy(np.load(%r)).cuda(); r = np.load(%r); "
+                "d = e.decompress_2d(c, %r, True).cpu().numpy(); "
+                "sys.exit(0 if np.array_equal(d.view(np.uint32), r.view(np.uint32)) else 3)"
+                % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(td, "c.npy"),
+                   os.path.join(td, "r.npy"), shape))
+        env = dict(os.environ, SPERR_HIP_SLICE_MIXED="0")
+        assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0

@@ -172,3 +172,54 @@ def test_shape_classes_are_consistent(model):
     for dims in [(250, 250, 250), (129, 129, 129), (100, 70, 33), (96, 96, 96), (17, 300, 21), (1, 1, 9),
                  (80, 80, 80), (64, 64, 320), (30, 40, 8), (2, 3, 5)]:
         assert lib.model_check_classes((_sz * 3)(*dims)) == 0, dims
+
+
+def _speck2d_oracle(oracle, coef2d, sign, budget):
+    lib = oracle.lib
+    lib.orc_speck2d_encode.argtypes = [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+    lib.orc_speck2d_encode.restype = C.c_int
+    lib.orc_speck2d_decode.argtypes = [_vp, _sz, _sz, _sz, _vp, _vp]
+    lib.orc_speck2d_decode.restype = C.c_int
+    dy, dx = coef2d.shape
+    out, n = _vp(None), _sz(0)
+    c = np.ascontiguousarray(coef2d, dtype=np.uint64)
+    assert lib.orc_speck2d_encode(c.ctypes.data, sign.ctypes.data, dx, dy, budget, C.byref(out), C.byref(n)) == 0
+    s = C.string_at(out.value, n.value)
+    C.CDLL(None).free(out)
+    return s
+
+
+def _speck2d_oracle_decode(oracle, stream, shape_yx):
+    dy, dx = shape_yx
+    buf = np.frombuffer(stream, dtype=np.uint8)
+    coef = np.zeros(shape_yx, dtype=np.uint64)
+    sign = np.zeros((coef.size + 63) // 64, dtype=np.uint64)
+    assert oracle.lib.orc_speck2d_decode(buf.ctypes.data, buf.size, dx, dy, coef.ctypes.data, sign.ctypes.data) == 0
+    return coef, sign
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (17, 23), (64, 64), (99, 100), (40, 9), (128, 96), (9, 9), (200, 33)])
+@pytest.mark.parametrize("window,hmax", [(200, 1), (4096, 2), (64, 0)])
+def test_model_2d_decoder_on_the_mixed_machinery(oracle, model, shape, window, hmax):
+    """The 2D coder's streams (SPECK2D_INT: quadtrees, children from the bottom right backwards, the
+    subbands released by the type-I set at the end of a pass) decoded with the forest / shape-class /
+    window machinery of the 3D decoder in its 2D mode, against the oracle's SPECK2D decoder."""
+    lib = model
+    lib.model_speck2d_decode_mixed.argtypes = [_vp, _sz, _vp, _vp, _vp, C.c_int, C.c_int]
+    lib.model_speck2d_decode_mixed.restype = C.c_int
+    dy, dx = shape
+    for scale in (3000.0, 4294967295.0):
+        coef3, sign = quantized(oracle, (1, dy, dx), scale)
+        coef = coef3.reshape(dy, dx)
+        for budget in (0, 20000):
+            stream = _speck2d_oracle(oracle, coef, sign, budget)
+            for cut in (len(stream), 9 + (len(stream) - 9) // 3):
+                s = stream[:cut]
+                c0, s0 = _speck2d_oracle_decode(oracle, s, shape)
+                buf = np.frombuffer(s, dtype=np.uint8)
+                c1 = np.zeros(shape, dtype=np.uint64)
+                s1 = np.zeros((c1.size + 63) // 64, dtype=np.uint64)
+                assert lib.model_speck2d_decode_mixed(buf.ctypes.data, buf.size, (_sz * 3)(dx, dy, 1),
+                                                      c1.ctypes.data, s1.ctypes.data, window, hmax) == 0
+                assert np.array_equal(c0, c1), (shape, scale, budget, cut)
+                assert np.array_equal(s0, s1)
