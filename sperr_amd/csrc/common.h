@@ -99,6 +99,7 @@ struct EncState {
   uint64_t total_bits;
   uint64_t budget;               // rounded up to a multiple of 8, or ~0
   uint64_t lisBits;              // bits of the current LIS phase
+  uint32_t iPart, iPad;          // 2D coder: part_level of what is left of the type-I set (0: nothing)
   PlaneRec rec[kMaxPlanes];
   uint64_t lipTot[kMaxPlanes], refTot[kMaxPlanes];
   uint32_t listLen[2][spk::kMaxLevels];

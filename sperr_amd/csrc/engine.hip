@@ -833,6 +833,8 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   e.bornStride = P.ht.nsets + 8;
   TAKE(e.bornPacked, uint64_t, e.bornStride * B);
   TAKE(e.bornPosLev, uint64_t, e.bornStride * B);
+  e.iRoots = P.d_iRoots;
+  e.iLevels = P.ht.iLevels;
   e.levelSlot = P.d_levelSlot;
   e.slotLevel = P.d_slotLevel;
   e.nSlots = P.nSlots;
@@ -1217,6 +1219,14 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   return 0;
 }
 
+// SPERR_HIP_SLICE_MIXED=0: slices are coded by k_speck2d's quadtree walk (one workgroup) instead of
+// the kernels of the 3D coder on the 2D coder's forest
+bool slice_forest_enabled()
+{
+  static const bool on = !(getenv("SPERR_HIP_SLICE_MIXED") && atoi(getenv("SPERR_HIP_SLICE_MIXED")) == 0);
+  return on;
+}
+
 // ---- 2D slices (sperr_comp_2d / sperr_decomp_2d, src/SPERR_C_API.cpp:7-134): a slice is a
 // one-chunk batch of dims (x, y, 1) -- its transform plan already is dwt2d -- coded by the 2D
 // coder of speck2d.hip instead of the 3D one
@@ -1314,12 +1324,16 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
   }
 
+  // (a slice is coded on the 2D coder's forest, the plan with z extent 0; SPERR_HIP_SLICE_MIXED=0: by
+  //  k_speck2d's quadtree walk)
+  auto planZ = [&](const Dims& d) -> size_t { return slice && slice_forest_enabled() ? 0 : d[2]; };
+
   // slots for the finished chunk streams
   std::vector<uint64_t> slotOff(nchunks + 1, 0);
   {
     std::vector<uint64_t> slotLen(nchunks, 0);
     for (auto& g : groups) {
-      ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+      ShapePlan* P = E.plan(g.first[0], g.first[1], planZ(g.first));
       if (!P)
         return -1;
       const uint64_t raw = (uint64_t)(bpp * (double)P->N);
@@ -1368,7 +1382,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
     for (auto& g : groups) {
-      ShapePlan* P = E.plan(g.first[0], g.first[1], g.first[2]);
+      ShapePlan* P = E.plan(g.first[0], g.first[1], planZ(g.first));
       groupOff.push_back(need);
       need += round_up(g.second.size() * enc_bytes_per_chunk(*P, (uint64_t)(bpp * (double)P->N)) + 4096, 4096);
       sideBySide = sideBySide && g.second.size() <= 256;
@@ -1385,7 +1399,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   late.resize(groups.size());
   std::vector<ShapePlan*> groupPlan;   // (looked up here: the plan cache is not for several threads)
   for (auto& g : groups)
-    groupPlan.push_back(E.plan(g.first[0], g.first[1], g.first[2]));
+    groupPlan.push_back(E.plan(g.first[0], g.first[1], planZ(g.first)));
   auto do_group = [&](uint32_t gi, std::pair<const Dims, std::vector<ChunkRef>>& g) -> int {
     hipStream_t ss = sideBySide ? E.sub[gi % kSubStreams] : st;
     ShapePlan* P = groupPlan[gi];
@@ -1468,7 +1482,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       // ---- integer coder, 32-bit coefficients ----
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
       Speck2dBufs sb;
-      if (slice) {
+      const bool quadWalk = slice && !(P->ht.flags & spk::kTree2D);   // (SPERR_HIP_SLICE_MIXED=0)
+      if (quadWalk) {
         if (carve_slice2d(E, *P, sb))
           return -1;
         sb.coef = bb.coef32;
@@ -1512,7 +1527,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         EncBuffers ew = e;
         ew.coef = bb.vals;
         ew.coefStride = bb.valsStride;
-        if (slice) {
+        if (quadWalk) {
           sb.coef = bb.vals;
           if (launch_speck2d_encode(ss, sb, raw_budget, rate, true))
             return -1;
@@ -1996,7 +2011,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   bool deferSized = false;
   // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mixed and its
   // type-I phase); SPERR_HIP_SLICE_MIXED=0: by k_speck2d_decode, one workgroup walking the quadtree
-  static const bool sliceMixed = !(getenv("SPERR_HIP_SLICE_MIXED") && atoi(getenv("SPERR_HIP_SLICE_MIXED")) == 0);
+  const bool sliceMixed = slice_forest_enabled();
   for (int pass = 0; pass < 2; pass++)
   for (auto& g : groups) {
     ShapePlan* P = nullptr;

@@ -2484,7 +2484,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   }
   if (stamps)
     stamp_t = __builtin_readcyclecounter();
-  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0;
+  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0, cnt_tight = 0, cnt_words = 0, cnt_walks = 0;
+  uint64_t tick_tight = 0, tick_enter = 0, tick_round = 0, tick_rec = 0;
 
   auto bit_at = [&](uint32_t r) -> uint32_t {
     const uint32_t q = r + wq0;
@@ -2855,7 +2856,9 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             const uint32_t eEnd = e + rem;
             uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
             bool unusual = false;
+            const uint64_t tt0 = stamps ? __builtin_readcyclecounter() : 0;
             while (true) {
+              cnt_words++;
               if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
                 if (kk != curK) {
                   curK = kk;
@@ -2905,6 +2908,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
                   break;
               }
               cnt_hops += ns - ns0;
+              cnt_tight += ns - ns0;
               qcost += (ns - ns0) * itemCost;
               if (unusual)
                 break;
@@ -2916,6 +2920,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             }
             r = kk * 64u + oo - wq0;
             rem = eEnd - e;
+            if (stamps)
+              tick_tight += __builtin_readcyclecounter() - tt0;
             if (!unusual)
               continue;
             if (kk != curK) {   // (cannot happen: an unusual entry lies in the word just walked)
@@ -2962,6 +2968,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           }
           else {   // walk into it
             cnt_push++;
+            const uint64_t te0 = stamps ? __builtin_readcyclecounter() : 0;
             const uint64_t packed = list[e];
             if (lane == 0)
               atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
@@ -2977,11 +2984,14 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             }
             depth = 2;
             r += 1;
+            if (stamps)
+              tick_enter += __builtin_readcyclecounter() - te0;
           }
           e++;
           rem--;
           continue;
         }
+        const uint64_t tr0 = stamps ? __builtin_readcyclecounter() : 0;
         // ---- a set that is being walked into: its children from `next` on, one look-up each;
         //      lane k remembers what became of child k and writes its record afterwards
         MixCtx& cx = sh_ctx[depth - 1];
@@ -3058,6 +3068,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           break;
         }
         // the records of the children handled in this round
+        const uint64_t tr1 = stamps ? __builtin_readcyclecounter() : 0;
         {
           const uint64_t rel = a + myY - phase0;
           const bool bornOk = myAct == 1 && sh_levelSlot[kb.kidlev] != 0xff && rel < maskBits;
@@ -3101,10 +3112,19 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           }
           depth++;
         }
-        else if (halted)
+        else if (halted) {
+          if (stamps) {
+            tick_round += tr1 - tr0;
+            tick_rec += __builtin_readcyclecounter() - tr1;
+          }
           break;
+        }
         else
           depth--;
+        if (stamps) {
+          tick_round += tr1 - tr0;
+          tick_rec += __builtin_readcyclecounter() - tr1;
+        }
       }
       flush();
       // (a window that changes nothing would be walked for ever: cannot happen while the window is
@@ -3497,6 +3517,12 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     out[20] += cnt_bits;
     out[21] += cnt_skips;
     out[22] += cnt_items;
+    out[23] += cnt_tight;
+    out[24] += cnt_words;
+    out[30] += tick_tight;
+    out[31] += tick_enter;
+    out[40] += tick_round;
+    out[41] += tick_rec;
   }
   if (b.lisStamps != nullptr && isHelper && lane == 0)
     b.lisStamps[(size_t)c * 64 + 32 + helperRank] += myWork;

@@ -71,6 +71,10 @@ struct EncBuffers {
   // output bit buffer (zero-initialised)
   uint64_t* stream;
   size_t streamStride;
+  // 2D coder (spk::kTree2D): packed roots of the subbands the type-I set releases, three per level
+  // from the coarsest on (~0: empty); iLevels: transform levels
+  const uint64_t* iRoots;
+  uint32_t iLevels;
 };
 
 struct EncPlanHost {

@@ -52,6 +52,7 @@ __global__ void k_enc_state_init(EncBuffers b, const uint64_t* initLIS, const ui
   s.budget = budget;
   s.lisBits = 0;
   s.cur = 0;
+  s.iPart = b.iLevels;
   for (int q = 0; q < kMaxPlanes; q++)
     s.bucketCnt[q] = 0;
   for (uint32_t l = 0; l < b.tree.nlevels; l++) {
@@ -605,6 +606,76 @@ __global__ void __launch_bounds__(kThreads) k_list_apply(EncBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// 2D coder: the type-I set -- everything outside the coarsest approximation band -- is tested at the
+// end of every sorting pass (SPECK2D_INT.cpp:44-98,149-186).  When it is significant, the three
+// subbands of its level are tested one after the other (a significant one splits on the spot: its
+// split is written by k_split_emit like that of a list entry, an insignificant one joins the list
+// of its level), and what is left of it is tested next -- a test that is implied when none of the
+// three was significant.  A few bits per plane: one thread per chunk, after the lists' positions
+// are known (k_list_scan) and before the splits are written.
+// ------------------------------------------------------------------------------------------
+__global__ void k_enc_iphase(EncBuffers b, int p)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  ACTIVE_OR_RETURN(s, p);
+  uint32_t iPart = s.iPart;
+  if (iPart == 0)
+    return;
+  const Tree& t = b.tree;
+  const int8_t* M = b.M + c * b.nodeStride;
+  const uint32_t* E = b.E + c * b.nodeStride;
+  uint64_t* stream = b.stream + c * b.streamStride;
+  const uint64_t baseLIS = s.rec[p].baseLIS;
+  uint64_t pos = baseLIS + s.lisBits;
+  bool need = true;
+  while (iPart > 0) {
+    if (need) {
+      // the set's largest coefficient: that of the subbands it still holds
+      int mi = -1;
+      for (uint32_t k = (b.iLevels - iPart) * 3u; k < b.iLevels * 3u; k++)
+        if (b.iRoots[k] != ~0ull)
+          mi = max(mi, (int)M[flat_id(t, unpack_node(b.iRoots[k]))]);
+      const bool isig = mi >= p;
+      put_bits(stream, pos, isig ? 1u : 0u, 1, s.budget);
+      pos++;
+      if (!isig)
+        break;
+    }
+    uint32_t counter = 0;
+    for (uint32_t j = 0; j < 3; j++) {
+      const uint64_t root = b.iRoots[(b.iLevels - iPart) * 3u + j];
+      if (root == ~0ull)
+        continue;
+      const uint32_t id = flat_id(t, unpack_node(root));
+      if (M[id] >= p) {
+        put_bits(stream, pos, 1u, 1, s.budget);
+        b.opos[c * b.nodeStride + id] = pos;
+        pos += 1u + E[id];
+        counter++;
+      }
+      else {
+        const uint64_t rel = pos - baseLIS;
+        const uint32_t slot = b.levelSlot[iPart];
+        if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
+          const uint32_t k = atomicAdd(&s.bornCount, 1u);
+          b.bornPacked[c * b.bornStride + k] = root;
+          b.bornPosLev[c * b.bornStride + k] = ((uint64_t)iPart << 48) | rel;
+          atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6), 1ull << (rel & 63));
+        }
+        pos++;
+      }
+    }
+    iPart--;
+    need = counter != 0;
+  }
+  s.iPart = iPart;
+  s.lisBits = pos - baseLIS;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_split_emit: every set whose msb equals the plane splits now
 // ------------------------------------------------------------------------------------------
 // Nodes are bucketed by the plane at which they split (k_bucket_*), so a plane only visits its
@@ -775,7 +846,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     node_kids(t, nd, kg);
     kids_info(t, nd, kg, M, E, msb, ki);
     const NodeGeom q = node_geom(t, nd);
-    kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+    kidlev = kid_level(t, nd, q);
     slot = b.levelSlot[kidlev];
     uint64_t q2 = pos;
     bool fnd = false;
@@ -1157,6 +1228,8 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
     LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
+    if (b.tree.flags & kTree2D)
+      LAUNCH_K(k_enc_iphase, perChunk, dim3(64), 0, stream, b, p);
     LAUNCH_K(k_split_emit, dim3(capped_blocks(kSplitBlocks, nc), nc), dim3(kNodeBlock), 0, stream, b, p);
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);

@@ -284,6 +284,25 @@ SPK_HD void node_kids(const Tree& t, const Node& n, Kids& k)
         k.count[k.n] = cnt;
         k.n++;
       }
+  if (t.flags & kTree2D)   // the 2D coder's order: from the bottom right backwards (SPECK2D_INT.cpp:109-147)
+    for (int lo = 0, hi = k.n - 1; lo < hi; lo++, hi--) {
+      for (int a = 0; a < 3; a++) {
+        const uint32_t v = k.idx[lo][a];
+        k.idx[lo][a] = k.idx[hi][a];
+        k.idx[hi][a] = v;
+      }
+      const uint32_t cnt = k.count[lo];
+      k.count[lo] = k.count[hi];
+      k.count[hi] = cnt;
+    }
+}
+
+// LIS level of the children of a set that are sets themselves (q = node_geom of the set)
+SPK_HD uint32_t kid_level(const Tree& t, const Node& n, const NodeGeom& q)
+{
+  if (t.flags & kTree2D)
+    return node_level(t, n) + 1u;
+  return node_level(t, n) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
 }
 
 SPK_HD uint32_t kid_flat(const Tree& t, const Kids& k, int j)

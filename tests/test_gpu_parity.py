@@ -769,8 +769,8 @@ def test_2d_slice_decoder_on_the_shared_forest(eng, oracle, shape):
 
 
 def test_2d_quadtree_walk_decoder_in_a_fresh_process(oracle):
-    """`SPERR_HIP_SLICE_MIXED=0` (read once per process) decodes slices with k_speck2d_decode, the
-    quadtree walk that also takes the slices the shared forest does not: the same bits."""
+    """`SPERR_HIP_SLICE_MIXED=0` (read once per process) codes slices with k_speck2d's quadtree walk, which
+    also decodes the slices the shared forest does not take: the same stream, the same values."""
     import subprocess
     import sys
     import tempfile
@@ -781,11 +781,14 @@ def test_2d_quadtree_walk_decoder_in_a_fresh_process(oracle):
     with tempfile.TemporaryDirectory() as td:
         np.save(os.path.join(td, "c.npy"), np.frombuffer(want, dtype=np.uint8))
         np.save(os.path.join(td, "r.npy"), ref)
+        np.save(os.path.join(td, "i.npy"), img)
         code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from sperr_amd.api import SperrHip; "
                 "e = SperrHip(); c = torch.from_numpy(np.load(%r)).cuda(); r = np.load(%r); "
                 "d = e.decompress_2d(c, %r, True).cpu().numpy(); "
-                "sys.exit(0 if np.array_equal(d.view(np.uint32), r.view(np.uint32)) else 3)"
+                "s = e.compress_2d(torch.from_numpy(np.load(%r)).cuda(), 90.0, mode=2, header=False); "
+                "ok = np.array_equal(d.view(np.uint32), r.view(np.uint32)) and torch.equal(s, c); "
+                "sys.exit(0 if ok else 3)"
                 % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(td, "c.npy"),
-                   os.path.join(td, "r.npy"), shape))
+                   os.path.join(td, "r.npy"), shape, os.path.join(td, "i.npy")))
         env = dict(os.environ, SPERR_HIP_SLICE_MIXED="0")
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
