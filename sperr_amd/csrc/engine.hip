@@ -462,6 +462,8 @@ struct Engine {
   Profiler prof;
   hipStream_t sub[kSubStreams] = {};
   hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {};
+  hipStream_t outl = nullptr;               // the 1D decoder of outlier streams runs here, beside the chunk decoders
+  hipEvent_t evOutl = nullptr;
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
@@ -482,6 +484,8 @@ struct Engine {
       HIP_CHECK(hipEventCreateWithFlags(&evJoin[q], hipEventDisableTiming));
     }
     HIP_CHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+    HIP_CHECK(hipStreamCreateWithFlags(&outl, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&evOutl, hipEventDisableTiming));
     ready = true;
     return 0;
   }
@@ -1294,6 +1298,8 @@ struct DrainOnError {
     for (uint32_t q = 0; q < kSubStreams; q++)
       if (E.sub[q])
         (void)hipStreamSynchronize(E.sub[q]);
+    if (E.outl)
+      (void)hipStreamSynchronize(E.outl);
     (void)hipGetLastError();
   }
 };
@@ -2146,6 +2152,73 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         }
         if (maxWide > kMaxPlanes)
           return -1;
+        // Outlier streams (point-wise error mode) are decoded by the 1D coder on a stream of their own,
+        // beside everything below: it needs the container only; the correctors are added at the end
+        bool batchOutliers = false;
+        for (uint32_t i = 0; i < nb; i++)
+          batchOutliers |= outHead[g.second[first + i].gid].has;
+        std::vector<OutlierChunk> hoc;
+        OutlierBufs ob;
+        {
+          hipStream_t so = E.outl;
+          if (batchOutliers) {
+            HIP_CHECK(hipEventRecord(E.evFork, ss));
+            HIP_CHECK(hipStreamWaitEvent(so, E.evFork, 0));
+          }
+          if (batchOutliers) {
+            hoc.assign(nb, OutlierChunk{});
+            memset(hoc.data(), 0, nb * sizeof(OutlierChunk));
+            uint64_t maxBits = 0;
+            int maxNbp = 1;
+            for (uint32_t i = 0; i < nb; i++) {
+              const OutHead& oh = outHead[g.second[first + i].gid];
+              if (!oh.has)
+                continue;
+              hoc[i].has = 1;
+              hoc[i].streamOff = oh.off;
+              hoc[i].total_bits = oh.total_bits;
+              hoc[i].nbp = oh.nbp;
+              if (oh.nbp > kMaxPlanes)
+                return -1;
+              maxBits = std::max(maxBits, oh.total_bits);
+              maxNbp = std::max(maxNbp, oh.nbp);
+            }
+            memset(&ob, 0, sizeof(ob));
+            ob.nchunks = nb;
+            ob.N = P->N;
+            ob.nw = (P->N + 63) / 64;
+            ob.wordStride = round_up((size_t)ob.nw + 2, 32);
+            // every value found costs at least its sign bit, every run kept on a list its test bit
+            ob.kStride = round_up((size_t)std::min<uint64_t>(P->N, maxBits) + 1, 64);
+            speck1d_level_offsets(ob, P->N, std::min<uint64_t>(maxBits + 2, 2ull * P->N));
+            ob.streamStride = (size_t)(maxBits / 64) + 4;
+            ob.planeStride = (size_t)maxNbp * ob.wordStride;
+            const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) +
+                                 (size_t)nb * (ob.wordStride * 16 + ob.kStride * 5 + ob.runStride * 8 +
+                                               ob.streamStride * 8 + ob.planeStride * 8) + 8192;
+            if (E.outlVar.ensure(bytes))
+              return -1;
+            Arena OA;
+            OA.base = static_cast<char*>(E.outlVar.p);
+            OA.cap = E.outlVar.n;
+            ob.oc = OA.take<OutlierChunk>(nb);
+            ob.lip = OA.take<uint64_t>(nb * ob.wordStride);
+            ob.lsp = OA.take<uint64_t>(nb * ob.wordStride);
+            ob.runs = OA.take<uint64_t>(nb * ob.runStride);
+            ob.stream = OA.take<uint64_t>(nb * ob.streamStride);
+            ob.planeBits = OA.take<uint64_t>(nb * ob.planeStride);
+            ob.pos = OA.take<uint32_t>(nb * ob.kStride);
+            ob.sgn = OA.take<uint8_t>(nb * ob.kStride);
+            if (!ob.oc || !ob.lip || !ob.lsp || !ob.runs || !ob.stream || !ob.planeBits || !ob.pos || !ob.sgn)
+              return -1;
+            HIP_CHECK(hipMemcpyAsync(ob.oc, hoc.data(), nb * sizeof(OutlierChunk), hipMemcpyHostToDevice, so));
+            HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 16, so));   // lip + lsp
+            if (launch_speck1d_decode(so, ob, d_src))
+              return -1;
+            HIP_CHECK(hipEventRecord(E.evOutl, so));
+          }
+
+        }
         HIP_CHECK(hipMemcpyAsync(bb.geom, S.hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, ss));
         HIP_CHECK(hipMemcpyAsync(bb.chunkOff, S.ho.data(), nb * 8, hipMemcpyHostToDevice, ss));
         HIP_CHECK(hipMemcpyAsync(bb.chunkLen, S.hl.data(), nb * 8, hipMemcpyHostToDevice, ss));
@@ -2223,9 +2296,6 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters --
         // unless outlier correctors have to be added to the transformed values first
         // (src/SPECK_FLT.cpp:573-590), in which case every pass stays in the chunk buffer
-        bool batchOutliers = false;
-        for (uint32_t i = 0; i < nb; i++)
-          batchOutliers |= outHead[g.second[first + i].gid].has;
         const bool fxy = fuse_xy(*P) && !batchOutliers;
         // a level of the inverse transform is 3 passes (z y x) of a dyadic chunk, 2 (y x) of a slice
         const size_t perLevel = slice ? 2 : 3;
@@ -2264,56 +2334,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         if (fxy && launch_lift_xy(ss, false, bb.vals, bb.valsStride, nb, cd, d.cst,
                                   std::is_same<T, float>::value ? 1 : 2, d_dst, vd, bb.geom))
           return -1;
-        if (batchOutliers) {
-          std::vector<OutlierChunk> hoc(nb);
-          memset(hoc.data(), 0, nb * sizeof(OutlierChunk));
-          uint64_t maxBits = 0;
-          int maxNbp = 1;
-          for (uint32_t i = 0; i < nb; i++) {
-            const OutHead& oh = outHead[g.second[first + i].gid];
-            if (!oh.has)
-              continue;
-            hoc[i].has = 1;
-            hoc[i].streamOff = oh.off;
-            hoc[i].total_bits = oh.total_bits;
-            hoc[i].nbp = oh.nbp;
-            if (oh.nbp > kMaxPlanes)
-              return -1;
-            maxBits = std::max(maxBits, oh.total_bits);
-            maxNbp = std::max(maxNbp, oh.nbp);
-          }
-          OutlierBufs ob;
-          memset(&ob, 0, sizeof(ob));
-          ob.nchunks = nb;
-          ob.N = P->N;
-          ob.nw = (P->N + 63) / 64;
-          ob.wordStride = round_up((size_t)ob.nw + 2, 32);
-          // every value found costs at least its sign bit, every run kept on a list its test bit
-          ob.kStride = round_up((size_t)std::min<uint64_t>(P->N, maxBits) + 1, 64);
-          speck1d_level_offsets(ob, P->N, std::min<uint64_t>(maxBits + 2, 2ull * P->N));
-          ob.streamStride = (size_t)(maxBits / 64) + 4;
-          ob.planeStride = (size_t)maxNbp * ob.wordStride;
-          const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) +
-                               (size_t)nb * (ob.wordStride * 16 + ob.kStride * 5 + ob.runStride * 8 +
-                                             ob.streamStride * 8 + ob.planeStride * 8) + 8192;
-          if (E.outlVar.ensure(bytes))
-            return -1;
-          Arena OA;
-          OA.base = static_cast<char*>(E.outlVar.p);
-          OA.cap = E.outlVar.n;
-          ob.oc = OA.take<OutlierChunk>(nb);
-          ob.lip = OA.take<uint64_t>(nb * ob.wordStride);
-          ob.lsp = OA.take<uint64_t>(nb * ob.wordStride);
-          ob.runs = OA.take<uint64_t>(nb * ob.runStride);
-          ob.stream = OA.take<uint64_t>(nb * ob.streamStride);
-          ob.planeBits = OA.take<uint64_t>(nb * ob.planeStride);
-          ob.pos = OA.take<uint32_t>(nb * ob.kStride);
-          ob.sgn = OA.take<uint8_t>(nb * ob.kStride);
-          if (!ob.oc || !ob.lip || !ob.lsp || !ob.runs || !ob.stream || !ob.planeBits || !ob.pos || !ob.sgn)
-            return -1;
-          HIP_CHECK(hipMemcpyAsync(ob.oc, hoc.data(), nb * sizeof(OutlierChunk), hipMemcpyHostToDevice, ss));
-          HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 16, ss));   // lip + lsp
-          if (launch_speck1d_decode(ss, ob, d_src, d.cst, bb.vals, bb.valsStride))
+        if (batchOutliers) {   // the correctors of the values the 1D decoder found meanwhile
+          HIP_CHECK(hipStreamWaitEvent(ss, E.evOutl, 0));
+          if (launch_outlier_apply(ss, ob, d.cst, bb.vals, bb.valsStride))
             return -1;
           HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, ss));
           HIP_CHECK(hipStreamSynchronize(ss));

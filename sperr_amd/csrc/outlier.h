@@ -47,7 +47,6 @@ struct OutlierBufs {
   uint8_t* msb;                  // encoder: msb of every magnitude
   uint32_t* posGE;               // encoder, per plane: positions / signs of the outliers at or
   uint8_t* sgnGE;                //   above the threshold, in order
-  uint32_t singleMax;            // decoder: runs up to this length are tried as single-outlier paths
   uint32_t nlists;               // LIS levels (src/SPECK1D_INT.cpp:19-34)
   uint32_t levelOff[kO1MaxLevels + 1];   // first entry of each level inside a chunk's list storage
   size_t runStride;
@@ -71,10 +70,13 @@ int launch_speck1d_encode(hipStream_t st, const OutlierBufs& b);
 int launch_outlier_stream_out(hipStream_t st, const OutlierBufs& b, const uint32_t* gids,
                               uint8_t* slots, const uint64_t* slotOff, uint64_t* lens2);
 
-// decoder: loads the streams (oc[c].has / streamOff / nbp / total_bits set by the host), decodes
-// them and adds the correctors to vals (tolerance q / 1.5, src/SPECK_FLT.cpp:578)
-int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b, const uint8_t* container,
-                          const CoderState* cst, double* vals, size_t valsStride);
+// decoder: loads the streams (oc[c].has / streamOff / nbp / total_bits set by the host) and decodes
+// them: positions, planes and signs of the values found (pos, sgn, planeBits; oc[c].found).  Needs
+// nothing but the container, so it can run beside the chunks' SPECK3D decoder on another stream
+int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b, const uint8_t* container);
+// adds the correctors of the values found to vals (tolerance q / 1.5, src/SPECK_FLT.cpp:578)
+int launch_outlier_apply(hipStream_t st, const OutlierBufs& b, const CoderState* cst, double* vals,
+                         size_t valsStride);
 
 }  // namespace sperrhip
 #endif

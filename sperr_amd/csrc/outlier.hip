@@ -154,6 +154,17 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l)
 {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
+// inclusive prefix sum over the wavefront with DPP moves (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return v;
+}
 __device__ __forceinline__ void wrlane(uint32_t& v, uint32_t l, uint32_t val)
 {
   v = threadIdx.x == l ? val : v;   // (val and l are wave-uniform)
@@ -161,7 +172,7 @@ __device__ __forceinline__ void wrlane(uint32_t& v, uint32_t l, uint32_t val)
 
 template <bool ENC>
 __global__ void __launch_bounds__(64)
-k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
+k_speck1d(OutlierBufs b)
 {
   const uint32_t c = blockIdx.x;
   OutlierChunk& oc = b.oc[c];
@@ -229,29 +240,23 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
       flush_acc();
     wpos += n;
   };
-  // ---- bit reader (decoder)
-  uint64_t rpos = 0, w0 = 0, w1 = 0, cw = 1ull << 62;   // (cw: index of the word held in w0; none yet)
-  auto window = [&]() -> uint64_t {
+  // ---- bit reader (decoder): 64 words of the stream sit in a register pair, lane = word, so that
+  //      the serial parse waits for memory once per 4032 bits instead of once per word
+  uint64_t rpos = 0, vW = 0, cBase = 1ull << 62;   // (cBase: index of the word in lane 0; none yet)
+  auto window = [&]() -> uint64_t {   // the next 64 bits from rpos on
     const uint64_t wi = rpos >> 6;
-    if (wi != cw) {
-      w0 = (wi == cw + 1) ? w1 : rfl64(words[wi]);
-      w1 = rfl64(words[wi + 1]);
-      cw = wi;
+    if (wi - cBase >= 63u) {
+      cBase = wi;
+      vW = wi + lane < b.streamStride ? words[wi + lane] : 0ull;
     }
+    const uint32_t k = (uint32_t)(wi - cBase);
+    const uint64_t w0 = (uint64_t)rdlane((uint32_t)vW, k) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k) << 32);
+    const uint64_t w1 = (uint64_t)rdlane((uint32_t)vW, k + 1u) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k + 1u) << 32);
     const uint32_t sh = (uint32_t)(rpos & 63);
     return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
   };
-  // (bbuf: the next bn bits from rpos on; whoever moves rpos otherwise resets bn)
-  uint64_t bbuf = 0;
-  uint32_t bn = 0;
   auto get = [&]() -> uint32_t {
-    if (bn == 0) {
-      bbuf = window();
-      bn = 64;
-    }
-    const uint32_t bit = (uint32_t)(bbuf & 1ull);
-    bbuf >>= 1;
-    bn--;
+    const uint32_t bit = (uint32_t)(window() & 1ull);
     rpos++;
     return bit;
   };
@@ -461,78 +466,121 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     nfound++;
   };
   int curPlane = 0;
-  // Most significant runs hold a single outlier.  Their code is a plain path: one bit per level
-  // ('1' = it lies in the left half, whose right sibling then gets a closing '0' on the way back;
-  // '0' = in the right half, the left sibling is born at once), the sign, then the closing zeros.
-  // single_path() reads that shape off the next 64 stream bits: if the closing bits are all zero
-  // the parse is what the general walk would have done, and the siblings -- exactly one per level,
-  // so their mutual order does not matter -- are appended by the lanes that keep their levels'
-  // lists, all at once.  Anything else is left to the general walk.
-  uint32_t vSibS = 0, vSibL = 0;
-  const uint32_t kSingleMax = b.singleMax;
-  auto single_path = [&](uint32_t ns, uint32_t nl, uint32_t nlev) -> bool {
-    const uint64_t peek = window();
-    uint32_t t = 0, lefts = 0, s0 = ns, l0 = nl, lv = nlev, pixel = 0;
-    for (;;) {
-      if (t >= 40 || lv + 1 >= 64)
-        return false;
-      const uint32_t bit = (uint32_t)(peek >> t) & 1u;
-      t++;
-      const uint32_t h0 = l0 - l0 / 2, r0 = l0 / 2;
-      lv++;
-      if (bit) {
-        wrlane(vSibS, lv, s0 + h0);
-        wrlane(vSibL, lv, r0);
-        lefts++;
-        if (h0 == 1) {
-          pixel = s0;
-          break;
-        }
-        l0 = h0;
-      }
-      else {
-        wrlane(vSibS, lv, s0);
-        wrlane(vSibL, lv, h0);
-        if (r0 == 1) {
-          pixel = s0 + h0;
-          break;
-        }
-        s0 += h0;
-        l0 = r0;
-      }
-    }
-    const uint32_t sg = (uint32_t)(peek >> t) & 1u;
-    t++;
-    if (t + lefts > 64 || ((peek >> t) & low_mask(lefts)) != 0)
-      return false;
-    // commit
-    rpos += t + lefts;
-    bn = 0;
-    if (nfound < b.kStride && lane == 0) {
-      fpos[nfound] = pixel;
-      fmeta[nfound] = (uint8_t)((uint32_t)curPlane | (sg << 7));
-    }
-    nfound++;
-    if (lane > nlev && lane <= lv) {   // the sibling born on level `lane`
-      if (vSibL == 1)
-        atomicOr(reinterpret_cast<unsigned long long*>(lip) + (vSibS >> 6), 1ull << (vSibS & 63u));
+  // The code below a significant run is a sequence of PATHS: from a run, one bit per level ('1':
+  // go into the left half and park the right one, '0': the left half is born insignificant and the
+  // right one is significant without a bit) down to a single value and its sign; then one closing
+  // bit per parked half, innermost first: '0' hands it to its list (or the LIP), '1' starts the next
+  // path there (a parked single value: its sign follows).  A whole path is parsed by the wave at
+  // once, lane = list level of the halves born at a step: the length of the run at step t follows
+  // from the first t bits (the interval at depth t that the complemented bits, reversed, index:
+  // (L >> t) + (rev < L mod 2^t)), its start from a prefix sum; the lanes of the halves that are
+  // born append them to their own level's list, the parked ones stay in their lanes (vPS, vPL and
+  // the mask `parked`: levels grow inwards, so the innermost parked half is the highest bit).
+  uint32_t vPS = 0, vPL = 0;
+  uint64_t parked = 0;
+  auto commit_born = [&](bool mine, uint32_t bs, uint32_t bl) {   // lane = level of the half
+    if (mine) {
+      if (bl == 1)
+        atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
       else if (vOff + vCnt < vEnd) {
-        runs[vOff + vCnt] = (uint64_t)vSibS | ((uint64_t)vSibL << 32);
+        runs[vOff + vCnt] = (uint64_t)bs | ((uint64_t)bl << 32);
         vCnt++;
       }
       else
-        vErr = 2;
+        vErr = 2;   // list storage exhausted (cannot happen with the host's bounds)
     }
-    return true;
   };
-  auto expand_dec = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {
+  auto record_found = [&](uint32_t idx, uint32_t sg) {
+    if (nfound < b.kStride && lane == 0) {
+      fpos[nfound] = idx;
+      fmeta[nfound] = (uint8_t)((uint32_t)curPlane | (sg << 7));
+    }
+    nfound++;
+  };
+  auto expand_dec = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {   // a run of at least two values
+    parked = 0;
+    for (;;) {
+      // ---- one path, from the run (ns, nl) of level nlev down to a value
+      const uint64_t peek = window();
+      const uint32_t t = lane - (nlev + 1u);            // this lane: the halves born at step t, level nlev + 1 + t
+      const bool inr = lane > nlev && t < 32u;
+      const uint32_t mk = inr ? (1u << t) - 1u : 0u;
+      const uint32_t lt = inr ? (nl >> t) + (((~(uint32_t)peek & mk) < (nl & mk)) ? 1u : 0u) : 0u;
+      const uint32_t bt = inr ? (uint32_t)(peek >> t) & 1u : 0u;
+      const uint32_t h0 = lt - lt / 2, r0 = lt / 2;
+      const uint64_t tm = __ballot(inr && lt > 1 && (bt ? h0 : r0) == 1u);
+      if (tm == 0) {   // (cannot happen: a run of two or more values ends within 32 steps)
+        err = 2;
+        return;
+      }
+      const uint32_t LT = (uint32_t)__ffsll((long long)tm) - 1u;
+      const bool onPath = inr && lane <= LT;
+      const uint32_t add = (onPath && !bt) ? h0 : 0u;
+      const uint32_t st = ns + wave_scan_dpp(add) - add;
+      const uint32_t steps = LT - nlev;                // bits of the path
+      const uint32_t sg = (uint32_t)(peek >> steps) & 1u;
+      record_found(rdlane(bt ? st : st + h0, LT), sg);
+      rpos += steps + 1u;
+      // (left halves are born insignificant: appended together with the parked halves that close first)
+      bool pend = onPath && !bt;
+      uint32_t pS = st, pL = h0;
+      if (onPath && bt) {                              // right halves wait for their bit
+        vPS = st + h0;
+        vPL = r0;
+      }
+      parked |= __ballot(onPath && bt);
+      // ---- closing bits (the first ones still are in `peek` unless the path was long)
+      bool next = false, first = true;
+      while (parked) {
+        const uint32_t cnt = (uint32_t)__popcll(parked);
+        const uint64_t w = (first && steps + 1u + cnt < 64u) ? peek >> (steps + 1u) : window();
+        first = false;
+        const uint32_t z = min(w ? (uint32_t)__ffsll((long long)w) - 1u : 64u, cnt);
+        if (z) {   // the z innermost parked halves are born insignificant
+          const bool isP = ((parked >> lane) & 1ull) != 0;
+          const uint32_t above = (uint32_t)__popcll((parked >> lane) >> 1);
+          const bool close = isP && above < z;
+          pS = close ? vPS : pS;
+          pL = close ? vPL : pL;
+          pend = pend || close;
+          parked &= ~__ballot(close);
+          rpos += z;
+        }
+        if (__ballot(pend)) {
+          commit_born(pend, pS, pL);
+          pend = false;
+        }
+        if (z == cnt)
+          break;
+        rpos++;   // (a '1': z < cnt <= 64, so the bit is inside the window)
+        const uint32_t top = 63u - (uint32_t)__clzll((long long)parked);
+        parked &= ~(1ull << top);
+        const uint32_t rs = rdlane(vPS, top), rl = rdlane(vPL, top);
+        if (rl == 1) {
+          record_found(rs, get());
+          continue;
+        }
+        ns = rs;
+        nl = rl;
+        nlev = top;
+        next = true;
+        break;
+      }
+      if (__ballot(pend))
+        commit_born(pend, pS, pL);
+      if (!next)
+        return;
+    }
+  };
+
+  // (runs of a single value on a list -- arrays of fewer than four values -- keep the serial walk: a
+  //  descent with a stack of the right halves that still wait for their test bit)
+  auto expand_serial = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {
     uint32_t sp = 0;
     while (true) {
       const uint32_t h0 = nl - nl / 2, r0 = nl / 2;
       bool atPixel = false;
-      if (nl <= kSingleMax && single_path(ns, nl, nlev))   // (longer runs rarely hold just one outlier)
-        atPixel = true;
-      else if (get()) {
+      if (get()) {
         wrlane(vS, sp, ns + h0);
         wrlane(vL, sp, r0);
         wrlane(vT, sp, nlev + 1);
@@ -755,7 +803,6 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
               skip_zeros(z);
             else
               rpos += z;
-              bn = 0;
             i += z;
           }
           if (i >= blockN)
@@ -767,8 +814,13 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
             put(1);
           else {
             rpos++;
-            bn = 0;
-            expand_dec(rdlane((uint32_t)myRun, i), rdlane((uint32_t)(myRun >> 32), i), lev);
+            {
+              const uint32_t es = rdlane((uint32_t)myRun, i), el = rdlane((uint32_t)(myRun >> 32), i);
+              if (el >= 2)
+                expand_dec(es, el, lev);
+              else
+                expand_serial(es, el, lev);
+            }
             i++;
             continue;
           }
@@ -914,7 +966,6 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
           pb[w] = res;
         }
         rpos += rdlane(inc, 63);
-        bn = 0;
       }
       // the values found in this plane join the LSP (SPECK_INT.cpp:462-468)
       __threadfence_block();
@@ -946,23 +997,34 @@ k_speck1d(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
     }
     if (lane == 0)
       oc.found = nfound;
-    __threadfence_block();
-    // correctors (src/Outlier_Coder.cpp:199-233): 1.1 tol for magnitude 1, (m - 0.25) tol above
-    const double tol = cst[c].q / 1.5;
-    double* out = vals + c * valsStride;
-    for (uint32_t kb = 0; kb < nfound; kb += 64) {
-      const uint32_t k = kb + lane;
-      if (k >= nfound)
-        break;
-      const uint32_t x = fpos[k], meta = fmeta[k];
-      const int pl = (int)(meta & 0x7f);
-      unsigned long long m = 1ull << pl;
-      for (int q = 0; q < pl; q++)
-        m |= ((planeBits[(size_t)q * b.wordStride + (x >> 6)] >> (x & 63u)) & 1ull) << q;
-      double e = m == 1 ? 1.1 : (double)m - 0.25;
-      e *= tol * ((meta >> 7) ? 1.0 : -1.0);
-      out[x] += e;
-    }
+  }
+}
+
+// The correctors of the values the 1D decoder found (src/Outlier_Coder.cpp:199-233): 1.1 tol for
+// magnitude 1, (m - 0.25) tol above.  A kernel of its own: the decoder needs nothing but the outlier
+// stream, so it runs beside the chunk's SPECK3D decoder and the inverse transform on another stream.
+__global__ void __launch_bounds__(kThreads)
+k_outlier_apply(OutlierBufs b, const CoderState* cst, double* vals, size_t valsStride)
+{
+  const uint32_t c = blockIdx.y;
+  const OutlierChunk& oc = b.oc[c];
+  if (!oc.has || oc.nbp == 0 || oc.error)
+    return;
+  const uint32_t nfound = oc.found;
+  const uint32_t* fpos = b.pos + c * b.kStride;
+  const uint8_t* fmeta = b.sgn + c * b.kStride;
+  const uint64_t* planeBits = b.planeBits + c * b.planeStride;
+  const double tol = cst[c].q / 1.5;
+  double* out = vals + c * valsStride;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nfound; k += gridDim.x * blockDim.x) {
+    const uint32_t x = fpos[k], meta = fmeta[k];
+    const int pl = (int)(meta & 0x7f);
+    unsigned long long m = 1ull << pl;
+    for (int q = 0; q < pl; q++)
+      m |= ((planeBits[(size_t)q * b.wordStride + (x >> 6)] >> (x & 63u)) & 1ull) << q;
+    double e = m == 1 ? 1.1 : (double)m - 0.25;
+    e *= tol * ((meta >> 7) ? 1.0 : -1.0);
+    out[x] += e;
   }
 }
 
@@ -1053,8 +1115,7 @@ int launch_outlier_prefix(hipStream_t st, const OutlierBufs& b)
 
 int launch_speck1d_encode(hipStream_t st, const OutlierBufs& b)
 {
-  LAUNCH_K(k_speck1d<true>, dim3(b.nchunks), dim3(64), 0, st, b, (const CoderState*)nullptr,
-           (double*)nullptr, (size_t)0);
+  LAUNCH_K(k_speck1d<true>, dim3(b.nchunks), dim3(64), 0, st, b);
   HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1070,16 +1131,22 @@ int launch_outlier_stream_out(hipStream_t st, const OutlierBufs& b, const uint32
   return 0;
 }
 
-int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b_, const uint8_t* container,
-                          const CoderState* cst, double* vals, size_t valsStride)
+int launch_speck1d_decode(hipStream_t st, const OutlierBufs& b, const uint8_t* container)
 {
-  OutlierBufs b = b_;
-  static const uint32_t singleMax = getenv("SPERR_HIP_SINGLE_MAX") ? (uint32_t)atoi(getenv("SPERR_HIP_SINGLE_MAX")) : 64u;
-  b.singleMax = singleMax;
   const uint32_t blocks =
       capped_blocks((uint32_t)((b.streamStride + kThreads - 1) / kThreads), b.nchunks);
   LAUNCH_K(k_outlier_stream_in, dim3(blocks, b.nchunks), dim3(kThreads), 0, st, b, container);
-  LAUNCH_K(k_speck1d<false>, dim3(b.nchunks), dim3(64), 0, st, b, cst, vals, valsStride);
+  LAUNCH_K(k_speck1d<false>, dim3(b.nchunks), dim3(64), 0, st, b);
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_outlier_apply(hipStream_t st, const OutlierBufs& b, const CoderState* cst, double* vals,
+                         size_t valsStride)
+{
+  const uint32_t blocks = capped_blocks((uint32_t)((b.kStride + kThreads - 1) / kThreads), b.nchunks);
+  LAUNCH_K(k_outlier_apply, dim3(std::max(1u, std::min(blocks, 256u)), b.nchunks), dim3(kThreads), 0, st, b, cst,
+           vals, valsStride);
   HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -2370,7 +2370,8 @@ struct MixCtx {
   uint8_t pad;
 };
 
-template <typename CT>
+// kStamps: the build with the tick counters (sperrhip_debug_lis_stamps); the production build carries none
+template <bool kStamps>
 __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.x;
@@ -2475,7 +2476,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   __syncthreads();
   uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t stamp_t = 0;
-  const bool stamps = b.lisStamps != nullptr && tid == 0;
+  const bool stamps = kStamps && b.lisStamps != nullptr && tid == 0;
+  const bool wstamps = kStamps && b.lisStamps != nullptr;   // (wave-uniform: the walker's own counters)
 #define STAMP(i)                                        \
   if (stamps) {                                         \
     const uint64_t now_ = __builtin_readcyclecounter(); \
@@ -2484,8 +2486,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   }
   if (stamps)
     stamp_t = __builtin_readcyclecounter();
-  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0, cnt_tight = 0, cnt_words = 0, cnt_walks = 0;
-  uint64_t tick_tight = 0, tick_enter = 0, tick_round = 0, tick_rec = 0;
+  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0, cnt_tight = 0, cnt_words = 0, cnt_walks = 0, cnt_rounds = 0;
+  uint64_t tick_tight = 0, tick_enter = 0, tick_round = 0;
 
   auto bit_at = [&](uint32_t r) -> uint32_t {
     const uint32_t q = r + wq0;
@@ -2817,6 +2819,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
                    ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMixCols + grp * 4u)
                    : ~0ull;
       };
+      uint64_t tSet0 = (wstamps && depth >= 2) ? __builtin_readcyclecounter() : 0;   // (time inside the sets walked into)
       uint32_t eb = 0x80000000u;     // lane = list entry eb + lane: its ecls word (nothing loaded yet: no
                                      //   entry index is within 64 of this value)
       uint32_t ecv = 0;
@@ -2856,7 +2859,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             const uint32_t eEnd = e + rem;
             uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
             bool unusual = false;
-            const uint64_t tt0 = stamps ? __builtin_readcyclecounter() : 0;
+            const uint64_t tt0 = wstamps ? __builtin_readcyclecounter() : 0;
             while (true) {
               cnt_words++;
               if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
@@ -2920,7 +2923,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             }
             r = kk * 64u + oo - wq0;
             rem = eEnd - e;
-            if (stamps)
+            if (wstamps)
               tick_tight += __builtin_readcyclecounter() - tt0;
             if (!unusual)
               continue;
@@ -2968,7 +2971,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           }
           else {   // walk into it
             cnt_push++;
-            const uint64_t te0 = stamps ? __builtin_readcyclecounter() : 0;
+            const uint64_t te0 = wstamps ? __builtin_readcyclecounter() : 0;
             const uint64_t packed = list[e];
             if (lane == 0)
               atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
@@ -2984,14 +2987,15 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
             }
             depth = 2;
             r += 1;
-            if (stamps)
-              tick_enter += __builtin_readcyclecounter() - te0;
+            if (wstamps) {
+              tSet0 = __builtin_readcyclecounter();
+              tick_enter += tSet0 - te0;
+            }
           }
           e++;
           rem--;
           continue;
         }
-        const uint64_t tr0 = stamps ? __builtin_readcyclecounter() : 0;
         // ---- a set that is being walked into: its children from `next` on, one look-up each;
         //      lane k remembers what became of child k and writes its record afterwards
         MixCtx& cx = sh_ctx[depth - 1];
@@ -3068,7 +3072,6 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           break;
         }
         // the records of the children handled in this round
-        const uint64_t tr1 = stamps ? __builtin_readcyclecounter() : 0;
         {
           const uint64_t rel = a + myY - phase0;
           const bool bornOk = myAct == 1 && sh_levelSlot[kb.kidlev] != 0xff && rel < maskBits;
@@ -3112,20 +3115,19 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           }
           depth++;
         }
-        else if (halted) {
-          if (stamps) {
-            tick_round += tr1 - tr0;
-            tick_rec += __builtin_readcyclecounter() - tr1;
-          }
+        else if (halted)
           break;
-        }
-        else
+        else {
           depth--;
-        if (stamps) {
-          tick_round += tr1 - tr0;
-          tick_rec += __builtin_readcyclecounter() - tr1;
+          cnt_rounds++;
+          if (wstamps && depth == 1) {
+            tick_round += __builtin_readcyclecounter() - tSet0;
+            tSet0 = 0;
+          }
         }
       }
+      if (wstamps && tSet0)   // (stopped inside a set)
+        tick_round += __builtin_readcyclecounter() - tSet0;
       flush();
       // (a window that changes nothing would be walked for ever: cannot happen while the window is
       // longer than every split that has a column, which the host checks -- kept as a guard)
@@ -3395,7 +3397,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       const uint32_t eNow = sh_e;
       const uint32_t ringTo = min(n, eNow + 2u * W), ringFrom = min(max(ringHi, eNow), ringTo);
       __syncthreads();
-      const uint64_t hphase0 = b.lisStamps != nullptr ? __builtin_readcyclecounter() : 0;
+      const uint64_t hphase0 = wstamps ? __builtin_readcyclecounter() : 0;
       if (tid < 64) {
         set_view(curB, aCur);
         walk(curB, r0, S, r0 == 0, ringHi);
@@ -3403,7 +3405,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       }
       else if (isHelper) {
         const uint32_t t0 = helperRank * 64u + lane, NT = nHelpers * 64u;
-        const bool hst = b.lisStamps != nullptr && t0 == 0;
+        const bool hst = wstamps && t0 == 0;
         uint64_t h0 = hst ? __builtin_readcyclecounter() : 0;
         if (pend >= 0) {
           set_view((uint32_t)pend, aPend);
@@ -3424,11 +3426,11 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
         build_rows(t0, NT, true);
         if (hst)
           hstamp[2] += __builtin_readcyclecounter() - h0;
-        if (b.lisStamps != nullptr && lane == 0)
+        if (wstamps && lane == 0)
           myWork += __builtin_readcyclecounter() - hphase0;
       }
       __syncthreads();
-      if (b.lisStamps != nullptr && isHelper && helperRank == 0 && lane == 0)
+      if (wstamps && isHelper && helperRank == 0 && lane == 0)
         hstamp[3] += __builtin_readcyclecounter() - hphase0;
       if (sh_depth < 0) {
         if (tid == 0) {
@@ -3522,11 +3524,11 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     out[30] += tick_tight;
     out[31] += tick_enter;
     out[40] += tick_round;
-    out[41] += tick_rec;
+    out[41] += cnt_rounds;
   }
-  if (b.lisStamps != nullptr && isHelper && lane == 0)
+  if (wstamps && isHelper && lane == 0)
     b.lisStamps[(size_t)c * 64 + 32 + helperRank] += myWork;
-  if (b.lisStamps != nullptr && isHelper && helperRank == 0 && lane == 0) {
+  if (wstamps && isHelper && helperRank == 0 && lane == 0) {
     uint64_t* out = b.lisStamps + (size_t)c * 64;
     out[25] += hstamp[0];
     out[26] += hstamp[1];
@@ -5107,8 +5109,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 160u;
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
   if (plan.mixed) {
-    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<uint32_t>), (int)b.mixSmemBytes) ||
-        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<uint64_t>), (int)b.mixSmemBytes))
+    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<false>), (int)b.mixSmemBytes) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<true>), (int)b.mixSmemBytes))
       return -1;
   }
   if (plan.tables && plan.hi) {
@@ -5144,7 +5146,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else if (plan.mixed) {
-        LAUNCH_K(k_lis_mixed<uint64_t>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
+        if (b.lisStamps)
+          LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
+        else
+          LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -5179,7 +5184,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
       }
       else if (plan.mixed) {
-        LAUNCH_K(k_lis_mixed<uint32_t>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
+        if (b.lisStamps)
+          LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
+        else
+          LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
         if (b.nSlots) {
           LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
           LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);

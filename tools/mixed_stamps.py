@@ -38,7 +38,7 @@ if out[28]:
           (out[28], out[25] // w, out[26] // w, out[27] // w, out[29] // w))
 print("helper wavefronts, ticks of work per window:", [out[32 + i] // w for i in range(8)])
 print("walk: %d of the significant list entries in the per-word loop, %d words, %d ticks there" % (out[23], out[24], out[30]))
-print("walk: ticks entering list entries %d, child rounds %d, their records and pushes %d" % (out[31], out[40], out[41]))
+print("walk: ticks entering list entries %d, inside the sets walked into %d (%d sets finished)" % (out[31], out[40], out[41]))
 print("walk: %d significant list entries, %d child steps in %d entered sets, %d zero runs; %d skip rounds; %d expanded items"
       % (out[16], out[17], out[18], out[19], out[21], out[22]))
 if out[16] + out[17]:
