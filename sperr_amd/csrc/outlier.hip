@@ -290,167 +290,85 @@ k_speck1d(OutlierBufs b)
     }
   };
 
-  // ---- encoder: the whole expansion of a significant run that holds at most 64 outliers, by the
-  //      wave at once.  Lane i is the run's i-th outlier (all of them have their msb on this
-  //      plane).  Depth by depth the lanes follow their outlier down the halving tree; the lanes of
-  //      one node are contiguous, its first lane leads it.  Then, bottom-up, the bits every node's
-  //      expansion takes (E); top-down, where each expansion starts; the leaders set their node's
-  //      test bits and sign bits in an LDS bit buffer and hand the runs / pixels born
-  //      insignificant to the lists / the LIP in lane order, which is stream order.
-  constexpr int kWT = kO1MaxLevels + 2;
-  constexpr int kWTWords = 128;
-  __shared__ uint32_t wtL[ENC ? kWT : 1][64], wtS[ENC ? kWT : 1][64], wtO[ENC ? kWT : 1][64];
-  __shared__ uint16_t wtE[ENC ? kWT : 1][64];
-  __shared__ unsigned long long wtSide[ENC ? kWT : 1], wtLead[ENC ? kWT : 1];
-  __shared__ unsigned long long wtBits[ENC ? kWTWords : 1];
-  auto wave_tree = [&](uint32_t ns, uint32_t nl, uint32_t nlev, uint32_t a, uint32_t e) -> bool {
-    const uint32_t cnt = e - a;
-    const bool mine = lane < cnt;
-    const uint32_t pos = mine ? posGE[a + lane] : 0xffffffffu;
-    const uint32_t sgn = mine ? (uint32_t)sgnGE[a + lane] : 0u;
-    const uint64_t validMask = low_mask(cnt);
-    const uint64_t sgnMask = __ballot(sgn != 0);
-    // ---- structure, top-down
-    uint32_t S = ns, L = nl;
-    uint64_t lead = 1ull;
-    uint32_t D = 0;
-    for (;; D++) {
-      if (D >= (uint32_t)kWT)
-        return false;
-      wtS[D][lane] = S;
-      wtL[D][lane] = L;
-      const uint64_t alive = __ballot(mine && L > 1);
-      const uint32_t h0 = L - L / 2;
-      const bool side = mine && L > 1 && pos >= S + h0;
-      const uint64_t sideMask = __ballot(side);
-      if (lane == 0) {
-        wtLead[D] = lead;
-        wtSide[D] = sideMask;
-      }
-      if (alive == 0)
-        break;
-      lead |= sideMask & ~(sideMask << 1) & ~lead;
-      if (L > 1) {
-        if (side) {
-          S += h0;
-          L = L / 2;
-        }
-        else
-          L = h0;
-      }
-    }
-    __syncthreads();
-    // group of the node this lane leads at depth d
-    auto group = [&](uint32_t d, uint32_t& nLeft, uint32_t& nRight) -> bool {
-      const uint64_t lm = wtLead[d];
-      if (!mine || !((lm >> lane) & 1ull) || wtL[d][lane] <= 1)
-        return false;
-      const uint64_t above = lm & validMask & ~low_mask(lane + 1);
-      const uint32_t ge = above ? (uint32_t)__ffsll((long long)above) - 1u : cnt;
-      const uint64_t gm = low_mask(ge) & ~low_mask(lane);
-      nRight = (uint32_t)__popcll(wtSide[d] & gm);
-      nLeft = ge - lane - nRight;
-      return true;
-    };
-    // ---- expansion sizes, bottom-up
-    for (uint32_t d = D; d-- > 0;) {
-      uint32_t nLeft = 0, nRight = 0;
-      if (group(d, nLeft, nRight)) {
-        const uint32_t Ln = wtL[d][lane], h0 = Ln - Ln / 2, r0 = Ln / 2;
-        const uint32_t size0 = nLeft ? (h0 == 1 ? 1u : (uint32_t)wtE[d + 1][lane]) : 0u;
-        const uint32_t size1 = nRight ? (r0 == 1 ? 1u : (uint32_t)wtE[d + 1][lane + nLeft]) : 0u;
-        wtE[d][lane] = (uint16_t)(1u + size0 + (nLeft ? 1u : 0u) + size1);
-      }
-      __syncthreads();
-    }
-    const uint32_t total = wtE[0][0];
-    if (total + 64 > (uint32_t)kWTWords * 64)
-      return false;
-    for (uint32_t w = lane; w < (total + 63) / 64 + 1; w += 64)
-      wtBits[w] = 0ull;
-    if (lane == 0)
-      wtO[0][0] = 0;
-    __syncthreads();
-    auto setbit = [&](uint32_t x) { atomicOr(&wtBits[x >> 6], 1ull << (x & 63u)); };
-    // ---- offsets, bits and births, top-down
-    for (uint32_t d = 0; d < D; d++) {
-      uint32_t nLeft = 0, nRight = 0;
-      const bool leads = group(d, nLeft, nRight);
-      bool bornSet = false, bornPix = false;
-      uint32_t bs = 0, bl = 0;
-      if (leads) {
-        const uint32_t Ln = wtL[d][lane], Sn = wtS[d][lane], h0 = Ln - Ln / 2, r0 = Ln / 2;
-        const uint32_t O = wtO[d][lane];
-        uint32_t size0 = 0;
-        if (nLeft) {
-          setbit(O);
-          if (h0 == 1) {
-            size0 = 1;
-            if (sgn)
-              setbit(O + 1);
-          }
-          else {
-            size0 = wtE[d + 1][lane];
-            wtO[d + 1][lane] = O + 1;
-          }
-        }
-        else {   // the left half is born insignificant; the right one is significant by inference
-          bs = Sn;
-          bl = h0;
-          bornSet = h0 > 1;
-          bornPix = h0 == 1;
-        }
-        const uint32_t posB = O + 1 + size0;
-        const uint32_t c1 = posB + (nLeft ? 1u : 0u);
-        if (nRight) {
-          if (nLeft)
-            setbit(posB);
-          if (r0 == 1) {
-            if ((sgnMask >> (lane + nLeft)) & 1ull)
-              setbit(c1);
-          }
-          else
-            wtO[d + 1][lane + nLeft] = c1;
-        }
-        else {   // (coded, since the left half was significant) born insignificant
-          bs = Sn + h0;
-          bl = r0;
-          bornSet = r0 > 1;
-          bornPix = r0 == 1;
-        }
-      }
-      if (bornPix)
-        atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
-      const uint64_t bm = __ballot(bornSet);
-      if (bm) {
-        const uint32_t lvl = nlev + d + 1;
-        const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
-        const uint32_t nbn = (uint32_t)__popcll(bm);
-        if (lvl >= b.nlists || first + nbn > rdlane(vEnd, lvl))
-          err = 2;
-        else {
-          if (bornSet)
-            runs[first + (uint32_t)__popcll(bm & low_mask(lane))] = (uint64_t)bs | ((uint64_t)bl << 32);
-          wrlane(vCnt, lvl, have + nbn);
-        }
-      }
-      __syncthreads();
-    }
-    // ---- the bit buffer goes into the stream
+  // ---- encoder: the whole expansion of a significant run, 64 of its outliers at a time, lane =
+  //      outlier (all of them at or above this plane's threshold, ascending position).  The code
+  //      below a run is one PATH per outlier: the closing '1' of the parked right half it lies in
+  //      (not for the run's first outlier, whose run got its '1' from the list), one bit per level
+  //      from there down ('1': it lies in the left half and the right one is parked; '0': the left
+  //      half is born insignificant and the right one is significant without a bit), its sign, and a
+  //      '0' for every parked right half on its way that the next outlier does not lie in.  A node
+  //      that also holds the previous outlier was coded by an earlier path, so every lane finds its
+  //      own bits from its position and its two neighbours alone; all lanes walk down from the run
+  //      together, one level per round, and the halves born at that level -- at most one per lane,
+  //      in lane order, which is stream order -- are appended to the level's list at once.
+  auto expand_enc = [&](uint32_t ns, uint32_t nl, uint32_t nlev, uint32_t a, uint32_t e) {
     flush_acc();
-    for (uint32_t w = lane; w < (total + 63) / 64; w += 64) {
-      const uint64_t v = wtBits[w];
-      if (v) {
-        const uint64_t at = wpos + (uint64_t)w * 64;
-        const uint32_t sh = (uint32_t)(at & 63);
-        atomicOr(words + (at >> 6), (unsigned long long)(v << sh));
-        if (sh && (v >> (64 - sh)))
-          atomicOr(words + (at >> 6) + 1, (unsigned long long)(v >> (64 - sh)));
+    for (uint32_t k0 = a; k0 < e; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool mine = k < e;
+      const uint32_t x = mine ? posGE[k] : 0u;
+      const bool hasPrev = mine && k > a, hasNext = mine && k + 1 < e;
+      const uint32_t prev = hasPrev ? posGE[k - 1] : 0u;
+      const uint32_t next = hasNext ? posGE[k + 1] : 0u;
+      uint64_t code = hasPrev ? 1ull : 0ull;
+      uint32_t nbits = hasPrev ? 1u : 0u, nz = 0;
+      uint32_t s0 = ns, l0 = nl;
+      for (uint32_t d = 0;; d++) {
+        const bool act = mine && l0 > 1;
+        if (__ballot(act) == 0)
+          break;
+        const uint32_t lvl = nlev + d + 1;   // list level of the halves of this round's nodes
+        const uint32_t h0 = l0 - l0 / 2, r0 = l0 / 2;
+        const bool left = x < s0 + h0;
+        const bool owned = !(hasPrev && prev >= s0);          // no earlier outlier of the run in this node
+        const bool nextIn = hasNext && next < s0 + l0;         // the next outlier lies in this node
+        if (act && owned) {
+          code |= (uint64_t)(left ? 1u : 0u) << nbits;
+          nbits++;
+        }
+        const bool closes = act && left && !nextIn;            // the parked right half gets its '0' after this path
+        nz += closes ? 1u : 0u;
+        const bool born = (act && owned && !left) || closes;
+        const uint32_t bs = left ? s0 + h0 : s0, bl = left ? r0 : h0;
+        if (born && bl == 1)
+          atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
+        const uint64_t bm = __ballot(born && bl > 1);
+        if (bm) {
+          const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
+          const uint32_t nbn = (uint32_t)__popcll(bm);
+          if (lvl >= b.nlists || first + nbn > rdlane(vEnd, lvl))
+            err = 2;
+          else {
+            if (born && bl > 1)
+              runs[first + (uint32_t)__popcll(bm & low_mask(lane))] = (uint64_t)bs | ((uint64_t)bl << 32);
+            wrlane(vCnt, lvl, have + nbn);
+          }
+        }
+        if (act) {
+          if (left)
+            l0 = h0;
+          else {
+            s0 += h0;
+            l0 = r0;
+          }
+        }
       }
+      // sign, then the closing zeros
+      if (mine) {
+        code |= (uint64_t)sgnGE[k] << nbits;
+        nbits++;
+      }
+      const uint32_t len = mine ? nbits + nz : 0u;   // (at most 1 + 31 + 1 + 31 bits)
+      const uint32_t inc = wave_scan_dpp(len);
+      if (mine && code) {
+        const uint64_t at = wpos + (inc - len);
+        const uint32_t sh = (uint32_t)(at & 63);
+        atomicOr(words + (at >> 6), (unsigned long long)(code << sh));
+        if (sh && (code >> (64 - sh)))
+          atomicOr(words + (at >> 6) + 1, (unsigned long long)(code >> (64 - sh)));
+      }
+      wpos += rdlane(inc, 63);
     }
-    wpos += total;
-    __syncthreads();
-    return true;
   };
 
   // ---- decoder: the recursion below one significant run (m_code_S), written as a descent with a
@@ -658,12 +576,22 @@ k_speck1d(OutlierBufs b)
       }
       __threadfence_block();
       uint32_t run = 0;
-      for (uint32_t wb = 0; wb < nw; wb += 64) {
-        const uint32_t w = wb + lane;
-        const uint32_t cntw = w < nw ? (uint32_t)__popcll(maskGE[w]) : 0u;
-        const uint32_t inc = wave_inclusive_scan<uint32_t>(cntw);
-        if (w < nw)
-          cpos[w] = run + inc - cntw;
+      for (uint32_t wb = 0; wb < nw; wb += 512) {   // eight words per lane and round: the loads overlap
+        const uint32_t w0 = wb + lane * 8u;
+        uint32_t cw[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          cw[j] = w0 + j < nw ? (uint32_t)__popcll(maskGE[w0 + j]) : 0u;
+          sum += cw[j];
+        }
+        const uint32_t inc = wave_scan_dpp(sum);
+        uint32_t at = run + inc - sum;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (w0 + j < nw)
+            cpos[w0 + j] = at;
+          at += cw[j];
+        }
         run += rdlane(inc, 63);
       }
       if (lane == 0)
@@ -683,9 +611,21 @@ k_speck1d(OutlierBufs b)
     }
     __threadfence_block();
     // ================= LIP pass (src/SPECK1D_INT_ENC.cpp:15-45, _DEC.cpp:15-45) =================
-    for (uint32_t wb = 0; wb < nw; wb += 64) {
+    for (uint32_t wb8 = 0; wb8 < nw; wb8 += 512) {   // (eight blocks of 64 words are loaded at once)
+      uint64_t lwv[8], any = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t wj = wb8 + (uint32_t)j * 64u + lane;
+        lwv[j] = wj < nw ? lip[wj] : 0ull;
+        any |= lwv[j];
+      }
+      if (__ballot(any != 0) == 0)
+        continue;
+#pragma unroll
+      for (int jb = 0; jb < 8; jb++) {
+      const uint32_t wb = wb8 + (uint32_t)jb * 64u;
       const uint32_t w = wb + lane;
-      const uint64_t lw = w < nw ? lip[w] : 0ull;
+      const uint64_t lw = lwv[jb];
       uint64_t nz = __ballot(lw != 0);
       if (nz == 0)
         continue;
@@ -719,7 +659,7 @@ k_speck1d(OutlierBufs b)
             lip[w] = lw & ~sig;
         }
         flush_acc();
-        const uint32_t inc = wave_inclusive_scan<uint32_t>(len);
+        const uint32_t inc = wave_scan_dpp(len);
         const uint32_t total = rdlane(inc, 63);
         if (plo | phi) {
           const uint64_t at = wpos + (inc - len);
@@ -760,6 +700,7 @@ k_speck1d(OutlierBufs b)
           if (keep != wv && lane == 0)
             lip[wb + l] = keep;
         }
+      }
       }
     }
 
@@ -832,9 +773,10 @@ k_speck1d(OutlierBufs b)
             const uint32_t a0 = rdlane(myA, i), e0 = rdlane(myB, i);
             wrlane(vA, 0, a0);
             wrlane(vB, 0, e0);
-            if (e0 - a0 <= 64 &&
-                wave_tree(rdlane((uint32_t)myRun, i), rdlane((uint32_t)(myRun >> 32), i), lev, a0, e0))
-              sp = 0;   // (the whole expansion is done)
+            if (rdlane((uint32_t)(myRun >> 32), i) >= 2) {
+              expand_enc(rdlane((uint32_t)myRun, i), rdlane((uint32_t)(myRun >> 32), i), lev, a0, e0);
+              sp = 0;   // (the whole expansion is done; runs of one value keep the serial walk below)
+            }
           }
           i++;
           while (sp > 0) {
@@ -904,8 +846,6 @@ k_speck1d(OutlierBufs b)
               if (sig) {
                 nstate |= 1u << 8;
                 wrlane(vT, f, nstate);
-                if (ENC && chi - clo <= 64 && wave_tree(cs, cl, flev + 1, clo, chi))
-                  continue;   // (at most 64 outliers below: expanded by the wave at once)
                 wrlane(vS, sp, cs);
                 wrlane(vL, sp, cl);
                 wrlane(vT, sp, (flev + 1) << 16);
@@ -944,13 +884,25 @@ k_speck1d(OutlierBufs b)
     else {
       __threadfence_block();
       uint64_t* pb = planeBits + (size_t)p * b.wordStride;
-      for (uint32_t wb = 0; wb < nw; wb += 64) {
+      for (uint32_t wb8 = 0; wb8 < nw; wb8 += 512) {
+        uint64_t swv[8], any = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t wj = wb8 + (uint32_t)j * 64u + lane;
+          swv[j] = wj < nw ? lsp[wj] : 0ull;
+          any |= swv[j];
+        }
+        if (__ballot(any != 0) == 0)
+          continue;
+#pragma unroll
+        for (int jb = 0; jb < 8; jb++) {
+        const uint32_t wb = wb8 + (uint32_t)jb * 64u;
         const uint32_t w = wb + lane;
-        const uint64_t sw = w < nw ? lsp[w] : 0ull;
+        const uint64_t sw = swv[jb];
         if (__ballot(sw != 0) == 0)
           continue;
         const uint32_t cnt = (uint32_t)__popcll(sw);
-        const uint32_t inc = wave_inclusive_scan<uint32_t>(cnt);
+        const uint32_t inc = wave_scan_dpp(cnt);
         if (cnt) {
           const uint64_t at = rpos + (inc - cnt);
           const uint32_t sh = (uint32_t)(at & 63);
@@ -966,6 +918,7 @@ k_speck1d(OutlierBufs b)
           pb[w] = res;
         }
         rpos += rdlane(inc, 63);
+        }
       }
       // the values found in this plane join the LSP (SPECK_INT.cpp:462-468)
       __threadfence_block();
