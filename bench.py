@@ -22,6 +22,8 @@ Besides the contract fields the JSON line carries
                 the N devices of this launch, transfers included: the H2D/D2H-inclusive rate of
                 SURVEY 8(d) at N = 1, and the strong-scaling figure (a fixed 64-chunk volume dealt
                 to N GPUs) at N > 1.  Driven by rank 0; never used as `value`.
+  other_modes   the bench volume in point-wise error mode (tolerance 1e-3 of the range) and one
+                999 x 999 slice at PSNR 90 dB through the 2D coder.  Rank 0; never used as `value`.
   ragged_volume a 1000^3 volume in the same 256^3 chunks: the chunk size does not divide it, so most
                 chunks have extents that are not powers of two (decoded by k_lis_mixed).  Rank 0;
                 never used as `value`.
@@ -132,6 +134,7 @@ def main():
     ap.add_argument("--host-reps", type=int, default=3)
     ap.add_argument("--no-ragged", action="store_true", help="skip the volume the chunk size does not divide")
     ap.add_argument("--ragged-size", type=int, default=1000)
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the point-wise error run and the 2D slice")
     args = ap.parse_args()
 
     import torch
@@ -270,6 +273,68 @@ def main():
         except Exception as ex:
             ragged = {"error": f"{type(ex).__name__}: {ex}"}
 
+    # ---- the other modes of the path (rank 0; reported beside the metric, never as it): the bench
+    #      volume in point-wise error mode (mode 3: the SPECK1D coder of the outliers on top of the
+    #      chunk pipeline), and BASELINE configs[3]'s shape, one 999 x 999 slice at PSNR 90 dB through
+    #      the 2D coder
+    other = None
+    if not args.no_other_modes:
+        try:
+            other = {}
+            rngv = float(vol.max() - vol.min())
+            tol = 1e-3 * rngv
+            obuf = torch.empty(eng.max_compressed_size(vol.shape, chunks, tol, 3), dtype=torch.uint8, device=dev)
+            ps = eng.compress(vol, chunks, tol, mode=3, out=obuf)
+            po = eng.decompress(ps, output_float=True)
+            torch.cuda.synchronize()
+            best_c, best_d = 1e9, 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                ps = eng.compress(vol, chunks, tol, mode=3, out=obuf)
+                torch.cuda.synchronize()
+                b = time.perf_counter()
+                po = eng.decompress(ps, output_float=True)
+                torch.cuda.synchronize()
+                c = time.perf_counter()
+                best_c, best_d = min(best_c, b - a), min(best_d, c - b)
+            other["pwe_volume"] = {
+                "what": f"the bench volume in point-wise error mode, tolerance 1e-3 of the range ({tol:.4g}); best of 2",
+                "compress_GBps": round(vol.numel() * 4 / best_c / 1e9, 3),
+                "decompress_GBps": round(vol.numel() * 4 / best_d / 1e9, 3),
+                "bpp": round(ps.numel() * 8 / vol.numel(), 3),
+                "max_abs_err": float((po.double() - vol.double()).abs().max().item()),
+                # (the decoder narrows to fp32: half an fp32 ulp of the largest value comes on top)
+                "within_tolerance": bool(float((po.double() - vol.double()).abs().max().item())
+                                         <= tol + 6e-8 * float(vol.abs().max())),
+            }
+            del obuf, ps, po
+            img = turbulence_torch((1, 999, 999), dev, seed=3)[0].contiguous()
+            ss = eng.compress_2d(img, 90.0, mode=2).clone()
+            so = eng.decompress_2d(ss, (999, 999), True)
+            torch.cuda.synchronize()
+            best_c, best_d = 1e9, 1e9
+            for _ in range(3):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                eng.compress_2d(img, 90.0, mode=2)
+                torch.cuda.synchronize()
+                b = time.perf_counter()
+                so = eng.decompress_2d(ss, (999, 999), True)
+                torch.cuda.synchronize()
+                c = time.perf_counter()
+                best_c, best_d = min(best_c, b - a), min(best_d, c - b)
+            mse = float(((so.double() - img.double()) ** 2).mean().item())
+            rng2 = float(img.max() - img.min())
+            other["slice_2d"] = {
+                "what": "one 999 x 999 fp32 slice, PSNR 90 dB (sperr_comp_2d / sperr_decomp_2d on device buffers); best of 3",
+                "compress_ms": round(best_c * 1e3, 3), "decompress_ms": round(best_d * 1e3, 3),
+                "bpp": round(ss.numel() * 8 / img.numel(), 3),
+                "psnr_dB": round(10 * __import__("math").log10(rng2 * rng2 / mse), 2),
+            }
+        except Exception as ex:
+            other = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- roofline of the dominant kernel (HIP events recorded by the engine, timed region) ----
     kern = sorted(prof_all.items(), key=lambda kv: -kv[1][0])   # (one untimed step, all kernels)
     # (the timed steps) top_ms: time during which the kernel was running -- decoding enqueues
@@ -373,6 +438,7 @@ def main():
         "cpu_baseline": cpu,
         "host_path": host_path,
         "ragged_volume": ragged,
+        "other_modes": other,
     }
     print(json.dumps(line))
     if world > 1:
