@@ -191,8 +191,10 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
     const uint64_t fresh = *sn;
     uint64_t sig = *so;
     uint64_t born = b.bornM[c * b.maskPixStride + wi];
-    uint64_t lb, ls, ln;
-    if (leaf_word(b, c, wi, lb, ls, ln)) {   // idempotent: old leaf results are folded again
+    uint64_t lb = 0, ls = 0, ln = 0;
+    // (idempotent: old leaf results are folded again -- but once all 64 samples of the word are born,
+    //  every leaf over it has split and was folded by an earlier plane: their states are final)
+    if (born != ~0ull && leaf_word(b, c, wi, lb, ls, ln)) {
       if (lb & ~born) {
         born |= lb;
         b.bornM[c * b.maskPixStride + wi] = born;
