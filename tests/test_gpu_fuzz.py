@@ -76,9 +76,12 @@ def test_random_case(eng, seed):
 def test_random_slice(eng, seed):
     """The 2D entry points on random slices: sperr_comp_2d / sperr_decomp_2d, the three modes."""
     from oracle.pyoracle import Oracle
-    oracle = Oracle()
+    check_slice(eng, Oracle(), seed)
+
+
+def make_slice(seed, maxdim=140):
     rng = np.random.default_rng(5000 + seed)
-    shape = (int(rng.integers(9, 140)), int(rng.integers(9, 140)))
+    shape = (int(rng.integers(9, maxdim)), int(rng.integers(9, maxdim)))
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     img = turbulence((1,) + shape, seed=seed + 11, dtype=dtype)[0]
     if rng.random() < 0.3:
@@ -88,6 +91,11 @@ def test_random_slice(eng, seed):
     quality = (float(rng.choice([0.4, 1.5, 4.0, 11.0])), float(rng.choice([35.0, 70.0, 120.0, 200.0])),
                span * float(rng.choice([0.1, 1e-2, 1e-4, 1e-7])))[mode - 1]
     hdr = bool(rng.integers(0, 2))
+    return rng, shape, dtype, img, mode, quality, hdr
+
+
+def check_slice(eng, oracle, seed, maxdim=140):
+    rng, shape, dtype, img, mode, quality, hdr = make_slice(seed, maxdim)
     want = oracle.comp_2d(img, mode, quality, hdr)
     got = bytes(eng.compress_2d(cuda(img), quality, mode=mode, header=hdr).cpu().numpy())
     assert got == want, (shape, mode, quality, str(dtype))

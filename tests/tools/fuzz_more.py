@@ -1,4 +1,5 @@
-"""Wider run of the randomised parity sweep of tests/test_gpu_fuzz.py: python tests/tools/fuzz_more.py 40 600"""
+"""Wider run of the randomised parity sweep of tests/test_gpu_fuzz.py:
+python tests/tools/fuzz_more.py 40 600 [slice_lo slice_hi [max slice edge]]"""
 import os
 import sys
 
@@ -10,7 +11,7 @@ import torch
 
 from oracle.pyoracle import Oracle
 from sperr_amd.api import SperrHip
-from test_gpu_fuzz import bits, make_case
+from test_gpu_fuzz import bits, check_slice, make_case
 
 eng, oracle = SperrHip(), Oracle()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
@@ -32,3 +33,18 @@ for seed in range(lo, hi):
         bad += 1
         print("MISMATCH seed", seed, v.shape, chunks, mode, quality, v.dtype)
 print("cases", hi - lo, "bad", bad)
+
+if len(sys.argv) > 4:   # random slices through the 2D entry points (streams cut short included)
+    slo, shi = int(sys.argv[3]), int(sys.argv[4])
+    maxdim = int(sys.argv[5]) if len(sys.argv) > 5 else 140
+    sbad = 0
+    for seed in range(slo, shi):
+        try:
+            check_slice(eng, oracle, seed, maxdim)
+        except AssertionError as e:
+            sbad += 1
+            print("SLICE MISMATCH seed", seed, str(e)[:200])
+        except Exception as e:   # noqa: BLE001
+            sbad += 1
+            print("slice exception seed", seed, e)
+    print("slices", shi - slo, "bad", sbad)
