@@ -1711,6 +1711,7 @@ struct DecBatchBufs {
   double* vals;
   size_t valsStride;
   uint32_t* coef32;
+  uint32_t* live;   // chunks that still decode (DecPlanHost::d_live)
 };
 
 bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o)
@@ -1730,6 +1731,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(o.geom, ChunkGeom, B);
   TAKE(o.chunkOff, uint64_t, B);
   TAKE(o.chunkLen, uint64_t, B);
+  TAKE(o.live, uint32_t, 64);
   o.valsStride = Npad;
   TAKE(o.vals, double, Npad * B);
   d.coefStride = Npad;
@@ -2093,6 +2095,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       // LIS phase of the larger sets: 1 stream 74 ms, 3 streams 65 ms).
       // SPERR_HIP_SUBSTREAMS=n overrides the choice (1 = a single stream).
       static const int subEnv = getenv("SPERR_HIP_SUBSTREAMS") ? atoi(getenv("SPERR_HIP_SUBSTREAMS")) : 0;
+      static const bool threads = !(getenv("SPERR_HIP_ENQUEUE_THREADS") && atoi(getenv("SPERR_HIP_ENQUEUE_THREADS")) == 0);
       uint32_t nsub = nbAll >= 32 ? 2u : 1u;
       if (subEnv > 0)
         nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
@@ -2230,6 +2233,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
+        // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
+        static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
+        ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;
         // the inverse passes dequantise on the way (not for the resolution hierarchy, whose coarsest
         // level is read before any pass has run)
         const bool fuseDq = plan_fusable(*P) && !mr && !slice;
@@ -2362,8 +2368,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         }
       }
       else {
-        // (SPERR_HIP_ENQUEUE_THREADS=1: one host thread per sub-batch; measured no gain on MI355X)
-        static const bool threads = getenv("SPERR_HIP_ENQUEUE_THREADS") != nullptr;
+        // one host thread per sub-batch (SPERR_HIP_ENQUEUE_THREADS=0: one thread for all): by itself no
+        // gain on MI355X, but a thread of its own may wait for its stream, which lets the launcher
+        // stop at the plane where the chunks run out of bits (DecPlanHost::d_live)
         std::vector<int> rc(nsub, 0);
         if (threads) {
           std::vector<std::thread> workers;

@@ -144,6 +144,13 @@ struct DecPlanHost {
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
   bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
+  // Fixed-rate streams run out of bits many planes above plane 0, and the launches of a plane that
+  // holds no work still cost about 0.1 ms per batch.  With d_live set (a device word) the launcher
+  // asks after 16 planes, and then after every fourth, how many chunks still decode -- a small
+  // kernel, a copy and a wait for the stream -- and stops launching when none does.  Only for a
+  // caller whose host thread may wait for this stream (the other sub-batches of a call are enqueued
+  // by threads of their own).
+  uint32_t* d_live = nullptr;
 };
 
 constexpr int kTabWMax = 28672;   // window bits: < 2^15 (table entries keep a flag in bit 15)

@@ -5071,6 +5071,17 @@ __global__ void k_dec_plane_end(DecBuffers b, int p)
     s.done = 1;
 }
 
+// chunks of the batch that still have planes to decode
+__global__ void __launch_bounds__(kThreads) k_dec_live(DecBuffers b, uint32_t* out)
+{
+  uint32_t live = 0;
+  for (uint32_t c = threadIdx.x; c < b.nchunks; c += blockDim.x)
+    live += (b.st[c].active && !b.st[c].done) ? 1u : 0u;
+  live = (uint32_t)__syncthreads_count(live != 0);
+  if (threadIdx.x == 0)
+    *out = live;
+}
+
 // ------------------------------------------------------------------------------------------
 int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,
                         const uint8_t* container, const uint64_t* d_chunkOff,
@@ -5202,6 +5213,15 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
                dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
+    const int planesDone = maxPlanes - p;
+    if (plan.d_live && p > 0 && planesDone >= 16 && planesDone % 4 == 0) {
+      uint32_t live = 1;
+      LAUNCH_K(k_dec_live, dim3(1), dim3(kThreads), 0, stream, b, plan.d_live);
+      HIP_CHECK(hipMemcpyAsync(&live, plan.d_live, sizeof(live), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (live == 0)
+        break;   // (every launch below would return at once)
+    }
   }
   {
     const uint32_t n = b.tree.nvals;
