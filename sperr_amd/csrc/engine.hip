@@ -2779,6 +2779,48 @@ int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int outp
   });
 }
 
+// What a host thread that codes slices keeps: a stream of its own (calls of several threads then run
+// side by side; on the null stream they would queue behind each other) and two device buffers that
+// only grow (hipMalloc / hipFree per call would synchronise the device; the stream-ordered allocator
+// handed out blocks whose contents the next call did not see: not used).  Freed with the thread.
+struct ThreadSliceBufs {
+  hipStream_t s = nullptr;
+  void* p[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  hipStream_t stream()
+  {
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+      s = nullptr;
+    return s;
+  }
+  void* get(int i, size_t bytes)
+  {
+    if (bytes > cap[i]) {
+      if (p[i])
+        (void)hipFree(p[i]);
+      p[i] = nullptr;
+      cap[i] = 0;
+      if (hipMalloc(&p[i], round_up(bytes, 1 << 20)) != hipSuccess)
+        return nullptr;
+      cap[i] = round_up(bytes, 1 << 20);
+    }
+    return p[i];
+  }
+  ~ThreadSliceBufs()
+  {
+    for (int i = 0; i < 2; i++)
+      if (p[i])
+        (void)hipFree(p[i]);
+    if (s)
+      (void)hipStreamDestroy(s);
+  }
+};
+ThreadSliceBufs& thread_slice_bufs()
+{
+  static thread_local ThreadSliceBufs t;
+  return t;
+}
+
 // ---- 2D slices (include/SPERR_C_API.h:53-81, src/SPERR_C_API.cpp:7-134) ------------------------
 size_t sperrhip_max_compressed_size_2d(size_t dimx, size_t dimy, int mode, double quality)
 {
@@ -3059,21 +3101,24 @@ int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int m
       return 2;
     const size_t n = dimx * dimy, esz = is_float ? 4 : 8;
     const size_t cap = sperrhip_max_compressed_size_2d(dimx, dimy, mode, quality);
-    void *d_in = nullptr, *d_out = nullptr;
-    if (hipMalloc(&d_in, n * esz) != hipSuccess || hipMalloc(&d_out, cap) != hipSuccess) {
+    // on the calling thread's own stream, with its own device buffers: slices coded from several host
+    // threads run side by side
+    ThreadSliceBufs& tb = thread_slice_bufs();
+    hipStream_t ts = tb.stream();
+    void *d_in = tb.get(0, n * esz), *d_out = tb.get(1, cap);
+    if (!d_in || !d_out) {
       fprintf(stderr, "[sperr_hip] device allocation failed\n");
-      if (d_in)
-        (void)hipFree(d_in);
       return -1;
     }
     int rtn = -1;
     size_t len = 0;
-    if (hipMemcpy(d_in, src, n * esz, hipMemcpyHostToDevice) == hipSuccess)
+    if (hipMemcpyAsync(d_in, src, n * esz, hipMemcpyHostToDevice, ts) == hipSuccess)
       rtn = sperrhip_compress_2d_dev(d_in, is_float, dimx, dimy, mode, quality, out_inc_header, d_out,
-                                     cap, &len, nullptr);
+                                     cap, &len, ts);
     if (rtn == 0) {
       void* buf = malloc(len);
-      if (buf && hipMemcpy(buf, d_out, len, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (buf && hipMemcpyAsync(buf, d_out, len, hipMemcpyDeviceToHost, ts) == hipSuccess &&
+          hipStreamSynchronize(ts) == hipSuccess) {
         *dst = buf;
         *dst_len = len;
       }
@@ -3082,8 +3127,7 @@ int sperr_comp_2d(const void* src, int is_float, size_t dimx, size_t dimy, int m
         rtn = -1;
       }
     }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    (void)hipStreamSynchronize(ts);
     return rtn;
   });
 }
@@ -3210,27 +3254,25 @@ int sperr_decomp_2d(const void* src, size_t src_len, int output_float, size_t di
     if (*dst != nullptr)
       return 1;
     const size_t n = dimx * dimy, esz = output_float ? 4 : 8;
-    void *d_in = nullptr, *d_out = nullptr;
-    if (src_len < 17 || hipMalloc(&d_in, src_len) != hipSuccess ||
-        hipMalloc(&d_out, n * esz) != hipSuccess) {
-      if (d_in)
-        (void)hipFree(d_in);
+    ThreadSliceBufs& tb = thread_slice_bufs();   // (see sperr_comp_2d)
+    hipStream_t ts = tb.stream();
+    void *d_in = src_len >= 17 ? tb.get(0, src_len) : nullptr, *d_out = tb.get(1, n * esz);
+    if (!d_in || !d_out)
       return -1;
-    }
     int rtn = -1;
-    if (hipMemcpy(d_in, src, src_len, hipMemcpyHostToDevice) == hipSuccess)
-      rtn = sperrhip_decompress_2d_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, nullptr);
+    if (hipMemcpyAsync(d_in, src, src_len, hipMemcpyHostToDevice, ts) == hipSuccess)
+      rtn = sperrhip_decompress_2d_dev(d_in, src_len, output_float, dimx, dimy, d_out, n * esz, ts);
     if (rtn == 0) {
       void* buf = malloc(n * esz);
-      if (buf && hipMemcpy(buf, d_out, n * esz, hipMemcpyDeviceToHost) == hipSuccess)
+      if (buf && hipMemcpyAsync(buf, d_out, n * esz, hipMemcpyDeviceToHost, ts) == hipSuccess &&
+          hipStreamSynchronize(ts) == hipSuccess)
         *dst = buf;
       else {
         free(buf);
         rtn = -1;
       }
     }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    (void)hipStreamSynchronize(ts);
     return rtn;
   });
 }
