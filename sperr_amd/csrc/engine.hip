@@ -1322,17 +1322,30 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     if (vol[a] > 0xffffffffull || cdim[a] > 0xffff)
       return -1;
 
-  // group chunks by shape, keeping chunk order inside a group
-  std::map<Dims, std::vector<ChunkRef>> groups;
-  for (uint32_t i = 0; i < nchunks; i++) {
-    const auto& c = chunks[i];
-    groups[Dims{c[1], c[3], c[5]}].push_back(
-        {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
+  // group chunks by shape, keeping chunk order inside a group.  (key: extents + part.)  In fixed-rate
+  // mode a group of 64 and more chunks is cut into two parts that run side by side like the shape
+  // groups of a ragged volume do: the per-plane chains of small launches of one part overlap the
+  // bandwidth-bound kernels of the other (SPERR_HIP_ENC_PARTS=1: one part)
+  using GKey = std::array<size_t, 4>;
+  std::map<GKey, std::vector<ChunkRef>> groups;
+  {
+    std::map<Dims, uint32_t> count, seen;
+    for (uint32_t i = 0; i < nchunks; i++)
+      count[Dims{chunks[i][1], chunks[i][3], chunks[i][5]}]++;
+    static const uint32_t partsEnv = getenv("SPERR_HIP_ENC_PARTS") ? (uint32_t)std::max(1, atoi(getenv("SPERR_HIP_ENC_PARTS"))) : 2u;
+    for (uint32_t i = 0; i < nchunks; i++) {
+      const auto& c = chunks[i];
+      const Dims d{c[1], c[3], c[5]};
+      const uint32_t n = count[d], k = seen[d]++;
+      const uint32_t parts = (mode == 1 && !slice && n >= 64 && n <= 512) ? std::min<uint32_t>(partsEnv, kSubStreams) : 1u;
+      groups[GKey{c[1], c[3], c[5], (size_t)((uint64_t)k * parts / n)}].push_back(
+          {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
+    }
   }
 
   // (a slice is coded on the 2D coder's forest, the plan with z extent 0; SPERR_HIP_SLICE_MIXED=0: by
   //  k_speck2d's quadtree walk)
-  auto planZ = [&](const Dims& d) -> size_t { return slice && slice_forest_enabled() ? 0 : d[2]; };
+  auto planZ = [&](const GKey& d) -> size_t { return slice && slice_forest_enabled() ? 0 : d[2]; };
 
   // slots for the finished chunk streams
   std::vector<uint64_t> slotOff(nchunks + 1, 0);
@@ -1406,7 +1419,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   std::vector<ShapePlan*> groupPlan;   // (looked up here: the plan cache is not for several threads)
   for (auto& g : groups)
     groupPlan.push_back(E.plan(g.first[0], g.first[1], planZ(g.first)));
-  auto do_group = [&](uint32_t gi, std::pair<const Dims, std::vector<ChunkRef>>& g) -> int {
+  auto do_group = [&](uint32_t gi, std::pair<const GKey, std::vector<ChunkRef>>& g) -> int {
     hipStream_t ss = sideBySide ? E.sub[gi % kSubStreams] : st;
     ShapePlan* P = groupPlan[gi];
     const uint64_t raw_budget = (uint64_t)(bpp * (double)P->N);  // SPECK_FLT.cpp:491

@@ -792,3 +792,19 @@ def test_2d_quadtree_walk_decoder_in_a_fresh_process(oracle):
                    os.path.join(td, "r.npy"), shape, os.path.join(td, "i.npy")))
         env = dict(os.environ, SPERR_HIP_SLICE_MIXED="0")
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
+
+
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), (16, 16, 16)), ((48, 80, 160), (16, 16, 16)),
+                                          ((70, 96, 96), (16, 24, 16))])
+@pytest.mark.parametrize("bpp", [0.8, 4.0, 20.0])
+def test_many_chunks_of_one_shape_coded_in_two_parts(eng, oracle, shape, chunks, bpp):
+    """Fixed-rate compression cuts a group of 64 and more equally shaped chunks into two parts that run
+    side by side on two streams (compress_impl, `SPERR_HIP_ENC_PARTS`); the chunk streams land in the
+    container in chunk order all the same, the 64-bit retry of single chunks (20 bpp) included; 70 / 16
+    leaves border chunks of a second shape beside the 144 regular ones."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 1, bpp)
+    got = bytes(eng.compress(cuda(v), chunks, bpp).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
