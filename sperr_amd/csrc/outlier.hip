@@ -243,17 +243,21 @@ k_speck1d(OutlierBufs b)
   // ---- bit reader (decoder): 64 words of the stream sit in a register pair, lane = word, so that
   //      the serial parse waits for memory once per 4032 bits instead of once per word
   uint64_t rpos = 0, vW = 0, cBase = 1ull << 62;   // (cBase: index of the word in lane 0; none yet)
+  uint64_t cw0 = 0, cw1 = 0, cwi = 1ull << 62;      // the two words the window lies in, as scalars (none yet)
   auto window = [&]() -> uint64_t {   // the next 64 bits from rpos on
     const uint64_t wi = rpos >> 6;
-    if (wi - cBase >= 63u) {
-      cBase = wi;
-      vW = wi + lane < b.streamStride ? words[wi + lane] : 0ull;
+    if (wi != cwi) {
+      if (wi - cBase >= 63u) {
+        cBase = wi;
+        vW = wi + lane < b.streamStride ? words[wi + lane] : 0ull;
+      }
+      const uint32_t k = (uint32_t)(wi - cBase);
+      cw0 = wi == cwi + 1 ? cw1 : (uint64_t)rdlane((uint32_t)vW, k) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k) << 32);
+      cw1 = (uint64_t)rdlane((uint32_t)vW, k + 1u) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k + 1u) << 32);
+      cwi = wi;
     }
-    const uint32_t k = (uint32_t)(wi - cBase);
-    const uint64_t w0 = (uint64_t)rdlane((uint32_t)vW, k) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k) << 32);
-    const uint64_t w1 = (uint64_t)rdlane((uint32_t)vW, k + 1u) | ((uint64_t)rdlane((uint32_t)(vW >> 32), k + 1u) << 32);
     const uint32_t sh = (uint32_t)(rpos & 63);
-    return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    return sh ? (cw0 >> sh) | (cw1 << (64 - sh)) : cw0;
   };
   auto get = [&]() -> uint32_t {
     const uint32_t bit = (uint32_t)(window() & 1ull);
