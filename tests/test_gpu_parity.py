@@ -808,3 +808,45 @@ def test_many_chunks_of_one_shape_coded_in_two_parts(eng, oracle, shape, chunks,
     assert got == want
     dev = cuda(np.frombuffer(want, dtype=np.uint8))
     assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
+
+
+def test_2d_host_entry_points_from_several_threads(eng, oracle):
+    """sperr_comp_2d / sperr_decomp_2d called from four host threads at once (each call takes an engine of
+    the device's pool and works on a stream and device buffers of the calling thread): every thread gets
+    the oracle's stream and values, call after call."""
+    import ctypes as C
+    import threading
+    lib = eng.lib
+    lib.sperr_comp_2d.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.c_int,
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.sperr_decomp_2d.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    shapes = [(150, 211), (96, 96), (33, 300), (257, 129)]
+    imgs = [turbulence((1,) + sh, seed=7 + i)[0] for i, sh in enumerate(shapes)]
+    wants = [oracle.comp_2d(im, 2, 80.0, False) for im in imgs]
+    decs = [oracle.decomp_2d(w, sh, False) for w, sh in zip(wants, shapes)]
+    bad = []
+
+    def work(i):
+        dy, dx = shapes[i]
+        for _ in range(3):
+            dst, ln = C.c_void_p(None), C.c_size_t(0)
+            rc = lib.sperr_comp_2d(imgs[i].ctypes.data, 1, dx, dy, 2, 80.0, 0, C.byref(dst), C.byref(ln))
+            if rc != 0 or C.string_at(dst.value, ln.value) != wants[i]:
+                bad.append(("compress", i, rc))
+            libc.free(dst)
+            out = C.c_void_p(None)
+            rc = lib.sperr_decomp_2d(wants[i], len(wants[i]), 0, dx, dy, C.byref(out))
+            got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_double)), shape=(dy, dx)).copy() if rc == 0 else None
+            if rc != 0 or not np.array_equal(bits(got), bits(decs[i])):
+                bad.append(("decompress", i, rc))
+            if out.value:
+                libc.free(out)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(shapes))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad
