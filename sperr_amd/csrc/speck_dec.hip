@@ -2634,7 +2634,10 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
   uint64_t hstamp[4] = {0, 0, 0, 0};
   uint64_t myWork = 0;   // diagnostics: ticks of the first helper thread in expand / classes / rows
   uint32_t hbarGoal = 0;
+  uint64_t barTicks = 0;   // diagnostics: ticks a helper spends in its barriers
+  uint32_t barCount = 0;
   auto hbar = [&]() {
+    const uint64_t t0_ = wstamps ? __builtin_readcyclecounter() : 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0)
       atomicAdd(&sh_hbar, 1u);
@@ -2642,6 +2645,10 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     while (__hip_atomic_load(&sh_hbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hbarGoal)
       __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (wstamps) {
+      barTicks += __builtin_readcyclecounter() - t0_;
+      barCount++;
+    }
   };
 
   // all of the per-level state the lambdas below use
@@ -3537,6 +3544,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     out[27] += hstamp[2];
     out[28] += nHelpers;
     out[29] += hstamp[3];
+    out[42] += barTicks;
+    out[43] += barCount;
   }
 #undef STAMP
   if (tid == 0) {

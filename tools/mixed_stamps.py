@@ -36,6 +36,8 @@ print("windows %d (%d pipeline restarts): ticks/window walk %d, waiting for the 
 if out[28]:
     print("helpers (%d wavefronts per plane sum): ticks/window expand %d, entry classes %d, rows %d; whole phase %d" %
           (out[28], out[25] // w, out[26] // w, out[27] // w, out[29] // w))
+if out[43]:
+    print("first helper: %d barriers per window, %d ticks per window inside them" % (out[43] // w, out[42] // w))
 print("helper wavefronts, ticks of work per window:", [out[32 + i] // w for i in range(8)])
 print("walk: %d of the significant list entries in the per-word loop, %d words, %d ticks there" % (out[23], out[24], out[30]))
 print("walk: ticks entering list entries %d, inside the sets walked into %d (%d sets finished)" % (out[31], out[40], out[41]))
