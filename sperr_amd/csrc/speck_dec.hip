@@ -2632,6 +2632,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     }
   }
   uint64_t hstamp[4] = {0, 0, 0, 0};
+  uint64_t wphase[2] = {0, 0};
   uint64_t myWork = 0;   // diagnostics: ticks of the first helper thread in expand / classes / rows
   uint32_t hbarGoal = 0;
   uint64_t barTicks = 0;   // diagnostics: ticks a helper spends in its barriers
@@ -3410,6 +3411,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
       if (tid < 64) {
         set_view(curB, aCur);
         walk(curB, r0, S, r0 == 0, ringHi);
+        if (stamps)
+          wphase[0] += __builtin_readcyclecounter() - hphase0;   // the walk, from the start of the phase
         STAMP(7);
       }
       else if (isHelper) {
@@ -3439,6 +3442,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
           myWork += __builtin_readcyclecounter() - hphase0;
       }
       __syncthreads();
+      if (stamps)
+        wphase[1] += __builtin_readcyclecounter() - hphase0;     // the whole phase as the walker sees it
       if (wstamps && isHelper && helperRank == 0 && lane == 0)
         hstamp[3] += __builtin_readcyclecounter() - hphase0;
       if (sh_depth < 0) {
@@ -3528,6 +3533,8 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
     out[20] += cnt_bits;
     out[21] += cnt_skips;
     out[22] += cnt_items;
+    out[44] += wphase[0];
+    out[45] += wphase[1];
     out[23] += cnt_tight;
     out[24] += cnt_words;
     out[30] += tick_tight;

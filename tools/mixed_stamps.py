@@ -36,6 +36,8 @@ print("windows %d (%d pipeline restarts): ticks/window walk %d, waiting for the 
 if out[28]:
     print("helpers (%d wavefronts per plane sum): ticks/window expand %d, entry classes %d, rows %d; whole phase %d" %
           (out[28], out[25] // w, out[26] // w, out[27] // w, out[29] // w))
+if out[45]:
+    print("phase as the walker sees it: walk done after %d ticks, phase over after %d" % (out[44] // w, out[45] // w))
 if out[43]:
     print("first helper: %d barriers per window, %d ticks per window inside them" % (out[43] // w, out[42] // w))
 print("helper wavefronts, ticks of work per window:", [out[32 + i] // w for i in range(8)])
