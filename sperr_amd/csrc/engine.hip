@@ -463,11 +463,13 @@ struct Engine {
   hipStream_t sub[kSubStreams] = {};
   hipEvent_t evFork = nullptr, evJoin[kSubStreams] = {};
   hipStream_t outl = nullptr;               // the 1D decoder of outlier streams runs here, beside the chunk decoders
-  hipEvent_t evOutl = nullptr;
+  hipStream_t outlQ[kSubStreams] = {};      //   (one per sub-batch; outlQ[0] == outl)
+  hipEvent_t evOutl[kSubStreams] = {}, evOutlFork[kSubStreams] = {};   // (per sub-batch)
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
+  DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
   std::vector<std::unique_ptr<DevBuf>> pweBufs;   // outlier streams of the batches of one call
   size_t freeMemAtInit = 0;
@@ -485,7 +487,13 @@ struct Engine {
     }
     HIP_CHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
     HIP_CHECK(hipStreamCreateWithFlags(&outl, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&evOutl, hipEventDisableTiming));
+    outlQ[0] = outl;
+    for (uint32_t q = 1; q < kSubStreams; q++)
+      HIP_CHECK(hipStreamCreateWithFlags(&outlQ[q], hipStreamNonBlocking));
+    for (uint32_t q = 0; q < kSubStreams; q++) {
+      HIP_CHECK(hipEventCreateWithFlags(&evOutl[q], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&evOutlFork[q], hipEventDisableTiming));
+    }
     ready = true;
     return 0;
   }
@@ -1298,8 +1306,9 @@ struct DrainOnError {
     for (uint32_t q = 0; q < kSubStreams; q++)
       if (E.sub[q])
         (void)hipStreamSynchronize(E.sub[q]);
-    if (E.outl)
-      (void)hipStreamSynchronize(E.outl);
+    for (uint32_t q = 0; q < kSubStreams; q++)
+      if (E.outlQ[q])
+        (void)hipStreamSynchronize(E.outlQ[q]);
     (void)hipGetLastError();
   }
 };
@@ -2112,7 +2121,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       uint32_t nsub = nbAll >= 32 ? 2u : 1u;
       if (subEnv > 0)
         nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
-      if (anyOutlier || nbAll < 2 * nsub || deferG)
+      // (with outlier streams every sub-batch waits for its stream when it reads back the 1D decoder's
+      //  state: several sub-batches only when each has a host thread of its own)
+      if ((anyOutlier && !threads) || nbAll < 2 * nsub || deferG)
         nsub = 1;
       std::vector<SubHost> subs(nsub);
       if (nsub > 1) {
@@ -2176,10 +2187,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         std::vector<OutlierChunk> hoc;
         OutlierBufs ob;
         {
-          hipStream_t so = E.outl;
+          hipStream_t so = E.outlQ[q];
           if (batchOutliers) {
-            HIP_CHECK(hipEventRecord(E.evFork, ss));
-            HIP_CHECK(hipStreamWaitEvent(so, E.evFork, 0));
+            HIP_CHECK(hipEventRecord(E.evOutlFork[q], ss));
+            HIP_CHECK(hipStreamWaitEvent(so, E.evOutlFork[q], 0));
           }
           if (batchOutliers) {
             hoc.assign(nb, OutlierChunk{});
@@ -2212,11 +2223,11 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             const size_t bytes = round_up(nb * sizeof(OutlierChunk), 256) +
                                  (size_t)nb * (ob.wordStride * 16 + ob.kStride * 5 + ob.runStride * 8 +
                                                ob.streamStride * 8 + ob.planeStride * 8) + 8192;
-            if (E.outlVar.ensure(bytes))
+            if (E.outlDec[q].ensure(bytes))   // (its own buffer: the sub-batches are enqueued by separate threads)
               return -1;
             Arena OA;
-            OA.base = static_cast<char*>(E.outlVar.p);
-            OA.cap = E.outlVar.n;
+            OA.base = static_cast<char*>(E.outlDec[q].p);
+            OA.cap = E.outlDec[q].n;
             ob.oc = OA.take<OutlierChunk>(nb);
             ob.lip = OA.take<uint64_t>(nb * ob.wordStride);
             ob.lsp = OA.take<uint64_t>(nb * ob.wordStride);
@@ -2231,7 +2242,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             HIP_CHECK(hipMemsetAsync(ob.lip, 0, (size_t)nb * ob.wordStride * 16, so));   // lip + lsp
             if (launch_speck1d_decode(so, ob, d_src))
               return -1;
-            HIP_CHECK(hipEventRecord(E.evOutl, so));
+            HIP_CHECK(hipEventRecord(E.evOutl[q], so));
           }
 
         }
@@ -2354,7 +2365,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
                                   std::is_same<T, float>::value ? 1 : 2, d_dst, vd, bb.geom))
           return -1;
         if (batchOutliers) {   // the correctors of the values the 1D decoder found meanwhile
-          HIP_CHECK(hipStreamWaitEvent(ss, E.evOutl, 0));
+          HIP_CHECK(hipStreamWaitEvent(ss, E.evOutl[q], 0));
           if (launch_outlier_apply(ss, ob, d.cst, bb.vals, bb.valsStride))
             return -1;
           HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, ss));

@@ -850,3 +850,17 @@ def test_2d_host_entry_points_from_several_threads(eng, oracle):
     for t in ts:
         t.join()
     assert not bad, bad
+
+
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), (16, 16, 16)), ((48, 80, 160), (16, 16, 16))])
+@pytest.mark.parametrize("tol", [3e-2, 1e-4])
+def test_many_chunks_pwe_in_two_sub_batches(eng, oracle, shape, chunks, tol):
+    """Point-wise error mode with 64 and more chunks of one shape: the decoder runs two sub-batches, each
+    with its own 1D decoder of the outlier streams beside it (per sub-batch buffers and events)."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 3, tol)
+    assert bytes(eng.compress(cuda(v), chunks, tol, mode=3).cpu().numpy()) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    for as_float in (True, False):
+        assert np.array_equal(bits(eng.decompress(dev, as_float).cpu().numpy()),
+                              bits(oracle.decomp_3d(want, as_float)))
