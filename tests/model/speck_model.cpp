@@ -132,7 +132,7 @@ void emit_splits(Enc& s, int p, BitSink& out, const std::vector<uint64_t>& sign,
     node_kids(t, nd, k);
     KidInfo ki;
     kids_info(t, nd, k, s.M.data(), s.E.data(), s.msb.data(), ki);
-    const uint32_t kidlev = node_level(t, nd) + (q.len[0] > 1) + (q.len[1] > 1) + (q.len[2] > 1);
+    const uint32_t kidlev = kid_level(t, nd, q);
     bool found = false;
     for (int j = 0; j < k.n; j++) {
       const bool coded = found || (j + 1 != k.n);
@@ -159,11 +159,11 @@ void emit_splits(Enc& s, int p, BitSink& out, const std::vector<uint64_t>& sign,
 extern "C" {
 
 // Same contract as orc_speck3d_encode (oracle/sperr_oracle.h)
-int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
-                         size_t budget_bits, uint8_t** stream, size_t* stream_len)
+static int model_encode_impl(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
+                             size_t budget_bits, uint8_t** stream, size_t* stream_len, bool twoD)
 {
   Enc s;
-  s.ht = build_tree(dims[0], dims[1], dims[2]);
+  s.ht = build_tree(dims[0], dims[1], dims[2], twoD);
   s.t = s.ht.view();
   const Tree& t = s.t;
   const size_t N = t.nvals;
@@ -201,6 +201,7 @@ int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const si
   }
 
   std::vector<std::vector<uint64_t>> lis(s.ht.initLIS), next(t.nlevels);
+  uint32_t iPart = s.ht.iLevels;   // 2D: part_level of what is left of the type-I set
   std::vector<uint64_t> baseLIP(64, 0), baseLIS(64, 0), baseREF(64, 0);
   std::vector<char> didREF(64, 0);
   uint64_t pos = 0;
@@ -247,8 +248,50 @@ int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const si
         if (s.M[id] == p)
           out.put(s.opos[id], 1);
       }
-    // kernel K2 + K2b
     born.clear();
+    // 2D coder (k_enc_iphase): the type-I set at the end of the sorting pass (SPECK2D_INT.cpp:44-98).
+    // Its test bit; when it is significant the three subbands of its level: a significant one splits on
+    // the spot (its split is written by emit_splits like that of a list entry), an insignificant one
+    // joins the list of its level; then what is left of it, implied when none of the three was
+    if (twoD) {
+      bool need = true;
+      while (iPart > 0) {
+        if (need) {
+          int mi = -1;
+          for (size_t k = (size_t)(s.ht.iLevels - iPart) * 3; k < (size_t)s.ht.iLevels * 3; k++)
+            if (s.ht.iRoots[k] != HostTree::kNoRoot)
+              mi = std::max<int>(mi, s.M[flat_id(t, unpack_node(s.ht.iRoots[k]))]);
+          ensure(pos + 1);
+          out.put(pos++, mi >= p);
+          if (mi < p)
+            break;
+        }
+        int counter = 0;
+        for (int j = 0; j < 3; j++) {
+          const uint64_t root = s.ht.iRoots[(size_t)(s.ht.iLevels - iPart) * 3 + j];
+          if (root == HostTree::kNoRoot)
+            continue;
+          const uint32_t id = flat_id(t, unpack_node(root));
+          if (s.M[id] >= p) {
+            ensure(pos + 2 + s.E[id]);
+            out.put(pos, 1);
+            s.opos[id] = pos;
+            pos += 1 + s.E[id];
+            counter++;
+          }
+          else {
+            ensure(pos + 1);
+            out.put(pos, 0);
+            born.push_back({iPart, pos, root});
+            pos++;
+          }
+        }
+        iPart--;
+        need = counter != 0;
+      }
+      ensure(pos);
+    }
+    // kernel K2 + K2b
     emit_splits(s, p, out, std::vector<uint64_t>(signs, signs + (N + 63) / 64), born);
     std::stable_sort(born.begin(), born.end(), [](const Born& a, const Born& b) {
       return a.lev != b.lev ? a.lev < b.lev : a.pos < b.pos;
@@ -291,6 +334,19 @@ int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const si
   *stream = o;
   *stream_len = 9 + nbytes;
   return 0;
+}
+
+int model_speck3d_encode(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
+                         size_t budget_bits, uint8_t** stream, size_t* stream_len)
+{
+  return model_encode_impl(coeffs, signs, dims, budget_bits, stream, stream_len, false);
+}
+
+// the 2D coder's stream of a slice (dims = {x, y, 1}) from the same formulation on the 2D forest
+int model_speck2d_encode(const uint64_t* coeffs, const uint64_t* signs, const size_t dims[3],
+                         size_t budget_bits, uint8_t** stream, size_t* stream_len)
+{
+  return model_encode_impl(coeffs, signs, dims, budget_bits, stream, stream_len, true);
 }
 
 

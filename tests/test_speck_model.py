@@ -223,3 +223,26 @@ def test_model_2d_decoder_on_the_mixed_machinery(oracle, model, shape, window, h
                                                       c1.ctypes.data, s1.ctypes.data, window, hmax) == 0
                 assert np.array_equal(c0, c1), (shape, scale, budget, cut)
                 assert np.array_equal(s0, s1)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (17, 23), (64, 64), (99, 100), (40, 9), (128, 96), (9, 9), (200, 33), (8, 8), (5, 300)])
+@pytest.mark.parametrize("budget", [0, 1500, 40000])
+def test_model_2d_encoder_on_the_shared_forest(oracle, model, shape, budget):
+    """The count -> scan -> scatter formulation of the 3D encoder on the 2D coder's forest, with the
+    type-I phase the kernel k_enc_iphase runs (tests/model/speck_model.cpp::model_speck2d_encode):
+    the oracle's SPECK2D stream, byte for byte."""
+    lib = model
+    lib.model_speck2d_encode.argtypes = [_vp, _vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+    lib.model_speck2d_encode.restype = C.c_int
+    dy, dx = shape
+    for scale in (3000.0, 4294967295.0):
+        coef3, sign = quantized(oracle, (1, dy, dx), scale)
+        coef = np.ascontiguousarray(coef3.reshape(dy, dx), dtype=np.uint64)
+        want = _speck2d_oracle(oracle, coef, sign, budget)
+        out, n = _vp(None), _sz(0)
+        assert lib.model_speck2d_encode(coef.ctypes.data, sign.ctypes.data, (_sz * 3)(dx, dy, 1), budget,
+                                        C.byref(out), C.byref(n)) == 0
+        got = C.string_at(out.value, n.value)
+        C.CDLL(None).free(out)
+        assert got[:9] == want[:9], (shape, scale, budget)
+        assert got == want, (shape, scale, budget)
