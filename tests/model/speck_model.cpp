@@ -1431,4 +1431,293 @@ int model_check_classes(const size_t dims[3])
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// SPECK1D (the coder of the outlier list, src/SPECK1D_INT*.cpp) in the formulations of
+// sperr_amd/csrc/outlier.hip: the ENCODER gives every outlier of a significant run one path of its
+// own, found from its position and its two neighbours (expand_enc); the DECODER parses a whole path
+// per step, the run lengths along it in closed form from the bits (expand_dec).  Arrays of at least
+// four values (shorter ones keep the serial walk in the kernel).
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Bits1D {
+  std::vector<uint64_t> w;
+  uint64_t n = 0;
+  void put(int b)
+  {
+    if ((n >> 6) >= w.size())
+      w.resize((n >> 6) + 2, 0);
+    if (b)
+      w[n >> 6] |= 1ull << (n & 63);
+    n++;
+  }
+  void zeros(uint64_t k)
+  {
+    n += k;
+    if ((n >> 6) >= w.size())
+      w.resize((n >> 6) + 2, 0);
+  }
+};
+struct Run1D {
+  uint32_t s, l;
+};
+}  // namespace
+
+int model_speck1d_encode(const uint64_t* coef, const uint64_t* signmask, size_t n, uint8_t** stream,
+                         size_t* stream_len)
+{
+  if (n < 4)
+    return -1;
+  std::vector<uint32_t> pos;
+  std::vector<int> msb;
+  for (size_t i = 0; i < n; i++)
+    if (coef[i]) {
+      pos.push_back((uint32_t)i);
+      msb.push_back(msb_of(coef[i]));
+    }
+  int nbp = 0;
+  for (int m : msb)
+    nbp = std::max(nbp, m + 1);
+  const uint32_t nlists = (uint32_t)num_of_partitions(n) + 1;
+  std::vector<std::vector<Run1D>> lists(nlists + 2);
+  lists[1].push_back({0u, (uint32_t)(n - n / 2)});
+  lists[1].push_back({(uint32_t)(n - n / 2), (uint32_t)(n / 2)});
+  std::vector<char> lip(n, 0);
+  Bits1D out;
+  auto sign_of = [&](uint32_t x) { return (int)((signmask[x >> 6] >> (x & 63)) & 1); };
+  for (int p = nbp - 1; p >= 0; p--) {
+    std::vector<uint32_t> ge;   // positions of the outliers at or above the threshold, ascending
+    for (size_t k = 0; k < pos.size(); k++)
+      if (msb[k] >= p)
+        ge.push_back(pos[k]);
+    // LIP pass
+    for (size_t x = 0; x < n; x++)
+      if (lip[x]) {
+        const bool sig = coef[x] && msb_of(coef[x]) == p;
+        out.put(sig);
+        if (sig) {
+          out.put(sign_of((uint32_t)x));
+          lip[x] = 0;
+        }
+      }
+    // LIS pass, smallest sets first
+    for (uint32_t lev = nlists; lev-- > 0;) {
+      std::vector<Run1D> cur;
+      cur.swap(lists[lev]);
+      for (const Run1D& r : cur) {
+        const size_t a = std::lower_bound(ge.begin(), ge.end(), r.s) - ge.begin();
+        const size_t e = std::lower_bound(ge.begin(), ge.end(), r.s + r.l) - ge.begin();
+        if (e == a) {
+          out.put(0);
+          lists[lev].push_back(r);   // (kept entries stay in front of what is born into this level later)
+          continue;
+        }
+        out.put(1);
+        if (r.l < 2)
+          return -2;
+        // ---- expand_enc: one path per outlier of the run
+        for (size_t k = a; k < e; k++) {
+          const uint32_t x = ge[k];
+          const bool hasPrev = k > a, hasNext = k + 1 < e;
+          const uint32_t prev = hasPrev ? ge[k - 1] : 0, next = hasNext ? ge[k + 1] : 0;
+          if (hasPrev)
+            out.put(1);   // the closing '1' of the parked half this outlier lies in
+          uint32_t s0 = r.s, l0 = r.l, nz = 0;
+          for (uint32_t d = 0; l0 > 1; d++) {
+            const uint32_t lvl = lev + d + 1, h0 = l0 - l0 / 2, r0 = l0 / 2;
+            const bool left = x < s0 + h0;
+            const bool owned = !(hasPrev && prev >= s0);
+            const bool nextIn = hasNext && next < s0 + l0;
+            if (owned)
+              out.put(left);
+            const bool closes = left && !nextIn;
+            nz += closes;
+            if ((owned && !left) || closes) {
+              const uint32_t bs = left ? s0 + h0 : s0, bl = left ? r0 : h0;
+              if (bl == 1)
+                lip[bs] = 1;
+              else {
+                if (lvl >= lists.size())
+                  return -3;
+                lists[lvl].push_back({bs, bl});
+              }
+            }
+            if (left)
+              l0 = h0;
+            else {
+              s0 += h0;
+              l0 = r0;
+            }
+          }
+          out.put(sign_of(x));
+          out.zeros(nz);
+        }
+      }
+    }
+    // refinement pass: the values found on earlier planes, in position order
+    for (size_t k = 0; k < pos.size(); k++)
+      if (msb[k] > p)
+        out.put((int)((coef[pos[k]] >> p) & 1));
+  }
+  const uint64_t total = nbp ? out.n : 0;
+  const size_t nbytes = (size_t)((total + 7) / 8);
+  out.w.resize(nbytes / 8 + 2, 0);
+  uint8_t* o = (uint8_t*)calloc(9 + nbytes + 8, 1);
+  o[0] = (uint8_t)nbp;
+  memcpy(o + 1, &total, 8);
+  memcpy(o + 9, out.w.data(), nbytes);
+  *stream = o;
+  *stream_len = 9 + nbytes;
+  return 0;
+}
+
+int model_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* coef, uint64_t* signmask)
+{
+  if (n < 4 || len < 9)
+    return -1;
+  const int nbp = stream[0];
+  uint64_t total;
+  memcpy(&total, stream + 1, 8);
+  std::vector<uint64_t> w((len - 9) / 8 + 3, 0);
+  memcpy(w.data(), stream + 9, len - 9);
+  uint64_t rpos = 0;
+  auto window = [&]() -> uint64_t {
+    const uint64_t wi = rpos >> 6;
+    const uint32_t sh = (uint32_t)(rpos & 63);
+    const uint64_t w0 = wi < w.size() ? w[wi] : 0, w1 = wi + 1 < w.size() ? w[wi + 1] : 0;
+    return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+  };
+  auto get = [&]() -> int {
+    const int b = (int)(window() & 1);
+    rpos++;
+    return b;
+  };
+  const uint32_t nlists = (uint32_t)num_of_partitions(n) + 1;
+  std::vector<std::vector<Run1D>> lists(nlists + 2);
+  lists[1].push_back({0u, (uint32_t)(n - n / 2)});
+  lists[1].push_back({(uint32_t)(n - n / 2), (uint32_t)(n / 2)});
+  std::vector<char> lip(n, 0), lsp(n, 0);
+  for (size_t i = 0; i < n; i++)
+    coef[i] = 0;
+  for (size_t i = 0; i < (n + 63) / 64; i++)
+    signmask[i] = 0;
+  std::vector<uint32_t> foundNow;
+  auto found = [&](uint32_t x, int p, int sg) {
+    coef[x] = 1ull << p;
+    if (sg)
+      signmask[x >> 6] |= 1ull << (x & 63);
+    foundNow.push_back(x);
+  };
+  auto born = [&](uint32_t lvl, uint32_t bs, uint32_t bl) -> int {
+    if (bl == 1)
+      lip[bs] = 1;
+    else {
+      if (lvl >= lists.size())
+        return -3;
+      lists[lvl].push_back({bs, bl});
+    }
+    return 0;
+  };
+  for (int p = nbp - 1; p >= 0; p--) {
+    foundNow.clear();
+    for (size_t x = 0; x < n; x++)
+      if (lip[x] && get()) {
+        found((uint32_t)x, p, get());
+        lip[x] = 0;
+      }
+    for (uint32_t lev = nlists; lev-- > 0;) {
+      std::vector<Run1D> cur;
+      cur.swap(lists[lev]);
+      for (const Run1D& r : cur) {
+        if (!get()) {
+          lists[lev].push_back(r);
+          continue;
+        }
+        if (r.l < 2)
+          return -2;
+        // ---- expand_dec: a whole path per step; parked right halves by level
+        uint32_t ns = r.s, nl = r.l, nlev = lev;
+        uint64_t parked = 0;
+        uint32_t pS[64] = {0}, pL[64] = {0};
+        for (;;) {
+          const uint64_t peek = window();
+          // run length at step t in closed form: the interval at depth t that the complemented bits,
+          // reversed, index
+          uint32_t T = 64;
+          uint32_t lt[33], st[33];
+          uint32_t acc = ns;
+          for (uint32_t t = 0; t < 32; t++) {
+            const uint32_t mk = (1u << t) - 1u;
+            lt[t] = (nl >> t) + (((~(uint32_t)peek & mk) < (nl & mk)) ? 1u : 0u);
+            const uint32_t bt = (uint32_t)(peek >> t) & 1u, h0 = lt[t] - lt[t] / 2, r0 = lt[t] / 2;
+            st[t] = acc;
+            if (lt[t] > 1 && (bt ? h0 : r0) == 1u) {
+              T = t;
+              break;
+            }
+            acc += bt ? 0u : h0;
+          }
+          if (T == 64)
+            return -4;
+          for (uint32_t t = 0; t <= T; t++) {
+            const uint32_t bt = (uint32_t)(peek >> t) & 1u, h0 = lt[t] - lt[t] / 2, r0 = lt[t] / 2;
+            const uint32_t lvl = nlev + 1 + t;
+            if (!bt) {
+              if (born(lvl, st[t], h0))
+                return -3;
+            }
+            else {
+              pS[lvl] = st[t] + h0;
+              pL[lvl] = r0;
+              parked |= 1ull << lvl;
+            }
+          }
+          {
+            const uint32_t bt = (uint32_t)(peek >> T) & 1u, h0 = lt[T] - lt[T] / 2;
+            found(bt ? st[T] : st[T] + h0, p, (int)((peek >> (T + 1)) & 1));
+          }
+          rpos += T + 2;
+          bool nextPath = false;
+          while (parked) {
+            const uint64_t cw = window();
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(parked);
+            const uint32_t z = std::min<uint32_t>(cw ? (uint32_t)__builtin_ctzll(cw) : 64u, cnt);
+            for (uint32_t k = 0; k < z; k++) {   // the z innermost parked halves are born insignificant
+              const uint32_t top = 63u - (uint32_t)__builtin_clzll(parked);
+              parked &= ~(1ull << top);
+              if (born(top, pS[top], pL[top]))
+                return -3;
+            }
+            rpos += z;
+            if (z == cnt)
+              break;
+            rpos++;
+            const uint32_t top = 63u - (uint32_t)__builtin_clzll(parked);
+            parked &= ~(1ull << top);
+            if (pL[top] == 1) {
+              found(pS[top], p, get());
+              continue;
+            }
+            ns = pS[top];
+            nl = pL[top];
+            nlev = top;
+            nextPath = true;
+            break;
+          }
+          if (!nextPath)
+            break;
+        }
+      }
+    }
+    // refinement: the values found on earlier planes, in position order
+    for (size_t x = 0; x < n; x++)
+      if (lsp[x] && get())
+        coef[x] |= 1ull << p;
+    for (uint32_t x : foundNow)
+      lsp[x] = 1;
+  }
+  (void)total;
+  return 0;
+}
+
 }  // extern "C"

@@ -246,3 +246,39 @@ def test_model_2d_encoder_on_the_shared_forest(oracle, model, shape, budget):
         C.CDLL(None).free(out)
         assert got[:9] == want[:9], (shape, scale, budget)
         assert got == want, (shape, scale, budget)
+
+
+@pytest.mark.parametrize("n,k,top", [(4, 2, 3), (5, 5, 9), (100, 7, 200), (1000, 1000, 5), (4097, 300, 5),
+                                     (65536, 1000, 70000), (50000, 20000, 3), (1 << 18, 3000, 2), (777, 1, 1)])
+def test_model_1d_coder_paths(oracle, model, n, k, top):
+    """The coder of the outlier list in the kernels' formulations (tests/model/speck_model.cpp::
+    model_speck1d_encode / _decode): the encoder gives every outlier of a significant run one path found from
+    its position and its neighbours, the decoder parses a whole path per step with the run lengths in closed
+    form -- the oracle's stream byte for byte, and the values back from it."""
+    from oracle.pyoracle import pack_mask, unpack_mask
+    lib = model
+    lib.model_speck1d_encode.argtypes = [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
+    lib.model_speck1d_encode.restype = C.c_int
+    lib.model_speck1d_decode.argtypes = [_vp, _sz, _sz, _vp, _vp]
+    lib.model_speck1d_decode.restype = C.c_int
+    rng = np.random.default_rng(n + k)
+    for rep in range(3):
+        coef = np.zeros(n, dtype=np.uint64)
+        pos = rng.choice(n, size=min(k, n), replace=False)
+        if rep == 2:   # clustered outliers
+            pos = np.unique(np.clip(pos // 7 + n // 3, 0, n - 1))
+        coef[pos] = rng.integers(1, top + 1, size=pos.size, dtype=np.uint64)
+        sign = rng.integers(0, 2, size=n).astype(bool)
+        want = oracle.speck1d_encode(coef, sign)
+        sm = pack_mask(sign)
+        out, ln = _vp(None), _sz(0)
+        assert lib.model_speck1d_encode(coef.ctypes.data, sm.ctypes.data, n, C.byref(out), C.byref(ln)) == 0
+        got = C.string_at(out.value, ln.value)
+        C.CDLL(None).free(out)
+        assert got == want, (n, k, top, rep)
+        buf = np.frombuffer(want, dtype=np.uint8)
+        c2 = np.zeros(n, dtype=np.uint64)
+        s2 = np.zeros((n + 63) // 64, dtype=np.uint64)
+        assert lib.model_speck1d_decode(buf.ctypes.data, buf.size, n, c2.ctypes.data, s2.ctypes.data) == 0
+        assert np.array_equal(c2, coef), (n, k, top, rep)
+        assert np.array_equal(unpack_mask(s2, n)[coef > 0], sign[coef > 0])
