@@ -1371,9 +1371,9 @@ int model_speck2d_decode_mixed(const uint8_t* stream, size_t len, const size_t d
 }
 
 // every set node against its shape class (tests/test_speck_model.py::test_shape_classes_are_consistent)
-int model_check_classes(const size_t dims[3])
+static int check_classes_impl(const size_t dims[3], bool twoD)
 {
-  HostTree ht = build_tree(dims[0], dims[1], dims[2]);
+  HostTree ht = build_tree(dims[0], dims[1], dims[2], twoD);
   if (ht.cls.empty())
     return -2;
   const Tree t = ht.view();
@@ -1718,6 +1718,17 @@ int model_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* 
   }
   (void)total;
   return 0;
+}
+
+int model_check_classes(const size_t dims[3])
+{
+  return check_classes_impl(dims, false);
+}
+
+// the same for the 2D coder's forest of a slice (dims = {x, y, 1})
+int model_check_classes_2d(const size_t dims[3])
+{
+  return check_classes_impl(dims, true);
 }
 
 }  // extern "C"

@@ -172,6 +172,10 @@ def test_shape_classes_are_consistent(model):
     for dims in [(250, 250, 250), (129, 129, 129), (100, 70, 33), (96, 96, 96), (17, 300, 21), (1, 1, 9),
                  (80, 80, 80), (64, 64, 320), (30, 40, 8), (2, 3, 5)]:
         assert lib.model_check_classes((_sz * 3)(*dims)) == 0, dims
+    lib.model_check_classes_2d.argtypes = [_vp]
+    lib.model_check_classes_2d.restype = C.c_int
+    for dims in [(999, 999, 1), (64, 64, 1), (17, 23, 1), (300, 9, 1), (128, 96, 1), (1, 50, 1), (1024, 1000, 1)]:
+        assert lib.model_check_classes_2d((_sz * 3)(*dims)) == 0, dims   # (children in the 2D coder's order)
 
 
 def _speck2d_oracle(oracle, coef2d, sign, budget):
