@@ -864,3 +864,16 @@ def test_many_chunks_pwe_in_two_sub_batches(eng, oracle, shape, chunks, tol):
     for as_float in (True, False):
         assert np.array_equal(bits(eng.decompress(dev, as_float).cpu().numpy()),
                               bits(oracle.decomp_3d(want, as_float)))
+
+
+@pytest.mark.parametrize("shape,chunks", [((64, 64, 64), (16, 16, 16)), ((48, 80, 160), (16, 16, 16))])
+@pytest.mark.parametrize("psnr", [60.0, 110.0])
+def test_many_chunks_psnr(eng, oracle, shape, chunks, psnr):
+    """PSNR mode with 64 and more chunks of one shape (one batch on the encoder's side, two sub-batches
+    on the decoder's)."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 2, psnr)
+    for _ in range(2):
+        assert bytes(eng.compress(cuda(v), chunks, psnr, mode=2).cpu().numpy()) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
