@@ -375,6 +375,108 @@ k_speck1d(OutlierBufs b)
     }
   };
 
+  // ---- encoder: ALL significant entries of a block of 64 list entries at once.  Most significant runs
+  //      hold a handful of outliers, so a block per run leaves most lanes idle: here the outliers of the
+  //      block's significant entries fill the lanes in list order (a lane finds its entry by a search over
+  //      the entries' running counts).  The '1' of a run's list test is the leading bit of its first
+  //      outlier's code, like the closing '1' of the others; an insignificant entry is one position.
+  auto expand_block = [&](uint64_t myRun, uint32_t myA, uint32_t myB, uint64_t sigmask, uint32_t blockN,
+                          uint32_t lev) {
+    flush_acc();
+    const bool sig = ((sigmask >> lane) & 1ull) != 0;
+    const uint32_t cnt = sig ? myB - myA : 0u;
+    const uint32_t incl = wave_scan_dpp(cnt);
+    const uint32_t T = rdlane(incl, 63);
+    const uint32_t cstart = incl - cnt;
+    const uint32_t insigBefore = (uint32_t)__popcll(~sigmask & low_mask(lane));
+    const uint32_t nInsig = blockN - (uint32_t)__popcll(sigmask);
+    uint64_t carry = 0;   // code bits of the outliers of the chunks before
+    for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+      const uint32_t o = c0 + lane;
+      const bool mine = o < T;
+      uint32_t lo = 0, hi = 64;   // the first entry whose running count exceeds o
+#pragma unroll
+      for (int it = 0; it < 7; it++) {   // (65 possible answers)
+        const uint32_t mid = min((lo + hi) >> 1, 63u);
+        const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid, 64);
+        if (lo < hi) {
+          if (v <= o)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+      }
+      const int j = (int)min(lo, 63u);
+      const uint32_t ja = (uint32_t)__shfl((int)myA, j, 64), jcs = (uint32_t)__shfl((int)cstart, j, 64),
+                     jcnt = (uint32_t)__shfl((int)cnt, j, 64), jins = (uint32_t)__shfl((int)insigBefore, j, 64);
+      const uint32_t js = (uint32_t)__shfl((int)(uint32_t)myRun, j, 64),
+                     jl = (uint32_t)__shfl((int)(uint32_t)(myRun >> 32), j, 64);
+      const uint32_t k = ja + (o - jcs);
+      const uint32_t x = mine ? posGE[k] : 0u;
+      const bool hasPrev = mine && o > jcs, hasNext = mine && o + 1 < jcs + jcnt;
+      const uint32_t prev = hasPrev ? posGE[k - 1] : 0u;
+      const uint32_t next = hasNext ? posGE[k + 1] : 0u;
+      uint64_t code = mine ? 1ull : 0ull;
+      uint32_t nbits = mine ? 1u : 0u, nz = 0;
+      uint32_t s0 = js, l0 = mine ? jl : 0u;
+      for (uint32_t d = 0;; d++) {
+        const bool act = mine && l0 > 1;
+        if (__ballot(act) == 0)
+          break;
+        const uint32_t lvl = lev + d + 1;
+        const uint32_t h0 = l0 - l0 / 2, r0 = l0 / 2;
+        const bool left = x < s0 + h0;
+        const bool owned = !(hasPrev && prev >= s0);
+        const bool nextIn = hasNext && next < s0 + l0;
+        if (act && owned) {
+          code |= (uint64_t)(left ? 1u : 0u) << nbits;
+          nbits++;
+        }
+        const bool closes = act && left && !nextIn;
+        nz += closes ? 1u : 0u;
+        const bool born = (act && owned && !left) || closes;
+        const uint32_t bs = left ? s0 + h0 : s0, bl = left ? r0 : h0;
+        if (born && bl == 1)
+          atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
+        const uint64_t bm = __ballot(born && bl > 1);
+        if (bm) {
+          const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
+          const uint32_t nbn = (uint32_t)__popcll(bm);
+          if (lvl >= b.nlists || first + nbn > rdlane(vEnd, lvl))
+            err = 2;
+          else {
+            if (born && bl > 1)
+              runs[first + (uint32_t)__popcll(bm & low_mask(lane))] = (uint64_t)bs | ((uint64_t)bl << 32);
+            wrlane(vCnt, lvl, have + nbn);
+          }
+        }
+        if (act) {
+          if (left)
+            l0 = h0;
+          else {
+            s0 += h0;
+            l0 = r0;
+          }
+        }
+      }
+      if (mine) {
+        code |= (uint64_t)sgnGE[k] << nbits;
+        nbits++;
+      }
+      const uint32_t len = mine ? nbits + nz : 0u;
+      const uint32_t inc = wave_scan_dpp(len);
+      if (mine) {   // (the leading '1' is always there)
+        const uint64_t at = wpos + jins + carry + (inc - len);
+        const uint32_t sh = (uint32_t)(at & 63);
+        atomicOr(words + (at >> 6), (unsigned long long)(code << sh));
+        if (sh && (code >> (64 - sh)))
+          atomicOr(words + (at >> 6) + 1, (unsigned long long)(code >> (64 - sh)));
+      }
+      carry += rdlane(inc, 63);
+    }
+    wpos += nInsig + carry;
+  };
+
   // ---- decoder: the recursion below one significant run (m_code_S), written as a descent with a
   //      stack of the right halves that still wait for their test bit: a '1' goes down the left
   //      half and parks the right one, a '0' hands the left half to its list (or the LIP) and goes
@@ -727,6 +829,18 @@ k_speck1d(OutlierBufs b)
           myB = e0 >= N ? cpos[nw] : cpos[e0 >> 6] + (uint32_t)__popcll(maskGE[e0 >> 6] & low_mask(e0 & 63u));
         }
         const uint64_t sigmask = ENC ? __ballot(valid && myB > myA) : 0ull;
+        if (ENC && sigmask && __ballot(valid && myB > myA && (uint32_t)(myRun >> 32) < 2u) == 0) {
+          // (runs of two and more values: all the block's significant entries at once)
+          expand_block(myRun, myA, myB, sigmask, blockN, lev);
+          const uint64_t keepM = ~sigmask & low_mask(blockN);
+          if ((keepM >> lane) & 1ull) {
+            const uint32_t dst = wr + (uint32_t)__popcll(keepM & low_mask(lane));
+            if (dst != rd + lane)
+              runs[base + dst] = myRun;
+          }
+          wr += (uint32_t)__popcll(keepM);
+          continue;
+        }
         uint32_t i = 0;
         while (i < blockN) {
           // entries that stay insignificant, up to the next significant one
