@@ -42,6 +42,13 @@ def load_library():
         raise SperrHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch brings a HIP runtime of its own: when the library is loaded first it binds to the system's,
+    # and a process with two runtimes does not see the GPU through the second one.  Callers here move
+    # their data with torch anyway, so its runtime is loaded first and serves both.
+    try:
+        import torch  # noqa: F401
+    except Exception:   # noqa: BLE001  (the loader itself does not need it)
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.sperr_comp_3d.restype = C.c_int
     lib.sperr_comp_3d.argtypes = [_vp, C.c_int, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_double,
