@@ -877,3 +877,15 @@ def test_many_chunks_psnr(eng, oracle, shape, chunks, psnr):
         assert bytes(eng.compress(cuda(v), chunks, psnr, mode=2).cpu().numpy()) == want
     dev = cuda(np.frombuffer(want, dtype=np.uint8))
     assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
+
+
+def test_build_then_smoke_in_one_process():
+    """`python __graft_entry__.py smoke` builds, loads the library and then runs the smoke check in the same
+    process (the library must not bring a second HIP runtime in before torch has loaded its own)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "smoke"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke ok" in r.stdout
