@@ -1,0 +1,6 @@
+// SPECK2D_FLT.h -- the reference's header name for sperr::SPECK2D_FLT (/root/reference/include/SPECK2D_FLT.h),
+// served by the header-only mirrors over the C ABI of libsperr_hip.so (= libSPERR.so).
+#ifndef SPERR_HIP_COMPAT_SPECK2D_FLT_H
+#define SPERR_HIP_COMPAT_SPECK2D_FLT_H
+#include "sperr_helper.h"
+#endif
