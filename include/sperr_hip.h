@@ -207,6 +207,13 @@ int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_m
  * the list levels whose class chain has length K. */
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64);
 
+/* Gives back what the library keeps between calls (it keeps workspaces, shape tables, pinned staging
+ * buffers and device buffers so that the next call does not pay for them again): everything held by
+ * engines and farm workers that are idle, and the calling thread's slice buffers.  Calls running on
+ * other threads are not disturbed.  For hosts that embed the library and call it rarely (an HDF5
+ * filter in a long-running service); never needed for correctness. */
+void sperrhip_release(void);
+
 /* Library/engine identification, e.g. "sperr_hip 0.1 (gfx950)". */
 const char* sperrhip_version(void);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "sperrhip_decompress_2d_dev", "sperrhip_version", "sperrhip_debug_lis_stamps",
     "sperrhip_multires_levels_2d", "sperrhip_decompress_2d_multires_dev", "sperrhip_decomp_2d_multires",
     "sperrhip_comp_3d_farm", "sperrhip_decomp_3d_farm", "sperrhip_decomp_3d_into",
-    "sperrhip_farm_selftest",
+    "sperrhip_farm_selftest", "sperrhip_release",
 ]
 
 
@@ -281,13 +281,29 @@ class SperrHip:
         self._libc.free(dst)
         return out
 
-    def _host_array(self, vol):
+    def _host_array(self, vol, writable=False):
+        """(pointer, shape, is_float) of a host volume.  float32 or float64 only -- anything else would
+        be read with the wrong element size; an output buffer must be C-contiguous (a copy made here
+        would take the values and the caller's array would stay empty)."""
         if isinstance(vol, np.ndarray):
+            if vol.dtype not in (np.float32, np.float64):
+                raise SperrHipError(f"host volumes are float32 or float64, not {vol.dtype}")
+            if writable and not (vol.flags.c_contiguous and vol.flags.writeable):
+                raise SperrHipError("the output array must be C-contiguous and writable")
             vol = np.ascontiguousarray(vol)
             self._keep = vol
             return vol.ctypes.data, vol.shape, int(vol.dtype == np.float32)
-        assert not vol.is_cuda and vol.is_contiguous()
+        if vol.is_cuda or not vol.is_contiguous():
+            raise SperrHipError("a torch host volume must be a contiguous CPU tensor")
+        if vol.dtype not in (self.torch.float32, self.torch.float64):
+            raise SperrHipError(f"host volumes are float32 or float64, not {vol.dtype}")
         return vol.data_ptr(), tuple(vol.shape), int(vol.dtype == self.torch.float32)
+
+    def release(self):
+        """sperrhip_release: idle engines and farm workers give their memory back."""
+        self.lib.sperrhip_release.restype = None
+        self.lib.sperrhip_release.argtypes = []
+        self.lib.sperrhip_release()
 
     def decomp_3d_farm(self, stream, output_float=True, devices=None, nthreads=0):
         buf = np.frombuffer(stream, dtype=np.uint8)
@@ -310,7 +326,7 @@ class SperrHip:
         buf = np.frombuffer(stream, dtype=np.uint8) if isinstance(stream, (bytes, bytearray)) else stream
         sptr = buf.ctypes.data if isinstance(buf, np.ndarray) else buf.data_ptr()
         slen = buf.size if isinstance(buf, np.ndarray) else buf.numel()
-        ptr, shape, is_float = self._host_array(out)
+        ptr, shape, is_float = self._host_array(out, writable=True)
         nbytes = int(np.prod(shape)) * (4 if is_float else 8)
         dx, dy, dz = _sz(0), _sz(0), _sz(0)
         arr, nd = self._devs(devices)

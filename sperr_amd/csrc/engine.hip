@@ -164,6 +164,13 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   size_t n = 0;
+  void drop()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
   int ensure(size_t bytes)
   {
     if (bytes <= n)
@@ -184,14 +191,23 @@ struct Arena {
   template <typename T>
   T* take(size_t count)
   {
+    // sizes may come from an untrusted header: nothing here may wrap
+    if (used > cap || count > (cap - used) / sizeof(T))
+      return nullptr;
     const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
-    if (used + bytes > cap)
+    if (bytes > cap - used)
       return nullptr;
     T* r = reinterpret_cast<T*>(base + used);
     used += bytes;
     return r;
   }
 };
+
+// bytes that hold `bits` bits; bit counts read from a container may be anything up to 2^64 - 1
+inline uint64_t bytes_of_bits(uint64_t bits)
+{
+  return bits / 8 + (bits % 8 != 0);
+}
 
 size_t round_up(size_t v, size_t m)
 {
@@ -519,6 +535,23 @@ struct Engine {
     plans[key] = std::move(p);
     planOrder.push_back(key);
     return raw;
+  }
+  // sperrhip_release(): everything an idle engine holds in HBM goes back (streams and events
+  // stay; the next call sizes the workspaces again).  The engine's device is current.
+  void drop_memory()
+  {
+    for (auto& kv : plans)
+      kv.second->tables.drop();
+    plans.clear();
+    planOrder.clear();
+    for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &slice2d})
+      b->drop();
+    for (auto& b : outlDec)
+      b.drop();
+    for (auto& b : pweBufs)
+      if (b)
+        b->drop();
+    pweBufs.clear();
   }
   // called between calls only (no kernel of this engine is in flight)
   void trim_plans()
@@ -1949,7 +1982,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         continue;
       uint64_t tb;
       memcpy(&tb, hd + 18, 8);
-      const uint64_t speckLen = std::min<uint64_t>(9 + (tb + 7) / 8, ci.len[i] - 17);
+      const uint64_t speckLen = std::min<uint64_t>(9 + bytes_of_bits(tb), ci.len[i] - 17);
       if (17 + speckLen + 9 <= ci.len[i]) {
         tailOff[i] = ci.off[i] + 17 + speckLen;
         tailLen[i] = ci.len[i] - 17 - speckLen;
@@ -1970,7 +2003,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         const uint8_t* t = tails.data() + (size_t)i * 32;
         uint64_t ob;
         memcpy(&ob, t + 1, 8);
-        if (tailLen[i] != 9 + (ob + 7) / 8)
+        if (tailLen[i] != 9 + bytes_of_bits(ob))   // no wrap for ob near 2^64
           continue;
         outHead[i].has = true;
         outHead[i].off = tailOff[i];
@@ -2581,6 +2614,38 @@ static int guarded(const char* what, F&& body) noexcept
 
 extern "C" {
 
+// Gives back what the library keeps between calls: the workspaces and shape tables of every idle
+// engine, the staging and device buffers of every idle farm worker, the calling thread's slice
+// buffers.  Engines and workers in use by other threads are left alone.  For hosts that embed the
+// library (an HDF5 filter, a long-running service) and call it rarely.
+static void thread_slice_bufs_drop();
+void sperrhip_release(void)
+{
+  (void)guarded("sperrhip_release", [&]() -> int {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    {
+      std::unique_lock<std::mutex> lock(g_pool.mu);
+      for (auto& e : g_pool.all) {
+        if (e->busy || e->dev < 0)
+          continue;
+        e->busy = true;            // nobody leases it while its memory goes
+        lock.unlock();
+        if (hipSetDevice(e->dev) == hipSuccess)
+          e->drop_memory();
+        lock.lock();
+        e->busy = false;
+      }
+    }
+    g_pool.cv.notify_all();
+    farm_release_idle();
+    if (have)
+      (void)hipSetDevice(cur);
+    thread_slice_bufs_drop();
+    return 0;
+  });
+}
+
 const char* sperrhip_version(void)
 {
   return "sperr_hip 0.1 (gfx950; SPERR bitstream major version 0)";
@@ -2808,6 +2873,7 @@ int sperrhip_decompress_multires_dev(const void* d_src, size_t src_len, int outp
 // only grow (hipMalloc / hipFree per call would synchronise the device; the stream-ordered allocator
 // handed out blocks whose contents the next call did not see: not used).  Freed with the thread.
 struct ThreadSliceBufs {
+  int dev = -1;          // the device the stream and the buffers belong to
   hipStream_t s = nullptr;
   void* p[2] = {nullptr, nullptr};
   size_t cap[2] = {0, 0};
@@ -2830,19 +2896,73 @@ struct ThreadSliceBufs {
     }
     return p[i];
   }
-  ~ThreadSliceBufs()
+  void drop()
   {
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
       if (p[i])
         (void)hipFree(p[i]);
+      p[i] = nullptr;
+      cap[i] = 0;
+    }
     if (s)
       (void)hipStreamDestroy(s);
+    s = nullptr;
   }
 };
-ThreadSliceBufs& thread_slice_bufs()
+// One set per device the thread has coded slices on: a thread that moves to another device
+// (hipSetDevice between two calls) leases an engine of THAT device, whose arena, sub-streams and
+// events must not meet a stream or buffers of the device it came from.
+struct ThreadSliceCache {
+  std::vector<ThreadSliceBufs> sets;
+  ThreadSliceBufs& of_current_device()
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+      dev = 0;
+    for (auto& b : sets)
+      if (b.dev == dev)
+        return b;
+    sets.emplace_back();
+    sets.back().dev = dev;
+    return sets.back();
+  }
+  ~ThreadSliceCache()
+  {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto& b : sets) {
+      if (have && b.dev != cur)
+        (void)hipSetDevice(b.dev);
+      b.drop();
+    }
+    if (have)
+      (void)hipSetDevice(cur);
+  }
+};
+static ThreadSliceCache& thread_slice_cache()
 {
-  static thread_local ThreadSliceBufs t;
+  static thread_local ThreadSliceCache t;
   return t;
+}
+static ThreadSliceBufs& thread_slice_bufs()
+{
+  return thread_slice_cache().of_current_device();
+}
+static void thread_slice_bufs_drop()
+{
+  ThreadSliceCache& c = thread_slice_cache();
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (auto& b : c.sets) {
+    if (have && b.dev != cur)
+      (void)hipSetDevice(b.dev);
+    if (b.s)
+      (void)hipStreamSynchronize(b.s);
+    b.drop();
+  }
+  c.sets.clear();
+  if (have)
+    (void)hipSetDevice(cur);
 }
 
 // ---- 2D slices (include/SPERR_C_API.h:53-81, src/SPERR_C_API.cpp:7-134) ------------------------

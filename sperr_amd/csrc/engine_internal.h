@@ -27,6 +27,9 @@ int host_parse_container(const uint8_t* p, size_t len, HostContainer& out);
 // upper bound of one chunk stream (conditioner + SPECK headers + payload [+ outlier stream])
 size_t host_chunk_stream_bound(size_t nvals, int mode, double quality);
 
+// farm.hip: the buffers of every idle farm worker go back (sperrhip_release)
+void farm_release_idle();
+
 }  // namespace sperrhip
 
 #endif

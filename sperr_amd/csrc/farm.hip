@@ -35,6 +35,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -178,11 +179,21 @@ void parallel_do(size_t nthreads, F&& fn)
     fn(size_t(0));
     return;
   }
+  // a thread that cannot be started (std::system_error) must not leave started ones joinable:
+  // its share is done by the caller instead
   std::vector<std::thread> th;
   th.reserve(nthreads - 1);
-  for (size_t t = 1; t < nthreads; t++)
-    th.emplace_back([&fn, t]() { fn(t); });
-  fn(size_t(0));
+  std::vector<size_t> mine = {0};
+  for (size_t t = 1; t < nthreads; t++) {
+    try {
+      th.emplace_back([&fn, t]() { fn(t); });
+    }
+    catch (const std::system_error&) {
+      mine.push_back(t);
+    }
+  }
+  for (size_t t : mine)
+    fn(t);
   for (auto& t : th)
     t.join();
 }
@@ -312,6 +323,30 @@ WorkerCtx* ctx_acquire(int dev)
   return g_ctx.back().get();
 }
 
+}  // namespace (reopened below)
+// sperrhip_release(): the buffers of every idle worker go back (the worker and its stream stay)
+void farm_release_idle()
+{
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  for (auto& c : g_ctx) {
+    if (c->busy)
+      continue;
+    if (hipSetDevice(c->dev) != hipSuccess)
+      continue;
+    if (c->pinIn)
+      (void)hipHostFree(c->pinIn);
+    if (c->pinOut)
+      (void)hipHostFree(c->pinOut);
+    if (c->dIn)
+      (void)hipFree(c->dIn);
+    if (c->dOut)
+      (void)hipFree(c->dOut);
+    c->pinIn = c->pinOut = c->dIn = c->dOut = nullptr;
+    c->pinInCap = c->pinOutCap = c->dInCap = c->dOutCap = 0;
+  }
+}
+namespace {
+
 void ctx_release(WorkerCtx* c)
 {
   // staging memory above SPERR_HIP_FARM_KEEP_MB (default 4096) per worker is given back
@@ -436,6 +471,10 @@ struct Job {
   const HostContainer* hc = nullptr;
   int output_float = 1;
   uint8_t* dstVol = nullptr;
+  Job() = default;
+  Job(const Job&) = delete;
+  Job& operator=(const Job&) = delete;
+  ~Job() { free(outBuf); }   // (whatever ends the call early; handed over = set to nullptr)
 };
 
 int comp_item(Job& J, WorkerCtx& C, const Item& it)
@@ -594,9 +633,19 @@ int run_workers(Job& J, F&& doItem)
     (void)hipStreamSynchronize(C->st);
     ctx_release(C);
   };
-  // the calling thread keeps its current device: all workers are threads of their own
-  for (size_t w = 0; w < nw; w++)
-    th.emplace_back(body, w);
+  // the calling thread keeps its current device: all workers are threads of their own (the items
+  // come from a shared queue, so fewer workers than planned still do all of them; none at all fails)
+  th.reserve(nw);
+  for (size_t w = 0; w < nw; w++) {
+    try {
+      th.emplace_back(body, w);
+    }
+    catch (const std::system_error&) {
+      break;
+    }
+  }
+  if (th.empty())
+    J.failed = -1;
   for (auto& t : th)
     t.join();
   return J.failed.load();
@@ -677,27 +726,30 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
   }
 
   const int rc = run_workers(J, comp_item);
-  if (rc) {
-    free(J.outBuf);
+  if (rc)
     return rc;
-  }
 
   // header (src/SPERR3D_OMP_C.cpp:163-234) + the chunk streams back to back
   size_t total = hdr;
   for (size_t i = 0; i < nchunks; i++) {
-    if (J.chunkLen[i] > 0xffffffffull) {
-      free(J.outBuf);
+    if (J.chunkLen[i] > 0xffffffffull)
       return -1;
-    }
     total += J.chunkLen[i];
   }
+  std::vector<size_t> at;
+  if (!inPlace) {
+    at.assign(nchunks + 1, hdr);
+    for (size_t i = 0; i < nchunks; i++)
+      at[i + 1] = at[i] + J.chunkLen[i];
+  }
   uint8_t* out = J.outBuf;
+  J.outBuf = nullptr;   // nothing below throws
   if (inPlace) {
-    size_t at = hdr;
+    size_t to = hdr;
     for (size_t i = 0; i < nchunks; i++) {   // (moves nothing when every stream fills its slot)
-      if (at != J.slotOff[i])
-        memmove(out + at, out + J.slotOff[i], J.chunkLen[i]);
-      at += J.chunkLen[i];
+      if (to != J.slotOff[i])
+        memmove(out + to, out + J.slotOff[i], J.chunkLen[i]);
+      to += J.chunkLen[i];
     }
     if (total < J.slotOff[nchunks]) {
       uint8_t* shrunk = static_cast<uint8_t*>(realloc(out, total));
@@ -709,9 +761,6 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     out = static_cast<uint8_t*>(malloc(total));
     if (!out)
       return -1;
-    std::vector<size_t> at(nchunks + 1, hdr);
-    for (size_t i = 0; i < nchunks; i++)
-      at[i + 1] = at[i] + J.chunkLen[i];
     const size_t nt = std::max<size_t>(1, std::min<size_t>(J.fs.helpers * J.workerDev.size(), nchunks));
     parallel_do(nt, [&](size_t t) {
       for (size_t i = nchunks * t / nt; i < nchunks * (t + 1) / nt; i++)

@@ -139,3 +139,41 @@ def test_header_with_absurd_dimensions_is_rejected(eng):
             eng.decomp_3d(bytes(bad))
         with pytest.raises(SperrHipError):
             eng.trunc_3d(bytes(bad), 50)
+
+
+def test_bit_counts_near_2_to_64_do_not_wrap(eng):
+    """A PWE chunk whose outlier header claims 2^64 - k bits (k < 8) with nothing behind it: rounding
+    the bit count up to bytes must not wrap to zero (the 9-byte tail would pass for a complete outlier
+    stream and every buffer sized from it would be tiny).  The same for the SPECK header's count.
+    The decoder may reject the container or decode it without outliers; afterwards the undamaged
+    container gives what it gave before."""
+    v = (turbulence((24, 24, 24), seed=9, dtype=np.float64) +
+         0.3 * (np.random.default_rng(2).random((24, 24, 24)) < 0.1)).astype(np.float32)
+    for chunks, nchunk in (((24, 24, 24), 1), ((24, 24, 8), 3)):     # one chunk; eight-divisible batches aside
+        good = eng.compress(cuda(v), chunks, 1e-3, mode=3).cpu().numpy()
+        ref = eng.decompress(cuda(good), True).cpu().numpy()
+        hdr = (14 if nchunk == 1 else 20) + 4 * nchunk
+        lens = np.frombuffer(good[hdr - 4 * nchunk:hdr].tobytes(), dtype=np.uint32).astype(np.int64)
+        assert hdr + lens.sum() == len(good)
+        tb = int(np.frombuffer(good[hdr + 18:hdr + 26].tobytes(), dtype=np.uint64)[0])
+        speck_end = hdr + 26 + (tb + 7) // 8          # first chunk: outlier header starts here
+        assert speck_end + 9 < hdr + lens[0], "first chunk has no outlier stream; pick a noisier field"
+        for k in (1, 3, 7, 8, 9):
+            # chunk 0 cut right behind its outlier header, which now claims 2^64 - k bits
+            bad = np.concatenate([good[:speck_end + 9], good[hdr + lens[0]:]]).copy()
+            bad[speck_end + 1:speck_end + 9] = np.frombuffer(np.uint64((1 << 64) - k).tobytes(), dtype=np.uint8)
+            newlen = np.uint32(speck_end + 9 - hdr)
+            bad[hdr - 4 * nchunk:hdr - 4 * nchunk + 4] = np.frombuffer(newlen.tobytes(), dtype=np.uint8)
+            try:
+                eng.decompress(cuda(bad), True, shape_zyx=(24, 24, 24))
+            except SperrHipError:
+                pass
+            # the SPECK stream's own count
+            bad2 = good.copy()
+            bad2[hdr + 18:hdr + 26] = np.frombuffer(np.uint64((1 << 64) - k).tobytes(), dtype=np.uint8)
+            try:
+                eng.decompress(cuda(bad2), True, shape_zyx=(24, 24, 24))
+            except SperrHipError:
+                pass
+        again = eng.decompress(cuda(good), True).cpu().numpy()
+        assert np.array_equal(ref.view(np.uint32), again.view(np.uint32))
