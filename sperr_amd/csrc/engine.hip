@@ -652,6 +652,24 @@ struct Lease {
   Lease& operator=(const Lease&) = delete;
 };
 
+// How much workspace a call may use: 80 % of what is free plus what the engine already holds --
+// or SPERR_HIP_ARENA_MAX_MB when that is less (a soft cap: it bounds how many chunks of a batch
+// are in flight together, one chunk is always allowed; for hosts that share the device, and for
+// tests that want a volume NOT to fit).
+size_t arena_cap_env()
+{
+  const char* v = getenv("SPERR_HIP_ARENA_MAX_MB");   // read per call: a test changes it
+  return v ? (size_t)std::max(1ll, atoll(v)) << 20 : ~size_t(0);
+}
+size_t arena_room(size_t have, size_t freeNow)
+{
+  return std::min((size_t)((freeNow + have) * 0.80), arena_cap_env());
+}
+size_t arena_budget(size_t have, size_t freeNow)
+{
+  return std::min(std::max(have, (size_t)((freeNow + have) * 0.80)), arena_cap_env());
+}
+
 // bytes of workspace one chunk of this shape needs
 struct EncSizes {
   size_t streamWords, maskWords, perChunk;
@@ -1441,7 +1459,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   if (sideBySide) {
     size_t fr = 0, tot = 0, need = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
-    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    const size_t budgetBytes = arena_budget(E.arena.n, fr);
     for (auto& g : groups) {
       ShapePlan* P = E.plan(g.first[0], g.first[1], planZ(g.first));
       groupOff.push_back(need);
@@ -1468,7 +1486,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     const size_t per = enc_bytes_per_chunk(*P, raw_budget);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
-    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    const size_t budgetBytes = arena_budget(E.arena.n, fr);
     uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
     B = std::min<uint32_t>(B, 256);
     if (sideBySide)
@@ -2106,7 +2124,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       }
       size_t fr = 0, tot = 0;
       HIP_CHECK(hipMemGetInfo(&fr, &tot));
-      const size_t room = (size_t)((fr + E.arena.n) * 0.80);
+      const size_t room = arena_room(E.arena.n, fr);
       if (E.arena.ensure(std::min(sum, room)))
         return -1;
     }
@@ -2116,7 +2134,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     const size_t per = bytes_per_chunk(*P, maxPayload);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
-    const size_t budgetBytes = std::max(E.arena.n, (size_t)((fr + E.arena.n) * 0.80));
+    const size_t budgetBytes = arena_budget(E.arena.n, fr);
     uint32_t B = (uint32_t)std::min<size_t>(g.second.size(), std::max<size_t>(1, budgetBytes / per));
     B = std::min<uint32_t>(B, 256);
     const size_t needBytes = (size_t)B * per + (1 << 20);

@@ -141,3 +141,54 @@ def test_device_pointers_through_the_host_entry_points(eng, oracle):
                                          C.byref(d[0]), C.byref(d[1]), C.byref(d[2]))
     assert rc == 0 and (d[0].value, d[1].value, d[2].value) == (80, 64, 48)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.decomp_3d(want, True).view(np.uint32))
+
+
+def test_config5_shape_pinned_pwe_256_cubes_streamed(eng, oracle):
+    """BASELINE config 5 at its own shape on one GPU: a PINNED fp32 volume of 16 chunks of 256^3
+    (512 x 512 x 1024), point-wise error mode with the outlier coder, streamed through the farm in
+    work items of 2 chunks by 3 workers, the engines' workspace capped (SPERR_HIP_ARENA_MAX_MB) so
+    that neither the volume's fp64 chunk buffers nor a whole item's workspace could be resident at
+    once: container byte-identical to the oracle's (its OpenMP chunk loop on all host threads, the
+    reference's src/SPERR3D_OMP_C.cpp:94-130 + src/SPECK_FLT.cpp:461-486), decoded floats
+    bit-identical, tolerance met -- and the same once from pageable memory."""
+    import torch
+    from sperr_amd.synth import turbulence_torch
+    shape, chunks = (1024, 512, 512), (256, 256, 256)
+    dvol = turbulence_torch(shape, torch.device("cuda", 0))
+    span = float(dvol.max() - dvol.min())
+    tol = 1e-3 * span
+    pinned = torch.empty(shape, dtype=torch.float32).pin_memory()
+    pinned.copy_(dvol)
+    del dvol
+    torch.cuda.empty_cache()
+    vol = pinned.numpy()
+    nthreads = os.cpu_count() or 8
+    want = oracle.comp_3d(vol, chunks, 3, tol, nthreads=nthreads)
+    ref = oracle.decomp_3d(want, True, nthreads=nthreads)
+    assert float(np.abs(ref.astype(np.float64) - vol).max()) <= tol
+    # every chunk carries an outlier stream at this tolerance? at least most of them must, or the
+    # outlier coder is not what is being tested
+    hdr = 20 + 4 * 16
+    lens = np.frombuffer(want[20:hdr], dtype=np.uint32).astype(np.int64)
+    at, with_outliers = hdr, 0
+    for l in lens:
+        tb = int(np.frombuffer(want[at + 18:at + 26], dtype=np.uint64)[0])
+        with_outliers += int(26 + (tb + 7) // 8 + 9 < l)
+        at += int(l)
+    assert with_outliers >= 8, f"only {with_outliers} of 16 chunks have outliers at tol {tol}"
+
+    with _Env(SPERR_HIP_FARM_ITEM=2, SPERR_HIP_FARM_WORKERS=3, SPERR_HIP_FARM_DEC_WORKERS=3,
+              SPERR_HIP_ARENA_MAX_MB=1024):
+        eng.release()                       # engines sized by earlier tests start from nothing
+        got = eng.comp_3d_farm(pinned, chunks, 3, tol, devices=[0])
+        assert len(got) == len(want) and got == want
+        out = torch.empty(shape, dtype=torch.float32).pin_memory()
+        eng.decomp_3d_into(got, out, devices=[0])
+        assert np.array_equal(out.numpy().view(np.uint32), ref.view(np.uint32))
+        # pageable: rows staged by the helper threads
+        pageable = vol.copy()
+        assert eng.comp_3d_farm(pageable, chunks, 3, tol, devices=[0]) == want
+        pout = np.empty(shape, dtype=np.float32)
+        eng.decomp_3d_into(got, pout, devices=[0])
+        assert np.array_equal(pout.view(np.uint32), ref.view(np.uint32))
+    eng.release()

@@ -9,7 +9,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-args="bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-ragged --no-other-modes"
+args="bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-ragged --no-other-modes --no-small-batch"
 timeout 600 python3 bench.py --size 1024 --steps 5 --warmup 1 --no-ragged --no-other-modes --profile-out $out/engine_events.csv > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $args > $out/trace.log 2>&1
