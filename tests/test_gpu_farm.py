@@ -192,3 +192,75 @@ def test_config5_shape_pinned_pwe_256_cubes_streamed(eng, oracle):
         eng.decomp_3d_into(got, pout, devices=[0])
         assert np.array_equal(pout.view(np.uint32), ref.view(np.uint32))
     eng.release()
+
+
+def _hip_fns(eng):
+    import torch
+
+    def comp(v, c, m, q):
+        return bytes(eng.compress(torch.from_numpy(np.ascontiguousarray(v)).cuda(), c, q, mode=m).cpu().numpy())
+
+    def decomp(s, as_float):
+        return eng.decompress(torch.from_numpy(np.frombuffer(s, dtype=np.uint8).copy()).cuda(), as_float).cpu().numpy()
+
+    return comp, decomp
+
+
+@pytest.mark.parametrize("shape,chunks,mode,quality",
+                         [((96, 80, 72), (32, 32, 32), 1, 2.0), ((72, 48, 40), (24, 24, 20), 3, 1e-3)])
+def test_process_per_gpu_farm_with_the_hip_compressor(eng, oracle, shape, chunks, mode, quality):
+    """sperr_amd/farm.py (the one-process-per-GPU dealing of bench.py --gpus N) with the HIP engine as
+    the per-rank compressor, world size 1: the stitched container and the scattered volume are the
+    oracle's.  (tests/test_farm_gloo.py runs the same module on two CPU ranks with the oracle.)"""
+    from sperr_amd import farm
+    comp, decomp = _hip_fns(eng)
+    vol = turbulence(shape)
+    want = oracle.comp_3d(vol, chunks, mode, quality)
+    assert farm.farm_compress(vol, chunks, quality, comp, mode=mode) == want
+    back = farm.farm_decompress(want, decomp, True)
+    assert np.array_equal(back.view(np.uint32), oracle.decomp_3d(want, True).view(np.uint32))
+
+
+def _rank_main(rank, world, port, shape, chunks, mode, quality, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sperr_amd import farm
+    from sperr_amd.api import SperrHip
+    comp, decomp = _hip_fns(SperrHip())
+    vol = turbulence(shape)
+    out = farm.farm_compress(vol, chunks, quality, comp, mode=mode)
+    # every rank needs the container to decode its share: rank 0 hands it out
+    box = [out]
+    dist.broadcast_object_list(box, src=0)
+    back = farm.farm_decompress(box[0], decomp, True)
+    if rank == 0:
+        q.put((out, back.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_device_with_the_hip_compressor(oracle):
+    """Two ranks (gloo for the host-side gather, both on cuda:0): each compresses and decodes its
+    half of the chunks on the GPU; rank 0 stitches.  No data-path collective."""
+    import socket
+    import torch.multiprocessing as mp
+    shape, chunks, mode, quality = (64, 64, 96), (32, 32, 32), 1, 2.0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, shape, chunks, mode, quality, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, back = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    vol = turbulence(shape)
+    want = oracle.comp_3d(vol, chunks, mode, quality)
+    assert merged == want
+    assert back == oracle.decomp_3d(want, True).tobytes()
