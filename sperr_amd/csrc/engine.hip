@@ -486,6 +486,8 @@ struct Engine {
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
+  uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
+  hipEvent_t liveEv[kSubStreams][kLiveSlots] = {};
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
   std::vector<std::unique_ptr<DevBuf>> pweBufs;   // outlier streams of the batches of one call
   size_t freeMemAtInit = 0;
@@ -509,6 +511,11 @@ struct Engine {
     for (uint32_t q = 0; q < kSubStreams; q++) {
       HIP_CHECK(hipEventCreateWithFlags(&evOutl[q], hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&evOutlFork[q], hipEventDisableTiming));
+    }
+    for (uint32_t q = 0; q < kSubStreams; q++) {
+      HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&liveHost[q]), kLiveSlots * sizeof(uint32_t), hipHostMallocDefault));
+      for (int k = 0; k < kLiveSlots; k++)
+        HIP_CHECK(hipEventCreateWithFlags(&liveEv[q][k], hipEventDisableTiming));
     }
     ready = true;
     return 0;
@@ -945,6 +952,17 @@ bool fuse_xy(const ShapePlan& P)
     if (P.fwd[0].region[a] != P.dims[a] || P.fwd[1].region[a] != P.dims[a])
       return false;
   return lift_xy_applicable(P.dims);
+}
+
+// ... and the full-size z pass follows (every dyadic shape): all three in one kernel
+bool fuse_xyz(const ShapePlan& P)
+{
+  if (!fuse_xy(P) || P.fwd.size() < 3 || P.fwd[2].axis != 2)
+    return false;
+  for (int a = 0; a < 3; a++)
+    if (P.fwd[2].region[a] != P.dims[a])
+      return false;
+  return lift_xyz_applicable(P.dims);
 }
 
 // LiftFuse of pass k (xform.h): the samples of its region that no LATER pass of the forward order
@@ -1530,15 +1548,24 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
                               orgAligned))
         return -1;
       size_t k0 = 0;
-      if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume
+      // the passes after which samples have their final value also collect the largest magnitude
+      // (src/SPECK_FLT.cpp:282-301): no pass over the coefficients of its own
+      const bool fuseMax = plan_fusable(*P);
+      if (fuse_xyz(*P)) {   // the three full-size passes in one kernel, straight from the volume
+        LiftFuse lf;
+        if (fuseMax && pass_fuse(*P, 2, lf.inner) > 0)
+          lf.mode = 1;
+        if (launch_lift_xyz(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io, const_cast<T*>(d_src), vd,
+                            bb.geom, &lf))
+          return -1;
+        k0 = 3;
+      }
+      else if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume
         if (launch_lift_xy(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io,
                            const_cast<T*>(d_src), vd, bb.geom))
           return -1;
         k0 = 2;
       }
-      // the passes after which samples have their final value also collect the largest magnitude
-      // (src/SPECK_FLT.cpp:282-301): no pass over the coefficients of its own
-      const bool fuseMax = plan_fusable(*P);
       for (size_t k = k0; k < P->fwd.size(); k++) {
         const LiftPass& ps = P->fwd[k];
         LiftFuse lf;
@@ -1863,6 +1890,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
     d.hiAhead = ahead;
     static const uint32_t extra = getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_EXTRA")) : 1u;
     d.hiExtra = extra;
+    static const uint32_t hop2 = getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_HOP2")) : 1u;
+    d.hiHop2 = hop2;
   }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
   d.hiW = hi_window((int)d.hiK, d.hiSmemBytes);
@@ -2304,13 +2333,18 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        use_tables(*P), P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
-        ph.skipFinish = true;   // launch_inv_quantize below completes the coefficients
+        // launch_inv_quantize / the dequantising inverse passes complete the coefficients that were never
+        // refined from the decoder's masks -- the fused x-y-z pass reads coefficients and signs only, so
+        // k_dec_finish does it for a plan that takes that pass
+        ph.skipFinish = !fuse_xyz(*P);
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
         static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
         ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;
+        ph.h_live = E.liveHost[q % kSubStreams];
+        ph.liveEv = E.liveEv[q % kSubStreams];
         // the inverse passes dequantise on the way (not for the resolution hierarchy, whose coarsest
         // level is read before any pass has run)
         const bool fuseDq = plan_fusable(*P) && !mr && !slice;
@@ -2377,7 +2411,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the last inverse pass covers the whole chunk: it adds the mean, narrows and scatters --
         // unless outlier correctors have to be added to the transformed values first
         // (src/SPECK_FLT.cpp:573-590), in which case every pass stays in the chunk buffer
-        const bool fxy = fuse_xy(*P) && !batchOutliers;
+        const bool fxyz = fuse_xyz(*P) && !batchOutliers;
+        const bool fxy = fuse_xy(*P) && !batchOutliers && !fxyz;
         // a level of the inverse transform is 3 passes (z y x) of a dyadic chunk, 2 (y x) of a slice
         const size_t perLevel = slice ? 2 : 3;
         auto sub_volume = [&](size_t k) -> int {   // before pass k, the first of its level
@@ -2389,11 +2424,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
                    mr->grid[0], mr->grid[1], mr->d_level[h]);
           return 0;
         };
-        for (size_t k = P->fwd.size(); k-- > (fxy ? 2u : 0u);) {
-          const LiftPass& ps = P->fwd[k];
-          if (mr && mr->nlev && k % perLevel == perLevel - 1 && sub_volume(k))
-            return -1;
-          LiftFuse lf;
+        auto dequant_fuse = [&](size_t k, LiftFuse& lf) {
           if (fuseDq && pass_fuse(*P, k, lf.inner) > 0) {
             lf.mode = 2;
             lf.coef = bb.coef32;
@@ -2405,9 +2436,25 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             lf.maskStride = d.maskPixStride;
             lf.dst = d.st;
           }
+        };
+        for (size_t k = P->fwd.size(); k-- > (fxyz ? 3u : fxy ? 2u : 0u);) {
+          const LiftPass& ps = P->fwd[k];
+          if (mr && mr->nlev && k % perLevel == perLevel - 1 && sub_volume(k))
+            return -1;
+          LiftFuse lf;
+          dequant_fuse(k, lf);
           if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
                           (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
                           d_dst, vd, bb.geom, &lf))
+            return -1;
+        }
+        if (fxyz) {   // the finest level: z, y and x pass in one kernel, into the volume
+          if (mr && mr->nlev && sub_volume(2))
+            return -1;
+          LiftFuse lf;
+          dequant_fuse(2, lf);
+          if (launch_lift_xyz(ss, false, bb.vals, bb.valsStride, nb, cd, d.cst, std::is_same<T, float>::value ? 1 : 2,
+                              d_dst, vd, bb.geom, &lf))
             return -1;
         }
         if (fxy && mr && mr->nlev && slice && sub_volume(1))   // the finest level of a slice is the fused pair

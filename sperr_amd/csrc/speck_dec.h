@@ -122,6 +122,7 @@ struct DecBuffers {
   uint32_t hiW;                // region bits (tab_window of the shape's longest class chain)
   uint32_t hiK;                // classes the LDS tables have room for
   uint32_t hiSmemBytes;        // dynamic LDS given to k_lis_hi
+  uint32_t hiHop2;             // the next class's pointer-jump table is built ahead of the chain (else on demand)
   uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for (<= 8)
   uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
   uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
@@ -145,13 +146,17 @@ struct DecPlanHost {
   bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
   // Fixed-rate streams run out of bits many planes above plane 0, and the launches of a plane that
-  // holds no work still cost about 0.1 ms per batch.  With d_live set (a device word) the launcher
-  // asks after 16 planes, and then after every fourth, how many chunks still decode -- a small
-  // kernel, a copy and a wait for the stream -- and stops launching when none does.  Only for a
-  // caller whose host thread may wait for this stream (the other sub-batches of a call are enqueued
-  // by threads of their own).
+  // holds no work still cost about 0.1 ms per batch.  With d_live set (kLiveSlots device words) the
+  // launcher asks after 16 planes, and then after every second, how many chunks still decode -- a
+  // small kernel, a copy into h_live (pinned) and an event -- and stops launching when the answer to
+  // the PREVIOUS question is "none": the host waits for an event that lies two planes back in the
+  // queue, never for the stream itself, so the device does not run dry.  Only for a caller whose
+  // host thread may block (the other sub-batches of a call are enqueued by threads of their own).
   uint32_t* d_live = nullptr;
+  uint32_t* h_live = nullptr;
+  hipEvent_t* liveEv = nullptr;
 };
+constexpr int kLiveSlots = 24;
 
 constexpr int kTabWMax = 28672;   // window bits: < 2^15 (table entries keep a flag in bit 15)
 // LDS bytes per window bit for a level with chain length K: T_0..T_{K-2} and U_0..U_{K-1} (u16

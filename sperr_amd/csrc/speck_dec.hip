@@ -4159,7 +4159,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       build_tables(lv, 0, K);
       if (stamps) dbg1 = __builtin_readcyclecounter();
       build_hop(hop, Kh - 1);
-      if (Kh < K)
+      const bool hop2Now = Kh < K && b.hiHop2;
+      if (hop2Now)
         build_hop(hop2, Kh);
       if (stamps) dbg2 = __builtin_readcyclecounter();
       if (tid < 64) {   // which lists the tables serve: one lane per level
@@ -4167,7 +4168,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         if (tid == 0) {
           sh_tabK = K;
           sh_hopTop[0] = Kh - 1;
-          sh_hopTop[1] = Kh < K ? Kh : -1;
+          sh_hopTop[1] = hop2Now ? Kh : -1;
           sh_serve = m;
         }
       }
@@ -5229,14 +5230,23 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
                dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
+    // Have the chunks run out of bits?  Asked after 16 planes and then after every second one, and
+    // answered ONE QUESTION LATE: the host waits for the answer to the previous question while the
+    // planes launched since are still queued, so the device never runs dry (a wait for the stream
+    // itself drained it twice or three times per batch).
     const int planesDone = maxPlanes - p;
-    if (plan.d_live && p > 0 && planesDone >= 16 && planesDone % 4 == 0) {
-      uint32_t live = 1;
-      LAUNCH_K(k_dec_live, dim3(1), dim3(kThreads), 0, stream, b, plan.d_live);
-      HIP_CHECK(hipMemcpyAsync(&live, plan.d_live, sizeof(live), hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
-      if (live == 0)
-        break;   // (every launch below would return at once)
+    if (plan.d_live && p > 0 && planesDone >= 16 && planesDone % 2 == 0 && plan.h_live && plan.liveEv) {
+      const int k = (planesDone - 16) / 2;
+      if (k < kLiveSlots) {
+        LAUNCH_K(k_dec_live, dim3(1), dim3(kThreads), 0, stream, b, plan.d_live + k);
+        HIP_CHECK(hipMemcpyAsync(plan.h_live + k, plan.d_live + k, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipEventRecord(plan.liveEv[k], stream));
+        if (k >= 1) {
+          HIP_CHECK(hipEventSynchronize(plan.liveEv[k - 1]));
+          if (plan.h_live[k - 1] == 0)
+            break;   // (every launch below would return at once)
+        }
+      }
     }
   }
   {

@@ -62,6 +62,16 @@ int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsSt
                    uint32_t nchunks, const uint32_t cdims[3], const CoderState* st, int io,
                    void* volume, VolDesc vd, const ChunkGeom* geom);
 
+// The x, y AND z pass of the finest level in one kernel (k_lift_xyz_fwd / _inv): the z direction is
+// a sliding window of per-position lifting pipelines in registers.  Forward: volume -> vals, with
+// the largest magnitude collected when fuse->mode == 1; inverse: (coefficients dequantised on the
+// way when fuse->mode == 2, never-refined ones already completed by k_dec_finish) -> volume.  Only
+// for chunks whose first three passes are the full-size x, y and z ones and whose rows fit.
+bool lift_xyz_applicable(const uint32_t cdims[3]);
+int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsStride, uint32_t nchunks,
+                    const uint32_t cdims[3], CoderState* st, int io, void* volume, VolDesc vd,
+                    const ChunkGeom* geom, const LiftFuse* fuse);
+
 // have_max: CoderState::maxabs is already there (the lifting passes collected it)
 int launch_maxabs_q(hipStream_t stream, const double* vals, size_t valsStride, uint32_t nchunks,
                     uint32_t n, CoderState* st, bool have_max = false);

@@ -713,6 +713,459 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
 }
 
 // ------------------------------------------------------------------------------------------
+// The THREE passes of the finest level fused with the volume access (round 3): the z pass joins
+// k_lift_xy's x and y passes, so the fp64 chunk buffer is written once (forward) / the integer
+// coefficients are read once (inverse) instead of a 16-byte-per-sample round trip through HBM for
+// the z pass alone.  A brick that is whole along all three axes is the chunk, so the z direction
+// is a SLIDING WINDOW: a workgroup owns kXYZRows rows (all of x) and marches through the slices;
+// every slice is staged with a halo of four rows, x- and y-lifted in LDS exactly as in k_lift_xy,
+// and its samples then enter per-position lifting PIPELINES along z held in registers.
+//
+// The four lifting steps along z as a pipeline (forward; x = input, d = odd, e = even samples):
+//     d1[2m-1] = x[2m-1] + a (x[2m-2] + x[2m])         known when slice 2m arrives
+//     e1[2m-2] = x[2m-2] + b (d1[2m-3] + d1[2m-1])
+//     d2[2m-3] = d1[2m-3] + g (e1[2m-4] + e1[2m-2])    -> high[m-2] = -1/eps d2[2m-3]
+//     e2[2m-4] = eps (e1[2m-4] + d (d2[2m-5] + d2[2m-3]))   -> low[m-2]
+// so five values per position (x[2m], x[2m+1], d1[2m-1], e1[2m-2], d2[2m-3]) carry everything;
+// the ends follow the reference's clamped indices (src/CDF97.cpp:598-666: a = max(i,1)-1,
+// b = min(i, odd_len-1), r = min(i+1, even_len-1)), written out below.  Every sample goes through
+// the very same operations, in the same order, as in k_lift_axis: bit-identical.
+// The inverse runs the mirror image: pairs (low[m], high[m]) enter, four values per position stay
+// (o1[m], e1[m], o2[m-1], e2[m-1]), slices 2m-3 and 2m-2 leave and go through the y and x passes.
+// ------------------------------------------------------------------------------------------
+constexpr int kXYZThreads = 512;   // 8 wavefronts, 2 per SIMD, up to 256 VGPRs: the pipelines live in registers
+constexpr int kXYZRows = 16;
+constexpr int kXYZStaged = kXYZRows + 2 * kXYHalo;   // LDS rows of a slice
+constexpr int kXYZPosF = 8;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
+constexpr int kXYZPosI = 12;   // inverse (the halo rows are inverted along z too): kXYZStaged * cx <= 6144
+
+// LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
+// (the four rows above and below the tile -- mirrored at the ends of the slice, so the first and the
+// last tile need nothing special), each row as [4 mirrored samples | cx samples | 4 mirrored samples]:
+// lift16 then never has to reflect an index along x or y.
+__host__ __device__ inline uint32_t xyz_row_stride(uint32_t cx)
+{
+  return ((cx + 7u) & ~7u) + 9u;   // (odd: rows start in different banks)
+}
+
+// A workgroup barrier that waits for the LDS traffic only.  __syncthreads() also waits for every global
+// load and store in flight (s_waitcnt vmcnt(0)): here those are the NEXT slice's samples on their way
+// in and the last slice's results on their way out, which no other thread of the workgroup looks at.
+#define XYZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// sample x of LDS row `row`, with its mirror images in the row's apron
+__device__ __forceinline__ void xyz_put(double* row, uint32_t x, uint32_t cx, double v)
+{
+  row[4 + x] = v;
+  if (x - 1u < 4u)
+    row[4 - x] = v;
+  if (cx - 2u - x < 4u)
+    row[2 * cx + 2 - x] = v;   // 4 + (cx - 1) + ((cx - 1) - x)
+}
+
+// x pass: rows [jlo, jhi) of `src` (aprons filled) -> the same rows of `dst` (another buffer: no barrier
+// inside); aprons of dst are filled when `apron`
+template <bool FORWARD, int NT>
+__device__ __forceinline__ void xyz_lift_x(const double* src, double* dst, uint32_t RS, uint32_t cx, uint32_t jlo,
+                                           uint32_t jhi, uint32_t tid, const LiftConsts& K)
+{
+  const uint32_t nseg = (cx + kSeg - 1) / kSeg;
+  const uint32_t ntask = (jhi - jlo) * nseg;
+#pragma unroll 1
+  for (uint32_t t = tid; t < ntask; t += NT) {
+    // lanes of a wavefront take different rows: their addresses differ by the (odd) row stride
+    const uint32_t rows = jhi - jlo, sg = t / rows, rb = jlo + (t - sg * rows);
+    const double* row = src + (size_t)rb * RS + sg * kSeg;
+    double r[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      r[k] = row[k];
+    lift16<FORWARD>(r, K);
+    double* out = dst + (size_t)rb * RS + 4 + sg * kSeg;
+#pragma unroll
+    for (int k = 0; k < kSeg; k++)
+      if (sg * kSeg + k < cx)
+        out[k] = r[4 + k];
+  }
+}
+
+// y pass: tile rows (LDS rows 4 .. 4 + nt) of `src` -> the same rows of `dst`
+template <bool FORWARD, bool APRON, int NT>
+__device__ __forceinline__ void xyz_lift_y(const double* src, double* dst, uint32_t RS, uint32_t cx, uint32_t nt,
+                                           uint32_t tid, const LiftConsts& K)
+{
+  const uint32_t nq = (nt + kSeg - 1) / kSeg;
+  const uint32_t ntask = nq * cx;
+#pragma unroll 1
+  for (uint32_t t = tid; t < ntask; t += NT) {
+    const uint32_t q = t / cx, x = t - q * cx;   // lanes take consecutive columns
+    const double* top = src + (size_t)(q * kSeg) * RS + 4 + x;
+    double r[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      r[k] = top[(size_t)k * RS];
+    lift16<FORWARD>(r, K);
+#pragma unroll
+    for (int k = 0; k < kSeg; k++) {
+      if (q * kSeg + k < nt) {
+        double* row = dst + (size_t)(4 + q * kSeg + k) * RS;
+        if (APRON)
+          xyz_put(row, x, cx, r[4 + k]);
+        else
+          row[4 + x] = r[4 + k];
+      }
+    }
+  }
+}
+
+template <int IO>
+__global__ void __launch_bounds__(kXYZThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
+               CoderState* st, const void* volume, VolDesc vd, const ChunkGeom* geom, int wantMax,
+               uint32_t in0, uint32_t in1, uint32_t in2)
+{
+  static_assert(IO == 1 || IO == 2, "float or double volume");
+  using VT = typename std::conditional<IO == 1, float, double>::type;
+  const uint32_t c = blockIdx.y;
+  if (st[c].is_const != 0)
+    return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t y0 = blockIdx.x * kXYZRows;
+  const uint32_t nt = min((uint32_t)kXYZRows, cy - y0);   // rows of this tile
+  const uint32_t RS = xyz_row_stride(cx);
+  // two staging buffers that swap roles from pass to pass (three barriers per slice instead of six);
+  // (offsets, not an array of pointers: the compiler must see that these are LDS addresses)
+  double* sm = reinterpret_cast<double*>(dyn_smem);
+  const uint32_t bufN = (uint32_t)kXYZStaged * RS;
+  const uint32_t xe = cx - cx / 2, ye = cy - cy / 2, ze = cz - cz / 2;
+  const VT* vol = reinterpret_cast<const VT*>(volume);
+  const size_t vsy = vd.dims[0], vsz = (size_t)vd.dims[0] * vd.dims[1];
+  const VT* volc = vol + ((size_t)geom[c].org[2] * vsz + (size_t)geom[c].org[1] * vsy + geom[c].org[0]);
+  double* buf = vals + c * valsStride;
+  const size_t sliceN = (size_t)cx * cy;
+  const double mean = st[c].mean;
+
+  // staging map: value k of this thread is sample x of LDS row j = row ysrc of the slice:
+  // j << 27 | ysrc << 12 | x
+  const uint32_t nstage = (uint32_t)kXYZStaged * cx;
+  uint32_t pk[kXYZPosI];
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++) {
+    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+    const uint32_t j = q / cx, x = q - j * cx;
+    pk[k] = (j << 27) | (reflect_index((int)y0 - kXYHalo + (int)j, (int)cy) << 12) | x;
+  }
+  // z pipelines: position k of this thread is (row y0 + row, column col) of the tile
+  const uint32_t npos = nt * cx;
+  uint32_t srow[kXYZPosF], ooff[kXYZPosF];   // (LDS row << 16 | column), offset in a slice of the chunk buffer
+  uint32_t outerMask = 0;   // bit k: position k lies outside the next level's box along x or y
+#pragma unroll
+  for (int k = 0; k < kXYZPosF; k++) {
+    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+    const uint32_t row = q / cx, col = q - row * cx, y = y0 + row;
+    srow[k] = ((row + kXYHalo) << 16) | col;
+    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (col & 1) ? xe + (col >> 1) : (col >> 1);
+    ooff[k] = drow * cx + dcol;
+    if (!(dcol < in0 && drow < in1))
+      outerMask |= 1u << k;
+  }
+  double sxe[kXYZPosF], sxo[kXYZPosF], d1p[kXYZPosF], e1p[kXYZPosF], d2p[kXYZPosF];
+#pragma unroll
+  for (int k = 0; k < kXYZPosF; k++)
+    sxe[k] = sxo[k] = d1p[k] = e1p[k] = d2p[k] = 0.0;
+  double vmax = 0.0;
+  auto emit = [&](int k, uint32_t zp, double v) {   // sample (ooff, zp) of the transformed chunk
+    buf[(size_t)zp * sliceN + ooff[k]] = v;
+    if (wantMax && (((outerMask >> k) & 1u) || zp >= in2))
+      vmax = fmax(vmax, fabs(v));
+  };
+
+  VT pre[kXYZPosI];
+  auto issue = [&](uint32_t z) {
+    const VT* src = volc + (size_t)z * vsz;
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++)
+      pre[k] = (tid + (uint32_t)k * kXYZThreads) < nstage
+                   ? src[(size_t)((pk[k] >> 12) & 0x7fffu) * vsy + (pk[k] & 0xfffu)] : (VT)0;
+  };
+  issue(0);
+  for (uint32_t z = 0; z < cz; z++) {
+    // (what the addresses below are made of goes through an empty asm once per slice: otherwise the
+    //  compiler computes every one of them before the loop and keeps -- spills -- some 200 values)
+    uint32_t RSv = RS, tidv = tid;
+    asm volatile("" : "+s"(RSv), "+v"(tidv));
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++)
+      asm volatile("" : "+v"(pk[k]));
+#pragma unroll
+    for (int k = 0; k < kXYZPosF; k++)
+      asm volatile("" : "+v"(srow[k]), "+v"(ooff[k]));
+    double* A = sm + ((z & 1) ? bufN : 0u);
+    double* B = sm + ((z & 1) ? 0u : bufN);
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++)
+      if ((tid + (uint32_t)k * kXYZThreads) < nstage)
+        xyz_put(A + (pk[k] >> 27) * RSv, pk[k] & 0xfffu, cx, (double)pre[k] - mean);
+    if (z + 1 < cz)
+      issue(z + 1);   // (in flight while this slice is lifted)
+    XYZ_LDS_BARRIER();
+    xyz_lift_x<true, kXYZThreads>(A, B, RSv, cx, 0, kXYZStaged, tidv, K);
+    XYZ_LDS_BARRIER();
+    xyz_lift_y<true, false, kXYZThreads>(B, A, RSv, cx, nt, tidv, K);
+    XYZ_LDS_BARRIER();   // (A's tile rows: this slice after x and y; the next slice is staged into B)
+    const uint32_t m = z >> 1;
+    if (z & 1) {
+#pragma unroll
+      for (int k = 0; k < kXYZPosF; k++)
+        if ((tid + (uint32_t)k * kXYZThreads) < npos)
+          sxo[k] = A[(srow[k] >> 16) * RSv + 4 + (srow[k] & 0xffffu)];
+    }
+    else {
+#pragma unroll
+      for (int k = 0; k < kXYZPosF; k++) {
+        if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+          continue;
+        const double v = A[(srow[k] >> 16) * RSv + 4 + (srow[k] & 0xffffu)];
+        if (m >= 1) {
+          const double d1n = fma(K.alpha, sxe[k] + v, sxo[k]);                          // d1[2m-1]
+          const double e1n = fma(K.beta, (m == 1 ? d1n : d1p[k]) + d1n, sxe[k]);        // e1[2m-2]
+          if (m >= 2) {
+            const double d2n = fma(K.gamma, e1p[k] + e1n, d1p[k]);                      // d2[2m-3]
+            const double e2 = K.eps * fma(K.delta, (m == 2 ? d2n : d2p[k]) + d2n, e1p[k]);   // e2[2m-4]
+            emit(k, m - 2, e2);
+            emit(k, ze + m - 2, (-K.inv_eps) * d2n);
+            d2p[k] = d2n;
+          }
+          d1p[k] = d1n;
+          e1p[k] = e1n;
+        }
+        sxe[k] = v;
+      }
+    }
+  }
+  // ---- the end of the lines: the samples still in the pipelines
+#pragma unroll
+  for (int k = 0; k < kXYZPosF; k++) {
+    if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+      continue;
+    if ((cz & 1) == 0) {   // the last sample is odd: x[2M+1], M = cz / 2 - 1
+      const uint32_t M = cz / 2 - 1;
+      const double d1L = fma(K.alpha, sxe[k] + sxe[k], sxo[k]);          // d1[2M+1]
+      const double e1M = fma(K.beta, d1p[k] + d1L, sxe[k]);              // e1[2M]
+      const double d2a = fma(K.gamma, e1p[k] + e1M, d1p[k]);             // d2[2M-1]
+      const double e2a = K.eps * fma(K.delta, d2p[k] + d2a, e1p[k]);     // e2[2M-2]
+      const double d2L = fma(K.gamma, e1M + e1M, d1L);                   // d2[2M+1]
+      const double e2L = K.eps * fma(K.delta, d2a + d2L, e1M);           // e2[2M]
+      emit(k, M - 1, e2a);
+      emit(k, ze + M - 1, (-K.inv_eps) * d2a);
+      emit(k, M, e2L);
+      emit(k, ze + M, (-K.inv_eps) * d2L);
+    }
+    else {                 // the last sample is even: x[2M], M = cz / 2 (its slice went through the loop)
+      const uint32_t M = cz / 2;
+      const double e1M = fma(K.beta, d1p[k] + d1p[k], sxe[k]);           // e1[2M]
+      const double d2a = fma(K.gamma, e1p[k] + e1M, d1p[k]);             // d2[2M-1]
+      const double e2a = K.eps * fma(K.delta, d2p[k] + d2a, e1p[k]);     // e2[2M-2]
+      const double e2L = K.eps * fma(K.delta, d2a + d2a, e1M);           // e2[2M]
+      emit(k, M - 1, e2a);
+      emit(k, ze + M - 1, (-K.inv_eps) * d2a);
+      emit(k, M, e2L);
+    }
+  }
+  if (wantMax) {
+    for (int d = 32; d > 0; d >>= 1)
+      vmax = fmax(vmax, __shfl_xor(vmax, d, 64));
+    if ((tid & 63) == 0 && vmax > 0.0)
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[c].maxabs),
+                (unsigned long long)__double_as_longlong(vmax));
+  }
+}
+
+template <int IO>
+__global__ void __launch_bounds__(kXYZThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
+               const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F)
+{
+  static_assert(IO == 1 || IO == 2, "float or double volume");
+  using VT = typename std::conditional<IO == 1, float, double>::type;
+  const uint32_t c = blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t y0 = blockIdx.x * kXYZRows;
+  const uint32_t nt = min((uint32_t)kXYZRows, cy - y0);
+  const uint32_t RS = xyz_row_stride(cx);
+  double* sm = reinterpret_cast<double*>(dyn_smem);
+  const uint32_t bufN = (uint32_t)kXYZStaged * RS;
+  const uint32_t xe = cx - cx / 2, ye = cy - cy / 2, ze = cz - cz / 2;
+  VT* vol = reinterpret_cast<VT*>(volume);
+  const size_t vsy = vd.dims[0], vsz = (size_t)vd.dims[0] * vd.dims[1];
+  VT* volc = vol + ((size_t)geom[c].org[2] * vsz + (size_t)geom[c].org[1] * vsy + geom[c].org[0]);
+  const double* buf = vals + c * valsStride;
+  const size_t sliceN = (size_t)cx * cy;
+  const double mean = st[c].mean;
+  const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYZThreads / 64;
+
+  if (st[c].is_const != 0) {   // the chunk is its constant
+    for (uint32_t z = 0; z < cz; z++)
+      for (uint32_t k = tid; k < nt * cx; k += kXYZThreads)
+        volc[(size_t)z * vsz + (size_t)(y0 + k / cx) * vsy + k % cx] = (VT)mean;
+    return;
+  }
+
+  // position k of this thread: sample x of LDS row j = row ysrc of a slice (j << 27 | ysrc << 12 | x);
+  // in the transformed chunk that is sample (dcol, drow): low | high halves along x and y
+  const uint32_t npos = (uint32_t)kXYZStaged * cx;
+  uint32_t pk[kXYZPosI];
+  uint32_t innerMask = 0;   // bit k: inside the next level's box along x and y
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++) {
+    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+    const uint32_t j = q / cx, x = q - j * cx, y = reflect_index((int)y0 - kXYHalo + (int)j, (int)cy);
+    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+    pk[k] = (j << 27) | (y << 12) | x;
+    if (dcol < F.inner[0] && drow < F.inner[1])
+      innerMask |= 1u << k;
+  }
+  const bool dequant = F.mode == 2 && !st[c].wide;
+  const double fq = dequant ? st[c].q : 0.0;
+  const uint32_t* coef = F.coef + c * F.coefStride;
+  const uint64_t* sign = F.sign + c * F.signStride;
+  // sample (dcol, drow, zp): straight from the decoder (q * double(c) * (+-1.0), src/SPECK_FLT.cpp:373-399)
+  // unless a coarser level's passes have produced it
+  auto fetch = [&](int k, uint32_t zp) -> double {
+    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
+    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+    const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
+    if (dequant && !(((innerMask >> k) & 1u) && zp < F.inner[2])) {
+      const uint32_t v = coef[idx];
+      const uint64_t sgw = sign[idx >> 6];
+      return fq * (double)v * (((sgw >> (idx & 63)) & 1ull) ? 1.0 : -1.0);
+    }
+    return buf[idx];
+  };
+  // The slice of z-inverted samples staged in X (all staged rows) -> y pass into Y, x pass back into
+  // X, volume.  X and Y swap from slice to slice: three barriers per slice.
+  uint32_t flip = 0;
+  // sample k of the slice that is finished next (its staging buffer is free: see finish_slice)
+  auto stage = [&](int k, double v) {
+    uint32_t p = pk[k];
+    asm volatile("" : "+v"(p));   // (keeps the LDS address from being computed ahead and spilled)
+    (sm + (flip ? bufN : 0u))[(p >> 27) * RS + 4 + (p & 0xfffu)] = v;
+  };
+  auto stage_all = [&](const double (&v)[kXYZPosI]) {
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++)
+      if ((tid + (uint32_t)k * kXYZThreads) < npos)
+        stage(k, v[k]);
+  };
+  auto finish_slice = [&](uint32_t z) {
+    uint32_t RSv = RS, tidv = tid;   // (see k_lift_xyz_fwd)
+    asm volatile("" : "+s"(RSv), "+v"(tidv));
+    double* X = sm + (flip ? bufN : 0u);
+    double* Y = sm + (flip ? 0u : bufN);
+    flip ^= 1u;
+    XYZ_LDS_BARRIER();
+    xyz_lift_y<false, true, kXYZThreads>(X, Y, RSv, cx, nt, tidv, K);
+    XYZ_LDS_BARRIER();
+    xyz_lift_x<false, kXYZThreads>(Y, X, RSv, cx, kXYHalo, kXYHalo + nt, tidv, K);
+    XYZ_LDS_BARRIER();
+    for (uint32_t r = wave; r < nt; r += nwaves) {
+      VT* dstrow = volc + (size_t)z * vsz + (size_t)(y0 + r) * vsy;
+      const double* srow = X + (size_t)(kXYHalo + r) * RSv + 4;
+      for (uint32_t x = lane; x < cx; x += 64)
+        dstrow[x] = (VT)(srow[x] + mean);
+    }
+    // (the next slice is staged into Y, which nobody reads any more; its y pass writes X only after
+    //  the barrier behind that staging, when every row above has been stored)
+  };
+
+  double o1p[kXYZPosI], e1p[kXYZPosI], o2p[kXYZPosI], e2p[kXYZPosI];
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++)
+    o1p[k] = e1p[k] = o2p[k] = e2p[k] = 0.0;
+  const uint32_t npairs = cz / 2;
+  for (uint32_t m = 0; m < npairs; m++) {
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++)
+      asm volatile("" : "+v"(pk[k]));
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++) {
+      if ((k & 3) == 0)
+        __builtin_amdgcn_sched_barrier(0);   // (four positions' loads in flight at a time, not all twelve)
+      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+        continue;
+      const double E = fetch(k, m), O = fetch(k, ze + m);
+      const double o1 = (-K.eps) * O;                                        // o1[m]
+      const double t = K.delta * ((m == 0 ? o1 : o1p[k]) + o1);
+      const double e1 = fma(E, K.inv_eps, -t);                               // e1[m]
+      if (m >= 1) {
+        const double o2 = fma(-K.gamma, e1p[k] + e1, o1p[k]);                // o2[m-1]
+        const double e2 = fma(-K.beta, (m == 1 ? o2 : o2p[k]) + o2, e1p[k]); // e2[m-1]
+        if (m >= 2)
+          stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                      // o3[m-2]: slice 2m-3
+        o2p[k] = o2;
+        e2p[k] = e2;
+      }
+      o1p[k] = o1;
+      e1p[k] = e1;
+    }
+    if (m >= 2)
+      finish_slice(2 * m - 3);
+    if (m >= 1) {
+      stage_all(e2p);
+      finish_slice(2 * m - 2);
+    }
+  }
+  // ---- the end of the lines
+  if ((cz & 1) == 0) {   // pairs 0 .. M, M = cz / 2 - 1
+    const uint32_t M = npairs - 1;
+    double outC[kXYZPosI];
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++) {
+      outC[k] = 0.0;
+      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+        continue;
+      const double o2 = fma(-K.gamma, e1p[k] + e1p[k], o1p[k]);              // o2[M]
+      const double e2 = fma(-K.beta, o2p[k] + o2, e1p[k]);                   // e2[M]
+      stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                          // o3[M-1]: slice 2M-1
+      e2p[k] = e2;                                                           // slice 2M
+      outC[k] = fma(-K.alpha, e2 + e2, o2);                                  // o3[M]: slice 2M+1
+    }
+    finish_slice(2 * M - 1);
+    stage_all(e2p);
+    finish_slice(2 * M);
+    stage_all(outC);
+    finish_slice(2 * M + 1);
+  }
+  else {                 // pairs 0 .. M-1 and the lone even sample low[M], M = cz / 2
+    const uint32_t M = npairs;
+    double outC[kXYZPosI], outD[kXYZPosI];
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++) {
+      outC[k] = outD[k] = 0.0;
+      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+        continue;
+      const double E = fetch(k, M);
+      const double t = K.delta * (o1p[k] + o1p[k]);
+      const double e1 = fma(E, K.inv_eps, -t);                               // e1[M]
+      const double o2 = fma(-K.gamma, e1p[k] + e1, o1p[k]);                  // o2[M-1]
+      const double e2 = fma(-K.beta, o2p[k] + o2, e1p[k]);                   // e2[M-1]
+      stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                          // o3[M-2]: slice 2M-3
+      e2p[k] = e2;                                                           // slice 2M-2
+      const double e2L = fma(-K.beta, o2 + o2, e1);                          // e2[M]: slice 2M
+      outC[k] = fma(-K.alpha, e2 + e2L, o2);                                 // o3[M-1]: slice 2M-1
+      outD[k] = e2L;
+    }
+    finish_slice(2 * M - 3);
+    stage_all(e2p);
+    finish_slice(2 * M - 2);
+    stage_all(outC);
+    finish_slice(2 * M - 1);
+    stage_all(outD);
+    finish_slice(2 * M);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // quantiser
 // ------------------------------------------------------------------------------------------
 
@@ -1067,6 +1520,55 @@ int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsSt
       LAUNCH_K((k_lift_xy<false, 2>), grid, dim3(kXYThreads), smem, stream, XY_ARGS);
   }
 #undef XY_ARGS
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+bool lift_xyz_applicable(const uint32_t cdims[3])
+{
+  static const bool on = !(getenv("SPERR_HIP_LIFT_XYZ") && atoi(getenv("SPERR_HIP_LIFT_XYZ")) == 0);
+  if (!on || cdims[0] < 9 || cdims[1] < 9 || cdims[2] < 9)
+    return false;
+  // a thread's z pipelines are registers: (rows + halo) * cx positions over the workgroup's threads
+  // (and the packed staging map holds 12 bits of x, 15 bits of y)
+  return (size_t)kXYZStaged * cdims[0] <= (size_t)kXYZPosI * kXYZThreads &&
+         (size_t)kXYZRows * cdims[0] <= (size_t)kXYZPosF * kXYZThreads && cdims[0] < 4096 && cdims[1] < 32768;
+}
+
+int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsStride, uint32_t nchunks,
+                    const uint32_t cdims[3], CoderState* st, int io, void* volume, VolDesc vd,
+                    const ChunkGeom* geom, const LiftFuse* fuse)
+{
+  if (!lift_xyz_applicable(cdims) || (io != 1 && io != 2))
+    return -1;
+  const LiftFuse F = fuse ? *fuse : LiftFuse{};
+  const size_t smem = 2 * (size_t)kXYZStaged * xyz_row_stride(cdims[0]) * sizeof(double);   // two staging buffers
+  {
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_lift_xyz_fwd<1>), reinterpret_cast<const void*>(&k_lift_xyz_fwd<2>),
+                          reinterpret_cast<const void*>(&k_lift_xyz_inv<1>), reinterpret_cast<const void*>(&k_lift_xyz_inv<2>)};
+    for (const void* f : fns)
+      if (set_max_dyn_lds(f, 160 * 1024))
+        return -1;
+  }
+  const dim3 grid((cdims[1] + kXYZRows - 1) / kXYZRows, nchunks);
+  const LiftConsts K = lift_consts();
+  if (forward) {
+    const int wantMax = F.mode == 1 ? 1 : 0;
+    if (io == 1)
+      LAUNCH_K((k_lift_xyz_fwd<1>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
+    else
+      LAUNCH_K((k_lift_xyz_fwd<2>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
+  }
+  else {
+    if (io == 1)
+      LAUNCH_K((k_lift_xyz_inv<1>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+               cdims[2], K, st, volume, vd, geom, F);
+    else
+      LAUNCH_K((k_lift_xyz_inv<2>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+               cdims[2], K, st, volume, vd, geom, F);
+  }
   HIP_CHECK(hipGetLastError());
   return 0;
 }

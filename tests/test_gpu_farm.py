@@ -165,7 +165,8 @@ def test_config5_shape_pinned_pwe_256_cubes_streamed(eng, oracle):
     nthreads = os.cpu_count() or 8
     want = oracle.comp_3d(vol, chunks, 3, tol, nthreads=nthreads)
     ref = oracle.decomp_3d(want, True, nthreads=nthreads)
-    assert float(np.abs(ref.astype(np.float64) - vol).max()) <= tol
+    # (narrowing the decoded doubles to fp32 adds up to half an fp32 ulp of the value)
+    assert float(np.abs(ref.astype(np.float64) - vol).max()) <= tol + 6e-8 * float(np.abs(vol).max())
     # every chunk carries an outlier stream at this tolerance? at least most of them must, or the
     # outlier coder is not what is being tested
     hdr = 20 + 4 * 16
