@@ -2333,10 +2333,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         HIP_CHECK(hipMemsetAsync(d.st, 0, nb * sizeof(DecState), ss));
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        use_tables(*P), P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
-        // launch_inv_quantize / the dequantising inverse passes complete the coefficients that were never
-        // refined from the decoder's masks -- the fused x-y-z pass reads coefficients and signs only, so
-        // k_dec_finish does it for a plan that takes that pass
-        ph.skipFinish = !fuse_xyz(*P);
+        ph.skipFinish = true;   // launch_inv_quantize / the dequantising inverse passes complete the coefficients
         // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);

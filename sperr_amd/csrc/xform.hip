@@ -733,11 +733,14 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
 // The inverse runs the mirror image: pairs (low[m], high[m]) enter, four values per position stay
 // (o1[m], e1[m], o2[m-1], e2[m-1]), slices 2m-3 and 2m-2 leave and go through the y and x passes.
 // ------------------------------------------------------------------------------------------
-constexpr int kXYZThreads = 512;   // 8 wavefronts, 2 per SIMD, up to 256 VGPRs: the pipelines live in registers
+// (the pipelines live in registers: the forward kernel fits 16 wavefronts of 128 VGPRs, the inverse one,
+//  which inverts the halo rows along z too, as well -- with a few spills outside its main loop)
+constexpr int kXYZThreadsF = 1024, kXYZThreadsI = 1024;
 constexpr int kXYZRows = 16;
 constexpr int kXYZStaged = kXYZRows + 2 * kXYHalo;   // LDS rows of a slice
-constexpr int kXYZPosF = 8;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
-constexpr int kXYZPosI = 12;   // inverse (the halo rows are inverted along z too): kXYZStaged * cx <= 6144
+constexpr int kXYZPosF = 4;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
+constexpr int kXYZStageF = 6;  // staged samples per thread, forward: kXYZStaged * cx <= 6144
+constexpr int kXYZPosI = 6;   // inverse: kXYZStaged * cx <= 6144
 
 // LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
 // (the four rows above and below the tile -- mirrored at the ends of the slice, so the first and the
@@ -819,7 +822,7 @@ __device__ __forceinline__ void xyz_lift_y(const double* src, double* dst, uint3
 }
 
 template <int IO>
-__global__ void __launch_bounds__(kXYZThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(kXYZThreadsF) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                CoderState* st, const void* volume, VolDesc vd, const ChunkGeom* geom, int wantMax,
                uint32_t in0, uint32_t in1, uint32_t in2)
@@ -848,10 +851,10 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
   // staging map: value k of this thread is sample x of LDS row j = row ysrc of the slice:
   // j << 27 | ysrc << 12 | x
   const uint32_t nstage = (uint32_t)kXYZStaged * cx;
-  uint32_t pk[kXYZPosI];
+  uint32_t pk[kXYZStageF];
 #pragma unroll
-  for (int k = 0; k < kXYZPosI; k++) {
-    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+  for (int k = 0; k < kXYZStageF; k++) {
+    const uint32_t q = tid + (uint32_t)k * kXYZThreadsF;
     const uint32_t j = q / cx, x = q - j * cx;
     pk[k] = (j << 27) | (reflect_index((int)y0 - kXYHalo + (int)j, (int)cy) << 12) | x;
   }
@@ -861,7 +864,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
   uint32_t outerMask = 0;   // bit k: position k lies outside the next level's box along x or y
 #pragma unroll
   for (int k = 0; k < kXYZPosF; k++) {
-    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+    const uint32_t q = tid + (uint32_t)k * kXYZThreadsF;
     const uint32_t row = q / cx, col = q - row * cx, y = y0 + row;
     srow[k] = ((row + kXYHalo) << 16) | col;
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (col & 1) ? xe + (col >> 1) : (col >> 1);
@@ -880,12 +883,12 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
       vmax = fmax(vmax, fabs(v));
   };
 
-  VT pre[kXYZPosI];
+  VT pre[kXYZStageF];
   auto issue = [&](uint32_t z) {
     const VT* src = volc + (size_t)z * vsz;
 #pragma unroll
-    for (int k = 0; k < kXYZPosI; k++)
-      pre[k] = (tid + (uint32_t)k * kXYZThreads) < nstage
+    for (int k = 0; k < kXYZStageF; k++)
+      pre[k] = (tid + (uint32_t)k * kXYZThreadsF) < nstage
                    ? src[(size_t)((pk[k] >> 12) & 0x7fffu) * vsy + (pk[k] & 0xfffu)] : (VT)0;
   };
   issue(0);
@@ -895,7 +898,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
     uint32_t RSv = RS, tidv = tid;
     asm volatile("" : "+s"(RSv), "+v"(tidv));
 #pragma unroll
-    for (int k = 0; k < kXYZPosI; k++)
+    for (int k = 0; k < kXYZStageF; k++)
       asm volatile("" : "+v"(pk[k]));
 #pragma unroll
     for (int k = 0; k < kXYZPosF; k++)
@@ -903,27 +906,27 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
     double* A = sm + ((z & 1) ? bufN : 0u);
     double* B = sm + ((z & 1) ? 0u : bufN);
 #pragma unroll
-    for (int k = 0; k < kXYZPosI; k++)
-      if ((tid + (uint32_t)k * kXYZThreads) < nstage)
+    for (int k = 0; k < kXYZStageF; k++)
+      if ((tid + (uint32_t)k * kXYZThreadsF) < nstage)
         xyz_put(A + (pk[k] >> 27) * RSv, pk[k] & 0xfffu, cx, (double)pre[k] - mean);
     if (z + 1 < cz)
       issue(z + 1);   // (in flight while this slice is lifted)
     XYZ_LDS_BARRIER();
-    xyz_lift_x<true, kXYZThreads>(A, B, RSv, cx, 0, kXYZStaged, tidv, K);
+    xyz_lift_x<true, kXYZThreadsF>(A, B, RSv, cx, 0, kXYZStaged, tidv, K);
     XYZ_LDS_BARRIER();
-    xyz_lift_y<true, false, kXYZThreads>(B, A, RSv, cx, nt, tidv, K);
+    xyz_lift_y<true, false, kXYZThreadsF>(B, A, RSv, cx, nt, tidv, K);
     XYZ_LDS_BARRIER();   // (A's tile rows: this slice after x and y; the next slice is staged into B)
     const uint32_t m = z >> 1;
     if (z & 1) {
 #pragma unroll
       for (int k = 0; k < kXYZPosF; k++)
-        if ((tid + (uint32_t)k * kXYZThreads) < npos)
+        if ((tid + (uint32_t)k * kXYZThreadsF) < npos)
           sxo[k] = A[(srow[k] >> 16) * RSv + 4 + (srow[k] & 0xffffu)];
     }
     else {
 #pragma unroll
       for (int k = 0; k < kXYZPosF; k++) {
-        if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+        if ((tid + (uint32_t)k * kXYZThreadsF) >= npos)
           continue;
         const double v = A[(srow[k] >> 16) * RSv + 4 + (srow[k] & 0xffffu)];
         if (m >= 1) {
@@ -946,7 +949,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
   // ---- the end of the lines: the samples still in the pipelines
 #pragma unroll
   for (int k = 0; k < kXYZPosF; k++) {
-    if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+    if ((tid + (uint32_t)k * kXYZThreadsF) >= npos)
       continue;
     if ((cz & 1) == 0) {   // the last sample is odd: x[2M+1], M = cz / 2 - 1
       const uint32_t M = cz / 2 - 1;
@@ -982,7 +985,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
 }
 
 template <int IO>
-__global__ void __launch_bounds__(kXYZThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(kXYZThreadsI) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F)
 {
@@ -1002,11 +1005,11 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const double* buf = vals + c * valsStride;
   const size_t sliceN = (size_t)cx * cy;
   const double mean = st[c].mean;
-  const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYZThreads / 64;
+  const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYZThreadsI / 64;
 
   if (st[c].is_const != 0) {   // the chunk is its constant
     for (uint32_t z = 0; z < cz; z++)
-      for (uint32_t k = tid; k < nt * cx; k += kXYZThreads)
+      for (uint32_t k = tid; k < nt * cx; k += kXYZThreadsI)
         volc[(size_t)z * vsz + (size_t)(y0 + k / cx) * vsy + k % cx] = (VT)mean;
     return;
   }
@@ -1018,7 +1021,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   uint32_t innerMask = 0;   // bit k: inside the next level's box along x and y
 #pragma unroll
   for (int k = 0; k < kXYZPosI; k++) {
-    const uint32_t q = tid + (uint32_t)k * kXYZThreads;
+    const uint32_t q = tid + (uint32_t)k * kXYZThreadsI;
     const uint32_t j = q / cx, x = q - j * cx, y = reflect_index((int)y0 - kXYHalo + (int)j, (int)cy);
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
     pk[k] = (j << 27) | (y << 12) | x;
@@ -1029,6 +1032,14 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const double fq = dequant ? st[c].q : 0.0;
   const uint32_t* coef = F.coef + c * F.coefStride;
   const uint64_t* sign = F.sign + c * F.signStride;
+  // a coefficient that became significant on the last decoded plane / the one before and was never
+  // refined still holds 0: its value comes from the decoder's masks (k_inv_quantize, k_lift_axis)
+  const bool haveMasks = dequant && F.sigNew != nullptr && F.dst != nullptr;
+  const uint64_t* mNew = haveMasks ? F.sigNew + c * F.maskStride : sign;
+  const uint64_t* mOld = haveMasks ? F.sigOld + c * F.maskStride : sign;
+  const uint32_t lastPl = haveMasks ? (uint32_t)F.dst[c].lastPlane : 0u;
+  const uint32_t initNew = haveMasks ? (1u << lastPl) + (1u << lastPl) - (1u << lastPl) / 2 - 1 : 0u;
+  const uint32_t initOld = (haveMasks && lastPl < 31) ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
   // sample (dcol, drow, zp): straight from the decoder (q * double(c) * (+-1.0), src/SPECK_FLT.cpp:373-399)
   // unless a coarser level's passes have produced it
   auto fetch = [&](int k, uint32_t zp) -> double {
@@ -1036,9 +1047,12 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
     const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
     if (dequant && !(((innerMask >> k) & 1u) && zp < F.inner[2])) {
-      const uint32_t v = coef[idx];
-      const uint64_t sgw = sign[idx >> 6];
-      return fq * (double)v * (((sgw >> (idx & 63)) & 1ull) ? 1.0 : -1.0);
+      uint32_t v = coef[idx];
+      const uint32_t sh = (uint32_t)(idx & 63);
+      const uint64_t sgw = sign[idx >> 6], mnw = mNew[idx >> 6], mow = mOld[idx >> 6];   // (independent loads)
+      const uint32_t fill = ((mnw >> sh) & 1ull) ? initNew : (((mow >> sh) & 1ull) ? initOld : 0u);
+      v = v ? v : fill;
+      return fq * (double)v * (((sgw >> sh) & 1ull) ? 1.0 : -1.0);
     }
     return buf[idx];
   };
@@ -1054,7 +1068,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   auto stage_all = [&](const double (&v)[kXYZPosI]) {
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++)
-      if ((tid + (uint32_t)k * kXYZThreads) < npos)
+      if ((tid + (uint32_t)k * kXYZThreadsI) < npos)
         stage(k, v[k]);
   };
   auto finish_slice = [&](uint32_t z) {
@@ -1064,9 +1078,9 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     double* Y = sm + (flip ? 0u : bufN);
     flip ^= 1u;
     XYZ_LDS_BARRIER();
-    xyz_lift_y<false, true, kXYZThreads>(X, Y, RSv, cx, nt, tidv, K);
+    xyz_lift_y<false, true, kXYZThreadsI>(X, Y, RSv, cx, nt, tidv, K);
     XYZ_LDS_BARRIER();
-    xyz_lift_x<false, kXYZThreads>(Y, X, RSv, cx, kXYHalo, kXYHalo + nt, tidv, K);
+    xyz_lift_x<false, kXYZThreadsI>(Y, X, RSv, cx, kXYHalo, kXYHalo + nt, tidv, K);
     XYZ_LDS_BARRIER();
     for (uint32_t r = wave; r < nt; r += nwaves) {
       VT* dstrow = volc + (size_t)z * vsz + (size_t)(y0 + r) * vsy;
@@ -1089,9 +1103,9 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       asm volatile("" : "+v"(pk[k]));
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++) {
-      if ((k & 3) == 0)
+      if ((k % 3) == 0)
         __builtin_amdgcn_sched_barrier(0);   // (four positions' loads in flight at a time, not all twelve)
-      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+      if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
         continue;
       const double E = fetch(k, m), O = fetch(k, ze + m);
       const double o1 = (-K.eps) * O;                                        // o1[m]
@@ -1122,7 +1136,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++) {
       outC[k] = 0.0;
-      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+      if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
         continue;
       const double o2 = fma(-K.gamma, e1p[k] + e1p[k], o1p[k]);              // o2[M]
       const double e2 = fma(-K.beta, o2p[k] + o2, e1p[k]);                   // e2[M]
@@ -1142,7 +1156,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++) {
       outC[k] = outD[k] = 0.0;
-      if ((tid + (uint32_t)k * kXYZThreads) >= npos)
+      if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
         continue;
       const double E = fetch(k, M);
       const double t = K.delta * (o1p[k] + o1p[k]);
@@ -1531,8 +1545,9 @@ bool lift_xyz_applicable(const uint32_t cdims[3])
     return false;
   // a thread's z pipelines are registers: (rows + halo) * cx positions over the workgroup's threads
   // (and the packed staging map holds 12 bits of x, 15 bits of y)
-  return (size_t)kXYZStaged * cdims[0] <= (size_t)kXYZPosI * kXYZThreads &&
-         (size_t)kXYZRows * cdims[0] <= (size_t)kXYZPosF * kXYZThreads && cdims[0] < 4096 && cdims[1] < 32768;
+  return (size_t)kXYZStaged * cdims[0] <= (size_t)kXYZPosI * kXYZThreadsI &&
+         (size_t)kXYZStaged * cdims[0] <= (size_t)kXYZStageF * kXYZThreadsF &&
+         (size_t)kXYZRows * cdims[0] <= (size_t)kXYZPosF * kXYZThreadsF && cdims[0] < 4096 && cdims[1] < 32768;
 }
 
 int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsStride, uint32_t nchunks,
@@ -1555,18 +1570,18 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
   if (forward) {
     const int wantMax = F.mode == 1 ? 1 : 0;
     if (io == 1)
-      LAUNCH_K((k_lift_xyz_fwd<1>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+      LAUNCH_K((k_lift_xyz_fwd<1>), grid, dim3(kXYZThreadsF), smem, stream, vals, valsStride, cdims[0], cdims[1],
                cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
     else
-      LAUNCH_K((k_lift_xyz_fwd<2>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+      LAUNCH_K((k_lift_xyz_fwd<2>), grid, dim3(kXYZThreadsF), smem, stream, vals, valsStride, cdims[0], cdims[1],
                cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
   }
   else {
     if (io == 1)
-      LAUNCH_K((k_lift_xyz_inv<1>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+      LAUNCH_K((k_lift_xyz_inv<1>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
                cdims[2], K, st, volume, vd, geom, F);
     else
-      LAUNCH_K((k_lift_xyz_inv<2>), grid, dim3(kXYZThreads), smem, stream, vals, valsStride, cdims[0], cdims[1],
+      LAUNCH_K((k_lift_xyz_inv<2>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
                cdims[2], K, st, volume, vd, geom, F);
   }
   HIP_CHECK(hipGetLastError());
@@ -1709,3 +1724,4 @@ int launch_inv_quantize(hipStream_t stream, bool wide, const void* coef, size_t 
 }
 
 }  // namespace sperrhip
+
