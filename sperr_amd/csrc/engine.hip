@@ -1919,6 +1919,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.wordLeaf = P.d_wordLeaf;
   d.leafStateStride = round_up(P.ht.nnodes, 64);
   TAKE(d.leafState, uint16_t, d.leafStateStride * B);
+  d.leafDirtyStride = d.leafStateStride / 32 + 1;
+  TAKE(d.leafDirty, uint8_t, d.leafDirtyStride * B);
 #undef TAKE
   return true;
 }
@@ -2366,6 +2368,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * nb * 2, ss));
+          HIP_CHECK(hipMemsetAsync(d.leafDirty, 0, d.leafDirtyStride * nb, ss));
           HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * nb * 8, ss));
           DecBuffers dw = d;
           if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
@@ -3239,6 +3242,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.leafState, 0, d.leafStateStride * 2, st));
+    HIP_CHECK(hipMemsetAsync(d.leafDirty, 0, d.leafDirtyStride, st));
     HIP_CHECK(hipMemsetAsync(d.stream, 0, d.streamStride * 8, st));
     const uint32_t n = P->N;
     if (wide) {

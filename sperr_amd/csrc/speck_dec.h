@@ -108,6 +108,8 @@ struct DecBuffers {
   // (a multiple of 32) | (row parity selector / 2), or 0xffffffff; nullptr when no word qualifies.
   uint16_t* leafState;
   size_t leafStateStride;
+  uint8_t* leafDirty;          // per block of 32 leaves: 1 + the plane on which one of them split last
+  size_t leafDirtyStride;
   const uint32_t* wordLeaf;
   // k_lis_l0: one look-back word per block of kL0W stream bits (tagged with the plane)
   unsigned long long* l0Flags;

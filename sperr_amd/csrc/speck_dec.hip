@@ -131,14 +131,19 @@ constexpr int kDecTileWords = kThreads;
 // of a split leaf has been tested (born), some are significant (sig), some of those negative
 // (neg).  Sample (x, y, z) is child (x & 1) + 2 (y & 1) + 4 (z & 1) of leaf (x/2, y/2, z/2), so
 // the word takes two adjacent bits of each of its 32 leaves.
+// `tag`: only when a leaf of the word's 32-leaf block split on plane tag - 1 (k_leaf_apply leaves
+// 1 + the plane in leafDirty): what earlier planes did to the block was folded when they ended, and
+// a block's 64 bytes of states are not worth reading again on every plane (0: whatever its tag).
 __device__ __forceinline__ bool leaf_word(const DecBuffers& b, uint32_t c, uint32_t wi,
-                                          uint64_t& born, uint64_t& sig, uint64_t& neg)
+                                          uint64_t& born, uint64_t& sig, uint64_t& neg, uint32_t tag)
 {
   born = sig = neg = 0;
   if (b.wordLeaf == nullptr)
     return false;
   const uint32_t wl = b.wordLeaf[wi];
   if (wl == 0xffffffffu)
+    return false;
+  if (tag && b.leafDirty[c * b.leafDirtyStride + (wl >> 5)] != (uint8_t)tag)
     return false;
   const uint32_t sel = (wl & 3u) * 2u;
   const uint4* q = reinterpret_cast<const uint4*>(b.leafState + c * b.leafStateStride + (wl & ~31u));
@@ -194,7 +199,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
     uint64_t lb = 0, ls = 0, ln = 0;
     // (idempotent: old leaf results are folded again -- but once all 64 samples of the word are born,
     //  every leaf over it has split and was folded by an earlier plane: their states are final)
-    if (born != ~0ull && leaf_word(b, c, wi, lb, ls, ln)) {
+    if (born != ~0ull && leaf_word(b, c, wi, lb, ls, ln, (uint32_t)p + 2u)) {   // leaves that split on plane p + 1
       if (lb & ~born) {
         born |= lb;
         b.bornM[c * b.maskPixStride + wi] = born;
@@ -4869,6 +4874,7 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
     const Grid g = t.grids[nd.grid];
     if (g.kind & kGridLeafWord) {   // folded into the masks by k_dec_count / k_dec_fold
       b.leafState[c * b.leafStateStride + (uint32_t)ev] = (uint16_t)(sigm | (negm << 8));
+      b.leafDirty[c * b.leafDirtyStride + ((uint32_t)ev >> 5)] = (uint8_t)(p + 1);   // (every writer stores the same value)
       continue;
     }
     if (!(g.kind & kGridOct)) {   // any shape (events of k_lis_mixed): the existing children by ordinal
@@ -5035,7 +5041,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_fold(DecBuffers b)
   if (wi >= nw)
     return;
   uint64_t lb, ls, ln;
-  if (!leaf_word(b, c, wi, lb, ls, ln))
+  if (!leaf_word(b, c, wi, lb, ls, ln, (uint32_t)s.lastPlane + 1u))   // leaves that split on the last plane
     return;
   const uint64_t fresh = ls & ~b.sigOld[c * b.maskPixStride + wi];
   if (fresh)

@@ -1321,6 +1321,46 @@ __global__ void k_quantize(const double* vals, size_t valsStride, uint32_t n, CT
     sign[c * signStride + (i >> 6)] = word;
 }
 
+// The same for 32-bit magnitudes, four consecutive samples per thread: 32-byte loads, 16-byte stores of
+// the magnitudes, one 4-byte store of the four msb positions; the sign word of 64 samples is put
+// together by the 16 lanes that hold them (all strides and n are multiples of 4 -- launch_quantize).
+__global__ void __launch_bounds__(kThreads)
+k_quantize4(const double* vals, size_t valsStride, uint32_t n, uint32_t* coef, size_t coefStride,
+            uint64_t* sign, size_t signStride, int8_t* msb, size_t msbStride, const CoderState* st)
+{
+  const uint32_t c = blockIdx.y;
+  const CoderState& s = st[c];
+  if (s.is_const)
+    return;
+  const double inv = 1.0 / s.q;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  uint32_t nn = 0;   // bit e: sample i + e is non-negative
+  if (i < n) {
+    const double2* in = reinterpret_cast<const double2*>(vals + c * valsStride + i);
+    const double2 a = in[0], b2 = in[1];
+    const double v[4] = {a.x, a.y, b2.x, b2.y};
+    uint32_t mag[4], mb = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const long long ll = __double2ll_rn(v[e] * inv);
+      nn |= (ll >= 0 ? 1u : 0u) << e;
+      const unsigned long long m = (unsigned long long)(ll < 0 ? -ll : ll);
+      mag[e] = (uint32_t)m;
+      mb |= (uint32_t)(uint8_t)(m ? (int8_t)(63 - __clzll((long long)m)) : (int8_t)-1) << (8 * e);
+    }
+    *reinterpret_cast<uint4*>(coef + c * coefStride + i) = make_uint4(mag[0], mag[1], mag[2], mag[3]);
+    *reinterpret_cast<uint32_t*>(msb + c * msbStride + i) = mb;
+  }
+  // 16 lanes x 4 bits = one sign word
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t word = (uint64_t)nn << (4 * (lane & 15u));
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1)
+    word |= __shfl_xor(word, d, 64);
+  if ((lane & 15u) == 0 && i < n)
+    sign[c * signStride + (i >> 6)] = word;
+}
+
 // SPECK_FLT.cpp:373-399 : (q * c) * (+-1.0), left to right.  When the decoder's masks are given,
 // the coefficients that became significant but were never refined are completed here instead of
 // in a pass of their own (k_dec_finish, speck_dec.hip: 1.5 * 2^plane - 1, SPECK_INT.cpp:462-468).
@@ -1697,6 +1737,9 @@ int launch_quantize(hipStream_t stream, bool wide, const double* vals, size_t va
   if (wide)
     LAUNCH_K(k_quantize<uint64_t>, grid, dim3(kThreads), 0, stream, vals, valsStride, n,
                        (uint64_t*)coef, coefStride, sign, signStride, msb, msbStride, st, 1);
+  else if (n % 64 == 0 && valsStride % 4 == 0 && coefStride % 4 == 0 && msbStride % 4 == 0)
+    LAUNCH_K(k_quantize4, dim3((n / 4 + kThreads - 1) / kThreads, nchunks), dim3(kThreads), 0, stream, vals,
+             valsStride, n, (uint32_t*)coef, coefStride, sign, signStride, msb, msbStride, st);
   else
     LAUNCH_K(k_quantize<uint32_t>, grid, dim3(kThreads), 0, stream, vals, valsStride, n,
                        (uint32_t*)coef, coefStride, sign, signStride, msb, msbStride, st, 0);
