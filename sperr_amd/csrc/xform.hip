@@ -825,7 +825,7 @@ template <int IO>
 __global__ void __launch_bounds__(kXYZThreadsF) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                CoderState* st, const void* volume, VolDesc vd, const ChunkGeom* geom, int wantMax,
-               uint32_t in0, uint32_t in1, uint32_t in2)
+               uint32_t in0, uint32_t in1, uint32_t in2, uint32_t nseg)
 {
   static_assert(IO == 1 || IO == 2, "float or double volume");
   using VT = typename std::conditional<IO == 1, float, double>::type;
@@ -833,7 +833,16 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
   if (st[c].is_const != 0)
     return;
   const uint32_t tid = threadIdx.x;
-  const uint32_t y0 = blockIdx.x * kXYZRows;
+  // A small batch has too few tiles for the device: the slices are then dealt to `nseg` workgroups
+  // per tile.  Segment g emits what the even slices 2m, m in [mA, mB), complete (the last one also
+  // the end of the lines); a pipeline's output depends on the ten slices before it, so the segment
+  // starts that much earlier and throws away what comes out before its own part.
+  const uint32_t seg = blockIdx.x % nseg, npairsAll = (cz + 1) / 2;   // even slices 0, 2, ...: m < npairsAll
+  const uint32_t mA = seg == 0 ? 0u : (uint32_t)((uint64_t)npairsAll * seg / nseg);
+  const uint32_t mB = seg + 1 == nseg ? npairsAll : (uint32_t)((uint64_t)npairsAll * (seg + 1) / nseg);
+  const uint32_t zFirst = mA >= 6 ? 2 * (mA - 6) : 0u;          // first slice this workgroup lifts
+  const uint32_t zEnd = seg + 1 == nseg ? cz : 2 * mB - 1;       // one past its last slice
+  const uint32_t y0 = (blockIdx.x / nseg) * kXYZRows;
   const uint32_t nt = min((uint32_t)kXYZRows, cy - y0);   // rows of this tile
   const uint32_t RS = xyz_row_stride(cx);
   // two staging buffers that swap roles from pass to pass (three barriers per slice instead of six);
@@ -891,8 +900,8 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
       pre[k] = (tid + (uint32_t)k * kXYZThreadsF) < nstage
                    ? src[(size_t)((pk[k] >> 12) & 0x7fffu) * vsy + (pk[k] & 0xfffu)] : (VT)0;
   };
-  issue(0);
-  for (uint32_t z = 0; z < cz; z++) {
+  issue(zFirst);
+  for (uint32_t z = zFirst; z < zEnd; z++) {
     // (what the addresses below are made of goes through an empty asm once per slice: otherwise the
     //  compiler computes every one of them before the loop and keeps -- spills -- some 200 values)
     uint32_t RSv = RS, tidv = tid;
@@ -909,7 +918,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
     for (int k = 0; k < kXYZStageF; k++)
       if ((tid + (uint32_t)k * kXYZThreadsF) < nstage)
         xyz_put(A + (pk[k] >> 27) * RSv, pk[k] & 0xfffu, cx, (double)pre[k] - mean);
-    if (z + 1 < cz)
+    if (z + 1 < zEnd)
       issue(z + 1);   // (in flight while this slice is lifted)
     XYZ_LDS_BARRIER();
     xyz_lift_x<true, kXYZThreadsF>(A, B, RSv, cx, 0, kXYZStaged, tidv, K);
@@ -935,8 +944,10 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
           if (m >= 2) {
             const double d2n = fma(K.gamma, e1p[k] + e1n, d1p[k]);                      // d2[2m-3]
             const double e2 = K.eps * fma(K.delta, (m == 2 ? d2n : d2p[k]) + d2n, e1p[k]);   // e2[2m-4]
-            emit(k, m - 2, e2);
-            emit(k, ze + m - 2, (-K.inv_eps) * d2n);
+            if (m >= mA) {   // (before that: the segment's run-up)
+              emit(k, m - 2, e2);
+              emit(k, ze + m - 2, (-K.inv_eps) * d2n);
+            }
             d2p[k] = d2n;
           }
           d1p[k] = d1n;
@@ -946,10 +957,10 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
       }
     }
   }
-  // ---- the end of the lines: the samples still in the pipelines
+  // ---- the end of the lines: the samples still in the pipelines (the last segment's to emit)
 #pragma unroll
   for (int k = 0; k < kXYZPosF; k++) {
-    if ((tid + (uint32_t)k * kXYZThreadsF) >= npos)
+    if ((tid + (uint32_t)k * kXYZThreadsF) >= npos || seg + 1 != nseg)
       continue;
     if ((cz & 1) == 0) {   // the last sample is odd: x[2M+1], M = cz / 2 - 1
       const uint32_t M = cz / 2 - 1;
@@ -987,13 +998,20 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
 template <int IO>
 __global__ void __launch_bounds__(kXYZThreadsI) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
-               const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F)
+               const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F, uint32_t nseg)
 {
   static_assert(IO == 1 || IO == 2, "float or double volume");
   using VT = typename std::conditional<IO == 1, float, double>::type;
   const uint32_t c = blockIdx.y;
   const uint32_t tid = threadIdx.x;
-  const uint32_t y0 = blockIdx.x * kXYZRows;
+  // (small batches: `nseg` workgroups per tile share the slices, see k_lift_xyz_fwd; segment g finishes
+  //  the slices that the pairs [mA, mB) complete, the last one also the end of the lines, and runs
+  //  its pipelines six pairs ahead of that)
+  const uint32_t seg = blockIdx.x % nseg, npairsAll = cz / 2;
+  const uint32_t mA = seg == 0 ? 0u : (uint32_t)((uint64_t)npairsAll * seg / nseg);
+  const uint32_t mB = seg + 1 == nseg ? npairsAll : (uint32_t)((uint64_t)npairsAll * (seg + 1) / nseg);
+  const uint32_t mFirst = mA >= 6 ? mA - 6 : 0u;
+  const uint32_t y0 = (blockIdx.x / nseg) * kXYZRows;
   const uint32_t nt = min((uint32_t)kXYZRows, cy - y0);
   const uint32_t RS = xyz_row_stride(cx);
   double* sm = reinterpret_cast<double*>(dyn_smem);
@@ -1008,7 +1026,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYZThreadsI / 64;
 
   if (st[c].is_const != 0) {   // the chunk is its constant
-    for (uint32_t z = 0; z < cz; z++)
+    for (uint32_t z = seg; z < cz; z += nseg)
       for (uint32_t k = tid; k < nt * cx; k += kXYZThreadsI)
         volc[(size_t)z * vsz + (size_t)(y0 + k / cx) * vsy + k % cx] = (VT)mean;
     return;
@@ -1097,7 +1115,8 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   for (int k = 0; k < kXYZPosI; k++)
     o1p[k] = e1p[k] = o2p[k] = e2p[k] = 0.0;
   const uint32_t npairs = cz / 2;
-  for (uint32_t m = 0; m < npairs; m++) {
+  for (uint32_t m = mFirst; m < mB; m++) {
+    const bool mine = m >= mA;   // (else: the segment's run-up)
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++)
       asm volatile("" : "+v"(pk[k]));
@@ -1114,7 +1133,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       if (m >= 1) {
         const double o2 = fma(-K.gamma, e1p[k] + e1, o1p[k]);                // o2[m-1]
         const double e2 = fma(-K.beta, (m == 1 ? o2 : o2p[k]) + o2, e1p[k]); // e2[m-1]
-        if (m >= 2)
+        if (m >= 2 && mine)
           stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                      // o3[m-2]: slice 2m-3
         o2p[k] = o2;
         e2p[k] = e2;
@@ -1122,14 +1141,16 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       o1p[k] = o1;
       e1p[k] = e1;
     }
-    if (m >= 2)
+    if (m >= 2 && mine)
       finish_slice(2 * m - 3);
-    if (m >= 1) {
+    if (m >= 1 && mine) {
       stage_all(e2p);
       finish_slice(2 * m - 2);
     }
   }
-  // ---- the end of the lines
+  // ---- the end of the lines (the last segment's)
+  if (seg + 1 != nseg)
+    return;
   if ((cz & 1) == 0) {   // pairs 0 .. M, M = cz / 2 - 1
     const uint32_t M = npairs - 1;
     double outC[kXYZPosI];
@@ -1605,24 +1626,29 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
       if (set_max_dyn_lds(f, 160 * 1024))
         return -1;
   }
-  const dim3 grid((cdims[1] + kXYZRows - 1) / kXYZRows, nchunks);
+  // a batch with fewer tiles than two per CU: the slices of a tile are dealt to several workgroups
+  const uint32_t ntile = (cdims[1] + kXYZRows - 1) / kXYZRows;
+  uint32_t nseg = 1;
+  while (nseg < 4 && (size_t)ntile * nchunks * nseg < 512 && cdims[2] / (2 * nseg) >= 24)
+    nseg *= 2;
+  const dim3 grid(ntile * nseg, nchunks);
   const LiftConsts K = lift_consts();
   if (forward) {
     const int wantMax = F.mode == 1 ? 1 : 0;
     if (io == 1)
       LAUNCH_K((k_lift_xyz_fwd<1>), grid, dim3(kXYZThreadsF), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
+               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2], nseg);
     else
       LAUNCH_K((k_lift_xyz_fwd<2>), grid, dim3(kXYZThreadsF), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2]);
+               cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2], nseg);
   }
   else {
     if (io == 1)
       LAUNCH_K((k_lift_xyz_inv<1>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, F);
+               cdims[2], K, st, volume, vd, geom, F, nseg);
     else
       LAUNCH_K((k_lift_xyz_inv<2>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, F);
+               cdims[2], K, st, volume, vd, geom, F, nseg);
   }
   HIP_CHECK(hipGetLastError());
   return 0;
