@@ -668,6 +668,12 @@ size_t arena_cap_env()
   const char* v = getenv("SPERR_HIP_ARENA_MAX_MB");   // read per call: a test changes it
   return v ? (size_t)std::max(1ll, atoll(v)) << 20 : ~size_t(0);
 }
+// SPERR_HIP_ARENA_DEBUG=1: every array of a batch's workspace with its size, on stderr
+bool arena_debug()
+{
+  static const bool on = getenv("SPERR_HIP_ARENA_DEBUG") && atoi(getenv("SPERR_HIP_ARENA_DEBUG")) != 0;
+  return on;
+}
 size_t arena_room(size_t have, size_t freeNow)
 {
   return std::min((size_t)((freeNow + have) * 0.80), arena_cap_env());
@@ -855,10 +861,12 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   memset(&e, 0, sizeof(e));
   e.tree = P.dtree;
   e.nchunks = B;
-#define TAKE(dst, T, count)            \
-  dst = A.take<T>((size_t)(count));    \
-  if (!dst)                            \
-    return false;
+#define TAKE(dst, T, count)                                                            \
+  dst = A.take<T>((size_t)(count));                                                    \
+  if (!dst)                                                                            \
+    return false;                                                                      \
+  if (arena_debug())                                                                   \
+    fprintf(stderr, "[sperr_hip] arena %-18s %10.2f MB\n", #dst, (double)((size_t)(count) * sizeof(T)) / 1048576.0);
   TAKE(e.cst, CoderState, B);
   TAKE(e.st, EncState, B);
   TAKE(o.geom, ChunkGeom, B);
@@ -1410,12 +1418,13 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     std::map<Dims, uint32_t> count, seen;
     for (uint32_t i = 0; i < nchunks; i++)
       count[Dims{chunks[i][1], chunks[i][3], chunks[i][5]}]++;
-    static const uint32_t partsEnv = getenv("SPERR_HIP_ENC_PARTS") ? (uint32_t)std::max(1, atoi(getenv("SPERR_HIP_ENC_PARTS"))) : 2u;
+    static const uint32_t partsEnv = getenv("SPERR_HIP_ENC_PARTS") ? (uint32_t)std::max(1, atoi(getenv("SPERR_HIP_ENC_PARTS"))) : 3u;
     for (uint32_t i = 0; i < nchunks; i++) {
       const auto& c = chunks[i];
       const Dims d{c[1], c[3], c[5]};
       const uint32_t n = count[d], k = seen[d]++;
-      const uint32_t parts = (mode == 1 && !slice && n >= 64 && n <= 512) ? std::min<uint32_t>(partsEnv, kSubStreams) : 1u;
+      static const uint32_t partsMin = getenv("SPERR_HIP_ENC_PARTS_MIN") ? (uint32_t)std::max(2, atoi(getenv("SPERR_HIP_ENC_PARTS_MIN"))) : 64u;
+      const uint32_t parts = (mode == 1 && !slice && n >= partsMin && n <= 512) ? std::min<uint32_t>(std::min<uint32_t>(partsEnv, n / 4), kSubStreams) : 1u;
       groups[GKey{c[1], c[3], c[5], (size_t)((uint64_t)k * parts / n)}].push_back(
           {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
     }
@@ -1822,10 +1831,12 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.tree = P.dtree;
   d.treeTabLen = (uint32_t)P.ht.tab.size();
   d.nchunks = B;
-#define TAKE(dst, T, count)            \
-  dst = A.take<T>((size_t)(count));    \
-  if (!dst)                            \
-    return false;
+#define TAKE(dst, T, count)                                                            \
+  dst = A.take<T>((size_t)(count));                                                    \
+  if (!dst)                                                                            \
+    return false;                                                                      \
+  if (arena_debug())                                                                   \
+    fprintf(stderr, "[sperr_hip] arena %-18s %10.2f MB\n", #dst, (double)((size_t)(count) * sizeof(T)) / 1048576.0);
   TAKE(d.cst, CoderState, B);
   TAKE(d.st, DecState, B);
   TAKE(o.geom, ChunkGeom, B);
