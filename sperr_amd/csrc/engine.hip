@@ -1895,7 +1895,10 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   }
   d.queueCap = 28672 + 64;
   // k_lis_hi: a pair of queues per workgroup, up to hiGroupsMax workgroups per chunk
-  d.hiK = (uint32_t)std::max(2, P.maxK);
+  // k_lis_hi keeps tables for the classes of the smallest sets only (2^3 .. 32^3 by default: SPERR_HIP_HI_KCAP);
+  // larger sets are walked into bit by bit, which leaves the LDS to longer regions of the stream
+  static const int hiKcap = getenv("SPERR_HIP_HI_KCAP") ? std::max(2, atoi(getenv("SPERR_HIP_HI_KCAP"))) : 5;
+  d.hiK = (uint32_t)std::min(std::max(2, P.maxK), hiKcap);
   {
     static const uint32_t ahead = getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_AHEAD")) : 384u;
     d.hiAhead = ahead;

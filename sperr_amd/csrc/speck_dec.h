@@ -181,7 +181,7 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 8) + 1u;   // eighths of a byte
   const uint32_t fixed = 4 * 8 + 2 * 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
-  w = w / 1024 * 1024;
+  w = w / 256 * 256;   // (any multiple of 64 works; round 2 took multiples of 1024: 4096 instead of 4352 bits for a 256^3 chunk)
   if (w > (uint32_t)kTabWMax)
     w = kTabWMax;
   return w;

@@ -3887,8 +3887,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     if (ok) {
       const LevelClass& A = sh_lc[tl];
       const LevelClass& B = sh_lc[l];
-      ok = (int)B.K <= tk;
-      for (int j = 0; ok && j < (int)B.K; j++)
+      const int BK = min((int)B.K, Kcap);
+      ok = BK <= tk;
+      for (int j = 0; ok && j < BK; j++)
         ok = A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
     }
     return __ballot(ok);
@@ -3898,9 +3899,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       return false;
     const LevelClass& A = sh_lc[sh_tabLevel];
     const LevelClass& B = sh_lc[lv];
-    if ((int)B.K > sh_tabK)
+    const int BK = min((int)B.K, Kcap);
+    if (BK > sh_tabK)
       return false;
-    for (int j = 0; j < (int)B.K; j++)
+    for (int j = 0; j < BK; j++)
       if (A.arity[j] != B.arity[j] || A.lev[j] != B.lev[j])
         return false;
     return true;
@@ -4122,11 +4124,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         hint = next_level((int)t.nlevels);
       const int lv_ = (int)lane;
       const bool inr = lv_ < (int)t.nlevels;
-      const int Kl = inr ? (int)sh_lc[lv_].K : 0;
-      const bool usable = inr && sh_len[lv_] != 0 && sh_lc[lv_].regular && Kl <= Kcap;
+      // (class chains are compared up to the classes the tables have room for: the sets above that are
+      //  walked into bit by bit, whatever their list -- round 3)
+      const int Kl = inr ? min((int)sh_lc[lv_].K, Kcap) : 0;
+      const bool usable = inr && sh_len[lv_] != 0 && sh_lc[lv_].regular;
       int best = hint;
       if (hint >= 0) {
-        const int AK = (int)sh_lc[hint].K;
+        const int AK = min((int)sh_lc[hint].K, Kcap);
         int bestK = AK;
         uint64_t cm = __ballot(usable && lv_ < hint && Kl > AK && Kl <= AK + kSpecExtra);
         while (cm) {   // from the level below the hint downwards, as long as the chains get longer
@@ -4160,11 +4164,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     const bool zeroRegion = sh_any == 0;
     if (!zeroRegion && sh_tabLevel >= 0) {
       const int lv = sh_tabLevel;
-      const int K = sh_lc[lv].K, Kh = sh_hintK;
+      const int K = min((int)sh_lc[lv].K, Kcap), KhT = sh_hintK, Kh = min(KhT, Kcap);
       build_tables(lv, 0, K);
       if (stamps) dbg1 = __builtin_readcyclecounter();
-      build_hop(hop, Kh - 1);
-      const bool hop2Now = Kh < K && b.hiHop2;
+      const bool hop1 = KhT <= Kcap;   // the hinted list's entries (class KhT - 1) have a table
+      if (hop1)
+        build_hop(hop, Kh - 1);
+      const bool hop2Now = hop1 && Kh < K && b.hiHop2;
       if (hop2Now)
         build_hop(hop2, Kh);
       if (stamps) dbg2 = __builtin_readcyclecounter();
@@ -4172,7 +4178,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         const uint64_t m = serve_mask(lv, K);
         if (tid == 0) {
           sh_tabK = K;
-          sh_hopTop[0] = Kh - 1;
+          sh_hopTop[0] = hop1 ? Kh - 1 : -1;
           sh_hopTop[1] = hop2Now ? Kh : -1;
           sh_serve = m;
         }
@@ -4327,6 +4333,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               }
               else if (sh_depth > 1)
                 act = 8;    // serial hop
+              else if (K - 1 >= Kcap)
+                act = 10;   // a list of sets the tables do not cover: entry by entry
               else if (sh_hopTop[0] == K - 1 || sh_hopTop[1] == K - 1)
                 act = 9;    // list entries
               else
@@ -4402,7 +4410,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 const bool coded = found || (n - k) > 1;
                 uint32_t kind, at;
                 if (coded) {
-                  const uint32_t u = Uu[(size_t)cls * TS + y];
+                  // (children of a class without a table: their test bit decides, a significant one
+                  //  is entered)
+                  const uint32_t u = cls < Kcap ? (uint32_t)Uu[(size_t)cls * TS + y] : (bit_at(y) ? (uint32_t)kTInf : 1u);
                   if (u == 1) {
                     kind = 1;
                     at = y;
@@ -4424,7 +4434,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 else {
                   found = 1;
                   at = y;
-                  const uint32_t len = Tt[(size_t)cls * TS + y];
+                  const uint32_t len = cls < Kcap - 1 ? (uint32_t)Tt[(size_t)cls * TS + y] : (uint32_t)kTInf;
                   if (len == kTInf)
                     kind = 3;
                   else {
@@ -4494,6 +4504,53 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               sh_depth = (uint32_t)depth;
               if (sh_nhb > (uint32_t)kHiHopBorn)
                 sh_nhb = kHiHopBorn;
+            }
+            HI_WAVE_SYNC();
+            HI_T(2);
+            continue;
+          }
+          if (act == 10) {
+            // A list whose sets are larger than the tables' classes (at most a few hundred entries per
+            // chunk, each of which splits once in its life): '0' entries are counted off 32 at a time,
+            // a '1' entry is walked into like an entry that leaves the region.
+            if (lane == 0) {
+              uint32_t r = (uint32_t)(sh_pos - a), e = sh_e, rem = sh_rem, depth = 1;
+              const uint32_t lOff = b.levelOff[sh_level];
+              while (rem > 0 && r < SR) {
+                const uint32_t lim = min(rem, SR - r);
+                const uint32_t v = bits32(r);
+                const uint32_t z = v ? (uint32_t)__ffs((int)v) - 1u : 32u;
+                if (z >= lim) {
+                  e += lim;
+                  rem -= lim;
+                  r += lim;
+                  break;
+                }
+                e += z;
+                rem -= z;
+                r += z;
+                if (z == 32)
+                  continue;
+                const uint32_t ei = lOff + e;
+                const uint64_t ent = lisCur[ei];
+                TabCtx& nc = sh_ctx[1];
+                nc.parent = ent;
+                nc.remaining = C.arity[K - 1];
+                nc.cls = (int8_t)(K - 2);
+                nc.found = 0;
+                nc.nextOrd = 0;
+                sh_base = ent;
+                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+                e++;
+                rem--;
+                r += 1;   // its '1'
+                depth = 2;
+                break;
+              }
+              sh_e = e;
+              sh_rem = rem;
+              sh_pos = a + r;
+              sh_depth = depth;
             }
             HI_WAVE_SYNC();
             HI_T(2);
@@ -4612,7 +4669,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       }
       if (act == kActTables) {
         const int lv = (int)sh_level;
-        const int K = sh_lc[lv].K;
+        const int K = min((int)sh_lc[lv].K, Kcap);
         const int j0 = sh_tabFrom;
         build_tables(lv, j0, K);
         if (tid < 64) {
