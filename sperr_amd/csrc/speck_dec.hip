@@ -5193,7 +5193,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
-  const uint32_t l0Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l0Total / nc));
+  static const uint32_t l01Cap = getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
+  const uint32_t l0Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l0Total / nc));
   if (plan.tables && plan.l0) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l0), (int)kL0Smem) ||
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l1), (int)kL1Smem))
@@ -5201,7 +5202,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
   static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
-  const uint32_t l1Groups = std::min<uint32_t>(16, std::max<uint32_t>(1, l1Total / nc));
+  const uint32_t l1Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l1Total / nc));
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
   // workgroups per chunk of the k_lis_hi pass, at most what the queues were sized for
   // (SPERR_HIP_HI_WGS: the total over the batch's chunks; measured on MI355X with two sub-batches
