@@ -5,12 +5,14 @@ run() {
 import json,sys
 l=json.loads(sys.stdin.readline())
 sb=l.get('small_batch') or {}
-print('$*', 'value', l['value'], 'comp', l['compress_GBps_per_gpu'], 'decomp', l['decompress_GBps_per_gpu'], 'small', sb.get('compress_GBps'), sb.get('decompress_GBps'), 'top', l['roofline']['kernel'], l['roofline']['kernel_ms_per_step'], l['roofline']['kernel_busy_ms_per_step'])
+print('$*', 'value', l['value'], 'comp', l['compress_GBps_per_gpu'], 'decomp', l['decompress_GBps_per_gpu'], 'small', sb.get('compress_GBps'), sb.get('decompress_GBps'))
 "
 }
 run A=0
-run SPERR_HIP_HI_HOP2=0
-run SPERR_HIP_HI_EXTRA=0
-run SPERR_HIP_HI_HOP2=0 SPERR_HIP_HI_EXTRA=0
-run SPERR_HIP_HI_HOP2=0 SPERR_HIP_HI_WGS=192
-run SPERR_HIP_LIVE_CHECK=0
+run SPERR_HIP_HI_WGS=128
+run SPERR_HIP_HI_WGS=224
+run SPERR_HIP_HI_WGS=320
+run SPERR_HIP_L1_WGS=1024 SPERR_HIP_L0_WGS=768
+run SPERR_HIP_L1_WGS=512 SPERR_HIP_L0_WGS=384
+run SPERR_HIP_HI_AHEAD=256
+run SPERR_HIP_HI_AHEAD=512
