@@ -91,8 +91,12 @@ FarmShape farm_shape(size_t nthreads, size_t ndev)
 // Equally shaped chunks, in chunk_volume order, `perItem` at a time.  An item is sized so that
 // every worker sees a few of them (balance) but none is tiny (the per-plane kernels of the coder
 // have a fixed cost per launch) or larger than the staging buffers should be.
+// `perWorker`: items every worker should see.  Measured on one MI355X, 1024^3 fp32 in 256^3 chunks,
+// 3 workers, pinned volume (round 3, `tools/farm_tune.py`): compression 90.5 / 87.2 / 86.8 / 87.1 /
+// 91.0 / 95.1 ms for items of 3 / 4 / 5 / 6 / 8 / 11 chunks (four items per worker), decompression
+// 126 / 114 / 110 / 107 / 108 ms for 4 / 5 / 6 / 8 / 11 (two: its list kernels want larger batches).
 std::vector<Item> make_items(const std::vector<std::array<size_t, 6>>& chunks, size_t bytesPerValue,
-                             size_t nworkers, const FarmShape& fs)
+                             size_t nworkers, const FarmShape& fs, size_t perWorker = 2)
 {
   std::map<Dims3, std::vector<uint32_t>> groups;
   for (uint32_t i = 0; i < chunks.size(); i++)
@@ -111,7 +115,10 @@ std::vector<Item> make_items(const std::vector<std::array<size_t, 6>>& chunks, s
     const size_t n = g->second.size();
     const size_t kMax = std::max<size_t>(1, fs.itemBytesMax / std::max<size_t>(1, chunkBytes));
     const size_t kMin = std::max<size_t>(1, (size_t(32) << 20) / std::max<size_t>(1, chunkBytes));
-    size_t k = (n + 2 * nworkers - 1) / (2 * nworkers);
+    size_t k = (n + perWorker * nworkers - 1) / (perWorker * nworkers);
+    // (but not below four chunks while every worker still gets an item: a batch of one or two chunks
+    //  is all launch latency)
+    k = std::max(k, std::min<size_t>(4, (n + nworkers - 1) / nworkers));
     k = std::min(std::max(k, kMin), kMax);
     k = std::min<size_t>(k, 256);   // (a batch of the engine holds at most 256 chunks)
     if (fs.itemChunksForced)
@@ -686,7 +693,7 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     return -1;
   J.fs = farm_shape(nthreads, devs.size());
   J.esz = is_float ? 4 : 8;
-  J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs);
+  J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs, mode == 1 ? 4 : 2);
   assign_workers(J, devs);
   J.src = static_cast<const uint8_t*>(src);
   J.is_float = is_float;
