@@ -145,6 +145,32 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* smem, T* total)
   return base + inc - v;
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load,
+// store and atomic the wavefront has in flight (s_waitcnt vmcnt(0)); a kernel whose threads talk
+// through LDS while results stream out to memory pays a round trip to HBM / L2 per barrier for that.
+#define LDS_ONLY_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// block_exclusive_scan with such barriers
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan_lds(T v, T* smem, T* total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const T inc = wave_inclusive_scan(v);
+  LDS_ONLY_BARRIER();  // protect smem reuse between consecutive calls
+  if (lane == 63)
+    smem[wave] = inc;
+  LDS_ONLY_BARRIER();
+  T base = 0, tot = 0;
+  for (int w = 0; w < nw; w++) {
+    const T s = smem[w];
+    if (w < wave)
+      base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
 __device__ __forceinline__ void atomic_or64(uint64_t* p, uint64_t v)
 {
   if (v)
