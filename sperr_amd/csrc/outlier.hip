@@ -494,106 +494,116 @@ k_speck1d(OutlierBufs b)
   // go into the left half and park the right one, '0': the left half is born insignificant and the
   // right one is significant without a bit) down to a single value and its sign; then one closing
   // bit per parked half, innermost first: '0' hands it to its list (or the LIP), '1' starts the next
-  // path there (a parked single value: its sign follows).  A whole path is parsed by the wave at
-  // once, lane = list level of the halves born at a step: the length of the run at step t follows
-  // from the first t bits (the interval at depth t that the complemented bits, reversed, index:
-  // (L >> t) + (rev < L mod 2^t)), its start from a prefix sum; the lanes of the halves that are
-  // born append them to their own level's list, the parked ones stay in their lanes (vPS, vPL and
-  // the mask `parked`: levels grow inwards, so the innermost parked half is the highest bit).
-  uint32_t vPS = 0, vPL = 0;
-  uint64_t parked = 0;
-  auto commit_born = [&](bool mine, uint32_t bs, uint32_t bl) {   // lane = level of the half
-    if (mine) {
-      if (bl == 1)
+  // path there (a parked single value: its sign follows).
+  //
+  // Round 3: the serial part, the CHAIN, only finds out where every path starts and ends.  A half is
+  // known by its depth below the list entry and the way to it (R: bit j = "went right at depth j"),
+  // its length in closed form ((L >> d) + (R mod 2^d < L mod 2^d), the rule of speck_tree.h), the
+  // parked right halves by a mask of depths `m` -- so a path costs a few dozen scalar instructions on
+  // the stream window (it ends at the first step whose chosen half is one value: step e - 1 or e for
+  // a half of 2^e .. 2^(e+1) - 1 values) and leaves one RECORD in lane `nrec` of five registers.
+  // What the paths mean for the lists, the LIP and the values found is worked out 64 records at a
+  // time (`flush_paths`, lane = record): all lanes walk down from their list entry together, one
+  // depth per round; at a depth a record has at most one half to hand over -- the left half it
+  // passed by on the right during its own path, or the parked right half that one of its closing
+  // zeros released -- and the halves of a round join that level's list in lane order, which is
+  // stream order.  tests/model/speck_model.cpp::model_speck1d_decode_batched is the CPU model.
+  // (Before: a whole path per step with lane = level, about 1400 cycles per path.)
+  uint32_t rES = 0, rEL = 0, rR = 0, rMeta = 0, rClosed = 0, nrec = 0;
+  auto flush_paths = [&](uint32_t lev) {
+    if (nrec == 0)
+      return;
+    const bool valid = lane < nrec;
+    const uint32_t u = rMeta & 0xffu, tEnd = (rMeta >> 8) & 0xffu;
+    uint32_t s = rES, l = rEL;
+    for (uint32_t j = 0;; j++) {
+      const bool act = valid && j < tEnd;
+      if (__ballot(act) == 0)
+        break;
+      const uint32_t h0 = l - l / 2, r0 = l / 2;
+      const bool right = ((rR >> j) & 1u) != 0;
+      const bool born = act && (right ? j >= u : ((rClosed >> (j + 1u)) & 1u) != 0);
+      const uint32_t bs = right ? s : s + h0, bl = right ? h0 : r0;
+      if (born && bl == 1)
         atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
-      else if (vOff + vCnt < vEnd) {
-        runs[vOff + vCnt] = (uint64_t)bs | ((uint64_t)bl << 32);
-        vCnt++;
+      const uint64_t bm = __ballot(born && bl > 1);
+      if (bm) {
+        const uint32_t lvl = lev + j + 1u;
+        if (lvl >= b.nlists)
+          err = 2;
+        else {
+          const uint32_t have = rdlane(vCnt, lvl), first = rdlane(vOff, lvl) + have;
+          const uint32_t nbn = (uint32_t)__popcll(bm);
+          if (first + nbn > rdlane(vEnd, lvl))
+            err = 2;   // list storage exhausted (cannot happen with the host's bounds)
+          else {
+            if (born && bl > 1)
+              runs[first + (uint32_t)__popcll(bm & low_mask(lane))] = (uint64_t)bs | ((uint64_t)bl << 32);
+            wrlane(vCnt, lvl, have + nbn);
+          }
+        }
       }
-      else
-        vErr = 2;   // list storage exhausted (cannot happen with the host's bounds)
+      if (act) {
+        if (right) {
+          s += h0;
+          l = r0;
+        }
+        else
+          l = h0;
+      }
     }
-  };
-  auto record_found = [&](uint32_t idx, uint32_t sg) {
-    if (nfound < b.kStride && lane == 0) {
-      fpos[nfound] = idx;
-      fmeta[nfound] = (uint8_t)((uint32_t)curPlane | (sg << 7));
+    if (valid && nfound + lane < b.kStride) {
+      fpos[nfound + lane] = s;
+      fmeta[nfound + lane] = (uint8_t)((uint32_t)curPlane | (((rMeta >> 16) & 1u) << 7));
     }
-    nfound++;
+    nfound += nrec;
+    nrec = 0;
   };
-  auto expand_dec = [&](uint32_t ns, uint32_t nl, uint32_t nlev) {   // a run of at least two values
-    parked = 0;
+  auto expand_chain = [&](uint32_t es, uint32_t el, uint32_t lev) {   // a run of at least two values
+    uint32_t R = 0, m = 0, u = 0, lo = el;
     for (;;) {
-      // ---- one path, from the run (ns, nl) of level nlev down to a value
       const uint64_t peek = window();
-      const uint32_t t = lane - (nlev + 1u);            // this lane: the halves born at step t, level nlev + 1 + t
-      const bool inr = lane > nlev && t < 32u;
-      const uint32_t mk = inr ? (1u << t) - 1u : 0u;
-      const uint32_t lt = inr ? (nl >> t) + (((~(uint32_t)peek & mk) < (nl & mk)) ? 1u : 0u) : 0u;
-      const uint32_t bt = inr ? (uint32_t)(peek >> t) & 1u : 0u;
-      const uint32_t h0 = lt - lt / 2, r0 = lt / 2;
-      const uint64_t tm = __ballot(inr && lt > 1 && (bt ? h0 : r0) == 1u);
-      if (tm == 0) {   // (cannot happen: a run of two or more values ends within 32 steps)
+      uint32_t nsteps = 0;
+      if (lo > 1) {
+        const uint32_t t0 = 30u - (uint32_t)__clz((int)lo), mk = (1u << t0) - 1u;
+        const uint32_t lt = (lo >> t0) + (((~(uint32_t)peek & mk) < (lo & mk)) ? 1u : 0u);
+        const uint32_t bt = (uint32_t)(peek >> t0) & 1u;
+        nsteps = (lt == 2u || (lt == 3u && bt == 0u)) ? t0 + 1u : t0 + 2u;
+      }
+      if (u + nsteps > 31u) {   // (cannot happen: N < 2^32)
         err = 2;
         return;
       }
-      const uint32_t LT = (uint32_t)__ffsll((long long)tm) - 1u;
-      const bool onPath = inr && lane <= LT;
-      const uint32_t add = (onPath && !bt) ? h0 : 0u;
-      const uint32_t st = ns + wave_scan_dpp(add) - add;
-      const uint32_t steps = LT - nlev;                // bits of the path
-      const uint32_t sg = (uint32_t)(peek >> steps) & 1u;
-      record_found(rdlane(bt ? st : st + h0, LT), sg);
-      rpos += steps + 1u;
-      // (left halves are born insignificant: appended together with the parked halves that close first)
-      bool pend = onPath && !bt;
-      uint32_t pS = st, pL = h0;
-      if (onPath && bt) {                              // right halves wait for their bit
-        vPS = st + h0;
-        vPL = r0;
+      const uint32_t pm = (1u << nsteps) - 1u;
+      R |= (~(uint32_t)peek & pm) << u;
+      m |= ((uint32_t)peek & pm) << (u + 1u);
+      const uint32_t sg = (uint32_t)(peek >> nsteps) & 1u;
+      const uint32_t cnt = (uint32_t)__popc(m);
+      const uint64_t cw = peek >> (nsteps + 1u);   // (at least 31 valid bits, cnt <= 31)
+      const uint32_t z = min(cw ? (uint32_t)__ffsll((long long)cw) - 1u : 64u, cnt);
+      uint32_t closed = 0;
+      for (uint32_t k = 0; k < z; k++) {   // the z innermost parked halves are born insignificant
+        const uint32_t top = 31u - (uint32_t)__clz((int)m);
+        m &= ~(1u << top);
+        closed |= 1u << top;
       }
-      parked |= __ballot(onPath && bt);
-      // ---- closing bits (the first ones still are in `peek` unless the path was long)
-      bool next = false, first = true;
-      while (parked) {
-        const uint32_t cnt = (uint32_t)__popcll(parked);
-        const uint64_t w = (first && steps + 1u + cnt < 64u) ? peek >> (steps + 1u) : window();
-        first = false;
-        const uint32_t z = min(w ? (uint32_t)__ffsll((long long)w) - 1u : 64u, cnt);
-        if (z) {   // the z innermost parked halves are born insignificant
-          const bool isP = ((parked >> lane) & 1ull) != 0;
-          const uint32_t above = (uint32_t)__popcll((parked >> lane) >> 1);
-          const bool close = isP && above < z;
-          pS = close ? vPS : pS;
-          pL = close ? vPL : pL;
-          pend = pend || close;
-          parked &= ~__ballot(close);
-          rpos += z;
-        }
-        if (__ballot(pend)) {
-          commit_born(pend, pS, pL);
-          pend = false;
-        }
-        if (z == cnt)
-          break;
-        rpos++;   // (a '1': z < cnt <= 64, so the bit is inside the window)
-        const uint32_t top = 63u - (uint32_t)__clzll((long long)parked);
-        parked &= ~(1ull << top);
-        const uint32_t rs = rdlane(vPS, top), rl = rdlane(vPL, top);
-        if (rl == 1) {
-          record_found(rs, get());
-          continue;
-        }
-        ns = rs;
-        nl = rl;
-        nlev = top;
-        next = true;
-        break;
-      }
-      if (__ballot(pend))
-        commit_born(pend, pS, pL);
-      if (!next)
+      wrlane(rES, nrec, es);
+      wrlane(rEL, nrec, el);
+      wrlane(rR, nrec, R);
+      wrlane(rMeta, nrec, u | ((u + nsteps) << 8) | (sg << 16));
+      wrlane(rClosed, nrec, closed);
+      nrec++;
+      if (nrec == 64u)
+        flush_paths(lev);
+      rpos += nsteps + 1u + z;
+      if (z == cnt)
         return;
+      rpos++;   // (a '1': z < cnt <= 31, so the bit was inside the window)
+      u = 31u - (uint32_t)__clz((int)m);
+      m &= ~(1u << u);
+      R = (R & ((1u << (u - 1u)) - 1u)) | (1u << (u - 1u));
+      const uint32_t um = (1u << u) - 1u;
+      lo = (el >> u) + (((R & um) < (el & um)) ? 1u : 0u);
     }
   };
 
@@ -822,6 +832,39 @@ k_speck1d(OutlierBufs b)
         const uint32_t blockN = min(64u, n - rd);
         const bool valid = lane < blockN;
         const uint64_t myRun = valid ? runs[base + rd + lane] : 0ull;
+        if (!ENC) {
+          // entries that stay insignificant are counted off the stream window; a significant one
+          // hands its paths to the chain; the block's kept entries are compacted at its end
+          uint64_t sigm = 0;
+          uint32_t i = 0;
+          while (i < blockN) {
+            const uint64_t win = window();
+            const uint32_t z = win ? (uint32_t)__ffsll((long long)win) - 1u : 64u;
+            if (z >= blockN - i) {
+              rpos += blockN - i;
+              break;
+            }
+            i += z;
+            rpos += z + 1u;   // entry i is significant: its '1', then the recursion (m_code_S)
+            sigm |= 1ull << i;
+            const uint32_t es = rdlane((uint32_t)myRun, i), el = rdlane((uint32_t)(myRun >> 32), i);
+            if (el >= 2)
+              expand_chain(es, el, lev);
+            else {
+              flush_paths(lev);
+              expand_serial(es, el, lev);
+            }
+            i++;
+          }
+          const uint64_t keepM = ~sigm & low_mask(blockN);
+          if ((keepM >> lane) & 1ull) {
+            const uint32_t dst = wr + (uint32_t)__popcll(keepM & low_mask(lane));
+            if (dst != rd + lane)
+              runs[base + dst] = myRun;
+          }
+          wr += (uint32_t)__popcll(keepM);
+          continue;
+        }
         uint32_t myA = 0, myB = 0;
         if (ENC && valid) {   // every lane tests its own entry: outliers at or above the threshold inside
           const uint32_t s0 = (uint32_t)myRun, e0 = s0 + (uint32_t)(myRun >> 32);
@@ -875,10 +918,7 @@ k_speck1d(OutlierBufs b)
             rpos++;
             {
               const uint32_t es = rdlane((uint32_t)myRun, i), el = rdlane((uint32_t)(myRun >> 32), i);
-              if (el >= 2)
-                expand_dec(es, el, lev);
-              else
-                expand_serial(es, el, lev);
+              expand_serial(es, el, lev);   // (unreachable: the decoder's block loop is above)
             }
             i++;
             continue;
@@ -981,6 +1021,8 @@ k_speck1d(OutlierBufs b)
           }
         }
       }
+      if (!ENC)
+        flush_paths(lev);
       wrlane(vCnt, lev, wr);
     }
 

@@ -1720,6 +1720,166 @@ int model_speck1d_decode(const uint8_t* stream, size_t len, size_t n, uint64_t* 
   return 0;
 }
 
+// The 1D decoder as k_speck1d<false> runs it since round 3: the serial part (the CHAIN) only finds
+// out where every path starts and ends -- a handful of integer operations on the stream window, the
+// set being descended known by its depth below the list entry and the bits of the way to it
+// (R: bit j = "went right at depth j"), the parked right halves by a mask of depths -- and leaves
+// one record per path; what the path means for the lists, the LIP and the values found is worked
+// out for `batch` records at a time, one depth per round (the kernel: lane = record), the halves
+// born at a depth joining that level's list in record order, which is stream order.
+int model_speck1d_decode_batched(const uint8_t* stream, size_t len, size_t n, uint64_t* coef,
+                                 uint64_t* signmask, uint32_t batch)
+{
+  if (n < 4 || len < 9 || batch == 0 || batch > 64)
+    return -1;
+  const int nbp = stream[0];
+  std::vector<uint64_t> w((len - 9) / 8 + 3, 0);
+  memcpy(w.data(), stream + 9, len - 9);
+  uint64_t rpos = 0;
+  auto window = [&]() -> uint64_t {
+    const uint64_t wi = rpos >> 6;
+    const uint32_t sh = (uint32_t)(rpos & 63);
+    const uint64_t w0 = wi < w.size() ? w[wi] : 0, w1 = wi + 1 < w.size() ? w[wi + 1] : 0;
+    return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+  };
+  auto get = [&]() -> int {
+    const int b = (int)(window() & 1);
+    rpos++;
+    return b;
+  };
+  const uint32_t nlists = (uint32_t)num_of_partitions(n) + 1;
+  std::vector<std::vector<Run1D>> lists(nlists + 2);
+  lists[1].push_back({0u, (uint32_t)(n - n / 2)});
+  lists[1].push_back({(uint32_t)(n - n / 2), (uint32_t)(n / 2)});
+  std::vector<char> lip(n, 0), lsp(n, 0);
+  for (size_t i = 0; i < n; i++)
+    coef[i] = 0;
+  for (size_t i = 0; i < (n + 63) / 64; i++)
+    signmask[i] = 0;
+  std::vector<uint32_t> foundNow;
+  auto found = [&](uint32_t x, int p, int sg) {
+    coef[x] = 1ull << p;
+    if (sg)
+      signmask[x >> 6] |= 1ull << (x & 63);
+    foundNow.push_back(x);
+  };
+  struct Rec {
+    uint32_t es, el, R, u, tEnd, sg, closed;
+  };
+  std::vector<Rec> recs;
+  int rc = 0;
+  auto low = [](uint32_t k) -> uint32_t { return k >= 32 ? ~0u : (1u << k) - 1u; };
+  for (int p = nbp - 1; p >= 0 && rc == 0; p--) {
+    foundNow.clear();
+    for (size_t x = 0; x < n; x++)
+      if (lip[x] && get()) {
+        found((uint32_t)x, p, get());
+        lip[x] = 0;
+      }
+    for (uint32_t lev = nlists; lev-- > 0 && rc == 0;) {
+      auto flush = [&]() {
+        // one depth per round, all records of the batch side by side
+        std::vector<uint32_t> s(recs.size()), l(recs.size());
+        for (size_t k = 0; k < recs.size(); k++) {
+          s[k] = recs[k].es;
+          l[k] = recs[k].el;
+        }
+        for (uint32_t j = 0;; j++) {
+          bool any = false;
+          for (size_t k = 0; k < recs.size(); k++) {
+            const Rec& r = recs[k];
+            if (j >= r.tEnd)
+              continue;
+            any = true;
+            const uint32_t h0 = l[k] - l[k] / 2, r0 = l[k] / 2;
+            const bool right = (r.R >> j) & 1u;
+            const bool born = right ? j >= r.u : ((r.closed >> (j + 1)) & 1u) != 0;
+            const uint32_t bs = right ? s[k] : s[k] + h0, bl = right ? h0 : r0;
+            if (born) {
+              if (bl == 1)
+                lip[bs] = 1;
+              else if (lev + j + 1 >= lists.size())
+                rc = -3;
+              else
+                lists[lev + j + 1].push_back({bs, bl});
+            }
+            if (right) {
+              s[k] += h0;
+              l[k] = r0;
+            }
+            else
+              l[k] = h0;
+          }
+          if (!any)
+            break;
+        }
+        for (size_t k = 0; k < recs.size(); k++) {
+          if (l[k] != 1)
+            rc = -5;
+          found(s[k], p, (int)recs[k].sg);
+        }
+        recs.clear();
+      };
+      std::vector<Run1D> cur;
+      cur.swap(lists[lev]);
+      for (const Run1D& r : cur) {
+        if (!get()) {
+          lists[lev].push_back(r);
+          continue;
+        }
+        if (r.l < 2)
+          return -2;
+        // ---- the chain: integer work on the window only
+        uint32_t R = 0, m = 0, u = 0, lo = r.l;
+        for (;;) {
+          const uint64_t peek = window();
+          uint32_t nsteps = 0;
+          if (lo > 1) {
+            const uint32_t e = 31u - (uint32_t)__builtin_clz(lo), t0 = e - 1u, mk = low(t0);
+            const uint32_t lt = (lo >> t0) + (((~(uint32_t)peek & mk) < (lo & mk)) ? 1u : 0u);
+            const uint32_t bt = (uint32_t)(peek >> t0) & 1u;
+            nsteps = (lt == 2u || (lt == 3u && bt == 0u)) ? t0 + 1u : t0 + 2u;
+          }
+          if (u + nsteps > 31u)
+            return -4;
+          const uint32_t pm = low(nsteps);
+          R |= (~(uint32_t)peek & pm) << u;
+          m |= ((uint32_t)peek & pm) << (u + 1u);
+          const uint32_t sg = (uint32_t)(peek >> nsteps) & 1u;
+          const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+          const uint64_t cw = peek >> (nsteps + 1u);   // (at least 31 valid bits: cnt <= 31)
+          const uint32_t z = std::min<uint32_t>(cw ? (uint32_t)__builtin_ctzll(cw) : 64u, cnt);
+          uint32_t closed = 0;
+          for (uint32_t k = 0; k < z; k++) {
+            const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
+            m &= ~(1u << top);
+            closed |= 1u << top;
+          }
+          recs.push_back({r.s, r.l, R, u, u + nsteps, sg, closed});
+          if (recs.size() == batch)
+            flush();
+          rpos += nsteps + 1u + z;
+          if (z == cnt)
+            break;
+          rpos++;
+          u = 31u - (uint32_t)__builtin_clz(m);
+          m &= ~(1u << u);
+          R = (R & low(u - 1u)) | (1u << (u - 1u));
+          lo = (r.l >> u) + (((R & low(u)) < (r.l & low(u))) ? 1u : 0u);
+        }
+      }
+      if (!recs.empty())
+        flush();
+    }
+    for (size_t x = 0; x < n; x++)
+      if (lsp[x] && get())
+        coef[x] |= 1ull << p;
+    for (uint32_t x : foundNow)
+      lsp[x] = 1;
+  }
+  return rc;
+}
+
 int model_check_classes(const size_t dims[3])
 {
   return check_classes_impl(dims, false);

@@ -286,3 +286,13 @@ def test_model_1d_coder_paths(oracle, model, n, k, top):
         assert lib.model_speck1d_decode(buf.ctypes.data, buf.size, n, c2.ctypes.data, s2.ctypes.data) == 0
         assert np.array_equal(c2, coef), (n, k, top, rep)
         assert np.array_equal(unpack_mask(s2, n)[coef > 0], sign[coef > 0])
+        # the chain + batched-records formulation (k_speck1d<false> since round 3)
+        lib.model_speck1d_decode_batched.argtypes = [_vp, _sz, _sz, _vp, _vp, C.c_uint32]
+        lib.model_speck1d_decode_batched.restype = C.c_int
+        for batch in (64, 3):
+            c3 = np.zeros(n, dtype=np.uint64)
+            s3 = np.zeros((n + 63) // 64, dtype=np.uint64)
+            assert lib.model_speck1d_decode_batched(buf.ctypes.data, buf.size, n, c3.ctypes.data, s3.ctypes.data,
+                                                    batch) == 0
+            assert np.array_equal(c3, coef), (n, k, top, rep, batch)
+            assert np.array_equal(unpack_mask(s3, n)[coef > 0], sign[coef > 0])
