@@ -1823,7 +1823,9 @@ struct DecBatchBufs {
   uint32_t* live;   // chunks that still decode (DecPlanHost::d_live)
 };
 
-bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o)
+// valsElems: fp64 samples per chunk of the chunk buffer (0: the whole chunk; compact_box() otherwise)
+bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o,
+               size_t valsElems = 0)
 {
   const size_t N = P.N, Npad = round_up(N, 256);
   DecBuffers& d = o.db;
@@ -1843,8 +1845,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(o.chunkOff, uint64_t, B);
   TAKE(o.chunkLen, uint64_t, B);
   TAKE(o.live, uint32_t, 64);
-  o.valsStride = Npad;
-  TAKE(o.vals, double, Npad * B);
+  o.valsStride = valsElems ? round_up(valsElems, 256) : Npad;
+  TAKE(o.vals, double, o.valsStride * B);
   d.coefStride = Npad;
   TAKE(o.coef32, uint32_t, Npad * B);
   d.coef = o.coef32;
@@ -1884,7 +1886,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.maskPrefix, uint32_t, std::max<size_t>(d.maskStride, 1) * B);
   d.bornStride = P.ht.nsets + 8;
   d.hiGroupsMax = 8;
-  d.bornSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
+  // (a segment that fills up sends the rest to the shared part, which holds the worst case: eight
+  //  segments of a twelfth of it each were never seen to fill up at 2 to 4.5 bits per sample)
+  d.bornSeg = (uint32_t)((P.ht.nsets + 8) / 12 + 64);
   d.bornPitch = d.bornStride + (size_t)d.bornSeg * d.hiGroupsMax;
   TAKE(d.bornPacked, uint64_t, d.bornPitch * B);
   TAKE(d.bornPosLev, uint64_t, d.bornPitch * B);
@@ -1920,7 +1924,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.iRoots = P.d_iRoots;
   d.iLevels = P.ht.iLevels;
   d.leafCap = P.ht.nsets + 8;
-  d.leafSeg = (uint32_t)((P.ht.nsets + 8) / d.hiGroupsMax + 64);
+  d.leafSeg = (uint32_t)((P.ht.nsets + 8) / 12 + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
@@ -2126,13 +2130,35 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     deferOff = 0;
     return rc;
   };
-  auto bytes_per_chunk = [&](const ShapePlan& P, uint64_t maxPayload) -> size_t {
+  auto bytes_per_chunk = [&](const ShapePlan& P, uint64_t maxPayload, size_t valsElems = 0) -> size_t {
     Arena probe;
     probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
-    carve_dec(probe, P, 1, maxPayload, tmp);
+    carve_dec(probe, P, 1, maxPayload, tmp, valsElems);
     return probe.used;
+  };
+  // The fp64 chunk buffer of a group can be COMPACT (round 3): when the finest level runs as the fused
+  // x-y-z kernel and every inverse pass dequantises the samples no coarser level produces straight
+  // from the integer coefficients, the buffer only ever holds the box of the second level (an eighth
+  // of the chunk: 17 MB instead of 134 MB for 256^3).  Not with 64-bit coefficients (they live in the
+  // buffer), outlier correctors (every pass stays in the buffer), the resolution hierarchy or slices.
+  static const bool compactEnv = !(getenv("SPERR_HIP_DEC_COMPACT") && atoi(getenv("SPERR_HIP_DEC_COMPACT")) == 0);
+  auto compact_box = [&](const ShapePlan& P, const std::vector<Ref>& refs, uint32_t box[3]) -> size_t {
+    box[0] = box[1] = box[2] = 0;
+    if (!compactEnv || !fuse_xyz(P) || !plan_fusable(P) || mr || slice || anyOutlier || P.fwd.size() < 3)
+      return 0;
+    for (const Ref& r : refs) {
+      const uint8_t* hd = heads.data() + (size_t)r.gid * 32;
+      if (ci.len[r.gid] >= 26 && !(hd[0] & 0x01) && hd[17] > 32)
+        return 0;   // a chunk with 64-bit coefficients
+    }
+    for (size_t k = 3; k < P.fwd.size(); k++)
+      for (int a = 0; a < 3; a++)
+        box[a] = std::max(box[a], P.fwd[k].region[a]);
+    for (int a = 0; a < 3; a++)
+      box[a] = std::max(box[a], 1u);
+    return (size_t)box[0] * box[1] * box[2];
   };
   bool deferSized = false;
   // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mixed and its
@@ -2165,7 +2191,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         uint64_t mp = 0;
         for (auto& r : h.second)
           mp = std::max<uint64_t>(mp, ci.len[r.gid]);
-        sum += round_up(h.second.size() * bytes_per_chunk(*Q, mp) + (1 << 20), 4096);
+        uint32_t qbox[3];
+        sum += round_up(h.second.size() * bytes_per_chunk(*Q, mp, compact_box(*Q, h.second, qbox)) + (1 << 20), 4096);
       }
       size_t fr = 0, tot = 0;
       HIP_CHECK(hipMemGetInfo(&fr, &tot));
@@ -2176,7 +2203,9 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     uint64_t maxPayload = 0;
     for (auto& r : g.second)
       maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
-    const size_t per = bytes_per_chunk(*P, maxPayload);
+    uint32_t cbox[3];
+    const size_t compactElems = compact_box(*P, g.second, cbox);
+    const size_t per = bytes_per_chunk(*P, maxPayload, compactElems);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     const size_t budgetBytes = arena_budget(E.arena.n, fr);
@@ -2233,7 +2262,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         S.nb = (nbAll - done + (nsub - q) - 1) / (nsub - q);
         S.first = b0 + done;
         done += S.nb;
-        if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb))
+        if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb, compactElems))
           return -1;
       }
       int devId = 0;
@@ -2273,7 +2302,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
               maxNarrow = std::max(maxNarrow, nbp);
           }
         }
-        if (maxWide > kMaxPlanes)
+        if (maxWide > kMaxPlanes || (compactElems && maxWide))
           return -1;
         // Outlier streams (point-wise error mode) are decoded by the 1D coder on a stream of their own,
         // beside everything below: it needs the container only; the correctors are added at the end
@@ -2449,6 +2478,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             lf.sigOld = d.sigOld;
             lf.maskStride = d.maskPixStride;
             lf.dst = d.st;
+          }
+          if (compactElems) {
+            lf.bufx = cbox[0];
+            lf.bufy = cbox[1];
           }
         };
         for (size_t k = P->fwd.size(); k-- > (fxyz ? 3u : fxy ? 2u : 0u);) {

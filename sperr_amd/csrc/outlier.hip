@@ -510,9 +510,23 @@ k_speck1d(OutlierBufs b)
   // stream order.  tests/model/speck_model.cpp::model_speck1d_decode_batched is the CPU model.
   // (Before: a whole path per step with lane = level, about 1400 cycles per path.)
   uint32_t rES = 0, rEL = 0, rR = 0, rMeta = 0, rClosed = 0, nrec = 0;
+#ifdef SPERR_1D_STAMPS
+  long long tkLip = 0, tkLis = 0, tkChain = 0, tkFlush = 0, tkRef = 0, tkLsp = 0, tk0 = 0;
+  uint32_t nPaths = 0, nEntries = 0, nFlush = 0;
+#define STAMP_BEGIN() (tk0 = clock64())
+#define STAMP_END(acc) (acc += clock64() - tk0)
+#else
+#define STAMP_BEGIN() ((void)0)
+#define STAMP_END(acc) ((void)0)
+#endif
   auto flush_paths = [&](uint32_t lev) {
     if (nrec == 0)
       return;
+#ifdef SPERR_1D_STAMPS
+    const long long tf0 = clock64();
+    nFlush++;
+    nPaths += nrec;
+#endif
     const bool valid = lane < nrec;
     const uint32_t u = rMeta & 0xffu, tEnd = (rMeta >> 8) & 0xffu;
     uint32_t s = rES, l = rEL;
@@ -558,6 +572,9 @@ k_speck1d(OutlierBufs b)
     }
     nfound += nrec;
     nrec = 0;
+#ifdef SPERR_1D_STAMPS
+    tkFlush += clock64() - tf0;
+#endif
   };
   auto expand_chain = [&](uint32_t es, uint32_t el, uint32_t lev) {   // a run of at least two values
     uint32_t R = 0, m = 0, u = 0, lo = el;
@@ -727,6 +744,7 @@ k_speck1d(OutlierBufs b)
     }
     __threadfence_block();
     // ================= LIP pass (src/SPECK1D_INT_ENC.cpp:15-45, _DEC.cpp:15-45) =================
+    STAMP_BEGIN();
     for (uint32_t wb8 = 0; wb8 < nw; wb8 += 512) {   // (eight blocks of 64 words are loaded at once)
       uint64_t lwv[8], any = 0;
 #pragma unroll
@@ -820,7 +838,9 @@ k_speck1d(OutlierBufs b)
       }
     }
 
+    STAMP_END(tkLip);
     // ================= LIS pass, smallest sets first (ENC.cpp:47-56, DEC.cpp:47-54) =============
+    STAMP_BEGIN();
     for (uint32_t lev = b.nlists; lev-- > 0;) {
       const uint32_t n = rdlane(vCnt, lev);
       if (n == 0)
@@ -848,8 +868,16 @@ k_speck1d(OutlierBufs b)
             rpos += z + 1u;   // entry i is significant: its '1', then the recursion (m_code_S)
             sigm |= 1ull << i;
             const uint32_t es = rdlane((uint32_t)myRun, i), el = rdlane((uint32_t)(myRun >> 32), i);
-            if (el >= 2)
+            if (el >= 2) {
+#ifdef SPERR_1D_STAMPS
+              const long long tc0 = clock64();
+              nEntries++;
+#endif
               expand_chain(es, el, lev);
+#ifdef SPERR_1D_STAMPS
+              tkChain += clock64() - tc0;
+#endif
+            }
             else {
               flush_paths(lev);
               expand_serial(es, el, lev);
@@ -1026,7 +1054,9 @@ k_speck1d(OutlierBufs b)
       wrlane(vCnt, lev, wr);
     }
 
+    STAMP_END(tkLis);
     // ================= refinement pass (SPECK_INT.cpp:310-357 / 359-469) ========================
+    STAMP_BEGIN();
     if (ENC) {
       flush_acc();
       for (uint32_t kb = 0; kb < K; kb += 64) {
@@ -1080,6 +1110,8 @@ k_speck1d(OutlierBufs b)
         rpos += rdlane(inc, 63);
         }
       }
+      STAMP_END(tkRef);
+      STAMP_BEGIN();
       // the values found in this plane join the LSP (SPECK_INT.cpp:462-468)
       __threadfence_block();
       const uint32_t lim = min(nfound, (uint32_t)b.kStride);
@@ -1088,8 +1120,14 @@ k_speck1d(OutlierBufs b)
         atomicOr(reinterpret_cast<unsigned long long*>(lsp) + (x >> 6), 1ull << (x & 63u));
       }
       lspDone = lim;
+      STAMP_END(tkLsp);
     }
   }
+#ifdef SPERR_1D_STAMPS
+  if (!ENC && lane == 0 && c == 0)
+    printf("1D dec chunk0: lip %lld lis %lld (chain %lld incl flush %lld) ref %lld lsp %lld ticks; paths %u entries %u flushes %u found %u bits %llu\n",
+           tkLip, tkLis, tkChain, tkFlush, tkRef, tkLsp, nPaths, nEntries, nFlush, nfound, (unsigned long long)rpos);
+#endif
 
   if (__any(vErr != 0))
     err = 2;

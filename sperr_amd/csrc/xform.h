@@ -46,6 +46,10 @@ struct LiftFuse {
   const uint64_t* sigOld = nullptr;
   size_t maskStride = 0;
   const DecState* dst = nullptr;
+  // inverse, compact chunk buffer (round 3): `vals` holds only the box the coarser levels work in,
+  // rows of bufx samples and bufy rows per slice (0: the chunk's own dims); the coefficient and mask
+  // arrays keep the chunk's dims
+  uint32_t bufx = 0, bufy = 0;
 };
 
 // io: 0 in place; 1 / 2: the pass also reads (forward) or writes (inverse) the float / double

@@ -145,18 +145,32 @@ k_stride_sums_rows(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
   }
 }
 
+// The stride means added up in the reference's order (src/Conditioner.cpp:137-163): one thread does the
+// additions, but out of LDS, where the workgroup has put the means with coalesced loads (round 3: one
+// thread reading them from global memory one dependent load at a time took 0.44 ms for 2048 strides,
+// on the critical path of every compression call)
+constexpr int kMeanStage = 2048;
 template <typename T>
-__global__ void k_mean_finalize(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom,
-                                uint32_t nstrides, const double* strideMean,
-                                size_t strideMeanStride, CoderState* st)
+__global__ void __launch_bounds__(kThreads)
+k_mean_finalize(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uint32_t nstrides,
+                const double* strideMean, size_t strideMeanStride, CoderState* st)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= gridDim.x * blockDim.x)
-    return;
+  __shared__ double stage[kMeanStage];
+  const uint32_t c = blockIdx.x;
   const double* sm = strideMean + c * strideMeanStride;
   double total = 0.0;
-  for (uint32_t s = 0; s < nstrides; s++)
-    total += sm[s];
+  for (uint32_t base = 0; base < nstrides; base += kMeanStage) {
+    const uint32_t n = min((uint32_t)kMeanStage, nstrides - base);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += kThreads)
+      stage[k] = sm[base + k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (uint32_t k = 0; k < n; k++)
+        total += stage[k];
+  }
+  if (threadIdx.x != 0)
+    return;
   const ChunkGeom g = geom[c];
   const bool is_const = st[c].not_const_flag == 0;
   st[c].is_const = is_const ? 1u : 0u;
@@ -239,7 +253,8 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
   double* sm = reinterpret_cast<double*>(dyn_smem);
   double* buf = vals + c * valsStride;
   const uint32_t region[3] = {rx, ry, rz};
-  const size_t stride[3] = {1, cx, (size_t)cx * cy};
+  const uint32_t bx = (!FORWARD && F.bufx) ? F.bufx : cx, by = (!FORWARD && F.bufy) ? F.bufy : cy;   // (compact buffer)
+  const size_t stride[3] = {1, bx, (size_t)bx * by};
   const int ua = (axis == 0) ? 1 : 0;            // axis along which the NL lines are adjacent
   const int wa = (axis == 2) ? 1 : 2;            // remaining axis
   const uint32_t len = region[axis];
@@ -1022,6 +1037,8 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   VT* volc = vol + ((size_t)geom[c].org[2] * vsz + (size_t)geom[c].org[1] * vsy + geom[c].org[0]);
   const double* buf = vals + c * valsStride;
   const size_t sliceN = (size_t)cx * cy;
+  const uint32_t bufx = F.bufx ? F.bufx : cx;                       // the chunk buffer may be compact:
+  const size_t bufSlice = (size_t)bufx * (F.bufy ? F.bufy : cy);   // only the next level's box
   const double mean = st[c].mean;
   const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = kXYZThreadsI / 64;
 
@@ -1064,7 +1081,10 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
     const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
-    if (dequant && !(((innerMask >> k) & 1u) && zp < F.inner[2])) {
+    const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
+    if (!dequant && !inBox && F.bufx)
+      return 0.0;   // (a compact buffer holds the box only; the host asks for one only when every chunk dequantises here)
+    if (dequant && !inBox) {
       uint32_t v = coef[idx];
       const uint32_t sh = (uint32_t)(idx & 63);
       const uint64_t sgw = sign[idx >> 6], mnw = mNew[idx >> 6], mow = mOld[idx >> 6];   // (independent loads)
@@ -1072,7 +1092,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       v = v ? v : fill;
       return fq * (double)v * (((sgw >> sh) & 1ull) ? 1.0 : -1.0);
     }
-    return buf[idx];
+    return buf[(size_t)zp * bufSlice + drow * bufx + dcol];
   };
   // The slice of z-inverted samples staged in X (all staged rows) -> y pass into Y, x pass back into
   // X, volume.  X and Y swap from slice to slice: three barriers per slice.
@@ -1676,7 +1696,7 @@ int launch_condition(hipStream_t stream, const T* vol, VolDesc vd, const ChunkGe
     LAUNCH_K(k_stride_sums<T>, dim3((nstrides + kSumStrides - 1) / kSumStrides, nchunks),
              dim3(kThreads), 0, stream, vol, vd, geom, cdims[0], cdims[1], cdims[2], nstrides, ssz,
              strideMean, strideMeanStride, st, want_range ? 1 : 0);
-  LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(1), 0, stream, vol, vd, geom,
+  LAUNCH_K(k_mean_finalize<T>, dim3(nchunks), dim3(kThreads), 0, stream, vol, vd, geom,
                      nstrides, strideMean, strideMeanStride, st);
   if (gather)   // otherwise the first lifting pass reads the volume itself
     LAUNCH_K(k_gather_condition<T>, dim3((n + kThreads * 4 - 1) / (kThreads * 4), nchunks),
