@@ -489,6 +489,7 @@ struct Engine {
   uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
   hipEvent_t liveEv[kSubStreams][kLiveSlots] = {};
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
+  DevBuf wideScratch;                       // 64-bit retry of a batch whose coder arrays lay over the chunk buffer
   std::vector<std::unique_ptr<DevBuf>> pweBufs;   // outlier streams of the batches of one call
   size_t freeMemAtInit = 0;
 
@@ -551,7 +552,7 @@ struct Engine {
       kv.second->tables.drop();
     plans.clear();
     planOrder.clear();
-    for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &slice2d})
+    for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &slice2d, &wideScratch})
       b->drop();
     for (auto& b : outlDec)
       b.drop();
@@ -846,7 +847,33 @@ struct EncBatchBufs {
   uint32_t* coef32;
   int8_t* msb;
   size_t bytesPerChunk;
+  bool aliased;        // the coder's node arrays, birth records and second list lie over `vals` (carve_enc_coder)
+  size_t coderBytes;   // ... and take this many bytes for the batch
 };
+
+// the arrays of the integer coder that nothing reads or writes before the quantiser is done
+bool carve_enc_coder(Arena& A, const ShapePlan& P, uint32_t B, EncBuffers& e)
+{
+  const size_t nn = P.dtree.nnodes;
+#define TAKE(dst, T, count)                 \
+  dst = A.take<T>((size_t)(count));         \
+  if (!dst)                                 \
+    return false;
+  e.nodeStride = nn;
+  TAKE(e.M, int8_t, nn * B);
+  TAKE(e.E, uint32_t, nn * B);
+  TAKE(e.opos, uint64_t, nn * B);
+  TAKE(e.bucket, uint32_t, nn * B);
+  TAKE(e.koff, uint32_t, nn * B);
+  TAKE(e.chain, uint64_t, nn * B);
+  TAKE(e.leafDesc, uint16_t, nn * B);
+  TAKE(e.lis[1], uint64_t, P.lisEntries * B);
+  e.bornStride = P.ht.nsets + 8;
+  TAKE(e.bornPacked, uint64_t, e.bornStride * B);
+  TAKE(e.bornPosLev, uint64_t, e.bornStride * B);
+#undef TAKE
+  return true;
+}
 
 // carve the arrays of one batch out of the arena; returns false when it does not fit
 bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, EncBatchBufs& o)
@@ -886,17 +913,25 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(o.msb, int8_t, Npad * B);
   e.msb = o.msb;
   TAKE(e.bplane, int8_t, Npad * B);
-  e.nodeStride = nn;
-  TAKE(e.M, int8_t, nn * B);
-  TAKE(e.E, uint32_t, nn * B);
-  TAKE(e.opos, uint64_t, nn * B);
-  TAKE(e.bucket, uint32_t, nn * B);
-  TAKE(e.koff, uint32_t, nn * B);
-  TAKE(e.chain, uint64_t, nn * B);
-  TAKE(e.leafDesc, uint16_t, nn * B);
+  // The coder's node arrays, birth records and second list are written after the quantiser has read
+  // the chunk buffer for the last time: they lie over it (round 3; 127 of the 421 MB a 256^3 chunk
+  // took).  A batch that needs the 64-bit retry transforms its chunks again and gives these arrays
+  // memory of their own (Engine::wideScratch, compress_impl).  SPERR_HIP_ENC_ALIAS=0: no overlay.
+  static const bool aliasEnv = !(getenv("SPERR_HIP_ENC_ALIAS") && atoi(getenv("SPERR_HIP_ENC_ALIAS")) == 0);
+  {
+    Arena over;
+    over.base = reinterpret_cast<char*>(o.vals);
+    over.cap = Npad * B * sizeof(double);
+    o.aliased = aliasEnv && carve_enc_coder(over, P, B, e);
+    o.coderBytes = over.used;
+    if (!o.aliased && !carve_enc_coder(A, P, B, e))
+      return false;
+    if (arena_debug())
+      fprintf(stderr, "[sperr_hip] arena %-18s %10.2f MB %s\n", "coder arrays", (double)o.coderBytes / 1048576.0,
+              o.aliased ? "(over o.vals)" : "");
+  }
   e.lisStride = P.lisEntries;
   TAKE(e.lis[0], uint64_t, P.lisEntries * B);
-  TAKE(e.lis[1], uint64_t, P.lisEntries * B);
   e.levelOff = P.d_levelOff;
   e.nListTiles = P.nListTiles;
   e.tileLevel = P.d_tileLevel;
@@ -908,9 +943,6 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   TAKE(e.tileSurv, uint32_t, e.tileStride * B);
   TAKE(e.tileBitsOff, uint64_t, e.tileStride * B);
   TAKE(e.tileSurvOff, uint32_t, e.tileStride * B);
-  e.bornStride = P.ht.nsets + 8;
-  TAKE(e.bornPacked, uint64_t, e.bornStride * B);
-  TAKE(e.bornPosLev, uint64_t, e.bornStride * B);
   e.iRoots = P.d_iRoots;
   e.iLevels = P.ht.iLevels;
   e.levelSlot = P.d_levelSlot;
@@ -1013,6 +1045,70 @@ bool plan_fusable(const ShapePlan& P)
   if (fuse_xy(P) && (pass_fuse(P, 0, inner) != 0 || pass_fuse(P, 1, inner) != 0))
     return false;
   return true;
+}
+
+// conditioner + forward transform of one batch: volume -> bb.vals (mean, constness, largest magnitude
+// in CoderState).  Run once per batch -- and once more before a 64-bit retry when the coder's arrays
+// lay over the chunk buffer (carve_enc): the same launches on the same input give the same bits.
+template <typename T>
+int float_stages(hipStream_t ss, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb, const uint32_t cd[3],
+                 const T* d_src, VolDesc vd, bool orgAligned, bool wantRange)
+{
+  EncBuffers& e = bb.eb;
+  // the first lifting pass covers the whole chunk: it reads the volume itself (gather, widen,
+  // subtract the mean); chunks too small to be transformed take the plain gather kernel
+  const bool fuse = !P.fwd.empty();
+  const int io = std::is_same<T, float>::value ? 1 : 2;
+  if (launch_condition<T>(ss, d_src, vd, bb.geom, nb, cd, P.nstrides, bb.strideMean, bb.strideMeanStride,
+                          bb.vals, bb.valsStride, e.cst, !fuse, wantRange, orgAligned))
+    return -1;
+  size_t k0 = 0;
+  // the passes after which samples have their final value also collect the largest magnitude
+  // (src/SPECK_FLT.cpp:282-301): no pass over the coefficients of its own
+  const bool fuseMax = plan_fusable(P);
+  if (fuse_xyz(P)) {   // the three full-size passes in one kernel, straight from the volume
+    LiftFuse lf;
+    if (fuseMax && pass_fuse(P, 2, lf.inner) > 0)
+      lf.mode = 1;
+    if (launch_lift_xyz(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io, const_cast<T*>(d_src), vd,
+                        bb.geom, &lf))
+      return -1;
+    k0 = 3;
+  }
+  else if (fuse_xy(P)) {   // the full-size x and y passes in one kernel, straight from the volume
+    if (launch_lift_xy(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io, const_cast<T*>(d_src), vd,
+                       bb.geom))
+      return -1;
+    k0 = 2;
+  }
+  for (size_t k = k0; k < P.fwd.size(); k++) {
+    const LiftPass& ps = P.fwd[k];
+    LiftFuse lf;
+    if (fuseMax && pass_fuse(P, k, lf.inner) > 0)
+      lf.mode = 1;
+    if (launch_lift(ss, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst, k == 0 ? io : 0,
+                    const_cast<T*>(d_src), vd, bb.geom, &lf))
+      return -1;
+  }
+  return 0;
+}
+
+// before the 64-bit retry of a batch whose coder arrays lay over the chunk buffer: those arrays move
+// to memory of their own and the buffer gets its DWT coefficients back
+template <typename T>
+int wide_retry_prepare(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                       const uint32_t cd[3], const T* d_src, VolDesc vd, bool orgAligned, bool wantRange)
+{
+  HIP_CHECK(hipStreamSynchronize(ss));   // (the scratch buffer may grow: nothing of this stream may still use it)
+  if (E.wideScratch.ensure(bb.coderBytes + 4096))
+    return -1;
+  Arena W;
+  W.base = static_cast<char*>(E.wideScratch.p);
+  W.cap = E.wideScratch.n;
+  if (!carve_enc_coder(W, P, nb, bb.eb))
+    return -1;
+  bb.aliased = false;
+  return float_stages<T>(ss, P, bb, nb, cd, d_src, vd, orgAligned, wantRange);
 }
 
 // PSNR mode (src/SPECK_FLT.cpp:268-279,431-435): per chunk q = 2 sqrt(3 t), t = range^2 10^(-psnr/10),
@@ -1478,6 +1574,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     std::vector<CoderState> hc;
     std::vector<ChunkGeom> hg;
     std::vector<uint32_t> hid;
+    bool orgAligned;
   };
   std::vector<std::unique_ptr<LateGroup>> late;
   static const bool encGroupsEnv = !(getenv("SPERR_HIP_ENC_GROUPS") && atoi(getenv("SPERR_HIP_ENC_GROUPS")) == 0);
@@ -1541,8 +1638,6 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       HIP_CHECK(hipMemcpyAsync(bb.geom, hg.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, ss));
       HIP_CHECK(hipMemcpyAsync(bb.gids, hid.data(), nb * 4, hipMemcpyHostToDevice, ss));
       HIP_CHECK(hipMemsetAsync(e.cst, 0, nb * sizeof(CoderState), ss));
-      if (reset_enc_pass(ss, bb, nb))
-        return -1;
 
       // ---- float stages ----
       // the first lifting pass covers the whole chunk: it reads the volume itself (gather, widen,
@@ -1552,38 +1647,9 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       bool orgAligned = true;   // (lets the conditioner stream rows with 16-byte loads)
       for (uint32_t i = 0; i < nb; i++)
         orgAligned = orgAligned && hg[i].org[0] % (16 / sizeof(T)) == 0;
-      if (launch_condition<T>(ss, d_src, vd, bb.geom, nb, cd, P->nstrides, bb.strideMean,
-                              bb.strideMeanStride, bb.vals, bb.valsStride, e.cst, !fuse, mode == 2,
-                              orgAligned))
-        return -1;
-      size_t k0 = 0;
-      // the passes after which samples have their final value also collect the largest magnitude
-      // (src/SPECK_FLT.cpp:282-301): no pass over the coefficients of its own
       const bool fuseMax = plan_fusable(*P);
-      if (fuse_xyz(*P)) {   // the three full-size passes in one kernel, straight from the volume
-        LiftFuse lf;
-        if (fuseMax && pass_fuse(*P, 2, lf.inner) > 0)
-          lf.mode = 1;
-        if (launch_lift_xyz(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io, const_cast<T*>(d_src), vd,
-                            bb.geom, &lf))
-          return -1;
-        k0 = 3;
-      }
-      else if (fuse_xy(*P)) {   // the full-size x and y passes in one kernel, straight from the volume
-        if (launch_lift_xy(ss, true, bb.vals, bb.valsStride, nb, cd, e.cst, io,
-                           const_cast<T*>(d_src), vd, bb.geom))
-          return -1;
-        k0 = 2;
-      }
-      for (size_t k = k0; k < P->fwd.size(); k++) {
-        const LiftPass& ps = P->fwd[k];
-        LiftFuse lf;
-        if (fuseMax && pass_fuse(*P, k, lf.inner) > 0)
-          lf.mode = 1;
-        if (launch_lift(ss, true, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst,
-                        k == 0 ? io : 0, const_cast<T*>(d_src), vd, bb.geom, &lf))
-          return -1;
-      }
+      if (float_stages<T>(ss, *P, bb, nb, cd, d_src, vd, orgAligned, mode == 2))
+        return -1;
       if (launch_maxabs_q(ss, bb.vals, bb.valsStride, nb, P->N, e.cst, fuseMax))
         return -1;
       if (mode == 2 && psnr_q_search(ss, *P, bb, nb, quality))
@@ -1592,6 +1658,9 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         return -1;
       if (launch_quantize(ss, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
+        return -1;
+      // (only now: the coder's arrays may lie over the chunk buffer the quantiser has just read)
+      if (reset_enc_pass(ss, bb, nb))
         return -1;
 
       // ---- integer coder, 32-bit coefficients ----
@@ -1620,7 +1689,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
       if (sideBySide) {   // (the read-back is looked at once every group is enqueued)
         std::unique_ptr<LateGroup> L(new LateGroup{P, bb, nb, wblocks, raw_budget, ss, std::vector<CoderState>(nb),
-                                                   std::move(hg), std::move(hid)});
+                                                   std::move(hg), std::move(hid), orgAligned});
         late[gi] = std::move(L);        // (a read-back into pageable memory would block the host until
         continue;                       //  this group's stream has drained: it is done further down)
       }
@@ -1631,6 +1700,10 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       for (auto& c : hc)
         retry |= (c.need_retry != 0);
       if (retry) {
+        // the DWT coefficients again when the coder's arrays were written over them, and memory of
+        // their own for those arrays (the 64-bit magnitudes live in the chunk buffer)
+        if (bb.aliased && wide_retry_prepare<T>(ss, E, *P, bb, nb, cd, d_src, vd, orgAligned, mode == 2))
+          return -1;
         // fixed rate: a finer q for the flagged chunks; PSNR: the same q, coefficients need 64 bits
         if ((rate ? launch_make_q_wide(ss, nb, e.cst) : launch_mark_wide(ss, nb, e.cst)) ||
             reset_enc_pass(ss, bb, nb))
@@ -1703,6 +1776,12 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     EncBuffers& e = bb.eb;
     ShapePlan* P = L->P;
     EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+    if (bb.aliased) {   // (see the retry above; the scratch memory is the engine's: one group at a time)
+      const uint32_t cdl[3] = {P->dims[0], P->dims[1], P->dims[2]};
+      HIP_CHECK(hipDeviceSynchronize());
+      if (wide_retry_prepare<T>(L->ss, E, *P, bb, L->nb, cdl, d_src, vd, L->orgAligned, false))
+        return -1;
+    }
     if (launch_make_q_wide(L->ss, L->nb, e.cst) || reset_enc_pass(L->ss, bb, L->nb))
       return -1;
     if (launch_quantize(L->ss, true, bb.vals, bb.valsStride, L->nb, P->N, bb.vals, bb.valsStride,
@@ -1716,6 +1795,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     LAUNCH_K(k_write_slot, dim3(std::max(1u, L->wblocks), L->nb), dim3(kThreads), 0, L->ss, e.cst, e.st,
              e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff, d_lens,
              P->N, 1);
+    if (bb.aliased)
+      HIP_CHECK(hipStreamSynchronize(L->ss));
   }
   if (sideBySide)
     for (uint32_t q = 0; q < kSubStreams; q++) {
