@@ -207,6 +207,12 @@ int sperrhip_profile_get2(const char** names, double* busy_millis, double* sum_m
  * the list levels whose class chain has length K. */
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64);
 
+/* Diagnostics: how often this process took one of the workspace-saving paths (for the tests that
+ * have to know they ran): 0 = 64-bit retries of a batch whose coder arrays lay over the chunk buffer
+ * (the batch is transformed again), 1 = compression batches with the coder arrays over the chunk
+ * buffer, 2 = decompression batches with a compact chunk buffer.  Other values: 0. */
+unsigned long long sperrhip_debug_counter(int which);
+
 /* Gives back what the library keeps between calls (it keeps workspaces, shape tables, pinned staging
  * buffers and device buffers so that the next call does not pay for them again): everything held by
  * engines and farm workers that are idle, and the calling thread's slice buffers.  Calls running on

@@ -29,7 +29,7 @@ EXPORTS = [
     "sperrhip_decompress_2d_dev", "sperrhip_version", "sperrhip_debug_lis_stamps",
     "sperrhip_multires_levels_2d", "sperrhip_decompress_2d_multires_dev", "sperrhip_decomp_2d_multires",
     "sperrhip_comp_3d_farm", "sperrhip_decomp_3d_farm", "sperrhip_decomp_3d_into",
-    "sperrhip_farm_selftest", "sperrhip_release",
+    "sperrhip_farm_selftest", "sperrhip_release", "sperrhip_debug_counter",
 ]
 
 

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <condition_variable>
@@ -184,6 +185,8 @@ struct DevBuf {
     return 0;
   }
 };
+
+std::atomic<unsigned long long> g_dbg_counter[3];   // sperrhip_debug_counter
 
 struct Arena {
   char* base = nullptr;
@@ -851,26 +854,30 @@ struct EncBatchBufs {
   size_t coderBytes;   // ... and take this many bytes for the batch
 };
 
-// the arrays of the integer coder that nothing reads or writes before the quantiser is done
-bool carve_enc_coder(Arena& A, const ShapePlan& P, uint32_t B, EncBuffers& e)
+// the arrays of the integer coder that nothing reads or writes before the quantiser is done: each from
+// `first` when it fits there, else from `second` (may be null)
+bool carve_enc_coder(Arena& first, Arena* second, const ShapePlan& P, uint32_t B, EncBuffers& e)
 {
   const size_t nn = P.dtree.nnodes;
-#define TAKE(dst, T, count)                 \
-  dst = A.take<T>((size_t)(count));         \
-  if (!dst)                                 \
+#define TAKE(dst, T, count)                            \
+  dst = first.take<T>((size_t)(count));                \
+  if (!dst && second)                                  \
+    dst = second->take<T>((size_t)(count));            \
+  if (!dst)                                            \
     return false;
   e.nodeStride = nn;
-  TAKE(e.M, int8_t, nn * B);
-  TAKE(e.E, uint32_t, nn * B);
-  TAKE(e.opos, uint64_t, nn * B);
-  TAKE(e.bucket, uint32_t, nn * B);
-  TAKE(e.koff, uint32_t, nn * B);
-  TAKE(e.chain, uint64_t, nn * B);
-  TAKE(e.leafDesc, uint16_t, nn * B);
-  TAKE(e.lis[1], uint64_t, P.lisEntries * B);
   e.bornStride = P.ht.nsets + 8;
+  // (the large ones first: what does not fit any more is small)
+  TAKE(e.opos, uint64_t, nn * B);
+  TAKE(e.chain, uint64_t, nn * B);
   TAKE(e.bornPacked, uint64_t, e.bornStride * B);
   TAKE(e.bornPosLev, uint64_t, e.bornStride * B);
+  TAKE(e.lis[1], uint64_t, P.lisEntries * B);
+  TAKE(e.E, uint32_t, nn * B);
+  TAKE(e.bucket, uint32_t, nn * B);
+  TAKE(e.koff, uint32_t, nn * B);
+  TAKE(e.leafDesc, uint16_t, nn * B);
+  TAKE(e.M, int8_t, nn * B);
 #undef TAKE
   return true;
 }
@@ -921,14 +928,15 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   {
     Arena over;
     over.base = reinterpret_cast<char*>(o.vals);
-    over.cap = Npad * B * sizeof(double);
-    o.aliased = aliasEnv && carve_enc_coder(over, P, B, e);
-    o.coderBytes = over.used;
-    if (!o.aliased && !carve_enc_coder(A, P, B, e))
+    over.cap = aliasEnv ? Npad * B * sizeof(double) : 0;
+    const size_t before = A.used;
+    if (!carve_enc_coder(over, &A, P, B, e))
       return false;
+    o.aliased = over.used != 0;
+    o.coderBytes = over.used + (A.used - before);
     if (arena_debug())
-      fprintf(stderr, "[sperr_hip] arena %-18s %10.2f MB %s\n", "coder arrays", (double)o.coderBytes / 1048576.0,
-              o.aliased ? "(over o.vals)" : "");
+      fprintf(stderr, "[sperr_hip] arena %-18s %10.2f MB, %.2f MB of them over o.vals\n", "coder arrays",
+              (double)o.coderBytes / 1048576.0, (double)over.used / 1048576.0);
   }
   e.lisStride = P.lisEntries;
   TAKE(e.lis[0], uint64_t, P.lisEntries * B);
@@ -1105,9 +1113,10 @@ int wide_retry_prepare(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBu
   Arena W;
   W.base = static_cast<char*>(E.wideScratch.p);
   W.cap = E.wideScratch.n;
-  if (!carve_enc_coder(W, P, nb, bb.eb))
+  if (!carve_enc_coder(W, nullptr, P, nb, bb.eb))
     return -1;
   bb.aliased = false;
+  g_dbg_counter[0]++;
   return float_stages<T>(ss, P, bb, nb, cd, d_src, vd, orgAligned, wantRange);
 }
 
@@ -1626,6 +1635,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       EncBatchBufs bb;
       if (!carve_enc(A, *P, nb, raw_budget, bb))
         return -1;
+      if (bb.aliased)
+        g_dbg_counter[1]++;
       EncBuffers& e = bb.eb;
       std::vector<ChunkGeom> hg(nb);
       std::vector<uint32_t> hid(nb);
@@ -2345,6 +2356,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         done += S.nb;
         if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb, compactElems))
           return -1;
+        if (S.nb && compactElems)
+          g_dbg_counter[2]++;
       }
       int devId = 0;
       HIP_CHECK(hipGetDevice(&devId));
@@ -2853,6 +2866,10 @@ void sperrhip_profile_only(const char* kernel)
 {
   std::lock_guard<std::mutex> lock(g_prof_cfg_mu);
   g_prof_only = kernel ? kernel : "";
+}
+unsigned long long sperrhip_debug_counter(int which)
+{
+  return which >= 0 && which < 3 ? g_dbg_counter[which].load() : 0ull;
 }
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
 {

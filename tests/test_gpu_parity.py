@@ -277,6 +277,53 @@ def test_high_precision_retry(eng, oracle):
                           bits(oracle.decomp_3d(want, False)))
 
 
+def test_retry_of_a_batch_whose_coder_arrays_lay_over_the_chunk_buffer(eng, oracle):
+    """Round 3: the coder's node arrays, birth records and second list lie over the fp64 chunk buffer once
+    the quantiser has read it (carve_enc); a batch that then needs the 64-bit retry (src/SPECK_FLT.cpp:530-538)
+    transforms its chunks again and moves those arrays to scratch memory (wide_retry_prepare).  64^3 chunks
+    are large enough for the overlay (smaller ones lose it to the 256-byte rounding of ten arrays): one
+    chunk, then a volume whose two shape groups run side by side and retry after both are enqueued."""
+    import ctypes as C
+    eng.lib.sperrhip_debug_counter.restype = C.c_ulonglong
+    eng.lib.sperrhip_debug_counter.argtypes = [C.c_int]
+    over0, redo0 = eng.lib.sperrhip_debug_counter(1), eng.lib.sperrhip_debug_counter(0)
+    r = ramp_field((64, 64, 64))
+    want = oracle.comp_3d(r, (64, 64, 64), 1, 40.0)
+    assert want[18 + 17] == 53
+    assert bytes(eng.compress(cuda(r), (64, 64, 64), 40.0).cpu().numpy()) == want
+    assert eng.lib.sperrhip_debug_counter(1) > over0, "the coder arrays were not laid over the chunk buffer"
+    assert eng.lib.sperrhip_debug_counter(0) > redo0, "the retry did not transform the batch again"
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
+    # two shape groups (64^3 and 64 x 64 x 70) side by side, some chunks retry, PSNR and PWE mode as well
+    v = turbulence((64, 64, 134))
+    v[:, :, :64] = ramp_field((64, 64, 64))
+    redo1 = eng.lib.sperrhip_debug_counter(0)
+    for mode, q in ((1, 40.0), (3, 1e-9)):
+        want = oracle.comp_3d(v, (64, 64, 64), mode, q)
+        assert bytes(eng.compress(cuda(v), (64, 64, 64), q, mode=mode).cpu().numpy()) == want, mode
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
+    assert eng.lib.sperrhip_debug_counter(0) > redo1
+
+
+def test_compact_chunk_buffer_of_the_decoder(eng, oracle):
+    """Round 3: when the finest level is the fused x-y-z kernel and every inverse pass dequantises on load,
+    the decoder's fp64 chunk buffer holds the second level's box only (carve_dec, compact_box): dyadic
+    chunks of even and odd extents, several per batch, against the oracle."""
+    import ctypes as C
+    eng.lib.sperrhip_debug_counter.restype = C.c_ulonglong
+    eng.lib.sperrhip_debug_counter.argtypes = [C.c_int]
+    for shape, chunks in (((64, 64, 128), (64, 64, 64)), ((33, 45, 82), (33, 45, 41)), ((40, 48, 56), (20, 24, 56))):
+        c0 = eng.lib.sperrhip_debug_counter(2)
+        v = turbulence(shape)
+        want = oracle.comp_3d(v, chunks[::-1], 1, 3.0)
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True))), shape
+        assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False))), shape
+        assert eng.lib.sperrhip_debug_counter(2) > c0, ("compact buffer not used", shape)
+
+
 def test_constant_and_mixed_chunks(eng, oracle):
     v = turbulence((32, 32, 64))
     v[:, :, :32] = 1.25                       # first chunk constant -> 17-byte stream
