@@ -536,7 +536,7 @@ k_speck1d(OutlierBufs b)
         break;
       const uint32_t h0 = l - l / 2, r0 = l / 2;
       const bool right = ((rR >> j) & 1u) != 0;
-      const bool born = act && (right ? j >= u : ((rClosed >> (j + 1u)) & 1u) != 0);
+      const bool born = act && (right ? j >= u : ((rClosed >> (30u - j)) & 1u) != 0);   // (depth j + 1, bit-reversed)
       const uint32_t bs = right ? s : s + h0, bl = right ? h0 : r0;
       if (born && bl == 1)
         atomicOr(reinterpret_cast<unsigned long long*>(lip) + (bs >> 6), 1ull << (bs & 63u));
@@ -576,16 +576,27 @@ k_speck1d(OutlierBufs b)
     tkFlush += clock64() - tf0;
 #endif
   };
-  auto expand_chain = [&](uint32_t es, uint32_t el, uint32_t lev) {   // a run of at least two values
-    uint32_t R = 0, m = 0, u = 0, lo = el;
+  // (P2: the run's length is a power of two -- every run of a chunk of 2^k values -- so all halves are
+  //  and a path from depth u is log2(el) - u steps; the parked depths are kept bit-REVERSED, `mr` bit
+  //  31 - d for depth d, so that the innermost parked halves are the lowest set bits: closing z of them
+  //  is z times x & (x - 1))
+  auto expand_chain = [&](auto p2tag, uint32_t es, uint32_t el, uint32_t lev) {   // a run of at least two values
+    constexpr bool P2 = decltype(p2tag)::value;
+    const uint32_t lgEl = 31u - (uint32_t)__clz((int)el);
+    uint32_t R = 0, mr = 0, u = 0, lo = el;
     for (;;) {
       const uint64_t peek = window();
-      uint32_t nsteps = 0;
-      if (lo > 1) {
-        const uint32_t t0 = 30u - (uint32_t)__clz((int)lo), mk = (1u << t0) - 1u;
-        const uint32_t lt = (lo >> t0) + (((~(uint32_t)peek & mk) < (lo & mk)) ? 1u : 0u);
-        const uint32_t bt = (uint32_t)(peek >> t0) & 1u;
-        nsteps = (lt == 2u || (lt == 3u && bt == 0u)) ? t0 + 1u : t0 + 2u;
+      uint32_t nsteps;
+      if (P2)
+        nsteps = lgEl - u;
+      else {
+        nsteps = 0;
+        if (lo > 1) {
+          const uint32_t t0 = 30u - (uint32_t)__clz((int)lo), mk = (1u << t0) - 1u;
+          const uint32_t lt = (lo >> t0) + (((~(uint32_t)peek & mk) < (lo & mk)) ? 1u : 0u);
+          const uint32_t bt = (uint32_t)(peek >> t0) & 1u;
+          nsteps = (lt == 2u || (lt == 3u && bt == 0u)) ? t0 + 1u : t0 + 2u;
+        }
       }
       if (u + nsteps > 31u) {   // (cannot happen: N < 2^32)
         err = 2;
@@ -593,22 +604,20 @@ k_speck1d(OutlierBufs b)
       }
       const uint32_t pm = (1u << nsteps) - 1u;
       R |= (~(uint32_t)peek & pm) << u;
-      m |= ((uint32_t)peek & pm) << (u + 1u);
+      mr |= __brev((uint32_t)peek & pm) >> (u + 1u);   // a '1' at step j parks the right half of depth u + j + 1
       const uint32_t sg = (uint32_t)(peek >> nsteps) & 1u;
-      const uint32_t cnt = (uint32_t)__popc(m);
+      const uint32_t cnt = (uint32_t)__popc(mr);
       const uint64_t cw = peek >> (nsteps + 1u);   // (at least 31 valid bits, cnt <= 31)
       const uint32_t z = min(cw ? (uint32_t)__ffsll((long long)cw) - 1u : 64u, cnt);
-      uint32_t closed = 0;
-      for (uint32_t k = 0; k < z; k++) {   // the z innermost parked halves are born insignificant
-        const uint32_t top = 31u - (uint32_t)__clz((int)m);
-        m &= ~(1u << top);
-        closed |= 1u << top;
-      }
+      uint32_t rest = mr;
+      for (uint32_t k = 0; k < z; k++)   // the z innermost parked halves are born insignificant
+        rest &= rest - 1u;
       wrlane(rES, nrec, es);
       wrlane(rEL, nrec, el);
       wrlane(rR, nrec, R);
       wrlane(rMeta, nrec, u | ((u + nsteps) << 8) | (sg << 16));
-      wrlane(rClosed, nrec, closed);
+      wrlane(rClosed, nrec, mr ^ rest);
+      mr = rest;
       nrec++;
       if (nrec == 64u)
         flush_paths(lev);
@@ -616,11 +625,13 @@ k_speck1d(OutlierBufs b)
       if (z == cnt)
         return;
       rpos++;   // (a '1': z < cnt <= 31, so the bit was inside the window)
-      u = 31u - (uint32_t)__clz((int)m);
-      m &= ~(1u << u);
+      u = 32u - (uint32_t)__ffs((int)mr);
+      mr &= mr - 1u;
       R = (R & ((1u << (u - 1u)) - 1u)) | (1u << (u - 1u));
-      const uint32_t um = (1u << u) - 1u;
-      lo = (el >> u) + (((R & um) < (el & um)) ? 1u : 0u);
+      if (!P2) {
+        const uint32_t um = (1u << u) - 1u;
+        lo = (el >> u) + (((R & um) < (el & um)) ? 1u : 0u);
+      }
     }
   };
 
@@ -873,7 +884,10 @@ k_speck1d(OutlierBufs b)
               const long long tc0 = clock64();
               nEntries++;
 #endif
-              expand_chain(es, el, lev);
+              if ((el & (el - 1u)) == 0u)
+                expand_chain(std::true_type{}, es, el, lev);
+              else
+                expand_chain(std::false_type{}, es, el, lev);
 #ifdef SPERR_1D_STAMPS
               tkChain += clock64() - tc0;
 #endif
@@ -1084,30 +1098,35 @@ k_speck1d(OutlierBufs b)
         }
         if (__ballot(any != 0) == 0)
           continue;
+        // the stream words of all eight blocks are asked for before the first deposit (block after block,
+        // each waited for its own loads: 1000 rounds of eight memory latencies per plane)
+        uint64_t av[8], dv[8];
+        uint32_t shv[8], cntv[8];
 #pragma unroll
         for (int jb = 0; jb < 8; jb++) {
-        const uint32_t wb = wb8 + (uint32_t)jb * 64u;
-        const uint32_t w = wb + lane;
-        const uint64_t sw = swv[jb];
-        if (__ballot(sw != 0) == 0)
-          continue;
-        const uint32_t cnt = (uint32_t)__popcll(sw);
-        const uint32_t inc = wave_scan_dpp(cnt);
-        if (cnt) {
+          const uint32_t cnt = (uint32_t)__popcll(swv[jb]);
+          const uint32_t inc = wave_scan_dpp(cnt);
           const uint64_t at = rpos + (inc - cnt);
-          const uint32_t sh = (uint32_t)(at & 63);
-          const uint64_t a = words[at >> 6], d = words[(at >> 6) + 1];
-          uint64_t bits = sh ? (a >> sh) | (d << (64 - sh)) : a;
-          uint64_t res = 0, m = sw;   // deposit the next cnt bits under the mask
-          while (m) {
-            const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
-            m &= m - 1;
-            res |= (bits & 1ull) << j;
-            bits >>= 1;
-          }
-          pb[w] = res;
+          cntv[jb] = cnt;
+          shv[jb] = (uint32_t)(at & 63);
+          av[jb] = cnt ? words[at >> 6] : 0ull;
+          dv[jb] = cnt ? words[(at >> 6) + 1] : 0ull;
+          rpos += rdlane(inc, 63);
         }
-        rpos += rdlane(inc, 63);
+#pragma unroll
+        for (int jb = 0; jb < 8; jb++) {
+          if (cntv[jb]) {
+            const uint32_t sh = shv[jb];
+            uint64_t bits = sh ? (av[jb] >> sh) | (dv[jb] << (64 - sh)) : av[jb];
+            uint64_t res = 0, m = swv[jb];   // deposit the next cnt bits under the mask
+            while (m) {
+              const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
+              m &= m - 1;
+              res |= (bits & 1ull) << j;
+              bits >>= 1;
+            }
+            pb[wb8 + (uint32_t)jb * 64u + lane] = res;
+          }
         }
       }
       STAMP_END(tkRef);
