@@ -1103,9 +1103,9 @@ int float_stages(hipStream_t ss, const ShapePlan& P, EncBatchBufs& bb, uint32_t 
 
 // before the 64-bit retry of a batch whose coder arrays lay over the chunk buffer: those arrays move
 // to memory of their own and the buffer gets its DWT coefficients back
-template <typename T>
-int wide_retry_prepare(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
-                       const uint32_t cd[3], const T* d_src, VolDesc vd, bool orgAligned, bool wantRange)
+// the coder's arrays off the chunk buffer, into scratch memory of the engine (64-bit magnitudes are
+// about to live in the buffer)
+int unalias_coder(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb)
 {
   HIP_CHECK(hipStreamSynchronize(ss));   // (the scratch buffer may grow: nothing of this stream may still use it)
   if (E.wideScratch.ensure(bb.coderBytes + 4096))
@@ -1116,6 +1116,15 @@ int wide_retry_prepare(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBu
   if (!carve_enc_coder(W, nullptr, P, nb, bb.eb))
     return -1;
   bb.aliased = false;
+  return 0;
+}
+
+template <typename T>
+int wide_retry_prepare(hipStream_t ss, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                       const uint32_t cd[3], const T* d_src, VolDesc vd, bool orgAligned, bool wantRange)
+{
+  if (unalias_coder(ss, E, P, bb, nb))
+    return -1;
   g_dbg_counter[0]++;
   return float_stages<T>(ss, P, bb, nb, cd, d_src, vd, orgAligned, wantRange);
 }
@@ -3293,8 +3302,10 @@ int sperrhip_speck3d_encode_dev(const void* d_coef, int width, const uint64_t* d
     EncBatchBufs bb;
     if (!carve_enc(A, *P, 1, raw_budget, bb))
       return -1;
-    EncBuffers e = bb.eb;
     const bool wide = width == 8;
+    if (wide && bb.aliased && unalias_coder(st, E, *P, bb, 1))   // (the 64-bit magnitudes go into the chunk buffer)
+      return -1;
+    EncBuffers e = bb.eb;
     CoderState hcs;
     memset(&hcs, 0, sizeof(hcs));
     hcs.need_retry = wide ? 1u : 0u;  // the 64-bit pass only encodes chunks flagged for it

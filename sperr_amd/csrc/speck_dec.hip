@@ -5094,6 +5094,77 @@ __global__ void __launch_bounds__(kThreads * kRefGroups) k_ref_apply(DecBuffers 
   }
 }
 
+// The same pass with one lane per CANDIDATE instead of one per sample (round 3).  In k_ref_apply a
+// wavefront spends its instructions on the 64 samples of a mask word, of which a few percent are
+// significant in the fine subbands, where 7/8 of the samples are: it was bound by its instruction
+// count (0.3 ms per launch of 32 chunks for 10 GB of traffic per step).  Here the significant samples of
+// a tile are first listed in LDS in raster order (thread = mask word: it writes its word's set bits at
+// the word's rank, 14 bits each), then candidate r of the tile -- lane r -- takes stream bit base + r
+// and its coefficient: consecutive lanes read consecutive bits and touch the cache lines one
+// instruction of the old kernel touched each.  A workgroup of 256 threads strides over the tiles.
+template <typename CT>
+__global__ void __launch_bounds__(kThreads) k_ref_apply2(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  __shared__ uint32_t sm[kThreads / 64 + 1];
+  __shared__ uint16_t list[kDecTileWords * 64];   // word << 6 | bit of every candidate, raster order
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
+  const CT thr = (CT)1 << p, half = thr / 2;
+  const CT initPrev = thr * 2 + thr * 2 - thr - 1;   // 1.5 * (2 thr) - 1  (SPECK_INT.cpp:462-468)
+  const uint64_t avail = s.avail, pos0 = s.pos;
+  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
+    if (b.tileRef[c * b.tileStride + tile] == 0)
+      continue;   // (uniform: the whole workgroup reads the same word)
+    const uint32_t w0 = tile * kDecTileWords, wi = w0 + threadIdx.x;
+    uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
+    uint32_t total;
+    uint32_t o = block_exclusive_scan_lds<uint32_t>((uint32_t)__popcll(sig), sm, &total);
+    const uint32_t wtag = threadIdx.x << 6;
+    while (sig) {
+      const uint32_t j = (uint32_t)__ffsll((long long)sig) - 1u;
+      sig &= sig - 1;
+      list[o++] = (uint16_t)(wtag | j);
+    }
+    LDS_ONLY_BARRIER();
+    const uint64_t base = pos0 + (uint64_t)b.tileRefOff[c * b.tileStride + tile];
+    // the pass stops the moment the stream is exhausted (SPECK_INT.cpp:388-389)
+    const uint32_t lim = base >= avail ? 0u : (uint32_t)min((uint64_t)total, avail - base);
+    constexpr int kB = 4;   // candidates per thread and round: their loads are issued together
+    for (uint32_t r0 = threadIdx.x; r0 < lim; r0 += kThreads * kB) {
+      uint32_t idx[kB];
+      uint64_t sw[kB];
+      CT cv[kB];
+#pragma unroll
+      for (int u = 0; u < kB; u++) {
+        const uint32_t r = r0 + (uint32_t)u * kThreads;
+        const bool act = r < lim;
+        idx[u] = act ? w0 * 64u + list[r] : 0xffffffffu;
+        const uint64_t at = base + r;
+        sw[u] = act ? (words[at >> 6] >> (at & 63)) & 1ull : 0ull;
+        cv[u] = act ? coef[idx[u]] : (CT)0;
+      }
+#pragma unroll
+      for (int u = 0; u < kB; u++) {
+        if (idx[u] == 0xffffffffu)
+          continue;
+        CT v2 = cv[u];
+        if (v2 == 0)          // first touch: found significant on the previous plane (threshold 2*thr)
+          v2 = initPrev;
+        if (p >= 1)
+          v2 = sw[u] ? v2 + half : v2 - half;
+        else if (sw[u])
+          v2 += 1;
+        coef[idx[u]] = v2;
+      }
+    }
+    LDS_ONLY_BARRIER();   // (the list is rewritten for the next tile)
+  }
+}
+
 // After the last plane: leaf results that no k_dec_count has folded yet are those of the last
 // decoded plane -- they are "new" for k_dec_finish.
 __global__ void __launch_bounds__(kThreads) k_dec_fold(DecBuffers b)
@@ -5221,6 +5292,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint64_t>), (int)b.hiSmemBytes))
       return -1;
   }
+  // refinement pass with one lane per candidate (k_ref_apply2); SPERR_HIP_REF_LANES=0: one lane per sample
+  static const bool refLanes = !(getenv("SPERR_HIP_REF_LANES") && atoi(getenv("SPERR_HIP_REF_LANES")) == 0);
   for (int p = maxPlanes - 1; p >= 0; p--) {
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
@@ -5261,8 +5334,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       else
         LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint64_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
-               dim3(kThreads * kRefGroups), 0, stream, b, p);
+      if (refLanes)
+        LAUNCH_K(k_ref_apply2<uint64_t>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+      else
+        LAUNCH_K(k_ref_apply<uint64_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
+                 dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     else {
       LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
@@ -5299,8 +5375,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
-               dim3(kThreads * kRefGroups), 0, stream, b, p);
+      if (refLanes)
+        LAUNCH_K(k_ref_apply2<uint32_t>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+      else
+        LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
+                 dim3(kThreads * kRefGroups), 0, stream, b, p);
     }
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
     // Have the chunks run out of bits?  Asked after 16 planes and then after every second one, and

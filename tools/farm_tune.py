@@ -61,7 +61,11 @@ def setenv(**kv):
 dst0, n0, _ = comp()
 print(f"# {kind} {S}^3; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}")
 print("# compress: workers item helpers copy -> ms GB/s")
-for w, item, hl, cp in itertools.product((2, 3, 4), (4, 8, 11, 16), (4, 8) if kind != "pinned" else (4,),
+CW = tuple(int(v) for v in os.environ.get("TUNE_CW", "2,3,4").split(","))
+CI = tuple(int(v) for v in os.environ.get("TUNE_CI", "4,8,11,16").split(","))
+DW = tuple(int(v) for v in os.environ.get("TUNE_DW", "2,3,4").split(","))
+DI = tuple(int(v) for v in os.environ.get("TUNE_DI", "8,16,22,32").split(","))
+for w, item, hl, cp in itertools.product(CW, CI, (4, 8) if kind != "pinned" else (4,),
                                          ("3d", "stage") if kind == "pinned" else ("stage",)):
     setenv(SPERR_HIP_FARM_WORKERS=w, SPERR_HIP_FARM_ITEM=item, SPERR_HIP_FARM_HELPERS=hl, SPERR_HIP_PINNED_COPY=cp)
     ts = []
@@ -72,7 +76,7 @@ for w, item, hl, cp in itertools.product((2, 3, 4), (4, 8, 11, 16), (4, 8) if ki
             ts.append(t)
     print(f"C w={w} item={item} helpers={hl} copy={cp}: {min(ts) * 1e3:.1f} ms {nbytes / min(ts) / 1e9:.1f} GB/s", flush=True)
 print("# decompress: workers item helpers copy -> ms GB/s")
-for w, item, hl, cp in itertools.product((2, 3, 4), (8, 16, 22, 32), (4, 8) if kind != "pinned" else (4,),
+for w, item, hl, cp in itertools.product(DW, DI, (4, 8) if kind != "pinned" else (4,),
                                          ("3d", "stage") if kind == "pinned" else ("stage",)):
     setenv(SPERR_HIP_FARM_DEC_WORKERS=w, SPERR_HIP_FARM_ITEM=item, SPERR_HIP_FARM_HELPERS=hl, SPERR_HIP_PINNED_COPY=cp)
     ts = []
