@@ -1954,17 +1954,6 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.signStride = Npad / 64;
   TAKE(d.sign, uint64_t, d.signStride * B);
   d.maskPixStride = Npad / 64;
-  // dense refinement planes (speck_dec.h; 32-bit coefficients only; SPERR_HIP_REF_PLANES=0: the
-  // coefficients are updated plane by plane instead)
-  static const bool refPlanesEnv = !(getenv("SPERR_HIP_REF_PLANES") && atoi(getenv("SPERR_HIP_REF_PLANES")) == 0);
-  d.refPlanes = nullptr;
-  d.refMask = nullptr;
-  d.refPlaneStride = 0;
-  if (refPlanesEnv) {
-    d.refPlaneStride = (size_t)32 * d.maskPixStride;
-    TAKE(d.refPlanes, uint64_t, d.refPlaneStride * B);
-    TAKE(d.refMask, uint64_t, d.maskPixStride * B);
-  }
   TAKE(d.bornM, uint64_t, d.maskPixStride * B);
   TAKE(d.sigOld, uint64_t, d.maskPixStride * B);
   TAKE(d.sigNew, uint64_t, d.maskPixStride * B);
@@ -2531,14 +2520,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
             dw.coef = bb.vals;
             dw.coefStride = bb.valsStride;
-            dw.refPlanes = nullptr;
             HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, ss));
           }
-          else {
+          else
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
-            if (d.refPlanes)
-              HIP_CHECK(hipMemsetAsync(d.refPlanes, 0, d.refPlaneStride * nb * 8, ss));
-          }
           if (slice && !(P->ht.flags & spk::kTree2D)) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
             DecPlanHost ph2 = ph;
             ph2.tables = ph2.l0 = ph2.l1 = ph2.mixed = false;
@@ -3419,14 +3404,10 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     if (wide) {
       d.coef = bb.vals;
       d.coefStride = bb.valsStride;
-      d.refPlanes = nullptr;
       HIP_CHECK(hipMemsetAsync(bb.vals, 0, (size_t)n * 8, st));
     }
-    else {
+    else
       HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
-      if (d.refPlanes)
-        HIP_CHECK(hipMemsetAsync(d.refPlanes, 0, d.refPlaneStride * 8, st));
-    }
     DecPlanHost ph{P->d_initLIS, P->d_initLen, use_tables(*P),
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);

@@ -15,8 +15,6 @@ struct DecState {
   uint32_t nLip, nRef;           // candidates of the current plane's pixel passes
   uint32_t nLeafEv;              // leaf events of the plane just decoded
   int32_t lastPlane;             // last plane whose sorting pass ran
-  int32_t refPlaneP1;            // 1 + the last plane whose refinement pass ran (0: none yet)
-  uint32_t refPartial;           //   ... and the stream ended inside that pass
   uint64_t pos;                  // next unread bit
   uint64_t avail;                // usable bits of the stream
   uint64_t total_bits;
@@ -61,14 +59,6 @@ struct DecBuffers {
   size_t maskPixStride;
   void* coef;                  // uint32_t or uint64_t magnitudes being reconstructed
   size_t coefStride;
-  // Dense refinement planes (round 3, 32-bit coefficients): refPlanes[plane][word] holds, for every
-  // sample, bit `plane` of its magnitude -- the '1' of the plane it was found on and the refinement
-  // bits of the planes below -- as one bit per sample in raster order; k_ref_assemble turns them
-  // into coefficients after the last plane.  nullptr: k_ref_apply2 updates the coefficients plane
-  // by plane.  refMask: the samples that got a bit in a refinement pass the stream's end cut short.
-  uint64_t* refPlanes;
-  size_t refPlaneStride;       // words per chunk (planes x maskPixStride)
-  uint64_t* refMask;
   uint64_t* sign;              // initialised to all ones (SPECK_INT.cpp:174-175)
   size_t signStride;
   uint64_t* lis[2];

@@ -50,8 +50,6 @@ __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint6
   const uint64_t len = chunkLen[c];
   s.active = 0;
   s.done = 0;
-  s.refPlaneP1 = 0;
-  s.refPartial = 0;
   s.nbp = 0;
   s.pos = 0;
   s.cur = 0;
@@ -213,8 +211,6 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
       }
     }
     if (fresh | (ls & ~sig)) {
-      if (b.refPlanes)   // found on plane p + 1: bit p + 1 of their magnitudes
-        b.refPlanes[c * b.refPlaneStride + (size_t)(p + 1) * b.maskPixStride + wi] |= (fresh | ls) & ~sig;
       sig |= fresh | ls;
       *so = sig;
     }
@@ -5169,119 +5165,6 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply2(DecBuffers b, int p)
   }
 }
 
-// Round 3, 32-bit coefficients: the refinement pass does not touch the coefficients at all.  The old
-// passes updated 4 bytes here and there in a 64 MB array on every plane (10 GB per step of the bench
-// volume at 1 TB/s: whole cache lines moved for a few samples each).  Now plane p's bits are
-// DEPOSITED under the significance mask into a dense bit plane (thread = mask word: candidate i of
-// the word is its i-th set bit, the word's candidates start at the tile's offset + the word's rank),
-// one 8-byte store per word; k_dec_count adds the '1' of the plane a sample was found on; and after
-// the last plane k_ref_assemble gathers every sample's bits (lane = sample) and writes the
-// coefficient once: magnitude bits + 2^(q-1) - 1, q the lowest plane the sample was refined on
-// (the plane it was found on when none: 1.5 * 2^p - 1, src/SPECK_INT.cpp:462-468).
-__global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.y;
-  const DecState& s = b.st[c];
-  DEC_ACTIVE_OR_RETURN(s, p);
-  __shared__ uint32_t sm[kThreads / 64 + 1];
-  const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint64_t* words = b.stream + c * b.streamStride;
-  uint64_t* plane = b.refPlanes + c * b.refPlaneStride + (size_t)p * b.maskPixStride;
-  const uint64_t avail = s.avail, pos0 = s.pos;
-  const bool partial = pos0 + (uint64_t)s.nRef > avail;   // the stream ends inside this pass
-  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
-    if (b.tileRef[c * b.tileStride + tile] == 0)
-      continue;   // (uniform)
-    const uint32_t wi = tile * kDecTileWords + threadIdx.x;
-    const uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
-    const uint32_t cnt = (uint32_t)__popcll(sig);
-    uint32_t total;
-    const uint32_t o = block_exclusive_scan_lds<uint32_t>(cnt, sm, &total);
-    if (cnt == 0)
-      continue;
-    const uint64_t at = pos0 + (uint64_t)b.tileRefOff[c * b.tileStride + tile] + o;
-    // the pass stops the moment the stream is exhausted (SPECK_INT.cpp:388-389)
-    const uint32_t n = at >= avail ? 0u : (uint32_t)min((uint64_t)cnt, avail - at);
-    uint64_t res = 0, m = sig;
-    if (n) {
-      uint64_t bits = get64(words, at);
-      for (uint32_t k = 0; k < n; k++) {   // candidate k of the word is the k-th set bit of the mask
-        const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
-        m &= m - 1;
-        res |= (bits & 1ull) << j;
-        bits >>= 1;
-      }
-      if (res)
-        plane[wi] = res;   // (still zero here: the '1's of the samples found on this plane are added later, by k_dec_count)
-    }
-    if (partial)
-      b.refMask[c * b.maskPixStride + wi] = sig & ~m;   // the candidates that did get a bit
-  }
-}
-
-__global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
-{
-  const uint32_t c = blockIdx.y;
-  const DecState& s = b.st[c];
-  if (!s.active || s.nbp == 0)
-    return;   // (coefficients stay zero)
-  const uint32_t nw = (b.tree.nvals + 63) / 64, n = b.tree.nvals;
-  const uint32_t lane = threadIdx.x & 63u;
-  const int lastPlane = s.lastPlane, refPlane = s.refPlaneP1 - 1;
-  const bool partial = s.refPartial != 0;
-  const int pLow = refPlane >= 0 ? min(refPlane, lastPlane) : lastPlane, nbp = s.nbp;
-  const uint64_t* planes = b.refPlanes + c * b.refPlaneStride;
-  uint32_t* coef = reinterpret_cast<uint32_t*>(b.coef) + c * b.coefStride;
-  constexpr int kW = 4;   // mask words per wavefront and round
-  const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6, nwave = (gridDim.x * kThreads) >> 6;
-  for (uint32_t w0 = wave * kW; w0 < nw; w0 += nwave * kW) {
-    uint64_t so[kW], sn[kW], any = 0;
-#pragma unroll
-    for (int u = 0; u < kW; u++) {
-      const uint32_t w = w0 + (uint32_t)u;
-      so[u] = w < nw ? b.sigOld[c * b.maskPixStride + w] : 0ull;
-      sn[u] = w < nw ? b.sigNew[c * b.maskPixStride + w] : 0ull;
-      any |= so[u] | sn[u];
-    }
-    if (any == 0)
-      continue;   // (wave-uniform: every lane loads the same words)
-    uint32_t M[kW] = {0, 0, 0, 0};
-    for (int pl = pLow; pl < nbp; pl++) {
-#pragma unroll
-      for (int u = 0; u < kW; u++) {
-        const uint32_t w = w0 + (uint32_t)u;
-        const uint64_t pw = (so[u] && w < nw) ? planes[(size_t)pl * b.maskPixStride + w] : 0ull;
-        M[u] |= ((uint32_t)(pw >> lane) & 1u) << pl;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kW; u++) {
-      const uint32_t w = w0 + (uint32_t)u;
-      if (w >= nw || (so[u] | sn[u]) == 0)
-        continue;
-      const bool isNew = ((sn[u] >> lane) & 1ull) != 0, isOld = ((so[u] >> lane) & 1ull) != 0;
-      const uint32_t idx = w * 64u + lane;
-      if (!(isNew || isOld) || idx >= n)
-        continue;
-      uint32_t m = isOld ? M[u] : 0u;
-      if (isNew)
-        m |= 1u << lastPlane;
-      const int p0 = 31 - __clz((int)m);
-      int q = p0;   // lowest plane the sample was refined on, the plane it was found on when none
-      if (isOld && refPlane >= 0) {
-        bool atRef = p0 > refPlane;
-        if (atRef && partial)
-          atRef = ((b.refMask[c * b.maskPixStride + w] >> lane) & 1ull) != 0;
-        if (atRef)
-          q = refPlane;
-        else if (p0 > refPlane + 1)
-          q = refPlane + 1;
-      }
-      coef[idx] = m + (q >= 1 ? (1u << (q - 1)) - 1u : 0u);
-    }
-  }
-}
-
 // After the last plane: leaf results that no k_dec_count has folded yet are those of the last
 // decoded plane -- they are "new" for k_dec_finish.
 __global__ void __launch_bounds__(kThreads) k_dec_fold(DecBuffers b)
@@ -5343,8 +5226,6 @@ __global__ void k_dec_plane_end(DecBuffers b, int p)
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   const uint64_t room = s.avail - s.pos;
-  s.refPlaneP1 = p + 1;
-  s.refPartial = (uint64_t)s.nRef > room ? 1u : 0u;
   s.pos += min((uint64_t)s.nRef, room);
   if (s.pos >= s.avail || p == 0)  // SPECK_INT.cpp:204-205
     s.done = 1;
@@ -5494,9 +5375,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       else
         LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      if (b.refPlanes)
-        LAUNCH_K(k_ref_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
-      else if (refLanes)
+      if (refLanes)
         LAUNCH_K(k_ref_apply2<uint32_t>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
       else
         LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
@@ -5526,9 +5405,6 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     const uint32_t n = b.tree.nvals;
     if ((plan.tables || plan.mixed) && b.wordLeaf)
       LAUNCH_K(k_dec_fold, dim3(((n + 63) / 64 + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
-               stream, b);
-    if (b.refPlanes && !wide_pass)
-      LAUNCH_K(k_ref_assemble, dim3(capped_blocks(((n + 63) / 64 + 15) / 16, nc, kGridCapWide), nc), dim3(kThreads), 0,
                stream, b);
     if (!plan.skipFinish) {
       if (wide_pass)
