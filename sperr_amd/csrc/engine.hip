@@ -157,6 +157,8 @@ void prof_end(hipStream_t stream)
   t_prof_cur = nullptr;
 }
 
+thread_local bool t_shared_device = false;   // (engine_internal.h)
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
@@ -634,6 +636,15 @@ struct EnginePool {
       e->busy = false;
     }
     cv.notify_all();
+  }
+  // engines of a device that are on a call right now (the caller's own included)
+  size_t busy_on(int dev)
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    size_t n = 0;
+    for (auto& e : all)
+      n += (e->dev == dev && e->busy) ? 1 : 0;
+    return n;
   }
 };
 
@@ -2345,6 +2356,16 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       static const int subEnv = getenv("SPERR_HIP_SUBSTREAMS") ? atoi(getenv("SPERR_HIP_SUBSTREAMS")) : 0;
       static const bool threads = !(getenv("SPERR_HIP_ENQUEUE_THREADS") && atoi(getenv("SPERR_HIP_ENQUEUE_THREADS")) == 0);
       uint32_t nsub = nbAll >= 32 ? 2u : 1u;
+      // A call that has the device to itself cuts a smaller batch finer (round 3): the chunks' serial
+      // chains bound it, and four sub-batches side by side decode 8 chunks in 14.4 ms instead of 16.5,
+      // 27 chunks in 26.7 instead of 30.1 (64 chunks: two 85.0, three 83.3, four 82.1 GB/s).  Not when
+      // other calls run on the device (the chunk farm's workers: their items already overlap, and
+      // sub-batches on top took its decompression from 40 to 26 GB/s).
+      {
+        int devNow = 0;
+        if (!t_shared_device && hipGetDevice(&devNow) == hipSuccess && g_pool.busy_on(devNow) <= 1)
+          nsub = nbAll >= 56 ? 2u : nbAll >= 8 ? 4u : nbAll >= 4 ? 2u : 1u;
+      }
       if (subEnv > 0)
         nsub = std::min<uint32_t>(kSubStreams, (uint32_t)subEnv);
       // (with outlier streams every sub-batch waits for its stream when it reads back the 1D decoder's

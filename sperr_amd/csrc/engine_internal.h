@@ -30,6 +30,10 @@ size_t host_chunk_stream_bound(size_t nvals, int mode, double quality);
 // farm.hip: the buffers of every idle farm worker go back (sperrhip_release)
 void farm_release_idle();
 
+// Set by a thread whose device calls run beside those of other threads on the same device (the farm's
+// workers): the engine then does not cut a small batch into sub-batches of its own.
+extern thread_local bool t_shared_device;
+
 }  // namespace sperrhip
 
 #endif

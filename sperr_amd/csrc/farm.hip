@@ -584,7 +584,9 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
   if (C.need_dev_out(outBytes))
     return -1;
   size_t x = 0, y = 0, z = 0;
+  t_shared_device = true;   // (the other workers of the device run beside this call)
   const int rc = sperrhip_decompress_dev(C.dIn, total, J.output_float, C.dOut, outBytes, &x, &y, &z, C.st);
+  t_shared_device = false;
   if (rc)
     return rc;
   if (J.direct) {
