@@ -122,20 +122,16 @@ __device__ __forceinline__ void oct_load(const Tree& t, const Grid& g, const Roo
 // ------------------------------------------------------------------------------------------
 // k_pyramid: one thread per node of the grids at one depth (deepest first)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kNodeBlock)
-k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
+// (returns the plane at which the node splits when it is a set with a significant sample, else -1)
+__device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uint32_t id)
 {
-  const uint32_t c = blockIdx.y;
-  if (!b.st[c].active)
-    return;
   const Tree& t = b.tree;
-  const uint32_t id = depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x;
   Node nd;
   if (!node_from_flat(t, id, nd))
-    return;
+    return -1;
   const NodeGeom q = node_geom(t, nd);
   if (q.count == 0)
-    return;
+    return -1;
   int8_t* M = b.M + c * b.nodeStride;
   uint32_t* E = b.E + c * b.nodeStride;
   const int8_t* msb = b.msb + c * b.pixStride;
@@ -187,14 +183,14 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
       for (int q2 = 0; q2 < 4; q2++)
         *reinterpret_cast<uint2*>(koff + oct_kid(k, 2 * q2)) = make_uint2(ko[2 * q2], ko[2 * q2 + 1]);
     }
-    return;
+    return m;
   }
   const bool isset = q.count > 1 || g.depth == 0;
   if (!isset) {
     const int e[3] = {g.e[0], g.e[1], g.e[2]};
     const uint32_t ii[3] = {nd.i[0], nd.i[1], nd.i[2]};
     M[id] = msb[pixel_raster(t, r, e, ii)];
-    return;
+    return -1;
   }
   Kids k;
   node_kids(t, nd, k);
@@ -221,6 +217,28 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
       koff[kid_flat(t, k, j)] = before + (coded ? 1u : 0u);
     }
   }
+  return m;
+}
+
+// one thread per node; the splitting sets are counted per plane on the way (the bucket histogram: a
+// pass of its own over every node before, k_bucket_hist, 1.1 ms per launch of 21 chunks)
+__global__ void __launch_bounds__(kNodeBlock)
+k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
+{
+  const uint32_t c = blockIdx.y;
+  EncState& s = b.st[c];
+  if (!s.active)
+    return;
+  __shared__ uint32_t h[kMaxPlanes];
+  if (threadIdx.x < kMaxPlanes)
+    h[threadIdx.x] = 0;
+  __syncthreads();
+  const int sp = pyramid_node(b, c, depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x);
+  if (sp >= 0)
+    atomicAdd(&h[sp], 1u);
+  __syncthreads();
+  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
+    atomicAdd(&s.bucketCnt[threadIdx.x], h[threadIdx.x]);
 }
 
 // Top-down over the depths (shallowest first): where each set's split sits relative to the list
@@ -689,25 +707,6 @@ __device__ __forceinline__ bool splitting_set(const Tree& t, uint32_t id, int m)
     return false;
   const NodeGeom q = node_geom(t, nd);
   return q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
-}
-
-__global__ void __launch_bounds__(kNodeBlock) k_bucket_hist(EncBuffers b)
-{
-  const uint32_t c = blockIdx.y;
-  EncState& s = b.st[c];
-  if (!s.active)
-    return;
-  __shared__ uint32_t h[kMaxPlanes];
-  if (threadIdx.x < kMaxPlanes)
-    h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
-  const int m = b.M[c * b.nodeStride + id];
-  if (splitting_set(b.tree, id, m))
-    atomicAdd(&h[m], 1u);
-  __syncthreads();
-  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
-    atomicAdd(&s.bucketCnt[threadIdx.x], h[threadIdx.x]);
 }
 
 __global__ void k_bucket_scan(EncBuffers b)
@@ -1313,7 +1312,6 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
   {
     const uint32_t nodeBlocksAll = b.tree.nnodes / kNodeBlock;
-    LAUNCH_K(k_bucket_hist, dim3(nodeBlocksAll, nc), dim3(kNodeBlock), 0, stream, b);
     LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);
     LAUNCH_K(k_bucket_fill, dim3(nodeBlocksAll, nc), dim3(kNodeBlock), 0, stream, b);
   }
