@@ -245,34 +245,55 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
 // entry that starts its chain of nested splits.  A set whose parent splits on the same plane
 // (M equal) is coded inside the parent's split; otherwise it is a list entry itself.  The sets of
 // a root's deepest depth are not stored: k_split_emit takes the one step from their parent.
+// On the way the splitting sets are dealt to the buckets of their planes (k_bucket_fill, a pass of its own
+// over every node before: 1.2 ms per launch of 21 chunks; k_bucket_scan has run on k_pyramid's counts).
 __global__ void __launch_bounds__(kNodeBlock)
 k_chain(EncBuffers b, const uint32_t* depthBlocks)
 {
   const uint32_t c = blockIdx.y;
-  if (!b.st[c].active)
+  EncState& s = b.st[c];
+  if (!s.active)
     return;
+  __shared__ uint32_t h[kMaxPlanes], base[kMaxPlanes];
+  if (threadIdx.x < kMaxPlanes)
+    h[threadIdx.x] = 0;
+  __syncthreads();
   const Tree& t = b.tree;
   const uint32_t id = depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x;
-  Node nd;
-  if (!node_from_flat(t, id, nd))
-    return;
-  const Grid& g = t.grids[nd.grid];
-  if (g.depth + 1 == t.roots[g.root].Dmax && g.depth != 0)
-    return;
   const int8_t* M = b.M + c * b.nodeStride;
-  uint64_t* chain = b.chain + c * b.nodeStride;
-  const int m = M[id];
-  if (m < 0)
-    return;
-  uint64_t v = id;
-  if (g.depth != 0) {
-    const uint32_t pid = flat_id(t, node_parent(t, nd));
-    if (M[pid] == m) {
-      const uint64_t pc = chain[pid];
-      v = (pc & 0xffffffffull) | ((uint64_t)((uint32_t)(pc >> 32) + b.koff[c * b.nodeStride + id]) << 32);
+  Node nd;
+  const bool valid = node_from_flat(t, id, nd);
+  const int m = valid ? (int)M[id] : -1;
+  bool mine = false;   // a set that splits at plane m (splitting_set)
+  if (m >= 0) {
+    const Grid& g = t.grids[nd.grid];
+    mine = (g.kind & kGridOct) != 0;
+    if (!mine) {
+      const NodeGeom q = node_geom(t, nd);
+      mine = q.count > 1 || (g.depth == 0 && q.count == 1);
+    }
+    if (!(g.depth + 1 == t.roots[g.root].Dmax && g.depth != 0)) {
+      uint64_t* chain = b.chain + c * b.nodeStride;
+      uint64_t v = id;
+      if (g.depth != 0) {
+        const uint32_t pid = flat_id(t, node_parent(t, nd));
+        if (M[pid] == m) {
+          const uint64_t pc = chain[pid];
+          v = (pc & 0xffffffffull) | ((uint64_t)((uint32_t)(pc >> 32) + b.koff[c * b.nodeStride + id]) << 32);
+        }
+      }
+      chain[id] = v;
     }
   }
-  chain[id] = v;
+  uint32_t rank = 0;
+  if (mine)
+    rank = atomicAdd(&h[m], 1u);
+  __syncthreads();
+  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
+    base[threadIdx.x] = atomicAdd(&s.bucketCur[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (mine)
+    b.bucket[c * b.nodeStride + base[m] + rank] = id;
 }
 
 __global__ void k_enc_planes_setup(EncBuffers b)
@@ -696,19 +717,9 @@ __global__ void k_enc_iphase(EncBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 // k_split_emit: every set whose msb equals the plane splits now
 // ------------------------------------------------------------------------------------------
-// Nodes are bucketed by the plane at which they split (k_bucket_*), so a plane only visits its
-// own splitting sets instead of scanning every node.
-__device__ __forceinline__ bool splitting_set(const Tree& t, uint32_t id, int m)
-{
-  if (m < 0)
-    return false;
-  Node nd;
-  if (!node_from_flat(t, id, nd))
-    return false;
-  const NodeGeom q = node_geom(t, nd);
-  return q.count > 1 || (t.grids[nd.grid].depth == 0 && q.count == 1);
-}
-
+// Nodes are bucketed by the plane at which they split, so a plane only visits its own splitting sets
+// instead of scanning every node: k_pyramid counts them per plane, k_bucket_scan turns the counts into
+// offsets, k_chain deals the nodes out.
 __global__ void k_bucket_scan(EncBuffers b)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -723,30 +734,6 @@ __global__ void k_bucket_scan(EncBuffers b)
     s.bucketCur[p] = off;
     off += s.bucketCnt[p];
   }
-}
-
-__global__ void __launch_bounds__(kNodeBlock) k_bucket_fill(EncBuffers b)
-{
-  const uint32_t c = blockIdx.y;
-  EncState& s = b.st[c];
-  if (!s.active)
-    return;
-  __shared__ uint32_t h[kMaxPlanes], base[kMaxPlanes];
-  if (threadIdx.x < kMaxPlanes)
-    h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t id = blockIdx.x * kNodeBlock + threadIdx.x;
-  const int m = b.M[c * b.nodeStride + id];
-  const bool mine = splitting_set(b.tree, id, m);
-  uint32_t rank = 0;
-  if (mine)
-    rank = atomicAdd(&h[m], 1u);
-  __syncthreads();
-  if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
-    base[threadIdx.x] = atomicAdd(&s.bucketCur[threadIdx.x], h[threadIdx.x]);
-  __syncthreads();
-  if (mine)
-    b.bucket[c * b.nodeStride + base[m] + rank] = id;
 }
 
 constexpr int kSplitBlocks = 512;
@@ -1303,6 +1290,7 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
       LAUNCH_K(k_pyramid, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
                          plan.d_depthBlocks + plan.depthBlockOff[d]);
   }
+  LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);   // (k_pyramid has counted the splitting sets per plane)
   for (int d = 0; d < (int)b.tree.maxDepth; d++) {
     const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
     if (nb)
@@ -1310,11 +1298,6 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
                plan.d_depthBlocks + plan.depthBlockOff[d]);
   }
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
-  {
-    const uint32_t nodeBlocksAll = b.tree.nnodes / kNodeBlock;
-    LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);
-    LAUNCH_K(k_bucket_fill, dim3(nodeBlocksAll, nc), dim3(kNodeBlock), 0, stream, b);
-  }
   LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b);
   const int maxPlanes = wide_pass ? kMaxPlanes : 32;
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
