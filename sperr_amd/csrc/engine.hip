@@ -1696,6 +1696,14 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
 
       // ---- integer coder, 32-bit coefficients ----
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
+      // (the census of the pixel passes on a stream of its own beside the pyramid's upper levels: the
+      //  decoder's outlier streams and events are idle during a compression call)
+      static const bool sideEnv = !(getenv("SPERR_HIP_ENC_SIDE") && atoi(getenv("SPERR_HIP_ENC_SIDE")) == 0);
+      if (sideEnv) {
+        ph.side = E.outlQ[gi % kSubStreams];
+        ph.evFork = E.evOutlFork[gi % kSubStreams];
+        ph.evJoin = E.evOutl[gi % kSubStreams];
+      }
       Speck2dBufs sb;
       const bool quadWalk = slice && !(P->ht.flags & spk::kTree2D);   // (SPERR_HIP_SLICE_MIXED=0)
       if (quadWalk) {

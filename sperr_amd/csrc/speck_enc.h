@@ -83,6 +83,10 @@ struct EncPlanHost {
   const uint32_t* d_depthBlocks;
   std::vector<uint32_t> depthBlockOff;   // [maxDepth + 1]
   uint32_t nsets;
+  // optional: a second stream (and two events) of the caller's: the census of the pixel passes, which
+  // only needs the pyramid, runs there beside the chain pass -- eight small dependent launches (round 3)
+  hipStream_t side = nullptr;
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,

@@ -338,11 +338,13 @@ __device__ __forceinline__ void load_pix(const int8_t* a, uint32_t i0, uint32_t 
 // Bits each plane's LIP scan and refinement pass take inside one tile.  A sample with msb m that
 // enters the LIP at plane b (b >= m) costs one LIP bit on planes m <= p < b plus a sign bit on
 // plane m, and one refinement bit on every plane p < m: all of it follows from three histograms.
-__global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
+// (rows of all `maxPlanes` planes are written, zeros above the chunk's own plane count: the kernel may
+//  run before k_enc_planes_setup has found that count -- on a second stream, launch_speck_encode)
+__global__ void __launch_bounds__(kThreads) k_census(EncBuffers b, int maxPlanes)
 {
   const uint32_t c = blockIdx.y;
   const EncState& s = b.st[c];
-  if (!s.active || s.done)
+  if (!s.active)
     return;
   // bin q + 1 counts value q (-1 .. kMaxPlanes - 1); one set of histograms per wavefront
   // [0]: msb, low half = all samples, high half = those that sit in the LIP before they become
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b)
   }
   __syncthreads();
   const int p = threadIdx.x;
-  if (p < s.nbp) {
+  if (p < maxPlanes) {
     const uint32_t le_m = (uint32_t)pre[p + 1], le_b = (uint32_t)(pre[p + 1] >> 32);
     const uint32_t all_m = (uint32_t)pre[kMaxPlanes], eq = tot[0][p + 1] >> 16;
     uint32_t* cnt = b.pixCnt + c * b.pixCntStride;
@@ -1284,11 +1286,21 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
   const dim3 perChunk((nc + 63) / 64);
   LAUNCH_K(k_enc_state_init, perChunk, dim3(64), 0, stream, b, plan.d_initLIS,
                      plan.d_initLen, budget, wide_pass ? 1 : 0);
+  const int maxPlanes = wide_pass ? kMaxPlanes : 32;
+  const bool sideCensus = plan.side && plan.evFork && plan.evJoin && b.tree.maxDepth >= 2;
   for (int d = (int)b.tree.maxDepth - 1; d >= 0; d--) {
     const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
     if (nb)
       LAUNCH_K(k_pyramid, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
                          plan.d_depthBlocks + plan.depthBlockOff[d]);
+    if (sideCensus && d == 0) {
+      // every sample's birth plane is known now (samples are born at any depth: the roots' trees differ in
+      // height, and an odd set has a single sample for a child): the census needs nothing else
+      // (k_enc_planes_setup's plane count only bounds its output rows: see k_census)
+      HIP_CHECK(hipEventRecord(plan.evFork, stream));
+      HIP_CHECK(hipStreamWaitEvent(plan.side, plan.evFork, 0));
+      LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, plan.side, b, maxPlanes);
+    }
   }
   LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);   // (k_pyramid has counted the splitting sets per plane)
   for (int d = 0; d < (int)b.tree.maxDepth; d++) {
@@ -1298,8 +1310,12 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
                plan.d_depthBlocks + plan.depthBlockOff[d]);
   }
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
-  LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b);
-  const int maxPlanes = wide_pass ? kMaxPlanes : 32;
+  if (sideCensus) {
+    HIP_CHECK(hipEventRecord(plan.evJoin, plan.side));
+    HIP_CHECK(hipStreamWaitEvent(stream, plan.evJoin, 0));
+  }
+  else
+    LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, maxPlanes);
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
   const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
