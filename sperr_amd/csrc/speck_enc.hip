@@ -122,6 +122,29 @@ __device__ __forceinline__ void oct_load(const Tree& t, const Grid& g, const Roo
 // ------------------------------------------------------------------------------------------
 // k_pyramid: one thread per node of the grids at one depth (deepest first)
 // ------------------------------------------------------------------------------------------
+// h[bin] += 1 for every lane with bin >= 0; returns the lane's rank inside its bin.  The lanes of a
+// wavefront that share a bin send ONE LDS atomic (neighbouring nodes split at a handful of planes: 64
+// lanes on one LDS word are 64 serialised atomics).
+__device__ __forceinline__ uint32_t wave_hist_add(uint32_t* h, int bin)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t rank = 0;
+  uint64_t todo = __ballot(bin >= 0);
+  while (todo) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int bb = __shfl(bin, lead, 64);
+    const uint64_t same = __ballot(bin == bb) & todo;
+    uint32_t base0 = 0;
+    if ((int)lane == lead)
+      base0 = atomicAdd(&h[bb], (uint32_t)__popcll(same));
+    base0 = (uint32_t)__shfl((int)base0, lead, 64);
+    if (bin == bb)
+      rank = base0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return rank;
+}
+
 // (returns the plane at which the node splits when it is a set with a significant sample, else -1)
 __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uint32_t id)
 {
@@ -234,8 +257,7 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
     h[threadIdx.x] = 0;
   __syncthreads();
   const int sp = pyramid_node(b, c, depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x);
-  if (sp >= 0)
-    atomicAdd(&h[sp], 1u);
+  wave_hist_add(h, sp);
   __syncthreads();
   if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
     atomicAdd(&s.bucketCnt[threadIdx.x], h[threadIdx.x]);
@@ -285,9 +307,7 @@ k_chain(EncBuffers b, const uint32_t* depthBlocks)
       chain[id] = v;
     }
   }
-  uint32_t rank = 0;
-  if (mine)
-    rank = atomicAdd(&h[m], 1u);
+  const uint32_t rank = wave_hist_add(h, mine ? m : -1);
   __syncthreads();
   if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
     base[threadIdx.x] = atomicAdd(&s.bucketCur[threadIdx.x], h[threadIdx.x]);
