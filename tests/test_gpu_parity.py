@@ -307,6 +307,20 @@ def test_retry_of_a_batch_whose_coder_arrays_lay_over_the_chunk_buffer(eng, orac
     assert eng.lib.sperrhip_debug_counter(0) > redo1
 
 
+@pytest.mark.parametrize("shape,chunks,mode,q", [((32, 64, 64), (16, 16, 16), 1, 3.0), ((48, 32, 48), (16, 16, 24), 3, 1e-3),
+                                                 ((16, 48, 64), (16, 16, 16), 2, 70.0), ((20, 33, 47), (10, 11, 12), 1, 6.0)])
+def test_small_batches_decode_in_several_sub_batches(eng, oracle, shape, chunks, mode, q):
+    """Round 3: a decompression call that has the device to itself cuts a batch of 4 to 55 equally shaped
+    chunks into two or four sub-batches that decode side by side (decompress_impl: streams, events and
+    workspace per sub-batch, outlier streams included); 32, 12, 12 and 24 chunks here, all three modes."""
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks[::-1], mode, q)
+    assert bytes(eng.compress(cuda(v), chunks[::-1], q, mode=mode).cpu().numpy()) == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    for as_float in (True, False):
+        assert np.array_equal(bits(eng.decompress(dev, as_float).cpu().numpy()), bits(oracle.decomp_3d(want, as_float)))
+
+
 def test_compact_chunk_buffer_of_the_decoder(eng, oracle):
     """Round 3: when the finest level is the fused x-y-z kernel and every inverse pass dequantises on load,
     the decoder's fp64 chunk buffer holds the second level's box only (carve_dec, compact_box): dyadic
