@@ -264,6 +264,19 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- device workspace of the call: the engine's arena holds every chunk of the batch in flight
+    workspace = None
+    try:
+        import ctypes as C_
+        eng.lib.sperrhip_debug_counter.restype = C_.c_ulonglong
+        eng.lib.sperrhip_debug_counter.argtypes = [C_.c_int]
+        arena = int(eng.lib.sperrhip_debug_counter(3))
+        workspace = {"arena_GB": round(arena / 1e9, 2), "MB_per_chunk_in_flight": round(arena / nchunks / 1e6, 1),
+                     "what": "largest workspace arena of an engine after the timed steps (all chunks of the volume "
+                             "in flight: the larger of the compression and the decompression layout)"}
+    except Exception as ex:   # noqa: BLE001
+        workspace = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- a small batch (rank 0): 8 chunks = 512^3, what one GPU gets when config 3's 64 chunks are
     #      dealt to 8 GPUs (strong scaling); device-resident like `value`
     small = None
@@ -506,6 +519,7 @@ def main():
         "strong_compress_GBps": (host_path or {}).get("compress_GBps"),
         "strong_decompress_GBps": (host_path or {}).get("decompress_GBps"),
         "small_batch": small,
+        "workspace": workspace,
         "ragged_volume": ragged,
         "other_modes": other,
     }

@@ -210,7 +210,8 @@ void sperrhip_debug_lis_stamps(int on, unsigned long long* out64);
 /* Diagnostics: how often this process took one of the workspace-saving paths (for the tests that
  * have to know they ran): 0 = 64-bit retries of a batch whose coder arrays lay over the chunk buffer
  * (the batch is transformed again), 1 = compression batches with the coder arrays over the chunk
- * buffer, 2 = decompression batches with a compact chunk buffer.  Other values: 0. */
+ * buffer, 2 = decompression batches with a compact chunk buffer, 3 = bytes of the largest workspace
+ * arena an engine of this process holds right now.  Other values: 0. */
 unsigned long long sperrhip_debug_counter(int which);
 
 /* Gives back what the library keeps between calls (it keeps workspaces, shape tables, pinned staging

@@ -2907,6 +2907,13 @@ void sperrhip_profile_only(const char* kernel)
 }
 unsigned long long sperrhip_debug_counter(int which)
 {
+  if (which == 3) {   // bytes of the largest workspace arena an engine of this process holds
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    size_t most = 0;
+    for (auto& e : g_pool.all)
+      most = std::max(most, e->arena.n);
+    return (unsigned long long)most;
+  }
   return which >= 0 && which < 3 ? g_dbg_counter[which].load() : 0ull;
 }
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)
