@@ -476,12 +476,8 @@ __global__ void __launch_bounds__(kThreads) k_census_scan(EncBuffers b)
 // ------------------------------------------------------------------------------------------
 // plane bookkeeping
 // ------------------------------------------------------------------------------------------
-__global__ void k_plane_begin(EncBuffers b, int p)
+__device__ __forceinline__ void plane_begin(const EncBuffers& b, EncState& s, int p)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= b.nchunks)
-    return;
-  EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
   s.rec[p].baseLIP = s.pos;
   s.pos += s.lipTot[p];
@@ -494,12 +490,8 @@ __global__ void k_plane_begin(EncBuffers b, int p)
     s.bornTot[l] = 0;
 }
 
-__global__ void k_plane_end(EncBuffers b, int p)
+__device__ __forceinline__ void plane_end(const EncBuffers& b, EncState& s, int p)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= b.nchunks)
-    return;
-  EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
   const uint32_t nx = s.cur ^ 1u;
   for (uint32_t l = 0; l < b.tree.nlevels; l++)
@@ -518,6 +510,20 @@ __global__ void k_plane_end(EncBuffers b, int p)
     s.done = 1;
     s.total_bits = s.pos;
   }
+}
+
+// the bookkeeping between two planes in one launch: plane pEnd ends (pEnd < 0: none), plane pBegin
+// begins (pBegin < 0: none) -- 31 launches fewer on every batch's serial chain
+__global__ void k_plane_turn(EncBuffers b, int pEnd, int pBegin)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.nchunks)
+    return;
+  EncState& s = b.st[c];
+  if (pEnd >= 0)
+    plane_end(b, s, pEnd);
+  if (pBegin >= 0)
+    plane_begin(b, s, pBegin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1339,8 +1345,8 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
   const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
+  LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, maxPlanes - 1);
   for (int p = maxPlanes - 1; p >= 0; p--) {
-    LAUNCH_K(k_plane_begin, perChunk, dim3(64), 0, stream, b, p);
     LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
@@ -1352,7 +1358,7 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
       LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
       LAUNCH_K(k_mask_clear, dim3(capped_blocks(maskBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
     }
-    LAUNCH_K(k_plane_end, perChunk, dim3(64), 0, stream, b, p);
+    LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, p, p - 1);
   }
   if (wide_pass)
     LAUNCH_K(k_emit_pixels<uint64_t>, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream,
