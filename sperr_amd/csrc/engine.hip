@@ -760,9 +760,8 @@ k_write_slot(const CoderState* cst, const EncState* est, const uint64_t* stream,
   (void)est;
   const uint64_t payload = len - 26;
   const uint64_t* w = stream + c * streamStride;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < payload;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    out[26 + i] = (uint8_t)(w[i >> 3] >> (8 * (i & 7)));
+  copy_bytes_wide(out + 26, reinterpret_cast<const uint8_t*>(w), payload,
+                  (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // container header (SPERR3D_OMP_C.cpp:163-234) + chunk offsets
@@ -808,9 +807,7 @@ k_copy_slots(uint8_t* dst, uint64_t dst_cap, const uint8_t* slots, const uint64_
       continue;
     const uint8_t* in = slots + slotOff[g];
     uint8_t* out = dst + offs[g];
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
-         i += (uint64_t)gridDim.x * blockDim.x)
-      out[i] = in[i];
+    copy_bytes_wide(out, in, len, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
   }
 }
 
