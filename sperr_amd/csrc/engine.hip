@@ -498,10 +498,41 @@ struct Engine {
   std::vector<std::unique_ptr<DevBuf>> pweBufs;   // outlier streams of the batches of one call
   size_t freeMemAtInit = 0;
 
+  // an engine whose initialisation fails is never handed out (EnginePool::acquire): what it made
+  // up to the failure goes back at once
   int init()
   {
     if (ready)
       return 0;
+    const int rc = init_handles();
+    if (rc)
+      destroy_handles();
+    return rc;
+  }
+  void destroy_handles()
+  {
+    auto ds = [](hipStream_t& s) { if (s) (void)hipStreamDestroy(s); s = nullptr; };
+    auto de = [](hipEvent_t& e) { if (e) (void)hipEventDestroy(e); e = nullptr; };
+    for (uint32_t q = 0; q < kSubStreams; q++) {
+      ds(sub[q]);
+      de(evJoin[q]);
+      if (q > 0)
+        ds(outlQ[q]);
+      de(evOutl[q]);
+      de(evOutlFork[q]);
+      if (liveHost[q])
+        (void)hipHostFree(liveHost[q]);
+      liveHost[q] = nullptr;
+      for (int k = 0; k < kLiveSlots; k++)
+        de(liveEv[q][k]);
+    }
+    de(evFork);
+    ds(outl);
+    outlQ[0] = nullptr;
+    ready = false;
+  }
+  int init_handles()
+  {
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     freeMemAtInit = fr;
@@ -978,14 +1009,21 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   return true;
 }
 
-size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget)
+// bytes carve_enc takes for a batch of B chunks.  Probed with the batch's own B: which coder arrays
+// find room over the chunk buffer (carve_enc_coder, first fit) depends on the 256-byte rounding of
+// B arrays, so B times the one-chunk figure can fall short for small chunks.
+size_t enc_bytes_for(const ShapePlan& P, uint32_t B, uint64_t raw_budget)
 {
   Arena probe;
   probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // never dereferenced: size probe only
   probe.cap = ~size_t(0) / 2;
   EncBatchBufs tmp;
-  carve_enc(probe, P, 1, raw_budget, tmp);
+  carve_enc(probe, P, std::max<uint32_t>(B, 1), raw_budget, tmp);
   return probe.used;
+}
+size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget)
+{
+  return enc_bytes_for(P, 1, raw_budget);
 }
 
 int reset_enc_pass(hipStream_t st, const EncBatchBufs& bb, uint32_t B)
@@ -1613,7 +1651,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     for (auto& g : groups) {
       ShapePlan* P = E.plan(g.first[0], g.first[1], planZ(g.first));
       groupOff.push_back(need);
-      need += round_up(g.second.size() * enc_bytes_per_chunk(*P, (uint64_t)(bpp * (double)P->N)) + 4096, 4096);
+      need += round_up(enc_bytes_for(*P, (uint32_t)g.second.size(), (uint64_t)(bpp * (double)P->N)) + 4096, 4096);
       sideBySide = sideBySide && g.second.size() <= 256;
     }
     sideBySide = sideBySide && need <= budgetBytes;
@@ -1641,7 +1679,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     B = std::min<uint32_t>(B, 256);
     if (sideBySide)
       B = (uint32_t)g.second.size();
-    else if (E.arena.ensure((size_t)B * per + 4096))
+    else if (E.arena.ensure(std::max((size_t)B * per, enc_bytes_for(*P, B, raw_budget)) + 4096))
       return -1;
     const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
     for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
@@ -1812,9 +1850,11 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     EncBuffers& e = bb.eb;
     ShapePlan* P = L->P;
     EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
-    if (bb.aliased) {   // (see the retry above; the scratch memory is the engine's: one group at a time)
+    // (wide_retry_prepare clears bb.aliased: remember it, the guard after the launches needs it)
+    const bool wasAliased = bb.aliased;
+    if (wasAliased) {   // (see the retry above; the scratch memory is the engine's: one group at a time --
+                        // the previous retrying group synchronised its stream below before this one starts)
       const uint32_t cdl[3] = {P->dims[0], P->dims[1], P->dims[2]};
-      HIP_CHECK(hipDeviceSynchronize());
       if (wide_retry_prepare<T>(L->ss, E, *P, bb, L->nb, cdl, d_src, vd, L->orgAligned, false))
         return -1;
     }
@@ -1831,7 +1871,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     LAUNCH_K(k_write_slot, dim3(std::max(1u, L->wblocks), L->nb), dim3(kThreads), 0, L->ss, e.cst, e.st,
              e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff, d_lens,
              P->N, 1);
-    if (bb.aliased)
+    if (wasAliased)   // the next retrying group takes the engine's scratch memory over
       HIP_CHECK(hipStreamSynchronize(L->ss));
   }
   if (sideBySide)
@@ -2865,18 +2905,26 @@ void sperrhip_release(void)
   (void)guarded("sperrhip_release", [&]() -> int {
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
+    // The idle engines are picked (and marked busy, so nobody leases them) under the pool's lock;
+    // their memory goes with the lock released.  `all` may grow meanwhile (acquire() on another
+    // thread): only the raw pointers collected here are used, the engines themselves never move.
+    std::vector<Engine*> idle;
     {
-      std::unique_lock<std::mutex> lock(g_pool.mu);
-      for (auto& e : g_pool.all) {
-        if (e->busy || e->dev < 0)
-          continue;
-        e->busy = true;            // nobody leases it while its memory goes
-        lock.unlock();
-        if (hipSetDevice(e->dev) == hipSuccess)
-          e->drop_memory();
-        lock.lock();
+      std::lock_guard<std::mutex> lock(g_pool.mu);
+      idle.reserve(g_pool.all.size());
+      for (auto& e : g_pool.all)
+        if (!e->busy && e->dev >= 0) {
+          e->busy = true;
+          idle.push_back(e.get());
+        }
+    }
+    for (Engine* e : idle)
+      if (hipSetDevice(e->dev) == hipSuccess)
+        e->drop_memory();
+    {
+      std::lock_guard<std::mutex> lock(g_pool.mu);
+      for (Engine* e : idle)
         e->busy = false;
-      }
     }
     g_pool.cv.notify_all();
     farm_release_idle();

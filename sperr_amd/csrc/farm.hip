@@ -655,6 +655,9 @@ int run_workers(Job& J, F&& doItem)
   }
   if (th.empty())
     J.failed = -1;
+  else if (th.size() < nw)   // (the queue still hands every item out, but maybe not to every device)
+    fprintf(stderr, "[sperr_hip] chunk farm: only %zu of %zu worker threads started; devices without a worker idle\n",
+            th.size(), nw);
   for (auto& t : th)
     t.join();
   return J.failed.load();
@@ -751,8 +754,12 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     for (size_t i = 0; i < nchunks; i++)
       at[i + 1] = at[i] + J.chunkLen[i];
   }
+  // (parallel_do below may throw -- bad_alloc, a thread that does not start: `out`, gigabytes at
+  // times, is owned until it is handed to the caller)
+  struct FreeDel { void operator()(uint8_t* p) const { free(p); } };
+  std::unique_ptr<uint8_t, FreeDel> outOwner(J.outBuf);
   uint8_t* out = J.outBuf;
-  J.outBuf = nullptr;   // nothing below throws
+  J.outBuf = nullptr;
   if (inPlace) {
     size_t to = hdr;
     for (size_t i = 0; i < nchunks; i++) {   // (moves nothing when every stream fills its slot)
@@ -762,12 +769,16 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     }
     if (total < J.slotOff[nchunks]) {
       uint8_t* shrunk = static_cast<uint8_t*>(realloc(out, total));
-      if (shrunk)
+      if (shrunk) {
+        (void)outOwner.release();
+        outOwner.reset(shrunk);
         out = shrunk;
+      }
     }
   }
   else {
-    out = static_cast<uint8_t*>(malloc(total));
+    outOwner.reset(static_cast<uint8_t*>(malloc(total)));   // (frees the slot buffer, if there was one)
+    out = outOwner.get();
     if (!out)
       return -1;
     const size_t nt = std::max<size_t>(1, std::min<size_t>(J.fs.helpers * J.workerDev.size(), nchunks));
@@ -790,7 +801,7 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     const uint32_t l = (uint32_t)J.chunkLen[i];
     memcpy(out + pos + 4 * i, &l, 4);
   }
-  *dst = out;
+  *dst = outOwner.release();
   *dst_len = total;
   return 0;
 }

@@ -295,16 +295,20 @@ def test_retry_of_a_batch_whose_coder_arrays_lay_over_the_chunk_buffer(eng, orac
     assert eng.lib.sperrhip_debug_counter(0) > redo0, "the retry did not transform the batch again"
     dev = cuda(np.frombuffer(want, dtype=np.uint8))
     assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
-    # two shape groups (64^3 and 64 x 64 x 70) side by side, some chunks retry, PSNR and PWE mode as well
+    # two shape groups (64^3 and 64 x 64 x 70) side by side, some chunks retry; rate, PSNR and PWE mode
     v = turbulence((64, 64, 134))
     v[:, :, :64] = ramp_field((64, 64, 64))
-    redo1 = eng.lib.sperrhip_debug_counter(0)
-    for mode, q in ((1, 40.0), (3, 1e-9)):
+    # (mode 2 at 200 dB: both chunks need 35 planes, so the retry runs with wantRange -- the conditioner's
+    # range atomics again -- while q from psnr_q_search has to survive the rewritten coder state)
+    for mode, q in ((1, 40.0), (2, 200.0), (3, 1e-9)):
+        redo1 = eng.lib.sperrhip_debug_counter(0)
         want = oracle.comp_3d(v, (64, 64, 64), mode, q)
+        if mode == 2:
+            assert want[28 + 17] > 32, "the PSNR case no longer needs the 64-bit pass"
         assert bytes(eng.compress(cuda(v), (64, 64, 64), q, mode=mode).cpu().numpy()) == want, mode
+        assert eng.lib.sperrhip_debug_counter(0) > redo1, mode
         dev = cuda(np.frombuffer(want, dtype=np.uint8))
         assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
-    assert eng.lib.sperrhip_debug_counter(0) > redo1
 
 
 @pytest.mark.parametrize("shape,chunks,mode,q", [((32, 64, 64), (16, 16, 16), 1, 3.0), ((48, 32, 48), (16, 16, 24), 3, 1e-3),
