@@ -85,6 +85,20 @@ int sperrhip_farm_selftest(size_t dimx, size_t dimy, size_t dimz, size_t chunk_x
                            size_t chunk_z, size_t bytes_per_value, size_t ndevices,
                            size_t workers_per_device, int lockstep, uint32_t* per_worker_chunks,
                            uint32_t* item_of_chunk, uint32_t* worker_of_chunk, size_t* nitems);
+/* NUMA placement of the farm.  A worker thread binds itself (its helper threads inherit the mask,
+ * the staging memory it pins is first touched by it) to the CPUs of the NUMA node its device hangs
+ * off: hipDeviceGetPCIBusId -> <sysfs>/bus/pci/devices/<bdf>/numa_node ->
+ * <sysfs>/devices/system/node/node<N>/cpulist.  The reference leaves placement to the OpenMP runtime
+ * of its chunk loop (/root/reference/src/SPERR3D_OMP_C.cpp:94-130, SPERR3D_OMP_D.cpp:101-127).
+ * SPERR_HIP_FARM_NUMA=0 switches it off, SPERR_HIP_SYSFS_ROOT names another tree.  The first two
+ * are host only (no device is touched; sysfs_root NULL = the default tree): what the tree says
+ * about a PCI device, and the binding applied to the CALLING thread (returns the number of CPUs it
+ * is bound to; 0 = left as it was).  The third reports a device's PCI address, node (-1 unknown)
+ * and CPU count as the farm sees them. */
+int sperrhip_numa_probe(const char* sysfs_root, const char* pci_bdf, int* node, int* cpus,
+                        size_t cpus_cap, size_t* ncpus);
+int sperrhip_numa_bind_self(const char* sysfs_root, const char* pci_bdf);
+int sperrhip_farm_device_place(int dev, char* bdf, size_t bdf_cap, int* node, size_t* ncpus);
 
 /* ---- device-resident API ---------------------------------------------------------------------- */
 

@@ -30,6 +30,7 @@ EXPORTS = [
     "sperrhip_multires_levels_2d", "sperrhip_decompress_2d_multires_dev", "sperrhip_decomp_2d_multires",
     "sperrhip_comp_3d_farm", "sperrhip_decomp_3d_farm", "sperrhip_decomp_3d_into",
     "sperrhip_farm_selftest", "sperrhip_release", "sperrhip_debug_counter",
+    "sperrhip_numa_probe", "sperrhip_numa_bind_self", "sperrhip_farm_device_place",
 ]
 
 

@@ -44,6 +44,7 @@
 #include "../../include/sperr_hip.h"
 #include "common.h"
 #include "engine_internal.h"
+#include "numa_place.hpp"
 
 namespace sperrhip {
 namespace {
@@ -608,6 +609,24 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
   return 0;
 }
 
+// NUMA node and CPUs of a device (numa_place.hpp), looked up once per device
+const numa::Place& device_place(int dev)
+{
+  static std::mutex mu;
+  static std::map<int, numa::Place> all;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = all.find(dev);
+  if (it != all.end())
+    return it->second;
+  numa::Place pl;
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) == hipSuccess)
+    pl = numa::probe(numa::sysfs_root(), bdf);
+  else
+    (void)hipGetLastError();
+  return all.emplace(dev, std::move(pl)).first->second;
+}
+
 template <typename F>
 int run_workers(Job& J, F&& doItem)
 {
@@ -619,6 +638,10 @@ int run_workers(Job& J, F&& doItem)
       J.failed = -1;
       return;
     }
+    // this thread, the helper threads it starts (they inherit the mask) and the staging memory it
+    // pins from now on stay on the socket of its device (SPERR_HIP_FARM_NUMA=0: wherever the OS puts them)
+    if (numa::enabled())
+      (void)numa::bind_self(device_place(dev));
     WorkerCtx* C = ctx_acquire(dev);
     if (!C) {
       J.failed = -1;
@@ -991,6 +1014,68 @@ int sperr_decomp_3d(const void* src, size_t src_len, int output_float, size_t nt
 {
   return sperrhip_decomp_3d_farm(src, src_len, output_float, nthreads, nullptr, 0, dimx, dimy, dimz,
                                  dst);
+}
+
+// ---- NUMA placement of the farm (numa_place.hpp) -------------------------------------------
+// host only: NUMA node and CPUs of the PCI device `pci_bdf` as the sysfs tree under `sysfs_root`
+// (NULL: SPERR_HIP_SYSFS_ROOT or /sys) describes them
+int sperrhip_numa_probe(const char* sysfs_root, const char* pci_bdf, int* node, int* cpus, size_t cpus_cap,
+                        size_t* ncpus)
+{
+  return guarded_farm("sperrhip_numa_probe", [&]() -> int {
+    if (!pci_bdf)
+      return -1;
+    const numa::Place pl = numa::probe(sysfs_root && *sysfs_root ? std::string(sysfs_root) : numa::sysfs_root(), pci_bdf);
+    if (node)
+      *node = pl.node;
+    if (ncpus)
+      *ncpus = pl.cpus.size();
+    if (cpus)
+      for (size_t i = 0; i < std::min(cpus_cap, pl.cpus.size()); i++)
+        cpus[i] = pl.cpus[i];
+    return 0;
+  });
+}
+// host only: what a farm worker of that device does to itself -- the CALLING thread is bound to the
+// device's NUMA node; returns the number of CPUs it is bound to (0: left as it was, also with
+// SPERR_HIP_FARM_NUMA=0), -1 on error
+int sperrhip_numa_bind_self(const char* sysfs_root, const char* pci_bdf)
+{
+  return guarded_farm("sperrhip_numa_bind_self", [&]() -> int {
+    if (!pci_bdf)
+      return -1;
+    if (!numa::enabled())
+      return 0;
+    const numa::Place pl = numa::probe(sysfs_root && *sysfs_root ? std::string(sysfs_root) : numa::sysfs_root(), pci_bdf);
+    return (int)numa::bind_self(pl);
+  });
+}
+// where the farm puts the workers of device `dev`: its PCI address (bdf_cap bytes of room), NUMA
+// node (-1: unknown) and the number of CPUs of that node
+int sperrhip_farm_device_place(int dev, char* bdf, size_t bdf_cap, int* node, size_t* ncpus)
+{
+  return guarded_farm("sperrhip_farm_device_place", [&]() -> int {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || dev < 0 || dev >= ndev) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    char buf[64] = {0};
+    if (hipDeviceGetPCIBusId(buf, (int)sizeof(buf), dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    if (bdf && bdf_cap) {
+      strncpy(bdf, buf, bdf_cap - 1);
+      bdf[bdf_cap - 1] = 0;
+    }
+    const numa::Place& pl = device_place(dev);
+    if (node)
+      *node = pl.node;
+    if (ncpus)
+      *ncpus = pl.cpus.size();
+    return 0;
+  });
 }
 
 // The queue without any device: how the chunks of a volume are cut into items and which worker

@@ -265,3 +265,46 @@ def test_two_ranks_share_the_device_with_the_hip_compressor(oracle):
     want = oracle.comp_3d(vol, chunks, mode, quality)
     assert merged == want
     assert back == oracle.decomp_3d(want, True).tobytes()
+
+
+def test_distinct_devices_when_the_box_has_them(eng, oracle):
+    """The farm over TWO DIFFERENT devices (round 4): runs only where `torch.cuda.device_count() >= 2` -- the pool's
+    one-GPU boxes skip it, the first multi-GPU box exercises it.  No peer access, no collective: each
+    device's workers stream their items through their own staging buffers; the container and the decoded
+    volume must be the oracle's whichever device took which item.  All three modes, pageable and pinned."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: the farm's multi-device path needs two")
+    devices = list(range(min(torch.cuda.device_count(), 4)))
+    for shape, chunks, mode, quality in CASES[:4]:
+        vol = turbulence(shape)
+        want = oracle.comp_3d(vol, chunks, mode, quality)
+        for pinned in (False, True):
+            src = torch.from_numpy(vol).pin_memory() if pinned else vol
+            with _Env(SPERR_HIP_FARM_ITEM=1):     # one chunk per item: every device gets work
+                got = eng.comp_3d_farm(src, chunks, mode, quality, devices=devices)
+                assert got == want, (shape, mode, pinned)
+                back = eng.decomp_3d_farm(got, True, devices=devices)
+            assert np.array_equal(back.view(np.uint32), oracle.decomp_3d(want, True).view(np.uint32))
+    # every listed device has a place the farm could look up (node may be -1 in a VM)
+    import ctypes as C
+    for d in devices:
+        bdf = C.create_string_buffer(64)
+        node, n = C.c_int(-9), C.c_size_t(0)
+        assert eng.lib.sperrhip_farm_device_place(d, bdf, 64, C.byref(node), C.byref(n)) == 0
+        assert bdf.value and node.value >= -1
+
+
+def test_farm_reports_the_place_of_device_0(eng):
+    """sperrhip_farm_device_place on the real sysfs of the GPU box: a PCI address in the usual spelling and,
+    where the platform names a node, a non-empty CPU list (the workers of the tests above ran bound to it)."""
+    import ctypes as C
+    import re
+    bdf = C.create_string_buffer(64)
+    node, n = C.c_int(-9), C.c_size_t(0)
+    assert eng.lib.sperrhip_farm_device_place(0, bdf, 64, C.byref(node), C.byref(n)) == 0
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", bdf.value.decode())
+    assert node.value >= -1
+    if node.value >= 0:
+        assert n.value > 0
+    assert eng.lib.sperrhip_farm_device_place(10 ** 6, bdf, 64, C.byref(node), C.byref(n)) == -1
