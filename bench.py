@@ -440,6 +440,15 @@ def main():
         "kernel_ms_per_step": round(per_step_ms, 3),
         "kernel_busy_ms_per_step": round(busy_per_step_ms, 3),
         "top5_ms_per_step": {k: round(v[2], 3) for k, v in kern[:5]},
+        # the whole step against the same peak: compress reads 4 B and writes BPP/8 B per value, decompress
+        # the mirror (2 x 4.25 B per value per step) over the step's wall time
+        "step_algorithmic_bytes": 2 * ALGO_BYTES_PER_VALUE * values,
+        "step_achieved": round(2 * ALGO_BYTES_PER_VALUE * values / dt_max / 1e9, 3),
+        "step_frac": round(2 * ALGO_BYTES_PER_VALUE * values / dt_max / 1e9 / HBM_PEAK_GBS, 6),
+        "compress_frac": round(ALGO_BYTES_PER_VALUE * values / tc / 1e9 / HBM_PEAK_GBS, 6),
+        "decompress_frac": round(ALGO_BYTES_PER_VALUE * values / td / 1e9 / HBM_PEAK_GBS, 6),
+        # kernel launches of one step (the untimed step in which every kernel was bracketed)
+        "launches_per_step_all_kernels": int(sum(v[1] for v in prof_all.values())),
     }
 
     if args.profile_out:

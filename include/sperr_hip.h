@@ -225,7 +225,8 @@ void sperrhip_debug_lis_stamps(int on, unsigned long long* out64);
  * have to know they ran): 0 = 64-bit retries of a batch whose coder arrays lay over the chunk buffer
  * (the batch is transformed again), 1 = compression batches with the coder arrays over the chunk
  * buffer, 2 = decompression batches with a compact chunk buffer, 3 = bytes of the largest workspace
- * arena an engine of this process holds right now.  Other values: 0. */
+ * arena an engine of this process holds right now, 4 / 5 = bytes of pinned staging memory / of device
+ * buffers the chunk farm's workers hold right now (all devices).  Other values: 0. */
 unsigned long long sperrhip_debug_counter(int which);
 
 /* Gives back what the library keeps between calls (it keeps workspaces, shape tables, pinned staging

@@ -2959,6 +2959,8 @@ unsigned long long sperrhip_debug_counter(int which)
       most = std::max(most, e->arena.n);
     return (unsigned long long)most;
   }
+  if (which == 4 || which == 5)   // pinned staging / device bytes the farm's workers hold right now
+    return farm_footprint(which == 4);
   return which >= 0 && which < 3 ? g_dbg_counter[which].load() : 0ull;
 }
 void sperrhip_debug_lis_stamps(int on, unsigned long long* out64)

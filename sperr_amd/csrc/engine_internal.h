@@ -29,6 +29,8 @@ size_t host_chunk_stream_bound(size_t nvals, int mode, double quality);
 
 // farm.hip: the buffers of every idle farm worker go back (sperrhip_release)
 void farm_release_idle();
+// farm.hip: bytes the farm's workers hold right now -- pinned staging memory, or device buffers
+unsigned long long farm_footprint(bool pinned);
 
 // Set by a thread whose device calls run beside those of other threads on the same device (the farm's
 // workers): the engine then does not cut a small batch into sub-batches of its own.

@@ -353,6 +353,14 @@ void farm_release_idle()
     c->pinInCap = c->pinOutCap = c->dInCap = c->dOutCap = 0;
   }
 }
+unsigned long long farm_footprint(bool pinned)
+{
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  unsigned long long n = 0;
+  for (auto& c : g_ctx)
+    n += pinned ? c->pinInCap + c->pinOutCap : c->dInCap + c->dOutCap;
+  return n;
+}
 namespace {
 
 void ctx_release(WorkerCtx* c)

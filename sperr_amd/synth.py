@@ -55,8 +55,9 @@ def turbulence(shape_zyx, seed=42, dtype=np.float32, origin=(0, 0, 0), period=25
     return out.astype(dtype)
 
 
-def turbulence_torch(shape_zyx, device, seed=42, dtype=None, period=256.0, slab=32):
-    """torch generator for large volumes, evaluated on `device` slab by slab."""
+def turbulence_torch(shape_zyx, device, seed=42, dtype=None, period=256.0, slab=32, origin_z=0):
+    """torch generator for large volumes, evaluated on `device` slab by slab.  `origin_z`: the z
+    index of the first plane (a volume too large for the device is generated in pieces)."""
     import torch
 
     dtype = dtype or torch.float32
@@ -68,7 +69,7 @@ def turbulence_torch(shape_zyx, device, seed=42, dtype=None, period=256.0, slab=
     x = torch.arange(dx, dtype=torch.float64, device=device) * w
     for z0 in range(0, dz, slab):
         z1 = min(dz, z0 + slab)
-        z = torch.arange(z0, z1, dtype=torch.float64, device=device) * w
+        z = torch.arange(origin_z + z0, origin_z + z1, dtype=torch.float64, device=device) * w
         acc = torch.zeros((z1 - z0, dy, dx), dtype=torch.float64, device=device)
         for m in range(len(ph)):
             arg = (kv[m, 0] * x)[None, None, :] + (kv[m, 1] * y)[None, :, None] + \

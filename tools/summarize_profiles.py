@@ -76,6 +76,32 @@ with open(os.path.join(src, "bench.json")) as f:
     line = [l for l in f if l.startswith("{")][-1]
 with open(os.path.join(dst, f"{dst_tag}_bench_1024cube.json"), "w") as f:
     json.dump(json.loads(line), f, indent=1)
-top = sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step_corrected"])[:8]
+# per kernel: counter bytes over the SUM of its launch durations (the kernel trace of the same
+# workload) = the HBM rate it actually runs at; a bandwidth-shaped kernel far below the 8 TB/s peak
+# is latency- or LDS-bound, whatever its share of the traffic
+dur = {}
+with open(os.path.join(src, "trace", "run_kernel_stats.csv")) as f:
+    for r in csv.DictReader(f):
+        if "sperrhip" in r["Name"]:
+            dur[short(r["Name"])] = (float(r["TotalDurationNs"]) / steps, int(r["Calls"]) / steps)
+with open(os.path.join(dst, f"{dst_tag}_kernel_rates.csv"), "w") as f:
+    f.write("kernel,launches_per_step,sum_ms_per_step,hbm_GB_per_step,TBps,frac_of_8TBps\n")
+    for k, (ns, calls) in sorted(dur.items(), key=lambda kv: -kv[1][0]):
+        b = rows.get(k, {}).get("hbm_bytes_per_step_corrected")
+        tb = (b / ns * 1e9 / 1e12) if (b and ns > 0) else None
+        rows.setdefault(k, {})["sum_ms_per_step"] = round(ns / 1e6, 4)
+        if tb is not None:
+            rows[k]["TBps"] = round(tb, 3)
+        f.write(f'"{k}",{calls:g},{ns / 1e6:.4f},{(b or 0) / 1e9:.3f},{"" if tb is None else f"{tb:.3f}"},'
+                f'{"" if tb is None else f"{tb / 8.0:.4f}"}\n')
+with open(os.path.join(dst, f"{dst_tag}_pmc_traffic.json")) as f:
+    rec = json.load(f)
+rec["kernels"] = rows
+rec["total_hbm_GB_per_step"] = round(sum(v.get("hbm_bytes_per_step_corrected", 0) for v in rows.values()) / 1e9, 2)
+rec["launches_per_step"] = round(sum(c for _, c in dur.values()), 1)
+with open(os.path.join(dst, f"{dst_tag}_pmc_traffic.json"), "w") as f:
+    json.dump(rec, f, indent=1)
+print("total", rec["total_hbm_GB_per_step"], "GB/step,", rec["launches_per_step"], "launches/step")
+top = sorted(rows.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_step_corrected", 0))[:8]
 for k, v in top:
-    print(f"{k:34s} {v['hbm_bytes_per_step_corrected'] / 1e9:8.2f} GB/step")
+    print(f"{k:34s} {v['hbm_bytes_per_step_corrected'] / 1e9:8.2f} GB/step  {v.get('sum_ms_per_step', 0):8.3f} ms  {v.get('TBps', 0):6.3f} TB/s")
