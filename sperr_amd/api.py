@@ -14,7 +14,8 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsperr_hip.so")
+# (SPERR_HIP_LIB: another build of the same library, e.g. one with diagnostic switches compiled in)
+LIB_PATH = os.environ.get("SPERR_HIP_LIB") or os.path.join(_HERE, "libsperr_hip.so")
 _sz, _vp = C.c_size_t, C.c_void_p
 
 # every symbol include/sperr_hip.h declares

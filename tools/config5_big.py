@@ -32,10 +32,31 @@ from sperr_amd.synth import turbulence_torch
 
 
 def mem_available():
+    """What this job may take: /proc/meminfo's MemAvailable is the HOST's, a pod's share can be far smaller
+    (cgroup v2 memory.max / v1 memory.limit_in_bytes, minus what is in use); the smaller of the two."""
+    avail = 0
     for line in open("/proc/meminfo"):
         if line.startswith("MemAvailable:"):
-            return int(line.split()[1]) * 1024
-    return 0
+            avail = int(line.split()[1]) * 1024
+    rel = "/"
+    try:
+        for line in open("/proc/self/cgroup"):
+            f = line.strip().split(":")
+            if f[1] in ("", "memory"):
+                rel = f[2]
+    except OSError:
+        pass
+    for base, lim, cur in (("/sys/fs/cgroup", "memory.max", "memory.current"),
+                           ("/sys/fs/cgroup/memory", "memory.limit_in_bytes", "memory.usage_in_bytes")):
+        for d in (base + rel, base):
+            try:
+                v = open(os.path.join(d, lim)).read().strip()
+                if v != "max" and int(v) < (1 << 60):
+                    used = int(open(os.path.join(d, cur)).read().strip())
+                    avail = min(avail, max(0, int(v) - used))
+            except (OSError, ValueError):
+                pass
+    return avail
 
 
 def main():
@@ -45,13 +66,22 @@ def main():
     ap.add_argument("--sample", type=int, default=16)
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--max-edge", type=int, default=2048, help="largest edge `--edge auto` may choose")
     args = ap.parse_args()
     avail = mem_available()
+    # Two pinned volumes + the container + the farm's staging: 2.4 x the volume.  Pinned memory cannot be
+    # reclaimed, and a box whose pod runs out of memory is LOST (round 4 lost one to `auto` choosing 4096^3
+    # from the host's MemAvailable): never more than a quarter of what is available, `auto` never above
+    # --max-edge, and an explicit --edge is refused when it does not fit either.
+    fits = lambda e: 2.4 * 4 * e ** 3 < 0.25 * avail
     if args.edge == "auto":
-        # two pinned volumes + the container + the farm's staging must stay well inside the host's memory
-        edge = next((e for e in (4096, 3072, 2048, 1536, 1024) if 2.4 * 4 * e ** 3 < 0.6 * avail), 1024)
+        edge = next((e for e in (4096, 3072, 2048, 1536, 1024) if e <= args.max_edge and fits(e)), 0)
     else:
         edge = int(args.edge)
+    if edge == 0 or not fits(edge):
+        print(f"# refused: {edge or args.max_edge}^3 needs {2.4 * 4 * (edge or 1024) ** 3 / 2**30:.0f} GiB of host memory, "
+              f"a quarter of what this job may take is {0.25 * avail / 2**30:.0f} GiB")
+        sys.exit(3)
     S, Cn = edge, args.chunk
     nvals = S ** 3
     nbytes = 4 * nvals
