@@ -21,8 +21,10 @@
 //                  container -> chunk streams to their place in the output
 //     decompress:  the item's chunk streams as a small container -> H2D -> sperrhip_decompress_dev
 //                  -> D2H -> rows scattered into the caller's volume
-// Each step of a worker is synchronous; overlap of copies and kernels comes from the other workers
-// of the device, balance between devices from the queue.  No collective, no peer traffic.  The
+// A worker has two sets of buffers and the device two copy streams (one per direction) shared by its
+// workers: item i + 1's input travels in and item i - 1's output travels out while item i computes
+// (events between the streams; the host waits only when it needs an item's bytes).  Balance between
+// devices comes from the queue.  No collective, no peer traffic.  The
 // volume is never resident on a device as a whole, so its size is bounded by host memory only
 // (BASELINE.json config 5).
 #include <algorithm>
@@ -74,7 +76,8 @@ struct FarmShape {
 FarmShape farm_shape(size_t nthreads, size_t ndev)
 {
   FarmShape f;
-  f.workersPerDevice = env_size("SPERR_HIP_FARM_WORKERS", 3);
+  // (two double-buffered workers per device since round 4; rounds 1-3: three synchronous ones)
+  f.workersPerDevice = env_size("SPERR_HIP_FARM_WORKERS", 2);
   f.itemBytesMax = env_size("SPERR_HIP_FARM_ITEM_MB", 768) << 20;
   f.itemChunksForced = env_size("SPERR_HIP_FARM_ITEM", 0);
   // `nthreads` (the reference's OpenMP team size, src/SPERR3D_OMP_C.cpp:12-20) is taken as the
@@ -244,14 +247,17 @@ struct DeviceGuard {
 };
 
 // ------------------------------------------------------------------------------------------
-// worker contexts: stream + staging buffers, kept between calls (pinning memory is slow)
+// worker contexts: stream + two sets of staging buffers, kept between calls (pinning memory is slow)
 // ------------------------------------------------------------------------------------------
-struct WorkerCtx {
-  int dev = -1;
-  bool busy = false;
-  hipStream_t st = nullptr;
+// A worker has TWO slots (round 4): while item i computes out of one, item i + 1's input is on its way into
+// the other and item i - 1's output is on its way out of it.
+struct Slot {
   void *pinIn = nullptr, *pinOut = nullptr, *dIn = nullptr, *dOut = nullptr;
   size_t pinInCap = 0, pinOutCap = 0, dInCap = 0, dOutCap = 0;
+  hipEvent_t evIn = nullptr, evComp = nullptr, evOut = nullptr;   // input on the device / computed / output on the host
+  bool usedIn = false, usedComp = false;                          // the events have been recorded at least once
+  const Item* it = nullptr;
+  size_t len = 0;   // compress: bytes of the item's container; decompress: of the small container sent in
 
   static int grow_pinned(void*& p, size_t& cap, size_t bytes)
   {
@@ -283,29 +289,63 @@ struct WorkerCtx {
   int need_pin_out(size_t b) { return grow_pinned(pinOut, pinOutCap, b); }
   int need_dev_in(size_t b) { return grow_dev(dIn, dInCap, b); }
   int need_dev_out(size_t b) { return grow_dev(dOut, dOutCap, b); }
+  void drop_pinned()
+  {
+    if (pinIn)
+      (void)hipHostFree(pinIn);
+    if (pinOut)
+      (void)hipHostFree(pinOut);
+    pinIn = pinOut = nullptr;
+    pinInCap = pinOutCap = 0;
+  }
+  void drop_dev()
+  {
+    if (dIn)
+      (void)hipFree(dIn);
+    if (dOut)
+      (void)hipFree(dOut);
+    dIn = dOut = nullptr;
+    dInCap = dOutCap = 0;
+  }
+};
+
+struct WorkerCtx {
+  int dev = -1;
+  bool busy = false;
+  hipStream_t st = nullptr;   // the device-resident calls of this worker
+  Slot slot[2];
+  size_t pinned_bytes() const { return slot[0].pinInCap + slot[0].pinOutCap + slot[1].pinInCap + slot[1].pinOutCap; }
+  size_t device_bytes() const { return slot[0].dInCap + slot[0].dOutCap + slot[1].dInCap + slot[1].dOutCap; }
 };
 
 std::mutex g_ctx_mu;
 std::vector<std::unique_ptr<WorkerCtx>> g_ctx;
 
-// One large copy per device and direction at a time: PCIe is shared, and three workers that copy
-// their items at once all finish late and then all compute at once; one after the other, the
-// second item's copy runs behind the first item's kernels and the link never idles (measured on
-// MI355X, 1024^3 fp32: compress 106 -> 97 ms; decompress, which is bound by its kernels, stays at
-// 110 ms; H2D and D2H are separate
-// tokens because the link is full duplex: 57 GB/s each way, 97 GB/s together).
-struct CopyTokens {
-  std::mutex h2d, d2h;
+// One copy stream per device and direction, shared by the device's workers: the large copies of the
+// items go one after the other in the order they were asked for (PCIe is shared: copies side by side all
+// finish late), H2D and D2H on separate streams because the link is full duplex (57 GB/s each way, 97
+// GB/s together, tools/micro/copybw.cpp).  Rounds 1-3 had a mutex per direction around synchronous
+// copies; now nobody waits on the host.
+struct CopyLanes {
+  hipStream_t h2d = nullptr, d2h = nullptr;
 };
-CopyTokens& copy_tokens(int dev)
+// (the calling thread has made `dev` current)
+CopyLanes* copy_lanes(int dev)
 {
   static std::mutex mu;
-  static std::map<int, std::unique_ptr<CopyTokens>> all;
+  static std::map<int, std::unique_ptr<CopyLanes>> all;
   std::lock_guard<std::mutex> lock(mu);
   auto& p = all[dev];
-  if (!p)
-    p = std::make_unique<CopyTokens>();
-  return *p;
+  if (!p) {
+    auto l = std::make_unique<CopyLanes>();
+    if (hipStreamCreateWithFlags(&l->h2d, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&l->d2h, hipStreamNonBlocking) != hipSuccess) {
+      fprintf(stderr, "[sperr_hip] cannot create the copy streams of device %d\n", dev);
+      return nullptr;
+    }
+    p = std::move(l);
+  }
+  return p.get();
 }
 
 // (the calling thread has made `dev` current)
@@ -322,7 +362,11 @@ WorkerCtx* ctx_acquire(int dev)
   auto c = std::make_unique<WorkerCtx>();
   c->dev = dev;
   c->busy = true;
-  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) {
+  bool ok = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) == hipSuccess;
+  for (Slot& sl : c->slot)
+    for (hipEvent_t* e : {&sl.evIn, &sl.evComp, &sl.evOut})
+      ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     fprintf(stderr, "[sperr_hip] cannot create a stream on device %d\n", dev);
     return nullptr;
   }
@@ -341,16 +385,10 @@ void farm_release_idle()
       continue;
     if (hipSetDevice(c->dev) != hipSuccess)
       continue;
-    if (c->pinIn)
-      (void)hipHostFree(c->pinIn);
-    if (c->pinOut)
-      (void)hipHostFree(c->pinOut);
-    if (c->dIn)
-      (void)hipFree(c->dIn);
-    if (c->dOut)
-      (void)hipFree(c->dOut);
-    c->pinIn = c->pinOut = c->dIn = c->dOut = nullptr;
-    c->pinInCap = c->pinOutCap = c->dInCap = c->dOutCap = 0;
+    for (Slot& sl : c->slot) {
+      sl.drop_pinned();
+      sl.drop_dev();
+    }
   }
 }
 unsigned long long farm_footprint(bool pinned)
@@ -358,7 +396,7 @@ unsigned long long farm_footprint(bool pinned)
   std::lock_guard<std::mutex> lock(g_ctx_mu);
   unsigned long long n = 0;
   for (auto& c : g_ctx)
-    n += pinned ? c->pinInCap + c->pinOutCap : c->dInCap + c->dOutCap;
+    n += pinned ? c->pinned_bytes() : c->device_bytes();
   return n;
 }
 namespace {
@@ -367,22 +405,12 @@ void ctx_release(WorkerCtx* c)
 {
   // staging memory above SPERR_HIP_FARM_KEEP_MB (default 4096) per worker is given back
   static const size_t keep = env_size("SPERR_HIP_FARM_KEEP_MB", 4096) << 20;
-  if (c->pinInCap + c->pinOutCap > keep) {
-    if (c->pinIn)
-      (void)hipHostFree(c->pinIn);
-    if (c->pinOut)
-      (void)hipHostFree(c->pinOut);
-    c->pinIn = c->pinOut = nullptr;
-    c->pinInCap = c->pinOutCap = 0;
-  }
-  if (c->dInCap + c->dOutCap > 2 * keep) {
-    if (c->dIn)
-      (void)hipFree(c->dIn);
-    if (c->dOut)
-      (void)hipFree(c->dOut);
-    c->dIn = c->dOut = nullptr;
-    c->dInCap = c->dOutCap = 0;
-  }
+  if (c->pinned_bytes() > keep)
+    for (Slot& sl : c->slot)
+      sl.drop_pinned();
+  if (c->device_bytes() > 2 * keep)
+    for (Slot& sl : c->slot)
+      sl.drop_dev();
   std::lock_guard<std::mutex> lock(g_ctx_mu);
   c->busy = false;
 }
@@ -493,39 +521,56 @@ struct Job {
   ~Job() { free(outBuf); }   // (whatever ends the call early; handed over = set to nullptr)
 };
 
-int comp_item(Job& J, WorkerCtx& C, const Item& it)
+// ---- the three stages of an item (round 4: no step waits on the host for the one before it) ------
+//   prefetch  input -> device, on the device's H2D lane       (records slot.evIn)
+//   compute   the device-resident call on the worker's stream  (waits for evIn; records evComp and queues
+//             the copy of the result on the D2H lane, which records evOut)
+//   finish    waits for evOut; what is left to do on the host
+// compress ----------------------------------------------------------------------------------------
+int comp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
 {
   const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
   const size_t inBytes = nb * cx * cy * cz * J.esz;
-  if (C.need_dev_in(inBytes))
+  S.it = &it;
+  if (S.usedIn)
+    HIP_CHECK(hipEventSynchronize(S.evIn));     // (the slot's staging buffer: its last copy left long ago)
+  if (S.need_dev_in(inBytes))
     return -1;
+  if (S.usedComp)
+    HIP_CHECK(hipStreamWaitEvent(L.h2d, S.evComp, 0));   // the slot's last item has been computed
   if (J.direct) {
-    std::lock_guard<std::mutex> token(copy_tokens(C.dev).h2d);
-    if (dma_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.dIn), it, J.esz, C.st))
+    if (dma_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(S.dIn), it, J.esz, L.h2d))
       return -1;
-    HIP_CHECK(hipStreamSynchronize(C.st));
   }
   else {
-    if (C.need_pin_in(inBytes))
+    if (S.need_pin_in(inBytes))
       return -1;
-    move_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(C.pinIn), it, J.esz,
-              J.fs.helpers);
-    std::lock_guard<std::mutex> token(copy_tokens(C.dev).h2d);
-    HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, inBytes, hipMemcpyHostToDevice, C.st));
-    HIP_CHECK(hipStreamSynchronize(C.st));
+    move_item(true, const_cast<uint8_t*>(J.src), J.vol, static_cast<uint8_t*>(S.pinIn), it, J.esz, J.fs.helpers);
+    HIP_CHECK(hipMemcpyAsync(S.dIn, S.pinIn, inBytes, hipMemcpyHostToDevice, L.h2d));
   }
+  HIP_CHECK(hipEventRecord(S.evIn, L.h2d));
+  S.usedIn = true;
+  return 0;
+}
+
+int comp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
+{
+  const Item& it = *S.it;
+  const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
+  const size_t inBytes = nb * cx * cy * cz * J.esz;
+  HIP_CHECK(hipStreamWaitEvent(C.st, S.evIn, 0));
   // the item's chunks stacked along z are a volume of their own, cut into exactly these chunks.
   // Without a bit budget the bound on the container is 33 bytes per value; real containers are a
-  // fraction of the input, so the first attempt gets three times the input and only a container
-  // that does not fit (never seen) is produced again into the full bound.
+  // fraction of the input, so the first attempt gets as much room as the input takes and only a
+  // container that does not fit (never seen) is produced again into the full bound.
   const size_t bound = sperrhip_max_compressed_size(cx, cy, cz * nb, cx, cy, cz, J.mode, J.quality);
-  size_t cap = std::min(bound, 3 * inBytes + (size_t(1) << 20));
+  size_t cap = std::min(bound, inBytes + (size_t(1) << 20));
   size_t len = 0;
   for (;;) {
-    if (C.need_dev_out(cap))
+    if (S.need_dev_out(cap))
       return -1;
-    const int rc = sperrhip_compress_dev(C.dIn, J.is_float, cx, cy, cz * nb, cx, cy, cz, J.mode,
-                                         J.quality, C.dOut, cap, &len, C.st);
+    const int rc = sperrhip_compress_dev(S.dIn, J.is_float, cx, cy, cz * nb, cx, cy, cz, J.mode,
+                                         J.quality, S.dOut, cap, &len, C.st);
     if (rc == 0)
       break;
     if (rc != -1 || cap >= bound)
@@ -533,11 +578,24 @@ int comp_item(Job& J, WorkerCtx& C, const Item& it)
     cap = bound;
   }
   const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
-  if (len < hdr || C.need_pin_out(len))
+  if (len < hdr || S.need_pin_out(len))
     return -1;
-  HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, len, hipMemcpyDeviceToHost, C.st));
-  HIP_CHECK(hipStreamSynchronize(C.st));
-  const uint8_t* h = static_cast<const uint8_t*>(C.pinOut);
+  S.len = len;
+  HIP_CHECK(hipEventRecord(S.evComp, C.st));
+  S.usedComp = true;
+  HIP_CHECK(hipStreamWaitEvent(L.d2h, S.evComp, 0));
+  HIP_CHECK(hipMemcpyAsync(S.pinOut, S.dOut, len, hipMemcpyDeviceToHost, L.d2h));
+  HIP_CHECK(hipEventRecord(S.evOut, L.d2h));
+  return 0;
+}
+
+int comp_finish(Job& J, WorkerCtx&, CopyLanes&, Slot& S)
+{
+  HIP_CHECK(hipEventSynchronize(S.evOut));
+  const Item& it = *S.it;
+  const size_t nb = it.gid.size(), len = S.len;
+  const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
+  const uint8_t* h = static_cast<const uint8_t*>(S.pinOut);
   size_t at = hdr;
   for (size_t i = 0; i < nb; i++) {
     uint32_t l;
@@ -560,7 +618,8 @@ int comp_item(Job& J, WorkerCtx& C, const Item& it)
   return 0;
 }
 
-int decomp_item(Job& J, WorkerCtx& C, const Item& it)
+// decompress --------------------------------------------------------------------------------------
+int decomp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
 {
   const HostContainer& hc = *J.hc;
   const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
@@ -568,9 +627,13 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
   size_t total = hdr;
   for (uint32_t g : it.gid)
     total += hc.len[g];
-  if (C.need_pin_in(total) || C.need_dev_in(total))
+  S.it = &it;
+  S.len = total;
+  if (S.usedIn)
+    HIP_CHECK(hipEventSynchronize(S.evIn));     // (the staging buffer is rewritten below)
+  if (S.need_pin_in(total) || S.need_dev_in(total))
     return -1;
-  uint8_t* h = static_cast<uint8_t*>(C.pinIn);
+  uint8_t* h = static_cast<uint8_t*>(S.pinIn);
   h[0] = 0;   // SPERR_VERSION_MAJOR
   h[1] = (uint8_t)(0x40 | (hc.is_float ? 0x20 : 0) | (nb > 1 ? 0x10 : 0) | (hc.portion ? 0x80 : 0));
   const uint32_t v3[3] = {(uint32_t)cx, (uint32_t)cy, (uint32_t)(cz * nb)};
@@ -587,33 +650,50 @@ int decomp_item(Job& J, WorkerCtx& C, const Item& it)
     memcpy(h + at, J.container + hc.off[g], l);
     at += l;
   }
-  HIP_CHECK(hipMemcpyAsync(C.dIn, C.pinIn, total, hipMemcpyHostToDevice, C.st));
+  if (S.usedComp)
+    HIP_CHECK(hipStreamWaitEvent(L.h2d, S.evComp, 0));
+  HIP_CHECK(hipMemcpyAsync(S.dIn, S.pinIn, total, hipMemcpyHostToDevice, L.h2d));
+  HIP_CHECK(hipEventRecord(S.evIn, L.h2d));
+  S.usedIn = true;
+  return 0;
+}
+
+int decomp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
+{
+  const Item& it = *S.it;
+  const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
   const size_t osz = J.output_float ? 4 : 8;
   const size_t outBytes = nb * cx * cy * cz * osz;
-  if (C.need_dev_out(outBytes))
+  if (S.need_dev_out(outBytes))
     return -1;
+  HIP_CHECK(hipStreamWaitEvent(C.st, S.evIn, 0));
   size_t x = 0, y = 0, z = 0;
-  t_shared_device = true;   // (the other workers of the device run beside this call)
-  const int rc = sperrhip_decompress_dev(C.dIn, total, J.output_float, C.dOut, outBytes, &x, &y, &z, C.st);
+  t_shared_device = J.workerDev.size() > 1;   // (then other workers' calls run beside this one)
+  const int rc = sperrhip_decompress_dev(S.dIn, S.len, J.output_float, S.dOut, outBytes, &x, &y, &z, C.st);
   t_shared_device = false;
   if (rc)
     return rc;
+  HIP_CHECK(hipEventRecord(S.evComp, C.st));
+  S.usedComp = true;
+  HIP_CHECK(hipStreamWaitEvent(L.d2h, S.evComp, 0));
   if (J.direct) {
-    std::lock_guard<std::mutex> token(copy_tokens(C.dev).d2h);
-    if (dma_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.dOut), it, osz, C.st))
+    if (dma_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(S.dOut), it, osz, L.d2h))
       return -1;
-    HIP_CHECK(hipStreamSynchronize(C.st));
   }
   else {
-    if (C.need_pin_out(outBytes))
+    if (S.need_pin_out(outBytes))
       return -1;
-    {
-      std::lock_guard<std::mutex> token(copy_tokens(C.dev).d2h);
-      HIP_CHECK(hipMemcpyAsync(C.pinOut, C.dOut, outBytes, hipMemcpyDeviceToHost, C.st));
-      HIP_CHECK(hipStreamSynchronize(C.st));
-    }
-    move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(C.pinOut), it, osz, J.fs.helpers);
+    HIP_CHECK(hipMemcpyAsync(S.pinOut, S.dOut, outBytes, hipMemcpyDeviceToHost, L.d2h));
   }
+  HIP_CHECK(hipEventRecord(S.evOut, L.d2h));
+  return 0;
+}
+
+int decomp_finish(Job& J, WorkerCtx&, CopyLanes&, Slot& S)
+{
+  HIP_CHECK(hipEventSynchronize(S.evOut));
+  if (!J.direct)
+    move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(S.pinOut), *S.it, J.output_float ? 4 : 8, J.fs.helpers);
   return 0;
 }
 
@@ -635,8 +715,8 @@ const numa::Place& device_place(int dev)
   return all.emplace(dev, std::move(pl)).first->second;
 }
 
-template <typename F>
-int run_workers(Job& J, F&& doItem)
+template <typename P, typename Cm, typename Fi>
+int run_workers(Job& J, P&& prefetch, Cm&& compute, Fi&& finish)
 {
   const size_t nw = J.workerDev.size();
   std::vector<std::thread> th;
@@ -651,26 +731,61 @@ int run_workers(Job& J, F&& doItem)
     if (numa::enabled())
       (void)numa::bind_self(device_place(dev));
     WorkerCtx* C = ctx_acquire(dev);
-    if (!C) {
+    CopyLanes* L = C ? copy_lanes(dev) : nullptr;
+    if (!C || !L) {
+      if (C)
+        ctx_release(C);
       J.failed = -1;
       return;
     }
+    auto take = [&]() -> const Item* {
+      if (J.failed.load())
+        return nullptr;
+      const size_t i = J.next.fetch_add(1);
+      return i < J.items.size() ? &J.items[i] : nullptr;
+    };
     try {
-      while (!J.failed.load()) {
-        const size_t i = J.next.fetch_add(1);
-        if (i >= J.items.size())
-          break;
-        const int rc = doItem(J, *C, J.items[i]);
-        if (rc) {
-          J.failed = rc;
-          break;
+      // item i computes out of one slot while item i + 1's input travels into the other and item
+      // i - 1's output leaves it (the device-resident calls block this thread until their kernels
+      // are queued or done; the copies never do)
+      Slot* pending = nullptr;   // computed, its output on the way to the host
+      int cur = 0;
+      const Item* it = take();
+      int rc = it ? prefetch(J, *C, *L, C->slot[cur], *it) : 0;
+      while (it && rc == 0) {
+        const Item* nextIt = take();
+        if (nextIt)
+          rc = prefetch(J, *C, *L, C->slot[cur ^ 1], *nextIt);
+        if (rc == 0)
+          rc = compute(J, *C, *L, C->slot[cur]);
+        if (rc == 0 && pending) {
+          rc = finish(J, *C, *L, *pending);
+          pending = nullptr;
         }
+        if (rc == 0)
+          pending = &C->slot[cur];
+        cur ^= 1;
+        it = nextIt;
       }
+      if (rc == 0 && pending)
+        rc = finish(J, *C, *L, *pending);
+      if (rc)
+        J.failed = rc;
     }
     catch (...) {
       J.failed = -1;
     }
+    // nothing of this worker may still be in flight when its buffers go back to the pool (a failed
+    // item leaves copies queued on the lanes: they are waited for here as well)
     (void)hipStreamSynchronize(C->st);
+    for (Slot& sl : C->slot) {
+      if (sl.usedIn)
+        (void)hipEventSynchronize(sl.evIn);
+      if (sl.usedComp) {
+        (void)hipEventSynchronize(sl.evComp);
+        (void)hipEventSynchronize(sl.evOut);
+      }
+    }
     ctx_release(C);
   };
   // the calling thread keeps its current device: all workers are threads of their own (the items
@@ -729,7 +844,10 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     return -1;
   J.fs = farm_shape(nthreads, devs.size());
   J.esz = is_float ? 4 : 8;
-  J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs, mode == 1 ? 4 : 2);
+  // (items per worker: enough of them that the first item's copy in and the last item's copy out, which
+  //  nothing overlaps, stay short; SPERR_HIP_FARM_PER_WORKER)
+  J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs,
+                       env_size("SPERR_HIP_FARM_PER_WORKER", mode == 1 ? 6 : 3));
   assign_workers(J, devs);
   J.src = static_cast<const uint8_t*>(src);
   J.is_float = is_float;
@@ -768,7 +886,7 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
     J.chunkBytes.resize(nchunks);
   }
 
-  const int rc = run_workers(J, comp_item);
+  const int rc = run_workers(J, comp_prefetch, comp_compute, comp_finish);
   if (rc)
     return rc;
 
@@ -854,7 +972,8 @@ int farm_decompress(const void* src, size_t src_len, int output_float, size_t nt
   // decoder's list kernels keep one workgroup per chunk busy)
   J.fs.itemBytesMax = env_size("SPERR_HIP_FARM_DEC_ITEM_MB", 1536) << 20;
   J.fs.workersPerDevice = env_size("SPERR_HIP_FARM_DEC_WORKERS", J.fs.workersPerDevice);
-  J.items = make_items(chunks, output_float ? 4 : 8, devs.size() * J.fs.workersPerDevice, J.fs);
+  J.items = make_items(chunks, output_float ? 4 : 8, devs.size() * J.fs.workersPerDevice, J.fs,
+                       env_size("SPERR_HIP_FARM_DEC_PER_WORKER", 4));
   assign_workers(J, devs);
   J.container = static_cast<const uint8_t*>(src);
   J.hc = &hc;
@@ -863,7 +982,7 @@ int farm_decompress(const void* src, size_t src_len, int output_float, size_t nt
   const bool allowDirect = !(getenv("SPERR_HIP_PINNED_COPY") && strcmp(getenv("SPERR_HIP_PINNED_COPY"), "stage") == 0);
   J.direct = allowDirect && host_ptr_is_pinned(dstVol);
   (void)src_len;
-  return run_workers(J, decomp_item);
+  return run_workers(J, decomp_prefetch, decomp_compute, decomp_finish);
 }
 
 template <typename F>

@@ -750,12 +750,21 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
 // ------------------------------------------------------------------------------------------
 // (the pipelines live in registers: the forward kernel fits 16 wavefronts of 128 VGPRs, the inverse one,
 //  which inverts the halo rows along z too, as well -- with a few spills outside its main loop)
-constexpr int kXYZThreadsF = 1024, kXYZThreadsI = 1024;
+#ifndef XYZ_INV_THREADS
+#define XYZ_INV_THREADS 1024
+#endif
+#ifndef XYZ_INV_PREFETCH
+#define XYZ_INV_PREFETCH 0
+#endif
+#ifndef XYZ_FWD_THREADS
+#define XYZ_FWD_THREADS 1024
+#endif
+constexpr int kXYZThreadsF = XYZ_FWD_THREADS, kXYZThreadsI = XYZ_INV_THREADS;
 constexpr int kXYZRows = 16;
 constexpr int kXYZStaged = kXYZRows + 2 * kXYHalo;   // LDS rows of a slice
-constexpr int kXYZPosF = 4;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
-constexpr int kXYZStageF = 6;  // staged samples per thread, forward: kXYZStaged * cx <= 6144
-constexpr int kXYZPosI = 6;   // inverse: kXYZStaged * cx <= 6144
+constexpr int kXYZPosF = (4096 + kXYZThreadsF - 1) / kXYZThreadsF;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
+constexpr int kXYZStageF = (6144 + kXYZThreadsF - 1) / kXYZThreadsF;  // staged samples per thread, forward: kXYZStaged * cx <= 6144
+constexpr int kXYZPosI = 6144 / kXYZThreadsI;   // inverse: kXYZStaged * cx <= 6144
 
 // LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
 // (the four rows above and below the tile -- mirrored at the ends of the slice, so the first and the
@@ -837,7 +846,7 @@ __device__ __forceinline__ void xyz_lift_y(const double* src, double* dst, uint3
 }
 
 template <int IO>
-__global__ void __launch_bounds__(kXYZThreadsF) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kXYZThreadsF) __attribute__((amdgpu_waves_per_eu(kXYZThreadsF / 256, kXYZThreadsF / 256)))
 k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                CoderState* st, const void* volume, VolDesc vd, const ChunkGeom* geom, int wantMax,
                uint32_t in0, uint32_t in1, uint32_t in2, uint32_t nseg)
@@ -1011,7 +1020,7 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
 }
 
 template <int IO>
-__global__ void __launch_bounds__(kXYZThreadsI) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kXYZThreadsI) __attribute__((amdgpu_waves_per_eu(kXYZThreadsI / 256, kXYZThreadsI / 256)))
 k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F, uint32_t nseg)
 {
@@ -1077,6 +1086,38 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const uint32_t initOld = (haveMasks && lastPl < 31) ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
   // sample (dcol, drow, zp): straight from the decoder (q * double(c) * (+-1.0), src/SPECK_FLT.cpp:373-399)
   // unless a coarser level's passes have produced it
+  // The loads of a sample in two steps, so that pair m + 1's coefficients are on their way while pair m's
+  // two slices go through the y and x passes (round 4: the kernel spent half its time waiting for them):
+  // raw_issue starts the one load that comes from HBM (the 32-bit coefficient, or the fp64 sample of the
+  // coarser levels' box), raw_value turns what arrived into the sample (sign and mask words: a few words
+  // per wavefront, cache hits).
+  auto raw_issue = [&](int k, uint32_t zp) -> uint64_t {
+    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
+    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+    const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
+    if (!dequant && !inBox && F.bufx)
+      return 0ull;
+    if (dequant && !inBox)
+      return (uint64_t)coef[(size_t)zp * sliceN + drow * cx + dcol];
+    return (uint64_t)__double_as_longlong(buf[(size_t)zp * bufSlice + drow * bufx + dcol]);
+  };
+  auto raw_value = [&](int k, uint32_t zp, uint64_t raw) -> double {
+    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
+    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+    const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
+    const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
+    if (!dequant && !inBox && F.bufx)
+      return 0.0;   // (a compact buffer holds the box only; the host asks for one only when every chunk dequantises here)
+    if (dequant && !inBox) {
+      uint32_t v = (uint32_t)raw;
+      const uint32_t sh = (uint32_t)(idx & 63);
+      const uint64_t sgw = sign[idx >> 6], mnw = mNew[idx >> 6], mow = mOld[idx >> 6];   // (independent loads)
+      const uint32_t fill = ((mnw >> sh) & 1ull) ? initNew : (((mow >> sh) & 1ull) ? initOld : 0u);
+      v = v ? v : fill;
+      return fq * (double)v * (((sgw >> sh) & 1ull) ? 1.0 : -1.0);
+    }
+    return __longlong_as_double((long long)raw);
+  };
   auto fetch = [&](int k, uint32_t zp) -> double {
     const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
@@ -1135,6 +1176,17 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   for (int k = 0; k < kXYZPosI; k++)
     o1p[k] = e1p[k] = o2p[k] = e2p[k] = 0.0;
   const uint32_t npairs = cz / 2;
+#if XYZ_INV_PREFETCH
+  uint64_t rawE[kXYZPosI], rawO[kXYZPosI];
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++) {
+    rawE[k] = rawO[k] = 0;
+    if ((tid + (uint32_t)k * kXYZThreadsI) < npos && mFirst < mB) {
+      rawE[k] = raw_issue(k, mFirst);
+      rawO[k] = raw_issue(k, ze + mFirst);
+    }
+  }
+#endif
   for (uint32_t m = mFirst; m < mB; m++) {
     const bool mine = m >= mA;   // (else: the segment's run-up)
 #pragma unroll
@@ -1146,7 +1198,15 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
         __builtin_amdgcn_sched_barrier(0);   // (four positions' loads in flight at a time, not all twelve)
       if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
         continue;
+#if XYZ_INV_PREFETCH
+      const double E = raw_value(k, m, rawE[k]), O = raw_value(k, ze + m, rawO[k]);
+      if (m + 1 < mB) {   // (the next pair's: in flight while this pair's slices are finished)
+        rawE[k] = raw_issue(k, m + 1);
+        rawO[k] = raw_issue(k, ze + m + 1);
+      }
+#else
       const double E = fetch(k, m), O = fetch(k, ze + m);
+#endif
       const double o1 = (-K.eps) * O;                                        // o1[m]
       const double t = K.delta * ((m == 0 ? o1 : o1p[k]) + o1);
       const double e1 = fma(E, K.inv_eps, -t);                               // e1[m]
