@@ -272,6 +272,10 @@ def main():
         eng.lib.sperrhip_debug_counter.argtypes = [C_.c_int]
         arena = int(eng.lib.sperrhip_debug_counter(3))
         workspace = {"arena_GB": round(arena / 1e9, 2), "MB_per_chunk_in_flight": round(arena / nchunks / 1e6, 1),
+                     # what the chunk farm's workers hold after the host-path runs (all devices of the launch:
+                     # two slots per worker, two workers per device)
+                     "farm_pinned_staging_GB": round(int(eng.lib.sperrhip_debug_counter(4)) / 1e9, 3),
+                     "farm_device_buffers_GB": round(int(eng.lib.sperrhip_debug_counter(5)) / 1e9, 3),
                      "what": "largest workspace arena of an engine after the timed steps (all chunks of the volume "
                              "in flight: the larger of the compression and the decompression layout)"}
     except Exception as ex:   # noqa: BLE001

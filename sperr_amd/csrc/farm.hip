@@ -31,6 +31,7 @@
 #include <array>
 #include <atomic>
 #include <condition_variable>
+#include <future>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -256,8 +257,12 @@ struct Slot {
   size_t pinInCap = 0, pinOutCap = 0, dInCap = 0, dOutCap = 0;
   hipEvent_t evIn = nullptr, evComp = nullptr, evOut = nullptr;   // input on the device / computed / output on the host
   bool usedIn = false, usedComp = false;                          // the events have been recorded at least once
-  const Item* it = nullptr;
-  size_t len = 0;   // compress: bytes of the item's container; decompress: of the small container sent in
+  // a slot holds TWO items at a time: the one whose input is in (or on its way into) dIn, and the one before
+  // the last whose output is on its way out of dOut -- so each side has its own record
+  const Item* itIn = nullptr;    // set by prefetch, read by compute
+  size_t lenIn = 0;              //   decompress: bytes of the small container sent in
+  const Item* itOut = nullptr;   // set by compute, read by finish
+  size_t lenOut = 0;             //   compress: bytes of the item's container
 
   static int grow_pinned(void*& p, size_t& cap, size_t bytes)
   {
@@ -521,17 +526,20 @@ struct Job {
   ~Job() { free(outBuf); }   // (whatever ends the call early; handed over = set to nullptr)
 };
 
-// ---- the three stages of an item (round 4: no step waits on the host for the one before it) ------
+// ---- the three stages of an item (round 4) -----------------------------------------------------------
 //   prefetch  input -> device, on the device's H2D lane       (records slot.evIn)
-//   compute   the device-resident call on the worker's stream  (waits for evIn; records evComp and queues
-//             the copy of the result on the D2H lane, which records evOut)
-//   finish    waits for evOut; what is left to do on the host
+//   compute   the device-resident call on the worker's stream  (waits for evIn; records evComp)
+//   finish    the result -> host on the D2H lane (waits for evComp), then what is left to do on the host
+// Item i's compute runs on the worker's thread while item i + 1's prefetch and item i - 1's finish run on
+// two helper threads of their own: a copy call that keeps its caller until the bytes have moved (the 3D
+// copies of a pinned volume do; measured: one worker with the copies issued from its own thread ran copy
+// and kernels strictly one after the other) then still overlaps the kernels.
 // compress ----------------------------------------------------------------------------------------
 int comp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
 {
   const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
   const size_t inBytes = nb * cx * cy * cz * J.esz;
-  S.it = &it;
+  S.itIn = &it;
   if (S.usedIn)
     HIP_CHECK(hipEventSynchronize(S.evIn));     // (the slot's staging buffer: its last copy left long ago)
   if (S.need_dev_in(inBytes))
@@ -555,7 +563,7 @@ int comp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
 
 int comp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
 {
-  const Item& it = *S.it;
+  const Item& it = *S.itIn;
   const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
   const size_t inBytes = nb * cx * cy * cz * J.esz;
   HIP_CHECK(hipStreamWaitEvent(C.st, S.evIn, 0));
@@ -580,20 +588,21 @@ int comp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
   const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
   if (len < hdr || S.need_pin_out(len))
     return -1;
-  S.len = len;
+  S.itOut = S.itIn;
+  S.lenOut = len;
   HIP_CHECK(hipEventRecord(S.evComp, C.st));
   S.usedComp = true;
-  HIP_CHECK(hipStreamWaitEvent(L.d2h, S.evComp, 0));
-  HIP_CHECK(hipMemcpyAsync(S.pinOut, S.dOut, len, hipMemcpyDeviceToHost, L.d2h));
-  HIP_CHECK(hipEventRecord(S.evOut, L.d2h));
   return 0;
 }
 
-int comp_finish(Job& J, WorkerCtx&, CopyLanes&, Slot& S)
+int comp_finish(Job& J, WorkerCtx&, CopyLanes& L, Slot& S)
 {
+  HIP_CHECK(hipStreamWaitEvent(L.d2h, S.evComp, 0));
+  HIP_CHECK(hipMemcpyAsync(S.pinOut, S.dOut, S.lenOut, hipMemcpyDeviceToHost, L.d2h));
+  HIP_CHECK(hipEventRecord(S.evOut, L.d2h));
   HIP_CHECK(hipEventSynchronize(S.evOut));
-  const Item& it = *S.it;
-  const size_t nb = it.gid.size(), len = S.len;
+  const Item& it = *S.itOut;
+  const size_t nb = it.gid.size(), len = S.lenOut;
   const size_t hdr = nb > 1 ? 20 + 4 * nb : 18;
   const uint8_t* h = static_cast<const uint8_t*>(S.pinOut);
   size_t at = hdr;
@@ -627,8 +636,8 @@ int decomp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
   size_t total = hdr;
   for (uint32_t g : it.gid)
     total += hc.len[g];
-  S.it = &it;
-  S.len = total;
+  S.itIn = &it;
+  S.lenIn = total;
   if (S.usedIn)
     HIP_CHECK(hipEventSynchronize(S.evIn));     // (the staging buffer is rewritten below)
   if (S.need_pin_in(total) || S.need_dev_in(total))
@@ -660,7 +669,8 @@ int decomp_prefetch(Job& J, WorkerCtx&, CopyLanes& L, Slot& S, const Item& it)
 
 int decomp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
 {
-  const Item& it = *S.it;
+  const Item& it = *S.itIn;
+  S.itOut = S.itIn;
   const size_t nb = it.gid.size(), cx = it.shape[0], cy = it.shape[1], cz = it.shape[2];
   const size_t osz = J.output_float ? 4 : 8;
   const size_t outBytes = nb * cx * cy * cz * osz;
@@ -669,31 +679,33 @@ int decomp_compute(Job& J, WorkerCtx& C, CopyLanes& L, Slot& S)
   HIP_CHECK(hipStreamWaitEvent(C.st, S.evIn, 0));
   size_t x = 0, y = 0, z = 0;
   t_shared_device = J.workerDev.size() > 1;   // (then other workers' calls run beside this one)
-  const int rc = sperrhip_decompress_dev(S.dIn, S.len, J.output_float, S.dOut, outBytes, &x, &y, &z, C.st);
+  const int rc = sperrhip_decompress_dev(S.dIn, S.lenIn, J.output_float, S.dOut, outBytes, &x, &y, &z, C.st);
   t_shared_device = false;
   if (rc)
     return rc;
   HIP_CHECK(hipEventRecord(S.evComp, C.st));
   S.usedComp = true;
+  if (!J.direct && S.need_pin_out(outBytes))
+    return -1;
+  return 0;
+}
+
+int decomp_finish(Job& J, WorkerCtx&, CopyLanes& L, Slot& S)
+{
+  const Item& it = *S.itOut;
+  const size_t osz = J.output_float ? 4 : 8;
+  const size_t outBytes = it.gid.size() * it.shape[0] * it.shape[1] * it.shape[2] * osz;
   HIP_CHECK(hipStreamWaitEvent(L.d2h, S.evComp, 0));
   if (J.direct) {
     if (dma_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(S.dOut), it, osz, L.d2h))
       return -1;
   }
-  else {
-    if (S.need_pin_out(outBytes))
-      return -1;
+  else
     HIP_CHECK(hipMemcpyAsync(S.pinOut, S.dOut, outBytes, hipMemcpyDeviceToHost, L.d2h));
-  }
   HIP_CHECK(hipEventRecord(S.evOut, L.d2h));
-  return 0;
-}
-
-int decomp_finish(Job& J, WorkerCtx&, CopyLanes&, Slot& S)
-{
   HIP_CHECK(hipEventSynchronize(S.evOut));
   if (!J.direct)
-    move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(S.pinOut), *S.it, J.output_float ? 4 : 8, J.fs.helpers);
+    move_item(false, J.dstVol, J.vol, static_cast<uint8_t*>(S.pinOut), it, osz, J.fs.helpers);
   return 0;
 }
 
@@ -744,37 +756,74 @@ int run_workers(Job& J, P&& prefetch, Cm&& compute, Fi&& finish)
       const size_t i = J.next.fetch_add(1);
       return i < J.items.size() ? &J.items[i] : nullptr;
     };
+    static const bool helpersOn = !(getenv("SPERR_HIP_FARM_ASYNC") && atoi(getenv("SPERR_HIP_FARM_ASYNC")) == 0);
+    std::future<int> fIn, fOut[2];   // item i + 1's prefetch; the slots' finishes
+    // (a helper thread: the worker's device, its NUMA placement by inheritance; nothing escapes it)
+    auto helper = [&](auto&& fn) -> std::future<int> {
+      if (!helpersOn) {
+        std::promise<int> pr;
+        pr.set_value(fn());
+        return pr.get_future();
+      }
+      return std::async(std::launch::async, [dev, fn]() -> int {
+        try {
+          if (hipSetDevice(dev) != hipSuccess)
+            return -1;
+          return fn();
+        }
+        catch (...) {
+          return -1;
+        }
+      });
+    };
+    int rc = 0;
     try {
-      // item i computes out of one slot while item i + 1's input travels into the other and item
-      // i - 1's output leaves it (the device-resident calls block this thread until their kernels
-      // are queued or done; the copies never do)
-      Slot* pending = nullptr;   // computed, its output on the way to the host
       int cur = 0;
       const Item* it = take();
-      int rc = it ? prefetch(J, *C, *L, C->slot[cur], *it) : 0;
+      if (it)
+        rc = prefetch(J, *C, *L, C->slot[cur], *it);
       while (it && rc == 0) {
+        Slot& S = C->slot[cur];
+        Slot& N = C->slot[cur ^ 1];
         const Item* nextIt = take();
-        if (nextIt)
-          rc = prefetch(J, *C, *L, C->slot[cur ^ 1], *nextIt);
+        if (nextIt)   // (N's input side is free: the item that computed out of it has been computed)
+          fIn = helper([&J, C, L, &N, nextIt, &prefetch]() { return prefetch(J, *C, *L, N, *nextIt); });
+        if (fOut[cur].valid())   // S's output side: the item before the last must have left it
+          rc = fOut[cur].get();
         if (rc == 0)
-          rc = compute(J, *C, *L, C->slot[cur]);
-        if (rc == 0 && pending) {
-          rc = finish(J, *C, *L, *pending);
-          pending = nullptr;
+          rc = compute(J, *C, *L, S);
+        if (rc == 0)
+          fOut[cur] = helper([&J, C, L, &S, &finish]() { return finish(J, *C, *L, S); });
+        if (nextIt) {
+          const int r2 = fIn.get();
+          rc = rc ? rc : r2;
         }
-        if (rc == 0)
-          pending = &C->slot[cur];
         cur ^= 1;
         it = nextIt;
       }
-      if (rc == 0 && pending)
-        rc = finish(J, *C, *L, *pending);
-      if (rc)
-        J.failed = rc;
     }
     catch (...) {
-      J.failed = -1;
+      rc = -1;
     }
+    for (auto& f : fOut)   // (also after a failure: a helper may still be at work on this worker's buffers)
+      if (f.valid()) {
+        int r2 = -1;
+        try {
+          r2 = f.get();
+        }
+        catch (...) {
+        }
+        rc = rc ? rc : r2;
+      }
+    if (fIn.valid()) {
+      try {
+        (void)fIn.get();
+      }
+      catch (...) {
+      }
+    }
+    if (rc)
+      J.failed = rc;
     // nothing of this worker may still be in flight when its buffers go back to the pool (a failed
     // item leaves copies queued on the lanes: they are waited for here as well)
     (void)hipStreamSynchronize(C->st);

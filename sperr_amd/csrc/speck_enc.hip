@@ -557,11 +557,20 @@ __device__ __forceinline__ void load_list4(const EncBuffers& b, uint32_t c, cons
   }
 }
 
-__global__ void __launch_bounds__(kThreads) k_list_count(EncBuffers b, int p)
+// clearPrev: first the part of the birth masks the plane before used is cleared (s.lisBits still is that
+// plane's; a launch of its own until round 4 -- nothing between here and k_split_emit touches the masks)
+__global__ void __launch_bounds__(kThreads) k_list_count(EncBuffers b, int p, int clearPrev)
 {
   const uint32_t c = blockIdx.y;
   const EncState& s = b.st[c];
   ACTIVE_OR_RETURN(s, p);
+  if (clearPrev && b.nSlots) {
+    const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
+    const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x)
+      for (uint32_t slot = 0; slot < b.nSlots; slot++)
+        b.mask[c * b.maskStride + (size_t)slot * b.maskWords + w] = 0;
+  }
   __shared__ uint64_t sm[kThreads / 64 + 1];
   for (uint32_t tile = blockIdx.x; tile < b.nListTiles; tile += gridDim.x) {
     if (b.tileStart[tile] >= s.listLen[s.cur][b.tileLevel[tile]]) {   // past the end of its list
@@ -1045,18 +1054,6 @@ __global__ void __launch_bounds__(kThreads) k_born_place(EncBuffers b, int p)
   }
 }
 
-// clear the part of the birth masks this plane used
-__global__ void __launch_bounds__(kThreads) k_mask_clear(EncBuffers b, int p)
-{
-  const uint32_t c = blockIdx.y;
-  const EncState& s = b.st[c];
-  ACTIVE_OR_RETURN(s, p);
-  const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
-  const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x)
-    for (uint32_t slot = 0; slot < b.nSlots; slot++)
-      b.mask[c * b.maskStride + (size_t)slot * b.maskWords + w] = 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // k_emit_pixels: LIP-scan bits and refinement bits of every processed plane, raster order.
@@ -1344,10 +1341,10 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
     LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, maxPlanes);
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
-  const uint32_t maskBlocks = (b.maskWords + kThreads - 1) / kThreads;
   LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, maxPlanes - 1);
   for (int p = maxPlanes - 1; p >= 0; p--) {
-    LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p,
+             p < maxPlanes - 1 ? 1 : 0);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
     if (b.tree.flags & kTree2D)
@@ -1356,7 +1353,6 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
       LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_mask_clear, dim3(capped_blocks(maskBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
     }
     LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, p, p - 1);
   }

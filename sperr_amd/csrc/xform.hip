@@ -754,7 +754,7 @@ k_lift_xy(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz
 #define XYZ_INV_THREADS 1024
 #endif
 #ifndef XYZ_INV_PREFETCH
-#define XYZ_INV_PREFETCH 0
+#define XYZ_INV_PREFETCH 2   // 0: the loads of rounds 1-3 (kept for A/B builds, tools/build_variant.sh)
 #endif
 #ifndef XYZ_FWD_THREADS
 #define XYZ_FWD_THREADS 1024
@@ -765,6 +765,13 @@ constexpr int kXYZStaged = kXYZRows + 2 * kXYHalo;   // LDS rows of a slice
 constexpr int kXYZPosF = (4096 + kXYZThreadsF - 1) / kXYZThreadsF;    // z pipelines per thread, forward: kXYZRows * cx <= 4096
 constexpr int kXYZStageF = (6144 + kXYZThreadsF - 1) / kXYZThreadsF;  // staged samples per thread, forward: kXYZStaged * cx <= 6144
 constexpr int kXYZPosI = 6144 / kXYZThreadsI;   // inverse: kXYZStaged * cx <= 6144
+#ifndef XYZ_INV_GROUP
+#define XYZ_INV_GROUP 3
+#endif
+#ifndef XYZ_INV_DEFER
+#define XYZ_INV_DEFER 0   // 1: the pair's second slice stored after the next pair's loads (measured: no gain)
+#endif
+constexpr int kXYZGroupI = XYZ_INV_GROUP;       // positions whose loads are in flight together
 
 // LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
 // (the four rows above and below the tile -- mirrored at the ends of the slice, so the first and the
@@ -1086,38 +1093,6 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const uint32_t initOld = (haveMasks && lastPl < 31) ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
   // sample (dcol, drow, zp): straight from the decoder (q * double(c) * (+-1.0), src/SPECK_FLT.cpp:373-399)
   // unless a coarser level's passes have produced it
-  // The loads of a sample in two steps, so that pair m + 1's coefficients are on their way while pair m's
-  // two slices go through the y and x passes (round 4: the kernel spent half its time waiting for them):
-  // raw_issue starts the one load that comes from HBM (the 32-bit coefficient, or the fp64 sample of the
-  // coarser levels' box), raw_value turns what arrived into the sample (sign and mask words: a few words
-  // per wavefront, cache hits).
-  auto raw_issue = [&](int k, uint32_t zp) -> uint64_t {
-    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
-    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
-    const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
-    if (!dequant && !inBox && F.bufx)
-      return 0ull;
-    if (dequant && !inBox)
-      return (uint64_t)coef[(size_t)zp * sliceN + drow * cx + dcol];
-    return (uint64_t)__double_as_longlong(buf[(size_t)zp * bufSlice + drow * bufx + dcol]);
-  };
-  auto raw_value = [&](int k, uint32_t zp, uint64_t raw) -> double {
-    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
-    const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
-    const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
-    const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
-    if (!dequant && !inBox && F.bufx)
-      return 0.0;   // (a compact buffer holds the box only; the host asks for one only when every chunk dequantises here)
-    if (dequant && !inBox) {
-      uint32_t v = (uint32_t)raw;
-      const uint32_t sh = (uint32_t)(idx & 63);
-      const uint64_t sgw = sign[idx >> 6], mnw = mNew[idx >> 6], mow = mOld[idx >> 6];   // (independent loads)
-      const uint32_t fill = ((mnw >> sh) & 1ull) ? initNew : (((mow >> sh) & 1ull) ? initOld : 0u);
-      v = v ? v : fill;
-      return fq * (double)v * (((sgw >> sh) & 1ull) ? 1.0 : -1.0);
-    }
-    return __longlong_as_double((long long)raw);
-  };
   auto fetch = [&](int k, uint32_t zp) -> double {
     const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
     const uint32_t drow = (y & 1) ? ye + (y >> 1) : (y >> 1), dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
@@ -1150,9 +1125,22 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       if ((tid + (uint32_t)k * kXYZThreadsI) < npos)
         stage(k, v[k]);
   };
-  auto finish_slice = [&](uint32_t z) {
+  // rows of a finished slice (in staging buffer `which`) -> volume, mean added, narrowed
+  auto store_rows = [&](uint32_t z, uint32_t which) {
+    const double* X = sm + (which ? bufN : 0u);
+    for (uint32_t r = wave; r < nt; r += nwaves) {
+      VT* dstrow = volc + (size_t)z * vsz + (size_t)(y0 + r) * vsy;
+      const double* srow = X + (size_t)(kXYHalo + r) * RS + 4;
+      for (uint32_t x = lane; x < cx; x += 64)
+        dstrow[x] = (VT)(srow[x] + mean);
+    }
+  };
+  // `defer`: the caller stores the slice's rows later -- store_rows(z, flip ^ 1), before the next
+  // finish_slice (whose y pass overwrites that buffer after its first barrier)
+  auto finish_slice = [&](uint32_t z, bool defer = false) {
     uint32_t RSv = RS, tidv = tid;   // (see k_lift_xyz_fwd)
     asm volatile("" : "+s"(RSv), "+v"(tidv));
+    const uint32_t which = flip;
     double* X = sm + (flip ? bufN : 0u);
     double* Y = sm + (flip ? 0u : bufN);
     flip ^= 1u;
@@ -1161,12 +1149,8 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     XYZ_LDS_BARRIER();
     xyz_lift_x<false, kXYZThreadsI>(Y, X, RSv, cx, kXYHalo, kXYHalo + nt, tidv, K);
     XYZ_LDS_BARRIER();
-    for (uint32_t r = wave; r < nt; r += nwaves) {
-      VT* dstrow = volc + (size_t)z * vsz + (size_t)(y0 + r) * vsy;
-      const double* srow = X + (size_t)(kXYHalo + r) * RSv + 4;
-      for (uint32_t x = lane; x < cx; x += 64)
-        dstrow[x] = (VT)(srow[x] + mean);
-    }
+    if (!defer)
+      store_rows(z, which);
     // (the next slice is staged into Y, which nobody reads any more; its y pass writes X only after
     //  the barrier behind that staging, when every row above has been stored)
   };
@@ -1176,58 +1160,151 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   for (int k = 0; k < kXYZPosI; k++)
     o1p[k] = e1p[k] = o2p[k] = e2p[k] = 0.0;
   const uint32_t npairs = cz / 2;
-#if XYZ_INV_PREFETCH
-  uint64_t rawE[kXYZPosI], rawO[kXYZPosI];
-#pragma unroll
-  for (int k = 0; k < kXYZPosI; k++) {
-    rawE[k] = rawO[k] = 0;
-    if ((tid + (uint32_t)k * kXYZThreadsI) < npos && mFirst < mB) {
-      rawE[k] = raw_issue(k, mFirst);
-      rawO[k] = raw_issue(k, ze + mFirst);
+  // one pair (low[m], high[m]) of position k enters its pipeline; slice 2m-3's sample is staged
+  auto zstep = [&](int k, uint32_t m, bool mine, bool active, double E, double O) {
+    const double o1 = (-K.eps) * O;                                        // o1[m]
+    const double t = K.delta * ((m == 0 ? o1 : o1p[k]) + o1);
+    const double e1 = fma(E, K.inv_eps, -t);                               // e1[m]
+    if (m >= 1) {
+      const double o2 = fma(-K.gamma, e1p[k] + e1, o1p[k]);                // o2[m-1]
+      const double e2 = fma(-K.beta, (m == 1 ? o2 : o2p[k]) + o2, e1p[k]); // e2[m-1]
+      if (m >= 2 && mine && active)
+        stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                      // o3[m-2]: slice 2m-3
+      o2p[k] = o2;
+      e2p[k] = e2;
     }
-  }
+    o1p[k] = o1;
+    e1p[k] = e1;
+  };
+#if XYZ_INV_PREFETCH == 2
+  // Round 4.  The kernel spent half its time waiting for loads, one after the other: every sample's sign and
+  // mask words sat behind a branch of their own (box or not), so a pair was some thirty-six dependent round
+  // trips.  Now (chunks that dequantise here):
+  //  * pair m + 1's coefficients travel from HBM straight into LDS (global_load_lds: no register holds them)
+  //    while pair m's two slices go through the y and x passes; every wavefront has its own 64-dword row
+  //    per (position, low / high half) behind the two staging buffers.  They are issued AFTER the pair's
+  //    own loads: the memory counter retires in order, a wait for those would wait for these too;
+  //  * the sign / mask dwords and the fp64 samples of the coarser levels' box (an eighth of all) are loaded
+  //    without any branch -- a lane that does not need one reads a harmless address --, three positions'
+  //    worth at a time: two round trips per pair.
+  // The arithmetic per sample is what it was.
+  uint32_t* myPre = reinterpret_cast<uint32_t*>(sm + 2 * (size_t)bufN) + (size_t)wave * (kXYZPosI * 2 * 64);
+  const uint32_t* sign32 = reinterpret_cast<const uint32_t*>(sign);
+  const uint32_t* mNew32 = reinterpret_cast<const uint32_t*>(mNew);
+  const uint32_t* mOld32 = reinterpret_cast<const uint32_t*>(mOld);
+  uint32_t activeMask = 0;
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++)
+    if ((tid + (uint32_t)k * kXYZThreadsI) < npos)
+      activeMask |= 1u << k;
+    else
+      pk[k] = pk[0];   // (a valid position: its loads are harmless, nothing of it is staged)
+  auto pos_off = [&](int k, uint32_t& drow, uint32_t& dcol) {
+    const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
+    drow = (y & 1) ? ye + (y >> 1) : (y >> 1);
+    dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
+  };
+  auto pre_issue = [&](uint32_t m) {
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++) {
+      uint32_t drow, dcol;
+      pos_off(k, drow, dcol);
+      const uint32_t off = drow * cx + dcol;
+      __builtin_amdgcn_global_load_lds(coef + ((size_t)m * sliceN + off), myPre + (k * 2) * 64, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(coef + ((size_t)(ze + m) * sliceN + off), myPre + (k * 2 + 1) * 64, 4, 0, 0);
+    }
+  };
+  // (a high-half sample never lies in the next level's box when that box ends at or before the low half)
+  const bool fastLoads = dequant && F.inner[2] <= ze;
+  if (fastLoads && mFirst < mB)
+    pre_issue(mFirst);
 #endif
   for (uint32_t m = mFirst; m < mB; m++) {
     const bool mine = m >= mA;   // (else: the segment's run-up)
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++)
       asm volatile("" : "+v"(pk[k]));
+#if XYZ_INV_PREFETCH == 2
+    if (fastLoads) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pair's coefficients have landed in LDS
 #pragma unroll
-    for (int k = 0; k < kXYZPosI; k++) {
-      if ((k % 3) == 0)
-        __builtin_amdgcn_sched_barrier(0);   // (four positions' loads in flight at a time, not all twelve)
-      if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
-        continue;
-#if XYZ_INV_PREFETCH
-      const double E = raw_value(k, m, rawE[k]), O = raw_value(k, ze + m, rawO[k]);
-      if (m + 1 < mB) {   // (the next pair's: in flight while this pair's slices are finished)
-        rawE[k] = raw_issue(k, m + 1);
-        rawO[k] = raw_issue(k, ze + m + 1);
+      for (int g = 0; g < kXYZPosI; g += kXYZGroupI) {
+        __builtin_amdgcn_sched_barrier(0);   // (kXYZGroupI positions' loads in flight at a time)
+        constexpr int NV = 2 * kXYZGroupI;
+        uint32_t sgw[NV], mnw[NV], mow[NV], cv[NV], shv[NV], boxm = 0;
+        double bx[kXYZGroupI];   // (only a low-half sample can lie in the box: fastLoads)
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+          const int k = g + j / 2;
+          if (k >= kXYZPosI)
+            continue;
+          const uint32_t zp = (j & 1) ? ze + m : m;
+          uint32_t drow, dcol;
+          pos_off(k, drow, dcol);
+          const size_t idx = (size_t)zp * sliceN + drow * cx + dcol;
+          sgw[j] = sign32[idx >> 5];
+          mnw[j] = mNew32[idx >> 5];
+          mow[j] = mOld32[idx >> 5];
+          if ((j & 1) == 0) {
+            const bool inBox = ((innerMask >> k) & 1u) && zp < F.inner[2];
+            boxm |= inBox ? 1u << j : 0u;
+            bx[j / 2] = buf[inBox ? (size_t)zp * bufSlice + drow * bufx + dcol : (size_t)0];
+          }
+          cv[j] = myPre[(k * 2 + (j & 1)) * 64 + lane];
+          shv[j] = (uint32_t)idx & 31u;
+        }
+        double val[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+          if (g + j / 2 >= kXYZPosI)
+            continue;
+          const uint32_t fill = ((mnw[j] >> shv[j]) & 1u) ? initNew : (((mow[j] >> shv[j]) & 1u) ? initOld : 0u);
+          const uint32_t v = cv[j] ? cv[j] : fill;
+          const double dq = fq * (double)v * (((sgw[j] >> shv[j]) & 1u) ? 1.0 : -1.0);
+          val[j] = ((j & 1) == 0 && ((boxm >> j) & 1u)) ? bx[j / 2] : dq;
+        }
+#pragma unroll
+        for (int kk = 0; kk < kXYZGroupI; kk++)
+          if (g + kk < kXYZPosI)
+            zstep(g + kk, m, mine, ((activeMask >> (g + kk)) & 1u) != 0, val[2 * kk], val[2 * kk + 1]);
       }
-#else
-      const double E = fetch(k, m), O = fetch(k, ze + m);
+      __builtin_amdgcn_sched_barrier(0);
+      // the second slice of the pair before is stored only now: the wait above would have waited for those
+      // stores to be acknowledged had they been issued before it (the memory counter retires in order)
+      if (XYZ_INV_DEFER && m >= 2 && m - 1 >= mA)
+        store_rows(2 * m - 4, flip ^ 1u);
+      if (m + 1 < mB)
+        pre_issue(m + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    else
 #endif
-      const double o1 = (-K.eps) * O;                                        // o1[m]
-      const double t = K.delta * ((m == 0 ? o1 : o1p[k]) + o1);
-      const double e1 = fma(E, K.inv_eps, -t);                               // e1[m]
-      if (m >= 1) {
-        const double o2 = fma(-K.gamma, e1p[k] + e1, o1p[k]);                // o2[m-1]
-        const double e2 = fma(-K.beta, (m == 1 ? o2 : o2p[k]) + o2, e1p[k]); // e2[m-1]
-        if (m >= 2 && mine)
-          stage(k, fma(-K.alpha, e2p[k] + e2, o2p[k]));                      // o3[m-2]: slice 2m-3
-        o2p[k] = o2;
-        e2p[k] = e2;
+    {
+#pragma unroll
+      for (int k = 0; k < kXYZPosI; k++) {
+        if ((k % 3) == 0)
+          __builtin_amdgcn_sched_barrier(0);   // (four positions' loads in flight at a time, not all twelve)
+        if ((tid + (uint32_t)k * kXYZThreadsI) >= npos)
+          continue;
+        const double E = fetch(k, m), O = fetch(k, ze + m);
+        zstep(k, m, mine, true, E, O);
       }
-      o1p[k] = o1;
-      e1p[k] = e1;
     }
     if (m >= 2 && mine)
       finish_slice(2 * m - 3);
     if (m >= 1 && mine) {
       stage_all(e2p);
+#if XYZ_INV_PREFETCH == 2
+      finish_slice(2 * m - 2, fastLoads && XYZ_INV_DEFER);
+#else
       finish_slice(2 * m - 2);
+#endif
     }
   }
+#if XYZ_INV_PREFETCH == 2
+  if (fastLoads && XYZ_INV_DEFER && mB >= 2 && mB - 1 >= mA && mB > mFirst)
+    store_rows(2 * mB - 4, flip ^ 1u);   // the last pair's second slice
+#endif
   // ---- the end of the lines (the last segment's)
   if (seg + 1 != nseg)
     return;
@@ -1698,7 +1775,11 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
   if (!lift_xyz_applicable(cdims) || (io != 1 && io != 2))
     return -1;
   const LiftFuse F = fuse ? *fuse : LiftFuse{};
-  const size_t smem = 2 * (size_t)kXYZStaged * xyz_row_stride(cdims[0]) * sizeof(double);   // two staging buffers
+  size_t smem = 2 * (size_t)kXYZStaged * xyz_row_stride(cdims[0]) * sizeof(double);   // two staging buffers
+#if XYZ_INV_PREFETCH == 2
+  if (!forward)
+    smem += (size_t)kXYZThreadsI * kXYZPosI * 2 * sizeof(uint32_t);   // + the coefficients on their way in
+#endif
   {
     const void* fns[4] = {reinterpret_cast<const void*>(&k_lift_xyz_fwd<1>), reinterpret_cast<const void*>(&k_lift_xyz_fwd<2>),
                           reinterpret_cast<const void*>(&k_lift_xyz_inv<1>), reinterpret_cast<const void*>(&k_lift_xyz_inv<2>)};

@@ -18,6 +18,17 @@ for _ in range(2):
     s = eng.compress(vol, (256, 256, 256), 2.0, out=cbuf)
     eng.decompress(s, True, out=out, shape_zyx=vol.shape)
 torch.cuda.synchronize()
+import time
+tc, td = [], []
+for _ in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    s = eng.compress(vol, (256, 256, 256), 2.0, out=cbuf)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    eng.decompress(s, True, out=out, shape_zyx=vol.shape)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    tc.append(t1 - t0); td.append(t2 - t1)
+print(f"lib={os.path.basename(os.environ.get('SPERR_HIP_LIB', 'default'))} wall: compress {min(tc) * 1e3:.2f} ms {vol.numel() * 4 / min(tc) / 1e9:.1f} GB/s   "
+      f"decompress {min(td) * 1e3:.2f} ms {vol.numel() * 4 / min(td) / 1e9:.1f} GB/s")
 eng.profile(True)
 for _ in range(3):
     s = eng.compress(vol, (256, 256, 256), 2.0, out=cbuf)
