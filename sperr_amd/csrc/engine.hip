@@ -1939,8 +1939,9 @@ int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci,
   return r == 0 ? 0 : -1;
 }
 
-// the lists of the larger sets GPU-wide (k_lis_hi) or one workgroup per chunk (k_lis_tables:
-// SPERR_HIP_LIS_HI=0, trees whose geometry tables do not fit the kernel's LDS, diagnostics stamps)
+// the lists of the larger sets GPU-wide (k_lis_hi); SPERR_HIP_LIS_HI=0 and regular trees whose geometry
+// tables do not fit the kernel's LDS go to k_lis_mixed, which takes any shape (k_lis_tables, one workgroup
+// per chunk, was the table kernel of rounds 1-3: removed in round 4)
 bool g_lis_stamps_on = false;
 constexpr int kHiMaxK = 9;   // longest class chain k_lis_hi takes (chunk dims up to 1024)
 bool use_lis_hi(const ShapePlan& P, bool tables)
@@ -1949,13 +1950,12 @@ bool use_lis_hi(const ShapePlan& P, bool tables)
   return hiEnv && tables && P.ht.grids.size() <= 288 && P.ht.roots.size() <= 48 &&
          P.maxK >= 1 && P.maxK <= kHiMaxK;
 }
-// every LIS level is regular and the table kernels can take the shape: k_lis_tables up to chains of
-// 8 classes, k_lis_hi one more
+// every LIS level is regular and the table kernels (k_lis_l0 / _l1 / _hi) can take the shape
 bool use_tables(const ShapePlan& P)
 {
   if (!P.ht.allRegular || P.maxK < 1)
     return false;
-  return P.maxK <= 8 || use_lis_hi(P, true);
+  return use_lis_hi(P, true);
 }
 // lists that mix set shapes (any chunk extent that is not a power of two): k_lis_mixed, tables keyed
 // by shape class and one walking thread per chunk (SPERR_HIP_LIS_MIXED=0: k_lis_walk, the serial walk)
@@ -2049,7 +2049,6 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.bornPitch = d.bornStride + (size_t)d.bornSeg * d.hiGroupsMax;
   TAKE(d.bornPacked, uint64_t, d.bornPitch * B);
   TAKE(d.bornPosLev, uint64_t, d.bornPitch * B);
-  d.tabSmemBytes = 152 * 1024;   // (k_lis_tables has 7 KB of static LDS: 160 KB in all)
   d.lisStamps = nullptr;
   if (g_lis_stamps_on) {
     TAKE(d.lisStamps, uint64_t, 64 * B);
@@ -2548,7 +2547,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        use_tables(*P), P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize / the dequantising inverse passes complete the coefficients
-        // the lists of the larger sets GPU-wide (SPERR_HIP_LIS_HI=0: k_lis_tables, one workgroup per chunk)
+        // the lists of the larger sets GPU-wide
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
@@ -2559,7 +2558,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the inverse passes dequantise on the way (not for the resolution hierarchy, whose coarsest
         // level is read before any pass has run)
         const bool fuseDq = plan_fusable(*P) && !mr && !slice;
-        // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_tables
+        // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_hi
         static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
         if (!gpuWide)
           ph.l0 = ph.l1 = false;

@@ -39,7 +39,7 @@ struct DecState {
   uint32_t hiBornCnt[8];         // births / leaf events in the workgroups' own segments
   uint32_t hiLeafCnt[8];
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes
-  uint32_t leafCount;            //   of the current plane (bornCount: all births once k_lis_tables ends)
+  uint32_t leafCount;            //   of the current plane (bornCount: all births once the list kernels end)
   uint64_t lisPhaseBits;         // bits of the plane's LIS phase covered by the birth masks
   uint32_t iPart, iPad;          // 2D coder: part_level of what is left of the type-I set (0: nothing)
   uint32_t slotBorn[spk::kMaxLevels];   // births per mask slot of the plane (k_place_scan)
@@ -97,7 +97,6 @@ struct DecBuffers {
   size_t queueStride;
   uint64_t* sigbits;           // significance bit of every old entry of the level being decoded
   size_t sigbitsStride;
-  uint32_t tabSmemBytes;       // dynamic LDS given to k_lis_tables
   uint32_t treeTabLen;         // entries of tree.tab (k_lis_walk stages the tree's tables in LDS)
   uint64_t* leafEv;            // leaf-parent splits of one plane: node id | sig mask | neg mask
   uint32_t leafCap;
@@ -140,7 +139,7 @@ struct DecBuffers {
 struct DecPlanHost {
   const uint64_t* d_initLIS;
   const uint32_t* d_initLen;
-  bool tables;                 // every LIS level is regular: use k_lis_tables
+  bool tables;                 // every LIS level is regular: the table kernels (k_lis_l0 / _l1 / _hi)
   bool l0;                     // the level of the smallest sets is made of 2x2x2 leaf sets: k_lis_l0
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)

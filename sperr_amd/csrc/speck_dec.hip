@@ -9,10 +9,10 @@
 //                always followed by its sign bit), so token starts and token ranks come from
 //                prefix sums; the results are written by token rank and picked up by the pixels
 //                through the rank of each candidate in raster order;
-//   LIS phase    (k_lis_l0/_l1/_hi or k_lis_tables; k_lis_mixed for lists that mix set shapes)  what each bit means depends
+//   LIS phase    (k_lis_l0/_l1/_hi; k_lis_mixed for lists that mix set shapes)  what each bit means depends
 //                on every earlier bit of the phase: one workgroup per chunk; chunks run
 //                concurrently;
-//   refinement   (k_ref_apply)  the j-th significant pixel in raster order takes bit j.
+//   refinement   (k_ref_apply2)  the j-th significant pixel in raster order takes bit j.
 //
 // Bits past the available length read as zero (the reference zero-pads a truncated stream,
 // SPECK_INT.cpp:95-105); the loop stops where the reference's does.
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
     const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
     // the tokens that start in this word have consecutive ranks j, j + 1, ...: their results go
     // to bits j, j + 1, ... of lipSig (found significant) and lipNeg (and negative).  The
-    // magnitude is not written here: k_ref_apply / the inverse quantiser give a newly significant
+    // magnitude is not written here: k_ref_apply2 / the inverse quantiser give a newly significant
     // coefficient its value 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it.
     uint64_t runS = 0, runN = 0;
     uint32_t i = 0;
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 // LIS phase, list of the smallest sets (2x2x2 leaf sets: class 0).  The sorting pass visits the
 // lists from the smallest sets to the largest (SPECK_INT.cpp:317-327), so this list's code starts
 // where the LIP scan ended and its entry count is known: the whole GPU decodes it before
-// k_lis_tables takes the other lists.  An entry is '0', or '1' followed by the <= 16 bits of its
+// k_lis_l1 / k_lis_hi take the other lists.  An entry is '0', or '1' followed by the <= 16 bits of its
 // eight pixels; nothing is born.  The stream is cut into blocks of kL0W bits handed out by a
 // ticket counter; each block
 //   * finds, for every bit position, the length of a token that would start there, and by pointer
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   const uint32_t cur = s.cur, nx = cur ^ 1u;
   const uint32_t n = s.listLen[cur][L];
   if (n == 0)
-    return;   // (k_lis_tables finds the list empty as well)
+    return;   // (k_lis_hi finds the list empty as well)
   extern __shared__ __attribute__((aligned(16))) char l0_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(l0_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l0_smem);
@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
 // LIS phase, the next list: 4x4x4 sets (class 1) whose children are the 2x2x2 leaf sets.  Same
 // scheme as k_lis_l0 with one more level inside a token: an entry is '0', or '1' followed by its
 // eight children, each '0' (the child joins the list of the smallest sets: a birth, recorded
-// with its stream position exactly like k_lis_tables does) or '1' + eight pixels (a leaf event).
+// with its stream position exactly like k_lis_hi does) or '1' + eight pixels (a leaf event).
 // A token takes at most 1 + 7 * 17 + 17 = 137 bits, so the tables of a block cover kL1Ahead
 // positions more than the block itself.  Births and leaf events get their slots per block: each
 // token reserves block-local slots while it is counted, the block reserves its range with one
@@ -1179,7 +1179,7 @@ k_lis_l1(DecBuffers b, int p)
   const uint32_t n = s.listLen[cur][L];
   const bool l0done = s.l0PlaneP1 == p + 1;
   if (n == 0 || (!l0done && s.listLen[cur][L0] != 0))
-    return;   // (k_lis_tables takes the list)
+    return;   // (k_lis_hi takes the list)
   extern __shared__ __attribute__((aligned(16))) char l1_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(l1_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l1_smem);
@@ -1542,18 +1542,17 @@ k_lis_l1(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
-// LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): one
-// 1024-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_par is the
-// CPU model of this kernel.
-//
-// Per window of kTabW stream bits (staged in LDS):
+// LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): what
+// k_lis_hi below shares with its predecessor k_lis_tables (one 1024-thread workgroup per chunk,
+// rounds 1-3; removed in round 4 -- a regular tree k_lis_hi cannot take goes to k_lis_mixed).
+// tests/model/speck_model.cpp::model_speck3d_decode_par is the CPU model of the method:
 //   tables   T_j[x] = bits the split of a class-j set takes when it starts at bit x (kTInf when
 //            that would leave the window): speculative, one thread per bit position and class;
-//   hop      one thread walks the entries: '0' -> next bit, '1' -> 1 + T lookup.  It only
-//            descends into an entry (serially) when the entry does not fit in any window;
+//   hop      the list entries: '0' -> next bit, '1' -> 1 + T lookup; an entry that does not fit
+//            the tables is walked into;
 //   expand   every set that splits inside the window is one work item; a thread finds its
-//            children with T_{j-1}, writes pixel results, queues significant child sets for the
-//            next round and records insignificant ones with their stream position.
+//            children with T_{j-1}, queues significant child sets for the next round and records
+//            insignificant ones with their stream position.
 // After the last level the recorded sets are ranked by position (popcount prefix of per-level
 // position masks) and appended to the next lists; old entries are compacted in order.
 // ------------------------------------------------------------------------------------------
@@ -1612,730 +1611,6 @@ __device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& 
 //   U_j[r]  the CODED item of class j at r: bit 15 = its test bit, low 15 bits = code length
 //           (1 for an insignificant item, 1 + T_j[r+1] otherwise), or kTInf when it is
 //           significant but leaves the window
-template <typename CT>
-__global__ void __launch_bounds__(kTabThreads) k_lis_tables(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.x;
-  DecState& s = b.st[c];
-  DEC_ACTIVE_OR_RETURN(s, p);
-  extern __shared__ __attribute__((aligned(16))) char tab_smem[];
-  uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
-  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(tab_smem);
-  uint32_t W = 0, TS = 0;
-  uint32_t* hop = nullptr;   // [W + 130]  cnt << 16 | stop << 15 | exit
-  uint16_t* Tt = nullptr;    // [K - 1][TS]
-  uint16_t* Uu = nullptr;    // [K][TS]
-  constexpr int kBlk = kTabWMax / 64 + 4;
-  __shared__ uint32_t blkEB[kBlk];             // entry position | entries before it << 16
-  __shared__ uint32_t sh_total, sh_stopped, sh_newr;
-  __shared__ uint64_t sh_pos;
-  __shared__ int sh_depth;
-  __shared__ TabCtx sh_ctx[kMaxClasses + 2];
-  __shared__ uint32_t sh_e, sh_rem, sh_qn[3], sh_born, sh_flag, sh_leaf;
-  __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
-  // the expansion reads the geometry of every splitting set: keep the root / grid tables in LDS
-  constexpr int kLdsRoots = 48, kLdsGrids = 288;
-  __shared__ Root sh_roots[kLdsRoots];
-  __shared__ Grid sh_grids[kLdsGrids];
-
-  const Tree& t = b.tree;
-  const int tid = threadIdx.x;
-  const bool ldsGeom = t.nroots <= (uint32_t)kLdsRoots && t.ngrids <= (uint32_t)kLdsGrids;
-  if (ldsGeom) {
-    for (uint32_t i = tid; i < t.nroots; i += kTabThreads)
-      sh_roots[i] = t.roots[i];
-    for (uint32_t i = tid; i < t.ngrids; i += kTabThreads)
-      sh_grids[i] = t.grids[i];
-  }
-  const uint64_t* words = b.stream + c * b.streamStride;
-  const uint64_t nwordsAvail = (s.avail + 63) / 64;
-  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
-  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
-  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
-  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
-  const CT thr = (CT)1 << p;
-  const CT init = thr + thr - thr / 2 - 1;
-  const uint32_t cur = s.cur, nx = cur ^ 1u;
-  const uint64_t phase0 = s.lipStart + s.lipBits;
-  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
-  uint64_t* qbuf[2] = {b.queue + c * b.queueStride, b.queue + c * b.queueStride + b.queueCap * 2};
-  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
-  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
-  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
-
-  uint64_t* leafEv = b.leafEv + c * b.leafStride;
-  // the list of the smallest sets may already have been decoded by k_lis_l0
-  const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
-  const bool l1done = b.l1Level >= 0 && s.l1PlaneP1 == p + 1;
-  if (tid == 0) {
-    sh_pos = l1done ? s.l1End : l0done ? s.l0End : phase0;
-    sh_born = s.bornCount;
-    sh_leaf = s.leafCount;
-  }
-  __syncthreads();
-  // diagnostic stamps (thread 0 only, when b.lisStamps != nullptr): ticks per phase
-  uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t stamp_t = 0;
-  const bool stamps = b.lisStamps != nullptr && tid == 0;
-#define STAMP(i)                                        \
-  if (stamps) {                                         \
-    const uint64_t now_ = __builtin_readcyclecounter(); \
-    stamp_acc[i] += now_ - stamp_t;                     \
-    stamp_t = now_;                                     \
-  }
-  if (stamps)
-    stamp_t = __builtin_readcyclecounter();
-
-  uint32_t wq0 = 0;  // bit offset of window position 0 inside wbits[0]
-  auto bit_at = [&](uint32_t r) -> uint32_t {
-    const uint32_t q = r + wq0;
-    return (w32[q >> 5] >> (q & 31)) & 1u;
-  };
-  auto bits32 = [&](uint32_t r) -> uint32_t {  // 32 stream bits starting at r
-    const uint32_t q = r + wq0, sh = q & 31;
-    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
-    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-  };
-  auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
-    atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
-    if (sig) {
-      atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
-      if (!signbit)
-        atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
-    }
-  };
-  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
-    const uint64_t rel = abs - phase0;
-    const uint32_t slot = b.levelSlot[lev];
-    if (slot == 0xff || rel >= maskBits)
-      return;  // past the usable stream: decoding stops after this plane anyway
-    const uint32_t k = atomicAdd(&sh_born, 1u);
-    if (k >= b.bornStride)
-      return;
-    bornPacked[k] = packed;
-    bornPosLev[k] = ((uint64_t)lev << 48) | rel;
-    atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
-                1ull << (rel & 63));
-  };
-
-  for (uint32_t l = t.nlevels; l-- > 0;) {
-    if ((l0done && l == (uint32_t)b.l0Level) || (l1done && l == (uint32_t)b.l1Level))
-      continue;
-    const uint32_t n = s.listLen[cur][l];
-    if (n == 0) {
-      if (tid == 0)
-        s.listLen[nx][l] = 0;
-      continue;
-    }
-    const LevelClass C = b.levelClass[l];
-    const int K = C.K;
-    // children of a class-j set and the LIS level of class j, one byte per class, in registers:
-    // indexing the struct would be a scratch (vector-memory) load, and those queue behind every
-    // global store a thread has in flight
-    uint64_t arityP = 0, levP = 0;
-    for (int j = 0; j < K && j < 8; j++) {
-      arityP |= (uint64_t)C.arity[j] << (8 * j);
-      levP |= (uint64_t)C.lev[j] << (8 * j);
-    }
-    auto arity_of = [&](int j) -> int { return (int)((arityP >> (8 * j)) & 0xffull); };
-    auto lev_of = [&](int j) -> uint32_t { return (uint32_t)((levP >> (8 * j)) & 0xffull); };
-    W = tab_window(K, b.tabSmemBytes);
-    TS = W + 2;
-    const uint32_t kWords = W / 64 + 4;
-    hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);
-    Tt = reinterpret_cast<uint16_t*>(hop + (W + 130));
-    Uu = Tt + (size_t)(K - 1) * TS;
-    const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
-    const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
-    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kTabThreads)
-      sigbits[i] = 0;
-    if (tid == 0) {
-      sh_depth = 1;
-      sh_rem = n;
-      sh_e = 0;
-    }
-    __syncthreads();
-
-    // split length of a class-j set starting at r (uses the tables of class j-1).  Octree
-    // classes (8 children) take straight-line code: an item that leaves the window parks the
-    // cursor on index W + 1, whose entries are kTInf in every table, so there is no early exit.
-    auto split_len = [&](int j, uint32_t r) -> uint32_t {
-      const int ar = arity_of(j);
-      if (j == 0) {
-        if (r >= W)
-          return kTInf;
-        const uint32_t v = bits32(r);
-        uint32_t y = 0, found = 0;
-        if (ar == 8) {
-#pragma unroll
-          for (int i = 0; i < 7; i++) {
-            const uint32_t bit = (v >> y) & 1u;
-            found |= bit;
-            y += 1u + bit;
-          }
-          const uint32_t bit = found ? (v >> y) & 1u : 1u;
-          y += found + bit;
-        }
-        else {
-          for (int i = 0; i < ar; i++) {
-            const uint32_t coded = found | (uint32_t)(i + 1 != ar);
-            const uint32_t bit = coded ? (v >> y) & 1u : 1u;
-            y += coded;
-            found |= bit;
-            y += bit;  // sign bit
-          }
-        }
-        return r + y <= W ? y : kTInf;
-      }
-      const uint16_t* Up = Uu + (size_t)(j - 1) * TS;
-      const uint16_t* Tp = Tt + (size_t)(j - 1) * TS;
-      if (ar == 8) {
-        uint32_t y = min(r, W + 1), fl = 0;
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-          const uint32_t u = Up[y];
-          fl |= u;
-          y = min(y + (u & 0x7fffu), W + 1);
-        }
-        const uint32_t v = ((fl & 0x8000u) ? Up : Tp)[y];
-        return (y > W || v == kTInf) ? kTInf : y + (v & 0x7fffu) - r;
-      }
-      uint32_t y = r, found = 0;
-      for (int i = 0; i + 1 < ar; i++) {
-        const uint32_t u = Up[y];
-        if (u == kTInf)
-          return kTInf;
-        found |= u >> 15;
-        y += u & 0x7fffu;
-      }
-      uint32_t last;
-      if (found) {
-        const uint32_t u = Up[y];
-        if (u == kTInf)
-          return kTInf;
-        last = u & 0x7fffu;
-      }
-      else {
-        last = Tp[y];
-        if (last == kTInf)
-          return kTInf;
-      }
-      return y + last - r;
-    };
-
-    while (sh_depth > 0) {
-      if (sh_depth == 1) {
-        // A window always starts at a significant entry: the insignificant entries in front of it
-        // (one '0' each) are counted off the stream without building tables.  In the sparse
-        // planes whole lists go this way.
-        __syncthreads();
-        if (tid == 0) {
-          uint64_t pos = sh_pos;
-          uint32_t rem = sh_rem, e = sh_e;
-          while (rem) {
-            const uint64_t wi = pos >> 6;
-            const uint32_t sh = (uint32_t)(pos & 63);
-            const uint64_t lo = wi < nwordsAvail ? words[wi] : 0ull;
-            const uint64_t hi = wi + 1 < nwordsAvail ? words[wi + 1] : 0ull;
-            const uint64_t bits = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-            const uint32_t z = min(bits ? (uint32_t)__ffsll((long long)bits) - 1u : 64u, rem);
-            pos += z;
-            e += z;
-            rem -= z;
-            if (z < 64)
-              break;   // (a '1' follows, or the list has ended)
-          }
-          sh_pos = pos;
-          sh_e = e;
-          sh_rem = rem;
-          if (rem == 0)
-            sh_depth = 0;
-        }
-        __syncthreads();
-        if (sh_depth == 0)
-          break;
-      }
-      const uint64_t a = sh_pos;
-      __syncthreads();  // everyone has read sh_pos / sh_depth before thread 0 changes them
-      const uint64_t w0 = a >> 6;
-      wq0 = (uint32_t)(a & 63);
-      for (uint32_t i = tid; i < kWords; i += kTabThreads) {
-        const uint64_t idx = w0 + i;
-        wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
-      }
-      __syncthreads();
-      STAMP(0);
-      // ---- tables (indices W and W + 1 of every table hold kTInf)
-      for (int j = 0; j < K; j++) {
-        uint16_t* Uj = Uu + (size_t)j * TS;
-        if (j < K - 1) {
-          uint16_t* Tj = Tt + (size_t)j * TS;
-          // two independent positions per iteration: their LDS chains overlap.  The thread that has
-          // T_j[r] also writes the coded form of the item one position earlier, U_j[r - 1] (its
-          // test bit, then a class-j split from r), so a class costs one pass and one barrier.
-          auto coded = [&](uint32_t q, uint32_t tl) -> uint16_t {   // U_j[q] given T_j[q + 1]
-            if (q >= W)
-              return (uint16_t)kTInf;
-            if (!bit_at(q))
-              return (uint16_t)1;
-            return (uint16_t)(tl == kTInf ? kTInf : (0x8000u | (1u + tl)));
-          };
-          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
-            const uint32_t r2 = r + kTabThreads;
-            const uint32_t t1 = split_len(j, r);
-            const uint32_t t2 = r2 <= W + 1 ? split_len(j, r2) : kTInf;
-            Tj[r] = (uint16_t)t1;
-            if (r >= 1)
-              Uj[r - 1] = coded(r - 1, t1);
-            if (r2 <= W + 1) {
-              Tj[r2] = (uint16_t)t2;
-              Uj[r2 - 1] = coded(r2 - 1, t2);
-            }
-            if (r == W + 1 || r2 == W + 1)
-              Uj[W + 1] = (uint16_t)kTInf;
-          }
-        }
-        else {  // the level's own class: only the coded form is ever needed
-          for (uint32_t r = tid; r <= W + 1; r += 2 * kTabThreads) {
-            const uint32_t r2 = r + kTabThreads;
-            const uint32_t t1 = r < W ? split_len(j, r + 1) : kTInf;
-            const uint32_t t2 = r2 < W ? split_len(j, r2 + 1) : kTInf;
-            uint32_t u1 = kTInf, u2 = kTInf;
-            if (r < W)
-              u1 = !bit_at(r) ? 1u : (t1 == kTInf ? kTInf : (0x8000u | (1u + t1)));
-            if (r2 < W)
-              u2 = !bit_at(r2) ? 1u : (t2 == kTInf ? kTInf : (0x8000u | (1u + t2)));
-            Uj[r] = (uint16_t)u1;
-            if (r2 <= W + 1)
-              Uj[r2] = (uint16_t)u2;
-          }
-        }
-        __syncthreads();
-      }
-      if (stamps) {  // per chain length K: windows, table ticks
-        uint64_t* out = b.lisStamps + (size_t)c * 64;
-        out[16 + K] += 1;
-        out[32 + K] += __builtin_readcyclecounter() - stamp_t;
-      }
-      STAMP(1);
-      if (stamps)
-        stamp_acc[9] += 1;
-      // ---- hop, part S: contexts below the list (an entry larger than a window is being
-      //      walked into) are handled serially by one thread
-      if (tid == 0) {
-        uint32_t r = 0;
-        int depth = sh_depth;
-        uint32_t qn = 0;
-        bool full = false;
-        while (depth > 1 && !full) {
-          TabCtx& cx = sh_ctx[depth - 1];
-          if (cx.remaining == 0) {
-            depth--;
-            continue;
-          }
-          const bool coded = cx.found || cx.remaining > 1;
-          if (cx.cls < 0) {  // pixel item of a descended leaf parent
-            uint32_t bit = 1, y = r;
-            if (coded) {
-              if (y >= W) {
-                full = true;
-                break;
-              }
-              bit = bit_at(y);
-              y++;
-            }
-            if (bit && y >= W) {
-              full = true;
-              break;
-            }
-            const uint32_t ridx = reg_child_raster(t, unpack_node(cx.parent), cx.nextOrd);
-            pixel_event(ridx, bit != 0, bit ? bit_at(y) : 1u);
-            if (bit) {
-              y++;
-              cx.found = 1;
-            }
-            cx.remaining--;
-            cx.nextOrd++;
-            r = y;
-            continue;
-          }
-          const int cls = cx.cls;
-          const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd);
-          uint32_t sig, start, len;   // test bit, first bit of the split, bits of the split
-          if (coded) {
-            const uint32_t u = r < W ? Uu[(size_t)cls * TS + r] : kTInf;
-            if (u == 1) {  // insignificant
-              record_born(lev_of(cls), a + r, kid);
-              cx.remaining--;
-              cx.nextOrd++;
-              r += 1;
-              continue;
-            }
-            if (r >= W) {
-              full = true;
-              break;
-            }
-            sig = 1;
-            start = r + 1;
-            len = u == kTInf ? kTInf : (u & 0x7fffu) - 1u;
-          }
-          else {
-            sig = 1;
-            start = r;
-            len = Tt[(size_t)cls * TS + r];
-          }
-          (void)sig;
-          if (len == kTInf && r != 0) {
-            full = true;  // retry at the start of the next window
-            break;
-          }
-          cx.found = 1;
-          cx.remaining--;
-          cx.nextOrd++;
-          if (len != kTInf) {
-            qbuf[0][qn * 2] = kid;
-            qbuf[0][qn * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)cls << 1);
-            qn++;
-            r = start + len;
-          }
-          else {  // larger than a window: walk into it
-            r = start;
-            TabCtx& nc = sh_ctx[depth];
-            nc.parent = kid;
-            nc.remaining = arity_of(cls);
-            nc.cls = (int8_t)(cls - 1);
-            nc.found = 0;
-            nc.nextOrd = 0;
-            depth++;
-          }
-        }
-        sh_pos = a + r;
-        sh_depth = depth;
-        sh_qn[0] = qn;
-        sh_qn[1] = 0;
-        sh_qn[2] = 0;
-        sh_flag = full ? 1u : 0u;
-      }
-      __syncthreads();
-      STAMP(2);
-      // ---- hop, part P: the list itself, in parallel.  64-bit blocks aligned to stream words;
-      //      (P1) per block a backward memo: where the chain leaves the block from each position
-      //      and how many entries it passes; (P2) one thread walks the blocks; (P3) the blocks
-      //      emit their entries.
-      const uint32_t pr = (uint32_t)(sh_pos - a);   // first position of the list part
-      const bool doP = sh_depth == 1 && sh_flag == 0 && sh_rem > 0 && pr < W;
-      __syncthreads();
-      if (doP) {
-        const uint32_t remaining = sh_rem;
-        const uint32_t e0 = sh_e;
-        // hop index h = (r + wq0) - 64 * firstBlock, so blocks are stream words
-        const uint32_t fb = (pr + wq0) >> 6;
-        const uint32_t nblk = ((W - 1 + wq0) >> 6) - fb + 1;
-        const int32_t rbase = (int32_t)(fb * 64) - (int32_t)wq0;   // r = h + rbase
-        {  // P1: one wavefront per block, lane = position; in-block chains by pointer jumping
-          const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
-          for (uint32_t bi = wave; bi < nblk; bi += kTabThreads / 64) {
-            const uint32_t h = bi * 64 + lane;
-            const int32_t rs = (int32_t)h + rbase;
-            const bool live = rs >= (int32_t)pr && rs < (int32_t)W;
-            // state: cnt << 16 | stop << 15 | position the chain has reached (window-relative);
-            // inb: that position is an entry of this block, so the chain goes on
-            uint32_t v = 0x8000u;
-            bool inb = false;
-            const uint32_t hEnd = (bi + 1) * 64;
-            if (live) {
-              const uint32_t r = (uint32_t)rs;
-              const uint32_t u = Utop[r];
-              if (u == kTInf)
-                v = 0x8000u | r;
-              else {
-                const uint32_t nr = r + (u & 0x7fffu);
-                v = (1u << 16) | nr;
-                inb = nr < W && (uint32_t)((int32_t)nr - rbase) < hEnd;
-              }
-            }
-            for (int it = 0; it < 6 && __any(inb); it++) {
-              const uint32_t src = (uint32_t)((int32_t)(v & 0x7fffu) - rbase) & 63u;
-              const uint32_t o = __shfl(v, src, 64);
-              if (inb) {
-                v = (v & 0xffff0000u) + o;   // counts add, exit / stop come from ahead
-                const uint32_t np = v & 0x7fffu;
-                inb = !(v & 0x8000u) && np < W && (uint32_t)((int32_t)np - rbase) < hEnd;
-              }
-            }
-            const uint32_t out = v;
-            if (live)
-              hop[h] = out;
-            if (lane == 0)
-              blkEB[bi] = 0xffffffffu;
-          }
-        }
-        __syncthreads();
-        // widen the memo from 64- to 128- and 256-bit blocks: one more jump per level, through
-        // LDS.  In-place and racy on purpose: whichever version of hop[] a thread reads, old or
-        // already widened, is a correct summary of the chain from that position.
-        for (uint32_t wide = 128; wide <= 256; wide <<= 1) {
-          for (uint32_t h = (uint32_t)tid; h < nblk * 64; h += kTabThreads) {
-            const int32_t rs = (int32_t)h + rbase;
-            if (rs < (int32_t)pr || rs >= (int32_t)W)
-              continue;
-            const uint32_t v = hop[h];
-            if (v & 0x8000u)
-              continue;
-            const uint32_t er = v & 0x7fffu;
-            if (er >= W)
-              continue;
-            const uint32_t eh = (uint32_t)((int32_t)er - rbase);
-            if (eh / wide != h / wide)
-              continue;
-            const uint32_t v2 = hop[eh];
-            hop[h] = (v & 0xffff0000u) + v2;
-          }
-          __syncthreads();
-        }
-        STAMP(3);
-        if (tid == 0) {  // P2
-          uint32_t r = pr, total = 0, stopped = 0, newr = 0xffffffffu;
-          while (true) {
-            if (r >= W) {
-              newr = r;
-              break;
-            }
-            const uint32_t h = (uint32_t)((int32_t)r - rbase);
-            const uint32_t v = hop[h];
-            const uint32_t cn = v >> 16;
-            blkEB[h >> 6] = r | (total << 16);
-            if (total + cn >= remaining) {
-              total = remaining;   // the list ends inside this block; P3 reports where
-              break;
-            }
-            total += cn;
-            if (v & 0x8000u) {
-              stopped = 1;
-              newr = v & 0x7fffu;
-              break;
-            }
-            r = v & 0x7fffu;
-          }
-          sh_total = total;
-          sh_stopped = stopped;
-          sh_newr = newr;
-        }
-        __syncthreads();
-        STAMP(4);
-        if ((uint32_t)tid < nblk && blkEB[tid] != 0xffffffffu) {  // P3
-          const uint32_t eb = blkEB[tid];
-          uint32_t r = eb & 0xffffu;
-          const uint32_t base = eb >> 16;
-          const uint32_t cn = hop[(uint32_t)((int32_t)r - rbase)] >> 16;
-          const uint32_t lim_k = min(cn, remaining - base);
-          for (uint32_t k = 0; k < lim_k; k++) {
-            const uint32_t u = Utop[r];
-            if (u & 0x8000u) {
-              const uint32_t ei = e0 + base + k;
-              const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
-              qbuf[0][slot * 2] = ei;
-              qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
-              atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
-            }
-            r += u & 0x7fffu;
-          }
-          if (lim_k > 0 && base + lim_k == remaining)
-            sh_newr = r;  // the list ended in this block (only one block satisfies this)
-        }
-        __syncthreads();
-        STAMP(5);
-        if (tid == 0) {  // P4
-          const uint32_t total = sh_total;
-          uint32_t e = e0 + total;
-          uint32_t rem = remaining - total;
-          uint32_t r = sh_newr;
-          int depth = 1;
-          if (sh_stopped && r == 0) {
-            // the entry at the very start of the window does not fit: walk into it
-            TabCtx& nc = sh_ctx[1];
-            nc.parent = list[e];
-            nc.remaining = arity_of(K - 1);
-            nc.cls = (int8_t)(K - 2);
-            nc.found = 0;
-            nc.nextOrd = 0;
-            atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
-            e++;
-            rem--;
-            r = 1;  // its '1'
-            depth = 2;
-          }
-          else if (rem == 0)
-            depth = 0;
-          sh_rem = rem;
-          sh_e = e;
-          sh_pos = a + r;
-          sh_depth = depth;
-        }
-        __syncthreads();
-      }
-      else {
-        if (tid == 0 && sh_depth == 1 && sh_rem == 0)
-          sh_depth = 0;
-        __syncthreads();
-      }
-      STAMP(6);
-      // ---- expand, breadth first
-      for (int round = 0;; round++) {
-        const uint32_t nin = sh_qn[round % 3];
-        if (nin == 0)
-          break;
-        const uint64_t* qin = qbuf[round & 1];
-        uint64_t* qout = qbuf[(round + 1) & 1];
-        for (uint32_t i = tid; i < nin; i += kTabThreads) {
-          const uint64_t ident = qin[i * 2], meta = qin[i * 2 + 1];
-          const int cls = (int)((meta >> 1) & 0x7f);
-          uint32_t y = (uint32_t)(meta >> 8);
-          const Node nd = unpack_node((meta & 1ull) ? list[ident] : ident);
-          const int ar = arity_of(cls);
-          const Grid g = ldsGeom ? sh_grids[nd.grid] : t.grids[nd.grid];
-          if (cls == 0) {
-            // a leaf parent: its pixel results become ONE event word (node id, significance
-            // and sign masks by child ordinal); k_leaf_apply turns the events of the plane into
-            // mask updates on the whole GPU instead of scattering from this one CU
-            const uint32_t v = bits32(y);
-            uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
-            if (ar == 8) {
-#pragma unroll
-              for (int k = 0; k < 7; k++) {
-                const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
-                sigm |= bit << k;
-                negm |= (bit & (sgn ^ 1u)) << k;
-                found |= bit;
-                yy += 1u + bit;
-              }
-              const uint32_t bit = found ? (v >> yy) & 1u : 1u;
-              const uint32_t sgn = (v >> (yy + found)) & 1u;
-              sigm |= bit << 7;
-              negm |= (bit & (sgn ^ 1u)) << 7;
-            }
-            else {
-              for (int k = 0; k < ar; k++) {
-                const uint32_t coded = found | (uint32_t)(k + 1 != ar);
-                const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
-                yy += coded;
-                const uint32_t sgn = (v >> yy) & 1u;
-                sigm |= bit << k;
-                negm |= (bit & (sgn ^ 1u)) << k;
-                found |= bit;
-                yy += bit;
-              }
-            }
-            const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) +
-                                 nd.i[0];
-            const uint32_t slot = atomicAdd(&sh_leaf, 1u);
-            if (slot < b.leafCap)
-              leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
-            continue;
-          }
-          // geometry of the children, once per item (regular shapes: every axis of the set that
-          // is longer than one sample splits; pixel coordinates are org + index)
-          const Root rt = ldsGeom ? sh_roots[g.root] : t.roots[g.root];
-          uint32_t cbase[3], cshift[3];  // child index = cbase | ((ord >> cshift) & 1) when it splits
-          uint32_t nb = 0;
-          for (int ax = 0; ax < 3; ax++) {
-            if (g.depth < rt.D[ax]) {
-              cbase[ax] = (uint32_t)nd.i[ax] * 2u;
-              cshift[ax] = nb++;
-            }
-            else {
-              cbase[ax] = nd.i[ax];
-              cshift[ax] = 31;   // (ord >> 31) == 0: no bit of the ordinal
-            }
-          }
-          const uint64_t gridBits = (uint64_t)(nd.grid + 1) << 48;
-          const uint16_t* Up = Uu + (size_t)(cls - 1) * TS;
-          uint32_t found = 0;
-          for (int k = 0; k < ar; k++) {
-            const uint64_t kid = gridBits |
-                                 ((uint64_t)(cbase[2] | (((uint32_t)k >> cshift[2]) & 1u)) << 32) |
-                                 ((uint64_t)(cbase[1] | (((uint32_t)k >> cshift[1]) & 1u)) << 16) |
-                                 (uint64_t)(cbase[0] | (((uint32_t)k >> cshift[0]) & 1u));
-            const bool coded = found || (k + 1 != ar);
-            uint32_t start = y;
-            if (coded) {
-              const uint32_t u = Up[y];
-              if (!(u & 0x8000u)) {
-                record_born(lev_of(cls - 1), a + y, kid);
-                y += 1;
-                continue;
-              }
-              start = y + 1;
-              y += u & 0x7fffu;
-            }
-            found = 1;   // (an inferred child is the last one: nothing follows it in this split)
-            const uint32_t slot = atomicAdd(&sh_qn[(round + 1) % 3], 1u);
-            qout[slot * 2] = kid;
-            qout[slot * 2 + 1] = ((uint64_t)start << 8) | ((uint64_t)(cls - 1) << 1);
-          }
-        }
-        if (tid == 0)
-          sh_qn[(round + 2) % 3] = 0;   // the counter of the round after next
-        __syncthreads();
-      }
-      STAMP(7);
-      if (stamps)   // stream bits this window consumed
-        b.lisStamps[(size_t)c * 64 + 48 + K] += sh_pos - a;
-    }
-    // ---- old entries that stayed insignificant keep their order
-    {
-      uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
-      uint32_t carry = 0;
-      const uint32_t nw = (n + 63) / 64;
-      for (uint32_t base = 0; base < nw; base += kTabThreads) {
-        const uint32_t wi = base + tid;
-        uint64_t stay = 0;
-        if (wi < nw) {
-          stay = ~__hip_atomic_load(sigbits + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t valid = n - wi * 64;
-          if (valid < 64)
-            stay &= (1ull << valid) - 1;
-        }
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), sh_scan, &total) + carry;
-        while (stay) {
-          const int k = __ffsll((long long)stay) - 1;
-          stay &= stay - 1;
-          keep[ex++] = list[wi * 64 + k];
-        }
-        carry += total;
-      }
-      if (tid == 0)
-        s.listLen[nx][l] = carry;
-      __syncthreads();
-    }
-    STAMP(8);
-  }
-
-  // ---- newborn insignificant sets join their lists in stream order: k_place_scan / _scatter /
-  //      _finish do that on the whole GPU from the position masks and the birth records
-  __syncthreads();
-  const uint64_t phaseBits = min(sh_pos - phase0, maskBits);
-  if (stamps) {
-    const uint64_t now_ = __builtin_readcyclecounter();
-    uint64_t* out = b.lisStamps + (size_t)c * 64;
-    for (int i = 0; i < 10; i++)
-      out[i] += stamp_acc[i];
-    out[10] += now_ - stamp_t;  // placement
-  }
-#undef STAMP
-  if (tid == 0) {
-    s.cur = nx;
-    s.pos = sh_pos;
-    s.nLeafEv = min(sh_leaf, b.leafCap);
-    s.bornCount = min(sh_born, (uint32_t)b.bornStride);
-    s.lisPhaseBits = phaseBits;
-    s.lastPlane = p;
-    if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
-      s.done = 1;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // LIS phase for chunks whose lists MIX set shapes (any extent that is not a power of two): one
 // 512-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_mixed is the
@@ -3574,7 +2849,7 @@ __global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
-// LIS phase, lists of the 8x8x8 and larger sets, GPU-WIDE: k_lis_tables' method (speculative
+// LIS phase, lists of the 8x8x8 and larger sets, GPU-WIDE: the table method above (speculative
 // tables per window, pointer jumping over the list entries, breadth-first expansion of the sets
 // that split inside the window) with the windows at FIXED places, so that several workgroups per
 // chunk work on one chunk's phase at a time and only a short hop stays on the serial chain.
@@ -3716,7 +2991,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   };
   uint64_t a = 0;   // absolute bit of window position 0
 
-  // ---- tables of classes [j0, j1) of level `lv`'s chain (see k_lis_tables)
+  // ---- tables of classes [j0, j1) of level `lv`'s chain (see the section comment above)
   auto split_len = [&](const LevelClass& C, int j, uint32_t r) -> uint32_t {
     const int ar = C.arity[j];
     if (j == 0) {
@@ -4388,7 +3663,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           const LevelClass& C = sh_lc[sh_level];
           const int K = C.K;
           if (act == 8) {
-            // The sets being walked into (k_lis_tables, "hop, part S"); an item that leaves the
+            // The sets being walked into (the table method's serial hop); an item that leaves the
             // tables is entered, so the chain always reaches the region's end.  The whole wavefront
             // runs this with uniform values: the children of a frame are stepped over with one table
             // look-up each, then lane k does what child k needs (its node, its birth record or
@@ -4801,7 +4076,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
   if (tid == 0) {
     if (!skip)
       s.listLen[nx][l] = carry;
-    // the workgroup that finishes last sets the chunk's state after the phase (what k_lis_tables'
+    // the workgroup that finishes last sets the chunk's state after the phase (what the one-workgroup table kernel's
     // last lines do): nobody reads the current lists any more
     __threadfence();
     if (atomicAdd(&s.hiCompactDone, 1u) == gridDim.x - 1) {
@@ -4821,7 +4096,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
 }
 
 // ------------------------------------------------------------------------------------------
-// Placement of the sets born in the plane k_lis_tables (and k_lis_l1) just decoded: a set joins
+// Placement of the sets born in the plane the list kernels just decoded: a set joins
 // the list of its level behind the entries that survived, in the order of the stream positions at
 // which the sets were born (= the reference's append order).  Every birth set one bit of its
 // level's position mask; the rank of a birth is the number of mask bits before its own.
@@ -4869,7 +4144,7 @@ __global__ void __launch_bounds__(kThreads) k_place_scatter(DecBuffers b, int p)
   const uint32_t c = blockIdx.y;
   const DecState& s = b.st[c];
   PLACE_ACTIVE_OR_RETURN(s, p);
-  const uint32_t cur = s.cur;   // (k_lis_tables has already made the next lists current)
+  const uint32_t cur = s.cur;   // (the list kernels have already made the next lists current)
   const uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
   const uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
   // the shared part, then the segments the workgroups of k_lis_hi filled
@@ -5008,100 +4283,12 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 // refinement: the j-th pixel that was significant before this plane takes bit pos + j
 // ------------------------------------------------------------------------------------------
-// Four tiles per workgroup (one per group of 256 threads): a grid sized for every tile costs a
-// quarter as many workgroups on the planes where most tiles hold nothing.
-constexpr int kRefGroups = 4;
-
-template <typename CT>
-__global__ void __launch_bounds__(kThreads * kRefGroups) k_ref_apply(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.y;
-  const DecState& s = b.st[c];
-  DEC_ACTIVE_OR_RETURN(s, p);
-  __shared__ uint32_t sm[kRefGroups][kThreads / 64 + 1];
-  __shared__ uint32_t wordBaseAll[kRefGroups][kDecTileWords];   // refinement candidates before each word
-  __shared__ uint64_t wordSigAll[kRefGroups][kDecTileWords];
-  const uint32_t grp = threadIdx.x / kThreads, gt = threadIdx.x % kThreads;
-  const uint32_t tile = blockIdx.x * kRefGroups + grp;
-  const bool on = tile < b.nPixTiles && b.tileRef[c * b.tileStride + tile] != 0;
-  uint32_t* wordBase = wordBaseAll[grp];
-  uint64_t* wordSig = wordSigAll[grp];
-  const uint32_t nw = (b.tree.nvals + 63) / 64;
-  const uint32_t w0 = tile * kDecTileWords;
-  {
-    // exclusive scan of the popcounts inside the group's 256 threads (4 wavefronts)
-    const uint32_t wi = w0 + gt;
-    const uint64_t sig = (on && wi < nw) ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
-    const uint32_t cnt = (uint32_t)__popcll(sig);
-    const uint32_t inc = wave_inclusive_scan<uint32_t>(cnt);
-    const uint32_t lane = gt & 63u, wave = gt >> 6;
-    if (lane == 63)
-      sm[grp][wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; w++)
-      base += sm[grp][w];
-    wordBase[gt] = base + inc - cnt;
-    wordSig[gt] = sig;
-  }
-  __syncthreads();
-  if (!on)
-    return;
-  const uint64_t base = s.pos + (uint64_t)b.tileRefOff[c * b.tileStride + tile];
-  const uint64_t* words = b.stream + c * b.streamStride;
-  CT* coef = reinterpret_cast<CT*>(b.coef) + c * b.coefStride;
-  const CT thr = (CT)1 << p, half = thr / 2;
-  const CT initPrev = thr * 2 + thr * 2 - thr - 1;
-  const uint32_t lane = gt & 63u, wave = gt >> 6;
-  // one wavefront per mask word: lane = sample, so coefficient accesses are contiguous.  Four words
-  // per round: their stream and coefficient loads are issued together (one word at a time left the
-  // pass waiting for a load most of the time)
-  constexpr int kRefBatch = 4;
-  for (uint32_t k0 = wave; k0 < (uint32_t)kDecTileWords; k0 += (kThreads / 64) * kRefBatch) {
-    bool act[kRefBatch];
-    uint64_t at[kRefBatch];
-    uint32_t idx[kRefBatch];
-    uint64_t sw[kRefBatch];
-    CT cv[kRefBatch];
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      const uint32_t k = k0 + (uint32_t)u * (kThreads / 64);
-      const uint64_t sig = k < (uint32_t)kDecTileWords ? wordSig[k] : 0ull;
-      act[u] = ((sig >> lane) & 1ull) != 0;
-      at[u] = act[u] ? base + wordBase[k] + (uint64_t)__popcll(sig & ((1ull << lane) - 1ull)) : 0ull;
-      act[u] = act[u] && at[u] < s.avail;   // the pass stops the moment the stream is exhausted
-      idx[u] = (w0 + k) * 64 + lane;        // (SPECK_INT.cpp:388-389)
-    }
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      sw[u] = act[u] ? words[at[u] >> 6] : 0ull;
-      cv[u] = act[u] ? coef[idx[u]] : (CT)0;
-    }
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      if (!act[u])
-        continue;
-      const int bit = (int)((sw[u] >> (at[u] & 63)) & 1);
-      CT v2 = cv[u];
-      if (v2 == 0)          // first touch: found significant on the previous plane (threshold 2*thr)
-        v2 = initPrev;      // 1.5 * (2 thr) - 1  (SPECK_INT.cpp:462-468)
-      if (p >= 1)
-        v2 = bit ? v2 + half : v2 - half;
-      else if (bit)
-        v2 += 1;
-      coef[idx[u]] = v2;
-    }
-  }
-}
-
-// The same pass with one lane per CANDIDATE instead of one per sample (round 3).  In k_ref_apply a
-// wavefront spends its instructions on the 64 samples of a mask word, of which a few percent are
-// significant in the fine subbands, where 7/8 of the samples are: it was bound by its instruction
-// count (0.3 ms per launch of 32 chunks for 10 GB of traffic per step).  Here the significant samples of
-// a tile are first listed in LDS in raster order (thread = mask word: it writes its word's set bits at
-// the word's rank, 14 bits each), then candidate r of the tile -- lane r -- takes stream bit base + r
-// and its coefficient: consecutive lanes read consecutive bits and touch the cache lines one
-// instruction of the old kernel touched each.  A workgroup of 256 threads strides over the tiles.
+// One lane per CANDIDATE (round 3; rounds 1-2 had one lane per sample of a mask word, of which a few
+// percent are significant in the fine subbands, where 7/8 of the samples are: 0.34 against 0.25 ms per
+// launch of 32 chunks).  The significant samples of a tile are first listed in LDS in raster order
+// (thread = mask word: it writes its word's set bits at the word's rank, 14 bits each), then candidate r
+// of the tile -- lane r -- takes stream bit base + r and its coefficient: consecutive lanes read
+// consecutive bits.  A workgroup of 256 threads strides over the tiles.
 template <typename CT>
 __global__ void __launch_bounds__(kThreads) k_ref_apply2(DecBuffers b, int p)
 {
@@ -5256,12 +4443,6 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
                      container);
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
   const uint32_t tokGrid = capped_blocks(tokBlocks, nc), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide);
-  const size_t tabSmem = b.tabSmemBytes;
-  if (plan.tables) {
-    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_tables<uint32_t>), (int)tabSmem) ||
-        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_tables<uint64_t>), (int)tabSmem))
-      return -1;
-  }
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
   static const uint32_t l01Cap = getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
@@ -5292,95 +4473,47 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint64_t>), (int)b.hiSmemBytes))
       return -1;
   }
-  // refinement pass with one lane per candidate (k_ref_apply2); SPERR_HIP_REF_LANES=0: one lane per sample
-  static const bool refLanes = !(getenv("SPERR_HIP_REF_LANES") && atoi(getenv("SPERR_HIP_REF_LANES")) == 0);
-  for (int p = maxPlanes - 1; p >= 0; p--) {
+  // the kernels of a plane; CT: the integer type of the coefficients (the 64-bit pass of chunks whose
+  // largest coefficient needs it, src/SPECK_FLT.cpp:324-337)
+  auto plane = [&](auto ct, int p) -> int {
+    using CT = decltype(ct);
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_words, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    if (wide_pass) {
-      LAUNCH_K(k_lip_apply<uint64_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
-      if (plan.tables) {
-        if (plan.l0)
-          LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
-        if (plan.l1)
-          LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
-        if (plan.hi) {
-          LAUNCH_K(k_lis_hi<uint64_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
-          LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
-        }
-        else if (plan.maxK <= 8)
-          LAUNCH_K(k_lis_tables<uint64_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
-        else
-          return -1;
-        if (b.nSlots) {
-          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-        }
-        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
-      }
-      else if (plan.mixed) {
-        if (b.lisStamps)
-          LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
-        else
-          LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
-        if (b.nSlots) {
-          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-        }
-        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
-      }
-      else
-        LAUNCH_K(k_lis_walk<uint64_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      if (refLanes)
-        LAUNCH_K(k_ref_apply2<uint64_t>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
-      else
-        LAUNCH_K(k_ref_apply<uint64_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
-                 dim3(kThreads * kRefGroups), 0, stream, b, p);
+    LAUNCH_K(k_lip_apply<CT>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+    if (plan.tables) {
+      if (plan.l0)
+        LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
+      if (plan.l1)
+        LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
+      if (!plan.hi)
+        return -1;   // (use_tables() implies use_lis_hi(): engine.hip)
+      LAUNCH_K(k_lis_hi<CT>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
+      LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
     }
-    else {
-      LAUNCH_K(k_lip_apply<uint32_t>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
-      if (plan.tables) {
-        if (plan.l0)
-          LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
-        if (plan.l1)
-          LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
-        if (plan.hi) {
-          LAUNCH_K(k_lis_hi<uint32_t>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
-          LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
-        }
-        else if (plan.maxK <= 8)
-          LAUNCH_K(k_lis_tables<uint32_t>, dim3(nc), dim3(kTabThreads), tabSmem, stream, b, p);
-        else
-          return -1;
-        if (b.nSlots) {
-          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-        }
-        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
-      }
-      else if (plan.mixed) {
-        if (b.lisStamps)
-          LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
-        else
-          LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
-        if (b.nSlots) {
-          LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
-          LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
-        }
-        LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
-      }
+    else if (plan.mixed) {
+      if (b.lisStamps)
+        LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
       else
-        LAUNCH_K(k_lis_walk<uint32_t>, dim3(nc), dim3(64), 0, stream, b, p);
-      if (refLanes)
-        LAUNCH_K(k_ref_apply2<uint32_t>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
-      else
-        LAUNCH_K(k_ref_apply<uint32_t>, dim3((b.nPixTiles + kRefGroups - 1) / kRefGroups, nc),
-                 dim3(kThreads * kRefGroups), 0, stream, b, p);
+        LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
     }
+    else
+      LAUNCH_K(k_lis_walk<CT>, dim3(nc), dim3(64), 0, stream, b, p);
+    if (plan.tables || plan.mixed) {
+      if (b.nSlots) {
+        LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
+        LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
+      }
+      LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
+    }
+    LAUNCH_K(k_ref_apply2<CT>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+    return 0;
+  };
+  for (int p = maxPlanes - 1; p >= 0; p--) {
+    if (wide_pass ? plane(uint64_t{}, p) : plane(uint32_t{}, p))
+      return -1;
     LAUNCH_K(k_dec_plane_end, perChunk, dim3(64), 0, stream, b, p);
     // Have the chunks run out of bits?  Asked after 16 planes and then after every second one, and
     // answered ONE QUESTION LATE: the host waits for the answer to the previous question while the

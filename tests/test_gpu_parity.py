@@ -728,7 +728,7 @@ def test_tiny_chunks_pwe(eng, oracle, shape):
 @pytest.mark.parametrize("shape", [(16, 16, 1024), (1, 1024, 1024), (32, 32, 1024), (8, 8, 4096)])
 def test_long_class_chains(eng, oracle, shape):
     """Chunks with an axis of 1024 samples: list levels whose class chain is 9 long (sets of 512 down
-    to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes and k_lis_tables does not; an
+    to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes (its predecessor k_lis_tables did not); an
     axis of 4096 (chains of 11) goes to k_lis_mixed, whose tables are keyed by shape class.
     Streams, truncated streams and whole containers against the oracle."""
     coef, sign = quantized(oracle, shape, 200000.0)
