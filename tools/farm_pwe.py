@@ -46,7 +46,7 @@ def decomp(dst, n):
 
 
 print(f"# PWE tol {tol}, {S}^3 fp32 pinned, 256^3 chunks")
-for w, item in ((3, 0), (6, 0), (8, 0), (4, 16), (2, 32), (8, 4)):
+for w, item in ((2, 0), (3, 0), (2, 8), (3, 8), (3, 11), (4, 8)):
     os.environ["SPERR_HIP_FARM_WORKERS"] = str(w)
     os.environ["SPERR_HIP_FARM_DEC_WORKERS"] = str(w)
     if item:
