@@ -506,6 +506,11 @@ struct Job {
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
   bool direct = false;   // the caller's volume is pinned: DMA instead of staging
+  // prefetch and finish of an item on helper threads beside the worker's device call (run_workers).  Not for
+  // compression without a bit budget: measured (1024^3, tolerance 1e-3 of the range, three workers) 154 ms
+  // with the helpers against 106 ms with every step on the worker's own thread -- its device call goes back
+  // to the host a dozen times per batch, and copies issued beside it get in the way of those round trips
+  bool helperThreads = true;
   // compress
   const uint8_t* src = nullptr;
   int is_float = 1, mode = 1;
@@ -756,7 +761,8 @@ int run_workers(Job& J, P&& prefetch, Cm&& compute, Fi&& finish)
       const size_t i = J.next.fetch_add(1);
       return i < J.items.size() ? &J.items[i] : nullptr;
     };
-    static const bool helpersOn = !(getenv("SPERR_HIP_FARM_ASYNC") && atoi(getenv("SPERR_HIP_FARM_ASYNC")) == 0);
+    static const int helpersEnv = getenv("SPERR_HIP_FARM_ASYNC") ? atoi(getenv("SPERR_HIP_FARM_ASYNC")) : -1;
+    const bool helpersOn = helpersEnv < 0 ? J.helperThreads : helpersEnv != 0;
     std::future<int> fIn, fOut[2];   // item i + 1's prefetch; the slots' finishes
     // (a helper thread: the worker's device, its NUMA placement by inheritance; nothing escapes it)
     auto helper = [&](auto&& fn) -> std::future<int> {
@@ -900,6 +906,7 @@ int farm_compress(const void* src, int is_float, const Dims3& vol, const Dims3& 
   //  the range: 132 ms with two workers, 106 with three)
   if (mode != 1 && !getenv("SPERR_HIP_FARM_WORKERS"))
     J.fs.workersPerDevice = 3;
+  J.helperThreads = mode == 1;
   J.items = make_items(chunks, J.esz, devs.size() * J.fs.workersPerDevice, J.fs,
                        env_size("SPERR_HIP_FARM_PER_WORKER", mode == 1 ? 6 : 2));
   assign_workers(J, devs);
