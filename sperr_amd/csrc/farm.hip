@@ -761,7 +761,8 @@ int run_workers(Job& J, P&& prefetch, Cm&& compute, Fi&& finish)
       const size_t i = J.next.fetch_add(1);
       return i < J.items.size() ? &J.items[i] : nullptr;
     };
-    static const int helpersEnv = getenv("SPERR_HIP_FARM_ASYNC") ? atoi(getenv("SPERR_HIP_FARM_ASYNC")) : -1;
+    // (SPERR_HIP_FARM_ASYNC is read at every call: the tuning sweeps change it between calls)
+    const int helpersEnv = getenv("SPERR_HIP_FARM_ASYNC") ? atoi(getenv("SPERR_HIP_FARM_ASYNC")) : -1;
     const bool helpersOn = helpersEnv < 0 ? J.helperThreads : helpersEnv != 0;
     std::future<int> fIn, fOut[2];   // item i + 1's prefetch; the slots' finishes
     // (a helper thread: the worker's device, its NUMA placement by inheritance; nothing escapes it)

@@ -4475,13 +4475,21 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   }
   // the kernels of a plane; CT: the integer type of the coefficients (the 64-bit pass of chunks whose
   // largest coefficient needs it, src/SPECK_FLT.cpp:324-337)
+  // (LAUNCH_CT: the kernel under its own name -- k_lis_hi<uint32_t>, not k_lis_hi<CT> -- for the profiler)
+#define LAUNCH_CT(kern, ...)                    \
+  do {                                          \
+    if constexpr (sizeof(CT) == 4)              \
+      LAUNCH_K(kern<uint32_t>, __VA_ARGS__);    \
+    else                                        \
+      LAUNCH_K(kern<uint64_t>, __VA_ARGS__);    \
+  } while (0)
   auto plane = [&](auto ct, int p) -> int {
     using CT = decltype(ct);
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_words, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_lip_apply<CT>, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_CT(k_lip_apply, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     if (plan.tables) {
       if (plan.l0)
@@ -4490,7 +4498,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
       if (!plan.hi)
         return -1;   // (use_tables() implies use_lis_hi(): engine.hip)
-      LAUNCH_K(k_lis_hi<CT>, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
+      LAUNCH_CT(k_lis_hi, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
       LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
     }
     else if (plan.mixed) {
@@ -4500,7 +4508,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
     }
     else
-      LAUNCH_K(k_lis_walk<CT>, dim3(nc), dim3(64), 0, stream, b, p);
+      LAUNCH_CT(k_lis_walk, dim3(nc), dim3(64), 0, stream, b, p);
     if (plan.tables || plan.mixed) {
       if (b.nSlots) {
         LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
@@ -4508,9 +4516,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
     }
-    LAUNCH_K(k_ref_apply2<CT>, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_CT(k_ref_apply2, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     return 0;
   };
+#undef LAUNCH_CT
   for (int p = maxPlanes - 1; p >= 0; p--) {
     if (wide_pass ? plane(uint64_t{}, p) : plane(uint32_t{}, p))
       return -1;

@@ -46,13 +46,18 @@ def decomp(dst, n):
 
 
 print(f"# PWE tol {tol}, {S}^3 fp32 pinned, 256^3 chunks")
-for w, item in ((2, 0), (3, 0), (2, 8), (3, 8), (3, 11), (4, 8)):
-    os.environ["SPERR_HIP_FARM_WORKERS"] = str(w)
-    os.environ["SPERR_HIP_FARM_DEC_WORKERS"] = str(w)
-    if item:
-        os.environ["SPERR_HIP_FARM_ITEM"] = str(item)
+# (workers, chunks per item or 0 = the farm's own choice, helper threads: 1 / 0 / -1 = the farm's own choice)
+SWEEP = ((0, 0, -1), (3, 0, 0), (3, 0, 1), (2, 0, 1), (3, 8, 0), (3, 6, 0), (4, 6, 0), (3, 4, 0))
+for w, item, helpers in SWEEP:
+    for k, v in (("SPERR_HIP_FARM_WORKERS", w), ("SPERR_HIP_FARM_DEC_WORKERS", w), ("SPERR_HIP_FARM_ITEM", item)):
+        if v:
+            os.environ[k] = str(v)
+        else:
+            os.environ.pop(k, None)
+    if helpers >= 0:
+        os.environ["SPERR_HIP_FARM_ASYNC"] = str(helpers)
     else:
-        os.environ.pop("SPERR_HIP_FARM_ITEM", None)
+        os.environ.pop("SPERR_HIP_FARM_ASYNC", None)
     tc, td = [], []
     for r in range(3):
         d, n, a = comp()
@@ -62,5 +67,5 @@ for w, item in ((2, 0), (3, 0), (2, 8), (3, 8), (3, 11), (4, 8)):
             tc.append(a)
             td.append(b)
     err = float((hout - hvol).abs().max())
-    print(f"workers {w} item {item or 'auto'}: compress {min(tc) * 1e3:7.1f} ms {nbytes / min(tc) / 1e9:5.1f} GB/s   "
+    print(f"workers {w or 'auto'} item {item or 'auto'} helpers {helpers if helpers >= 0 else 'auto'}: compress {min(tc) * 1e3:7.1f} ms {nbytes / min(tc) / 1e9:5.1f} GB/s   "
           f"decompress {min(td) * 1e3:7.1f} ms {nbytes / min(td) / 1e9:5.1f} GB/s   bytes {n} max err {err:.3g}", flush=True)
