@@ -818,6 +818,35 @@ def test_serial_walk_fallback_in_a_fresh_process(oracle):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
 
 
+@pytest.mark.parametrize("knobs", [{"SPERR_HIP_HI_ONLY_BITS": "0"}, {"SPERR_HIP_HI_ONLY_BITS": "2000000000"},
+                                   {"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}])
+def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
+    """Who decodes which list is a matter of speed, never of bits (round 4; the knobs are read once per process):
+    `SPERR_HIP_HI_ONLY_BITS` = 0 / huge -- k_lis_l0 and k_lis_l1 take their lists on every plane / on none
+    (k_lis_hi alone; by default it has the planes that follow a short LIS phase); `SPERR_HIP_LIS_HI=0` -- a regular
+    tree through k_lis_mixed, where regular trees that k_lis_hi cannot take go since k_lis_tables was removed;
+    `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 at all.  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
+    short, against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-212)."""
+    import subprocess
+    import sys
+    import tempfile
+    shape = (64, 64, 64)
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, (64, 64, 32), 1, 3.0)
+    ref = oracle.decomp_3d(want, True)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "c.npy"), np.frombuffer(want, dtype=np.uint8))
+        np.save(os.path.join(td, "r.npy"), ref)
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from sperr_amd.api import SperrHip; "
+                "e = SperrHip(); c = torch.from_numpy(np.load(%r)).cuda(); r = np.load(%r); "
+                "d = e.decompress(c, True).cpu().numpy(); "
+                "sys.exit(0 if np.array_equal(d.view(np.uint32), r.view(np.uint32)) else 3)"
+                % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(td, "c.npy"),
+                   os.path.join(td, "r.npy")))
+        env = dict(os.environ, **knobs)
+        assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0, knobs
+
+
 @pytest.mark.parametrize("shape", [(8, 8), (5, 300), (2, 9), (1, 40), (33, 17), (500, 301), (1024, 1024)])
 def test_2d_slice_decoder_on_the_shared_forest(eng, oracle, shape):
     """Slices are decoded by the 3D decoder's kernels on the 2D coder's forest (quadtrees whose
