@@ -2066,9 +2066,6 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
     d.hiExtra = extra;
     static const uint32_t hop2 = getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_HOP2")) : 1u;
     d.hiHop2 = hop2;
-    // (SPERR_HIP_HI_ONLY_BITS: k_lis_hi alone decodes the planes that follow a LIS phase of at most so many bits; 0: never)
-    static const uint32_t hiOnly = getenv("SPERR_HIP_HI_ONLY_BITS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_ONLY_BITS")) : 4096u;
-    d.hiOnlyBits = hiOnly;
   }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
   d.hiW = hi_window((int)d.hiK, d.hiSmemBytes);

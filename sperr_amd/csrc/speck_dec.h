@@ -35,7 +35,6 @@ struct DecState {
   int32_t hiPlaneP1;             // 1 + the plane whose pass has ended (0: none)
   int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
   uint32_t hiCompactDone;        // workgroups of k_lis_compact that have finished (the last one ends the phase)
-  int hiOnlyP1;                  // 1 + the plane whose lists k_lis_hi decodes all by itself (k_dec_scan: a short phase)
   uint64_t hiEnd;                // first bit after the phase
   uint32_t hiBornCnt[8];         // births / leaf events in the workgroups' own segments
   uint32_t hiLeafCnt[8];
@@ -127,7 +126,6 @@ struct DecBuffers {
   uint32_t hiHop2;             // the next class's pointer-jump table is built ahead of the chain (else on demand)
   uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for (<= 8)
   uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
-  uint32_t hiOnlyBits;         // a plane whose predecessor's LIS phase had at most this many bits: k_lis_hi alone (0: never)
   uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
                                //   the region and end within them are not walked into
   // k_lis_mixed (chunks whose lists mix set shapes): window bits and dynamic LDS

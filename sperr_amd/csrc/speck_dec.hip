@@ -256,12 +256,6 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.nLip = (uint32_t)carry;
     s.nRef = (uint32_t)(carry >> 32);
     s.lipStart = s.pos;
-    // A plane whose LIS phase is a few thousand bits (the dozen planes before the heavy ones) costs the three
-    // list kernels their fixed latencies -- tickets, tables, geometry into LDS: 80 + 80 + 100 us per sub-batch
-    // of 32 chunks, 14 such planes in the bench volume --, and k_lis_hi can decode every list by itself: it
-    // does, when the phase of the plane before was short (phases grow by a small factor from plane to plane;
-    // a wrong guess costs time, not bits: k_lis_l0 / _l1 just stay out, k_lis_compact takes their levels too).
-    s.hiOnlyP1 = (b.hiOnlyBits != 0 && s.lisPhaseBits <= (uint64_t)b.hiOnlyBits) ? p + 1 : 0;
     s.l0Ticket = 0;
     s.l1Ticket = 0;
     s.hiTicket = 0;
@@ -889,8 +883,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   const uint32_t L = (uint32_t)b.l0Level;
   const uint32_t cur = s.cur, nx = cur ^ 1u;
   const uint32_t n = s.listLen[cur][L];
-  if (n == 0 || s.hiOnlyP1 == p + 1)
-    return;   // (k_lis_hi finds the list empty as well; a short phase is all k_lis_hi's: k_dec_scan)
+  if (n == 0)
+    return;   // (k_lis_hi finds the list empty as well)
   extern __shared__ __attribute__((aligned(16))) char l0_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(l0_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l0_smem);
@@ -1184,7 +1178,7 @@ k_lis_l1(DecBuffers b, int p)
   const uint32_t cur = s.cur, nx = cur ^ 1u;
   const uint32_t n = s.listLen[cur][L];
   const bool l0done = s.l0PlaneP1 == p + 1;
-  if (n == 0 || (!l0done && s.listLen[cur][L0] != 0) || s.hiOnlyP1 == p + 1)
+  if (n == 0 || (!l0done && s.listLen[cur][L0] != 0))
     return;   // (k_lis_hi takes the list)
   extern __shared__ __attribute__((aligned(16))) char l1_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(l1_smem);

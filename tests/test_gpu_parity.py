@@ -818,14 +818,11 @@ def test_serial_walk_fallback_in_a_fresh_process(oracle):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
 
 
-@pytest.mark.parametrize("knobs", [{"SPERR_HIP_HI_ONLY_BITS": "0"}, {"SPERR_HIP_HI_ONLY_BITS": "2000000000"},
-                                   {"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}])
+@pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}])
 def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
     """Who decodes which list is a matter of speed, never of bits (round 4; the knobs are read once per process):
-    `SPERR_HIP_HI_ONLY_BITS` = 0 / huge -- k_lis_l0 and k_lis_l1 take their lists on every plane / on none
-    (k_lis_hi alone; by default it has the planes that follow a short LIS phase); `SPERR_HIP_LIS_HI=0` -- a regular
-    tree through k_lis_mixed, where regular trees that k_lis_hi cannot take go since k_lis_tables was removed;
-    `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 at all.  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
+    `SPERR_HIP_LIS_HI=0` -- a regular tree through k_lis_mixed, where regular trees that k_lis_hi cannot take go
+    since k_lis_tables was removed; `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 at all, k_lis_hi decodes every list.  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
     short, against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-212)."""
     import subprocess
     import sys
