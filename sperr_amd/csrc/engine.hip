@@ -2044,6 +2044,14 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.tileRef, uint32_t, d.tileStride * B);
   TAKE(d.tileLipOff, uint32_t, d.tileStride * B);
   TAKE(d.tileRefOff, uint32_t, d.tileStride * B);
+  {
+    // (only for the regular trees: there every birth of a sample comes through a leaf event; k_lis_mixed and
+    //  k_lis_walk set mask bits themselves.  SPERR_HIP_TILE_SKIP=0: every tile swept on every plane)
+    static const bool tileSkip = !(getenv("SPERR_HIP_TILE_SKIP") && atoi(getenv("SPERR_HIP_TILE_SKIP")) == 0);
+    uint8_t* tb = nullptr;
+    TAKE(tb, uint8_t, d.tileStride * B);
+    d.tileBorn = (tileSkip && use_tables(P)) ? tb : nullptr;
+  }
   d.lipResStride = Npad / 64 + 2;
   TAKE(d.lipSig, uint64_t, d.lipResStride * B);
   TAKE(d.lipNeg, uint64_t, d.lipResStride * B);
@@ -2596,6 +2604,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           if (wide && maxWide == 0)
             continue;
           HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * nb * 8, ss));
+          if (d.tileBorn)
+            HIP_CHECK(hipMemsetAsync(d.tileBorn, 0, d.tileStride * nb, ss));
           HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * nb * 8, ss));
           HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * nb * 8, ss));
@@ -3497,6 +3507,8 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     HIP_CHECK(hipMemsetAsync(d.cst, 0, sizeof(CoderState), st));
     HIP_CHECK(hipMemsetAsync(d.st, 0, sizeof(DecState), st));
     HIP_CHECK(hipMemsetAsync(d.bornM, 0, d.maskPixStride * 8, st));
+    if (d.tileBorn)
+      HIP_CHECK(hipMemsetAsync(d.tileBorn, 0, d.tileStride, st));
     HIP_CHECK(hipMemsetAsync(d.sigOld, 0, d.maskPixStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.sigNew, 0, d.maskPixStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.sign, 0xff, d.signStride * 8, st));

@@ -70,6 +70,7 @@ struct DecBuffers {
   uint32_t* tileLipOff;
   uint32_t* tileRefOff;
   size_t tileStride;
+  uint8_t* tileBorn;           // 1: some sample of the tile has been tested (k_dec_count skips the others); null: not kept
   uint64_t* lipSig;            // LIP scan results of the current plane by token rank: found
   uint64_t* lipNeg;            //   significant / and negative
   size_t lipResStride;

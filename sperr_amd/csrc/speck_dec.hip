@@ -189,7 +189,27 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
   const uint32_t nw = (b.tree.nvals + 63) / 64;
   for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
   const uint32_t wi = tile * kDecTileWords + threadIdx.x;
+  // A tile none of whose samples has ever been tested holds nothing to count, and nothing to fold unless a
+  // leaf over it split on the plane before: then its three mask words per thread are not read at all (round
+  // 4: the dozen planes before the heavy ones touch the coarse subbands only and swept every mask of the
+  // chunk, 85 us per launch of 32 chunks).  Only where every birth comes through the leaf states: a word
+  // without a leaf mapping (the small subbands, whose events k_leaf_apply applies itself) keeps its tile in.
+  if (b.tileBorn != nullptr && b.wordLeaf != nullptr && b.tileBorn[c * b.tileStride + tile] == 0) {
+    bool need = false;
+    if (wi < nw) {
+      const uint32_t wl = b.wordLeaf[wi];
+      need = wl == 0xffffffffu || b.leafDirty[c * b.leafDirtyStride + (wl >> 5)] == (uint8_t)(p + 2);
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) {
+      if (threadIdx.x == 0) {
+        b.tileLip[c * b.tileStride + tile] = 0;
+        b.tileRef[c * b.tileStride + tile] = 0;
+      }
+      continue;
+    }
+  }
   uint32_t v = 0;
+  bool anyBorn = false;
   if (wi < nw) {
     uint64_t* so = b.sigOld + c * b.maskPixStride + wi;
     uint64_t* sn = b.sigNew + c * b.maskPixStride + wi;
@@ -218,6 +238,12 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
       *sn = 0;
     const uint64_t lip = born & ~sig;
     v = (uint32_t)__popcll(lip) | ((uint32_t)__popcll(sig) << 16);
+    anyBorn = born != 0;
+  }
+  if (b.tileBorn != nullptr) {
+    const int anyB = __syncthreads_or(anyBorn ? 1 : 0);
+    if (threadIdx.x == 0 && anyB)
+      b.tileBorn[c * b.tileStride + tile] = 1;
   }
   // 256 words x 64 bits: both counts fit in 15 bits per thread, sums in 32 bits need care:
   uint32_t total_l, total_r;
