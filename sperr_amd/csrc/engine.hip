@@ -182,8 +182,12 @@ struct DevBuf {
       (void)hipFree(p);
     p = nullptr;
     n = 0;
-    HIP_CHECK(hipMalloc(&p, bytes));
-    n = bytes;
+    // (a quarter more than asked for, for the small buffers whose size follows the data -- outlier
+    //  streams, slots --: a hipFree waits for every stream of the device, the other workers' included,
+    //  and a buffer that fits exactly is too small for the next call's slightly longer streams)
+    const size_t want = bytes < (size_t(256) << 20) ? bytes + bytes / 4 + 4096 : bytes;
+    HIP_CHECK(hipMalloc(&p, want));
+    n = want;
     return 0;
   }
 };

@@ -25,16 +25,17 @@ libc = C.CDLL(None)
 libc.free.argtypes = [C.c_void_p]
 
 
-def farm(mode, q, reps=3):
+def farm(mode, q, reps=3, src=None, out=None):
     tc, td = [], []
+    src = src or hvol.data_ptr()
     for r in range(reps):
         dst, n = C.c_void_p(None), C.c_size_t(0)
         t0 = time.perf_counter()
-        rc = lib.sperrhip_comp_3d_farm(hvol.data_ptr(), 1, S, S, S, 256, 256, 256, mode, float(q), 0, None, 0, C.byref(dst), C.byref(n))
+        rc = lib.sperrhip_comp_3d_farm(src, 1, S, S, S, 256, 256, 256, mode, float(q), 0, None, 0, C.byref(dst), C.byref(n))
         t1 = time.perf_counter()
         assert rc == 0, rc
         x, y, z = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
-        rc = lib.sperrhip_decomp_3d_into(dst, n.value, 1, 0, None, 0, hout.data_ptr(), nbytes, C.byref(x), C.byref(y), C.byref(z))
+        rc = lib.sperrhip_decomp_3d_into(dst, n.value, 1, 0, None, 0, out or hout.data_ptr(), nbytes, C.byref(x), C.byref(y), C.byref(z))
         t2 = time.perf_counter()
         assert rc == 0, rc
         libc.free(dst)
@@ -58,5 +59,11 @@ dev_steps(3)
 print("after 3 device steps:     PWE compress %.1f ms decompress %.1f ms" % farm(3, tol), flush=True)
 print("  (rate mode:                 compress %.1f ms decompress %.1f ms)" % farm(1, 2.0), flush=True)
 print("after the rate-mode farm: PWE compress %.1f ms decompress %.1f ms" % farm(3, tol), flush=True)
+import numpy as np
+pvol = hvol.numpy().copy()
+pout = np.empty_like(pvol)
+print("  (rate mode, pageable:       compress %.1f ms decompress %.1f ms)" % farm(1, 2.0, 3, pvol.ctypes.data, pout.ctypes.data), flush=True)
+print("after the pageable farm:  PWE compress %.1f ms decompress %.1f ms" % farm(3, tol), flush=True)
+print("again:                    PWE compress %.1f ms decompress %.1f ms" % farm(3, tol), flush=True)
 lib.sperrhip_release()
 print("after sperrhip_release(): PWE compress %.1f ms decompress %.1f ms" % farm(3, tol), flush=True)
