@@ -768,9 +768,6 @@ constexpr int kXYZPosI = 6144 / kXYZThreadsI;   // inverse: kXYZStaged * cx <= 6
 #ifndef XYZ_INV_GROUP
 #define XYZ_INV_GROUP 3
 #endif
-#ifndef XYZ_INV_DEFER
-#define XYZ_INV_DEFER 0   // 1: the pair's second slice stored after the next pair's loads (measured: no gain)
-#endif
 constexpr int kXYZGroupI = XYZ_INV_GROUP;       // positions whose loads are in flight together
 
 // LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
@@ -1135,9 +1132,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
         dstrow[x] = (VT)(srow[x] + mean);
     }
   };
-  // `defer`: the caller stores the slice's rows later -- store_rows(z, flip ^ 1), before the next
-  // finish_slice (whose y pass overwrites that buffer after its first barrier)
-  auto finish_slice = [&](uint32_t z, bool defer = false) {
+  auto finish_slice = [&](uint32_t z) {
     uint32_t RSv = RS, tidv = tid;   // (see k_lift_xyz_fwd)
     asm volatile("" : "+s"(RSv), "+v"(tidv));
     const uint32_t which = flip;
@@ -1149,8 +1144,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     XYZ_LDS_BARRIER();
     xyz_lift_x<false, kXYZThreadsI>(Y, X, RSv, cx, kXYHalo, kXYHalo + nt, tidv, K);
     XYZ_LDS_BARRIER();
-    if (!defer)
-      store_rows(z, which);
+    store_rows(z, which);
     // (the next slice is staged into Y, which nobody reads any more; its y pass writes X only after
     //  the barrier behind that staging, when every row above has been stored)
   };
@@ -1269,10 +1263,6 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
             zstep(g + kk, m, mine, ((activeMask >> (g + kk)) & 1u) != 0, val[2 * kk], val[2 * kk + 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // the second slice of the pair before is stored only now: the wait above would have waited for those
-      // stores to be acknowledged had they been issued before it (the memory counter retires in order)
-      if (XYZ_INV_DEFER && m >= 2 && m - 1 >= mA)
-        store_rows(2 * m - 4, flip ^ 1u);
       if (m + 1 < mB)
         pre_issue(m + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1294,17 +1284,9 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       finish_slice(2 * m - 3);
     if (m >= 1 && mine) {
       stage_all(e2p);
-#if XYZ_INV_PREFETCH == 2
-      finish_slice(2 * m - 2, fastLoads && XYZ_INV_DEFER);
-#else
       finish_slice(2 * m - 2);
-#endif
     }
   }
-#if XYZ_INV_PREFETCH == 2
-  if (fastLoads && XYZ_INV_DEFER && mB >= 2 && mB - 1 >= mA && mB > mFirst)
-    store_rows(2 * mB - 4, flip ^ 1u);   // the last pair's second slice
-#endif
   // ---- the end of the lines (the last segment's)
   if (seg + 1 != nseg)
     return;
