@@ -272,6 +272,8 @@ struct ShapePlan {
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
   const uint8_t* d_levelGroup = nullptr;  // k_lis_mixed: column group of every list level
+  const uint8_t* d_mxSlot = nullptr;      // k_lis_mx: column of every shape class
+  const uint8_t* d_mxLevelGroup = nullptr;
   int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
   int l1Level = -1;                       // LIS level of 4x4x4 sets that k_lis_l1 can decode
   int maxK = 0;
@@ -394,7 +396,8 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
                oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf), oCls = blob.add(h.cls),
-               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup), oIR = blob.add(h.iRoots);
+               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup), oIR = blob.add(h.iRoots),
+               oMS = blob.add(h.mxSlot), oMG = blob.add(h.mxLevelGroup);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
     P.maxK = std::max<int>(P.maxK, lc.K);
@@ -430,6 +433,8 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
   P.dtree.cls = reinterpret_cast<const spk::ShapeCls*>(base + oCls);
   P.dtree.gridCls = reinterpret_cast<const uint8_t*>(base + oGC);
   P.d_levelGroup = reinterpret_cast<const uint8_t*>(base + oLG);
+  P.d_mxSlot = reinterpret_cast<const uint8_t*>(base + oMS);
+  P.d_mxLevelGroup = reinterpret_cast<const uint8_t*>(base + oMG);
   P.d_iRoots = h.iRoots.empty() ? nullptr : reinterpret_cast<const uint64_t*>(base + oIR);
   P.d_initLIS = reinterpret_cast<const uint64_t*>(base + oInit);
   P.d_initLen = reinterpret_cast<const uint32_t*>(base + oInitLen);
@@ -1993,6 +1998,17 @@ bool use_mixed(const ShapePlan& P)
   const uint32_t w = mix_window(kMixSmemBytes);
   return w >= 512 && w >= P.ht.slotMaxT + 2;
 }
+// ... GPU-wide (k_lis_mx, speck_mx.hip: several workgroups per chunk, only the walk on the serial chain).
+// SPERR_HIP_LIS_MX=0: k_lis_mixed (one workgroup per chunk) as in rounds 2-3
+bool use_mx(const ShapePlan& P)
+{
+  static const int mxEnv = getenv("SPERR_HIP_LIS_MX") ? atoi(getenv("SPERR_HIP_LIS_MX")) : 1;
+  if (!mxEnv || !use_mixed(P) || P.ht.mxSlot.size() != P.ht.cls.size() || P.lisEntries >= (1u << 28))
+    return false;
+  if ((P.ht.flags & spk::kTree2D) && mxEnv < 2)
+    return false;
+  return kMxS + 64 <= kMxRing && mx_smem_bytes(kMxS, kMxM, kMxQ) <= 146u * 1024u;
+}
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
 
 struct DecBatchBufs {
@@ -2106,6 +2122,14 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.queue, uint64_t, d.queueStride * B);
   d.hiAhead = std::min(d.hiAhead / 64 * 64, d.hiW / 2);
   d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 4) * 4;
+  d.mxSlot = P.d_mxSlot;
+  d.mxLevelGroup = P.d_mxLevelGroup;
+  d.mxS = kMxS;
+  d.mxM = kMxM;
+  d.mxQ = kMxQ;
+  d.mxSmemBytes = mx_smem_bytes(kMxS, kMxM, kMxQ);
+  if (use_mx(P))   // (k_lis_mx keeps its look-back words in the same array: kMxWordsPerRegion per region of mxS bits)
+    d.hiFlagStride = std::max<size_t>(d.hiFlagStride, ((d.streamStride * 64 + N) / kMxS + 4) * kMxWordsPerRegion);
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
   d.mixSmemBytes = kMixSmemBytes;
   d.mixW = mix_window(kMixSmemBytes);
@@ -2583,6 +2607,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the lists of the larger sets GPU-wide
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
+        ph.mx = use_mx(*P);
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
         static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
         ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;
@@ -3531,6 +3556,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);
     ph.mixed = use_mixed(*P);
+        ph.mx = use_mx(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));

@@ -135,6 +135,14 @@ struct DecBuffers {
   const uint64_t* iRoots;         // 2D coder (spk::kTree2D): packed roots of the subbands the type-I set releases,
   uint32_t iLevels;               //   three per level from the coarsest on (~0: empty); iLevels: transform levels
   const uint8_t* mixLevelGroup;   // per list level: the column group (0..2) most of its entries belong to
+  // k_lis_mx (speck_mx.hip): the same lists GPU-wide -- fixed regions of mxS stream bits handed out by a ticket
+  // counter (DecState::hiTicket), rows of sixteen columns over mxS + mxM bits built off the serial chain, the
+  // walker's state handed from region to region through DecBuffers::hiFlags (kMxWordsPerRegion words each)
+  const uint8_t* mxSlot;          // column of every shape class (0xff: none)
+  const uint8_t* mxLevelGroup;    // per list level: dominant column group | highest group << 4
+  uint32_t mxS, mxM;              // bits of a region, bits its rows look further
+  uint32_t mxQ;                   // items per expansion queue
+  uint32_t mxSmemBytes;
 };
 
 struct DecPlanHost {
@@ -146,6 +154,7 @@ struct DecPlanHost {
   int maxK;                    // longest class chain (sizes the LDS tables)
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
   bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
+  bool mx = false;             // ... GPU-wide: k_lis_mx instead of k_lis_mixed (several workgroups per chunk)
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
   // Fixed-rate streams run out of bits many planes above plane 0, and the launches of a plane that
   // holds no work still cost about 0.1 ms per batch.  With d_live set (kLiveSlots device words) the
@@ -205,6 +214,13 @@ __host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
     w = (uint32_t)kMixRing / 4u;
   return w;
 }
+
+// k_lis_mx (speck_mx.hip)
+constexpr int kMxWordsPerRegion = 8;
+constexpr uint32_t kMxS = 2048, kMxM = 768, kMxQ = 1024, kMxRing = 4096;
+uint32_t mx_smem_bytes(uint32_t S, uint32_t M, uint32_t Q);
+int prepare_lis_mx(const DecBuffers& b);
+int launch_lis_mx(hipStream_t stream, const DecBuffers& b, int p, uint32_t groups, bool stamps);
 
 int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHost& plan,
                         const uint8_t* container, const uint64_t* d_chunkOff,

@@ -4489,6 +4489,13 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   // bookkeeping went to one lane per level: 96 / 128 / 160 / 192 / 256 give 73.4 / 77.5 / 78.5 / 77.9 / 75.5)
   static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 160u;
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
+  // workgroups per chunk of k_lis_mx: the walk of a chunk is serial, the rows and the expansion of its regions are
+  // what the other workgroups are for (SPERR_HIP_MX_WGS: the total over the batch's chunks)
+  static const uint32_t mxTotal = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 256u;
+  const uint32_t mxGroups = std::min<uint32_t>(std::min<uint32_t>(8u, std::max<uint32_t>(1, b.hiGroupsMax)),
+                                               std::max<uint32_t>(1, mxTotal / nc));
+  if (plan.mixed && plan.mx && prepare_lis_mx(b))
+    return -1;
   if (plan.mixed) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<false>), (int)b.mixSmemBytes) ||
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<true>), (int)b.mixSmemBytes))
@@ -4525,6 +4532,11 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       if (!plan.hi)
         return -1;   // (use_tables() implies use_lis_hi(): engine.hip)
       LAUNCH_CT(k_lis_hi, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
+      LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
+    }
+    else if (plan.mixed && plan.mx) {
+      if (launch_lis_mx(stream, b, p, mxGroups, b.lisStamps != nullptr))
+        return -1;
       LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
     }
     else if (plan.mixed) {

@@ -1,0 +1,1288 @@
+// speck_mx.hip -- LIS phase of chunks whose lists MIX set shapes, GPU-WIDE (k_lis_mx, round 4).
+//
+// The sorting pass of a plane (/root/reference/src/SPECK3D_INT.cpp:99-138: the lists from the smallest sets to
+// the largest, m_process_S / m_code_S :140-212, the split rule :214-326; 2D: /root/reference/src/SPECK2D_INT.cpp:
+// 10-218) is a serial parse: what a bit means depends on every earlier bit.  k_lis_mixed (speck_dec.hip) runs
+// it with ONE workgroup per chunk that builds speculative tables (rows of split lengths per stream position and
+// shape class), walks the list entries with one wavefront and expands the sets that were hopped over -- all
+// three on the one workgroup's clock.  Here only the walk stays serial:
+//
+//   * the phase's stream is cut into fixed REGIONS of S bits, handed out by a ticket counter to the workgroups
+//     of a chunk (a region is handed out only after all earlier ones: a waiting workgroup always waits for a
+//     running one);
+//   * OFF the chain a workgroup loads its region (+ M bits of look-ahead) and builds the rows: sixteen columns
+//     per position -- a single sample, the leaf parents of 2 / 4 / 8 samples, and the four most frequent shape
+//     classes one, two and three steps above them (spk::build_mx_columns);
+//   * ON the chain its first wavefront takes the predecessor's state -- stream position, list level, entry
+//     index, entries left, the stack of sets being walked into (child ordinal + "found" bit per frame, the
+//     entry at the bottom), the 2D coder's type-I state -- from tagged words written and read with relaxed
+//     agent-scope atomics (no fence: k_lis_hi's protocol), walks its region (a significant entry with a column
+//     is a few register look-ups, any other set is walked into child by child; a set whose split leaves the
+//     rows is walked into as well, so the walk always reaches the region's end) and publishes the state there;
+//   * OFF the chain again it expands the sets it hopped over, breadth first with all threads: leaf parents
+//     become leaf events (k_leaf_apply), insignificant child sets are recorded with their stream position
+//     (k_place_scan / _scatter rank them), births and events go to segments that are the workgroup's alone.
+//
+// Old entries are compacted by k_lis_compact, which also sets the chunk's state after the phase.
+// tests/model/speck_model.cpp::model_speck3d_decode_mixed pins the formulation (rows, hops, walking into sets).
+#include "speck_dec.h"
+
+namespace sperrhip {
+
+using namespace spk;
+
+namespace {
+
+constexpr int kMxThreads = 1024;
+constexpr int kMxCols = 16;
+constexpr int kMxLdsRoots = 48, kMxLdsGrids = 352;   // (host: use_mx checks that the tree fits)
+constexpr uint32_t kTInf = 0xffffu, kTNone = 0xfffeu;
+constexpr uint32_t kMxTagShift = 57;
+constexpr unsigned long long kMxOver = 1ull << 56;
+constexpr int kMxFrames = kMaxDepth + 2;
+constexpr uint32_t kNoTicket = 0xffffffffu;
+
+// what the chain is doing (2D coder: the type-I set, /root/reference/src/SPECK2D_INT.cpp:44-98)
+constexpr uint32_t kModeList = 0;      // the entries of list `level`
+constexpr uint32_t kModeITest = 1;     // the type-I set's own test comes next
+constexpr uint32_t kModeISub = 2;      // the test of subband iJ of the type-I set's level comes next
+constexpr uint32_t kModeISubWalk = 3;  // inside a subband that was walked into
+
+struct MxCtx {
+  uint64_t parent;     // packed node of the set being walked into
+  KidBox kb;
+  uint8_t pc;          // its class
+  uint8_t next;        // ordinal of the next child
+  uint8_t found;       // an earlier child was significant
+  uint8_t pad;
+};
+
+#define MX_ACTIVE_OR_RETURN(s, p)                                \
+  if (!(s).active || (s).done || (int)(p) >= (s).nbp)            \
+    return;
+
+// lanes of ONE wavefront that talk through LDS (see HI_WAVE_SYNC in speck_dec.hip)
+#define MX_WAVE_SYNC()                                        \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+
+template <bool kStamps>
+__global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  MX_ACTIVE_OR_RETURN(s, p);
+  extern __shared__ __attribute__((aligned(16))) char mx_smem[];
+  __shared__ ShapeCls sh_cls[kMaxCls];
+  __shared__ uint64_t sh_kcol[kMaxCls];             // byte k: column of child k (0: a single sample, 0xff: none)
+  __shared__ uint8_t sh_slot[kMaxCls + 2];          // column of every class
+  __shared__ Root sh_roots[kMxLdsRoots];
+  __shared__ Grid sh_grids[kMxLdsGrids];
+  __shared__ uint8_t sh_gridCls[kMxLdsGrids * 8];
+  __shared__ MxCtx sh_ctx[kMxFrames + 1];
+  __shared__ uint8_t sh_colCls[kMxCols];            // class of every column (0xff: unused)
+  __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
+  __shared__ uint8_t sh_lgrp[kMaxLevels];           // dominant column group of every list level
+  __shared__ uint32_t sh_len[kMaxLevels], sh_lOff[kMaxLevels];
+  // chain state (the first wavefront owns it; the others read it between barriers)
+  __shared__ uint64_t sh_pos, sh_base;
+  __shared__ uint32_t sh_level, sh_e, sh_rem, sh_mode, sh_stop, sh_needFill, sh_ringHi, sh_ticket, sh_abort;
+  __shared__ uint32_t sh_iJ, sh_iPart, sh_iCounter, sh_iNeed;
+  __shared__ int sh_depth;
+  __shared__ uint32_t sh_qn[2], sh_ncand;
+  __shared__ uint32_t sh_segBorn, sh_segLeaf, sh_segBornEnd;   // filled slots of this workgroup's segments
+  __shared__ unsigned long long sh_in[8];
+  __shared__ uint64_t sh_tk[4];
+
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+  const uint32_t nlevels = b.tree.nlevels;
+  const bool twoD = (b.tree.flags & kTree2D) != 0;
+  const uint32_t cur = s.cur;
+  if (tid < kMxCols)
+    sh_colCls[tid] = 0xff;
+  if (tid < kMaxLevels) {
+    const bool in = (uint32_t)tid < nlevels;
+    sh_levelSlot[tid] = in ? b.levelSlot[tid] : (uint8_t)0xff;
+    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 3u) : (uint8_t)0;
+    sh_len[tid] = in ? s.listLen[cur][tid] : 0u;
+    sh_lOff[tid] = in ? b.levelOff[tid] : 0u;
+  }
+  if (tid == 0) {
+    sh_segBorn = sh_segLeaf = 0;
+    sh_segBornEnd = 0xffffffffu;
+    sh_slot[kMaxCls] = sh_slot[kMaxCls + 1] = 0xff;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < b.tree.nroots && i < (uint32_t)kMxLdsRoots; i += kMxThreads)
+    sh_roots[i] = b.tree.roots[i];
+  for (uint32_t i = tid; i < b.tree.ngrids && i < (uint32_t)kMxLdsGrids; i += kMxThreads)
+    sh_grids[i] = b.tree.grids[i];
+  for (uint32_t i = tid; i < b.tree.ngrids * 8 && i < (uint32_t)kMxLdsGrids * 8; i += kMxThreads)
+    sh_gridCls[i] = b.tree.gridCls[i];
+  for (uint32_t i = tid; i < b.tree.ncls && i < (uint32_t)kMaxCls; i += kMxThreads) {
+    const ShapeCls cc = b.tree.cls[i];
+    sh_cls[i] = cc;
+    uint64_t kc = 0;
+    for (int k = 0; k < 8; k++) {
+      const uint32_t kid = k < cc.nk ? cc.kid[k] : kClsPixel;
+      kc |= (uint64_t)(kid == kClsPixel ? 0u : b.mxSlot[kid]) << (8 * k);
+    }
+    sh_kcol[i] = kc;
+    const uint8_t sl = b.mxSlot[i];
+    sh_slot[i] = sl;
+    if (sl < kMxCols)
+      sh_colCls[sl] = (uint8_t)i;
+  }
+
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
+  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
+  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
+  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  const uint64_t* lisCur = b.lis[cur] + c * b.lisStride;
+  unsigned long long* flags = b.hiFlags + c * b.hiFlagStride;
+  const unsigned long long tag = (unsigned long long)(p + 1) << kMxTagShift;
+
+  const uint32_t S = b.mxS, W = b.mxS + b.mxM, Q = b.mxQ;
+  const uint32_t kWords = ((W >> 6) + 5u) & ~1u;
+  uint64_t* const wbits = reinterpret_cast<uint64_t*>(mx_smem);
+  const uint32_t* const w32 = reinterpret_cast<const uint32_t*>(mx_smem);
+  uint16_t* const Tr = reinterpret_cast<uint16_t*>(mx_smem + (size_t)kWords * 8);   // [W + 3][16]
+  char* const ldsQ = mx_smem + (size_t)kWords * 8 + (((size_t)(W + 3) * kMxCols * 2 + 15) & ~(size_t)15);
+  uint64_t* const qidA = reinterpret_cast<uint64_t*>(ldsQ);
+  uint32_t* const qmetaA = reinterpret_cast<uint32_t*>(qidA + Q);   // first bit | class << 16 | "list entry" << 24
+  uint64_t* const qidB = reinterpret_cast<uint64_t*>(qmetaA + Q);
+  uint32_t* const qmetaB = reinterpret_cast<uint32_t*>(qidB + Q);
+  uint16_t* const ecls = reinterpret_cast<uint16_t*>(qmetaB + Q);   // ring [kMxRing]: class | column in the list's group << 8
+  uint16_t* const cand = reinterpret_cast<uint16_t*>(qidB);         // [W] (the rows are built before anything is queued)
+  uint64_t a = 0;     // stream position of the region's bit 0
+  uint32_t wq0 = 0;   // bit offset of region position 0 inside wbits[0]
+  __syncthreads();
+
+  auto bit_at = [&](uint32_t r) -> uint32_t {
+    const uint32_t q = r + wq0;
+    return (w32[q >> 5] >> (q & 31)) & 1u;
+  };
+  auto bits32 = [&](uint32_t r) -> uint32_t {  // 32 stream bits starting at r
+    const uint32_t q = r + wq0, sh = q & 31;
+    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  };
+  auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
+    atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
+    if (sig) {
+      atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
+      if (!signbit)
+        atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
+    }
+  };
+  // births and leaf events go to a segment of the chunk's arrays that is this workgroup's alone (an LDS
+  // counter; the shared part, with its global counter, takes what does not fit) -- k_lis_hi's scheme
+  const uint32_t segB0 = (uint32_t)b.bornStride + blockIdx.x * b.bornSeg;
+  const uint32_t segL0 = b.leafCap + blockIdx.x * b.leafSeg;
+  auto born_slots = [&](uint32_t n) -> uint32_t {
+    const uint32_t k = atomicAdd(&sh_segBorn, n);
+    if (k + n <= b.bornSeg)
+      return segB0 + k;
+    atomicMin(&sh_segBornEnd, k);        // the segment is full from here on
+    return atomicAdd(&s.bornCount, n);   // (slots at or past bornStride are dropped by write_born)
+  };
+  auto leaf_slot = [&]() -> uint32_t {
+    const uint32_t k = atomicAdd(&sh_segLeaf, 1u);
+    if (k < b.leafSeg)
+      return segL0 + k;
+    const uint32_t g = atomicAdd(&s.leafCount, 1u);
+    return g < b.leafCap ? g : 0xffffffffu;
+  };
+  auto write_born = [&](uint32_t slot, uint32_t lev, uint64_t rel, uint64_t packed) {
+    if (!(slot < b.bornStride || (slot >= segB0 && slot < segB0 + b.bornSeg)))
+      return;   // (only a damaged stream asks for more slots than there are sets)
+    bornPacked[slot] = packed;
+    bornPosLev[slot] = ((uint64_t)lev << 48) | rel;
+    atomic_or64(b.mask + c * b.maskStride + (size_t)sh_levelSlot[lev] * b.maskWords + (rel >> 6),
+                1ull << (rel & 63));
+  };
+  auto born_counts = [&](uint32_t lev, uint64_t rel) -> bool {   // is this birth recorded at all
+    return lev < (uint32_t)kMaxLevels && sh_levelSlot[lev] != 0xff && rel < maskBits;
+  };
+  // a set born insignificant at stream position abs
+  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
+    const uint64_t rel = abs - phase0;
+    if (!born_counts(lev, rel))
+      return;  // past the usable stream: decoding stops after this plane anyway
+    write_born(born_slots(1u), lev, rel, packed);
+  };
+  // geometry with the tree's tables in LDS (spk::kid_box / node_cls with these arrays)
+  auto kid_box_l = [&](const Node& nd, KidBox& k) {
+    const Grid g = sh_grids[nd.grid];
+    const Root r = sh_roots[g.root];
+    k.grid = (uint16_t)(nd.grid + 1);
+    k.rev = (uint16_t)(b.tree.flags & kTree2D);
+    uint32_t lev = r.lev;
+    const int d = g.depth;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const int Da = r.D[ax];
+      if (Da != 0 && !k.rev) {   // spk::node_level
+        if (d < Da)
+          lev += (uint32_t)d;
+        else {
+          lev += (uint32_t)(Da - 1);
+          if (axis_len(r.len[ax], Da - 1, (uint32_t)nd.i[ax] >> 1) >= 2)
+            lev += 1;
+        }
+      }
+      const bool splits = d < Da;
+      k.e[ax] = splits ? g.e[ax] + 1 : g.e[ax];
+      k.base[ax] = splits ? (uint32_t)nd.i[ax] * 2u : (uint32_t)nd.i[ax];
+      k.n[ax] = (splits && axis_len(r.len[ax], k.e[ax], k.base[ax] + 1u) > 0) ? 2u : 1u;
+      if (!k.rev)
+        lev += k.n[ax] - 1u;
+    }
+    k.kidlev = k.rev ? r.lev + (uint32_t)d + 1u : lev;   // (2D coder: one level per partition step)
+    k.nk = k.n[0] * k.n[1] * k.n[2];
+  };
+  auto node_cls_l = [&](const Node& nd) -> uint32_t {
+    const Grid g = sh_grids[nd.grid];
+    const Root& r = sh_roots[g.root];
+    uint32_t k = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      const int e = g.e[ax];
+      const uint32_t rem = (uint32_t)r.len[ax] & ((1u << e) - 1u);
+      k |= (bitrev(nd.i[ax], e) < rem ? 1u : 0u) << ax;
+    }
+    return sh_gridCls[(uint32_t)nd.grid * 8u + k];
+  };
+  // a significant leaf parent of nk samples whose split starts at y: ONE event word (node id,
+  // significance and sign masks by child ordinal) that k_leaf_apply turns into mask updates
+  auto leaf_event = [&](const Node& nd, uint32_t y, uint32_t nk) {
+    const uint32_t v = bits32(y);
+    uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+      const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
+      yy += coded;
+      const uint32_t sgn = (v >> yy) & 1u;
+      sigm |= bit << k;
+      negm |= (bit & (sgn ^ 1u)) << k;
+      found |= bit;
+      yy += bit;
+    }
+    const Grid& g = sh_grids[nd.grid];
+    const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
+    const uint32_t slot = leaf_slot();
+    if (slot != 0xffffffffu)
+      leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+  };
+  // the next list after level `l` (exclusive) that holds entries
+  auto next_level = [&](int l) -> int {
+    for (l = l - 1; l >= 0; l--)
+      if (sh_len[l] != 0)
+        return l;
+    return -1;
+  };
+
+  // ---- the rows of the region in view (all threads)
+  auto build_rows = [&]() {
+    if (tid == 0)
+      sh_ncand = 0;
+    __syncthreads();
+    // columns 0..3 at every position (the next 16 bits give the three leaf parents' splits), the
+    // other columns marked "not computed"; positions where a coded item's split can start are collected
+    for (uint32_t x = tid; x <= W + 2; x += kMxThreads) {
+      uint32_t T0 = kTInf, T1 = kTInf, T2 = kTInf, T3 = kTInf, rest = 0xffffffffu;
+      bool isCand = false;
+      if (x < W) {
+        const uint32_t v = bits32(x);
+        // children 0..6 coded one after the other; the last child of 2 / 4 / 8 is coded only when
+        // an earlier one was significant
+        uint32_t y = 0, found = 0, t2 = 0, t4 = 0, t8 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (k == 1 || k == 3 || k == 7) {
+            const uint32_t bit = found ? (v >> y) & 1u : 1u;
+            const uint32_t tl = y + found + bit;
+            if (k == 1)
+              t2 = tl;
+            else if (k == 3)
+              t4 = tl;
+            else
+              t8 = tl;
+          }
+          if (k < 7) {
+            const uint32_t bit = (v >> y) & 1u;
+            found |= bit;
+            y += 1u + bit;
+          }
+        }
+        T0 = 1u;
+        T1 = x + t2 <= W ? t2 : kTInf;
+        T2 = x + t4 <= W ? t4 : kTInf;
+        T3 = x + t8 <= W ? t8 : kTInf;
+        rest = kTNone | (kTNone << 16);
+        // (a region may begin anywhere: position 0 can be the start of a split whose test bit the
+        //  region before holds)
+        isCand = x == 0 || bit_at(x - 1) != 0;
+      }
+      uint4* row = reinterpret_cast<uint4*>(Tr + (size_t)x * kMxCols);
+      row[0] = make_uint4(T0 | (T1 << 16), T2 | (T3 << 16), rest, rest);
+      row[1] = make_uint4(rest, rest, rest, rest);
+      const uint64_t cm = __ballot(isCand);
+      if (cm) {
+        uint32_t base = 0;
+        const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(true)) - 1u;
+        if (lane == leader)
+          base = atomicAdd(&sh_ncand, (uint32_t)__popcll(cm));
+        base = __shfl(base, (int)leader, 64);
+        if (isCand)
+          cand[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)x;
+      }
+    }
+    __syncthreads();
+    // columns 4..7, 8..11, 12..15: a chain of look-ups through the children's columns at the collected
+    // positions (four per thread and round: their LDS round trips overlap)
+    const uint32_t ncand = sh_ncand;
+    for (uint32_t g4 = 4; g4 < (uint32_t)kMxCols; g4 += 4) {
+      bool any = false;
+      for (uint32_t col = g4; col < g4 + 4; col++) {
+        const uint32_t ci = sh_colCls[col];
+        if (ci == 0xff)
+          continue;
+        any = true;
+        const uint32_t nk = sh_cls[ci].nk;
+        const uint64_t kc = sh_kcol[ci];
+        for (uint32_t i = tid; i < ncand; i += 4 * kMxThreads) {
+          uint32_t x[4], y[4], found[4], bad[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t iu = i + (uint32_t)u * kMxThreads;
+            x[u] = iu < ncand ? (uint32_t)cand[iu] : W + 1u;
+            y[u] = x[u];
+            found[u] = 0;
+            bad[u] = 0;
+          }
+          for (uint32_t k = 0; k < nk; k++) {
+            const uint32_t ccol = (uint32_t)(kc >> (8 * k)) & 0xffu;
+            const uint32_t last = k + 1 == nk ? 1u : 0u;
+            uint32_t bitv[4], s0[4], tl[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t coded = found[u] | (last ^ 1u);
+              const uint32_t yy = min(y[u], W + 1);
+              bitv[u] = coded ? bit_at(yy) : 1u;
+              s0[u] = yy + coded;
+              tl[u] = Tr[(size_t)s0[u] * kMxCols + ccol];
+              y[u] = yy;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              uint32_t t = tl[u];
+              if (t >= kTNone) {
+                bad[u] |= bitv[u] ? (t == kTInf ? 1u : 2u) : 0u;
+                t = 0;
+              }
+              y[u] = bitv[u] ? s0[u] + t : y[u] + 1;
+              found[u] |= bitv[u];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t iu = i + (uint32_t)u * kMxThreads;
+            if (iu < ncand) {
+              const uint32_t t = ((bad[u] & 1u) || y[u] > W) ? kTInf : (bad[u] & 2u) ? kTNone : y[u] - x[u];
+              Tr[(size_t)x[u] * kMxCols + col] = (uint16_t)t;
+            }
+          }
+        }
+      }
+      if (any)
+        __syncthreads();
+    }
+  };
+
+  // ---- classes of the entries [from, to) of list `l` into the ring, with their column inside the list's group
+  auto fill_ring = [&](uint32_t l, uint32_t from, uint32_t to) {
+    const uint64_t* list = lisCur + sh_lOff[l];
+    const uint32_t grp = sh_lgrp[l];
+    for (uint32_t i = from + (uint32_t)tid; i < to; i += kMxThreads) {
+      const uint32_t ci = node_cls_l(unpack_node(list[i]));
+      const uint32_t col = sh_slot[ci];
+      ecls[i & (uint32_t)(kMxRing - 1)] =
+          (uint16_t)(ci | ((col < (uint32_t)kMxCols && (col >> 2) == grp ? (col & 3u) : 0xffu) << 8));
+    }
+  };
+
+  // ---- the walk through the region (first wavefront, every lane carrying the same walker state): from
+  //      sh_pos on until an item starts at or past S, or the list ends (depth 0)
+  uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
+  uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
+  auto walk = [&]() {
+    const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
+    uint32_t r = (uint32_t)(sh_pos - a), e = __builtin_amdgcn_readfirstlane(sh_e),
+             rem = __builtin_amdgcn_readfirstlane(sh_rem);
+    uint32_t qn = __builtin_amdgcn_readfirstlane(sh_qn[0]), ns = 0;
+    int depth = __builtin_amdgcn_readfirstlane(sh_depth);
+    const uint32_t level = __builtin_amdgcn_readfirstlane(sh_level);
+    const uint32_t lOff = sh_lOff[level];
+    const uint64_t* list = lisCur + lOff;
+    const uint32_t grp = sh_lgrp[level];
+    const uint32_t ringHi = __builtin_amdgcn_readfirstlane(sh_ringHi);
+    uint32_t stE = 0, stM = 0;   // staged items of the list hops: lane = item
+    // lane = stream word of the region
+    const uint64_t sw0 = lane < kWords ? wbits[lane] : 0ull;
+    const uint64_t sw1 = lane + 64u < kWords ? wbits[lane + 64u] : 0ull;
+    uint32_t curK = 0xffffffffu;   // stream word the registers below belong to
+    uint64_t m = 0;                // that word (uniform)
+    uint64_t lrow = 0;             // lane = bit of it: the group's four row entries one position on
+    uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
+    uint64_t lrowNext = 0;         // the same for word nextK
+    uint32_t nextK = 0xfffffffeu;
+    auto load_lrow = [&](uint32_t kk) -> uint64_t {
+      const int32_t row = (int32_t)(kk * 64u + lane) - (int32_t)wq0 + 1;
+      return (row >= 0 && row <= (int32_t)W + 2)
+                 ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMxCols + grp * 4u)
+                 : ~0ull;
+    };
+    uint32_t eb = 0x80000000u;     // lane = list entry eb + lane: its ecls word (nothing loaded yet)
+    uint32_t ecv = 0;
+    auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
+      return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);
+    };
+    auto rl64 = [&](uint64_t v, uint32_t idx) -> uint64_t {
+      return (uint64_t)rl32((uint32_t)v, idx) | ((uint64_t)rl32((uint32_t)(v >> 32), idx) << 32);
+    };
+    auto flush = [&]() {
+      if (lane < ns && qn + lane < Q) {
+        qidA[qn + lane] = stE;
+        qmetaA[qn + lane] = stM;
+      }
+      qn += ns;
+      ns = 0;
+    };
+    while (true) {
+      if (r >= S)
+        break;
+      if (depth == 1) {   // the list itself
+        if (rem == 0) {
+          depth = 0;
+          break;
+        }
+        const uint32_t q = r + wq0, k = q >> 6, o = q & 63u;
+        if (k != curK) {
+          curK = k;
+          m = k < 64u ? rl64(sw0, k) : rl64(sw1, k - 64u);
+          lrowK = 0xffffffffu;
+        }
+        // Stream words that lie inside the region, with at least 64 entries left and room for 64 more
+        // items: their entries in a tight loop, word after word -- no end-of-list, end-of-region or queue
+        // checks per entry; anything unusual (a set to walk into) is left to the general code below.
+        if (rem >= 64u && k * 64u + 64u <= S + wq0 && qn + ns + 160u < Q) {
+          const uint32_t eEnd = e + rem;
+          uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
+          bool unusual = false;
+          const uint64_t tt0 = kStamps ? __builtin_readcyclecounter() : 0;
+          const uint32_t hops0 = qn + ns;
+          while (true) {
+            if (kStamps)
+              wk_words++;
+            if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
+              if (kk != curK) {
+                curK = kk;
+                m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
+              }
+              lrow = nextK == kk ? lrowNext : load_lrow(kk);
+              lrowK = kk;
+              nextK = kk + 1u;
+              lrowNext = load_lrow(nextK);
+            }
+            // (at most 64 entries start inside a word, at most 32 of them significant: one load
+            // of entry classes and the staging registers cover it)
+            if (e - eb > oo) {   // (the entries of this word: fewer than 64 - oo from e on)
+              eb = e;
+              ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMxRing - 1)] : 0xffffu;
+            }
+            if (ns > 32u)
+              flush();
+            const uint32_t pbase = kk * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
+            while (true) {   // oo < 64 here
+              const uint64_t mm = m >> oo;
+              const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
+              oo += z;
+              e += z;
+              const uint32_t ec = rl32(ecv, (e - eb) & 63u);
+              const uint32_t loc = ec >> 8;
+              const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
+              if (oo >= 64u)
+                break;   // the word is done
+              if (loc == 0xffu || tl >= kTNone) {
+                unusual = true;   // something the general code has to look at
+                break;
+              }
+              {   // lane ns of the staging registers takes the item (the values stay scalar)
+                const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
+                const uint32_t itemE = __builtin_amdgcn_readfirstlane(lOff + e), itemL = __builtin_amdgcn_readfirstlane(ns);
+                asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                             : "+v"(stE), "+v"(stM)
+                             : "s"(itemE), "s"(itemL), "s"(itemM)
+                             : "m0");
+              }
+              ns++;
+              oo += 1u + tl;
+              e++;
+              if (oo >= 64u)
+                break;
+            }
+            if (unusual)
+              break;
+            // on to the word the walk is in now (a long split may have skipped some)
+            kk += oo >> 6;
+            oo &= 63u;
+            if (!(eEnd - e >= 64u && kk * 64u + 64u <= S + wq0 && qn + ns + 160u < Q))
+              break;
+          }
+          r = kk * 64u + oo - wq0;
+          rem = eEnd - e;
+          if (kStamps) {
+            wk_tight += __builtin_readcyclecounter() - tt0;
+            wk_hopsT += qn + ns - hops0;
+          }
+          if (!unusual)
+            continue;
+          if (kk != curK) {   // (cannot happen: an unusual entry lies in the word just walked)
+            curK = kk;
+            m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
+          }
+        }
+        if (lrowK != curK) {
+          lrow = load_lrow(curK);
+          lrowK = curK;
+        }
+        const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
+        const uint64_t tt = m >> o2;
+        const uint32_t z = min(min(tt ? (uint32_t)__ffsll((long long)tt) - 1u : 64u - o2, rem), S - r);
+        if (z) {
+          r += z;
+          e += z;
+          rem -= z;
+          if (kStamps)
+            wk_zruns++;
+          continue;
+        }
+        if (kStamps)
+          wk_hopsG++;
+        if (e - eb >= 64u) {
+          eb = e;
+          ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMxRing - 1)] : 0xffffu;
+        }
+        const uint32_t ec = rl32(ecv, e - eb);
+        const uint32_t loc = ec >> 8, ci = ec & 0xffu;
+        uint32_t tl = kTNone;
+        if (loc != 0xffu)
+          tl = (uint32_t)(rl64(lrow, o2) >> (16u * loc)) & 0xffffu;
+        else {   // a class of another column group: its length from the rows in LDS
+          const uint32_t col = sh_slot[ci];
+          if (col < (uint32_t)kMxCols)
+            tl = Tr[(size_t)(r + 1u) * kMxCols + col];
+        }
+        if (tl < kTNone) {
+          if (lane == ns) {
+            stE = lOff + e;
+            stM = (r + 1u) | (ci << 16) | (1u << 24);
+          }
+          ns++;
+          if (ns == 64u)
+            flush();
+          r += 1u + tl;
+        }
+        else {   // no column, or the split leaves the rows: walk into it
+          const uint64_t packed = list[e];
+          if (lane == 0)
+            atomic_or64(sigbits + ((lOff + e) >> 6), 1ull << ((lOff + e) & 63));
+          KidBox kb;
+          kid_box_l(unpack_node(packed), kb);
+          if (lane == 0) {
+            MxCtx& nc = sh_ctx[1];
+            nc.parent = packed;
+            nc.kb = kb;
+            nc.pc = (uint8_t)ci;
+            nc.next = 0;
+            nc.found = 0;
+            sh_base = packed;
+          }
+          MX_WAVE_SYNC();
+          depth = 2;
+          r += 1;
+        }
+        e++;
+        rem--;
+        continue;
+      }
+      // ---- a set that is being walked into: its children from `next` on, one look-up each;
+      //      lane k remembers what became of child k and writes its record afterwards
+      const uint64_t ti0 = kStamps ? __builtin_readcyclecounter() : 0;
+      if (kStamps)
+        wk_rounds++;
+      MxCtx& cx = sh_ctx[depth - 1];
+      const uint32_t pc = cx.pc;
+      const uint32_t nk = sh_cls[pc].nk;
+      const uint64_t kcol = sh_kcol[pc];
+      const uint64_t parent = cx.parent;
+      const KidBox kb = cx.kb;
+      const uint32_t k0 = cx.next;
+      uint32_t found = cx.found, k = k0;
+      uint32_t myAct = 0, myY = 0;   // 1: born insignificant (test bit at myY), 2: hopped over (split starts at myY)
+      bool pushed = false, halted = false;
+      while (k < nk) {
+        if (r >= S) {
+          halted = true;
+          break;
+        }
+        const uint32_t col = (uint32_t)(kcol >> (8 * k)) & 0xffu;
+        const bool coded = found || (k + 1 != nk);
+        if (col == 0) {   // a single sample
+          uint32_t sig = 1, sgn, len = 1;
+          if (coded) {
+            sig = bit_at(r);
+            sgn = sig ? bit_at(r + 1) : 1u;
+            len = 1u + sig;
+          }
+          else
+            sgn = bit_at(r);
+          if (lane == 0)
+            pixel_event(kid_pixel_raster(b.tree, unpack_node(parent), kb, k), sig != 0, sgn);
+          found |= sig;
+          r += len;
+          k++;
+          continue;
+        }
+        uint32_t start = r, bit = 1;
+        if (coded) {
+          bit = bit_at(r);
+          start = r + 1;
+        }
+        if (!bit) {
+          if (lane == k) {
+            myAct = 1;
+            myY = r;
+          }
+          r += 1;
+          k++;
+          continue;
+        }
+        const uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)start * kMxCols + col] : kTNone;
+        found = 1;
+        if (tl < kTNone) {
+          if (lane == k) {
+            myAct = 2;
+            myY = start;
+          }
+          r = start + tl;
+          k++;
+          continue;
+        }
+        k++;   // walk into this child
+        pushed = true;
+        r = start;
+        break;
+      }
+      // the records of the children handled in this round
+      {
+        const uint64_t rel = a + myY - phase0;
+        const bool bornOk = myAct == 1 && born_counts(kb.kidlev, rel);
+        const uint64_t bm = __ballot(bornOk);
+        if (bm) {
+          uint32_t base = 0;
+          if (lane == 0)
+            base = born_slots((uint32_t)__popcll(bm));
+          base = rl32(base, 0);
+          if (bornOk)
+            write_born(base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), kb.kidlev, rel,
+                       kid_packed(kb, lane));
+        }
+        const uint64_t im = __ballot(myAct == 2);
+        if (im) {
+          flush();
+          if (myAct == 2) {
+            const uint32_t idx = qn + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
+            if (idx < Q) {
+              qidA[idx] = kid_packed(kb, lane);
+              qmetaA[idx] = myY | ((uint32_t)sh_cls[pc].kid[lane] << 16);
+            }
+          }
+          qn += (uint32_t)__popcll(im);
+        }
+      }
+      if (lane == 0) {
+        cx.next = (uint8_t)k;
+        cx.found = (uint8_t)found;
+      }
+      if (pushed && depth < kMxFrames) {
+        const uint64_t kid = kid_packed(kb, k - 1);
+        KidBox nkb;
+        kid_box_l(unpack_node(kid), nkb);
+        if (lane == 0) {
+          MxCtx& nc = sh_ctx[depth];
+          nc.parent = kid;
+          nc.kb = nkb;
+          nc.pc = sh_cls[pc].kid[k - 1];
+          nc.next = 0;
+          nc.found = 0;
+        }
+        depth++;
+      }
+      else if (pushed) {   // (cannot happen: the forest is not that deep)
+        if (lane == 0)
+          s.error = 1;
+        r = S;
+      }
+      else if (halted) {
+        MX_WAVE_SYNC();
+        break;
+      }
+      else
+        depth--;
+      MX_WAVE_SYNC();
+      if (kStamps)
+        wk_into += __builtin_readcyclecounter() - ti0;
+    }
+    flush();
+    if (lane == 0) {
+      sh_pos = a + r;
+      sh_e = e;
+      sh_rem = rem;
+      sh_depth = depth;
+      sh_qn[0] = qn;
+      if (qn > Q)
+        s.error = 1;   // (only a damaged stream packs that many sets into a region)
+    }
+    MX_WAVE_SYNC();
+    if (kStamps) {
+      wk_total += __builtin_readcyclecounter() - wk0;
+      wk_calls++;
+    }
+  };
+
+  // ---- expansion of the sets the walk hopped over, breadth first, all threads: leaf parents become leaf
+  //      events, the other sets parse their children with the rows; significant children that are no leaf
+  //      parents go to the next round
+  auto expand_all = [&]() {
+    __syncthreads();
+    uint32_t nin = min(sh_qn[0], Q);
+    for (uint32_t round = 0; nin != 0; round++) {
+      const uint64_t* qidIn = (round & 1u) ? qidB : qidA;
+      const uint32_t* qmIn = (round & 1u) ? qmetaB : qmetaA;
+      uint64_t* qidOut = (round & 1u) ? qidA : qidB;
+      uint32_t* qmOut = (round & 1u) ? qmetaA : qmetaB;
+      uint32_t* qnOut = &sh_qn[(round + 1u) & 1u];
+      if (tid == 0)
+        *qnOut = 0;
+      __syncthreads();
+      for (uint32_t i = (uint32_t)tid; i < nin; i += kMxThreads) {
+        const uint64_t ident = qidIn[i];
+        const uint32_t meta = qmIn[i];
+        const uint32_t ci = (meta >> 16) & 0xffu;
+        uint32_t y = meta & 0xffffu;
+        uint64_t packed = ident;
+        if (meta >> 24) {
+          packed = lisCur[ident];
+          atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
+        }
+        if (ci >= b.tree.ncls)
+          continue;   // (cannot happen)
+        const Node nd = unpack_node(packed);
+        const uint32_t nk = sh_cls[ci].nk;
+        if (sh_cls[ci].h == 0) {
+          leaf_event(nd, y, nk);
+          continue;
+        }
+        KidBox kb;
+        kid_box_l(nd, kb);
+        const uint64_t kc = sh_kcol[ci];
+        uint32_t found = 0;
+        for (uint32_t k = 0; k < nk; k++) {
+          const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+          const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
+          const uint32_t bit = coded ? bit_at(y) : 1u;
+          const uint32_t start = y + coded;
+          if (col == 0) {   // a single sample: its sign follows
+            pixel_event(kid_pixel_raster(b.tree, nd, kb, k), bit != 0, bit ? bit_at(start) : 1u);
+            found |= bit;
+            y = start + bit;
+            continue;
+          }
+          if (!bit) {
+            record_born(kb.kidlev, a + y, kid_packed(kb, k));
+            y += 1;
+            continue;
+          }
+          found = 1;
+          // (an implied child is the last one: nothing follows it, its length is not needed)
+          const uint32_t tl = (coded && col < (uint32_t)kMxCols) ? (uint32_t)Tr[(size_t)min(start, W + 2) * kMxCols + col] : 0u;
+          y = min(start + (tl < kTNone ? tl : 0u), W + 2);
+          if (col < 4u)
+            leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
+          else {
+            const uint32_t slot = atomicAdd(qnOut, 1u);
+            if (slot < Q) {
+              qidOut[slot] = kid_packed(kb, k);
+              qmOut[slot] = start | ((uint32_t)sh_cls[ci].kid[k] << 16);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (*qnOut > Q && tid == 0)
+        s.error = 1;   // (only a damaged stream packs that many sets into a region)
+      nin = min(*qnOut, Q);
+      if (round > 8)
+        break;   // (h <= 3: at most four rounds)
+    }
+    __syncthreads();
+  };
+
+  uint64_t tk0 = 0;
+  for (;;) {
+    // ---- ticket
+    if (tid == 0) {
+      const bool over = __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1;
+      sh_ticket = over ? kNoTicket : atomicAdd(&s.hiTicket, 1u);
+      sh_qn[0] = sh_qn[1] = 0;
+      sh_stop = 0;
+      sh_abort = 0;
+      sh_needFill = 0;
+      if (kStamps)
+        tk0 = __builtin_readcyclecounter();
+    }
+    __syncthreads();
+    const uint32_t i = sh_ticket;
+    if (i == kNoTicket)
+      break;
+    // (tickets are taken ahead of the chain: one past the flags is past the stream and all its padding, no
+    //  phase gets there)
+    if (((size_t)i + 1) * kMxWordsPerRegion > b.hiFlagStride)
+      break;
+    a = phase0 + (uint64_t)i * S;
+    wq0 = (uint32_t)(a & 63);
+    {
+      const uint64_t w0 = a >> 6;
+      for (uint32_t k = tid; k < kWords; k += kMxThreads) {
+        const uint64_t idx = w0 + k;
+        wbits[k] = idx < nwordsAvail ? words[idx] : 0ull;
+      }
+    }
+    __syncthreads();
+    build_rows();
+    __syncthreads();
+    if (kStamps && tid == 0)
+      sh_tk[0] = __builtin_readcyclecounter();
+
+    // ---- the chain
+    if (wave == 0) {
+      // look back (lanes 0..5 take one word each)
+      if (lane < 6) {
+        unsigned long long f = 0;
+        if (i > 0) {
+          uint32_t spins = 0;
+          for (;;) {
+            f = __hip_atomic_load(flags + (size_t)(i - 1) * kMxWordsPerRegion + lane, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+            if ((f >> kMxTagShift) == (unsigned long long)(p + 1))
+              break;
+            if ((++spins & 15u) == 0 &&
+                __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+              sh_abort = 1;   // the phase is over
+              break;
+            }
+            if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
+              s.error = 1;
+              __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              sh_abort = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        sh_in[lane] = f;
+      }
+      MX_WAVE_SYNC();
+      if (kStamps && lane == 0)
+        sh_tk[1] = __builtin_readcyclecounter();
+      // every lane works out the same state; lane 0 writes it
+      uint32_t stop = 0, mode = kModeList, level = 0, e = 0, rem = 0, iJ = 0, iPart = 0, iCounter = 0, iNeed = 1;
+      int depth = 1;
+      uint64_t pos = phase0, base = 0;
+      if (i == 0) {
+        const int lv = next_level((int)nlevels);
+        iPart = s.iPart;
+        if (lv >= 0) {
+          level = (uint32_t)lv;
+          rem = sh_len[lv];
+        }
+        // (no list holds an entry: level 0 with nothing left -- the chain below ends the phase, or goes on
+        //  to the type-I set)
+      }
+      else if (sh_abort || (sh_in[0] & kMxOver))
+        stop = 1;
+      else {
+        const unsigned long long f0 = sh_in[0], f1 = sh_in[1], f5 = sh_in[5];
+        pos = phase0 + (f0 & ((1ull << 40) - 1ull));
+        level = (uint32_t)(f0 >> 40) & 63u;
+        depth = (int)((f0 >> 46) & 31u);
+        mode = (uint32_t)(f0 >> 51) & 3u;
+        e = (uint32_t)f1 & 0xfffffffu;
+        rem = (uint32_t)(f1 >> 28) & 0xfffffffu;
+        base = sh_in[4] & ((1ull << kMxTagShift) - 1ull);
+        iJ = (uint32_t)f5 & 3u;
+        iPart = (uint32_t)(f5 >> 2) & 63u;
+        iCounter = (uint32_t)(f5 >> 8) & 3u;
+        iNeed = (uint32_t)(f5 >> 10) & 1u;
+        // (a state that does not add up cannot be followed: give up loudly)
+        bool bad = level >= nlevels || depth < 1 || depth > kMxFrames || pos < a || pos >= a + W;
+        if (mode == kModeList)
+          bad = bad || e + rem != sh_len[level];
+        else
+          bad = bad || !twoD;
+        if (bad) {
+          if (lane == 0) {
+            s.error = 1;
+            __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          stop = 1;
+          depth = 1;
+        }
+        // rebuild the stack of sets being walked into: frame d holds the children of the set that frame
+        // d - 1 entered (frame 1: of the entry at the bottom)
+        uint64_t parent = base;
+        for (int d = 1; d < depth && !stop; d++) {
+          const unsigned long long fw = d <= 11 ? sh_in[2] : sh_in[3];
+          const uint32_t fr = (uint32_t)(fw >> (5 * ((d - 1) % 11))) & 31u;
+          const Node pn = unpack_node(parent);
+          if (pn.grid + 1u >= b.tree.ngrids + 1u || pn.grid >= (uint32_t)kMxLdsGrids) {   // (cannot happen)
+            stop = 1;
+            if (lane == 0)
+              s.error = 1;
+            break;
+          }
+          KidBox kb;
+          kid_box_l(pn, kb);
+          const uint32_t pc = node_cls_l(pn);
+          if (lane == 0) {
+            MxCtx& cx = sh_ctx[d];
+            cx.parent = parent;
+            cx.kb = kb;
+            cx.pc = (uint8_t)pc;
+            cx.next = (uint8_t)(fr & 15u);
+            cx.found = (uint8_t)(fr >> 4);
+          }
+          if (d + 1 < depth) {
+            if ((fr & 15u) == 0 || pc >= b.tree.ncls) {   // (cannot happen: a frame above was entered through a child)
+              stop = 1;
+              if (lane == 0)
+                s.error = 1;
+              break;
+            }
+            parent = kid_packed(kb, (fr & 15u) - 1u);
+          }
+        }
+        if (stop == 1 && lane == 0)
+          __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        sh_pos = pos;
+        sh_base = base;
+        sh_level = level;
+        sh_e = e;
+        sh_rem = rem;
+        sh_depth = depth;
+        sh_mode = mode;
+        sh_iJ = iJ;
+        sh_iPart = iPart;
+        sh_iCounter = iCounter;
+        sh_iNeed = iNeed;
+        sh_stop = stop;
+        sh_needFill = (stop == 0 && mode == kModeList) ? 1u : 0u;
+      }
+      MX_WAVE_SYNC();
+    }
+    for (;;) {
+      __syncthreads();
+      if (sh_stop)
+        break;
+      if (sh_needFill) {
+        const uint64_t tf0 = kStamps ? __builtin_readcyclecounter() : 0;
+        if (kStamps)
+          wk_fills++;
+        const uint32_t l = sh_level, e0 = sh_e, n = sh_len[l];
+        const uint32_t to = min(n, e0 + S + 64u);
+        fill_ring(l, min(e0, to), to);
+        __syncthreads();
+        if (tid == 0) {
+          sh_ringHi = to;
+          sh_needFill = 0;
+        }
+        if (kStamps)
+          wk_fill += __builtin_readcyclecounter() - tf0;
+      }
+      __syncthreads();
+      if (wave != 0)
+        continue;
+      // ---- first wavefront: on until the region ends, the phase ends, or a new list needs its classes
+      for (;;) {
+        uint32_t mode = __builtin_amdgcn_readfirstlane(sh_mode);
+        uint32_t r = (uint32_t)(sh_pos - a);
+        int depth = __builtin_amdgcn_readfirstlane(sh_depth);
+        bool over = false;
+        if (mode == kModeList && depth <= 1 && __builtin_amdgcn_readfirstlane(sh_rem) == 0) {
+          // this list is through: the next one (no bits are read for that)
+          const int lv = next_level((int)sh_level);
+          if (lv >= 0) {
+            if (lane == 0) {
+              sh_level = (uint32_t)lv;
+              sh_e = 0;
+              sh_rem = sh_len[lv];
+              sh_depth = 1;
+              sh_needFill = 1;
+            }
+            MX_WAVE_SYNC();
+            if (r < S)
+              break;   // (all hands: the new list's classes)
+          }
+          else if (twoD) {
+            if (lane == 0) {
+              sh_mode = kModeITest;
+              sh_depth = 1;
+            }
+            MX_WAVE_SYNC();
+            continue;
+          }
+          else
+            over = true;
+        }
+        if (!over && r >= S) {
+          // ---- publish the state at the end of the region
+          const uint32_t dpt = (uint32_t)max(__builtin_amdgcn_readfirstlane(sh_depth), 1);
+          unsigned long long fr0 = 0, fr1 = 0;
+          for (uint32_t d = 1; d < dpt; d++) {
+            const unsigned long long v = (unsigned long long)((sh_ctx[d].next & 15u) | ((sh_ctx[d].found ? 1u : 0u) << 4));
+            if (d <= 11)
+              fr0 |= v << (5 * (d - 1));
+            else
+              fr1 |= v << (5 * (d - 12));
+          }
+          unsigned long long f = tag;
+          if (lane == 0)
+            f |= (sh_pos - phase0) | ((unsigned long long)sh_level << 40) | ((unsigned long long)dpt << 46) |
+                 ((unsigned long long)sh_mode << 51);
+          else if (lane == 1)
+            f |= (unsigned long long)sh_e | ((unsigned long long)sh_rem << 28);
+          else if (lane == 2)
+            f |= fr0;
+          else if (lane == 3)
+            f |= fr1;
+          else if (lane == 4)
+            f |= sh_base & ((1ull << kMxTagShift) - 1ull);
+          else if (lane == 5)
+            f |= (unsigned long long)sh_iJ | ((unsigned long long)sh_iPart << 2) |
+                 ((unsigned long long)sh_iCounter << 8) | ((unsigned long long)sh_iNeed << 10);
+          if (lane < 6)
+            __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, f, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0)
+            sh_stop = 3;
+          MX_WAVE_SYNC();
+          break;
+        }
+        if (!over && mode == kModeITest) {
+          // the type-I set: nothing left of it, or its test bit says the rest is insignificant: the phase ends
+          uint32_t iPart = __builtin_amdgcn_readfirstlane(sh_iPart);
+          if (iPart == 0)
+            over = true;
+          else {
+            uint32_t bit = 1;
+            if (__builtin_amdgcn_readfirstlane(sh_iNeed)) {
+              bit = bit_at(r);
+              r += 1;
+            }
+            if (lane == 0)
+              sh_pos = a + r;
+            if (!bit)
+              over = true;
+            else if (lane == 0) {
+              sh_iJ = 0;
+              sh_iCounter = 0;
+              sh_mode = kModeISub;
+            }
+            MX_WAVE_SYNC();
+            if (!over)
+              continue;
+          }
+        }
+        if (!over && mode == kModeISub) {
+          const uint32_t iJ = __builtin_amdgcn_readfirstlane(sh_iJ), iPart = __builtin_amdgcn_readfirstlane(sh_iPart);
+          if (iJ >= 3u) {   // the three subbands are through: what is left of the type-I set comes next
+            if (lane == 0) {
+              sh_iPart = iPart - 1u;
+              sh_iNeed = sh_iCounter != 0 ? 1u : 0u;
+              sh_mode = kModeITest;
+            }
+            MX_WAVE_SYNC();
+            continue;
+          }
+          const uint64_t root = b.iRoots[(size_t)(b.iLevels - iPart) * 3 + iJ];
+          if (lane == 0)
+            sh_iJ = iJ + 1u;
+          if (root == ~0ull) {   // (an empty subband)
+            MX_WAVE_SYNC();
+            continue;
+          }
+          // the subband is tested like a list of one entry
+          const uint32_t bit = bit_at(r);
+          if (!bit) {
+            if (lane == 0) {
+              record_born(iPart, a + r, root);
+              sh_pos = a + r + 1u;
+            }
+            MX_WAVE_SYNC();
+            continue;
+          }
+          const Node rn = unpack_node(root);
+          const uint32_t ci = node_cls_l(rn);
+          const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
+          const uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)(r + 1u) * kMxCols + col] : kTNone;
+          if (tl < kTNone) {
+            if (lane == 0) {
+              const uint32_t qn = sh_qn[0];
+              if (qn < Q) {
+                qidA[qn] = root;
+                qmetaA[qn] = (r + 1u) | (ci << 16);
+              }
+              sh_qn[0] = qn + 1u;
+              sh_iCounter = sh_iCounter + 1u;
+              sh_pos = a + r + 1u + tl;
+            }
+            MX_WAVE_SYNC();
+            continue;
+          }
+          KidBox kb;
+          kid_box_l(rn, kb);
+          if (lane == 0) {
+            MxCtx& nc = sh_ctx[1];
+            nc.parent = root;
+            nc.kb = kb;
+            nc.pc = (uint8_t)ci;
+            nc.next = 0;
+            nc.found = 0;
+            sh_base = root;
+            sh_iCounter = sh_iCounter + 1u;
+            sh_pos = a + r + 1u;
+            sh_depth = 2;
+            sh_rem = 0;
+            sh_e = 0;
+            sh_mode = kModeISubWalk;
+          }
+          MX_WAVE_SYNC();
+          continue;
+        }
+        if (over) {
+          // ---- the phase ends here
+          if (lane == 0) {
+            s.hiEnd = sh_pos;
+            if (twoD)
+              s.iPart = sh_iPart;
+          }
+          if (lane < 6)
+            __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, tag | kMxOver, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_stop = 2;
+          }
+          MX_WAVE_SYNC();
+          break;
+        }
+        // ---- list entries, or the children of the sets being walked into
+        walk();
+        if (mode == kModeISubWalk && __builtin_amdgcn_readfirstlane(sh_depth) == 0) {
+          if (lane == 0) {
+            sh_depth = 1;
+            sh_mode = kModeISub;
+          }
+          MX_WAVE_SYNC();
+        }
+      }
+    }
+    if (kStamps && tid == 0)
+      sh_tk[2] = __builtin_readcyclecounter();
+    const uint32_t stop = sh_stop;
+    if (stop != 1)
+      expand_all();
+    if (kStamps && tid == 0 && b.lisStamps) {
+      unsigned long long* out = reinterpret_cast<unsigned long long*>(b.lisStamps + (size_t)c * 64);
+      const uint64_t t3 = __builtin_readcyclecounter();
+      atomicAdd(out + 0, 1ull);
+      atomicAdd(out + 1, (unsigned long long)(sh_tk[0] - tk0));        // load + rows
+      atomicAdd(out + 2, (unsigned long long)(sh_tk[1] - sh_tk[0]));   // look-back wait
+      atomicAdd(out + 3, (unsigned long long)(sh_tk[2] - sh_tk[1]));   // on the chain
+      atomicAdd(out + 4, (unsigned long long)(t3 - sh_tk[2]));         // expansion
+      atomicAdd(out + 5, (unsigned long long)wk_fill);
+      atomicAdd(out + 6, (unsigned long long)wk_fills);
+      atomicAdd(out + 7, (unsigned long long)wk_total);
+      atomicAdd(out + 8, (unsigned long long)wk_calls);
+      atomicAdd(out + 9, (unsigned long long)wk_tight);
+      atomicAdd(out + 10, (unsigned long long)wk_hopsT);
+      atomicAdd(out + 11, (unsigned long long)wk_hopsG);
+      atomicAdd(out + 12, (unsigned long long)wk_rounds);
+      atomicAdd(out + 13, (unsigned long long)wk_into);
+      atomicAdd(out + 14, (unsigned long long)wk_words);
+      atomicAdd(out + 15, (unsigned long long)wk_zruns);
+      wk_fill = wk_total = wk_tight = wk_into = 0;
+      wk_fills = wk_calls = wk_hopsT = wk_hopsG = wk_rounds = wk_words = wk_zruns = 0;
+    }
+    if (stop == 1 || stop == 2)
+      break;
+    __syncthreads();   // LDS is reused by the next region
+  }
+  __syncthreads();
+  if (tid == 0 && blockIdx.x < 8) {
+    s.hiBornCnt[blockIdx.x] = min(min(sh_segBorn, sh_segBornEnd), b.bornSeg);
+    s.hiLeafCnt[blockIdx.x] = min(sh_segLeaf, b.leafSeg);
+  }
+}
+
+}  // namespace
+
+uint32_t mx_smem_bytes(uint32_t S, uint32_t M, uint32_t Q)
+{
+  const uint32_t W = S + M;
+  const uint32_t kWords = ((W >> 6) + 5u) & ~1u;
+  return kWords * 8u + (((W + 3u) * (uint32_t)kMxCols * 2u + 15u) & ~15u) + 2u * Q * 12u + kMxRing * 2u;
+}
+
+int prepare_lis_mx(const DecBuffers& b)
+{
+  if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mx<false>), (int)b.mxSmemBytes) ||
+      set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mx<true>), (int)b.mxSmemBytes))
+    return -1;
+  return 0;
+}
+
+int launch_lis_mx(hipStream_t stream, const DecBuffers& b, int p, uint32_t groups, bool stamps)
+{
+  if (stamps)
+    LAUNCH_K(k_lis_mx<true>, dim3(groups, b.nchunks), dim3(kMxThreads), b.mxSmemBytes, stream, b, p);
+  else
+    LAUNCH_K(k_lis_mx<false>, dim3(groups, b.nchunks), dim3(kMxThreads), b.mxSmemBytes, stream, b, p);
+  return 0;
+}
+
+}  // namespace sperrhip

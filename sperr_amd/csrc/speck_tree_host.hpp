@@ -72,6 +72,8 @@ struct HostTree {
   std::vector<uint8_t> gridCls;                // [grid][8]
   std::vector<uint64_t> clsCount;              // sets of the forest per class
   std::vector<uint8_t> levelGroup;             // per list level: column group of most of its entries
+  std::vector<uint8_t> mxSlot;                 // k_lis_mx: column of every class (0xff: none), build_mx_columns
+  std::vector<uint8_t> mxLevelGroup;           // k_lis_mx: per list level, dominant column group | highest << 4
   uint32_t nslots = 0;                         // classes that have a table slot
   uint32_t slotMaxT = 0;                       // longest split of a class with a table
   uint32_t dims[3] = {0, 0, 0};
@@ -315,6 +317,82 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
   }
 }
 
+// Columns of k_lis_mx (the GPU-wide decoder of lists that mix set shapes, speck_mx.hip): sixteen per
+// stream position -- 0 a single sample, 1..3 the leaf parents of 2 / 4 / 8 samples, then four each for
+// the most frequent classes one, two and THREE steps above the leaf parents (its rows are built off the
+// serial chain by as many workgroups as it takes, so it can afford a column group more than k_lis_mixed).
+// A class needs columns for all its children.  mxLevelGroup[l]: low bits = the group most entries of
+// list level l belong to, bits 4..5 = the highest group an entry of that level can have.
+constexpr int kMxGroups = 4;
+inline void build_mx_columns(HostTree& h)
+{
+  h.mxSlot.assign(h.cls.size(), 0xff);
+  h.mxLevelGroup.assign(h.nlevels, 0);
+  if (h.cls.empty())
+    return;
+  for (size_t i = 0; i < h.cls.size(); i++) {
+    const ShapeCls& c = h.cls[i];
+    if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8))
+      h.mxSlot[i] = (uint8_t)(c.nk == 2 ? 1 : c.nk == 4 ? 2 : 3);
+  }
+  for (int hh = 1; hh < kMxGroups; hh++) {
+    std::vector<size_t> order;
+    for (size_t i = 0; i < h.cls.size(); i++)
+      if (h.cls[i].h == hh)
+        order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+      return h.clsCount[x] != h.clsCount[y] ? h.clsCount[x] > h.clsCount[y] : x < y;
+    });
+    uint32_t next = 4u * (uint32_t)hh;
+    for (size_t i : order) {
+      const ShapeCls& c = h.cls[i];
+      bool ok = next < 4u * (uint32_t)hh + 4u && c.maxT < 0x7000u && h.clsCount[i] != 0;
+      for (int k = 0; k < c.nk; k++)
+        ok = ok && (c.kid[k] == kClsPixel || h.mxSlot[c.kid[k]] != 0xff);
+      if (ok)
+        h.mxSlot[i] = (uint8_t)next++;
+    }
+  }
+  std::vector<std::array<uint64_t, kMxGroups>> cnt(h.nlevels);
+  std::vector<uint32_t> top(h.nlevels, 0);
+  for (auto& c : cnt)
+    c.fill(0);
+  const Tree tv = h.view();
+  for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
+    const Grid& g = h.grids[gi];
+    const Root& r = h.roots[g.root];
+    // (class and level of a node depend on which of its three intervals are the long ones, and -- the level, on
+    //  saturated axes -- on whether the parent interval still split: enumerate every node, the grids are small
+    //  next to the volume)
+    Node n;
+    n.grid = (uint16_t)gi;
+    (void)r;
+    for (uint32_t z = 0; z < (1u << g.e[2]); z++)
+      for (uint32_t y = 0; y < (1u << g.e[1]); y++)
+        for (uint32_t x = 0; x < (1u << g.e[0]); x++) {
+          n.i[0] = (uint16_t)x;
+          n.i[1] = (uint16_t)y;
+          n.i[2] = (uint16_t)z;
+          const uint32_t ci = node_cls(tv, n);
+          if (ci == kClsPixel)
+            continue;
+          const uint32_t l = node_level(tv, n);
+          if (l >= h.nlevels)
+            continue;
+          top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, kMxGroups - 1));
+          if (h.mxSlot[ci] != 0xff)
+            cnt[l][h.mxSlot[ci] >> 2]++;
+        }
+  }
+  for (uint32_t l = 0; l < h.nlevels; l++) {
+    uint32_t best = 0;
+    for (uint32_t g = 1; g < (uint32_t)kMxGroups; g++)
+      if (cnt[l][g] > cnt[l][best])
+        best = g;
+    h.mxLevelGroup[l] = (uint8_t)(best | (top[l] << 4));
+  }
+}
+
 // twoD: the forest of the 2D coder for a slice of dx x dy samples (dz = 1): the root set S is the
 // coarsest approximation, at list level = the number of transform levels; the three detail subbands
 // of every level are roots too (released by the type-I set, SPECK2D_INT.cpp:149-218: they are NOT
@@ -546,6 +624,7 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false)
   if (twoD)   // (the chains of LevelClass follow the 3D level rule: the 2D forest goes by shape classes only)
     h.allRegular = false;
   build_classes(h, kClsTableH, kClsTableSlots);
+  build_mx_columns(h);
   return h;
 }
 
