@@ -2374,6 +2374,23 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     return (size_t)box[0] * box[1] * box[2];
   };
   bool deferSized = false;
+  // chunks of this call that decode through k_lis_mx, whatever their shape group: they run side by side, each with
+  // several one-per-CU workgroups (the rows of a chunk's regions take about four workgroups to keep its serial walk
+  // fed), so the groups share one budget of workgroups (SPERR_HIP_MX_WGS; with more workgroups than CUs the chunks
+  // launched last wait for the first ones to END: 1000^3 in 256^3 chunks, 37 such chunks at 8 workgroups each,
+  // decoded no faster than with one workgroup per chunk)
+  uint32_t mxGroupsCall = 0;
+  {
+    size_t nmx = 0;
+    for (auto& h : groups) {
+      ShapePlan* Q = (slice && slice_forest_enabled()) ? E.plan(h.first[0], h.first[1], 0) : E.plan(h.first[0], h.first[1], h.first[2]);
+      if (Q && use_mx(*Q))
+        nmx += h.second.size();
+    }
+    static const uint32_t mxBudget = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 208u;
+    if (nmx)
+      mxGroupsCall = std::min<uint32_t>(8u, std::max<uint32_t>(2u, (uint32_t)(mxBudget / nmx)));
+  }
   // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mixed and its
   // type-I phase); SPERR_HIP_SLICE_MIXED=0: by k_speck2d_decode, one workgroup walking the quadtree
   const bool sliceMixed = slice_forest_enabled();
@@ -2608,6 +2625,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
         ph.mx = use_mx(*P);
+        ph.mxGroups = mxGroupsCall;
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
         static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
         ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;
@@ -3556,7 +3574,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);
     ph.mixed = use_mixed(*P);
-        ph.mx = use_mx(*P);
+    ph.mx = use_mx(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));

@@ -155,6 +155,8 @@ struct DecPlanHost {
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
   bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
   bool mx = false;             // ... GPU-wide: k_lis_mx instead of k_lis_mixed (several workgroups per chunk)
+  uint32_t mxGroups = 0;       // workgroups per chunk of k_lis_mx (0: the launcher's own choice by the batch's size) --
+                               //   the caller knows how many such chunks of OTHER shapes decode beside this batch
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
   // Fixed-rate streams run out of bits many planes above plane 0, and the launches of a plane that
   // holds no work still cost about 0.1 ms per batch.  With d_live set (kLiveSlots device words) the

@@ -4491,9 +4491,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
   // workgroups per chunk of k_lis_mx: the walk of a chunk is serial, the rows and the expansion of its regions are
   // what the other workgroups are for (SPERR_HIP_MX_WGS: the total over the batch's chunks)
-  static const uint32_t mxTotal = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 256u;
+  static const uint32_t mxTotal = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 208u;
   const uint32_t mxGroups = std::min<uint32_t>(std::min<uint32_t>(8u, std::max<uint32_t>(1, b.hiGroupsMax)),
-                                               std::max<uint32_t>(1, mxTotal / nc));
+                                               plan.mxGroups ? plan.mxGroups : std::max<uint32_t>(1, mxTotal / nc));
   if (plan.mixed && plan.mx && prepare_lis_mx(b))
     return -1;
   if (plan.mixed) {

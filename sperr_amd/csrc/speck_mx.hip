@@ -41,6 +41,7 @@ constexpr uint32_t kMxTagShift = 57;
 constexpr unsigned long long kMxOver = 1ull << 56;
 constexpr int kMxFrames = kMaxDepth + 2;
 constexpr uint32_t kNoTicket = 0xffffffffu;
+constexpr int kMxRecs = 160;   // per-word records a region's walk can leave (one per word and reload of entry classes)
 
 // what the chain is doing (2D coder: the type-I set, /root/reference/src/SPECK2D_INT.cpp:44-98)
 constexpr uint32_t kModeList = 0;      // the entries of list `level`
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ MxCtx sh_ctx[kMxFrames + 1];
   __shared__ uint8_t sh_colCls[kMxCols];            // class of every column (0xff: unused)
   __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
-  __shared__ uint8_t sh_lgrp[kMaxLevels];           // dominant column group of every list level
+  __shared__ uint8_t sh_lgrp[kMaxLevels];           // the two column groups most entries of a list level belong to (2 bits each)
   __shared__ uint32_t sh_len[kMaxLevels], sh_lOff[kMaxLevels];
   // chain state (the first wavefront owns it; the others read it between barriers)
   __shared__ uint64_t sh_pos, sh_base;
@@ -94,6 +95,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ uint32_t sh_qn[2], sh_ncand;
   __shared__ uint32_t sh_segBorn, sh_segLeaf, sh_segBornEnd;   // filled slots of this workgroup's segments
   __shared__ unsigned long long sh_in[8];
+  __shared__ uint64_t sh_recM[kMxRecs][2];   // per-word records of the walk's tight loop: positions, entry ordinals
+  __shared__ uint32_t sh_recE[kMxRecs], sh_recK[kMxRecs], sh_nrec;   //   first entry (index into the chunk's lists), word
   __shared__ uint64_t sh_tk[4];
 
   const int tid = threadIdx.x;
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   if (tid < kMaxLevels) {
     const bool in = (uint32_t)tid < nlevels;
     sh_levelSlot[tid] = in ? b.levelSlot[tid] : (uint8_t)0xff;
-    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 3u) : (uint8_t)0;
+    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 31u) : (uint8_t)4;
     sh_len[tid] = in ? s.listLen[cur][tid] : 0u;
     sh_lOff[tid] = in ? b.levelOff[tid] : 0u;
   }
@@ -352,57 +355,41 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     // columns 4..7, 8..11, 12..15: a chain of look-ups through the children's columns at the collected
     // positions (four per thread and round: their LDS round trips overlap)
     const uint32_t ncand = sh_ncand;
+    uint32_t hPrev = 0;
     for (uint32_t g4 = 4; g4 < (uint32_t)kMxCols; g4 += 4) {
       bool any = false;
       for (uint32_t col = g4; col < g4 + 4; col++) {
         const uint32_t ci = sh_colCls[col];
         if (ci == 0xff)
           continue;
+        if (any && sh_cls[ci].h != hPrev)   // (its children's columns may be this group's: columns go by steps)
+          __syncthreads();
         any = true;
+        hPrev = sh_cls[ci].h;
         const uint32_t nk = sh_cls[ci].nk;
         const uint64_t kc = sh_kcol[ci];
-        for (uint32_t i = tid; i < ncand; i += 4 * kMxThreads) {
-          uint32_t x[4], y[4], found[4], bad[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t iu = i + (uint32_t)u * kMxThreads;
-            x[u] = iu < ncand ? (uint32_t)cand[iu] : W + 1u;
-            y[u] = x[u];
-            found[u] = 0;
-            bad[u] = 0;
-          }
+        // (one position per thread and round: sixteen wavefronts hide the LDS round trips of each other's chains --
+        //  k_lis_mixed's four chains per thread in lockstep cost this kernel four times the instructions for
+        //  windows that hold fewer candidates than the workgroup has threads)
+        for (uint32_t i = tid; i < ncand; i += kMxThreads) {
+          const uint32_t x = (uint32_t)cand[i];
+          uint32_t y = x, found = 0, bad = 0;
           for (uint32_t k = 0; k < nk; k++) {
             const uint32_t ccol = (uint32_t)(kc >> (8 * k)) & 0xffu;
-            const uint32_t last = k + 1 == nk ? 1u : 0u;
-            uint32_t bitv[4], s0[4], tl[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t coded = found[u] | (last ^ 1u);
-              const uint32_t yy = min(y[u], W + 1);
-              bitv[u] = coded ? bit_at(yy) : 1u;
-              s0[u] = yy + coded;
-              tl[u] = Tr[(size_t)s0[u] * kMxCols + ccol];
-              y[u] = yy;
+            const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+            const uint32_t yy = min(y, W + 1);
+            const uint32_t bitv = coded ? bit_at(yy) : 1u;
+            const uint32_t s0 = yy + coded;
+            uint32_t t = Tr[(size_t)s0 * kMxCols + ccol];
+            if (t >= kTNone) {
+              bad |= bitv ? (t == kTInf ? 1u : 2u) : 0u;
+              t = 0;
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              uint32_t t = tl[u];
-              if (t >= kTNone) {
-                bad[u] |= bitv[u] ? (t == kTInf ? 1u : 2u) : 0u;
-                t = 0;
-              }
-              y[u] = bitv[u] ? s0[u] + t : y[u] + 1;
-              found[u] |= bitv[u];
-            }
+            y = bitv ? s0 + t : yy + 1;
+            found |= bitv;
           }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t iu = i + (uint32_t)u * kMxThreads;
-            if (iu < ncand) {
-              const uint32_t t = ((bad[u] & 1u) || y[u] > W) ? kTInf : (bad[u] & 2u) ? kTNone : y[u] - x[u];
-              Tr[(size_t)x[u] * kMxCols + col] = (uint16_t)t;
-            }
-          }
+          const uint32_t t = ((bad & 1u) || y > W) ? kTInf : (bad & 2u) ? kTNone : y - x;
+          Tr[(size_t)x * kMxCols + col] = (uint16_t)t;
         }
       }
       if (any)
@@ -413,12 +400,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   // ---- classes of the entries [from, to) of list `l` into the ring, with their column inside the list's group
   auto fill_ring = [&](uint32_t l, uint32_t from, uint32_t to) {
     const uint64_t* list = lisCur + sh_lOff[l];
-    const uint32_t grp = sh_lgrp[l];
+    const uint32_t ga = sh_lgrp[l] & 3u, gb = (sh_lgrp[l] >> 2) & 3u;
     for (uint32_t i = from + (uint32_t)tid; i < to; i += kMxThreads) {
       const uint32_t ci = node_cls_l(unpack_node(list[i]));
       const uint32_t col = sh_slot[ci];
-      ecls[i & (uint32_t)(kMxRing - 1)] =
-          (uint16_t)(ci | ((col < (uint32_t)kMxCols && (col >> 2) == grp ? (col & 3u) : 0xffu) << 8));
+      const uint32_t loc = col >= (uint32_t)kMxCols ? 0xffu : (col >> 2) == ga ? (col & 3u) : (col >> 2) == gb ? 4u + (col & 3u) : 0xffu;
+      ecls[i & (uint32_t)(kMxRing - 1)] = (uint16_t)(ci | (loc << 8));
     }
   };
 
@@ -428,33 +415,60 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
   auto walk = [&]() {
     const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
-    uint32_t r = (uint32_t)(sh_pos - a), e = __builtin_amdgcn_readfirstlane(sh_e),
+    uint32_t r = __builtin_amdgcn_readfirstlane((uint32_t)(sh_pos - a)), e = __builtin_amdgcn_readfirstlane(sh_e),
              rem = __builtin_amdgcn_readfirstlane(sh_rem);
     uint32_t qn = __builtin_amdgcn_readfirstlane(sh_qn[0]), ns = 0;
     int depth = __builtin_amdgcn_readfirstlane(sh_depth);
     const uint32_t level = __builtin_amdgcn_readfirstlane(sh_level);
     const uint32_t lOff = sh_lOff[level];
     const uint64_t* list = lisCur + lOff;
-    const uint32_t grp = sh_lgrp[level];
+    const uint32_t ga = sh_lgrp[level] & 3u, gb = (sh_lgrp[level] >> 2) & 3u;
+    const uint32_t hopLim = 0xfdu;
     const uint32_t ringHi = __builtin_amdgcn_readfirstlane(sh_ringHi);
     uint32_t stE = 0, stM = 0;   // staged items of the list hops: lane = item
     // lane = stream word of the region
     const uint64_t sw0 = lane < kWords ? wbits[lane] : 0ull;
-    const uint64_t sw1 = lane + 64u < kWords ? wbits[lane + 64u] : 0ull;
     uint32_t curK = 0xffffffffu;   // stream word the registers below belong to
     uint64_t m = 0;                // that word (uniform)
-    uint64_t lrow = 0;             // lane = bit of it: the group's four row entries one position on
+    // lane = bit of it: the split lengths of the list's two column groups one position on, eight bits each
+    // (0xff: 255 bits and more, or none -- the general code looks at the row itself)
+    uint32_t lrowA = 0, lrowB = 0;
     uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
-    uint64_t lrowNext = 0;         // the same for word nextK
-    uint32_t nextK = 0xfffffffeu;
-    auto load_lrow = [&](uint32_t kk) -> uint64_t {
+    typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+    auto pack8 = [&](uint64_t v) -> uint32_t {
+      const us2_t lim = {255, 255};
+      const us2_t lo = __builtin_elementwise_min(__builtin_bit_cast(us2_t, (uint32_t)v), lim);
+      const us2_t hi = __builtin_elementwise_min(__builtin_bit_cast(us2_t, (uint32_t)(v >> 32)), lim);
+      return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+    };
+    auto load_lrow = [&](uint32_t kk) {
       const int32_t row = (int32_t)(kk * 64u + lane) - (int32_t)wq0 + 1;
-      return (row >= 0 && row <= (int32_t)W + 2)
-                 ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMxCols + grp * 4u)
-                 : ~0ull;
+      uint64_t va = ~0ull, vb = ~0ull;
+      if (row >= 0 && row <= (int32_t)W + 2) {
+        va = *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMxCols + ga * 4u);
+        vb = *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMxCols + gb * 4u);
+      }
+      lrowA = pack8(va);
+      lrowB = pack8(vb);
     };
     uint32_t eb = 0x80000000u;     // lane = list entry eb + lane: its ecls word (nothing loaded yet)
-    uint32_t ecv = 0;
+    uint32_t ecv = 0, ecb = 0;
+    uint32_t nrec = __builtin_amdgcn_readfirstlane(sh_nrec), nloc = 0;   // records in LDS, records in the registers below
+    uint32_t rcL = 0, rcH = 0, riL = 0, riH = 0, rE = 0, rK = 0;         // lane = record: position mask, ordinal mask, first entry, word
+    auto rec_flush = [&]() {
+      if (lane < nloc && nrec + lane < (uint32_t)kMxRecs) {
+        sh_recM[nrec + lane][0] = (uint64_t)rcL | ((uint64_t)rcH << 32);
+        sh_recM[nrec + lane][1] = (uint64_t)riL | ((uint64_t)riH << 32);
+        sh_recE[nrec + lane] = rE;
+        sh_recK[nrec + lane] = rK;
+      }
+      nrec += nloc;
+      nloc = 0;
+    };
+    const uint32_t kkLast = ((S + wq0) >> 6) - 1u;   // last stream word that lies inside the region
+    // LDS address of lane's row entries (the list's column group) for word 0: + word << 11
+    const uint32_t adBase = (uint32_t)(size_t)Tr + (uint32_t)((int32_t)(lane + 1u) - (int32_t)wq0) * (uint32_t)(kMxCols * 2);
+    const uint32_t adBaseA = adBase + ga * 8u, adBaseB = adBase + gb * 8u;
     auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
       return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);
     };
@@ -480,92 +494,133 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         const uint32_t q = r + wq0, k = q >> 6, o = q & 63u;
         if (k != curK) {
           curK = k;
-          m = k < 64u ? rl64(sw0, k) : rl64(sw1, k - 64u);
+          m = rl64(sw0, k & 63u);
           lrowK = 0xffffffffu;
         }
-        // Stream words that lie inside the region, with at least 64 entries left and room for 64 more
-        // items: their entries in a tight loop, word after word -- no end-of-list, end-of-region or queue
-        // checks per entry; anything unusual (a set to walk into) is left to the general code below.
-        if (rem >= 64u && k * 64u + 64u <= S + wq0 && qn + ns + 160u < Q) {
-          const uint32_t eEnd = e + rem;
+        // Stream words that lie inside the region, with at least 64 entries left: their entries in a tight
+        // loop, word after word -- no end-of-list or end-of-region checks per entry; anything unusual (a set to
+        // walk into) is left to the general code below.  The loop only HOPS: per significant entry one bit in
+        // each of two masks of a per-word record (its position in the word, its ordinal among the entries from
+        // `eb` on); the work items are made from the records off the chain (convert_records).
+        if (rem >= 64u && k <= kkLast && nrec + nloc + 2u < (uint32_t)kMxRecs) {
+          const uint32_t eEnd = e + rem, eStop = eEnd - 64u;
           uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
           bool unusual = false;
           const uint64_t tt0 = kStamps ? __builtin_readcyclecounter() : 0;
-          const uint32_t hops0 = qn + ns;
+          if (lrowK != kk)
+            load_lrow(kk);
           while (true) {
             if (kStamps)
               wk_words++;
-            if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
-              if (kk != curK) {
-                curK = kk;
-                m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
-              }
-              lrow = nextK == kk ? lrowNext : load_lrow(kk);
-              lrowK = kk;
-              nextK = kk + 1u;
-              lrowNext = load_lrow(nextK);
-            }
-            // (at most 64 entries start inside a word, at most 32 of them significant: one load
-            // of entry classes and the staging registers cover it)
+            m = rl64(sw0, kk);
+            // the next word's row entries are fetched while this word is walked (inside the asm block below: the
+            // compiler waits for every LDS load in flight before an asm statement).  Rows 1 .. S + 128 exist.
+            uint64_t lrowNA, lrowNB;
+            const uint32_t adNA = adBaseA + ((kk + 1u) << 11), adNB = adBaseB + ((kk + 1u) << 11);
+            // (at most 64 entries start inside a word: one load of entry classes covers it)
             if (e - eb > oo) {   // (the entries of this word: fewer than 64 - oo from e on)
               eb = e;
               ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMxRing - 1)] : 0xffffu;
+              // what the loop wants of an entry: the s_bfe_u32 operand that cuts its class's split length out of
+              // one of the two group registers (offset 0 / 8 / 16 / 24, width 8; bit 8: the second group) -- width 0
+              // for a class of neither group: length 0, "unusual"
+              const uint32_t loc = ecv >> 8;
+              ecb = loc >= 8u ? 0u : (((loc & 3u) << 3) | (8u << 16) | ((loc >> 2) << 8));
             }
-            if (ns > 32u)
-              flush();
-            const uint32_t pbase = kk * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
-            while (true) {   // oo < 64 here
-              const uint64_t mm = m >> oo;
-              const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
-              oo += z;
-              e += z;
-              const uint32_t ec = rl32(ecv, (e - eb) & 63u);
-              const uint32_t loc = ec >> 8;
-              const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
-              if (oo >= 64u)
-                break;   // the word is done
-              if (loc == 0xffu || tl >= kTNone) {
-                unusual = true;   // something the general code has to look at
-                break;
-              }
-              {   // lane ns of the staging registers takes the item (the values stay scalar)
-                const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
-                const uint32_t itemE = __builtin_amdgcn_readfirstlane(lOff + e), itemL = __builtin_amdgcn_readfirstlane(ns);
-                asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                             : "+v"(stE), "+v"(stM)
-                             : "s"(itemE), "s"(itemL), "s"(itemM)
-                             : "m0");
-              }
-              ns++;
-              oo += 1u + tl;
-              e++;
-              if (oo >= 64u)
-                break;
+            uint32_t idx = e - eb, st;
+            uint64_t cm = 0, im = 0;
+            {
+              uint32_t t_, z_, ec_, lo_, hi_;
+              uint64_t mm_;
+              asm volatile(
+                  "ds_read_b64 %[nxa], %[ada]\n\t"
+                  "ds_read_b64 %[nxb], %[adb]\n\t"
+                  "1:\n\t"
+                  "s_lshr_b64 %[mm], %[m], %[oo]\n\t"
+                  "s_cmp_eq_u64 %[mm], 0\n\t"
+                  "s_cbranch_scc1 3f\n\t"
+                  "s_ff1_i32_b64 %[z], %[mm]\n\t"           // insignificant entries: one bit each
+                  "s_add_u32 %[oo], %[oo], %[z]\n\t"
+                  "s_add_u32 %[idx], %[idx], %[z]\n\t"
+                  "v_readlane_b32 %[ec], %[ecb], %[idx]\n\t"
+                  "v_readlane_b32 %[lo], %[rlo], %[oo]\n\t"
+                  "v_readlane_b32 %[hi], %[rhi], %[oo]\n\t"
+                  "s_bitcmp1_b32 %[ec], 8\n\t"
+                  "s_cselect_b32 %[lo], %[hi], %[lo]\n\t"
+                  "s_bfe_u32 %[t], %[lo], %[ec]\n\t"        // bits of the entry's split
+                  "s_add_u32 %[z], %[t], -1\n\t"
+                  "s_cmp_gt_u32 %[z], %[lim]\n\t"           // 0 (a class of neither group), 0xff (255 bits and more, or none) / kTNone, kTInf
+                  "s_cbranch_scc1 4f\n\t"
+                  "s_bitset1_b64 %[cm], %[oo]\n\t"
+                  "s_bitset1_b64 %[im], %[idx]\n\t"
+                  "s_add_u32 %[oo], %[oo], %[t]\n\t"
+                  "s_add_u32 %[oo], %[oo], 1\n\t"
+                  "s_add_u32 %[idx], %[idx], 1\n\t"
+                  "s_cmp_lt_u32 %[oo], 64\n\t"
+                  "s_cbranch_scc1 1b\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 5f\n\t"
+                  "3:\n\t"                                   // the rest of the word is zeros
+                  "s_sub_u32 %[z], 64, %[oo]\n\t"
+                  "s_add_u32 %[idx], %[idx], %[z]\n\t"
+                  "s_mov_b32 %[oo], 64\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 5f\n\t"
+                  "4:\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "5:\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  : [nxa] "=&v"(lrowNA), [nxb] "=&v"(lrowNB), [oo] "+s"(oo), [idx] "+s"(idx), [cm] "+s"(cm), [im] "+s"(im), [st] "=&s"(st), [mm] "=&s"(mm_),
+                    [z] "=&s"(z_), [ec] "=&s"(ec_), [lo] "=&s"(lo_), [hi] "=&s"(hi_), [t] "=&s"(t_)
+                  : [m] "s"(m), [ecb] "v"(ecb), [rlo] "v"(lrowA), [rhi] "v"(lrowB), [ada] "v"(adNA), [adb] "v"(adNB), [lim] "s"(hopLim)
+                  : "scc", "memory");
             }
-            if (unusual)
+            e = eb + idx;
+            if (cm) {   // lane nloc of the record registers takes the word's record
+              asm volatile("s_mov_b32 m0, %[n]\n\t"
+                           "v_writelane_b32 %[a], %[cl], m0\n\t"
+                           "v_writelane_b32 %[b], %[ch], m0\n\t"
+                           "v_writelane_b32 %[c], %[il], m0\n\t"
+                           "v_writelane_b32 %[d], %[ih], m0\n\t"
+                           "v_writelane_b32 %[f], %[eb], m0\n\t"
+                           "v_writelane_b32 %[g], %[kk], m0\n\t"
+                           : [a] "+v"(rcL), [b] "+v"(rcH), [c] "+v"(riL), [d] "+v"(riH), [f] "+v"(rE), [g] "+v"(rK)
+                           : [n] "s"(nloc), [cl] "s"((uint32_t)cm), [ch] "s"((uint32_t)(cm >> 32)), [il] "s"((uint32_t)im),
+                             [ih] "s"((uint32_t)(im >> 32)), [eb] "s"(lOff + eb), [kk] "s"(kk)
+                           : "m0");
+              nloc++;
+              if (kStamps)
+                wk_hopsT += (uint32_t)__popcll(cm);
+              if (nloc == 64u)
+                rec_flush();
+            }
+            if (st) {
+              unusual = true;   // something the general code has to look at
               break;
+            }
             // on to the word the walk is in now (a long split may have skipped some)
-            kk += oo >> 6;
+            const uint32_t adv = oo >> 6;
             oo &= 63u;
-            if (!(eEnd - e >= 64u && kk * 64u + 64u <= S + wq0 && qn + ns + 160u < Q))
+            kk += adv;
+            if (adv == 1u) {
+              lrowA = pack8(lrowNA);
+              lrowB = pack8(lrowNB);
+            }
+            else
+              load_lrow(kk);
+            if (kk > kkLast || e > eStop || nrec + nloc + 2u >= (uint32_t)kMxRecs)
               break;
           }
           r = kk * 64u + oo - wq0;
           rem = eEnd - e;
-          if (kStamps) {
+          if (kStamps)
             wk_tight += __builtin_readcyclecounter() - tt0;
-            wk_hopsT += qn + ns - hops0;
-          }
-          if (!unusual)
+          lrowK = kk;
+          if (!unusual) {
+            curK = 0xffffffffu;
             continue;
-          if (kk != curK) {   // (cannot happen: an unusual entry lies in the word just walked)
-            curK = kk;
-            m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
           }
-        }
-        if (lrowK != curK) {
-          lrow = load_lrow(curK);
-          lrowK = curK;
+          curK = kk;   // (an unusual entry lies in the word just walked: m and lrow are that word's)
         }
         const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
         const uint64_t tt = m >> o2;
@@ -585,12 +640,10 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMxRing - 1)] : 0xffffu;
         }
         const uint32_t ec = rl32(ecv, e - eb);
-        const uint32_t loc = ec >> 8, ci = ec & 0xffu;
+        const uint32_t ci = ec & 0xffu;
         uint32_t tl = kTNone;
-        if (loc != 0xffu)
-          tl = (uint32_t)(rl64(lrow, o2) >> (16u * loc)) & 0xffffu;
-        else {   // a class of another column group: its length from the rows in LDS
-          const uint32_t col = sh_slot[ci];
+        {   // its length from the rows in LDS
+          const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
           if (col < (uint32_t)kMxCols)
             tl = Tr[(size_t)(r + 1u) * kMxCols + col];
         }
@@ -756,12 +809,14 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         wk_into += __builtin_readcyclecounter() - ti0;
     }
     flush();
+    rec_flush();
     if (lane == 0) {
       sh_pos = a + r;
       sh_e = e;
       sh_rem = rem;
       sh_depth = depth;
       sh_qn[0] = qn;
+      sh_nrec = nrec;
       if (qn > Q)
         s.error = 1;   // (only a damaged stream packs that many sets into a region)
     }
@@ -777,6 +832,27 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   //      parents go to the next round
   auto expand_all = [&]() {
     __syncthreads();
+    {   // the records of the walk's tight loop become work items
+      const uint32_t nr = sh_nrec;
+      for (uint32_t ri = (uint32_t)tid; ri < nr; ri += kMxThreads) {
+        uint64_t cm = sh_recM[ri][0], im = sh_recM[ri][1];
+        uint32_t slot = atomicAdd(&sh_qn[0], (uint32_t)__popcll(cm));
+        const uint32_t e0 = sh_recE[ri], pb = sh_recK[ri] * 64u + 1u - wq0;
+        while (cm && im) {
+          const uint32_t pbit = (uint32_t)__builtin_ctzll(cm), ebit = (uint32_t)__builtin_ctzll(im);
+          cm &= cm - 1;
+          im &= im - 1;
+          if (slot < Q) {
+            qidA[slot] = e0 + ebit;
+            qmetaA[slot] = (pb + pbit) | (0xffu << 16) | (1u << 24);
+          }
+          slot++;
+        }
+      }
+      __syncthreads();
+      if (sh_qn[0] > Q && tid == 0)
+        s.error = 1;   // (only a damaged stream packs that many sets into a region)
+    }
     uint32_t nin = min(sh_qn[0], Q);
     for (uint32_t round = 0; nin != 0; round++) {
       const uint64_t* qidIn = (round & 1u) ? qidB : qidA;
@@ -790,16 +866,18 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       for (uint32_t i = (uint32_t)tid; i < nin; i += kMxThreads) {
         const uint64_t ident = qidIn[i];
         const uint32_t meta = qmIn[i];
-        const uint32_t ci = (meta >> 16) & 0xffu;
+        uint32_t ci = (meta >> 16) & 0xffu;
         uint32_t y = meta & 0xffffu;
         uint64_t packed = ident;
         if (meta >> 24) {
           packed = lisCur[ident];
           atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
         }
+        const Node nd = unpack_node(packed);
+        if (meta >> 24)
+          ci = nd.grid < b.tree.ngrids ? node_cls_l(nd) : 0xffu;
         if (ci >= b.tree.ncls)
           continue;   // (cannot happen)
-        const Node nd = unpack_node(packed);
         const uint32_t nk = sh_cls[ci].nk;
         if (sh_cls[ci].h == 0) {
           leaf_event(nd, y, nk);
@@ -857,6 +935,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       const bool over = __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1;
       sh_ticket = over ? kNoTicket : atomicAdd(&s.hiTicket, 1u);
       sh_qn[0] = sh_qn[1] = 0;
+      sh_nrec = 0;
       sh_stop = 0;
       sh_abort = 0;
       sh_needFill = 0;

@@ -318,11 +318,14 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
 }
 
 // Columns of k_lis_mx (the GPU-wide decoder of lists that mix set shapes, speck_mx.hip): sixteen per
-// stream position -- 0 a single sample, 1..3 the leaf parents of 2 / 4 / 8 samples, then four each for
-// the most frequent classes one, two and THREE steps above the leaf parents (its rows are built off the
-// serial chain by as many workgroups as it takes, so it can afford a column group more than k_lis_mixed).
-// A class needs columns for all its children.  mxLevelGroup[l]: low bits = the group most entries of
-// list level l belong to, bits 4..5 = the highest group an entry of that level can have.
+// stream position in four groups of four -- group 0: a single sample and the leaf parents of 2 / 4 / 8 samples;
+// groups 1..3: twelve more classes, handed out by steps above the leaf parents (all classes one step up that
+// hold at least 1 % of the sets of their step, at most eight; then two steps up, and so on while columns are
+// left): a chunk with three ragged axes has eight classes of 4x4x4-sized sets of comparable frequency (232 =
+// 40 x 4 + 24 x 3 per axis: 24 % of them are 4x4x4), a chunk of 250^3 four (74 % are 4x4x4), a slice four
+// per step.  A class needs columns for all its children.  The walk's tight loop sees TWO groups of a list at a
+// time (eight split lengths of eight bits per lane): mxLevelGroup[l] = the group most entries of list level l
+// belong to | the runner-up << 2.
 constexpr int kMxGroups = 4;
 inline void build_mx_columns(HostTree& h)
 {
@@ -335,38 +338,53 @@ inline void build_mx_columns(HostTree& h)
     if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8))
       h.mxSlot[i] = (uint8_t)(c.nk == 2 ? 1 : c.nk == 4 ? 2 : 3);
   }
-  for (int hh = 1; hh < kMxGroups; hh++) {
-    std::vector<size_t> order;
-    for (size_t i = 0; i < h.cls.size(); i++)
-      if (h.cls[i].h == hh)
-        order.push_back(i);
-    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-      return h.clsCount[x] != h.clsCount[y] ? h.clsCount[x] > h.clsCount[y] : x < y;
-    });
-    uint32_t next = 4u * (uint32_t)hh;
-    for (size_t i : order) {
+  // twelve more columns, greedily: the class that saves the most walking into sets among those whose children
+  // all have columns (sets of the forest x 2^steps: a set further up costs more rounds when it is walked into,
+  // and no class above it can have a column either); up to three steps above the leaf parents
+  for (uint32_t next = 4; next < 16u; next++) {
+    int best = -1;
+    double bestW = 0.0;
+    for (size_t i = 0; i < h.cls.size(); i++) {
       const ShapeCls& c = h.cls[i];
-      bool ok = next < 4u * (uint32_t)hh + 4u && c.maxT < 0x7000u && h.clsCount[i] != 0;
+      if (h.mxSlot[i] != 0xff || c.h == 0 || c.h > 3 || c.maxT >= 0x7000u || h.clsCount[i] == 0)
+        continue;
+      bool ok = true;
       for (int k = 0; k < c.nk; k++)
         ok = ok && (c.kid[k] == kClsPixel || h.mxSlot[c.kid[k]] != 0xff);
-      if (ok)
-        h.mxSlot[i] = (uint8_t)next++;
+      const double w = (double)h.clsCount[i] * (double)(1u << c.h);
+      if (ok && w > bestW) {
+        bestW = w;
+        best = (int)i;
+      }
     }
+    if (best < 0)
+      break;
+    h.mxSlot[best] = (uint8_t)next;
+  }
+  {   // columns numbered by steps, then by frequency: the classes of one list level end up in neighbouring groups
+    std::vector<size_t> sel;
+    for (size_t i = 0; i < h.cls.size(); i++)
+      if (h.mxSlot[i] != 0xff && h.mxSlot[i] >= 4)
+        sel.push_back(i);
+    std::sort(sel.begin(), sel.end(), [&](size_t x, size_t y) {
+      if (h.cls[x].h != h.cls[y].h)
+        return h.cls[x].h < h.cls[y].h;
+      return h.clsCount[x] != h.clsCount[y] ? h.clsCount[x] > h.clsCount[y] : x < y;
+    });
+    for (size_t k = 0; k < sel.size(); k++)
+      h.mxSlot[sel[k]] = (uint8_t)(4 + k);
   }
   std::vector<std::array<uint64_t, kMxGroups>> cnt(h.nlevels);
-  std::vector<uint32_t> top(h.nlevels, 0);
   for (auto& c : cnt)
     c.fill(0);
   const Tree tv = h.view();
   for (uint32_t gi = 0; gi < h.grids.size(); gi++) {
     const Grid& g = h.grids[gi];
-    const Root& r = h.roots[g.root];
     // (class and level of a node depend on which of its three intervals are the long ones, and -- the level, on
     //  saturated axes -- on whether the parent interval still split: enumerate every node, the grids are small
     //  next to the volume)
     Node n;
     n.grid = (uint16_t)gi;
-    (void)r;
     for (uint32_t z = 0; z < (1u << g.e[2]); z++)
       for (uint32_t y = 0; y < (1u << g.e[1]); y++)
         for (uint32_t x = 0; x < (1u << g.e[0]); x++) {
@@ -379,7 +397,6 @@ inline void build_mx_columns(HostTree& h)
           const uint32_t l = node_level(tv, n);
           if (l >= h.nlevels)
             continue;
-          top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, kMxGroups - 1));
           if (h.mxSlot[ci] != 0xff)
             cnt[l][h.mxSlot[ci] >> 2]++;
         }
@@ -389,7 +406,11 @@ inline void build_mx_columns(HostTree& h)
     for (uint32_t g = 1; g < (uint32_t)kMxGroups; g++)
       if (cnt[l][g] > cnt[l][best])
         best = g;
-    h.mxLevelGroup[l] = (uint8_t)(best | (top[l] << 4));
+    uint32_t second = best == 0 ? 1u : 0u;
+    for (uint32_t g = 0; g < (uint32_t)kMxGroups; g++)
+      if (g != best && cnt[l][g] > cnt[l][second])
+        second = g;
+    h.mxLevelGroup[l] = (uint8_t)(best | (second << 2));
   }
 }
 
