@@ -2005,9 +2005,8 @@ bool use_mx(const ShapePlan& P)
   static const int mxEnv = getenv("SPERR_HIP_LIS_MX") ? atoi(getenv("SPERR_HIP_LIS_MX")) : 1;
   if (!mxEnv || !use_mixed(P) || P.ht.mxSlot.size() != P.ht.cls.size() || P.lisEntries >= (1u << 28))
     return false;
-  if ((P.ht.flags & spk::kTree2D) && mxEnv < 2)
-    return false;
-  return kMxS + 64 <= kMxRing && mx_smem_bytes(kMxS, kMxM, kMxQ) <= 146u * 1024u;
+  return kMxS + 64 <= kMxRing && ((kMxS + kMxM) >> 6) + 5 <= 64 && kMxM >= 192 &&
+         mx_smem_bytes(kMxS, kMxM, kMxQ) <= 138u * 1024u;   // (k_lis_mx has 21 KB of static LDS)
 }
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch
 
@@ -2332,6 +2331,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     int rc = 0;
     for (uint32_t q = 0; q < kSubStreams; q++)
       HIP_CHECK(hipStreamSynchronize(E.sub[q]));
+    HIP_CHECK(hipStreamSynchronize(E.outlQ[1]));
     for (auto& S : pending) {                  // stream errors (wrong lengths) surface here
       S->hs.resize(S->nb);
       HIP_CHECK(hipMemcpy(S->hs.data(), S->bb.db.st, S->nb * sizeof(DecState), hipMemcpyDeviceToHost));
@@ -2460,9 +2460,18 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           HIP_CHECK(hipEventRecord(E.evFork, st));
           for (uint32_t q = 0; q < kSubStreams; q++)
             HIP_CHECK(hipStreamWaitEvent(E.sub[q], E.evFork, 0));
+          HIP_CHECK(hipStreamWaitEvent(E.outlQ[1], E.evFork, 0));
           deferForked = true;
         }
-        deferStream = E.sub[deferNext++ % kSubStreams];
+        // (a group of regular chunks beside groups that decode through k_lis_mx: those hold most CUs for the whole
+        //  call with workgroups that mostly wait for their turn on a chunk's serial walk, and eight groups on the
+        //  eight normal-priority hardware queues -- one of which the caller's stream has -- put two groups on one
+        //  queue, one behind the other.  The regular chunks take the 1D decoder's idle high-priority stream: a queue
+        //  pool of its own, 1000^3 in 256^3 chunks 178 -> see DESIGN.md section 9)
+        if (mxGroupsCall != 0 && use_tables(*P))
+          deferStream = E.outlQ[1];
+        else
+          deferStream = E.sub[deferNext++ % kSubStreams];
         deferOff += round_up(needBytes, 4096);
       }
       // The LIS phase of a plane keeps one latency-bound workgroup per chunk busy; sub-batches on
@@ -2775,8 +2784,13 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         return 0;
       };
       if (nsub == 1) {
+        static const bool enqTiming = getenv("SPERR_HIP_ENQ_TIMING") != nullptr;
+        const auto tq0 = std::chrono::steady_clock::now();
         if (enqueue(0))
           return -1;
+        if (enqTiming)
+          fprintf(stderr, "[sperr_hip] group %u x %u x %u, %u chunks: enqueued in %.2f ms\n", cd[0], cd[1], cd[2], nbAll,
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
         if (deferG) {   // waited for in drain()
           pending.push_back(std::make_unique<SubHost>(std::move(subs[0])));
           continue;

@@ -81,6 +81,13 @@ def run(trials=60, seed=0, eng=None):
     for mode, quality in ((1, 2.0), (3, 1e-3)):
         c = eng.compress(torch.from_numpy(cube).cuda(), (64, 64, 64), quality, mode=mode).cpu().numpy()
         cases.append((f"3d 64-cube chunks mode {mode}", c, dec3))
+    big = field((100, 90, 110), 4)   # one chunk whose lists mix set shapes and whose LIS phases span many regions of k_lis_mx
+    for mode, quality in ((1, 3.0), (2, 80.0)):
+        c = eng.compress(torch.from_numpy(big).cuda(), (110, 90, 100), quality, mode=mode).cpu().numpy()
+        cases.append((f"3d 110x90x100 chunk mode {mode}", c, dec3))
+    wide = field((1, 300, 420), 5)[0]
+    c = eng.compress_2d(torch.from_numpy(wide).cuda(), 70.0, mode=2).cpu().numpy()
+    cases.append(("2d 420x300 mode 2", c, lambda s: eng.decompress_2d(s, wide.shape, True)))
     for mode, quality in ((1, 3.0), (3, 1e-3)):
         c = eng.compress_2d(torch.from_numpy(img).cuda(), quality, mode=mode).cpu().numpy()
         cases.append((f"2d mode {mode}", c, lambda s: eng.decompress_2d(s, img.shape, True)))
@@ -88,7 +95,10 @@ def run(trials=60, seed=0, eng=None):
     for name, good, dec in cases:
         ref = dec(torch.from_numpy(good).cuda()).cpu().numpy()
         rejected = decoded = 0
-        heads = chunk_headers(good) if name.startswith("3d") else None
+        try:
+            heads = chunk_headers(good) if name.startswith("3d") else None
+        except (IndexError, ValueError):
+            heads = None
         for t in range(trials):
             bad = damage(rng, good, t % 4, heads)
             if len(bad) == 0:
