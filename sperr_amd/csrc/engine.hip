@@ -2327,11 +2327,25 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   size_t deferOff = 0;
   uint32_t deferNext = 0;
   bool deferForked = false;
+  hipEvent_t timingFork = nullptr;
+  std::vector<std::pair<hipEvent_t, std::array<uint32_t, 4>>> timingEnds;
   auto drain = [&]() -> int {
     int rc = 0;
     for (uint32_t q = 0; q < kSubStreams; q++)
       HIP_CHECK(hipStreamSynchronize(E.sub[q]));
     HIP_CHECK(hipStreamSynchronize(E.outlQ[1]));
+    for (auto& te : timingEnds) {
+      float ms = 0.f;
+      if (timingFork && hipEventElapsedTime(&ms, timingFork, te.first) == hipSuccess)
+        fprintf(stderr, "[sperr_hip] group %u x %u x %u, %u chunks: through %.2f ms after the first group's fork\n",
+                te.second[0], te.second[1], te.second[2], te.second[3], ms);
+      (void)hipEventDestroy(te.first);
+    }
+    timingEnds.clear();
+    if (timingFork) {
+      (void)hipEventDestroy(timingFork);
+      timingFork = nullptr;
+    }
     for (auto& S : pending) {                  // stream errors (wrong lengths) surface here
       S->hs.resize(S->nb);
       HIP_CHECK(hipMemcpy(S->hs.data(), S->bb.db.st, S->nb * sizeof(DecState), hipMemcpyDeviceToHost));
@@ -2788,9 +2802,18 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         const auto tq0 = std::chrono::steady_clock::now();
         if (enqueue(0))
           return -1;
-        if (enqTiming)
+        if (enqTiming) {
           fprintf(stderr, "[sperr_hip] group %u x %u x %u, %u chunks: enqueued in %.2f ms\n", cd[0], cd[1], cd[2], nbAll,
                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
+          // (diagnostics: when the group's stream is through, measured from the caller's stream at the fork)
+          hipEvent_t evEnd = nullptr;
+          if (deferStream && hipEventCreate(&evEnd) == hipSuccess) {
+            if (!timingFork && hipEventCreate(&timingFork) == hipSuccess)
+              (void)hipEventRecord(timingFork, st);
+            (void)hipEventRecord(evEnd, deferStream);
+            timingEnds.push_back({evEnd, {cd[0], cd[1], cd[2], nbAll}});
+          }
+        }
         if (deferG) {   // waited for in drain()
           pending.push_back(std::make_unique<SubHost>(std::move(subs[0])));
           continue;

@@ -36,6 +36,7 @@ struct DecState {
   int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
   uint32_t hiCompactDone;        // workgroups of k_lis_compact that have finished (the last one ends the phase)
   uint64_t hiEnd;                // first bit after the phase
+  uint64_t mxHint;               // k_lis_mx: (plane + 1) << 57 | list level << 48 | region << 28 | entries left, as the chain last published
   uint32_t hiBornCnt[8];         // births / leaf events in the workgroups' own segments
   uint32_t hiLeafCnt[8];
   uint32_t bornCount;            // sets born / leaf events written so far by the GPU-wide passes

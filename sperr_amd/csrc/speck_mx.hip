@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ uint32_t sh_level, sh_e, sh_rem, sh_mode, sh_stop, sh_needFill, sh_ringHi, sh_ticket, sh_abort;
   __shared__ uint32_t sh_iJ, sh_iPart, sh_iCounter, sh_iNeed;
   __shared__ int sh_depth;
-  __shared__ uint32_t sh_qn[2], sh_ncand;
+  __shared__ uint32_t sh_qn[2], sh_ncand, sh_hcap;
   __shared__ uint32_t sh_segBorn, sh_segLeaf, sh_segBornEnd;   // filled slots of this workgroup's segments
   __shared__ unsigned long long sh_in[8];
   __shared__ uint64_t sh_recM[kMxRecs][2];   // per-word records of the walk's tight loop: positions, entry ordinals
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   if (tid < kMaxLevels) {
     const bool in = (uint32_t)tid < nlevels;
     sh_levelSlot[tid] = in ? b.levelSlot[tid] : (uint8_t)0xff;
-    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 31u) : (uint8_t)4;
+    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 63u) : (uint8_t)4;
     sh_len[tid] = in ? s.listLen[cur][tid] : 0u;
     sh_lOff[tid] = in ? b.levelOff[tid] : 0u;
   }
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   };
 
   // ---- the rows of the region in view (all threads)
-  auto build_rows = [&]() {
+  auto build_rows = [&](uint32_t hcap) {
     if (tid == 0)
       sh_ncand = 0;
     __syncthreads();
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       bool any = false;
       for (uint32_t col = g4; col < g4 + 4; col++) {
         const uint32_t ci = sh_colCls[col];
-        if (ci == 0xff)
+        if (ci == 0xff || sh_cls[ci].h > hcap)   // (a column left "not computed": such a set is walked into)
           continue;
         if (any && sh_cls[ci].h != hPrev)   // (its children's columns may be this group's: columns go by steps)
           __syncthreads();
@@ -934,6 +934,45 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     if (tid == 0) {
       const bool over = __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1;
       sh_ticket = over ? kNoTicket : atomicAdd(&s.hiTicket, 1u);
+      // Which columns this region's rows need: sets of at most so many steps above the leaf parents.  The lists come
+      // smallest sets first, so most regions lie in the lists of the leaf parents and of the sets made of those, whose
+      // rows need no or few chains of look-ups.  The chain leaves a hint behind (list level, region, entries left of
+      // that list); a guess that falls short costs speed only: a column that is "not computed" sends the walk into
+      // the set, child by child.
+      {
+        const unsigned long long hint = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&s.mxHint), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        int lv = -1;
+        uint32_t left = 0, at = 0;
+        if ((hint >> kMxTagShift) == (unsigned long long)(p + 1)) {
+          lv = (int)((hint >> 48) & 63u);
+          at = (uint32_t)(hint >> 28) & 0xfffffu;
+          left = (uint32_t)hint & 0xfffffffu;
+        }
+        if (lv < 0 || lv >= (int)nlevels) {
+          lv = next_level((int)nlevels);
+          left = lv >= 0 ? sh_len[lv] : 0u;
+          at = 0;
+        }
+        uint32_t hc = 0;
+        if (lv >= 0) {
+          hc = sh_lgrp[lv] >> 4;
+          // entries of that list the regions in between cannot have used up (an entry takes a bit at least)
+          const uint32_t span = (sh_ticket >= at ? sh_ticket - at + 2u : 2u) * (b.mxS + b.mxM);
+          if (left < span) {   // the next lists (larger sets) may begin in this region
+            int l2 = lv;
+            for (int k = 0; k < 3; k++) {
+              l2 = next_level(l2);
+              if (l2 < 0)
+                break;
+              hc = max(hc, (uint32_t)(sh_lgrp[l2] >> 4));
+            }
+          }
+        }
+        if (twoD)
+          hc = 3;   // (the subbands the type-I set releases are tested behind the lists)
+        sh_hcap = hc;
+      }
       sh_qn[0] = sh_qn[1] = 0;
       sh_nrec = 0;
       sh_stop = 0;
@@ -960,7 +999,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       }
     }
     __syncthreads();
-    build_rows();
+    build_rows(sh_hcap);
     __syncthreads();
     if (kStamps && tid == 0)
       sh_tk[0] = __builtin_readcyclecounter();
@@ -1176,8 +1215,13 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           if (lane < 6)
             __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, f, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-          if (lane == 0)
+          if (lane == 0) {
             sh_stop = 3;
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.mxHint),
+                               tag | ((unsigned long long)sh_level << 48) | ((unsigned long long)(i & 0xfffffu) << 28) |
+                                   (unsigned long long)(sh_mode == kModeList ? sh_rem : 0u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           MX_WAVE_SYNC();
           break;
         }

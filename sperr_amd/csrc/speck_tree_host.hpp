@@ -325,7 +325,7 @@ inline void build_classes(HostTree& h, int hmax, uint32_t maxSlots, double minSh
 // 40 x 4 + 24 x 3 per axis: 24 % of them are 4x4x4), a chunk of 250^3 four (74 % are 4x4x4), a slice four
 // per step.  A class needs columns for all its children.  The walk's tight loop sees TWO groups of a list at a
 // time (eight split lengths of eight bits per lane): mxLevelGroup[l] = the group most entries of list level l
-// belong to | the runner-up << 2.
+// belong to | the runner-up << 2 | the most steps above the leaf parents a set of the level can be (capped at 3) << 4.
 constexpr int kMxGroups = 4;
 inline void build_mx_columns(HostTree& h)
 {
@@ -375,6 +375,7 @@ inline void build_mx_columns(HostTree& h)
       h.mxSlot[sel[k]] = (uint8_t)(4 + k);
   }
   std::vector<std::array<uint64_t, kMxGroups>> cnt(h.nlevels);
+  std::vector<uint32_t> top(h.nlevels, 0);   // the most steps above the leaf parents a set of the level can be
   for (auto& c : cnt)
     c.fill(0);
   const Tree tv = h.view();
@@ -397,6 +398,7 @@ inline void build_mx_columns(HostTree& h)
           const uint32_t l = node_level(tv, n);
           if (l >= h.nlevels)
             continue;
+          top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, 3));
           if (h.mxSlot[ci] != 0xff)
             cnt[l][h.mxSlot[ci] >> 2]++;
         }
@@ -410,7 +412,7 @@ inline void build_mx_columns(HostTree& h)
     for (uint32_t g = 0; g < (uint32_t)kMxGroups; g++)
       if (g != best && cnt[l][g] > cnt[l][second])
         second = g;
-    h.mxLevelGroup[l] = (uint8_t)(best | (second << 2));
+    h.mxLevelGroup[l] = (uint8_t)(best | (second << 2) | (top[l] << 4));
   }
 }
 

@@ -844,6 +844,48 @@ def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0, knobs
 
 
+@pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_MX": "0"}, {"SPERR_HIP_MX_WGS": "1"}, {"SPERR_HIP_MX_WGS": "4096"}])
+def test_mixed_shape_decoders_in_a_fresh_process(oracle, knobs):
+    """Chunks whose lists mix set shapes decode through k_lis_mx (round 4: fixed regions of the stream handed out to
+    several workgroups per chunk, the walker's state passed from region to region); the knobs are read once per
+    process.  `SPERR_HIP_LIS_MX=0`: k_lis_mixed, one workgroup per chunk, as in rounds 2-3; `SPERR_HIP_MX_WGS=1`:
+    one workgroup per chunk takes every region itself; `=4096`: eight per chunk whatever else runs.  A volume of
+    96 x 75 x 110 in chunks of 64 x 50 x 80 (eight chunks of eight shapes, LIS phases of many regions) at 5 bpp, cut
+    short as well, and a slice of 300 x 211 -- against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-326,
+    /root/reference/src/SPECK2D_INT.cpp:10-218)."""
+    import subprocess
+    import sys
+    import tempfile
+    shape = (110, 75, 96)
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, (64, 50, 80), 1, 5.0)
+    ref = oracle.decomp_3d(want, True)
+    img = turbulence((1, 211, 300), dtype=np.float64)[0]
+    want2 = oracle.comp_2d(img, 2, 85.0, False)
+    cut2 = 26 + (len(want2) - 26) // 2
+    ref2 = oracle.decomp_2d(want2, (211, 300), False)
+    ref2c = oracle.decomp_2d(want2[:cut2], (211, 300), False)
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "c.npy"), np.frombuffer(want, dtype=np.uint8))
+        np.save(os.path.join(td, "r.npy"), ref)
+        np.save(os.path.join(td, "c2.npy"), np.frombuffer(want2, dtype=np.uint8))
+        np.save(os.path.join(td, "r2.npy"), ref2)
+        np.save(os.path.join(td, "r2c.npy"), ref2c)
+        code = ("import sys, os, numpy as np, torch; sys.path.insert(0, %r); from sperr_amd.api import SperrHip; td = %r; "
+                "L = lambda n: np.load(os.path.join(td, n)); e = SperrHip(); "
+                "d = e.decompress(torch.from_numpy(L('c.npy')).cuda(), True).cpu().numpy(); "
+                "ok = np.array_equal(d.view(np.uint32), L('r.npy').view(np.uint32)); "
+                "c2 = L('c2.npy'); "
+                "d2 = e.decompress_2d(torch.from_numpy(c2).cuda(), (211, 300), False).cpu().numpy(); "
+                "ok = ok and np.array_equal(d2.view(np.uint64), L('r2.npy').view(np.uint64)); "
+                "d3 = e.decompress_2d(torch.from_numpy(c2[:%d].copy()).cuda(), (211, 300), False).cpu().numpy(); "
+                "ok = ok and np.array_equal(d3.view(np.uint64), L('r2c.npy').view(np.uint64)); "
+                "sys.exit(0 if ok else 3)"
+                % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), td, cut2))
+        env = dict(os.environ, **knobs)
+        assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0, knobs
+
+
 @pytest.mark.parametrize("shape", [(8, 8), (5, 300), (2, 9), (1, 40), (33, 17), (500, 301), (1024, 1024)])
 def test_2d_slice_decoder_on_the_shared_forest(eng, oracle, shape):
     """Slices are decoded by the 3D decoder's kernels on the 2D coder's forest (quadtrees whose
