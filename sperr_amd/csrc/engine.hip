@@ -2005,7 +2005,7 @@ bool use_mx(const ShapePlan& P)
   static const int mxEnv = getenv("SPERR_HIP_LIS_MX") ? atoi(getenv("SPERR_HIP_LIS_MX")) : 1;
   if (!mxEnv || !use_mixed(P) || P.ht.mxSlot.size() != P.ht.cls.size() || P.lisEntries >= (1u << 28))
     return false;
-  return kMxS + 64 <= kMxRing && ((kMxS + kMxM) >> 6) + 5 <= 64 && kMxM >= 192 &&
+  return 2 * kMxS + 256 <= kMxRing && ((kMxS + kMxM) >> 6) + 5 <= 64 && kMxM >= 192 &&
          mx_smem_bytes(kMxS, kMxM, kMxQ) <= 138u * 1024u;   // (k_lis_mx has 21 KB of static LDS)
 }
 std::vector<uint64_t> g_lis_stamps_host;   // chunk 0 of the last decoded batch

@@ -220,7 +220,7 @@ __host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
 
 // k_lis_mx (speck_mx.hip)
 constexpr int kMxWordsPerRegion = 8;
-constexpr uint32_t kMxS = 2048, kMxM = 768, kMxQ = 1024, kMxRing = 4096;
+constexpr uint32_t kMxS = 2048, kMxM = 768, kMxQ = 1024, kMxRing = 8192;
 uint32_t mx_smem_bytes(uint32_t S, uint32_t M, uint32_t Q);
 int prepare_lis_mx(const DecBuffers& b);
 int launch_lis_mx(hipStream_t stream, const DecBuffers& b, int p, uint32_t groups, bool stamps);

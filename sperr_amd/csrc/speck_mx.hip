@@ -41,6 +41,7 @@ constexpr uint32_t kMxTagShift = 57;
 constexpr unsigned long long kMxOver = 1ull << 56;
 constexpr int kMxFrames = kMaxDepth + 2;
 constexpr uint32_t kNoTicket = 0xffffffffu;
+constexpr int kMxPreWaves = 4;   // wavefronts that fill the ring of entry classes while the region waits for its turn
 constexpr int kMxRecs = 160;   // per-word records a region's walk can leave (one per word and reload of entry classes)
 
 // what the chain is doing (2D coder: the type-I set, /root/reference/src/SPECK2D_INT.cpp:44-98)
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ uint32_t sh_iJ, sh_iPart, sh_iCounter, sh_iNeed;
   __shared__ int sh_depth;
   __shared__ uint32_t sh_qn[2], sh_ncand, sh_hcap;
+  __shared__ uint32_t sh_preLevel, sh_preLo, sh_preHi, sh_go, sh_goDone;   // list entries whose classes were put into the ring ahead of the chain
   __shared__ uint32_t sh_segBorn, sh_segLeaf, sh_segBornEnd;   // filled slots of this workgroup's segments
   __shared__ unsigned long long sh_in[8];
   __shared__ uint64_t sh_recM[kMxRecs][2];   // per-word records of the walk's tight loop: positions, entry ordinals
@@ -398,15 +400,25 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   };
 
   // ---- classes of the entries [from, to) of list `l` into the ring, with their column inside the list's group
-  auto fill_ring = [&](uint32_t l, uint32_t from, uint32_t to) {
+  auto fill_ring = [&](uint32_t l, uint32_t from, uint32_t to, uint32_t t0, uint32_t nt) {
     const uint64_t* list = lisCur + sh_lOff[l];
     const uint32_t ga = sh_lgrp[l] & 3u, gb = (sh_lgrp[l] >> 2) & 3u;
-    for (uint32_t i = from + (uint32_t)tid; i < to; i += kMxThreads) {
-      const uint32_t ci = node_cls_l(unpack_node(list[i]));
+    auto put = [&](uint32_t i, uint64_t ent) {
+      const uint32_t ci = node_cls_l(unpack_node(ent));
       const uint32_t col = sh_slot[ci];
       const uint32_t loc = col >= (uint32_t)kMxCols ? 0xffu : (col >> 2) == ga ? (col & 3u) : (col >> 2) == gb ? 4u + (col & 3u) : 0xffu;
       ecls[i & (uint32_t)(kMxRing - 1)] = (uint16_t)(ci | (loc << 8));
+    };
+    uint32_t i = from + t0;
+    for (; i + 3u * nt < to; i += 4u * nt) {   // (four loads in flight per thread)
+      const uint64_t e0 = list[i], e1 = list[i + nt], e2 = list[i + 2u * nt], e3 = list[i + 3u * nt];
+      put(i, e0);
+      put(i + nt, e1);
+      put(i + 2u * nt, e2);
+      put(i + 3u * nt, e3);
     }
+    for (; i < to; i += nt)
+      put(i, list[i]);
   };
 
   // ---- the walk through the region (first wavefront, every lane carrying the same walker state): from
@@ -975,6 +987,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       }
       sh_qn[0] = sh_qn[1] = 0;
       sh_nrec = 0;
+      sh_go = sh_goDone = 0;
       sh_stop = 0;
       sh_abort = 0;
       sh_needFill = 0;
@@ -1006,6 +1019,64 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
 
     // ---- the chain
     if (wave == 0) {
+      // While this region waits for its turn: the classes of the list entries its walk will most likely visit.  The
+      // region before this one starts where the one before THAT ended, and ends at most S entries further on (an entry
+      // takes a bit at least): as soon as that state is out, the 2 S + 128 entries from there go into the ring.
+      {
+        unsigned long long f = 0;
+        bool have = false;
+        if (i >= 2) {
+          uint32_t spins = 0;
+          for (;;) {
+            if (lane < 2)
+              f = __hip_atomic_load(flags + (size_t)(i - 2) * kMxWordsPerRegion + lane, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+            have = __ballot(lane < 2 && (f >> kMxTagShift) == (unsigned long long)(p + 1)) == 3ull;
+            if (have)
+              break;
+            if ((++spins & 15u) == 0 &&
+                __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1)
+              break;
+            if (spins > (1u << 22))
+              break;   // (the look-back below gives up loudly)
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const unsigned long long f0 = __shfl(f, 0, 64), f1 = __shfl(f, 1, 64);
+        have = have && !(f0 & kMxOver) && ((uint32_t)(f0 >> 51) & 3u) == kModeList;
+        const uint32_t l = (uint32_t)(f0 >> 40) & 63u, e0 = (uint32_t)f1 & 0xfffffffu;
+        uint32_t lo = 0, hi = 0;
+        if (have && l < nlevels && e0 <= sh_len[l]) {
+          lo = e0;
+          hi = min(sh_len[l], e0 + 2u * S + 128u);
+        }
+        if (lane == 0) {
+          sh_preLevel = (have && hi > lo) ? l : 0xffffffffu;
+          sh_preLo = lo;
+          sh_preHi = hi;
+          __hip_atomic_store(&sh_go, (have && hi > lo) ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        MX_WAVE_SYNC();
+      }
+    }
+    // (four wavefronts put the classes into the ring: one alone takes longer than the region before this one walks)
+    if (wave < (uint32_t)kMxPreWaves) {
+      uint32_t go = 0, spins = 0;
+      while ((go = __hip_atomic_load(&sh_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++spins < (1u << 26))
+        __builtin_amdgcn_s_sleep(2);
+      if (go == 2)
+        fill_ring(sh_preLevel, sh_preLo, sh_preHi, (uint32_t)tid, (uint32_t)kMxPreWaves * 64u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        atomicAdd(&sh_goDone, 1u);
+    }
+    if (wave == 0) {
+      {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&sh_goDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)kMxPreWaves &&
+               ++spins < (1u << 26))
+          __builtin_amdgcn_s_sleep(1);
+      }
       // look back (lanes 0..5 take one word each)
       if (lane < 6) {
         unsigned long long f = 0;
@@ -1128,7 +1199,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         sh_iCounter = iCounter;
         sh_iNeed = iNeed;
         sh_stop = stop;
-        sh_needFill = (stop == 0 && mode == kModeList) ? 1u : 0u;
+        // (the classes of the list's entries from e on: in the ring already when the guess above held)
+        const bool pre = mode == kModeList && level == sh_preLevel && e >= sh_preLo &&
+                         min(sh_len[level], e + S + 64u) <= sh_preHi;
+        sh_needFill = (stop == 0 && mode == kModeList && !pre) ? 1u : 0u;
+        if (pre)
+          sh_ringHi = sh_preHi;
       }
       MX_WAVE_SYNC();
     }
@@ -1142,18 +1218,19 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           wk_fills++;
         const uint32_t l = sh_level, e0 = sh_e, n = sh_len[l];
         const uint32_t to = min(n, e0 + S + 64u);
-        fill_ring(l, min(e0, to), to);
+        fill_ring(l, min(e0, to), to, (uint32_t)tid, kMxThreads);
         __syncthreads();
         if (tid == 0) {
           sh_ringHi = to;
           sh_needFill = 0;
+          sh_preLevel = 0xffffffffu;
         }
         if (kStamps)
           wk_fill += __builtin_readcyclecounter() - tf0;
       }
-      __syncthreads();
       if (wave != 0)
         continue;
+      MX_WAVE_SYNC();   // (what thread 0 wrote above is this wavefront's own LDS traffic)
       // ---- first wavefront: on until the region ends, the phase ends, or a new list needs its classes
       for (;;) {
         uint32_t mode = __builtin_amdgcn_readfirstlane(sh_mode);
