@@ -1885,6 +1885,56 @@ int model_check_classes(const size_t dims[3])
   return check_classes_impl(dims, false);
 }
 
+// The columns of k_lis_mx (spk::build_mx_columns, speck_mx.hip): every column is one class's alone, the leaf parents sit
+// in columns 1..3, a class with a column has columns for all its children -- and those columns are LOWER (the rows of a
+// region are built column after column) --, columns are numbered by steps above the leaf parents, and every list level
+// names two different groups of four.  Returns 0, or which rule broke; *ncols: columns handed out.
+int model_check_mx_columns(const size_t dims[3], int twoD, int* ncols)
+{
+  HostTree ht = build_tree(dims[0], dims[1], dims[2], twoD != 0);
+  if (ht.cls.empty())
+    return -2;
+  if (ht.mxSlot.size() != ht.cls.size() || ht.mxLevelGroup.size() != ht.nlevels)
+    return 1;
+  int used[16] = {0};
+  int n = 0;
+  for (size_t i = 0; i < ht.cls.size(); i++) {
+    const ShapeCls& c = ht.cls[i];
+    const uint8_t sl = ht.mxSlot[i];
+    if (c.h == 0 && (c.nk == 2 || c.nk == 4 || c.nk == 8)) {
+      if (sl != (c.nk == 2 ? 1 : c.nk == 4 ? 2 : 3))
+        return 2;
+      continue;
+    }
+    if (sl == 0xff)
+      continue;
+    if (sl < 4 || sl >= 16 || used[sl]++)
+      return 3;
+    n++;
+    if (c.h == 0 || c.h > 3 || c.maxT >= 0x7000u)
+      return 4;
+    for (int k = 0; k < c.nk; k++)
+      if (c.kid[k] != kClsPixel && (ht.mxSlot[c.kid[k]] == 0xff || ht.mxSlot[c.kid[k]] >= sl))
+        return 5;
+  }
+  for (int col = 5; col < 16; col++)
+    if (used[col] && !used[col - 1])
+      return 6;   // (columns are handed out without gaps)
+  for (size_t i = 0; i < ht.cls.size(); i++)
+    for (size_t j = 0; j < ht.cls.size(); j++)
+      if (ht.mxSlot[i] >= 4 && ht.mxSlot[i] != 0xff && ht.mxSlot[j] >= 4 && ht.mxSlot[j] != 0xff &&
+          ht.cls[i].h < ht.cls[j].h && ht.mxSlot[i] > ht.mxSlot[j])
+        return 7;
+  for (uint32_t l = 0; l < ht.nlevels; l++) {
+    const uint32_t ga = ht.mxLevelGroup[l] & 3u, gb = (ht.mxLevelGroup[l] >> 2) & 3u;
+    if (ga == gb || (ht.mxLevelGroup[l] >> 6))
+      return 8;
+  }
+  if (ncols)
+    *ncols = n;
+  return 0;
+}
+
 // the same for the 2D coder's forest of a slice (dims = {x, y, 1})
 int model_check_classes_2d(const size_t dims[3])
 {

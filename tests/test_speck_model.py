@@ -178,6 +178,27 @@ def test_shape_classes_are_consistent(model):
         assert lib.model_check_classes_2d((_sz * 3)(*dims)) == 0, dims   # (children in the 2D coder's order)
 
 
+def test_mx_columns(model):
+    """The columns of k_lis_mx (spk::build_mx_columns): one class per column, children in lower columns, numbered by
+    steps above the leaf parents, two different column groups per list level; a chunk with three ragged axes (232 =
+    40 x 4 + 24 x 3 per axis: eight classes of 4x4x4-sized sets of comparable frequency) gets all twelve, and so do a
+    250^3 chunk and a 999 x 999 slice."""
+    lib = model
+    lib.model_check_mx_columns.argtypes = [_vp, C.c_int, C.POINTER(C.c_int)]
+    lib.model_check_mx_columns.restype = C.c_int
+    n = C.c_int(0)
+    for dims in [(250, 250, 250), (232, 232, 232), (232, 256, 256), (129, 129, 129), (100, 70, 33), (17, 300, 21),
+                 (64, 64, 64), (30, 40, 8), (2, 3, 5), (1, 1, 9)]:
+        assert lib.model_check_mx_columns((_sz * 3)(*dims), 0, C.byref(n)) == 0, dims
+        if dims in ((250, 250, 250), (232, 232, 232)):
+            assert n.value == 12, (dims, n.value)
+        elif min(dims) >= 100:   # (one ragged axis: two classes per step)
+            assert n.value >= 6, (dims, n.value)
+    for dims in [(999, 999, 1), (64, 64, 1), (17, 23, 1), (300, 9, 1), (1, 50, 1)]:
+        assert lib.model_check_mx_columns((_sz * 3)(*dims), 1, C.byref(n)) == 0, dims
+    assert lib.model_check_mx_columns((_sz * 3)(999, 999, 1), 1, C.byref(n)) == 0 and n.value == 12
+
+
 def _speck2d_oracle(oracle, coef2d, sign, budget):
     lib = oracle.lib
     lib.orc_speck2d_encode.argtypes = [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp), C.POINTER(_sz)]
