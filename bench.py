@@ -25,7 +25,7 @@ Besides the contract fields the JSON line carries
   other_modes   the bench volume in point-wise error mode (tolerance 1e-3 of the range) and one
                 999 x 999 slice at PSNR 90 dB through the 2D coder.  Rank 0; never used as `value`.
   ragged_volume a 1000^3 volume in the same 256^3 chunks: the chunk size does not divide it, so most
-                chunks have extents that are not powers of two (decoded by k_lis_mixed).  Rank 0;
+                chunks have extents that are not powers of two (decoded by k_lis_mx).  Rank 0;
                 never used as `value`.
 """
 import argparse
@@ -315,7 +315,7 @@ def main():
 
     # ---- a volume the chunk size does not divide (rank 0; reported beside the metric, never as it):
     #      chunk_volume (src/sperr_helper.cpp:542-592) leaves border chunks whose extents are not
-    #      powers of two; their lists mix set shapes and decode through k_lis_mixed
+    #      powers of two; their lists mix set shapes and decode through k_lis_mx
     ragged = None
     if not args.no_ragged and args.ragged_size > C:
         try:
