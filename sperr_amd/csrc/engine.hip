@@ -271,7 +271,6 @@ struct ShapePlan {
   const uint8_t* d_slotLevel = nullptr;
   const spk::LevelClass* d_levelClass = nullptr;
   const uint32_t* d_wordLeaf = nullptr;   // nullptr: no raster word lies over leaf-word grids
-  const uint8_t* d_levelGroup = nullptr;  // k_lis_mixed: column group of every list level
   const uint8_t* d_mxSlot = nullptr;      // k_lis_mx: column of every shape class
   const uint8_t* d_mxLevelGroup = nullptr;
   int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
@@ -312,12 +311,6 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
   P.dims[2] = (uint32_t)dz;
   P.N = (uint32_t)(dx * dy * dz);
   P.ht = spk::build_tree(dx, dy, dz, twoD);
-  {   // SPERR_HIP_MIX_H: classes up to this many steps above the leaf parents get table columns (k_lis_mixed)
-    static const int mixH = getenv("SPERR_HIP_MIX_H") ? atoi(getenv("SPERR_HIP_MIX_H")) : spk::kClsTableH;
-    static const double mixShare = getenv("SPERR_HIP_MIX_SHARE") ? atof(getenv("SPERR_HIP_MIX_SHARE")) / 100.0 : spk::kClsMinShare;
-    if ((mixH != spk::kClsTableH || mixShare != spk::kClsMinShare) && !P.ht.cls.empty())
-      spk::build_classes(P.ht, mixH, spk::kClsTableSlots, mixShare);
-  }
   const spk::HostTree& h = P.ht;
   const uint32_t nlev = h.nlevels;
 
@@ -396,7 +389,7 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
                oLFT = blob.add(levelFirstTile), oLNT = blob.add(levelNumTiles),
                oDB = blob.add(depthBlocks), oLS = blob.add(levelSlot), oSL = blob.add(slotLevel),
                oLC = blob.add(h.levelClass), oWL = blob.add(wordLeaf), oCls = blob.add(h.cls),
-               oGC = blob.add(h.gridCls), oLG = blob.add(h.levelGroup), oIR = blob.add(h.iRoots),
+               oGC = blob.add(h.gridCls), oIR = blob.add(h.iRoots),
                oMS = blob.add(h.mxSlot), oMG = blob.add(h.mxLevelGroup);
   P.maxK = 0;
   for (const auto& lc : h.levelClass)
@@ -432,7 +425,6 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
   P.dtree.blockGrid = reinterpret_cast<const uint16_t*>(base + oBG);
   P.dtree.cls = reinterpret_cast<const spk::ShapeCls*>(base + oCls);
   P.dtree.gridCls = reinterpret_cast<const uint8_t*>(base + oGC);
-  P.d_levelGroup = reinterpret_cast<const uint8_t*>(base + oLG);
   P.d_mxSlot = reinterpret_cast<const uint8_t*>(base + oMS);
   P.d_mxLevelGroup = reinterpret_cast<const uint8_t*>(base + oMG);
   P.d_iRoots = h.iRoots.empty() ? nullptr : reinterpret_cast<const uint64_t*>(base + oIR);
@@ -1970,7 +1962,7 @@ int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci,
 }
 
 // the lists of the larger sets GPU-wide (k_lis_hi); SPERR_HIP_LIS_HI=0 and regular trees whose geometry
-// tables do not fit the kernel's LDS go to k_lis_mixed, which takes any shape (k_lis_tables, one workgroup
+// tables do not fit the kernel's LDS go to k_lis_mx, which takes any shape (k_lis_tables, one workgroup
 // per chunk, was the table kernel of rounds 1-3: removed in round 4)
 bool g_lis_stamps_on = false;
 constexpr int kHiMaxK = 9;   // longest class chain k_lis_hi takes (chunk dims up to 1024)
@@ -1987,23 +1979,16 @@ bool use_tables(const ShapePlan& P)
     return false;
   return use_lis_hi(P, true);
 }
-// lists that mix set shapes (any chunk extent that is not a power of two): k_lis_mixed, tables keyed
-// by shape class and one walking thread per chunk (SPERR_HIP_LIS_MIXED=0: k_lis_walk, the serial walk)
-constexpr uint32_t kMixSmemBytes = 144 * 1024;   // (k_lis_mixed has 15 KB of static LDS)
+// lists that mix set shapes (any chunk extent that is not a power of two, every slice): k_lis_mx (speck_mx.hip:
+// rows keyed by shape class, several workgroups per chunk, only the walk serial).  SPERR_HIP_LIS_MIXED=0, and trees
+// the class machinery does not take (more than 254 classes, 48 roots, 352 grids): k_lis_walk, the serial walk.
+// (k_lis_mixed, the one-workgroup-per-chunk kernel of rounds 2-3 whose formulation k_lis_mx took over, was removed
+// at the end of round 4.)
 bool use_mixed(const ShapePlan& P)
 {
   static const bool mixEnv = !(getenv("SPERR_HIP_LIS_MIXED") && atoi(getenv("SPERR_HIP_LIS_MIXED")) == 0);
-  if (!mixEnv || use_tables(P) || P.ht.cls.empty() || P.ht.roots.size() > 48 || P.ht.grids.size() > 352)
-    return false;
-  const uint32_t w = mix_window(kMixSmemBytes);
-  return w >= 512 && w >= P.ht.slotMaxT + 2;
-}
-// ... GPU-wide (k_lis_mx, speck_mx.hip: several workgroups per chunk, only the walk on the serial chain).
-// SPERR_HIP_LIS_MX=0: k_lis_mixed (one workgroup per chunk) as in rounds 2-3
-bool use_mx(const ShapePlan& P)
-{
-  static const int mxEnv = getenv("SPERR_HIP_LIS_MX") ? atoi(getenv("SPERR_HIP_LIS_MX")) : 1;
-  if (!mxEnv || !use_mixed(P) || P.ht.mxSlot.size() != P.ht.cls.size() || P.lisEntries >= (1u << 28))
+  if (!mixEnv || use_tables(P) || P.ht.cls.empty() || P.ht.roots.size() > 48 || P.ht.grids.size() > 352 ||
+      P.ht.mxSlot.size() != P.ht.cls.size())
     return false;
   return 2 * kMxS + 256 <= kMxRing && ((kMxS + kMxM) >> 6) + 5 <= 64 && kMxM >= 192 &&
          mx_smem_bytes(kMxS, kMxM, kMxQ) <= 138u * 1024u;   // (k_lis_mx has 21 KB of static LDS)
@@ -2127,12 +2112,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.mxM = kMxM;
   d.mxQ = kMxQ;
   d.mxSmemBytes = mx_smem_bytes(kMxS, kMxM, kMxQ);
-  if (use_mx(P))   // (k_lis_mx keeps its look-back words in the same array: kMxWordsPerRegion per region of mxS bits)
+  if (use_mixed(P))   // (k_lis_mx keeps its look-back words in the same array: kMxWordsPerRegion per region of mxS bits)
     d.hiFlagStride = std::max<size_t>(d.hiFlagStride, ((d.streamStride * 64 + N) / kMxS + 4) * kMxWordsPerRegion);
   TAKE(d.hiFlags, unsigned long long, d.hiFlagStride * B);
-  d.mixSmemBytes = kMixSmemBytes;
-  d.mixW = mix_window(kMixSmemBytes);
-  d.mixLevelGroup = P.d_levelGroup;
   d.iRoots = P.d_iRoots;
   d.iLevels = P.ht.iLevels;
   d.leafCap = P.ht.nsets + 8;
@@ -2398,14 +2380,14 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     size_t nmx = 0;
     for (auto& h : groups) {
       ShapePlan* Q = (slice && slice_forest_enabled()) ? E.plan(h.first[0], h.first[1], 0) : E.plan(h.first[0], h.first[1], h.first[2]);
-      if (Q && use_mx(*Q))
+      if (Q && use_mixed(*Q))
         nmx += h.second.size();
     }
     static const uint32_t mxBudget = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 208u;
     if (nmx)
       mxGroupsCall = std::min<uint32_t>(8u, std::max<uint32_t>(2u, (uint32_t)(mxBudget / nmx)));
   }
-  // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mixed and its
+  // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mx and its
   // type-I phase); SPERR_HIP_SLICE_MIXED=0: by k_speck2d_decode, one workgroup walking the quadtree
   const bool sliceMixed = slice_forest_enabled();
   for (int pass = 0; pass < 2; pass++)
@@ -2647,7 +2629,6 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // the lists of the larger sets GPU-wide
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
-        ph.mx = use_mx(*P);
         ph.mxGroups = mxGroupsCall;
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
         static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
@@ -3611,7 +3592,6 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
     ph.hi = use_lis_hi(*P, ph.tables);
     ph.mixed = use_mixed(*P);
-    ph.mx = use_mx(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));

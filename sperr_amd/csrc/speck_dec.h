@@ -130,13 +130,9 @@ struct DecBuffers {
   uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
   uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
                                //   the region and end within them are not walked into
-  // k_lis_mixed (chunks whose lists mix set shapes): window bits and dynamic LDS
-  uint32_t mixW;
-  uint32_t mixSmemBytes;
   const uint64_t* iRoots;         // 2D coder (spk::kTree2D): packed roots of the subbands the type-I set releases,
   uint32_t iLevels;               //   three per level from the coarsest on (~0: empty); iLevels: transform levels
-  const uint8_t* mixLevelGroup;   // per list level: the column group (0..2) most of its entries belong to
-  // k_lis_mx (speck_mx.hip): the same lists GPU-wide -- fixed regions of mxS stream bits handed out by a ticket
+  // k_lis_mx (speck_mx.hip; chunks whose lists mix set shapes, slices) -- fixed regions of mxS stream bits handed out by a ticket
   // counter (DecState::hiTicket), rows of sixteen columns over mxS + mxM bits built off the serial chain, the
   // walker's state handed from region to region through DecBuffers::hiFlags (kMxWordsPerRegion words each)
   const uint8_t* mxSlot;          // column of every shape class (0xff: none)
@@ -154,8 +150,7 @@ struct DecPlanHost {
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
-  bool mixed = false;          // lists that mix set shapes: k_lis_mixed (shape-class tables) instead of k_lis_walk
-  bool mx = false;             // ... GPU-wide: k_lis_mx instead of k_lis_mixed (several workgroups per chunk)
+  bool mixed = false;          // lists that mix set shapes: k_lis_mx (shape-class rows, several workgroups per chunk) instead of k_lis_walk
   uint32_t mxGroups = 0;       // workgroups per chunk of k_lis_mx (0: the launcher's own choice by the batch's size) --
                                //   the caller knows how many such chunks of OTHER shapes decode beside this batch
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients
@@ -196,25 +191,6 @@ __host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
   w = w / 256 * 256;   // (any multiple of 64 works; round 2 took multiples of 1024: 4096 instead of 4352 bits for a 256^3 chunk)
   if (w > (uint32_t)kTabWMax)
     w = kTabWMax;
-  return w;
-}
-
-// k_lis_mixed keeps two windows in LDS (one being walked, one being expanded / built): per window
-// bit two rows of twelve split lengths (u16 each), a slot of the list of candidate positions and the
-// bit itself twice; the two item queues, the ring of entry classes and the slack of the arrays are
-// fixed.  The window is the largest multiple of 256 that fits.
-constexpr int kMixQueue = 768;      // sets the walk of one window can hand to the expansion
-constexpr int kMixRing = 8192;      // list entries whose class words are kept (at least two windows' worth)
-__host__ __device__ inline uint32_t mix_window(uint32_t smemBytes)
-{
-  const uint32_t perBit8 = 8u * (2u * 24u + 2u) + 2u;   // eighths of a byte
-  const uint32_t fixed = 2 * 6 * 8 + 2 * 3 * 24 + 2u * (uint32_t)kMixQueue * 12u + (uint32_t)kMixRing * 2u + 64;
-  if (smemBytes <= fixed)
-    return 0;
-  uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
-  w = w / 256 * 256;
-  if (w > (uint32_t)kMixRing / 4u)
-    w = (uint32_t)kMixRing / 4u;
   return w;
 }
 

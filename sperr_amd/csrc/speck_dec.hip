@@ -9,7 +9,7 @@
 //                always followed by its sign bit), so token starts and token ranks come from
 //                prefix sums; the results are written by token rank and picked up by the pixels
 //                through the rank of each candidate in raster order;
-//   LIS phase    (k_lis_l0/_l1/_hi; k_lis_mixed for lists that mix set shapes)  what each bit means depends
+//   LIS phase    (k_lis_l0/_l1/_hi; k_lis_mx, speck_mx.hip, for lists that mix set shapes)  what each bit means depends
 //                on every earlier bit of the phase: one workgroup per chunk; chunks run
 //                concurrently;
 //   refinement   (k_ref_apply2)  the j-th significant pixel in raster order takes bit j.
@@ -1570,7 +1570,7 @@ k_lis_l1(DecBuffers b, int p)
 // ------------------------------------------------------------------------------------------
 // LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): what
 // k_lis_hi below shares with its predecessor k_lis_tables (one 1024-thread workgroup per chunk,
-// rounds 1-3; removed in round 4 -- a regular tree k_lis_hi cannot take goes to k_lis_mixed).
+// rounds 1-3; removed in round 4 -- a regular tree k_lis_hi cannot take goes to k_lis_mx).
 // tests/model/speck_model.cpp::model_speck3d_decode_par is the CPU model of the method:
 //   tables   T_j[x] = bits the split of a class-j set takes when it starts at bit x (kTInf when
 //            that would leave the window): speculative, one thread per bit position and class;
@@ -1637,1243 +1637,6 @@ __device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& 
 //   U_j[r]  the CODED item of class j at r: bit 15 = its test bit, low 15 bits = code length
 //           (1 for an insignificant item, 1 + T_j[r+1] otherwise), or kTInf when it is
 //           significant but leaves the window
-// ------------------------------------------------------------------------------------------
-// LIS phase for chunks whose lists MIX set shapes (any extent that is not a power of two): one
-// 512-thread workgroup per chunk.  tests/model/speck_model.cpp::model_speck3d_decode_mixed is the
-// CPU model of this kernel.
-//
-// The code of a set depends on its extents only, so every set has a SHAPE CLASS (spk::ShapeCls,
-// built on the host): a leaf parent of 2, 4 or 8 samples (h = 0), a set made of such leaf parents
-// and single samples (h = 1), and so on.  A list entry's class is read off the entry (which of
-// its three intervals are the long ones).  What pointer jumping needs -- one code structure for
-// all entries of a list -- is gone, so the list is walked serially, but the walk only hops:
-//   rows     per window of W stream bits and for every bit position x a row of twelve 16-bit
-//            entries T[x][col]: the bits the split of a set of column col takes when it starts at
-//            x (kTInf: it leaves the window, kTNone: not computed).  Column 0 is a single sample,
-//            1..3 the leaf parents of 2 / 4 / 8 samples (from the next 16 bits, every x), 4..7 and
-//            8..11 the most frequent h = 1 and h = 2 classes of the chunk shape (host:
-//            build_classes): a chain of look-ups through the children's columns, only where a
-//            coded item can start (the bit in front of x is set).  Speculative, all threads;
-//   walk     the first wavefront, control flow wave-uniform: runs of '0' entries are counted off
-//            the stream (in front of a window by the whole workgroup), a significant entry whose
-//            class has a column costs a few register look-ups (lane = position: the stream word
-//            and the row entries of the list's column group; lane = entry: its class), any other
-//            set is walked into: one look-up per child, the children's records written by one
-//            lane each;
-//   expand   every set that was hopped over is a work item: a thread finds its children with the
-//            rows; leaf parents become leaf events (k_leaf_apply), insignificant child sets are
-//            recorded with their stream position (k_place_scan / _scatter rank them).
-// ------------------------------------------------------------------------------------------
-constexpr int kMixThreads = 512;
-constexpr int kMixCols = 12;
-constexpr int kMixLdsRoots = 48, kMixLdsGrids = 352;   // (host: use_mixed checks that the tree fits)
-constexpr uint32_t kTNone = 0xfffeu;                   // (kTInf = 0xffff)
-
-struct MixCtx {
-  uint64_t parent;     // packed node of the set being walked into
-  KidBox kb;
-  uint8_t pc;          // its class
-  uint8_t next;        // ordinal of the next child
-  uint8_t found;       // an earlier child was significant
-  uint8_t pad;
-};
-
-// kStamps: the build with the tick counters (sperrhip_debug_lis_stamps); the production build carries none
-template <bool kStamps>
-__global__ void __launch_bounds__(kMixThreads) k_lis_mixed(DecBuffers b, int p)
-{
-  const uint32_t c = blockIdx.x;
-  DecState& s = b.st[c];
-  DEC_ACTIVE_OR_RETURN(s, p);
-  extern __shared__ __attribute__((aligned(16))) char mix_smem[];
-  __shared__ ShapeCls sh_cls[kMaxCls];
-  __shared__ uint64_t sh_kcol[kMaxCls];             // byte k: column of child k (0: a single sample, 0xff: none)
-  __shared__ Root sh_roots[kMixLdsRoots];
-  __shared__ Grid sh_grids[kMixLdsGrids];
-  __shared__ uint8_t sh_gridCls[kMixLdsGrids * 8];
-  __shared__ MixCtx sh_ctx[kMaxDepth + 2];
-  __shared__ uint8_t sh_colCls[kMixCols];           // class of every column (0xff: unused)
-  __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
-  __shared__ uint64_t sh_pos;
-  __shared__ uint32_t sh_e, sh_rem, sh_qnB[2], sh_born, sh_leaf, sh_zfound, sh_ncand, sh_stop, sh_hbar, sh_qn2;
-    __shared__ int sh_depth;
-  __shared__ uint32_t sh_scan[kMixThreads / 64 + 1];
-  __shared__ uint32_t sh_simd[kMixThreads / 64];
-  __shared__ uint64_t sh_one;                       // 2D coder: the subband being tested, as a list of one entry
-
-  const int tid = threadIdx.x;
-  const uint32_t lane = (uint32_t)tid & 63u;
-  const uint32_t nlevels = b.tree.nlevels;
-  // which SIMD of the CU this wavefront runs on (HW_ID bits 5:4): the walking wavefront is bound by
-  // its instruction issue, so wavefronts that share its SIMD do not help while it walks
-  if (lane == 0)
-    sh_simd[tid >> 6] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
-  if (tid < kMixCols)
-    sh_colCls[tid] = 0xff;
-  if (tid < kMaxLevels)
-    sh_levelSlot[tid] = (uint32_t)tid < nlevels ? b.levelSlot[tid] : (uint8_t)0xff;
-  __syncthreads();
-  for (uint32_t i = tid; i < b.tree.nroots; i += kMixThreads)
-    sh_roots[i] = b.tree.roots[i];
-  for (uint32_t i = tid; i < b.tree.ngrids; i += kMixThreads)
-    sh_grids[i] = b.tree.grids[i];
-  for (uint32_t i = tid; i < b.tree.ngrids * 8; i += kMixThreads)
-    sh_gridCls[i] = b.tree.gridCls[i];
-  for (uint32_t i = tid; i < b.tree.ncls; i += kMixThreads) {
-    const ShapeCls cc = b.tree.cls[i];
-    sh_cls[i] = cc;
-    uint64_t kc = 0;
-    for (int k = 0; k < 8; k++) {
-      const uint32_t kid = k < cc.nk ? cc.kid[k] : kClsPixel;
-      kc |= (uint64_t)(kid == kClsPixel ? 0u : b.tree.cls[kid].slot) << (8 * k);
-    }
-    sh_kcol[i] = kc;
-    if (cc.slot < kMixCols)
-      sh_colCls[cc.slot] = (uint8_t)i;
-  }
-
-  const uint64_t* words = b.stream + c * b.streamStride;
-  const uint64_t nwordsAvail = (s.avail + 63) / 64;
-  unsigned long long* bornM = reinterpret_cast<unsigned long long*>(b.bornM + c * b.maskPixStride);
-  unsigned long long* sigNew = reinterpret_cast<unsigned long long*>(b.sigNew + c * b.maskPixStride);
-  unsigned long long* sign = reinterpret_cast<unsigned long long*>(b.sign + c * b.signStride);
-  const uint32_t cur = s.cur, nx = cur ^ 1u;
-  const uint64_t phase0 = s.lipStart + s.lipBits;
-  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
-  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
-  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
-  uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
-  uint64_t* leafEv = b.leafEv + c * b.leafStride;
-
-  // Two windows are in flight: while the first wavefront walks one, the other seven expand the items
-  // of the window before it and build the rows of the window after it (whose start is fixed
-  // in advance: `S` bits past the start of the one being walked).
-  const uint32_t W = b.mixW;
-  const uint32_t kWords = (W / 64 + 4 + 1) & ~1u;   // (at most 128: the walk keeps them in two registers per lane)
-  const size_t rowBytes = (size_t)(W + 3) * kMixCols * 2;
-  char* const lds0 = mix_smem;
-  char* const ldsTr = lds0 + 2 * (size_t)kWords * 8;
-  char* const ldsQ = ldsTr + 2 * rowBytes;
-  uint16_t* const ecls = reinterpret_cast<uint16_t*>(ldsQ + 2 * (size_t)kMixQueue * 12);   // ring [kMixRing]: class | column in the level's group << 8
-  uint16_t* const cand = ecls + kMixRing;                                                   // [W]: positions where a coded item's split can start
-  // the window a thread is working on (every thread keeps its own view)
-  uint64_t* wbits = reinterpret_cast<uint64_t*>(lds0);
-  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(lds0);
-  uint16_t* Tr = reinterpret_cast<uint16_t*>(ldsTr);   // [W + 3][12]
-  uint64_t* qid = reinterpret_cast<uint64_t*>(ldsQ);   // [kMixQueue]
-  uint32_t* qmeta = nullptr;                           // [kMixQueue]: first bit | class << 16 | list entry << 24
-  uint64_t a = 0;                                      // stream position of the window's bit 0
-  uint32_t wq0 = 0;                                    // bit offset of window position 0 inside wbits[0]
-  auto set_view = [&](uint32_t bi, uint64_t base) {
-    wbits = reinterpret_cast<uint64_t*>(lds0 + (size_t)bi * kWords * 8);
-    w32 = reinterpret_cast<const uint32_t*>(wbits);
-    Tr = reinterpret_cast<uint16_t*>(ldsTr + (size_t)bi * rowBytes);
-    qid = reinterpret_cast<uint64_t*>(ldsQ + (size_t)bi * kMixQueue * 12);
-    qmeta = reinterpret_cast<uint32_t*>(qid + kMixQueue);
-    a = base;
-    wq0 = (uint32_t)(base & 63);
-  };
-  set_view(0, 0);
-
-  if (tid == 0) {
-    sh_pos = phase0;
-    sh_born = s.bornCount;
-    sh_leaf = s.leafCount;
-    sh_hbar = 0;
-  }
-  __syncthreads();
-  uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t stamp_t = 0;
-  const bool stamps = kStamps && b.lisStamps != nullptr && tid == 0;
-  const bool wstamps = kStamps && b.lisStamps != nullptr;   // (wave-uniform: the walker's own counters)
-#define STAMP(i)                                        \
-  if (stamps) {                                         \
-    const uint64_t now_ = __builtin_readcyclecounter(); \
-    stamp_acc[i] += now_ - stamp_t;                     \
-    stamp_t = now_;                                     \
-  }
-  if (stamps)
-    stamp_t = __builtin_readcyclecounter();
-  uint32_t cnt_hops = 0, cnt_steps = 0, cnt_push = 0, cnt_zruns = 0, cnt_bits = 0, cnt_skips = 0, cnt_items = 0, cnt_tight = 0, cnt_words = 0, cnt_walks = 0, cnt_rounds = 0;
-  uint64_t tick_tight = 0, tick_enter = 0, tick_round = 0;
-
-  auto bit_at = [&](uint32_t r) -> uint32_t {
-    const uint32_t q = r + wq0;
-    return (w32[q >> 5] >> (q & 31)) & 1u;
-  };
-  auto bits32 = [&](uint32_t r) -> uint32_t {  // 32 stream bits starting at r
-    const uint32_t q = r + wq0, sh = q & 31;
-    const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
-    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-  };
-  auto pixel_event = [&](uint32_t ridx, bool sig, uint32_t signbit) {
-    atomicOr(bornM + (ridx >> 6), 1ull << (ridx & 63));
-    if (sig) {
-      atomicOr(sigNew + (ridx >> 6), 1ull << (ridx & 63));
-      if (!signbit)
-        atomicAnd(sign + (ridx >> 6), ~(1ull << (ridx & 63)));
-    }
-  };
-  // a set born insignificant at stream position phase0 + rel; k = its record (the walk counts its
-  // own records in a register, the expansion's threads claim theirs from sh_born)
-  auto write_born = [&](uint32_t k, uint32_t lev, uint64_t rel, uint64_t packed) {
-    if (k >= b.bornStride)
-      return;
-    bornPacked[k] = packed;
-    bornPosLev[k] = ((uint64_t)lev << 48) | rel;
-    atomic_or64(b.mask + c * b.maskStride + (size_t)sh_levelSlot[lev] * b.maskWords + (rel >> 6),
-                1ull << (rel & 63));
-  };
-  auto record_born = [&](uint32_t lev, uint64_t abs, uint64_t packed) {
-    const uint64_t rel = abs - phase0;
-    if (sh_levelSlot[lev] == 0xff || rel >= maskBits)
-      return;  // past the usable stream: decoding stops after this plane anyway
-    write_born(atomicAdd(&sh_born, 1u), lev, rel, packed);
-  };
-  // geometry with the tree's tables in LDS (spk::kid_box / node_cls with these arrays)
-  auto kid_box_l = [&](const Node& nd, KidBox& k) {
-    const Grid g = sh_grids[nd.grid];
-    const Root r = sh_roots[g.root];
-    k.grid = (uint16_t)(nd.grid + 1);
-    k.rev = (uint16_t)(b.tree.flags & kTree2D);
-    uint32_t lev = r.lev;
-    const int d = g.depth;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const int Da = r.D[a];
-      if (Da != 0 && !k.rev) {   // spk::node_level
-        if (d < Da)
-          lev += (uint32_t)d;
-        else {
-          lev += (uint32_t)(Da - 1);
-          if (axis_len(r.len[a], Da - 1, (uint32_t)nd.i[a] >> 1) >= 2)
-            lev += 1;
-        }
-      }
-      const bool splits = d < Da;
-      k.e[a] = splits ? g.e[a] + 1 : g.e[a];
-      k.base[a] = splits ? (uint32_t)nd.i[a] * 2u : (uint32_t)nd.i[a];
-      k.n[a] = (splits && axis_len(r.len[a], k.e[a], k.base[a] + 1u) > 0) ? 2u : 1u;
-      if (!k.rev)
-        lev += k.n[a] - 1u;
-    }
-    k.kidlev = k.rev ? r.lev + (uint32_t)d + 1u : lev;   // (2D coder: one level per partition step)
-    k.nk = k.n[0] * k.n[1] * k.n[2];
-  };
-  auto node_cls_l = [&](const Node& nd) -> uint32_t {
-    const Grid g = sh_grids[nd.grid];
-    const Root& r = sh_roots[g.root];
-    uint32_t k = 0;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const int e = g.e[a];
-      const uint32_t rem = (uint32_t)r.len[a] & ((1u << e) - 1u);
-      k |= (bitrev(nd.i[a], e) < rem ? 1u : 0u) << a;
-    }
-    return sh_gridCls[(uint32_t)nd.grid * 8u + k];
-  };
-  // a significant leaf parent of nk samples whose split starts at y: ONE event word (node id,
-  // significance and sign masks by child ordinal) that k_leaf_apply turns into mask updates
-  auto leaf_event = [&](const Node& nd, uint32_t y, uint32_t nk) {
-    const uint32_t v = bits32(y);
-    uint32_t yy = 0, found = 0, sigm = 0, negm = 0;
-    for (uint32_t k = 0; k < nk; k++) {
-      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-      const uint32_t bit = coded ? (v >> yy) & 1u : 1u;
-      yy += coded;
-      const uint32_t sgn = (v >> yy) & 1u;
-      sigm |= bit << k;
-      negm |= (bit & (sgn ^ 1u)) << k;
-      found |= bit;
-      yy += bit;
-    }
-    const Grid& g = sh_grids[nd.grid];
-    const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
-    const uint32_t slot = atomicAdd(&sh_leaf, 1u);
-    if (slot < b.leafCap)
-      leafEv[slot] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
-  };
-  // bits of the split of a class (nk children, their columns in kc) that starts at x: one look-up
-  // per child through the children's columns
-  auto chain = [&](uint32_t nk, uint64_t kc, uint32_t x) -> uint32_t {
-    uint32_t y = x, found = 0, bad = 0;
-    for (uint32_t k = 0; k < nk; k++) {
-      const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
-      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-      const uint32_t yy = min(y, W + 1);
-      const uint32_t bit = coded ? bit_at(yy) : 1u;
-      const uint32_t s0 = yy + coded;   // where the child's split (or a sample's sign) starts
-      uint32_t tl = Tr[(size_t)s0 * kMixCols + col];
-      if (tl >= kTNone) {
-        bad |= bit ? (tl == kTInf ? 1u : 2u) : 0u;
-        tl = 0;
-      }
-      y = bit ? s0 + tl : yy + 1;
-      found |= bit;
-    }
-    if ((bad & 1u) || y > W)
-      return kTInf;
-    return (bad & 2u) ? kTNone : y - x;
-  };
-
-
-  // ---- synchronisation of the seven helper wavefronts among themselves (the first one is walking):
-  //      a counter in LDS that only grows; every helper knows how far it has to get
-  uint32_t nHelpers = 0, helperRank = 0;   // helpers: the wavefronts on other SIMDs than the first one's
-  bool isHelper = false;
-  {
-    const uint32_t myWave = (uint32_t)tid >> 6;
-    for (uint32_t w = 1; w < (uint32_t)kMixThreads / 64u; w++)
-      if (sh_simd[w] != sh_simd[0]) {
-        if (w == myWave) {
-          isHelper = true;
-          helperRank = nHelpers;
-        }
-        nHelpers++;
-      }
-    if (nHelpers == 0) {   // (not expected: a workgroup's wavefronts are spread over the SIMDs)
-      nHelpers = (uint32_t)kMixThreads / 64u - 1u;
-      isHelper = myWave != 0;
-      helperRank = myWave - 1u;
-    }
-  }
-  uint64_t hstamp[4] = {0, 0, 0, 0};
-  uint64_t wphase[2] = {0, 0};
-  uint64_t myWork = 0;   // diagnostics: ticks of the first helper thread in expand / classes / rows
-  uint32_t hbarGoal = 0;
-  uint64_t barTicks = 0;   // diagnostics: ticks a helper spends in its barriers
-  uint32_t barCount = 0;
-  auto hbar = [&]() {
-    const uint64_t t0_ = wstamps ? __builtin_readcyclecounter() : 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0)
-      atomicAdd(&sh_hbar, 1u);
-    hbarGoal += nHelpers;
-    while (__hip_atomic_load(&sh_hbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hbarGoal)
-      __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (wstamps) {
-      barTicks += __builtin_readcyclecounter() - t0_;
-      barCount++;
-    }
-  };
-
-  // all of the per-level state the lambdas below use
-  const uint64_t* list = nullptr;
-  uint32_t n = 0, grp = 0, topGrp = 0;
-
-  // classes of the list entries [from, to) into the ring, with their column inside the list's group
-  auto fill_ring = [&](uint32_t from, uint32_t to, uint32_t t0, uint32_t NT) {
-    for (uint32_t i = from + t0; i < to; i += NT) {
-      const uint32_t ci = node_cls_l(unpack_node(list[i]));
-      const uint32_t col = sh_cls[ci].slot;
-      ecls[i & (uint32_t)(kMixRing - 1)] =
-          (uint16_t)(ci | ((col < (uint32_t)kMixCols && (col >> 2) == grp ? (col & 3u) : 0xffu) << 8));
-    }
-  };
-
-  // ---- the rows of the window in view (its stream words are loaded here too), by the threads
-  //      t0, t0 + 1, ... of NT; `pipe`: these are the helper wavefronts
-  auto build_rows = [&](uint32_t t0, uint32_t NT, bool pipe) {
-    auto bar = [&]() {
-      if (pipe)
-        hbar();
-      else
-        __syncthreads();
-    };
-    const uint64_t w0 = a >> 6;
-    for (uint32_t i = t0; i < kWords; i += NT) {
-      const uint64_t idx = w0 + i;
-      wbits[i] = idx < nwordsAvail ? words[idx] : 0ull;
-    }
-    if (t0 == 0)
-      sh_ncand = 0;
-    bar();
-    // columns 0..3 at every position (the next 16 bits give the three leaf parents' splits), the
-    // other columns marked "not computed"; positions where a coded item's split can start are
-    // collected
-    for (uint32_t x = t0; x <= W + 2; x += NT) {
-      uint32_t T0 = kTInf, T1 = kTInf, T2 = kTInf, T3 = kTInf, rest = 0xffffffffu;
-      bool isCand = false;
-      if (x < W) {
-        const uint32_t v = bits32(x);
-        // children 0..6 coded one after the other; the last child of 2 / 4 / 8 is coded only when
-        // an earlier one was significant
-        uint32_t y = 0, found = 0, t2 = 0, t4 = 0, t8 = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (k == 1 || k == 3 || k == 7) {
-            const uint32_t bit = found ? (v >> y) & 1u : 1u;
-            const uint32_t tl = y + found + bit;
-            if (k == 1)
-              t2 = tl;
-            else if (k == 3)
-              t4 = tl;
-            else
-              t8 = tl;
-          }
-          if (k < 7) {
-            const uint32_t bit = (v >> y) & 1u;
-            found |= bit;
-            y += 1u + bit;
-          }
-        }
-        T0 = 1u;
-        T1 = x + t2 <= W ? t2 : kTInf;
-        T2 = x + t4 <= W ? t4 : kTInf;
-        T3 = x + t8 <= W ? t8 : kTInf;
-        rest = kTNone | (kTNone << 16);
-        isCand = x >= 1 && bit_at(x - 1) != 0;
-      }
-      uint2* row = reinterpret_cast<uint2*>(Tr + (size_t)x * kMixCols);
-      row[0] = make_uint2(T0 | (T1 << 16), T2 | (T3 << 16));
-      row[1] = make_uint2(rest, rest);
-      row[2] = make_uint2(rest, rest);
-      const uint64_t cm = __ballot(isCand);
-      if (cm) {
-        uint32_t base = 0;
-        const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(true)) - 1u;
-        if (lane == leader)
-          base = atomicAdd(&sh_ncand, (uint32_t)__popcll(cm));
-        base = __shfl(base, (int)leader, 64);
-        if (isCand)
-          cand[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)x;
-      }
-    }
-    bar();
-    // columns 4..7, then 8..11: a chain of look-ups through the children's columns at the collected
-    // positions (four per thread and round: their LDS round trips overlap)
-    {
-      const uint32_t ncand = sh_ncand;
-      for (uint32_t g4 = 4; g4 <= 4u * topGrp; g4 += 4) {
-        bool any = false;
-        for (uint32_t col = g4; col < g4 + 4; col++) {
-          const uint32_t ci = sh_colCls[col];
-          if (ci == 0xff)
-            continue;
-          any = true;
-          const uint32_t nk = sh_cls[ci].nk;
-          const uint64_t kc = sh_kcol[ci];
-          for (uint32_t i = t0; i < ncand; i += 4 * NT) {
-            // four positions per thread and round, their chains in lockstep: the LDS round trips overlap
-            uint32_t x[4], y[4], found[4], bad[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t iu = i + (uint32_t)u * NT;
-              x[u] = iu < ncand ? (uint32_t)cand[iu] : W + 1u;
-              y[u] = x[u];
-              found[u] = 0;
-              bad[u] = 0;
-            }
-            for (uint32_t k = 0; k < nk; k++) {
-              const uint32_t ccol = (uint32_t)(kc >> (8 * k)) & 0xffu;
-              const uint32_t last = k + 1 == nk ? 1u : 0u;
-              uint32_t bitv[4], s0[4], tl[4];
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const uint32_t coded = found[u] | (last ^ 1u);
-                const uint32_t yy = min(y[u], W + 1);
-                bitv[u] = coded ? bit_at(yy) : 1u;
-                s0[u] = yy + coded;
-                tl[u] = Tr[(size_t)s0[u] * kMixCols + ccol];
-                y[u] = yy;
-              }
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                uint32_t t = tl[u];
-                if (t >= kTNone) {
-                  bad[u] |= bitv[u] ? (t == kTInf ? 1u : 2u) : 0u;
-                  t = 0;
-                }
-                y[u] = bitv[u] ? s0[u] + t : y[u] + 1;
-                found[u] |= bitv[u];
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t iu = i + (uint32_t)u * NT;
-              if (iu < ncand) {
-                const uint32_t t = ((bad[u] & 1u) || y[u] > W) ? kTInf : (bad[u] & 2u) ? kTNone : y[u] - x[u];
-                Tr[(size_t)x[u] * kMixCols + col] = (uint16_t)t;
-              }
-            }
-          }
-        }
-        if (any)
-          bar();
-      }
-    }
-  };
-
-  // ---- the walk of the window in view (buffer bi): the first wavefront, every lane carrying the
-  //      same walker state.  It starts at window position r0 and stops at the first item that
-  //      starts at or past S (the next window's rows begin there), or earlier when an item leaves
-  //      the window / the list ends / the queue is full.  `fresh`: the window was built for this
-  //      very position (a walk that changes nothing then would repeat for ever).
-  auto walk = [&](uint32_t bi, uint32_t r0, uint32_t S, bool fresh, uint32_t ringHi) {
-    {
-      // (the walker's state is wave-uniform: kept in scalar registers)
-      uint32_t r = r0, e = __builtin_amdgcn_readfirstlane(sh_e), rem = __builtin_amdgcn_readfirstlane(sh_rem);
-      uint32_t qn = 0, qcost = 0, ns = 0;
-      int depth = __builtin_amdgcn_readfirstlane(sh_depth);
-      const uint32_t itemCost = grp == 2u ? 9u : 1u;   // (an h = 2 item queues up to 8 more)
-      const uint32_t e_in = e;
-      const int depth_in = depth;
-      uint32_t stE = 0, stM = 0;   // staged items of the list hops: lane = item
-      // lane = stream word of the window
-      const uint64_t sw0 = wbits[lane];
-      const uint64_t sw1 = lane + 64u < kWords ? wbits[lane + 64u] : 0ull;
-      uint32_t curK = 0xffffffffu;   // stream word the registers below belong to
-      uint64_t m = 0;                // that word (uniform)
-      uint64_t lrow = 0;             // lane = bit of it: the group's four row entries one position on
-      uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
-      uint64_t lrowNext = 0;         // the same for word nextK
-      uint32_t nextK = 0xfffffffeu;
-      auto load_lrow = [&](uint32_t kk) -> uint64_t {
-        const int32_t row = (int32_t)(kk * 64u + lane) - (int32_t)wq0 + 1;
-        return (row >= 0 && row <= (int32_t)W + 2)
-                   ? *reinterpret_cast<const uint64_t*>(Tr + (size_t)row * kMixCols + grp * 4u)
-                   : ~0ull;
-      };
-      uint64_t tSet0 = (wstamps && depth >= 2) ? __builtin_readcyclecounter() : 0;   // (time inside the sets walked into)
-      uint32_t eb = 0x80000000u;     // lane = list entry eb + lane: its ecls word (nothing loaded yet: no
-                                     //   entry index is within 64 of this value)
-      uint32_t ecv = 0;
-      auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx);
-      };
-      auto rl64 = [&](uint64_t v, uint32_t idx) -> uint64_t {
-        return (uint64_t)rl32((uint32_t)v, idx) | ((uint64_t)rl32((uint32_t)(v >> 32), idx) << 32);
-      };
-      auto flush = [&]() {
-        if (lane < ns) {
-          qid[qn + lane] = stE;
-          qmeta[qn + lane] = stM;
-        }
-        qn += ns;
-        ns = 0;
-      };
-      while (true) {
-        if (r >= S || qcost + 80u >= (uint32_t)kMixQueue)
-          break;
-        if (depth == 1) {   // the list itself
-          if (rem == 0) {
-            depth = 0;
-            break;
-          }
-          const uint32_t q = r + wq0, k = q >> 6, o = q & 63u;
-          if (k != curK) {
-            curK = k;
-            m = k < 64u ? rl64(sw0, k) : rl64(sw1, k - 64u);
-            lrowK = 0xffffffffu;
-          }
-          // Stream words that lie inside the window, with at least 64 entries left and room for
-          // 64 more items: their entries in a tight loop, word after word -- no end-of-list,
-          // end-of-window or queue checks per entry; anything unusual (a set to walk into, a split
-          // that leaves the window) is left to the general code below.
-          if (rem >= 64u && k * 64u + 64u <= S + wq0 && qcost + 64u * itemCost + 80u < (uint32_t)kMixQueue) {
-            const uint32_t eEnd = e + rem;
-            uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
-            bool unusual = false;
-            const uint64_t tt0 = wstamps ? __builtin_readcyclecounter() : 0;
-            while (true) {
-              cnt_words++;
-              if (lrowK != kk) {   // (the next word's row entries are fetched while this word is walked)
-                if (kk != curK) {
-                  curK = kk;
-                  m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
-                }
-                lrow = nextK == kk ? lrowNext : load_lrow(kk);
-                lrowK = kk;
-                nextK = kk + 1u;
-                lrowNext = load_lrow(nextK);
-              }
-              // (at most 64 entries start inside a word, at most 32 of them significant: one load
-              // of entry classes and the staging registers cover it)
-              if (e - eb > oo) {   // (the entries of this word: fewer than 64 - oo from e on)
-                eb = e;
-                ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMixRing - 1)] : 0xffffu;
-              }
-              if (ns > 32u)
-                flush();
-              const uint32_t ns0 = ns;
-              const uint32_t pbase = kk * 64u + 1u - wq0;   // split start of an entry whose bit is bit 0 of the word
-              while (true) {   // oo < 64 here
-                const uint64_t mm = m >> oo;
-                const uint32_t z = mm ? (uint32_t)__builtin_ctzll(mm) : 64u - oo;   // insignificant entries
-                oo += z;
-                e += z;
-                const uint32_t ec = rl32(ecv, (e - eb) & 63u);
-                const uint32_t loc = ec >> 8;
-                const uint32_t tl = (uint32_t)(rl64(lrow, oo & 63u) >> (16u * (loc & 3u))) & 0xffffu;
-                if (oo >= 64u)
-                  break;   // the word is done
-                if (loc == 0xffu || tl >= kTNone) {
-                  unusual = true;   // something the general code has to look at
-                  break;
-                }
-                {   // lane ns of the staging registers takes the item (the values stay scalar)
-                  const uint32_t itemM = __builtin_amdgcn_readfirstlane((pbase + oo) | ((ec & 0xffu) << 16) | (1u << 24));
-                  const uint32_t itemE = __builtin_amdgcn_readfirstlane(e), itemL = __builtin_amdgcn_readfirstlane(ns);
-                  asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                               : "+v"(stE), "+v"(stM)
-                               : "s"(itemE), "s"(itemL), "s"(itemM)
-                               : "m0");
-                }
-                ns++;
-                oo += 1u + tl;
-                e++;
-                if (oo >= 64u)
-                  break;
-              }
-              cnt_hops += ns - ns0;
-              cnt_tight += ns - ns0;
-              qcost += (ns - ns0) * itemCost;
-              if (unusual)
-                break;
-              // on to the word the walk is in now (a long split may have skipped some)
-              kk += oo >> 6;
-              oo &= 63u;
-              if (!(eEnd - e >= 64u && kk * 64u + 64u <= S + wq0 && qcost + 64u * itemCost + 80u < (uint32_t)kMixQueue))
-                break;
-            }
-            r = kk * 64u + oo - wq0;
-            rem = eEnd - e;
-            if (wstamps)
-              tick_tight += __builtin_readcyclecounter() - tt0;
-            if (!unusual)
-              continue;
-            if (kk != curK) {   // (cannot happen: an unusual entry lies in the word just walked)
-              curK = kk;
-              m = kk < 64u ? rl64(sw0, kk) : rl64(sw1, kk - 64u);
-            }
-          }
-          if (lrowK != curK) {
-            lrow = load_lrow(curK);
-            lrowK = curK;
-          }
-          const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
-          const uint64_t tt = m >> o2;
-          const uint32_t z = min(min(tt ? (uint32_t)__ffsll((long long)tt) - 1u : 64u - o2, rem), S - r);
-          if (z) {
-            cnt_zruns++;
-            r += z;
-            e += z;
-            rem -= z;
-            continue;
-          }
-          cnt_hops++;
-          if (e - eb >= 64u) {
-            eb = e;
-            ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMixRing - 1)] : 0xffffu;
-          }
-          const uint32_t ec = rl32(ecv, e - eb);
-          const uint32_t loc = ec >> 8, ci = ec & 0xffu;
-          uint32_t tl = kTNone;
-          if (loc != 0xffu)
-            tl = (uint32_t)(rl64(lrow, o2) >> (16u * loc)) & 0xffffu;
-          if (tl == kTInf)
-            break;   // the next window starts at this entry
-          if (tl != kTNone) {
-            if (lane == ns) {
-              stE = e;
-              stM = (r + 1u) | (ci << 16) | (1u << 24);
-            }
-            ns++;
-            qcost += itemCost;
-            if (ns == 64u)
-              flush();
-            r += 1u + tl;
-          }
-          else {   // walk into it
-            cnt_push++;
-            const uint64_t te0 = wstamps ? __builtin_readcyclecounter() : 0;
-            const uint64_t packed = list[e];
-            if (lane == 0)
-              atomic_or64(sigbits + (e >> 6), 1ull << (e & 63));
-            KidBox kb;
-            kid_box_l(unpack_node(packed), kb);
-            if (lane == 0) {
-              MixCtx& nc = sh_ctx[1];
-              nc.parent = packed;
-              nc.kb = kb;
-              nc.pc = (uint8_t)ci;
-              nc.next = 0;
-              nc.found = 0;
-            }
-            depth = 2;
-            r += 1;
-            if (wstamps) {
-              tSet0 = __builtin_readcyclecounter();
-              tick_enter += tSet0 - te0;
-            }
-          }
-          e++;
-          rem--;
-          continue;
-        }
-        // ---- a set that is being walked into: its children from `next` on, one look-up each;
-        //      lane k remembers what became of child k and writes its record afterwards
-        MixCtx& cx = sh_ctx[depth - 1];
-        const uint32_t pc = cx.pc;
-        const uint32_t nk = sh_cls[pc].nk;
-        const uint64_t kcol = sh_kcol[pc];
-        const uint64_t parent = cx.parent;
-        const KidBox kb = cx.kb;
-        const uint32_t k0 = cx.next;
-        uint32_t found = cx.found, k = k0;
-        uint32_t myAct = 0, myY = 0;   // 1: born insignificant (test bit at myY), 2: hopped over (split starts at myY)
-        bool pushed = false, halted = false;
-        while (k < nk) {
-          if (r >= S) {
-            halted = true;
-            break;
-          }
-          cnt_steps++;
-          const uint32_t col = (uint32_t)(kcol >> (8 * k)) & 0xffu;
-          const bool coded = found || (k + 1 != nk);
-          if (col == 0) {   // a single sample
-            uint32_t sig = 1, sgn, len = 1;
-            if (coded) {
-              sig = bit_at(r);
-              if (sig && r + 1 >= W) {
-                halted = true;
-                break;
-              }
-              sgn = sig ? bit_at(r + 1) : 1u;
-              len = 1u + sig;
-            }
-            else
-              sgn = bit_at(r);
-            if (lane == 0)
-              pixel_event(kid_pixel_raster(b.tree, unpack_node(parent), kb, k), sig != 0, sgn);
-            found |= sig;
-            r += len;
-            k++;
-            continue;
-          }
-          uint32_t start = r, bit = 1;
-          if (coded) {
-            bit = bit_at(r);
-            start = r + 1;
-          }
-          if (!bit) {
-            if (lane == k) {
-              myAct = 1;
-              myY = r;
-            }
-            r += 1;
-            k++;
-            continue;
-          }
-          const uint32_t tl = col != 0xffu ? (uint32_t)Tr[(size_t)start * kMixCols + col] : kTNone;
-          if (tl == kTInf) {
-            halted = true;   // the next window starts at this child's first bit
-            break;
-          }
-          found = 1;
-          if (tl != kTNone) {
-            if (lane == k) {
-              myAct = 2;
-              myY = start;
-            }
-            qcost += (col >> 2) == 2u ? 9u : 1u;
-            r = start + tl;
-            k++;
-            continue;
-          }
-          k++;   // walk into this child
-          pushed = true;
-          r = start;
-          break;
-        }
-        // the records of the children handled in this round
-        {
-          const uint64_t rel = a + myY - phase0;
-          const bool bornOk = myAct == 1 && sh_levelSlot[kb.kidlev] != 0xff && rel < maskBits;
-          const uint64_t bm = __ballot(bornOk);
-          if (bm) {   // (the expansion's threads claim records from the same counter at the same time)
-            uint32_t base = 0;
-            if (lane == 0)
-              base = atomicAdd(&sh_born, (uint32_t)__popcll(bm));
-            base = rl32(base, 0);
-            if (bornOk)
-              write_born(base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull)), kb.kidlev, rel,
-                         kid_packed(kb, lane));
-          }
-          const uint64_t im = __ballot(myAct == 2);
-          if (im) {
-            flush();
-            if (myAct == 2) {
-              const uint32_t idx = qn + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
-              qid[idx] = kid_packed(kb, lane);
-              qmeta[idx] = myY | ((uint32_t)sh_cls[pc].kid[lane] << 16);
-            }
-            qn += (uint32_t)__popcll(im);
-          }
-        }
-        if (lane == 0) {
-          cx.next = (uint8_t)k;
-          cx.found = (uint8_t)found;
-        }
-        if (pushed) {
-          cnt_push++;
-          const uint64_t kid = kid_packed(kb, k - 1);
-          KidBox nkb;
-          kid_box_l(unpack_node(kid), nkb);
-          if (lane == 0) {
-            MixCtx& nc = sh_ctx[depth];
-            nc.parent = kid;
-            nc.kb = nkb;
-            nc.pc = sh_cls[pc].kid[k - 1];
-            nc.next = 0;
-            nc.found = 0;
-          }
-          depth++;
-        }
-        else if (halted)
-          break;
-        else {
-          depth--;
-          cnt_rounds++;
-          if (wstamps && depth == 1) {
-            tick_round += __builtin_readcyclecounter() - tSet0;
-            tSet0 = 0;
-          }
-        }
-      }
-      if (wstamps && tSet0)   // (stopped inside a set)
-        tick_round += __builtin_readcyclecounter() - tSet0;
-      flush();
-      // (a window that changes nothing would be walked for ever: cannot happen while the window is
-      // longer than every split that has a column, which the host checks -- kept as a guard)
-      cnt_bits += r;
-      const bool stuck = fresh && r == 0 && e == e_in && depth == depth_in && qn == 0;
-      if (lane == 0) {
-        sh_pos = a + r;
-        sh_e = e;
-        sh_rem = rem;
-        sh_depth = stuck ? -1 : depth;
-        sh_qnB[bi] = qn;
-        sh_stop = depth == 0 ? 1u : (r >= S ? 0u : 2u);
-      }
-    }
-  };
-
-  // ---- expansion of the sets the walk of the window in view hopped over, by the threads t0,
-  //      t0 + 1, ... of NT: leaf parents become leaf events, an h = 1 set parses its leaf-parent
-  //      children in line, an h = 2 set its h = 1 children likewise
-  auto expand_h1 = [&](const Node& nd, uint32_t ci, uint32_t y) {
-    KidBox kb;
-    kid_box_l(nd, kb);
-    const uint32_t nk = sh_cls[ci].nk;
-    const uint64_t kc = sh_kcol[ci];
-    uint32_t found = 0;
-    for (uint32_t k = 0; k < nk; k++) {
-      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-      const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
-      const uint32_t bit = coded ? bit_at(y) : 1u;
-      const uint32_t start = y + coded;
-      if (col == 0) {   // a single sample: its sign follows
-        pixel_event(kid_pixel_raster(b.tree, nd, kb, k), bit != 0, bit ? bit_at(start) : 1u);
-        found |= bit;
-        y = start + bit;
-        continue;
-      }
-      if (!bit) {
-        record_born(kb.kidlev, a + y, kid_packed(kb, k));
-        y += 1;
-        continue;
-      }
-      found = 1;
-      // (an implied child is the last one: nothing follows it, its length is not needed)
-      y = start + (coded ? (uint32_t)Tr[(size_t)start * kMixCols + col] : 0u);
-      leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
-    }
-  };
-  auto expand = [&](uint32_t bi, uint32_t t0, uint32_t NT, bool pipe) {
-    const uint32_t n1 = sh_qnB[bi];
-    if (t0 == 0)
-      sh_qn2 = n1;
-    if (pipe)
-      hbar();
-    else
-      __syncthreads();
-    for (int round = 0; round < 2; round++) {
-    // (second round: the h = 1 children of the h = 2 items, queued behind the walk's items)
-    const uint32_t i0 = round == 0 ? 0u : n1;
-    const uint32_t nin = round == 0 ? n1 : min(sh_qn2, (uint32_t)kMixQueue);
-    for (uint32_t i = i0 + t0; i < nin; i += NT) {
-      const uint64_t ident = qid[i];
-      const uint32_t meta = qmeta[i];
-      const uint32_t ci = (meta >> 16) & 0xffu;
-      uint32_t y = meta & 0xffffu;
-      uint64_t packed = ident;
-      if (meta >> 24) {
-        packed = list[ident];
-        atomic_or64(sigbits + (ident >> 6), 1ull << (ident & 63));
-      }
-      const Node nd = unpack_node(packed);
-      const uint32_t hh = sh_cls[ci].h;
-      if (hh == 0) {
-        leaf_event(nd, y, sh_cls[ci].nk);
-        continue;
-      }
-      if (hh == 1) {
-        expand_h1(nd, ci, y);
-        continue;
-      }
-      KidBox kb;
-      kid_box_l(nd, kb);
-      const uint32_t nk = sh_cls[ci].nk;
-      const uint64_t kc = sh_kcol[ci];
-      uint32_t found = 0;
-      for (uint32_t k = 0; k < nk; k++) {
-        const uint32_t coded = found | (uint32_t)(k + 1 != nk);
-        const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
-        const uint32_t bit = coded ? bit_at(y) : 1u;
-        const uint32_t start = y + coded;
-        if (col == 0) {
-          pixel_event(kid_pixel_raster(b.tree, nd, kb, k), bit != 0, bit ? bit_at(start) : 1u);
-          found |= bit;
-          y = start + bit;
-          continue;
-        }
-        if (!bit) {
-          record_born(kb.kidlev, a + y, kid_packed(kb, k));
-          y += 1;
-          continue;
-        }
-        found = 1;
-        y = start + (coded ? (uint32_t)Tr[(size_t)start * kMixCols + col] : 0u);
-        if (col < 4u)
-          leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
-        else {
-          const uint32_t slot = atomicAdd(&sh_qn2, 1u);
-          if (slot < (uint32_t)kMixQueue) {   // (the walk counts nine places for every h = 2 item)
-            qid[slot] = kid_packed(kb, k);
-            qmeta[slot] = start | ((uint32_t)sh_cls[ci].kid[k] << 16);
-          }
-        }
-      }
-    }
-    if (pipe)
-      hbar();
-    else
-      __syncthreads();
-    }
-  };
-
-  // The lists, deepest level first.  2D coder (spk::kTree2D): then the type-I set, tested at the end
-  // of every sorting pass (SPECK2D_INT.cpp:44-98): when it is significant, the three subbands of its
-  // level are tested -- each goes through the machinery below as a list of one entry, and joins the
-  // list of its level as a birth when it is insignificant -- and the rest of it is tested next (a
-  // test that is implied when none of the three was significant).
-  const bool twoD = (b.tree.flags & kTree2D) != 0;
-  uint32_t lv = nlevels;
-  bool inI = false, iNeed = true;
-  int iJ = -1;                     // next of the three subbands (-1: the type-I set's own test)
-  uint32_t iPart = s.iPart, iCounter = 0;
-  uint64_t iRoot = 0, iPos0 = 0;
-  for (;;) {
-    uint32_t l;
-    if (!inI) {
-      if (lv == 0) {
-        if (!twoD)
-          break;
-        inI = true;
-        continue;
-      }
-      l = --lv;
-      n = s.listLen[cur][l];
-      if (n == 0) {
-        if (tid == 0)
-          s.listLen[nx][l] = 0;
-        continue;
-      }
-      list = b.lis[cur] + c * b.lisStride + b.levelOff[l];
-    }
-    else {
-      if (iJ < 0) {
-        if (iPart == 0)
-          break;
-        if (iNeed) {
-          __syncthreads();
-          const uint64_t pos = sh_pos;
-          const uint32_t bit = (pos >> 6) < nwordsAvail ? (uint32_t)(words[pos >> 6] >> (pos & 63)) & 1u : 0u;
-          __syncthreads();
-          if (tid == 0)
-            sh_pos = pos + 1;
-          __syncthreads();
-          if (!bit)
-            break;
-        }
-        iJ = 0;
-        iCounter = 0;
-        continue;
-      }
-      if (iJ == 3) {
-        iPart--;
-        iNeed = iCounter != 0;
-        iJ = -1;
-        continue;
-      }
-      iRoot = b.iRoots[(size_t)(b.iLevels - iPart) * 3 + (uint32_t)iJ];
-      iJ++;
-      if (iRoot == ~0ull)   // (an empty subband)
-        continue;
-      __syncthreads();
-      if (tid == 0)
-        sh_one = iRoot;
-      iPos0 = sh_pos;
-      l = iPart;
-      n = 1;
-      list = &sh_one;
-      __syncthreads();
-    }
-    grp = b.mixLevelGroup[l] & 3u;      // column group of (most of) this list's entries
-    topGrp = b.mixLevelGroup[l] >> 4;   // highest column group its windows can need
-    // the walk of a window stops at S: items of the columns in use that start before S end inside
-    // the window (a longer one, rare, restarts the pipeline at its first bit)
-    const uint32_t S = W - (topGrp == 0 ? 24u : topGrp == 1 ? 144u : 320u);
-    for (uint32_t i = tid; i < (n + 63) / 64 + 1; i += kMixThreads)
-      sigbits[i] = 0;
-    if (tid == 0) {
-      sh_depth = 1;
-      sh_rem = n;
-      sh_e = 0;
-      sh_qnB[0] = sh_qnB[1] = 0;
-    }
-    __syncthreads();
-    uint32_t ringHi = 0;      // list entries below this index have their class word in the ring
-    uint32_t curB = 0;        // buffer of the window to walk next
-    uint64_t aCur = 0;        // its first stream position
-    bool haveRows = false;    // its rows are built
-    int pend = -1;            // buffer whose items are still to be expanded
-    uint64_t aPend = 0;
-
-    while (true) {
-      if (!haveRows) {
-        // ---- the pipeline (re)starts.  In front of a window the insignificant entries up to the
-        //      next '1' of the list are counted off the stream by the whole workgroup, 32 Kbit per
-        //      round (no tables: in the sparse planes whole lists go this way)
-        while (sh_depth == 1) {
-          __syncthreads();
-          if (tid == 0)
-            sh_zfound = 0xffffffffu;
-          __syncthreads();
-          const uint64_t pos = sh_pos;
-          const uint32_t rem = sh_rem;
-          const uint32_t off = (uint32_t)(pos & 63);
-          const uint64_t wi = (pos >> 6) + (uint32_t)tid;
-          uint64_t w = wi < nwordsAvail ? words[wi] : 0ull;
-          if (tid == 0)
-            w &= ~0ull << off;
-          if (w)
-            atomicMin(&sh_zfound, (uint32_t)tid * 64u + (uint32_t)__ffsll((long long)w) - 1u);
-          __syncthreads();
-          const uint32_t f = sh_zfound;
-          const uint32_t zeros = (f == 0xffffffffu ? (uint32_t)kMixThreads * 64u : f) - off;
-          const uint32_t z = min(zeros, rem);
-          __syncthreads();
-          if (tid == 0) {
-            sh_pos = pos + z;
-            sh_e += z;
-            sh_rem = rem - z;
-            if (rem == z)
-              sh_depth = 0;
-          }
-          __syncthreads();
-          cnt_skips++;
-          if (f != 0xffffffffu || rem == z)
-            break;
-        }
-        __syncthreads();
-        STAMP(5);
-        if (sh_depth == 0)
-          break;
-        aCur = sh_pos;
-        const uint32_t eNow = sh_e;
-        const uint32_t to = min(n, eNow + 2u * W), from = min(max(ringHi, eNow), to);
-        __syncthreads();
-        set_view(curB, aCur);
-        fill_ring(from, to, (uint32_t)tid, kMixThreads);
-        ringHi = to;
-        STAMP(0);
-        build_rows((uint32_t)tid, kMixThreads, false);
-        __syncthreads();
-        STAMP(1);
-        haveRows = true;
-        if (stamps)
-          stamp_acc[8] += 1;
-      }
-      // ---- one phase: the first wavefront walks the window, the others expand the items of the
-      //      window before it and build the rows of the window S bits on
-      const uint32_t r0 = (uint32_t)(sh_pos - aCur);
-      const uint32_t eNow = sh_e;
-      const uint32_t ringTo = min(n, eNow + 2u * W), ringFrom = min(max(ringHi, eNow), ringTo);
-      __syncthreads();
-      const uint64_t hphase0 = wstamps ? __builtin_readcyclecounter() : 0;
-      if (tid < 64) {
-        set_view(curB, aCur);
-        walk(curB, r0, S, r0 == 0, ringHi);
-        if (stamps)
-          wphase[0] += __builtin_readcyclecounter() - hphase0;   // the walk, from the start of the phase
-        STAMP(7);
-      }
-      else if (isHelper) {
-        const uint32_t t0 = helperRank * 64u + lane, NT = nHelpers * 64u;
-        const bool hst = wstamps && t0 == 0;
-        uint64_t h0 = hst ? __builtin_readcyclecounter() : 0;
-        if (pend >= 0) {
-          set_view((uint32_t)pend, aPend);
-          expand((uint32_t)pend, t0, NT, true);   // (ends with a barrier: the rows of that window are overwritten next)
-        }
-        if (hst) {
-          const uint64_t h1 = __builtin_readcyclecounter();
-          hstamp[0] += h1 - h0;
-          h0 = h1;
-        }
-        set_view(curB ^ 1u, aCur + S);
-        fill_ring(ringFrom, ringTo, t0, NT);
-        if (hst) {
-          const uint64_t h1 = __builtin_readcyclecounter();
-          hstamp[1] += h1 - h0;
-          h0 = h1;
-        }
-        build_rows(t0, NT, true);
-        if (hst)
-          hstamp[2] += __builtin_readcyclecounter() - h0;
-        if (wstamps && lane == 0)
-          myWork += __builtin_readcyclecounter() - hphase0;
-      }
-      __syncthreads();
-      if (stamps)
-        wphase[1] += __builtin_readcyclecounter() - hphase0;     // the whole phase as the walker sees it
-      if (wstamps && isHelper && helperRank == 0 && lane == 0)
-        hstamp[3] += __builtin_readcyclecounter() - hphase0;
-      if (sh_depth < 0) {
-        if (tid == 0) {
-          s.error = 1;
-          s.done = 1;
-        }
-        return;
-      }
-      STAMP(2);
-      if (stamps)
-        stamp_acc[9] += 1;
-      ringHi = ringTo;
-      cnt_items += sh_qnB[curB];
-      pend = (int)curB;
-      aPend = aCur;
-      const uint32_t stop = sh_stop;
-      if (stop == 0) {   // the walk reached S: the rows built meanwhile are the next window's
-        aCur += S;
-        curB ^= 1u;
-      }
-      else {             // the list has ended, or the pipeline restarts where the walk stopped
-        haveRows = false;
-        curB ^= 1u;
-        if (stop == 1)
-          break;
-      }
-    }
-    // ---- the items of the last window
-    __syncthreads();
-    if (pend >= 0)
-      set_view((uint32_t)pend, aPend);
-    if (pend >= 0)   // (every thread: the expansion synchronises the workgroup)
-      expand((uint32_t)pend, (uint32_t)tid, kMixThreads, false);
-    __syncthreads();
-    STAMP(3);
-    if (inI) {   // a subband the type-I set released
-      const bool sig = (__hip_atomic_load(sigbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull) != 0;
-      if (sig)
-        iCounter++;
-      else if (tid == 0)
-        record_born(iPart, iPos0, iRoot);
-      __syncthreads();
-      continue;
-    }
-    // ---- old entries that stayed insignificant keep their order
-    {
-      __syncthreads();
-      uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[l];
-      uint32_t carry = 0;
-      const uint32_t nw = (n + 63) / 64;
-      for (uint32_t base = 0; base < nw; base += kMixThreads) {
-        const uint32_t wi = base + tid;
-        uint64_t stay = 0;
-        if (wi < nw) {
-          stay = ~__hip_atomic_load(sigbits + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t valid = n - wi * 64;
-          if (valid < 64)
-            stay &= (1ull << valid) - 1;
-        }
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan<uint32_t>((uint32_t)__popcll(stay), sh_scan, &total) + carry;
-        while (stay) {
-          const int k = __ffsll((long long)stay) - 1;
-          stay &= stay - 1;
-          keep[ex++] = list[wi * 64 + k];
-        }
-        carry += total;
-      }
-      if (tid == 0)
-        s.listLen[nx][l] = carry;
-      __syncthreads();
-    }
-    STAMP(4);
-  }
-
-  __syncthreads();
-  const uint64_t phaseBits = min(sh_pos - phase0, maskBits);
-  if (stamps) {
-    uint64_t* out = b.lisStamps + (size_t)c * 64;
-    for (int i = 0; i < 10; i++)
-      out[i] += stamp_acc[i];
-    out[16] += cnt_hops;
-    out[17] += cnt_steps;
-    out[18] += cnt_push;
-    out[19] += cnt_zruns;
-    out[20] += cnt_bits;
-    out[21] += cnt_skips;
-    out[22] += cnt_items;
-    out[44] += wphase[0];
-    out[45] += wphase[1];
-    out[23] += cnt_tight;
-    out[24] += cnt_words;
-    out[30] += tick_tight;
-    out[31] += tick_enter;
-    out[40] += tick_round;
-    out[41] += cnt_rounds;
-  }
-  if (wstamps && isHelper && lane == 0)
-    b.lisStamps[(size_t)c * 64 + 32 + helperRank] += myWork;
-  if (wstamps && isHelper && helperRank == 0 && lane == 0) {
-    uint64_t* out = b.lisStamps + (size_t)c * 64;
-    out[25] += hstamp[0];
-    out[26] += hstamp[1];
-    out[27] += hstamp[2];
-    out[28] += nHelpers;
-    out[29] += hstamp[3];
-    out[42] += barTicks;
-    out[43] += barCount;
-  }
-#undef STAMP
-  if (tid == 0) {
-    s.cur = nx;
-    s.pos = sh_pos;
-    s.iPart = iPart;
-    s.nLeafEv = min(sh_leaf, b.leafCap);
-    s.bornCount = min(sh_born, (uint32_t)b.bornStride);
-    s.lisPhaseBits = phaseBits;
-    s.lastPlane = p;
-    if (sh_pos >= s.avail)  // SPECK_INT.cpp:200-201
-      s.done = 1;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // LIS phase, lists of the 8x8x8 and larger sets, GPU-WIDE: the table method above (speculative
 // tables per window, pointer jumping over the list entries, breadth-first expansion of the sets
@@ -4244,7 +3007,7 @@ __global__ void __launch_bounds__(kThreads) k_leaf_apply(DecBuffers b, int p)
       b.leafDirty[c * b.leafDirtyStride + ((uint32_t)ev >> 5)] = (uint8_t)(p + 1);   // (every writer stores the same value)
       continue;
     }
-    if (!(g.kind & kGridOct)) {   // any shape (events of k_lis_mixed): the existing children by ordinal
+    if (!(g.kind & kGridOct)) {   // any shape (events of k_lis_mx): the existing children by ordinal
       KidBox kb;
       kid_box(t, nd, kb);
       for (uint32_t q = 0; q < kb.nk; q++) {
@@ -4494,13 +3257,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   static const uint32_t mxTotal = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 208u;
   const uint32_t mxGroups = std::min<uint32_t>(std::min<uint32_t>(8u, std::max<uint32_t>(1, b.hiGroupsMax)),
                                                plan.mxGroups ? plan.mxGroups : std::max<uint32_t>(1, mxTotal / nc));
-  if (plan.mixed && plan.mx && prepare_lis_mx(b))
+  if (plan.mixed && prepare_lis_mx(b))
     return -1;
-  if (plan.mixed) {
-    if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<false>), (int)b.mixSmemBytes) ||
-        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_mixed<true>), (int)b.mixSmemBytes))
-      return -1;
-  }
   if (plan.tables && plan.hi) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint32_t>), (int)b.hiSmemBytes) ||
         set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_hi<uint64_t>), (int)b.hiSmemBytes))
@@ -4534,16 +3292,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       LAUNCH_CT(k_lis_hi, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);
       LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
     }
-    else if (plan.mixed && plan.mx) {
+    else if (plan.mixed) {
       if (launch_lis_mx(stream, b, p, mxGroups, b.lisStamps != nullptr))
         return -1;
       LAUNCH_K(k_lis_compact, dim3(b.tree.nlevels, nc), dim3(kTabThreads), 0, stream, b, p);
-    }
-    else if (plan.mixed) {
-      if (b.lisStamps)
-        LAUNCH_K(k_lis_mixed<true>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
-      else
-        LAUNCH_K(k_lis_mixed<false>, dim3(nc), dim3(kMixThreads), b.mixSmemBytes, stream, b, p);
     }
     else
       LAUNCH_CT(k_lis_walk, dim3(nc), dim3(64), 0, stream, b, p);

@@ -2,9 +2,9 @@
 //
 // The sorting pass of a plane (/root/reference/src/SPECK3D_INT.cpp:99-138: the lists from the smallest sets to
 // the largest, m_process_S / m_code_S :140-212, the split rule :214-326; 2D: /root/reference/src/SPECK2D_INT.cpp:
-// 10-218) is a serial parse: what a bit means depends on every earlier bit.  k_lis_mixed (speck_dec.hip) runs
-// it with ONE workgroup per chunk that builds speculative tables (rows of split lengths per stream position and
-// shape class), walks the list entries with one wavefront and expands the sets that were hopped over -- all
+// 10-218) is a serial parse: what a bit means depends on every earlier bit.  k_lis_mixed (rounds 2-3, removed at
+// the end of round 4) ran it with ONE workgroup per chunk that built speculative tables (rows of split lengths per stream position and
+// shape class), walked the list entries with one wavefront and expanded the sets that were hopped over -- all
 // three on the one workgroup's clock.  Here only the walk stays serial:
 //
 //   * the phase's stream is cut into fixed REGIONS of S bits, handed out by a ticket counter to the workgroups
@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kMxThreads = 1024;
 constexpr int kMxCols = 16;
-constexpr int kMxLdsRoots = 48, kMxLdsGrids = 352;   // (host: use_mx checks that the tree fits)
+constexpr int kMxLdsRoots = 48, kMxLdsGrids = 352;   // (host: use_mixed checks that the tree fits)
 constexpr uint32_t kTInf = 0xffffu, kTNone = 0xfffeu;
 constexpr uint32_t kMxTagShift = 57;
 constexpr unsigned long long kMxOver = 1ull << 56;
@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         }
         const unsigned long long f0 = __shfl(f, 0, 64), f1 = __shfl(f, 1, 64);
         have = have && !(f0 & kMxOver) && ((uint32_t)(f0 >> 51) & 3u) == kModeList;
-        const uint32_t l = (uint32_t)(f0 >> 40) & 63u, e0 = (uint32_t)f1 & 0xfffffffu;
+        const uint32_t l = (uint32_t)(f0 >> 40) & 63u, e0 = (uint32_t)f1;
         uint32_t lo = 0, hi = 0;
         if (have && l < nlevels && e0 <= sh_len[l]) {
           lo = e0;
@@ -1077,8 +1077,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                ++spins < (1u << 26))
           __builtin_amdgcn_s_sleep(1);
       }
-      // look back (lanes 0..5 take one word each)
-      if (lane < 6) {
+      // look back (lanes 0..6 take one word each)
+      if (lane < 7) {
         unsigned long long f = 0;
         if (i > 0) {
           uint32_t spins = 0;
@@ -1128,8 +1128,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         level = (uint32_t)(f0 >> 40) & 63u;
         depth = (int)((f0 >> 46) & 31u);
         mode = (uint32_t)(f0 >> 51) & 3u;
-        e = (uint32_t)f1 & 0xfffffffu;
-        rem = (uint32_t)(f1 >> 28) & 0xfffffffu;
+        e = (uint32_t)f1;
+        rem = (uint32_t)sh_in[6];
         base = sh_in[4] & ((1ull << kMxTagShift) - 1ull);
         iJ = (uint32_t)f5 & 3u;
         iPart = (uint32_t)(f5 >> 2) & 63u;
@@ -1279,7 +1279,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             f |= (sh_pos - phase0) | ((unsigned long long)sh_level << 40) | ((unsigned long long)dpt << 46) |
                  ((unsigned long long)sh_mode << 51);
           else if (lane == 1)
-            f |= (unsigned long long)sh_e | ((unsigned long long)sh_rem << 28);
+            f |= (unsigned long long)sh_e;
+          else if (lane == 6)
+            f |= (unsigned long long)sh_rem;
           else if (lane == 2)
             f |= fr0;
           else if (lane == 3)
@@ -1289,14 +1291,14 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           else if (lane == 5)
             f |= (unsigned long long)sh_iJ | ((unsigned long long)sh_iPart << 2) |
                  ((unsigned long long)sh_iCounter << 8) | ((unsigned long long)sh_iNeed << 10);
-          if (lane < 6)
+          if (lane < 7)
             __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, f, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           if (lane == 0) {
             sh_stop = 3;
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.mxHint),
                                tag | ((unsigned long long)sh_level << 48) | ((unsigned long long)(i & 0xfffffu) << 28) |
-                                   (unsigned long long)(sh_mode == kModeList ? sh_rem : 0u),
+                                   (unsigned long long)(sh_mode == kModeList ? min(sh_rem, 0xfffffffu) : 0u),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           MX_WAVE_SYNC();
@@ -1400,7 +1402,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             if (twoD)
               s.iPart = sh_iPart;
           }
-          if (lane < 6)
+          if (lane < 7)
             __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, tag | kMxOver, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           if (lane == 0) {

@@ -69,7 +69,7 @@ struct Grid {          // all nodes of one root at one depth, as a dense 3D arra
 // The CODE of a set (the bits its split takes, /root/reference/src/SPECK3D_INT.cpp:140-212) depends
 // on the set's extents only: every axis longer than one sample is cut into (len - len/2, len/2),
 // the children come x fastest, and so on down to single samples.  Sets with the same structure
-// share a SHAPE CLASS; the decoder of chunks whose lists mix shapes (k_lis_mixed) keys its
+// share a SHAPE CLASS; the decoder of chunks whose lists mix shapes (k_lis_mx) keys its
 // speculative tables by class instead of by list level.  Classes are numbered children first.
 constexpr uint8_t kClsPixel = 0xff;   // "class" of a single sample
 constexpr int kMaxCls = 254;

@@ -1013,7 +1013,7 @@ int model_speck3d_decode_par(const uint8_t* stream, size_t len, const size_t dim
 }
 
 // ------------------------------------------------------------------------------------------
-// Model of the LIS-phase decoder for chunks whose lists mix set shapes (kernel k_lis_mixed in
+// Model of the LIS-phase decoder for chunks whose lists mix set shapes (kernel k_lis_mx, and before it k_lis_mixed, in
 // speck_dec.hip).  The code of a set depends on its extents only (spk::ShapeCls): per window of W
 // stream bits the kernel builds, for every class that has a table slot and EVERY bit position, the
 // length of a split of that class starting there (speculative, parallel); ONE thread then walks

@@ -729,7 +729,7 @@ def test_tiny_chunks_pwe(eng, oracle, shape):
 def test_long_class_chains(eng, oracle, shape):
     """Chunks with an axis of 1024 samples: list levels whose class chain is 9 long (sets of 512 down
     to 2 along x), which the GPU-wide list kernel (k_lis_hi) takes (its predecessor k_lis_tables did not); an
-    axis of 4096 (chains of 11) goes to k_lis_mixed, whose tables are keyed by shape class.
+    axis of 4096 (chains of 11) goes to k_lis_mx, whose rows are keyed by shape class.
     Streams, truncated streams and whole containers against the oracle."""
     coef, sign = quantized(oracle, shape, 200000.0)
     stream = oracle.speck3d_encode(coef, sign, 0)
@@ -752,7 +752,7 @@ def test_long_class_chains(eng, oracle, shape):
                                               ((100, 100, 100), (100, 100, 100), 0.5),
                                               ((17, 300, 21), (17, 300, 21), 2.0)])
 def test_mixed_shape_chunks(eng, oracle, shape, chunks, bpp):
-    """Chunks whose lists mix set shapes (k_lis_mixed: shape-class tables and one walking wavefront,
+    """Chunks whose lists mix set shapes (k_lis_mx: shape-class rows and one walking wavefront per chunk,
     /root/reference/src/SPECK3D_INT.cpp:214-326 is the split rule behind the classes): odd lengths,
     lengths of the form 3 * 2^k, levels that hold leaf parents and larger sets side by side,
     wavelet-packet shapes; containers and decoded values identical to the oracle, also for a
@@ -783,7 +783,7 @@ def test_block_of_a_1000_cube_volume(eng, oracle):
     """A chunk of 232 x 256 x 256 cut from a 1000^3 field (what `chunk_volume` leaves at the border of
     such a volume in 256^3 chunks).  Regression: in one of its planes a list of sets that are walked
     into holds a run of more than 64 insignificant entries right after a window restart; the
-    walker's class window (k_lis_mixed) was taken for loaded there and one entry decoded as a leaf
+    walker's class window (k_lis_mixed then, k_lis_mx now) was taken for loaded there and one entry decoded as a leaf
     parent -- every later bit of the chunk was read out of place."""
     from sperr_amd.synth import turbulence_torch
     v = turbulence_torch((1000, 1000, 1000), "cuda", seed=7)[256:512, 256:512, 768:1000].contiguous()
@@ -821,7 +821,7 @@ def test_serial_walk_fallback_in_a_fresh_process(oracle):
 @pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}])
 def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
     """Who decodes which list is a matter of speed, never of bits (round 4; the knobs are read once per process):
-    `SPERR_HIP_LIS_HI=0` -- a regular tree through k_lis_mixed, where regular trees that k_lis_hi cannot take go
+    `SPERR_HIP_LIS_HI=0` -- a regular tree through k_lis_mx, where regular trees that k_lis_hi cannot take go
     since k_lis_tables was removed; `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 at all, k_lis_hi decodes every list.  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
     short, against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-212)."""
     import subprocess
@@ -844,12 +844,13 @@ def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0, knobs
 
 
-@pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_MX": "0"}, {"SPERR_HIP_MX_WGS": "1"}, {"SPERR_HIP_MX_WGS": "4096"}])
+@pytest.mark.parametrize("knobs", [{"SPERR_HIP_MX_WGS": "1"}, {"SPERR_HIP_MX_WGS": "3"}, {"SPERR_HIP_MX_WGS": "4096"}])
 def test_mixed_shape_decoders_in_a_fresh_process(oracle, knobs):
     """Chunks whose lists mix set shapes decode through k_lis_mx (round 4: fixed regions of the stream handed out to
     several workgroups per chunk, the walker's state passed from region to region); the knobs are read once per
-    process.  `SPERR_HIP_LIS_MX=0`: k_lis_mixed, one workgroup per chunk, as in rounds 2-3; `SPERR_HIP_MX_WGS=1`:
-    one workgroup per chunk takes every region itself; `=4096`: eight per chunk whatever else runs.  A volume of
+    process.  `SPERR_HIP_MX_WGS=1`: one workgroup per chunk takes every region itself (no hand-over between
+    workgroups at all); `=3`: fewer workgroups than chunks, at least two each; `=4096`: eight per chunk whatever else runs.
+    (`SPERR_HIP_LIS_MIXED=0`, the serial walk k_lis_walk, has a test of its own above.)  A volume of
     96 x 75 x 110 in chunks of 64 x 50 x 80 (eight chunks of eight shapes, LIS phases of many regions) at 5 bpp, cut
     short as well, and a slice of 300 x 211 -- against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-326,
     /root/reference/src/SPECK2D_INT.cpp:10-218)."""

@@ -146,7 +146,7 @@ MIXED_SHAPES = [(17, 17, 17), (13, 21, 30), (3, 5, 7), (1, 16, 16), (2, 2, 2), (
 @pytest.mark.parametrize("shape", MIXED_SHAPES)
 @pytest.mark.parametrize("window,hmax", [(64, 0), (150, 1), (4096, 1), (1200, 2), (300, -1)])
 def test_model_mixed_shape_decoder_matches_oracle(oracle, model, shape, window, hmax):
-    """Shape-class tables + one serial walk + parallel expansion (k_lis_mixed's formulation) on
+    """Shape-class tables + one serial walk + parallel expansion (the formulation of k_lis_mx and of its predecessor k_lis_mixed) on
     chunks whose lists mix set shapes: odd lengths, wavelet-packet shapes, tiny chunks; small
     windows stress the window boundaries, hmax = -1 walks into every set (no tables at all)."""
     for scale in (3000.0, 4294967295.0):

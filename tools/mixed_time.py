@@ -1,4 +1,4 @@
-"""Decode time of chunks whose lists mix set shapes (k_lis_mixed; SPERR_HIP_LIS_MIXED=0: the serial
+"""Decode time of chunks whose lists mix set shapes (k_lis_mx; SPERR_HIP_LIS_MIXED=0: the serial
 walk k_lis_walk):  python tools/mixed_time.py [edge ...]"""
 import os
 import sys
