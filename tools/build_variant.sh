@@ -10,7 +10,7 @@ here=$(cd $(dirname $0)/../sperr_amd/csrc && pwd)
 make -s -C $here
 mkdir -p $here/_build/var_$name
 objs=""
-for f in xform speck_enc speck_dec outlier speck2d engine farm; do
+for f in xform speck_enc speck_dec speck_mx outlier speck2d engine farm; do
   if echo " $srcs " | grep -q " $f.hip "; then
     hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-value $flags -c $here/$f.hip -o $here/_build/var_$name/$f.o
     objs="$objs $here/_build/var_$name/$f.o"
