@@ -435,7 +435,6 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     const uint32_t lOff = sh_lOff[level];
     const uint64_t* list = lisCur + lOff;
     const uint32_t ga = sh_lgrp[level] & 3u, gb = (sh_lgrp[level] >> 2) & 3u;
-    const uint32_t hopLim = 0xfdu;
     const uint32_t ringHi = __builtin_amdgcn_readfirstlane(sh_ringHi);
     uint32_t stE = 0, stM = 0;   // staged items of the list hops: lane = item
     // lane = stream word of the region
@@ -447,11 +446,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     uint32_t lrowA = 0, lrowB = 0;
     uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
     typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+    // four 16-bit split lengths as four bytes: length + 1, 255 for 254 bits and more (or none: kTNone, kTInf)
     auto pack8 = [&](uint64_t v) -> uint32_t {
-      const us2_t lim = {255, 255};
+      const us2_t lim = {254, 254};
       const us2_t lo = __builtin_elementwise_min(__builtin_bit_cast(us2_t, (uint32_t)v), lim);
       const us2_t hi = __builtin_elementwise_min(__builtin_bit_cast(us2_t, (uint32_t)(v >> 32)), lim);
-      return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+      return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u) + 0x01010101u;
     };
     auto load_lrow = [&](uint32_t kk) {
       const int32_t row = (int32_t)(kk * 64u + lane) - (int32_t)wq0 + 1;
@@ -549,25 +549,24 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "ds_read_b64 %[nxb], %[adb]\n\t"
                   "1:\n\t"
                   "s_lshr_b64 %[mm], %[m], %[oo]\n\t"
+                  "s_ff1_i32_b64 %[z], %[mm]\n\t"           // insignificant entries: one bit each
                   "s_cmp_eq_u64 %[mm], 0\n\t"
                   "s_cbranch_scc1 3f\n\t"
-                  "s_ff1_i32_b64 %[z], %[mm]\n\t"           // insignificant entries: one bit each
-                  "s_add_u32 %[oo], %[oo], %[z]\n\t"
                   "s_add_u32 %[idx], %[idx], %[z]\n\t"
+                  "s_add_u32 %[oo], %[oo], %[z]\n\t"
                   "v_readlane_b32 %[ec], %[ecb], %[idx]\n\t"
                   "v_readlane_b32 %[lo], %[rlo], %[oo]\n\t"
                   "v_readlane_b32 %[hi], %[rhi], %[oo]\n\t"
+                  "s_bitset1_b64 %[im], %[idx]\n\t"         // (taken back at 4: when the entry turns out to be unusual)
                   "s_bitcmp1_b32 %[ec], 8\n\t"
-                  "s_cselect_b32 %[lo], %[hi], %[lo]\n\t"
-                  "s_bfe_u32 %[t], %[lo], %[ec]\n\t"        // bits of the entry's split
-                  "s_add_u32 %[z], %[t], -1\n\t"
-                  "s_cmp_gt_u32 %[z], %[lim]\n\t"           // 0 (a class of neither group), 0xff (255 bits and more, or none) / kTNone, kTInf
-                  "s_cbranch_scc1 4f\n\t"
                   "s_bitset1_b64 %[cm], %[oo]\n\t"
-                  "s_bitset1_b64 %[im], %[idx]\n\t"
-                  "s_add_u32 %[oo], %[oo], %[t]\n\t"
-                  "s_add_u32 %[oo], %[oo], 1\n\t"
+                  "s_cselect_b32 %[lo], %[hi], %[lo]\n\t"
+                  "s_bfe_u32 %[t], %[lo], %[ec]\n\t"        // bits of the entry's split + 1
                   "s_add_u32 %[idx], %[idx], 1\n\t"
+                  "s_add_u32 %[z], %[t], -3\n\t"
+                  "s_add_u32 %[oo], %[oo], %[t]\n\t"
+                  "s_cmp_gt_u32 %[z], 251\n\t"              // 0 (a class of neither group), 255 (254 bits and more, or none)
+                  "s_cbranch_scc1 4f\n\t"
                   "s_cmp_lt_u32 %[oo], 64\n\t"
                   "s_cbranch_scc1 1b\n\t"
                   "s_mov_b32 %[st], 0\n\t"
@@ -578,13 +577,17 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "s_mov_b32 %[oo], 64\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 5f\n\t"
-                  "4:\n\t"
+                  "4:\n\t"                                   // an unusual entry: back to its bit
+                  "s_sub_u32 %[oo], %[oo], %[t]\n\t"
+                  "s_sub_u32 %[idx], %[idx], 1\n\t"
+                  "s_bitset0_b64 %[cm], %[oo]\n\t"
+                  "s_bitset0_b64 %[im], %[idx]\n\t"
                   "s_mov_b32 %[st], 1\n\t"
                   "5:\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
                   : [nxa] "=&v"(lrowNA), [nxb] "=&v"(lrowNB), [oo] "+s"(oo), [idx] "+s"(idx), [cm] "+s"(cm), [im] "+s"(im), [st] "=&s"(st), [mm] "=&s"(mm_),
                     [z] "=&s"(z_), [ec] "=&s"(ec_), [lo] "=&s"(lo_), [hi] "=&s"(hi_), [t] "=&s"(t_)
-                  : [m] "s"(m), [ecb] "v"(ecb), [rlo] "v"(lrowA), [rhi] "v"(lrowB), [ada] "v"(adNA), [adb] "v"(adNB), [lim] "s"(hopLim)
+                  : [m] "s"(m), [ecb] "v"(ecb), [rlo] "v"(lrowA), [rhi] "v"(lrowB), [ada] "v"(adNA), [adb] "v"(adNB)
                   : "scc", "memory");
             }
             e = eb + idx;
