@@ -3,22 +3,25 @@
 // The sorting pass of a plane (/root/reference/src/SPECK3D_INT.cpp:99-138: the lists from the smallest sets to
 // the largest, m_process_S / m_code_S :140-212, the split rule :214-326; 2D: /root/reference/src/SPECK2D_INT.cpp:
 // 10-218) is a serial parse: what a bit means depends on every earlier bit.  k_lis_mixed (rounds 2-3, removed at
-// the end of round 4) ran it with ONE workgroup per chunk that built speculative tables (rows of split lengths per stream position and
-// shape class), walked the list entries with one wavefront and expanded the sets that were hopped over -- all
+// the end of round 4) ran it with ONE workgroup per chunk that built speculative tables (rows of split lengths per
+// stream position and shape class), walked the list entries with one wavefront and expanded the sets that were hopped over -- all
 // three on the one workgroup's clock.  Here only the walk stays serial:
 //
 //   * the phase's stream is cut into fixed REGIONS of S bits, handed out by a ticket counter to the workgroups
 //     of a chunk (a region is handed out only after all earlier ones: a waiting workgroup always waits for a
 //     running one);
 //   * OFF the chain a workgroup loads its region (+ M bits of look-ahead) and builds the rows: sixteen columns
-//     per position -- a single sample, the leaf parents of 2 / 4 / 8 samples, and the four most frequent shape
-//     classes one, two and three steps above them (spk::build_mx_columns);
+//     per position -- a single sample, the leaf parents of 2 / 4 / 8 samples, and the twelve shape classes up to
+//     three steps above them whose columns save the most (spk::build_mx_columns) -- of which a region builds
+//     only those its lists can need (a hint the chain leaves behind);
 //   * ON the chain its first wavefront takes the predecessor's state -- stream position, list level, entry
 //     index, entries left, the stack of sets being walked into (child ordinal + "found" bit per frame, the
 //     entry at the bottom), the 2D coder's type-I state -- from tagged words written and read with relaxed
 //     agent-scope atomics (no fence: k_lis_hi's protocol), walks its region (a significant entry with a column
-//     is a few register look-ups, any other set is walked into child by child; a set whose split leaves the
-//     rows is walked into as well, so the walk always reaches the region's end) and publishes the state there;
+//     is 21 hand-written scalar instructions -- lane = stream bit: eight split lengths of the list's two column
+//     groups, lane = entry: which of them is its class's --, any other set is walked into child by child; a set
+//     whose split leaves the rows is walked into as well, so the walk always reaches the region's end) and
+//     publishes the state there; the classes of the entries it will visit are loaded while it waits for its turn;
 //   * OFF the chain again it expands the sets it hopped over, breadth first with all threads: leaf parents
 //     become leaf events (k_leaf_apply), insignificant child sets are recorded with their stream position
 //     (k_place_scan / _scatter rank them), births and events go to segments that are the workgroup's alone.
