@@ -2384,8 +2384,16 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         nmx += h.second.size();
     }
     static const uint32_t mxBudget = getenv("SPERR_HIP_MX_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_WGS")) : 208u;
+    // (calls that share the device -- the chunk farm's workers, several host threads -- share the budget: each of these
+    //  workgroups has a CU to itself for as long as its chunk's phase lasts)
+    size_t sharers = 1;
+    {
+      int devNow = 0;
+      if (hipGetDevice(&devNow) == hipSuccess)
+        sharers = std::max<size_t>(1, g_pool.busy_on(devNow));
+    }
     if (nmx)
-      mxGroupsCall = std::min<uint32_t>(8u, std::max<uint32_t>(2u, (uint32_t)(mxBudget / nmx)));
+      mxGroupsCall = std::min<uint32_t>(8u, std::max<uint32_t>(2u, (uint32_t)(mxBudget / (nmx * sharers))));
   }
   // a slice is decoded by the kernels of the 3D decoder on the 2D coder's forest (k_lis_mx and its
   // type-I phase); SPERR_HIP_SLICE_MIXED=0: by k_speck2d_decode, one workgroup walking the quadtree
