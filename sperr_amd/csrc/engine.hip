@@ -2638,6 +2638,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
         ph.mxGroups = mxGroupsCall;
+        {
+          static const uint32_t gdivEnv = getenv("SPERR_HIP_MX_GRID_DIV") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_GRID_DIV")) : 4u;
+          ph.gridDiv = (deferStream && mxGroupsCall != 0 && groups.size() >= 4) ? std::max<uint32_t>(1u, gdivEnv) : 1u;
+        }
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
         static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
         ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;

@@ -151,6 +151,8 @@ struct DecPlanHost {
   int maxK;                    // longest class chain (sizes the LDS tables)
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
   bool mixed = false;          // lists that mix set shapes: k_lis_mx (shape-class rows, several workgroups per chunk) instead of k_lis_walk
+  uint32_t gridDiv = 1;        // the per-plane kernels' grid caps divided by this: a batch that decodes beside other shape groups
+                               //   whose k_lis_mx workgroups hold most CUs (1000^3 in 256^3 chunks: 150 -> 146 ms with 4)
   uint32_t mxGroups = 0;       // workgroups per chunk of k_lis_mx (0: the launcher's own choice by the batch's size) --
                                //   the caller knows how many such chunks of OTHER shapes decode beside this batch
   bool skipFinish = false;     // the caller's inverse quantiser completes the coefficients

@@ -3231,7 +3231,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   LAUNCH_K(k_dec_load_words, dim3(wordBlocks, nc), dim3(kThreads), 0, stream, b,
                      container);
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
-  const uint32_t tokGrid = capped_blocks(tokBlocks, nc), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide);
+  // (plan.gridDiv: the batch decodes beside others that hold most of the device -- grids that fill a quarter of it)
+  const uint32_t gdiv = std::max<uint32_t>(1u, plan.gridDiv);
+  const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide / gdiv);
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
   static const uint32_t l01Cap = getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
@@ -3244,7 +3246,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
   static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
   const uint32_t l1Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l1Total / nc));
-  const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc);
+  const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc, kGridCap / gdiv);
   // workgroups per chunk of the k_lis_hi pass, at most what the queues were sized for
   // (SPERR_HIP_HI_WGS: the total over the batch's chunks; measured on MI355X with two sub-batches
   // of 32 chunks side by side: 96 / 128 / 160 / 192 / 224 / 256 / 384 workgroups per sub-batch give
@@ -3304,7 +3306,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_place_scan, dim3(b.nSlots, nc), dim3(kTabThreads), 0, stream, b, p);
         LAUNCH_K(k_place_scatter, dim3(placeGrid, nc), dim3(kThreads), 0, stream, b, p);
       }
-      LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc), nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc, kGridCap / gdiv), nc), dim3(kThreads), 0, stream, b, p);
     }
     LAUNCH_CT(k_ref_apply2, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     return 0;
