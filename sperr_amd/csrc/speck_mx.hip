@@ -424,6 +424,39 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       put(i, list[i]);
   };
 
+  // Bits of the split of a set of class ci that starts at x, worked out ON the chain from its children's columns
+  // (first wavefront, uniform): for a set without a column of its own -- or whose column this region did not build --
+  // all of whose significant children have one.  Such a set is then hopped over like any other, and its records are
+  // the expansion's (which only ever needs the CHILDREN's columns), instead of being walked into: a round in there
+  // costs four times this.  kTNone / kTInf: no luck.
+  auto chain_len = [&](uint32_t ci, uint32_t x) -> uint32_t {
+    if (ci >= b.tree.ncls || ci >= (uint32_t)kMaxCls)
+      return kTNone;
+    const uint32_t nk = sh_cls[ci].nk;
+    const uint64_t kc = sh_kcol[ci];
+    uint32_t y = x, found = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+      const uint32_t col = (uint32_t)(kc >> (8 * k)) & 0xffu;
+      const uint32_t coded = found | (uint32_t)(k + 1 != nk);
+      if (y > W)
+        return kTInf;
+      const uint32_t bit = coded ? bit_at(y) : 1u;
+      const uint32_t s0 = y + coded;
+      if (!bit) {
+        y += 1;
+        continue;
+      }
+      if (col >= (uint32_t)kMxCols)
+        return kTNone;
+      const uint32_t t = Tr[(size_t)min(s0, W + 2) * kMxCols + col];
+      if (t >= kTNone)
+        return t;
+      y = s0 + t;
+      found = 1;
+    }
+    return y > W ? kTInf : y - x;
+  };
+
   // ---- the walk through the region (first wavefront, every lane carrying the same walker state): from
   //      sh_pos on until an item starts at or past S, or the list ends (depth 0)
   uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
@@ -664,6 +697,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
           if (col < (uint32_t)kMxCols)
             tl = Tr[(size_t)(r + 1u) * kMxCols + col];
+          if (tl == kTNone)
+            tl = chain_len(ci, r + 1u);
         }
         if (tl < kTNone) {
           if (lane == ns) {
@@ -750,7 +785,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           k++;
           continue;
         }
-        const uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)start * kMxCols + col] : kTNone;
+        uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)start * kMxCols + col] : kTNone;
+        if (tl == kTNone)
+          tl = chain_len(pc < b.tree.ncls ? (uint32_t)sh_cls[pc].kid[k] : 0xffu, start);
         found = 1;
         if (tl < kTNone) {
           if (lane == k) {
@@ -1366,7 +1403,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           const Node rn = unpack_node(root);
           const uint32_t ci = node_cls_l(rn);
           const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
-          const uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)(r + 1u) * kMxCols + col] : kTNone;
+          uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)(r + 1u) * kMxCols + col] : kTNone;
+          if (tl == kTNone)
+            tl = chain_len(ci, r + 1u);
           if (tl < kTNone) {
             if (lane == 0) {
               const uint32_t qn = sh_qn[0];
