@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     const uint64_t sw0 = lane < kWords ? wbits[lane] : 0ull;
     uint32_t curK = 0xffffffffu;   // stream word the registers below belong to
     uint64_t m = 0;                // that word (uniform)
-    // lane = bit of it: the split lengths of the list's two column groups one position on, eight bits each
-    // (0xff: 255 bits and more, or none -- the general code looks at the row itself)
+    // lane = bit of it: the split lengths (+ 1) of the list's two column groups one position on, eight bits each
+    // (255: 254 bits and more, or none -- the general code looks at the row itself)
     uint32_t lrowA = 0, lrowB = 0;
     uint32_t lrowK = 0xffffffffu;  //   (loaded for this word)
     typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       nloc = 0;
     };
     const uint32_t kkLast = ((S + wq0) >> 6) - 1u;   // last stream word that lies inside the region
-    // LDS address of lane's row entries (the list's column group) for word 0: + word << 11
+    // LDS address of lane's row entries for word 0 (+ word << 11: 64 rows of 32 bytes), then of the list's two column groups
     const uint32_t adBase = (uint32_t)(size_t)Tr + (uint32_t)((int32_t)(lane + 1u) - (int32_t)wq0) * (uint32_t)(kMxCols * 2);
     const uint32_t adBaseA = adBase + ga * 8u, adBaseB = adBase + gb * 8u;
     auto rl32 = [&](uint32_t v, uint32_t idx) -> uint32_t {
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         // loop, word after word -- no end-of-list or end-of-region checks per entry; anything unusual (a set to
         // walk into) is left to the general code below.  The loop only HOPS: per significant entry one bit in
         // each of two masks of a per-word record (its position in the word, its ordinal among the entries from
-        // `eb` on); the work items are made from the records off the chain (convert_records).
+        // `eb` on); the work items are made from the records off the chain (the first step of expand_all).
         if (rem >= 64u && k <= kkLast && nrec + nloc + 2u < (uint32_t)kMxRecs) {
           const uint32_t eEnd = e + rem, eStop = eEnd - 64u;
           uint32_t kk = k, oo = o;   // the word and the bit of it the walk is at
