@@ -1104,8 +1104,10 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     }
     // (four wavefronts put the classes into the ring: one alone takes longer than the region before this one walks)
     if (wave < (uint32_t)kMxPreWaves) {
-      uint32_t go = 0, spins = 0;
-      while ((go = __hip_atomic_load(&sh_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++spins < (1u << 26))
+      // (no bound on this wait: the first wavefront gets to its store whatever happens -- its own waits above are bounded --
+      //  and a helper that gave up early would leave a ring that is announced as filled and is not)
+      uint32_t go = 0;
+      while ((go = __hip_atomic_load(&sh_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0)
         __builtin_amdgcn_s_sleep(2);
       if (go == 2)
         fill_ring(sh_preLevel, sh_preLo, sh_preHi, (uint32_t)tid, (uint32_t)kMxPreWaves * 64u);
