@@ -461,6 +461,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   //      sh_pos on until an item starts at or past S, or the list ends (depth 0)
   uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
   uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
+  uint32_t wk_gSat = 0, wk_gView = 0, wk_gInf = 0, wk_gChain = 0;
   auto walk = [&]() {
     const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
     uint32_t r = __builtin_amdgcn_readfirstlane((uint32_t)(sh_pos - a)), e = __builtin_amdgcn_readfirstlane(sh_e),
@@ -697,8 +698,20 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
           if (col < (uint32_t)kMxCols)
             tl = Tr[(size_t)(r + 1u) * kMxCols + col];
-          if (tl == kTNone)
+          if (kStamps) {   // why the tight loop left this entry to the general code
+            const uint32_t loc = ec >> 8;
+            if (loc < 8u && tl < kTNone)
+              wk_gSat++;       // in the view, 254 bits and more (or a list of fewer than 64 entries)
+            else if (tl < kTNone)
+              wk_gView++;      // a column outside the list's two groups
+            else if (col < (uint32_t)kMxCols && tl == kTInf)
+              wk_gInf++;       // leaves the rows
+          }
+          if (tl == kTNone) {
             tl = chain_len(ci, r + 1u);
+            if (kStamps && tl < kTNone)
+              wk_gChain++;     // no column: length from the children's
+          }
         }
         if (tl < kTNone) {
           if (lane == ns) {
@@ -1494,6 +1507,11 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       atomicAdd(out + 13, (unsigned long long)wk_into);
       atomicAdd(out + 14, (unsigned long long)wk_words);
       atomicAdd(out + 15, (unsigned long long)wk_zruns);
+      atomicAdd(out + 16, (unsigned long long)wk_gSat);
+      atomicAdd(out + 17, (unsigned long long)wk_gView);
+      atomicAdd(out + 18, (unsigned long long)wk_gInf);
+      atomicAdd(out + 19, (unsigned long long)wk_gChain);
+      wk_gSat = wk_gView = wk_gInf = wk_gChain = 0;
       wk_fill = wk_total = wk_tight = wk_into = 0;
       wk_fills = wk_calls = wk_hopsT = wk_hopsG = wk_rounds = wk_words = wk_zruns = 0;
     }

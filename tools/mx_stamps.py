@@ -36,3 +36,5 @@ for k in range(5, 24):
 print("chain parts (ticks): ring fills %d (%d fills), walk %d (%d calls): tight loop %d (%d hops, %d words), "
       "general-path hops %d, zero runs %d, rounds inside entered sets %d (%d ticks)" %
       (out[5], out[6], out[7], out[8], out[9], out[10], out[14], out[11], out[15], out[12], out[13]))
+print("general-path entries by reason: length of 254 bits and more %d, column outside the list's two groups %d, split leaves the rows %d, "
+      "no column but a length from the children's %d" % (out[16], out[17], out[18], out[19]))
