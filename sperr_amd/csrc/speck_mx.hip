@@ -514,7 +514,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       nrec += nloc;
       nloc = 0;
     };
-    const uint32_t kkLast = ((S + wq0) >> 6) - 1u;   // last stream word that lies inside the region
+    // last stream word the tight loop takes: the one the region's last bit lies in, ALL of it -- the walk may leave a
+    // region up to 63 bits late (a long split does that anyway; rows 1 .. S + 128 exist, entry classes to e + S + 128)
+    const uint32_t kkLast = (S + wq0 - 1u) >> 6;
     // LDS address of lane's row entries for word 0 (+ word << 11: 64 rows of 32 bytes), then of the list's two column groups
     const uint32_t adBase = (uint32_t)(size_t)Tr + (uint32_t)((int32_t)(lane + 1u) - (int32_t)wq0) * (uint32_t)(kMxCols * 2);
     const uint32_t adBaseA = adBase + ga * 8u, adBaseB = adBase + gb * 8u;
@@ -1259,7 +1261,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         sh_stop = stop;
         // (the classes of the list's entries from e on: in the ring already when the guess above held)
         const bool pre = mode == kModeList && level == sh_preLevel && e >= sh_preLo &&
-                         min(sh_len[level], e + S + 64u) <= sh_preHi;
+                         min(sh_len[level], e + S + 128u) <= sh_preHi;
         sh_needFill = (stop == 0 && mode == kModeList && !pre) ? 1u : 0u;
         if (pre)
           sh_ringHi = sh_preHi;
@@ -1275,7 +1277,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         if (kStamps)
           wk_fills++;
         const uint32_t l = sh_level, e0 = sh_e, n = sh_len[l];
-        const uint32_t to = min(n, e0 + S + 64u);
+        const uint32_t to = min(n, e0 + S + 128u);
         fill_ring(l, min(e0, to), to, (uint32_t)tid, kMxThreads);
         __syncthreads();
         if (tid == 0) {
