@@ -410,7 +410,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       const uint32_t ci = node_cls_l(unpack_node(ent));
       const uint32_t col = sh_slot[ci];
       const uint32_t loc = col >= (uint32_t)kMxCols ? 0xffu : (col >> 2) == ga ? (col & 3u) : (col >> 2) == gb ? 4u + (col & 3u) : 0xffu;
-      ecls[i & (uint32_t)(kMxRing - 1)] = (uint16_t)(ci | (loc << 8));
+      // (high byte: the bit offset of the class's byte in the list's pair of row words, 0x80: in neither group)
+      ecls[i & (uint32_t)(kMxRing - 1)] = (uint16_t)(ci | ((loc < 8u ? loc << 3 : 0x80u) << 8));
     };
     uint32_t i = from + t0;
     for (; i + 3u * nt < to; i += 4u * nt) {   // (four loads in flight per thread)
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   //      sh_pos on until an item starts at or past S, or the list ends (depth 0)
   uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
   uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
-  uint32_t wk_gSat = 0, wk_gView = 0, wk_gInf = 0, wk_gChain = 0;
+  uint32_t wk_gSat = 0, wk_gView = 0, wk_gInf = 0, wk_gChain = 0, wk_enters = 0, wk_reloads = 0;
   auto walk = [&]() {
     const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
     uint32_t r = __builtin_amdgcn_readfirstlane((uint32_t)(sh_pos - a)), e = __builtin_amdgcn_readfirstlane(sh_e),
@@ -560,120 +561,192 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           const uint64_t tt0 = kStamps ? __builtin_readcyclecounter() : 0;
           if (lrowK != kk)
             load_lrow(kk);
+          // The whole loop over the words is one asm statement: what a lone wavefront pays for is the length of its
+          // dependency chains and where its loop lies in memory (tools/micro/hop_loop.cpp, hop_align.cpp: the loop head
+          // at a 128-byte boundary and the hop below, four copies in a row, is 160 cycles per significant entry
+          // where the loop of 21 instructions placed by chance was 197 to 239).  Per hop: the zeros up to the next
+          // significant entry (s_lshr_b64, s_ff1), its class word (lane = ordinal mod 64) and the two row words of its
+          // position (lane = position), s_bfe_u64 cuts the split's length + 1 out of the pair, and the position --
+          // kept as position - 64 -- carries out of the add when the word is through.  A length of 255 ("look it up")
+          // ends a word the same way and is found there, once per word; a class with no byte in the pair has bit 7
+          // of its class word set.
+          // The entry classes are a window of 64 ordinals that rolls along: at the end of a word every lane fetches
+          // the class of the one ordinal of [idx, idx + 64) that is congruent to it (a word of 64 bits uses up some
+          // fifty ordinals: reloading the window from outside the statement was every other word's exit); the load
+          // is in flight while the word's record and the next word's rows are put together.
+          // The statement comes back for what is rare: an unusual entry (st 1), a split that skipped a word (st 3:
+          // the row registers want a load), and (st 0) the record registers full, the region's last word, the ring's
+          // or the list's last entries.  Every word visited leaves one record in lane nloc of rcL .. riH and rE (an
+          // empty one if nothing was significant); their words are filled in below.
+          // m: vcc; position mask: s[92:93]; ordinal mask: s[94:95]; row words: s[96:97]; length: s98; next rows:
+          // v[120:123]; ring address and class: v124, v125.
+#define MX_HOP                                                                                     \
+  "s_lshr_b64 %[mm], vcc, %[oo]\n\t"                                                               \
+  "s_ff1_i32_b64 %[st], %[mm]\n\t"          /* insignificant entries: one bit each */              \
+  "s_cmp_eq_u64 %[mm], 0\n\t"                                                                      \
+  "s_cbranch_scc1 3f\n\t"                                                                          \
+  "s_add_u32 %[idx], %[idx], %[st]\n\t"                                                            \
+  "s_add_u32 %[oo], %[oo], %[st]\n\t"                                                              \
+  "v_readlane_b32 %[ec], %[ecb], %[idx]\n\t"                                                       \
+  "v_readlane_b32 s96, %[rlo], %[oo]\n\t"                                                          \
+  "v_readlane_b32 s97, %[rhi], %[oo]\n\t"                                                          \
+  "s_bitset1_b64 s[94:95], %[idx]\n\t"                                                             \
+  "s_bitset1_b64 s[92:93], %[oo]\n\t"                                                              \
+  "s_add_u32 %[idx], %[idx], 1\n\t"                                                                \
+  "s_bitcmp1_b32 %[ec], 7\n\t"                                                                     \
+  "s_cbranch_scc1 9f\n\t"                                                                          \
+  "s_bfe_u64 s[98:99], s[96:97], %[ec]\n\t" /* bits of the entry's split + 1 */                    \
+  "s_add_u32 %[oo], %[oo], s98\n\t"
+          static_assert(kMxRing == 8192, "the ring's index mask is a literal of the statement below");
           while (true) {
-            if (kStamps)
-              wk_words++;
-            m = rl64(sw0, kk);
-            // the next word's row entries are fetched while this word is walked (inside the asm block below: the
-            // compiler waits for every LDS load in flight before an asm statement).  Rows 1 .. S + 128 exist.
-            uint64_t lrowNA, lrowNB;
-            const uint32_t adNA = adBaseA + ((kk + 1u) << 11), adNB = adBaseB + ((kk + 1u) << 11);
-            // (at most 64 entries start inside a word: one load of entry classes covers it)
-            if (e - eb > oo) {   // (the entries of this word: fewer than 64 - oo from e on)
-              eb = e;
-              ecv = e + lane < ringHi ? (uint32_t)ecls[(e + lane) & (uint32_t)(kMxRing - 1)] : 0xffffu;
-              // what the loop wants of an entry: the s_bfe_u32 operand that cuts its class's split length out of
-              // one of the two group registers (offset 0 / 8 / 16 / 24, width 8; bit 8: the second group) -- width 0
-              // for a class of neither group: length 0, "unusual"
-              const uint32_t loc = ecv >> 8;
-              ecb = loc >= 8u ? 0u : (((loc & 3u) << 3) | (8u << 16) | ((loc >> 2) << 8));
+            uint32_t idx = e, st;   // (ordinals: as they are; lanes and mask bits take them mod 64)
+            const uint32_t nloc0 = nloc, kk0 = kk;
+            const uint32_t nlocLim = min(64u, (uint32_t)kMxRecs - 2u - nrec);
+            // a word at position p with entry ordinal idx may touch the ordinals up to idx + 63 - p: all of them on the
+            // list and in the ring (compared with idx - p + 64)
+            const uint32_t limAbs = min(eEnd, ringHi);
+            {   // the window: lane = ordinal mod 64
+              const uint32_t eo = e + ((lane - e) & 63u);
+              ecb = ((uint32_t)ecls[eo & (uint32_t)(kMxRing - 1)] >> 8) | (8u << 16);
             }
-            uint32_t idx = e - eb, st;
-            uint64_t cm = 0, im = 0;
+            if (kStamps)
+              wk_enters++;
+            // (rows 1 .. S + 128 exist: the next word's are fetched while a word is walked)
+            uint32_t adNA = adBaseA + ((kk + 1u) << 11), adNB = adBaseB + ((kk + 1u) << 11);
             {
-              uint32_t t_, z_, ec_, lo_, hi_;
+              uint32_t ec_;
               uint64_t mm_;
               asm volatile(
-                  "ds_read_b64 %[nxa], %[ada]\n\t"
-                  "ds_read_b64 %[nxb], %[adb]\n\t"
-                  "1:\n\t"
-                  "s_lshr_b64 %[mm], %[m], %[oo]\n\t"
-                  "s_ff1_i32_b64 %[z], %[mm]\n\t"           // insignificant entries: one bit each
-                  "s_cmp_eq_u64 %[mm], 0\n\t"
-                  "s_cbranch_scc1 3f\n\t"
-                  "s_add_u32 %[idx], %[idx], %[z]\n\t"
-                  "s_add_u32 %[oo], %[oo], %[z]\n\t"
-                  "v_readlane_b32 %[ec], %[ecb], %[idx]\n\t"
-                  "v_readlane_b32 %[lo], %[rlo], %[oo]\n\t"
-                  "v_readlane_b32 %[hi], %[rhi], %[oo]\n\t"
-                  "s_bitset1_b64 %[im], %[idx]\n\t"         // (taken back at 4: when the entry turns out to be unusual)
-                  "s_bitcmp1_b32 %[ec], 8\n\t"
-                  "s_bitset1_b64 %[cm], %[oo]\n\t"
-                  "s_cselect_b32 %[lo], %[hi], %[lo]\n\t"
-                  "s_bfe_u32 %[t], %[lo], %[ec]\n\t"        // bits of the entry's split + 1
-                  "s_add_u32 %[idx], %[idx], 1\n\t"
-                  "s_add_u32 %[z], %[t], -3\n\t"
-                  "s_add_u32 %[oo], %[oo], %[t]\n\t"
-                  "s_cmp_gt_u32 %[z], 251\n\t"              // 0 (a class of neither group), 255 (254 bits and more, or none)
+                  "s_sub_u32 %[oo], %[oo], 64\n\t"
+                  "s_branch 0f\n\t"
+                  ".p2align 7\n\t"
+                  "1:\n\t"                                   // ---- the hops of a word
+                  MX_HOP "s_cbranch_scc1 2f\n\t"
+                  MX_HOP "s_cbranch_scc1 2f\n\t"
+                  MX_HOP "s_cbranch_scc1 2f\n\t"
+                  MX_HOP "s_cbranch_scc0 1b\n\t"
+                  "2:\n\t"                                   // ---- the word is through (a split went past its end)
+                  "s_cmp_eq_u32 s98, 255\n\t"
                   "s_cbranch_scc1 4f\n\t"
-                  "s_cmp_lt_u32 %[oo], 64\n\t"
-                  "s_cbranch_scc1 1b\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 5f\n\t"
-                  "3:\n\t"                                   // the rest of the word is zeros
-                  "s_sub_u32 %[z], 64, %[oo]\n\t"
-                  "s_add_u32 %[idx], %[idx], %[z]\n\t"
-                  "s_mov_b32 %[oo], 64\n\t"
-                  "s_mov_b32 %[st], 0\n\t"
-                  "s_branch 5f\n\t"
-                  "4:\n\t"                                   // an unusual entry: back to its bit
-                  "s_sub_u32 %[oo], %[oo], %[t]\n\t"
-                  "s_sub_u32 %[idx], %[idx], 1\n\t"
-                  "s_bitset0_b64 %[cm], %[oo]\n\t"
-                  "s_bitset0_b64 %[im], %[idx]\n\t"
-                  "s_mov_b32 %[st], 1\n\t"
-                  "5:\n\t"
+                  "8:\n\t"                                   // the classes of the next 64 ordinals, the word's record, the next word's rows
+                  "v_subrev_u32 v124, %[idx], %[lane]\n\t"
+                  "s_lshr_b32 %[st], %[oo], 6\n\t"           // (words skipped)
+                  "v_and_b32 v124, 63, v124\n\t"
+                  "s_or_b32 %[oo], %[oo], 0xffffffc0\n\t"
+                  "v_add_u32 v124, %[idx], v124\n\t"
+                  "s_add_u32 %[kk], %[kk], %[st]\n\t"
+                  "v_and_b32 v124, 0x1fff, v124\n\t"
+                  "s_add_u32 %[kk], %[kk], 1\n\t"
+                  "v_lshl_add_u32 v124, v124, 1, %[ring]\n\t"
+                  "v_writelane_b32 %[rcl], s92, m0\n\t"
+                  "ds_read_u16 v125, v124\n\t"
+                  "v_writelane_b32 %[rch], s93, m0\n\t"
+                  "v_writelane_b32 %[ril], s94, m0\n\t"
+                  "v_writelane_b32 %[rih], s95, m0\n\t"
+                  "s_add_u32 %[nloc], %[nloc], 1\n\t"
+                  "s_waitcnt lgkmcnt(1)\n\t"
+                  "s_cmp_lg_u32 %[st], 0\n\t"
+                  "s_cbranch_scc1 6f\n\t"                    // (a long split skipped a word)
+                  "v_pk_min_u16 v120, v120, %[lim]\n\t"      // four 16-bit lengths -> four bytes: length + 1, 255 = look it up
+                  "v_pk_min_u16 v121, v121, %[lim]\n\t"
+                  "v_pk_min_u16 v122, v122, %[lim]\n\t"
+                  "v_pk_min_u16 v123, v123, %[lim]\n\t"
+                  "v_perm_b32 v120, v121, v120, %[sel]\n\t"
+                  "v_perm_b32 v122, v123, v122, %[sel]\n\t"
+                  "v_add_u32 %[rlo], 0x1010101, v120\n\t"
+                  "v_add_u32 %[rhi], 0x1010101, v122\n\t"
+                  "s_cmp_gt_u32 %[kk], %[kl]\n\t"            // the region's last word,
+                  "s_cbranch_scc1 5f\n\t"
+                  "s_cmp_ge_u32 %[nloc], %[nl]\n\t"          // the record registers full,
+                  "s_cbranch_scc1 5f\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
-                  : [nxa] "=&v"(lrowNA), [nxb] "=&v"(lrowNB), [oo] "+s"(oo), [idx] "+s"(idx), [cm] "+s"(cm), [im] "+s"(im), [st] "=&s"(st), [mm] "=&s"(mm_),
-                    [z] "=&s"(z_), [ec] "=&s"(ec_), [lo] "=&s"(lo_), [hi] "=&s"(hi_), [t] "=&s"(t_)
-                  : [m] "s"(m), [ecb] "v"(ecb), [rlo] "v"(lrowA), [rhi] "v"(lrowB), [ada] "v"(adNA), [adb] "v"(adNB)
-                  : "scc", "memory");
+                  "v_lshrrev_b32 v125, 8, v125\n\t"
+                  "v_or_b32 %[ecb], 0x80000, v125\n\t"
+                  "0:\n\t"                                   // ---- a word
+                  "s_sub_u32 %[st], %[idx], %[oo]\n\t"
+                  "v_readlane_b32 vcc_lo, %[swl], %[kk]\n\t"
+                  "v_readlane_b32 vcc_hi, %[swh], %[kk]\n\t"
+                  "s_cmp_gt_u32 %[st], %[la]\n\t"            // the ring's or the list's last entries
+                  "s_cbranch_scc1 5f\n\t"
+                  "s_mov_b32 m0, %[nloc]\n\t"
+                  "ds_read_b64 v[120:121], %[ada]\n\t"
+                  "ds_read_b64 v[122:123], %[adb]\n\t"
+                  "s_mov_b64 s[92:93], 0\n\t"
+                  "s_mov_b64 s[94:95], 0\n\t"
+                  "v_writelane_b32 %[re], %[idx], m0\n\t"    // (the ordinal the word starts with)
+                  "v_add_u32 %[ada], 0x800, %[ada]\n\t"
+                  "v_add_u32 %[adb], 0x800, %[adb]\n\t"
+                  "s_branch 1b\n\t"
+                  "3:\n\t"                                   // the rest of the word is zeros
+                  "s_sub_u32 %[st], 0, %[oo]\n\t"
+                  "s_add_u32 %[idx], %[idx], %[st]\n\t"
+                  "s_mov_b32 %[oo], 0\n\t"
+                  "s_branch 8b\n\t"
+                  "4:\n\t"                                   // the last hop's length was 255: back to its bit
+                  "s_sub_u32 %[oo], %[oo], 255\n\t"
+                  "9:\n\t"                                   // an unusual entry: the word's record so far
+                  "s_sub_u32 %[idx], %[idx], 1\n\t"
+                  "s_bitset0_b64 s[92:93], %[oo]\n\t"
+                  "s_bitset0_b64 s[94:95], %[idx]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "v_writelane_b32 %[rcl], s92, m0\n\t"
+                  "v_writelane_b32 %[rch], s93, m0\n\t"
+                  "v_writelane_b32 %[ril], s94, m0\n\t"
+                  "v_writelane_b32 %[rih], s95, m0\n\t"
+                  "s_add_u32 %[nloc], %[nloc], 1\n\t"
+                  "s_branch 10f\n\t"
+                  "5:\n\t"
+                  "s_mov_b32 %[st], 0\n\t"
+                  "s_branch 10f\n\t"
+                  "6:\n\t"
+                  "s_mov_b32 %[st], 3\n\t"
+                  "10:\n\t"
+                  "s_waitcnt lgkmcnt(0)\n\t"
+                  "s_add_u32 %[oo], %[oo], 64\n\t"
+                  : [kk] "+s"(kk), [oo] "+s"(oo), [idx] "+s"(idx), [nloc] "+s"(nloc), [rcl] "+v"(rcL), [rch] "+v"(rcH), [ril] "+v"(riL),
+                    [rih] "+v"(riH), [re] "+v"(rE), [rlo] "+v"(lrowA), [rhi] "+v"(lrowB), [ada] "+v"(adNA), [adb] "+v"(adNB), [ecb] "+v"(ecb),
+                    [st] "=&s"(st), [mm] "=&s"(mm_), [ec] "=&s"(ec_)
+                  : [kl] "s"(kkLast), [la] "s"(limAbs), [nl] "s"(nlocLim), [lim] "s"(0x00fe00feu), [sel] "s"(0x06040200u),
+                    [ring] "s"((uint32_t)(size_t)ecls), [swl] "v"((uint32_t)sw0), [swh] "v"((uint32_t)(sw0 >> 32)), [lane] "v"(lane)
+                  : "scc", "vcc", "m0", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123",
+                    "v124", "v125");
             }
-            e = eb + idx;
-            if (cm) {   // lane nloc of the record registers takes the word's record
-              asm volatile("s_mov_b32 m0, %[n]\n\t"
-                           "v_writelane_b32 %[a], %[cl], m0\n\t"
-                           "v_writelane_b32 %[b], %[ch], m0\n\t"
-                           "v_writelane_b32 %[c], %[il], m0\n\t"
-                           "v_writelane_b32 %[d], %[ih], m0\n\t"
-                           "v_writelane_b32 %[f], %[eb], m0\n\t"
-                           "v_writelane_b32 %[g], %[kk], m0\n\t"
-                           : [a] "+v"(rcL), [b] "+v"(rcH), [c] "+v"(riL), [d] "+v"(riH), [f] "+v"(rE), [g] "+v"(rK)
-                           : [n] "s"(nloc), [cl] "s"((uint32_t)cm), [ch] "s"((uint32_t)(cm >> 32)), [il] "s"((uint32_t)im),
-                             [ih] "s"((uint32_t)(im >> 32)), [eb] "s"(lOff + eb), [kk] "s"(kk)
-                           : "m0");
-              nloc++;
-              if (kStamps)
-                wk_hopsT += (uint32_t)__popcll(cm);
-              if (nloc == 64u)
-                rec_flush();
+            if (lane >= nloc0 && lane < nloc) {   // the records just written: stream word | first ordinal mod 64, first entry
+              rK = (kk0 + (lane - nloc0)) | ((rE & 63u) << 8);
+              rE += lOff;
             }
-            if (st) {
+            e = idx;
+            if (kStamps) {
+              wk_words += nloc - nloc0;
+              for (uint32_t j = nloc0; j < nloc; j++)
+                wk_hopsT += (uint32_t)__popc(rl32(rcL, j)) + (uint32_t)__popc(rl32(rcH, j));
+            }
+            if (nloc == 64u)
+              rec_flush();
+            if (st == 1u) {
               unusual = true;   // something the general code has to look at
+              m = rl64(sw0, kk);
               break;
             }
-            // on to the word the walk is in now (a long split may have skipped some)
-            const uint32_t adv = oo >> 6;
-            oo &= 63u;
-            kk += adv;
-            if (adv == 1u) {
-              lrowA = pack8(lrowNA);
-              lrowB = pack8(lrowNB);
-            }
-            else
+            if (st == 3u)
               load_lrow(kk);
             if (kk > kkLast || e > eStop || nrec + nloc + 2u >= (uint32_t)kMxRecs)
               break;
+            if (st == 0u && e + 64u - oo > limAbs)   // (the ring's or the list's last entries)
+              break;
           }
+#undef MX_HOP
           r = kk * 64u + oo - wq0;
           rem = eEnd - e;
           if (kStamps)
             wk_tight += __builtin_readcyclecounter() - tt0;
           lrowK = kk;
-          if (!unusual) {
+          if (!unusual && !(kk == k && oo == o)) {
             curK = 0xffffffffu;
             continue;
           }
+          if (!unusual)   // (nothing done -- the ring ends here: the general code takes an entry)
+            m = rl64(sw0, kk);
           curK = kk;   // (an unusual entry lies in the word just walked: m and lrow are that word's)
         }
         const uint32_t q2 = r + wq0, o2 = q2 & 63u;   // (same word: the tight loop stops inside it)
@@ -701,8 +774,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           if (col < (uint32_t)kMxCols)
             tl = Tr[(size_t)(r + 1u) * kMxCols + col];
           if (kStamps) {   // why the tight loop left this entry to the general code
-            const uint32_t loc = ec >> 8;
-            if (loc < 8u && tl < kTNone)
+            if (!(ec & 0x8000u) && tl < kTNone)
               wk_gSat++;       // in the view, 254 bits and more (or a list of fewer than 64 entries)
             else if (tl < kTNone)
               wk_gView++;      // a column outside the list's two groups
@@ -907,7 +979,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       for (uint32_t ri = (uint32_t)tid; ri < nr; ri += kMxThreads) {
         uint64_t cm = sh_recM[ri][0], im = sh_recM[ri][1];
         uint32_t slot = atomicAdd(&sh_qn[0], (uint32_t)__popcll(cm));
-        const uint32_t e0 = sh_recE[ri], pb = sh_recK[ri] * 64u + 1u - wq0;
+        // (the ordinal mask's bits are ordinals mod 64: turned so that bit 0 is the word's first ordinal)
+        const uint32_t e0 = sh_recE[ri], rk = sh_recK[ri], pb = (rk & 0xffu) * 64u + 1u - wq0, r6 = (rk >> 8) & 63u;
+        im = r6 ? (im >> r6) | (im << (64u - r6)) : im;
         while (cm && im) {
           const uint32_t pbit = (uint32_t)__builtin_ctzll(cm), ebit = (uint32_t)__builtin_ctzll(im);
           cm &= cm - 1;
@@ -1513,7 +1587,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       atomicAdd(out + 17, (unsigned long long)wk_gView);
       atomicAdd(out + 18, (unsigned long long)wk_gInf);
       atomicAdd(out + 19, (unsigned long long)wk_gChain);
-      wk_gSat = wk_gView = wk_gInf = wk_gChain = 0;
+      atomicAdd(out + 20, (unsigned long long)wk_enters);
+      atomicAdd(out + 21, (unsigned long long)wk_reloads);
+      wk_gSat = wk_gView = wk_gInf = wk_gChain = wk_enters = wk_reloads = 0;
       wk_fill = wk_total = wk_tight = wk_into = 0;
       wk_fills = wk_calls = wk_hopsT = wk_hopsG = wk_rounds = wk_words = wk_zruns = 0;
     }
