@@ -609,6 +609,11 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
               const uint32_t eo = e + ((lane - e) & 63u);
               ecb = ((uint32_t)ecls[eo & (uint32_t)(kMxRing - 1)] >> 8) | (8u << 16);
             }
+            // words the statement may take: to the region's last, one record each, 64 ordinals each at most
+            if (e + 64u - oo > limAbs)
+              break;
+            uint32_t wl = (uint32_t)__builtin_amdgcn_readfirstlane(   // (one less: the count's borrow ends it)
+                (int)min(min(kkLast - kk, nlocLim - nloc - 1u), (limAbs - (e + 64u - oo)) >> 6));
             if (kStamps)
               wk_enters++;
             // (rows 1 .. S + 128 exist: the next word's are fetched while a word is walked)
@@ -626,15 +631,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   MX_HOP "s_cbranch_scc1 2f\n\t"
                   MX_HOP "s_cbranch_scc0 1b\n\t"
                   "2:\n\t"                                   // ---- the word is through (a split went past its end)
-                  "s_cmp_eq_u32 s98, 255\n\t"
-                  "s_cbranch_scc1 4f\n\t"
                   "8:\n\t"                                   // the classes of the next 64 ordinals, the word's record, the next word's rows
                   "v_subrev_u32 v124, %[idx], %[lane]\n\t"
                   "s_lshr_b32 %[st], %[oo], 6\n\t"           // (words skipped)
                   "v_and_b32 v124, 63, v124\n\t"
                   "s_or_b32 %[oo], %[oo], 0xffffffc0\n\t"
                   "v_add_u32 v124, %[idx], v124\n\t"
-                  "s_add_u32 %[kk], %[kk], %[st]\n\t"
                   "v_and_b32 v124, 0x1fff, v124\n\t"
                   "s_add_u32 %[kk], %[kk], 1\n\t"
                   "v_lshl_add_u32 v124, v124, 1, %[ring]\n\t"
@@ -646,7 +648,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "s_add_u32 %[nloc], %[nloc], 1\n\t"
                   "s_waitcnt lgkmcnt(1)\n\t"
                   "s_cmp_lg_u32 %[st], 0\n\t"
-                  "s_cbranch_scc1 6f\n\t"                    // (a long split skipped a word)
+                  "s_cbranch_scc1 6f\n\t"                    // (a long split skipped a word, or a length of 255)
                   "v_pk_min_u16 v120, v120, %[lim]\n\t"      // four 16-bit lengths -> four bytes: length + 1, 255 = look it up
                   "v_pk_min_u16 v121, v121, %[lim]\n\t"
                   "v_pk_min_u16 v122, v122, %[lim]\n\t"
@@ -655,19 +657,14 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "v_perm_b32 v122, v123, v122, %[sel]\n\t"
                   "v_add_u32 %[rlo], 0x1010101, v120\n\t"
                   "v_add_u32 %[rhi], 0x1010101, v122\n\t"
-                  "s_cmp_gt_u32 %[kk], %[kl]\n\t"            // the region's last word,
-                  "s_cbranch_scc1 5f\n\t"
-                  "s_cmp_ge_u32 %[nloc], %[nl]\n\t"          // the record registers full,
-                  "s_cbranch_scc1 5f\n\t"
+                  "s_sub_u32 %[wl], %[wl], 1\n\t"            // the region's last word, the record registers full, the ring's
+                  "s_cbranch_scc1 5f\n\t"                    // or the list's last entries: a count of words
                   "s_waitcnt lgkmcnt(0)\n\t"
                   "v_lshrrev_b32 v125, 8, v125\n\t"
                   "v_or_b32 %[ecb], 0x80000, v125\n\t"
                   "0:\n\t"                                   // ---- a word
-                  "s_sub_u32 %[st], %[idx], %[oo]\n\t"
                   "v_readlane_b32 vcc_lo, %[swl], %[kk]\n\t"
                   "v_readlane_b32 vcc_hi, %[swh], %[kk]\n\t"
-                  "s_cmp_gt_u32 %[st], %[la]\n\t"            // the ring's or the list's last entries
-                  "s_cbranch_scc1 5f\n\t"
                   "s_mov_b32 m0, %[nloc]\n\t"
                   "ds_read_b64 v[120:121], %[ada]\n\t"
                   "ds_read_b64 v[122:123], %[adb]\n\t"
@@ -682,8 +679,6 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "s_add_u32 %[idx], %[idx], %[st]\n\t"
                   "s_mov_b32 %[oo], 0\n\t"
                   "s_branch 8b\n\t"
-                  "4:\n\t"                                   // the last hop's length was 255: back to its bit
-                  "s_sub_u32 %[oo], %[oo], 255\n\t"
                   "9:\n\t"                                   // an unusual entry: the word's record so far
                   "s_sub_u32 %[idx], %[idx], 1\n\t"
                   "s_bitset0_b64 s[92:93], %[oo]\n\t"
@@ -698,15 +693,33 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "5:\n\t"
                   "s_mov_b32 %[st], 0\n\t"
                   "s_branch 10f\n\t"
-                  "6:\n\t"
+                  "6:\n\t"                                   // ---- words skipped (st of them)
+                  "s_cmp_eq_u32 s98, 255\n\t"
+                  "s_cbranch_scc1 4f\n\t"
+                  "s_add_u32 %[kk], %[kk], %[st]\n\t"
                   "s_mov_b32 %[st], 3\n\t"
+                  "s_branch 10f\n\t"
+                  "4:\n\t"                                   // by a length of 255 ("look it up"): back to that entry's bit,
+                  "s_lshl_b32 %[st], %[st], 6\n\t"           // the word's record once more without it
+                  "s_and_b32 %[oo], %[oo], 63\n\t"
+                  "s_sub_u32 %[kk], %[kk], 1\n\t"
+                  "s_add_u32 %[oo], %[oo], %[st]\n\t"
+                  "s_sub_u32 %[idx], %[idx], 1\n\t"
+                  "s_sub_u32 %[oo], %[oo], 255\n\t"
+                  "s_bitset0_b64 s[94:95], %[idx]\n\t"
+                  "s_bitset0_b64 s[92:93], %[oo]\n\t"
+                  "s_mov_b32 %[st], 1\n\t"
+                  "v_writelane_b32 %[rcl], s92, m0\n\t"
+                  "v_writelane_b32 %[rch], s93, m0\n\t"
+                  "v_writelane_b32 %[ril], s94, m0\n\t"
+                  "v_writelane_b32 %[rih], s95, m0\n\t"
                   "10:\n\t"
                   "s_waitcnt lgkmcnt(0)\n\t"
                   "s_add_u32 %[oo], %[oo], 64\n\t"
                   : [kk] "+s"(kk), [oo] "+s"(oo), [idx] "+s"(idx), [nloc] "+s"(nloc), [rcl] "+v"(rcL), [rch] "+v"(rcH), [ril] "+v"(riL),
                     [rih] "+v"(riH), [re] "+v"(rE), [rlo] "+v"(lrowA), [rhi] "+v"(lrowB), [ada] "+v"(adNA), [adb] "+v"(adNB), [ecb] "+v"(ecb),
-                    [st] "=&s"(st), [mm] "=&s"(mm_), [ec] "=&s"(ec_)
-                  : [kl] "s"(kkLast), [la] "s"(limAbs), [nl] "s"(nlocLim), [lim] "s"(0x00fe00feu), [sel] "s"(0x06040200u),
+                    [wl] "+s"(wl), [st] "=&s"(st), [mm] "=&s"(mm_), [ec] "=&s"(ec_)
+                  : [lim] "s"(0x00fe00feu), [sel] "s"(0x06040200u),
                     [ring] "s"((uint32_t)(size_t)ecls), [swl] "v"((uint32_t)sw0), [swh] "v"((uint32_t)(sw0 >> 32)), [lane] "v"(lane)
                   : "scc", "vcc", "m0", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123",
                     "v124", "v125");
@@ -731,8 +744,6 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             if (st == 3u)
               load_lrow(kk);
             if (kk > kkLast || e > eStop || nrec + nloc + 2u >= (uint32_t)kMxRecs)
-              break;
-            if (st == 0u && e + 64u - oo > limAbs)   // (the ring's or the list's last entries)
               break;
           }
 #undef MX_HOP
