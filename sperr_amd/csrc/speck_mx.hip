@@ -583,8 +583,6 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
 #define MX_HOP                                                                                     \
   "s_lshr_b64 %[mm], vcc, %[oo]\n\t"                                                               \
   "s_ff1_i32_b64 %[st], %[mm]\n\t"          /* insignificant entries: one bit each */              \
-  "s_cmp_eq_u64 %[mm], 0\n\t"                                                                      \
-  "s_cbranch_scc1 3f\n\t"                                                                          \
   "s_add_u32 %[idx], %[idx], %[st]\n\t"                                                            \
   "s_add_u32 %[oo], %[oo], %[st]\n\t"                                                              \
   "v_readlane_b32 %[ec], %[ecb], %[idx]\n\t"                                                       \
@@ -592,9 +590,11 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   "v_readlane_b32 s97, %[rhi], %[oo]\n\t"                                                          \
   "s_bitset1_b64 s[94:95], %[idx]\n\t"                                                             \
   "s_bitset1_b64 s[92:93], %[oo]\n\t"                                                              \
-  "s_add_u32 %[idx], %[idx], 1\n\t"                                                                \
-  "s_bitcmp1_b32 %[ec], 7\n\t"                                                                     \
-  "s_cbranch_scc1 9f\n\t"                                                                          \
+  "s_add_u32 %[idx], %[idx], 1\n\t"
+#define MX_HOP_TEST                                                                                \
+  "s_bitcmp1_b32 %[ec], 7\n\t"            /* a class with no byte in the pair */                   \
+  "s_cbranch_scc1 9f\n\t"
+#define MX_HOP_END                                                                                 \
   "s_bfe_u64 s[98:99], s[96:97], %[ec]\n\t" /* bits of the entry's split + 1 */                    \
   "s_add_u32 %[oo], %[oo], s98\n\t"
           static_assert(kMxRing == 8192, "the ring's index mask is a literal of the statement below");
@@ -626,11 +626,14 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "s_branch 0f\n\t"
                   ".p2align 7\n\t"
                   "1:\n\t"                                   // ---- the hops of a word
-                  MX_HOP "s_cbranch_scc1 2f\n\t"
-                  MX_HOP "s_cbranch_scc1 2f\n\t"
-                  MX_HOP "s_cbranch_scc1 2f\n\t"
-                  MX_HOP "s_cbranch_scc0 1b\n\t"
-                  "2:\n\t"                                   // ---- the word is through (a split went past its end)
+                  MX_HOP MX_HOP_END "s_cbranch_scc1 2f\n\t"
+                  MX_HOP MX_HOP_END "s_cbranch_scc1 2f\n\t"
+                  MX_HOP MX_HOP_END "s_cbranch_scc1 2f\n\t"
+                  MX_HOP MX_HOP_END "s_cbranch_scc0 1b\n\t"
+                  "2:\n\t"                                   // ---- the word is through (a split went past its end):
+                  "s_lshr_b32 %[st], s93, 31\n\t"            // by a hop at bit 63 that is only the statement's own?
+                  "s_cmp_gt_u32 %[st], s91\n\t"
+                  "s_cbranch_scc1 3f\n\t"
                   "8:\n\t"                                   // the classes of the next 64 ordinals, the word's record, the next word's rows
                   "v_subrev_u32 v124, %[idx], %[lane]\n\t"
                   "s_lshr_b32 %[st], %[oo], 6\n\t"           // (words skipped)
@@ -665,6 +668,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "0:\n\t"                                   // ---- a word
                   "v_readlane_b32 vcc_lo, %[swl], %[kk]\n\t"
                   "v_readlane_b32 vcc_hi, %[swh], %[kk]\n\t"
+                  "v_cmp_lt_u32_e64 s[96:97], %[nth], %[ecb]\n\t"   // (the window's entries of a class with no byte)
                   "s_mov_b32 m0, %[nloc]\n\t"
                   "ds_read_b64 v[120:121], %[ada]\n\t"
                   "ds_read_b64 v[122:123], %[adb]\n\t"
@@ -673,10 +677,18 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                   "v_writelane_b32 %[re], %[idx], m0\n\t"    // (the ordinal the word starts with)
                   "v_add_u32 %[ada], 0x800, %[ada]\n\t"
                   "v_add_u32 %[adb], 0x800, %[adb]\n\t"
-                  "s_branch 1b\n\t"
-                  "3:\n\t"                                   // the rest of the word is zeros
-                  "s_sub_u32 %[st], 0, %[oo]\n\t"
-                  "s_add_u32 %[idx], %[idx], %[st]\n\t"
+                  "s_lshr_b32 s91, vcc_hi, 31\n\t"           // bit 63 of the word as it is; set for the loop, which then
+                  "s_bitset1_b32 vcc_hi, 31\n\t"             // needs no test for "the rest is zeros"
+                  "s_cmp_lg_u64 s[96:97], 0\n\t"
+                  "s_cbranch_scc0 1b\n\t"
+                  "7:\n\t"                                   // ---- the hops of a word that may meet a class with no byte
+                  MX_HOP MX_HOP_TEST MX_HOP_END
+                  "s_cbranch_scc0 7b\n\t"
+                  "s_branch 2b\n\t"
+                  "3:\n\t"                                   // bit 63 was a zero: an insignificant entry, the word's last
+                  "s_sub_u32 %[st], %[idx], 1\n\t"
+                  "s_bitset0_b32 s93, 31\n\t"
+                  "s_bitset0_b64 s[94:95], %[st]\n\t"
                   "s_mov_b32 %[oo], 0\n\t"
                   "s_branch 8b\n\t"
                   "9:\n\t"                                   // an unusual entry: the word's record so far
@@ -720,8 +732,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
                     [rih] "+v"(riH), [re] "+v"(rE), [rlo] "+v"(lrowA), [rhi] "+v"(lrowB), [ada] "+v"(adNA), [adb] "+v"(adNB), [ecb] "+v"(ecb),
                     [wl] "+s"(wl), [st] "=&s"(st), [mm] "=&s"(mm_), [ec] "=&s"(ec_)
                   : [lim] "s"(0x00fe00feu), [sel] "s"(0x06040200u),
-                    [ring] "s"((uint32_t)(size_t)ecls), [swl] "v"((uint32_t)sw0), [swh] "v"((uint32_t)(sw0 >> 32)), [lane] "v"(lane)
-                  : "scc", "vcc", "m0", "memory", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123",
+                    [ring] "s"((uint32_t)(size_t)ecls), [nth] "s"(0x8007fu), [swl] "v"((uint32_t)sw0), [swh] "v"((uint32_t)(sw0 >> 32)), [lane] "v"(lane)
+                  : "scc", "vcc", "m0", "memory", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v120", "v121", "v122", "v123",
                     "v124", "v125");
             }
             if (lane >= nloc0 && lane < nloc) {   // the records just written: stream word | first ordinal mod 64, first entry
@@ -747,6 +759,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
               break;
           }
 #undef MX_HOP
+#undef MX_HOP_TEST
+#undef MX_HOP_END
           r = kk * 64u + oo - wq0;
           rem = eEnd - e;
           if (kStamps)
