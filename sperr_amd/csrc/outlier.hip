@@ -510,6 +510,10 @@ k_speck1d(OutlierBufs b)
   // stream order.  tests/model/speck_model.cpp::model_speck1d_decode_batched is the CPU model.
   // (Before: a whole path per step with lane = level, about 1400 cycles per path.)
   uint32_t rES = 0, rEL = 0, rR = 0, rMeta = 0, rClosed = 0, nrec = 0;
+  // (records of chain_p2 below hold the path's own bits and its first depth instead of R and the meta word: `recRaw` marks
+  //  them, flush_paths works R out for all of them at once; `rCarry`: R of the last record flushed)
+  uint64_t recRaw = 0;
+  uint32_t rCarry = 0;
 #ifdef SPERR_1D_STAMPS
   long long tkLip = 0, tkLis = 0, tkChain = 0, tkFlush = 0, tkRef = 0, tkLsp = 0, tk0 = 0;
   uint32_t nPaths = 0, nEntries = 0, nFlush = 0;
@@ -528,6 +532,33 @@ k_speck1d(OutlierBufs b)
     nPaths += nrec;
 #endif
     const bool valid = lane < nrec;
+    if (recRaw) {
+      // A path from depth u of a run of 2^g values: its g - u bits (a '0' = went right) and its sign are rR's low bits.
+      // R of a record = R of the record before it below depth u - 1, a 1 at depth u - 1, the path's bits from u on: the
+      // records' (keep, value) pairs compose, so a scan over the lanes gives every R (a run's first record keeps nothing).
+      const bool raw = ((recRaw >> lane) & 1ull) != 0;
+      const uint32_t u0 = raw ? rMeta - 1u : 0u, g = 31u - (uint32_t)__clz((int)(rEL | 1u)), ns = raw ? g - u0 : 0u;
+      uint32_t keep = 0, val = rR;
+      if (raw) {
+        keep = u0 ? (1u << (u0 - 1u)) - 1u : 0u;
+        val = (u0 ? 1u << (u0 - 1u) : 0u) | ((~rR & ((1u << ns) - 1u)) << u0);
+      }
+      const uint32_t sg = (rR >> ns) & 1u;
+      for (uint32_t off = 1; off < 64u; off <<= 1) {
+        const uint32_t pk = (uint32_t)__shfl_up((int)keep, off, 64), pv = (uint32_t)__shfl_up((int)val, off, 64);
+        if (lane >= off) {
+          val = (pv & keep) | val;
+          keep &= pk;
+        }
+      }
+      val = (rCarry & keep) | val;
+      if (raw) {
+        rR = val;
+        rMeta = u0 | (g << 8) | (sg << 16);
+      }
+      recRaw = 0;
+    }
+    rCarry = rdlane(rR, nrec - 1u);
     const uint32_t u = rMeta & 0xffu, tEnd = (rMeta >> 8) & 0xffu;
     uint32_t s = rES, l = rEL;
     for (uint32_t j = 0;; j++) {
@@ -632,6 +663,120 @@ k_speck1d(OutlierBufs b)
         const uint32_t um = (1u << u) - 1u;
         lo = (el >> u) + (((R & um) < (el & um)) ? 1u : 0u);
       }
+    }
+  };
+
+  // The chain for a run of 2^g values, g <= 30, as one asm statement per run (a lone wavefront completes an instruction
+  // every nine cycles or so: the compiler's 83 per path were 630 cycles): 36 instructions per path.  State: the two
+  // stream words the window lies in (`cw0`, `cw1s` = the second one shifted left by one, so that a shift by 63 - sh never
+  // is one by 64) and the bit offset `sh` into the first, `wk` = that word's lane in vW; the parked depths `mr`
+  // (bit-reversed, as above) and `u1` = the path's first depth + 1.  A record is three lane writes: the path's bits with
+  // its sign on top, the first depth, the closed halves; the run's start and length are filled in for all of its records
+  // afterwards, R and the meta word by flush_paths.  Clearing the z lowest set bits of `mr` is three vector instructions
+  // (lane i: does bit i have z set bits below it).  The statement comes back when the run is through (0), the record
+  // registers are full (1), the stream words in vW are used up (2).
+  // peek: s[88:89]; scratch: s[90:95], v[T].
+  auto chain_p2 = [&](uint32_t es, uint32_t el, uint32_t lev) {
+    const uint32_t g = 31u - (uint32_t)__clz((int)el);
+    const uint32_t l2 = rfl(g + 2u), dm = rfl(((1u << g) - 1u) << (31u - g));
+    const uint32_t lowm = lane < 32u ? (1u << lane) - 1u : 0xffffffffu;
+    uint32_t mr = 0, u1 = 1, n0 = nrec;
+    for (;;) {
+      // the window's state from rpos
+      uint64_t wi = rpos >> 6;
+      if (wi - cBase >= 62u) {
+        cBase = wi;
+        vW = wi + lane < b.streamStride ? words[wi + lane] : 0ull;
+      }
+      uint32_t wk = rfl((uint32_t)(wi - cBase)), sh = rfl((uint32_t)(rpos & 63u)), st, nr = rfl(nrec);
+      const uint32_t a0 = rdlane((uint32_t)vW, wk), a1 = rdlane((uint32_t)(vW >> 32), wk);
+      const uint32_t b0 = rdlane((uint32_t)vW, wk + 1u), b1 = rdlane((uint32_t)(vW >> 32), wk + 1u);
+      uint64_t c0 = (uint64_t)rfl(a0) | ((uint64_t)rfl(a1) << 32);
+      uint64_t c1s = (uint64_t)rfl(b0 << 1) | ((uint64_t)rfl((b1 << 1) | (b0 >> 31)) << 32);
+      uint32_t tv_;
+      mr = rfl(mr);
+      u1 = rfl(u1);
+      asm volatile(
+          "s_mov_b32 m0, %[nr]\n\t"
+          "s_branch 0f\n\t"
+          ".p2align 7\n\t"
+          "0:\n\t"                                   // ---- a path
+          "s_lshr_b64 s[88:89], %[cw0], %[sh]\n\t"
+          "s_xor_b32 s90, %[sh], 63\n\t"
+          "s_lshl_b64 s[90:91], %[cw1s], s90\n\t"
+          "s_sub_u32 s92, %[l2], %[u1]\n\t"          // its steps + 1 (the sign)
+          "s_or_b64 s[88:89], s[88:89], s[90:91]\n\t"  // the next 64 bits of the stream
+          "s_bfm_b32 s93, s92, 0\n\t"
+          "s_lshr_b64 s[90:91], s[88:89], s92\n\t"   // the closing bits
+          "s_and_b32 s93, s88, s93\n\t"              // the path's bits, the sign on top
+          "s_add_u32 %[sh], %[sh], s92\n\t"
+          "s_brev_b32 s94, s93\n\t"
+          "v_writelane_b32 %[rb], s93, m0\n\t"
+          "s_lshr_b32 s94, s94, %[u1]\n\t"           // a '1' at step j parks the right half of depth u + j + 1
+          "v_writelane_b32 %[ru], %[u1], m0\n\t"
+          "s_and_b32 s94, s94, %[dm]\n\t"            // (not the sign)
+          "s_ff1_i32_b64 s95, s[90:91]\n\t"          // zeros at the head of the closing bits
+          "s_or_b32 %[mr], %[mr], s94\n\t"
+          "s_bcnt1_i32_b32 s94, %[mr]\n\t"
+          "v_and_b32 %[tv], %[mr], %[lowm]\n\t"
+          "s_min_u32 s95, s95, s94\n\t"              // z: that many parked halves are born insignificant, innermost first
+          "v_bcnt_u32_b32 %[tv], %[tv], 0\n\t"
+          "s_add_u32 %[sh], %[sh], s95\n\t"
+          "v_cmp_le_u32 vcc, s95, %[tv]\n\t"         // (bits of mr with z set bits below them stay)
+          "s_andn2_b32 s93, %[mr], vcc_lo\n\t"
+          "s_and_b32 %[mr], %[mr], vcc_lo\n\t"
+          "v_writelane_b32 %[rc], s93, m0\n\t"
+          "s_add_u32 m0, m0, 1\n\t"
+          "s_cmp_eq_u32 s95, s94\n\t"
+          "s_cbranch_scc1 8f\n\t"                    // all of them: the run is through
+          "s_ff1_i32_b32 s93, %[mr]\n\t"             // the next path starts in the innermost half left (its '1')
+          "s_add_u32 %[sh], %[sh], 1\n\t"
+          "s_sub_u32 %[u1], 32, s93\n\t"
+          "s_bitset0_b32 %[mr], s93\n\t"
+          "s_cmp_eq_u32 m0, 64\n\t"
+          "s_cbranch_scc1 7f\n\t"
+          "s_cmp_lt_u32 %[sh], 64\n\t"
+          "s_cbranch_scc1 0b\n\t"
+          "s_sub_u32 %[sh], %[sh], 64\n\t"           // ---- the next stream word
+          "s_add_u32 %[wk], %[wk], 1\n\t"
+          "s_cmp_ge_u32 %[wk], 62\n\t"
+          "s_cbranch_scc1 6f\n\t"
+          "s_add_u32 s92, %[wk], 1\n\t"
+          "v_readlane_b32 s90, %[wlo], %[wk]\n\t"
+          "v_readlane_b32 s91, %[whi], %[wk]\n\t"
+          "v_readlane_b32 s94, %[wlo], s92\n\t"
+          "v_readlane_b32 s95, %[whi], s92\n\t"
+          "s_mov_b64 %[cw0], s[90:91]\n\t"
+          "s_lshl_b64 %[cw1s], s[94:95], 1\n\t"
+          "s_branch 0b\n\t"
+          "6:\n\t"
+          "s_mov_b32 %[st], 2\n\t"
+          "s_branch 9f\n\t"
+          "7:\n\t"
+          "s_mov_b32 %[st], 1\n\t"
+          "s_branch 9f\n\t"
+          "8:\n\t"
+          "s_mov_b32 %[st], 0\n\t"
+          "9:\n\t"
+          "s_mov_b32 %[nr], m0\n\t"
+          : [sh] "+s"(sh), [wk] "+s"(wk), [mr] "+s"(mr), [u1] "+s"(u1), [nr] "+s"(nr), [cw0] "+s"(c0), [cw1s] "+s"(c1s), [rb] "+v"(rR),
+            [ru] "+v"(rMeta), [rc] "+v"(rClosed), [st] "=&s"(st), [tv] "=&v"(tv_)
+          : [l2] "s"(l2), [dm] "s"(dm), [lowm] "v"(lowm), [wlo] "v"((uint32_t)vW), [whi] "v"((uint32_t)(vW >> 32))
+          : "scc", "vcc", "m0", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+      rpos = (cBase + wk) * 64ull + sh;
+      cwi = 1ull << 62;   // (window()'s two words are not the statement's)
+      if (lane >= n0 && lane < nr) {   // the records just written belong to this run
+        rES = es;
+        rEL = el;
+      }
+      recRaw |= low_mask(nr) & ~low_mask(n0);
+      nrec = nr;
+      if (nrec == 64u) {   // (st 1, or the run's last record was the 64th)
+        flush_paths(lev);
+        n0 = 0;
+      }
+      if (st == 0u)
+        return;
     }
   };
 
@@ -884,7 +1029,9 @@ k_speck1d(OutlierBufs b)
               const long long tc0 = clock64();
               nEntries++;
 #endif
-              if ((el & (el - 1u)) == 0u)
+              if ((el & (el - 1u)) == 0u && el <= (1u << 30))
+                chain_p2(es, el, lev);
+              else if ((el & (el - 1u)) == 0u)
                 expand_chain(std::true_type{}, es, el, lev);
               else
                 expand_chain(std::false_type{}, es, el, lev);
