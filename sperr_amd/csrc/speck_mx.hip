@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ uint32_t sh_len[kMaxLevels], sh_lOff[kMaxLevels];
   // chain state (the first wavefront owns it; the others read it between barriers)
   __shared__ uint64_t sh_pos, sh_base;
-  __shared__ uint32_t sh_level, sh_e, sh_rem, sh_mode, sh_stop, sh_needFill, sh_ringHi, sh_ticket, sh_abort;
+  __shared__ uint32_t sh_level, sh_e, sh_rem, sh_mode, sh_stop, sh_needFill, sh_ringHi, sh_ticket, sh_abort, sh_published;
   __shared__ uint32_t sh_iJ, sh_iPart, sh_iCounter, sh_iNeed;
   __shared__ int sh_depth;
   __shared__ uint32_t sh_qn[2], sh_ncand, sh_hcap;
@@ -463,8 +463,13 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
   uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
   uint32_t wk_gSat = 0, wk_gView = 0, wk_gInf = 0, wk_gChain = 0, wk_enters = 0, wk_reloads = 0;
+  uint32_t curRegion = 0, curMode = 0;   // (set by the chain below before it calls walk())
   auto walk = [&]() {
     const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
+    // (read here, off the end of the walk: what the state words 4 and 5 hold while a list is walked)
+    const unsigned long long pubBase = sh_base & ((1ull << kMxTagShift) - 1ull);
+    const unsigned long long pubI = (unsigned long long)sh_iJ | ((unsigned long long)sh_iPart << 2) |
+                                    ((unsigned long long)sh_iCounter << 8) | ((unsigned long long)sh_iNeed << 10);
     uint32_t r = __builtin_amdgcn_readfirstlane((uint32_t)(sh_pos - a)), e = __builtin_amdgcn_readfirstlane(sh_e),
              rem = __builtin_amdgcn_readfirstlane(sh_rem);
     uint32_t qn = __builtin_amdgcn_readfirstlane(sh_qn[0]), ns = 0;
@@ -975,6 +980,31 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       if (kStamps)
         wk_into += __builtin_readcyclecounter() - ti0;
     }
+    // The region's end in the middle of a list, no set being walked into (the usual end): the state goes out from the
+    // registers NOW -- the region after this one waits for it -- and what this workgroup still has to put away (staged
+    // items, records, its own copy of the state) comes after; the chain's own publishing code below skips its stores.
+    if (r >= S && depth == 1 && rem != 0 && curMode == kModeList) {
+      unsigned long long f = tag;
+      if (lane == 0)
+        f |= (a + r - phase0) | ((unsigned long long)level << 40) | (1ull << 46) | ((unsigned long long)kModeList << 51);
+      else if (lane == 1)
+        f |= (unsigned long long)e;
+      else if (lane == 6)
+        f |= (unsigned long long)rem;
+      else if (lane == 4)
+        f |= pubBase;
+      else if (lane == 5)
+        f |= pubI;
+      if (lane < 7)
+        __hip_atomic_store(flags + (size_t)curRegion * kMxWordsPerRegion + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.mxHint),
+                           tag | ((unsigned long long)level << 48) | ((unsigned long long)(curRegion & 0xfffffu) << 28) |
+                               (unsigned long long)min(rem, 0xfffffffu),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_published = 1;
+      }
+    }
     flush();
     rec_flush();
     if (lane == 0) {
@@ -1146,6 +1176,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       sh_nrec = 0;
       sh_go = sh_goDone = 0;
       sh_stop = 0;
+      sh_published = 0;
       sh_abort = 0;
       sh_needFill = 0;
       if (kStamps)
@@ -1450,11 +1481,13 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           else if (lane == 5)
             f |= (unsigned long long)sh_iJ | ((unsigned long long)sh_iPart << 2) |
                  ((unsigned long long)sh_iCounter << 8) | ((unsigned long long)sh_iNeed << 10);
-          if (lane < 7)
+          const bool done = __builtin_amdgcn_readfirstlane(sh_published) != 0;   // (walk() has published this very state)
+          if (lane < 7 && !done)
             __hip_atomic_store(flags + (size_t)i * kMxWordsPerRegion + lane, f, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-          if (lane == 0) {
+          if (lane == 0)
             sh_stop = 3;
+          if (lane == 0 && !done) {
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.mxHint),
                                tag | ((unsigned long long)sh_level << 48) | ((unsigned long long)(i & 0xfffffu) << 28) |
                                    (unsigned long long)(sh_mode == kModeList ? min(sh_rem, 0xfffffffu) : 0u),
@@ -1574,6 +1607,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           break;
         }
         // ---- list entries, or the children of the sets being walked into
+        curRegion = i;
+        curMode = mode;
         walk();
         if (mode == kModeISubWalk && __builtin_amdgcn_readfirstlane(sh_depth) == 0) {
           if (lane == 0) {
