@@ -463,6 +463,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   uint64_t wk_tight = 0, wk_into = 0, wk_total = 0, wk_fill = 0;
   uint32_t wk_hopsT = 0, wk_hopsG = 0, wk_rounds = 0, wk_words = 0, wk_calls = 0, wk_fills = 0, wk_zruns = 0;
   uint32_t wk_gSat = 0, wk_gView = 0, wk_gInf = 0, wk_gChain = 0, wk_enters = 0, wk_reloads = 0;
+  uint64_t wk_seen = 0, wk_toWalk = 0, wk_pro = 0, wk_epi = 0, wk_dec = 0;   // (seen: the state words are in; cycles from there to the first walk; the walk's set-up; its end)
   uint32_t curRegion = 0, curMode = 0;   // (set by the chain below before it calls walk())
   auto walk = [&]() {
     const uint64_t wk0 = kStamps ? __builtin_readcyclecounter() : 0;
@@ -540,6 +541,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       qn += ns;
       ns = 0;
     };
+    if (kStamps)
+      wk_pro += __builtin_readcyclecounter() - wk0;
     while (true) {
       if (r >= S)
         break;
@@ -980,6 +983,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       if (kStamps)
         wk_into += __builtin_readcyclecounter() - ti0;
     }
+    const uint64_t we0 = kStamps ? __builtin_readcyclecounter() : 0;
     // The region's end in the middle of a list, no set being walked into (the usual end): the state goes out from the
     // registers NOW -- the region after this one waits for it -- and what this workgroup still has to put away (staged
     // items, records, its own copy of the state) comes after; the chain's own publishing code below skips its stores.
@@ -1020,6 +1024,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     MX_WAVE_SYNC();
     if (kStamps) {
       wk_total += __builtin_readcyclecounter() - wk0;
+      wk_epi += __builtin_readcyclecounter() - we0;
       wk_calls++;
     }
   };
@@ -1296,6 +1301,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       MX_WAVE_SYNC();
       if (kStamps && lane == 0)
         sh_tk[1] = __builtin_readcyclecounter();
+      if (kStamps)
+        wk_seen = __builtin_readcyclecounter();
       // every lane works out the same state; lane 0 writes it
       uint32_t stop = 0, mode = kModeList, level = 0, e = 0, rem = 0, iJ = 0, iPart = 0, iCounter = 0, iNeed = 1;
       int depth = 1;
@@ -1376,6 +1383,10 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         if (stop == 1 && lane == 0)
           __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      // (the classes of the list's entries from e on: in the ring already when the guess above held)
+      const bool pre = mode == kModeList && level == sh_preLevel && e >= sh_preLo &&
+                       min(sh_len[level < nlevels ? level : 0], e + S + 128u) <= sh_preHi;
+      const bool needFill = stop == 0 && mode == kModeList && !pre;
       if (lane == 0) {
         sh_pos = pos;
         sh_base = base;
@@ -1389,14 +1400,13 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         sh_iCounter = iCounter;
         sh_iNeed = iNeed;
         sh_stop = stop;
-        // (the classes of the list's entries from e on: in the ring already when the guess above held)
-        const bool pre = mode == kModeList && level == sh_preLevel && e >= sh_preLo &&
-                         min(sh_len[level], e + S + 128u) <= sh_preHi;
-        sh_needFill = (stop == 0 && mode == kModeList && !pre) ? 1u : 0u;
+        sh_needFill = needFill ? 1u : 0u;
         if (pre)
           sh_ringHi = sh_preHi;
       }
       MX_WAVE_SYNC();
+      if (kStamps && wk_seen)
+        wk_dec += __builtin_readcyclecounter() - wk_seen;
     }
     for (;;) {
       __syncthreads();
@@ -1609,6 +1619,10 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         // ---- list entries, or the children of the sets being walked into
         curRegion = i;
         curMode = mode;
+        if (kStamps && wk_seen) {
+          wk_toWalk += __builtin_readcyclecounter() - wk_seen;
+          wk_seen = 0;
+        }
         walk();
         if (mode == kModeISubWalk && __builtin_amdgcn_readfirstlane(sh_depth) == 0) {
           if (lane == 0) {
@@ -1648,6 +1662,11 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       atomicAdd(out + 18, (unsigned long long)wk_gInf);
       atomicAdd(out + 19, (unsigned long long)wk_gChain);
       atomicAdd(out + 20, (unsigned long long)wk_enters);
+      atomicAdd(out + 22, (unsigned long long)wk_toWalk);
+      atomicAdd(out + 23, (unsigned long long)wk_pro);
+      atomicAdd(out + 24, (unsigned long long)wk_epi);
+      atomicAdd(out + 25, (unsigned long long)wk_dec);
+      wk_toWalk = wk_pro = wk_epi = wk_dec = 0;
       atomicAdd(out + 21, (unsigned long long)wk_reloads);
       wk_gSat = wk_gView = wk_gInf = wk_gChain = wk_enters = wk_reloads = 0;
       wk_fill = wk_total = wk_tight = wk_into = 0;

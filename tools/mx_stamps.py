@@ -30,7 +30,7 @@ n = max(out[0], 1)
 print("regions %d; ticks per region: load + rows %d, look-back wait %d, on the chain %d, expansion %d" %
       (out[0], out[1] // n, out[2] // n, out[3] // n, out[4] // n))
 print("sum over the regions (ticks): rows %d, wait %d, chain %d, expansion %d" % (out[1], out[2], out[3], out[4]))
-for k in range(5, 24):
+for k in range(5, 27):
     if out[k]:
         print("  counter %d: %d  (%d per region)" % (k, out[k], out[k] // n))
 print("chain parts (ticks): ring fills %d (%d fills), walk %d (%d calls): tight loop %d (%d hops, %d words), "
@@ -38,3 +38,5 @@ print("chain parts (ticks): ring fills %d (%d fills), walk %d (%d calls): tight 
       (out[5], out[6], out[7], out[8], out[9], out[10], out[14], out[11], out[15], out[12], out[13]))
 print("general-path entries by reason: length of 254 bits and more %d, column outside the list's two groups %d, split leaves the rows %d, "
       "no column but a length from the children's %d" % (out[16], out[17], out[18], out[19]))
+
+print("per region (ticks): from the state words to the first walk %d, the walk's set-up %d, its end (publishing, staged items, records, state) %d; of the first: working the state out and putting it into LDS %d" % (out[22] // n, out[23] // n, out[24] // n, out[25] // n))
