@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   // all of whose significant children have one.  Such a set is then hopped over like any other, and its records are
   // the expansion's (which only ever needs the CHILDREN's columns), instead of being walked into: a round in there
   // costs four times this.  kTNone / kTInf: no luck.
-  auto chain_len = [&](uint32_t ci, uint32_t x) -> uint32_t {
+  auto chain_len_with = [&](auto&& bit_of, uint32_t ci, uint32_t x) -> uint32_t {
     if (ci >= b.tree.ncls || ci >= (uint32_t)kMaxCls)
       return kTNone;
     const uint32_t nk = sh_cls[ci].nk;
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       const uint32_t coded = found | (uint32_t)(k + 1 != nk);
       if (y > W)
         return kTInf;
-      const uint32_t bit = coded ? bit_at(y) : 1u;
+      const uint32_t bit = coded ? bit_of(y) : 1u;
       const uint32_t s0 = y + coded;
       if (!bit) {
         y += 1;
@@ -457,6 +457,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     }
     return y > W ? kTInf : y - x;
   };
+  auto chain_len = [&](uint32_t ci, uint32_t x) -> uint32_t { return chain_len_with(bit_at, ci, x); };
 
   // ---- the walk through the region (first wavefront, every lane carrying the same walker state): from
   //      sh_pos on until an item starts at or past S, or the list ends (depth 0)
@@ -533,6 +534,13 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     auto rl64 = [&](uint64_t v, uint32_t idx) -> uint64_t {
       return (uint64_t)rl32((uint32_t)v, idx) | ((uint64_t)rl32((uint32_t)(v >> 32), idx) << 32);
     };
+    // (a stream bit out of the words in the lane registers: two v_readlane instead of an LDS round trip -- the walk
+    //  into a set and the lengths worked out on the chain read a bit per child)
+    auto bit_w = [&](uint32_t rr) -> uint32_t {
+      const uint32_t q = rr + wq0;
+      return (uint32_t)(rl64(sw0, (q >> 6) & 63u) >> (q & 63u)) & 1u;
+    };
+    auto chain_len_w = [&](uint32_t ci, uint32_t x) -> uint32_t { return chain_len_with(bit_w, ci, x); };
     auto flush = [&]() {
       if (lane < ns && qn + lane < Q) {
         qidA[qn + lane] = stE;
@@ -815,7 +823,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
               wk_gInf++;       // leaves the rows
           }
           if (tl == kTNone) {
-            tl = chain_len(ci, r + 1u);
+            tl = chain_len_w(ci, r + 1u);
             if (kStamps && tl < kTNone)
               wk_gChain++;     // no column: length from the children's
           }
@@ -878,12 +886,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         if (col == 0) {   // a single sample
           uint32_t sig = 1, sgn, len = 1;
           if (coded) {
-            sig = bit_at(r);
-            sgn = sig ? bit_at(r + 1) : 1u;
+            sig = bit_w(r);
+            sgn = sig ? bit_w(r + 1) : 1u;
             len = 1u + sig;
           }
           else
-            sgn = bit_at(r);
+            sgn = bit_w(r);
           if (lane == 0)
             pixel_event(kid_pixel_raster(b.tree, unpack_node(parent), kb, k), sig != 0, sgn);
           found |= sig;
@@ -893,7 +901,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         }
         uint32_t start = r, bit = 1;
         if (coded) {
-          bit = bit_at(r);
+          bit = bit_w(r);
           start = r + 1;
         }
         if (!bit) {
@@ -907,7 +915,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         }
         uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)start * kMxCols + col] : kTNone;
         if (tl == kTNone)
-          tl = chain_len(pc < b.tree.ncls ? (uint32_t)sh_cls[pc].kid[k] : 0xffu, start);
+          tl = chain_len_w(pc < b.tree.ncls ? (uint32_t)sh_cls[pc].kid[k] : 0xffu, start);
         found = 1;
         if (tl < kTNone) {
           if (lane == k) {
