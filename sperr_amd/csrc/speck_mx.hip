@@ -38,6 +38,7 @@ namespace {
 
 constexpr int kMxThreads = 1024;
 constexpr int kMxCols = 16;
+constexpr int kMxColsAll = 17;   // + one column of its own array (`Tx`): the heaviest class the sixteen leave out, up to four steps up
 constexpr int kMxLdsRoots = 48, kMxLdsGrids = 352;   // (host: use_mixed checks that the tree fits)
 constexpr uint32_t kTInf = 0xffffu, kTNone = 0xfffeu;
 constexpr uint32_t kMxTagShift = 57;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   __shared__ Grid sh_grids[kMxLdsGrids];
   __shared__ uint8_t sh_gridCls[kMxLdsGrids * 8];
   __shared__ MxCtx sh_ctx[kMxFrames + 1];
-  __shared__ uint8_t sh_colCls[kMxCols];            // class of every column (0xff: unused)
+  __shared__ uint8_t sh_colCls[kMxColsAll + 3];     // class of every column (0xff: unused)
   __shared__ uint8_t sh_levelSlot[kMaxLevels];      // birth-mask slot of every list level
   __shared__ uint8_t sh_lgrp[kMaxLevels];           // the two column groups most entries of a list level belong to (2 bits each)
   __shared__ uint32_t sh_len[kMaxLevels], sh_lOff[kMaxLevels];
@@ -109,12 +110,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   const uint32_t nlevels = b.tree.nlevels;
   const bool twoD = (b.tree.flags & kTree2D) != 0;
   const uint32_t cur = s.cur;
-  if (tid < kMxCols)
+  if (tid < kMxColsAll + 3)
     sh_colCls[tid] = 0xff;
   if (tid < kMaxLevels) {
     const bool in = (uint32_t)tid < nlevels;
     sh_levelSlot[tid] = in ? b.levelSlot[tid] : (uint8_t)0xff;
-    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 63u) : (uint8_t)4;
+    sh_lgrp[tid] = in ? (uint8_t)(b.mxLevelGroup[tid] & 127u) : (uint8_t)4;
     sh_len[tid] = in ? s.listLen[cur][tid] : 0u;
     sh_lOff[tid] = in ? b.levelOff[tid] : 0u;
   }
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     sh_kcol[i] = kc;
     const uint8_t sl = b.mxSlot[i];
     sh_slot[i] = sl;
-    if (sl < kMxCols)
+    if (sl < kMxColsAll)
       sh_colCls[sl] = (uint8_t)i;
   }
 
@@ -165,7 +166,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
   uint64_t* const wbits = reinterpret_cast<uint64_t*>(mx_smem);
   const uint32_t* const w32 = reinterpret_cast<const uint32_t*>(mx_smem);
   uint16_t* const Tr = reinterpret_cast<uint16_t*>(mx_smem + (size_t)kWords * 8);   // [W + 3][16]
-  char* const ldsQ = mx_smem + (size_t)kWords * 8 + (((size_t)(W + 3) * kMxCols * 2 + 15) & ~(size_t)15);
+  uint16_t* const Tx = Tr + (size_t)(W + 3) * kMxCols;   // [W + 3]: column 16
+  char* const ldsQ = mx_smem + (size_t)kWords * 8 + (((size_t)(W + 3) * kMxColsAll * 2 + 15) & ~(size_t)15);
+  auto row_at = [&](uint32_t pos, uint32_t col) -> uint32_t { return col < (uint32_t)kMxCols ? Tr[(size_t)pos * kMxCols + col] : Tx[pos]; };
   uint64_t* const qidA = reinterpret_cast<uint64_t*>(ldsQ);
   uint32_t* const qmetaA = reinterpret_cast<uint32_t*>(qidA + Q);   // first bit | class << 16 | "list entry" << 24
   uint64_t* const qidB = reinterpret_cast<uint64_t*>(qmetaA + Q);
@@ -345,6 +348,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       uint4* row = reinterpret_cast<uint4*>(Tr + (size_t)x * kMxCols);
       row[0] = make_uint4(T0 | (T1 << 16), T2 | (T3 << 16), rest, rest);
       row[1] = make_uint4(rest, rest, rest, rest);
+      Tx[x] = (uint16_t)(x < W ? kTNone : kTInf);
       const uint64_t cm = __ballot(isCand);
       if (cm) {
         uint32_t base = 0;
@@ -361,7 +365,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     // positions (four per thread and round: their LDS round trips overlap)
     const uint32_t ncand = sh_ncand;
     uint32_t hPrev = 0;
-    for (uint32_t g4 = 4; g4 < (uint32_t)kMxCols; g4 += 4) {
+    for (uint32_t g4 = 4; g4 < (uint32_t)kMxColsAll + 3u; g4 += 4) {   // (16..19: only 16 exists, behind all the others)
       bool any = false;
       for (uint32_t col = g4; col < g4 + 4; col++) {
         const uint32_t ci = sh_colCls[col];
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             const uint32_t yy = min(y, W + 1);
             const uint32_t bitv = coded ? bit_at(yy) : 1u;
             const uint32_t s0 = yy + coded;
-            uint32_t t = Tr[(size_t)s0 * kMxCols + ccol];
+            uint32_t t = row_at(s0, ccol);
             if (t >= kTNone) {
               bad |= bitv ? (t == kTInf ? 1u : 2u) : 0u;
               t = 0;
@@ -394,7 +398,10 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             found |= bitv;
           }
           const uint32_t t = ((bad & 1u) || y > W) ? kTInf : (bad & 2u) ? kTNone : y - x;
-          Tr[(size_t)x * kMxCols + col] = (uint16_t)t;
+          if (col < (uint32_t)kMxCols)
+            Tr[(size_t)x * kMxCols + col] = (uint16_t)t;
+          else
+            Tx[x] = (uint16_t)t;
         }
       }
       if (any)
@@ -447,9 +454,9 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         y += 1;
         continue;
       }
-      if (col >= (uint32_t)kMxCols)
+      if (col >= (uint32_t)kMxColsAll)
         return kTNone;
-      const uint32_t t = Tr[(size_t)min(s0, W + 2) * kMxCols + col];
+      const uint32_t t = row_at(min(s0, W + 2), col);
       if (t >= kTNone)
         return t;
       y = s0 + t;
@@ -812,8 +819,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         uint32_t tl = kTNone;
         {   // its length from the rows in LDS
           const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
-          if (col < (uint32_t)kMxCols)
-            tl = Tr[(size_t)(r + 1u) * kMxCols + col];
+          if (col < (uint32_t)kMxColsAll)
+            tl = row_at(r + 1u, col);
           if (kStamps) {   // why the tight loop left this entry to the general code
             if (!(ec & 0x8000u) && tl < kTNone)
               wk_gSat++;       // in the view, 254 bits and more (or a list of fewer than 64 entries)
@@ -913,7 +920,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           k++;
           continue;
         }
-        uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)start * kMxCols + col] : kTNone;
+        uint32_t tl = col < (uint32_t)kMxColsAll ? row_at(start, col) : kTNone;
         if (tl == kTNone)
           tl = chain_len_w(pc < b.tree.ncls ? (uint32_t)sh_cls[pc].kid[k] : 0xffu, start);
         found = 1;
@@ -1117,7 +1124,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           }
           found = 1;
           // (an implied child is the last one: nothing follows it, its length is not needed)
-          const uint32_t tl = (coded && col < (uint32_t)kMxCols) ? (uint32_t)Tr[(size_t)min(start, W + 2) * kMxCols + col] : 0u;
+          const uint32_t tl = (coded && col < (uint32_t)kMxColsAll) ? row_at(min(start, W + 2), col) : 0u;
           y = min(start + (tl < kTNone ? tl : 0u), W + 2);
           if (col < 4u)
             leaf_event(unpack_node(kid_packed(kb, k)), start, 1u << col);
@@ -1182,7 +1189,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           }
         }
         if (twoD)
-          hc = 3;   // (the subbands the type-I set releases are tested behind the lists)
+          hc = 4;   // (the subbands the type-I set releases are tested behind the lists)
         sh_hcap = hc;
       }
       sh_qn[0] = sh_qn[1] = 0;
@@ -1570,7 +1577,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
           const Node rn = unpack_node(root);
           const uint32_t ci = node_cls_l(rn);
           const uint32_t col = ci < (uint32_t)kMaxCls ? sh_slot[ci] : 0xffu;
-          uint32_t tl = col < (uint32_t)kMxCols ? (uint32_t)Tr[(size_t)(r + 1u) * kMxCols + col] : kTNone;
+          uint32_t tl = col < (uint32_t)kMxColsAll ? row_at(r + 1u, col) : kTNone;
           if (tl == kTNone)
             tl = chain_len(ci, r + 1u);
           if (tl < kTNone) {
@@ -1697,7 +1704,7 @@ uint32_t mx_smem_bytes(uint32_t S, uint32_t M, uint32_t Q)
 {
   const uint32_t W = S + M;
   const uint32_t kWords = ((W >> 6) + 5u) & ~1u;
-  return kWords * 8u + (((W + 3u) * (uint32_t)kMxCols * 2u + 15u) & ~15u) + 2u * Q * 12u + kMxRing * 2u;
+  return kWords * 8u + (((W + 3u) * 17u * 2u + 15u) & ~15u) + 2u * Q * 12u + kMxRing * 2u;
 }
 
 int prepare_lis_mx(const DecBuffers& b)

@@ -374,6 +374,25 @@ inline void build_mx_columns(HostTree& h)
     for (size_t k = 0; k < sel.size(); k++)
       h.mxSlot[sel[k]] = (uint8_t)(4 + k);
   }
+  {   // one more, in an array of its own (column 16): the heaviest class left, up to four steps up
+    int best = -1;
+    double bestW = 0.0;
+    for (size_t i = 0; i < h.cls.size(); i++) {
+      const ShapeCls& c = h.cls[i];
+      if (h.mxSlot[i] != 0xff || c.h == 0 || c.h > 4 || c.maxT >= 0x7000u || h.clsCount[i] == 0)
+        continue;
+      bool ok = true;
+      for (int k = 0; k < c.nk; k++)
+        ok = ok && (c.kid[k] == kClsPixel || h.mxSlot[c.kid[k]] != 0xff);
+      const double w = (double)h.clsCount[i] * (double)(1u << c.h);
+      if (ok && w > bestW) {
+        bestW = w;
+        best = (int)i;
+      }
+    }
+    if (best >= 0)
+      h.mxSlot[best] = 16;
+  }
   std::vector<std::array<uint64_t, kMxGroups>> cnt(h.nlevels);
   std::vector<uint32_t> top(h.nlevels, 0);   // the most steps above the leaf parents a set of the level can be
   for (auto& c : cnt)
@@ -398,8 +417,8 @@ inline void build_mx_columns(HostTree& h)
           const uint32_t l = node_level(tv, n);
           if (l >= h.nlevels)
             continue;
-          top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, 3));
-          if (h.mxSlot[ci] != 0xff)
+          top[l] = std::max<uint32_t>(top[l], std::min<uint32_t>(h.cls[ci].h, 4));
+          if (h.mxSlot[ci] < 16)
             cnt[l][h.mxSlot[ci] >> 2]++;
         }
   }

@@ -1908,6 +1908,14 @@ int model_check_mx_columns(const size_t dims[3], int twoD, int* ncols)
     }
     if (sl == 0xff)
       continue;
+    if (sl == 16) {   // (the one column beside the sixteen: up to four steps up, children with columns)
+      if (c.h == 0 || c.h > 4 || c.maxT >= 0x7000u)
+        return 4;
+      for (int k = 0; k < c.nk; k++)
+        if (c.kid[k] != kClsPixel && ht.mxSlot[c.kid[k]] == 0xff)
+          return 5;
+      continue;
+    }
     if (sl < 4 || sl >= 16 || used[sl]++)
       return 3;
     n++;
@@ -1922,12 +1930,12 @@ int model_check_mx_columns(const size_t dims[3], int twoD, int* ncols)
       return 6;   // (columns are handed out without gaps)
   for (size_t i = 0; i < ht.cls.size(); i++)
     for (size_t j = 0; j < ht.cls.size(); j++)
-      if (ht.mxSlot[i] >= 4 && ht.mxSlot[i] != 0xff && ht.mxSlot[j] >= 4 && ht.mxSlot[j] != 0xff &&
+      if (ht.mxSlot[i] >= 4 && ht.mxSlot[i] < 16 && ht.mxSlot[j] >= 4 && ht.mxSlot[j] < 16 &&
           ht.cls[i].h < ht.cls[j].h && ht.mxSlot[i] > ht.mxSlot[j])
         return 7;
   for (uint32_t l = 0; l < ht.nlevels; l++) {
     const uint32_t ga = ht.mxLevelGroup[l] & 3u, gb = (ht.mxLevelGroup[l] >> 2) & 3u;
-    if (ga == gb || (ht.mxLevelGroup[l] >> 6))
+    if (ga == gb || (ht.mxLevelGroup[l] >> 7))
       return 8;
   }
   if (ncols)
