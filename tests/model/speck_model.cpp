@@ -1764,10 +1764,11 @@ int model_speck1d_decode_batched(const uint8_t* stream, size_t len, size_t n, ui
     foundNow.push_back(x);
   };
   struct Rec {
-    uint32_t es, el, R, u, tEnd, sg, closed;
+    uint32_t es, el, R, u, tEnd, sg, closed, raw;   // raw: the path's own bits with its sign on top (what chain_p2's records hold)
   };
   std::vector<Rec> recs;
   int rc = 0;
+  uint32_t rCarry = 0;   // R of the last record of the batch before
   auto low = [](uint32_t k) -> uint32_t { return k >= 32 ? ~0u : (1u << k) - 1u; };
   for (int p = nbp - 1; p >= 0 && rc == 0; p--) {
     foundNow.clear();
@@ -1778,6 +1779,41 @@ int model_speck1d_decode_batched(const uint8_t* stream, size_t len, size_t n, ui
       }
     for (uint32_t lev = nlists; lev-- > 0 && rc == 0;) {
       auto flush = [&]() {
+        // k_speck1d's flush_paths works R out of the raw records of runs of 2^g values (sperr_amd/csrc/outlier.hip,
+        // chain_p2): a record is "keep R below depth u - 1, set bit u - 1, my bits from u on"; the (keep, value) pairs
+        // compose, so log2(batch) steps over the lanes give every R.  Checked here against the R the chain carried along.
+        {
+          const size_t nr = recs.size();
+          std::vector<uint32_t> keep(nr), val(nr);
+          for (size_t k = 0; k < nr; k++) {
+            const Rec& r = recs[k];
+            if ((r.el & (r.el - 1u)) == 0u) {
+              const uint32_t ns = r.tEnd - r.u;
+              keep[k] = r.u ? low(r.u - 1u) : 0u;
+              val[k] = (r.u ? 1u << (r.u - 1u) : 0u) | ((~r.raw & low(ns)) << r.u);
+              if (((r.raw >> ns) & 1u) != r.sg)
+                rc = -8;
+            }
+            else {
+              keep[k] = 0;
+              val[k] = r.R;
+            }
+          }
+          for (size_t off = 1; off < nr; off <<= 1) {
+            std::vector<uint32_t> k2 = keep, v2 = val;
+            for (size_t k = off; k < nr; k++) {
+              v2[k] = (val[k - off] & keep[k]) | val[k];
+              k2[k] = keep[k] & keep[k - off];
+            }
+            keep.swap(k2);
+            val.swap(v2);
+          }
+          for (size_t k = 0; k < nr; k++)
+            if (((rCarry & keep[k]) | val[k]) != recs[k].R)
+              rc = -7;
+          if (nr)
+            rCarry = recs[nr - 1].R;
+        }
         // one depth per round, all records of the batch side by side
         std::vector<uint32_t> s(recs.size()), l(recs.size());
         for (size_t k = 0; k < recs.size(); k++) {
@@ -1855,7 +1891,7 @@ int model_speck1d_decode_batched(const uint8_t* stream, size_t len, size_t n, ui
             m &= ~(1u << top);
             closed |= 1u << top;
           }
-          recs.push_back({r.s, r.l, R, u, u + nsteps, sg, closed});
+          recs.push_back({r.s, r.l, R, u, u + nsteps, sg, closed, (uint32_t)peek & low(nsteps + 1u)});
           if (recs.size() == batch)
             flush();
           rpos += nsteps + 1u + z;

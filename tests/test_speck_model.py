@@ -279,7 +279,9 @@ def test_model_1d_coder_paths(oracle, model, n, k, top):
     """The coder of the outlier list in the kernels' formulations (tests/model/speck_model.cpp::
     model_speck1d_encode / _decode): the encoder gives every outlier of a significant run one path found from
     its position and its neighbours, the decoder parses a whole path per step with the run lengths in closed
-    form -- the oracle's stream byte for byte, and the values back from it."""
+    form -- the oracle's stream byte for byte, and the values back from it.  The batched decoder model also works R out of
+    the raw records of runs of 2^g values with the scan k_speck1d's flush_paths uses for the asm chain's records
+    (sperr_amd/csrc/outlier.hip, chain_p2) and checks it against the R the chain carried along (-7 / -8 if not)."""
     from oracle.pyoracle import pack_mask, unpack_mask
     lib = model
     lib.model_speck1d_encode.argtypes = [_vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]
