@@ -1335,14 +1335,19 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
       else if (sh_abort || (sh_in[0] & kMxOver))
         stop = 1;
       else {
-        const unsigned long long f0 = sh_in[0], f1 = sh_in[1], f5 = sh_in[5];
+        // (the same in every lane: as scalars, so that the rest is scalar code)
+        auto uni = [&](unsigned long long v) -> unsigned long long {
+          return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+        };
+        const unsigned long long f0 = uni(sh_in[0]), f1 = uni(sh_in[1]), f5 = uni(sh_in[5]);
         pos = phase0 + (f0 & ((1ull << 40) - 1ull));
         level = (uint32_t)(f0 >> 40) & 63u;
         depth = (int)((f0 >> 46) & 31u);
         mode = (uint32_t)(f0 >> 51) & 3u;
         e = (uint32_t)f1;
-        rem = (uint32_t)sh_in[6];
-        base = sh_in[4] & ((1ull << kMxTagShift) - 1ull);
+        rem = (uint32_t)uni(sh_in[6]);
+        base = uni(sh_in[4]) & ((1ull << kMxTagShift) - 1ull);
         iJ = (uint32_t)f5 & 3u;
         iPart = (uint32_t)(f5 >> 2) & 63u;
         iCounter = (uint32_t)(f5 >> 8) & 3u;
