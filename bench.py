@@ -82,8 +82,10 @@ def run_host_path(eng, vol, chunks, bpp, devices, reps, dev_stream, dev_out, mod
         assert rc == 0, f"sperrhip_decomp_3d_into returned {rc}"
         return t1 - t0
 
+    from sperr_amd.api import host_throttle
     tc, td = [], []
     same = None
+    thr0 = host_throttle(lib)
     for it in range(reps + 1):          # the first pass allocates the staging buffers: untimed
         dst, n, a = comp(hvol.data_ptr())
         b = decomp(dst, n, hout.data_ptr())
@@ -96,6 +98,7 @@ def run_host_path(eng, vol, chunks, bpp, devices, reps, dev_stream, dev_out, mod
             tc.append(a)
             td.append(b)
         libc.free(dst)
+    thr1 = host_throttle(lib)
     c, d = min(tc), min(td)
     what = f"BPP {bpp}" if mode == 1 else f"point-wise error mode, tolerance {bpp:.4g}, outlier coder"
     res = {
@@ -108,6 +111,10 @@ def run_host_path(eng, vol, chunks, bpp, devices, reps, dev_stream, dev_out, mod
         "round_trip_GBps": round(nbytes / (c + d) / 1e9, 3),
         "compress_ms": round(c * 1e3, 2), "decompress_ms": round(d * 1e3, 2),
         "container_bytes": int(n),
+        # CFS throttling of this process's cgroup over the reps + 1 passes above (cpu.stat deltas): a host
+        # path that misses its rate on a box whose quota was exhausted says so here
+        "cfs_throttle": (None if thr0 is None or thr1 is None else
+                         {"nr_throttled": thr1[0] - thr0[0], "throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 2)}),
     }
     if mode == 3:
         err = float((hout.double() - hvol.double()).abs().max().item())
@@ -473,17 +480,25 @@ def main():
         from oracle import pyoracle
         n = min(args.cpu_sample, S)
         sample = vol[:n, :n, :n].contiguous().cpu().numpy()
-        cores = os.cpu_count() or 1
+        # threads: what this process MAY use -- min(affinity mask, cgroup CFS quota), not os.cpu_count() (the
+        # pool's GPU box shows 256 CPUs and grants the pod 16: 64 OpenMP threads on 16 CPUs of quota is a
+        # throttled run, round 4's mistake) -- and no more than there are chunks, since the reference's chunk
+        # loop gives a thread one chunk at a time (SPERR3D_OMP_C.cpp:94)
+        from sperr_amd.api import host_cpus, host_throttle
+        hc = host_cpus(eng.lib)
         nch = max(1, (n // C)) ** 3
+        cores = max(1, min(hc["usable"], nch))
         if pyoracle.have_ref():
             impl, kind = pyoracle.Ref(), "reference"
         else:
             impl, kind = pyoracle.Oracle(), "port"
+        thr_a = host_throttle(eng.lib)
         a = time.perf_counter()
         cs = impl.comp_3d(sample, chunks, 1, args.bpp, nthreads=cores)
         b = time.perf_counter()
         impl.decomp_3d(cs, True, nthreads=cores)
         c = time.perf_counter()
+        thr_b = host_throttle(eng.lib)
         # parity of the timed data: the HIP container of the same sample must be byte-identical
         if n == S:
             hs = bytes(stream.cpu().numpy())
@@ -497,10 +512,14 @@ def main():
         d1 = time.perf_counter()
         cpu = {
             "value": round(sample.nbytes / (c - a) / 1e9, 4), "unit": "GB/s", "cores": cores,
-            "effective_threads": min(cores, nch),
+            "nthreads_used": cores, "cores_visible": hc["cores_visible"], "affinity_cpus": hc["affinity"],
+            "cpu_quota": hc["cpu_quota"],
+            "cfs_throttle": (None if thr_a is None or thr_b is None else
+                             {"nr_throttled": thr_b[0] - thr_a[0], "throttled_ms": round((thr_b[1] - thr_a[1]) / 1e3, 2)}),
             "kind": kind,
-            "sample": f"{n}^3 fp32 of the bench volume ({nch} chunks of {C}^3), bpp {args.bpp}, all {cores} "
-                      f"threads offered: compress {b - a:.2f} s + decompress {c - b:.2f} s",
+            "sample": f"{n}^3 fp32 of the bench volume ({nch} chunks of {C}^3), bpp {args.bpp}, {cores} OpenMP "
+                      f"threads = min(CPUs this process may use: {hc['usable']} of {hc['cores_visible']} visible, "
+                      f"chunks: {nch}): compress {b - a:.2f} s + decompress {c - b:.2f} s",
             "compress_GBps": round(sample.nbytes / (b - a) / 1e9, 4),
             "decompress_GBps": round(sample.nbytes / (c - b) / 1e9, 4),
             "one_thread": {"sample": f"one {C}^3 chunk", "compress_GBps": round(one.nbytes / (b1 - a1) / 1e9, 4),

@@ -99,6 +99,22 @@ int sperrhip_numa_probe(const char* sysfs_root, const char* pci_bdf, int* node, 
                         size_t cpus_cap, size_t* ncpus);
 int sperrhip_numa_bind_self(const char* sysfs_root, const char* pci_bdf);
 int sperrhip_farm_device_place(int dev, char* bdf, size_t bdf_cap, int* node, size_t* ncpus);
+/* Host CPUs this process may use, and what the farm does with them (host only, no device touched).
+ * The reference sizes its chunk loop by the caller's nthreads, 0 = omp_get_max_threads()
+ * (/root/reference/src/SPERR3D_OMP_C.cpp:12-20).  The farm starts threads of its own, and sizes them by
+ * min(affinity mask, cgroup CFS quota) -- cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us, the
+ * tightest over the process's group and its ancestors -- never by the machine's CPU count: a container
+ * that shows 256 CPUs and grants 16 throttles what runs beyond 16.  cgroup_root / proc_cgroup NULL = the
+ * system's (SPERR_HIP_CGROUP_ROOT / SPERR_HIP_PROC_CGROUP name others).  quota_cpus 0 = unlimited.
+ * sperrhip_host_throttle reads cpu.stat (returns 1 when there is none).  sperrhip_farm_threads reports
+ * the thread plan for ndevices devices. */
+int sperrhip_host_cpus(const char* cgroup_root, const char* proc_cgroup, size_t* visible, size_t* affinity,
+                       double* quota_cpus, size_t* usable);
+int sperrhip_host_throttle(const char* cgroup_root, const char* proc_cgroup, unsigned long long* nr_throttled,
+                           unsigned long long* throttled_usec);
+int sperrhip_farm_threads(size_t nthreads, size_t ndevices, size_t* workers_per_device,
+                          size_t* dec_workers_per_device, size_t* helpers_per_worker, size_t* threads_total,
+                          size_t* cpus_usable);
 
 /* ---- device-resident API ---------------------------------------------------------------------- */
 

@@ -32,11 +32,34 @@ EXPORTS = [
     "sperrhip_comp_3d_farm", "sperrhip_decomp_3d_farm", "sperrhip_decomp_3d_into",
     "sperrhip_farm_selftest", "sperrhip_release", "sperrhip_debug_counter",
     "sperrhip_numa_probe", "sperrhip_numa_bind_self", "sperrhip_farm_device_place",
+    "sperrhip_host_cpus", "sperrhip_host_throttle", "sperrhip_farm_threads",
 ]
 
 
 class SperrHipError(RuntimeError):
     pass
+
+
+def host_cpus(lib):
+    """CPUs this process may use, as the library's farm sees them (sperr_amd/csrc/host_cpus.hpp): the machine's
+    count, the affinity mask, the cgroup's CFS quota in CPUs (0.0: none) and the smallest of them."""
+    vis, aff, use = _sz(0), _sz(0), _sz(0)
+    quota = C.c_double(0.0)
+    lib.sperrhip_host_cpus.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_double),
+                                       C.POINTER(_sz)]
+    rc = lib.sperrhip_host_cpus(None, None, C.byref(vis), C.byref(aff), C.byref(quota), C.byref(use))
+    if rc != 0:
+        raise SperrHipError(f"sperrhip_host_cpus returned {rc}")
+    return {"cores_visible": vis.value, "affinity": aff.value, "cpu_quota": quota.value or None, "usable": use.value}
+
+
+def host_throttle(lib):
+    """(nr_throttled, throttled_usec) of the process's cgroup so far, or None when there is no cpu.stat"""
+    nr, us = C.c_ulonglong(0), C.c_ulonglong(0)
+    lib.sperrhip_host_throttle.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    if lib.sperrhip_host_throttle(None, None, C.byref(nr), C.byref(us)) != 0:
+        return None
+    return nr.value, us.value
 
 
 def load_library():

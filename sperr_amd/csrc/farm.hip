@@ -48,6 +48,7 @@
 #include "common.h"
 #include "engine_internal.h"
 #include "numa_place.hpp"
+#include "host_cpus.hpp"
 
 namespace sperrhip {
 namespace {
@@ -82,13 +83,19 @@ FarmShape farm_shape(size_t nthreads, size_t ndev)
   f.itemBytesMax = env_size("SPERR_HIP_FARM_ITEM_MB", 768) << 20;
   f.itemChunksForced = env_size("SPERR_HIP_FARM_ITEM", 0);
   // `nthreads` (the reference's OpenMP team size, src/SPERR3D_OMP_C.cpp:12-20) is taken as the
-  // number of host threads that move rows between the caller's buffers and the staging buffers
-  // (default: half of the host's threads shared out to the workers, 4 to 12 each; measured on a
-  //  256-thread host with one MI355X, pageable 1024^3 volume: 4 -> 8 helpers per worker gains 8 %)
-  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-  size_t helpers = std::min<size_t>(12, std::max<size_t>(4, hw / (2 * std::max<size_t>(1, ndev * f.workersPerDevice))));
+  // number of host threads that move rows between the caller's buffers and the staging buffers.
+  // Default: half of the CPUs THIS PROCESS MAY USE shared out to the workers, at most 12 each
+  // (measured on a 256-thread host with one MI355X, pageable 1024^3 volume: 4 -> 8 helpers per worker
+  // gains 8 %).  "May use" is the affinity mask and the cgroup's CFS quota (host_cpus.hpp), not
+  // hardware_concurrency(): the pool's box shows 256 CPUs and grants 16, and worker + helper threads
+  // beyond the quota are throttled, not run -- eight devices x two workers on 16 CPUs get one helper each.
+  const size_t hw = hostcpu::probe().usable;
+  const size_t nworkers = std::max<size_t>(1, ndev * f.workersPerDevice);
+  size_t helpers = std::min<size_t>(12, std::max<size_t>(1, hw / (2 * nworkers)));
+  if (hw >= 8 * nworkers)   // (room for it: never fewer than four, as rounds 1-4 had it)
+    helpers = std::max<size_t>(helpers, 4);
   if (nthreads > 0)
-    helpers = std::max<size_t>(1, nthreads / std::max<size_t>(1, ndev * f.workersPerDevice));
+    helpers = std::max<size_t>(1, nthreads / nworkers);
   f.helpers = env_size("SPERR_HIP_FARM_HELPERS", helpers);
   return f;
 }
@@ -1250,6 +1257,70 @@ int sperrhip_numa_bind_self(const char* sysfs_root, const char* pci_bdf)
       return 0;
     const numa::Place pl = numa::probe(sysfs_root && *sysfs_root ? std::string(sysfs_root) : numa::sysfs_root(), pci_bdf);
     return (int)numa::bind_self(pl);
+  });
+}
+// host only: the CPUs this process may use (host_cpus.hpp) -- what the farm sizes its threads by.
+// cgroup_root / proc_cgroup NULL = /sys/fs/cgroup and /proc/self/cgroup (or SPERR_HIP_CGROUP_ROOT /
+// SPERR_HIP_PROC_CGROUP).  quota_cpus 0 = no CFS limit found.
+int sperrhip_host_cpus(const char* cgroup_root, const char* proc_cgroup, size_t* visible, size_t* affinity,
+                       double* quota_cpus, size_t* usable)
+{
+  return guarded_farm("sperrhip_host_cpus", [&]() -> int {
+    const hostcpu::Budget b = (cgroup_root && *cgroup_root)
+                                  ? hostcpu::probe(cgroup_root, (proc_cgroup && *proc_cgroup) ? proc_cgroup : "/proc/self/cgroup")
+                                  : hostcpu::probe();
+    if (visible)
+      *visible = b.visible;
+    if (affinity)
+      *affinity = b.affinity;
+    if (quota_cpus)
+      *quota_cpus = b.quota;
+    if (usable)
+      *usable = b.usable;
+    return 0;
+  });
+}
+// host only: CFS throttling of the process's cgroup so far (cpu.stat: nr_throttled, throttled_usec);
+// 1 when no cpu.stat with those fields was found (then both are 0)
+int sperrhip_host_throttle(const char* cgroup_root, const char* proc_cgroup, unsigned long long* nr_throttled,
+                           unsigned long long* throttled_usec)
+{
+  return guarded_farm("sperrhip_host_throttle", [&]() -> int {
+    const char* r = getenv("SPERR_HIP_CGROUP_ROOT");
+    const char* q = getenv("SPERR_HIP_PROC_CGROUP");
+    const std::string root = (cgroup_root && *cgroup_root) ? cgroup_root : ((r && *r) ? r : "/sys/fs/cgroup");
+    const std::string proc = (proc_cgroup && *proc_cgroup) ? proc_cgroup : ((q && *q) ? q : "/proc/self/cgroup");
+    unsigned long long nr = 0, us = 0;
+    const bool ok = hostcpu::throttle_stat(root, proc, nr, us);
+    if (nr_throttled)
+      *nr_throttled = nr;
+    if (throttled_usec)
+      *throttled_usec = us;
+    return ok ? 0 : 1;
+  });
+}
+// host only: the farm's thread plan for `ndevices` devices and a caller's `nthreads` (0: the library's
+// choice) -- workers per device (compress / decompress), helper threads per worker, and the sum of
+// worker + helper threads of a compression against the CPUs the process may use
+int sperrhip_farm_threads(size_t nthreads, size_t ndevices, size_t* workers_per_device, size_t* dec_workers_per_device,
+                          size_t* helpers_per_worker, size_t* threads_total, size_t* cpus_usable)
+{
+  return guarded_farm("sperrhip_farm_threads", [&]() -> int {
+    if (ndevices == 0)
+      return -1;
+    const FarmShape fs = farm_shape(nthreads, ndevices);
+    const size_t decW = env_size("SPERR_HIP_FARM_DEC_WORKERS", fs.workersPerDevice);
+    if (workers_per_device)
+      *workers_per_device = fs.workersPerDevice;
+    if (dec_workers_per_device)
+      *dec_workers_per_device = decW;
+    if (helpers_per_worker)
+      *helpers_per_worker = fs.helpers;
+    if (threads_total)
+      *threads_total = ndevices * fs.workersPerDevice * (1 + fs.helpers);
+    if (cpus_usable)
+      *cpus_usable = hostcpu::probe().usable;
+    return 0;
   });
 }
 // where the farm puts the workers of device `dev`: its PCI address (bdf_cap bytes of room), NUMA
