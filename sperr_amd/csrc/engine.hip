@@ -2006,8 +2006,9 @@ struct DecBatchBufs {
 };
 
 // valsElems: fp64 samples per chunk of the chunk buffer (0: the whole chunk; compact_box() otherwise)
+// refNPlanes: refinement bit planes per chunk (DecBuffers::refPlanes; 0: the coefficients are updated plane by plane)
 bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o,
-               size_t valsElems = 0)
+               size_t valsElems = 0, uint32_t refNPlanes = 0)
 {
   const size_t N = P.N, Npad = round_up(N, 256);
   DecBuffers& d = o.db;
@@ -2035,6 +2036,19 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.signStride = Npad / 64;
   TAKE(d.sign, uint64_t, d.signStride * B);
   d.maskPixStride = Npad / 64;
+  d.refPlanes = nullptr;
+  d.refMask = nullptr;
+  d.wordTop = nullptr;
+  d.refNPlanes = 0;
+  d.refPlaneStride = d.wordTopStride = 0;
+  if (refNPlanes) {
+    d.refNPlanes = refNPlanes;
+    d.refPlaneStride = (size_t)refNPlanes * d.maskPixStride;
+    d.wordTopStride = round_up(d.maskPixStride, 64);
+    TAKE(d.refPlanes, uint64_t, d.refPlaneStride * B);
+    TAKE(d.refMask, uint64_t, d.maskPixStride * B);
+    TAKE(d.wordTop, uint8_t, d.wordTopStride * B);
+  }
   TAKE(d.bornM, uint64_t, d.maskPixStride * B);
   TAKE(d.sigOld, uint64_t, d.maskPixStride * B);
   TAKE(d.sigNew, uint64_t, d.maskPixStride * B);
@@ -2339,13 +2353,29 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
     deferOff = 0;
     return rc;
   };
-  auto bytes_per_chunk = [&](const ShapePlan& P, uint64_t maxPayload, size_t valsElems = 0) -> size_t {
+  auto bytes_per_chunk = [&](const ShapePlan& P, uint64_t maxPayload, size_t valsElems = 0, uint32_t refNPlanes = 0) -> size_t {
     Arena probe;
     probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
-    carve_dec(probe, P, 1, maxPayload, tmp, valsElems);
+    carve_dec(probe, P, 1, maxPayload, tmp, valsElems, refNPlanes);
     return probe.used;
+  };
+  // Refinement bit planes (speck_dec.h, DecBuffers::refPlanes): as many as the chunks of a group with 32-bit
+  // coefficients have planes (byte 17 of a chunk: src/SPECK_INT.cpp:284-308); not for a slice that goes through
+  // the quadtree walk of speck2d.hip, which updates coefficients itself.  SPERR_HIP_REF_PLANES=0: none
+  // (k_ref_apply2 updates the coefficients plane by plane, as rounds 3 and 4 did).
+  static const bool refPlanesEnv = !(getenv("SPERR_HIP_REF_PLANES") && atoi(getenv("SPERR_HIP_REF_PLANES")) == 0);
+  auto ref_planes_of = [&](const ShapePlan& P, const std::vector<Ref>& refs) -> uint32_t {
+    if (!refPlanesEnv || (slice && !(P.ht.flags & spk::kTree2D)))
+      return 0;
+    uint32_t n = 0;
+    for (const Ref& r : refs) {
+      const uint8_t* hd = heads.data() + (size_t)r.gid * 32;
+      if (ci.len[r.gid] >= 26 && !(hd[0] & 0x01) && hd[17] <= 32)
+        n = std::max<uint32_t>(n, hd[17]);
+    }
+    return n;
   };
   // The fp64 chunk buffer of a group can be COMPACT (round 3): when the finest level runs as the fused
   // x-y-z kernel and every inverse pass dequantises the samples no coarser level produces straight
@@ -2426,7 +2456,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         for (auto& r : h.second)
           mp = std::max<uint64_t>(mp, ci.len[r.gid]);
         uint32_t qbox[3];
-        sum += round_up(h.second.size() * bytes_per_chunk(*Q, mp, compact_box(*Q, h.second, qbox)) + (1 << 20), 4096);
+        sum += round_up(h.second.size() * bytes_per_chunk(*Q, mp, compact_box(*Q, h.second, qbox), ref_planes_of(*Q, h.second)) + (1 << 20), 4096);
       }
       size_t fr = 0, tot = 0;
       HIP_CHECK(hipMemGetInfo(&fr, &tot));
@@ -2439,7 +2469,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       maxPayload = std::max<uint64_t>(maxPayload, ci.len[r.gid]);
     uint32_t cbox[3];
     const size_t compactElems = compact_box(*P, g.second, cbox);
-    const size_t per = bytes_per_chunk(*P, maxPayload, compactElems);
+    const uint32_t refNPlanes = ref_planes_of(*P, g.second);
+    const size_t per = bytes_per_chunk(*P, maxPayload, compactElems, refNPlanes);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     const size_t budgetBytes = arena_budget(E.arena.n, fr);
@@ -2515,7 +2546,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         S.nb = (nbAll - done + (nsub - q) - 1) / (nsub - q);
         S.first = b0 + done;
         done += S.nb;
-        if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb, compactElems))
+        if (S.nb && !carve_dec(A, *P, S.nb, maxPayload, S.bb, compactElems, refNPlanes))
           return -1;
         if (S.nb && compactElems)
           g_dbg_counter[2]++;
@@ -2679,8 +2710,11 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           if (wide) {  // 64-bit magnitudes live in the fp64 buffer, converted in place afterwards
             dw.coef = bb.vals;
             dw.coefStride = bb.valsStride;
+            dw.refPlanes = nullptr;
             HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, ss));
           }
+          else if (d.refPlanes)   // (k_ref_assemble writes every coefficient; a plane's words are valid from wordTop down)
+            HIP_CHECK(hipMemsetAsync(d.wordTop, 0, d.wordTopStride * nb, ss));
           else
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
           if (slice && !(P->ht.flags & spk::kTree2D)) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
@@ -3568,14 +3602,17 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // size probe only
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
-    carve_dec(probe, *P, 1, 17 + stream_len, tmp);
+    // (refinement bit planes like decompress_impl's: SPERR_HIP_REF_PLANES=0 switches them off)
+    static const bool refPlanesEnv = !(getenv("SPERR_HIP_REF_PLANES") && atoi(getenv("SPERR_HIP_REF_PLANES")) == 0);
+    const uint32_t refNPlanes = (refPlanesEnv && !wide) ? (uint32_t)nbp : 0u;
+    carve_dec(probe, *P, 1, 17 + stream_len, tmp, 0, refNPlanes);
     if (E.arena.ensure(probe.used + 4096))
       return -1;
     Arena A;
     A.base = static_cast<char*>(E.arena.p);
     A.cap = E.arena.n;
     DecBatchBufs bb;
-    if (!carve_dec(A, *P, 1, 17 + stream_len, bb))
+    if (!carve_dec(A, *P, 1, 17 + stream_len, bb, 0, refNPlanes))
       return -1;
     DecBuffers d = bb.db;
     const uint64_t off = 0, len = 17 + stream_len;
@@ -3598,6 +3635,8 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
       d.coefStride = bb.valsStride;
       HIP_CHECK(hipMemsetAsync(bb.vals, 0, (size_t)n * 8, st));
     }
+    else if (d.refPlanes)
+      HIP_CHECK(hipMemsetAsync(d.wordTop, 0, d.wordTopStride, st));
     else
       HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
     DecPlanHost ph{P->d_initLIS, P->d_initLen, use_tables(*P),

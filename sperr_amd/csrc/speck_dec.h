@@ -15,6 +15,8 @@ struct DecState {
   uint32_t nLip, nRef;           // candidates of the current plane's pixel passes
   uint32_t nLeafEv;              // leaf events of the plane just decoded
   int32_t lastPlane;             // last plane whose sorting pass ran
+  int32_t refPlaneP1;            // 1 + the last plane whose refinement pass ran (0: none yet)
+  uint32_t refPartial;           //   ... and the stream ended inside that pass
   uint64_t pos;                  // next unread bit
   uint64_t avail;                // usable bits of the stream
   uint64_t total_bits;
@@ -60,6 +62,22 @@ struct DecBuffers {
   size_t maskPixStride;
   void* coef;                  // uint32_t or uint64_t magnitudes being reconstructed
   size_t coefStride;
+  // Refinement bit planes (32-bit coefficients; round 5, after an experiment of round 3): the refinement pass
+  // does not touch the coefficients.  refPlanes[plane][word] holds, one bit per sample in raster order, bit
+  // `plane` of every magnitude -- the '1' of the plane a sample was found on (added by k_dec_count) and the
+  // refinement bits of the planes below (k_ref_deposit: one 8-byte store per mask word instead of a 4-byte
+  // read-modify-write per candidate scattered over 64 MB).  A word of a plane is valid from the plane on which
+  // the word's first sample became significant downwards: wordTop[word] = 1 + that plane (0: none), so nothing
+  // is cleared beforehand and k_ref_assemble reads only the planes a word has.  k_ref_assemble writes every
+  // coefficient once after the last plane (src/SPECK_INT.cpp:359-469: found at p0, refined down to q ->
+  // magnitude bits + 2^(q-1) - 1).  refMask: the candidates that got a bit in a pass the stream's end cut
+  // short.  nullptr: k_ref_apply2 updates the coefficients plane by plane (64-bit coefficients, the 2D walk).
+  uint64_t* refPlanes;
+  size_t refPlaneStride;       // words per chunk (refNPlanes x maskPixStride)
+  uint32_t refNPlanes;
+  uint64_t* refMask;
+  uint8_t* wordTop;
+  size_t wordTopStride;
   uint64_t* sign;              // initialised to all ones (SPECK_INT.cpp:174-175)
   size_t signStride;
   uint64_t* lis[2];

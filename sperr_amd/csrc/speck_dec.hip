@@ -50,6 +50,8 @@ __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint6
   const uint64_t len = chunkLen[c];
   s.active = 0;
   s.done = 0;
+  s.refPlaneP1 = 0;
+  s.refPartial = 0;
   s.nbp = 0;
   s.pos = 0;
   s.cur = 0;
@@ -231,6 +233,17 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
       }
     }
     if (fresh | (ls & ~sig)) {
+      if (b.refPlanes) {
+        // found on plane p + 1: bit p + 1 of their magnitudes.  The word of that plane holds the refinement
+        // bits of the older samples when there were any (k_ref_deposit(p + 1) wrote it), else nothing yet
+        const uint64_t found = (fresh | ls) & ~sig;
+        if (found && (uint32_t)(p + 1) < b.refNPlanes) {
+          uint64_t* pw = b.refPlanes + c * b.refPlaneStride + (size_t)(p + 1) * b.maskPixStride + wi;
+          *pw = sig ? (*pw | found) : found;
+          if (!sig)
+            b.wordTop[c * b.wordTopStride + wi] = (uint8_t)(p + 2);
+        }
+      }
       sig |= fresh | ls;
       *so = sig;
     }
@@ -3141,6 +3154,154 @@ __global__ void __launch_bounds__(kThreads) k_ref_apply2(DecBuffers b, int p)
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Refinement through bit planes (DecBuffers::refPlanes, 32-bit coefficients).  k_ref_apply2 above updates 4
+// bytes here and there in a 64 MB array on every plane: whole cache lines moved for a few samples each, 10 GB
+// per step of the bench volume at under 1 TB/s.  k_ref_deposit puts plane p's bits under the significance
+// mask instead -- thread = mask word: candidate i of the word is its i-th set bit, the word's candidates start
+// at the tile's offset + the word's rank -- with one 8-byte store per word; k_dec_count adds the '1' of the
+// plane a sample was found on; k_ref_assemble gathers every sample's bits after the last plane.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  if ((uint32_t)p >= b.refNPlanes)
+    return;
+  __shared__ uint32_t sm[kThreads / 64 + 1];
+  const uint32_t nw = (b.tree.nvals + 63) / 64;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  uint64_t* plane = b.refPlanes + c * b.refPlaneStride + (size_t)p * b.maskPixStride;
+  const uint64_t avail = s.avail, pos0 = s.pos;
+  const bool partial = pos0 + (uint64_t)s.nRef > avail;   // the stream ends inside this pass
+  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
+    if (b.tileRef[c * b.tileStride + tile] == 0)
+      continue;   // (uniform: the whole workgroup reads the same word)
+    const uint32_t wi = tile * kDecTileWords + threadIdx.x;
+    const uint64_t sig = wi < nw ? b.sigOld[c * b.maskPixStride + wi] : 0ull;
+    const uint32_t cnt = (uint32_t)__popcll(sig);
+    uint32_t total;
+    const uint32_t o = block_exclusive_scan_lds<uint32_t>(cnt, sm, &total);
+    if (cnt == 0)
+      continue;
+    const uint64_t at = pos0 + (uint64_t)b.tileRefOff[c * b.tileStride + tile] + o;
+    // the pass stops the moment the stream is exhausted (SPECK_INT.cpp:388-389)
+    const uint32_t n = at >= avail ? 0u : (uint32_t)min((uint64_t)cnt, avail - at);
+    uint64_t res = 0, m = sig;
+    if (n) {
+      uint64_t bits = get64(words, at);
+      if (n == 64)
+        res = bits;   // (every sample of the word is a candidate)
+      else
+        for (uint32_t k = 0; k < n; k++) {   // candidate k of the word is the k-th set bit of the mask
+          const uint64_t low = m & (0ull - m);
+          m ^= low;
+          res |= (bits & 1ull) ? low : 0ull;
+          bits >>= 1;
+        }
+    }
+    if (n == 64)
+      m = 0;
+    plane[wi] = res;   // (always: the word is valid from the plane of its first significant sample on)
+    if (partial)
+      b.refMask[c * b.maskPixStride + wi] = sig & ~m;   // the candidates that did get a bit
+  }
+}
+
+// Every coefficient, once: magnitude bits (the '1' of the plane p0 a sample was found on, the refinement
+// bits below it) + 2^(q-1) - 1, q = the lowest plane the sample was refined on, p0 itself when none
+// (1.5 * 2^p0 - 1, src/SPECK_INT.cpp:462-468; plane 0 adds the bare bit, :440-447).  A wavefront takes
+// four mask words per round, lane = sample: the plane words are wave-uniform (scalar loads) and a sample's
+// bit of one is its lane's bit -- a select and a shift-or per plane.  Samples that are not significant get
+// their zero here: the coefficient array is not cleared beforehand.
+__global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
+{
+  const uint32_t c = blockIdx.y;
+  const DecState& s = b.st[c];
+  const uint32_t nw = (uint32_t)(b.coefStride / 64);   // (the padding of the array is written too)
+  const uint32_t nwv = (b.tree.nvals + 63) / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t* coef = reinterpret_cast<uint32_t*>(b.coef) + c * b.coefStride;
+  constexpr uint32_t kW = 4;   // mask words per wavefront and round
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
+  const uint32_t nwave = (gridDim.x * kThreads) >> 6;
+  if (!s.active || s.nbp == 0) {   // nothing was decoded: zeros
+    for (uint32_t w = wave; w < nw; w += nwave)
+      coef[(size_t)w * 64 + lane] = 0;
+    return;
+  }
+  const int lastPlane = s.lastPlane, refPlane = s.refPlaneP1 - 1;
+  const bool partial = s.refPartial != 0;
+  // the planes whose words are there: those a refinement pass ran on (k_ref_deposit) -- k_dec_count's '1's of the
+  // samples found on plane lastPlane + 1 went into a plane at or above the last of them
+  const int pLow = refPlane >= 0 ? refPlane : lastPlane + 1;
+  const int nbp = min(s.nbp, (int)b.refNPlanes);
+  const uint64_t* planes = b.refPlanes + c * b.refPlaneStride;
+  const uint64_t* sigOld = b.sigOld + c * b.maskPixStride;
+  const uint64_t* sigNew = b.sigNew + c * b.maskPixStride;
+  const uint64_t* refMask = b.refMask + c * b.maskPixStride;
+  const uint8_t* wordTop = b.wordTop + c * b.wordTopStride;
+  for (uint32_t w0 = wave * kW; w0 < nw; w0 += nwave * kW) {
+    uint64_t so[kW], sn[kW];
+    int top[kW], maxTop = 0;
+    uint64_t any = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < kW; u++) {
+      const uint32_t w = w0 + u;
+      const bool in = w < nwv;
+      so[u] = in ? sigOld[w] : 0ull;
+      sn[u] = in ? sigNew[w] : 0ull;
+      top[u] = (in && so[u]) ? min((int)wordTop[w], nbp) : 0;
+      maxTop = max(maxTop, top[u]);
+      any |= so[u] | sn[u];
+    }
+    uint32_t M[kW];
+#pragma unroll
+    for (uint32_t u = 0; u < kW; u++)
+      M[u] = 0;
+    if (any) {
+      // from the highest plane a word of the round has down to the lowest plane that was refined
+      for (int pl = maxTop - 1; pl >= pLow; pl--) {
+#pragma unroll
+        for (uint32_t u = 0; u < kW; u++) {
+          // (loaded whether the word has the plane or not -- four independent scalar loads, no branch; the
+          //  address is inside the chunk's planes either way)
+          const uint64_t raw = planes[(size_t)pl * b.maskPixStride + min(w0 + u, nw - 1u)];
+          const uint64_t pw = pl < top[u] ? raw : 0ull;
+          M[u] = 2u * M[u] + (__builtin_amdgcn_inverse_ballot_w64(pw) ? 1u : 0u);
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kW; u++) {
+      const uint32_t w = w0 + u;
+      if (w >= nw)
+        continue;
+      uint32_t v = 0;
+      const bool isNew = ((sn[u] >> lane) & 1ull) != 0, isOld = ((so[u] >> lane) & 1ull) != 0;
+      if (isNew || isOld) {
+        uint32_t m = (isOld && maxTop > pLow) ? M[u] << pLow : 0u;
+        if (isNew)
+          m |= 1u << lastPlane;
+        const int p0 = 31 - __clz((int)m);
+        int q = p0;   // lowest plane the sample was refined on, the plane it was found on when none
+        if (isOld && refPlane >= 0) {
+          bool atRef = p0 > refPlane;
+          if (atRef && partial)
+            atRef = ((refMask[w] >> lane) & 1ull) != 0;
+          if (atRef)
+            q = refPlane;
+          else if (p0 > refPlane + 1)
+            q = refPlane + 1;
+        }
+        v = m ? m + (q >= 1 ? (1u << (q - 1)) - 1u : 0u) : 0u;
+      }
+      coef[(size_t)w * 64 + lane] = v;
+    }
+  }
+}
+
 // After the last plane: leaf results that no k_dec_count has folded yet are those of the last
 // decoded plane -- they are "new" for k_dec_finish.
 __global__ void __launch_bounds__(kThreads) k_dec_fold(DecBuffers b)
@@ -3202,6 +3363,8 @@ __global__ void k_dec_plane_end(DecBuffers b, int p)
   DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   const uint64_t room = s.avail - s.pos;
+  s.refPlaneP1 = p + 1;
+  s.refPartial = (uint64_t)s.nRef > room ? 1u : 0u;
   s.pos += min((uint64_t)s.nRef, room);
   if (s.pos >= s.avail || p == 0)  // SPECK_INT.cpp:204-205
     s.done = 1;
@@ -3308,7 +3471,10 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       }
       LAUNCH_K(k_leaf_apply, dim3(capped_blocks(1024, nc, kGridCap / gdiv), nc), dim3(kThreads), 0, stream, b, p);
     }
-    LAUNCH_CT(k_ref_apply2, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+    if (b.refPlanes && sizeof(CT) == 4)
+      LAUNCH_K(k_ref_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
+    else
+      LAUNCH_CT(k_ref_apply2, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     return 0;
   };
 #undef LAUNCH_CT
@@ -3340,6 +3506,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     if ((plan.tables || plan.mixed) && b.wordLeaf)
       LAUNCH_K(k_dec_fold, dim3(((n + 63) / 64 + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
                stream, b);
+    if (b.refPlanes && !wide_pass)
+      LAUNCH_K(k_ref_assemble, dim3(capped_blocks((uint32_t)((b.coefStride / 64 + 15) / 16), nc, kGridCapWide), nc),
+               dim3(kThreads), 0, stream, b);
     if (!plan.skipFinish) {
       if (wide_pass)
         LAUNCH_K(k_dec_finish<uint64_t>, dim3((n + kThreads - 1) / kThreads, nc), dim3(kThreads), 0,
