@@ -2010,7 +2010,7 @@ struct DecBatchBufs {
 bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadBytes, DecBatchBufs& o,
                size_t valsElems = 0, uint32_t refNPlanes = 0)
 {
-  const size_t N = P.N, Npad = round_up(N, 256);
+  const size_t N = P.N, Npad = round_up(N, 512);   // (512: k_ref_assemble takes eight mask words per round)
   DecBuffers& d = o.db;
   memset(&d, 0, sizeof(d));
   d.tree = P.dtree;

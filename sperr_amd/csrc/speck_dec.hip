@@ -2369,6 +2369,42 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         }
         // (LDS traffic of one wavefront is in order: what lane 0 wrote above is what the lanes read)
         uint64_t tmark = b.lisStamps ? __builtin_readcyclecounter() : 0;
+        // The entries a pointer-jump pass has stepped over are queued (and their significance bits set) by all
+        // lanes, block by block (P3 below).  Nothing on the chain depends on that unless the list ENDS inside the
+        // region (then P3 finds where): otherwise it is put off until the region's state is published -- the
+        // successor's chain starts a few thousand cycles earlier -- or until the tables it reads are about to change.
+        bool pend = false;
+        const uint32_t* pendHp = nullptr;
+        uint32_t pendK = 0, pendRemaining = 0, pendE0 = 0, pendLOff = 0;
+        auto emit_entries = [&](const uint32_t* hp, uint32_t K, uint32_t remaining, uint32_t e0, uint32_t lOff) {
+          const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
+          const uint32_t nblk = ((SR - 1 + wq0) >> 6) + 1;
+          const int32_t rbase = -(int32_t)wq0;
+          for (uint32_t kb = lane; kb < nblk; kb += 64) {  // P3: the blocks emit their entries
+            const uint32_t eb = blkEB[kb];
+            if (eb == 0xffffffffu)
+              continue;
+            uint32_t r = eb & 0xffffu;
+            const uint32_t base = eb >> 16;
+            const uint32_t cn = hp[(uint32_t)((int32_t)r - rbase)] >> 16;
+            const uint32_t lim_k = min(cn, remaining - base);
+            for (uint32_t k = 0; k < lim_k; k++) {
+              const uint32_t u = Utop[r];
+              if (u & 0x8000u) {
+                const uint32_t ei = lOff + e0 + base + k;   // index into the chunk's list storage
+                const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+                if (slot < b.queueCap) {
+                  qbuf[0][slot * 2] = ei;
+                  qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+                }
+                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              }
+              r += u & 0x7fffu;
+            }
+            if (lim_k > 0 && base + lim_k == remaining)
+              sh_newr = r;  // the list ended in this block (only one block satisfies this)
+          }
+        };
         for (;;) {
           if (lane == 0) {
             uint32_t act = kActDone;
@@ -2406,7 +2442,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                     extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
                 }
                 sh_tabFrom = extend ? sh_tabK : 0;
-                act = (!extend && sh_tabLevel >= 0 && sh_qn[0] != 0) ? kActFlushTables : kActTables;
+                act = (!extend && sh_tabLevel >= 0 && (sh_qn[0] != 0 || pend)) ? kActFlushTables : kActTables;   // (pend: entries of the tables in place still to be queued)
               }
               else if (sh_depth > 1)
                 act = 8;    // serial hop
@@ -2460,6 +2496,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               sh_action = act;
             }
             HI_T(1);
+            if (pend) {   // (after the state is out; before the workgroup expands the queue or rebuilds tables)
+              emit_entries(pendHp, pendK, pendRemaining, pendE0, pendLOff);
+              pend = false;
+              HI_T(4);
+            }
             break;
           }
           const LevelClass& C = sh_lc[sh_level];
@@ -2634,8 +2675,12 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             continue;
           }
           // ---- act == 9: the list entries from sh_pos on, by pointer jumping
+          if (pend) {   // (this pass rewrites the blocks' entry points)
+            emit_entries(pendHp, pendK, pendRemaining, pendE0, pendLOff);
+            pend = false;
+            HI_WAVE_SYNC();
+          }
           const uint32_t* hp = sh_hopTop[0] == K - 1 ? hop : hop2;
-          const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
           const uint32_t pr = (uint32_t)(sh_pos - a);
           const uint32_t remaining = sh_rem, e0 = sh_e;
           const uint32_t lOff = b.levelOff[sh_level];
@@ -2673,29 +2718,16 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           }
           HI_WAVE_SYNC();
           HI_T(3);
-          for (uint32_t kb = lane; kb < nblk; kb += 64) {  // P3: the blocks emit their entries
-            const uint32_t eb = blkEB[kb];
-            if (eb == 0xffffffffu)
-              continue;
-            uint32_t r = eb & 0xffffu;
-            const uint32_t base = eb >> 16;
-            const uint32_t cn = hp[(uint32_t)((int32_t)r - rbase)] >> 16;
-            const uint32_t lim_k = min(cn, remaining - base);
-            for (uint32_t k = 0; k < lim_k; k++) {
-              const uint32_t u = Utop[r];
-              if (u & 0x8000u) {
-                const uint32_t ei = lOff + e0 + base + k;   // index into the chunk's list storage
-                const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
-                if (slot < b.queueCap) {
-                  qbuf[0][slot * 2] = ei;
-                  qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
-                }
-                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
-              }
-              r += u & 0x7fffu;
-            }
-            if (lim_k > 0 && base + lim_k == remaining)
-              sh_newr = r;  // the list ended in this block (only one block satisfies this)
+          if (sh_newr == 0xffffffffu) {   // the list ends inside the region: where, P3 finds out
+            emit_entries(hp, (uint32_t)K, remaining, e0, lOff);
+          }
+          else {
+            pend = true;
+            pendHp = hp;
+            pendK = (uint32_t)K;
+            pendRemaining = remaining;
+            pendE0 = e0;
+            pendLOff = lOff;
           }
           HI_WAVE_SYNC();
           HI_T(4);
@@ -3223,7 +3255,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
   const uint32_t nwv = (b.tree.nvals + 63) / 64;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t* coef = reinterpret_cast<uint32_t*>(b.coef) + c * b.coefStride;
-  constexpr uint32_t kW = 4;   // mask words per wavefront and round
+  constexpr uint32_t kW = 8;   // mask words per wavefront and round (wordTopStride is a multiple of 64)
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * kThreads + threadIdx.x) >> 6));
   const uint32_t nwave = (gridDim.x * kThreads) >> 6;
   if (!s.active || s.nbp == 0) {   // nothing was decoded: zeros
@@ -3242,17 +3274,22 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
   const uint64_t* sigNew = b.sigNew + c * b.maskPixStride;
   const uint64_t* refMask = b.refMask + c * b.maskPixStride;
   const uint8_t* wordTop = b.wordTop + c * b.wordTopStride;
-  for (uint32_t w0 = wave * kW; w0 < nw; w0 += nwave * kW) {
-    uint64_t so[kW], sn[kW];
+  for (uint32_t w0 = wave * kW; w0 + kW <= nw; w0 += nwave * kW) {
+    uint64_t so[kW], sn[kW], rm[kW];
     int top[kW], maxTop = 0;
     uint64_t any = 0;
+    // (the eight words' tops as two aligned dwords: scalar loads like the mask words)
+    const uint32_t tops[2] = {reinterpret_cast<const uint32_t*>(wordTop + w0)[0], reinterpret_cast<const uint32_t*>(wordTop + w0)[1]};
 #pragma unroll
     for (uint32_t u = 0; u < kW; u++) {
       const uint32_t w = w0 + u;
       const bool in = w < nwv;
-      so[u] = in ? sigOld[w] : 0ull;
-      sn[u] = in ? sigNew[w] : 0ull;
-      top[u] = (in && so[u]) ? min((int)wordTop[w], nbp) : 0;
+      so[u] = sigOld[w];   // (w < nw <= maskPixStride, nw a multiple of eight: carve_dec)
+      sn[u] = sigNew[w];
+      rm[u] = refMask[w];  // (read with the others whether the pass was cut short or not: no load behind a branch)
+      if (!in)
+        so[u] = sn[u] = 0;
+      top[u] = so[u] ? min((int)((tops[u >> 2] >> (8 * (u & 3))) & 0xffu), nbp) : 0;
       maxTop = max(maxTop, top[u]);
       any |= so[u] | sn[u];
     }
@@ -3267,7 +3304,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
         for (uint32_t u = 0; u < kW; u++) {
           // (loaded whether the word has the plane or not -- four independent scalar loads, no branch; the
           //  address is inside the chunk's planes either way)
-          const uint64_t raw = planes[(size_t)pl * b.maskPixStride + min(w0 + u, nw - 1u)];
+          const uint64_t raw = planes[(size_t)pl * b.maskPixStride + w0 + u];
           const uint64_t pw = pl < top[u] ? raw : 0ull;
           M[u] = 2u * M[u] + (__builtin_amdgcn_inverse_ballot_w64(pw) ? 1u : 0u);
         }
@@ -3276,8 +3313,6 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
 #pragma unroll
     for (uint32_t u = 0; u < kW; u++) {
       const uint32_t w = w0 + u;
-      if (w >= nw)
-        continue;
       uint32_t v = 0;
       const bool isNew = ((sn[u] >> lane) & 1ull) != 0, isOld = ((so[u] >> lane) & 1ull) != 0;
       if (isNew || isOld) {
@@ -3289,7 +3324,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
         if (isOld && refPlane >= 0) {
           bool atRef = p0 > refPlane;
           if (atRef && partial)
-            atRef = ((refMask[w] >> lane) & 1ull) != 0;
+            atRef = ((rm[u] >> lane) & 1ull) != 0;
           if (atRef)
             q = refPlane;
           else if (p0 > refPlane + 1)
