@@ -288,6 +288,22 @@ def main():
     except Exception as ex:   # noqa: BLE001
         workspace = {"error": f"{type(ex).__name__}: {ex}"}
 
+    # ---- the farm's host-thread plan against the CPUs this process may use (affinity mask, cgroup quota), for the
+    #      devices of this launch and for a full node of 8
+    farm_threads = None
+    try:
+        import ctypes as C_
+        from sperr_amd.api import host_cpus
+        eng.lib.sperrhip_farm_threads.argtypes = [C_.c_size_t, C_.c_size_t] + [C_.POINTER(C_.c_size_t)] * 5
+        farm_threads = {"host": host_cpus(eng.lib)}
+        for nd in sorted({max(1, world), 8}):
+            v = [C_.c_size_t(0) for _ in range(5)]
+            if eng.lib.sperrhip_farm_threads(0, nd, *[C_.byref(x) for x in v]) == 0:
+                farm_threads[f"{nd}_devices"] = dict(zip(("workers_per_device", "dec_workers_per_device", "helpers_per_worker",
+                                                          "threads_total", "cpus_usable"), (x.value for x in v)))
+    except Exception as ex:   # noqa: BLE001
+        farm_threads = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- a small batch (rank 0): 8 chunks = 512^3, what one GPU gets when config 3's 64 chunks are
     #      dealt to 8 GPUs (strong scaling); device-resident like `value`
     small = None
@@ -434,17 +450,27 @@ def main():
     # HBM traffic of that kernel per step: PMC counters cannot be collected from inside this
     # process; profiles/*_pmc_traffic.json holds them for this very workload (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes)
-    traffic = None
+    traffic = traffic_from = None
     if S == 1024 and C == 256 and args.bpp == 2.0:
         import glob
-        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        from sperr_amd.srchash import bench_path_hash
+        now = bench_path_hash()
+        # only a record taken from THESE sources counts (newest first); none: null, and the line says why
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime, reverse=True):
             with open(pf) as f:
-                rec = json.load(f)["kernels"].get(top_name)
-            if rec:
+                doc = json.load(f)
+            rec = doc["kernels"].get(top_name)
+            if rec and doc.get("source_sha16") == now:
                 traffic = rec["hbm_bytes_per_step_corrected"]
+                traffic_from = {"file": os.path.basename(pf), "commit": doc.get("commit"), "source_sha16": now,
+                                "step_total_GB": doc.get("total_hbm_GB_per_step")}
+                break
+        if traffic is None:
+            traffic_from = {"file": None, "source_sha16": now,
+                            "why": "no profiles/*_pmc_traffic.json was collected from the sources of this build"}
     roofline = {
         "bound": "hbm", "kernel": top_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_from": traffic_from,
         "algorithmic_bytes_per_step": ALGO_BYTES_PER_VALUE * values,
         "launches_per_step": top_launches // args.steps,
         "avg_launch_ms": round(top_sum / max(1, top_launches), 4),
@@ -551,6 +577,16 @@ def main():
         "strong_compress_GBps": (host_path or {}).get("compress_GBps"),
         "strong_decompress_GBps": (host_path or {}).get("decompress_GBps"),
         "small_batch": small,
+        # what 8 GPUs can reach on ONE 1024^3 volume (config 3 dealt 8 chunks per GPU) if every GPU runs at this
+        # GPU's 8-chunk rate and nothing else limits: the expectation a measured 8-GPU strong-scaling run is judged by
+        "strong_ceiling_from_small_batch": (None if not small or "error" in small else {
+            "n_gpus": 8,
+            "compress_GBps": round(8 * small["compress_GBps"], 1), "decompress_GBps": round(8 * small["decompress_GBps"], 1),
+            "x_one_gpu_compress": round(8 * small["compress_GBps"] / (nbytes / tc / 1e9), 2),
+            "x_one_gpu_decompress": round(8 * small["decompress_GBps"] / (nbytes / td / 1e9), 2),
+            "what": "8 x small_batch rate, device-resident; the host path adds PCIe (about 57 GB/s each way per GPU) and "
+                    "the host's copy threads, which the farm sizes by the CPU quota (farm_threads)"}),
+        "farm_threads": farm_threads,
         "workspace": workspace,
         "ragged_volume": ragged,
         "other_modes": other,

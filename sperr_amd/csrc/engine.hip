@@ -2111,11 +2111,14 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
     d.hiAhead = ahead;
     static const uint32_t extra = getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_EXTRA")) : 1u;
     d.hiExtra = extra;
-    static const uint32_t hop2 = getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_HOP2")) : 1u;
+    // (round 5: off -- without the second table a region holds 6912 positions instead of 5632, a chunk has a fifth
+    //  fewer regions on its serial chain, and the table it rebuilds now and then costs less than that:
+    //  decompression of the bench volume 91.5 -> 94.5 GB/s, eight chunks 38.2 -> 39.3)
+    static const uint32_t hop2 = getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_HOP2")) : 0u;
     d.hiHop2 = hop2;
   }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
-  d.hiW = hi_window((int)d.hiK, d.hiSmemBytes);
+  d.hiW = hi_window((int)d.hiK, d.hiSmemBytes, d.hiHop2);
   d.queueStride = (size_t)d.queueCap * 4 * d.hiGroupsMax;
   TAKE(d.queue, uint64_t, d.queueStride * B);
   d.hiAhead = std::min(d.hiAhead / 64 * 64, d.hiW / 2);

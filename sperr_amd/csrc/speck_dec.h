@@ -203,9 +203,11 @@ __host__ __device__ inline uint32_t tab_window(int K, uint32_t smemBytes)
 }
 
 // the same for k_lis_hi, which keeps two pointer-jump tables (the list's class and the next one)
-__host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes)
+// (hop2 == 0: one pointer-jump table only -- the second is built on demand into the first's place --, 4 bytes
+//  per position less: 6912 instead of 5632 positions for a 256^3 chunk)
+__host__ __device__ inline uint32_t hi_window(int K, uint32_t smemBytes, uint32_t hop2 = 1)
 {
-  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + 8) + 1u;   // eighths of a byte
+  const uint32_t perBit8 = 8u * (uint32_t)(2 * (2 * K - 1) + (hop2 ? 8 : 4)) + 1u;   // eighths of a byte
   const uint32_t fixed = 4 * 8 + 2 * 130 * 4 + (uint32_t)(2 * K) * 8 + 64;
   uint32_t w = (uint32_t)(((uint64_t)(smemBytes - fixed) * 8) / perBit8);
   w = w / 256 * 256;   // (any multiple of 64 works; round 2 took multiples of 1024: 4096 instead of 4352 bits for a 256^3 chunk)

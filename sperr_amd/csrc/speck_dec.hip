@@ -1700,8 +1700,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   const int Kcap = (int)b.hiK;                     // classes the LDS tables have room for
   const uint32_t kWords = W / 64 + 4;
   uint32_t* hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);   // [W + 130]
-  uint32_t* hop2 = hop + (W + 130);                                             // [W + 130]
-  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop2 + (W + 130));                 // [Kcap - 1][TS]
+  uint32_t* hop2 = b.hiHop2 ? hop + (W + 130) : hop;                            // [W + 130], or none (never built then)
+  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop + (b.hiHop2 ? 2 : 1) * (W + 130));   // [Kcap - 1][TS]
   uint16_t* Uu = Tt + (size_t)(Kcap - 1) * TS;                                  // [Kcap][TS]
   constexpr int kBlk = kTabWMax / 64 + 4;
   __shared__ uint32_t blkEB[kBlk];

@@ -9,6 +9,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+python3 -c "from sperr_amd.srchash import bench_path_hash as h; print(h())" > $out/source_sha16.txt
 args="bench.py --size 1024 --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-ragged --no-other-modes --no-small-batch"
 timeout 600 python3 bench.py --size 1024 --steps 5 --warmup 1 --no-ragged --no-other-modes --profile-out $out/engine_events.csv > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?"

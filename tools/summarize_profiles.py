@@ -12,6 +12,8 @@ import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from sperr_amd.srchash import bench_path_hash, head_commit   # noqa: E402
 src_tag, dst_tag = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + src_tag)
 dst = os.path.join(ROOT, "profiles")
@@ -64,6 +66,11 @@ with open(os.path.join(dst, f"{dst_tag}_pmc_traffic.json"), "w") as f:
                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (HBM section); the x2 "
                 "holds for wide coalesced reads and over-counts scattered ones",
         "steps_profiled": steps,
+        # the sources the counters belong to (bench.py reports roofline.traffic only while they are unchanged).
+        # SRC_HASH of the run that collected the counters, when the collector recorded it; else the tree's now
+        "source_sha16": (open(os.path.join(src, "source_sha16.txt")).read().strip()
+                         if os.path.exists(os.path.join(src, "source_sha16.txt")) else bench_path_hash()),
+        "commit": head_commit(),
         "kernels": rows,
     }, f, indent=1)
 shutil.copy(os.path.join(src, "trace", "run_kernel_stats.csv"),
