@@ -1598,14 +1598,6 @@ k_lis_l1(DecBuffers b, int p)
 constexpr int kTabThreads = 1024;
 constexpr uint32_t kTInf = 0xffffu;
 
-struct TabCtx {
-  uint64_t parent;     // packed parent node of the items
-  uint32_t remaining;  // items left in this context
-  int8_t cls;          // class of the items (-1: pixels)
-  uint8_t found;       // an earlier item of this context was significant
-  uint8_t nextOrd;     // ordinal of the next child
-  uint8_t pad;
-};
 
 __device__ __forceinline__ Node reg_child(const Tree& t, const Node& nd, uint32_t ord, int ee[3],
                                           uint32_t idx[3])
@@ -1706,7 +1698,24 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   constexpr int kBlk = kTabWMax / 64 + 4;
   __shared__ uint32_t blkEB[kBlk];
   __shared__ uint32_t sh_total, sh_stopped, sh_newr;
-  __shared__ TabCtx sh_ctx[kHiFrames + 2];
+  // The serial chain keeps NO geometry (round 5).  A frame -- the children of a set being walked into -- is one word:
+  // children left | next ordinal << 8 | found << 16 | children's class << 24.  What the walk steps over goes to a
+  // log (per step: the frame, its first ordinal, and per child what became of it and where), and the sets' nodes
+  // are worked out from the log AFTER the region's state is published (hi_replay): the list entry at the bottom
+  // is known by its index in the list storage, the set a frame entered by its ordinal.  Before, every step
+  // derived eight child nodes from LDS geometry tables, claimed birth slots and wrote queue items on the chain,
+  // the look-back rebuilt the parents of the open frames, and an entry that left the region was a global load.
+  constexpr int kHiLogCap = 32;
+  // A list with no more entries left than this is gone through entry by entry (one table look-up each) when the
+  // region has no pointer-jump table of its class, instead of all hands leaving the chain to build one (with one
+  // table per region, round 5, the dozen short lists of every light plane cost 94 such builds per chunk); and the
+  // region's one table is built for the first list from the hinted one on that is longer than this.
+  constexpr uint32_t kHiSerial = 48;
+  __shared__ uint32_t sh_fr[kHiFrames + 2];
+  __shared__ uint32_t sh_logHdr[kHiLogCap], sh_logBase[kHiLogCap], sh_logLane[kHiLogCap][8];
+  __shared__ uint32_t sh_nlog, sh_baseIdx, sh_parInit, sh_baseIdx0, sh_depth0;
+  __shared__ uint8_t sh_ord0[kHiFrames + 2];
+  __shared__ uint64_t sh_par[kHiFrames + 2];
   __shared__ uint32_t sh_qn[3];
   __shared__ uint32_t sh_len[kMaxLevels];
   __shared__ LevelClass sh_lc[kMaxLevels];
@@ -1717,11 +1726,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   __shared__ Root sh_roots[kLdsRoots];
   __shared__ Grid sh_grids[kLdsGrids];
   // chain state (thread 0 owns it; the others read it between barriers)
-  __shared__ uint64_t sh_pos, sh_base;
+  __shared__ uint64_t sh_pos;
   __shared__ uint32_t sh_level, sh_depth, sh_e, sh_rem, sh_stop, sh_action, sh_ticket, sh_any;
   __shared__ unsigned long long sh_in[4];
   __shared__ int sh_tabLevel, sh_tabK, sh_hopTop[2], sh_tabFrom, sh_hintK;   // what the tables in LDS were built for
-  __shared__ uint32_t sh_over, sh_nhb, sh_haveState, sh_act2;
+  __shared__ uint32_t sh_over, sh_haveState, sh_act2;
   __shared__ uint64_t sh_t2, sh_t3, sh_tacc[8];
 #define HI_T(k)                                               \
   if (b.lisStamps && lane == 0) {                             \
@@ -1729,8 +1738,6 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     sh_tacc[k] += now_ - tmark;                               \
     tmark = now_;                                             \
   }
-  constexpr int kHiHopBorn = 96;   // births the serial hop found: their slots are taken off the chain
-  __shared__ uint64_t sh_hbKid[kHiHopBorn], sh_hbMeta[kHiHopBorn];
 
   // (the tree's geometry tables are read from LDS: the serial hop derives child sets from them)
   Tree t = b.tree;
@@ -2155,7 +2162,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       sh_ticket = over ? kL0None : atomicAdd(&s.hiTicket, 1u);
       sh_any = 0;
       sh_over = 0;
-      sh_nhb = 0;
+      sh_nlog = 0;
+      sh_parInit = 0;
       sh_haveState = 0;
       sh_stop = 0;
       for (int k = 0; k < 8; k++)
@@ -2231,7 +2239,21 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       }
       if (lane == 0) {
         sh_tabLevel = best;
-        sh_hintK = hint >= 0 ? (int)sh_lc[hint].K : 0;
+        int hk = hint >= 0 ? (int)sh_lc[hint].K : 0;
+        if (hint >= 0 && best >= 0) {
+          // short lists are walked entry by entry: the table goes to the first longer list the class tables serve
+          const int bestK = min((int)sh_lc[best].K, Kcap);
+          for (int lv2 = hint; lv2 >= 0; lv2 = next_level(lv2)) {
+            const int K2 = (int)sh_lc[lv2].K;
+            if (K2 > bestK || !sh_lc[lv2].regular)
+              break;
+            if (sh_len[lv2] > kHiSerial) {
+              hk = K2;
+              break;
+            }
+          }
+        }
+        sh_hintK = hk;
       }
     }
     __syncthreads();
@@ -2319,7 +2341,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               sh_e = 0;
               sh_rem = lv < 0 ? 0u : sh_len[lv];
               sh_pos = S0;
-              sh_base = 0;
+              sh_baseIdx = sh_baseIdx0 = 0;
+              sh_depth0 = 1;
               if (lv < 0)
                 stop = 2;   // nothing for this kernel to decode: the phase ends where it starts
             }
@@ -2333,7 +2356,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 sh_pos = S0 + (f0 & ((1ull << 46) - 1ull));
                 sh_e = (uint32_t)(f1 >> 28) & 0xfffffffu;
                 sh_rem = (uint32_t)f1 & 0xfffffffu;
-                sh_base = f3 & kHiPayloadMask;
+                sh_baseIdx = sh_baseIdx0 = (uint32_t)(f3 & kHiPayloadMask);
                 // (a state that does not add up cannot be followed: give up loudly)
                 if (sh_level >= t.nlevels || sh_depth == 0 || sh_depth > (uint32_t)kHiFrames ||
                     sh_e + sh_rem != sh_len[sh_level] || sh_pos < a ||
@@ -2344,21 +2367,16 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                   sh_depth = 1;
                   sh_level = 0;
                 }
-                // rebuild the stack of sets being walked into: frame d holds the children of the set
-                // that frame d - 1 entered (frame 1: of the list entry)
+                // the frames of the sets being walked into: frame d holds the children of the set that frame
+                // d - 1 entered (frame 1: of the list entry); their nodes are hi_replay's business
                 const LevelClass& C = sh_lc[sh_level];
-                uint64_t parent = sh_base;
+                sh_depth0 = sh_depth;
                 for (uint32_t d = 1; d < sh_depth; d++) {
                   const uint32_t fr = (uint32_t)(f2 >> (5 * (d - 1))) & 31u;
-                  TabCtx& cx = sh_ctx[d];
                   const int pcls = (int)C.K - (int)d;   // class of the parent set
-                  cx.parent = parent;
-                  cx.cls = (int8_t)(pcls - 1);
-                  cx.nextOrd = (uint8_t)(fr & 15u);
-                  cx.found = (uint8_t)(fr >> 4);
-                  cx.remaining = (uint32_t)C.arity[pcls] - (fr & 15u);
-                  if (d + 1 < sh_depth)
-                    parent = reg_child_packed(t, unpack_node(parent), (fr & 15u) - 1u);
+                  sh_fr[d] = (((uint32_t)C.arity[pcls] - (fr & 15u)) & 0xffu) | ((fr & 15u) << 8) | ((fr >> 4) << 16) |
+                             ((uint32_t)(pcls - 1) << 24);
+                  sh_ord0[d] = (uint8_t)(fr & 15u);
                 }
               }
             }
@@ -2373,6 +2391,64 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         // lanes, block by block (P3 below).  Nothing on the chain depends on that unless the list ENDS inside the
         // region (then P3 finds where): otherwise it is put off until the region's state is published -- the
         // successor's chain starts a few thousand cycles earlier -- or until the tables it reads are about to change.
+        // wavefront 0, all lanes: the nodes, birth records and queue items of what the log holds (see sh_fr above)
+        auto hi_replay = [&]() {
+          if (!sh_parInit) {   // the sets the open frames of the region's start belong to
+            if (lane == 0) {
+              const uint32_t d0 = sh_depth0;
+              if (d0 > 1) {
+                uint64_t parent = lisCur[sh_baseIdx0];
+                sh_par[1] = parent;
+                for (uint32_t d = 1; d + 1 < d0; d++) {
+                  parent = reg_child_packed(t, unpack_node(parent), (uint32_t)sh_ord0[d] - 1u);
+                  sh_par[d + 1] = parent;
+                }
+              }
+              sh_parInit = 1;
+            }
+            HI_WAVE_SYNC();
+          }
+          const uint32_t nlog = sh_nlog;
+          for (uint32_t j = 0; j < nlog; j++) {
+            const uint32_t hdr = sh_logHdr[j];
+            if (hdr & 1u) {   // a list entry was entered: the set at the bottom of the stack from here on
+              if (lane == 0) {
+                const uint32_t ei = sh_logBase[j];
+                sh_par[1] = lisCur[ei];
+                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              }
+              HI_WAVE_SYNC();
+              continue;
+            }
+            const uint32_t fi = (hdr >> 4) & 15u, firstOrd = (hdr >> 8) & 15u, done = (hdr >> 12) & 15u;
+            const uint32_t cls = (hdr >> 16) & 15u, lv = (hdr >> 20) & 63u;
+            if (lane < done) {
+              const uint32_t v = sh_logLane[j][lane];
+              const uint32_t kind = v & 3u, at = v >> 2;
+              if (kind) {
+                const uint64_t kid = reg_child_packed(t, unpack_node(sh_par[fi]), firstOrd + lane);
+                if (kind == 1) {
+                  const uint32_t lev = sh_lc[lv].lev[cls];
+                  if (born_counts(lev, a + at))
+                    write_born(born_slots(1u), lev, a + at, kid);
+                }
+                else if (kind == 2) {
+                  const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+                  if (slot < b.queueCap) {
+                    qbuf[0][slot * 2] = kid;
+                    qbuf[0][slot * 2 + 1] = ((uint64_t)at << 8) | ((uint64_t)cls << 1);
+                  }
+                }
+                else
+                  sh_par[fi + 1] = kid;
+              }
+            }
+            HI_WAVE_SYNC();
+          }
+          if (lane == 0)
+            sh_nlog = 0;
+          HI_WAVE_SYNC();
+        };
         bool pend = false;
         const uint32_t* pendHp = nullptr;
         uint32_t pendK = 0, pendRemaining = 0, pendE0 = 0, pendLOff = 0;
@@ -2442,7 +2518,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                     extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
                 }
                 sh_tabFrom = extend ? sh_tabK : 0;
-                act = (!extend && sh_tabLevel >= 0 && (sh_qn[0] != 0 || pend)) ? kActFlushTables : kActTables;   // (pend: entries of the tables in place still to be queued)
+                act = (!extend && sh_tabLevel >= 0 && (sh_qn[0] != 0 || pend || sh_nlog != 0)) ? kActFlushTables : kActTables;   // (pend: entries of the tables in place still to be queued)
               }
               else if (sh_depth > 1)
                 act = 8;    // serial hop
@@ -2450,6 +2526,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 act = 10;   // a list of sets the tables do not cover: entry by entry
               else if (sh_hopTop[0] == K - 1 || sh_hopTop[1] == K - 1)
                 act = 9;    // list entries
+              else if (sh_rem <= kHiSerial)
+                act = 11;   // a few entries without a pointer-jump table: one by one
               else
                 act = kActHopTab;
               break;
@@ -2473,9 +2551,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 }
                 else {
                   unsigned long long fr = 0;
-                  for (uint32_t d = 1; d < sh_depth; d++)
-                    fr |= (unsigned long long)((sh_ctx[d].nextOrd & 15u) | ((sh_ctx[d].found ? 1u : 0u) << 4))
-                          << (5 * (d - 1));
+                  for (uint32_t d = 1; d < sh_depth; d++) {
+                    const uint32_t fw = sh_fr[d];
+                    fr |= (unsigned long long)(((fw >> 8) & 15u) | (((fw >> 16) & 1u) << 4)) << (5 * (d - 1));
+                  }
                   const unsigned long long f0 = tag | ((unsigned long long)sh_depth << 52) |
                                                 ((unsigned long long)sh_level << 46) |
                                                 (unsigned long long)(sh_pos - S0);
@@ -2483,7 +2562,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                   __hip_atomic_store(flags + (size_t)i * 4 + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (sh_base & kHiPayloadMask), __ATOMIC_RELAXED,
+                  __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (unsigned long long)sh_baseIdx, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(&s.hiHint, ((p + 1) << 8) | (int)sh_level, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
@@ -2501,6 +2580,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               pend = false;
               HI_T(4);
             }
+            if (sh_nlog)
+              hi_replay();
             break;
           }
           const LevelClass& C = sh_lc[sh_level];
@@ -2509,19 +2590,20 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             // The sets being walked into (the table method's serial hop); an item that leaves the
             // tables is entered, so the chain always reaches the region's end.  The whole wavefront
             // runs this with uniform values: the children of a frame are stepped over with one table
-            // look-up each, then lane k does what child k needs (its node, its birth record or
-            // queue entry), all children at once.
+            // look-up each; what became of child k and where goes to the log (lane k), the frame's word is
+            // updated, and nothing else: no node, no slot, no queue item on the chain (hi_replay).
             uint32_t r = (uint32_t)(sh_pos - a);
             int depth = (int)sh_depth;
+            const uint32_t lvNow = sh_level;
             while (depth > 1 && r < SR) {
-              const TabCtx cx = sh_ctx[depth - 1];
-              if (cx.remaining == 0) {
+              const uint32_t fw = sh_fr[depth - 1];
+              if ((fw & 0xffu) == 0) {
                 depth--;
                 continue;
               }
-              const int cls = cx.cls;
-              const uint32_t n = cx.remaining;
-              uint32_t y = r, found = cx.found, done = 0;
+              const int cls = (int)(fw >> 24);
+              const uint32_t n = fw & 0xffu, ord0 = (fw >> 8) & 0xffu;
+              uint32_t y = r, found = (fw >> 16) & 1u, done = 0;
               uint32_t myKind = 0, myPos = 0;   // 1: born at myPos, 2: splits from myPos on (queued), 3: entered
               bool enter = false;
               for (uint32_t k = 0; k < n && y < SR; k++) {
@@ -2576,41 +2658,19 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 r = SR;
                 break;
               }
-              if (myKind) {
-                const uint64_t kid = reg_child_packed(t, unpack_node(cx.parent), cx.nextOrd + lane);
-                if (myKind == 1) {
-                  const uint32_t lev = C.lev[cls];
-                  if (born_counts(lev, a + myPos)) {
-                    const uint32_t slot = atomicAdd(&sh_nhb, 1u);
-                    if (slot < (uint32_t)kHiHopBorn) {
-                      sh_hbKid[slot] = kid;
-                      sh_hbMeta[slot] = ((uint64_t)lev << 48) | (a + myPos);
-                    }
-                    else
-                      write_born(atomicAdd(&s.bornCount, 1u), lev, a + myPos, kid);
-                  }
-                }
-                else if (myKind == 2) {
-                  const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
-                  if (slot < b.queueCap) {
-                    qbuf[0][slot * 2] = kid;
-                    qbuf[0][slot * 2 + 1] = ((uint64_t)myPos << 8) | ((uint64_t)cls << 1);
-                  }
-                }
-                else {
-                  TabCtx& nc = sh_ctx[depth];
-                  nc.parent = kid;
-                  nc.remaining = C.arity[cls];
-                  nc.cls = (int8_t)(cls - 1);
-                  nc.found = 0;
-                  nc.nextOrd = 0;
-                }
+              uint32_t j = sh_nlog;
+              if (j >= (uint32_t)kHiLogCap) {   // (the log is full: work it off here, for once on the chain)
+                hi_replay();
+                j = 0;
               }
+              if (lane < 8u)
+                sh_logLane[j][lane] = myKind | (myPos << 2);
               if (lane == 0) {
-                TabCtx& w = sh_ctx[depth - 1];
-                w.remaining = n - done;
-                w.nextOrd = (uint8_t)(cx.nextOrd + done);
-                w.found = (uint8_t)found;
+                sh_logHdr[j] = ((uint32_t)(depth - 1) << 4) | (ord0 << 8) | (done << 12) | ((uint32_t)cls << 16) | (lvNow << 20);
+                sh_nlog = j + 1;
+                sh_fr[depth - 1] = (n - done) | ((ord0 + done) << 8) | (found << 16) | ((uint32_t)cls << 24);
+                if (enter)
+                  sh_fr[depth] = (uint32_t)C.arity[cls] | ((uint32_t)(cls - 1) << 24);
               }
               HI_WAVE_SYNC();
               r = y;
@@ -2620,8 +2680,6 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             if (lane == 0) {
               sh_pos = a + r;
               sh_depth = (uint32_t)depth;
-              if (sh_nhb > (uint32_t)kHiHopBorn)
-                sh_nhb = kHiHopBorn;
             }
             HI_WAVE_SYNC();
             HI_T(2);
@@ -2631,6 +2689,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             // A list whose sets are larger than the tables' classes (at most a few hundred entries per
             // chunk, each of which splits once in its life): '0' entries are counted off 32 at a time,
             // a '1' entry is walked into like an entry that leaves the region.
+            if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry it may enter)
+              hi_replay();
             if (lane == 0) {
               uint32_t r = (uint32_t)(sh_pos - a), e = sh_e, rem = sh_rem, depth = 1;
               const uint32_t lOff = b.levelOff[sh_level];
@@ -2650,20 +2710,65 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 if (z == 32)
                   continue;
                 const uint32_t ei = lOff + e;
-                const uint64_t ent = lisCur[ei];
-                TabCtx& nc = sh_ctx[1];
-                nc.parent = ent;
-                nc.remaining = C.arity[K - 1];
-                nc.cls = (int8_t)(K - 2);
-                nc.found = 0;
-                nc.nextOrd = 0;
-                sh_base = ent;
-                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+                sh_fr[1] = (uint32_t)C.arity[K - 1] | ((uint32_t)(K - 2) << 24);
+                sh_baseIdx = ei;   // (the entry itself is read, and its significance bit set, by hi_replay)
+                sh_logHdr[sh_nlog] = 1u;
+                sh_logBase[sh_nlog] = ei;
+                sh_nlog++;
                 e++;
                 rem--;
                 r += 1;   // its '1'
                 depth = 2;
                 break;
+              }
+              sh_e = e;
+              sh_rem = rem;
+              sh_pos = a + r;
+              sh_depth = depth;
+            }
+            HI_WAVE_SYNC();
+            HI_T(2);
+            continue;
+          }
+          if (act == 11) {
+            // The rest of a short list, entry by entry: an insignificant one is a bit, a significant one whose split
+            // lies within the tables is queued like the pointer-jump pass queues it, one that leaves them is entered.
+            if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry it may enter)
+              hi_replay();
+            if (lane == 0) {
+              const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
+              uint32_t r = (uint32_t)(sh_pos - a), e = sh_e, rem = sh_rem, depth = 1;
+              const uint32_t lOff = b.levelOff[sh_level];
+              while (rem > 0 && r < SR) {
+                const uint32_t u = Utop[r];
+                if (u == 1u) {
+                  e++;
+                  rem--;
+                  r++;
+                  continue;
+                }
+                const uint32_t ei = lOff + e;
+                if (u == kTInf) {
+                  sh_fr[1] = (uint32_t)C.arity[K - 1] | ((uint32_t)(K - 2) << 24);
+                  sh_baseIdx = ei;
+                  sh_logHdr[sh_nlog] = 1u;
+                  sh_logBase[sh_nlog] = ei;
+                  sh_nlog++;
+                  e++;
+                  rem--;
+                  r += 1;   // its '1'
+                  depth = 2;
+                  break;
+                }
+                const uint32_t slot = atomicAdd(&sh_qn[0], 1u);
+                if (slot < b.queueCap) {
+                  qbuf[0][slot * 2] = ei;
+                  qbuf[0][slot * 2 + 1] = ((uint64_t)(r + 1) << 8) | ((uint64_t)(K - 1) << 1) | 1ull;
+                }
+                atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+                e++;
+                rem--;
+                r += u & 0x7fffu;
               }
               sh_e = e;
               sh_rem = rem;
@@ -2731,6 +2836,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           }
           HI_WAVE_SYNC();
           HI_T(4);
+          if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry P4 may enter)
+            hi_replay();
           if (lane == 0) {  // P4
             const uint32_t total = sh_total;
             uint32_t e = e0 + total;
@@ -2745,15 +2852,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             else if (sh_stopped && rem > 0) {
               // the entry at r leaves the region: walk into it
               const uint32_t ei = lOff + e;
-              const uint64_t ent = lisCur[ei];
-              TabCtx& nc = sh_ctx[1];
-              nc.parent = ent;
-              nc.remaining = C.arity[K - 1];
-              nc.cls = (int8_t)(K - 2);
-              nc.found = 0;
-              nc.nextOrd = 0;
-              sh_base = ent;
-              atomic_or64(sigbits + (ei >> 6), 1ull << (ei & 63));
+              sh_fr[1] = (uint32_t)C.arity[K - 1] | ((uint32_t)(K - 2) << 24);
+              sh_baseIdx = ei;   // (the entry itself is read, and its significance bit set, by hi_replay)
+              sh_logHdr[sh_nlog] = 1u;
+              sh_logBase[sh_nlog] = ei;
+              sh_nlog++;
               e++;
               rem--;
               r += 1;  // its '1'
@@ -2804,18 +2907,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     const bool last = sh_stop == 1 || sh_stop == 3;
     if (sh_stop == 1)
       break;
-    // ---- off the chain: the births the serial hop found, then the sets that split in this region
-    if (sh_nhb) {
-      const uint32_t nhb = sh_nhb;
-      if (tid == 0)
-        sh_total = atomicAdd(&s.bornCount, nhb);
-      __syncthreads();
-      if ((uint32_t)tid < nhb) {
-        const uint64_t m = sh_hbMeta[tid];
-        write_born(sh_total + (uint32_t)tid, (uint32_t)(m >> 48), m & ((1ull << 48) - 1ull), sh_hbKid[tid]);
-      }
-      __syncthreads();
-    }
+    // ---- off the chain: the sets that split in this region
     if (sh_tabLevel >= 0)
       expand_all();
     if (stamps) {
