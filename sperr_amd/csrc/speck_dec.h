@@ -35,7 +35,8 @@ struct DecState {
   // GPU-wide pass over the lists of the larger sets (k_lis_hi)
   uint32_t hiTicket;             // next region of the pass to hand out
   int32_t hiPlaneP1;             // 1 + the plane whose pass has ended (0: none)
-  int32_t hiHint;                // (plane + 1) << 8 | list level the chain was last seen in
+  int32_t hiHintPad;
+  uint64_t hiHint;               // (plane + 1) << 40 | list level the chain was last seen in << 32 | entries that list had left
   uint32_t hiCompactDone;        // workgroups of k_lis_compact that have finished (the last one ends the phase)
   uint64_t hiEnd;                // first bit after the phase
   uint64_t mxHint;               // k_lis_mx: (plane + 1) << 57 | list level << 48 | region << 28 | entries left, as the chain last published

@@ -2198,15 +2198,24 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       // The first wavefront, one lane per level (a loop over the levels on one lane is a
       // dependent LDS load per step).
       int hint = 0;
-      if (lane == 0)
-        hint = __hip_atomic_load(&s.hiHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hint = __shfl(hint, 0, 64);
-      if ((hint >> 8) != p + 1)
-        hint = -1;
-      else
-        hint &= 0xff;
-      if (hint < 0 || hint >= (int)t.nlevels || sh_len[hint] == 0)
+      uint32_t hintRem = 0;   // entries the hinted list had left when the chain was last seen (0: not known)
+      {
+        unsigned long long h64 = 0;
+        if (lane == 0)
+          h64 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&s.hiHint), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int hi32 = __shfl((int)(h64 >> 32), 0, 64);
+        hintRem = (uint32_t)__shfl((int)(uint32_t)h64, 0, 64);
+        hint = ((hi32 >> 8) != p + 1) ? -1 : (hi32 & 0xff);
+      }
+      if (hint < 0 || hint >= (int)t.nlevels || sh_len[hint] == 0) {
         hint = next_level((int)t.nlevels);
+        hintRem = 0;
+      }
+      // A list that had more entries left than the region has bits cannot end inside it (an entry is a bit at
+      // least): no class tables beyond its own chain then -- a quarter of the table work of the heavy planes,
+      // whose lists hold 10^5 entries and whose regions the workgroups' table building bounds at 64 chunks
+      // (several regions may have been handed out since the hint was left: each takes at most TS bits)
+      const int specExtra = (hintRem > 8u * TS) ? 0 : kSpecExtra;
       const int lv_ = (int)lane;
       const bool inr = lv_ < (int)t.nlevels;
       // (class chains are compared up to the classes the tables have room for: the sets above that are
@@ -2217,7 +2226,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       if (hint >= 0) {
         const int AK = min((int)sh_lc[hint].K, Kcap);
         int bestK = AK;
-        uint64_t cm = __ballot(usable && lv_ < hint && Kl > AK && Kl <= AK + kSpecExtra);
+        uint64_t cm = __ballot(usable && lv_ < hint && Kl > AK && Kl <= AK + specExtra);
         while (cm) {   // from the level below the hint downwards, as long as the chains get longer
           const int lv = 63 - __builtin_clzll(cm);
           cm &= ~(1ull << lv);
@@ -2564,8 +2573,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                   __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (unsigned long long)sh_baseIdx, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
-                  __hip_atomic_store(&s.hiHint, ((p + 1) << 8) | (int)sh_level, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.hiHint),
+                                     ((unsigned long long)(((p + 1) << 8) | (int)sh_level) << 32) | (unsigned long long)sh_rem,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (over)
                   sh_stop = 3;   // published the end of the phase
