@@ -1661,6 +1661,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     std::vector<ChunkGeom> hg;
     std::vector<uint32_t> hid;
     bool orgAligned;
+    EncPlanHost ph;   // the plane loop of the group is enqueued after every group's first half (launch_speck_encode_planes)
   };
   std::vector<std::unique_ptr<LateGroup>> late;
   static const bool encGroupsEnv = !(getenv("SPERR_HIP_ENC_GROUPS") && atoi(getenv("SPERR_HIP_ENC_GROUPS")) == 0);
@@ -1752,6 +1753,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         return -1;
 
       // ---- integer coder, 32-bit coefficients ----
+      const bool quadWalkGroup = slice && !(P->ht.flags & spk::kTree2D);   // (SPERR_HIP_SLICE_MIXED=0)
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
       // (the census of the pixel passes on a stream of its own beside the pyramid's upper levels: the
       //  decoder's outlier streams and events are idle during a compression call)
@@ -1761,8 +1763,18 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         ph.evFork = E.evOutlFork[gi % kSubStreams];
         ph.evJoin = E.evOutl[gi % kSubStreams];
       }
+      // the planes that can hold work are asked of the device before the plane loop is enqueued (speck_enc.h;
+      // the decoder's pinned words and events are idle during a compression call).  SPERR_HIP_ENC_BOUND=0: all planes
+      static const bool boundEnv = !(getenv("SPERR_HIP_ENC_BOUND") && atoi(getenv("SPERR_HIP_ENC_BOUND")) == 0);
+      if (boundEnv && !quadWalkGroup) {
+        ph.d_bound = A.take<uint32_t>(64);
+        ph.h_bound = E.liveHost[gi % kSubStreams];
+        ph.evBound = E.liveEv[gi % kSubStreams][0];
+        if (!ph.d_bound)
+          ph.h_bound = nullptr;
+      }
       Speck2dBufs sb;
-      const bool quadWalk = slice && !(P->ht.flags & spk::kTree2D);   // (SPERR_HIP_SLICE_MIXED=0)
+      const bool quadWalk = quadWalkGroup;
       if (quadWalk) {
         if (carve_slice2d(E, *P, sb))
           return -1;
@@ -1775,17 +1787,20 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         if (launch_speck2d_encode(ss, sb, raw_budget, rate, false))
           return -1;
       }
-      else if (launch_speck_encode(ss, e, ph, raw_budget, rate, false))
+      else if (sideBySide && ph.h_bound
+                   ? launch_speck_encode_head(ss, e, ph, raw_budget, rate, false)   // (its planes: once every group's first half is enqueued)
+                   : launch_speck_encode(ss, e, ph, raw_budget, rate, false))
         return -1;
       const uint32_t wblocks = (uint32_t)std::min<size_t>(4096, (e.streamStride * 8 + kThreads - 1) / kThreads);
-      LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, ss, e.cst, e.st,
-               e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
-               d_lens, P->N, 0);
+      if (!(sideBySide && ph.h_bound))
+        LAUNCH_K(k_write_slot, dim3(std::max(1u, wblocks), nb), dim3(kThreads), 0, ss, e.cst, e.st,
+                 e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
+                 d_lens, P->N, 0);
 
       // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
       if (sideBySide) {   // (the read-back is looked at once every group is enqueued)
         std::unique_ptr<LateGroup> L(new LateGroup{P, bb, nb, wblocks, raw_budget, ss, std::vector<CoderState>(nb),
-                                                   std::move(hg), std::move(hid), orgAligned});
+                                                   std::move(hg), std::move(hid), orgAligned, ph});
         late[gi] = std::move(L);        // (a read-back into pageable memory would block the host until
         continue;                       //  this group's stream has drained: it is done further down)
       }
@@ -1858,7 +1873,16 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       if (r)
         return -1;
   }
-  for (auto& L : late) {   // the groups that ran side by side: the 64-bit retry, where a chunk asked for it
+  for (auto& L : late) {   // the groups that ran side by side: their plane loops, each over the planes that can hold work
+    if (!L || !L->ph.h_bound)
+      continue;
+    EncBuffers& e = L->bb.eb;
+    if (launch_speck_encode_planes(L->ss, e, L->ph, L->raw_budget, rate, false))
+      return -1;
+    LAUNCH_K(k_write_slot, dim3(std::max(1u, L->wblocks), L->nb), dim3(kThreads), 0, L->ss, e.cst, e.st,
+             e.stream, e.streamStride, L->bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff, d_lens, L->P->N, 0);
+  }
+  for (auto& L : late) {   // the 64-bit retry, where a chunk asked for it
     if (!L)
       continue;
     HIP_CHECK(hipMemcpyAsync(L->hc.data(), L->bb.eb.cst, L->nb * sizeof(CoderState), hipMemcpyDeviceToHost, L->ss));

@@ -87,10 +87,26 @@ struct EncPlanHost {
   // only needs the pyramid, runs there beside the chain pass -- eight small dependent launches (round 3)
   hipStream_t side = nullptr;
   hipEvent_t evFork = nullptr, evJoin = nullptr;
+  // optional (round 5): the planes that can hold work, asked of the device before the plane loop is enqueued.
+  // A fixed-rate stream runs out of budget long before plane 0 (the bench volume: 18 of 32 planes), and the seven
+  // launches of a plane without work still cost 35 to 100 us on the batch's serial chain.  The pixel passes' bit
+  // counts (the census) bound the planes from below: where they alone exceed the budget, no later plane runs;
+  // the chunks' plane counts bound them from above.  k_enc_bound leaves both in d_bound[0..1], a copy lands in
+  // h_bound (pinned) and evBound is recorded: launch_speck_encode_head() ends there, and
+  // launch_speck_encode_planes() -- called once the caller has enqueued what else it has -- waits for the
+  // event and launches the planes in between only.  All three null: every plane is launched.
+  uint32_t* d_bound = nullptr;
+  uint32_t* h_bound = nullptr;
+  hipEvent_t evBound = nullptr;
 };
 
 int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
                         uint64_t raw_budget, bool rate_mode, bool wide_pass);
+// the same in two steps (plan.d_bound / h_bound / evBound set): everything up to the plane loop; the planes and the rest
+int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                             uint64_t raw_budget, bool rate_mode, bool wide_pass);
+int launch_speck_encode_planes(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                               uint64_t raw_budget, bool rate_mode, bool wide_pass);
 
 }  // namespace sperrhip
 #endif

@@ -1296,8 +1296,41 @@ __global__ void k_enc_finalize(EncBuffers b, uint64_t raw_budget, int rate_mode,
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
-                        uint64_t raw_budget, bool rate_mode, bool wide_pass)
+// The planes of a batch that can hold work (EncPlanHost::d_bound): out[1] = the largest plane count of its chunks,
+// out[0] = the lowest plane any chunk can reach -- where the bits of the pixel passes alone (the census: LIP scan
+// and refinement bits of every plane down to it) have used up the budget, the loop of src/SPECK_INT.cpp:146-158
+// has ended for that chunk whatever its sorting passes took.  One workgroup; thread = chunk.
+__global__ void __launch_bounds__(kThreads) k_enc_bound(EncBuffers b, uint32_t* out)
+{
+  __shared__ uint32_t lo, hi;
+  if (threadIdx.x == 0) {
+    lo = 0xffffffffu;
+    hi = 0;
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < b.nchunks; c += blockDim.x) {
+    const EncState& s = b.st[c];
+    if (!s.active || s.nbp <= 0)
+      continue;
+    int p = s.nbp - 1;
+    uint64_t cum = 0;
+    for (; p > 0; p--) {
+      cum += s.lipTot[p] + s.refTot[p];
+      if (cum >= s.budget)   // (the budget of a mode without one is ~0: never)
+        break;
+    }
+    atomicMin(&lo, (uint32_t)p);
+    atomicMax(&hi, (uint32_t)s.nbp);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = lo == 0xffffffffu ? 0u : lo;
+    out[1] = hi;
+  }
+}
+
+int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                             uint64_t raw_budget, bool rate_mode, bool wide_pass)
 {
   uint64_t budget = ~0ull;
   if (raw_budget != 0) {  // SPECK_INT.cpp:48-58
@@ -1340,11 +1373,32 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
   else
     LAUNCH_K(k_census, dim3(b.nPixTiles, nc), dim3(kThreads), 0, stream, b, maxPlanes);
   LAUNCH_K(k_census_scan, dim3(maxPlanes * 2, nc), dim3(kThreads), 0, stream, b);
+  if (plan.d_bound && plan.h_bound && plan.evBound) {
+    LAUNCH_K(k_enc_bound, dim3(1), dim3(kThreads), 0, stream, b, plan.d_bound);
+    HIP_CHECK(hipMemcpyAsync(plan.h_bound, plan.d_bound, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(plan.evBound, stream));
+  }
+  HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_speck_encode_planes(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                               uint64_t raw_budget, bool rate_mode, bool wide_pass)
+{
+  const uint32_t nc = b.nchunks;
+  const dim3 perChunk((nc + 63) / 64);
+  const int maxPlanes = wide_pass ? kMaxPlanes : 32;
+  int pTop = maxPlanes, pLow = 0;   // planes pTop - 1 .. pLow are launched
+  if (plan.d_bound && plan.h_bound && plan.evBound) {
+    HIP_CHECK(hipEventSynchronize(plan.evBound));
+    pLow = std::min<int>(maxPlanes - 1, (int)plan.h_bound[0]);
+    pTop = std::max(pLow + 1, std::min<int>(maxPlanes, (int)plan.h_bound[1]));
+  }
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
-  LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, maxPlanes - 1);
-  for (int p = maxPlanes - 1; p >= 0; p--) {
+  LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, pTop - 1);
+  for (int p = pTop - 1; p >= pLow; p--) {
     LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p,
-             p < maxPlanes - 1 ? 1 : 0);
+             p < pTop - 1 ? 1 : 0);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
     if (b.tree.flags & kTree2D)
@@ -1366,6 +1420,15 @@ int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHo
                      rate_mode ? 1 : 0, wide_pass ? 1 : 0);
   HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int launch_speck_encode(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
+                        uint64_t raw_budget, bool rate_mode, bool wide_pass)
+{
+  return launch_speck_encode_head(stream, b, plan, raw_budget, rate_mode, wide_pass) ||
+                 launch_speck_encode_planes(stream, b, plan, raw_budget, rate_mode, wide_pass)
+             ? -1
+             : 0;
 }
 
 }  // namespace sperrhip
