@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <stdlib.h>
 #include "speck_tree.h"
 
 #define HIP_CHECK(expr)                                                                       \
@@ -194,6 +195,46 @@ __device__ __forceinline__ void copy_bytes_wide(uint8_t* out, const uint8_t* in,
       dst64[j] = (s64[j] >> sh) | (s64[j + 1] << (64u - sh));
   for (uint64_t i = head + nb * 8 + tid; i < len; i += nthreads)
     out[i] = in[i];
+}
+
+// Tuning knobs whose sweeps are settled (round 5: the workgroup counts of the list kernels, k_lis_hi's table shape, the
+// lifting tiles, which experiments of rounds 2-5 stay switched on ...) are constants of the product build -- it reads
+// about twenty environment variables instead of fifty -- and environment variables only of the diagnostics build
+// (`make -C sperr_amd/csrc diag` -> sperr_amd/libsperr_hip_diag.so, -DSPERR_HIP_DIAG; SPERR_HIP_LIB loads it: the
+// sweeps under tools/ use that one).  What selects a code path tests exercise, places the farm's threads or caps memory
+// stays an environment variable of both.
+inline const char* tune_getenv(const char* name)
+{
+#ifdef SPERR_HIP_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+// A look-back wait (one workgroup waiting for the state its predecessor publishes: k_lis_l0 / _l1 / _hi, k_lis_mx) is
+// bounded by WALL TIME, not by a spin count: the protocols are deadlock-free (a waiter always waits for a running
+// workgroup), so the bound only guards against a device that has stopped making progress -- and a slow predecessor
+// (a shared or time-sliced device, a profiler, a debugger) must not turn a valid stream into a decode error, which a
+// count of 2^22 polls could.  s_memrealtime counts at 100 MHz whatever the shader clock does.  Callers set
+// DecState::error = kErrLookBackTimeout, which the host reports apart from a damaged stream.
+constexpr uint64_t kSpinLimitTicks = 60ull * 100000000ull;   // one minute
+constexpr uint32_t kErrCorrupt = 1u, kErrLookBackTimeout = 2u;
+__device__ __forceinline__ bool spin_expired(uint32_t spins, uint64_t& t0)
+{
+  if ((spins & 0x3fffu) != 0)
+    return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint64_t now = __builtin_amdgcn_s_memrealtime();
+#else
+  const uint64_t now = 0;   // (the host pass only parses this)
+#endif
+  if (t0 == 0) {
+    t0 = now | 1ull;
+    return false;
+  }
+  return now - t0 > kSpinLimitTicks;
 }
 
 __device__ __forceinline__ void atomic_or64(uint64_t* p, uint64_t v)

@@ -185,8 +185,16 @@ struct DevBuf {
     // (a quarter more than asked for, for the small buffers whose size follows the data -- outlier
     //  streams, slots --: a hipFree waits for every stream of the device, the other workers' included,
     //  and a buffer that fits exactly is too small for the next call's slightly longer streams)
-    const size_t want = bytes < (size_t(256) << 20) ? bytes + bytes / 4 + 4096 : bytes;
-    HIP_CHECK(hipMalloc(&p, want));
+    size_t want = bytes < (size_t(256) << 20) ? bytes + bytes / 4 + 4096 : bytes;
+    // (callers size their requests against the free memory they saw: when the slack is what does not fit,
+    //  the exact size still may)
+    if (want != bytes && hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      want = bytes;
+    }
+    if (!p)
+      HIP_CHECK(hipMalloc(&p, want));
     n = want;
     return 0;
   }
@@ -282,6 +290,8 @@ struct ShapePlan {
   size_t lisEntries = 0;
   std::vector<LiftPass> fwd;
 };
+bool use_tables(const ShapePlan& P);   // (defined with the decoder's plan logic below)
+
 
 struct Blob {  // host-side staging of all tables of a plan, uploaded in one copy
   std::vector<char> bytes;
@@ -310,7 +320,13 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
   P.dims[1] = (uint32_t)dy;
   P.dims[2] = (uint32_t)dz;
   P.N = (uint32_t)(dx * dy * dz);
-  P.ht = spk::build_tree(dx, dy, dz, twoD);
+  // (the columns of k_lis_mx only for the trees that can end up there: they cost as much as the rest of the tree)
+  P.ht = spk::build_tree(dx, dy, dz, twoD, false);
+  P.maxK = 0;
+  for (const auto& lc : P.ht.levelClass)
+    P.maxK = std::max<int>(P.maxK, lc.K);
+  if (!use_tables(P))
+    spk::build_mx_columns(P.ht);
   const spk::HostTree& h = P.ht;
   const uint32_t nlev = h.nlevels;
 
@@ -982,7 +998,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   // the chunk buffer for the last time: they lie over it (round 3; 127 of the 421 MB a 256^3 chunk
   // took).  A batch that needs the 64-bit retry transforms its chunks again and gives these arrays
   // memory of their own (Engine::wideScratch, compress_impl).  SPERR_HIP_ENC_ALIAS=0: no overlay.
-  static const bool aliasEnv = !(getenv("SPERR_HIP_ENC_ALIAS") && atoi(getenv("SPERR_HIP_ENC_ALIAS")) == 0);
+  static const bool aliasEnv = !(tune_getenv("SPERR_HIP_ENC_ALIAS") && atoi(tune_getenv("SPERR_HIP_ENC_ALIAS")) == 0);
   {
     Arena over;
     over.base = reinterpret_cast<char*>(o.vals);
@@ -1108,7 +1124,7 @@ bool plan_fusable(const ShapePlan& P)
 {
   if (P.fwd.empty())
     return false;
-  static const bool on = !(getenv("SPERR_HIP_LIFT_FUSE") && atoi(getenv("SPERR_HIP_LIFT_FUSE")) == 0);
+  static const bool on = !(tune_getenv("SPERR_HIP_LIFT_FUSE") && atoi(tune_getenv("SPERR_HIP_LIFT_FUSE")) == 0);
   if (!on)
     return false;
   uint32_t inner[3];
@@ -1605,7 +1621,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       const auto& c = chunks[i];
       const Dims d{c[1], c[3], c[5]};
       const uint32_t n = count[d], k = seen[d]++;
-      static const uint32_t partsMin = getenv("SPERR_HIP_ENC_PARTS_MIN") ? (uint32_t)std::max(2, atoi(getenv("SPERR_HIP_ENC_PARTS_MIN"))) : 64u;
+      static const uint32_t partsMin = tune_getenv("SPERR_HIP_ENC_PARTS_MIN") ? (uint32_t)std::max(2, atoi(tune_getenv("SPERR_HIP_ENC_PARTS_MIN"))) : 64u;
       const uint32_t parts = (mode == 1 && !slice && n >= partsMin && n <= 512) ? std::min<uint32_t>(std::min<uint32_t>(partsEnv, n / 4), kSubStreams) : 1u;
       groups[GKey{c[1], c[3], c[5], (size_t)((uint64_t)k * parts / n)}].push_back(
           {i, {(uint32_t)c[0], (uint32_t)c[2], (uint32_t)c[4]}});
@@ -1664,7 +1680,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     EncPlanHost ph;   // the plane loop of the group is enqueued after every group's first half (launch_speck_encode_planes)
   };
   std::vector<std::unique_ptr<LateGroup>> late;
-  static const bool encGroupsEnv = !(getenv("SPERR_HIP_ENC_GROUPS") && atoi(getenv("SPERR_HIP_ENC_GROUPS")) == 0);
+  static const bool encGroupsEnv = !(tune_getenv("SPERR_HIP_ENC_GROUPS") && atoi(tune_getenv("SPERR_HIP_ENC_GROUPS")) == 0);
   bool sideBySide = encGroupsEnv && mode == 1 && !slice && groups.size() > 1;
   std::vector<size_t> groupOff;
   if (sideBySide) {
@@ -1757,7 +1773,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       EncPlanHost ph{P->d_initLIS, P->d_initLen, P->d_depthBlocks, P->depthBlockOff, P->ht.nsets};
       // (the census of the pixel passes on a stream of its own beside the pyramid's upper levels: the
       //  decoder's outlier streams and events are idle during a compression call)
-      static const bool sideEnv = !(getenv("SPERR_HIP_ENC_SIDE") && atoi(getenv("SPERR_HIP_ENC_SIDE")) == 0);
+      static const bool sideEnv = !(tune_getenv("SPERR_HIP_ENC_SIDE") && atoi(tune_getenv("SPERR_HIP_ENC_SIDE")) == 0);
       if (sideEnv) {
         ph.side = E.sideQ[gi % kSubStreams];
         ph.evFork = E.evOutlFork[gi % kSubStreams];
@@ -1765,7 +1781,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       }
       // the planes that can hold work are asked of the device before the plane loop is enqueued (speck_enc.h;
       // the decoder's pinned words and events are idle during a compression call).  SPERR_HIP_ENC_BOUND=0: all planes
-      static const bool boundEnv = !(getenv("SPERR_HIP_ENC_BOUND") && atoi(getenv("SPERR_HIP_ENC_BOUND")) == 0);
+      static const bool boundEnv = !(tune_getenv("SPERR_HIP_ENC_BOUND") && atoi(tune_getenv("SPERR_HIP_ENC_BOUND")) == 0);
       if (boundEnv && !quadWalkGroup) {
         ph.d_bound = A.take<uint32_t>(64);
         ph.h_bound = E.liveHost[gi % kSubStreams];
@@ -1849,7 +1865,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     // (measured on MI355X, 1000^3 in 256^3 chunks, eight groups of about 1100 launches: 64.6 ms
     // with one thread, 66 ms with eight -- the groups' chains of small launches bound the call,
     // not the enqueueing host thread; off by default)
-    static const bool encThreadsEnv = getenv("SPERR_HIP_ENC_THREADS") && atoi(getenv("SPERR_HIP_ENC_THREADS")) != 0;
+    static const bool encThreadsEnv = tune_getenv("SPERR_HIP_ENC_THREADS") && atoi(tune_getenv("SPERR_HIP_ENC_THREADS")) != 0;
     const bool threaded = sideBySide && encThreadsEnv && !(t_prof && t_prof->on);
     std::vector<int> rcs(groups.size(), 0);
     int dev = 0;
@@ -1967,6 +1983,17 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
 // ------------------------------------------------------------------------------------------
 // decompression
 // ------------------------------------------------------------------------------------------
+// what a chunk's DecState::error says (common.h): a stream that does not add up, or a look-back wait that ran into
+// its wall-time bound -- the second is the device's trouble (shared, stalled), not the container's
+void report_dec_error(uint32_t code)
+{
+  if (code == kErrLookBackTimeout)
+    fprintf(stderr, "[sperr_hip] decoder: a look-back wait timed out after %llu s (device shared, paused or stalled?) -- "
+                    "the container may be fine\n", (unsigned long long)(kSpinLimitTicks / 100000000ull));
+  else
+    fprintf(stderr, "[sperr_hip] decoder: a chunk stream does not add up (damaged or truncated container)\n");
+}
+
 int read_container_info(const uint8_t* d_src, size_t src_len, ContainerInfo& ci, hipStream_t st)
 {
   std::vector<uint8_t> h(std::min<size_t>(src_len, 20));
@@ -2089,7 +2116,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   {
     // (only for the regular trees: there every birth of a sample comes through a leaf event; k_lis_mixed and
     //  k_lis_walk set mask bits themselves.  SPERR_HIP_TILE_SKIP=0: every tile swept on every plane)
-    static const bool tileSkip = !(getenv("SPERR_HIP_TILE_SKIP") && atoi(getenv("SPERR_HIP_TILE_SKIP")) == 0);
+    static const bool tileSkip = !(tune_getenv("SPERR_HIP_TILE_SKIP") && atoi(tune_getenv("SPERR_HIP_TILE_SKIP")) == 0);
     uint8_t* tb = nullptr;
     TAKE(tb, uint8_t, d.tileStride * B);
     d.tileBorn = (tileSkip && use_tables(P)) ? tb : nullptr;
@@ -2128,17 +2155,17 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   // k_lis_hi: a pair of queues per workgroup, up to hiGroupsMax workgroups per chunk
   // k_lis_hi keeps tables for the classes of the smallest sets only (2^3 .. 32^3 by default: SPERR_HIP_HI_KCAP);
   // larger sets are walked into bit by bit, which leaves the LDS to longer regions of the stream
-  static const int hiKcap = getenv("SPERR_HIP_HI_KCAP") ? std::max(2, atoi(getenv("SPERR_HIP_HI_KCAP"))) : 5;
+  static const int hiKcap = tune_getenv("SPERR_HIP_HI_KCAP") ? std::max(2, atoi(tune_getenv("SPERR_HIP_HI_KCAP"))) : 5;
   d.hiK = (uint32_t)std::min(std::max(2, P.maxK), hiKcap);
   {
-    static const uint32_t ahead = getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_AHEAD")) : 384u;
+    static const uint32_t ahead = tune_getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_AHEAD")) : 384u;
     d.hiAhead = ahead;
-    static const uint32_t extra = getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_EXTRA")) : 1u;
+    static const uint32_t extra = tune_getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_EXTRA")) : 1u;
     d.hiExtra = extra;
     // (round 5: off -- without the second table a region holds 6912 positions instead of 5632, a chunk has a fifth
     //  fewer regions on its serial chain, and the table it rebuilds now and then costs less than that:
     //  decompression of the bench volume 91.5 -> 94.5 GB/s, eight chunks 38.2 -> 39.3)
-    static const uint32_t hop2 = getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_HOP2")) : 0u;
+    static const uint32_t hop2 = tune_getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_HOP2")) : 0u;
     d.hiHop2 = hop2;
   }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
@@ -2339,7 +2366,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   // decode through the serial walk, one wavefront each) are not waited for one by one: each gets
   // its own piece of the arena and one of the sub-streams, and all of them are drained together.
   // SPERR_HIP_DEFER_GROUPS=0 decodes group after group.
-  static const bool deferEnv = !(getenv("SPERR_HIP_DEFER_GROUPS") && atoi(getenv("SPERR_HIP_DEFER_GROUPS")) == 0);
+  static const bool deferEnv = !(tune_getenv("SPERR_HIP_DEFER_GROUPS") && atoi(tune_getenv("SPERR_HIP_DEFER_GROUPS")) == 0);
   const bool deferOK = deferEnv && !anyOutlier && !mr && !slice && groups.size() > 1;
   // (groups of 32 and more chunks of a shape the table kernels take keep the sub-batch scheme)
   auto deferrable = [](const ShapePlan& P, size_t nchunksOfShape) {
@@ -2373,8 +2400,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       S->hs.resize(S->nb);
       HIP_CHECK(hipMemcpy(S->hs.data(), S->bb.db.st, S->nb * sizeof(DecState), hipMemcpyDeviceToHost));
       for (auto& hsx : S->hs)
-        if (hsx.error)
+        if (hsx.error) {
+          report_dec_error(hsx.error);
           rc = -1;
+        }
     }
     pending.clear();
     deferOff = 0;
@@ -2392,7 +2421,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   // coefficients have planes (byte 17 of a chunk: src/SPECK_INT.cpp:284-308); not for a slice that goes through
   // the quadtree walk of speck2d.hip, which updates coefficients itself.  SPERR_HIP_REF_PLANES=0: none
   // (k_ref_apply2 updates the coefficients plane by plane, as rounds 3 and 4 did).
-  static const bool refPlanesEnv = !(getenv("SPERR_HIP_REF_PLANES") && atoi(getenv("SPERR_HIP_REF_PLANES")) == 0);
+  static const bool refPlanesEnv = !(tune_getenv("SPERR_HIP_REF_PLANES") && atoi(tune_getenv("SPERR_HIP_REF_PLANES")) == 0);
   auto ref_planes_of = [&](const ShapePlan& P, const std::vector<Ref>& refs) -> uint32_t {
     if (!refPlanesEnv || (slice && !(P.ht.flags & spk::kTree2D)))
       return 0;
@@ -2409,7 +2438,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
   // from the integer coefficients, the buffer only ever holds the box of the second level (an eighth
   // of the chunk: 17 MB instead of 134 MB for 256^3).  Not with 64-bit coefficients (they live in the
   // buffer), outlier correctors (every pass stays in the buffer), the resolution hierarchy or slices.
-  static const bool compactEnv = !(getenv("SPERR_HIP_DEC_COMPACT") && atoi(getenv("SPERR_HIP_DEC_COMPACT")) == 0);
+  static const bool compactEnv = !(tune_getenv("SPERR_HIP_DEC_COMPACT") && atoi(tune_getenv("SPERR_HIP_DEC_COMPACT")) == 0);
   auto compact_box = [&](const ShapePlan& P, const std::vector<Ref>& refs, uint32_t box[3]) -> size_t {
     box[0] = box[1] = box[2] = 0;
     if (!compactEnv || !fuse_xyz(P) || !plan_fusable(P) || mr || slice || anyOutlier || P.fwd.size() < 3)
@@ -2543,7 +2572,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
       // LIS phase of the larger sets: 1 stream 74 ms, 3 streams 65 ms).
       // SPERR_HIP_SUBSTREAMS=n overrides the choice (1 = a single stream).
       static const int subEnv = getenv("SPERR_HIP_SUBSTREAMS") ? atoi(getenv("SPERR_HIP_SUBSTREAMS")) : 0;
-      static const bool threads = !(getenv("SPERR_HIP_ENQUEUE_THREADS") && atoi(getenv("SPERR_HIP_ENQUEUE_THREADS")) == 0);
+      static const bool threads = !(tune_getenv("SPERR_HIP_ENQUEUE_THREADS") && atoi(tune_getenv("SPERR_HIP_ENQUEUE_THREADS")) == 0);
       uint32_t nsub = nbAll >= 32 ? 2u : 1u;
       // A call that has the device to itself cuts a smaller batch finer (round 3): the chunks' serial
       // chains bound it, and four sub-batches side by side decode 8 chunks in 14.4 ms instead of 16.5,
@@ -2696,12 +2725,21 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
         ph.mxGroups = mxGroupsCall;
+        if (!ph.tables && !ph.mixed && !(slice && !(P->ht.flags & spk::kTree2D))) {
+          // (a tree neither the table kernels nor k_lis_mx take -- more than 288 / 352 grids or 48 roots: chunks of
+          //  2^30 samples and more -- decodes correctly, through one serial wavefront per chunk: say so, once)
+          static std::atomic<bool> warned{false};
+          if (!warned.exchange(true))
+            fprintf(stderr, "[sperr_hip] note: chunks of %u x %u x %u decode through the serial walk (k_lis_walk): their tree "
+                            "(%zu grids, %zu roots) exceeds what the parallel list kernels hold in LDS -- expect it to be slow\n",
+                    cd[0], cd[1], cd[2], P->ht.grids.size(), P->ht.roots.size());
+        }
         {
-          static const uint32_t gdivEnv = getenv("SPERR_HIP_MX_GRID_DIV") ? (uint32_t)atoi(getenv("SPERR_HIP_MX_GRID_DIV")) : 4u;
+          static const uint32_t gdivEnv = tune_getenv("SPERR_HIP_MX_GRID_DIV") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_MX_GRID_DIV")) : 4u;
           ph.gridDiv = (deferStream && mxGroupsCall != 0 && groups.size() >= 4) ? std::max<uint32_t>(1u, gdivEnv) : 1u;
         }
         // (the host thread may wait for this stream: it is the call's only one, or has a thread of its own)
-        static const bool liveEnv = !(getenv("SPERR_HIP_LIVE_CHECK") && atoi(getenv("SPERR_HIP_LIVE_CHECK")) == 0);
+        static const bool liveEnv = !(tune_getenv("SPERR_HIP_LIVE_CHECK") && atoi(tune_getenv("SPERR_HIP_LIVE_CHECK")) == 0);
         ph.d_live = (liveEnv && !deferStream && (nsub == 1 || threads)) ? bb.live : nullptr;
         ph.h_live = E.liveHost[q % kSubStreams];
         ph.liveEv = E.liveEv[q % kSubStreams];
@@ -2921,8 +2959,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           HIP_CHECK(hipStreamSynchronize(E.sub[q]));
       for (auto& S : subs)
         for (auto& hsx : S.hs)
-          if (hsx.error)
+          if (hsx.error) {
+            report_dec_error(hsx.error);
             return -1;
+          }
     }
   }
   if (drain())
@@ -3630,7 +3670,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     probe.cap = ~size_t(0) / 2;
     DecBatchBufs tmp;
     // (refinement bit planes like decompress_impl's: SPERR_HIP_REF_PLANES=0 switches them off)
-    static const bool refPlanesEnv = !(getenv("SPERR_HIP_REF_PLANES") && atoi(getenv("SPERR_HIP_REF_PLANES")) == 0);
+    static const bool refPlanesEnv = !(tune_getenv("SPERR_HIP_REF_PLANES") && atoi(tune_getenv("SPERR_HIP_REF_PLANES")) == 0);
     const uint32_t refNPlanes = (refPlanesEnv && !wide) ? (uint32_t)nbp : 0u;
     carve_dec(probe, *P, 1, 17 + stream_len, tmp, 0, refNPlanes);
     if (E.arena.ensure(probe.used + 4096))

@@ -779,16 +779,25 @@ int run_workers(Job& J, P&& prefetch, Cm&& compute, Fi&& finish)
         pr.set_value(fn());
         return pr.get_future();
       }
-      return std::async(std::launch::async, [dev, fn]() -> int {
-        try {
-          if (hipSetDevice(dev) != hipSuccess)
+      try {
+        return std::async(std::launch::async, [dev, fn]() -> int {
+          try {
+            if (hipSetDevice(dev) != hipSuccess)
+              return -1;
+            return fn();
+          }
+          catch (...) {
             return -1;
-          return fn();
-        }
-        catch (...) {
-          return -1;
-        }
-      });
+          }
+        });
+      }
+      catch (const std::system_error&) {
+        // no thread to be had (a process at its limit): the stage runs here, on the worker's own thread, like with
+        // helpersOn == false -- slower, not a failed call (parallel_do and run_workers degrade the same way)
+        std::promise<int> pr;
+        pr.set_value(fn());
+        return pr.get_future();
+      }
     };
     int rc = 0;
     try {

@@ -942,7 +942,7 @@ int launch_speck2d_encode(hipStream_t st, const Speck2dBufs& b_, uint64_t raw_bu
                           bool wide_pass)
 {
   Speck2dBufs b = b_;
-  static const uint32_t wbMin = getenv("SPERR_HIP_WB_MIN") ? (uint32_t)atoi(getenv("SPERR_HIP_WB_MIN")) : 4u;
+  static const uint32_t wbMin = tune_getenv("SPERR_HIP_WB_MIN") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_WB_MIN")) : 4u;
   b.wbMin = wbMin;
   uint64_t budget = ~0ull;
   if (raw_budget != 0) {  // SPECK_INT.cpp:48-58

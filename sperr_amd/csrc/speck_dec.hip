@@ -1038,6 +1038,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       if (i > 0) {
         unsigned long long f = 0;
         uint32_t spins = 0;
+        uint64_t spinT0 = 0;
         for (;;) {
           f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 56) == (unsigned long long)(p + 1))
@@ -1048,8 +1049,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
             stop = 1;
             break;
           }
-          if (spins > (1u << 21)) {   // cannot happen; never leave a wave spinning for ever
-            s.error = 1;
+          if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
+            s.error = kErrLookBackTimeout;
             __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;
             break;
@@ -1364,6 +1365,7 @@ k_lis_l1(DecBuffers b, int p)
       if (i > 0) {
         unsigned long long f = 0;
         uint32_t spins = 0;
+        uint64_t spinT0 = 0;
         for (;;) {
           f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 56) == (unsigned long long)(p + 1))
@@ -1374,8 +1376,8 @@ k_lis_l1(DecBuffers b, int p)
             stop = 1;
             break;
           }
-          if (spins > (1u << 21)) {   // cannot happen; never leave a wave spinning for ever
-            s.error = 1;
+          if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
+            s.error = kErrLookBackTimeout;
             __hip_atomic_store(&s.l1PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stop = 1;
             break;
@@ -2319,6 +2321,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             unsigned long long f = 0;
             if (i > 0) {
               uint32_t spins = 0;
+        uint64_t spinT0 = 0;
               for (;;) {
                 f = __hip_atomic_load(flags + (size_t)(i - 1) * 4 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((f >> kHiTagShift) == (unsigned long long)(p + 1))
@@ -2328,8 +2331,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                   f = tag | (1ull << 56);   // the phase is over
                   break;
                 }
-                if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
-                  s.error = 1;
+                if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
+                  s.error = kErrLookBackTimeout;
                   __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   f = tag | (1ull << 56);
                   break;
@@ -3535,8 +3538,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   const uint32_t gdiv = std::max<uint32_t>(1u, plan.gridDiv);
   const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide / gdiv);
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
-  static const uint32_t l0Total = getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L0_WGS")) : 512u;
-  static const uint32_t l01Cap = getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
+  static const uint32_t l0Total = tune_getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L0_WGS")) : 512u;
+  static const uint32_t l01Cap = tune_getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
   const uint32_t l0Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l0Total / nc));
   if (plan.tables && plan.l0) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l0), (int)kL0Smem) ||
@@ -3544,7 +3547,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       return -1;
   }
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
-  static const uint32_t l1Total = getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_L1_WGS")) : 768u;
+  static const uint32_t l1Total = tune_getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L1_WGS")) : 768u;
   const uint32_t l1Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l1Total / nc));
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc, kGridCap / gdiv);
   // workgroups per chunk of the k_lis_hi pass, at most what the queues were sized for
@@ -3552,7 +3555,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   // of 32 chunks side by side: 96 / 128 / 160 / 192 / 224 / 256 / 384 workgroups per sub-batch give
   // 70.8 / 75.3 / 76.3 / 76.0 / 75.0 / 74.5 / 74.3 GB/s of decompression; again after the region
   // bookkeeping went to one lane per level: 96 / 128 / 160 / 192 / 256 give 73.4 / 77.5 / 78.5 / 77.9 / 75.5)
-  static const uint32_t hiTotal = getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(getenv("SPERR_HIP_HI_WGS")) : 160u;
+  static const uint32_t hiTotal = tune_getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_WGS")) : 160u;
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
   // workgroups per chunk of k_lis_mx: the walk of a chunk is serial, the rows and the expansion of its regions are
   // what the other workgroups are for (SPERR_HIP_MX_WGS: the total over the batch's chunks)

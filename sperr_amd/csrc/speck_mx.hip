@@ -1235,6 +1235,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         bool have = false;
         if (i >= 2) {
           uint32_t spins = 0;
+          uint64_t spinT0 = 0;
           for (;;) {
             if (lane < 2)
               f = __hip_atomic_load(flags + (size_t)(i - 2) * kMxWordsPerRegion + lane, __ATOMIC_RELAXED,
@@ -1245,7 +1246,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
             if ((++spins & 15u) == 0 &&
                 __hip_atomic_load(&s.hiPlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1)
               break;
-            if (spins > (1u << 22))
+            if (spin_expired(spins, spinT0))
               break;   // (the look-back below gives up loudly)
             __builtin_amdgcn_s_sleep(1);
           }
@@ -1283,6 +1284,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     if (wave == 0) {
       {
         uint32_t spins = 0;
+          uint64_t spinT0 = 0;
         while (__hip_atomic_load(&sh_goDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)kMxPreWaves &&
                ++spins < (1u << 26))
           __builtin_amdgcn_s_sleep(1);
@@ -1292,6 +1294,7 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
         unsigned long long f = 0;
         if (i > 0) {
           uint32_t spins = 0;
+          uint64_t spinT0 = 0;
           for (;;) {
             f = __hip_atomic_load(flags + (size_t)(i - 1) * kMxWordsPerRegion + lane, __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
@@ -1302,8 +1305,8 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
               sh_abort = 1;   // the phase is over
               break;
             }
-            if (spins > (1u << 22)) {   // cannot happen; never leave a wave spinning for ever
-              s.error = 1;
+            if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
+              s.error = kErrLookBackTimeout;
               __hip_atomic_store(&s.hiPlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               sh_abort = 1;
               break;

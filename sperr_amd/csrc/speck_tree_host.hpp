@@ -439,7 +439,9 @@ inline void build_mx_columns(HostTree& h)
 // coarsest approximation, at list level = the number of transform levels; the three detail subbands
 // of every level are roots too (released by the type-I set, SPECK2D_INT.cpp:149-218: they are NOT
 // in the initial lists), at list level = their transform level.
-inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false)
+// mxColumns: also the columns of k_lis_mx (build_mx_columns); a caller that knows the tree goes to the table kernels
+// builds them later, if ever
+inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false, bool mxColumns = true)
 {
   using detail::Box;
   HostTree h;
@@ -666,7 +668,14 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false)
   if (twoD)   // (the chains of LevelClass follow the 3D level rule: the 2D forest goes by shape classes only)
     h.allRegular = false;
   build_classes(h, kClsTableH, kClsTableSlots);
-  build_mx_columns(h);
+  // (the columns of k_lis_mx enumerate every node of every grid -- as long as the rest of build_tree together: 57 of
+  //  116 ms for 256^3, half a second for 512^3 -- and a regular tree the table kernels take never looks at them)
+  if (mxColumns)
+    build_mx_columns(h);
+  else {
+    h.mxSlot.clear();
+    h.mxLevelGroup.assign(h.nlevels, 0);
+  }
   return h;
 }
 

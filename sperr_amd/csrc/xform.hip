@@ -1614,7 +1614,7 @@ static int pick_nl(uint32_t len, int axis, size_t* smem)
 {
   // (measured again with the dequantising inverse passes, SPERR_HIP_LIFT_LDS_KB: 20 / 36 / 72 KB
   //  along y and z give 9.1 / 8.3 / 11.5 ms for the 13 inverse passes of the bench volume)
-  static const int capYZ = getenv("SPERR_HIP_LIFT_LDS_KB") ? atoi(getenv("SPERR_HIP_LIFT_LDS_KB")) : 36;
+  static const int capYZ = tune_getenv("SPERR_HIP_LIFT_LDS_KB") ? atoi(tune_getenv("SPERR_HIP_LIFT_LDS_KB")) : 36;
   const size_t cap = (size_t)(axis == 0 ? 20 : capYZ) * 1024;
   for (int nl = 32; nl >= 1; nl >>= 1) {
     const size_t bytes = (size_t)len * (nl + 1) * sizeof(double);
@@ -1684,8 +1684,8 @@ static int xy_rows(uint32_t cx, uint32_t cy)
   if (cx < 2 || cy < 2)
     return 0;
   const size_t rowBytes = (size_t)(cx + 1) * sizeof(double);
-  static const int ldsKB = getenv("SPERR_HIP_XY_LDS_KB") ? atoi(getenv("SPERR_HIP_XY_LDS_KB")) : 68;
-  static const int maxRows = getenv("SPERR_HIP_XY_ROWS") ? atoi(getenv("SPERR_HIP_XY_ROWS")) : 32;
+  static const int ldsKB = tune_getenv("SPERR_HIP_XY_LDS_KB") ? atoi(tune_getenv("SPERR_HIP_XY_LDS_KB")) : 68;
+  static const int maxRows = tune_getenv("SPERR_HIP_XY_ROWS") ? atoi(tune_getenv("SPERR_HIP_XY_ROWS")) : 32;
   int rows = (int)(((size_t)ldsKB * 1024) / rowBytes);
   if (rows > maxRows)
     rows = maxRows;
@@ -1740,7 +1740,7 @@ int launch_lift_xy(hipStream_t stream, bool forward, double* vals, size_t valsSt
 
 bool lift_xyz_applicable(const uint32_t cdims[3])
 {
-  static const bool on = !(getenv("SPERR_HIP_LIFT_XYZ") && atoi(getenv("SPERR_HIP_LIFT_XYZ")) == 0);
+  static const bool on = !(tune_getenv("SPERR_HIP_LIFT_XYZ") && atoi(tune_getenv("SPERR_HIP_LIFT_XYZ")) == 0);
   if (!on || cdims[0] < 9 || cdims[1] < 9 || cdims[2] < 9)
     return false;
   // a thread's z pipelines are registers: (rows + halo) * cx positions over the workgroup's threads
