@@ -2158,7 +2158,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   static const int hiKcap = tune_getenv("SPERR_HIP_HI_KCAP") ? std::max(2, atoi(tune_getenv("SPERR_HIP_HI_KCAP"))) : 5;
   d.hiK = (uint32_t)std::min(std::max(2, P.maxK), hiKcap);
   {
-    static const uint32_t ahead = tune_getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_AHEAD")) : 384u;
+    static const uint32_t ahead = tune_getenv("SPERR_HIP_HI_AHEAD") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_AHEAD")) : 512u;   // (round 5, with regions of 6912 positions: eight chunks 38.9 -> 39.7 GB/s, 64 chunks the same)
     d.hiAhead = ahead;
     static const uint32_t extra = tune_getenv("SPERR_HIP_HI_EXTRA") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_EXTRA")) : 1u;
     d.hiExtra = extra;
