@@ -1377,6 +1377,11 @@ int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncP
     LAUNCH_K(k_enc_bound, dim3(1), dim3(kThreads), 0, stream, b, plan.d_bound);
     HIP_CHECK(hipMemcpyAsync(plan.h_bound, plan.d_bound, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipEventRecord(plan.evBound, stream));
+    // (something behind the event: under `rocprofv3 --pmc`, which runs one kernel at a time, the copy in front of an
+    //  event that is the LAST thing in its queue was never seen to complete -- the counter pass of a 64-chunk volume
+    //  hung in hipEventSynchronize until its timeout; the decoder's live check, the same copy + event with planes
+    //  queued behind it, never did.  A launch that does nothing costs 5 us once per batch.)
+    LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, -1);
   }
   HIP_CHECK(hipGetLastError());
   return 0;
