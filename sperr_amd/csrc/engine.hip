@@ -2193,6 +2193,13 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.sigbits, uint64_t, d.sigbitsStride * B);
   d.l0FlagStride = (d.streamStride * 64 + N) / 4096 + 4;   // (zero padding may be walked)
   TAKE(d.l0Flags, unsigned long long, d.l0FlagStride * B);
+  {
+    static const bool lbEnv = !(tune_getenv("SPERR_HIP_L01_LOOKBACK") && atoi(tune_getenv("SPERR_HIP_L01_LOOKBACK")) == 0);
+    d.l0Tab = nullptr;
+    if (lbEnv) {
+      TAKE(d.l0Tab, unsigned long long, d.l0FlagStride * 17 * B);
+    }
+  }
   d.l0Level = P.l0Level;
   TAKE(d.l1Flags, unsigned long long, d.l0FlagStride * B);
   d.l1Level = P.l1Level;
@@ -2752,6 +2759,8 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
           ph.l0 = ph.l1 = false;
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
+        if (d.l0Tab)
+          HIP_CHECK(hipMemsetAsync(d.l0Tab, 0, d.l0FlagStride * 17 * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * nb * 8, ss));
@@ -3712,6 +3721,8 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     ph.mixed = use_mixed(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * 8, st));
+    if (d.l0Tab)
+      HIP_CHECK(hipMemsetAsync(d.l0Tab, 0, d.l0FlagStride * 17 * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * 8, st));

@@ -135,6 +135,7 @@ struct DecBuffers {
   unsigned long long* l0Flags;
   size_t l0FlagStride;
   int32_t l0Level;             // LIS level it handles, or -1
+  unsigned long long* l0Tab;   // 17 words per block: its memo table (exit offset, entries, significant entries per entry offset), tagged like the look-back words; null: blocks wait for their predecessor's state only
   unsigned long long* l1Flags; // same for k_lis_l1
   int32_t l1Level;
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr

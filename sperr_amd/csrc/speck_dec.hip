@@ -948,6 +948,8 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[L];
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
   unsigned long long* flags = b.l0Flags + c * b.l0FlagStride;
+  unsigned long long* tabs = b.l0Tab ? b.l0Tab + c * b.l0FlagStride * 17 : nullptr;   // the blocks' published memo tables
+  __shared__ unsigned long long sh_lbT[64][17];
   const unsigned long long tag = (unsigned long long)(p + 1) << 56;
 
   for (;;) {
@@ -1032,40 +1034,93 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       memoS[tid] = sg;
     }
     __syncthreads();
-    // ---- look back, publish
-    if (tid == 0) {
-      uint32_t e = 0, rank = 0, sg = 0, stop = 0, last = 0;
+    // ---- look back, publish.  The state a chain enters a block with is (offset, entries so far, significant so
+    //      far); what a block does to it is its memo table: a function of the 17 offsets.  Until round 5 a block
+    //      waited for its predecessor's state, applied its table and published -- a hand-over through L2 per block,
+    //      about a microsecond each, the list's whole length in series (what bounded a batch of a few chunks).  Now
+    //      a block PUBLISHES ITS TABLE as soon as it has it (tagged entries, no fence), and a block that looks back
+    //      takes the nearest state that is out (64 blocks back at most: as many workgroups as a chunk has) and
+    //      applies the tables of the blocks in between itself -- the decoupled look-back of a scan whose carry is a
+    //      function, not a sum.  Blocks that wait resolve together instead of one after the other.
+    if (b.l0Tab && tid < 17)
+      __hip_atomic_store(tabs + (size_t)i * 17 + tid,
+                         tag | ((unsigned long long)memoX[tid] << 50) | ((unsigned long long)memoC[tid] << 25) |
+                             (unsigned long long)memoS[tid],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+      uint32_t e = 0, rank = 0, sg = 0, stop = 0;
       if (i > 0) {
-        unsigned long long f = 0;
         uint32_t spins = 0;
         uint64_t spinT0 = 0;
+        const int idx = (int)i - 1 - (int)lane;   // lane j looks at block i - 1 - j (-1: before the first block)
         for (;;) {
-          f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((f >> 56) == (unsigned long long)(p + 1))
+          unsigned long long f = 0;
+          if (idx >= 0 && (lane == 0 || b.l0Tab))
+            f = __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool out = (idx >= 0 && (f >> 56) == (unsigned long long)(p + 1)) || (idx == -1 && b.l0Tab);
+          const uint64_t om = __ballot(out);
+          bool done = false;
+          if (om) {
+            const uint32_t j0 = (uint32_t)__ffsll((long long)om) - 1u;   // the nearest state that is out
+            const unsigned long long f0 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f, (int)j0) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f >> 32), (int)j0) << 32);
+            const bool virt = (int)i - 1 - (int)j0 < 0;
+            if (!virt && ((f0 >> 55) & 1ull)) {
+              stop = 1;   // the list ended in that block
+              done = true;
+            }
+            else {
+              e = virt ? 0u : (uint32_t)(f0 >> 50) & 31u;
+              rank = virt ? 0u : (uint32_t)(f0 >> 25) & 0x1ffffffu;
+              sg = virt ? 0u : (uint32_t)f0 & 0x1ffffffu;
+              // the tables of the blocks in between: lane j < j0 loads block i - 1 - j's
+              bool have = true;
+              if (lane < j0) {
+#pragma unroll
+                for (int k = 0; k < 17; k++) {
+                  const unsigned long long t = __hip_atomic_load(tabs + (size_t)idx * 17 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  have = have && (t >> 56) == (unsigned long long)(p + 1);
+                  sh_lbT[lane][k] = t;
+                }
+              }
+              if (__ballot(lane < j0 && !have) == 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int j = (int)j0 - 1; j >= 0; j--) {   // (uniform: every lane follows the chain)
+                  const unsigned long long t = sh_lbT[j][e];
+                  const uint32_t cn = (uint32_t)(t >> 25) & 0x1ffffffu;
+                  if (rank + cn >= n) {   // the list ended in a block before this one (it says so itself)
+                    stop = 1;
+                    break;
+                  }
+                  rank += cn;
+                  sg += (uint32_t)t & 0x1ffffffu;
+                  e = (uint32_t)(t >> 50) & 31u;
+                }
+                done = true;
+              }
+            }
+          }
+          if (done)
             break;
-          // (the end-of-pass marker is looked at now and then: the poll stays one load long)
+          // (the end-of-pass marker is looked at now and then: the poll stays one round of loads long)
           if ((++spins & 15u) == 0 &&
               __hip_atomic_load(&s.l0PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
             stop = 1;
             break;
           }
           if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
-            s.error = kErrLookBackTimeout;
-            __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+              s.error = kErrLookBackTimeout;
+              __hip_atomic_store(&s.l0PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             stop = 1;
             break;
           }
         }
-        if (!stop) {
-          if ((f >> 55) & 1ull)
-            stop = 1;
-          else {
-            e = (uint32_t)(f >> 50) & 31u;
-            rank = (uint32_t)(f >> 25) & 0x1ffffffu;
-            sg = (uint32_t)f & 0x1ffffffu;
-          }
-        }
       }
+      if (tid == 0) {
+      uint32_t last = 0;
       if (!stop) {
         if (rank + memoC[e] >= n) {   // the list ends inside this block
           last = 1;
@@ -1086,6 +1141,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       sh_stop = stop;
       sh_endpos = 0;
       sh_endsig = 0;
+      }
     }
     for (uint32_t k = tid; k < (uint32_t)kL0Sub; k += kL0Threads)
       blkE[k] = kL0None;
