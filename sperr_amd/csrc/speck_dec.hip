@@ -1775,7 +1775,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   __shared__ uint8_t sh_ord0[kHiFrames + 2];
   __shared__ uint64_t sh_par[kHiFrames + 2];
   __shared__ uint32_t sh_qn[3];
-  __shared__ uint32_t sh_len[kMaxLevels];
+  __shared__ uint32_t sh_len[kMaxLevels], sh_lOff[kMaxLevels];
   __shared__ LevelClass sh_lc[kMaxLevels];
   __shared__ uint8_t sh_lslot[kMaxLevels];
   __shared__ uint64_t sh_serve;   // bit l: the tables in LDS serve level l's lists
@@ -1810,6 +1810,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   const uint32_t cur = s.cur;
   for (uint32_t l = tid; l < t.nlevels; l += kTabThreads) {
     sh_len[l] = s.listLen[cur][l];
+    sh_lOff[l] = b.levelOff[l];
     sh_lc[l] = b.levelClass[l];
     sh_lslot[l] = b.levelSlot[l];
   }
@@ -2549,69 +2550,76 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               sh_newr = r;  // the list ended in this block (only one block satisfies this)
           }
         };
+        // The chain's scalars -- position, list level, frames open, entry index, entries left -- are the same in
+        // every lane and live in REGISTERS while the chain runs (until round 5: LDS words owned by lane 0, read and
+        // written back around every step, a wave-wide fence each time); they go back to LDS where others look: at
+        // the publish, before an all-hands table build, behind the chain.
+        uint64_t cpos = sh_pos;
+        uint32_t clevel = sh_level, cdepth = sh_depth, ce = sh_e, crem = sh_rem, cstop = sh_stop, cover = sh_over;
         for (;;) {
-          if (lane == 0) {
-            uint32_t act = kActDone;
-            for (; sh_stop == 0;) {
-              const uint64_t pos = sh_pos;
-              if (pos >= a + SR)
-                break;
-              if (sh_depth == 1 && sh_rem == 0) {   // this list is through: the next one
-                const int lv = next_level((int)sh_level);
-                if (lv < 0) {
-                  sh_over = 1;
-                  break;
-                }
-                sh_level = (uint32_t)lv;
-                sh_e = 0;
-                sh_rem = sh_len[lv];
-              }
-              if (zeroRegion && sh_depth == 1) {
-                // one '0' per entry, nothing splits: count them off
-                const uint32_t z = min((uint32_t)(a + SR - pos), sh_rem);
-                sh_e += z;
-                sh_rem -= z;
-                sh_pos = pos + z;
-                continue;
-              }
-              const int lv = (int)sh_level;
-              const int K = sh_lc[lv].K;
-              if (!((sh_serve >> lv) & 1ull)) {
-                // chains that agree from the leaf class upwards share tables: classes are only added
-                bool extend = sh_tabLevel >= 0;
-                if (extend) {
-                  const LevelClass& A = sh_lc[sh_tabLevel];
-                  const LevelClass& B = sh_lc[lv];
-                  for (int j = 0; j < sh_tabK && j < (int)B.K; j++)
-                    extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
-                }
-                sh_tabFrom = extend ? sh_tabK : 0;
-                act = (!extend && sh_tabLevel >= 0 && (sh_qn[0] != 0 || pend || sh_nlog != 0)) ? kActFlushTables : kActTables;   // (pend: entries of the tables in place still to be queued)
-              }
-              else if (sh_depth > 1)
-                act = 8;    // serial hop
-              else if (K - 1 >= Kcap)
-                act = 10;   // a list of sets the tables do not cover: entry by entry
-              else if (sh_hopTop[0] == K - 1 || sh_hopTop[1] == K - 1)
-                act = 9;    // list entries
-              else if (sh_rem <= kHiSerial)
-                act = 11;   // a few entries without a pointer-jump table: one by one
-              else
-                act = kActHopTab;
+          uint32_t act = kActDone;
+          for (; cstop == 0;) {   // (every lane, the same values)
+            if (cpos >= a + SR)
               break;
+            if (cdepth == 1 && crem == 0) {   // this list is through: the next one
+              const int lv = next_level((int)clevel);
+              if (lv < 0) {
+                cover = 1;
+                break;
+              }
+              clevel = (uint32_t)lv;
+              ce = 0;
+              crem = sh_len[lv];
             }
-            sh_act2 = act;
+            if (zeroRegion && cdepth == 1) {
+              // one '0' per entry, nothing splits: count them off
+              const uint32_t z = min((uint32_t)(a + SR - cpos), crem);
+              ce += z;
+              crem -= z;
+              cpos += z;
+              continue;
+            }
+            const int lv = (int)clevel;
+            const int K = sh_lc[lv].K;
+            if (!((sh_serve >> lv) & 1ull)) {
+              // chains that agree from the leaf class upwards share tables: classes are only added
+              bool extend = sh_tabLevel >= 0;
+              if (extend) {
+                const LevelClass& A = sh_lc[sh_tabLevel];
+                const LevelClass& B = sh_lc[lv];
+                for (int j = 0; j < sh_tabK && j < (int)B.K; j++)
+                  extend = extend && A.arity[j] == B.arity[j] && A.lev[j] == B.lev[j];
+              }
+              if (lane == 0)
+                sh_tabFrom = extend ? sh_tabK : 0;
+              act = (!extend && sh_tabLevel >= 0 && (sh_qn[0] != 0 || pend || sh_nlog != 0)) ? kActFlushTables : kActTables;   // (pend: entries of the tables in place still to be queued)
+            }
+            else if (cdepth > 1)
+              act = 8;    // serial hop
+            else if (K - 1 >= Kcap)
+              act = 10;   // a list of sets the tables do not cover: entry by entry
+            else if (sh_hopTop[0] == K - 1 || sh_hopTop[1] == K - 1)
+              act = 9;    // list entries
+            else if (crem <= kHiSerial)
+              act = 11;   // a few entries without a pointer-jump table: one by one
+            else
+              act = kActHopTab;
+            break;
           }
-          HI_WAVE_SYNC();
           HI_T(0);
-          const uint32_t act = sh_act2;
           if (act < 8) {   // through the region, or all hands needed
             if (lane == 0) {
-              if (act == kActDone && sh_stop != 1) {
+              sh_pos = cpos;   // (where the other wavefronts, and this one when it comes back, look)
+              sh_level = clevel;
+              sh_depth = cdepth;
+              sh_e = ce;
+              sh_rem = crem;
+              sh_over = cover;
+              if (act == kActDone && cstop != 1) {
                 // ---- publish the state at the end of the region (or the end of the phase)
-                const bool over = sh_stop == 2 || sh_over != 0;
+                const bool over = cstop == 2 || cover != 0;
                 if (over) {
-                  s.hiEnd = sh_pos;
+                  s.hiEnd = cpos;
                   for (int k = 0; k < 4; k++)
                     __hip_atomic_store(flags + (size_t)i * 4 + k, tag | (1ull << 56), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -2619,28 +2627,29 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 }
                 else {
                   unsigned long long fr = 0;
-                  for (uint32_t d = 1; d < sh_depth; d++) {
+                  for (uint32_t d = 1; d < cdepth; d++) {
                     const uint32_t fw = sh_fr[d];
                     fr |= (unsigned long long)(((fw >> 8) & 15u) | (((fw >> 16) & 1u) << 4)) << (5 * (d - 1));
                   }
-                  const unsigned long long f0 = tag | ((unsigned long long)sh_depth << 52) |
-                                                ((unsigned long long)sh_level << 46) |
-                                                (unsigned long long)(sh_pos - S0);
-                  const unsigned long long f1 = tag | ((unsigned long long)sh_e << 28) | (unsigned long long)sh_rem;
+                  const unsigned long long f0 = tag | ((unsigned long long)cdepth << 52) |
+                                                ((unsigned long long)clevel << 46) |
+                                                (unsigned long long)(cpos - S0);
+                  const unsigned long long f1 = tag | ((unsigned long long)ce << 28) | (unsigned long long)crem;
                   __hip_atomic_store(flags + (size_t)i * 4 + 0, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 1, f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 2, tag | fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(flags + (size_t)i * 4 + 3, tag | (unsigned long long)sh_baseIdx, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
                   __hip_atomic_store(reinterpret_cast<unsigned long long*>(&s.hiHint),
-                                     ((unsigned long long)(((p + 1) << 8) | (int)sh_level) << 32) | (unsigned long long)sh_rem,
+                                     ((unsigned long long)(((p + 1) << 8) | (int)clevel) << 32) | (unsigned long long)crem,
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (over)
-                  sh_stop = 3;   // published the end of the phase
+                sh_stop = over ? 3u : cstop;   // (3: published the end of the phase)
                 if (b.lisStamps)
                   sh_t3 = __builtin_readcyclecounter();
               }
+              else
+                sh_stop = cstop;
               sh_action = act;
             }
             HI_T(1);
@@ -2653,7 +2662,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               hi_replay();
             break;
           }
-          const LevelClass& C = sh_lc[sh_level];
+          const LevelClass& C = sh_lc[clevel];
           const int K = C.K;
           if (act == 8) {
             // The sets being walked into (the table method's serial hop); an item that leaves the
@@ -2661,9 +2670,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             // runs this with uniform values: the children of a frame are stepped over with one table
             // look-up each; what became of child k and where goes to the log (lane k), the frame's word is
             // updated, and nothing else: no node, no slot, no queue item on the chain (hi_replay).
-            uint32_t r = (uint32_t)(sh_pos - a);
-            int depth = (int)sh_depth;
-            const uint32_t lvNow = sh_level;
+            uint32_t r = (uint32_t)(cpos - a);
+            int depth = (int)cdepth;
+            const uint32_t lvNow = clevel;
             while (depth > 1 && r < SR) {
               const uint32_t fw = sh_fr[depth - 1];
               if ((fw & 0xffu) == 0) {
@@ -2746,11 +2755,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
               if (enter)
                 depth++;
             }
-            if (lane == 0) {
-              sh_pos = a + r;
-              sh_depth = (uint32_t)depth;
-            }
-            HI_WAVE_SYNC();
+            cpos = a + r;
+            cdepth = (uint32_t)depth;
             HI_T(2);
             continue;
           }
@@ -2760,9 +2766,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             // a '1' entry is walked into like an entry that leaves the region.
             if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry it may enter)
               hi_replay();
+            uint32_t r = (uint32_t)(cpos - a), e = ce, rem = crem, depth = 1;
             if (lane == 0) {
-              uint32_t r = (uint32_t)(sh_pos - a), e = sh_e, rem = sh_rem, depth = 1;
-              const uint32_t lOff = b.levelOff[sh_level];
+              const uint32_t lOff = sh_lOff[clevel];
               while (rem > 0 && r < SR) {
                 const uint32_t lim = min(rem, SR - r);
                 const uint32_t v = bits32(r);
@@ -2790,11 +2796,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 depth = 2;
                 break;
               }
-              sh_e = e;
-              sh_rem = rem;
-              sh_pos = a + r;
-              sh_depth = depth;
             }
+            cpos = a + (uint32_t)__builtin_amdgcn_readfirstlane((int)r);   // (lane 0's, in every lane)
+            ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+            crem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+            cdepth = (uint32_t)__builtin_amdgcn_readfirstlane((int)depth);
             HI_WAVE_SYNC();
             HI_T(2);
             continue;
@@ -2804,10 +2810,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             // lies within the tables is queued like the pointer-jump pass queues it, one that leaves them is entered.
             if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry it may enter)
               hi_replay();
+            uint32_t r = (uint32_t)(cpos - a), e = ce, rem = crem, depth = 1;
             if (lane == 0) {
               const uint16_t* Utop = Uu + (size_t)(K - 1) * TS;
-              uint32_t r = (uint32_t)(sh_pos - a), e = sh_e, rem = sh_rem, depth = 1;
-              const uint32_t lOff = b.levelOff[sh_level];
+              const uint32_t lOff = sh_lOff[clevel];
               while (rem > 0 && r < SR) {
                 const uint32_t u = Utop[r];
                 if (u == 1u) {
@@ -2839,11 +2845,11 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
                 rem--;
                 r += u & 0x7fffu;
               }
-              sh_e = e;
-              sh_rem = rem;
-              sh_pos = a + r;
-              sh_depth = depth;
             }
+            cpos = a + (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+            ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+            crem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+            cdepth = (uint32_t)__builtin_amdgcn_readfirstlane((int)depth);
             HI_WAVE_SYNC();
             HI_T(2);
             continue;
@@ -2855,9 +2861,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
             HI_WAVE_SYNC();
           }
           const uint32_t* hp = sh_hopTop[0] == K - 1 ? hop : hop2;
-          const uint32_t pr = (uint32_t)(sh_pos - a);
-          const uint32_t remaining = sh_rem, e0 = sh_e;
-          const uint32_t lOff = b.levelOff[sh_level];
+          const uint32_t pr = (uint32_t)(cpos - a);
+          const uint32_t remaining = crem, e0 = ce;
+          const uint32_t lOff = sh_lOff[clevel];
           const uint32_t nblk = ((SR - 1 + wq0) >> 6) + 1;
           const int32_t rbase = -(int32_t)wq0;
           for (uint32_t k = lane; k < nblk; k += 64)
@@ -2907,34 +2913,37 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
           HI_T(4);
           if (sh_nlog >= (uint32_t)kHiLogCap)   // (room for the entry P4 may enter)
             hi_replay();
-          if (lane == 0) {  // P4
+          {  // P4 (every lane: the same LDS words in, the same values out)
             const uint32_t total = sh_total;
             uint32_t e = e0 + total;
             uint32_t rem = remaining - total;
             uint32_t r = sh_newr;
             uint32_t depth = 1;
-            if (r == 0xffffffffu || e + rem != sh_len[sh_level]) {   // cannot happen
-              s.error = 1;
+            if (r == 0xffffffffu || e + rem != sh_len[clevel]) {   // cannot happen
+              if (lane == 0)
+                s.error = 1;
               r = SR;
-              rem = sh_len[sh_level] - min(e, sh_len[sh_level]);
+              rem = sh_len[clevel] - min(e, sh_len[clevel]);
             }
             else if (sh_stopped && rem > 0) {
               // the entry at r leaves the region: walk into it
               const uint32_t ei = lOff + e;
-              sh_fr[1] = (uint32_t)C.arity[K - 1] | ((uint32_t)(K - 2) << 24);
-              sh_baseIdx = ei;   // (the entry itself is read, and its significance bit set, by hi_replay)
-              sh_logHdr[sh_nlog] = 1u;
-              sh_logBase[sh_nlog] = ei;
-              sh_nlog++;
+              if (lane == 0) {
+                sh_fr[1] = (uint32_t)C.arity[K - 1] | ((uint32_t)(K - 2) << 24);
+                sh_baseIdx = ei;   // (the entry itself is read, and its significance bit set, by hi_replay)
+                sh_logHdr[sh_nlog] = 1u;
+                sh_logBase[sh_nlog] = ei;
+                sh_nlog++;
+              }
               e++;
               rem--;
               r += 1;  // its '1'
               depth = 2;
             }
-            sh_rem = rem;
-            sh_e = e;
-            sh_pos = a + r;
-            sh_depth = depth;
+            crem = rem;
+            ce = e;
+            cpos = a + r;
+            cdepth = depth;
           }
           HI_WAVE_SYNC();
           HI_T(5);
