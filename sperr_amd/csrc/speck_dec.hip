@@ -1929,7 +1929,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   };
   // all threads; T_j for j < j1 - 1 ... every class in [j0, j1) gets both T_j and U_j (the top
   // class of a level only needs U, but a later level of the same chain may sit on top of it)
-  auto build_tables = [&](int lv, int j0, int j1) {
+  // (from: the first position anybody will look at -- a build in the middle of a region, when the chain has come to a
+  //  list the tables do not serve, starts where the chain stands: half the positions on average)
+  auto build_tables = [&](int lv, int j0, int j1, uint32_t from = 0) {
     const LevelClass& C = sh_lc[lv];
     for (int j = j0; j < j1; j++) {
       uint16_t* Uj = Uu + (size_t)j * TS;
@@ -1942,7 +1944,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         return (uint16_t)(tl == kTInf ? kTInf : (0x8000u | (1u + tl)));
       };
       // four independent positions per thread and pass: their LDS chains overlap
-      for (uint32_t r0 = tid; r0 <= W + 1; r0 += 4 * kTabThreads) {
+      for (uint32_t r0 = from + (uint32_t)tid; r0 <= W + 1; r0 += 4 * kTabThreads) {
         uint32_t tl[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1967,12 +1969,13 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   };
   // all threads; pointer-jump table over the coded items of class `top`, from every position:
   // hop[h] for h = r + wq0 (64-bit blocks are stream words): cnt << 16 | stop << 15 | exit
-  auto build_hop = [&](uint32_t* hop, int top) {
+  auto build_hop = [&](uint32_t* hop, int top, uint32_t from = 0) {
     const uint16_t* Utop = Uu + (size_t)top * TS;
     const uint32_t nblk = ((SR - 1 + wq0) >> 6) + 1;
+    const uint32_t blk0 = (min(from, SR - 1) + wq0) >> 6;   // the block position `from` lies in
     const int32_t rbase = -(int32_t)wq0;
     const uint32_t wave = (uint32_t)tid >> 6;
-    for (uint32_t bi = wave; bi < nblk; bi += kTabThreads / 64) {
+    for (uint32_t bi = blk0 + wave; bi < nblk; bi += kTabThreads / 64) {
       const uint32_t h = bi * 64 + lane;
       const int32_t rs = (int32_t)h + rbase;
       const bool live = rs >= 0 && rs < (int32_t)SR;
@@ -2004,9 +2007,9 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     }
     __syncthreads();
     for (uint32_t wide = 128; wide <= 256; wide <<= 1) {
-      for (uint32_t h = (uint32_t)tid; h < nblk * 64; h += kTabThreads) {
+      for (uint32_t h = (blk0 & ~3u) * 64u + (uint32_t)tid; h < nblk * 64; h += kTabThreads) {   // (from a 256-position boundary on)
         const int32_t rs = (int32_t)h + rbase;
-        if (rs < 0 || rs >= (int32_t)SR)
+        if (rs < 0 || rs >= (int32_t)SR || (h >> 6) < blk0)
           continue;
         const uint32_t v = hop[h];
         if (v & 0x8000u)
@@ -2961,7 +2964,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
         const int lv = (int)sh_level;
         const int K = min((int)sh_lc[lv].K, Kcap);
         const int j0 = sh_tabFrom;
-        build_tables(lv, j0, K);
+        build_tables(lv, j0, K, (uint32_t)min((uint64_t)(sh_pos - a), (uint64_t)SR));
         if (tid < 64) {
           const uint64_t m = serve_mask(lv, K);
           if (tid == 0) {
@@ -2974,7 +2977,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
       }
       else {   // kActHopTab
         const int K = sh_lc[sh_level].K;
-        build_hop(hop, K - 1);
+        build_hop(hop, K - 1, (uint32_t)min((uint64_t)(sh_pos - a), (uint64_t)SR));
         if (tid == 0)
           sh_hopTop[0] = K - 1;
       }
