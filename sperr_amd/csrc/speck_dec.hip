@@ -1768,7 +1768,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   // region has no pointer-jump table of its class, instead of all hands leaving the chain to build one (with one
   // table per region, round 5, the dozen short lists of every light plane cost 94 such builds per chunk); and the
   // region's one table is built for the first list from the hinted one on that is longer than this.
-  constexpr uint32_t kHiSerial = 48;
+#ifndef HI_SERIAL
+#define HI_SERIAL 48
+#endif
+  constexpr uint32_t kHiSerial = HI_SERIAL;
   __shared__ uint32_t sh_fr[kHiFrames + 2];
   __shared__ uint32_t sh_logHdr[kHiLogCap], sh_logBase[kHiLogCap], sh_logLane[kHiLogCap][8];
   __shared__ uint32_t sh_nlog, sh_baseIdx, sh_parInit, sh_baseIdx0, sh_depth0;
@@ -3084,8 +3087,10 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
     if (!skip)
       s.listLen[nx][l] = carry;
     // the workgroup that finishes last sets the chunk's state after the phase (what the one-workgroup table kernel's
-    // last lines do): nobody reads the current lists any more
-    __threadfence();
+    // last lines do): nobody reads the current lists any more.  (No fence in front of the count: the last workgroup
+    // reads nothing the others of this launch wrote -- its inputs are k_lis_hi's, a kernel ago -- and what all of them
+    // write is for the next kernel.  Rounds 2-4 had a __threadfence() here: an agent-scope release per workgroup,
+    // 25 levels x 32 chunks of them per plane, each writing back its XCD's L2.)
     if (atomicAdd(&s.hiCompactDone, 1u) == gridDim.x - 1) {
       const uint64_t phase0 = s.lipStart + s.lipBits;
       const uint64_t maskBits = (uint64_t)b.maskWords * 64;
