@@ -3609,7 +3609,12 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   const uint32_t tokBlocks = (uint32_t)((b.tokStride + kThreads - 1) / kThreads);
   // (plan.gridDiv: the batch decodes beside others that hold most of the device -- grids that fill a quarter of it)
   const uint32_t gdiv = std::max<uint32_t>(1u, plan.gridDiv);
-  const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, kGridCapWide / gdiv);
+  // (workgroups of the tile sweeps -- k_dec_count, k_lip_deposit, k_ref_deposit -- over all chunks: a large batch's light
+  //  planes pay for the dispatch of 16 K workgroups that find nothing to do; a quarter of them loop over four tiles
+  //  each: decompression of 64 chunks 93.6 -> 94.2 GB/s in alternating runs, round 5.  A few chunks keep the wide grid)
+  static const uint32_t tileCapEnv = tune_getenv("SPERR_HIP_TILE_GRID") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_TILE_GRID")) : 0u;
+  const uint32_t tileCap = tileCapEnv ? tileCapEnv : (nc >= 16 ? 4096u : kGridCapWide);
+  const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, tileCap / gdiv);
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = tune_getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L0_WGS")) : 512u;
   static const uint32_t l01Cap = tune_getenv("SPERR_HIP_L01_CAP") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L01_CAP")) : 64u;   // workgroups per chunk at most (round 2: 16 -- a batch of 8 chunks left most CUs idle)
