@@ -1400,18 +1400,25 @@ int launch_speck_encode_planes(hipStream_t stream, const EncBuffers& b, const En
     pTop = std::max(pLow + 1, std::min<int>(maxPlanes, (int)plan.h_bound[1]));
   }
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
+  // grid caps of the per-plane sweeps: a part of 16 chunks and more fills the chip four times over with 4096 / 2048
+  // workgroups, and in a light plane the launch costs what its idle workgroups take to dispatch (133.9 -> 137.5 GB/s
+  // at 64 chunks); a small batch keeps the wide grids, its heavy planes need them (profiles/r5_enc_grid_ab.txt)
+  static const char* wideEnv = tune_getenv("SPERR_HIP_ENC_WIDE_GRID");
+  static const char* smallEnv = tune_getenv("SPERR_HIP_ENC_SMALL_GRID");
+  const uint32_t wideCap = wideEnv ? (uint32_t)atoi(wideEnv) : (nc >= 16 ? 4096u : kGridCapWide);
+  const uint32_t smallCap = smallEnv ? (uint32_t)atoi(smallEnv) : (nc >= 16 ? 2048u : kGridCap);
   LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, pTop - 1);
   for (int p = pTop - 1; p >= pLow; p--) {
-    LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc), nc), dim3(kThreads), 0, stream, b, p,
+    LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc, smallCap), nc), dim3(kThreads), 0, stream, b, p,
              p < pTop - 1 ? 1 : 0);
     LAUNCH_K(k_list_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, kGridCapWide), nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, wideCap), nc), dim3(kThreads), 0, stream, b, p);
     if (b.tree.flags & kTree2D)
       LAUNCH_K(k_enc_iphase, perChunk, dim3(64), 0, stream, b, p);
-    LAUNCH_K(k_split_emit, dim3(capped_blocks(kSplitBlocks, nc), nc), dim3(kNodeBlock), 0, stream, b, p);
+    LAUNCH_K(k_split_emit, dim3(capped_blocks(kSplitBlocks, nc, smallCap), nc), dim3(kNodeBlock), 0, stream, b, p);
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
-      LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc), nc), dim3(kThreads), 0, stream, b, p);
+      LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc, smallCap), nc), dim3(kThreads), 0, stream, b, p);
     }
     LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, p, p - 1);
   }
