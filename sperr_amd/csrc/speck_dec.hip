@@ -914,7 +914,8 @@ constexpr uint32_t kL0None = 0xffffffffu;
 constexpr size_t kL0Smem = (size_t)(kL0W / 64 + 4) * 8 + (size_t)kL0W * (1 + 4 + 4);
 
 // chain summary: tokens << 21 | significant tokens << 14 | position reached (block-relative)
-__global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
+__global__ void __launch_bounds__(kL0Threads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_lis_l0(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
   DecState& s = b.st[c];
@@ -934,13 +935,10 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   __shared__ uint32_t entR[kL0W / 1024], entK[kL0W / 1024], entS[kL0W / 1024];
   __shared__ uint32_t blkE[kL0Sub], blkK[kL0Sub], blkS[kL0Sub];
   __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
-  __shared__ Grid sh_grids[kTabLdsGrids];   // (the launcher checks that the tree's grids fit)
 
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
   const Tree& t = b.tree;
-  for (uint32_t k = tid; k < t.ngrids; k += kL0Threads)
-    sh_grids[k] = t.grids[k];
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t* words = b.stream + c * b.streamStride;
   const uint64_t nwordsAvail = (s.avail + 63) / 64;
@@ -949,7 +947,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
   uint64_t* leafEv = b.leafEv + c * b.leafStride;
   unsigned long long* flags = b.l0Flags + c * b.l0FlagStride;
   unsigned long long* tabs = b.l0Tab ? b.l0Tab + c * b.l0FlagStride * 17 : nullptr;   // the blocks' published memo tables
-  __shared__ unsigned long long sh_lbT[64][17];
+  __shared__ uint32_t sh_lbT[64][17];   // X << 24 | tokens << 10 | significant tokens
   const unsigned long long tag = (unsigned long long)(p + 1) << 56;
 
   for (;;) {
@@ -1080,22 +1078,22 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
                 for (int k = 0; k < 17; k++) {
                   const unsigned long long t = __hip_atomic_load(tabs + (size_t)idx * 17 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   have = have && (t >> 56) == (unsigned long long)(p + 1);
-                  sh_lbT[lane][k] = t;
+                  sh_lbT[lane][k] = ((uint32_t)(t >> 50) & 31u) << 24 | ((uint32_t)(t >> 25) & 0x3fffu) << 10 | ((uint32_t)t & 0x3ffu);
                 }
               }
               if (__ballot(lane < j0 && !have) == 0ull) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int j = (int)j0 - 1; j >= 0; j--) {   // (uniform: every lane follows the chain)
-                  const unsigned long long t = sh_lbT[j][e];
-                  const uint32_t cn = (uint32_t)(t >> 25) & 0x1ffffffu;
+                  const uint32_t t = sh_lbT[j][e];
+                  const uint32_t cn = (t >> 10) & 0x3fffu;
                   if (rank + cn >= n) {   // the list ended in a block before this one (it says so itself)
                     stop = 1;
                     break;
                   }
                   rank += cn;
-                  sg += (uint32_t)t & 0x1ffffffu;
-                  e = (uint32_t)(t >> 50) & 31u;
+                  sg += t & 0x3ffu;
+                  e = t >> 24;
                 }
                 done = true;
               }
@@ -1227,7 +1225,7 @@ __global__ void __launch_bounds__(kL0Threads) k_lis_l0(DecBuffers b, int p)
       sigm |= bit << 7;
       negm |= (bit & (sgn ^ 1u)) << 7;
       const Node nd = unpack_node(ident);
-      const Grid g = sh_grids[nd.grid];
+      const Grid g = t.grids[nd.grid];
       const uint32_t fid = g.nodeOff + ((((uint32_t)nd.i[2] << g.e[1]) + nd.i[1]) << g.e[0]) + nd.i[0];
       if (sb < b.leafCap)
         leafEv[sb] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
