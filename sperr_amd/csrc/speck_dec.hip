@@ -906,9 +906,17 @@ __global__ void __launch_bounds__(64) k_lis_walk(DecBuffers b, int p)
 // A block is handed out only after all earlier ones, so a waiting block always waits for a
 // workgroup that is running (or has seen the pass end).
 // ------------------------------------------------------------------------------------------
+// (k_lis_l0's tick counters cost registers the kernel does not have at two workgroups a compute unit: they are compiled
+//  in with -DSPERR_HIP_L0_STAMPS=1 only, for tools/hi_stamps.py)
+#ifndef SPERR_HIP_L0_STAMPS
+#define SPERR_HIP_L0_STAMPS 0
+#endif
 constexpr int kTabLdsGrids = 288;   // grid descriptors the GPU-wide list kernels keep in LDS
 constexpr int kL0W = 8192;
 constexpr int kL0Threads = 1024;
+// (k_lis_l1 with 512 threads: two workgroups of eight wavefronts a compute unit and 128 registers a thread, where 1024
+//  threads at 64 registers spilled 38 of them: 98.3 -> 100.8 GB/s of decompression at 64 chunks, round 5)
+constexpr int kL1Threads = 512;
 constexpr int kL0Sub = kL0W / 64;
 constexpr uint32_t kL0None = 0xffffffffu;
 constexpr size_t kL0Smem = (size_t)(kL0W / 64 + 4) * 8 + (size_t)kL0W * (1 + 4 + 4);
@@ -960,6 +968,8 @@ k_lis_l0(DecBuffers b, int p)
     const uint32_t i = sh_ticket;
     if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
       break;
+    const bool l0stamps = SPERR_HIP_L0_STAMPS && b.lisStamps != nullptr && tid == 0 && c == 0;
+    uint64_t l0t[6] = {l0stamps ? __builtin_readcyclecounter() : 0, 0, 0, 0, 0, 0};
     const uint64_t a = phase0 + (uint64_t)i * kL0W;
     const uint64_t w0 = a >> 6;
     const uint32_t q0 = (uint32_t)(a & 63);
@@ -1040,6 +1050,8 @@ k_lis_l0(DecBuffers b, int p)
     //      takes the nearest state that is out (64 blocks back at most: as many workgroups as a chunk has) and
     //      applies the tables of the blocks in between itself -- the decoupled look-back of a scan whose carry is a
     //      function, not a sum.  Blocks that wait resolve together instead of one after the other.
+    if (l0stamps)
+      l0t[1] = __builtin_readcyclecounter();
     if (b.l0Tab && tid < 17)
       __hip_atomic_store(tabs + (size_t)i * 17 + tid,
                          tag | ((unsigned long long)memoX[tid] << 50) | ((unsigned long long)memoC[tid] << 25) |
@@ -1148,6 +1160,8 @@ k_lis_l0(DecBuffers b, int p)
     __syncthreads();
     if (sh_stop)
       break;
+    if (l0stamps)
+      l0t[2] = __builtin_readcyclecounter();
     // ---- where the chain enters each 1024-block, then each sub-block
     if (tid == 0) {
       uint32_t r = sh_e, rk = 0, sg = 0;
@@ -1176,6 +1190,8 @@ k_lis_l0(DecBuffers b, int p)
       }
     }
     __syncthreads();
+    if (l0stamps)
+      l0t[3] = __builtin_readcyclecounter();
     // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
     for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads)
       hopW[r] = 0;
@@ -1199,7 +1215,10 @@ k_lis_l0(DecBuffers b, int p)
       }
     }
     __syncthreads();
-    // ---- every thread handles the tokens that start at its positions
+    if (l0stamps)
+      l0t[4] = __builtin_readcyclecounter();
+    // ---- every thread handles the tokens that start at its positions (loading the list entries of several positions
+    //      before any is used was measured: the registers it takes spill at this kernel's 64, 98.6 -> 97.2 GB/s)
     for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads) {
       const uint32_t mk = hopW[r];
       if (mk == 0)
@@ -1230,6 +1249,12 @@ k_lis_l0(DecBuffers b, int p)
       if (sb < b.leafCap)
         leafEv[sb] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
     }
+    if (l0stamps) {
+      l0t[5] = __builtin_readcyclecounter();
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 48), 1ull);
+      for (int k = 0; k < 5; k++)
+        atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 49 + k), l0t[k + 1] - l0t[k]);
+    }
     if (sh_last) {
       if (tid == 0) {
         s.l0End = a + sh_endpos;
@@ -1257,12 +1282,14 @@ constexpr int kL1W = 4096;
 constexpr int kL1Ahead = 192;
 constexpr int kL1P = kL1W + kL1Ahead;           // positions with class-0 tables
 constexpr int kL1MaxTok = 137;
-constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1W * (4 + 1) +
+constexpr int kL1Per = kL1W / kL1Threads;        // positions a thread looks at in a sweep
+constexpr int kL1Rec = kL1W + 16;               // marks, and the child records of a token that starts at the block's end
+constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1Rec * 4 + (size_t)kL1W +
                            (size_t)kL1P * 2;
 
 // (eight waves per SIMD = two of these workgroups per CU: the phases are barrier- and latency-
 //  bound, a second resident workgroup fills the gaps)
-__global__ void __launch_bounds__(kL0Threads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(kL1Threads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_lis_l1(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
@@ -1279,7 +1306,7 @@ k_lis_l1(DecBuffers b, int p)
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l1_smem);
   uint32_t* hop64 = reinterpret_cast<uint32_t*>(l1_smem + (size_t)(kL1P / 64 + 4) * 8);
   uint32_t* hopW = hop64 + kL1W + 4;     // later: the marks of the tokens on the chain
-  uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1W);   // token length at every position
+  uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1Rec);   // token length at every position
   uint8_t* U0 = U1 + kL1W;           // coded class-0 item: 1, or 1 + T0 of the next position
   uint8_t* T0 = U0 + kL1P;           // split of a class-0 set that starts here
   __shared__ uint32_t memoX[kL1MaxTok + 1], memoC[kL1MaxTok + 1], memoS[kL1MaxTok + 1];
@@ -1292,7 +1319,7 @@ k_lis_l1(DecBuffers b, int p)
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
   const Tree& t = b.tree;
-  for (uint32_t k = tid; k < t.ngrids; k += kL0Threads)
+  for (uint32_t k = tid; k < t.ngrids; k += kL1Threads)
     sh_grids[k] = t.grids[k];
   const uint64_t phase0 = s.lipStart + s.lipBits;
   const uint64_t start0 = l0done ? s.l0End : phase0;
@@ -1323,11 +1350,11 @@ k_lis_l1(DecBuffers b, int p)
     if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
       break;
     const bool l1stamps = b.lisStamps != nullptr && tid == 0 && c == 0;
-    uint64_t l1t0 = l1stamps ? __builtin_readcyclecounter() : 0, l1t1 = 0, l1t2 = 0;
+    uint64_t l1t0 = l1stamps ? __builtin_readcyclecounter() : 0, l1t1 = 0, l1t2 = 0, l1t3 = 0, l1t4 = 0, l1t5 = 0;
     const uint64_t a = start0 + (uint64_t)i * kL1W;
     const uint64_t w0 = a >> 6;
     const uint32_t q0 = (uint32_t)(a & 63);
-    for (uint32_t k = tid; k < (uint32_t)(kL1P / 64 + 4); k += kL0Threads)
+    for (uint32_t k = tid; k < (uint32_t)(kL1P / 64 + 4); k += kL1Threads)
       wbits[k] = w0 + k < nwordsAvail ? words[w0 + k] : 0ull;
     __syncthreads();
     auto bit_at = [&](uint32_t r) -> uint32_t {
@@ -1340,7 +1367,7 @@ k_lis_l1(DecBuffers b, int p)
       return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
     };
     // ---- class 0: split length, then the coded item
-    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL0Threads) {
+    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL1Threads) {
       const uint32_t v = bits32(r);
       uint32_t y = 0, found = 0;
 #pragma unroll
@@ -1353,11 +1380,11 @@ k_lis_l1(DecBuffers b, int p)
       T0[r] = (uint8_t)(y + found + bit);
     }
     __syncthreads();
-    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL0Threads)
+    for (uint32_t r = tid; r < (uint32_t)kL1P; r += kL1Threads)
       U0[r] = (uint8_t)((bit_at(r) && r + 1 < (uint32_t)kL1P) ? 1u + T0[r + 1] : 1u);
     __syncthreads();
     // ---- class 1: the token at every position of the block
-    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL1Threads) {
       uint32_t len = 1;
       if (bit_at(r)) {
         uint32_t y = r + 1, found = 0;
@@ -1374,7 +1401,7 @@ k_lis_l1(DecBuffers b, int p)
     }
     __syncthreads();
     // ---- chains inside 64-position sub-blocks (lane = position)
-    for (uint32_t sb = wave; sb < (uint32_t)(kL1W / 64); sb += kL0Threads / 64) {
+    for (uint32_t sb = wave; sb < (uint32_t)(kL1W / 64); sb += kL1Threads / 64) {
       const uint32_t r = sb * 64 + lane, hEnd = (sb + 1) * 64;
       uint32_t v = (1u << 21) | (bit_at(r) << 14) | (r + U1[r]);
       bool inb = (v & 0x3fffu) < hEnd;
@@ -1390,7 +1417,7 @@ k_lis_l1(DecBuffers b, int p)
     }
     __syncthreads();
     for (uint32_t wide = 128; wide <= 1024; wide <<= 1) {
-      for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
+      for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL1Threads) {
         const uint32_t v = hopW[r], e = v & 0x3fffu;
         if (e < (uint32_t)kL1W && e / wide == r / wide)
           hopW[r] = (v & ~0x3fffu) + hopW[e];
@@ -1470,7 +1497,7 @@ k_lis_l1(DecBuffers b, int p)
       if (l1stamps)
         l1t2 = __builtin_readcyclecounter();
     }
-    for (uint32_t k = tid; k < (uint32_t)(kL1W / 64); k += kL0Threads)
+    for (uint32_t k = tid; k < (uint32_t)(kL1W / 64); k += kL1Threads)
       blkE[k] = kL0None;
     if (tid < kL1W / 1024)
       entR[tid] = kL0None;
@@ -1505,8 +1532,10 @@ k_lis_l1(DecBuffers b, int p)
       }
     }
     __syncthreads();
+    if (l1stamps)
+      l1t3 = __builtin_readcyclecounter();
     // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
-    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads)
+    for (uint32_t r = tid; r < (uint32_t)kL1Rec; r += kL1Threads)
       hopW[r] = 0;
     __syncthreads();
     const uint32_t rank0 = sh_rank, sig0 = sh_sig;
@@ -1528,38 +1557,61 @@ k_lis_l1(DecBuffers b, int p)
       }
     }
     __syncthreads();
+    if (l1stamps)
+      l1t4 = __builtin_readcyclecounter();
     // ---- first sweep: insignificant entries stay; significant ones count their births and leaf
-    //      events and take block-local slots (hop64[r] = birth slot | event slot << 16)
-    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
-      const uint32_t mk = hopW[r];
-      if (mk == 0)
-        continue;
-      const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
-      const uint64_t ident = list[q];
-      if (!bit_at(r)) {
-        keep[q - sb] = ident;
-        continue;
-      }
-      hop64[r + 1] = (uint32_t)ident;          // (a significant token is at least 10 bits long:
-      hop64[r + 2] = (uint32_t)(ident >> 32);  //  these words are its own)
-      uint32_t y = r + 1, found = 0, nb = 0, nl = 0;
+    //      events and take block-local slots (hop64[r] = birth slot | event slot << 16), and leave one record per child
+    //      in hopW[r + 3 + k] (a significant token is 16 bits and more: words r .. r + 15 of both arrays are its own,
+    //      and no token of the chain starts inside it, so the marks there are zero):
+    //        1 << 31 | k << 24 | coded << 23 | births before << 20 | leaf events before << 17 | splits << 16 | y - r
+    //      The second sweep then has one CHILD per thread and position instead of one token with its eight children
+    //      in series (a token every 40 positions or so: six lanes of a wavefront were busy, 25 of a block's 78
+    //      thousand cycles).  The list entries of a thread's four positions are loaded before any is used.
+    {
+      uint32_t mk4[kL1Per];
+      uint64_t id4[kL1Per];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const bool coded = found || k != 7;
-        const uint32_t u = coded ? U0[y] : T0[y];
-        if (coded && u == 1) {
-          const uint64_t rel = a + y - phase0;
-          nb += (bornSlot != 0xff && rel < maskBits) ? 1u : 0u;
+      for (int j = 0; j < kL1Per; j++)
+        mk4[j] = hopW[(uint32_t)tid + (uint32_t)j * kL1Threads];
+#pragma unroll
+      for (int j = 0; j < kL1Per; j++)
+        id4[j] = (mk4[j] && !(mk4[j] & 0x80000000u)) ? list[rank0 + (mk4[j] & 0xffffu) - 1u] : 0ull;
+#pragma unroll
+      for (int j = 0; j < kL1Per; j++) {
+        const uint32_t r = (uint32_t)tid + (uint32_t)j * kL1Threads;
+        const uint32_t mk = mk4[j];
+        if (mk == 0 || (mk & 0x80000000u))   // (a record another thread has just left inside its token: no mark here)
+          continue;
+        const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
+        const uint64_t ident = id4[j];
+        if (!bit_at(r)) {
+          keep[q - sb] = ident;
+          continue;
         }
-        else {
-          found = 1;
-          nl++;
+        hop64[r + 1] = (uint32_t)ident;
+        hop64[r + 2] = (uint32_t)(ident >> 32);
+        uint32_t y = r + 1, found = 0, nb = 0, nl = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const bool coded = found || k != 7;
+          const uint32_t u = coded ? U0[y] : T0[y];
+          uint32_t rec = 0x80000000u | ((uint32_t)k << 24) | ((uint32_t)coded << 23) | (nb << 20) | (nl << 17) | (y - r);
+          if (coded && u == 1) {
+            const uint64_t rel = a + y - phase0;
+            nb += (bornSlot != 0xff && rel < maskBits) ? 1u : 0u;
+          }
+          else {
+            found = 1;
+            nl++;
+            rec |= 1u << 16;
+          }
+          hopW[r + 3 + k] = rec;
+          y += u;
         }
-        y += u;
+        const uint32_t slotB = nb ? atomicAdd(&sh_nb, nb) : 0u;
+        const uint32_t slotL = atomicAdd(&sh_nl, nl);
+        hop64[r] = slotB | (slotL << 16);
       }
-      const uint32_t slotB = nb ? atomicAdd(&sh_nb, nb) : 0u;
-      const uint32_t slotL = atomicAdd(&sh_nl, nl);
-      hop64[r] = slotB | (slotL << 16);
     }
     __syncthreads();
     if (tid == 0)     // (two threads: the two returning atomics are in flight together)
@@ -1567,55 +1619,48 @@ k_lis_l1(DecBuffers b, int p)
     if (tid == 64)
       sh_baseL = sh_nl ? atomicAdd(&s.leafCount, sh_nl) : 0u;
     __syncthreads();
-    // ---- second sweep: write the births and the leaf events
-    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL0Threads) {
-      const uint32_t mk = hopW[r];
-      if (mk == 0 || !bit_at(r))
+    if (l1stamps)
+      l1t5 = __builtin_readcyclecounter();
+    // ---- second sweep: write the births and the leaf events, a child per record
+    for (uint32_t rr = tid; rr < (uint32_t)kL1Rec; rr += kL1Threads) {
+      const uint32_t rec = hopW[rr];
+      if (!(rec & 0x80000000u))
         continue;
+      const uint32_t k = (rec >> 24) & 7u, r = rr - 3u - k, y = r + (rec & 0xffffu);
+      const bool coded = (rec >> 23) & 1u;
       const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
-      const Grid g1 = sh_grids[nd.grid + 1];   // the grid of the children
-      uint32_t slotB = sh_baseB + (hop64[r] & 0xffffu), slotL = sh_baseL + (hop64[r] >> 16);
-      uint32_t y = r + 1, found = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const bool coded = found || k != 7;
-        const uint32_t u = coded ? U0[y] : T0[y];
-        const uint32_t cx = 2u * nd.i[0] + (uint32_t)(k & 1), cy = 2u * nd.i[1] + (uint32_t)((k >> 1) & 1),
-                       cz = 2u * nd.i[2] + (uint32_t)(k >> 2);
-        if (coded && u == 1) {   // stays insignificant: joins the list of the smallest sets
-          const uint64_t rel = a + y - phase0;
-          if (bornSlot != 0xff && rel < maskBits) {
-            if (slotB < b.bornStride) {
-              bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) |
-                                  ((uint64_t)cy << 16) | (uint64_t)cx;
-              bornPosLev[slotB] = ((uint64_t)bornLev << 48) | rel;
-              atomic_or64(bornMask + (rel >> 6), 1ull << (rel & 63));
-            }
-            slotB++;
+      const uint32_t cx = 2u * nd.i[0] + (k & 1u), cy = 2u * nd.i[1] + ((k >> 1) & 1u), cz = 2u * nd.i[2] + (k >> 2);
+      if (!((rec >> 16) & 1u)) {   // stays insignificant: joins the list of the smallest sets
+        const uint64_t rel = a + y - phase0;
+        if (bornSlot != 0xff && rel < maskBits) {
+          const uint32_t slotB = sh_baseB + (hop64[r] & 0xffffu) + ((rec >> 20) & 7u);
+          if (slotB < b.bornStride) {
+            bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) | ((uint64_t)cy << 16) | (uint64_t)cx;
+            bornPosLev[slotB] = ((uint64_t)bornLev << 48) | rel;
+            atomic_or64(bornMask + (rel >> 6), 1ull << (rel & 63));
           }
         }
-        else {                   // splits into its pixels
-          found = 1;
-          const uint32_t v = bits32(coded ? y + 1 : y);
-          uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
+      }
+      else {                       // splits into its pixels
+        const Grid g1 = sh_grids[nd.grid + 1];   // the grid of the children
+        const uint32_t slotL = sh_baseL + (hop64[r] >> 16) + ((rec >> 17) & 7u);
+        const uint32_t v = bits32(coded ? y + 1 : y);
+        uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
 #pragma unroll
-          for (int j = 0; j < 7; j++) {
-            const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
-            sigm |= bit << j;
-            negm |= (bit & (sgn ^ 1u)) << j;
-            fnd |= bit;
-            yy += 1u + bit;
-          }
-          const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
-          const uint32_t sgn = (v >> (yy + fnd)) & 1u;
-          sigm |= bit << 7;
-          negm |= (bit & (sgn ^ 1u)) << 7;
-          const uint32_t fid = g1.nodeOff + (((cz << g1.e[1]) + cy) << g1.e[0]) + cx;
-          if (slotL < b.leafCap)
-            leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
-          slotL++;
+        for (int j = 0; j < 7; j++) {
+          const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+          sigm |= bit << j;
+          negm |= (bit & (sgn ^ 1u)) << j;
+          fnd |= bit;
+          yy += 1u + bit;
         }
-        y += u;
+        const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
+        const uint32_t sgn = (v >> (yy + fnd)) & 1u;
+        sigm |= bit << 7;
+        negm |= (bit & (sgn ^ 1u)) << 7;
+        const uint32_t fid = g1.nodeOff + (((cz << g1.e[1]) + cy) << g1.e[0]) + cx;
+        if (slotL < b.leafCap)
+          leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
       }
     }
     if (l1stamps) {
@@ -1624,6 +1669,10 @@ k_lis_l1(DecBuffers b, int p)
       atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 57), l1t1 - l1t0);
       atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 58), l1t2 - l1t1);
       atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 59), now_ - l1t2);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 60), l1t3 - l1t2);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 61), l1t4 - l1t3);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 62), l1t5 - l1t4);
+      atomicAdd(reinterpret_cast<unsigned long long*>(b.lisStamps + 63), now_ - l1t5);
     }
     if (sh_last) {
       if (tid == 0) {
@@ -3667,7 +3716,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       if (plan.l0)
         LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
       if (plan.l1)
-        LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL0Threads), kL1Smem, stream, b, p);
+        LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL1Threads), kL1Smem, stream, b, p);
       if (!plan.hi)
         return -1;   // (use_tables() implies use_lis_hi(): engine.hip)
       LAUNCH_CT(k_lis_hi, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);

@@ -33,3 +33,8 @@ for i, name in enumerate(["decide", "publish", "hop", "P2", "P3", "P4"]):
 print("on-chain table builds", out[5], "hop rebuilds", out[6], "serial hops", out[7], "list passes", out[8])
 print("table phase per region: load+decide %d, class tables %d, hop tables %d, serve mask %d" % tuple(out[40 + i] // nb for i in range(4)))
 print("expansion per region: %.1f rounds, %d items" % (out[44] / nb, out[45] // nb))
+n0, n1 = max(1, out[48]), max(1, out[56])
+print("k_lis_l0 blocks %d: tables+memo %d, look-back %d, entry walks %d, marks %d, tokens %d ticks per block" %
+      ((out[48],) + tuple(out[49 + i] // n0 for i in range(5))))
+print("k_lis_l1 blocks %d: tables+memo %d, look-back %d, after %d (entry walks %d, marks %d, sweep 1 %d, sweep 2 %d) ticks per block" %
+      ((out[56],) + tuple(out[57 + i] // n1 for i in range(7))))
