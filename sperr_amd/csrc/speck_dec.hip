@@ -1283,8 +1283,8 @@ constexpr int kL1Ahead = 192;
 constexpr int kL1P = kL1W + kL1Ahead;           // positions with class-0 tables
 constexpr int kL1MaxTok = 137;
 constexpr int kL1Per = kL1W / kL1Threads;        // positions a thread looks at in a sweep
-constexpr int kL1Rec = kL1W + 16;               // marks, and the child records of a token that starts at the block's end
-constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1Rec * 4 + (size_t)kL1W +
+constexpr int kL1QCap = kL1W / 2;               // children of a block's significant tokens: eight of each of kL1W / 16 tokens
+constexpr size_t kL1Smem = (size_t)(kL1P / 64 + 4) * 8 + (size_t)(kL1W + 4) * 4 + (size_t)kL1W * (4 + 1) +
                            (size_t)kL1P * 2;
 
 // (eight waves per SIMD = two of these workgroups per CU: the phases are barrier- and latency-
@@ -1306,14 +1306,15 @@ k_lis_l1(DecBuffers b, int p)
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l1_smem);
   uint32_t* hop64 = reinterpret_cast<uint32_t*>(l1_smem + (size_t)(kL1P / 64 + 4) * 8);
   uint32_t* hopW = hop64 + kL1W + 4;     // later: the marks of the tokens on the chain
-  uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1Rec);   // token length at every position
+  uint8_t* U1 = reinterpret_cast<uint8_t*>(hopW + kL1W);   // token length at every position
   uint8_t* U0 = U1 + kL1W;           // coded class-0 item: 1, or 1 + T0 of the next position
   uint8_t* T0 = U0 + kL1P;           // split of a class-0 set that starts here
   __shared__ uint32_t memoX[kL1MaxTok + 1], memoC[kL1MaxTok + 1], memoS[kL1MaxTok + 1];
   __shared__ uint32_t entR[kL1W / 1024], entK[kL1W / 1024], entS[kL1W / 1024];
   __shared__ uint32_t blkE[kL1W / 64], blkK[kL1W / 64], blkS[kL1W / 64];
   __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
-  __shared__ uint32_t sh_nb, sh_nl, sh_baseB, sh_baseL;
+  __shared__ uint32_t sh_nb, sh_nl, sh_baseB, sh_baseL, sh_ntok;
+  __shared__ uint16_t tokQ[kL1W / 16];   // the significant tokens of a block: 16 bits each and more
   __shared__ Grid sh_grids[kTabLdsGrids];   // (the launcher checks that the tree's grids fit)
 
   const int tid = threadIdx.x;
@@ -1344,6 +1345,7 @@ k_lis_l1(DecBuffers b, int p)
       sh_ticket = over ? kL0None : atomicAdd(&s.l1Ticket, 1u);
       sh_nb = 0;
       sh_nl = 0;
+      sh_ntok = 0;
     }
     __syncthreads();
     const uint32_t i = sh_ticket;
@@ -1535,7 +1537,7 @@ k_lis_l1(DecBuffers b, int p)
     if (l1stamps)
       l1t3 = __builtin_readcyclecounter();
     // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
-    for (uint32_t r = tid; r < (uint32_t)kL1Rec; r += kL1Threads)
+    for (uint32_t r = tid; r < (uint32_t)kL1W; r += kL1Threads)
       hopW[r] = 0;
     __syncthreads();
     const uint32_t rank0 = sh_rank, sig0 = sh_sig;
@@ -1559,14 +1561,9 @@ k_lis_l1(DecBuffers b, int p)
     __syncthreads();
     if (l1stamps)
       l1t4 = __builtin_readcyclecounter();
-    // ---- first sweep: insignificant entries stay; significant ones count their births and leaf
-    //      events and take block-local slots (hop64[r] = birth slot | event slot << 16), and leave one record per child
-    //      in hopW[r + 3 + k] (a significant token is 16 bits and more: words r .. r + 15 of both arrays are its own,
-    //      and no token of the chain starts inside it, so the marks there are zero):
-    //        1 << 31 | k << 24 | coded << 23 | births before << 20 | leaf events before << 17 | splits << 16 | y - r
-    //      The second sweep then has one CHILD per thread and position instead of one token with its eight children
-    //      in series (a token every 40 positions or so: six lanes of a wavefront were busy, 25 of a block's 78
-    //      thousand cycles).  The list entries of a thread's four positions are loaded before any is used.
+    // ---- first sweep: insignificant entries stay, significant ones leave their list entry in their own words of
+    //      hop64 (a significant token is 16 bits and more) and queue up.  The list entries of a thread's positions are
+    //      loaded before any is used.
     {
       uint32_t mk4[kL1Per];
       uint64_t id4[kL1Per];
@@ -1575,12 +1572,12 @@ k_lis_l1(DecBuffers b, int p)
         mk4[j] = hopW[(uint32_t)tid + (uint32_t)j * kL1Threads];
 #pragma unroll
       for (int j = 0; j < kL1Per; j++)
-        id4[j] = (mk4[j] && !(mk4[j] & 0x80000000u)) ? list[rank0 + (mk4[j] & 0xffffu) - 1u] : 0ull;
+        id4[j] = mk4[j] ? list[rank0 + (mk4[j] & 0xffffu) - 1u] : 0ull;
 #pragma unroll
       for (int j = 0; j < kL1Per; j++) {
         const uint32_t r = (uint32_t)tid + (uint32_t)j * kL1Threads;
         const uint32_t mk = mk4[j];
-        if (mk == 0 || (mk & 0x80000000u))   // (a record another thread has just left inside its token: no mark here)
+        if (mk == 0)
           continue;
         const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
         const uint64_t ident = id4[j];
@@ -1590,27 +1587,47 @@ k_lis_l1(DecBuffers b, int p)
         }
         hop64[r + 1] = (uint32_t)ident;
         hop64[r + 2] = (uint32_t)(ident >> 32);
-        uint32_t y = r + 1, found = 0, nb = 0, nl = 0;
+        tokQ[atomicAdd(&sh_ntok, 1u)] = (uint16_t)r;
+      }
+    }
+    __syncthreads();
+    // ---- the significant tokens, one per thread (a token every 40 positions or so: found where they lie, six lanes of
+    //      a wavefront walked eight children each while the others waited -- 20 of a block's 67 thousand cycles):
+    //      births and leaf events are counted, take block-local slots, and every child is queued under its slot --
+    //      births from the front of Q (the marks' array: they are dead now), leaf events from its back:
+    //        position of the token | child << 12 | (child's position - token's) << 15 | coded << 23
+    uint32_t* Q = hopW;
+    if ((uint32_t)tid < sh_ntok) {
+      const uint32_t r = tokQ[tid];
+      uint32_t y = r + 1, found = 0, nb = 0, nl = 0, kinds = 0, offs[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const bool coded = found || k != 7;
-          const uint32_t u = coded ? U0[y] : T0[y];
-          uint32_t rec = 0x80000000u | ((uint32_t)k << 24) | ((uint32_t)coded << 23) | (nb << 20) | (nl << 17) | (y - r);
-          if (coded && u == 1) {
-            const uint64_t rel = a + y - phase0;
-            nb += (bornSlot != 0xff && rel < maskBits) ? 1u : 0u;
+      for (int k = 0; k < 8; k++) {
+        const bool coded = found || k != 7;
+        const uint32_t u = coded ? U0[y] : T0[y];
+        offs[k] = (y - r) | ((uint32_t)coded << 8);
+        if (coded && u == 1) {
+          const uint64_t rel = a + y - phase0;
+          if (bornSlot != 0xff && rel < maskBits) {
+            kinds |= 0x100u << k;
+            nb++;
           }
-          else {
-            found = 1;
-            nl++;
-            rec |= 1u << 16;
-          }
-          hopW[r + 3 + k] = rec;
-          y += u;
         }
-        const uint32_t slotB = nb ? atomicAdd(&sh_nb, nb) : 0u;
-        const uint32_t slotL = atomicAdd(&sh_nl, nl);
-        hop64[r] = slotB | (slotL << 16);
+        else {
+          found = 1;
+          nl++;
+          kinds |= 1u << k;
+        }
+        y += u;
+      }
+      uint32_t slotB = nb ? atomicAdd(&sh_nb, nb) : 0u;
+      uint32_t slotL = atomicAdd(&sh_nl, nl);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t desc = r | ((uint32_t)k << 12) | (offs[k] << 15);
+        if ((kinds >> (8 + k)) & 1u)
+          Q[slotB++] = desc;
+        else if ((kinds >> k) & 1u)
+          Q[kL1QCap - 1 - slotL++] = desc;
       }
     }
     __syncthreads();
@@ -1621,47 +1638,46 @@ k_lis_l1(DecBuffers b, int p)
     __syncthreads();
     if (l1stamps)
       l1t5 = __builtin_readcyclecounter();
-    // ---- second sweep: write the births and the leaf events, a child per record
-    for (uint32_t rr = tid; rr < (uint32_t)kL1Rec; rr += kL1Threads) {
-      const uint32_t rec = hopW[rr];
-      if (!(rec & 0x80000000u))
-        continue;
-      const uint32_t k = (rec >> 24) & 7u, r = rr - 3u - k, y = r + (rec & 0xffffu);
-      const bool coded = (rec >> 23) & 1u;
+    // ---- second sweep, a child per thread: the births ...
+    for (uint32_t i2 = tid; i2 < sh_nb; i2 += kL1Threads) {
+      const uint32_t desc = Q[i2];
+      const uint32_t r = desc & 0xfffu, k = (desc >> 12) & 7u, y = r + ((desc >> 15) & 0xffu);
       const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
       const uint32_t cx = 2u * nd.i[0] + (k & 1u), cy = 2u * nd.i[1] + ((k >> 1) & 1u), cz = 2u * nd.i[2] + (k >> 2);
-      if (!((rec >> 16) & 1u)) {   // stays insignificant: joins the list of the smallest sets
-        const uint64_t rel = a + y - phase0;
-        if (bornSlot != 0xff && rel < maskBits) {
-          const uint32_t slotB = sh_baseB + (hop64[r] & 0xffffu) + ((rec >> 20) & 7u);
-          if (slotB < b.bornStride) {
-            bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) | ((uint64_t)cy << 16) | (uint64_t)cx;
-            bornPosLev[slotB] = ((uint64_t)bornLev << 48) | rel;
-            atomic_or64(bornMask + (rel >> 6), 1ull << (rel & 63));
-          }
-        }
+      const uint64_t rel = a + y - phase0;
+      const uint32_t slotB = sh_baseB + i2;
+      if (slotB < b.bornStride) {   // stays insignificant: joins the list of the smallest sets
+        bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) | ((uint64_t)cy << 16) | (uint64_t)cx;
+        bornPosLev[slotB] = ((uint64_t)bornLev << 48) | rel;
+        atomic_or64(bornMask + (rel >> 6), 1ull << (rel & 63));
       }
-      else {                       // splits into its pixels
-        const Grid g1 = sh_grids[nd.grid + 1];   // the grid of the children
-        const uint32_t slotL = sh_baseL + (hop64[r] >> 16) + ((rec >> 17) & 7u);
-        const uint32_t v = bits32(coded ? y + 1 : y);
-        uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
+    }
+    // ---- ... and the leaf events: a child that splits into its pixels
+    for (uint32_t i2 = tid; i2 < sh_nl; i2 += kL1Threads) {
+      const uint32_t desc = Q[kL1QCap - 1 - i2];
+      const uint32_t r = desc & 0xfffu, k = (desc >> 12) & 7u, y = r + ((desc >> 15) & 0xffu);
+      const bool coded = (desc >> 23) & 1u;
+      const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
+      const uint32_t cx = 2u * nd.i[0] + (k & 1u), cy = 2u * nd.i[1] + ((k >> 1) & 1u), cz = 2u * nd.i[2] + (k >> 2);
+      const Grid g1 = sh_grids[nd.grid + 1];   // the grid of the children
+      const uint32_t slotL = sh_baseL + i2;
+      const uint32_t v = bits32(coded ? y + 1 : y);
+      uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-          const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
-          sigm |= bit << j;
-          negm |= (bit & (sgn ^ 1u)) << j;
-          fnd |= bit;
-          yy += 1u + bit;
-        }
-        const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
-        const uint32_t sgn = (v >> (yy + fnd)) & 1u;
-        sigm |= bit << 7;
-        negm |= (bit & (sgn ^ 1u)) << 7;
-        const uint32_t fid = g1.nodeOff + (((cz << g1.e[1]) + cy) << g1.e[0]) + cx;
-        if (slotL < b.leafCap)
-          leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+      for (int j = 0; j < 7; j++) {
+        const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+        sigm |= bit << j;
+        negm |= (bit & (sgn ^ 1u)) << j;
+        fnd |= bit;
+        yy += 1u + bit;
       }
+      const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
+      const uint32_t sgn = (v >> (yy + fnd)) & 1u;
+      sigm |= bit << 7;
+      negm |= (bit & (sgn ^ 1u)) << 7;
+      const uint32_t fid = g1.nodeOff + (((cz << g1.e[1]) + cy) << g1.e[0]) + cx;
+      if (slotL < b.leafCap)
+        leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
     }
     if (l1stamps) {
       const uint64_t now_ = __builtin_readcyclecounter();
