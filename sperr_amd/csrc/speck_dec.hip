@@ -918,6 +918,7 @@ constexpr int kL0Threads = 1024;
 //  threads at 64 registers spilled 38 of them: 98.3 -> 100.8 GB/s of decompression at 64 chunks, round 5)
 constexpr int kL1Threads = 512;
 constexpr int kL0Sub = kL0W / 64;
+constexpr int kL0Stage = kL0W / 2;   // list entries of a block staged in LDS (hop64's 32 KB)
 constexpr uint32_t kL0None = 0xffffffffu;
 constexpr size_t kL0Smem = (size_t)(kL0W / 64 + 4) * 8 + (size_t)kL0W * (1 + 4 + 4);
 
@@ -939,6 +940,7 @@ k_lis_l0(DecBuffers b, int p)
   uint32_t* hop64 = reinterpret_cast<uint32_t*>(l0_smem + (size_t)(kL0W / 64 + 4) * 8);
   uint32_t* hopW = hop64 + kL0W;     // later: the marks of the tokens on the chain
   uint8_t* U = reinterpret_cast<uint8_t*>(hopW + kL0W);
+  const uint64_t* stg64 = reinterpret_cast<const uint64_t*>(hop64);   // (later: the block's list entries)
   __shared__ uint32_t memoX[32], memoC[32], memoS[32];
   __shared__ uint32_t entR[kL0W / 1024], entK[kL0W / 1024], entS[kL0W / 1024];
   __shared__ uint32_t blkE[kL0Sub], blkK[kL0Sub], blkS[kL0Sub];
@@ -1192,12 +1194,22 @@ k_lis_l0(DecBuffers b, int p)
     __syncthreads();
     if (l0stamps)
       l0t[3] = __builtin_readcyclecounter();
+    const uint32_t rank0 = sh_rank, sig0 = sh_sig;
+    const uint32_t nloc = n - rank0;   // entries the list still holds at the start of the block
+    // ---- the block's list entries are one stretch of the list: they travel from HBM straight into LDS (hop64 is
+    //      free now: 4096 entries; global_load_lds, no register holds them) while the marks are worked out.  Fetched
+    //      where each token is handled they were eight loads in series per thread, two thousand cycles each (the
+    //      registers to have them in flight together this kernel does not have: profiles/r5_l01_phases.txt).
+    const uint32_t nstg = min(min(memoC[sh_e], nloc), (uint32_t)kL0Stage);
+    {
+      const uint32_t* list32 = reinterpret_cast<const uint32_t*>(list + rank0);
+      for (uint32_t d0 = wave * 64u; d0 < 2u * nstg; d0 += (kL0Threads / 64) * 64u)
+        __builtin_amdgcn_global_load_lds(list32 + min(d0 + lane, 2u * nstg - 1u), hop64 + d0, 4, 0, 0);
+    }
     // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
     for (uint32_t r = tid; r < (uint32_t)kL0W; r += kL0Threads)
       hopW[r] = 0;
     __syncthreads();
-    const uint32_t rank0 = sh_rank, sig0 = sh_sig;
-    const uint32_t nloc = n - rank0;   // entries the list still holds at the start of the block
     if (tid < kL0Sub && blkE[tid] != kL0None) {
       uint32_t r = blkE[tid], rk = blkK[tid], sg = blkS[tid];
       const uint32_t end = ((uint32_t)tid + 1) * 64;
@@ -1214,6 +1226,7 @@ k_lis_l0(DecBuffers b, int p)
         sh_endsig = sg;
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the staged list entries have landed)
     __syncthreads();
     if (l0stamps)
       l0t[4] = __builtin_readcyclecounter();
@@ -1224,7 +1237,8 @@ k_lis_l0(DecBuffers b, int p)
       if (mk == 0)
         continue;
       const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
-      const uint64_t ident = list[q];
+      const uint32_t li = (mk & 0xffffu) - 1u;
+      const uint64_t ident = li < nstg ? stg64[li] : list[q];
       if (!bit_at(r)) {
         keep[q - sb] = ident;
         continue;
