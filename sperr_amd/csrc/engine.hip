@@ -2787,8 +2787,10 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             dw.refPlanes = nullptr;
             HIP_CHECK(hipMemsetAsync(bb.vals, 0, bb.valsStride * nb * 8, ss));
           }
-          else if (d.refPlanes)   // (k_ref_assemble writes every coefficient; a plane's words are valid from wordTop down)
+          else if (d.refPlanes) { // (k_ref_assemble writes every coefficient; a plane's words are valid from wordTop down)
             HIP_CHECK(hipMemsetAsync(d.wordTop, 0, d.wordTopStride * nb, ss));
+            dw.coefSigned = fuseDq ? 1u : 0u;   // (read by the dequantising inverse passes only: LiftFuse::coefSigned)
+          }
           else
             HIP_CHECK(hipMemsetAsync(bb.coef32, 0, d.coefStride * nb * 4, ss));
           if (slice && !(P->ht.flags & spk::kTree2D)) {   // header + stream words by the 3D launcher (no planes), then the 2D coder
@@ -2848,6 +2850,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             lf.sigOld = d.sigOld;
             lf.maskStride = d.maskPixStride;
             lf.dst = d.st;
+            lf.coefSigned = d.refPlanes ? 1 : 0;
           }
           if (compactElems) {
             lf.bufx = cbox[0];

@@ -50,6 +50,31 @@ struct DecState {
   uint32_t listLen[2][spk::kMaxLevels];
 };
 
+// How k_ref_assemble hands a chunk's finished 32-bit coefficients to the dequantising inverse passes when the host
+// asks for it (DecBuffers::coefSigned, LiftFuse::coefSigned): with the SIGN IN BIT 31, so that those passes read
+// neither the sign nor the mask words.  Fixed-rate mode quantises to the full range of uint32_t
+// (src/SPECK_FLT.cpp:282-290), so a magnitude may need all 32 bits; but a decoded magnitude is
+// m + 2^(q-1) - 1 with q the lowest plane the sample was refined on (src/SPECK_INT.cpp:440-468): odd whenever q >= 2.
+//   1: at most 31 planes -- magnitude | sign << 31
+//   2: 32 planes, every q of the chunk >= 2 (the stream ran out at plane 2 or above) -- magnitude >> 1 | sign << 31
+//      (a non-zero magnitude is 2 t + 1)
+//   0: neither: magnitudes as they are, sign and masks read as ever
+// (sign: 1 = negative here; DecBuffers::sign has 1 = positive, src/SPECK_INT.cpp:174-175)
+__host__ __device__ inline int coef_scheme(const DecState& s)
+{
+  if (s.nbp <= 31)
+    return 1;
+  const int refPlane = s.refPlaneP1 - 1;
+  const int qmin = (refPlane >= 0 && refPlane < s.lastPlane) ? refPlane : s.lastPlane;
+  return qmin >= 2 ? 2 : 0;
+}
+// the magnitude of such a word (scheme 1 or 2)
+__host__ __device__ inline uint32_t coef_scheme_mag(uint32_t stored, bool two)
+{
+  const uint32_t t = stored & 0x7fffffffu;
+  return (two && t) ? 2u * t + 1u : t;
+}
+
 struct DecBuffers {
   spk::Tree tree;
   uint32_t nchunks;
@@ -79,6 +104,7 @@ struct DecBuffers {
   uint64_t* refMask;
   uint8_t* wordTop;
   size_t wordTopStride;
+  uint32_t coefSigned;         // k_ref_assemble: the sign goes into the coefficient word where the chunk allows it (coef_scheme)
   uint64_t* sign;              // initialised to all ones (SPECK_INT.cpp:174-175)
   size_t signStride;
   uint64_t* lis[2];

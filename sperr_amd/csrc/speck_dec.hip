@@ -3529,8 +3529,11 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
   const uint64_t* sigNew = b.sigNew + c * b.maskPixStride;
   const uint64_t* refMask = b.refMask + c * b.maskPixStride;
   const uint8_t* wordTop = b.wordTop + c * b.wordTopStride;
+  // the sign in bit 31 for the dequantising inverse passes where the chunk allows it (coef_scheme, speck_dec.h)
+  const int scheme = b.coefSigned != 0 ? coef_scheme(s) : 0;
+  const uint64_t* sign = b.sign + c * b.signStride;
   for (uint32_t w0 = wave * kW; w0 + kW <= nw; w0 += nwave * kW) {
-    uint64_t so[kW], sn[kW], rm[kW];
+    uint64_t so[kW], sn[kW], rm[kW], sg[kW];
     int top[kW], maxTop = 0;
     uint64_t any = 0;
     // (the eight words' tops as two aligned dwords: scalar loads like the mask words)
@@ -3542,6 +3545,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
       so[u] = sigOld[w];   // (w < nw <= maskPixStride, nw a multiple of eight: carve_dec)
       sn[u] = sigNew[w];
       rm[u] = refMask[w];  // (read with the others whether the pass was cut short or not: no load behind a branch)
+      sg[u] = sign[in ? w : 0u];
       if (!in)
         so[u] = sn[u] = 0;
       top[u] = so[u] ? min((int)((tops[u >> 2] >> (8 * (u & 3))) & 0xffu), nbp) : 0;
@@ -3586,6 +3590,8 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
             q = refPlane + 1;
         }
         v = m ? m + (q >= 1 ? (1u << (q - 1)) - 1u : 0u) : 0u;
+        if (scheme)   // (a set bit of the sign array is "positive", SPECK_INT.cpp:174-175)
+          v = (scheme == 2 ? v >> 1 : v) | (((sg[u] >> lane) & 1ull) ? 0u : 0x80000000u);
       }
       coef[(size_t)w * 64 + lane] = v;
     }

@@ -46,6 +46,10 @@ struct LiftFuse {
   const uint64_t* sigOld = nullptr;
   size_t maskStride = 0;
   const DecState* dst = nullptr;
+  // 1: k_ref_assemble has written the coefficients complete (never-refined ones included) and, chunk by chunk where
+  // coef_scheme(dst[c]) allows it, with the sign in bit 31 (speck_dec.h): the sign and mask words are not read at all then.
+  // q * double(magnitude), sign flipped = q * double(magnitude) * (+-1.0) bit for bit (a zero is positive either way)
+  int coefSigned = 0;
   // inverse, compact chunk buffer (round 3): `vals` holds only the box the coarser levels work in,
   // rows of bufx samples and bufy rows per slice (0: the chunk's own dims); the coefficient and mask
   // arrays keep the chunk's dims

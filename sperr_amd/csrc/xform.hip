@@ -301,6 +301,7 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
   // value of a coefficient that became significant on the last decoded plane / the one before and
   // was never refined (k_inv_quantize)
   const uint32_t lastPl = (dequant && F.dst) ? (uint32_t)F.dst[c].lastPlane : 0u;
+  const int scheme = (dequant && F.coefSigned != 0 && F.dst) ? coef_scheme(F.dst[c]) : 0;
   const uint32_t initNew = (1u << lastPl) + (1u << lastPl) - (1u << lastPl) / 2 - 1;
   const uint32_t initOld = lastPl < 31 ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
   auto fetch = [&](uint32_t l, uint32_t p) -> LT {
@@ -309,6 +310,10 @@ k_lift_axis(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, int axis,
     if (!FORWARD && dequant) {
       size_t idx;
       if (outside_inner(l, p, idx)) {   // k_inv_quantize for this one sample; the loads are independent
+        if (scheme) {   // (the sign in bit 31, the value complete: LiftFuse::coefSigned)
+          const uint32_t sv = F.coef[c * F.coefStride + idx];
+          return (LT)(fq * (double)coef_scheme_mag(sv, scheme == 2) * ((sv >> 31) ? -1.0 : 1.0));
+        }
         const uint32_t w = (uint32_t)(idx >> 6), sh = (uint32_t)(idx & 63);
         uint32_t v = F.coef[c * F.coefStride + idx];
         const uint64_t sgw = F.sign[c * F.signStride + w];
@@ -1023,7 +1028,10 @@ k_lift_xyz_fwd(double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32
   }
 }
 
-template <int IO>
+// SG: the coefficients carry their sign where the chunk allows it (LiftFuse::coefSigned, coef_scheme), a kernel of its own -- with both fast paths in
+// one function the register allocator spilled inside the slice loop (88 registers against 38) and the kernel took 5.4 ms
+// instead of 3.7
+template <int IO, bool SG>
 __global__ void __launch_bounds__(kXYZThreadsI) __attribute__((amdgpu_waves_per_eu(kXYZThreadsI / 256, kXYZThreadsI / 256)))
 k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, uint32_t cz, LiftConsts K,
                const CoderState* st, void* volume, VolDesc vd, const ChunkGeom* geom, LiftFuse F, uint32_t nseg)
@@ -1088,6 +1096,13 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
   const uint32_t lastPl = haveMasks ? (uint32_t)F.dst[c].lastPlane : 0u;
   const uint32_t initNew = haveMasks ? (1u << lastPl) + (1u << lastPl) - (1u << lastPl) / 2 - 1 : 0u;
   const uint32_t initOld = (haveMasks && lastPl < 31) ? (2u << lastPl) + (2u << lastPl) - (2u << lastPl) / 2 - 1 : 0u;
+  // the sign in bit 31, the value complete (k_ref_assemble, LiftFuse::coefSigned): neither the sign nor the mask words are read
+  const int scheme = (SG && dequant && F.dst) ? coef_scheme(F.dst[c]) : 0;   // (0: this chunk keeps magnitudes and masks)
+  const bool two = scheme == 2;
+  auto sg_value = [&](uint32_t sv) -> double {
+    double d = fq * (double)coef_scheme_mag(sv, two);
+    return __hiloint2double(__double2hiint(d) ^ (int)(sv & 0x80000000u), __double2loint(d));   // * -1.0, exactly
+  };
   // sample (dcol, drow, zp): straight from the decoder (q * double(c) * (+-1.0), src/SPECK_FLT.cpp:373-399)
   // unless a coarser level's passes have produced it
   auto fetch = [&](int k, uint32_t zp) -> double {
@@ -1098,6 +1113,8 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     if (!dequant && !inBox && F.bufx)
       return 0.0;   // (a compact buffer holds the box only; the host asks for one only when every chunk dequantises here)
     if (dequant && !inBox) {
+      if (SG && scheme)
+        return sg_value(coef[idx]);
       uint32_t v = coef[idx];
       const uint32_t sh = (uint32_t)(idx & 63);
       const uint64_t sgw = sign[idx >> 6], mnw = mNew[idx >> 6], mow = mOld[idx >> 6];   // (independent loads)
@@ -1193,6 +1210,11 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       activeMask |= 1u << k;
     else
       pk[k] = pk[0];   // (a valid position: its loads are harmless, nothing of it is staged)
+  uint32_t boxAny = 0;   // bit k: some lane of this wavefront has position k inside the coarser levels' box (along x and y)
+#pragma unroll
+  for (int k = 0; k < kXYZPosI; k++)
+    boxAny |= __ballot((innerMask >> k) & 1u) != 0ull ? 1u << k : 0u;
+  boxAny = (uint32_t)__builtin_amdgcn_readfirstlane((int)boxAny);
   auto pos_off = [&](int k, uint32_t& drow, uint32_t& dcol) {
     const uint32_t y = (pk[k] >> 12) & 0x7fffu, x = pk[k] & 0xfffu;
     drow = (y & 1) ? ye + (y >> 1) : (y >> 1);
@@ -1209,7 +1231,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     }
   };
   // (a high-half sample never lies in the next level's box when that box ends at or before the low half)
-  const bool fastLoads = dequant && F.inner[2] <= ze;
+  const bool fastLoads = dequant && F.inner[2] <= ze && (!SG || scheme != 0);
   if (fastLoads && mFirst < mB)
     pre_issue(mFirst);
 #endif
@@ -1219,7 +1241,46 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     for (int k = 0; k < kXYZPosI; k++)
       asm volatile("" : "+v"(pk[k]));
 #if XYZ_INV_PREFETCH == 2
-    if (fastLoads) {
+    if (SG && fastLoads) {
+      // (round 5) the coefficients carry their sign and are complete: a pair's global loads are the fp64 samples of
+      // the coarser levels' box alone -- and only in the wavefronts that have a lane in the box (with 256 samples a
+      // row: those whose rows are the even ones)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pair's coefficients have landed in LDS
+      const bool boxWave = boxAny != 0 && m < F.inner[2];   // (uniform)
+#pragma unroll
+      for (int g = 0; g < kXYZPosI; g += kXYZGroupI) {
+        __builtin_amdgcn_sched_barrier(0);   // (kXYZGroupI positions' loads in flight at a time)
+        double bx[kXYZGroupI];
+        uint32_t boxm = 0;
+        if (boxWave) {
+#pragma unroll
+          for (int kk = 0; kk < kXYZGroupI; kk++) {
+            const int k = g + kk;
+            if (k >= kXYZPosI)
+              continue;
+            uint32_t drow, dcol;
+            pos_off(k, drow, dcol);
+            const bool inBox = ((innerMask >> k) & 1u) != 0;
+            boxm |= inBox ? 1u << kk : 0u;
+            bx[kk] = buf[inBox ? (size_t)m * bufSlice + drow * bufx + dcol : (size_t)0];
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < kXYZGroupI; kk++) {
+          const int k = g + kk;
+          if (k >= kXYZPosI)
+            continue;
+          const double lo = sg_value(myPre[(k * 2) * 64 + lane]);
+          const double hi = sg_value(myPre[(k * 2 + 1) * 64 + lane]);
+          zstep(k, m, mine, ((activeMask >> k) & 1u) != 0, ((boxm >> kk) & 1u) ? bx[kk] : lo, hi);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (m + 1 < mB)
+        pre_issue(m + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    else if (!SG && fastLoads) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pair's coefficients have landed in LDS
 #pragma unroll
       for (int g = 0; g < kXYZPosI; g += kXYZGroupI) {
@@ -1763,8 +1824,9 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
     smem += (size_t)kXYZThreadsI * kXYZPosI * 2 * sizeof(uint32_t);   // + the coefficients on their way in
 #endif
   {
-    const void* fns[4] = {reinterpret_cast<const void*>(&k_lift_xyz_fwd<1>), reinterpret_cast<const void*>(&k_lift_xyz_fwd<2>),
-                          reinterpret_cast<const void*>(&k_lift_xyz_inv<1>), reinterpret_cast<const void*>(&k_lift_xyz_inv<2>)};
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_lift_xyz_fwd<1>), reinterpret_cast<const void*>(&k_lift_xyz_fwd<2>),
+                          reinterpret_cast<const void*>(&k_lift_xyz_inv<1, false>), reinterpret_cast<const void*>(&k_lift_xyz_inv<2, false>),
+                          reinterpret_cast<const void*>(&k_lift_xyz_inv<1, true>), reinterpret_cast<const void*>(&k_lift_xyz_inv<2, true>)};
     for (const void* f : fns)
       if (set_max_dyn_lds(f, 160 * 1024))
         return -1;
@@ -1786,12 +1848,23 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
                cdims[2], K, st, volume, vd, geom, wantMax, F.inner[0], F.inner[1], F.inner[2], nseg);
   }
   else {
-    if (io == 1)
-      LAUNCH_K((k_lift_xyz_inv<1>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, F, nseg);
-    else
-      LAUNCH_K((k_lift_xyz_inv<2>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1],
-               cdims[2], K, st, volume, vd, geom, F, nseg);
+    const bool sg = F.mode == 2 && F.coefSigned != 0;
+#define XYZ_INV_LAUNCH(io_, sg_)                                                                                    \
+  LAUNCH_K((k_lift_xyz_inv<io_, sg_>), grid, dim3(kXYZThreadsI), smem, stream, vals, valsStride, cdims[0], cdims[1], \
+           cdims[2], K, st, volume, vd, geom, F, nseg)
+    if (io == 1) {
+      if (sg)
+        XYZ_INV_LAUNCH(1, true);
+      else
+        XYZ_INV_LAUNCH(1, false);
+    }
+    else {
+      if (sg)
+        XYZ_INV_LAUNCH(2, true);
+      else
+        XYZ_INV_LAUNCH(2, false);
+    }
+#undef XYZ_INV_LAUNCH
   }
   HIP_CHECK(hipGetLastError());
   return 0;

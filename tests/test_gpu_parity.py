@@ -277,6 +277,22 @@ def test_high_precision_retry(eng, oracle):
                           bits(oracle.decomp_3d(want, False)))
 
 
+@pytest.mark.parametrize("bpp", [2.0, 9.0, 14.0, 16.0, 17.0, 18.0, 18.5, 19.0, 19.5, 20.0, 24.0, 29.5])
+def test_decoded_coefficients_hand_over_schemes(eng, oracle, bpp):
+    """k_ref_assemble hands the inverse passes the sign inside the coefficient word where the chunk allows it
+    (coef_scheme, speck_dec.h): fixed-rate chunks have 32 planes (src/SPECK_FLT.cpp:282-290), so which scheme a chunk
+    takes depends on the plane its stream runs out on -- from plane 2 up the low bit makes room, below it the
+    magnitudes stay as they are and the masks are read.  A sweep of rates down to the last planes, two chunk shapes
+    (the fused x-y-z inverse kernel and the per-axis passes)."""
+    for shape in ((32, 32, 32), (16, 40, 24)):
+        v = turbulence(shape)
+        want = oracle.comp_3d(v, shape, 1, bpp)
+        assert want[18 + 17] >= 32   # (more than 32: the 64-bit retry took over, SPECK_FLT.cpp:530-538)
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        assert np.array_equal(bits(eng.decompress(dev, True).cpu().numpy()), bits(oracle.decomp_3d(want, True)))
+        assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
+
+
 def test_retry_of_a_batch_whose_coder_arrays_lay_over_the_chunk_buffer(eng, oracle):
     """Round 3: the coder's node arrays, birth records and second list lie over the fp64 chunk buffer once
     the quantiser has read it (carve_enc); a batch that then needs the 64-bit retry (src/SPECK_FLT.cpp:530-538)
