@@ -3556,16 +3556,39 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
 #pragma unroll
     for (uint32_t u = 0; u < kW; u++)
       M[u] = 0;
-    if (any) {
-      // from the highest plane a word of the round has down to the lowest plane that was refined
-      for (int pl = maxTop - 1; pl >= pLow; pl--) {
+    if (any && maxTop > pLow) {
+      // The planes some word of the round has, from the highest down to the lowest plane that was refined: at most
+      // 32, fetched in ONE go -- lane (plane slot << 3 | word) loads its 8-byte word of up to four planes (a plane
+      // the word does not have is not read: zero), and a sample's bit of plane word (pl, u) is its lane's bit of
+      // the word read back from lane (pl - pLow) % 8 * 8 + u.  (Eight scalar loads per plane, one plane after the
+      // other, before: a round waited for as many load round trips as it had planes -- 1.75 ms per launch of 32
+      // chunks.)
+      const int nPl = maxTop - pLow;
+      const uint32_t myU = lane & 7u, myPs = lane >> 3;
+      int mytop = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < kW; u++) {
-          // (loaded whether the word has the plane or not -- four independent scalar loads, no branch; the
-          //  address is inside the chunk's planes either way)
-          const uint64_t raw = planes[(size_t)pl * b.maskPixStride + w0 + u];
-          const uint64_t pw = pl < top[u] ? raw : 0ull;
-          M[u] = 2u * M[u] + (__builtin_amdgcn_inverse_ballot_w64(pw) ? 1u : 0u);
+      for (uint32_t u = 0; u < kW; u++)
+        mytop = myU == u ? top[u] : mytop;
+      uint64_t pv[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        pv[g] = 0ull;
+        const int pl = pLow + g * 8 + (int)myPs;
+        if (g * 8 < nPl)   // (uniform)
+          pv[g] = pl < mytop ? planes[(size_t)pl * b.maskPixStride + w0 + myU] : 0ull;
+      }
+#pragma unroll
+      for (int g = 3; g >= 0; g--) {
+        if (g * 8 >= nPl)
+          continue;
+        for (int ps = min(7, nPl - 1 - g * 8); ps >= 0; ps--) {
+#pragma unroll
+          for (uint32_t u = 0; u < kW; u++) {
+            const int src = ps * 8 + (int)u;
+            const uint64_t pw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv[g], src) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv[g] >> 32), src) << 32);
+            M[u] = 2u * M[u] + (__builtin_amdgcn_inverse_ballot_w64(pw) ? 1u : 0u);
+          }
         }
       }
     }
