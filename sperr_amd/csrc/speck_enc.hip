@@ -122,27 +122,31 @@ __device__ __forceinline__ void oct_load(const Tree& t, const Grid& g, const Roo
 // ------------------------------------------------------------------------------------------
 // k_pyramid: one thread per node of the grids at one depth (deepest first)
 // ------------------------------------------------------------------------------------------
-// h[bin] += 1 for every lane with bin >= 0; returns the lane's rank inside its bin.  The lanes of a
-// wavefront that share a bin send ONE LDS atomic (neighbouring nodes split at a handful of planes: 64
-// lanes on one LDS word are 64 serialised atomics).
+// h[bin] += 1 for every lane with bin >= 0 (bin < 64); returns the lane's rank inside its bin.  The lanes of a
+// wavefront that share a bin send ONE LDS atomic (neighbouring nodes split at a handful of planes: 64 lanes on one
+// LDS word are 64 serialised atomics).  Who shares a lane's bin comes out of six ballots, one per bit of the bin
+// (round 5) -- a loop over the distinct bins of the wavefront before: a ballot, two shuffles and an LDS round trip
+// per bin, a dozen times in a wavefront of the deepest depth, where k_pyramid and k_chain spend 1.4 and 1.5 ms.
 __device__ __forceinline__ uint32_t wave_hist_add(uint32_t* h, int bin)
 {
+  static_assert(kMaxPlanes <= 64, "six bits of bin");
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t rank = 0;
-  uint64_t todo = __ballot(bin >= 0);
-  while (todo) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const int bb = __shfl(bin, lead, 64);
-    const uint64_t same = __ballot(bin == bb) & todo;
-    uint32_t base0 = 0;
-    if ((int)lane == lead)
-      base0 = atomicAdd(&h[bb], (uint32_t)__popcll(same));
-    base0 = (uint32_t)__shfl((int)base0, lead, 64);
-    if (bin == bb)
-      rank = base0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
+  uint64_t same = __ballot(bin >= 0);
+  if (same == 0)
+    return 0;   // (uniform)
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const uint64_t bk = __ballot((bin >> k) & 1);
+    same &= ((bin >> k) & 1) ? bk : ~bk;
   }
-  return rank;
+  if (bin < 0)
+    same = 1ull << lane;   // (takes no part: its own leader, no atomic)
+  const int lead = __ffsll((long long)same) - 1;
+  uint32_t base0 = 0;
+  if ((int)lane == lead && bin >= 0)
+    base0 = atomicAdd(&h[bin], (uint32_t)__popcll(same));
+  base0 = (uint32_t)__shfl((int)base0, lead, 64);
+  return bin >= 0 ? base0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)) : 0u;
 }
 
 // (returns the plane at which the node splits when it is a set with a significant sample, else -1)
@@ -245,8 +249,12 @@ __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uin
 
 // one thread per node; the splitting sets are counted per plane on the way (the bucket histogram: a
 // pass of its own over every node before, k_bucket_hist, 1.1 ms per launch of 21 chunks)
+// (round 5: a workgroup takes `per` node blocks of the depth one after the other -- eight at the deepest depths, where
+//  150 K workgroups of one node per thread each paid the look-ups of their grid and a histogram's worth of global
+//  atomics on the chunk's few plane counters)
+constexpr int kNodePerMax = 8;
 __global__ void __launch_bounds__(kNodeBlock)
-k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
+k_pyramid(EncBuffers b, const uint32_t* depthBlocks, uint32_t nblk, uint32_t per)
 {
   const uint32_t c = blockIdx.y;
   EncState& s = b.st[c];
@@ -256,8 +264,10 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
   if (threadIdx.x < kMaxPlanes)
     h[threadIdx.x] = 0;
   __syncthreads();
-  const int sp = pyramid_node(b, c, depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x);
-  wave_hist_add(h, sp);
+  for (uint32_t q = 0, bi = blockIdx.x * per; q < per && bi < nblk; q++, bi++) {
+    const int sp = pyramid_node(b, c, depthBlocks[bi] * kNodeBlock + threadIdx.x);
+    wave_hist_add(h, sp);
+  }
   __syncthreads();
   if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
     atomicAdd(&s.bucketCnt[threadIdx.x], h[threadIdx.x]);
@@ -270,7 +280,7 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks)
 // On the way the splitting sets are dealt to the buckets of their planes (k_bucket_fill, a pass of its own
 // over every node before: 1.2 ms per launch of 21 chunks; k_bucket_scan has run on k_pyramid's counts).
 __global__ void __launch_bounds__(kNodeBlock)
-k_chain(EncBuffers b, const uint32_t* depthBlocks)
+k_chain(EncBuffers b, const uint32_t* depthBlocks, uint32_t nblk, uint32_t per)
 {
   const uint32_t c = blockIdx.y;
   EncState& s = b.st[c];
@@ -281,39 +291,55 @@ k_chain(EncBuffers b, const uint32_t* depthBlocks)
     h[threadIdx.x] = 0;
   __syncthreads();
   const Tree& t = b.tree;
-  const uint32_t id = depthBlocks[blockIdx.x] * kNodeBlock + threadIdx.x;
   const int8_t* M = b.M + c * b.nodeStride;
-  Node nd;
-  const bool valid = node_from_flat(t, id, nd);
-  const int m = valid ? (int)M[id] : -1;
-  bool mine = false;   // a set that splits at plane m (splitting_set)
-  if (m >= 0) {
-    const Grid& g = t.grids[nd.grid];
-    mine = (g.kind & kGridOct) != 0;
-    if (!mine) {
-      const NodeGeom q = node_geom(t, nd);
-      mine = q.count > 1 || (g.depth == 0 && q.count == 1);
-    }
-    if (!(g.depth + 1 == t.roots[g.root].Dmax && g.depth != 0)) {
-      uint64_t* chain = b.chain + c * b.nodeStride;
-      uint64_t v = id;
-      if (g.depth != 0) {
-        const uint32_t pid = flat_id(t, node_parent(t, nd));
-        if (M[pid] == m) {
-          const uint64_t pc = chain[pid];
-          v = (pc & 0xffffffffull) | ((uint64_t)((uint32_t)(pc >> 32) + b.koff[c * b.nodeStride + id]) << 32);
-        }
+  // (`per` node blocks per workgroup, see k_pyramid: the ranks of a thread's nodes wait in registers for the
+  //  workgroup's one claim per plane)
+  uint32_t ids[kNodePerMax], ranks[kNodePerMax];
+  int bins[kNodePerMax];
+#pragma unroll
+  for (int q = 0; q < kNodePerMax; q++) {
+    bins[q] = -1;
+    ids[q] = ranks[q] = 0;
+    const uint32_t bi = blockIdx.x * per + (uint32_t)q;
+    if ((uint32_t)q >= per || bi >= nblk)   // (uniform)
+      continue;
+    const uint32_t id = depthBlocks[bi] * kNodeBlock + threadIdx.x;
+    Node nd;
+    const bool valid = node_from_flat(t, id, nd);
+    const int m = valid ? (int)M[id] : -1;
+    bool mine = false;   // a set that splits at plane m (splitting_set)
+    if (m >= 0) {
+      const Grid& g = t.grids[nd.grid];
+      mine = (g.kind & kGridOct) != 0;
+      if (!mine) {
+        const NodeGeom qg = node_geom(t, nd);
+        mine = qg.count > 1 || (g.depth == 0 && qg.count == 1);
       }
-      chain[id] = v;
+      if (!(g.depth + 1 == t.roots[g.root].Dmax && g.depth != 0)) {
+        uint64_t* chain = b.chain + c * b.nodeStride;
+        uint64_t v = id;
+        if (g.depth != 0) {
+          const uint32_t pid = flat_id(t, node_parent(t, nd));
+          if (M[pid] == m) {
+            const uint64_t pc = chain[pid];
+            v = (pc & 0xffffffffull) | ((uint64_t)((uint32_t)(pc >> 32) + b.koff[c * b.nodeStride + id]) << 32);
+          }
+        }
+        chain[id] = v;
+      }
     }
+    ids[q] = id;
+    bins[q] = mine ? m : -1;
+    ranks[q] = wave_hist_add(h, bins[q]);
   }
-  const uint32_t rank = wave_hist_add(h, mine ? m : -1);
   __syncthreads();
   if (threadIdx.x < kMaxPlanes && h[threadIdx.x])
     base[threadIdx.x] = atomicAdd(&s.bucketCur[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
-  if (mine)
-    b.bucket[c * b.nodeStride + base[m] + rank] = id;
+#pragma unroll
+  for (int q = 0; q < kNodePerMax; q++)
+    if (bins[q] >= 0)
+      b.bucket[c * b.nodeStride + base[bins[q]] + ranks[q]] = ids[q];
 }
 
 __global__ void k_enc_planes_setup(EncBuffers b)
@@ -1329,6 +1355,18 @@ __global__ void __launch_bounds__(kThreads) k_enc_bound(EncBuffers b, uint32_t* 
   }
 }
 
+// node blocks a workgroup of k_pyramid / k_chain takes: as many as leave the chip four workgroups per CU and more
+static uint32_t node_blocks_per_group(uint32_t nb, uint32_t nc)
+{
+  static const uint32_t perEnv = tune_getenv("SPERR_HIP_NODE_PER") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_NODE_PER")) : 0u;
+  if (perEnv)
+    return std::min<uint32_t>(std::max(1u, perEnv), (uint32_t)kNodePerMax);
+  uint32_t per = 1;
+  while (per < (uint32_t)kNodePerMax && (uint64_t)nb * nc / (2 * per) >= 4096)
+    per *= 2;
+  return per;
+}
+
 int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncPlanHost& plan,
                              uint64_t raw_budget, bool rate_mode, bool wide_pass)
 {
@@ -1346,9 +1384,11 @@ int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncP
   const bool sideCensus = plan.side && plan.evFork && plan.evJoin && b.tree.maxDepth >= 2;
   for (int d = (int)b.tree.maxDepth - 1; d >= 0; d--) {
     const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
-    if (nb)
-      LAUNCH_K(k_pyramid, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
-                         plan.d_depthBlocks + plan.depthBlockOff[d]);
+    if (nb) {
+      const uint32_t per = node_blocks_per_group(nb, nc);
+      LAUNCH_K(k_pyramid, dim3((nb + per - 1) / per, nc), dim3(kNodeBlock), 0, stream, b,
+                         plan.d_depthBlocks + plan.depthBlockOff[d], nb, per);
+    }
     if (sideCensus && d == 0) {
       // every sample's birth plane is known now (samples are born at any depth: the roots' trees differ in
       // height, and an odd set has a single sample for a child): the census needs nothing else
@@ -1361,9 +1401,11 @@ int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncP
   LAUNCH_K(k_bucket_scan, perChunk, dim3(64), 0, stream, b);   // (k_pyramid has counted the splitting sets per plane)
   for (int d = 0; d < (int)b.tree.maxDepth; d++) {
     const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
-    if (nb)
-      LAUNCH_K(k_chain, dim3(nb, nc), dim3(kNodeBlock), 0, stream, b,
-               plan.d_depthBlocks + plan.depthBlockOff[d]);
+    if (nb) {
+      const uint32_t per = node_blocks_per_group(nb, nc);
+      LAUNCH_K(k_chain, dim3((nb + per - 1) / per, nc), dim3(kNodeBlock), 0, stream, b,
+               plan.d_depthBlocks + plan.depthBlockOff[d], nb, per);
+    }
   }
   LAUNCH_K(k_enc_planes_setup, perChunk, dim3(64), 0, stream, b);
   if (sideCensus) {
