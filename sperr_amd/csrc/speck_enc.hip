@@ -249,6 +249,86 @@ __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uin
 
 // one thread per node; the splitting sets are counted per plane on the way (the bucket histogram: a
 // pass of its own over every node before, k_bucket_hist, 1.1 ms per launch of 21 chunks)
+// The deepest depth of an octree grid, four leaf parents in a row per thread (round 5): their 32 samples are four
+// 8-byte loads (two rows of two slices), what comes out is one store per array -- M, E, leaf descriptor, and the four
+// rows of birth planes.  One node per thread moved the same bytes two at a time: 1.4 ms per launch of 21 chunks for
+// under a gigabyte.  Needs rows of eight samples that start on a multiple of eight (root origin, row length).
+__device__ __forceinline__ bool leaf4_block(const Tree& t, uint32_t blockId)
+{
+  const Grid& g = t.grids[t.blockGrid[blockId]];
+  const Root& r = t.roots[g.root];
+  return (g.kind & kGridOct) && g.depth + 1 == r.Dmax && g.e[0] >= 2 && ((r.org[0] | t.dims[0]) & 7u) == 0;
+}
+__device__ __forceinline__ void pyramid_leaf4(const EncBuffers& b, uint32_t c, uint32_t id0, uint32_t* h)
+{
+  const Tree& t = b.tree;
+  const Grid& g = t.grids[t.blockGrid[id0 / kNodeBlock]];
+  const Root& r = t.roots[g.root];
+  const uint32_t local = id0 - g.nodeOff;
+  if (local >= (1u << (g.e[0] + g.e[1] + g.e[2])))
+    return;   // (padding ids)
+  const uint32_t i0 = local & ((1u << g.e[0]) - 1u), i1 = (local >> g.e[0]) & ((1u << g.e[1]) - 1u),
+                 i2 = local >> (g.e[0] + g.e[1]);
+  const uint32_t sy = t.dims[0], sz = t.dims[0] * t.dims[1];
+  const uint32_t base = ((uint32_t)r.org[2] + 2u * i2) * sz + ((uint32_t)r.org[1] + 2u * i1) * sy + (uint32_t)r.org[0] + 2u * i0;
+  const int8_t* msb = b.msb + c * b.pixStride;
+  int8_t* bplane = b.bplane + c * b.pixStride;
+  const uint64_t* sign = b.sign + c * b.signStride;
+  uint2 rows[4];
+  uint32_t sg[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {   // row k: y + (k & 1), z + (k >> 1)
+    const uint32_t ridx = base + (uint32_t)(k & 1) * sy + (uint32_t)(k >> 1) * sz;
+    rows[k] = *reinterpret_cast<const uint2*>(msb + ridx);
+    sg[k] = (uint32_t)(sign[ridx >> 6] >> (ridx & 63)) & 0xffu;   // (eight samples of one sign word)
+  }
+  uint32_t mPack = 0, ePack[4], dPack[2] = {0, 0};
+  int mv[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    int km[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {   // child j = (x + (j & 1), y + ((j >> 1) & 1), z + (j >> 2))
+      const uint2 rw = rows[((j >> 1) & 1) + 2 * (j >> 2)];
+      const uint32_t byte = 2u * (uint32_t)n + (uint32_t)(j & 1);
+      km[j] = (int)(int8_t)(((byte < 4 ? rw.x : rw.y) >> (8u * (byte & 3u))) & 0xffu);
+    }
+    int m = -1;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      m = max(m, km[j]);
+    uint32_t bits = 0, desc = 0;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const bool coded = found || j != 7;
+      bits += coded ? 1u : 0u;
+      if (!coded || km[j] == m) {
+        found = true;
+        bits += 1u;
+      }
+      desc |= (uint32_t)(km[j] == m) << j;
+      desc |= ((sg[((j >> 1) & 1) + 2 * (j >> 2)] >> (2u * (uint32_t)n + (uint32_t)(j & 1))) & 1u) << (8 + j);
+    }
+    mv[n] = m;
+    mPack |= ((uint32_t)m & 0xffu) << (8 * n);
+    ePack[n] = m >= 0 ? bits : 0u;
+    dPack[n >> 1] |= (desc & 0xffffu) << (16 * (n & 1));
+    if (m >= 0)
+      atomicAdd(&h[m], 1u);
+  }
+  *reinterpret_cast<uint32_t*>(b.M + c * b.nodeStride + id0) = mPack;
+  *reinterpret_cast<uint4*>(b.E + c * b.nodeStride + id0) = make_uint4(ePack[0], ePack[1], ePack[2], ePack[3]);
+  *reinterpret_cast<uint2*>(b.leafDesc + c * b.nodeStride + id0) = make_uint2(dPack[0], dPack[1]);
+  // the samples' birth planes: their parent's msb, two samples a node
+  const uint32_t pairs[4] = {((uint32_t)mv[0] & 0xffu) * 0x0101u, ((uint32_t)mv[1] & 0xffu) * 0x0101u,
+                             ((uint32_t)mv[2] & 0xffu) * 0x0101u, ((uint32_t)mv[3] & 0xffu) * 0x0101u};
+  const uint2 bp = make_uint2(pairs[0] | (pairs[1] << 16), pairs[2] | (pairs[3] << 16));
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    *reinterpret_cast<uint2*>(bplane + base + (uint32_t)(k & 1) * sy + (uint32_t)(k >> 1) * sz) = bp;
+}
+
 // (round 5: a workgroup takes `per` node blocks of the depth one after the other -- eight at the deepest depths, where
 //  150 K workgroups of one node per thread each paid the look-ups of their grid and a histogram's worth of global
 //  atomics on the chunk's few plane counters)
@@ -264,8 +344,23 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks, uint32_t nblk, uint32_t per
   if (threadIdx.x < kMaxPlanes)
     h[threadIdx.x] = 0;
   __syncthreads();
+  static_assert(kNodeBlock == 256, "a wavefront takes a node block four nodes a lane");
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // blocks of leaf parents that pyramid_leaf4 takes: a wavefront each, four at a time
+  for (uint32_t q = wave; q < per; q += kNodeBlock / 64) {
+    const uint32_t bi = blockIdx.x * per + q;
+    if (bi >= nblk)
+      break;
+    const uint32_t blk = depthBlocks[bi];
+    if (leaf4_block(b.tree, blk))   // (uniform over the wavefront)
+      pyramid_leaf4(b, c, blk * kNodeBlock + lane * 4u, h);
+  }
+  // every other block: a node per thread
   for (uint32_t q = 0, bi = blockIdx.x * per; q < per && bi < nblk; q++, bi++) {
-    const int sp = pyramid_node(b, c, depthBlocks[bi] * kNodeBlock + threadIdx.x);
+    const uint32_t blk = depthBlocks[bi];
+    if (leaf4_block(b.tree, blk))   // (uniform over the workgroup)
+      continue;
+    const int sp = pyramid_node(b, c, blk * kNodeBlock + threadIdx.x);
     wave_hist_add(h, sp);
   }
   __syncthreads();

@@ -9,7 +9,7 @@ vol = turbulence_torch((256, 256, 256), "cuda")
 s = eng.compress(vol, (256, 256, 256), 2.0).cpu().numpy()
 # one chunk: 14 + 4 bytes of container header, 17 of conditioner, then the SPECK stream
 coef, sign = eng.speck3d_decode(bytes(s[18 + 17:]), (256, 256, 256))[:2]
-c = coef.cpu().numpy().reshape(-1)
+c = np.asarray(coef).reshape(-1)
 nz = c != 0
 w = nz.reshape(-1, 64).any(axis=1)
 print("significant samples %.2f %%, words with one %.2f %%, rows of 256 with one %.2f %%" % (100 * nz.mean(), 100 * w.mean(), 100 * nz.reshape(-1, 256).any(axis=1).mean()))
