@@ -1607,7 +1607,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       return -1;
 
   // group chunks by shape, keeping chunk order inside a group.  (key: extents + part.)  In fixed-rate
-  // mode a group of 64 and more chunks is cut into two parts that run side by side like the shape
+  // mode a group of 64 and more chunks is cut into parts (four: round 5, 16 chunks each of the bench volume -- three
+  // before; five and more fall under the sixteen chunks the capped grids want) that run side by side like the shape
   // groups of a ragged volume do: the per-plane chains of small launches of one part overlap the
   // bandwidth-bound kernels of the other (SPERR_HIP_ENC_PARTS=1: one part)
   using GKey = std::array<size_t, 4>;
@@ -1616,7 +1617,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     std::map<Dims, uint32_t> count, seen;
     for (uint32_t i = 0; i < nchunks; i++)
       count[Dims{chunks[i][1], chunks[i][3], chunks[i][5]}]++;
-    static const uint32_t partsEnv = getenv("SPERR_HIP_ENC_PARTS") ? (uint32_t)std::max(1, atoi(getenv("SPERR_HIP_ENC_PARTS"))) : 3u;
+    static const uint32_t partsEnv = getenv("SPERR_HIP_ENC_PARTS") ? (uint32_t)std::max(1, atoi(getenv("SPERR_HIP_ENC_PARTS"))) : 4u;
     for (uint32_t i = 0; i < nchunks; i++) {
       const auto& c = chunks[i];
       const Dims d{c[1], c[3], c[5]};
