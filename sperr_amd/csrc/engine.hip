@@ -2129,6 +2129,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   TAKE(d.tokMask, uint64_t, d.tokStride * B);
   TAKE(d.tokCnt, uint32_t, d.tokStride * B);
   TAKE(d.tokOff, uint32_t, d.tokStride * B);
+  d.tokSegStride = round_up(d.tokStride / 2048 + 2, 32);   // (kLipSeg words a segment, speck_dec.hip)
+  TAKE(d.tokSegSum, uint32_t, d.tokSegStride * B);
+  TAKE(d.tokSegBase, uint32_t, d.tokSegStride * B);
   d.streamStride = (size_t)(maxPayloadBytes / 8) + 4;
   TAKE(d.stream, uint64_t, d.streamStride * B);
   // table-driven LIS phase

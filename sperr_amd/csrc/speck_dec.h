@@ -122,8 +122,11 @@ struct DecBuffers {
   size_t lipResStride;
   uint64_t* tokMask;           // token starts of every 64-bit word of the LIP scan
   uint32_t* tokCnt;
-  uint32_t* tokOff;
+  uint32_t* tokOff;            // ... rank of a word's first token INSIDE its segment of kLipSeg words (k_lip_words)
   size_t tokStride;
+  uint32_t* tokSegSum;         // tokens per segment, and (k_lip_scan) the rank of a segment's first token
+  uint32_t* tokSegBase;
+  size_t tokSegStride;
   // table-driven LIS phase (regular shapes)
   const spk::LevelClass* levelClass;
   const uint8_t* levelSlot;    // level -> birth-mask slot (0xff: none)

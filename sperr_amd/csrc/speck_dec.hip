@@ -377,6 +377,14 @@ __device__ __forceinline__ uint64_t lip_word(const uint64_t* words, const DecSta
   return v;
 }
 
+// Round 5: the token ranks are a SEGMENTED scan.  k_lip_words takes the words a segment (kLipSeg = 2048 words, eight in a
+// row per thread) at a time and leaves every word's rank inside its segment and the segment's token count;
+// k_lip_scan scans the few hundred segment counts and looks for the phase's end inside ONE segment; k_lip_apply adds
+// the segment's rank.  (k_lip_scan scanned every word before, one workgroup per chunk, a block scan per 2048 words:
+// 50 rounds = 180 us in the late planes, 37 us a launch on average in a batch of two chunks.)
+constexpr int kLipPer = 8;
+constexpr int kLipSeg = kThreads * kLipPer;
+static_assert(kLipSeg == 2048, "carve_dec sizes tokSegSum by it");
 __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
@@ -384,37 +392,65 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
   DEC_ACTIVE_OR_RETURN(s, p);
   if (s.nLip == 0)
     return;
+  __shared__ uint32_t sm[kThreads / 64 + 1];
   const uint64_t nbits = 2ull * s.nLip + 1;
   const uint64_t nwords = (nbits + 63) / 64;
+  const uint32_t nseg = (uint32_t)((nwords + kLipSeg - 1) / kLipSeg);
   const uint64_t* words = b.stream + c * b.streamStride;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
-       w += (uint64_t)gridDim.x * blockDim.x) {
-    // parity of the run of 1s that ends right before this word
+  for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const uint64_t w0 = (uint64_t)seg * kLipSeg + (uint64_t)threadIdx.x * kLipPer;
+    uint32_t cntv[kLipPer], tsum = 0;
+    // parity of the run of 1s that ends right before the thread's first word
     uint32_t parity = 0;
-    for (uint64_t back = w; back > 0;) {
-      back--;
-      const uint64_t v = lip_word(words, s, back, nbits);
-      if (v == ~0ull)
-        continue;  // 64 more ones: parity unchanged, keep looking
-      parity = (uint32_t)__clzll((long long)~v) & 1u;  // leading ones of the previous word
-      break;
+    if (w0 < nwords)
+      for (uint64_t back = w0; back > 0;) {
+        back--;
+        const uint64_t v = lip_word(words, s, back, nbits);
+        if (v == ~0ull)
+          continue;  // 64 more ones: parity unchanged, keep looking
+        parity = (uint32_t)__clzll((long long)~v) & 1u;  // leading ones of the previous word
+        break;
+      }
+#pragma unroll
+    for (int k = 0; k < kLipPer; k++) {
+      const uint64_t w = w0 + (uint64_t)k;
+      cntv[k] = 0;
+      if (w >= nwords)
+        continue;
+      const uint64_t x = lip_word(words, s, w, nbits);
+      // A bit starts a token when the run of 1s in front of it is of even length (a 1 at a token's start is followed
+      // by its sign): the escaped characters of a run of backslashes, worked out for 64 bits at once with one
+      // addition -- odd-length runs are found by the carry they send past their end (a loop over the 64 bits
+      // before: 300 operations a word).  `parity`: the first bit is a sign.
+      const uint64_t even = 0x5555555555555555ull;
+      const uint64_t bs = x & ~(uint64_t)parity;
+      const uint64_t follows = (bs << 1) | (uint64_t)parity;
+      const uint64_t oddStarts = bs & ~even & ~follows;
+      const uint64_t sum = oddStarts + bs;
+      parity = sum < bs ? 1u : 0u;   // (the run of 1s that ends with this word is odd: the next word opens with a sign)
+      uint64_t starts = ~((even ^ (sum << 1)) & follows);
+      if (w == nwords - 1 && (nbits & 63))
+        starts &= (1ull << (nbits & 63)) - 1;
+      b.tokMask[c * b.tokStride + w] = starts;
+      cntv[k] = (uint32_t)__popcll(starts);
+      b.tokCnt[c * b.tokStride + w] = cntv[k];
+      tsum += cntv[k];
+      if (w <= (uint64_t)(s.nLip - 1) / 64) {   // results by token rank, filled by k_lip_apply
+        b.lipSig[c * b.lipResStride + w] = 0;
+        b.lipNeg[c * b.lipResStride + w] = 0;
+      }
     }
-    const uint64_t x = lip_word(words, s, w, nbits);
-    uint64_t starts = 0;
-    uint32_t ones = parity;  // only the parity matters
-    for (int k = 0; k < 64; k++) {
-      if ((ones & 1u) == 0)
-        starts |= 1ull << k;
-      ones = ((x >> k) & 1ull) ? ones + 1 : 0;
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total);
+#pragma unroll
+    for (int k = 0; k < kLipPer; k++) {
+      const uint64_t w = w0 + (uint64_t)k;
+      if (w < nwords)
+        b.tokOff[c * b.tokStride + w] = ex;
+      ex += cntv[k];
     }
-    if (w == nwords - 1 && (nbits & 63))
-      starts &= (1ull << (nbits & 63)) - 1;
-    b.tokMask[c * b.tokStride + w] = starts;
-    b.tokCnt[c * b.tokStride + w] = (uint32_t)__popcll(starts);
-    if (w <= (uint64_t)(s.nLip - 1) / 64) {   // results by token rank, filled by k_lip_apply
-      b.lipSig[c * b.lipResStride + w] = 0;
-      b.lipNeg[c * b.lipResStride + w] = 0;
-    }
+    if (threadIdx.x == 0)
+      b.tokSegSum[c * b.tokSegStride + seg] = total;
   }
 }
 
@@ -429,43 +465,48 @@ __global__ void __launch_bounds__(kThreads) k_lip_scan(DecBuffers b, int p)
     return;
   }
   __shared__ uint32_t sm[kThreads / 64 + 1];
+  __shared__ uint32_t sh_seg, sh_segBase;
   const uint64_t nbits = 2ull * s.nLip + 1;
   const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
-  uint32_t* cnt = b.tokCnt + c * b.tokStride;
-  uint32_t* off = b.tokOff + c * b.tokStride;
-  const uint64_t* mask = b.tokMask + c * b.tokStride;
-  // one workgroup per chunk walks the words: kLipPer consecutive words per thread and round, so a
-  // round is one batch of loads and one block scan for 2048 words (a word per thread and round
-  // made the late planes, with their 10^5 words, a chain of dependent round trips)
-  constexpr int kLipPer = 8;
+  const uint32_t nseg = (nwords + kLipSeg - 1) / kLipSeg;
+  const uint32_t* segSum = b.tokSegSum + c * b.tokSegStride;
+  uint32_t* segBase = b.tokSegBase + c * b.tokSegStride;
   const uint32_t nLip = s.nLip;
+  if (threadIdx.x == 0)
+    sh_seg = sh_segBase = 0;   // (the block scan's barriers come before anybody writes them)
+  // the segments' ranks; the one token #nLip (0-based) starts in: the phase is as long as where it starts
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < nwords; base += kThreads * kLipPer) {
-    const uint32_t i0 = base + threadIdx.x * kLipPer;
-    uint32_t v[kLipPer], tsum = 0;
-#pragma unroll
-    for (int k = 0; k < kLipPer; k++) {
-      v[k] = i0 + k < nwords ? cnt[i0 + k] : 0;
-      tsum += v[k];
-    }
+  for (uint32_t base = 0; base < nseg; base += kThreads) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nseg ? segSum[i] : 0u;
     uint32_t total;
-    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total) + carry;
-#pragma unroll
-    for (int k = 0; k < kLipPer; k++) {
-      const uint32_t i = i0 + k;
-      if (i < nwords) {
-        off[i] = ex;
-        // token #nLip (0-based) starts in this word?  Then the phase is that many bits long.
-        if (ex <= nLip && nLip < ex + v[k]) {
-          uint64_t m = mask[i];
-          for (uint32_t r = nLip - ex; r > 0; r--)
-            m &= m - 1;
-          s.lipBits = (uint64_t)i * 64 + (uint64_t)__ffsll((long long)m) - 1;
-        }
+    const uint32_t ex = block_exclusive_scan<uint32_t>(v, sm, &total) + carry;
+    if (i < nseg) {
+      segBase[i] = ex;
+      if (ex <= nLip && nLip < ex + v) {
+        sh_seg = i;
+        sh_segBase = ex;
       }
-      ex += v[k];
     }
     carry += total;
+  }
+  __syncthreads();
+  const uint32_t seg = sh_seg, sb = sh_segBase;
+  const uint32_t* cnt = b.tokCnt + c * b.tokStride;
+  const uint32_t* off = b.tokOff + c * b.tokStride;
+  const uint64_t* mask = b.tokMask + c * b.tokStride;
+#pragma unroll
+  for (int k = 0; k < kLipPer; k++) {
+    const uint32_t i = seg * kLipSeg + threadIdx.x * kLipPer + (uint32_t)k;
+    if (i >= nwords)
+      continue;
+    const uint32_t ex = sb + off[i], v = cnt[i];
+    if (ex <= nLip && nLip < ex + v) {
+      uint64_t m = mask[i];
+      for (uint32_t r = nLip - ex; r > 0; r--)
+        m &= m - 1;
+      s.lipBits = (uint64_t)i * 64 + (uint64_t)__ffsll((long long)m) - 1;
+    }
   }
 }
 
@@ -486,7 +527,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
        w += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t x = lip_word(words, s, w, nbits);
     uint64_t sig = b.tokMask[c * b.tokStride + w];
-    const uint32_t j = b.tokOff[c * b.tokStride + w];
+    const uint32_t j = b.tokOff[c * b.tokStride + w] + b.tokSegBase[c * b.tokSegStride + (w >> 11)];   // (kLipSeg words a segment)
     if (j >= s.nLip)
       continue;
     const uint64_t nextbit = lip_word(words, s, w + 1, nbits) & 1ull;
@@ -3720,6 +3761,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   //  each: decompression of 64 chunks 93.6 -> 94.2 GB/s in alternating runs, round 5.  A few chunks keep the wide grid)
   static const uint32_t tileCapEnv = tune_getenv("SPERR_HIP_TILE_GRID") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_TILE_GRID")) : 0u;
   const uint32_t tileCap = tileCapEnv ? tileCapEnv : (nc >= 16 ? 4096u : kGridCapWide);
+  const uint32_t tokSegGrid = capped_blocks((uint32_t)(b.tokStride / kLipSeg + 1), nc, kGridCap / gdiv);   // (k_lip_words: a segment a workgroup)
   const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, tileCap / gdiv);
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
   static const uint32_t l0Total = tune_getenv("SPERR_HIP_L0_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L0_WGS")) : 512u;
@@ -3767,7 +3809,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
     using CT = decltype(ct);
     LAUNCH_K(k_dec_count, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_dec_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
-    LAUNCH_K(k_lip_words, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
+    LAUNCH_K(k_lip_words, dim3(tokSegGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_scan, dim3(nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_CT(k_lip_apply, dim3(tokGrid, nc), dim3(kThreads), 0, stream, b, p);
     LAUNCH_K(k_lip_deposit, dim3(tileGrid, nc), dim3(kThreads), 0, stream, b, p);
