@@ -3618,13 +3618,18 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
         if (g * 8 < nPl)   // (uniform)
           pv[g] = pl < mytop ? planes[(size_t)pl * b.maskPixStride + w0 + myU] : 0ull;
       }
+      // word by word, the planes the word has (the kernel is bound by its vector instructions: a word without a
+      // significant sample -- half of the bench volume's -- costs a scalar branch here and one below)
 #pragma unroll
-      for (int g = 3; g >= 0; g--) {
-        if (g * 8 >= nPl)
+      for (uint32_t u = 0; u < kW; u++) {
+        const int nu = top[u] - pLow;   // (uniform)
+        if (nu <= 0)
           continue;
-        for (int ps = min(7, nPl - 1 - g * 8); ps >= 0; ps--) {
 #pragma unroll
-          for (uint32_t u = 0; u < kW; u++) {
+        for (int g = 3; g >= 0; g--) {
+          if (g * 8 >= nu)
+            continue;
+          for (int ps = min(7, nu - 1 - g * 8); ps >= 0; ps--) {
             const int src = ps * 8 + (int)u;
             const uint64_t pw = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv[g], src) |
                                 ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv[g] >> 32), src) << 32);
@@ -3636,6 +3641,10 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
 #pragma unroll
     for (uint32_t u = 0; u < kW; u++) {
       const uint32_t w = w0 + u;
+      if ((so[u] | sn[u]) == 0ull) {   // (uniform) no significant sample in the word
+        coef[(size_t)w * 64 + lane] = 0;
+        continue;
+      }
       uint32_t v = 0;
       const bool isNew = ((sn[u] >> lane) & 1ull) != 0, isOld = ((so[u] >> lane) & 1ull) != 0;
       if (isNew || isOld) {
