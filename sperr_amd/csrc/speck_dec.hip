@@ -37,6 +37,34 @@ __device__ __forceinline__ uint64_t get64(const uint64_t* words, uint64_t pos)
 // k_dec_load: parse the chunk stream (17-byte conditioner header, 9-byte SPECK header), copy the
 // payload into an aligned, zero-padded word buffer (SPECK_FLT.cpp:27-109, SPECK_INT.cpp:79-108)
 // ------------------------------------------------------------------------------------------
+// Bits of `x0` / `x1` (bit i: candidate i) spread to the set positions of `m` in order -- the parallel-suffix "expand" of
+// Hacker's Delight 7-5, its mask half shared by the two.  (The pixel passes of the decoder walked a word's candidates
+// one set bit at a time: a wavefront took as many rounds as its fullest word had candidates.)
+__device__ __forceinline__ void spread_under_mask(uint64_t m, uint64_t& x0, uint64_t& x1)
+{
+  const uint64_t m0 = m;
+  uint64_t mk = ~m << 1, mv[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint64_t mp = mk ^ (mk << 1);
+    mp ^= mp << 2;
+    mp ^= mp << 4;
+    mp ^= mp << 8;
+    mp ^= mp << 16;
+    mp ^= mp << 32;
+    mv[i] = mp & m;
+    m = (m ^ mv[i]) | (mv[i] >> (1 << i));
+    mk &= ~mp;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    x0 = (x0 & ~mv[i]) | ((x0 << (1 << i)) & mv[i]);
+    x1 = (x1 & ~mv[i]) | ((x1 << (1 << i)) & mv[i]);
+  }
+  x0 &= m0;
+  x1 &= m0;
+}
+
 __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint64_t* chunkOff,
                              const uint64_t* chunkLen, const uint64_t* initLIS,
                              const uint32_t* initLen, int wide_pass)
@@ -344,15 +372,8 @@ __global__ void __launch_bounds__(kThreads) k_lip_deposit(DecBuffers b, int p)
     }
     if (vs == 0)
       continue;
-    uint64_t outS = 0, outN = 0;
-    while (vs) {   // candidate i of the word is the i-th set bit of `lip`
-      const int k = __ffsll((long long)lip) - 1;
-      lip &= lip - 1;
-      outS |= (vs & 1ull) << k;
-      outN |= (vn & 1ull) << k;
-      vs >>= 1;
-      vn >>= 1;
-    }
+    uint64_t outS = vs, outN = vn;   // candidate i of the word is the i-th set bit of `lip`
+    spread_under_mask(lip, outS, outN);
     b.sigNew[c * b.maskPixStride + wi] |= outS;
     if (outN)
       b.sign[c * b.signStride + wi] &= ~outN;
@@ -3516,24 +3537,17 @@ __global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
     const uint64_t at = pos0 + (uint64_t)b.tileRefOff[c * b.tileStride + tile] + o;
     // the pass stops the moment the stream is exhausted (SPECK_INT.cpp:388-389)
     const uint32_t n = at >= avail ? 0u : (uint32_t)min((uint64_t)cnt, avail - at);
-    uint64_t res = 0, m = sig;
+    uint64_t res = 0, got = 0;   // the bits under the mask; the candidates that did get one
     if (n) {
-      uint64_t bits = get64(words, at);
-      if (n == 64)
-        res = bits;   // (every sample of the word is a candidate)
-      else
-        for (uint32_t k = 0; k < n; k++) {   // candidate k of the word is the k-th set bit of the mask
-          const uint64_t low = m & (0ull - m);
-          m ^= low;
-          res |= (bits & 1ull) ? low : 0ull;
-          bits >>= 1;
-        }
+      const uint64_t bits = get64(words, at);
+      res = n < 64 ? bits & ((1ull << n) - 1) : bits;   // candidate k of the word is the k-th set bit of the mask
+      got = n < 64 ? (1ull << n) - 1 : ~0ull;
+      if (cnt != 64)   // (64: every sample of the word is a candidate, the bits as they come)
+        spread_under_mask(sig, res, got);
     }
-    if (n == 64)
-      m = 0;
     plane[wi] = res;   // (always: the word is valid from the plane of its first significant sample on)
     if (partial)
-      b.refMask[c * b.maskPixStride + wi] = sig & ~m;   // the candidates that did get a bit
+      b.refMask[c * b.maskPixStride + wi] = got;   // the candidates that did get a bit
   }
 }
 
