@@ -65,6 +65,30 @@ __device__ __forceinline__ void spread_under_mask(uint64_t m, uint64_t& x0, uint
   x1 &= m0;
 }
 
+// The other way round: the bits of `x0` / `x1` at the set positions of `m`, packed to the bottom in order ("compress",
+// Hacker's Delight 7-4).
+__device__ __forceinline__ void gather_under_mask(uint64_t m, uint64_t& x0, uint64_t& x1)
+{
+  x0 &= m;
+  x1 &= m;
+  uint64_t mk = ~m << 1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint64_t mp = mk ^ (mk << 1);
+    mp ^= mp << 2;
+    mp ^= mp << 4;
+    mp ^= mp << 8;
+    mp ^= mp << 16;
+    mp ^= mp << 32;
+    const uint64_t mv = mp & m;
+    m = (m ^ mv) | (mv >> (1 << i));
+    const uint64_t t0 = x0 & mv, t1 = x1 & mv;
+    x0 = (x0 ^ t0) | (t0 >> (1 << i));
+    x1 = (x1 ^ t1) | (t1 >> (1 << i));
+    mk &= ~mp;
+  }
+}
+
 __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint64_t* chunkOff,
                              const uint64_t* chunkLen, const uint64_t* initLIS,
                              const uint32_t* initLen, int wide_pass)
@@ -556,18 +580,13 @@ __global__ void __launch_bounds__(kThreads) k_lip_apply(DecBuffers b, int p)
     // to bits j, j + 1, ... of lipSig (found significant) and lipNeg (and negative).  The
     // magnitude is not written here: k_ref_apply2 / the inverse quantiser give a newly significant
     // coefficient its value 1.5 * 2^plane - 1 (SPECK_INT.cpp:462-468) when they first touch it.
-    uint64_t runS = 0, runN = 0;
-    uint32_t i = 0;
-    while (sig && j + i < s.nLip) {
-      const int k = __ffsll((long long)sig) - 1;
-      sig &= sig - 1;
-      if ((x >> k) & 1ull) {
-        const uint64_t sb = k < 63 ? (x >> (k + 1)) & 1ull : nextbit;
-        runS |= 1ull << i;
-        runN |= (sb ^ 1ull) << i;
-      }
-      i++;
-    }
+    // token i of the word: its bit, and the bit behind it (the sign of a '1')
+    uint64_t runS = x, runN = ~((x >> 1) | (nextbit << 63));
+    gather_under_mask(sig, runS, runN);
+    const uint32_t left = s.nLip - j;   // (tokens past the phase's own do not count)
+    if (left < 64)
+      runS &= (1ull << left) - 1;
+    runN &= runS;
     if (runS == 0)
       continue;
     const uint32_t sh = j & 63u;
