@@ -240,27 +240,59 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
   const DecState& s = b.st[c];
   DEC_ACTIVE_OR_RETURN(s, p);
   __shared__ uint32_t sm[kThreads / 64 + 1];
+  __shared__ uint32_t sh_need;
   const uint32_t nw = (b.tree.nvals + 63) / 64;
-  for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
-  const uint32_t wi = tile * kDecTileWords + threadIdx.x;
   // A tile none of whose samples has ever been tested holds nothing to count, and nothing to fold unless a
   // leaf over it split on the plane before: then its three mask words per thread are not read at all (round
   // 4: the dozen planes before the heavy ones touch the coarse subbands only and swept every mask of the
   // chunk, 85 us per launch of 32 chunks).  Only where every birth comes through the leaf states: a word
   // without a leaf mapping (the small subbands, whose events k_leaf_apply applies itself) keeps its tile in.
-  if (b.tileBorn != nullptr && b.wordLeaf != nullptr && b.tileBorn[c * b.tileStride + tile] == 0) {
-    bool need = false;
-    if (wi < nw) {
-      const uint32_t wl = b.wordLeaf[wi];
-      need = wl == 0xffffffffu || b.leafDirty[c * b.leafDirtyStride + (wl >> 5)] == (uint8_t)(p + 2);
+  // The test is made for ALL of the workgroup's tiles at once (round 5, second session: a workgroup of a large batch
+  // walks eight tiles, and tile after tile the test was two dependent loads and a barrier -- 55 to 70 us a launch
+  // on the planes that hold next to nothing).
+  constexpr uint32_t kAhead = 8;
+  for (uint32_t tile0 = blockIdx.x; tile0 < b.nPixTiles; tile0 += gridDim.x * kAhead) {
+  uint32_t needMask = 0;
+  const bool skipTest = b.tileBorn != nullptr && b.wordLeaf != nullptr;
+  if (skipTest) {
+    if (threadIdx.x == 0)
+      sh_need = 0;
+    uint32_t wl[kAhead], tb[kAhead];
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; q++) {
+      const uint32_t tile = tile0 + q * gridDim.x;
+      const uint32_t wi = tile * kDecTileWords + threadIdx.x;
+      tb[q] = tile < b.nPixTiles ? (uint32_t)b.tileBorn[c * b.tileStride + tile] : 0u;
+      wl[q] = (tile < b.nPixTiles && wi < nw) ? b.wordLeaf[wi] : 0xfffffffeu;   // (..fe: no word here)
     }
-    if (!__syncthreads_or(need ? 1 : 0)) {
-      if (threadIdx.x == 0) {
-        b.tileLip[c * b.tileStride + tile] = 0;
-        b.tileRef[c * b.tileStride + tile] = 0;
-      }
-      continue;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; q++) {
+      const uint32_t tile = tile0 + q * gridDim.x;
+      if (tile >= b.nPixTiles)
+        continue;
+      bool need = tb[q] != 0;
+      if (!need && wl[q] != 0xfffffffeu)
+        need = wl[q] == 0xffffffffu || b.leafDirty[c * b.leafDirtyStride + (wl[q] >> 5)] == (uint8_t)(p + 2);
+      mine |= need ? 1u << q : 0u;
     }
+    __syncthreads();
+    if (mine)
+      atomicOr(&sh_need, mine);
+    __syncthreads();
+    needMask = sh_need;
+  }
+  for (uint32_t q = 0; q < kAhead; q++) {
+  const uint32_t tile = tile0 + q * gridDim.x;
+  if (tile >= b.nPixTiles)
+    break;
+  const uint32_t wi = tile * kDecTileWords + threadIdx.x;
+  if (skipTest && !((needMask >> q) & 1u)) {
+    if (threadIdx.x == 0) {
+      b.tileLip[c * b.tileStride + tile] = 0;
+      b.tileRef[c * b.tileStride + tile] = 0;
+    }
+    continue;
   }
   uint32_t v = 0;
   bool anyBorn = false;
@@ -310,13 +342,23 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
     if (threadIdx.x == 0 && anyB)
       b.tileBorn[c * b.tileStride + tile] = 1;
   }
-  // 256 words x 64 bits: both counts fit in 15 bits per thread, sums in 32 bits need care:
-  uint32_t total_l, total_r;
-  block_exclusive_scan<uint32_t>(v & 0xffffu, sm, &total_l);
-  block_exclusive_scan<uint32_t>(v >> 16, sm, &total_r);
+  // the tile's two counts: 256 words x 64 bits, both sums fit in 15 bits -- one reduction of the packed pair (two
+  // block scans before, whose prefixes nobody used)
+  uint32_t r = v;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+    r += (uint32_t)__shfl_xor((int)r, d, 64);
+  __syncthreads();   // (sm: the round before)
+  if ((threadIdx.x & 63) == 0)
+    sm[threadIdx.x >> 6] = r;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    b.tileLip[c * b.tileStride + tile] = total_l;
-    b.tileRef[c * b.tileStride + tile] = total_r;
+    uint32_t tot = 0;
+    for (int w = 0; w < kThreads / 64; w++)
+      tot += sm[w];
+    b.tileLip[c * b.tileStride + tile] = tot & 0xffffu;
+    b.tileRef[c * b.tileStride + tile] = tot >> 16;
+  }
   }
   }
 }
