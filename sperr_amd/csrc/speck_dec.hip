@@ -487,6 +487,11 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
   for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const uint64_t w0 = (uint64_t)seg * kLipSeg + (uint64_t)threadIdx.x * kLipPer;
     uint32_t cntv[kLipPer], tsum = 0;
+    // (the thread's words first, all loads in flight together: the parity below chains their token starts)
+    uint64_t xw[kLipPer];
+#pragma unroll
+    for (int k = 0; k < kLipPer; k++)
+      xw[k] = w0 + (uint64_t)k < nwords ? lip_word(words, s, w0 + (uint64_t)k, nbits) : 0ull;
     // parity of the run of 1s that ends right before the thread's first word
     uint32_t parity = 0;
     if (w0 < nwords)
@@ -504,7 +509,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
       cntv[k] = 0;
       if (w >= nwords)
         continue;
-      const uint64_t x = lip_word(words, s, w, nbits);
+      const uint64_t x = xw[k];
       // A bit starts a token when the run of 1s in front of it is of even length (a 1 at a token's start is followed
       // by its sign): the escaped characters of a run of backslashes, worked out for 64 bits at once with one
       // addition -- odd-length runs are found by the carry they send past their end (a loop over the 64 bits
