@@ -774,6 +774,7 @@ constexpr int kXYZPosI = 6144 / kXYZThreadsI;   // inverse: kXYZStaged * cx <= 6
 #define XYZ_INV_GROUP 3
 #endif
 constexpr int kXYZGroupI = XYZ_INV_GROUP;       // positions whose loads are in flight together
+constexpr int kXYZBoxSlots = 48;                // inverse, sign-in-word kernel: 256-byte rows of box samples on their way in (12 rows x 4)
 
 // LDS layout of a slice: kXYZStaged rows; row r holds row reflect_index(y0 - 4 + r, cy) of the slice
 // (the four rows above and below the tile -- mirrored at the ends of the slice, so the first and the
@@ -1220,6 +1221,41 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     drow = (y & 1) ? ye + (y >> 1) : (y >> 1);
     dcol = (x & 1) ? xe + (x >> 1) : (x >> 1);
   };
+  // (a high-half sample never lies in the next level's box when that box ends at or before the low half)
+  const bool fastLoads = dequant && F.inner[2] <= ze && (!SG || scheme != 0);
+  // The fp64 samples of the coarser levels' box THROUGH LDS as well (sign-in-word kernel, round 5): where the lanes of
+  // a wavefront that are in the box are exactly its even ones -- rows of a multiple of 64 samples: 32 doubles in a row
+  // of the chunk buffer --, the 256 bytes travel like a row of coefficients, a pair ahead (lane i fetches dword i),
+  // and lane 2 i reads double i.  Two load round trips per pair in half the wavefronts, with the other half waiting
+  // for them at the barrier, before.  A slot per (wavefront, position) that has a box row: 12 rows x cx / 64 <= 48.
+  uint32_t boxLds = 0, boxSlot0 = 0;   // (wave-uniform) bit k: position k's box samples come through LDS; the wavefront's first slot
+  uint32_t* boxRows = reinterpret_cast<uint32_t*>(sm + 2 * (size_t)bufN) + (size_t)nwaves * (kXYZPosI * 2 * 64);
+  if (SG && fastLoads) {
+    uint32_t reg = 0;
+#pragma unroll
+    for (int k = 0; k < kXYZPosI; k++) {
+      const uint64_t inb = __ballot((innerMask >> k) & 1u), act = __ballot((activeMask >> k) & 1u);
+      if (inb == 0x5555555555555555ull && act == ~0ull && (cx & 63u) == 0)
+        reg |= 1u << k;
+    }
+    reg = (uint32_t)__builtin_amdgcn_readfirstlane((int)reg);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sm);   // (the staging buffers are not in use yet)
+    if (lane == 0)
+      cnt[wave] = (uint32_t)__popc(reg);
+    XYZ_LDS_BARRIER();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < nwaves; w++) {
+      const uint32_t v = cnt[w];
+      before += w < wave ? v : 0u;
+      total += v;
+    }
+    XYZ_LDS_BARRIER();
+    if (total <= (uint32_t)kXYZBoxSlots && reg == (1u << kXYZPosI) - 1u) {   // (all of the wavefront's positions or none)
+      boxLds = reg;
+      boxSlot0 = before;
+    }
+  }
+  uint32_t* myBox = boxRows + (size_t)boxSlot0 * 64;   // position k's row: myBox + k * 64
   auto pre_issue = [&](uint32_t m) {
 #pragma unroll
     for (int k = 0; k < kXYZPosI; k++) {
@@ -1229,9 +1265,17 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       __builtin_amdgcn_global_load_lds(coef + ((size_t)m * sliceN + off), myPre + (k * 2) * 64, 4, 0, 0);
       __builtin_amdgcn_global_load_lds(coef + ((size_t)(ze + m) * sliceN + off), myPre + (k * 2 + 1) * 64, 4, 0, 0);
     }
+    if (SG && boxLds != 0 && m < F.inner[2]) {   // (uniform)
+#pragma unroll
+      for (int k = 0; k < kXYZPosI; k++) {
+        uint32_t drow, dcol;
+        pos_off(k, drow, dcol);
+        const uint32_t x0h = ((pk[k] & 0xfffu) - lane) >> 1;   // the box column of the wavefront's first lane
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(buf + ((size_t)m * bufSlice + (size_t)drow * bufx + x0h)) + lane;
+        __builtin_amdgcn_global_load_lds(src, myBox + k * 64, 4, 0, 0);
+      }
+    }
   };
-  // (a high-half sample never lies in the next level's box when that box ends at or before the low half)
-  const bool fastLoads = dequant && F.inner[2] <= ze && (!SG || scheme != 0);
   if (fastLoads && mFirst < mB)
     pre_issue(mFirst);
 #endif
@@ -1245,8 +1289,18 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
       // (round 5) the coefficients carry their sign and are complete: a pair's global loads are the fp64 samples of
       // the coarser levels' box alone -- and only in the wavefronts that have a lane in the box (with 256 samples a
       // row: those whose rows are the even ones)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pair's coefficients have landed in LDS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this pair's coefficients have landed in LDS (and its box rows)
       const bool boxWave = boxAny != 0 && m < F.inner[2];   // (uniform)
+      if (boxWave && boxLds != 0) {   // the box samples were prefetched with the coefficients
+#pragma unroll
+        for (int k = 0; k < kXYZPosI; k++) {
+          const double lo = sg_value(myPre[(k * 2) * 64 + lane]);
+          const double hi = sg_value(myPre[(k * 2 + 1) * 64 + lane]);
+          const double bxv = reinterpret_cast<const double*>(myBox + k * 64)[lane >> 1];
+          zstep(k, m, mine, true, (lane & 1u) ? lo : bxv, hi);   // (the even lanes are the ones in the box)
+        }
+      }
+      else {
 #pragma unroll
       for (int g = 0; g < kXYZPosI; g += kXYZGroupI) {
         __builtin_amdgcn_sched_barrier(0);   // (kXYZGroupI positions' loads in flight at a time)
@@ -1274,6 +1328,7 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
           const double hi = sg_value(myPre[(k * 2 + 1) * 64 + lane]);
           zstep(k, m, mine, ((activeMask >> k) & 1u) != 0, ((boxm >> kk) & 1u) ? bx[kk] : lo, hi);
         }
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (m + 1 < mB)
@@ -1821,7 +1876,8 @@ int launch_lift_xyz(hipStream_t stream, bool forward, double* vals, size_t valsS
   size_t smem = 2 * (size_t)kXYZStaged * xyz_row_stride(cdims[0]) * sizeof(double);   // two staging buffers
 #if XYZ_INV_PREFETCH == 2
   if (!forward)
-    smem += (size_t)kXYZThreadsI * kXYZPosI * 2 * sizeof(uint32_t);   // + the coefficients on their way in
+    smem += (size_t)kXYZThreadsI * kXYZPosI * 2 * sizeof(uint32_t) +   // + the coefficients on their way in
+            (size_t)kXYZBoxSlots * 64 * sizeof(uint32_t);              //   and the box samples (k_lift_xyz_inv<.., true>)
 #endif
   {
     const void* fns[6] = {reinterpret_cast<const void*>(&k_lift_xyz_fwd<1>), reinterpret_cast<const void*>(&k_lift_xyz_fwd<2>),
