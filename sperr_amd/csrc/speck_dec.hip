@@ -17,6 +17,7 @@
 // Bits past the available length read as zero (the reference zero-pads a truncated stream,
 // SPECK_INT.cpp:95-105); the loop stops where the reference's does.
 #include "speck_dec.h"
+#include "bit_words.h"
 
 namespace sperrhip {
 
@@ -37,58 +38,6 @@ __device__ __forceinline__ uint64_t get64(const uint64_t* words, uint64_t pos)
 // k_dec_load: parse the chunk stream (17-byte conditioner header, 9-byte SPECK header), copy the
 // payload into an aligned, zero-padded word buffer (SPECK_FLT.cpp:27-109, SPECK_INT.cpp:79-108)
 // ------------------------------------------------------------------------------------------
-// Bits of `x0` / `x1` (bit i: candidate i) spread to the set positions of `m` in order -- the parallel-suffix "expand" of
-// Hacker's Delight 7-5, its mask half shared by the two.  (The pixel passes of the decoder walked a word's candidates
-// one set bit at a time: a wavefront took as many rounds as its fullest word had candidates.)
-__device__ __forceinline__ void spread_under_mask(uint64_t m, uint64_t& x0, uint64_t& x1)
-{
-  const uint64_t m0 = m;
-  uint64_t mk = ~m << 1, mv[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    uint64_t mp = mk ^ (mk << 1);
-    mp ^= mp << 2;
-    mp ^= mp << 4;
-    mp ^= mp << 8;
-    mp ^= mp << 16;
-    mp ^= mp << 32;
-    mv[i] = mp & m;
-    m = (m ^ mv[i]) | (mv[i] >> (1 << i));
-    mk &= ~mp;
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    x0 = (x0 & ~mv[i]) | ((x0 << (1 << i)) & mv[i]);
-    x1 = (x1 & ~mv[i]) | ((x1 << (1 << i)) & mv[i]);
-  }
-  x0 &= m0;
-  x1 &= m0;
-}
-
-// The other way round: the bits of `x0` / `x1` at the set positions of `m`, packed to the bottom in order ("compress",
-// Hacker's Delight 7-4).
-__device__ __forceinline__ void gather_under_mask(uint64_t m, uint64_t& x0, uint64_t& x1)
-{
-  x0 &= m;
-  x1 &= m;
-  uint64_t mk = ~m << 1;
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    uint64_t mp = mk ^ (mk << 1);
-    mp ^= mp << 2;
-    mp ^= mp << 4;
-    mp ^= mp << 8;
-    mp ^= mp << 16;
-    mp ^= mp << 32;
-    const uint64_t mv = mp & m;
-    m = (m ^ mv) | (mv >> (1 << i));
-    const uint64_t t0 = x0 & mv, t1 = x1 & mv;
-    x0 = (x0 ^ t0) | (t0 >> (1 << i));
-    x1 = (x1 ^ t1) | (t1 >> (1 << i));
-    mk &= ~mp;
-  }
-}
-
 __global__ void k_dec_header(DecBuffers b, const uint8_t* container, const uint64_t* chunkOff,
                              const uint64_t* chunkLen, const uint64_t* initLIS,
                              const uint32_t* initLen, int wide_pass)
@@ -510,17 +459,7 @@ __global__ void __launch_bounds__(kThreads) k_lip_words(DecBuffers b, int p)
       if (w >= nwords)
         continue;
       const uint64_t x = xw[k];
-      // A bit starts a token when the run of 1s in front of it is of even length (a 1 at a token's start is followed
-      // by its sign): the escaped characters of a run of backslashes, worked out for 64 bits at once with one
-      // addition -- odd-length runs are found by the carry they send past their end (a loop over the 64 bits
-      // before: 300 operations a word).  `parity`: the first bit is a sign.
-      const uint64_t even = 0x5555555555555555ull;
-      const uint64_t bs = x & ~(uint64_t)parity;
-      const uint64_t follows = (bs << 1) | (uint64_t)parity;
-      const uint64_t oddStarts = bs & ~even & ~follows;
-      const uint64_t sum = oddStarts + bs;
-      parity = sum < bs ? 1u : 0u;   // (the run of 1s that ends with this word is odd: the next word opens with a sign)
-      uint64_t starts = ~((even ^ (sum << 1)) & follows);
+      uint64_t starts = lip_token_starts(x, parity);   // (bit_words.h; a loop over the 64 bits before: 300 operations a word)
       if (w == nwords - 1 && (nbits & 63))
         starts &= (1ull << (nbits & 63)) - 1;
       b.tokMask[c * b.tokStride + w] = starts;

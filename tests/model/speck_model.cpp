@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../sperr_amd/csrc/speck_tree_host.hpp"
+#include "../../sperr_amd/csrc/bit_words.h"
 
 using namespace spk;
 
@@ -1983,6 +1984,73 @@ int model_check_mx_columns(const size_t dims[3], int twoD, int* ncols)
 int model_check_classes_2d(const size_t dims[3])
 {
   return check_classes_impl(dims, true);
+}
+
+
+// ---- the word-level steps of the decoder's pixel passes (sperr_amd/csrc/bit_words.h) against bit-by-bit loops.
+// Returns the number of words that differ (0: all equal); `seed` picks the pseudo-random words, a third of them
+// sparse, a third dense, with runs of ones that cross the word's ends.
+static uint64_t bw_rng(uint64_t& st)
+{
+  st ^= st << 13;
+  st ^= st >> 7;
+  st ^= st << 17;
+  return st;
+}
+int model_check_bit_words(uint64_t seed, int n)
+{
+  uint64_t st = seed * 0x9e3779b97f4a7c15ull + 1;
+  int bad = 0;
+  for (int t = 0; t < n; t++) {
+    uint64_t m = bw_rng(st), x0 = bw_rng(st), x1 = bw_rng(st);
+    if (t % 3 == 1)
+      m &= bw_rng(st) & bw_rng(st);
+    if (t % 3 == 2)
+      m |= bw_rng(st) | bw_rng(st);
+    if (t % 97 == 0)
+      m = t % 2 ? ~0ull : 0ull;
+    // spread: bit i of x goes to the i-th set bit of m
+    {
+      uint64_t a0 = x0, a1 = x1, r0 = 0, r1 = 0;
+      sperrhip::spread_under_mask(m, a0, a1);
+      int k = 0;
+      for (int b = 0; b < 64; b++)
+        if ((m >> b) & 1ull) {
+          r0 |= ((x0 >> k) & 1ull) << b;
+          r1 |= ((x1 >> k) & 1ull) << b;
+          k++;
+        }
+      bad += (a0 != r0) + (a1 != r1);
+    }
+    // gather: the bits of x at the set bits of m, packed
+    {
+      uint64_t a0 = x0, a1 = x1, r0 = 0, r1 = 0;
+      sperrhip::gather_under_mask(m, a0, a1);
+      int k = 0;
+      for (int b = 0; b < 64; b++)
+        if ((m >> b) & 1ull) {
+          r0 |= ((x0 >> b) & 1ull) << k;
+          r1 |= ((x1 >> b) & 1ull) << k;
+          k++;
+        }
+      bad += (a0 != r0) + (a1 != r1);
+    }
+    // token starts of a word of the LIP scan, both parities
+    for (uint32_t par = 0; par < 2; par++) {
+      const uint64_t x = t % 5 == 0 ? (x0 | x1 | m) : (t % 7 == 0 ? ~0ull : x0);
+      uint32_t p = par;
+      const uint64_t got = sperrhip::lip_token_starts(x, p);
+      uint64_t want = 0;
+      uint32_t ones = par;
+      for (int q = 0; q < 64; q++) {
+        if ((ones & 1u) == 0)
+          want |= 1ull << q;
+        ones = ((x >> q) & 1ull) ? ones + 1 : 0;
+      }
+      bad += (got != want) + (p != (ones & 1u));
+    }
+  }
+  return bad;
 }
 
 }  // extern "C"
