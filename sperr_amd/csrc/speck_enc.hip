@@ -1195,21 +1195,35 @@ __global__ void __launch_bounds__(kThreads) k_emit_pixels(EncBuffers b)
   const uint32_t tile = blockIdx.x;
   const uint32_t i0 = tile * kPixTile + threadIdx.x * kPixPer;
   int m[kPixPer], bp[kPixPer];
-  load_pix(b.msb + c * b.pixStride, i0, n, m);
   load_pix(b.bplane + c * b.pixStride, i0, n, bp);
-  CT cf[kPixPer];
-  uint32_t sg = 0;
-  const CT* coef = reinterpret_cast<const CT*>(b.coef) + c * b.coefStride;
-  const uint64_t* sign = b.sign + c * b.signStride;
-  if (i0 < n)   // kPixPer divides 64: the signs of the thread's samples sit in one word
-    sg = (uint32_t)(sign[i0 >> 6] >> (i0 & 63));
-#pragma unroll
-  for (int k = 0; k < kPixPer; k++)
-    cf[k] = (i0 + k < n) ? coef[i0 + k] : (CT)0;
   int bpmax = -1;   // no sample of the thread is in the LIP or significant at planes >= bpmax
 #pragma unroll
   for (int k = 0; k < kPixPer; k++)
     bpmax = max(bpmax, bp[k]);
+  // A sample born at plane b gives LIP bits on planes below b and refinement bits below its msb <= b: nothing at all
+  // when b is not above the last plane coded.  Such a thread -- at 2 bits per sample half of them: the fine subbands
+  // whose sets never split inside the budget -- loads neither its coefficients nor their msbs (round 5, second
+  // session: 5 of the 6 bytes a sample costs here).
+  const bool live = bpmax > s.plast;
+  CT cf[kPixPer];
+  uint32_t sg = 0;
+  const CT* coef = reinterpret_cast<const CT*>(b.coef) + c * b.coefStride;
+  const uint64_t* sign = b.sign + c * b.signStride;
+#pragma unroll
+  for (int k = 0; k < kPixPer; k++) {
+    m[k] = -1;
+    cf[k] = (CT)0;
+  }
+  if (live) {
+    load_pix(b.msb + c * b.pixStride, i0, n, m);
+    if (i0 < n)   // kPixPer divides 64: the signs of the thread's samples sit in one word
+      sg = (uint32_t)(sign[i0 >> 6] >> (i0 & 63));
+#pragma unroll
+    for (int k = 0; k < kPixPer; k++)
+      cf[k] = (i0 + k < n) ? coef[i0 + k] : (CT)0;
+  }
+  else
+    bpmax = -1;   // (takes no part in the plane loop)
   // The thread's 16 samples BIT-SLICED (round 3): bit k of M[j] / B[j] = bit j of msb + 1 / birth plane + 1
   // of sample k.  "msb above plane p", "msb equal to p", "born above p" for all 16 samples are then a
   // dozen logic operations on 16-bit masks per plane instead of a chain of compares, shifts and
