@@ -2177,7 +2177,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.queueStride = (size_t)d.queueCap * 4 * d.hiGroupsMax;
   TAKE(d.queue, uint64_t, d.queueStride * B);
   d.hiAhead = std::min(d.hiAhead / 64 * 64, d.hiW / 2);
-  d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 4) * 4;
+  d.hiFlagStride = ((d.streamStride * 64 + N) / std::max<uint32_t>(512u, d.hiW - d.hiAhead) + 12) * 4;   // (+ the short first regions of a phase)
   d.mxSlot = P.d_mxSlot;
   d.mxLevelGroup = P.d_mxLevelGroup;
   d.mxS = kMxS;

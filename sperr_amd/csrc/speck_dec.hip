@@ -1870,6 +1870,10 @@ __device__ __forceinline__ uint32_t reg_child_raster(const Tree& t, const Node& 
 constexpr uint32_t kHiTagShift = 57;
 constexpr unsigned long long kHiPayloadMask = (1ull << kHiTagShift) - 1ull;
 constexpr int kHiFrames = 10;   // list level + the sets being walked into (chains of up to 9 classes)
+#ifndef HI_FIRST_REGION
+#define HI_FIRST_REGION 1024
+#endif
+constexpr uint32_t kHiFirstRegion = HI_FIRST_REGION;   // bits of a phase's first region; the next ones double up to the full size
 
 // Lanes of ONE wavefront that talk through LDS: the hardware keeps a wavefront's LDS traffic in
 // order, but the compiler reasons per thread (it may forward a lane's own earlier store to its
@@ -1889,13 +1893,18 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   extern __shared__ __attribute__((aligned(16))) char tab_smem[];
   uint64_t* wbits = reinterpret_cast<uint64_t*>(tab_smem);
   const uint32_t* w32 = reinterpret_cast<const uint32_t*>(tab_smem);
-  const uint32_t W = b.hiW, TS = W + 2;   // positions the tables cover
-  const uint32_t SR = W - b.hiAhead;      // bits of a region (the tables look hiAhead bits further)
+  // Round 5, second session: the FIRST regions of a plane's phase are short -- 1024, 2048, 4096 bits, then the full size
+  // (hi_region below: where a region starts is still a function of its number alone) --, so that a phase of a few
+  // hundred bits, which is what the dozen light planes hold, builds tables for 1.5 K positions and not for 6.9 K
+  // (26 us of the 55 to 90 the kernel took on such a plane).  A long phase pays three short regions for it.
+  const uint32_t Wmax = b.hiW, TS = Wmax + 2;   // positions the tables have room for
+  const uint32_t SRmax = Wmax - b.hiAhead;      // bits of a full region (the tables look hiAhead bits further)
+  uint32_t W = Wmax, SR = SRmax;                // of the region at hand (set with its ticket)
   const int Kcap = (int)b.hiK;                     // classes the LDS tables have room for
-  const uint32_t kWords = W / 64 + 4;
+  const uint32_t kWords = Wmax / 64 + 4;
   uint32_t* hop = reinterpret_cast<uint32_t*>(tab_smem + (size_t)kWords * 8);   // [W + 130]
-  uint32_t* hop2 = b.hiHop2 ? hop + (W + 130) : hop;                            // [W + 130], or none (never built then)
-  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop + (b.hiHop2 ? 2 : 1) * (W + 130));   // [Kcap - 1][TS]
+  uint32_t* hop2 = b.hiHop2 ? hop + (Wmax + 130) : hop;                         // [Wmax + 130], or none (never built then)
+  uint16_t* Tt = reinterpret_cast<uint16_t*>(hop + (b.hiHop2 ? 2 : 1) * (Wmax + 130));   // [Kcap - 1][TS]
   uint16_t* Uu = Tt + (size_t)(Kcap - 1) * TS;                                  // [Kcap][TS]
   constexpr int kBlk = kTabWMax / 64 + 4;
   __shared__ uint32_t blkEB[kBlk];
@@ -2386,12 +2395,25 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     // diagnostics (thread 0, when b.lisStamps != nullptr): ticks per part of a region
     const bool stamps = b.lisStamps != nullptr && tid == 0;
     uint64_t st0 = stamps ? __builtin_readcyclecounter() : 0, st1 = 0;
-    a = S0 + (uint64_t)i * SR;
+    {   // region i: bits [a, a + SR) of the phase
+      uint64_t off = 0;
+      uint32_t sz = kHiFirstRegion, j = 0;
+      for (; j < i && sz < SRmax; j++, sz <<= 1)
+        off += sz;
+      if (j < i)
+        off += (uint64_t)(i - j) * SRmax;
+      SR = min(sz, SRmax);
+      if (j < i)
+        SR = SRmax;
+      W = SR + b.hiAhead;
+      a = S0 + off;
+    }
     wq0 = (uint32_t)(a & 63);
     {
       const uint64_t w0 = a >> 6;
       uint64_t any = 0;
-      for (uint32_t k = tid; k < kWords; k += kTabThreads) {
+      const uint32_t nWordsNow = W / 64 + 4;
+      for (uint32_t k = tid; k < nWordsNow; k += kTabThreads) {
         const uint64_t idx = w0 + k;
         const uint64_t v = idx < nwordsAvail ? words[idx] : 0ull;
         wbits[k] = v;
