@@ -508,6 +508,7 @@ struct Engine {
   std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
+  DevBuf pweBox;                           //   ... and the coarser levels' box of its reconstruction (pwe_outlier_stage)
   DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
   uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
   hipEvent_t liveEv[kSubStreams][kLiveSlots] = {};
@@ -623,7 +624,7 @@ struct Engine {
       kv.second->tables.drop();
     plans.clear();
     planOrder.clear();
-    for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &slice2d, &wideScratch})
+    for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &pweBox, &slice2d, &wideScratch})
       b->drop();
     for (auto& b : outlDec)
       b.drop();
@@ -1348,21 +1349,73 @@ void speck1d_level_offsets(OutlierBufs& ob, uint32_t N, uint64_t most)
 template <typename T>
 int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
                       const T* d_src, VolDesc vd, const uint32_t cd[3], double tol,
-                      uint64_t* d_lens2, PweKeepList& keep)
+                      uint64_t* d_lens2, PweKeepList& keep, bool anyWide)
 {
   EncBuffers& e = bb.eb;
   HostMarks hm;
   hm.mark("(3D coder done)", st);
-  if (launch_inv_quantize(st, false, bb.coef32, e.coefStride, e.sign, e.signStride, nb, P.N, bb.vals,
-                          bb.valsStride, e.cst) ||
-      launch_inv_quantize(st, true, bb.vals, bb.valsStride, e.sign, e.signStride, nb, P.N, bb.vals,
-                          bb.valsStride, e.cst))
-    return -1;
-  for (size_t k = P.fwd.size(); k-- > 0;) {
-    const LiftPass& ps = P.fwd[k];
-    if (launch_lift(st, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst, 0, nullptr,
-                    vd, bb.geom))
+  // What the decoder will reconstruct, in the conditioned domain (src/SPECK_FLT.cpp:461-486).  Round 5: by the decoder's
+  // own kernels where the plan allows it -- the coarser levels in a compact buffer of their box, dequantising as they
+  // load (LiftFuse mode 2), the finest level by k_lift_xyz_inv writing doubles into the chunk buffer as if it were a
+  // volume of bricks (a chunk's offset rides in org[0]; no mean added) -- instead of an inverse quantiser pass and
+  // fifteen per-axis passes over the whole chunk (14.9 of the 56 ms a 1024^3 volume took to compress in this mode).
+  static const bool fusedEnv = !(tune_getenv("SPERR_HIP_PWE_FUSED_INV") && atoi(tune_getenv("SPERR_HIP_PWE_FUSED_INV")) == 0);
+  std::vector<ChunkGeom> bricks(nb);   // (lives until the stage's next wait for the stream)
+  const bool fused = fusedEnv && !anyWide && fuse_xyz(P) && plan_fusable(P) && P.fwd.size() >= 3 &&
+                     (uint64_t)nb * bb.valsStride <= 0xffffffffull;
+  if (fused) {
+    uint32_t cbox[3] = {1, 1, 1};
+    for (size_t k = 3; k < P.fwd.size(); k++)
+      for (int a = 0; a < 3; a++)
+        cbox[a] = std::max(cbox[a], P.fwd[k].region[a]);
+    const size_t cstride = round_up((size_t)cbox[0] * cbox[1] * cbox[2], 64);
+    const size_t geomOff = round_up((size_t)nb * cstride * 8, 256);
+    if (E.pweBox.ensure(geomOff + (size_t)nb * sizeof(ChunkGeom) + 256))
       return -1;
+    double* cvals = static_cast<double*>(E.pweBox.p);
+    ChunkGeom* d_bricks = reinterpret_cast<ChunkGeom*>(static_cast<char*>(E.pweBox.p) + geomOff);
+    for (uint32_t i = 0; i < nb; i++) {
+      bricks[i].org[0] = (uint32_t)((size_t)i * bb.valsStride);
+      bricks[i].org[1] = bricks[i].org[2] = 0;
+    }
+    HIP_CHECK(hipMemcpyAsync(d_bricks, bricks.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, st));
+    auto fuse = [&](size_t k, LiftFuse& lf) {
+      if (pass_fuse(P, k, lf.inner) > 0) {
+        lf.mode = 2;
+        lf.coef = bb.coef32;
+        lf.coefStride = e.coefStride;
+        lf.sign = e.sign;
+        lf.signStride = e.signStride;
+      }
+      lf.bufx = cbox[0];
+      lf.bufy = cbox[1];
+    };
+    for (size_t k = P.fwd.size(); k-- > 3;) {
+      const LiftPass& ps = P.fwd[k];
+      LiftFuse lf;
+      fuse(k, lf);
+      if (launch_lift(st, false, cvals, cstride, nb, cd, ps.axis, ps.region, e.cst, 0, nullptr, vd, bb.geom, &lf))
+        return -1;
+    }
+    LiftFuse lf;
+    fuse(2, lf);
+    lf.noMean = 1;
+    const VolDesc brickVol{{cd[0], cd[1], cd[2]}};   // (rows of cx samples, slices of cx * cy: a brick)
+    if (launch_lift_xyz(st, false, cvals, cstride, nb, cd, e.cst, 2, bb.vals, brickVol, d_bricks, &lf))
+      return -1;
+  }
+  else {
+    if (launch_inv_quantize(st, false, bb.coef32, e.coefStride, e.sign, e.signStride, nb, P.N, bb.vals,
+                            bb.valsStride, e.cst) ||
+        launch_inv_quantize(st, true, bb.vals, bb.valsStride, e.sign, e.signStride, nb, P.N, bb.vals,
+                            bb.valsStride, e.cst))
+      return -1;
+    for (size_t k = P.fwd.size(); k-- > 0;) {
+      const LiftPass& ps = P.fwd[k];
+      if (launch_lift(st, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, e.cst, 0, nullptr,
+                      vd, bb.geom))
+        return -1;
+    }
   }
   hm.mark("inverse path", st);
   OutlierBufs ob;
@@ -1855,7 +1908,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
                  d_lens, P->N, 1);
       }
       if (mode == 3 &&
-          pwe_outlier_stage<T>(ss, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep))
+          pwe_outlier_stage<T>(ss, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep,
+                               retry))   // (a chunk that was coded again has 64-bit coefficients)
         return -1;
     }
   

@@ -50,6 +50,9 @@ struct LiftFuse {
   // coef_scheme(dst[c]) allows it, with the sign in bit 31 (speck_dec.h): the sign and mask words are not read at all then.
   // q * double(magnitude), sign flipped = q * double(magnitude) * (+-1.0) bit for bit (a zero is positive either way)
   int coefSigned = 0;
+  // k_lift_xyz_inv: do not add the chunk's mean to what it writes (the encoder's point-wise error stage compares in the
+  // conditioned domain, src/SPECK_FLT.cpp:461-486)
+  int noMean = 0;
   // inverse, compact chunk buffer (round 3): `vals` holds only the box the coarser levels work in,
   // rows of bufx samples and bufy rows per slice (0: the chunk's own dims); the coefficient and mask
   // arrays keep the chunk's dims

@@ -1146,8 +1146,13 @@ k_lift_xyz_inv(const double* vals, size_t valsStride, uint32_t cx, uint32_t cy, 
     for (uint32_t r = wave; r < nt; r += nwaves) {
       VT* dstrow = volc + (size_t)z * vsz + (size_t)(y0 + r) * vsy;
       const double* srow = X + (size_t)(kXYHalo + r) * RS + 4;
-      for (uint32_t x = lane; x < cx; x += 64)
-        dstrow[x] = (VT)(srow[x] + mean);
+      if (F.noMean) {   // (uniform)
+        for (uint32_t x = lane; x < cx; x += 64)
+          dstrow[x] = (VT)srow[x];
+      }
+      else
+        for (uint32_t x = lane; x < cx; x += 64)
+          dstrow[x] = (VT)(srow[x] + mean);
     }
   };
   auto finish_slice = [&](uint32_t z) {
