@@ -510,6 +510,7 @@ struct Engine {
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   DevBuf pweBox;                           //   ... and the coarser levels' box of its reconstruction (pwe_outlier_stage)
   DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
+  DevBuf decBox[kSubStreams];              //   ... and the coarser levels' box of a sub-batch with outlier streams
   uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
   hipEvent_t liveEv[kSubStreams][kLiveSlots] = {};
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
@@ -627,6 +628,8 @@ struct Engine {
     for (DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &pweBox, &slice2d, &wideScratch})
       b->drop();
     for (auto& b : outlDec)
+      b.drop();
+    for (auto& b : decBox)
       b.drop();
     for (auto& b : pweBufs)
       if (b)
@@ -2886,6 +2889,36 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // (src/SPECK_FLT.cpp:573-590), in which case every pass stays in the chunk buffer
         const bool fxyz = fuse_xyz(*P) && !batchOutliers;
         const bool fxy = fuse_xy(*P) && !batchOutliers && !fxyz;
+        // With outlier correctors the transformed values have to stay doubles a little longer -- but they can still
+        // come from the fused kernels (round 5): the coarser levels in a compact buffer of their box, the finest level
+        // by k_lift_xyz_inv writing doubles, no mean added, into the chunk buffer as if it were a volume of bricks (a
+        // chunk's offset rides in org[0]); the correctors and the scatter pass follow as before.  (Fifteen per-axis
+        // passes over the whole chunk before: 12.7 ms for 64 chunks of 256^3.)
+        static const bool brickEnv = !(tune_getenv("SPERR_HIP_PWE_FUSED_INV") && atoi(tune_getenv("SPERR_HIP_PWE_FUSED_INV")) == 0);
+        const bool fbrick = brickEnv && batchOutliers && fuse_xyz(*P) && fuseDq && maxWide == 0 && P->fwd.size() >= 3 &&
+                            compactElems == 0 && (uint64_t)nb * bb.valsStride <= 0xffffffffull;
+        uint32_t bbox[3] = {1, 1, 1};
+        double* boxVals = nullptr;
+        size_t boxStride = 0;
+        ChunkGeom* d_bricks = nullptr;
+        std::vector<ChunkGeom> bricks;   // (lives until the wait for the stream below: batchOutliers)
+        if (fbrick) {
+          for (size_t k = 3; k < P->fwd.size(); k++)
+            for (int a = 0; a < 3; a++)
+              bbox[a] = std::max(bbox[a], P->fwd[k].region[a]);
+          boxStride = round_up((size_t)bbox[0] * bbox[1] * bbox[2], 64);
+          const size_t geomOff = round_up((size_t)nb * boxStride * 8, 256);
+          if (E.decBox[q].ensure(geomOff + (size_t)nb * sizeof(ChunkGeom) + 256))
+            return -1;
+          boxVals = static_cast<double*>(E.decBox[q].p);
+          d_bricks = reinterpret_cast<ChunkGeom*>(static_cast<char*>(E.decBox[q].p) + geomOff);
+          bricks.resize(nb);
+          for (uint32_t i = 0; i < nb; i++) {
+            bricks[i].org[0] = (uint32_t)((size_t)i * bb.valsStride);
+            bricks[i].org[1] = bricks[i].org[2] = 0;
+          }
+          HIP_CHECK(hipMemcpyAsync(d_bricks, bricks.data(), nb * sizeof(ChunkGeom), hipMemcpyHostToDevice, ss));
+        }
         // a level of the inverse transform is 3 passes (z y x) of a dyadic chunk, 2 (y x) of a slice
         const size_t perLevel = slice ? 2 : 3;
         auto sub_volume = [&](size_t k) -> int {   // before pass k, the first of its level
@@ -2914,16 +2947,29 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
             lf.bufx = cbox[0];
             lf.bufy = cbox[1];
           }
+          if (fbrick) {
+            lf.bufx = bbox[0];
+            lf.bufy = bbox[1];
+          }
         };
-        for (size_t k = P->fwd.size(); k-- > (fxyz ? 3u : fxy ? 2u : 0u);) {
+        for (size_t k = P->fwd.size(); k-- > ((fxyz || fbrick) ? 3u : fxy ? 2u : 0u);) {
           const LiftPass& ps = P->fwd[k];
           if (mr && mr->nlev && k % perLevel == perLevel - 1 && sub_volume(k))
             return -1;
           LiftFuse lf;
           dequant_fuse(k, lf);
-          if (launch_lift(ss, false, bb.vals, bb.valsStride, nb, cd, ps.axis, ps.region, d.cst,
+          if (launch_lift(ss, false, fbrick ? boxVals : bb.vals, fbrick ? boxStride : bb.valsStride, nb, cd, ps.axis,
+                          ps.region, d.cst,
                           (k == 0 && !batchOutliers) ? (std::is_same<T, float>::value ? 1 : 2) : 0,
                           d_dst, vd, bb.geom, &lf))
+            return -1;
+        }
+        if (fbrick) {   // the finest level into the chunk buffer, as doubles
+          LiftFuse lf;
+          dequant_fuse(2, lf);
+          lf.noMean = 1;
+          const VolDesc brickVol{{cd[0], cd[1], cd[2]}};
+          if (launch_lift_xyz(ss, false, boxVals, boxStride, nb, cd, d.cst, 2, bb.vals, brickVol, d_bricks, &lf))
             return -1;
         }
         if (fxyz) {   // the finest level: z, y and x pass in one kernel, into the volume
