@@ -657,6 +657,19 @@ struct ListItem {
   bool sig;
 };
 
+// A list entry carries its set's msb (round 5, second session): bits 57 .. 63 of the packed node hold msb + 2 (0: not
+// known -- the lists' first entries and the 2D coder's subbands, whose M is looked up as before).  An entry is tested
+// on every plane from its birth to the plane it splits on: the test was a dependent grid look-up for its flat id and a
+// random 1-byte read of M per entry, plane and pass (k_list_count, k_list_apply); now it is a compare on the word the
+// list walk reads anyway, and the id is worked out for the entries that split.  Trees of at most 511 grids (the
+// grid index keeps 9 of its 16 bits).
+constexpr int kEntryMsbShift = 57;
+constexpr uint64_t kEntryNodeMask = (1ull << kEntryMsbShift) - 1ull;
+__device__ __forceinline__ uint64_t entry_with_msb(const Tree& t, uint64_t packed, int m)
+{
+  return t.ngrids <= 511u ? packed | ((uint64_t)(uint32_t)(m + 2) << kEntryMsbShift) : packed;
+}
+
 __device__ __forceinline__ void load_list4(const EncBuffers& b, uint32_t c, const EncState& s,
                                            uint32_t tile, int p, ListItem it[4])
 {
@@ -665,14 +678,24 @@ __device__ __forceinline__ void load_list4(const EncBuffers& b, uint32_t c, cons
   const uint64_t* list = b.lis[s.cur] + c * b.lisStride + b.levelOff[l];
   const int8_t* M = b.M + c * b.nodeStride;
   const uint32_t* E = b.E + c * b.nodeStride;
+  const bool carries = b.tree.ngrids <= 511u;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t e = start + threadIdx.x * 4 + k;
+    it[k].packed = e < n ? list[e] : 0ull;
+  }
+#pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint32_t e = start + threadIdx.x * 4 + k;
     it[k].bits = 0;
     it[k].sig = false;
+    it[k].id = 0;
     if (e < n) {
-      it[k].packed = list[e];
-      it[k].id = flat_id(b.tree, unpack_node(it[k].packed));
-      it[k].sig = (M[it[k].id] == p);
+      const uint32_t mf = carries ? (uint32_t)(it[k].packed >> kEntryMsbShift) : 0u;
+      if (mf == 0 || (int)mf - 2 == p) {   // (the entries that split on this plane, and the few that carry no msb)
+        it[k].id = flat_id(b.tree, unpack_node(carries ? it[k].packed & kEntryNodeMask : it[k].packed));
+        it[k].sig = mf ? true : (M[it[k].id] == p);
+      }
       it[k].bits = 1u + (it[k].sig ? E[it[k].id] : 0u);
     }
   }
@@ -1073,7 +1096,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
           kn.i[0] = (uint16_t)(2u * nd.i[0] + (uint32_t)(j & 1));
           kn.i[1] = (uint16_t)(2u * nd.i[1] + (uint32_t)((j >> 1) & 1));
           kn.i[2] = (uint16_t)(2u * nd.i[2] + (uint32_t)(j >> 2));
-          b.bornPacked[c * b.bornStride + kslot] = pack_node(kn);
+          b.bornPacked[c * b.bornStride + kslot] = entry_with_msb(t, pack_node(kn), k.m[j]);
           b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
           kslot++;
           atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
@@ -1111,7 +1134,7 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     else if (!ki.pixel[j]) {  // insignificant set: joins LIS[kidlev] in stream order
       const uint64_t rel = pos - 1 - baseLIS;
       if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
-        b.bornPacked[c * b.bornStride + kslot] = pack_node(kid_node(kg, j));
+        b.bornPacked[c * b.bornStride + kslot] = entry_with_msb(t, pack_node(kid_node(kg, j)), (int)ki.m[j]);
         b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
         kslot++;
         atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
