@@ -54,7 +54,20 @@ k_outlier_scan(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uin
     const uint32_t i = w * 64u + lane;
     bool flag = false;
     double diff = 0.0;
-    if (i < b.N) {
+    // (pass 0 leaves the word's flags in maskGE, which nobody needs before the 1D coder clears it: the later passes
+    //  read the volume and the reconstruction only for the samples that were flagged -- round 5)
+    unsigned long long fw = ~0ull;
+    if (PASS > 0) {
+      fw = b.maskGE[c * b.wordStride + w];
+      if (fw == 0ull) {   // (uniform) no outlier in the word
+        if (PASS == 1 && lane == 0) {
+          b.outPre[c * b.wordStride + w] = 0;
+          b.signMask[c * b.wordStride + w] = 0;
+        }
+        continue;
+      }
+    }
+    if (i < b.N && ((fw >> lane) & 1ull)) {
       const uint32_t x = i % cx, r = i / cx;
       const uint32_t y = r % cy, z = r / cy;
       // the conditioned input, as the first lifting pass computed it (Conditioner.cpp:46-50)
@@ -64,7 +77,10 @@ k_outlier_scan(const T* __restrict__ vol, VolDesc vd, const ChunkGeom* geom, uin
       flag = fabs(diff) > tol;
     }
     if (PASS == 0) {
-      cnt += (uint32_t)__popcll(__ballot(flag));
+      const unsigned long long fl = __ballot(flag);
+      if (lane == 0)
+        b.maskGE[c * b.wordStride + w] = fl;
+      cnt += (uint32_t)__popcll(fl);
       if (flag) {
         const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(diff));
         best = key > best ? key : best;
