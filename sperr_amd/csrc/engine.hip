@@ -504,6 +504,7 @@ struct Engine {
   hipStream_t outlQ[kSubStreams] = {};      //   (one per sub-batch; outlQ[0] == outl; a priority of their own: init_handles)
   hipStream_t sideQ[kSubStreams] = {};      // the encoder's census beside a part's pyramid (normal priority)
   hipEvent_t evOutl[kSubStreams] = {}, evOutlFork[kSubStreams] = {};   // (per sub-batch)
+  hipEvent_t evPweFork = nullptr;          // encoder, point-wise error mode: the outlier stage's first half starts beside the 3D coder
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
@@ -512,6 +513,8 @@ struct Engine {
   DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
   DevBuf decBox[kSubStreams];              //   ... and the coarser levels' box of a sub-batch with outlier streams
   uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
+  void* pweHost = nullptr;                 // pinned: the outlier stage's first read-back (a copy into pageable memory
+  size_t pweHostBytes = 0;                 //   would hold the host until the stream gets there: compress_impl)
   hipEvent_t liveEv[kSubStreams][kLiveSlots] = {};
   DevBuf slice2d;                           // 2D slices: lists and masks of the 2D coder
   DevBuf wideScratch;                       // 64-bit retry of a batch whose coder arrays lay over the chunk buffer
@@ -541,9 +544,16 @@ struct Engine {
       ds(sideQ[q]);
       de(evOutl[q]);
       de(evOutlFork[q]);
+      if (q == 0)
+        de(evPweFork);
       if (liveHost[q])
         (void)hipHostFree(liveHost[q]);
       liveHost[q] = nullptr;
+      if (q == 0 && pweHost) {
+        (void)hipHostFree(pweHost);
+        pweHost = nullptr;
+        pweHostBytes = 0;
+      }
       for (int k = 0; k < kLiveSlots; k++)
         de(liveEv[q][k]);
     }
@@ -585,6 +595,8 @@ struct Engine {
     for (uint32_t q = 0; q < kSubStreams; q++) {
       HIP_CHECK(hipEventCreateWithFlags(&evOutl[q], hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&evOutlFork[q], hipEventDisableTiming));
+      if (q == 0)
+        HIP_CHECK(hipEventCreateWithFlags(&evPweFork, hipEventDisableTiming));
     }
     for (uint32_t q = 0; q < kSubStreams; q++) {
       HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&liveHost[q]), kLiveSlots * sizeof(uint32_t), hipHostMallocDefault));
@@ -961,7 +973,9 @@ bool carve_enc_coder(Arena& first, Arena* second, const ShapePlan& P, uint32_t B
 }
 
 // carve the arrays of one batch out of the arena; returns false when it does not fit
-bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, EncBatchBufs& o)
+// alias: the coder's arrays over the chunk buffer (not in point-wise error mode, whose outlier stage writes the chunk buffer
+// while the coder runs: compress_impl)
+bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, EncBatchBufs& o, bool alias = true)
 {
   const size_t N = P.N, Npad = round_up(N, 256);
   const size_t nn = P.dtree.nnodes;
@@ -1006,7 +1020,7 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   {
     Arena over;
     over.base = reinterpret_cast<char*>(o.vals);
-    over.cap = aliasEnv ? Npad * B * sizeof(double) : 0;
+    over.cap = (aliasEnv && alias) ? Npad * B * sizeof(double) : 0;
     const size_t before = A.used;
     if (!carve_enc_coder(over, &A, P, B, e))
       return false;
@@ -1051,18 +1065,18 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
 // bytes carve_enc takes for a batch of B chunks.  Probed with the batch's own B: which coder arrays
 // find room over the chunk buffer (carve_enc_coder, first fit) depends on the 256-byte rounding of
 // B arrays, so B times the one-chunk figure can fall short for small chunks.
-size_t enc_bytes_for(const ShapePlan& P, uint32_t B, uint64_t raw_budget)
+size_t enc_bytes_for(const ShapePlan& P, uint32_t B, uint64_t raw_budget, bool alias = true)
 {
   Arena probe;
   probe.base = reinterpret_cast<char*>(uintptr_t(4096));  // never dereferenced: size probe only
   probe.cap = ~size_t(0) / 2;
   EncBatchBufs tmp;
-  carve_enc(probe, P, std::max<uint32_t>(B, 1), raw_budget, tmp);
+  carve_enc(probe, P, std::max<uint32_t>(B, 1), raw_budget, tmp, alias);
   return probe.used;
 }
-size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget)
+size_t enc_bytes_per_chunk(const ShapePlan& P, uint64_t raw_budget, bool alias = true)
 {
-  return enc_bytes_for(P, 1, raw_budget);
+  return enc_bytes_for(P, 1, raw_budget, alias);
 }
 
 int reset_enc_pass(hipStream_t st, const EncBatchBufs& bb, uint32_t B)
@@ -1296,7 +1310,7 @@ struct HostMarks {
 
 // PWE mode (src/SPECK_FLT.cpp:280-281): q = 1.5 tol for every chunk; chunks whose largest
 // coefficient needs more than 32 bits are flagged for the 64-bit pass (SPECK_FLT.cpp:324-337)
-int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol)
+int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol, bool* anyWide = nullptr)
 {
   EncBuffers& e = bb.eb;
   std::vector<CoderState> hc(nb);
@@ -1313,6 +1327,8 @@ int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol)
     if (!(m < 9.3e18))
       return -1;   // llrint would raise FE_INVALID (SPECK_FLT.cpp:325-327)
     c.need_retry = std::llrint(m) > (long long)0xffffffffll ? 1u : 0u;
+    if (anyWide && c.need_retry)
+      *anyWide = true;   // (this mode chooses the width before coding: nothing else sets the flag, k_enc_finalize)
   }
   HIP_CHECK(hipMemcpyAsync(e.cst, hc.data(), nb * sizeof(CoderState), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));
@@ -1349,13 +1365,24 @@ void speck1d_level_offsets(OutlierBufs& ob, uint32_t N, uint64_t most)
 // PWE mode, after the integer coder (src/SPECK_FLT.cpp:461-486): rebuild the values the decoder
 // will see (inverse quantiser + inverse transform, in the chunk buffer), compare them with the
 // conditioned input, and code every error above the tolerance with the 1D coder.
+// The stage in two halves (round 5): `begin` -- the reconstruction, the first outlier pass and its read-back, enqueued,
+// not waited for -- needs nothing of the 3D coder, only the quantiser's coefficients, so it can run on a stream of its
+// own BESIDE the coder (compress_impl); `finish` waits for it and does the rest.
+struct PweStage {
+  OutlierBufs ob;
+  std::vector<OutlierChunk> hoc;
+  std::vector<ChunkGeom> bricks;
+  HostMarks hm;
+};
 template <typename T>
-int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
-                      const T* d_src, VolDesc vd, const uint32_t cd[3], double tol,
-                      uint64_t* d_lens2, PweKeepList& keep, bool anyWide)
+int pwe_stage_begin(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                    const T* d_src, VolDesc vd, const uint32_t cd[3], double tol, bool anyWide, PweStage& S)
 {
   EncBuffers& e = bb.eb;
-  HostMarks hm;
+  HostMarks& hm = S.hm;
+  OutlierBufs& ob = S.ob;
+  std::vector<OutlierChunk>& hoc = S.hoc;
+  std::vector<ChunkGeom>& bricks = S.bricks;
   hm.mark("(3D coder done)", st);
   // What the decoder will reconstruct, in the conditioned domain (src/SPECK_FLT.cpp:461-486).  Round 5: by the decoder's
   // own kernels where the plan allows it -- the coarser levels in a compact buffer of their box, dequantising as they
@@ -1363,7 +1390,7 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   // volume of bricks (a chunk's offset rides in org[0]; no mean added) -- instead of an inverse quantiser pass and
   // fifteen per-axis passes over the whole chunk (14.9 of the 56 ms a 1024^3 volume took to compress in this mode).
   static const bool fusedEnv = !(tune_getenv("SPERR_HIP_PWE_FUSED_INV") && atoi(tune_getenv("SPERR_HIP_PWE_FUSED_INV")) == 0);
-  std::vector<ChunkGeom> bricks(nb);   // (lives until the stage's next wait for the stream)
+  bricks.assign(nb, ChunkGeom{});   // (lives until the stage's next wait for the stream)
   const bool fused = fusedEnv && !anyWide && fuse_xyz(P) && plan_fusable(P) && P.fwd.size() >= 3 &&
                      (uint64_t)nb * bb.valsStride <= 0xffffffffull;
   if (fused) {
@@ -1421,7 +1448,6 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
     }
   }
   hm.mark("inverse path", st);
-  OutlierBufs ob;
   memset(&ob, 0, sizeof(ob));
   ob.nchunks = nb;
   ob.N = P.N;
@@ -1448,9 +1474,33 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   ob.kStride = 1;
   if (launch_outlier_scan<T>(st, 0, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
     return -1;
-  std::vector<OutlierChunk> hoc(nb);
-  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
+  hoc.assign(nb, OutlierChunk{});
+  {   // (into pinned memory: the call returns at once and the 3D coder can be enqueued meanwhile)
+    const size_t bytes = nb * sizeof(OutlierChunk);
+    if (E.pweHostBytes < bytes) {
+      if (E.pweHost)
+        (void)hipHostFree(E.pweHost);
+      E.pweHost = nullptr;
+      E.pweHostBytes = 0;
+      HIP_CHECK(hipHostMalloc(&E.pweHost, round_up(bytes, 4096), hipHostMallocDefault));
+      E.pweHostBytes = round_up(bytes, 4096);
+    }
+    HIP_CHECK(hipMemcpyAsync(E.pweHost, ob.oc, bytes, hipMemcpyDeviceToHost, st));
+  }
+  return 0;
+}
+
+template <typename T>
+int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                     const T* d_src, VolDesc vd, const uint32_t cd[3], double tol,
+                     uint64_t* d_lens2, PweKeepList& keep, PweStage& S)
+{
+  EncBuffers& e = bb.eb;
+  HostMarks& hm = S.hm;
+  OutlierBufs& ob = S.ob;
+  std::vector<OutlierChunk>& hoc = S.hoc;
   HIP_CHECK(hipStreamSynchronize(st));
+  memcpy(hoc.data(), E.pweHost, nb * sizeof(OutlierChunk));
   hm.mark("outlier pass 0", st);
   bool any = false;
   for (auto& o : hoc) {
@@ -1557,6 +1607,18 @@ int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBuf
   HIP_CHECK(hipStreamSynchronize(st));   // off2 goes out of scope
   hm.mark("stream out", st);
   return 0;
+}
+
+template <typename T>
+int pwe_outlier_stage(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs& bb, uint32_t nb,
+                      const T* d_src, VolDesc vd, const uint32_t cd[3], double tol,
+                      uint64_t* d_lens2, PweKeepList& keep, bool anyWide)
+{
+  PweStage S;
+  return pwe_stage_begin<T>(st, E, P, bb, nb, d_src, vd, cd, tol, anyWide, S) ||
+                 pwe_stage_finish<T>(st, E, P, bb, nb, d_src, vd, cd, tol, d_lens2, keep, S)
+             ? -1
+             : 0;
 }
 
 // SPERR_HIP_SLICE_MIXED=0: slices are coded by k_speck2d's quadtree walk (one workgroup) instead of
@@ -1767,7 +1829,11 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     hipStream_t ss = sideBySide ? E.sub[gi % kSubStreams] : st;
     ShapePlan* P = groupPlan[gi];
     const uint64_t raw_budget = (uint64_t)(bpp * (double)P->N);  // SPECK_FLT.cpp:491
-    const size_t per = enc_bytes_per_chunk(*P, raw_budget);
+    // (point-wise error mode: the coder's arrays get memory of their own -- 127 MB more per 256^3 chunk --, so that the
+    //  outlier stage's reconstruction can be written into the chunk buffer while the coder runs, see below)
+    static const bool pweOverlapEnv0 = !(tune_getenv("SPERR_HIP_PWE_OVERLAP") && atoi(tune_getenv("SPERR_HIP_PWE_OVERLAP")) == 0);
+    const bool encAlias = !(mode == 3 && pweOverlapEnv0 && !sideBySide);
+    const size_t per = enc_bytes_per_chunk(*P, raw_budget, encAlias);
     size_t fr = 0, tot = 0;
     HIP_CHECK(hipMemGetInfo(&fr, &tot));
     const size_t budgetBytes = arena_budget(E.arena.n, fr);
@@ -1775,7 +1841,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
     B = std::min<uint32_t>(B, 256);
     if (sideBySide)
       B = (uint32_t)g.second.size();
-    else if (E.arena.ensure(std::max((size_t)B * per, enc_bytes_for(*P, B, raw_budget)) + 4096))
+    else if (E.arena.ensure(std::max((size_t)B * per, enc_bytes_for(*P, B, raw_budget, encAlias)) + 4096))
       return -1;
     const uint32_t cd[3] = {P->dims[0], P->dims[1], P->dims[2]};
     for (size_t b0 = 0; b0 < g.second.size(); b0 += B) {
@@ -1784,7 +1850,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       A.base = static_cast<char*>(E.arena.p) + (sideBySide ? groupOff[gi] : 0);
       A.cap = E.arena.n - (sideBySide ? groupOff[gi] : 0);
       EncBatchBufs bb;
-      if (!carve_enc(A, *P, nb, raw_budget, bb))
+      if (!carve_enc(A, *P, nb, raw_budget, bb, encAlias))
         return -1;
       if (bb.aliased)
         g_dbg_counter[1]++;
@@ -1816,7 +1882,8 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         return -1;
       if (mode == 2 && psnr_q_search(ss, *P, bb, nb, quality))
         return -1;
-      if (mode == 3 && pwe_q_setup(ss, bb, nb, quality))
+      bool pweWide = false;
+      if (mode == 3 && pwe_q_setup(ss, bb, nb, quality, &pweWide))
         return -1;
       if (launch_quantize(ss, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
@@ -1824,6 +1891,22 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       // (only now: the coder's arrays may lie over the chunk buffer the quantiser has just read)
       if (reset_enc_pass(ss, bb, nb))
         return -1;
+      // Point-wise error mode: what the decoder will reconstruct, and which samples miss the tolerance, follows from
+      // the quantiser's coefficients alone -- the first half of the outlier stage (reconstruction, first outlier
+      // pass) runs on a stream of its own BESIDE the 3D coder (round 5; behind it, one stream, before: the 1D coder
+      // alone is 3.2 of the 11.8 ms a batch of eight chunks took).  Not when the coder's arrays lie over the chunk
+      // buffer the reconstruction is written to, and given up when a chunk turns out to need 64-bit coefficients.
+      static const bool pweOverlapEnv = !(tune_getenv("SPERR_HIP_PWE_OVERLAP") && atoi(tune_getenv("SPERR_HIP_PWE_OVERLAP")) == 0);
+      PweStage pweSt;
+      hipStream_t pweQ = E.outlQ[1];
+      const bool pweEarly = mode == 3 && pweOverlapEnv && !bb.aliased && !sideBySide && !pweWide && pweQ != nullptr &&
+                            E.evPweFork != nullptr;
+      if (pweEarly) {
+        HIP_CHECK(hipEventRecord(E.evPweFork, ss));
+        HIP_CHECK(hipStreamWaitEvent(pweQ, E.evPweFork, 0));
+        if (pwe_stage_begin<T>(pweQ, E, *P, bb, nb, d_src, vd, cd, quality, false, pweSt))
+          return -1;
+      }
 
       // ---- integer coder, 32-bit coefficients ----
       const bool quadWalkGroup = slice && !(P->ht.flags & spk::kTree2D);   // (SPERR_HIP_SLICE_MIXED=0)
@@ -1870,6 +1953,10 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
                  d_lens, P->N, 0);
 
+      // (point-wise error mode: the outlier stage's second half -- its waits are for its own stream -- while the plane
+      //  loop above runs)
+      if (pweEarly && pwe_stage_finish<T>(pweQ, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep, pweSt))
+        return -1;
       // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
       if (sideBySide) {   // (the read-back is looked at once every group is enqueued)
         std::unique_ptr<LateGroup> L(new LateGroup{P, bb, nb, wblocks, raw_budget, ss, std::vector<CoderState>(nb),
@@ -1888,6 +1975,10 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
         // their own for those arrays (the 64-bit magnitudes live in the chunk buffer)
         if (bb.aliased && wide_retry_prepare<T>(ss, E, *P, bb, nb, cd, d_src, vd, orgAligned, mode == 2))
           return -1;
+        if (pweEarly) {   // (cannot be: this mode knows the width before it codes, pwe_q_setup)
+          fprintf(stderr, "[sperr_hip] a chunk asked for 64-bit coefficients after its outlier stage had run\n");
+          return -1;
+        }
         // fixed rate: a finer q for the flagged chunks; PSNR: the same q, coefficients need 64 bits
         if ((rate ? launch_make_q_wide(ss, nb, e.cst) : launch_mark_wide(ss, nb, e.cst)) ||
             reset_enc_pass(ss, bb, nb))
@@ -1910,9 +2001,12 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
                  e.stream, e.streamStride, bb.gids, static_cast<uint8_t*>(E.slots.p), d_slotOff,
                  d_lens, P->N, 1);
       }
-      if (mode == 3 &&
-          pwe_outlier_stage<T>(ss, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep,
-                               retry))   // (a chunk that was coded again has 64-bit coefficients)
+      if (mode == 3 && pweEarly) {
+        // (done above, beside the coder)
+      }
+      else if (mode == 3 &&
+               pwe_outlier_stage<T>(ss, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep,
+                                    retry))   // (a chunk that was coded again has 64-bit coefficients)
         return -1;
     }
   

@@ -322,7 +322,9 @@ def test_retry_of_a_batch_whose_coder_arrays_lay_over_the_chunk_buffer(eng, orac
         if mode == 2:
             assert want[28 + 17] > 32, "the PSNR case no longer needs the 64-bit pass"
         assert bytes(eng.compress(cuda(v), (64, 64, 64), q, mode=mode).cpu().numpy()) == want, mode
-        assert eng.lib.sperrhip_debug_counter(0) > redo1, mode
+        if mode != 3:   # (round 5: in point-wise error mode the coder's arrays have memory of their own -- its outlier
+            #            stage writes the chunk buffer while the coder runs --, so its retry transforms nothing again)
+            assert eng.lib.sperrhip_debug_counter(0) > redo1, mode
         dev = cuda(np.frombuffer(want, dtype=np.uint8))
         assert np.array_equal(bits(eng.decompress(dev, False).cpu().numpy()), bits(oracle.decomp_3d(want, False)))
 
