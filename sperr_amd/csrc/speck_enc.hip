@@ -512,11 +512,33 @@ __global__ void __launch_bounds__(kThreads) k_census(EncBuffers b, int maxPlanes
           zeroM++;
         else
           atomicAdd(&hist[wave][0][m[k] + 1], bp[k] > m[k] ? 0x10001u : 1u);
-        if (bp[k] < 0)
-          zeroB++;
-        else
-          atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
       }
+    // (the kernel is bound by its LDS atomics: two samples side by side are children of one set nearly everywhere and
+    //  were born on the same plane -- one atomic for the pair)
+#pragma unroll
+    for (int k = 0; k < kPixPer; k += 2) {
+      const bool a = i0 + k < n, c2 = i0 + k + 1 < n;
+      if (a && c2 && bp[k] == bp[k + 1]) {
+        if (bp[k] < 0)
+          zeroB += 2;
+        else
+          atomicAdd(&hist[wave][1][bp[k] + 1], 2u);
+      }
+      else {
+        if (a) {
+          if (bp[k] < 0)
+            zeroB++;
+          else
+            atomicAdd(&hist[wave][1][bp[k] + 1], 1u);
+        }
+        if (c2) {
+          if (bp[k + 1] < 0)
+            zeroB++;
+          else
+            atomicAdd(&hist[wave][1][bp[k + 1] + 1], 1u);
+        }
+      }
+    }
   }
   uint32_t z = zeroM | (zeroB << 16);       // both at most 1024 per wavefront
   for (int d = 32; d > 0; d >>= 1)
