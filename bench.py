@@ -143,6 +143,33 @@ def run_host_path(eng, vol, chunks, bpp, devices, reps, dev_stream, dev_out, mod
     return res
 
 
+def compact_line(line):
+    """The bench line without its prose: "what" strings dropped, other long strings cut, bookkeeping that a
+    reader of the driver's record does not need (`traffic_from` beyond its file, `farm_threads.host`) folded."""
+    def strip(o, depth=0):
+        if isinstance(o, dict):
+            out = {}
+            for k, v in o.items():
+                if k == "what":
+                    continue
+                out[k] = v if k == "config" else strip(v, depth + 1)   # (config.workload names the workload: whole)
+            return out
+        if isinstance(o, list):
+            return [strip(v, depth + 1) for v in o]
+        if isinstance(o, str) and len(o) > 120 and depth > 0:
+            return o[:117] + "..."
+        return o
+    c = strip(line)
+    rf = c.get("roofline") or {}
+    if isinstance(rf.get("traffic_from"), dict):
+        rf["traffic_from"] = rf["traffic_from"].get("file") or rf["traffic_from"].get("why", "")[:60]
+    ft = c.get("farm_threads")
+    if isinstance(ft, dict):
+        c["farm_threads"] = {k: (v.get("threads_total") if isinstance(v, dict) and "threads_total" in v else v)
+                             for k, v in ft.items() if k != "host"}
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +187,8 @@ def main():
     ap.add_argument("--no-ragged", action="store_true", help="skip the volume the chunk size does not divide")
     ap.add_argument("--ragged-size", type=int, default=1000)
     ap.add_argument("--no-other-modes", action="store_true", help="skip the point-wise error run and the 2D slice")
+    ap.add_argument("--verbose", action="store_true", help="the JSON line with its descriptions (about 12 KB)")
+    ap.add_argument("--full-out", default="", help="write the verbose record to this file as well")
     args = ap.parse_args()
 
     import torch
@@ -591,7 +620,13 @@ def main():
         "ragged_volume": ragged,
         "other_modes": other,
     }
-    print(json.dumps(line))
+    # ONE line either way.  The default is the compact one (under 4 KB: the driver's record keeps the tail of
+    # stdout, and round 5's 12 KB line lost its host_path* fields there): every number, none of the prose --
+    # --verbose prints the line with its "what" / "sample" descriptions, --full-out writes that one to a file.
+    if args.full_out:
+        with open(args.full_out, "w") as f:
+            json.dump(line, f, indent=1)
+    print(json.dumps(line if args.verbose else compact_line(line), separators=(",", ":")))
     if world > 1:
         dist.destroy_process_group()
 

@@ -1924,8 +1924,14 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       static const bool boundEnv = !(tune_getenv("SPERR_HIP_ENC_BOUND") && atoi(tune_getenv("SPERR_HIP_ENC_BOUND")) == 0);
       if (boundEnv && !quadWalkGroup) {
         ph.d_bound = A.take<uint32_t>(64);
-        ph.h_bound = E.liveHost[gi % kSubStreams];
-        ph.evBound = E.liveEv[gi % kSubStreams][0];
+        // (a pinned word pair and an event per GROUP: groups gi and gi + kSubStreams share a stream, and every head
+        //  is enqueued before any plane loop reads its bounds back -- a ragged volume has up to 4 parts + 7 border
+        //  shapes = 11 groups.  Past kSubStreams * kLiveSlots / 2 groups: all planes are launched)
+        const uint32_t lane = gi % kSubStreams, turn = gi / kSubStreams;
+        if (turn < (uint32_t)kLiveSlots / 2) {
+          ph.h_bound = E.liveHost[lane] + 2 * turn;
+          ph.evBound = E.liveEv[lane][turn];
+        }
         if (!ph.d_bound)
           ph.h_bound = nullptr;
       }
@@ -2245,10 +2251,12 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.refNPlanes = 0;
   d.refPlaneStride = d.wordTopStride = 0;
   if (refNPlanes) {
-    d.refNPlanes = refNPlanes;
-    d.refPlaneStride = (size_t)refNPlanes * d.maskPixStride;
+    // (round 6: the planes live in the coefficient array -- 32 plane slots x 8 bytes per mask word = the 64 x 4 bytes
+    //  of its coefficients, speck_dec.h; Npad is a multiple of 512: whole tiles of eight mask words)
+    d.refNPlanes = std::min<uint32_t>(refNPlanes, 32u);
+    d.refPlaneStride = d.coefStride / 2;
     d.wordTopStride = round_up(d.maskPixStride, 64);
-    TAKE(d.refPlanes, uint64_t, d.refPlaneStride * B);
+    d.refPlanes = reinterpret_cast<uint64_t*>(o.coef32);
     TAKE(d.refMask, uint64_t, d.maskPixStride * B);
     TAKE(d.wordTop, uint8_t, d.wordTopStride * B);
   }

@@ -75,6 +75,12 @@ __host__ __device__ inline uint32_t coef_scheme_mag(uint32_t stored, bool two)
   return (two && t) ? 2u * t + 1u : t;
 }
 
+// word `w` of plane `p` inside a chunk's plane storage (DecBuffers::refPlanes): see there
+__host__ __device__ inline size_t ref_plane_word(uint32_t p, uint32_t w)
+{
+  return ((size_t)(w >> 3) << 8) + ((size_t)p << 3) + (size_t)(w & 7u);
+}
+
 struct DecBuffers {
   spk::Tree tree;
   uint32_t nchunks;
@@ -98,8 +104,16 @@ struct DecBuffers {
   // coefficient once after the last plane (src/SPECK_INT.cpp:359-469: found at p0, refined down to q ->
   // magnitude bits + 2^(q-1) - 1).  refMask: the candidates that got a bit in a pass the stream's end cut
   // short.  nullptr: k_ref_apply2 updates the coefficients plane by plane (64-bit coefficients, the 2D walk).
-  uint64_t* refPlanes;
-  size_t refPlaneStride;       // words per chunk (refNPlanes x maskPixStride)
+  //
+  // Round 6: the planes take NO memory of their own -- they live in the coefficient array, which nobody reads or
+  // writes before k_ref_assemble: 32 planes x 8 bytes per mask word are exactly the 64 x 4 bytes of the word's
+  // coefficients.  Layout (ref_plane_word below): tiles of eight mask words, a tile = 32 plane slots of eight
+  // consecutive words = 2 KB = the coefficients of those eight mask words -- k_ref_deposit's eight neighbouring
+  // threads store 64 contiguous bytes, and k_ref_assemble, whose wavefront takes exactly such a tile per round,
+  // reads the tile's plane words (512 contiguous bytes per eight planes) into registers before it writes the
+  // tile's 512 coefficients over them.  64 MB less per 256^3 chunk in flight (371 -> 307 MB).
+  uint64_t* refPlanes;         // == coef (32-bit coefficients), or nullptr
+  size_t refPlaneStride;       // 8-byte words per chunk (coefStride / 2)
   uint32_t refNPlanes;
   uint64_t* refMask;
   uint8_t* wordTop;

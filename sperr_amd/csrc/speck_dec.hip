@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_count(DecBuffers b, int p)
         // bits of the older samples when there were any (k_ref_deposit(p + 1) wrote it), else nothing yet
         const uint64_t found = (fresh | ls) & ~sig;
         if (found && (uint32_t)(p + 1) < b.refNPlanes) {
-          uint64_t* pw = b.refPlanes + c * b.refPlaneStride + (size_t)(p + 1) * b.maskPixStride + wi;
+          uint64_t* pw = b.refPlanes + c * b.refPlaneStride + ref_plane_word((uint32_t)(p + 1), wi);
           *pw = sig ? (*pw | found) : found;
           if (!sig)
             b.wordTop[c * b.wordTopStride + wi] = (uint8_t)(p + 2);
@@ -3196,10 +3196,16 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
   __shared__ uint32_t sh_stay[kTabThreads], sh_ex[kTabThreads];
   const uint32_t cur = s.cur, nx = cur ^ 1u;
-  const uint32_t n = skip ? 0u : s.listLen[cur][l];
+  // A phase that ran into the stream's end was the chunk's last (SPECK_INT.cpp:200-201): nobody reads its lists or
+  // its significance bits again (the bits are cleared before every decode).  Round 6: without this test the planes
+  // on which most chunks of a batch end -- 17 and 19 of the bench volume's 20 -- spent 1.1 and 1.4 ms here: a chunk
+  // whose stream ends inside k_lis_l0's list leaves the 4x4x4 sets' list, 10^5 entries, to this kernel
+  // (k_lis_l1 returns at once, k_lis_hi finds the end), one workgroup copying it for nothing.
+  const bool ended = s.hiEnd >= s.avail;
+  const uint32_t n = (skip || ended) ? 0u : s.listLen[cur][l];
   const uint32_t lOff = b.levelOff[l];
-  const uint64_t* list = b.lis[cur] + c * b.lisStride;
-  uint64_t* keep = b.lis[nx] + c * b.lisStride + lOff;
+  const uint64_t* __restrict__ list = b.lis[cur] + c * b.lisStride;
+  uint64_t* __restrict__ keep = b.lis[nx] + c * b.lisStride + lOff;
   uint64_t* sigbits = b.sigbits + c * b.sigbitsStride;
   const int tid = threadIdx.x;
   uint32_t carry = 0;
@@ -3226,11 +3232,24 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
     sh_ex[tid] = ex;
     __syncthreads();
     const uint32_t nHere = min(n - base, (uint32_t)kTabThreads * 32u);
-#pragma unroll 4
-    for (uint32_t i = (uint32_t)tid; i < nHere; i += kTabThreads) {
-      const uint32_t st = sh_stay[i >> 5], bit = i & 31u;
-      if ((st >> bit) & 1u)
-        keep[sh_ex[i >> 5] + (uint32_t)__popc(st & ((1u << bit) - 1u))] = list[lOff + base + i];
+    // (eight entries per thread in flight: with a load behind every conditional store the loop was a chain of 32
+    //  dependent round trips per 8192 entries, 90 us a round -- the 8x8x8 sets' list of plane 14 took 0.37 ms)
+    for (uint32_t i0 = (uint32_t)tid; i0 < nHere; i0 += 8u * kTabThreads) {
+      uint64_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = i0 + (uint32_t)k * kTabThreads;
+        v[k] = i < nHere ? list[lOff + base + i] : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t i = i0 + (uint32_t)k * kTabThreads;
+        if (i >= nHere)
+          break;
+        const uint32_t st = sh_stay[i >> 5], bit = i & 31u;
+        if ((st >> bit) & 1u)
+          keep[sh_ex[i >> 5] + (uint32_t)__popc(st & ((1u << bit) - 1u))] = v[k];
+      }
     }
     carry += total;
   }
@@ -3548,7 +3567,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
   __shared__ uint32_t sm[kThreads / 64 + 1];
   const uint32_t nw = (b.tree.nvals + 63) / 64;
   const uint64_t* words = b.stream + c * b.streamStride;
-  uint64_t* plane = b.refPlanes + c * b.refPlaneStride + (size_t)p * b.maskPixStride;
+  uint64_t* planes = b.refPlanes + c * b.refPlaneStride;
   const uint64_t avail = s.avail, pos0 = s.pos;
   const bool partial = pos0 + (uint64_t)s.nRef > avail;   // the stream ends inside this pass
   for (uint32_t tile = blockIdx.x; tile < b.nPixTiles; tile += gridDim.x) {
@@ -3572,7 +3591,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
       if (cnt != 64)   // (64: every sample of the word is a candidate, the bits as they come)
         spread_under_mask(sig, res, got);
     }
-    plane[wi] = res;   // (always: the word is valid from the plane of its first significant sample on)
+    planes[ref_plane_word((uint32_t)p, wi)] = res;   // (always: the word is valid from the plane of its first significant sample on)
     if (partial)
       b.refMask[c * b.maskPixStride + wi] = got;   // the candidates that did get a bit
   }
@@ -3583,7 +3602,9 @@ __global__ void __launch_bounds__(kThreads) k_ref_deposit(DecBuffers b, int p)
 // (1.5 * 2^p0 - 1, src/SPECK_INT.cpp:462-468; plane 0 adds the bare bit, :440-447).  A wavefront takes
 // four mask words per round, lane = sample: the plane words are wave-uniform (scalar loads) and a sample's
 // bit of one is its lane's bit -- a select and a shift-or per plane.  Samples that are not significant get
-// their zero here: the coefficient array is not cleared beforehand.
+// their zero here: the coefficient array is not cleared beforehand.  Round 6: IN PLACE -- the plane words of a
+// round's eight mask words are the 2 KB its 512 coefficients go to (DecBuffers::refPlanes); every plane word of
+// the round is in registers (pv[]) before the round's first store, and no other wavefront touches the tile.
 __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
 {
   const uint32_t c = blockIdx.y;
@@ -3657,7 +3678,7 @@ __global__ void __launch_bounds__(kThreads) k_ref_assemble(DecBuffers b)
         pv[g] = 0ull;
         const int pl = pLow + g * 8 + (int)myPs;
         if (g * 8 < nPl)   // (uniform)
-          pv[g] = pl < mytop ? planes[(size_t)pl * b.maskPixStride + w0 + myU] : 0ull;
+          pv[g] = pl < mytop ? planes[ref_plane_word((uint32_t)pl, w0 + myU)] : 0ull;   // (w0 is a multiple of eight: the round is one tile)
       }
       // word by word, the planes the word has (the kernel is bound by its vector instructions: a word without a
       // significant sample -- half of the bench volume's -- costs a scalar branch here and one below)
