@@ -120,6 +120,62 @@ __device__ __forceinline__ void oct_load(const Tree& t, const Grid& g, const Roo
 }
 
 // ------------------------------------------------------------------------------------------
+// Nodes of any other grid (chunks whose extents are not powers of two): up to eight children by ORDINAL
+// (spk::KidBox: the non-empty children of a set are a box of 1 or 2 intervals per axis), everything in
+// arrays that only ever see constant indices -- fully unrolled loops guarded by `j < n` -- so they stay in
+// registers.  Until round 6 these nodes went through spk::Kids / spk::KidInfo, which node_kids fills with a
+// running index: 156 bytes of private segment (scratch memory) in k_pyramid and k_split_emit, set up for every
+// wavefront whether its nodes take this path or not.
+// ------------------------------------------------------------------------------------------
+struct KidRegs {
+  KidBox kb;        // the children by ordinal (kid_index / kid_packed / kid_pixel_raster, speck_tree.h)
+  int n;            // number of (non-empty) children
+  bool deepest;     // the children are single samples of the deepest depth
+  uint32_t pixels;  // bit j: child j is a single sample
+  int m[8];         // msb of each child (-1 past the last)
+  uint32_t e[8];    // split length of each child set (0 for single samples)
+};
+
+__device__ __forceinline__ uint32_t kid_regs_flat(const Tree& t, const KidRegs& k, int j)
+{
+  uint32_t idx[3];
+  kid_index(k.kb, (uint32_t)j, idx);
+  const Grid& cg = t.grids[k.kb.grid];
+  return cg.nodeOff + (((idx[2] << cg.e[1]) + idx[1]) << cg.e[0]) + idx[0];
+}
+
+__device__ __forceinline__ void kid_regs_load(const Tree& t, const Node& nd, const int8_t* M, const uint32_t* E,
+                                              const int8_t* msb, KidRegs& k)
+{
+  const Grid& g = t.grids[nd.grid];
+  const Root& r = t.roots[g.root];
+  kid_box(t, nd, k.kb);
+  k.n = (int)k.kb.nk;
+  k.deepest = g.depth + 1 == r.Dmax;
+  k.pixels = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    k.m[j] = -1;
+    k.e[j] = 0;
+    if (j < k.n) {
+      uint32_t idx[3];
+      kid_index(k.kb, (uint32_t)j, idx);
+      const uint32_t cnt = axis_len(r.len[0], k.kb.e[0], idx[0]) * axis_len(r.len[1], k.kb.e[1], idx[1]) *
+                           axis_len(r.len[2], k.kb.e[2], idx[2]);
+      const bool pixel = cnt == 1;
+      k.pixels |= (pixel ? 1u : 0u) << j;
+      if (k.deepest)
+        k.m[j] = msb[pixel_raster(t, r, k.kb.e, idx)];
+      else {
+        const uint32_t fid = kid_regs_flat(t, k, j);
+        k.m[j] = M[fid];
+        k.e[j] = pixel ? 0u : E[fid];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_pyramid: one thread per node of the grids at one depth (deepest first)
 // ------------------------------------------------------------------------------------------
 // h[bin] += 1 for every lane with bin >= 0 (bin < 64); returns the lane's rank inside its bin.  The lanes of a
@@ -150,6 +206,9 @@ __device__ __forceinline__ uint32_t wave_hist_add(uint32_t* h, int bin)
 }
 
 // (returns the plane at which the node splits when it is a set with a significant sample, else -1)
+// (ANY: the tree has grids that are not octrees -- spk::kTreeAllOct unset; the `false` instantiation, what every
+//  power-of-two chunk runs, does not carry the general path's registers: 56 against 67)
+template <bool ANY>
 __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uint32_t id)
 {
   const Tree& t = b.tree;
@@ -212,6 +271,8 @@ __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uin
     }
     return m;
   }
+  if constexpr (!ANY)
+    return -1;   // (not reached: every grid is an octree)
   const bool isset = q.count > 1 || g.depth == 0;
   if (!isset) {
     const int e[3] = {g.e[0], g.e[1], g.e[2]};
@@ -219,30 +280,42 @@ __device__ __forceinline__ int pyramid_node(const EncBuffers& b, uint32_t c, uin
     M[id] = msb[pixel_raster(t, r, e, ii)];
     return -1;
   }
-  Kids k;
-  node_kids(t, nd, k);
-  KidInfo ki;
-  kids_info(t, nd, k, M, E, msb, ki);
+  KidRegs k;
+  kid_regs_load(t, nd, M, E, msb, k);
   int m = -1;
-  for (int j = 0; j < k.n; j++)
-    m = max(m, (int)ki.m[j]);
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    m = max(m, k.m[j]);   // (-1 past the last child)
+  // split_bits (spk, speck_tree.h) and kid_offset in one sweep: koff[child] = where the child's own split starts
+  // inside this node's split (bits of the earlier children + the child's test bit when it is coded): a split
+  // chain's position is then a sum of one word per ancestor instead of a re-evaluation of every ancestor's children
+  uint32_t bits = 0, ko[8];
+  bool found = false;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    ko[j] = 0;
+    if (j < k.n) {
+      const bool coded = found || (j + 1 != k.n);
+      bits += coded ? 1u : 0u;
+      ko[j] = bits;
+      if (!coded || k.m[j] == m) {
+        found = true;
+        bits += ((k.pixels >> j) & 1u) ? 1u : k.e[j];
+      }
+    }
+  }
   M[id] = (int8_t)m;
-  E[id] = m >= 0 ? split_bits(k, ki, m) : 0u;
-  for (int j = 0; j < k.n; j++)
-    if (ki.pixel[j])
-      bplane[kid_raster(t, nd, k, j)] = (int8_t)m;
-  // koff[child] = where the child's own split starts inside this node's split (bits of the
-  // earlier children + the child's test bit when it is coded): a split chain's position is then
-  // a sum of one word per ancestor instead of a re-evaluation of every ancestor's children
+  E[id] = m >= 0 ? bits : 0u;
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (j < k.n && ((k.pixels >> j) & 1u))
+      bplane[kid_pixel_raster(t, nd, k.kb, (uint32_t)j)] = (int8_t)m;
   if (m >= 0 && !k.deepest) {
     uint32_t* koff = b.koff + c * b.nodeStride;
-    for (int j = 0; j < k.n; j++) {
-      if (ki.pixel[j])
-        continue;
-      bool coded;
-      const uint32_t before = kid_offset(k, ki, m, j, coded);
-      koff[kid_flat(t, k, j)] = before + (coded ? 1u : 0u);
-    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (j < k.n && !((k.pixels >> j) & 1u))
+        koff[kid_regs_flat(t, k, j)] = ko[j];
   }
   return m;
 }
@@ -333,6 +406,7 @@ __device__ __forceinline__ void pyramid_leaf4(const EncBuffers& b, uint32_t c, u
 //  150 K workgroups of one node per thread each paid the look-ups of their grid and a histogram's worth of global
 //  atomics on the chunk's few plane counters)
 constexpr int kNodePerMax = 8;
+template <bool ANY>
 __global__ void __launch_bounds__(kNodeBlock)
 k_pyramid(EncBuffers b, const uint32_t* depthBlocks, uint32_t nblk, uint32_t per)
 {
@@ -360,7 +434,7 @@ k_pyramid(EncBuffers b, const uint32_t* depthBlocks, uint32_t nblk, uint32_t per
     const uint32_t blk = depthBlocks[bi];
     if (leaf4_block(b.tree, blk))   // (uniform over the workgroup)
       continue;
-    const int sp = pyramid_node(b, c, blk * kNodeBlock + threadIdx.x);
+    const int sp = pyramid_node<ANY>(b, c, blk * kNodeBlock + threadIdx.x);
     wave_hist_add(h, sp);
   }
   __syncthreads();
@@ -941,9 +1015,12 @@ __global__ void k_bucket_scan(EncBuffers b)
 
 constexpr int kSplitBlocks = 512;
 
+template <bool ANY>
 __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
                                                 uint32_t id, bool have);
 
+// (ANY: see pyramid_node; 73 registers without the general path, 87 with)
+template <bool ANY>
 __global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
 {
   const uint32_t c = blockIdx.y;
@@ -956,10 +1033,11 @@ __global__ void __launch_bounds__(kNodeBlock) k_split_emit(EncBuffers b, int p)
   for (uint32_t k0 = blockIdx.x * kNodeBlock; k0 < cnt; k0 += gridDim.x * kNodeBlock) {
     const uint32_t k = k0 + threadIdx.x;
     const bool have = k < cnt;
-    split_emit_node(b, c, s, p, have ? bucket[k] : 0u, have);
+    split_emit_node<ANY>(b, c, s, p, have ? bucket[k] : 0u, have);
   }
 }
 
+template <bool ANY>
 __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c, EncState& s, int p,
                                                 uint32_t id, bool have)
 {
@@ -1003,11 +1081,11 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
   const Grid& g = t.grids[nd.grid];
   // ---- births first: how many children of this set stay insignificant sets (they get consecutive
   //      slots of the chunk's birth records; one atomic per wavefront claims them)
-  const bool isOct = (g.kind & kGridOct) != 0;
+  const bool isOct = !ANY || (g.kind & kGridOct) != 0;
   const bool isLeafSet = isOct && g.depth + 1 == t.roots[g.root].Dmax;
   OctKids k;
-  Kids kg;
-  KidInfo ki;
+  KidRegs kr;
+  kr.n = 0;
   uint32_t kidlev = 0, slot = 0xff, nborn = 0;
   const uint64_t maskBits = (uint64_t)b.maskWords * 64;
   if (have && isOct && !isLeafSet) {
@@ -1031,23 +1109,24 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
       }
     }
   }
-  else if (have && !isOct) {
-    node_kids(t, nd, kg);
-    kids_info(t, nd, kg, M, E, msb, ki);
-    const NodeGeom q = node_geom(t, nd);
-    kidlev = kid_level(t, nd, q);
+  else if (ANY && have && !isOct) {
+    kid_regs_load(t, nd, M, E, msb, kr);
+    kidlev = kr.kb.kidlev;
     slot = b.levelSlot[kidlev];
     uint64_t q2 = pos;
     bool fnd = false;
-    for (int j = 0; j < kg.n; j++) {
-      const bool coded = fnd || (j + 1 != kg.n);
-      const bool sig = coded ? (ki.m[j] == p) : true;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (j >= kr.n)
+        break;
+      const bool coded = fnd || (j + 1 != kr.n);
+      const bool sig = coded ? (kr.m[j] == p) : true;
       q2 += coded ? 1u : 0u;
       if (sig) {
         fnd = true;
-        q2 += ki.pixel[j] ? 1u : ki.e[j];
+        q2 += ((kr.pixels >> j) & 1u) ? 1u : kr.e[j];
       }
-      else if (!ki.pixel[j] && slot != 0xff && q2 - 1 - baseLIS < maskBits)
+      else if (!((kr.pixels >> j) & 1u) && slot != 0xff && q2 - 1 - baseLIS < maskBits)
         nborn++;
     }
   }
@@ -1129,9 +1208,14 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     put_bits(stream, accpos, acc, nacc, s.budget);
     return;
   }
-  for (int j = 0; j < kg.n; j++) {
-    const bool coded = found || (j + 1 != kg.n);
-    const bool sig = coded ? (ki.m[j] == p) : true;
+  if constexpr (!ANY)
+    return;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (j >= kr.n)
+      break;
+    const bool coded = found || (j + 1 != kr.n);
+    const bool sig = coded ? (kr.m[j] == p) : true;
     if (coded) {
       acc |= (uint64_t)sig << nacc;
       nacc++;
@@ -1139,24 +1223,24 @@ __device__ __forceinline__ void split_emit_node(const EncBuffers& b, uint32_t c,
     }
     if (sig) {
       found = true;
-      if (ki.pixel[j]) {
-        const uint32_t ridx = kid_raster(t, nd, kg, j);
+      if ((kr.pixels >> j) & 1u) {
+        const uint32_t ridx = kid_pixel_raster(t, nd, kr.kb, (uint32_t)j);
         acc |= ((sign[ridx >> 6] >> (ridx & 63)) & 1ull) << nacc;
         nacc++;
         pos++;
       }
       else {  // the child writes its own split; flush what we have and skip over it
         put_bits(stream, accpos, acc, nacc, s.budget);
-        pos += ki.e[j];
+        pos += kr.e[j];
         acc = 0;
         nacc = 0;
         accpos = pos;
       }
     }
-    else if (!ki.pixel[j]) {  // insignificant set: joins LIS[kidlev] in stream order
+    else if (!((kr.pixels >> j) & 1u)) {  // insignificant set: joins LIS[kidlev] in stream order
       const uint64_t rel = pos - 1 - baseLIS;
       if (slot != 0xff && rel < (uint64_t)b.maskWords * 64) {
-        b.bornPacked[c * b.bornStride + kslot] = entry_with_msb(t, pack_node(kid_node(kg, j)), (int)ki.m[j]);
+        b.bornPacked[c * b.bornStride + kslot] = entry_with_msb(t, kid_packed(kr.kb, (uint32_t)j), kr.m[j]);
         b.bornPosLev[c * b.bornStride + kslot] = ((uint64_t)kidlev << 48) | rel;
         kslot++;
         atomic_or64(b.mask + c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6),
@@ -1540,8 +1624,12 @@ int launch_speck_encode_head(hipStream_t stream, const EncBuffers& b, const EncP
     const uint32_t nb = plan.depthBlockOff[d + 1] - plan.depthBlockOff[d];
     if (nb) {
       const uint32_t per = node_blocks_per_group(nb, nc);
-      LAUNCH_K(k_pyramid, dim3((nb + per - 1) / per, nc), dim3(kNodeBlock), 0, stream, b,
-                         plan.d_depthBlocks + plan.depthBlockOff[d], nb, per);
+      if (b.tree.flags & kTreeAllOct)
+        LAUNCH_K(k_pyramid<false>, dim3((nb + per - 1) / per, nc), dim3(kNodeBlock), 0, stream, b,
+                 plan.d_depthBlocks + plan.depthBlockOff[d], nb, per);
+      else
+        LAUNCH_K(k_pyramid<true>, dim3((nb + per - 1) / per, nc), dim3(kNodeBlock), 0, stream, b,
+                 plan.d_depthBlocks + plan.depthBlockOff[d], nb, per);
     }
     if (sideCensus && d == 0) {
       // every sample's birth plane is known now (samples are born at any depth: the roots' trees differ in
@@ -1611,7 +1699,10 @@ int launch_speck_encode_planes(hipStream_t stream, const EncBuffers& b, const En
     LAUNCH_K(k_list_apply, dim3(capped_blocks(b.nListTiles, nc, wideCap), nc), dim3(kThreads), 0, stream, b, p);
     if (b.tree.flags & kTree2D)
       LAUNCH_K(k_enc_iphase, perChunk, dim3(64), 0, stream, b, p);
-    LAUNCH_K(k_split_emit, dim3(capped_blocks(kSplitBlocks, nc, smallCap), nc), dim3(kNodeBlock), 0, stream, b, p);
+    if (b.tree.flags & kTreeAllOct)
+      LAUNCH_K(k_split_emit<false>, dim3(capped_blocks(kSplitBlocks, nc, smallCap), nc), dim3(kNodeBlock), 0, stream, b, p);
+    else
+      LAUNCH_K(k_split_emit<true>, dim3(capped_blocks(kSplitBlocks, nc, smallCap), nc), dim3(kNodeBlock), 0, stream, b, p);
     if (b.nSlots) {
       LAUNCH_K(k_mask_scan, dim3(b.nSlots, nc), dim3(kThreads), 0, stream, b, p);
       LAUNCH_K(k_born_place, dim3(capped_blocks(bornBlocks, nc, smallCap), nc), dim3(kThreads), 0, stream, b, p);

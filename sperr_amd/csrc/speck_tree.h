@@ -57,6 +57,8 @@ constexpr uint8_t kGridOct = 1;
 // folds them into the raster masks word by word instead of scattering them with atomics.
 constexpr uint8_t kGridLeafWord = 2;
 constexpr uint32_t kTree2D = 1;
+constexpr uint32_t kTreeAllOct = 2;   // every grid is an octree (kGridOct): all of a power-of-two chunk's -- the encoder's
+                                      //   node kernels then run without their any-shape path (build_tree sets it)
 
 struct Grid {          // all nodes of one root at one depth, as a dense 3D array
   uint32_t nodeOff;    // first flat node id (multiple of kNodeBlock)

@@ -594,6 +594,13 @@ inline HostTree build_tree(size_t dx, size_t dy, size_t dz, bool twoD = false, b
     }
   for (const auto& io : iOrder)
     h.iRoots.push_back(io.first == 0xffffffffu ? HostTree::kNoRoot : rootNode[io.first][io.second]);
+  {
+    bool allOct = !h.grids.empty();
+    for (const Grid& g : h.grids)
+      allOct = allOct && (g.kind & kGridOct) != 0;
+    if (allOct)
+      h.flags |= kTreeAllOct;
+  }
 
   // ---- list capacities: how many set nodes can ever sit in each LIS level ----------------
   h.levelCap.assign(h.nlevels, 0);
