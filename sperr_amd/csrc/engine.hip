@@ -283,6 +283,7 @@ struct ShapePlan {
   const uint8_t* d_mxLevelGroup = nullptr;
   int l0Level = -1;                       // LIS level of 2x2x2 leaf sets that k_lis_l0 can decode
   int l1Level = -1;                       // LIS level of 4x4x4 sets that k_lis_l1 can decode
+  int l2Level = -1;                       // LIS level of 8x8x8 sets that k_lis_l2 can decode
   int maxK = 0;
   std::vector<uint32_t> depthBlockOff;
   uint32_t nListTiles = 0, nSlots = 0, nPixTiles = 0, nstrides = 0;
@@ -428,6 +429,18 @@ int build_plan(ShapePlan& P, size_t dx, size_t dy, size_t dz, bool twoD = false)
       if (lc.regular && lc.K == 2 && lc.arity[0] == 8 && lc.arity[1] == 8 &&
           lc.lev[0] == (uint8_t)P.l0Level)
         P.l1Level = (int)l;
+      break;
+    }
+  P.l2Level = -1;   // and the one after it, when it holds 8x8x8 sets made of those (SPERR_HIP_LIS_L2=0: k_lis_hi takes it)
+  static const bool l2Env = !(getenv("SPERR_HIP_LIS_L2") && atoi(getenv("SPERR_HIP_LIS_L2")) == 0);
+  if (P.l1Level >= 0 && l2Env)
+    for (uint32_t l = (uint32_t)P.l1Level; l-- > 0;) {
+      if (cap[l] == 0)
+        continue;
+      const spk::LevelClass& lc = h.levelClass[l];
+      if (lc.regular && lc.K == 3 && lc.arity[0] == 8 && lc.arity[1] == 8 && lc.arity[2] == 8 &&
+          lc.lev[0] == (uint8_t)P.l0Level && lc.lev[1] == (uint8_t)P.l1Level)
+        P.l2Level = (int)l;
       break;
     }
   if (P.tables.ensure(blob.bytes.size()))
@@ -2366,6 +2379,8 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.l0Level = P.l0Level;
   TAKE(d.l1Flags, unsigned long long, d.l0FlagStride * B);
   d.l1Level = P.l1Level;
+  TAKE(d.l2Flags, unsigned long long, d.l0FlagStride * B);
+  d.l2Level = P.l2Level;
   d.wordLeaf = P.d_wordLeaf;
   d.leafStateStride = round_up(P.ht.nnodes, 64);
   TAKE(d.leafState, uint16_t, d.leafStateStride * B);
@@ -2891,6 +2906,7 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         DecPlanHost ph{P->d_initLIS, P->d_initLen,
                        use_tables(*P), P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
         ph.skipFinish = true;   // launch_inv_quantize / the dequantising inverse passes complete the coefficients
+        ph.l2 = ph.l1 && P->l2Level >= 0;
         // the lists of the larger sets GPU-wide
         ph.hi = use_lis_hi(*P, ph.tables);
         ph.mixed = use_mixed(*P);
@@ -2919,12 +2935,13 @@ int decompress_impl(Engine& E, const uint8_t* d_src, size_t src_len, T* d_dst, s
         // diagnostics: SPERR_HIP_LIS_GPUWIDE=0 leaves every list to k_lis_hi
         static const bool gpuWide = !(getenv("SPERR_HIP_LIS_GPUWIDE") && atoi(getenv("SPERR_HIP_LIS_GPUWIDE")) == 0);
         if (!gpuWide)
-          ph.l0 = ph.l1 = false;
+          ph.l0 = ph.l1 = ph.l2 = false;
         HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l0Flags, 0, d.l0FlagStride * nb * 8, ss));
         if (d.l0Tab)
           HIP_CHECK(hipMemsetAsync(d.l0Tab, 0, d.l0FlagStride * 17 * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * nb * 8, ss));
+        HIP_CHECK(hipMemsetAsync(d.l2Flags, 0, d.l0FlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * nb * 8, ss));
         HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * nb * 8, ss));
         if (d.lisStamps)
@@ -3926,6 +3943,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
       HIP_CHECK(hipMemsetAsync(bb.coef32, 0, (size_t)n * 4, st));
     DecPlanHost ph{P->d_initLIS, P->d_initLen, use_tables(*P),
                    P->l0Level >= 0 && P->ht.grids.size() <= 288, P->l1Level >= 0 && P->ht.grids.size() <= 288, P->maxK};
+    ph.l2 = ph.l1 && P->l2Level >= 0;
     ph.hi = use_lis_hi(*P, ph.tables);
     ph.mixed = use_mixed(*P);
     HIP_CHECK(hipMemsetAsync(d.mask, 0, std::max<size_t>(d.maskStride, 1) * 8, st));
@@ -3933,6 +3951,7 @@ int sperrhip_speck3d_decode_dev(const void* d_stream, size_t stream_len, size_t 
     if (d.l0Tab)
       HIP_CHECK(hipMemsetAsync(d.l0Tab, 0, d.l0FlagStride * 17 * 8, st));
     HIP_CHECK(hipMemsetAsync(d.l1Flags, 0, d.l0FlagStride * 8, st));
+    HIP_CHECK(hipMemsetAsync(d.l2Flags, 0, d.l0FlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.hiFlags, 0, d.hiFlagStride * 8, st));
     HIP_CHECK(hipMemsetAsync(d.sigbits, 0, d.sigbitsStride * 8, st));
     if (launch_speck_decode(st, d, ph, wrap, bb.chunkOff, bb.chunkLen, wide, nbp))

@@ -32,6 +32,10 @@ struct DecState {
   uint32_t l1Ticket;
   int32_t l1PlaneP1;
   uint64_t l1End;
+  // ... and the one after it (8x8x8 sets), k_lis_l2 (round 6)
+  uint32_t l2Ticket;
+  int32_t l2PlaneP1;
+  uint64_t l2End;
   // GPU-wide pass over the lists of the larger sets (k_lis_hi)
   uint32_t hiTicket;             // next region of the pass to hand out
   int32_t hiPlaneP1;             // 1 + the plane whose pass has ended (0: none)
@@ -181,6 +185,8 @@ struct DecBuffers {
   unsigned long long* l0Tab;   // 17 words per block: its memo table (exit offset, entries, significant entries per entry offset), tagged like the look-back words; null: blocks wait for their predecessor's state only
   unsigned long long* l1Flags; // same for k_lis_l1
   int32_t l1Level;
+  unsigned long long* l2Flags; // and k_lis_l2 (blocks of 4096 bits like k_lis_l1's: l0FlagStride words per chunk)
+  int32_t l2Level;             // LIS level of the 8x8x8 sets it handles, or -1
   uint64_t* lisStamps;         // diagnostics: 16 tick counters per chunk, or nullptr
   // k_lis_hi: four look-back words per region of hiW stream bits (tagged with the plane)
   unsigned long long* hiFlags;
@@ -213,6 +219,7 @@ struct DecPlanHost {
   bool l1;                     // and the next one of 4x4x4 sets: k_lis_l1
   int maxK;                    // longest class chain (sizes the LDS tables)
   bool hi = false;             // the other lists GPU-wide (k_lis_hi) instead of one workgroup per chunk
+  bool l2 = false;             // the list after k_lis_l1's, of 8x8x8 sets: k_lis_l2 (round 6)
   bool mixed = false;          // lists that mix set shapes: k_lis_mx (shape-class rows, several workgroups per chunk) instead of k_lis_walk
   uint32_t gridDiv = 1;        // the per-plane kernels' grid caps divided by this: a batch that decodes beside other shape groups
                                //   whose k_lis_mx workgroups hold most CUs (1000^3 in 256^3 chunks: 150 -> 146 ms with 4)

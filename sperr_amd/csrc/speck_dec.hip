@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_scan(DecBuffers b, int p)
     s.lipStart = s.pos;
     s.l0Ticket = 0;
     s.l1Ticket = 0;
+    s.l2Ticket = 0;
     s.hiTicket = 0;
     s.hiCompactDone = 0;
     s.bornCount = 0;
@@ -1783,6 +1784,500 @@ k_lis_l1(DecBuffers b, int p)
 }
 
 // ------------------------------------------------------------------------------------------
+// LIS phase, the third list: 8x8x8 sets (class 2) whose children are the 4x4x4 sets (round 6).  The scheme of
+// k_lis_l0 / k_lis_l1 with one more level inside a token: an entry is '0', or '1' followed by its eight
+// children, each '0' (a birth into the 4x4x4 sets' list) or '1' + ITS eight children, each '0' (a birth into
+// the list of the smallest sets) or '1' + eight pixels (a leaf event); the last child of a set none of whose
+// siblings was significant carries no test bit (src/SPECK3D_INT.cpp:140-212).  A token takes at most
+// 1 + 7 * 137 + 137 = 1097 bits, so a block's class-1 tables cover 1024 positions more than the block and its
+// class-0 tables 128 more than those; a chain can enter a block at 1098 offsets, which is the size of its memo
+// table.  Until round 6 this list was k_lis_hi's: in the heavy planes most of that kernel's bits (2.5 Mbit per
+// 256^3 chunk in plane 14 of the bench volume), decoded through its general machinery -- regions handed from
+// workgroup to workgroup over a chain of 15 K cycles each, class tables for any chain of classes, breadth-first
+// expansion through global queues.  Here a block's hand-over is one look-back word, as in k_lis_l1.
+//   sweep 1   the tokens on the chain: insignificant entries stay, significant ones leave their list entry in
+//             their own words of hop64 (a significant token is 24 bits and more) and queue up;
+//   sweep T   a significant token per thread: its children -- births counted, significant ones queued;
+//   sweep C   a significant child per thread: its children -- births and leaf events counted;
+//   the block reserves its birth and leaf-event slots with one atomic each, and sweeps T and C run again to write
+//   (a thread's records: at most eight).
+// ------------------------------------------------------------------------------------------
+constexpr int kL2Threads = 512;
+constexpr int kL2W = 4096;
+constexpr int kL2MaxTok = 1097;
+constexpr int kL2P1 = kL2W + 1024;              // positions with class-1 tables
+constexpr int kL2P0 = kL2P1 + 128;              // positions with class-0 tables
+constexpr int kL2Per = kL2W / kL2Threads;
+constexpr int kL2TokCap = 256;                  // significant tokens that START in a block: 24 bits each and more
+constexpr int kL2ChildCap = 512;                // their significant children: 16 bits each and more inside 4096 + 1097
+constexpr size_t kL2Smem = (size_t)(kL2P0 / 64 + 4) * 8 + (size_t)(kL2W + 4) * 4 + (size_t)kL2W * (4 + 2) +
+                           (size_t)kL2P1 * 2 + (size_t)kL2P0 * 2;
+
+__global__ void __launch_bounds__(kL2Threads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_lis_l2(DecBuffers b, int p, uint32_t minEntries)
+{
+  const uint32_t c = blockIdx.y;
+  DecState& s = b.st[c];
+  DEC_ACTIVE_OR_RETURN(s, p);
+  const uint32_t L = (uint32_t)b.l2Level, L1 = (uint32_t)b.l1Level, L0 = (uint32_t)b.l0Level;
+  const uint32_t cur = s.cur, nx = cur ^ 1u;
+  const uint32_t n = s.listLen[cur][L];
+  const bool l0done = s.l0PlaneP1 == p + 1, l1done = s.l1PlaneP1 == p + 1;
+  // (a short list stays with k_lis_hi: one block's tables -- 5 K positions, three classes -- are 35 us whatever it holds)
+  if (n < minEntries || (!l0done && s.listLen[cur][L0] != 0) || (!l1done && s.listLen[cur][L1] != 0))
+    return;   // (k_lis_hi takes the list)
+  extern __shared__ __attribute__((aligned(16))) char l2_smem[];
+  uint64_t* wbits = reinterpret_cast<uint64_t*>(l2_smem);
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(l2_smem);
+  uint32_t* hop64 = reinterpret_cast<uint32_t*>(l2_smem + (size_t)(kL2P0 / 64 + 4) * 8);
+  uint32_t* hopW = hop64 + kL2W + 4;     // later: the marks of the tokens on the chain, then the queues
+  uint16_t* U2 = reinterpret_cast<uint16_t*>(hopW + kL2W);   // token length at every position of the block
+  uint8_t* U1 = reinterpret_cast<uint8_t*>(U2 + kL2W);       // coded class-1 item: 1, or 1 + T1 of the next position
+  uint8_t* T1 = U1 + kL2P1;          // split of a class-1 set that starts here
+  uint8_t* U0 = T1 + kL2P1;          // the same for class 0
+  uint8_t* T0 = U0 + kL2P0;
+  __shared__ uint32_t memo[kL2MaxTok + 1];   // exit offset << 21 | entries << 8 | significant entries, per entry offset
+  __shared__ uint32_t entR[kL2W / 1024], entK[kL2W / 1024], entS[kL2W / 1024];
+  __shared__ uint32_t blkE[kL2W / 64], blkK[kL2W / 64], blkS[kL2W / 64];
+  __shared__ uint32_t sh_ticket, sh_e, sh_rank, sh_sig, sh_last, sh_stop, sh_endpos, sh_endsig;
+  __shared__ uint32_t sh_nb, sh_nl, sh_nc, sh_baseB, sh_baseL, sh_ntok;
+  __shared__ uint16_t tokQ[kL2TokCap];
+  __shared__ uint32_t tokSlot[kL2TokCap];    // first birth slot of a token's children (block-local)
+  __shared__ Grid sh_grids[kTabLdsGrids];    // (the launcher checks that the tree's grids fit)
+
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+  const Tree& t = b.tree;
+  for (uint32_t k = tid; k < t.ngrids; k += kL2Threads)
+    sh_grids[k] = t.grids[k];
+  const uint64_t phase0 = s.lipStart + s.lipBits;
+  const uint64_t start0 = l1done ? s.l1End : l0done ? s.l0End : phase0;
+  const uint64_t* words = b.stream + c * b.streamStride;
+  const uint64_t nwordsAvail = (s.avail + 63) / 64;
+  const uint64_t* list = b.lis[cur] + c * b.lisStride + b.levelOff[L];
+  uint64_t* keep = b.lis[nx] + c * b.lisStride + b.levelOff[L];
+  uint64_t* leafEv = b.leafEv + c * b.leafStride;
+  uint64_t* bornPacked = b.bornPacked + c * b.bornPitch;
+  uint64_t* bornPosLev = b.bornPosLev + c * b.bornPitch;
+  unsigned long long* flags = b.l2Flags + c * b.l0FlagStride;
+  const unsigned long long tag = (unsigned long long)(p + 1) << 56;
+  const uint64_t maskBits = (uint64_t)b.maskWords * 64;
+  const uint32_t lev1 = b.levelClass[L].lev[1], lev0 = b.levelClass[L].lev[0];
+  const uint32_t slot1 = b.levelSlot[lev1], slot0 = b.levelSlot[lev0];
+  uint64_t* mask1 = b.mask + c * b.maskStride + (size_t)slot1 * b.maskWords;
+  uint64_t* mask0 = b.mask + c * b.maskStride + (size_t)slot0 * b.maskWords;
+
+  for (;;) {
+    if (tid == 0) {
+      const bool over = __hip_atomic_load(&s.l2PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1;
+      sh_ticket = over ? kL0None : atomicAdd(&s.l2Ticket, 1u);
+      sh_nb = 0;
+      sh_nl = 0;
+      sh_nc = 0;
+      sh_ntok = 0;
+    }
+    __syncthreads();
+    const uint32_t i = sh_ticket;
+    if (i == kL0None || (size_t)i + 1 >= b.l0FlagStride)
+      break;
+    const uint64_t a = start0 + (uint64_t)i * kL2W;
+    const uint64_t w0 = a >> 6;
+    const uint32_t q0 = (uint32_t)(a & 63);
+    for (uint32_t k = tid; k < (uint32_t)(kL2P0 / 64 + 4); k += kL2Threads)
+      wbits[k] = w0 + k < nwordsAvail ? words[w0 + k] : 0ull;
+    __syncthreads();
+    auto bit_at = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0;
+      return (w32[q >> 5] >> (q & 31)) & 1u;
+    };
+    auto bits32 = [&](uint32_t r) -> uint32_t {
+      const uint32_t q = r + q0, sh = q & 31;
+      const uint32_t lo = w32[q >> 5], hi = w32[(q >> 5) + 1];
+      return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    };
+    // ---- class 0: split length, then the coded item
+    for (uint32_t r = tid; r < (uint32_t)kL2P0; r += kL2Threads) {
+      const uint32_t v = bits32(r);
+      uint32_t y = 0, found = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t bit = (v >> y) & 1u;
+        found |= bit;
+        y += 1u + bit;
+      }
+      const uint32_t bit = found ? (v >> y) & 1u : 1u;
+      T0[r] = (uint8_t)(y + found + bit);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < (uint32_t)kL2P0; r += kL2Threads)
+      U0[r] = (uint8_t)((bit_at(r) && r + 1 < (uint32_t)kL2P0) ? 1u + T0[r + 1] : 1u);
+    __syncthreads();
+    // ---- class 1
+    for (uint32_t r = tid; r < (uint32_t)kL2P1; r += kL2Threads) {
+      uint32_t y = r, found = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const uint32_t u = U0[y];
+        found |= u - 1u;
+        y += u;
+      }
+      y += found ? U0[y] : T0[y];
+      T1[r] = (uint8_t)(y - r);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < (uint32_t)kL2P1; r += kL2Threads)
+      U1[r] = (uint8_t)((bit_at(r) && r + 1 < (uint32_t)kL2P1) ? 1u + T1[r + 1] : 1u);
+    __syncthreads();
+    // ---- class 2: the token at every position of the block
+    for (uint32_t r = tid; r < (uint32_t)kL2W; r += kL2Threads) {
+      uint32_t len = 1;
+      if (bit_at(r)) {
+        uint32_t y = r + 1, found = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          const uint32_t u = U1[y];
+          found |= u - 1u;
+          y += u;
+        }
+        y += found ? U1[y] : T1[y];
+        len = y - r;
+      }
+      U2[r] = (uint16_t)len;
+    }
+    __syncthreads();
+    // ---- chains inside 64-position sub-blocks (lane = position)
+    for (uint32_t sb = wave; sb < (uint32_t)(kL2W / 64); sb += kL2Threads / 64) {
+      const uint32_t r = sb * 64 + lane, hEnd = (sb + 1) * 64;
+      uint32_t v = (1u << 21) | (bit_at(r) << 14) | (r + U2[r]);
+      bool inb = (v & 0x3fffu) < hEnd;
+      for (int it = 0; it < 6 && __any(inb); it++) {
+        const uint32_t o = __shfl(v, (v & 0x3fffu) & 63u, 64);
+        if (inb) {
+          v = (v & ~0x3fffu) + o;
+          inb = (v & 0x3fffu) < hEnd;
+        }
+      }
+      hop64[r] = v;
+      hopW[r] = v;
+    }
+    __syncthreads();
+    for (uint32_t wide = 128; wide <= 1024; wide <<= 1) {
+      for (uint32_t r = tid; r < (uint32_t)kL2W; r += kL2Threads) {
+        const uint32_t v = hopW[r], e = v & 0x3fffu;
+        if (e < (uint32_t)kL2W && e / wide == r / wide)
+          hopW[r] = (v & ~0x3fffu) + hopW[e];
+      }
+      __syncthreads();
+    }
+    // ---- the whole block, for each offset a chain can enter at
+    for (uint32_t e0 = tid; e0 <= (uint32_t)kL2MaxTok; e0 += kL2Threads) {
+      uint32_t r = e0, cnt = 0, sg = 0;
+      while (r < (uint32_t)kL2W) {
+        const uint32_t v = hopW[r];
+        cnt += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+      memo[e0] = ((r - kL2W) << 21) | (cnt << 8) | sg;   // (exit offset <= 1097, entries <= 4096, significant <= 171)
+    }
+    __syncthreads();
+    // ---- look back, publish: tag | done << 55 | exit offset << 44 | entries << 22 | significant
+    if (tid == 0) {
+      uint32_t e = 0, rank = 0, sg = 0, stop = 0, last = 0;
+      if (i > 0) {
+        unsigned long long f = 0;
+        uint32_t spins = 0;
+        uint64_t spinT0 = 0;
+        for (;;) {
+          f = __hip_atomic_load(flags + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> 56) == (unsigned long long)(p + 1))
+            break;
+          // (the end-of-pass marker is looked at now and then: the poll stays one load long)
+          if ((++spins & 15u) == 0 &&
+              __hip_atomic_load(&s.l2PlaneP1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p + 1) {
+            stop = 1;
+            break;
+          }
+          if (spin_expired(spins, spinT0)) {   // (a minute of wall time: the device has stopped making progress)
+            s.error = kErrLookBackTimeout;
+            __hip_atomic_store(&s.l2PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stop = 1;
+            break;
+          }
+        }
+        if (!stop) {
+          if ((f >> 55) & 1ull)
+            stop = 1;
+          else {
+            e = (uint32_t)(f >> 44) & 0x7ffu;
+            rank = (uint32_t)(f >> 22) & 0x3fffffu;
+            sg = (uint32_t)f & 0x3fffffu;
+          }
+        }
+      }
+      if (!stop) {
+        const uint32_t m = memo[e], mc = (m >> 8) & 0x1fffu;
+        if (rank + mc >= n) {   // the list ends inside this block
+          last = 1;
+          __hip_atomic_store(flags + i, tag | (1ull << 55), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&s.l2PlaneP1, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else
+          __hip_atomic_store(flags + i,
+                             tag | ((unsigned long long)(m >> 21) << 44) |
+                                 ((unsigned long long)(rank + mc) << 22) |
+                                 (unsigned long long)(sg + (m & 0xffu)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh_e = e;
+      sh_rank = rank;
+      sh_sig = sg;
+      sh_last = last;
+      sh_stop = stop;
+      sh_endpos = 0;
+      sh_endsig = 0;
+    }
+    for (uint32_t k = tid; k < (uint32_t)(kL2W / 64); k += kL2Threads)
+      blkE[k] = kL0None;
+    if (tid < kL2W / 1024)
+      entR[tid] = kL0None;
+    __syncthreads();
+    if (sh_stop)
+      break;
+    // ---- where the chain enters each 1024-block, then each sub-block
+    if (tid == 0) {
+      uint32_t r = sh_e, rk = 0, sg = 0;
+      while (r < (uint32_t)kL2W) {
+        entR[r >> 10] = r;
+        entK[r >> 10] = rk;
+        entS[r >> 10] = sg;
+        const uint32_t v = hopW[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    if (tid < kL2W / 1024 && entR[tid] != kL0None) {
+      uint32_t r = entR[tid], rk = entK[tid], sg = entS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 1024;
+      while (r < end) {
+        blkE[r >> 6] = r;
+        blkK[r >> 6] = rk;
+        blkS[r >> 6] = sg;
+        const uint32_t v = hop64[r];
+        rk += v >> 21;
+        sg += (v >> 14) & 0x7fu;
+        r = v & 0x3fffu;
+      }
+    }
+    __syncthreads();
+    // ---- marks: (1 + entries before the token) | significant entries before it << 16, block-local
+    for (uint32_t r = tid; r < (uint32_t)kL2W; r += kL2Threads)
+      hopW[r] = 0;
+    __syncthreads();
+    const uint32_t rank0 = sh_rank, sig0 = sh_sig;
+    const uint32_t nloc = n - rank0;
+    if (tid < kL2W / 64 && blkE[tid] != kL0None) {
+      uint32_t r = blkE[tid], rk = blkK[tid], sg = blkS[tid];
+      const uint32_t end = ((uint32_t)tid + 1) * 64;
+      bool did = false;
+      while (r < end && rk < nloc) {
+        hopW[r] = (rk + 1u) | (sg << 16);
+        rk++;
+        sg += bit_at(r);
+        r += U2[r];
+        did = true;
+      }
+      if (did && rk == nloc) {
+        sh_endpos = r;
+        sh_endsig = sg;
+      }
+    }
+    __syncthreads();
+    // ---- sweep 1: insignificant entries stay, significant ones leave their list entry in hop64 and queue up
+    {
+      uint32_t mk4[kL2Per];
+      uint64_t id4[kL2Per];
+#pragma unroll
+      for (int j = 0; j < kL2Per; j++)
+        mk4[j] = hopW[(uint32_t)tid + (uint32_t)j * kL2Threads];
+#pragma unroll
+      for (int j = 0; j < kL2Per; j++)
+        id4[j] = mk4[j] ? list[rank0 + (mk4[j] & 0xffffu) - 1u] : 0ull;
+#pragma unroll
+      for (int j = 0; j < kL2Per; j++) {
+        const uint32_t r = (uint32_t)tid + (uint32_t)j * kL2Threads;
+        const uint32_t mk = mk4[j];
+        if (mk == 0)
+          continue;
+        const uint32_t q = rank0 + (mk & 0xffffu) - 1u, sb = sig0 + (mk >> 16);
+        const uint64_t ident = id4[j];
+        if (!bit_at(r)) {
+          keep[q - sb] = ident;
+          continue;
+        }
+        hop64[r + 1] = (uint32_t)ident;
+        hop64[r + 2] = (uint32_t)(ident >> 32);
+        const uint32_t ti = atomicAdd(&sh_ntok, 1u);
+        if (ti < (uint32_t)kL2TokCap)
+          tokQ[ti] = (uint16_t)r;
+      }
+    }
+    __syncthreads();
+    // ---- sweeps T and C, twice: first counting (write == 0), then -- the block's slots reserved -- writing.
+    //      QC (the marks' array: they are dead now): a significant child as
+    //        position of the token | child << 12 | (child's position - token's) << 15 | coded << 26
+    //      QS: the child's first birth slot | first leaf slot << 16, block-local
+    uint32_t* QC = hopW;
+    uint32_t* QS = hopW + kL2ChildCap;
+    const uint32_t ntok = min(sh_ntok, (uint32_t)kL2TokCap);
+    for (int write = 0; write < 2; write++) {
+      // sweep T: a significant token per thread
+      if ((uint32_t)tid < ntok) {
+        const uint32_t r = tokQ[tid];
+        const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
+        uint32_t y = r + 1, found = 0, nb = 0, nsc = 0, kinds = 0, offs[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const bool coded = found || k != 7;
+          const uint32_t u = coded ? U1[y] : T1[y];
+          offs[k] = (y - r) | ((uint32_t)coded << 11);
+          if (coded && u == 1) {
+            const uint64_t rel = a + y - phase0;
+            if (slot1 != 0xff && rel < maskBits) {
+              kinds |= 0x100u << k;
+              nb++;
+            }
+          }
+          else {
+            found = 1;
+            nsc++;
+            kinds |= 1u << k;
+          }
+          y += u;
+        }
+        if (!write) {
+          tokSlot[tid] = nb ? atomicAdd(&sh_nb, nb) : 0u;
+          uint32_t sc = atomicAdd(&sh_nc, nsc);
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            if (((kinds >> k) & 1u) && sc < (uint32_t)kL2ChildCap)
+              QC[sc++] = r | ((uint32_t)k << 12) | (offs[k] << 15);
+        }
+        else {
+          uint32_t slotB = sh_baseB + tokSlot[tid];
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            if ((kinds >> (8 + k)) & 1u) {
+              const uint32_t cx = 2u * nd.i[0] + (uint32_t)(k & 1), cy = 2u * nd.i[1] + (uint32_t)((k >> 1) & 1),
+                             cz = 2u * nd.i[2] + (uint32_t)(k >> 2);
+              const uint64_t rel = a + r + (offs[k] & 0x7ffu) - phase0;
+              if (slotB < b.bornStride) {   // stays insignificant: joins the list of the 4x4x4 sets
+                bornPacked[slotB] = ((uint64_t)(nd.grid + 1) << 48) | ((uint64_t)cz << 32) | ((uint64_t)cy << 16) | (uint64_t)cx;
+                bornPosLev[slotB] = ((uint64_t)lev1 << 48) | rel;
+                atomic_or64(mask1 + (rel >> 6), 1ull << (rel & 63));
+              }
+              slotB++;
+            }
+        }
+      }
+      __syncthreads();   // (QC is complete)
+      // sweep C: a significant child per thread
+      const uint32_t nchild = min(sh_nc, (uint32_t)kL2ChildCap);
+      for (uint32_t i2 = tid; i2 < nchild; i2 += kL2Threads) {
+        const uint32_t desc = QC[i2];
+        const uint32_t r = desc & 0xfffu, k = (desc >> 12) & 7u, y0 = r + ((desc >> 15) & 0x7ffu);
+        const bool ccoded = (desc >> 26) & 1u;
+        uint32_t y = ccoded ? y0 + 1 : y0, found = 0, nb = 0, nl = 0, kinds = 0, offs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const bool coded = found || j != 7;
+          const uint32_t u = coded ? U0[y] : T0[y];
+          offs[j] = (y - y0) | ((uint32_t)coded << 8);
+          if (coded && u == 1) {
+            const uint64_t rel = a + y - phase0;
+            if (slot0 != 0xff && rel < maskBits) {
+              kinds |= 0x100u << j;
+              nb++;
+            }
+          }
+          else {
+            found = 1;
+            nl++;
+            kinds |= 1u << j;
+          }
+          y += u;
+        }
+        if (!write) {
+          const uint32_t sB = nb ? atomicAdd(&sh_nb, nb) : 0u;
+          const uint32_t sL = atomicAdd(&sh_nl, nl);
+          QS[i2] = sB | (sL << 16);
+          continue;
+        }
+        const Node nd = unpack_node((uint64_t)hop64[r + 1] | ((uint64_t)hop64[r + 2] << 32));
+        const uint32_t px = 2u * nd.i[0] + (k & 1u), py = 2u * nd.i[1] + ((k >> 1) & 1u), pz = 2u * nd.i[2] + (k >> 2);
+        const Grid g2 = sh_grids[nd.grid + 2];   // the grid of the 2x2x2 sets
+        uint32_t slotB = sh_baseB + (QS[i2] & 0xffffu), slotL = sh_baseL + (QS[i2] >> 16);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t cx = 2u * px + (uint32_t)(j & 1), cy = 2u * py + (uint32_t)((j >> 1) & 1), cz = 2u * pz + (uint32_t)(j >> 2);
+          const uint32_t yy0 = y0 + (offs[j] & 0xffu);
+          if ((kinds >> (8 + j)) & 1u) {
+            const uint64_t rel = a + yy0 - phase0;
+            if (slotB < b.bornStride) {   // stays insignificant: joins the list of the smallest sets
+              bornPacked[slotB] = ((uint64_t)(nd.grid + 2) << 48) | ((uint64_t)cz << 32) | ((uint64_t)cy << 16) | (uint64_t)cx;
+              bornPosLev[slotB] = ((uint64_t)lev0 << 48) | rel;
+              atomic_or64(mask0 + (rel >> 6), 1ull << (rel & 63));
+            }
+            slotB++;
+          }
+          else if ((kinds >> j) & 1u) {   // splits into its pixels: a leaf event
+            const bool coded = (offs[j] >> 8) & 1u;
+            const uint32_t v = bits32(coded ? yy0 + 1 : yy0);
+            uint32_t yy = 0, fnd = 0, sigm = 0, negm = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+              const uint32_t bit = (v >> yy) & 1u, sgn = (v >> (yy + 1)) & 1u;
+              sigm |= bit << q;
+              negm |= (bit & (sgn ^ 1u)) << q;
+              fnd |= bit;
+              yy += 1u + bit;
+            }
+            const uint32_t bit = fnd ? (v >> yy) & 1u : 1u;
+            const uint32_t sgn = (v >> (yy + fnd)) & 1u;
+            sigm |= bit << 7;
+            negm |= (bit & (sgn ^ 1u)) << 7;
+            const uint32_t fid = g2.nodeOff + (((cz << g2.e[1]) + cy) << g2.e[0]) + cx;
+            if (slotL < b.leafCap)
+              leafEv[slotL] = (uint64_t)fid | ((uint64_t)sigm << 32) | ((uint64_t)negm << 40);
+            slotL++;
+          }
+        }
+      }
+      __syncthreads();
+      if (!write) {
+        if (tid == 0)     // (two threads: the two returning atomics are in flight together)
+          sh_baseB = sh_nb ? atomicAdd(&s.bornCount, sh_nb) : 0u;
+        if (tid == 64)
+          sh_baseL = sh_nl ? atomicAdd(&s.leafCount, sh_nl) : 0u;
+        __syncthreads();
+      }
+    }
+    if (sh_ntok > (uint32_t)kL2TokCap || sh_nc > (uint32_t)kL2ChildCap)   // (cannot be: see the constants)
+      s.error = 1;
+    if (sh_last) {
+      if (tid == 0) {
+        s.l2End = a + sh_endpos;
+        s.listLen[nx][L] = n - (sig0 + sh_endsig);
+      }
+      break;
+    }
+    __syncthreads();   // LDS is reused by the next block
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LIS phase, table-driven (chunks whose LIS levels are all "regular", spk::LevelClass): what
 // k_lis_hi below shares with its predecessor k_lis_tables (one 1024-thread workgroup per chunk,
 // rounds 1-3; removed in round 4 -- a regular tree k_lis_hi cannot take goes to k_lis_mx).
@@ -1985,7 +2480,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   const unsigned long long tag = (unsigned long long)(p + 1) << kHiTagShift;
   const bool l0done = b.l0Level >= 0 && s.l0PlaneP1 == p + 1;
   const bool l1done = b.l1Level >= 0 && s.l1PlaneP1 == p + 1;
-  const uint64_t S0 = l1done ? s.l1End : l0done ? s.l0End : phase0;
+  const bool l2done = b.l2Level >= 0 && s.l2PlaneP1 == p + 1;
+  const uint64_t S0 = l2done ? s.l2End : l1done ? s.l1End : l0done ? s.l0End : phase0;
   if (tid == 0) {
     sh_segBorn = sh_segLeaf = 0;
     sh_segBornEnd = 0xffffffffu;
@@ -1995,7 +2491,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   // the next list after level `l` (exclusive) that holds entries and is this kernel's to decode
   auto next_level = [&](int l) -> int {
     for (l = l - 1; l >= 0; l--) {
-      if ((l0done && l == b.l0Level) || (l1done && l == b.l1Level))
+      if ((l0done && l == b.l0Level) || (l1done && l == b.l1Level) || (l2done && l == b.l2Level))
         continue;
       if (sh_len[l] != 0)
         return l;
@@ -3192,7 +3688,8 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_compact(DecBuffers b, int p
   DEC_ACTIVE_OR_RETURN(s, p);
   // (the GPU-wide kernels of the two smallest set sizes kept their own survivors)
   const bool skip = (b.l0Level >= 0 && s.l0PlaneP1 == p + 1 && (int)l == b.l0Level) ||
-                    (b.l1Level >= 0 && s.l1PlaneP1 == p + 1 && (int)l == b.l1Level);
+                    (b.l1Level >= 0 && s.l1PlaneP1 == p + 1 && (int)l == b.l1Level) ||
+                    (b.l2Level >= 0 && s.l2PlaneP1 == p + 1 && (int)l == b.l2Level);
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
   __shared__ uint32_t sh_stay[kTabThreads], sh_ex[kTabThreads];
   const uint32_t cur = s.cur, nx = cur ^ 1u;
@@ -3840,12 +4337,19 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   const uint32_t l0Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l0Total / nc));
   if (plan.tables && plan.l0) {
     if (set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l0), (int)kL0Smem) ||
-        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l1), (int)kL1Smem))
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l1), (int)kL1Smem) ||
+        set_max_dyn_lds(reinterpret_cast<const void*>(&k_lis_l2), (int)kL2Smem))
       return -1;
   }
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
   static const uint32_t l1Total = tune_getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L1_WGS")) : 768u;
   const uint32_t l1Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l1Total / nc));
+  // k_lis_l2: two workgroups a CU over all chunks (SPERR_HIP_L2_WGS in the diagnostics build)
+  static const uint32_t l2Total = tune_getenv("SPERR_HIP_L2_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L2_WGS")) : 512u;
+  const uint32_t l2Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l2Total / nc));
+  // (entries from which the list is k_lis_l2's; measured on MI355X, alternating runs: 1 / 512 / 2048 / 4096 / never give
+  //  50.0 / 50.7 / 47.5 / 47.0 / 45.7-46.8 GB/s for 8 chunks and 113.4 / 113.1-114.0 / 112.8 / 113.5 / 113.8-114.0 for 64)
+  static const uint32_t l2Min = tune_getenv("SPERR_HIP_L2_MIN") ? (uint32_t)std::max(1, atoi(tune_getenv("SPERR_HIP_L2_MIN"))) : 512u;
   const uint32_t placeGrid = capped_blocks((uint32_t)((b.bornStride + kThreads - 1) / kThreads), nc, kGridCap / gdiv);
   // workgroups per chunk of the k_lis_hi pass, at most what the queues were sized for
   // (SPERR_HIP_HI_WGS: the total over the batch's chunks; measured on MI355X with two sub-batches
@@ -3889,6 +4393,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
         LAUNCH_K(k_lis_l0, dim3(l0Groups, nc), dim3(kL0Threads), kL0Smem, stream, b, p);
       if (plan.l1)
         LAUNCH_K(k_lis_l1, dim3(l1Groups, nc), dim3(kL1Threads), kL1Smem, stream, b, p);
+      if (plan.l2)
+        LAUNCH_K(k_lis_l2, dim3(l2Groups, nc), dim3(kL2Threads), kL2Smem, stream, b, p, l2Min);
       if (!plan.hi)
         return -1;   // (use_tables() implies use_lis_hi(): engine.hip)
       LAUNCH_CT(k_lis_hi, dim3(hiGroups, nc), dim3(kTabThreads), b.hiSmemBytes, stream, b, p);

@@ -875,11 +875,12 @@ def test_serial_walk_fallback_in_a_fresh_process(oracle):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
 
 
-@pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}])
+@pytest.mark.parametrize("knobs", [{"SPERR_HIP_LIS_HI": "0"}, {"SPERR_HIP_LIS_GPUWIDE": "0"}, {"SPERR_HIP_LIS_L2": "0"}])
 def test_list_kernel_choices_in_a_fresh_process(oracle, knobs):
     """Who decodes which list is a matter of speed, never of bits (round 4; the knobs are read once per process):
     `SPERR_HIP_LIS_HI=0` -- a regular tree through k_lis_mx, where regular trees that k_lis_hi cannot take go
-    since k_lis_tables was removed; `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 at all, k_lis_hi decodes every list.  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
+    since k_lis_tables was removed; `SPERR_HIP_LIS_GPUWIDE=0` -- no k_lis_l0 / _l1 / _l2 at all, k_lis_hi decodes every
+    list; `SPERR_HIP_LIS_L2=0` -- the 8x8x8 sets' list back with k_lis_hi (round 6 gave it a kernel of its own).  Two chunks of 64 x 64 x 32 at 3 bpp and a stream cut
     short, against the oracle's bits (/root/reference/src/SPECK3D_INT.cpp:99-212)."""
     import subprocess
     import sys

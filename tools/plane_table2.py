@@ -57,7 +57,7 @@ for r in l:
         if prev_end is not None:
             cur["gap"] = cur.get("gap", 0) + max(0, r[0] - prev_end) / 1e3
     prev_end = r[1]
-names = ["k_plane_small", "k_small_pre", "k_small_post", "k_dec_count", "k_lip_words", "k_lip_scan", "k_lip_apply", "k_lip_deposit", "k_lis_l0", "k_lis_l1",
+names = ["k_plane_small", "k_small_pre", "k_small_post", "k_dec_count", "k_lip_words", "k_lip_scan", "k_lip_apply", "k_lip_deposit", "k_lis_l0", "k_lis_l1", "k_lis_l2",
          "k_lis_hi", "k_lis_compact", "k_place_scan", "k_place_scatter", "k_leaf_apply", "k_ref_apply2", "k_ref_deposit", "gap"]
 names = [n for n in names if any(n in pl for pl in planes)]
 print("plane  start " + " ".join(n.replace("k_", "")[:9].rjust(9) for n in names) + "     total")
