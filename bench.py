@@ -484,8 +484,10 @@ def main():
         import glob
         from sperr_amd.srchash import bench_path_hash
         now = bench_path_hash()
-        # only a record taken from THESE sources counts (newest first); none: null, and the line says why
-        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime, reverse=True):
+        # only a record taken from THESE sources counts (the source hash decides; the order of the search -- by file
+        # name, latest round's tag first -- only matters for speed: mtimes mean nothing in a fresh checkout); none:
+        # null, and the line says why
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             with open(pf) as f:
                 doc = json.load(f)
             rec = doc["kernels"].get(top_name)

@@ -97,6 +97,14 @@ FarmShape farm_shape(size_t nthreads, size_t ndev)
   if (nthreads > 0)
     helpers = std::max<size_t>(1, nthreads / nworkers);
   f.helpers = env_size("SPERR_HIP_FARM_HELPERS", helpers);
+  // (the plan must fit what the process may run: on a 16-CPU quota eight devices x two workers x (1 + 1 helper) are 32
+  //  runnable threads -- the workers themselves mostly wait for their device, so they stay, but it is said once)
+  if (ndev * f.workersPerDevice * (1 + f.helpers) > 2 * std::max<size_t>(1, hw)) {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+      fprintf(stderr, "[sperr_hip] farm: %zu devices x %zu workers x (1 + %zu helpers) threads on %zu usable CPUs\n", ndev,
+              f.workersPerDevice, f.helpers, hw);
+  }
   return f;
 }
 

@@ -28,6 +28,25 @@
 namespace sperrhip {
 namespace hostcpu {
 
+// a cgroup-v1 controller list ("cpu,cpuacct", "cpuset,cpu,cpuacct", "cpuset") names the CPU bandwidth controller when one
+// of its comma-separated entries is exactly "cpu" or "cpuacct" (round 5 looked for the substring and skipped every list
+// that STARTED with cpuset, which dropped "cpuset,cpu,cpuacct")
+inline bool names_cpu_controller(const std::string& ctrl)
+{
+  size_t a = 0;
+  while (a <= ctrl.size()) {
+    size_t e = ctrl.find(',', a);
+    if (e == std::string::npos)
+      e = ctrl.size();
+    const std::string one = ctrl.substr(a, e - a);
+    if (one == "cpu" || one == "cpuacct")
+      return true;
+    a = e + 1;
+  }
+  return false;
+}
+
+
 struct Budget {
   size_t visible = 1;    // logical CPUs the machine shows (hardware_concurrency)
   size_t affinity = 1;   // CPUs in the calling thread's affinity mask
@@ -97,7 +116,7 @@ inline double cgroup_quota(const std::string& root, const std::string& procCgrou
       if (c2 == std::string::npos)
         continue;
       const std::string ctrl = line.substr(c1 + 1, c2 - c1 - 1);
-      if (!(ctrl.empty() || ctrl.find("cpu") != std::string::npos) || ctrl.find("cpuset") == 0)
+      if (!(ctrl.empty() || names_cpu_controller(ctrl)))
         continue;
       std::string rel = line.substr(c2 + 1);
       if (rel.find("..") != std::string::npos)
@@ -193,7 +212,7 @@ inline bool throttle_stat(const std::string& root, const std::string& procCgroup
         continue;
       if (ctrl.empty())
         dirs.push_back(root + rel);
-      else if (ctrl.find("cpu") != std::string::npos && ctrl.find("cpuset") != 0) {
+      else if (names_cpu_controller(ctrl)) {
         dirs.push_back(root + "/cpu" + rel);
         dirs.push_back(root + "/cpu,cpuacct" + rel);
       }

@@ -1283,10 +1283,12 @@ __global__ void __launch_bounds__(kMxThreads) k_lis_mx(DecBuffers b, int p)
     }
     if (wave == 0) {
       {
+        // (bounded by wall time like the look-back waits, common.h: a slow, shared or profiled device must not turn
+        //  a spin count into an early exit)
         uint32_t spins = 0;
-          uint64_t spinT0 = 0;
+        uint64_t spinT0 = 0;
         while (__hip_atomic_load(&sh_goDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)kMxPreWaves &&
-               ++spins < (1u << 26))
+               !spin_expired(++spins, spinT0))
           __builtin_amdgcn_s_sleep(1);
       }
       // look back (lanes 0..6 take one word each)

@@ -94,6 +94,21 @@ def test_cgroup_v1(lib, tmp_path):
     assert (nr.value, us.value) == (3, 7000)
 
 
+def test_cgroup_v1_controller_list_that_starts_with_cpuset(lib, tmp_path):
+    """A v1 line whose controller list names cpu BEHIND cpuset ("cpuset,cpu,cpuacct") is the CPU bandwidth controller's
+    all the same; "cpuset" alone and a name that merely contains the letters ("cpuxyz") are not."""
+    root = tmp_path / "cg"
+    d = root / "cpu" / "grp"
+    d.mkdir(parents=True)
+    (d / "cpu.cfs_quota_us").write_text("300000\n")
+    (d / "cpu.cfs_period_us").write_text("100000\n")
+    proc = tmp_path / "proc_cgroup"
+    proc.write_text("7:cpuset,cpu,cpuacct:/grp\n1:name=systemd:/x\n")
+    assert cpus(lib, root, proc)[2] == 3.0
+    proc.write_text("7:cpuset:/grp\n6:cpuxyz:/grp\n")
+    assert cpus(lib, root, proc)[2] <= 0    # (no quota found)
+
+
 def test_throttle_counters_v2(lib, tmp_path):
     root, proc = v2_tree(tmp_path, "1600000 100000\n", rel="/pod",
                          stat="usage_usec 5\nuser_usec 1\nnr_periods 100\nnr_throttled 42\nthrottled_usec 123456\n")

@@ -1,6 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from sperr_amd.api import SperrHip
 from sperr_amd.synth import turbulence_torch
