@@ -426,7 +426,13 @@ def main():
                 torch.cuda.synchronize()
                 c = time.perf_counter()
                 best_c, best_d = min(best_c, b - a), min(best_d, c - b)
+            try:   # (everything the engine holds after a PWE volume: the arena, the slots and the mode's own buffers)
+                pwe_dev = int(eng.lib.sperrhip_debug_counter(6))
+            except Exception:   # noqa: BLE001
+                pwe_dev = 0
             other["pwe_volume"] = {
+                "engine_device_GB": round(pwe_dev / 1e9, 2),
+                "engine_MB_per_chunk_in_flight": round(pwe_dev / nchunks / 1e6, 1),
                 "what": f"the bench volume in point-wise error mode, tolerance 1e-3 of the range ({tol:.4g}); best of 2",
                 "compress_GBps": round(vol.numel() * 4 / best_c / 1e9, 3),
                 "decompress_GBps": round(vol.numel() * 4 / best_d / 1e9, 3),

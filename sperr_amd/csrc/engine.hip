@@ -661,6 +661,22 @@ struct Engine {
         b->drop();
     pweBufs.clear();
   }
+  // every device buffer of the engine: the arena, the containers' slots, and what point-wise error mode adds (the
+  // outlier coder's arrays, the boxes of the coarser levels, the outlier streams) -- sperrhip_debug_counter(6)
+  size_t device_bytes() const
+  {
+    size_t n = 0;
+    for (const DevBuf* b : {&arena, &slots, &misc, &outlFixed, &outlVar, &outlStream, &pweBox, &slice2d, &wideScratch})
+      n += b->n;
+    for (const auto& b : outlDec)
+      n += b.n;
+    for (const auto& b : decBox)
+      n += b.n;
+    for (const auto& b : pweBufs)
+      if (b)
+        n += b->n;
+    return n;
+  }
   // called between calls only (no kernel of this engine is in flight)
   void trim_plans()
   {
@@ -2318,8 +2334,10 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.bornStride = P.ht.nsets + 8;
   d.hiGroupsMax = 8;
   // (a segment that fills up sends the rest to the shared part, which holds the worst case: eight
-  //  segments of a twelfth of it each were never seen to fill up at 2 to 4.5 bits per sample)
-  d.bornSeg = (uint32_t)((P.ht.nsets + 8) / 12 + 64);
+  //  segments of a twelfth of it each were never seen to fill up at 2 to 4.5 bits per sample; round 6: a
+  //  sixteenth -- a set is born once, so a plane's births are a fraction of the sets, and the lists of the three
+  //  smallest set sizes, whose kernels claim slots of the shared part, hold most of them: 9.7 MB less per 256^3 chunk)
+  d.bornSeg = (uint32_t)((P.ht.nsets + 8) / 16 + 64);
   d.bornPitch = d.bornStride + (size_t)d.bornSeg * d.hiGroupsMax;
   TAKE(d.bornPacked, uint64_t, d.bornPitch * B);
   TAKE(d.bornPosLev, uint64_t, d.bornPitch * B);
@@ -2362,7 +2380,7 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.iRoots = P.d_iRoots;
   d.iLevels = P.ht.iLevels;
   d.leafCap = P.ht.nsets + 8;
-  d.leafSeg = (uint32_t)((P.ht.nsets + 8) / 12 + 64);
+  d.leafSeg = (uint32_t)((P.ht.nsets + 8) / 16 + 64);
   d.leafStride = d.leafCap + (size_t)d.leafSeg * d.hiGroupsMax;
   TAKE(d.leafEv, uint64_t, d.leafStride * B);
   d.sigbitsStride = P.lisEntries / 64 + 4;
@@ -3400,6 +3418,13 @@ unsigned long long sperrhip_debug_counter(int which)
     size_t most = 0;
     for (auto& e : g_pool.all)
       most = std::max(most, e->arena.n);
+    return (unsigned long long)most;
+  }
+  if (which == 6) {   // bytes of ALL device buffers of the engine that holds most (arena + slots + the PWE buffers)
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    size_t most = 0;
+    for (auto& e : g_pool.all)
+      most = std::max(most, e->device_bytes());
     return (unsigned long long)most;
   }
   if (which == 4 || which == 5)   // pinned staging / device bytes the farm's workers hold right now

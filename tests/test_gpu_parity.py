@@ -496,6 +496,28 @@ def test_multi_resolution_decode(eng, oracle, shape, chunks):
         assert np.array_equal(bits(got.cpu().numpy()), bits(want))
 
 
+@pytest.mark.parametrize("tol", [2e-2, 1e-4])
+def test_pwe_container_through_both_inverse_paths(eng, oracle, tol):
+    """A point-wise error container written by the encoder's FUSED reconstruction (pwe_stage_begin: the decoder's
+    values are rebuilt with k_lift_xyz_inv before the outliers are found, src/SPECK_FLT.cpp:461-486) decodes within the
+    tolerance, and to the reference's bits, through BOTH inverse paths of the decoder: the fused brick (plain
+    decompression) and the per-axis k_lift_axis passes (the resolution hierarchy keeps every pass in the chunk buffer).
+    The guarantee rests on the two paths computing the same fp64 values; this pins it for PWE containers."""
+    shape, chunks = (64, 128, 128), (64, 64, 64)
+    v = turbulence(shape)
+    want = oracle.comp_3d(v, chunks, 3, tol)
+    got = bytes(eng.compress(cuda(v), chunks, tol, mode=3).cpu().numpy())
+    assert got == want
+    dev = cuda(np.frombuffer(want, dtype=np.uint8))
+    ref = oracle.decomp_3d(want, False)
+    plain = eng.decompress(dev, False).cpu().numpy()
+    vol, levels = eng.decompress_multires(dev, output_float=False)
+    assert len(levels) > 0
+    for back in (plain, vol.cpu().numpy()):
+        assert np.array_equal(bits(back), bits(ref))
+        assert np.abs(back - v.astype(np.float64)).max() <= tol
+
+
 def test_multi_resolution_absent_for_other_shapes(eng, oracle):
     """Chunks that are not dyadic (wavelet-packet transform), or do not tile the volume, have no
     hierarchy (src/sperr_helper.cpp:70-123); the volume still decodes."""
