@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <deque>
 #include <map>
 #include <memory>
 #include <condition_variable>
@@ -518,11 +519,14 @@ struct Engine {
   hipStream_t sideQ[kSubStreams] = {};      // the encoder's census beside a part's pyramid (normal priority)
   hipEvent_t evOutl[kSubStreams] = {}, evOutlFork[kSubStreams] = {};   // (per sub-batch)
   hipEvent_t evPweFork = nullptr;          // encoder, point-wise error mode: the outlier stage's first half starts beside the 3D coder
+  hipEvent_t evPweJoin = nullptr;          //   ... and its end is waited for by the batch's stream, not by the host (round 6)
   std::map<Dims, std::unique_ptr<ShapePlan>> plans;
   std::vector<Dims> planOrder;             // least recently used first
   DevBuf arena, slots, misc;
   DevBuf outlFixed, outlVar, outlStream;   // point-wise error mode: workspace of the outlier coder
   DevBuf pweBox;                           //   ... and the coarser levels' box of its reconstruction (pwe_outlier_stage)
+  hipStream_t pweLastStream = nullptr;     //   stream the last batch's outlier stage ended on without a wait (round 6): the
+                                           //   next batch of the SAME call may run its stage on another one and reuses the buffers
   DevBuf outlDec[kSubStreams];             //   (decoder: one per sub-batch of a call)
   DevBuf decBox[kSubStreams];              //   ... and the coarser levels' box of a sub-batch with outlier streams
   uint32_t* liveHost[kSubStreams] = {};    // pinned: answers to "do any chunks still decode" (DecPlanHost)
@@ -557,8 +561,10 @@ struct Engine {
       ds(sideQ[q]);
       de(evOutl[q]);
       de(evOutlFork[q]);
-      if (q == 0)
+      if (q == 0) {
         de(evPweFork);
+        de(evPweJoin);
+      }
       if (liveHost[q])
         (void)hipHostFree(liveHost[q]);
       liveHost[q] = nullptr;
@@ -610,6 +616,7 @@ struct Engine {
       HIP_CHECK(hipEventCreateWithFlags(&evOutlFork[q], hipEventDisableTiming));
       if (q == 0)
         HIP_CHECK(hipEventCreateWithFlags(&evPweFork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&evPweJoin, hipEventDisableTiming));
     }
     for (uint32_t q = 0; q < kSubStreams; q++) {
       HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&liveHost[q]), kLiveSlots * sizeof(uint32_t), hipHostMallocDefault));
@@ -1339,10 +1346,12 @@ struct HostMarks {
 
 // PWE mode (src/SPECK_FLT.cpp:280-281): q = 1.5 tol for every chunk; chunks whose largest
 // coefficient needs more than 32 bits are flagged for the 64-bit pass (SPECK_FLT.cpp:324-337)
-int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol, bool* anyWide = nullptr)
+// (`hc`: the caller's, alive until the call's last wait -- the upload at the end is not waited for: round 6, one of the
+//  four host round trips per batch that went, see pwe_stage_finish)
+int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol, std::vector<CoderState>& hc, bool* anyWide = nullptr)
 {
   EncBuffers& e = bb.eb;
-  std::vector<CoderState> hc(nb);
+  hc.assign(nb, CoderState{});
   HIP_CHECK(hipMemcpyAsync(hc.data(), e.cst, nb * sizeof(CoderState), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   for (uint32_t i = 0; i < nb; i++) {
@@ -1360,7 +1369,6 @@ int pwe_q_setup(hipStream_t st, EncBatchBufs& bb, uint32_t nb, double tol, bool*
       *anyWide = true;   // (this mode chooses the width before coding: nothing else sets the flag, k_enc_finalize)
   }
   HIP_CHECK(hipMemcpyAsync(e.cst, hc.data(), nb * sizeof(CoderState), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -1371,6 +1379,7 @@ struct PweKeep {
   uint32_t* gids = nullptr;
   uint64_t* slotOff = nullptr;
   uint8_t* slots = nullptr;
+  std::vector<uint64_t> off2;   // host copy of slotOff: uploaded without a wait, lives until the container is out
 };
 // (the memory belongs to the engine, Engine::pweBufs, and is reused by later calls: a hipFree per
 //  batch waits for every stream of the device, which stalls the other workers of the chunk farm)
@@ -1412,6 +1421,10 @@ int pwe_stage_begin(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs&
   OutlierBufs& ob = S.ob;
   std::vector<OutlierChunk>& hoc = S.hoc;
   std::vector<ChunkGeom>& bricks = S.bricks;
+  if (E.pweLastStream) {   // (a second batch of one call: the first one's stage is not waited for at its end any more)
+    HIP_CHECK(hipStreamSynchronize(E.pweLastStream));
+    E.pweLastStream = nullptr;
+  }
   hm.mark("(3D coder done)", st);
   // What the decoder will reconstruct, in the conditioned domain (src/SPECK_FLT.cpp:461-486).  Round 5: by the decoder's
   // own kernels where the plan allows it -- the coarser levels in a compact buffer of their box, dequantising as they
@@ -1547,21 +1560,37 @@ int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs
   }
   if (!any)
     return 0;   // (d_lens2 stays zero for these chunks)
+  // Round 6: everything from here to the 1D coder's result is enqueued behind ONE wait.  Until then the host came
+  // back after the counting pass (for the number of outliers: the arrays' size), after the compaction (for the
+  // largest magnitude: the stream's size) and after the stream's copy -- a device call went back to the host a dozen
+  // times per batch, and the farm's pipeline (two workers a device) ran at the rate of those round trips.  The first
+  // pass has counted the samples beyond the tolerance (`flagged`: at least the outliers that survive the wrap to
+  // the integer width, Outlier_Coder.cpp:82-100) and found the largest error: both bounds are known now.
+  uint32_t kmax = 0;
+  int maxPlanes = 1;
+  for (auto& o : hoc) {
+    if (!o.flagged)
+      continue;
+    kmax = std::max(kmax, o.flagged);
+    double maxerr;
+    memcpy(&maxerr, &o.maxErrKey, 8);
+    // (a magnitude is llrint(error / tol) cut to the width: below both)
+    const double mq = std::min(maxerr / tol + 2.0, 1.8e19);
+    const unsigned long long bound = std::min<unsigned long long>(o.widthMask, (unsigned long long)mq);
+    maxPlanes = std::max(maxPlanes, 64 - __builtin_clzll(bound | 1ull));
+  }
   HIP_CHECK(hipMemcpyAsync(ob.oc, hoc.data(), nb * sizeof(OutlierChunk), hipMemcpyHostToDevice, st));
   if (launch_outlier_scan<T>(st, 1, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
     return -1;
   ob.kStride = P.N;   // (only the overflow check of the prefix kernel reads it here)
   if (launch_outlier_prefix(st, ob))
     return -1;
-  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
   hm.mark("outlier pass 1 + prefix", st);
-  uint32_t kmax = 0;
-  for (auto& o : hoc)
-    kmax = std::max(kmax, o.count);
   ob.kStride = round_up(std::max<size_t>(kmax, 1), 64);
   speck1d_level_offsets(ob, P.N, 2ull * kmax + 2);
   const size_t varFixed = (size_t)nb * (ob.kStride * (4 + 8 + 1 + 1 + 4 + 1) + ob.runStride * 8) + 8192;
+  if (E.outlVar.n < varFixed)
+    HIP_CHECK(hipStreamSynchronize(st));   // (the buffer grows: nothing enqueued may still point into the old one)
   if (E.outlVar.ensure(varFixed))
     return -1;
   {
@@ -1580,13 +1609,7 @@ int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs
   }
   if (launch_outlier_scan<T>(st, 2, d_src, vd, bb.geom, cd, bb.vals, bb.valsStride, e.cst, tol, ob))
     return -1;
-  HIP_CHECK(hipMemcpyAsync(hoc.data(), ob.oc, nb * sizeof(OutlierChunk), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
   hm.mark("alloc + outlier pass 2", st);
-  int maxPlanes = 1;
-  for (auto& o : hoc)
-    if (o.maxMag)
-      maxPlanes = std::max(maxPlanes, 64 - __builtin_clzll(o.maxMag));
   // bits of one chunk's stream: every outlier has at most nlists sets above it, each with a
   // sibling, and every one of those (and the value itself) gives at most one bit per plane, plus
   // the value's sign; and never more than every node of the whole tree doing so
@@ -1595,6 +1618,8 @@ int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs
   const uint64_t dense = (uint64_t)P.N * (4ull * maxPlanes + 1);
   const uint64_t maxBits = std::min(sparse, dense) + 64;
   ob.streamStride = round_up((size_t)(maxBits / 64) + 4, 32);
+  if (E.outlStream.n < (size_t)nb * ob.streamStride * 8 + 256)
+    HIP_CHECK(hipStreamSynchronize(st));
   if (E.outlStream.ensure((size_t)nb * ob.streamStride * 8 + 256))
     return -1;
   ob.stream = static_cast<uint64_t*>(E.outlStream.p);
@@ -1608,6 +1633,10 @@ int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs
   hm.mark("1D coder", st);
   std::vector<uint64_t> off2(nb + 1, 0);
   for (uint32_t i = 0; i < nb; i++) {
+    if (hoc[i].flagged && hoc[i].count > ob.kStride) {   // (cannot be: count <= flagged)
+      fprintf(stderr, "[sperr_hip] outlier coder: more outliers than the first pass counted (chunk %u)\n", i);
+      return -1;
+    }
     if (hoc[i].error) {
       fprintf(stderr, "[sperr_hip] outlier coder failed (chunk %u, code %u)\n", i, hoc[i].error);
       return -1;
@@ -1629,11 +1658,12 @@ int pwe_stage_finish(hipStream_t st, Engine& E, const ShapePlan& P, EncBatchBufs
   kk.slotOff = reinterpret_cast<uint64_t*>(kk.mem);
   kk.gids = reinterpret_cast<uint32_t*>(static_cast<char*>(kk.mem) + round_up((size_t)nb * 8, 256));
   kk.slots = reinterpret_cast<uint8_t*>(static_cast<char*>(kk.mem) + headBytes);
-  HIP_CHECK(hipMemcpyAsync(kk.slotOff, off2.data(), nb * 8, hipMemcpyHostToDevice, st));
+  kk.off2 = std::move(off2);   // (alive until the container is assembled: compress_impl waits for its stream at the end)
+  HIP_CHECK(hipMemcpyAsync(kk.slotOff, kk.off2.data(), nb * 8, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(kk.gids, bb.gids, nb * 4, hipMemcpyDeviceToDevice, st));
   if (launch_outlier_stream_out(st, ob, kk.gids, kk.slots, kk.slotOff, d_lens2))
     return -1;
-  HIP_CHECK(hipStreamSynchronize(st));   // off2 goes out of scope
+  E.pweLastStream = st;
   hm.mark("stream out", st);
   return 0;
 }
@@ -1808,6 +1838,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   uint64_t* d_total = d_lens2 + round_up(nchunks, 32);
   HIP_CHECK(hipMemsetAsync(d_lens2, 0, (size_t)nchunks * 8, st));
   PweKeepList pweKeep;
+  std::deque<std::vector<CoderState>> pweHcKeep;   // (mode 3 is enqueued by one host thread: no lock)
   HIP_CHECK(hipMemcpyAsync(d_slotOff, slotOff.data(), nchunks * 8, hipMemcpyHostToDevice, st));
 
   VolDesc vd{{vol[0], vol[1], vol[2]}};
@@ -1912,8 +1943,11 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       if (mode == 2 && psnr_q_search(ss, *P, bb, nb, quality))
         return -1;
       bool pweWide = false;
-      if (mode == 3 && pwe_q_setup(ss, bb, nb, quality, &pweWide))
-        return -1;
+      if (mode == 3) {
+        pweHcKeep.emplace_back();   // (the upload of the chunks' states is not waited for: alive until the call's end)
+        if (pwe_q_setup(ss, bb, nb, quality, pweHcKeep.back(), &pweWide))
+          return -1;
+      }
       if (launch_quantize(ss, false, bb.vals, bb.valsStride, nb, P->N, bb.coef32, e.coefStride,
                           const_cast<uint64_t*>(e.sign), e.signStride, bb.msb, e.pixStride, e.cst))
         return -1;
@@ -1929,7 +1963,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
       PweStage pweSt;
       hipStream_t pweQ = E.outlQ[1];
       const bool pweEarly = mode == 3 && pweOverlapEnv && !bb.aliased && !sideBySide && !pweWide && pweQ != nullptr &&
-                            E.evPweFork != nullptr;
+                            E.evPweFork != nullptr && E.evPweJoin != nullptr;
       if (pweEarly) {
         HIP_CHECK(hipEventRecord(E.evPweFork, ss));
         HIP_CHECK(hipStreamWaitEvent(pweQ, E.evPweFork, 0));
@@ -1990,8 +2024,14 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
 
       // (point-wise error mode: the outlier stage's second half -- its waits are for its own stream -- while the plane
       //  loop above runs)
-      if (pweEarly && pwe_stage_finish<T>(pweQ, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep, pweSt))
-        return -1;
+      if (pweEarly) {
+        if (pwe_stage_finish<T>(pweQ, E, *P, bb, nb, d_src, vd, cd, quality, d_lens2, pweKeep, pweSt))
+          return -1;
+        // (the stage no longer ends in a wait of the host: what follows on the batch's stream -- the container's
+        //  kernels read the outlier streams and their lengths -- waits for it on the device)
+        HIP_CHECK(hipEventRecord(E.evPweJoin, pweQ));
+        HIP_CHECK(hipStreamWaitEvent(ss, E.evPweJoin, 0));
+      }
       // ---- fixed-rate retry with 64-bit coefficients (SPECK_FLT.cpp:530-538) ----
       if (sideBySide) {   // (the read-back is looked at once every group is enqueued)
         std::unique_ptr<LateGroup> L(new LateGroup{P, bb, nb, wblocks, raw_budget, ss, std::vector<CoderState>(nb),
@@ -2156,6 +2196,7 @@ int compress_impl(Engine& E, const T* d_src, const Dims& vol, const Dims& chunkP
   HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   HIP_CHECK(hipGetLastError());
+  E.pweLastStream = nullptr;
   E.prof.collect();
   if (total > dst_cap) {
     fprintf(stderr, "[sperr_hip] output buffer too small (%zu < %llu)\n", dst_cap,
