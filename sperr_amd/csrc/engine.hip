@@ -2402,6 +2402,10 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
     //  decompression of the bench volume 91.5 -> 94.5 GB/s, eight chunks 38.2 -> 39.3)
     static const uint32_t hop2 = tune_getenv("SPERR_HIP_HI_HOP2") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_HOP2")) : 0u;
     d.hiHop2 = hop2;
+    // (round 6: 1 -- class tables 48.0 K -> 36.1 K cycles per region, k_lis_hi 16.7 -> 14.7 ms summed per step,
+    //  decompression of 64 chunks 113.0 -> 115.0 GB/s in alternating runs, profiles/r6_hi_candidates_ab.txt)
+    static const uint32_t hiCandEnv = tune_getenv("SPERR_HIP_HI_CAND") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_CAND")) : 1u;
+    d.hiCand = hiCandEnv;
   }
   d.hiSmemBytes = 148 * 1024;   // (k_lis_hi has 11.5 KB of static LDS)
   d.hiW = hi_window((int)d.hiK, d.hiSmemBytes, d.hiHop2);

@@ -197,6 +197,7 @@ struct DecBuffers {
   uint32_t hiHop2;             // the next class's pointer-jump table is built ahead of the chain (else on demand)
   uint32_t hiGroupsMax;        // workgroups per chunk the queues are sized for (<= 8)
   uint32_t hiExtra;            // classes built speculatively beyond the hinted list's own
+  uint32_t hiCand;             // class tables only where a split can start (build_tables, round 6; SPERR_HIP_HI_CAND=0: everywhere)
   uint32_t hiAhead;            // bits of a region's tables past the region's end: items that start in
                                //   the region and end within them are not walked into
   const uint64_t* iRoots;         // 2D coder (spk::kTree2D): packed roots of the subbands the type-I set releases,

@@ -2439,7 +2439,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   __shared__ uint32_t sh_level, sh_depth, sh_e, sh_rem, sh_stop, sh_action, sh_ticket, sh_any;
   __shared__ unsigned long long sh_in[4];
   __shared__ int sh_tabLevel, sh_tabK, sh_hopTop[2], sh_tabFrom, sh_hintK;   // what the tables in LDS were built for
-  __shared__ uint32_t sh_over, sh_haveState, sh_act2;
+  __shared__ uint32_t sh_over, sh_haveState, sh_act2, sh_zn;
   __shared__ uint64_t sh_t2, sh_t3, sh_tacc[8];
 #define HI_T(k)                                               \
   if (b.lisStamps && lane == 0) {                             \
@@ -2485,6 +2485,20 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   if (tid == 0) {
     sh_segBorn = sh_segLeaf = 0;
     sh_segBornEnd = 0xffffffffu;
+  }
+  __syncthreads();
+  // (candidate positions of the class tables, build_tables: the fewest '0' siblings that can stand in front of a set
+  //  whose test bit is implied -- one less than the smallest arity of any class of the tree: seven for octrees)
+  if (tid < 64) {
+    uint32_t zn = 31;
+    if ((uint32_t)tid < t.nlevels && sh_lc[tid].regular)
+      for (int j = 0; j < (int)sh_lc[tid].K && j < kMaxClasses; j++)
+        zn = min(zn, (uint32_t)max((int)sh_lc[tid].arity[j], 1) - 1u);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+      zn = min(zn, (uint32_t)__shfl_xor((int)zn, d, 64));
+    if (tid == 0)
+      sh_zn = zn;
   }
   __syncthreads();
 
@@ -2583,8 +2597,71 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   // class of a level only needs U, but a later level of the same chain may sit on top of it)
   // (from: the first position anybody will look at -- a build in the middle of a region, when the chain has come to a
   //  list the tables do not serve, starts where the chain stands: half the positions on average)
-  auto build_tables = [&](int lv, int j0, int j1, uint32_t from = 0) {
+  // Round 6 -- `candOnly` (the build at the head of a region): classes 1 and up are evaluated only where a split of a set
+  // can START: behind a '1' (a coded significant item's split), or behind as many '0's as the smallest arity leaves in
+  // front of an implied last child, or at the window's edges; every other T is "leaves the window" (never looked at: a
+  // reader that did would walk into the set, slow and right), every U of a '0' bit is 1 without a look-up.  At 2 bits
+  // per sample that is 35 to 45 % of the positions.  Round 5 tried the test WITHOUT compaction -- the other lanes sat
+  // the eight-deep look-up chain out -- and lost: the tables cost their ds_read_u16 wavefront instructions, 12.5 cycles
+  // each whatever the lanes hold (profiles/r5_knob_ab.txt).  Here every wavefront first lists the candidates of its
+  // slice of the window (a ballot and a prefix per 64 positions, in the pointer-jump table's memory: that table is
+  // built after these) and then runs the chains over the list, all lanes busy.
+  auto build_tables = [&](int lv, int j0, int j1, uint32_t from = 0, bool candOnly = false) {
     const LevelClass& C = sh_lc[lv];
+    if (candOnly) {
+      uint16_t* cand = reinterpret_cast<uint16_t*>(hop);
+      const uint32_t wv = (uint32_t)tid >> 6, npos = W + 2;
+      const uint32_t slice = ((npos + kTabThreads / 64 - 1) / (kTabThreads / 64) + 63u) & ~63u;   // positions a wavefront lists
+      const uint32_t zn = sh_zn, zmask = zn >= 32 ? 0xffffffffu : ((1u << zn) - 1u);
+      uint32_t ncand = 0;
+      for (uint32_t r0 = wv * slice; r0 < min(npos, (wv + 1) * slice); r0 += 64) {
+        const uint32_t r = r0 + lane;
+        bool is = false;
+        if (r < npos)
+          is = r <= zn || r >= W || bit_at(r - 1) != 0 || (bits32(r - zn) & zmask) == 0;
+        const uint64_t m = __ballot(is);
+        if (is)
+          cand[wv * slice + ncand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
+        ncand += (uint32_t)__popcll(m);
+      }
+      // every entry of every class once, two positions a store: T "leaves the window", U 1 behind a '0'
+      for (uint32_t h = (uint32_t)tid; 2 * h < npos; h += kTabThreads) {
+        const uint32_t r = 2 * h;
+        const uint32_t u0 = (r >= W || bit_at(r)) ? kTInf : 1u, u1 = (r + 1 >= W || bit_at(r + 1)) ? kTInf : 1u;
+        const uint32_t u = u0 | (u1 << 16);
+        for (int j = j0; j < j1; j++) {
+          reinterpret_cast<uint32_t*>(Uu + (size_t)j * TS)[h] = u;
+          if (j < Kcap - 1)
+            reinterpret_cast<uint32_t*>(Tt + (size_t)j * TS)[h] = kTInf | (kTInf << 16);
+        }
+      }
+      __syncthreads();
+      for (int j = j0; j < j1; j++) {
+        uint16_t* Uj = Uu + (size_t)j * TS;
+        uint16_t* Tj = j < Kcap - 1 ? Tt + (size_t)j * TS : nullptr;
+        for (uint32_t i0 = lane; i0 < ncand; i0 += 4 * 64) {
+          uint32_t rr[4], tl[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t i = i0 + (uint32_t)q * 64u;
+            rr[q] = i < ncand ? (uint32_t)cand[wv * slice + i] : 0xffffffffu;
+            tl[q] = rr[q] != 0xffffffffu ? split_len(C, j, rr[q]) : kTInf;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t r = rr[q];
+            if (r == 0xffffffffu)
+              continue;
+            if (Tj)
+              Tj[r] = (uint16_t)tl[q];
+            if (r >= 1 && r - 1 < W && bit_at(r - 1))
+              Uj[r - 1] = (uint16_t)(tl[q] == kTInf ? kTInf : (0x8000u | (1u + tl[q])));
+          }
+        }
+        __syncthreads();
+      }
+      return;
+    }
     for (int j = j0; j < j1; j++) {
       uint16_t* Uj = Uu + (size_t)j * TS;
       uint16_t* Tj = j < Kcap - 1 ? Tt + (size_t)j * TS : nullptr;
@@ -2865,6 +2942,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
   // classes built speculatively beyond the hinted list's own (SPERR_HIP_HI_EXTRA; the chain builds
   // what is missing when it gets further than that inside one region)
   const int kSpecExtra = (int)b.hiExtra;
+  const bool hiCand = b.hiCand != 0;
   // what the chain (wavefront 0) can ask the whole workgroup for
   constexpr uint32_t kActDone = 0, kActTables = 1, kActHopTab = 2, kActFlushTables = 4;
   const uint32_t wave = (uint32_t)tid >> 6;
@@ -3000,7 +3078,7 @@ __global__ void __launch_bounds__(kTabThreads) k_lis_hi(DecBuffers b, int p)
     if (!zeroRegion && sh_tabLevel >= 0) {
       const int lv = sh_tabLevel;
       const int K = min((int)sh_lc[lv].K, Kcap), KhT = sh_hintK, Kh = min(KhT, Kcap);
-      build_tables(lv, 0, K);
+      build_tables(lv, 0, K, 0, hiCand);
       if (stamps) dbg1 = __builtin_readcyclecounter();
       const bool hop1 = KhT <= Kcap;   // the hinted list's entries (class KhT - 1) have a table
       if (hop1)
