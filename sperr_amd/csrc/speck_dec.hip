@@ -4420,7 +4420,7 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
       return -1;
   }
   // (workgroups over all chunks; measured: 768 beats 512 and 256 on 64 chunks)
-  static const uint32_t l1Total = tune_getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L1_WGS")) : 768u;
+  static const uint32_t l1Total = tune_getenv("SPERR_HIP_L1_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L1_WGS")) : 512u;   // (round 6, three sub-batches of 21 chunks: 512 / 768 with k_lis_hi at 128: 119.5 / 117.3 GB/s)
   const uint32_t l1Groups = std::min<uint32_t>(l01Cap, std::max<uint32_t>(1, l1Total / nc));
   // k_lis_l2: two workgroups a CU over all chunks (SPERR_HIP_L2_WGS in the diagnostics build)
   static const uint32_t l2Total = tune_getenv("SPERR_HIP_L2_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_L2_WGS")) : 512u;
@@ -4434,7 +4434,8 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   // of 32 chunks side by side: 96 / 128 / 160 / 192 / 224 / 256 / 384 workgroups per sub-batch give
   // 70.8 / 75.3 / 76.3 / 76.0 / 75.0 / 74.5 / 74.3 GB/s of decompression; again after the region
   // bookkeeping went to one lane per level: 96 / 128 / 160 / 192 / 256 give 73.4 / 77.5 / 78.5 / 77.9 / 75.5)
-  static const uint32_t hiTotal = tune_getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_WGS")) : 160u;
+  static const uint32_t hiTotal = tune_getenv("SPERR_HIP_HI_WGS") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_HI_WGS")) : 128u;   // (round 6: 128 -- with three sub-batches side by side
+                                                                                  //  96 / 112 / 128 / 144 / 160 workgroups a sub-batch: 119.2 / 118.8 / 118.5 to 119.5 / 117.3 / 115.9 to 116.7 GB/s)
   const uint32_t hiGroups = std::min<uint32_t>(std::max<uint32_t>(1, b.hiGroupsMax), std::max<uint32_t>(1, hiTotal / nc));
   // workgroups per chunk of k_lis_mx: the walk of a chunk is serial, the rows and the expansion of its regions are
   // what the other workgroups are for (SPERR_HIP_MX_WGS: the total over the batch's chunks)
