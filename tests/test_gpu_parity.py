@@ -737,6 +737,21 @@ def test_sixteen_256_cube_chunks_reach_the_capped_grids(eng, oracle):
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
 
 
+def test_streams_that_end_anywhere_in_the_list_kernels(eng, oracle):
+    """One 128^3 chunk (4096 sets of 8^3: k_lis_l2 takes their list from 512 entries on, round 6) at twenty-four rates
+    between 0.25 and 6 bits per sample: the stream's end falls inside the LIP scan, inside the list of the 2^3, the 4^3 or
+    the 8^3 sets (k_lis_l0 / _l1 / _l2), inside k_lis_hi's lists or inside a refinement pass, on planes whose lists
+    are short and on planes whose lists are long -- every decoded value against the reference's bits
+    (src/SPECK_INT.cpp:165-228: the decoder stops the moment the bits run out; src/SPECK3D_INT.cpp:99-212)."""
+    v = turbulence((128, 128, 128), seed=11)
+    for i in range(24):
+        bpp = 0.25 + 0.25 * i
+        want = oracle.comp_3d(v, (128, 128, 128), 1, bpp)
+        dev = cuda(np.frombuffer(want, dtype=np.uint8))
+        got = eng.decompress(dev, True).cpu().numpy()
+        assert np.array_equal(bits(got), bits(oracle.decomp_3d(want, True))), bpp
+
+
 def test_256_cube_chunk_pwe(eng, oracle):
     """One 256^3 fp32 chunk in point-wise error mode (the chunk shape of BASELINE configs 3 and 5 with
     config 5's mode): outlier stream included, byte-identical to the oracle; decoded floats
