@@ -1087,7 +1087,9 @@ bool carve_enc(Arena& A, const ShapePlan& P, uint32_t B, uint64_t raw_budget, En
   e.maskWords = (uint32_t)maskWords;
   e.maskStride = (size_t)P.nSlots * maskWords;
   TAKE(e.mask, uint64_t, std::max<size_t>(e.maskStride, 1) * B);
-  TAKE(e.maskPrefix, uint32_t, std::max<size_t>(e.maskStride, 1) * B);
+  e.prefWords = (uint32_t)((maskWords + 3) / 4);
+  e.prefStride = (size_t)P.nSlots * e.prefWords;
+  TAKE(e.maskPrefix, uint32_t, std::max<size_t>(e.prefStride, 1) * B);
   e.nPixTiles = P.nPixTiles;
   e.pixCntStride = (size_t)kMaxPlanes * 2 * P.nPixTiles;
   TAKE(e.pixCnt, uint32_t, e.pixCntStride * B);
@@ -2371,7 +2373,9 @@ bool carve_dec(Arena& A, const ShapePlan& P, uint32_t B, uint64_t maxPayloadByte
   d.maskWords = (uint32_t)d.streamStride;
   d.maskStride = (size_t)P.nSlots * d.maskWords;
   TAKE(d.mask, uint64_t, std::max<size_t>(d.maskStride, 1) * B);
-  TAKE(d.maskPrefix, uint32_t, std::max<size_t>(d.maskStride, 1) * B);
+  d.prefWords = (d.maskWords + 3u) / 4u;
+  d.prefStride = (size_t)P.nSlots * d.prefWords;
+  TAKE(d.maskPrefix, uint32_t, std::max<size_t>(d.prefStride, 1) * B);
   d.bornStride = P.ht.nsets + 8;
   d.hiGroupsMax = 8;
   // (a segment that fills up sends the rest to the shared part, which holds the worst case: eight

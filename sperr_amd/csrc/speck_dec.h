@@ -152,7 +152,10 @@ struct DecBuffers {
   uint32_t nSlots;
   uint32_t maskWords;
   uint64_t* mask;              // [slot][maskWords] one bit per stream position of the phase
-  uint32_t* maskPrefix;
+  uint32_t* maskPrefix;        // popcount prefix of a slot's mask, one word per FOUR mask words (round 6: a word each before,
+                               //   14 MiB per 256^3 chunk): rank = prefix of the group + the group's words in front + the bits in front
+  uint32_t prefWords;          //   prefix words per slot ((maskWords + 3) / 4)
+  size_t prefStride;           //   ... per chunk (nSlots * prefWords)
   size_t maskStride;
   uint64_t* bornPacked;
   uint64_t* bornPosLev;

@@ -3886,8 +3886,8 @@ __global__ void __launch_bounds__(kTabThreads) k_place_scan(DecBuffers b, int p)
   __shared__ uint32_t sh_scan[kTabThreads / 64 + 1];
   const uint32_t pw = (uint32_t)((s.lisPhaseBits + 63) / 64);
   const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
-  uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
-  constexpr int kPer = 4;   // consecutive words per thread and round: one batch of loads per scan
+  uint32_t* pre = b.maskPrefix + c * b.prefStride + (size_t)slot * b.prefWords;   // (one word per four mask words)
+  constexpr int kPer = 4;   // consecutive words per thread and round: one batch of loads per scan, one prefix word
   uint32_t carry = 0;
   for (uint32_t base = 0; base < pw; base += kTabThreads * kPer) {
     const uint32_t w0 = base + threadIdx.x * kPer;
@@ -3898,13 +3898,9 @@ __global__ void __launch_bounds__(kTabThreads) k_place_scan(DecBuffers b, int p)
       tsum += v[k];
     }
     uint32_t total;
-    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sh_scan, &total) + carry;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-      if (w0 + k < pw)
-        pre[w0 + k] = ex;
-      ex += v[k];
-    }
+    const uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sh_scan, &total) + carry;
+    if (w0 < pw)
+      pre[w0 / kPer] = ex;
     carry += total;
   }
   if (threadIdx.x == 0)
@@ -3936,9 +3932,12 @@ __global__ void __launch_bounds__(kThreads) k_place_scatter(DecBuffers b, int p)
     const uint64_t pl = bornPosLev[k];
     const uint32_t lev = (uint32_t)(pl >> 48);
     const uint64_t rel = pl & ((1ull << 48) - 1);
-    const size_t mo = c * b.maskStride + (size_t)b.levelSlot[lev] * b.maskWords + (rel >> 6);
-    const uint32_t rank = b.maskPrefix[mo] +
-                          (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    const uint32_t wi = (uint32_t)(rel >> 6), slot = b.levelSlot[lev];
+    const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + wi;
+    uint32_t rank = b.maskPrefix[c * b.prefStride + (size_t)slot * b.prefWords + (wi >> 2)] +
+                    (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    for (uint32_t j = 1; j <= (wi & 3u); j++)   // (the words of the group in front of this one: the same 32 bytes)
+      rank += (uint32_t)__popcll(b.mask[mo - j]);
     b.lis[cur][c * b.lisStride + b.levelOff[lev] + s.listLen[cur][lev] + rank] = bornPacked[k];
   }
 }

@@ -1261,7 +1261,7 @@ __global__ void __launch_bounds__(kThreads) k_mask_scan(EncBuffers b, int p)
   const uint64_t nbits = min(s.lisBits, (uint64_t)b.maskWords * 64);
   const uint32_t nwords = (uint32_t)((nbits + 63) / 64);
   const uint64_t* mask = b.mask + c * b.maskStride + (size_t)slot * b.maskWords;
-  uint32_t* pre = b.maskPrefix + c * b.maskStride + (size_t)slot * b.maskWords;
+  uint32_t* pre = b.maskPrefix + c * b.prefStride + (size_t)slot * b.prefWords;   // (one word per four mask words)
   uint32_t carry = 0;
   for (uint32_t base = 0; base < nwords; base += kThreads * 4) {
     uint32_t v[4], tsum = 0;
@@ -1271,13 +1271,9 @@ __global__ void __launch_bounds__(kThreads) k_mask_scan(EncBuffers b, int p)
       tsum += v[k];
     }
     uint32_t total;
-    uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total) + carry;
-    for (int k = 0; k < 4; k++) {
-      const uint32_t i = base + threadIdx.x * 4 + k;
-      if (i < nwords)
-        pre[i] = ex;
-      ex += v[k];
-    }
+    const uint32_t ex = block_exclusive_scan<uint32_t>(tsum, sm, &total) + carry;
+    if (base + threadIdx.x * 4 < nwords)
+      pre[base / 4 + threadIdx.x] = ex;   // (the thread's four words are one group)
     carry += total;
   }
   if (threadIdx.x == 0)
@@ -1296,9 +1292,12 @@ __global__ void __launch_bounds__(kThreads) k_born_place(EncBuffers b, int p)
     const uint32_t lev = (uint32_t)(pl >> 48);
     const uint64_t rel = pl & ((1ull << 48) - 1);
     const uint32_t slot = b.levelSlot[lev];
-    const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + (rel >> 6);
-    const uint32_t rank = b.maskPrefix[mo] +
-                          (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    const uint32_t wi = (uint32_t)(rel >> 6);
+    const size_t mo = c * b.maskStride + (size_t)slot * b.maskWords + wi;
+    uint32_t rank = b.maskPrefix[c * b.prefStride + (size_t)slot * b.prefWords + (wi >> 2)] +
+                    (uint32_t)__popcll(b.mask[mo] & ((1ull << (rel & 63)) - 1ull));
+    for (uint32_t j = 1; j <= (wi & 3u); j++)   // (the words of the group in front of this one: the same 32 bytes)
+      rank += (uint32_t)__popcll(b.mask[mo - j]);
     b.lis[nx][c * b.lisStride + b.levelOff[lev] + s.listLen[nx][lev] + rank] =
         b.bornPacked[c * b.bornStride + k];
   }
