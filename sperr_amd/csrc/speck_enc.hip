@@ -1683,13 +1683,16 @@ int launch_speck_encode_planes(hipStream_t stream, const EncBuffers& b, const En
     pTop = std::max(pLow + 1, std::min<int>(maxPlanes, (int)plan.h_bound[1]));
   }
   const uint32_t bornBlocks = (plan.nsets + kThreads - 1) / kThreads;
-  // grid caps of the per-plane sweeps: a part of 16 chunks and more fills the chip four times over with 4096 / 2048
-  // workgroups, and in a light plane the launch costs what its idle workgroups take to dispatch (133.9 -> 137.5 GB/s
-  // at 64 chunks); a small batch keeps the wide grids, its heavy planes need them (profiles/r5_enc_grid_ab.txt)
+  // grid caps of the per-plane sweeps (workgroups over all chunks of the batch; a workgroup strides over its tiles): in a
+  // light plane a launch costs what its idle workgroups take to dispatch.  Round 5: 4096 / 2048 from 16 chunks on, the wide
+  // grids (16384 / 4096) below.  Round 6, with the node kernels' registers halved and four parts side by side: 1536 / 768
+  // for every batch -- 64 chunks 150.0 -> 153.3 to 154.7 GB/s (1280 / 640: 154.7; 2048 / 1024: 152.4 to 152.9; 3072 / 1536:
+  // 151.0; 8192 / 4096: 144.6), 8 chunks 85.6 -> 90.3 to 91.7 (6.23 -> 5.94 ms), one chunk the same 2.88 ms
+  // (profiles/r6_enc_grid_ab.txt)
   static const char* wideEnv = tune_getenv("SPERR_HIP_ENC_WIDE_GRID");
   static const char* smallEnv = tune_getenv("SPERR_HIP_ENC_SMALL_GRID");
-  const uint32_t wideCap = wideEnv ? (uint32_t)atoi(wideEnv) : (nc >= 16 ? 4096u : kGridCapWide);
-  const uint32_t smallCap = smallEnv ? (uint32_t)atoi(smallEnv) : (nc >= 16 ? 2048u : kGridCap);
+  const uint32_t wideCap = wideEnv ? (uint32_t)atoi(wideEnv) : 1536u;
+  const uint32_t smallCap = smallEnv ? (uint32_t)atoi(smallEnv) : 768u;
   LAUNCH_K(k_plane_turn, perChunk, dim3(64), 0, stream, b, -1, pTop - 1);
   for (int p = pTop - 1; p >= pLow; p--) {
     LAUNCH_K(k_list_count, dim3(capped_blocks(b.nListTiles, nc, smallCap), nc), dim3(kThreads), 0, stream, b, p,

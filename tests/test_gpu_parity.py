@@ -700,11 +700,11 @@ def test_full_size_roundtrip_properties(eng):
 
 def test_sixteen_256_cube_chunks_reach_the_capped_grids(eng, oracle):
     """1024 x 512 x 512 in 256^3 chunks at 2 bpp, byte for byte against the oracle: sixteen chunks of one shape
-    are what it takes for the per-plane sweeps to run on their CAPPED grids (from 16 chunks on: 4096 / 2048
-    workgroups over the batch, launch_speck_encode_planes and launch_speck_decode -- 1024 pixel tiles and as
-    many list tiles per chunk, so every workgroup strides over four to eight tiles); the suite's other
-    many-chunk cases use 16^3 chunks, far under the caps, and until round 6 only the bench's 1024^3 comparison
-    got here.  The decoder cuts sixteen chunks into four sub-batches of four when it has the device to itself
+    are what it takes for the decoder's per-plane sweeps to run on their CAPPED grids (from 16 chunks on: 4096
+    workgroups over the batch, launch_speck_decode -- 1024 pixel tiles per chunk, so every workgroup strides over
+    four tiles) and for the encoder's workgroups to stride over ten to twenty-five tiles each (1536 / 768
+    workgroups over the batch since round 6, launch_speck_encode_planes); the suite's other many-chunk cases use
+    16^3 chunks, far under the caps, and until round 6 only the bench's 1024^3 comparison got here.  The decoder cuts sixteen chunks into four sub-batches of four when it has the device to itself
     (wide grids again), so the container is decoded once more in a fresh process with SPERR_HIP_SUBSTREAMS=1: one
     batch of sixteen.  The field's period is 300 samples, so no two chunks hold the same data (the default
     period is the chunk size).  A tile loop with a broken stride fails this case (tried on MI355X with
