@@ -4405,7 +4405,9 @@ int launch_speck_decode(hipStream_t stream, const DecBuffers& b, const DecPlanHo
   //  planes pay for the dispatch of 16 K workgroups that find nothing to do; a quarter of them loop over four tiles
   //  each: decompression of 64 chunks 93.6 -> 94.2 GB/s in alternating runs, round 5.  A few chunks keep the wide grid)
   static const uint32_t tileCapEnv = tune_getenv("SPERR_HIP_TILE_GRID") ? (uint32_t)atoi(tune_getenv("SPERR_HIP_TILE_GRID")) : 0u;
-  const uint32_t tileCap = tileCapEnv ? tileCapEnv : (nc >= 16 ? 4096u : kGridCapWide);
+  // (round 6: 1536 for every batch -- 64 chunks in three sub-batches 119.4 -> 120.5 to 120.9 GB/s, 8 chunks 51.9 -> 52.3; 1024:
+  //  118.3, 2560: 118.5; round 5 had 4096 from 16 chunks on and the wide grid below)
+  const uint32_t tileCap = tileCapEnv ? tileCapEnv : 1536u;
   const uint32_t tokSegGrid = capped_blocks((uint32_t)(b.tokStride / kLipSeg + 1), nc, kGridCap / gdiv);   // (k_lip_words: a segment a workgroup)
   const uint32_t tokGrid = capped_blocks(tokBlocks, nc, kGridCap / gdiv), tileGrid = capped_blocks(b.nPixTiles, nc, tileCap / gdiv);
   // workgroups per chunk of the k_lis_l0 pass: about two per CU over all chunks
